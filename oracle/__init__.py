@@ -1,0 +1,5 @@
+"""CPU oracle for the MaskPlanner hot path -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this package.
+The product package (maskplanner_amd) never does.
+"""

@@ -1,0 +1,382 @@
+"""Generate tests/golden/*.npz by running the imported reference on CPU -- TEST INFRASTRUCTURE ONLY.
+
+Run in the build container (reference at /root/reference):   python -m oracle.gen_golden
+The fixtures hold inputs and the reference's outputs only (data, no reference source).  The oracle
+(mp_oracle.c) and the HIP kernels are both checked against them.
+
+Fixture  producer (reference file:line)                                   pins
+g1_fps   models/pointnet2_utils.py:65-86   farthest_point_sample           FPS indices, bit-exact
+g2_bq    models/pointnet2_utils.py:89-109  query_ball_point                ball-query indices, bit-exact
+g2_sqd   models/pointnet2_utils.py:21-42   square_distance                 expanded-form rounding
+g3_sa    models/pointnet2_utils.py:171-216 PointNetSetAbstraction          SA block fwd/bwd (train+eval)
+g4_msg   models/pointnet2_utils.py:219-276 PointNetSetAbstractionMsg       MSG block fwd/bwd
+g5_model models/pointnet2_cls_ssg.py:233-344 PointNet2Regressor_StrokeMasks full forward (eval)
+g6_cham  pytorch3d_chamfer.py:76-344 chamfer_distance (pytorch3d stand-in = oracle knn: contract-derived)
+g7_mask  loss_handler.py:596-666,816-935  asymm_v6 loss + stroke-mask loss
+g8_hung  models/hungarianMatcher.py:31-63 HungarianMatcher
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from oracle import ref_import as R  # noqa: E402
+from maskplanner_amd import synthetic as syn  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def save(name, **arrays):
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print(f"  wrote {name}.npz  {os.path.getsize(path) / 1024:.0f} KiB")
+
+
+def ref_fps(pu, xyz, npoint, seed):
+    """Run the reference FPS; recover its random start by replaying the CPU generator."""
+    B, N, _ = xyz.shape
+    torch.manual_seed(seed)
+    start = torch.randint(0, N, (B,), dtype=torch.long)
+    torch.manual_seed(seed)
+    idx = pu.farthest_point_sample(torch.from_numpy(xyz), npoint)
+    assert (idx[:, 0] == start).all()
+    return start.numpy(), idx.numpy()
+
+
+def g1_fps(pu):
+    print("g1_fps")
+    rng = np.random.default_rng(101)
+    cases = {}
+    clouds = {
+        "ucube5120": (syn.point_cloud(rng, 2, 5120, "ucube"), 512),
+        "cuboid5120": (syn.point_cloud(rng, 2, 5120, "cuboid"), 512),
+        "cuboid512": (syn.point_cloud(rng, 3, 512, "cuboid"), 128),
+        "ragged777": (syn.point_cloud(rng, 2, 777, "ucube"), 100),
+    }
+    # duplicates (coincident points) and exact ties: a regular integer lattice has many equal distances
+    lat = np.stack(np.meshgrid(np.arange(8), np.arange(8), np.arange(8), indexing="ij"), -1).reshape(-1, 3)
+    lat = (lat.astype(np.float32) - 3.5) / 4.0
+    dup = np.concatenate([lat, lat[:64]], 0)
+    clouds["lattice_dup"] = (np.stack([dup, dup[::-1].copy()]), 96)
+    for i, (k, (xyz, npoint)) in enumerate(clouds.items()):
+        start, idx = ref_fps(pu, xyz, npoint, 500 + i)
+        cases[k + "_xyz"] = xyz
+        cases[k + "_start"] = start
+        cases[k + "_idx"] = idx
+    save("g1_fps", **cases)
+
+
+def g2_bq(pu):
+    print("g2_bq")
+    rng = np.random.default_rng(202)
+    cases = {}
+
+    def add(name, xyz, npoint, radius, K, seed):
+        start, fidx = ref_fps(pu, xyz, npoint, seed)
+        new_xyz = pu.index_points(torch.from_numpy(xyz), torch.from_numpy(fidx)).numpy()
+        idx = pu.query_ball_point(radius, K, torch.from_numpy(xyz), torch.from_numpy(new_xyz)).numpy()
+        cases[name + "_xyz"] = xyz
+        cases[name + "_new_xyz"] = new_xyz
+        cases[name + "_radius"] = np.float64(radius)
+        cases[name + "_K"] = np.int64(K)
+        cases[name + "_idx"] = idx.astype(np.int32)  # values < 2^31; stored narrow to keep the fixture small
+
+    add("sa1_ucube", syn.point_cloud(rng, 2, 5120, "ucube"), 512, 0.2, 32, 11)
+    add("sa1_cuboid", syn.point_cloud(rng, 2, 5120, "cuboid"), 512, 0.2, 32, 12)
+    add("sa2_cuboid", syn.point_cloud(rng, 3, 512, "cuboid"), 128, 0.4, 64, 13)
+    add("dbg1024", syn.point_cloud(rng, 2, 1024, "cuboid"), 512, 0.2, 32, 14)
+    add("ragged", syn.point_cloud(rng, 2, 777, "ucube"), 100, 0.35, 48, 15)
+
+    # engineered: points within a few ulp of the sphere r around each query (threshold rounding)
+    for radius, tag in ((0.2, "r02"), (0.4, "r04")):
+        q = rng.uniform(-0.5, 0.5, size=(1, 16, 3)).astype(np.float32)
+        pts = []
+        for s in range(16):
+            d = rng.normal(size=(96, 3))
+            d /= np.linalg.norm(d, axis=1, keepdims=True)
+            eps = rng.integers(-6, 7, size=(96, 1)) * 2.0 ** -24
+            pts.append((q[0, s].astype(np.float64) + d * radius * (1.0 + eps)).astype(np.float32))
+        xyz = np.concatenate(pts)[None]  # [1,1536,3]
+        perm = rng.permutation(xyz.shape[1])
+        xyz = np.ascontiguousarray(xyz[:, perm])
+        sq = pu.square_distance(torch.from_numpy(q), torch.from_numpy(xyz)).numpy()
+        idx = pu.query_ball_point(radius, 64, torch.from_numpy(xyz), torch.from_numpy(q)).numpy()
+        r2f = np.float32(radius ** 2)
+        near = np.abs(sq - r2f) <= 4 * np.spacing(r2f)
+        print(f"   threshold case {tag}: {near.sum()} pairs within 4 ulp of r^2, {(sq == r2f).sum()} exactly equal")
+        cases[f"thr_{tag}_xyz"] = xyz
+        cases[f"thr_{tag}_new_xyz"] = q
+        cases[f"thr_{tag}_radius"] = np.float64(radius)
+        cases[f"thr_{tag}_K"] = np.int64(64)
+        cases[f"thr_{tag}_idx"] = idx.astype(np.int32)
+        cases[f"thr_{tag}_sqd"] = sq
+    save("g2_bq", **cases)
+
+    # expanded-form rounding on the real shapes (values, not only memberships)
+    xyz = syn.point_cloud(rng, 1, 5120, "cuboid")
+    q = xyz[:, rng.permutation(5120)[:16]]
+    sq = pu.square_distance(torch.from_numpy(q), torch.from_numpy(xyz)).numpy()
+    xyz2 = syn.point_cloud(rng, 2, 512, "ucube")
+    q2 = xyz2[:, :48]
+    sq2 = pu.square_distance(torch.from_numpy(q2), torch.from_numpy(xyz2)).numpy()
+    save("g2_sqd", a_src=q, a_dst=xyz, a_out=sq, b_src=q2, b_dst=xyz2, b_out=sq2)
+
+
+def _seed_module(mod, seed):
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name, p in mod.named_parameters():
+            if p.ndim > 1:
+                fan_in = p[0].numel()
+                p.copy_((torch.rand(p.shape, generator=g) * 2 - 1) / fan_in ** 0.5)
+            elif name.endswith("weight"):  # BN gamma (some negative, to exercise the min-pool branch)
+                p.copy_(torch.rand(p.shape, generator=g) * 1.5 - 0.25)
+            else:
+                p.copy_((torch.rand(p.shape, generator=g) * 2 - 1) * 0.1)
+
+
+def _state(mod):
+    return {"sd_" + k: v.detach().numpy().copy() for k, v in mod.state_dict().items()}
+
+
+def g3_sa(pu):
+    print("g3_sa")
+    rng = np.random.default_rng(303)
+    cases = {}
+
+    def run(tag, sa, xyz, feats, fps_seed, train):
+        sa.train(train)
+        x = torch.from_numpy(xyz).permute(0, 2, 1).contiguous().requires_grad_(True)
+        f = None if feats is None else torch.from_numpy(feats).permute(0, 2, 1).contiguous().requires_grad_(True)
+        if not sa.group_all:
+            start, _ = ref_fps(pu, xyz, sa.npoint, fps_seed)
+            cases[tag + "_fps_start"] = start
+        torch.manual_seed(fps_seed)
+        new_xyz, new_points = sa(x, f)
+        gw = torch.from_numpy(rng.normal(size=tuple(new_points.shape)).astype(np.float32))
+        cases[tag + "_gout"] = gw.numpy()
+        params = list(sa.parameters())
+        grads = torch.autograd.grad((new_points * gw).sum(), params + ([f] if f is not None else []), allow_unused=True)
+        cases[tag + "_new_xyz"] = new_xyz.detach().numpy()
+        cases[tag + "_new_points"] = new_points.detach().numpy()
+        for (n, _), g in zip(sa.named_parameters(), grads):
+            cases[tag + "_grad_" + n] = g.numpy()
+        if f is not None:
+            cases[tag + "_grad_feats"] = grads[-1].numpy()
+        if train:
+            for k, v in sa.state_dict().items():
+                if "running" in k:
+                    cases[tag + "_after_" + k] = v.numpy().copy()
+
+    # SA1-like (no features), SA2-like (features), group_all -- small channel counts, real structure
+    xyz = syn.point_cloud(rng, 2, 1024, "cuboid")
+    cases["xyz"] = xyz
+    sa1 = pu.PointNetSetAbstraction(npoint=128, radius=0.2, nsample=32, in_channel=3, mlp=[32, 32, 64], group_all=False)
+    _seed_module(sa1, 1)
+    cases.update({"sa1_" + k: v for k, v in _state(sa1).items()})
+    run("sa1_eval", sa1, xyz, None, 21, False)
+    run("sa1_train", sa1, xyz, None, 21, True)
+
+    xyz2 = syn.point_cloud(rng, 2, 256, "cuboid")
+    feats2 = rng.normal(size=(2, 256, 64)).astype(np.float32)
+    cases["xyz2"] = xyz2
+    cases["feats2"] = feats2
+    sa2 = pu.PointNetSetAbstraction(npoint=64, radius=0.4, nsample=64, in_channel=64 + 3, mlp=[64, 64, 128], group_all=False)
+    _seed_module(sa2, 2)
+    cases.update({"sa2_" + k: v for k, v in _state(sa2).items()})
+    run("sa2_eval", sa2, xyz2, feats2, 22, False)
+    run("sa2_train", sa2, xyz2, feats2, 22, True)
+
+    xyz3 = syn.point_cloud(rng, 4, 128, "cuboid")
+    feats3 = rng.normal(size=(4, 128, 61)).astype(np.float32)
+    cases["xyz3"] = xyz3
+    cases["feats3"] = feats3
+    sa3 = pu.PointNetSetAbstraction(npoint=None, radius=None, nsample=None, in_channel=61 + 3, mlp=[64, 96, 160], group_all=True)
+    _seed_module(sa3, 3)
+    cases.update({"sa3_" + k: v for k, v in _state(sa3).items()})
+    run("sa3_eval", sa3, xyz3, feats3, 23, False)
+    run("sa3_train", sa3, xyz3, feats3, 23, True)
+    save("g3_sa", **cases)
+
+
+def g4_msg(pu):
+    print("g4_msg")
+    rng = np.random.default_rng(404)
+    cases = {}
+    xyz = syn.point_cloud(rng, 2, 512, "cuboid")
+    feats = rng.normal(size=(2, 512, 13)).astype(np.float32)
+    msg = pu.PointNetSetAbstractionMsg(64, [0.1, 0.2, 0.4], [8, 16, 32], 13, [[16, 16, 32], [16, 24, 32], [16, 24, 48]])
+    _seed_module(msg, 4)
+    cases.update({"msg_" + k: v for k, v in _state(msg).items()})
+    cases["xyz"] = xyz
+    cases["feats"] = feats
+    for train in (False, True):
+        tag = "train" if train else "eval"
+        msg.train(train)
+        start, _ = ref_fps(pu, xyz, 64, 31)
+        cases["fps_start"] = start
+        x = torch.from_numpy(xyz).permute(0, 2, 1).contiguous()
+        f = torch.from_numpy(feats).permute(0, 2, 1).contiguous().requires_grad_(True)
+        torch.manual_seed(31)
+        new_xyz, new_points = msg(x, f)
+        gw = torch.from_numpy(rng.normal(size=tuple(new_points.shape)).astype(np.float32))
+        grads = torch.autograd.grad((new_points * gw).sum(), list(msg.parameters()) + [f])
+        cases[tag + "_gout"] = gw.numpy()
+        cases[tag + "_new_xyz"] = new_xyz.detach().numpy()
+        cases[tag + "_new_points"] = new_points.detach().numpy()
+        for (n, _), g in zip(msg.named_parameters(), grads):
+            cases[tag + "_grad_" + n] = g.numpy()
+        cases[tag + "_grad_feats"] = grads[-1].numpy()
+    save("g4_msg", **cases)
+
+
+def g5_model():
+    print("g5_model")
+    pc = R.pointnet2_cls_ssg()
+    pu = R.pointnet2_utils()
+    rng = np.random.default_rng(505)
+    torch.manual_seed(5)
+    # cuboids debug shape, reduced head width/out_vectors to keep the fixture small (structure unchanged)
+    model = pc.PointNet2Regressor_StrokeMasks(outdim=12, outdim_orient=12, weight_orient=0.25, out_vectors=99,
+                                              hidden_size=(64, 64), pred_stroke_masks=True, n_stroke_masks=6,
+                                              mask_confidence_scores=True, segment_confidence_scores=False)
+    model.eval()
+    xyz = syn.point_cloud(rng, 2, 1024, "cuboid")
+    s1, _ = ref_fps(pu, xyz, 512, 41)  # SA1 draw
+    torch.manual_seed(41)
+    _ = torch.randint(0, 1024, (2,))
+    s2 = torch.randint(0, 512, (2,)).numpy()  # SA2 draw follows in the same generator stream
+    torch.manual_seed(41)
+    with torch.no_grad():
+        out, sm_out, mask_conf, seg_conf = model(torch.from_numpy(xyz).permute(0, 2, 1))
+    assert seg_conf is None
+    # only the encoder weights are big-ish; heads are small here
+    sd = {"sd_" + k: v.numpy().copy() for k, v in model.state_dict().items()}
+    save("g5_model", xyz=xyz, fps_start1=s1, fps_start2=s2, out=out.numpy(), sm_out=sm_out.numpy(),
+         mask_conf=mask_conf.numpy(), **sd)
+
+
+def g6_cham():
+    print("g6_cham")
+    ch = R.chamfer_module()
+    rng = np.random.default_rng(606)
+    cases = {}
+    B, S = 3, 99
+    traj, traj_as_pc, stroke_ids, n_seg, n_pts = syn.ground_truth(rng, B, syn.Category("t", S, 6, 3, 6, 120, 300))
+    y_pred = rng.uniform(-1, 1, size=(B, S, 24)).astype(np.float32)
+    cases.update(y_pred=y_pred, traj=traj, traj_as_pc=traj_as_pc, n_seg=n_seg, n_pts=n_pts)
+
+    def call(tag, x, y, **kw):
+        xt = torch.from_numpy(x).requires_grad_(True)
+        yt = torch.from_numpy(y.copy())
+        res = ch.chamfer_distance(xt, yt, **kw)
+        d = res[0]
+        if d.ndim == 0:
+            (gx,) = torch.autograd.grad(d, xt)
+        else:
+            w = torch.from_numpy(rng.normal(size=tuple(d.shape)).astype(np.float32))
+            cases[tag + "_w"] = w.numpy()
+            (gx,) = torch.autograd.grad((d * w).sum(), xt)
+        cases[tag + "_dist"] = d.detach().numpy()
+        cases[tag + "_gx"] = gx.numpy()
+        if len(res) == 4:
+            cases[tag + "_idx_x"] = res[2].numpy()
+            cases[tag + "_idx_y"] = res[3].numpy()
+
+    # the three maskplanner call patterns (loss_handler.py:604-611, 633-637, 642-645)
+    call("c1", y_pred, traj, padded=True, asymmetric=True, return_matching=True, point_reduction=None, batch_reduction=None)
+    call("c2", y_pred.reshape(B, -1, 6), traj_as_pc, padded=True, reverse_asymmetric=True)
+    call("c3", y_pred, traj, padded=True, reverse_asymmetric=True)
+    # metrics_handler.get_pcd pattern (symmetric, mean/mean, padded) and plain unpadded variants
+    call("c4", y_pred.reshape(B, -1, 6), traj_as_pc, padded=True)
+    xs = rng.normal(size=(2, 50, 3)).astype(np.float32)
+    ys = rng.normal(size=(2, 70, 3)).astype(np.float32)
+    cases.update(xs=xs, ys=ys)
+    call("c5", xs, ys)
+    call("c6", xs, ys, batch_reduction="sum", point_reduction="sum")
+    call("c7", xs, ys, batch_reduction=None, point_reduction="mean")
+    save("g6_cham", **cases)
+
+
+def g7_mask():
+    print("g7_mask")
+    lh = R.loss_handler_module()
+    rng = np.random.default_rng(707)
+    cases = {}
+    for tag, B, S, M, cat in (("cub", 3, 99, 6, syn.Category("t", 99, 6, 6, 6, 150, 300)),
+                              ("win", 2, 149, 22, syn.Category("t", 149, 22, 8, 22, 300, 420))):
+        traj, traj_as_pc, stroke_ids, n_seg, n_pts = syn.ground_truth(rng, B, cat)
+        # predictions near GT segments so that several strokes get matched
+        y_pred = np.empty((B, S, 24), dtype=np.float32)
+        for b in range(B):
+            pick = rng.integers(0, n_seg[b], size=S)
+            y_pred[b] = traj[b, pick] + rng.normal(scale=0.02, size=(S, 24)).astype(np.float32)
+        masks = rng.normal(size=(B, M, S)).astype(np.float32)
+        scores = rng.normal(size=(B, M)).astype(np.float32)
+        handler = object.__new__(lh.LossHandler)
+        handler.config = R.maskplanner_loss_config(explicit_no_stroke_weight=0.5 if tag == "win" else 1.0)
+        yp = torch.from_numpy(y_pred).requires_grad_(True)
+        mk = torch.from_numpy(masks).requires_grad_(True)
+        sc = torch.from_numpy(scores).requires_grad_(True)
+        loss = handler.get_asymm_v6_chamfer_with_stroke_masks(
+            y_pred=yp, y=torch.from_numpy(traj), pred_stroke_masks=mk, mask_scores=sc, seg_logits=None,
+            stroke_ids=torch.from_numpy(stroke_ids), traj_as_pc=torch.from_numpy(traj_as_pc))
+        g = torch.autograd.grad(loss, [yp, mk, sc])
+        # the mask term alone (needs idx_x of chamfer call 1)
+        ch = R.chamfer_module()
+        d1, _, idx_x, _ = ch.chamfer_distance(torch.from_numpy(y_pred), torch.from_numpy(traj), padded=True, asymmetric=True,
+                                              return_matching=True, point_reduction=None, batch_reduction=None)
+        mk2 = torch.from_numpy(masks).requires_grad_(True)
+        sc2 = torch.from_numpy(scores).requires_grad_(True)
+        mloss = handler.get_stroke_masks_loss(idx_x, mk2, sc2, torch.from_numpy(stroke_ids), nn_distance=d1, smooth_targets=False)
+        gm = torch.autograd.grad(mloss, [mk2, sc2])
+        cases.update({
+            tag + "_y_pred": y_pred, tag + "_traj": traj, tag + "_traj_as_pc": traj_as_pc, tag + "_stroke_ids": stroke_ids,
+            tag + "_masks": masks, tag + "_scores": scores, tag + "_no_stroke_weight": np.float64(handler.config["explicit_no_stroke_weight"]),
+            tag + "_loss": loss.detach().numpy(), tag + "_g_y_pred": g[0].numpy(), tag + "_g_masks": g[1].numpy(),
+            tag + "_g_scores": g[2].numpy(), tag + "_idx_x": idx_x.numpy(), tag + "_mask_loss": mloss.detach().numpy(),
+            tag + "_gm_masks": gm[0].numpy(), tag + "_gm_scores": gm[1].numpy(),
+        })
+    save("g7_mask", **cases)
+
+
+def g8_hung():
+    print("g8_hung")
+    hm = R.hungarian_matcher()
+    rng = np.random.default_rng(808)
+    S = 200
+    sizes = [180, 150, 200]
+    out = rng.uniform(-1, 1, size=(3, S, 24)).astype(np.float32)
+    tg = [rng.uniform(-1, 1, size=(n, 24)).astype(np.float32) for n in sizes]
+    res = hm.HungarianMatcher()(torch.from_numpy(out), [torch.from_numpy(t) for t in tg])
+    cases = {"outputs": out}
+    for b, (i, j) in enumerate(res):
+        cases[f"target{b}"] = tg[b]
+        cases[f"i{b}"] = i.numpy()
+        cases[f"j{b}"] = j.numpy()
+    save("g8_hung", **cases)
+
+
+def main():
+    if not R.available():
+        raise SystemExit("reference checkout not found; fixtures can only be generated in the build container")
+    torch.set_num_threads(8)
+    pu = R.pointnet2_utils()
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8"]
+    if "g1" in which: g1_fps(pu)
+    if "g2" in which: g2_bq(pu)
+    if "g3" in which: g3_sa(pu)
+    if "g4" in which: g4_msg(pu)
+    if "g5" in which: g5_model()
+    if "g6" in which: g6_cham()
+    if "g7" in which: g7_mask()
+    if "g8" in which: g8_hung()
+
+
+if __name__ == "__main__":
+    main()

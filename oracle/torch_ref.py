@@ -1,0 +1,227 @@
+"""fp32 CPU restatement of the floating-point half of the hot path -- TEST INFRASTRUCTURE ONLY.
+
+Index-producing steps (FPS, ball query, kNN, LAP) come from the C oracle (oracle/mp_oracle.c);
+the floating-point algebra around them (shared MLP + BatchNorm + max-pool, heads, chamfer
+reductions, stroke-mask loss) is written here with plain torch CPU ops and autograd.  Checked
+against the golden fixtures g3..g7 (tests/test_oracle_golden.py); used as the checker for the
+HIP path at sizes the fixtures do not cover and as bench.py's cpu_baseline ("port").
+
+Layout note: activations are kept positions-major [B,S,K,C] (the reference uses [B,C,K,S]); a 1x1
+Conv2d is then a plain matmul over the last axis, and BatchNorm2d statistics are over all leading axes.
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import oracle as O
+
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+
+# ------------------------------------------------------------------------------------------------
+# set abstraction  (models/pointnet2_utils.py:112-216)
+# ------------------------------------------------------------------------------------------------
+def _bn_train(z, gamma, beta, running=None):
+    """BatchNorm (training mode) over all axes but the last; biased var for normalisation,
+    unbiased var for the running estimate (torch.nn.BatchNorm2d semantics)."""
+    red = tuple(range(z.ndim - 1))
+    mean = z.mean(red)
+    var = z.var(red, unbiased=False)
+    if running is not None:
+        n = z.numel() // z.shape[-1]
+        rm, rv = running
+        with torch.no_grad():
+            rm.mul_(1 - BN_MOMENTUM).add_(BN_MOMENTUM * mean)
+            rv.mul_(1 - BN_MOMENTUM).add_(BN_MOMENTUM * var * n / max(n - 1, 1))
+    return (z - mean) / torch.sqrt(var + BN_EPS) * gamma + beta
+
+
+def _bn_eval(z, gamma, beta, rm, rv):
+    return (z - rm) / torch.sqrt(rv + BN_EPS) * gamma + beta
+
+
+def shared_mlp_max(x, layers, train):
+    """x [B,S,K,Cin] -> [B,S,Cout]: (1x1 conv, BN, ReLU) x len(layers), then max over K.
+    layers: list of dict(weight[Co,Ci], bias[Co], gamma, beta, running_mean, running_var)."""
+    for L in layers:
+        z = x @ L["weight"].t() + L["bias"]
+        if train:
+            z = _bn_train(z, L["gamma"], L["beta"], (L["running_mean"], L["running_var"]))
+        else:
+            z = _bn_eval(z, L["gamma"], L["beta"], L["running_mean"], L["running_var"])
+        x = torch.relu(z)
+    return x.max(dim=2)[0]
+
+
+def layers_from_state(sd, prefix, convs="mlp_convs", bns="mlp_bns"):
+    """Collect SA layer tensors from a reference-layout state_dict (SURVEY section 5 key list)."""
+    out = []
+    i = 0
+    while f"{prefix}{convs}.{i}.weight" in sd:
+        w = sd[f"{prefix}{convs}.{i}.weight"]
+        out.append(dict(
+            weight=w.reshape(w.shape[0], w.shape[1]), bias=sd[f"{prefix}{convs}.{i}.bias"],
+            gamma=sd[f"{prefix}{bns}.{i}.weight"], beta=sd[f"{prefix}{bns}.{i}.bias"],
+            running_mean=sd[f"{prefix}{bns}.{i}.running_mean"], running_var=sd[f"{prefix}{bns}.{i}.running_var"]))
+        i += 1
+    return out
+
+
+def set_abstraction(xyz, feats, layers, npoint, radius, nsample, fps_start, train, group_all=False):
+    """xyz [B,N,3], feats [B,N,D] or None (points-major).  Returns new_xyz [B,S,3], new_feats [B,S,C']."""
+    B, N, _ = xyz.shape
+    if group_all:  # sample_and_group_all :151-168 -- xyz NOT centred, new_xyz = 0
+        x = xyz if feats is None else torch.cat([xyz, feats], -1)
+        return torch.zeros(B, 1, 3), shared_mlp_max(x[:, None], layers, train)
+    xyz_np = xyz.detach().numpy()
+    fidx = O.fps(xyz_np, npoint, fps_start)
+    new_xyz_np = O.index_points(xyz_np, fidx)
+    gidx = torch.from_numpy(O.ball_query(radius, nsample, xyz_np, new_xyz_np))
+    new_xyz = torch.from_numpy(new_xyz_np)
+    bidx = torch.arange(B)[:, None, None]
+    g = xyz[bidx, gidx] - new_xyz[:, :, None]
+    if feats is not None:
+        g = torch.cat([g, feats[bidx, gidx]], -1)  # xyz channels first (:138)
+    return new_xyz, shared_mlp_max(g, layers, train)
+
+
+def set_abstraction_msg(xyz, feats, blocks, npoint, radii, nsamples, fps_start, train):
+    """PointNetSetAbstractionMsg (:219-276): one FPS, per-radius ball query; channel order FEATS first, xyz last."""
+    B = xyz.shape[0]
+    xyz_np = xyz.detach().numpy()
+    fidx = O.fps(xyz_np, npoint, fps_start)
+    new_xyz_np = O.index_points(xyz_np, fidx)
+    new_xyz = torch.from_numpy(new_xyz_np)
+    bidx = torch.arange(B)[:, None, None]
+    outs = []
+    for layers, r, K in zip(blocks, radii, nsamples):
+        gidx = torch.from_numpy(O.ball_query(r, K, xyz_np, new_xyz_np))
+        g = xyz[bidx, gidx] - new_xyz[:, :, None]
+        if feats is not None:
+            g = torch.cat([feats[bidx, gidx], g], -1)
+        outs.append(shared_mlp_max(g, layers, train))
+    return new_xyz, torch.cat(outs, -1)
+
+
+# ------------------------------------------------------------------------------------------------
+# full model  (models/pointnet2_cls_ssg.py:233-344, eval or train without dropout)
+# ------------------------------------------------------------------------------------------------
+def _bn1d(x, sd, name, train):
+    g, b = sd[name + ".weight"], sd[name + ".bias"]
+    if train:
+        return _bn_train(x, g, b, (sd[name + ".running_mean"], sd[name + ".running_var"]))
+    return _bn_eval(x, g, b, sd[name + ".running_mean"], sd[name + ".running_var"])
+
+
+def strokemasks_forward(sd, xyz, fps_starts, train, out_vectors, n_masks, weight_orient=0.25, dropout_masks=None):
+    """sd: reference-layout state_dict of tensors; xyz [B,N,3].  dropout_masks: optional list of 4
+    pre-scaled keep masks (train mode) so dropout is reproducible; None = no dropout."""
+    B = xyz.shape[0]
+    l1_xyz, l1 = set_abstraction(xyz, None, layers_from_state(sd, "sa1."), 512, 0.2, 32, fps_starts[0], train)
+    l2_xyz, l2 = set_abstraction(l1_xyz, l1, layers_from_state(sd, "sa2."), 128, 0.4, 64, fps_starts[1], train)
+    _, l3 = set_abstraction(l2_xyz, l2, layers_from_state(sd, "sa3."), None, None, None, None, train, group_all=True)
+    feat = l3.reshape(B, -1)
+    dm = dropout_masks or [1.0, 1.0, 1.0, 1.0]
+    x = torch.relu(_bn1d(feat @ sd["fc1.weight"].t() + sd["fc1.bias"], sd, "bn1", train)) * dm[0]
+    final = torch.relu(_bn1d(x @ sd["fc2.weight"].t() + sd["fc2.bias"], sd, "bn2", train)) * dm[1]
+    pos = final @ sd["fc3.weight"].t() + sd["fc3.bias"]
+    s1 = torch.relu(_bn1d(feat @ sd["sm_fc1.weight"].t() + sd["sm_fc1.bias"], sd, "sm_bn1", train)) * dm[2]
+    s2 = torch.relu(_bn1d(s1 @ sd["sm_fc2.weight"].t() + sd["sm_fc2.bias"], sd, "sm_bn2", train)) * dm[3]
+    sm_out = (s2 @ sd["sm_fc3.weight"].t() + sd["sm_fc3.bias"]).view(B, n_masks, -1)
+    mask_conf = s2 @ sd["mask_conf_out.weight"].t() + sd["mask_conf_out.bias"]
+    nrm = torch.tanh(final @ sd["fc_normals.weight"].t() + sd["fc_normals.bias"]).view(B, -1, 3)
+    nrm = F.normalize(nrm, dim=-1) * weight_orient
+    out = torch.cat([pos.view(B, -1, 3), nrm], -1).view(B, out_vectors, -1)
+    return out, sm_out, mask_conf
+
+
+# ------------------------------------------------------------------------------------------------
+# chamfer  (pytorch3d_chamfer.py:76-344: the flags the maskplanner path exercises)
+# ------------------------------------------------------------------------------------------------
+class _Knn1(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, p1, p2, l1, l2):
+        d, i = O.knn_points(p1.detach().numpy(), p2.detach().numpy(), l1.numpy(), l2.numpy(), 1)
+        d, i = torch.from_numpy(d[..., 0].copy()), torch.from_numpy(i[..., 0].copy())
+        ctx.save_for_backward(p1, p2, l1, l2, i)
+        ctx.mark_non_differentiable(i)
+        return d, i
+
+    @staticmethod
+    def backward(ctx, gd, _):
+        p1, p2, l1, l2, i = ctx.saved_tensors
+        g1, g2 = O.knn_points_bwd(p1.detach().numpy(), p2.detach().numpy(), l1.numpy(), l2.numpy(),
+                                  i.numpy()[..., None], gd.contiguous().numpy()[..., None])
+        return torch.from_numpy(g1), torch.from_numpy(g2), None, None
+
+
+def chamfer_distance(x, y, padded=False, asymmetric=False, reverse_asymmetric=False, return_matching=False,
+                     batch_reduction="mean", point_reduction="mean"):
+    B, P1, D = x.shape
+    P2 = y.shape[1]
+    xl = torch.full((B,), P1, dtype=torch.int64)
+    yl = torch.from_numpy(O.padded_lengths(y.detach().numpy())) if padded else torch.full((B,), P2, dtype=torch.int64)
+    cx, ix = _Knn1.apply(x, y, xl, yl)
+    cy, iy = _Knn1.apply(y, x, yl, xl)
+    # rows beyond the length already hold 0 (knn contract) == the reference's masking (:263-266)
+    if point_reduction is not None:
+        cx, cy = cx.sum(1), cy.sum(1)
+        if point_reduction == "mean":
+            cx, cy = cx / xl, cy / yl
+    if batch_reduction is not None:
+        cx, cy = cx.sum(), cy.sum()
+        if batch_reduction == "mean":
+            cx, cy = cx / B, cy / B
+    d = cx if asymmetric else cy if reverse_asymmetric else cx + cy
+    return (d, ix, iy) if return_matching else d
+
+
+# ------------------------------------------------------------------------------------------------
+# stroke-mask loss  (loss_handler.py:816-935) and the asymm_v6 total (:596-666)
+# ------------------------------------------------------------------------------------------------
+def stroke_masks_loss(idx_x, pred_masks, scores, stroke_ids, w_masks=1.0, w_conf=100.0, no_stroke_weight=1.0,
+                      return_matching=False):
+    B, M, S = pred_masks.shape
+    tgt_ids = stroke_ids.gather(1, idx_x)
+    assert not (tgt_ids == -1).any()
+    matched_pred, matched_tgt, pairs = [], [], []
+    tscore = torch.zeros(B, M)
+    wts = torch.full((B, M), float(no_stroke_weight))
+    for b in range(B):
+        masks, _ = O.stroke_ids_to_masks(tgt_ids[b].numpy())
+        cost = O.mask_bce_cost(pred_masks[b].detach().numpy(), masks)
+        i, j = O.linear_sum_assignment(cost)
+        pairs.append((i, j))
+        matched_pred.append(pred_masks[b, torch.from_numpy(i)])
+        matched_tgt.append(torch.from_numpy(masks[j]))
+        tscore[b, torch.from_numpy(i)] = 1.0
+        wts[b, torch.from_numpy(i)] = 1.0
+    mp, mt = torch.cat(matched_pred), torch.cat(matched_tgt)
+    mask_loss = F.binary_cross_entropy_with_logits(mp, mt, reduction="none").sum(-1).mean()
+    conf_loss = F.binary_cross_entropy_with_logits(scores, tscore, weight=wts, reduction="none").mean()
+    loss = w_masks * mask_loss + w_conf * conf_loss
+    return (loss, pairs) if return_matching else loss
+
+
+def asymm_v6_loss(y_pred, traj, pred_masks, scores, stroke_ids, traj_as_pc, cfg):
+    """cfg: dict with the weights read at loss_handler.py:660-664,934."""
+    B = y_pred.shape[0]
+    d1, idx_x, _ = chamfer_distance(y_pred, traj, padded=True, asymmetric=True, return_matching=True,
+                                    point_reduction=None, batch_reduction=None)
+    t1 = 100 * d1.mean()
+    t2 = 100 * chamfer_distance(y_pred.reshape(B, -1, 6), traj_as_pc, padded=True, reverse_asymmetric=True)
+    t3 = 100 * chamfer_distance(y_pred, traj, padded=True, reverse_asymmetric=True)
+    t4 = stroke_masks_loss(idx_x, pred_masks, scores, stroke_ids, cfg["explicit_weight_stroke_masks"],
+                           cfg["explicit_weight_stroke_masks_confidence"], cfg["explicit_no_stroke_weight"])
+    return (cfg["weight_asymm_segment_chamfer"] * t1 + cfg["weight_reverse_asymm_point_chamfer"] * t2
+            + cfg["weight_reverse_asymm_segment_chamfer"] * t3 + t4)
+
+
+def hungarian_match(outputs, targets):
+    """models/hungarianMatcher.py:31-63 without the cross-batch cdist waste."""
+    res = []
+    for b, t in enumerate(targets):
+        c = O.cdist(outputs[b].detach().numpy(), t.detach().numpy())
+        res.append(O.linear_sum_assignment(c))
+    return res
