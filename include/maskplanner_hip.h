@@ -1,0 +1,131 @@
+/*
+ * maskplanner_hip.h -- C ABI of libmaskplanner_hip.so: the MI355X (gfx950 / CDNA4) kernels of the
+ * MaskPlanner hot path (PointNet++ set abstraction + set losses).
+ *
+ * The reference (gabrieletiboni/MaskPlanner) has no FFI layer: its hot path is PyTorch tensor algebra
+ * plus pytorch3d.ops.knn.knn_points and scipy.optimize.linear_sum_assignment.  Each entry point below
+ * replaces one of those Python-level operators; the `replaces:` line cites the reference file:line.
+ * INTEGRATION.md shows the ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions (all entry points)
+ *   - plain C: raw DEVICE pointers + int64 sizes; no torch / C++ types in any signature;
+ *   - layouts are contiguous row-major; coordinates points-major [B,N,C]; indices int64 (reference dtype);
+ *   - the caller owns every buffer (inputs, outputs, workspace).  The library never allocates, frees or
+ *     retains device memory and keeps no mutable global state: re-entrant, thread-safe;
+ *   - enqueue-only: work is queued on `stream` (a hipStream_t passed as void*; NULL = default stream);
+ *     no hipDeviceSynchronize, no hidden device->host copies => safe under hipGraph capture;
+ *   - return value: MP_OK (0) or a negative MP_E* code.  No exceptions, no abort().
+ *   - fp32 arithmetic follows the exact rounding sequence of the reference's CPU torch path (see each
+ *     entry); index outputs are bit-exact, fp32 outputs agree within 1e-5.
+ */
+#ifndef MASKPLANNER_HIP_H
+#define MASKPLANNER_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MP_OK 0
+#define MP_EINVAL (-1)        /* null pointer / negative or inconsistent dimension            */
+#define MP_EUNSUPPORTED (-2)  /* size outside what the kernels are built for (see each entry) */
+#define MP_EWORKSPACE (-3)    /* workspace too small                                          */
+#define MP_ELAUNCH (-4)       /* hipGetLastError() != hipSuccess after the launch             */
+
+#define MP_ABI_VERSION 1
+
+typedef void* mp_stream_t; /* hipStream_t */
+
+int mp_abi_version(void);
+const char* mp_error_string(int code);
+
+/* ---- farthest point sampling -------------------------------------------------------------------
+ * replaces: models/pointnet2_utils.py:65-86 farthest_point_sample(xyz, npoint)
+ *   xyz [B,N,3] f32; start_idx [B] i64 = the reference's torch.randint draw (:77), passed in so the
+ *   caller keeps seed compatibility; out_idx [B,S] i64; out_xyz [B,S,3] f32 or NULL (fused
+ *   index_points(xyz, fps_idx), :131).  dist = (dx*dx + dy*dy) + dz*dz without FMA; running min;
+ *   argmax with lowest index on ties.  N <= 13312 (cloud resident in LDS), else MP_EUNSUPPORTED. */
+int mp_fps_f32(const float* xyz, int64_t B, int64_t N, int64_t S, const int64_t* start_idx,
+               int64_t* out_idx, float* out_xyz, mp_stream_t stream);
+
+/* ---- ball query ------------------------------------------------------------------------------
+ * replaces: models/pointnet2_utils.py:89-109 query_ball_point(radius, nsample, xyz, new_xyz)
+ *   xyz [B,N,3], new_xyz [B,S,3] f32 -> out_idx [B,S,K] i64: the first K indices (ascending) with
+ *   !(d > (float)(radius*radius)), d in the reference's expanded form ((-2*dot)+|q|^2)+|p|^2 (:39-41),
+ *   dot = fma(qz,pz, fma(qy,py, qx*px)); empty slots take the first hit (a query with no hit yields N
+ *   in every slot, as the reference's intermediate does).  K <= 1024.  N <= 13312. */
+int mp_ball_query_f32(const float* xyz, const float* new_xyz, int64_t B, int64_t N, int64_t S,
+                      double radius, int64_t K, int64_t* out_idx, mp_stream_t stream);
+
+/* ---- square_distance -------------------------------------------------------------------------
+ * replaces: models/pointnet2_utils.py:21-42 square_distance(src, dst) -> [B,S,N] f32 (expanded form) */
+int mp_square_distance_f32(const float* src, const float* dst, int64_t B, int64_t S, int64_t N,
+                           float* out, mp_stream_t stream);
+
+/* ---- index_points (row gather) and its backward ------------------------------------------------
+ * replaces: models/pointnet2_utils.py:45-62 index_points(points, idx)
+ *   points [B,N,C] f32, idx [B,M] i64 (M = product of idx's trailing dims) -> out [B,M,C].
+ *   backward: grad_points [B,N,C] = scatter-add of grad_out rows (overwritten, not accumulated).
+ *   deterministic != 0 selects the fixed-order (bitwise reproducible) variant instead of atomics. */
+int mp_index_points_f32(const float* points, const int64_t* idx, int64_t B, int64_t N, int64_t C,
+                        int64_t M, float* out, mp_stream_t stream);
+int mp_index_points_bwd_f32(const float* grad_out, const int64_t* idx, int64_t B, int64_t N, int64_t C,
+                            int64_t M, float* grad_points, int deterministic, mp_stream_t stream);
+
+/* ---- grouping (gather + centre + concat) -----------------------------------------------------
+ * replaces: models/pointnet2_utils.py:133-143 (sample_and_group tail) and :258-262 (MSG variant)
+ *   out [B,S,K,3+D] = cat(xyz[idx] - new_xyz, feats[idx])   (xyz_last == 0, SSG order, :138)
+ *                   = cat(feats[idx], xyz[idx] - new_xyz)   (xyz_last != 0, MSG order, :262)
+ *   feats [B,N,D] may be NULL with D == 0.
+ *   backward: grad_feats [B,N,D] = scatter-add of the feature channels of grad_out (overwritten). */
+int mp_group_f32(const float* xyz, const float* feats, const float* new_xyz, const int64_t* idx,
+                 int64_t B, int64_t N, int64_t S, int64_t K, int64_t D, int xyz_last, float* out,
+                 mp_stream_t stream);
+int mp_group_bwd_f32(const float* grad_out, const int64_t* idx, int64_t B, int64_t N, int64_t S,
+                     int64_t K, int64_t D, int xyz_last, float* grad_feats, int deterministic,
+                     mp_stream_t stream);
+
+/* ---- K nearest neighbours (brute force) and backward ------------------------------------------------
+ * replaces: pytorch3d.ops.knn.knn_points (third party; call sites pytorch3d_chamfer.py:182-183,
+ *           205-206, 257-258) and its autograd backward.
+ *   p1 [B,P1,D], p2 [B,P2,D] f32; len1/len2 [B] i64 or NULL (= full);  K in {1,2,...,8}.
+ *   dists [B,P1,K] f32 (squared L2, ascending), idx [B,P1,K] i64.  dist = fma chain over d of
+ *   (p1[d]-p2[d])^2; strict < keeps the first index on ties; rows >= len1 and slots >= len2 hold 0.
+ *   backward: grad_p1 [B,P1,D] / grad_p2 [B,P2,D] (either may be NULL = not needed; overwritten):
+ *     g = 2*grad_dists[i,k]*(p1[i]-p2[idx]) ; grad_p1[i] += g ; grad_p2[idx] -= g.
+ *   workspace: mp_knn_workspace_bytes(B,P1,K) bytes (device). */
+size_t mp_knn_workspace_bytes(int64_t B, int64_t P1, int64_t K);
+int mp_knn_f32(const float* p1, const float* p2, const int64_t* len1, const int64_t* len2, int64_t B,
+               int64_t P1, int64_t P2, int64_t D, int64_t K, float* dists, int64_t* idx,
+               void* workspace, size_t workspace_bytes, mp_stream_t stream);
+int mp_knn_bwd_f32(const float* p1, const float* p2, const int64_t* len1, const int64_t* len2,
+                   const int64_t* idx, const float* grad_dists, int64_t B, int64_t P1, int64_t P2,
+                   int64_t D, int64_t K, float* grad_p1, float* grad_p2, int deterministic,
+                   mp_stream_t stream);
+
+/* ---- padded-length detection -------------------------------------------------------------------
+ * replaces: pytorch3d_chamfer.py:138-149 (`padded=True`): lengths[b] = first column c with
+ *   y[b,c,0] == -100, else P2.  Removes the reference's B host syncs. */
+int mp_padded_lengths_f32(const float* y, int64_t B, int64_t P2, int64_t D, int64_t* lengths,
+                          mp_stream_t stream);
+
+/* ---- stroke-mask matching: BCE cost + rectangular LAP, on device ------------------------------------
+ * replaces: loss_handler.py:838-875 (target ids -> binary masks -> BCE cost -> scipy
+ *           linear_sum_assignment, in a Python loop over the batch with one host sync per sample)
+ *   pred_masks [B,M,S] f32 logits; target_ids [B,S] f32 = stroke_ids.gather(1, idx_x) (:838).
+ *   Per sample: unique ids ascending, -1 skipped (:938-967) -> Kb masks; cost[m,k] = sum_s
+ *   BCEWithLogits(pred[m,s], mask[k,s]); LAP solved with scipy's algorithm and tie-breaking.
+ *   Outputs: match_col [B,M] i64 = matched mask index k or -1; uniq_ids [B,M_cap] f32 (ascending,
+ *   first n_targets[b] valid); n_targets [B] i64; cost [B,M,M_cap] f32 or NULL.  M_cap = 64.
+ *   M <= 64 and Kb <= 64, else status[b] (i32, [B]) is set to MP_EUNSUPPORTED (0 otherwise). */
+#define MP_MASK_CAP 64
+int mp_mask_match_f32(const float* pred_masks, const float* target_ids, int64_t B, int64_t M, int64_t S,
+                      int64_t* match_col, float* uniq_ids, int64_t* n_targets, float* cost,
+                      int32_t* status, mp_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MASKPLANNER_HIP_H */

@@ -1,0 +1,95 @@
+"""ctypes binding of libmaskplanner_hip.so (C ABI: include/maskplanner_hip.h).
+
+The library is the product: there is NO CPU or eager-PyTorch fallback.  If the shared object is missing or
+does not export the ABI this module raises, and every op in `maskplanner_amd.ops` refuses non-HIP tensors.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmaskplanner_hip.so")
+ABI_VERSION = 1
+
+MP_OK = 0
+MP_EINVAL = -1
+MP_EUNSUPPORTED = -2
+MP_EWORKSPACE = -3
+MP_ELAUNCH = -4
+MASK_CAP = 64
+
+_vp = ctypes.c_void_p
+_i64 = ctypes.c_int64
+_int = ctypes.c_int
+_dbl = ctypes.c_double
+_sz = ctypes.c_size_t
+
+# name -> (restype, argtypes).  One entry per symbol declared in include/maskplanner_hip.h.
+SIGNATURES = {
+    "mp_abi_version": (_int, []),
+    "mp_error_string": (ctypes.c_char_p, [_int]),
+    "mp_fps_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp]),
+    "mp_ball_query_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _dbl, _i64, _vp, _vp]),
+    "mp_square_distance_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp]),
+    "mp_index_points_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),
+    "mp_index_points_bwd_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _int, _vp]),
+    "mp_group_f32": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _int, _vp, _vp]),
+    "mp_group_bwd_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _i64, _int, _vp, _int, _vp]),
+    "mp_knn_workspace_bytes": (_sz, [_i64, _i64, _i64]),
+    "mp_knn_f32": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _sz, _vp]),
+    "mp_knn_bwd_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _int, _vp]),
+    "mp_padded_lengths_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _vp]),
+    "mp_mask_match_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
+}
+
+_lib = None
+
+
+class MaskPlannerHipError(RuntimeError):
+    pass
+
+
+def _promote_hip_runtime():
+    """libmaskplanner_hip.so is linked without a NEEDED entry for the HIP runtime (csrc/Makefile): it binds to
+    the runtime already in the process.  PyTorch-ROCm ships its own libamdhip64.so and loads it with local
+    visibility; re-opening it RTLD_GLOBAL makes its symbols the ones our library resolves against, so
+    kernels launch on the very runtime instance that owns torch's streams and allocations."""
+    import torch  # noqa: F401  (loads torch's HIP runtime)
+    cand = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+    else:  # a torch build that uses the system ROCm
+        ctypes.CDLL("libamdhip64.so", mode=ctypes.RTLD_GLOBAL)
+
+
+def load():
+    """Load the library, bind every ABI symbol, check the ABI version.  Raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MaskPlannerHipError(
+            f"{LIB_PATH} not found: build it with `make -C maskplanner_amd/csrc` (or __graft_entry__.build()). "
+            "There is no CPU / PyTorch fallback for the MaskPlanner hot path.")
+    _promote_hip_runtime()
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise MaskPlannerHipError(f"{LIB_PATH} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    got = lib.mp_abi_version()
+    if got != ABI_VERSION:
+        raise MaskPlannerHipError(f"ABI mismatch: library {got}, binding {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(rc, op):
+    if rc == MP_OK:
+        return
+    msg = load().mp_error_string(rc).decode()
+    if rc == MP_EINVAL:
+        raise ValueError(f"{op}: {msg}")
+    raise MaskPlannerHipError(f"{op}: {msg} (code {rc})")

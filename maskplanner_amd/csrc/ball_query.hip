@@ -1,0 +1,152 @@
+// Ball query + square_distance for gfx950.
+//
+// Reference: models/pointnet2_utils.py:89-109 (query_ball_point) builds a [B,S,N] int64 index tensor,
+// masks it with the all-pairs distance matrix (:21-42) and SORTS it to take the first `nsample` in-ball
+// indices.  Equivalent, and what runs here: scan the cloud in index order, keep the first K hits, stop.
+//
+// Design: the cloud (SoA, 12 B/point) is staged once per workgroup in LDS; one wave per query scans 64
+// points per step: lane-parallel membership test, one ballot, a popcount prefix gives every hit its output
+// slot in index order; the scan stops as soon as K hits are found (balls saturate on surface clouds).  The
+// K slots are buffered per wave in LDS and written as one coalesced row, padding included.
+//
+// Arithmetic (bit-exact membership is the contract): d = ((-2*dot) + |q|^2) + |p|^2 with
+// dot = fma(qz,pz, fma(qy,py, qx*px)), norms (x*x + y*y) + z*z, test !(d > (float)(radius*radius)).
+// -2*dot is exact, so fma(-2, dot, |q|^2) rounds once exactly like the reference's separate add.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float norm3(float x, float y, float z) { return (x * x + y * y) + z * z; }
+
+__device__ __forceinline__ float sqdist_expanded(float qx, float qy, float qz, float qn, float x, float y, float z)
+{
+    const float dot = __builtin_fmaf(qz, z, __builtin_fmaf(qy, y, qx * x));
+    return ((-2.0f * dot) + qn) + norm3(x, y, z);
+}
+
+constexpr int BQ_WAVES = 8;
+constexpr int BQ_THREADS = BQ_WAVES * MP_WAVE;
+constexpr int BQ_UNROLL = 4;
+
+__global__ __launch_bounds__(BQ_THREADS) void ball_query_kernel(const float* __restrict__ xyz,
+                                                                const float* __restrict__ new_xyz, int N, int S,
+                                                                float r2, int K, int qpb,
+                                                                int64_t* __restrict__ out_idx)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int npad = (N + 255) & ~255;
+    float* sx = reinterpret_cast<float*>(smem_raw);
+    float* sy = sx + npad;
+    float* sz = sy + npad;
+    int* hits = reinterpret_cast<int*>(sz + npad);  // [BQ_WAVES][K]
+
+    const int b = blockIdx.y;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const float* p = xyz + (size_t)b * N * 3;
+    for (int i = tid; i < 3 * N; i += BQ_THREADS) {
+        const float v = p[i];
+        const int pt = i / 3;
+        const int c = i - 3 * pt;
+        (c == 0 ? sx : (c == 1 ? sy : sz))[pt] = v;
+    }
+    // padding far outside any ball; it is also masked by the i < N test
+    for (int i = N + tid; i < npad; i += BQ_THREADS) { sx[i] = 3.0e18f; sy[i] = 3.0e18f; sz[i] = 3.0e18f; }
+    __syncthreads();
+
+    int* my = hits + wave * K;
+    const int q0 = blockIdx.x * qpb;
+    const int q1 = min(S, q0 + qpb);
+    for (int q = q0 + wave; q < q1; q += BQ_WAVES) {
+        const float* qp = new_xyz + ((size_t)b * S + q) * 3;
+        const float qx = qp[0], qy = qp[1], qz = qp[2];
+        const float qn = norm3(qx, qy, qz);
+        int cnt = 0;
+        for (int base = 0; base < N && cnt < K; base += 64 * BQ_UNROLL) {
+            unsigned long long masks[BQ_UNROLL];
+#pragma unroll
+            for (int u = 0; u < BQ_UNROLL; ++u) {
+                const int i = base + u * 64 + lane;  // < npad: the LDS image is padded to 256
+                const float d = sqdist_expanded(qx, qy, qz, qn, sx[i], sy[i], sz[i]);
+                masks[u] = __ballot(i < N && !(d > r2));
+            }
+#pragma unroll
+            for (int u = 0; u < BQ_UNROLL; ++u) {
+                const unsigned long long m = masks[u];
+                if (m != 0ull && cnt < K) {
+                    const int rank = cnt + mp::prefix_popc(m);
+                    if (((m >> lane) & 1ull) && rank < K) my[rank] = base + u * 64 + lane;
+                    cnt += __popcll(m);
+                }
+            }
+        }
+        cnt = min(cnt, K);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int first = cnt > 0 ? my[0] : N;
+        int64_t* o = out_idx + ((size_t)b * S + q) * K;
+        for (int k = lane; k < K; k += 64) o[k] = (int64_t)(k < cnt ? my[k] : first);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+__global__ __launch_bounds__(256) void square_distance_kernel(const float* __restrict__ src,
+                                                              const float* __restrict__ dst, int S, int N,
+                                                              float* __restrict__ out)
+{
+    // grid: (ceil(N/256), S, B).  One query per block row, points coalesced across lanes.
+    const int b = blockIdx.z, s = blockIdx.y;
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    const float* q = src + ((size_t)b * S + s) * 3;
+    const float qx = q[0], qy = q[1], qz = q[2];
+    const float qn = norm3(qx, qy, qz);
+    if (n < N) {
+        const float* p = dst + ((size_t)b * N + n) * 3;
+        out[((size_t)b * S + s) * N + n] = sqdist_expanded(qx, qy, qz, qn, p[0], p[1], p[2]);
+    }
+}
+
+}  // namespace
+
+extern "C" int mp_ball_query_f32(const float* xyz, const float* new_xyz, int64_t B, int64_t N, int64_t S,
+                                 double radius, int64_t K, int64_t* out_idx, mp_stream_t stream_)
+{
+    if (B < 0 || N <= 0 || S < 0 || K <= 0) return MP_EINVAL;
+    if (B == 0 || S == 0) return MP_OK;
+    if (!xyz || !new_xyz || !out_idx) return MP_EINVAL;
+    if (N > 13312 || K > 1024 || B > 65535) return MP_EUNSUPPORTED;
+    const int npad = ((int)N + 255) & ~255;
+    const size_t smem = (size_t)3 * npad * sizeof(float) + (size_t)BQ_WAVES * K * sizeof(int);
+    if (smem > 160 * 1024) return MP_EUNSUPPORTED;
+    // queries per block: enough blocks to fill 256 CUs several times over, whole waves' worth of queries
+    int64_t qpb = (B * S + 1023) / 1024;
+    qpb = ((qpb + BQ_WAVES - 1) / BQ_WAVES) * BQ_WAVES;
+    if (qpb < BQ_WAVES) qpb = BQ_WAVES;
+    const int chunks = (int)((S + qpb - 1) / qpb);
+    if (smem > 64 * 1024) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(ball_query_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+            return MP_ELAUNCH;
+    }
+    const float r2 = (float)(radius * radius);  // squared in double, then cast: pointnet2_utils.py:104
+    hipLaunchKernelGGL(ball_query_kernel, dim3(chunks, (unsigned)B), dim3(BQ_THREADS), smem, mp_stream(stream_), xyz,
+                       new_xyz, (int)N, (int)S, r2, (int)K, (int)qpb, out_idx);
+    MP_CHECK_LAUNCH();
+    return MP_OK;
+}
+
+extern "C" int mp_square_distance_f32(const float* src, const float* dst, int64_t B, int64_t S, int64_t N,
+                                      float* out, mp_stream_t stream_)
+{
+    if (B < 0 || S < 0 || N < 0) return MP_EINVAL;
+    if (B == 0 || S == 0 || N == 0) return MP_OK;
+    if (!src || !dst || !out) return MP_EINVAL;
+    if (B > 65535 || S > 65535) return MP_EUNSUPPORTED;
+    hipLaunchKernelGGL(square_distance_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)S, (unsigned)B), dim3(256), 0,
+                       mp_stream(stream_), src, dst, (int)S, (int)N, out);
+    MP_CHECK_LAUNCH();
+    return MP_OK;
+}

@@ -1,0 +1,92 @@
+// Shared device helpers for the gfx950 kernels (wave64 only; no other target is supported).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/maskplanner_hip.h"
+
+#define MP_WAVE 64
+
+#define MP_CHECK_LAUNCH()                                   \
+    do {                                                    \
+        if (hipGetLastError() != hipSuccess) return MP_ELAUNCH; \
+    } while (0)
+
+static inline hipStream_t mp_stream(mp_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+namespace mp {
+
+// DPP controls (CDNA ISA): quad_perm packs four 2-bit selectors; row_* act inside 16-lane rows.
+constexpr int DPP_QUAD_XOR1 = 0xB1;       // quad_perm [1,0,3,2]
+constexpr int DPP_QUAD_XOR2 = 0x4E;       // quad_perm [2,3,0,1]
+constexpr int DPP_ROW_HALF_MIRROR = 0x141;
+constexpr int DPP_ROW_MIRROR = 0x140;
+
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_u32(unsigned v)
+{
+    return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xF, 0xF, false);
+}
+
+// max over each 16-lane row, result in every lane of the row (4 DPP steps, no LDS).
+__device__ __forceinline__ unsigned row16_max_u32(unsigned v)
+{
+    unsigned t;
+    t = dpp_u32<DPP_QUAD_XOR1>(v); v = v > t ? v : t;
+    t = dpp_u32<DPP_QUAD_XOR2>(v); v = v > t ? v : t;
+    t = dpp_u32<DPP_ROW_HALF_MIRROR>(v); v = v > t ? v : t;
+    t = dpp_u32<DPP_ROW_MIRROR>(v); v = v > t ? v : t;
+    return v;
+}
+
+__device__ __forceinline__ unsigned row16_min_u32(unsigned v)
+{
+    unsigned t;
+    t = dpp_u32<DPP_QUAD_XOR1>(v); v = v < t ? v : t;
+    t = dpp_u32<DPP_QUAD_XOR2>(v); v = v < t ? v : t;
+    t = dpp_u32<DPP_ROW_HALF_MIRROR>(v); v = v < t ? v : t;
+    t = dpp_u32<DPP_ROW_MIRROR>(v); v = v < t ? v : t;
+    return v;
+}
+
+// wave-wide max of a u32 key as a wave-uniform (scalar) value.
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v)
+{
+    v = row16_max_u32(v);
+    unsigned a = (unsigned)__builtin_amdgcn_readlane((int)v, 0);
+    unsigned b = (unsigned)__builtin_amdgcn_readlane((int)v, 16);
+    unsigned c = (unsigned)__builtin_amdgcn_readlane((int)v, 32);
+    unsigned d = (unsigned)__builtin_amdgcn_readlane((int)v, 48);
+    a = a > b ? a : b;
+    c = c > d ? c : d;
+    return a > c ? a : c;
+}
+
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v)
+{
+    v = row16_min_u32(v);
+    unsigned a = (unsigned)__builtin_amdgcn_readlane((int)v, 0);
+    unsigned b = (unsigned)__builtin_amdgcn_readlane((int)v, 16);
+    unsigned c = (unsigned)__builtin_amdgcn_readlane((int)v, 32);
+    unsigned d = (unsigned)__builtin_amdgcn_readlane((int)v, 48);
+    a = a < b ? a : b;
+    c = c < d ? c : d;
+    return a < c ? a : c;
+}
+
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+
+// number of set bits of `mask` strictly below this lane
+__device__ __forceinline__ int prefix_popc(unsigned long long mask)
+{
+    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+}
+
+__device__ __forceinline__ float wave_sum_f32(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+}  // namespace mp

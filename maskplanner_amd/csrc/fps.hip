@@ -1,0 +1,165 @@
+// Farthest point sampling for gfx950.
+//
+// Reference: models/pointnet2_utils.py:65-86 (farthest_point_sample).  S dependent steps, each a
+// "distance to the newest centroid, running min, arg-max" over the N points of one cloud.  This is a
+// LATENCY-bound loop: the only lever is the length of one step.
+//
+// Design: one workgroup per cloud, the whole cloud resident on chip.
+//   - coordinates and running min-distances live in VGPRs: thread t owns the PPT CONTIGUOUS points
+//     [t*PPT, (t+1)*PPT), so "lowest lane among the maxima" == "lowest point index" and the arg-max needs
+//     only a value reduction + ballot (no (value,index) pairs through the cross-lane network);
+//   - distances are >= +0, so their bit patterns order like u32: reductions run on integer max;
+//   - in-wave reduction = 4 DPP row steps + 4 v_readlane + 3 s_max (no LDS); across waves one 8-byte
+//     LDS slot per wave, double buffered => ONE s_barrier per step;
+//   - the winner's coordinates come from an LDS copy of the cloud (SoA, broadcast read);
+//   - the S selected indices are buffered in LDS and written once at the end (a per-step global store
+//     would put a vmcnt(0) drain in front of every barrier).
+// Arithmetic is the reference's: d = (dx*dx + dy*dy) + dz*dz, separately rounded (no FMA: this file is
+// compiled with -ffp-contract=off), update `if (d < dist) dist = d`, first maximum wins.
+#include "common.h"
+
+namespace {
+
+template <int T, int PPT>
+__global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, int N, int S,
+                                                const int64_t* __restrict__ start_idx,
+                                                int64_t* __restrict__ out_idx, float* __restrict__ out_xyz)
+{
+    constexpr int NW = T / MP_WAVE;
+    constexpr int NPAD = T * PPT;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float* sx = reinterpret_cast<float*>(smem_raw);
+    float* sy = sx + NPAD;
+    float* sz = sy + NPAD;
+    uint2* slots = reinterpret_cast<uint2*>(sz + NPAD);  // [2][NW]
+    int* sel = reinterpret_cast<int*>(slots + 2 * NW);   // [S]
+
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const float* p = xyz + (size_t)b * N * 3;
+
+    // stage the cloud: coalesced AoS read, SoA LDS image
+    for (int i = tid; i < 3 * N; i += T) {
+        const float v = p[i];
+        const int pt = i / 3;
+        const int c = i - 3 * pt;
+        (c == 0 ? sx : (c == 1 ? sy : sz))[pt] = v;
+    }
+    for (int i = N + tid; i < NPAD; i += T) { sx[i] = 0.f; sy[i] = 0.f; sz[i] = 0.f; }
+    __syncthreads();
+
+    float px[PPT], py[PPT], pz[PPT], dist[PPT];
+    const int base = tid * PPT;
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+        px[j] = sx[base + j];
+        py[j] = sy[base + j];
+        pz[j] = sz[base + j];
+        // padded slots hold 0 forever: min(0, d>=0) == 0 and a real point of lower index wins every tie
+        dist[j] = (base + j < N) ? 1e10f : 0.0f;
+    }
+
+    int far = (int)start_idx[b];
+    far = far < 0 ? 0 : (far >= N ? N - 1 : far);  // the reference indexes with it unchecked; stay in bounds
+    for (int s = 0; s < S; ++s) {
+        if (tid == 0) sel[s] = far;
+        if (s == S - 1) break;
+        const float cx = sx[far], cy = sy[far], cz = sz[far];
+        float best = -1.0f;
+        int bj = 0;
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) {
+            const float dx = px[j] - cx;
+            const float dy = py[j] - cy;
+            const float dz = pz[j] - cz;
+            const float d = (dx * dx + dy * dy) + dz * dz;
+            float cur = dist[j];
+            if (d < cur) cur = d;
+            dist[j] = cur;
+            if (cur > best) { best = cur; bj = j; }
+        }
+        const unsigned key = __float_as_uint(best);
+        const unsigned wmax = mp::wave_max_u32(key);
+        const unsigned long long m = __ballot(key == wmax);
+        const int src = (int)__builtin_ctzll(m);
+        const int widx = __builtin_amdgcn_readlane(base + bj, src);
+        if constexpr (NW == 1) {
+            far = widx;
+        } else {
+            uint2* slot = slots + (s & 1) * NW;
+            if (lane == 0) slot[wave] = make_uint2(wmax, (unsigned)widx);
+            __syncthreads();
+            uint2 e = make_uint2(0u, 0u);
+            if (lane < NW) e = slot[lane];
+            unsigned r = mp::row16_max_u32(e.x);  // NW <= 16: all slots sit in row 0
+            const unsigned bmax = (unsigned)__builtin_amdgcn_readlane((int)r, 0);
+            const unsigned long long m2 = __ballot(lane < NW && e.x == bmax);
+            const int w = (int)__builtin_ctzll(m2);  // lowest wave == lowest index range
+            far = __builtin_amdgcn_readlane((int)e.y, w);
+        }
+    }
+    __syncthreads();
+    for (int s = tid; s < S; s += T) {
+        const int i = sel[s];
+        out_idx[(size_t)b * S + s] = (int64_t)i;
+        if (out_xyz) {
+            float* o = out_xyz + ((size_t)b * S + s) * 3;
+            o[0] = sx[i];
+            o[1] = sy[i];
+            o[2] = sz[i];
+        }
+    }
+}
+
+template <int T, int PPT>
+int launch_fps(const float* xyz, int B, int N, int S, const int64_t* start, int64_t* out_idx, float* out_xyz,
+               hipStream_t stream)
+{
+    constexpr int NW = T / MP_WAVE;
+    const size_t smem = (size_t)3 * T * PPT * sizeof(float) + 2 * NW * sizeof(uint2) + (size_t)S * sizeof(int);
+    if (smem > 160 * 1024) return MP_EUNSUPPORTED;
+    auto kern = fps_kernel<T, PPT>;
+    if (smem > 64 * 1024) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)smem) != hipSuccess)
+            return MP_ELAUNCH;
+    }
+    hipLaunchKernelGGL(kern, dim3(B), dim3(T), smem, stream, xyz, N, S, start, out_idx, out_xyz);
+    MP_CHECK_LAUNCH();
+    return MP_OK;
+}
+
+}  // namespace
+
+extern "C" int mp_fps_f32(const float* xyz, int64_t B, int64_t N, int64_t S, const int64_t* start_idx,
+                          int64_t* out_idx, float* out_xyz, mp_stream_t stream_)
+{
+    if (B < 0 || N <= 0 || S < 0) return MP_EINVAL;
+    if (B == 0 || S == 0) return MP_OK;
+    if (!xyz || !start_idx || !out_idx) return MP_EINVAL;
+    if (N > 13312 || S > 8192) return MP_EUNSUPPORTED;
+    hipStream_t stream = mp_stream(stream_);
+    const int b = (int)B, n = (int)N, s = (int)S;
+#define MP_FPS_CASE(T, P) \
+    if (n <= (T) * (P)) return launch_fps<T, P>(xyz, b, n, s, start_idx, out_idx, out_xyz, stream)
+    // one wave: no barrier at all
+    MP_FPS_CASE(64, 1);
+    MP_FPS_CASE(64, 2);
+    MP_FPS_CASE(64, 4);
+    MP_FPS_CASE(64, 8);
+    MP_FPS_CASE(256, 3);
+    MP_FPS_CASE(256, 4);
+    MP_FPS_CASE(256, 6);
+    MP_FPS_CASE(256, 8);
+    MP_FPS_CASE(1024, 3);
+    MP_FPS_CASE(1024, 4);
+    MP_FPS_CASE(1024, 5);
+    MP_FPS_CASE(1024, 6);
+    MP_FPS_CASE(1024, 8);
+    MP_FPS_CASE(1024, 10);
+    MP_FPS_CASE(1024, 13);
+#undef MP_FPS_CASE
+    return MP_EUNSUPPORTED;
+}

@@ -1,0 +1,240 @@
+"""torch-facing wrappers of the C ABI (include/maskplanner_hip.h).
+
+Every function takes HIP tensors, enqueues one or two kernels on torch's CURRENT stream and returns tensors that
+live on the same device; nothing here synchronises with the host.  PyTorch supplies memory, streams and autograd
+bookkeeping only -- all arithmetic on the hot path happens inside libmaskplanner_hip.so.  There is no CPU path:
+a non-HIP tensor raises.
+"""
+import torch
+
+from . import _lib
+
+# Scatter-add backwards use float atomics by default; set True for the fixed-order (bitwise reproducible) kernels.
+DETERMINISTIC = False
+
+
+def _need_hip(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("maskplanner_amd ops run on the MI355X only (HIP tensors); there is no CPU fallback")
+
+
+def _f32(t):
+    return t.contiguous() if t.dtype == torch.float32 else t.contiguous().float()
+
+
+def _i64(t):
+    return t.contiguous() if t.dtype == torch.int64 else t.contiguous().long()
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# index-producing ops (no autograd)
+# ----------------------------------------------------------------------------------------------------------------
+@torch.no_grad()
+def fps(xyz, npoint, start_idx, return_xyz=False):
+    """farthest_point_sample with an explicit start (models/pointnet2_utils.py:65-86).  xyz [B,N,3]."""
+    _need_hip(xyz, start_idx)
+    xyz = _f32(xyz)
+    if xyz.ndim != 3 or xyz.shape[2] != 3:
+        raise ValueError("xyz must be [B,N,3]")
+    B, N, _ = xyz.shape
+    start_idx = _i64(start_idx)
+    idx = torch.empty((B, npoint), dtype=torch.int64, device=xyz.device)
+    new_xyz = torch.empty((B, npoint, 3), dtype=torch.float32, device=xyz.device) if return_xyz else None
+    with torch.cuda.device(xyz.device):
+        rc = _lib.load().mp_fps_f32(_p(xyz), B, N, npoint, _p(start_idx), _p(idx), _p(new_xyz), _stream(xyz))
+    _lib.check(rc, "fps")
+    return (idx, new_xyz) if return_xyz else idx
+
+
+@torch.no_grad()
+def ball_query(radius, nsample, xyz, new_xyz):
+    """query_ball_point (models/pointnet2_utils.py:89-109).  xyz [B,N,3], new_xyz [B,S,3] -> i64 [B,S,nsample]."""
+    _need_hip(xyz, new_xyz)
+    xyz, new_xyz = _f32(xyz), _f32(new_xyz)
+    B, N, _ = xyz.shape
+    S = new_xyz.shape[1]
+    idx = torch.empty((B, S, nsample), dtype=torch.int64, device=xyz.device)
+    with torch.cuda.device(xyz.device):
+        rc = _lib.load().mp_ball_query_f32(_p(xyz), _p(new_xyz), B, N, S, float(radius), nsample, _p(idx), _stream(xyz))
+    _lib.check(rc, "ball_query")
+    return idx
+
+
+@torch.no_grad()
+def square_distance(src, dst):
+    """square_distance (models/pointnet2_utils.py:21-42), expanded form.  src [B,S,3], dst [B,N,3] -> [B,S,N]."""
+    _need_hip(src, dst)
+    src, dst = _f32(src), _f32(dst)
+    if src.shape[-1] != 3 or dst.shape[-1] != 3:
+        raise ValueError("square_distance kernel is specialised for 3-D points")
+    B, S, _ = src.shape
+    N = dst.shape[1]
+    out = torch.empty((B, S, N), dtype=torch.float32, device=src.device)
+    with torch.cuda.device(src.device):
+        rc = _lib.load().mp_square_distance_f32(_p(src), _p(dst), B, S, N, _p(out), _stream(src))
+    _lib.check(rc, "square_distance")
+    return out
+
+
+@torch.no_grad()
+def padded_lengths(y):
+    """pytorch3d_chamfer.py:138-149: first column with y[b,c,0] == -100, else P2.  -> i64 [B] on device."""
+    _need_hip(y)
+    y = _f32(y)
+    B, P2, D = y.shape
+    out = torch.empty((B,), dtype=torch.int64, device=y.device)
+    with torch.cuda.device(y.device):
+        rc = _lib.load().mp_padded_lengths_f32(_p(y), B, P2, D, _p(out), _stream(y))
+    _lib.check(rc, "padded_lengths")
+    return out
+
+
+@torch.no_grad()
+def mask_match(pred_masks, target_ids, return_cost=False):
+    """loss_handler.py:838-875 on device.  pred_masks [B,M,S] logits, target_ids [B,S] f32.
+    Returns match_col i64 [B,M] (-1 = unmatched), uniq_ids f32 [B,64], n_targets i64 [B], status i32 [B]
+    (and the fp32 cost [B,M,64] when asked)."""
+    _need_hip(pred_masks, target_ids)
+    pred_masks, target_ids = _f32(pred_masks), _f32(target_ids)
+    B, M, S = pred_masks.shape
+    dev = pred_masks.device
+    match = torch.empty((B, M), dtype=torch.int64, device=dev)
+    uniq = torch.empty((B, _lib.MASK_CAP), dtype=torch.float32, device=dev)
+    nt = torch.empty((B,), dtype=torch.int64, device=dev)
+    status = torch.empty((B,), dtype=torch.int32, device=dev)
+    cost = torch.empty((B, M, _lib.MASK_CAP), dtype=torch.float32, device=dev) if return_cost else None
+    with torch.cuda.device(dev):
+        rc = _lib.load().mp_mask_match_f32(_p(pred_masks), _p(target_ids), B, M, S, _p(match), _p(uniq), _p(nt), _p(cost),
+                                           _p(status), _stream(pred_masks))
+    _lib.check(rc, "mask_match")
+    return (match, uniq, nt, status, cost) if return_cost else (match, uniq, nt, status)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# differentiable ops
+# ----------------------------------------------------------------------------------------------------------------
+class _IndexPoints(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, points, idx):
+        B, N, C = points.shape
+        M = idx.numel() // B if B > 0 else 0
+        out = torch.empty(tuple(idx.shape) + (C,), dtype=torch.float32, device=points.device)
+        with torch.cuda.device(points.device):
+            rc = _lib.load().mp_index_points_f32(_p(points), _p(idx), B, N, C, M, _p(out), _stream(points))
+        _lib.check(rc, "index_points")
+        ctx.save_for_backward(idx)
+        ctx.dims = (B, N, C, M)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (idx,) = ctx.saved_tensors
+        B, N, C, M = ctx.dims
+        grad_out = _f32(grad_out)
+        grad = torch.empty((B, N, C), dtype=torch.float32, device=grad_out.device)
+        with torch.cuda.device(grad_out.device):
+            rc = _lib.load().mp_index_points_bwd_f32(_p(grad_out), _p(idx), B, N, C, M, _p(grad), int(DETERMINISTIC),
+                                                     _stream(grad_out))
+        _lib.check(rc, "index_points_bwd")
+        return grad, None
+
+
+def index_points(points, idx):
+    """index_points (models/pointnet2_utils.py:45-62): points [B,N,C], idx [B,...] -> [B,...,C]; grad w.r.t. points."""
+    _need_hip(points, idx)
+    if points.ndim != 3:
+        raise ValueError("points must be [B,N,C]")
+    return _IndexPoints.apply(_f32(points), _i64(idx))
+
+
+class _Group(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xyz, feats, new_xyz, idx, xyz_last):
+        B, N, _ = xyz.shape
+        _, S, K = idx.shape
+        D = 0 if feats is None else feats.shape[2]
+        out = torch.empty((B, S, K, D + 3), dtype=torch.float32, device=xyz.device)
+        with torch.cuda.device(xyz.device):
+            rc = _lib.load().mp_group_f32(_p(xyz), _p(feats), _p(new_xyz), _p(idx), B, N, S, K, D, int(xyz_last), _p(out),
+                                          _stream(xyz))
+        _lib.check(rc, "group")
+        ctx.save_for_backward(idx)
+        ctx.dims = (B, N, S, K, D, int(xyz_last))
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (idx,) = ctx.saved_tensors
+        B, N, S, K, D, xyz_last = ctx.dims
+        if D == 0 or not ctx.needs_input_grad[1]:
+            return None, None, None, None, None
+        grad_out = _f32(grad_out)
+        grad = torch.empty((B, N, D), dtype=torch.float32, device=grad_out.device)
+        with torch.cuda.device(grad_out.device):
+            rc = _lib.load().mp_group_bwd_f32(_p(grad_out), _p(idx), B, N, S, K, D, xyz_last, _p(grad), int(DETERMINISTIC),
+                                              _stream(grad_out))
+        _lib.check(rc, "group_bwd")
+        return None, grad, None, None, None
+
+
+def group(xyz, feats, new_xyz, idx, xyz_last=False):
+    """sample_and_group tail (models/pointnet2_utils.py:133-143; MSG order :258-262 when xyz_last):
+    [B,S,K,3+D] = cat(xyz[idx] - new_xyz, feats[idx]).  Differentiable w.r.t. feats (the coordinates are network
+    inputs / FPS selections and carry no gradient on this path)."""
+    _need_hip(xyz, feats, new_xyz, idx)
+    if xyz.requires_grad or new_xyz.requires_grad:
+        raise NotImplementedError("group(): gradients w.r.t. coordinates are not part of the hot path; "
+                                  "compose index_points() for that")
+    return _Group.apply(_f32(xyz), None if feats is None else _f32(feats), _f32(new_xyz), _i64(idx), bool(xyz_last))
+
+
+class _Knn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, p1, p2, len1, len2, K):
+        B, P1, D = p1.shape
+        P2 = p2.shape[1]
+        dists = torch.empty((B, P1, K), dtype=torch.float32, device=p1.device)
+        idx = torch.empty((B, P1, K), dtype=torch.int64, device=p1.device)
+        with torch.cuda.device(p1.device):
+            rc = _lib.load().mp_knn_f32(_p(p1), _p(p2), _p(len1), _p(len2), B, P1, P2, D, K, _p(dists), _p(idx), None, 0,
+                                        _stream(p1))
+        _lib.check(rc, "knn")
+        ctx.save_for_backward(p1, p2, len1, len2, idx)
+        ctx.mark_non_differentiable(idx)
+        ctx.K = K
+        return dists, idx
+
+    @staticmethod
+    def backward(ctx, grad_dists, _grad_idx):
+        p1, p2, len1, len2, idx = ctx.saved_tensors
+        B, P1, D = p1.shape
+        P2 = p2.shape[1]
+        need1, need2 = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        g1 = torch.empty_like(p1) if need1 else None
+        g2 = torch.empty_like(p2) if need2 else None
+        if need1 or need2:
+            grad_dists = _f32(grad_dists)
+            with torch.cuda.device(p1.device):
+                rc = _lib.load().mp_knn_bwd_f32(_p(p1), _p(p2), _p(len1), _p(len2), _p(idx), _p(grad_dists), B, P1, P2, D,
+                                                ctx.K, _p(g1), _p(g2), int(DETERMINISTIC), _stream(p1))
+            _lib.check(rc, "knn_bwd")
+        return g1, g2, None, None, None
+
+
+def knn(p1, p2, lengths1=None, lengths2=None, K=1):
+    """pytorch3d.ops.knn.knn_points contract: (dists [B,P1,K] squared L2 ascending, idx [B,P1,K] i64)."""
+    _need_hip(p1, p2, lengths1, lengths2)
+    if p1.ndim != 3 or p2.ndim != 3 or p1.shape[0] != p2.shape[0] or p1.shape[2] != p2.shape[2]:
+        raise ValueError("pts1 and pts2 must be [B,P,D] with equal batch and feature dimensions")
+    l1 = None if lengths1 is None else _i64(lengths1)
+    l2 = None if lengths2 is None else _i64(lengths2)
+    return _Knn.apply(_f32(p1), _f32(p2), l1, l2, int(K))

@@ -1,0 +1,265 @@
+"""HIP kernels (through the C ABI) against the CPU oracle and the reference-generated golden vectors.
+
+Bar: bit-exact for every index output (FPS, ball query, kNN indices, LAP assignment, padded lengths);
+fp32 values within 1e-5 (north_star tolerance) -- kNN distances are compared bit-for-bit because the kernel
+and the oracle share one rounding sequence.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from maskplanner_amd import ops as O
+    return O
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _cases(g, suffix):
+    return sorted({k[: -len(suffix)] for k in g.files if k.endswith(suffix)})
+
+
+# ------------------------------------------------------------------------------------------------ FPS
+def test_fps_golden_bit_exact(golden, ops):
+    g = golden("g1_fps")
+    for k in _cases(g, "_idx"):
+        want = g[k + "_idx"]
+        got, new_xyz = ops.fps(dev(g[k + "_xyz"]), want.shape[1], dev(g[k + "_start"]), return_xyz=True)
+        assert got.dtype == torch.int64
+        assert np.array_equal(got.cpu().numpy(), want), k
+        xyz = g[k + "_xyz"]
+        sel = np.take_along_axis(xyz, want[:, :, None].repeat(3, 2), axis=1)
+        assert np.array_equal(new_xyz.cpu().numpy(), sel), k
+
+
+@pytest.mark.parametrize("B,N,S,dist", [(32, 5120, 512, "cuboid"), (32, 5120, 512, "ucube"), (32, 512, 128, "cuboid"),
+                                        (3, 10240, 512, "cuboid"), (2, 777, 100, "ucube"), (5, 64, 64, "ucube"),
+                                        (2, 1, 1, "ucube"), (2, 2000, 300, "cuboid"), (1, 13312, 64, "ucube")])
+def test_fps_vs_oracle(oracle, ops, B, N, S, dist):
+    from maskplanner_amd import synthetic as syn
+    rng = np.random.default_rng(N * 7 + S)
+    xyz = syn.point_cloud(rng, B, N, dist)
+    start = rng.integers(0, N, size=B)
+    want = oracle.fps(xyz, S, start)
+    got = ops.fps(dev(xyz), S, dev(start))
+    assert np.array_equal(got.cpu().numpy(), want)
+
+
+def test_fps_all_coincident(oracle, ops):
+    xyz = np.zeros((2, 300, 3), np.float32) + 0.25
+    start = np.array([7, 299])
+    assert np.array_equal(ops.fps(dev(xyz), 40, dev(start)).cpu().numpy(), oracle.fps(xyz, 40, start))
+
+
+# ------------------------------------------------------------------------------------------------ ball query
+def test_ball_query_golden_bit_exact(golden, ops):
+    g = golden("g2_bq")
+    for k in _cases(g, "_idx"):
+        got = ops.ball_query(float(g[k + "_radius"]), int(g[k + "_K"]), dev(g[k + "_xyz"]), dev(g[k + "_new_xyz"]))
+        assert np.array_equal(got.cpu().numpy(), g[k + "_idx"].astype(np.int64)), k
+
+
+def test_square_distance_golden_bit_exact(golden, ops):
+    g = golden("g2_sqd")
+    for t in "ab":
+        got = ops.square_distance(dev(g[t + "_src"]), dev(g[t + "_dst"])).cpu().numpy()
+        assert np.array_equal(got.view(np.int32), g[t + "_out"].view(np.int32))
+
+
+@pytest.mark.parametrize("B,N,S,r,K,dist", [(32, 5120, 512, 0.2, 32, "cuboid"), (32, 5120, 512, 0.2, 32, "ucube"),
+                                            (32, 512, 128, 0.4, 64, "cuboid"), (4, 10240, 512, 0.1, 16, "cuboid"),
+                                            (4, 10240, 512, 0.4, 128, "cuboid"), (3, 777, 100, 0.35, 48, "ucube"),
+                                            (2, 300, 7, 5.0, 400, "ucube"), (2, 100, 9, 1e-4, 8, "ucube")])
+def test_ball_query_vs_oracle(oracle, ops, B, N, S, r, K, dist):
+    from maskplanner_amd import synthetic as syn
+    rng = np.random.default_rng(N + S + K)
+    xyz = syn.point_cloud(rng, B, N, dist)
+    fidx = oracle.fps(xyz, S, rng.integers(0, N, size=B))
+    new_xyz = oracle.index_points(xyz, fidx)
+    want = oracle.ball_query(r, K, xyz, new_xyz)
+    got = ops.ball_query(r, K, dev(xyz), dev(new_xyz))
+    assert np.array_equal(got.cpu().numpy(), want)
+
+
+def test_ball_query_no_hit_returns_N(oracle, ops):
+    xyz = np.random.default_rng(0).uniform(-1, 1, size=(1, 200, 3)).astype(np.float32)
+    q = np.full((1, 3, 3), 50.0, np.float32)
+    got = ops.ball_query(0.2, 8, dev(xyz), dev(q)).cpu().numpy()
+    assert np.array_equal(got, oracle.ball_query(0.2, 8, xyz, q)) and (got == 200).all()
+
+
+# ------------------------------------------------------------------------------------------------ gather / group
+@pytest.mark.parametrize("det", [False, True])
+def test_index_points_and_backward(oracle, ops, det):
+    rng = np.random.default_rng(5)
+    pts = rng.normal(size=(3, 50, 7)).astype(np.float32)
+    idx = rng.integers(0, 50, size=(3, 11, 6))
+    p = dev(pts).requires_grad_(True)
+    out = ops.index_points(p, dev(idx))
+    assert np.array_equal(out.detach().cpu().numpy(), oracle.index_points(pts, idx))
+    g = rng.normal(size=out.shape).astype(np.float32)
+    ops.DETERMINISTIC = det
+    try:
+        out.backward(dev(g))
+    finally:
+        ops.DETERMINISTIC = False
+    want = oracle.index_points_bwd(g.reshape(3, -1, 7), idx.reshape(3, -1), 50)
+    got = p.grad.cpu().numpy()
+    if det:
+        assert np.array_equal(got, want)  # same summation order as the serial oracle
+    else:
+        np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("D,xyz_last", [(0, False), (13, False), (128, False), (13, True)])
+def test_group_and_backward(oracle, ops, D, xyz_last):
+    rng = np.random.default_rng(6 + D)
+    B, N, S, K = 2, 200, 16, 8
+    xyz = rng.normal(size=(B, N, 3)).astype(np.float32)
+    feats = rng.normal(size=(B, N, D)).astype(np.float32) if D else None
+    new_xyz = xyz[:, :S].copy()
+    idx = rng.integers(0, N, size=(B, S, K))
+    want = oracle.group(xyz, feats, new_xyz, idx)
+    if xyz_last:
+        want = np.concatenate([want[..., 3:], want[..., :3]], -1)
+    f = dev(feats).requires_grad_(True) if D else None
+    out = ops.group(dev(xyz), f, dev(new_xyz), dev(idx), xyz_last=xyz_last)
+    assert np.array_equal(out.detach().cpu().numpy(), want)
+    if D:
+        g = rng.normal(size=out.shape).astype(np.float32)
+        gf = g[..., :D] if xyz_last else g[..., 3:]
+        want_g = oracle.index_points_bwd(np.ascontiguousarray(gf).reshape(B, -1, D), idx.reshape(B, -1), N)
+        for det in (False, True):
+            ops.DETERMINISTIC = det
+            try:
+                f.grad = None
+                ops.group(dev(xyz), f, dev(new_xyz), dev(idx), xyz_last=xyz_last).backward(dev(g))
+            finally:
+                ops.DETERMINISTIC = False
+            if det:
+                assert np.array_equal(f.grad.cpu().numpy(), want_g)
+            else:
+                np.testing.assert_allclose(f.grad.cpu().numpy(), want_g, rtol=1e-5, atol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------------ kNN
+@pytest.mark.parametrize("B,P1,P2,D,K", [(3, 999, 985, 24, 1), (2, 3996, 2959, 6, 1), (2, 2959, 3996, 6, 1),
+                                         (2, 700, 650, 3, 1), (2, 130, 70, 24, 2), (2, 64, 300, 5, 1), (1, 10, 3, 7, 4),
+                                         (2, 257, 513, 12, 8), (2, 50, 1, 3, 1)])
+def test_knn_vs_oracle(oracle, ops, B, P1, P2, D, K):
+    rng = np.random.default_rng(P1 + P2 + D)
+    p1 = rng.uniform(-1, 1, size=(B, P1, D)).astype(np.float32)
+    p2 = rng.uniform(-1, 1, size=(B, P2, D)).astype(np.float32)
+    l1 = rng.integers(max(1, P1 // 2), P1 + 1, size=B)
+    l2 = rng.integers(max(1, P2 // 2), P2 + 1, size=B)
+    l1[0], l2[0] = P1, P2
+    wd, wi = oracle.knn_points(p1, p2, l1, l2, K)
+    gd, gi = ops.knn(dev(p1), dev(p2), dev(l1), dev(l2), K)
+    assert np.array_equal(gi.cpu().numpy(), wi)
+    assert np.array_equal(gd.cpu().numpy().view(np.int32), wd.view(np.int32))
+    # no lengths = full
+    wd, wi = oracle.knn_points(p1, p2, None, None, K)
+    gd, gi = ops.knn(dev(p1), dev(p2), None, None, K)
+    assert np.array_equal(gi.cpu().numpy(), wi) and np.array_equal(gd.cpu().numpy(), wd)
+
+
+def test_knn_ties_first_index(oracle, ops):
+    lat = np.stack(np.meshgrid(np.arange(6), np.arange(6), np.arange(6), indexing="ij"), -1).reshape(1, -1, 3).astype(np.float32)
+    q = lat[:, ::5] + 0.5  # equidistant from 8 lattice points
+    wd, wi = oracle.knn_points(q, lat, None, None, 2)
+    gd, gi = ops.knn(dev(q), dev(lat), None, None, 2)
+    assert np.array_equal(gi.cpu().numpy(), wi) and np.array_equal(gd.cpu().numpy(), wd)
+
+
+@pytest.mark.parametrize("det", [False, True])
+@pytest.mark.parametrize("B,P1,P2,D,K", [(2, 300, 200, 24, 1), (2, 500, 900, 6, 1), (2, 40, 30, 3, 2)])
+def test_knn_backward(oracle, ops, det, B, P1, P2, D, K):
+    rng = np.random.default_rng(17 + D)
+    p1 = rng.uniform(-1, 1, size=(B, P1, D)).astype(np.float32)
+    p2 = rng.uniform(-1, 1, size=(B, P2, D)).astype(np.float32)
+    l1 = np.array([P1, P1 - 7])
+    l2 = np.array([P2 - 3, P2])
+    g = rng.normal(size=(B, P1, K)).astype(np.float32)
+    _, wi = oracle.knn_points(p1, p2, l1, l2, K)
+    w1, w2 = oracle.knn_points_bwd(p1, p2, l1, l2, wi, g)
+    a, b = dev(p1).requires_grad_(True), dev(p2).requires_grad_(True)
+    ops.DETERMINISTIC = det
+    try:
+        d, _ = ops.knn(a, b, dev(l1), dev(l2), K)
+        d.backward(dev(g))
+    finally:
+        ops.DETERMINISTIC = False
+    np.testing.assert_allclose(a.grad.cpu().numpy(), w1, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(b.grad.cpu().numpy(), w2, rtol=1e-5, atol=2e-6)
+
+
+def test_padded_lengths(oracle, ops):
+    rng = np.random.default_rng(3)
+    y = rng.normal(size=(5, 40, 6)).astype(np.float32)
+    y[0, 17:] = -100.0
+    y[1, 0:] = -100.0
+    y[3, 39:] = -100.0
+    y[4, 5, 0] = -100.0  # only the leading coordinate is tested by the reference
+    assert np.array_equal(ops.padded_lengths(dev(y)).cpu().numpy(), oracle.padded_lengths(y))
+    y2 = rng.normal(size=(2, 9, 3)).astype(np.float32)
+    assert np.array_equal(ops.padded_lengths(dev(y2)).cpu().numpy(), [9, 9])
+
+
+# ------------------------------------------------------------------------------------------------ mask matching
+@pytest.mark.parametrize("B,M,S,n_ids", [(4, 6, 999, 6), (3, 22, 449, 15), (3, 41, 1266, 41), (2, 33, 1333, 20),
+                                         (2, 6, 99, 9), (2, 64, 500, 64), (2, 5, 64, 1)])
+def test_mask_match_vs_scipy(oracle, ops, B, M, S, n_ids):
+    from scipy.optimize import linear_sum_assignment
+    rng = np.random.default_rng(M * S)
+    pred = (rng.normal(size=(B, M, S)) * 2).astype(np.float32)
+    ids = rng.integers(0, n_ids, size=(B, S)).astype(np.float32) * 3.0 + 1.0  # non-contiguous id values
+    match, uniq, nt, status, cost = ops.mask_match(dev(pred), dev(ids), return_cost=True)
+    match, uniq, nt, status, cost = (t.cpu().numpy() for t in (match, uniq, nt, status, cost))
+    assert (status == 0).all()
+    for b in range(B):
+        masks, u = oracle.stroke_ids_to_masks(ids[b])
+        assert nt[b] == len(u) and np.array_equal(uniq[b, :len(u)], u)
+        want_cost = oracle.mask_bce_cost(pred[b], masks)
+        np.testing.assert_allclose(cost[b, :, :len(u)], want_cost, rtol=1e-6, atol=1e-4)
+        # the assignment must be scipy's on the kernel's own fp32 cost (bit-exact index work) ...
+        r, c = linear_sum_assignment(cost[b, :, :len(u)].astype(np.float64))
+        want = np.full(M, -1)
+        want[r] = c
+        assert np.array_equal(match[b], want), b
+        # ... and optimal for the oracle's cost as well
+        r2, c2 = linear_sum_assignment(want_cost.astype(np.float64))
+        tot = want_cost[r, c].sum()
+        assert abs(tot - want_cost[r2, c2].sum()) <= 1e-5 * abs(tot)
+
+
+def test_mask_match_ties_follow_scipy(ops):
+    """All-equal logits => a constant cost matrix: scipy's tie-breaking yields the identity."""
+    from scipy.optimize import linear_sum_assignment
+    B, M, S = 2, 7, 70
+    pred = torch.zeros(B, M, S).cuda()
+    ids = torch.arange(S).remainder(7).float()[None].repeat(B, 1).cuda()
+    match, _, nt, status, cost = ops.mask_match(pred, ids, return_cost=True)
+    c = cost[0, :, :7].cpu().numpy().astype(np.float64)
+    r, cc = linear_sum_assignment(c)
+    assert np.array_equal(match[0].cpu().numpy()[r], cc)
+    # integer-valued costs with many ties
+    rng = np.random.default_rng(9)
+    pred = torch.from_numpy(rng.integers(-1, 2, size=(3, 9, 40)).astype(np.float32)).cuda()
+    ids = torch.from_numpy(rng.integers(0, 5, size=(3, 40)).astype(np.float32)).cuda()
+    match, _, nt, status, cost = ops.mask_match(pred, ids, return_cost=True)
+    for b in range(3):
+        k = int(nt[b])
+        r, cc = linear_sum_assignment(cost[b, :, :k].cpu().numpy().astype(np.float64))
+        want = np.full(9, -1)
+        want[r] = cc
+        assert np.array_equal(match[b].cpu().numpy(), want)
