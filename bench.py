@@ -1,0 +1,160 @@
+#!/usr/bin/env python3
+"""Headline benchmark: point-clouds/s, forward + loss + backward + Adam step, MaskPlanner cuboids_v2
+(N=5120 points, B=32 per GPU, PointNet++ SSG encoder + asymm_chamfer_v9 loss) -- BASELINE.json configs[1].
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One process per GPU; the batch is sharded by sample (weak scaling: 32 clouds per GPU), gradients are averaged with
+a bucketed RCCL all-reduce overlapped with backward (maskplanner_amd/dp.py).  Inputs are synthetic (the reference's
+dataset is not public) and resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+
+Extra objects in the line:
+  roofline     -- the entry point with the largest device time among the library's kernels, timed with HIP events
+                  on the launch stream inside the timed region; algorithmic bytes / flops per launch from DESIGN.md.
+  cpu_baseline -- the CPU restatement of the same step (oracle/: C for FPS / ball query / kNN / LAP + torch fp32
+                  for the MLP algebra) timed on this box's host cores on a bounded sample (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s
+FP32_PEAK_TFLOPS = 157.3     # fp32 vector == fp32-input MFMA peak
+
+
+def op_models(cat, B, N):
+    """Algorithmic work per entry-point CALL at the bench shapes (DESIGN.md 'Kernels' table).
+    Entries: bound, flops, bytes.  Calls of one entry point with different shapes are averaged by call count."""
+    S, D = cat.out_vectors, 24
+    sgt = (cat.points_lo + cat.points_hi) / 2 / 3.0   # ~ GT segments per sample
+    pgt = (cat.points_lo + cat.points_hi) / 2
+    knn_calls = [  # (queries, refs, dim): loss_handler calls (1) both directions, (2) and (3) GT->pred only
+        (S, sgt, D), (sgt, S, D), (pgt, 4 * S, 6), (sgt, S, D)]
+    knn_flops = sum(3 * d * q * r for q, r, d in knn_calls) * B / len(knn_calls)
+    knn_bytes = sum((q + r) * d * 4 + q * 12 for q, r, d in knn_calls) * B / len(knn_calls)
+    fps_pairs = (N * 512 + 512 * 128) / 2
+    bq_pairs = (N * 512 + 512 * 128) / 2
+    return {
+        "fps": dict(bound="hbm", flops=8 * fps_pairs * B, bytes=B * ((N + 512) * 12 + (512 + 128) * 8) / 2),
+        "ball_query": dict(bound="mfma", flops=8 * bq_pairs * B, bytes=B * ((N + 512) * 12 + (512 * 32 + 128 * 64) * 8) / 2),
+        "knn": dict(bound="mfma", flops=knn_flops, bytes=knn_bytes),
+        "group": dict(bound="hbm", flops=0, bytes=B * (512 * 32 * 3 + 128 * 64 * 131) * 4 * 2 / 2),
+        "group_bwd": dict(bound="hbm", flops=0, bytes=B * (128 * 64 * 128) * 4 * 2),
+        "knn_bwd": dict(bound="hbm", flops=0, bytes=knn_bytes),
+    }
+
+
+def cpu_baseline(cat, N, seed):
+    """The oracle's restatement of ONE training step (forward + loss + backward) on the host cores."""
+    from maskplanner_amd import synthetic as syn
+    from maskplanner_amd.loss_handler import maskplanner_loss_config
+    from maskplanner_amd.pointnet2_cls_ssg import maskplanner_model
+    from oracle import oracle as O
+    from oracle import torch_ref as T
+    O.build()
+    Bc = 4
+    batch = syn.make_batch(seed, Bc, N, cat.name, "cuboid")
+    torch.manual_seed(seed)
+    sd = {k: v.detach().clone().requires_grad_(v.dtype.is_floating_point and "running" not in k)
+          for k, v in maskplanner_model(cat).state_dict().items()}
+    cfg = maskplanner_loss_config()
+    t0 = time.perf_counter()
+    out, sm, conf = T.strokemasks_forward(sd, batch["point_cloud"], [s.numpy() for s in batch["fps_start"]], train=True,
+                                          out_vectors=cat.out_vectors, n_masks=cat.max_n_strokes)
+    loss = T.asymm_v6_loss(out, batch["traj"], sm, conf, batch["stroke_ids"], batch["traj_as_pc"], cfg)
+    loss.backward()
+    dt = time.perf_counter() - t0
+    return {"value": Bc / dt, "unit": "point-clouds/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"1 step of forward+loss+backward on {Bc} clouds of N={N} (no optimizer step), {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=32, help="clouds per GPU")
+    ap.add_argument("--points", type=int, default=5120)
+    ap.add_argument("--category", default="cuboids")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from maskplanner_amd import dp
+    rank, local, world = dp.init_from_env()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the MaskPlanner hot path has no CPU fallback")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    from maskplanner_amd import _lib, ops, synthetic
+    from maskplanner_amd.harness import TrainStep
+    _lib.load()  # fail loudly if the HIP library is missing
+    cat = synthetic.CATEGORIES[args.category]
+    ts = TrainStep(cat, B=args.batch, N=args.points, device=dev, rank=rank)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        ts.step()
+    barrier()
+    t0 = time.perf_counter()
+    with ops.KernelTimer() as kt:
+        for _ in range(args.steps):
+            loss = ts.step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    final_loss = float(loss)
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        timing = kt.summary()
+        models = op_models(cat, args.batch, args.points)
+        per_step = {k: (n / args.steps, m) for k, (n, m) in timing.items()}
+        dom = max((k for k in timing if k in models), key=lambda k: timing[k][0] * timing[k][1])
+        m, (calls, mean_ms) = models[dom], timing[dom]
+        if m["bound"] == "hbm":
+            ach, peak, unit = m["bytes"] / (mean_ms * 1e-3) / 1e9, HBM_PEAK_GBS, "GB/s"
+        else:
+            ach, peak, unit = m["flops"] / (mean_ms * 1e-3) / 1e12, FP32_PEAK_TFLOPS, "TFLOP/s"
+        line = {
+            "metric": "point-clouds/sec fwd+bwd (N=5120, B=32)", "value": args.batch * world * args.steps / dt,
+            "unit": "point-clouds/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{cat.name}_v2 N={args.points} B={args.batch}/GPU SSG encoder + asymm_chamfer_v9 loss "
+                                   f"(forward+loss+backward+Adam), S={cat.out_vectors} M={cat.max_n_strokes}",
+                       "parallelism": f"dp{world}", "global_batch": args.batch * world, "grad_allreduce_MB":
+                           round(ts.reducer.grad_bytes() / 1e6, 1)},
+            "roofline": {"kernel": dom, "bound": m["bound"], "achieved": ach, "peak": peak, "unit": unit,
+                         "frac": ach / peak, "traffic": None, "avg_ms": mean_ms, "launches_per_step": calls / args.steps},
+            "kernel_ms_per_step": {k: round(n * m_, 4) for k, (n, m_) in sorted(per_step.items())},
+            "final_loss": final_loss,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(cat, args.points, 1235)
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

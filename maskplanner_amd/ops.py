@@ -35,6 +35,44 @@ def _stream(t):
     return torch.cuda.current_stream(t.device).cuda_stream
 
 
+class KernelTimer:
+    """Optional per-entry-point device timing with HIP events recorded on the launch stream (bench.py's roofline
+    leg).  `with KernelTimer() as kt: ...; kt.summary()` -> {op: (calls, mean_ms)}.  Events are only read in
+    summary(), after the caller has synchronised: recording them does not stall the host."""
+    active = None
+
+    def __init__(self):
+        self.events = {}
+
+    def __enter__(self):
+        KernelTimer.active = self
+        return self
+
+    def __exit__(self, *exc):
+        KernelTimer.active = None
+
+    def summary(self):
+        out = {}
+        for name, pairs in self.events.items():
+            ms = [a.elapsed_time(b) for a, b in pairs]
+            out[name] = (len(ms), sum(ms) / max(len(ms), 1))
+        return out
+
+
+def _run(op, ref, fn, *args):
+    """Enqueue one C-ABI call on torch's current stream of ref's device and map its return code."""
+    kt = KernelTimer.active
+    with torch.cuda.device(ref.device):
+        if kt is not None:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+        rc = fn(*args, _stream(ref))
+        if kt is not None:
+            b.record()
+            kt.events.setdefault(op, []).append((a, b))
+    _lib.check(rc, op)
+
+
 # ----------------------------------------------------------------------------------------------------------------
 # index-producing ops (no autograd)
 # ----------------------------------------------------------------------------------------------------------------
@@ -49,9 +87,7 @@ def fps(xyz, npoint, start_idx, return_xyz=False):
     start_idx = _i64(start_idx)
     idx = torch.empty((B, npoint), dtype=torch.int64, device=xyz.device)
     new_xyz = torch.empty((B, npoint, 3), dtype=torch.float32, device=xyz.device) if return_xyz else None
-    with torch.cuda.device(xyz.device):
-        rc = _lib.load().mp_fps_f32(_p(xyz), B, N, npoint, _p(start_idx), _p(idx), _p(new_xyz), _stream(xyz))
-    _lib.check(rc, "fps")
+    _run("fps", xyz, _lib.load().mp_fps_f32, _p(xyz), B, N, npoint, _p(start_idx), _p(idx), _p(new_xyz))
     return (idx, new_xyz) if return_xyz else idx
 
 
@@ -63,9 +99,7 @@ def ball_query(radius, nsample, xyz, new_xyz):
     B, N, _ = xyz.shape
     S = new_xyz.shape[1]
     idx = torch.empty((B, S, nsample), dtype=torch.int64, device=xyz.device)
-    with torch.cuda.device(xyz.device):
-        rc = _lib.load().mp_ball_query_f32(_p(xyz), _p(new_xyz), B, N, S, float(radius), nsample, _p(idx), _stream(xyz))
-    _lib.check(rc, "ball_query")
+    _run("ball_query", xyz, _lib.load().mp_ball_query_f32, _p(xyz), _p(new_xyz), B, N, S, float(radius), nsample, _p(idx))
     return idx
 
 
@@ -79,9 +113,7 @@ def square_distance(src, dst):
     B, S, _ = src.shape
     N = dst.shape[1]
     out = torch.empty((B, S, N), dtype=torch.float32, device=src.device)
-    with torch.cuda.device(src.device):
-        rc = _lib.load().mp_square_distance_f32(_p(src), _p(dst), B, S, N, _p(out), _stream(src))
-    _lib.check(rc, "square_distance")
+    _run("square_distance", src, _lib.load().mp_square_distance_f32, _p(src), _p(dst), B, S, N, _p(out))
     return out
 
 
@@ -92,9 +124,7 @@ def padded_lengths(y):
     y = _f32(y)
     B, P2, D = y.shape
     out = torch.empty((B,), dtype=torch.int64, device=y.device)
-    with torch.cuda.device(y.device):
-        rc = _lib.load().mp_padded_lengths_f32(_p(y), B, P2, D, _p(out), _stream(y))
-    _lib.check(rc, "padded_lengths")
+    _run("padded_lengths", y, _lib.load().mp_padded_lengths_f32, _p(y), B, P2, D, _p(out))
     return out
 
 
@@ -112,10 +142,8 @@ def mask_match(pred_masks, target_ids, return_cost=False):
     nt = torch.empty((B,), dtype=torch.int64, device=dev)
     status = torch.empty((B,), dtype=torch.int32, device=dev)
     cost = torch.empty((B, M, _lib.MASK_CAP), dtype=torch.float32, device=dev) if return_cost else None
-    with torch.cuda.device(dev):
-        rc = _lib.load().mp_mask_match_f32(_p(pred_masks), _p(target_ids), B, M, S, _p(match), _p(uniq), _p(nt), _p(cost),
-                                           _p(status), _stream(pred_masks))
-    _lib.check(rc, "mask_match")
+    _run("mask_match", pred_masks, _lib.load().mp_mask_match_f32, _p(pred_masks), _p(target_ids), B, M, S, _p(match),
+         _p(uniq), _p(nt), _p(cost), _p(status))
     return (match, uniq, nt, status, cost) if return_cost else (match, uniq, nt, status)
 
 
@@ -128,9 +156,7 @@ class _IndexPoints(torch.autograd.Function):
         B, N, C = points.shape
         M = idx.numel() // B if B > 0 else 0
         out = torch.empty(tuple(idx.shape) + (C,), dtype=torch.float32, device=points.device)
-        with torch.cuda.device(points.device):
-            rc = _lib.load().mp_index_points_f32(_p(points), _p(idx), B, N, C, M, _p(out), _stream(points))
-        _lib.check(rc, "index_points")
+        _run("index_points", points, _lib.load().mp_index_points_f32, _p(points), _p(idx), B, N, C, M, _p(out))
         ctx.save_for_backward(idx)
         ctx.dims = (B, N, C, M)
         return out
@@ -141,10 +167,7 @@ class _IndexPoints(torch.autograd.Function):
         B, N, C, M = ctx.dims
         grad_out = _f32(grad_out)
         grad = torch.empty((B, N, C), dtype=torch.float32, device=grad_out.device)
-        with torch.cuda.device(grad_out.device):
-            rc = _lib.load().mp_index_points_bwd_f32(_p(grad_out), _p(idx), B, N, C, M, _p(grad), int(DETERMINISTIC),
-                                                     _stream(grad_out))
-        _lib.check(rc, "index_points_bwd")
+        _run("index_points_bwd", grad_out, _lib.load().mp_index_points_bwd_f32, _p(grad_out), _p(idx), B, N, C, M, _p(grad), int(DETERMINISTIC))
         return grad, None
 
 
@@ -163,10 +186,7 @@ class _Group(torch.autograd.Function):
         _, S, K = idx.shape
         D = 0 if feats is None else feats.shape[2]
         out = torch.empty((B, S, K, D + 3), dtype=torch.float32, device=xyz.device)
-        with torch.cuda.device(xyz.device):
-            rc = _lib.load().mp_group_f32(_p(xyz), _p(feats), _p(new_xyz), _p(idx), B, N, S, K, D, int(xyz_last), _p(out),
-                                          _stream(xyz))
-        _lib.check(rc, "group")
+        _run("group", xyz, _lib.load().mp_group_f32, _p(xyz), _p(feats), _p(new_xyz), _p(idx), B, N, S, K, D, int(xyz_last), _p(out))
         ctx.save_for_backward(idx)
         ctx.dims = (B, N, S, K, D, int(xyz_last))
         return out
@@ -179,10 +199,7 @@ class _Group(torch.autograd.Function):
             return None, None, None, None, None
         grad_out = _f32(grad_out)
         grad = torch.empty((B, N, D), dtype=torch.float32, device=grad_out.device)
-        with torch.cuda.device(grad_out.device):
-            rc = _lib.load().mp_group_bwd_f32(_p(grad_out), _p(idx), B, N, S, K, D, xyz_last, _p(grad), int(DETERMINISTIC),
-                                              _stream(grad_out))
-        _lib.check(rc, "group_bwd")
+        _run("group_bwd", grad_out, _lib.load().mp_group_bwd_f32, _p(grad_out), _p(idx), B, N, S, K, D, xyz_last, _p(grad), int(DETERMINISTIC))
         return None, grad, None, None, None
 
 
@@ -204,10 +221,7 @@ class _Knn(torch.autograd.Function):
         P2 = p2.shape[1]
         dists = torch.empty((B, P1, K), dtype=torch.float32, device=p1.device)
         idx = torch.empty((B, P1, K), dtype=torch.int64, device=p1.device)
-        with torch.cuda.device(p1.device):
-            rc = _lib.load().mp_knn_f32(_p(p1), _p(p2), _p(len1), _p(len2), B, P1, P2, D, K, _p(dists), _p(idx), None, 0,
-                                        _stream(p1))
-        _lib.check(rc, "knn")
+        _run("knn", p1, _lib.load().mp_knn_f32, _p(p1), _p(p2), _p(len1), _p(len2), B, P1, P2, D, K, _p(dists), _p(idx), None, 0)
         ctx.save_for_backward(p1, p2, len1, len2, idx)
         ctx.mark_non_differentiable(idx)
         ctx.K = K
@@ -223,10 +237,7 @@ class _Knn(torch.autograd.Function):
         g2 = torch.empty_like(p2) if need2 else None
         if need1 or need2:
             grad_dists = _f32(grad_dists)
-            with torch.cuda.device(p1.device):
-                rc = _lib.load().mp_knn_bwd_f32(_p(p1), _p(p2), _p(len1), _p(len2), _p(idx), _p(grad_dists), B, P1, P2, D,
-                                                ctx.K, _p(g1), _p(g2), int(DETERMINISTIC), _stream(p1))
-            _lib.check(rc, "knn_bwd")
+            _run("knn_bwd", p1, _lib.load().mp_knn_bwd_f32, _p(p1), _p(p2), _p(len1), _p(len2), _p(idx), _p(grad_dists), B, P1, P2, D, ctx.K, _p(g1), _p(g2), int(DETERMINISTIC))
         return g1, g2, None, None, None
 
 

@@ -1,0 +1,155 @@
+"""MaskPlanner backbones on top of the MI355X set-abstraction stack.
+
+Mirrors `models/pointnet2_cls_ssg.py` of the reference: same class names, constructor arguments, forward
+signature/outputs and -- for checkpoint compatibility (test_maskplanner.py:162-188) -- identical `state_dict`
+keys and shapes: sa{1,2,3}.mlp_convs/mlp_bns.*, fc1/fc2/fc3, bn1/bn2, fc_normals, sm_fc1..3, sm_bn1/2,
+mask_conf_out, seg_conf_fc1/2, seg_conf_out.  The encoder (`sa1..sa3`) is the hot path and runs the HIP
+kernels; the regression heads are a handful of dense layers on a [B,1024] feature and stay on rocBLAS via torch
+(weight-bandwidth bound GEMMs, "next" in the scope table).
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .pointnet2_utils import PointNetSetAbstraction
+
+
+class _SSGEncoder(nn.Module):
+    """sa1 (512 centroids, r=.2, K=32) -> sa2 (128, r=.4, K=64) -> sa3 (group all) -> [B,1024]
+    (models/pointnet2_cls_ssg.py:37-39, 266-268)."""
+
+    def _build_encoder(self, normal_channel, inputdim):
+        in_channel = 6 if normal_channel else 3
+        if inputdim is not None:
+            in_channel = inputdim
+        self.normal_channel = normal_channel
+        self.sa1 = PointNetSetAbstraction(npoint=512, radius=0.2, nsample=32, in_channel=in_channel,
+                                          mlp=[64, 64, 128], group_all=False)
+        self.sa2 = PointNetSetAbstraction(npoint=128, radius=0.4, nsample=64, in_channel=128 + 3,
+                                          mlp=[128, 128, 256], group_all=False)
+        self.sa3 = PointNetSetAbstraction(npoint=None, radius=None, nsample=None, in_channel=256 + 3,
+                                          mlp=[256, 512, 1024], group_all=True)
+
+    def encode(self, xyz):
+        """xyz [B,3(+3),N] -> global feature [B,1024]."""
+        B = xyz.shape[0]
+        norm = None
+        if self.normal_channel:
+            norm = xyz[:, 3:, :]
+            xyz = xyz[:, :3, :]
+        l1_xyz, l1_points = self.sa1(xyz, norm)
+        l2_xyz, l2_points = self.sa2(l1_xyz, l1_points)
+        _, l3_points = self.sa3(l2_xyz, l2_points)
+        return l3_points.reshape(B, 1024)
+
+
+def _pose_output(x, normals_raw, B, out_vectors, weight_orient):
+    """cat(position, weight_orient * unit normal) per pose, poses interleaved per output vector (:332-339)."""
+    normals = F.normalize(torch.tanh(normals_raw).view(B, -1, 3), dim=-1) * weight_orient
+    return torch.cat((x.view(B, -1, 3), normals), dim=-1).view(B, out_vectors, -1)
+
+
+class PointNet2Regressor(_SSGEncoder):
+    """models/pointnet2_cls_ssg.py:12-81 (`backbone: pointnet2`)."""
+
+    def __init__(self, outdim=3, outdim_orient=3, weight_orient=1., normal_channel=False, out_vectors=1500,
+                 hidden_size=(1024, 1024), inputdim=None):
+        super().__init__()
+        self.outdim, self.outdim_orient = outdim, outdim_orient
+        self.out_vectors, self.weight_orient = out_vectors, weight_orient
+        self._build_encoder(normal_channel, inputdim)
+        self.fc1 = nn.Linear(1024, hidden_size[0])
+        self.fc2 = nn.Linear(hidden_size[0], hidden_size[1])
+        self.fc3 = nn.Linear(hidden_size[1], out_vectors * outdim)
+        if outdim_orient > 0:
+            self.fc_normals = nn.Linear(hidden_size[1], out_vectors * outdim_orient)
+            self.tanh = nn.Tanh()
+        self.dropout = nn.Dropout(p=0.3)
+        self.bn1 = nn.BatchNorm1d(hidden_size[0])
+        self.bn2 = nn.BatchNorm1d(hidden_size[1])
+
+    def forward(self, xyz):
+        B = xyz.shape[0]
+        feat = self.encode(xyz)
+        x = self.dropout(F.relu(self.bn1(self.fc1(feat))))
+        final = self.dropout(F.relu(self.bn2(self.fc2(x))))
+        x = self.fc3(final)
+        if self.outdim_orient > 0:
+            return _pose_output(x, self.fc_normals(final), B, self.out_vectors, self.weight_orient)
+        return x.view(B, self.out_vectors, self.outdim)
+
+
+class PointNet2Regressor_StrokeMasks(_SSGEncoder):
+    """models/pointnet2_cls_ssg.py:233-344 (`backbone: pointnet2_strokemasks`, the MaskPlanner model).
+    forward(xyz [B,3,N]) -> (out [B,S,D], sm_out [B,M,S] | None, mask_conf [B,M] | None, seg_conf | None)."""
+
+    def __init__(self, outdim=3, outdim_orient=3, weight_orient=1., normal_channel=False, out_vectors=1500,
+                 hidden_size=(1024, 1024), inputdim=None, pred_stroke_masks=False, n_stroke_masks=None,
+                 mask_confidence_scores=False, segment_confidence_scores=False):
+        super().__init__()
+        self.outdim, self.outdim_orient = outdim, outdim_orient
+        self.out_vectors, self.weight_orient = out_vectors, weight_orient
+        self.pred_stroke_masks, self.n_stroke_masks = pred_stroke_masks, n_stroke_masks
+        self.mask_confidence_scores = mask_confidence_scores
+        self.segment_confidence_scores = segment_confidence_scores
+        self._build_encoder(normal_channel, inputdim)
+        h0, h1 = hidden_size
+        self.fc1 = nn.Linear(1024, h0)
+        self.fc2 = nn.Linear(h0, h1)
+        self.fc3 = nn.Linear(h1, out_vectors * outdim)
+        self.dropout = nn.Dropout(p=0.3)
+        self.bn1 = nn.BatchNorm1d(h0)
+        self.bn2 = nn.BatchNorm1d(h1)
+        if outdim_orient > 0:
+            self.fc_normals = nn.Linear(h1, out_vectors * outdim_orient)
+            self.tanh = nn.Tanh()
+        if segment_confidence_scores:
+            self.seg_conf_fc1 = nn.Linear(1024, h0)
+            self.seg_conf_fc2 = nn.Linear(h0, h1)
+            self.seg_conf_out = nn.Linear(h1, out_vectors)
+        if pred_stroke_masks:
+            self.sm_fc1 = nn.Linear(1024, h0)
+            self.sm_fc2 = nn.Linear(h0, h1)
+            self.sm_fc3 = nn.Linear(h1, out_vectors * n_stroke_masks)
+            self.sm_bn1 = nn.BatchNorm1d(h0)
+            self.sm_bn2 = nn.BatchNorm1d(h1)
+            if mask_confidence_scores:
+                self.mask_conf_out = nn.Linear(h1, n_stroke_masks)
+
+    def forward(self, xyz):
+        B = xyz.shape[0]
+        feat = self.encode(xyz)
+        x = self.dropout(F.relu(self.bn1(self.fc1(feat))))
+        final = self.dropout(F.relu(self.bn2(self.fc2(x))))
+        x = self.fc3(final)
+
+        seg_conf = None
+        if self.segment_confidence_scores:
+            s = self.dropout(F.relu(self.seg_conf_fc1(feat)))
+            s = self.dropout(F.relu(self.seg_conf_fc2(s)))
+            seg_conf = torch.sigmoid(self.seg_conf_out(s))
+
+        sm_out, mask_conf = None, None
+        if self.pred_stroke_masks:
+            s1 = self.dropout(F.relu(self.sm_bn1(self.sm_fc1(feat))))
+            s2 = self.dropout(F.relu(self.sm_bn2(self.sm_fc2(s1))))
+            sm_out = self.sm_fc3(s2).view(B, self.n_stroke_masks, -1)
+            if self.mask_confidence_scores:
+                mask_conf = self.mask_conf_out(s2)
+
+        if self.outdim_orient > 0:
+            out = _pose_output(x, self.fc_normals(final), B, self.out_vectors, self.weight_orient)
+        else:
+            out = x.view(B, self.out_vectors, self.outdim)
+        return out, sm_out, mask_conf, seg_conf
+
+
+def maskplanner_model(category, lambda_points=4, overlapping=1, outdim=6, orient_outdim=3, weight_orient=0.25,
+                      hidden_size=(1024, 1024)):
+    """The model `get_model(config, which='pointnet2_strokemasks', io_type='MaskPlanner')` builds
+    (models/__init__.py:111-122, 295-318) for a synthetic.Category."""
+    return PointNet2Regressor_StrokeMasks(
+        out_vectors=category.out_vectors, outdim=(outdim - orient_outdim) * lambda_points,
+        outdim_orient=orient_outdim * lambda_points, weight_orient=weight_orient, hidden_size=hidden_size,
+        pred_stroke_masks=True, n_stroke_masks=category.max_n_strokes, mask_confidence_scores=True,
+        segment_confidence_scores=False)

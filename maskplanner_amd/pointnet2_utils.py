@@ -1,0 +1,167 @@
+"""Drop-in for the reference's `models/pointnet2_utils.py` on MI355X.
+
+Same module-level names, signatures, return shapes/dtypes and `state_dict` layout as the reference
+(models/pointnet2_utils.py:21-276), so `models/pointnet2_cls_ssg.py` / `pointnet2_seg.py` -- and through them the
+unchanged `train_maskplanner.py` / `test_maskplanner.py` -- can import this module in its place.  Every function
+runs hand-written gfx950 kernels through libmaskplanner_hip.so (see ops.py); nothing falls back to the reference's
+tensor algebra, and CPU tensors are refused.
+
+Differences that are NOT visible in results:
+  * farthest_point_sample: one kernel with the cloud resident on chip instead of ~8 launches + a host sync per
+    step (:79-85).  The start index is still drawn with torch.randint on the global CPU generator (:77), in the
+    same call order, so seeded runs pick the same starts.
+  * query_ball_point: an index-ordered scan with early exit instead of materialising and sorting [B,S,N] (:102-105).
+  * the set-abstraction MLP works on positions-major activations [B*S*K, C] (1x1 Conv2d == a GEMM over the
+    channel axis; BatchNorm2d statistics == statistics over all rows).
+"""
+import contextlib
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from . import sa_mlp
+
+_fps_start_queue = []
+
+
+@contextlib.contextmanager
+def fps_start_override(starts):
+    """Inject explicit FPS start indices (one [B] tensor per upcoming farthest_point_sample call, in call
+    order) instead of drawing them -- parity tests and benchmarks use it for reproducibility."""
+    _fps_start_queue.extend(starts)
+    try:
+        yield
+    finally:
+        del _fps_start_queue[:]
+
+
+def square_distance(src, dst):
+    """[B,N,C] x [B,M,C] -> [B,N,M] squared distances in the reference's expanded form (:21-42)."""
+    if src.shape[-1] == 3:
+        return ops.square_distance(src, dst)
+    raise NotImplementedError("square_distance: only 3-D points are on the MaskPlanner hot path")
+
+
+def index_points(points, idx):
+    """points [B,N,C], idx [B,S] or [B,S,K] -> points[b, idx[b,...], :] (:45-62)."""
+    return ops.index_points(points, idx)
+
+
+def _draw_fps_start(B, N, device):
+    if _fps_start_queue:
+        s = _fps_start_queue.pop(0)
+        return torch.as_tensor(s, dtype=torch.long).to(device)
+    # reference: torch.randint(0, N, (B,), dtype=torch.long).to(device) -- CPU generator, then copied (:77)
+    return torch.randint(0, N, (B,), dtype=torch.long).to(device, non_blocking=True)
+
+
+def farthest_point_sample(xyz, npoint):
+    """xyz [B,N,3] -> sampled indices i64 [B,npoint] (:65-86)."""
+    B, N, _ = xyz.shape
+    return ops.fps(xyz, npoint, _draw_fps_start(B, N, xyz.device))
+
+
+def query_ball_point(radius, nsample, xyz, new_xyz):
+    """-> i64 [B,S,nsample]: first `nsample` in-ball indices in index order, padded with the first (:89-109)."""
+    return ops.ball_query(radius, nsample, xyz, new_xyz)
+
+
+def sample_and_group(npoint, radius, nsample, xyz, points, returnfps=False, full_points=None):
+    """FPS -> ball query -> gather/centre/concat (:112-148).  xyz [B,N,3], points [B,N,D] or None.
+    Returns new_xyz [B,npoint,3], new_points [B,npoint,nsample,3+D] (xyz channels first)."""
+    B, N, _ = xyz.shape
+    fps_idx, new_xyz = ops.fps(xyz, npoint, _draw_fps_start(B, N, xyz.device), return_xyz=True)
+    idx = ops.ball_query(radius, nsample, xyz, new_xyz)
+    if points is not None:
+        new_points = ops.group(xyz, points, new_xyz, idx)
+    elif full_points is not None:
+        new_points = ops.index_points(full_points, idx)  # un-centred full features (:139-141)
+    else:
+        new_points = ops.group(xyz, None, new_xyz, idx)
+    if returnfps:
+        return new_xyz, new_points, ops.index_points(xyz, idx), fps_idx
+    return new_xyz, new_points
+
+
+def sample_and_group_all(xyz, points):
+    """One group holding every point, new_xyz = 0, coordinates NOT centred (:151-168)."""
+    B, N, C = xyz.shape
+    new_xyz = torch.zeros(B, 1, C, device=xyz.device)
+    grouped = xyz.view(B, 1, N, C)
+    if points is not None:
+        grouped = torch.cat([grouped, points.reshape(B, 1, N, -1)], dim=-1)
+    return new_xyz, grouped
+
+
+def _points_major(t):
+    """[B,C,N] -> [B,N,C]; free when `t` is the permuted view a previous layer of this module returned."""
+    return t.permute(0, 2, 1).contiguous()
+
+
+class PointNetSetAbstraction(nn.Module):
+    """Same constructor, parameters and state_dict keys as the reference class (:171-216):
+    mlp_convs.{i}.{weight[Co,Ci,1,1],bias}, mlp_bns.{i}.{weight,bias,running_mean,running_var,num_batches_tracked}."""
+
+    def __init__(self, npoint, radius, nsample, in_channel, mlp, group_all):
+        super().__init__()
+        self.npoint = npoint
+        self.radius = radius
+        self.nsample = nsample
+        self.mlp_convs = nn.ModuleList()
+        self.mlp_bns = nn.ModuleList()
+        last = in_channel
+        for out_channel in mlp:
+            self.mlp_convs.append(nn.Conv2d(last, out_channel, 1))
+            self.mlp_bns.append(nn.BatchNorm2d(out_channel))
+            last = out_channel
+        self.group_all = group_all
+
+    def forward(self, xyz, points, full_points=None):
+        """xyz [B,3,N], points [B,D,N] or None -> new_xyz [B,3,S], new_points [B,D',S]."""
+        xyz = _points_major(xyz)
+        points = None if points is None else _points_major(points)
+        full_points = None if full_points is None else _points_major(full_points)
+        if self.group_all:
+            new_xyz, grouped = sample_and_group_all(xyz, points)
+        else:
+            new_xyz, grouped = sample_and_group(self.npoint, self.radius, self.nsample, xyz, points,
+                                                full_points=full_points)
+        new_points = sa_mlp.shared_mlp_max(grouped, self.mlp_convs, self.mlp_bns)  # [B,S,C']
+        return new_xyz.permute(0, 2, 1), new_points.permute(0, 2, 1)
+
+
+class PointNetSetAbstractionMsg(nn.Module):
+    """Multi-scale grouping (:219-276): one FPS, per-radius ball query + MLP, outputs concatenated over scales.
+    Channel order inside a group is FEATURES first, centred xyz last (:262).  state_dict keys conv_blocks.{i}.{j}.*,
+    bn_blocks.{i}.{j}.* as in the reference."""
+
+    def __init__(self, npoint, radius_list, nsample_list, in_channel, mlp_list):
+        super().__init__()
+        self.npoint = npoint
+        self.radius_list = radius_list
+        self.nsample_list = nsample_list
+        self.conv_blocks = nn.ModuleList()
+        self.bn_blocks = nn.ModuleList()
+        for mlp in mlp_list:
+            convs, bns = nn.ModuleList(), nn.ModuleList()
+            last = in_channel + 3
+            for out_channel in mlp:
+                convs.append(nn.Conv2d(last, out_channel, 1))
+                bns.append(nn.BatchNorm2d(out_channel))
+                last = out_channel
+            self.conv_blocks.append(convs)
+            self.bn_blocks.append(bns)
+
+    def forward(self, xyz, points):
+        xyz = _points_major(xyz)
+        points = None if points is None else _points_major(points)
+        B, N, _ = xyz.shape
+        _, new_xyz = ops.fps(xyz, self.npoint, _draw_fps_start(B, N, xyz.device), return_xyz=True)
+        outs = []
+        for radius, K, convs, bns in zip(self.radius_list, self.nsample_list, self.conv_blocks, self.bn_blocks):
+            idx = ops.ball_query(radius, K, xyz, new_xyz)
+            grouped = ops.group(xyz, points, new_xyz, idx, xyz_last=True)
+            outs.append(sa_mlp.shared_mlp_max(grouped, convs, bns))
+        return new_xyz.permute(0, 2, 1), torch.cat(outs, dim=-1).permute(0, 2, 1)

@@ -1,0 +1,181 @@
+"""Drop-in for the reference's `pytorch3d_chamfer.chamfer_distance` (pytorch3d_chamfer.py:76-344) on MI355X.
+
+Same signature, flags, return tuple and ValueErrors.  What changes is how the work is done:
+  * nearest neighbours come from the gfx950 kNN kernel (ops.knn) instead of pytorch3d's CUDA extension;
+  * `padded=True` lengths are detected by a kernel (ops.padded_lengths) -- the reference loops over the batch
+    with `.item()` and a device->host copy per sample (:142-147);
+  * only the direction(s) that reach the result are computed: the reference always runs both kNN passes
+    (:257-258) although `asymmetric` / `reverse_asymmetric` keep one of them (:329-334);
+  * no data-dependent host branch: rows beyond a cloud's length are already zero in the kernel's output, which
+    is what the reference's `cham_x[x_mask] = 0.0` (:263-266) produces.
+Values agree with the reference within 1e-5 (fp32); matching indices are identical.
+"""
+from typing import Union
+
+import torch
+import torch.nn.functional as F
+
+from . import ops
+
+
+def _validate_chamfer_reduction_inputs(batch_reduction: Union[str, None], point_reduction: Union[str, None]) -> None:
+    """Same accepted combinations and messages as pytorch3d_chamfer.py:16-30."""
+    if batch_reduction is not None and batch_reduction not in ["mean", "sum"]:
+        raise ValueError('batch_reduction must be one of ["mean", "sum"] or None')
+    if batch_reduction is not None and point_reduction not in ["mean", "sum"]:
+        raise ValueError('point_reduction must be one of ["mean", "sum"] if batch_reduction is not None')
+
+
+def _handle_pointcloud_input(points, lengths, normals):
+    """Tensor inputs only (pytorch3d's Pointclouds container is not part of this build): :38-73."""
+    if not torch.is_tensor(points):
+        raise ValueError("The input pointclouds should be either Pointclouds objects or torch.Tensor of shape "
+                         "(minibatch, num_points, 3).")
+    if points.ndim != 3:
+        raise ValueError("Expected points to be of shape (N, P, D)")
+    if lengths is not None and (lengths.ndim != 1 or lengths.shape[0] != points.shape[0]):
+        raise ValueError("Expected lengths to be of shape (N,)")
+    if lengths is None:
+        lengths = torch.full((points.shape[0],), points.shape[1], dtype=torch.int64, device=points.device)
+    if normals is not None and normals.ndim != 3:
+        raise ValueError("Expected normals to be of shape (N, P, 3")
+    return points, lengths, normals
+
+
+def _row_mask(lengths, P):
+    """True for rows at or beyond the cloud's length."""
+    return torch.arange(P, device=lengths.device)[None] >= lengths[:, None]
+
+
+def chamfer_distance(x, y, x_lengths=None, y_lengths=None, x_normals=None, y_normals=None, weights=None,
+                     batch_reduction: Union[str, None] = "mean", point_reduction: Union[str, None] = "mean",
+                     velocities=False, min_centroids=False, padded=False, avoid_in_sequence_collapsing=False,
+                     soft_attraction=False, asymmetric=False, reverse_asymmetric=False, return_matching=False):
+    """Chamfer distance between point sets x [N,P1,D] and y [N,P2,D]; see the reference docstring (:95-129) and the
+    custom flags (:84-93).  Returns (dist, normals_dist_or_None) and, with return_matching, also the nearest
+    neighbour indices (idx_x [N,P1], idx_y [N,P2])."""
+    if not soft_attraction:
+        _validate_chamfer_reduction_inputs(batch_reduction, point_reduction)
+    x, x_lengths, x_normals = _handle_pointcloud_input(x, x_lengths, x_normals)
+    y, y_lengths, y_normals = _handle_pointcloud_input(y, y_lengths, y_normals)
+    return_normals = x_normals is not None and y_normals is not None
+    N, P1, D = x.shape
+    P2 = y.shape[1]
+    if y.shape[0] != N or y.shape[2] != D:
+        raise ValueError("y does not have the correct shape.")
+
+    if padded:  # -100 sentinel in the leading coordinate marks fake GT rows (:138-149)
+        found = ops.padded_lengths(y)
+        # the reference overwrites y_lengths only if at least one sample is padded (:140); decided on device
+        y_lengths.copy_(torch.where((found != P2).any(), found, y_lengths))
+
+    if weights is not None:
+        if weights.size(0) != N:
+            raise ValueError("weights must be of shape (N,).")
+        if not (weights >= 0).all():
+            raise ValueError("weights cannot be negative.")
+        if weights.sum() == 0.0:
+            w = weights.view(N, 1)
+            if batch_reduction in ["mean", "sum"]:
+                z = (x.sum((1, 2)) * w).sum() * 0.0
+                return z, z.clone()
+            z = (x.sum((1, 2)) * w) * 0.0
+            return z, z.clone()
+
+    need_x = asymmetric or not reverse_asymmetric or return_matching or return_normals
+    need_y = (not asymmetric) or return_matching or return_normals
+    idx_x = idx_y = None
+
+    if velocities:
+        # neighbours on positions only, distance on the full 6-D pose (:180-199)
+        assert D == 6, 'Velocities is True but traj does not contain velocities'
+        xp, yp = x[:, :, :3], y[:, :, :3]
+        _, idx_x = ops.knn(xp, yp, x_lengths, y_lengths, 1)
+        _, idx_y = ops.knn(yp, xp, y_lengths, x_lengths, 1)
+        cham_x = torch.linalg.norm(x - ops.index_points(y, idx_x[..., 0]), dim=-1).square()
+        cham_y = torch.linalg.norm(y - ops.index_points(x, idx_y[..., 0]), dim=-1).square()
+        cham_x = cham_x.masked_fill(_row_mask(x_lengths, P1), 0.0)
+        cham_y = cham_y.masked_fill(_row_mask(y_lengths, P2), 0.0)
+    elif avoid_in_sequence_collapsing:
+        # attraction loss: a point may not pick its own sequence index, use the 2nd neighbour then (:201-239)
+        assert P1 == P2
+        seq = torch.arange(P1, device=x.device)[None]
+        dx, ix = ops.knn(x, y, x_lengths, y_lengths, 2)
+        dy, iy = ops.knn(y, x, y_lengths, x_lengths, 2)
+        other_x, other_y = ix[..., 0] != seq, iy[..., 0] != seq
+        if not soft_attraction:
+            cham_x = torch.where(other_x, dx[..., 0], dx[..., 1]).sum(1)
+            cham_y = torch.where(other_y, dy[..., 0], dy[..., 1]).sum(1)
+        else:
+            assert point_reduction is None and batch_reduction is None
+            cham_x = ((dx[..., 0] * other_x).sum(1) / other_x.sum(1)).mean()
+            cham_y = ((dy[..., 0] * other_y).sum(1) / other_y.sum(1)).mean()
+        idx_x, idx_y = ix, iy
+    else:
+        if min_centroids:  # centroid of the lambda poses of each segment (:244-255)
+            assert P1 == P2
+            assert D % 3 == 0
+            lmbda = D // 3
+            x = x.reshape(N, P1, lmbda, 3).mean(dim=-2)
+            y = y.reshape(N, P1, lmbda, 3).mean(dim=-2)
+        cham_x = cham_y = None
+        if need_x:
+            dx, idx_x = ops.knn(x, y, x_lengths, y_lengths, 1)
+            cham_x = dx[..., 0]
+        if need_y:
+            dy, idx_y = ops.knn(y, x, y_lengths, x_lengths, 1)
+            cham_y = dy[..., 0]
+        # a skipped direction never reaches the result; keep the algebra below uniform
+        if cham_x is None:
+            cham_x = x.new_zeros((N, P1))
+        if cham_y is None:
+            cham_y = x.new_zeros((N, P2))
+
+    if weights is not None:
+        cham_x = cham_x * weights.view(N, 1)
+        cham_y = cham_y * weights.view(N, 1)
+
+    cham_norm_x = x.new_zeros(())
+    cham_norm_y = x.new_zeros(())
+    if return_normals:
+        # cosine distance to the matched point's normal (:272-291)
+        xn_near = ops.index_points(y_normals, idx_x[..., 0])
+        yn_near = ops.index_points(x_normals, idx_y[..., 0])
+        cham_norm_x = 1 - torch.abs(F.cosine_similarity(x_normals, xn_near, dim=2, eps=1e-6))
+        cham_norm_y = 1 - torch.abs(F.cosine_similarity(y_normals, yn_near, dim=2, eps=1e-6))
+        cham_norm_x = cham_norm_x.masked_fill(_row_mask(x_lengths, P1), 0.0)
+        cham_norm_y = cham_norm_y.masked_fill(_row_mask(y_lengths, P2), 0.0)
+        if weights is not None:
+            cham_norm_x = cham_norm_x * weights.view(N, 1)
+            cham_norm_y = cham_norm_y * weights.view(N, 1)
+
+    if point_reduction is not None and not avoid_in_sequence_collapsing:  # (:295-308)
+        cham_x, cham_y = cham_x.sum(1), cham_y.sum(1)
+        if return_normals:
+            cham_norm_x, cham_norm_y = cham_norm_x.sum(1), cham_norm_y.sum(1)
+        if point_reduction == "mean":
+            cham_x, cham_y = cham_x / x_lengths, cham_y / y_lengths
+            if return_normals:
+                cham_norm_x, cham_norm_y = cham_norm_x / x_lengths, cham_norm_y / y_lengths
+
+    if batch_reduction is not None:  # (:312-326)
+        cham_x, cham_y = cham_x.sum(), cham_y.sum()
+        if return_normals:
+            cham_norm_x, cham_norm_y = cham_norm_x.sum(), cham_norm_y.sum()
+        if batch_reduction == "mean":
+            div = weights.sum() if weights is not None else N
+            cham_x, cham_y = cham_x / div, cham_y / div
+            if return_normals:
+                cham_norm_x, cham_norm_y = cham_norm_x / div, cham_norm_y / div
+
+    if asymmetric:
+        cham_dist = cham_x
+    elif reverse_asymmetric:
+        cham_dist = cham_y
+    else:
+        cham_dist = cham_x + cham_y
+    cham_normals = cham_norm_x + cham_norm_y if return_normals else None
+
+    if return_matching:
+        return cham_dist, cham_normals, idx_x.flatten(1, 2), idx_y.flatten(1, 2)
+    return cham_dist, cham_normals

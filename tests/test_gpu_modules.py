@@ -1,0 +1,307 @@
+"""Drop-in modules on the MI355X against the golden vectors produced by the imported reference
+(oracle/gen_golden.py) and against the CPU oracle (oracle/torch_ref.py) at sizes the fixtures do not cover.
+
+Tolerance: north_star's 1e-5 (relative to the tensor's scale) for fp32 values; indices exact.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-5
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def close(a, b, what, rtol=RTOL, atol=1e-5):
+    a = a.detach().cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
+    b = b.detach().cpu().numpy() if torch.is_tensor(b) else np.asarray(b)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    err = np.abs(a - b).max() if a.size else 0.0
+    scale = max(np.abs(b).max(), 1.0) if b.size else 1.0
+    assert err <= atol + rtol * scale, f"{what}: max err {err:.3e} (scale {scale:.3e})"
+
+
+def load_sd(module, g, prefix):
+    sd = {k[len(prefix):]: torch.from_numpy(g[k].copy()) for k in g.files if k.startswith(prefix)}
+    module.load_state_dict(sd, strict=True)
+    return module.cuda()
+
+
+# ------------------------------------------------------------------------------------------------ set abstraction
+@pytest.mark.parametrize("sa,xyzk,featk,ctor", [
+    ("sa1", "xyz", None, dict(npoint=128, radius=0.2, nsample=32, in_channel=3, mlp=[32, 32, 64], group_all=False)),
+    ("sa2", "xyz2", "feats2", dict(npoint=64, radius=0.4, nsample=64, in_channel=67, mlp=[64, 64, 128], group_all=False)),
+    ("sa3", "xyz3", "feats3", dict(npoint=None, radius=None, nsample=None, in_channel=64, mlp=[64, 96, 160], group_all=True)),
+])
+@pytest.mark.parametrize("train", [False, True])
+def test_set_abstraction_matches_reference(golden, sa, xyzk, featk, ctor, train):
+    from maskplanner_amd import pointnet2_utils as pu
+    g = golden("g3_sa")
+    tag = f"{sa}_{'train' if train else 'eval'}"
+    m = load_sd(pu.PointNetSetAbstraction(**ctor), g, f"{sa}_sd_")
+    m.train(train)
+    xyz = dev(g[xyzk]).permute(0, 2, 1).contiguous()
+    feats = None if featk is None else dev(g[featk]).permute(0, 2, 1).contiguous().requires_grad_(True)
+    starts = [g[tag + "_fps_start"]] if (tag + "_fps_start") in g.files else []
+    with pu.fps_start_override(starts):
+        new_xyz, new_points = m(xyz, feats)
+    close(new_xyz, g[tag + "_new_xyz"], "new_xyz", atol=0, rtol=0)
+    close(new_points, g[tag + "_new_points"], "new_points")
+    (new_points * dev(g[tag + "_gout"])).sum().backward()
+    for i in range(3):
+        close(m.mlp_convs[i].weight.grad, g[f"{tag}_grad_mlp_convs.{i}.weight"], f"dW{i}", atol=2e-4, rtol=1e-4)
+        close(m.mlp_bns[i].weight.grad, g[f"{tag}_grad_mlp_bns.{i}.weight"], f"dgamma{i}", atol=2e-4, rtol=1e-4)
+        close(m.mlp_bns[i].bias.grad, g[f"{tag}_grad_mlp_bns.{i}.bias"], f"dbeta{i}", atol=2e-4, rtol=1e-4)
+        if not train:
+            close(m.mlp_convs[i].bias.grad, g[f"{tag}_grad_mlp_convs.{i}.bias"], f"dbias{i}", atol=2e-4, rtol=1e-4)
+    if feats is not None:
+        close(feats.grad, g[tag + "_grad_feats"], "dfeats", atol=2e-4, rtol=1e-4)
+    if train:
+        for i in range(3):
+            close(m.mlp_bns[i].running_mean, g[f"{tag}_after_mlp_bns.{i}.running_mean"], "running_mean")
+            close(m.mlp_bns[i].running_var, g[f"{tag}_after_mlp_bns.{i}.running_var"], "running_var")
+            assert int(m.mlp_bns[i].num_batches_tracked) == 1
+
+
+@pytest.mark.parametrize("train", [False, True])
+def test_msg_matches_reference(golden, train):
+    from maskplanner_amd import pointnet2_utils as pu
+    g = golden("g4_msg")
+    tag = "train" if train else "eval"
+    m = load_sd(pu.PointNetSetAbstractionMsg(64, [0.1, 0.2, 0.4], [8, 16, 32], 13, [[16, 16, 32], [16, 24, 32], [16, 24, 48]]),
+                g, "msg_sd_")
+    m.train(train)
+    xyz = dev(g["xyz"]).permute(0, 2, 1).contiguous()
+    feats = dev(g["feats"]).permute(0, 2, 1).contiguous().requires_grad_(True)
+    with pu.fps_start_override([g["fps_start"]]):
+        new_xyz, out = m(xyz, feats)
+    close(new_xyz, g[tag + "_new_xyz"], "new_xyz", atol=0, rtol=0)
+    close(out, g[tag + "_new_points"], "new_points")
+    (out * dev(g[tag + "_gout"])).sum().backward()
+    close(feats.grad, g[tag + "_grad_feats"], "dfeats", atol=2e-4, rtol=1e-4)
+    for name, p in m.named_parameters():
+        if train and name.endswith("bias") and "conv" in name:
+            continue  # conv bias cancels inside train-mode BN: its gradient is rounding noise in the reference
+        close(p.grad, g[f"{tag}_grad_{name}"], name, atol=2e-4, rtol=1e-4)
+
+
+def test_full_model_eval_matches_reference(golden):
+    from maskplanner_amd import pointnet2_cls_ssg as pc
+    from maskplanner_amd import pointnet2_utils as pu
+    g = golden("g5_model")
+    model = pc.PointNet2Regressor_StrokeMasks(outdim=12, outdim_orient=12, weight_orient=0.25, out_vectors=99,
+                                              hidden_size=(64, 64), pred_stroke_masks=True, n_stroke_masks=6,
+                                              mask_confidence_scores=True, segment_confidence_scores=False)
+    ref_keys = sorted(k[3:] for k in g.files if k.startswith("sd_"))
+    assert sorted(model.state_dict().keys()) == ref_keys  # checkpoint compatibility (test_maskplanner.py:162-188)
+    load_sd(model, g, "sd_").eval()
+    with pu.fps_start_override([g["fps_start1"], g["fps_start2"]]), torch.no_grad():
+        out, sm_out, mask_conf, seg_conf = model(dev(g["xyz"]).permute(0, 2, 1))
+    assert seg_conf is None
+    close(out, g["out"], "out")
+    close(sm_out, g["sm_out"], "sm_out")
+    close(mask_conf, g["mask_conf"], "mask_conf")
+
+
+def test_fps_draw_is_seed_compatible():
+    """The start index comes from torch.randint on the global CPU generator, one draw per call (:77)."""
+    from maskplanner_amd import pointnet2_utils as pu
+    xyz = torch.rand(3, 700, 3).cuda()
+    torch.manual_seed(123)
+    want1 = torch.randint(0, 700, (3,), dtype=torch.long)
+    want2 = torch.randint(0, 700, (3,), dtype=torch.long)
+    torch.manual_seed(123)
+    a = pu.farthest_point_sample(xyz, 5)
+    b = pu.farthest_point_sample(xyz, 5)
+    assert torch.equal(a[:, 0].cpu(), want1) and torch.equal(b[:, 0].cpu(), want2)
+
+
+# ------------------------------------------------------------------------------------------------ chamfer
+def test_chamfer_matches_reference_wrapper(golden):
+    from maskplanner_amd.pytorch3d_chamfer import chamfer_distance
+    g = golden("g6_cham")
+    y_pred, traj, pc = (dev(g[k]) for k in ("y_pred", "traj", "traj_as_pc"))
+    B = y_pred.shape[0]
+    calls = {
+        "c1": (y_pred, traj, dict(padded=True, asymmetric=True, return_matching=True, point_reduction=None, batch_reduction=None)),
+        "c2": (y_pred.reshape(B, -1, 6), pc, dict(padded=True, reverse_asymmetric=True)),
+        "c3": (y_pred, traj, dict(padded=True, reverse_asymmetric=True)),
+        "c4": (y_pred.reshape(B, -1, 6), pc, dict(padded=True)),
+        "c5": (dev(g["xs"]), dev(g["ys"]), dict()),
+        "c6": (dev(g["xs"]), dev(g["ys"]), dict(batch_reduction="sum", point_reduction="sum")),
+        "c7": (dev(g["xs"]), dev(g["ys"]), dict(batch_reduction=None, point_reduction="mean")),
+    }
+    for tag, (x, y, kw) in calls.items():
+        x = x.clone().requires_grad_(True)
+        res = chamfer_distance(x, y, **kw)
+        assert len(res) == (4 if kw.get("return_matching") else 2) and res[1] is None
+        d = res[0]
+        close(d, g[tag + "_dist"], tag + " dist", rtol=1e-5, atol=1e-6)
+        w = dev(g[tag + "_w"]) if (tag + "_w") in g.files else None
+        ((d * w).sum() if w is not None else d).backward()
+        close(x.grad, g[tag + "_gx"], tag + " grad", rtol=1e-5, atol=1e-6)
+        if len(res) == 4:
+            assert np.array_equal(res[2].cpu().numpy(), g[tag + "_idx_x"])
+            assert np.array_equal(res[3].cpu().numpy(), g[tag + "_idx_y"])
+
+
+def test_chamfer_errors_like_reference():
+    from maskplanner_amd.pytorch3d_chamfer import chamfer_distance
+    x = torch.rand(2, 5, 3).cuda()
+    with pytest.raises(ValueError, match="batch_reduction"):
+        chamfer_distance(x, x, batch_reduction="max")
+    with pytest.raises(ValueError, match="point_reduction"):
+        chamfer_distance(x, x, point_reduction=None)
+    with pytest.raises(ValueError, match="shape"):
+        chamfer_distance(x[0], x)
+    with pytest.raises(ValueError, match="correct shape"):
+        chamfer_distance(x, torch.rand(2, 5, 4).cuda())
+    with pytest.raises(ValueError, match="lengths"):
+        chamfer_distance(x, x, x_lengths=torch.ones(3, dtype=torch.long).cuda())
+
+
+def test_chamfer_other_flags_vs_torch_algebra():
+    """velocities / min_centroids / avoid_in_sequence_collapsing / soft_attraction / weights / normals against the
+    same quantities written with dense torch ops on the GPU (cdist-free, direct differences)."""
+    from maskplanner_amd.pytorch3d_chamfer import chamfer_distance
+    g = torch.Generator().manual_seed(0)
+    x = torch.rand(2, 40, 6, generator=g).cuda()
+    y = torch.rand(2, 40, 6, generator=g).cuda()
+
+    def nn_d(a, b, k=1):
+        d = ((a[:, :, None, :] - b[:, None, :, :]) ** 2).sum(-1)
+        return d.topk(k, dim=-1, largest=False)
+
+    # velocities: neighbour on xyz, distance on all six dims
+    d, _ = chamfer_distance(x, y, velocities=True)
+    ix = nn_d(x[..., :3], y[..., :3])[1][..., 0]
+    iy = nn_d(y[..., :3], x[..., :3])[1][..., 0]
+    bi = torch.arange(2)[:, None].cuda()
+    want = ((x - y[bi, ix]) ** 2).sum(-1).mean(1).mean() + ((y - x[bi, iy]) ** 2).sum(-1).mean(1).mean()
+    close(d, want, "velocities", rtol=1e-5, atol=1e-6)
+    # min_centroids on 24-D segments
+    xs, ys = torch.rand(2, 30, 24, generator=g).cuda(), torch.rand(2, 30, 24, generator=g).cuda()
+    d, _ = chamfer_distance(xs, ys, min_centroids=True)
+    cx, cy = xs.view(2, 30, 8, 3).mean(-2), ys.view(2, 30, 8, 3).mean(-2)
+    want = nn_d(cx, cy)[0][..., 0].mean(1).mean() + nn_d(cy, cx)[0][..., 0].mean(1).mean()
+    close(d, want, "min_centroids", rtol=1e-5, atol=1e-6)
+    # attraction (2nd neighbour when the 1st is the point's own sequence index)
+    s, e = xs[..., :3].contiguous(), (xs[..., :3] + 0.01 * torch.rand(2, 30, 3, generator=g).cuda()).contiguous()
+    d, _ = chamfer_distance(s, e, avoid_in_sequence_collapsing=True)
+    seq = torch.arange(30).cuda()[None]
+
+    def attr(a, b):
+        dd, ii = nn_d(a, b, 2)
+        return torch.where(ii[..., 0] != seq, dd[..., 0], dd[..., 1]).sum(1)
+    close(d, (attr(s, e) + attr(e, s)).mean(), "attraction", rtol=1e-5, atol=1e-6)
+    d, _ = chamfer_distance(s, e, avoid_in_sequence_collapsing=True, soft_attraction=True, point_reduction=None,
+                            batch_reduction=None)
+    assert d.ndim == 0 and torch.isfinite(d)
+    # weights and normals
+    w = torch.tensor([0.5, 2.0]).cuda()
+    nx, ny = F_normalize(torch.rand(2, 40, 3, generator=g)).cuda(), F_normalize(torch.rand(2, 40, 3, generator=g)).cuda()
+    d, dn = chamfer_distance(x[..., :3].contiguous(), y[..., :3].contiguous(), x_normals=nx, y_normals=ny, weights=w)
+    dx, ix = nn_d(x[..., :3], y[..., :3])
+    dy, iy = nn_d(y[..., :3], x[..., :3])
+    want = ((dx[..., 0].mean(1) * w).sum() + (dy[..., 0].mean(1) * w).sum()) / w.sum()
+    close(d, want, "weighted", rtol=1e-5, atol=1e-6)
+    cosx = 1 - torch.abs(torch.nn.functional.cosine_similarity(nx, ny[bi, ix[..., 0]], dim=2, eps=1e-6))
+    cosy = 1 - torch.abs(torch.nn.functional.cosine_similarity(ny, nx[bi, iy[..., 0]], dim=2, eps=1e-6))
+    close(dn, ((cosx.mean(1) * w).sum() + (cosy.mean(1) * w).sum()) / w.sum(), "normals", rtol=1e-5, atol=1e-6)
+    z, zn = chamfer_distance(x, y, weights=torch.zeros(2).cuda())
+    assert float(z) == 0.0 and float(zn) == 0.0
+
+
+def F_normalize(t):
+    return torch.nn.functional.normalize(t, dim=-1)
+
+
+# ------------------------------------------------------------------------------------------------ losses
+@pytest.mark.parametrize("tag", ["cub", "win"])
+def test_asymm_v6_loss_matches_reference(golden, tag):
+    from maskplanner_amd.loss_handler import LossHandler, maskplanner_loss_config
+    g = golden("g7_mask")
+    cfg = maskplanner_loss_config(explicit_no_stroke_weight=float(g[tag + "_no_stroke_weight"]))
+    lh = LossHandler(["asymm_v6_chamfer_with_stroke_masks"], cfg)
+    yp = dev(g[tag + "_y_pred"]).requires_grad_(True)
+    mk = dev(g[tag + "_masks"]).requires_grad_(True)
+    sc = dev(g[tag + "_scores"]).requires_grad_(True)
+    loss, terms = lh.compute(y_pred=yp, y=dev(g[tag + "_traj"]), pred_stroke_masks=mk, mask_scores=sc, seg_logits=None,
+                             stroke_ids=torch.from_numpy(g[tag + "_stroke_ids"]),      # CPU tensor, as the collate gives it
+                             traj_as_pc=torch.from_numpy(g[tag + "_traj_as_pc"]))
+    assert isinstance(terms, np.ndarray) and terms.shape == (1,)
+    close(loss, g[tag + "_loss"], "loss", rtol=1e-5)
+    loss.backward()
+    close(yp.grad, g[tag + "_g_y_pred"], "g_y_pred", rtol=1e-4, atol=1e-6)
+    close(mk.grad, g[tag + "_g_masks"], "g_masks", rtol=1e-5, atol=1e-6)
+    close(sc.grad, g[tag + "_g_scores"], "g_scores", rtol=1e-5, atol=1e-6)
+    # the mask term alone, from the reference's own idx_x
+    mk2 = dev(g[tag + "_masks"]).requires_grad_(True)
+    sc2 = dev(g[tag + "_scores"]).requires_grad_(True)
+    ml = lh.get_stroke_masks_loss(dev(g[tag + "_idx_x"]), mk2, sc2, dev(g[tag + "_stroke_ids"]))
+    close(ml, g[tag + "_mask_loss"], "mask_loss", rtol=1e-5)
+    ml.backward()
+    close(mk2.grad, g[tag + "_gm_masks"], "gm_masks", rtol=1e-5, atol=1e-6)
+    close(sc2.grad, g[tag + "_gm_scores"], "gm_scores", rtol=1e-5, atol=1e-6)
+    # weights are read on every call (train_maskplanner.py:294-305 mutates the config)
+    cfg["explicit_weight_stroke_masks"] = 0.0
+    cfg["explicit_weight_stroke_masks_confidence"] = 0.0
+    l0 = lh.compute(return_list=False, y_pred=yp, y=dev(g[tag + "_traj"]), pred_stroke_masks=mk, mask_scores=sc,
+                    seg_logits=None, stroke_ids=dev(g[tag + "_stroke_ids"]), traj_as_pc=dev(g[tag + "_traj_as_pc"]))
+    assert float(l0) < float(loss)
+
+
+def test_hungarian_matcher_matches_reference(golden):
+    from maskplanner_amd.hungarianMatcher import HungarianMatcher
+    g = golden("g8_hung")
+    res = HungarianMatcher()(dev(g["outputs"]), [dev(g[f"target{b}"]) for b in range(3)])
+    for b, (i, j) in enumerate(res):
+        assert i.dtype == torch.int64 and not i.is_cuda
+        assert np.array_equal(i.numpy(), g[f"i{b}"]) and np.array_equal(j.numpy(), g[f"j{b}"]), b
+
+
+# ------------------------------------------------------------------------------------------------ full size
+def test_full_size_forward_loss_backward_vs_oracle(oracle):
+    """BASELINE config 2 shapes (cuboids, N=5120) at a reduced batch: model + loss on the GPU against the fp32
+    CPU restatement (oracle/torch_ref.py) with the same weights, FPS starts and (disabled) dropout."""
+    from maskplanner_amd import pointnet2_cls_ssg as pc
+    from maskplanner_amd import pointnet2_utils as pu
+    from maskplanner_amd import synthetic as syn
+    from maskplanner_amd.loss_handler import LossHandler, maskplanner_loss_config
+    from oracle import torch_ref as T
+    B, N = 4, 5120
+    cat = syn.CATEGORIES["cuboids"]
+    batch = syn.make_batch(7, B, N, "cuboids", "cuboid")
+    torch.manual_seed(3)
+    model = pc.maskplanner_model(cat, hidden_size=(256, 256))
+    model.dropout.p = 0.0
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model = model.cuda().train()
+    cfg = maskplanner_loss_config()
+    lh = LossHandler(["asymm_v6_chamfer_with_stroke_masks"], cfg)
+    with pu.fps_start_override(batch["fps_start"]):
+        out, sm, conf, _ = model(batch["point_cloud"].cuda().permute(0, 2, 1))
+    loss = lh.compute(return_list=False, y_pred=out, y=batch["traj"].cuda(), pred_stroke_masks=sm, mask_scores=conf,
+                      seg_logits=None, stroke_ids=batch["stroke_ids"], traj_as_pc=batch["traj_as_pc"])
+    loss.backward()
+    # oracle
+    sd_ref = {k: v.clone().requires_grad_(v.dtype.is_floating_point and "running" not in k) for k, v in sd.items()}
+    o_out, o_sm, o_conf = T.strokemasks_forward(sd_ref, batch["point_cloud"], [s.numpy() for s in batch["fps_start"]],
+                                                train=True, out_vectors=cat.out_vectors, n_masks=cat.max_n_strokes)
+    o_loss = T.asymm_v6_loss(o_out, batch["traj"], o_sm, o_conf, batch["stroke_ids"], batch["traj_as_pc"], cfg)
+    o_loss.backward()
+    close(out, o_out, "out", rtol=1e-4, atol=1e-4)       # train-mode BN over B=4 amplifies rounding: looser than 1e-5
+    close(loss, o_loss, "loss", rtol=1e-4)
+    for name in ("sa1.mlp_convs.0.weight", "sa2.mlp_convs.2.weight", "sa3.mlp_bns.1.weight", "fc3.weight", "sm_fc3.bias"):
+        gp = dict(model.named_parameters())[name].grad
+        close(gp, sd_ref[name].grad, name, rtol=2e-3, atol=2e-4)
