@@ -122,7 +122,7 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    final_loss = float(loss)
+    final_loss = float(loss.detach())
 
     if rank == 0:
         ms = dt / args.steps * 1e3

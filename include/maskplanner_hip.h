@@ -125,6 +125,52 @@ int mp_mask_match_f32(const float* pred_masks, const float* target_ids, int64_t 
                       int64_t* match_col, float* uniq_ids, int64_t* n_targets, float* cost,
                       int32_t* status, mp_stream_t stream);
 
+/* ---- set-abstraction shared MLP: (1x1 conv -> BatchNorm -> ReLU) x L -> max over the K group members ----------
+ * replaces: models/pointnet2_utils.py:208-214 (PointNetSetAbstraction.forward tail; :264-269 for MSG) and the
+ *           autograd graph torch builds for it.
+ *   x0 [P, c_0] f32: grouped input, positions-major (P = B*S*K rows, the K members of a group consecutive).
+ *   Layer l: weight [c_out, c_in] (Conv2d weight [c_out,c_in,1,1] as is), bias [c_out] or NULL, BatchNorm
+ *   gamma/beta, running_mean/var (updated in place when training; read when not).  The library writes the raw
+ *   pre-BN activations z [P, c_out] and the folded affine (scale, shift) + (mean, rstd) per layer: these are the
+ *   tensors backward needs, owned by the caller.
+ *   out [P/K, c_L] = max_k relu(bn(z_L)); argk i32 [P/K, c_L] = arg-max member (first wins); zmax = raw z there.
+ *   GEMMs run on v_mfma_f32_32x32x2_f32 (exact fp32); BatchNorm sums are reduced in fp64.
+ *   backward: grad_out [P/K, c_L] -> d_weight [c_out,c_in], d_bias (zeros in training: the bias cancels inside
+ *   BN), d_gamma, d_beta per layer, and grad_x0 [P, c_0] (NULL = not needed).  d_weight is accumulated with fp32
+ *   atomics over position slices (not bitwise reproducible).
+ *   workspace: mp_sa_mlp_workspace_bytes(P, K, L, channels[L+1], backward). */
+typedef struct {
+    const float* weight;
+    const float* bias;
+    const float* gamma;
+    const float* beta;
+    float* running_mean;
+    float* running_var;
+    int64_t c_in;
+    int64_t c_out;
+    float* z;     /* [P, c_out] */
+    float* mean;  /* [c_out] */
+    float* rstd;
+    float* scale;
+    float* shift;
+} mp_mlp_layer_t;
+
+typedef struct {
+    float* d_weight;
+    float* d_bias; /* may be NULL */
+    float* d_gamma;
+    float* d_beta;
+} mp_mlp_grads_t;
+
+size_t mp_sa_mlp_workspace_bytes(int64_t P, int64_t K, int n_layers, const int64_t* channels, int backward);
+int mp_sa_mlp_fwd_f32(const float* x0, int64_t P, int64_t K, int n_layers, const mp_mlp_layer_t* layers, int training,
+                      double momentum, double eps, float* out, int32_t* argk, float* zmax, void* workspace,
+                      size_t workspace_bytes, mp_stream_t stream);
+int mp_sa_mlp_bwd_f32(const float* x0, int64_t P, int64_t K, int n_layers, const mp_mlp_layer_t* layers, int training,
+                      const float* grad_out, const float* out, const int32_t* argk, const float* zmax,
+                      const mp_mlp_grads_t* grads, float* grad_x0, void* workspace, size_t workspace_bytes,
+                      mp_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -23,6 +23,21 @@ _int = ctypes.c_int
 _dbl = ctypes.c_double
 _sz = ctypes.c_size_t
 
+_fp = ctypes.POINTER(ctypes.c_float)
+
+
+class MlpLayer(ctypes.Structure):
+    """mp_mlp_layer_t"""
+    _fields_ = [("weight", _vp), ("bias", _vp), ("gamma", _vp), ("beta", _vp), ("running_mean", _vp),
+                ("running_var", _vp), ("c_in", _i64), ("c_out", _i64), ("z", _vp), ("mean", _vp), ("rstd", _vp),
+                ("scale", _vp), ("shift", _vp)]
+
+
+class MlpGrads(ctypes.Structure):
+    """mp_mlp_grads_t"""
+    _fields_ = [("d_weight", _vp), ("d_bias", _vp), ("d_gamma", _vp), ("d_beta", _vp)]
+
+
 # name -> (restype, argtypes).  One entry per symbol declared in include/maskplanner_hip.h.
 SIGNATURES = {
     "mp_abi_version": (_int, []),
@@ -39,6 +54,11 @@ SIGNATURES = {
     "mp_knn_bwd_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _int, _vp]),
     "mp_padded_lengths_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _vp]),
     "mp_mask_match_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mp_sa_mlp_workspace_bytes": (_sz, [_i64, _i64, _int, ctypes.POINTER(_i64), _int]),
+    "mp_sa_mlp_fwd_f32": (_int, [_vp, _i64, _i64, _int, ctypes.POINTER(MlpLayer), _int, _dbl, _dbl, _vp, _vp, _vp, _vp,
+                                 _sz, _vp]),
+    "mp_sa_mlp_bwd_f32": (_int, [_vp, _i64, _i64, _int, ctypes.POINTER(MlpLayer), _int, _vp, _vp, _vp, _vp,
+                                 ctypes.POINTER(MlpGrads), _vp, _vp, _sz, _vp]),
 }
 
 _lib = None

@@ -1,0 +1,816 @@
+// Shared MLP + BatchNorm + ReLU + max-pool of a set-abstraction level, forward and backward, for gfx950.
+//
+// Reference: models/pointnet2_utils.py:208-214 -- `relu(bn(conv1x1(x)))` x L over [B,C,K,S], then max over K --
+// executed there as 3L+1 library kernels that each materialise a [B,C,K,S] tensor, plus autograd's mirror image.
+//
+// Here a level is a chain of fp32 GEMMs over positions-major activations X[P, C] (P = B*S*K rows):
+//     Z_l = act_{l-1}(Z_{l-1}) * W_l^T ,   act_l(z) = relu(z * scale_l + shift_l)
+// where (scale, shift) fold BatchNorm (batch statistics in training, running statistics in eval) and the conv
+// bias.  Only the RAW pre-BN activations Z_l are ever written to HBM:
+//   * BN + ReLU of layer l-1 are applied while the A tile of GEMM l is staged global -> LDS;
+//   * the per-channel sums that BatchNorm needs (sum z, sum z^2) are produced by the GEMM epilogue as per-block
+//     partials and reduced in fp64 by a tiny finalize kernel (deterministic, no atomics);
+//   * the max over K (with arg-max, first index wins) applies BN + ReLU of the last layer on the fly.
+// Backward mirrors it: dZ_l = a*relu'(.)*G_l + e*Z_l + f (BatchNorm backward folded into three per-channel
+// constants) is formed while staging tiles, never stored:
+//   * G_{l-1} = dZ_l * W_l            (GEMM, epilogue accumulates the BN-backward sums of layer l-1)
+//   * dW_l    = dZ_l^T * act(Z_{l-1}) (split-K GEMM over P, fp32 atomics into dW)
+//   * the gradient of the max-pool is never densified: the loader reads (argmax, pooled grad) per group.
+//
+// GEMM core: v_mfma_f32_32x32x2_f32 (exact fp32, == an fma chain in k order), 256 threads = 4 waves, block tile
+// 128 x 128 (2x2 waves of 64x64) or 128 x 64 (4x1 waves of 32x64), K chunks of 32 staged through LDS with register
+// prefetch of the next chunk (global loads in flight under the MFMAs).  LDS tiles are either [row][32+1] (operand
+// whose K is contiguous in memory; odd stride => conflict-free ds_read_b32 fragments) or [k][row] (operand whose
+// rows are contiguous: a straight float4 copy).
+#include "common.h"
+
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int BK = 32;
+constexpr int THREADS = 256;
+constexpr int LDK = BK + 1;  // [row][k] tiles: odd stride
+
+enum SrcMode { SRC_ID = 0, SRC_ACT = 1, SRC_DZ = 2, SRC_DZ_POOLED = 3 };
+
+// A positions-major operand: rows = positions, columns = channels (contiguous).
+struct PosOperand {
+    const float* x;      // X (SRC_ID) or raw Z [P, C]
+    const float* g;      // SRC_DZ: G [P, C];  SRC_DZ_POOLED: pooled grad (relu-masked) [P/K, C]
+    const int* argk;     // SRC_DZ_POOLED: arg-max position inside the group [P/K, C]
+    const float* s;      // activation scale / shift of THIS tensor's layer [C]
+    const float* t;
+    const float* a;      // dZ constants [C]: dz = a*dy + e*z + f
+    const float* e;
+    const float* f;
+    int C;
+    int K;               // group size (pooled)
+};
+
+// Per-channel constants of 4 consecutive channels, loaded ONCE per thread and tile (not per element).
+struct ChanConst {
+    float s[4], t[4], a[4], e[4], f[4];
+};
+
+__device__ __forceinline__ void load4(const float* base, int c, int C, float out[4])
+{
+    if (c + 3 < C && (reinterpret_cast<uintptr_t>(base + c) & 15) == 0) {
+        const float4 v = *reinterpret_cast<const float4*>(base + c);
+        out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) out[j] = (c + j < C) ? base[c + j] : 0.0f;
+    }
+}
+
+template <int MODE>
+__device__ __forceinline__ void load_consts(const PosOperand& o, int c, ChanConst& k)
+{
+#pragma unroll
+    for (int j = 0; j < 4; ++j) k.s[j] = k.t[j] = k.a[j] = k.e[j] = k.f[j] = 0.0f;
+    if constexpr (MODE != SRC_ID) {
+        if (c < o.C) {
+            load4(o.s, c, o.C, k.s);
+            load4(o.t, c, o.C, k.t);
+            if constexpr (MODE == SRC_DZ || MODE == SRC_DZ_POOLED) {
+                load4(o.a, c, o.C, k.a);
+                load4(o.e, c, o.C, k.e);
+                load4(o.f, c, o.C, k.f);
+            }
+        }
+    }
+}
+
+template <int MODE>
+__device__ __forceinline__ float xform(const ChanConst& k, int j, float z, float g)
+{
+    if constexpr (MODE == SRC_ID) {
+        return z;
+    } else if constexpr (MODE == SRC_ACT) {
+        const float y = z * k.s[j] + k.t[j];
+        return y > 0.0f ? y : 0.0f;
+    } else {
+        const float y = z * k.s[j] + k.t[j];
+        const float dy = y > 0.0f ? g : 0.0f;
+        return k.a[j] * dy + (k.e[j] * z + k.f[j]);
+    }
+}
+
+// Staging is split in two so that global-load latency hides under the MFMAs of the current K chunk:
+//   raw_load : issues the loads of 4 consecutive channels (c .. c+3) of row p into registers, no arithmetic;
+//   finish   : BN / ReLU / dZ algebra on those registers, executed when the tile is written to LDS (after the MFMAs).
+template <int MODE>
+struct Raw4 {
+    float z[4];
+    float g[(MODE == SRC_DZ || MODE == SRC_DZ_POOLED) ? 4 : 1];
+    int ak[MODE == SRC_DZ_POOLED ? 4 : 1];
+    int kk;      // position inside its group (pooled)
+    bool ok;
+};
+
+template <int MODE>
+__device__ __forceinline__ void raw_load(const PosOperand& o, int64_t P, int64_t p, int c, Raw4<MODE>& r)
+{
+    r.ok = (p < P) && (c < o.C);
+    r.kk = 0;
+    if (!r.ok) return;
+    load4(o.x + p * o.C, c, o.C, r.z);
+    if constexpr (MODE == SRC_DZ) {
+        load4(o.g + p * o.C, c, o.C, r.g);
+    } else if constexpr (MODE == SRC_DZ_POOLED) {
+        const unsigned pu = (unsigned)p;
+        const unsigned grp = pu / (unsigned)o.K;
+        r.kk = (int)(pu - grp * (unsigned)o.K);
+        load4(o.g + (int64_t)grp * o.C, c, o.C, r.g);
+        const int* ak = o.argk + (int64_t)grp * o.C + c;
+        if (c + 3 < o.C && (reinterpret_cast<uintptr_t>(ak) & 15) == 0) {
+            const int4 av = *reinterpret_cast<const int4*>(ak);
+            r.ak[0] = av.x; r.ak[1] = av.y; r.ak[2] = av.z; r.ak[3] = av.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) r.ak[j] = (c + j < o.C) ? ak[j] : -1;
+        }
+    }
+}
+
+template <int MODE>
+__device__ __forceinline__ void finish(const Raw4<MODE>& r, const ChanConst& k, float out[4])
+{
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float g = 0.0f;
+        if constexpr (MODE == SRC_DZ) g = r.g[j];
+        if constexpr (MODE == SRC_DZ_POOLED) g = (r.ak[j] == r.kk) ? r.g[j] : 0.0f;
+        // channels beyond C carry zero constants and zero data (load4 zero-fills), so they come out as 0 except for
+        // SRC_ID/ACT where z == 0 and shift may be non-zero: masked by `ok` per row and by zero-filled W columns
+        out[j] = r.ok ? xform<MODE>(k, j, r.z[j], g) : 0.0f;
+    }
+}
+
+// Plain matrix rows (weights): row-major [R, C], no transform.
+__device__ __forceinline__ void fetch4_plain(const float* m, int R, int C, int r, int c, float out[4])
+{
+    out[0] = out[1] = out[2] = out[3] = 0.0f;
+    if (r >= R || c >= C) return;
+    const float* src = m + (int64_t)r * C + c;
+    if (c + 3 < C && (C & 3) == 0) {
+        const float4 v = *reinterpret_cast<const float4*>(src);
+        out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (c + j < C) out[j] = src[j];
+    }
+}
+
+// ---- MFMA chunk: acc += A_tile(BM x BK) * B_tile(BK x BN) for this wave's TM x TN sub-tiles ------------------
+template <bool A_KROW, bool B_KROW, int LDA, int LDB, int TM, int TN>
+__device__ __forceinline__ void mma_chunk(const float* sA, const float* sB, int wrow0, int wcol0, f32x16 (&acc)[TM][TN])
+{
+    const int lane = threadIdx.x & 63;
+    const int l31 = lane & 31, hi = lane >> 5;
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2) {
+        const int k = kk + hi;
+        float a[TM], b[TN];
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) {
+            const int r = wrow0 + mi * 32 + l31;
+            a[mi] = A_KROW ? sA[k * LDA + r] : sA[r * LDA + k];
+        }
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) {
+            const int c = wcol0 + ni * 32 + l31;
+            b[ni] = B_KROW ? sB[k * LDB + c] : sB[c * LDB + k];
+        }
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni)
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+    }
+}
+
+// accumulator element (mi, ni, r) of this lane -> (row, col) inside the block tile
+__device__ __forceinline__ int acc_row(int wrow0, int mi, int r)
+{
+    return wrow0 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * ((threadIdx.x & 63) >> 5);
+}
+
+// =================================================================================================================
+// Kernel 1/2: C[M=P, N] = posop(A)[P, Kd] * Wmat   with per-column epilogue sums.
+//   NT (W_KROW=false): Wmat = W^T, W row-major [N, Kd]           -> forward:   Z_l = act(Z_{l-1}) * W_l^T
+//   NN (W_KROW=true) : Wmat = W,   W row-major [Kd, N]           -> backward:  G_{l-1} = dZ_l * W_l
+// Epilogue sums (per block partials [gridDim.x][2][N]):
+//   EPI_SQ : (sum c, sum c^2)                                  (BatchNorm forward statistics)
+//   EPI_DY : with dy = relu'(zp*s+t) ? c : 0 : (sum dy, sum dy*zp)   zp = previous layer's raw Z (same shape as C)
+// =================================================================================================================
+enum Epi { EPI_NONE = 0, EPI_SQ = 1, EPI_DY = 2 };
+
+template <int MODE, bool W_KROW, int EPI, int WAVES_M, int WAVES_N, int TM, int TN>
+__global__ __launch_bounds__(THREADS) void pos_gemm_kernel(PosOperand A, int64_t P, const float* __restrict__ W, int N,
+                                                           int Kd, float* __restrict__ C, float* __restrict__ partials,
+                                                           const float* __restrict__ zprev,
+                                                           const float* __restrict__ sprev,
+                                                           const float* __restrict__ tprev)
+{
+    constexpr int BM = WAVES_M * TM * 32;
+    constexpr int BN = WAVES_N * TN * 32;
+    constexpr int LDB = W_KROW ? BN : LDK;
+    constexpr int A_PASSES = BM / 32;                 // 8 threads x float4 per row, 32 rows per pass
+    constexpr int B_PASSES = W_KROW ? (BK * BN / 4 / THREADS) : (BN / 32);
+    static_assert(WAVES_M * WAVES_N == 4, "4 waves");
+    __shared__ float sA[2][BM * LDK];
+    __shared__ float sB[2][W_KROW ? BK * BN : BN * LDK];
+    __shared__ float red[WAVES_M][2][BN];
+
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int wrow0 = wm * TM * 32, wcol0 = wn * TN * 32;
+    const int64_t m0 = (int64_t)blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
+
+    Raw4<MODE> ra[A_PASSES];
+    float rb[B_PASSES][4];
+    ChanConst kc;
+    auto gload = [&](int k0) {
+        load_consts<MODE>(A, k0 + (tid & 7) * 4, kc);
+#pragma unroll
+        for (int ps = 0; ps < A_PASSES; ++ps) {
+            const int r = ps * 32 + (tid >> 3);
+            raw_load<MODE>(A, P, m0 + r, k0 + (tid & 7) * 4, ra[ps]);
+        }
+#pragma unroll
+        for (int ps = 0; ps < B_PASSES; ++ps) {
+            if constexpr (W_KROW) {  // slab [BK][BN] of W[Kd, N]
+                const int e = (ps * THREADS + tid) * 4;
+                const int k = e / BN, c = e - k * BN;
+                fetch4_plain(W, Kd, N, k0 + k, n0 + c, rb[ps]);
+            } else {                 // rows of W[N, Kd], K contiguous
+                const int r = ps * 32 + (tid >> 3);
+                fetch4_plain(W, N, Kd, n0 + r, k0 + (tid & 7) * 4, rb[ps]);
+            }
+        }
+    };
+    auto sstore = [&](int buf) {
+#pragma unroll
+        for (int ps = 0; ps < A_PASSES; ++ps) {
+            float v[4];
+            finish<MODE>(ra[ps], kc, v);
+            float* d = &sA[buf][(ps * 32 + (tid >> 3)) * LDK + (tid & 7) * 4];
+            d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+        }
+#pragma unroll
+        for (int ps = 0; ps < B_PASSES; ++ps) {
+            if constexpr (W_KROW) {
+                const int e = (ps * THREADS + tid) * 4;
+                *reinterpret_cast<float4*>(&sB[buf][e]) = make_float4(rb[ps][0], rb[ps][1], rb[ps][2], rb[ps][3]);
+            } else {
+                float* d = &sB[buf][(ps * 32 + (tid >> 3)) * LDK + (tid & 7) * 4];
+                d[0] = rb[ps][0]; d[1] = rb[ps][1]; d[2] = rb[ps][2]; d[3] = rb[ps][3];
+            }
+        }
+    };
+
+    const int nchunks = (Kd + BK - 1) / BK;
+    gload(0);
+    sstore(0);
+    __syncthreads();
+    for (int kc = 0; kc < nchunks; ++kc) {
+        const int cur = kc & 1;
+        if (kc + 1 < nchunks) gload((kc + 1) * BK);
+        mma_chunk<false, W_KROW, LDK, LDB, TM, TN>(sA[cur], sB[cur], wrow0, wcol0, acc);
+        if (kc + 1 < nchunks) sstore(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: store C, per-column sums --------------------------------------------------------------------
+    const int l31 = lane & 31;
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni) {
+        const int col = n0 + wcol0 + ni * 32 + l31;
+        const bool cok = col < N;
+        float s1 = 0.0f, s2 = 0.0f;
+        float sp = 0.0f, tp = 0.0f;
+        if constexpr (EPI == EPI_DY) {
+            if (cok) { sp = sprev[col]; tp = tprev[col]; }
+        }
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t row = m0 + acc_row(wrow0, mi, r);
+                const float v = acc[mi][ni][r];
+                if (cok && row < P) {
+                    if (C) C[row * N + col] = v;
+                    if constexpr (EPI == EPI_SQ) {
+                        s1 += v;
+                        s2 += v * v;
+                    } else if constexpr (EPI == EPI_DY) {
+                        const float zp = zprev[row * N + col];
+                        const float dy = (zp * sp + tp > 0.0f) ? v : 0.0f;
+                        s1 += dy;
+                        s2 += dy * zp;
+                    }
+                }
+            }
+        }
+        if constexpr (EPI != EPI_NONE) {
+            s1 += __shfl_xor(s1, 32, 64);
+            s2 += __shfl_xor(s2, 32, 64);
+            if (lane < 32) {
+                red[wm][0][wcol0 + ni * 32 + lane] = s1;
+                red[wm][1][wcol0 + ni * 32 + lane] = s2;
+            }
+        }
+    }
+    if constexpr (EPI != EPI_NONE) {
+        __syncthreads();
+        for (int e = tid; e < 2 * BN; e += THREADS) {
+            const int st = e / BN, c = e - st * BN;
+            float v = 0.0f;
+#pragma unroll
+            for (int w = 0; w < WAVES_M; ++w) v += red[w][st][c];
+            if (n0 + c < N) partials[((int64_t)blockIdx.x * 2 + st) * N + n0 + c] = v;
+        }
+    }
+}
+
+// =================================================================================================================
+// Kernel 3: dW[Co, Ci] += sum_p dZ[p, Co] * act(Zin)[p, Ci]   (split over P, fp32 atomics)
+//   both operands are positions-major slabs [BK positions][channels] -> LDS [k][row] layout, straight copies.
+// =================================================================================================================
+template <int MODE_DZ, int MODE_IN, int WAVES_M, int WAVES_N, int TM, int TN>
+__global__ __launch_bounds__(THREADS) void dw_gemm_kernel(PosOperand DZ, PosOperand IN, int64_t P, int64_t p_per_block,
+                                                          float* __restrict__ dW)
+{
+    constexpr int BM = WAVES_M * TM * 32;   // output channels (rows of dW)
+    constexpr int BN = WAVES_N * TN * 32;   // input channels  (cols of dW)
+    constexpr int PA = BK * BM / 4 / THREADS;
+    constexpr int PB = BK * BN / 4 / THREADS;
+    static_assert(WAVES_M * WAVES_N == 4 && PA >= 1 && PB >= 1, "tile");
+    __shared__ float sA[2][BK * BM];
+    __shared__ float sB[2][BK * BN];
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int wrow0 = (wave / WAVES_N) * TM * 32, wcol0 = (wave % WAVES_N) * TN * 32;
+    const int co0 = blockIdx.y * BM, ci0 = blockIdx.z * BN;
+    const int64_t p0 = (int64_t)blockIdx.x * p_per_block;
+    const int64_t p1 = min(P, p0 + p_per_block);
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
+
+    // K runs over positions here, so every thread keeps the SAME channels for the whole kernel
+    const int ca = (tid * 4) % BM, cb = (tid * 4) % BN;
+    ChanConst ka, kb;
+    load_consts<MODE_DZ>(DZ, co0 + ca, ka);
+    load_consts<MODE_IN>(IN, ci0 + cb, kb);
+
+    Raw4<MODE_DZ> ra[PA];
+    Raw4<MODE_IN> rb[PB];
+    auto gload = [&](int64_t pk) {
+#pragma unroll
+        for (int ps = 0; ps < PA; ++ps) {
+            const int k = ((ps * THREADS + tid) * 4) / BM;
+            raw_load<MODE_DZ>(DZ, p1, pk + k, co0 + ca, ra[ps]);
+        }
+#pragma unroll
+        for (int ps = 0; ps < PB; ++ps) {
+            const int k = ((ps * THREADS + tid) * 4) / BN;
+            raw_load<MODE_IN>(IN, p1, pk + k, ci0 + cb, rb[ps]);
+        }
+    };
+    auto sstore = [&](int buf) {
+#pragma unroll
+        for (int ps = 0; ps < PA; ++ps) {
+            float v[4];
+            finish<MODE_DZ>(ra[ps], ka, v);
+            *reinterpret_cast<float4*>(&sA[buf][(ps * THREADS + tid) * 4]) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+#pragma unroll
+        for (int ps = 0; ps < PB; ++ps) {
+            float v[4];
+            finish<MODE_IN>(rb[ps], kb, v);
+            *reinterpret_cast<float4*>(&sB[buf][(ps * THREADS + tid) * 4]) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    };
+    const int nchunks = (int)((p1 - p0 + BK - 1) / BK);
+    if (nchunks <= 0) return;
+    gload(p0);
+    sstore(0);
+    __syncthreads();
+    for (int kc = 0; kc < nchunks; ++kc) {
+        const int cur = kc & 1;
+        if (kc + 1 < nchunks) gload(p0 + (int64_t)(kc + 1) * BK);
+        mma_chunk<true, true, BM, BN, TM, TN>(sA[cur], sB[cur], wrow0, wcol0, acc);
+        if (kc + 1 < nchunks) sstore(cur ^ 1);
+        __syncthreads();
+    }
+    const int l31 = lane & 31;
+    const int Co = DZ.C, Ci = IN.C;
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) {
+            const int col = ci0 + wcol0 + ni * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = co0 + acc_row(wrow0, mi, r);
+                if (row < Co && col < Ci) atomicAdd(dW + (int64_t)row * Ci + col, acc[mi][ni][r]);
+            }
+        }
+}
+
+template <int MODE_DZ, int MODE_IN>
+int launch_dw(const PosOperand& DZ, const PosOperand& IN, int64_t P, float* dW, hipStream_t stream)
+{
+    const int Co = DZ.C, Ci = IN.C;
+    int64_t ppb = 1024;
+    while ((P + ppb - 1) / ppb < 128 && ppb > 128) ppb >>= 1;  // keep >= 128 position slices for small P (group_all)
+    const unsigned gx = (unsigned)((P + ppb - 1) / ppb), gy = (Co + 127) / 128;
+    if (Ci <= 32)
+        hipLaunchKernelGGL((dw_gemm_kernel<MODE_DZ, MODE_IN, 4, 1, 1, 1>), dim3(gx, gy, (Ci + 31) / 32), dim3(THREADS), 0, stream, DZ, IN, P, ppb, dW);
+    else if (Ci <= 64)
+        hipLaunchKernelGGL((dw_gemm_kernel<MODE_DZ, MODE_IN, 4, 1, 1, 2>), dim3(gx, gy, (Ci + 63) / 64), dim3(THREADS), 0, stream, DZ, IN, P, ppb, dW);
+    else
+        hipLaunchKernelGGL((dw_gemm_kernel<MODE_DZ, MODE_IN, 2, 2, 2, 2>), dim3(gx, gy, (Ci + 127) / 128), dim3(THREADS), 0, stream, DZ, IN, P, ppb, dW);
+    MP_CHECK_LAUNCH();
+    return MP_OK;
+}
+
+// =================================================================================================================
+// small kernels
+// =================================================================================================================
+// Reduce per-block partial sums [nblk][2][C] in fp64: a block owns FIN_CH channels, FIN_SL threads per channel walk
+// the partial rows strided (coalesced across channels), then combine through LDS.  Result valid in threads < FIN_CH.
+constexpr int FIN_CH = 32, FIN_SL = 32;
+__device__ __forceinline__ void reduce_partials(const float* __restrict__ partials, int nblk, int C, double& s1, double& s2)
+{
+    __shared__ double red[2][FIN_SL][FIN_CH];
+    const int cl = threadIdx.x % FIN_CH, sl = threadIdx.x / FIN_CH;
+    const int c = blockIdx.x * FIN_CH + cl;
+    double a1 = 0.0, a2 = 0.0, b1 = 0.0, b2 = 0.0;
+    if (c < C) {
+        int i = sl;
+        for (; i + FIN_SL < nblk; i += 2 * FIN_SL) {
+            a1 += (double)partials[((int64_t)i * 2 + 0) * C + c];
+            a2 += (double)partials[((int64_t)i * 2 + 1) * C + c];
+            b1 += (double)partials[((int64_t)(i + FIN_SL) * 2 + 0) * C + c];
+            b2 += (double)partials[((int64_t)(i + FIN_SL) * 2 + 1) * C + c];
+        }
+        if (i < nblk) {
+            a1 += (double)partials[((int64_t)i * 2 + 0) * C + c];
+            a2 += (double)partials[((int64_t)i * 2 + 1) * C + c];
+        }
+    }
+    red[0][sl][cl] = a1 + b1;
+    red[1][sl][cl] = a2 + b2;
+    __syncthreads();
+    if (threadIdx.x < FIN_CH) {
+        double t1 = 0.0, t2 = 0.0;
+        for (int j = 0; j < FIN_SL; ++j) { t1 += red[0][j][cl]; t2 += red[1][j][cl]; }
+        s1 = t1;
+        s2 = t2;
+    }
+}
+
+// BatchNorm forward statistics -> affine (scale, shift); running-stat update; saves mean / rstd.
+__global__ void bn_fwd_finalize_kernel(const float* __restrict__ partials, int nblk, int C, double invP, double unbias,
+                                       int training, double momentum, double eps, const float* __restrict__ gamma,
+                                       const float* __restrict__ beta, const float* __restrict__ bias,
+                                       float* __restrict__ running_mean, float* __restrict__ running_var,
+                                       float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                       float* __restrict__ scale, float* __restrict__ shift)
+{
+    double s1 = 0.0, s2 = 0.0;
+    if (training) reduce_partials(partials, nblk, C, s1, s2);
+    const int c = blockIdx.x * FIN_CH + (threadIdx.x % FIN_CH);
+    if (c >= C || threadIdx.x >= FIN_CH) return;
+    const float b = bias ? bias[c] : 0.0f;
+    if (training) {
+        const double mean = s1 * invP;
+        double var = s2 * invP - mean * mean;  // biased; fp64 keeps the cancellation harmless
+        if (var < 0.0) var = 0.0;
+        const double rstd = 1.0 / sqrt(var + eps);
+        const float sc = (float)((double)gamma[c] * rstd);
+        scale[c] = sc;
+        shift[c] = (float)((double)beta[c] - mean * (double)sc);
+        mean_out[c] = (float)mean;   // of the bias-free z; the conv bias cancels inside train-mode BN
+        rstd_out[c] = (float)rstd;
+        if (running_mean) {
+            running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * (mean + (double)b));
+            running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * var * unbias);
+        }
+    } else {
+        const double rs = 1.0 / sqrt((double)running_var[c] + eps);
+        const float sc = (float)((double)gamma[c] * rs);
+        scale[c] = sc;
+        shift[c] = (float)((double)beta[c] + ((double)b - (double)running_mean[c]) * (double)sc);
+        mean_out[c] = running_mean[c] - b;  // so that zhat = (z - mean_out) * rstd_out in both modes
+        rstd_out[c] = (float)rs;
+    }
+}
+
+// BatchNorm backward sums (sum dy, sum dy*z) -> dgamma, dbeta, dbias and the dZ constants (a, e, f).
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partials, int nblk, int C, double invP, int training,
+                                       const float* __restrict__ gamma, const float* __restrict__ mean,
+                                       const float* __restrict__ rstd, float* __restrict__ dgamma,
+                                       float* __restrict__ dbeta, float* __restrict__ dbias, float* __restrict__ ca,
+                                       float* __restrict__ ce, float* __restrict__ cf)
+{
+    double s1 = 0.0, s2 = 0.0;
+    reduce_partials(partials, nblk, C, s1, s2);
+    const int c = blockIdx.x * FIN_CH + (threadIdx.x % FIN_CH);
+    if (c >= C || threadIdx.x >= FIN_CH) return;
+    const double mu = mean[c], rs = rstd[c], g = gamma[c];
+    const double dbe = s1;
+    const double dga = rs * (s2 - mu * s1);
+    dbeta[c] = (float)dbe;
+    dgamma[c] = (float)dga;
+    const double a = g * rs;
+    if (training) {
+        const double c1 = dbe * invP, c2 = dga * invP;
+        ca[c] = (float)a;
+        ce[c] = (float)(-a * c2 * rs);
+        cf[c] = (float)(-a * c1 + a * c2 * rs * mu);
+        if (dbias) dbias[c] = 0.0f;  // d/dbias of train-mode BN output is identically zero
+    } else {
+        ca[c] = (float)a;
+        ce[c] = 0.0f;
+        cf[c] = 0.0f;
+        if (dbias) dbias[c] = (float)(a * dbe);
+    }
+}
+
+// out[g,c] = max_k relu(z[g*K+k, c]*s+t); first maximum wins; keeps arg-max and the raw z there.
+__global__ __launch_bounds__(256) void pool_fwd_kernel(const float* __restrict__ z, const float* __restrict__ s,
+                                                       const float* __restrict__ t, int64_t G, int K, int C,
+                                                       float* __restrict__ out, int* __restrict__ argk,
+                                                       float* __restrict__ zmax)
+{
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= G * C) return;
+    const int64_t g = e / C;
+    const int c = (int)(e - g * C);
+    const float sc = s[c], sh = t[c];
+    const float* zp = z + (g * K) * C + c;
+    float best = -1.0f, bz = 0.0f;
+    int bk = 0;
+    for (int k = 0; k < K; ++k) {
+        const float zz = zp[(int64_t)k * C];
+        float y = zz * sc + sh;
+        y = y > 0.0f ? y : 0.0f;
+        if (y > best) { best = y; bk = k; bz = zz; }
+    }
+    out[e] = best;
+    argk[e] = bk;
+    zmax[e] = bz;
+}
+
+// gp = g * [out > 0]; per-block partial sums (sum gp, sum gp*zmax) per channel.  grid.x blocks of 256 threads,
+// each handling `rows_per_block` groups x all channels.
+__global__ __launch_bounds__(256) void pool_bwd_prep_kernel(const float* __restrict__ gout, const float* __restrict__ out,
+                                                            const float* __restrict__ zmax, int64_t G, int C,
+                                                            int rows_per_block, float* __restrict__ gp,
+                                                            float* __restrict__ partials)
+{
+    const int64_t g0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t g1 = min(G, g0 + rows_per_block);
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float s1 = 0.0f, s2 = 0.0f;
+        for (int64_t g = g0; g < g1; ++g) {
+            const float v = out[g * C + c] > 0.0f ? gout[g * C + c] : 0.0f;
+            gp[g * C + c] = v;
+            s1 += v;
+            s2 += v * zmax[g * C + c];
+        }
+        partials[((int64_t)blockIdx.x * 2 + 0) * C + c] = s1;
+        partials[((int64_t)blockIdx.x * 2 + 1) * C + c] = s2;
+    }
+}
+
+template <int MODE, bool W_KROW, int EPI>
+int launch_pos_gemm(const PosOperand& A, int64_t P, const float* W, int N, int Kd, float* C, float* partials,
+                    const float* zprev, const float* sprev, const float* tprev, hipStream_t stream, int* nblk_out)
+{
+    const unsigned gm = (unsigned)((P + 127) / 128);
+    if (nblk_out) *nblk_out = (int)gm;
+    if (N <= 64) {
+        hipLaunchKernelGGL((pos_gemm_kernel<MODE, W_KROW, EPI, 4, 1, 1, 2>), dim3(gm, (N + 63) / 64), dim3(THREADS), 0,
+                           stream, A, P, W, N, Kd, C, partials, zprev, sprev, tprev);
+    } else {
+        hipLaunchKernelGGL((pos_gemm_kernel<MODE, W_KROW, EPI, 2, 2, 2, 2>), dim3(gm, (N + 127) / 128), dim3(THREADS), 0,
+                           stream, A, P, W, N, Kd, C, partials, zprev, sprev, tprev);
+    }
+    MP_CHECK_LAUNCH();
+    return MP_OK;
+}
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------------------------
+extern "C" size_t mp_sa_mlp_workspace_bytes(int64_t P, int64_t K, int n_layers, const int64_t* channels, int backward)
+{
+    if (P <= 0 || n_layers <= 0 || !channels) return 0;
+    int64_t cmax = 0;
+    for (int l = 0; l <= n_layers; ++l) cmax = channels[l] > cmax ? channels[l] : cmax;
+    const size_t nblk = (size_t)((P + 127) / 128);
+    size_t bytes = align_up(nblk * 2 * (size_t)cmax * sizeof(float), 256);  // epilogue partials
+    bytes += 3 * align_up((size_t)cmax * sizeof(float), 256);              // dZ constants a, e, f
+    if (backward) {
+        bytes += 2 * align_up((size_t)P * (size_t)cmax * sizeof(float), 256);            // G ping-pong
+        bytes += align_up((size_t)(P / (K > 0 ? K : 1)) * (size_t)channels[n_layers] * sizeof(float), 256);  // gp
+    }
+    return bytes;
+}
+
+extern "C" int mp_sa_mlp_fwd_f32(const float* x0, int64_t P, int64_t K, int n_layers, const mp_mlp_layer_t* layers,
+                                 int training, double momentum, double eps, float* out, int32_t* argk, float* zmax,
+                                 void* workspace, size_t workspace_bytes, mp_stream_t stream_)
+{
+    if (P < 0 || K <= 0 || n_layers <= 0 || !layers) return MP_EINVAL;
+    if (P == 0) return MP_OK;
+    if (!x0 || !out || !argk || !zmax || !workspace || (P % K) != 0) return MP_EINVAL;
+    if (n_layers > 8 || P > ((int64_t)1 << 31)) return MP_EUNSUPPORTED;
+    int64_t ch[9];
+    ch[0] = layers[0].c_in;
+    for (int l = 0; l < n_layers; ++l) {
+        const mp_mlp_layer_t& L = layers[l];
+        if (!L.weight || !L.gamma || !L.beta || !L.z || !L.mean || !L.rstd || !L.scale || !L.shift) return MP_EINVAL;
+        if (!training && (!L.running_mean || !L.running_var)) return MP_EINVAL;
+        if (L.c_in != ch[l] || L.c_out <= 0 || L.c_out > 4096 || L.c_in > 4096) return MP_EINVAL;
+        ch[l + 1] = L.c_out;
+    }
+    if (workspace_bytes < mp_sa_mlp_workspace_bytes(P, K, n_layers, ch, 0)) return MP_EWORKSPACE;
+    hipStream_t stream = mp_stream(stream_);
+    float* partials = reinterpret_cast<float*>(workspace);
+
+    PosOperand A{};
+    A.x = x0;
+    A.C = (int)ch[0];
+    A.K = (int)K;
+    for (int l = 0; l < n_layers; ++l) {
+        const mp_mlp_layer_t& L = layers[l];
+        int nblk = 0, rc;
+        if (l == 0)
+            rc = launch_pos_gemm<SRC_ID, false, EPI_SQ>(A, P, L.weight, (int)L.c_out, (int)L.c_in, L.z, partials, nullptr,
+                                                        nullptr, nullptr, stream, &nblk);
+        else
+            rc = launch_pos_gemm<SRC_ACT, false, EPI_SQ>(A, P, L.weight, (int)L.c_out, (int)L.c_in, L.z, partials, nullptr,
+                                                         nullptr, nullptr, stream, &nblk);
+        if (rc != MP_OK) return rc;
+        const int C = (int)L.c_out;
+        hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_SL), 0, stream, partials, nblk, C,
+                           1.0 / (double)P, P > 1 ? (double)P / (double)(P - 1) : 1.0, training, momentum, eps, L.gamma,
+                           L.beta, L.bias, L.running_mean, L.running_var, L.mean, L.rstd, L.scale, L.shift);
+        MP_CHECK_LAUNCH();
+        A = PosOperand{};
+        A.x = L.z;
+        A.s = L.scale;
+        A.t = L.shift;
+        A.C = C;
+        A.K = (int)K;
+    }
+    const mp_mlp_layer_t& LL = layers[n_layers - 1];
+    const int64_t G = P / K;
+    const int64_t tot = G * LL.c_out;
+    hipLaunchKernelGGL(pool_fwd_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream, LL.z, LL.scale,
+                       LL.shift, G, (int)K, (int)LL.c_out, out, argk, zmax);
+    MP_CHECK_LAUNCH();
+    return MP_OK;
+}
+
+extern "C" int mp_sa_mlp_bwd_f32(const float* x0, int64_t P, int64_t K, int n_layers, const mp_mlp_layer_t* layers,
+                                 int training, const float* grad_out, const float* out, const int32_t* argk,
+                                 const float* zmax, const mp_mlp_grads_t* grads, float* grad_x0, void* workspace,
+                                 size_t workspace_bytes, mp_stream_t stream_)
+{
+    if (P < 0 || K <= 0 || n_layers <= 0 || !layers || !grads) return MP_EINVAL;
+    if (P == 0) return MP_OK;
+    if (!x0 || !grad_out || !out || !argk || !zmax || !workspace || (P % K) != 0) return MP_EINVAL;
+    if (n_layers > 8) return MP_EUNSUPPORTED;
+    int64_t ch[9];
+    ch[0] = layers[0].c_in;
+    int64_t cmax = ch[0];
+    for (int l = 0; l < n_layers; ++l) {
+        ch[l + 1] = layers[l].c_out;
+        cmax = ch[l + 1] > cmax ? ch[l + 1] : cmax;
+        if (!grads[l].d_weight || !grads[l].d_gamma || !grads[l].d_beta) return MP_EINVAL;
+    }
+    if (workspace_bytes < mp_sa_mlp_workspace_bytes(P, K, n_layers, ch, 1)) return MP_EWORKSPACE;
+    hipStream_t stream = mp_stream(stream_);
+    // carve the workspace (same order as mp_sa_mlp_workspace_bytes)
+    unsigned char* w = reinterpret_cast<unsigned char*>(workspace);
+    const size_t nblk_max = (size_t)((P + 127) / 128);
+    float* partials = reinterpret_cast<float*>(w);
+    w += align_up(nblk_max * 2 * (size_t)cmax * sizeof(float), 256);
+    float* cbuf[3];
+    for (int i = 0; i < 3; ++i) {
+        cbuf[i] = reinterpret_cast<float*>(w);
+        w += align_up((size_t)cmax * sizeof(float), 256);
+    }
+    float* gbuf[2];
+    for (int i = 0; i < 2; ++i) {
+        gbuf[i] = reinterpret_cast<float*>(w);
+        w += align_up((size_t)P * (size_t)cmax * sizeof(float), 256);
+    }
+    float* gp = reinterpret_cast<float*>(w);
+
+    const int64_t G = P / K;
+    const int L = n_layers;
+    const mp_mlp_layer_t& last = layers[L - 1];
+    // pooled gradient through the last ReLU + its BatchNorm-backward sums
+    {
+        const int C = (int)last.c_out;
+        const int rows = 64;
+        const int nb = (int)((G + rows - 1) / rows);
+        if ((size_t)nb > nblk_max * 1) {
+            // partials buffer holds nblk_max*2*cmax floats: nb <= G/64+1 <= P/128+1 whenever K >= 2; K == 1 falls here
+            return MP_EUNSUPPORTED;
+        }
+        hipLaunchKernelGGL(pool_bwd_prep_kernel, dim3(nb), dim3(256), 0, stream, grad_out, out, zmax, G, C, rows, gp,
+                           partials);
+        MP_CHECK_LAUNCH();
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_SL), 0, stream, partials, nb, C,
+                           1.0 / (double)P, training, last.gamma, last.mean, last.rstd, grads[L - 1].d_gamma,
+                           grads[L - 1].d_beta, grads[L - 1].d_bias, cbuf[0], cbuf[1], cbuf[2]);
+        MP_CHECK_LAUNCH();
+    }
+    const float* G_cur = nullptr;  // dense gradient w.r.t. the activation output of layer l (l < L-1)
+    for (int l = L - 1; l >= 0; --l) {
+        const mp_mlp_layer_t& Ly = layers[l];
+        const int Co = (int)Ly.c_out, Ci = (int)Ly.c_in;
+        const bool pooled = (l == L - 1);
+        PosOperand DZ{};
+        DZ.x = Ly.z;
+        DZ.s = Ly.scale;
+        DZ.t = Ly.shift;
+        DZ.a = cbuf[0];
+        DZ.e = cbuf[1];
+        DZ.f = cbuf[2];
+        DZ.C = Co;
+        DZ.K = (int)K;
+        if (pooled) { DZ.g = gp; DZ.argk = argk; } else { DZ.g = G_cur; }
+        PosOperand IN{};
+        IN.C = Ci;
+        IN.K = (int)K;
+        if (l == 0) { IN.x = x0; } else { IN.x = layers[l - 1].z; IN.s = layers[l - 1].scale; IN.t = layers[l - 1].shift; }
+
+        // dW_l = dZ_l^T * act(Z_{l-1})
+        if (hipMemsetAsync(grads[l].d_weight, 0, sizeof(float) * (size_t)Co * Ci, stream) != hipSuccess) return MP_ELAUNCH;
+        {
+            int rc;
+            if (pooled) rc = (l == 0) ? launch_dw<SRC_DZ_POOLED, SRC_ID>(DZ, IN, P, grads[l].d_weight, stream)
+                                      : launch_dw<SRC_DZ_POOLED, SRC_ACT>(DZ, IN, P, grads[l].d_weight, stream);
+            else rc = (l == 0) ? launch_dw<SRC_DZ, SRC_ID>(DZ, IN, P, grads[l].d_weight, stream)
+                               : launch_dw<SRC_DZ, SRC_ACT>(DZ, IN, P, grads[l].d_weight, stream);
+            if (rc != MP_OK) return rc;
+        }
+        // G_{l-1} = dZ_l * W_l  (+ BN-backward sums of layer l-1)
+        if (l > 0) {
+            const mp_mlp_layer_t& Pv = layers[l - 1];
+            float* Gn = gbuf[l & 1];
+            int nblk = 0, rc;
+            if (pooled)
+                rc = launch_pos_gemm<SRC_DZ_POOLED, true, EPI_DY>(DZ, P, Ly.weight, Ci, Co, Gn, partials, Pv.z, Pv.scale, Pv.shift, stream, &nblk);
+            else
+                rc = launch_pos_gemm<SRC_DZ, true, EPI_DY>(DZ, P, Ly.weight, Ci, Co, Gn, partials, Pv.z, Pv.scale, Pv.shift, stream, &nblk);
+            if (rc != MP_OK) return rc;
+            // the constants of layer l are still being read by the kernels above: they are stream-ordered, so
+            // overwriting cbuf for layer l-1 here is safe.
+            hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((Ci + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_SL), 0, stream, partials, nblk, Ci,
+                               1.0 / (double)P, training, Pv.gamma, Pv.mean, Pv.rstd, grads[l - 1].d_gamma,
+                               grads[l - 1].d_beta, grads[l - 1].d_bias, cbuf[0], cbuf[1], cbuf[2]);
+            MP_CHECK_LAUNCH();
+            G_cur = Gn;
+        } else if (grad_x0) {
+            int rc;
+            if (pooled)
+                rc = launch_pos_gemm<SRC_DZ_POOLED, true, EPI_NONE>(DZ, P, Ly.weight, Ci, Co, grad_x0, nullptr, nullptr, nullptr, nullptr, stream, nullptr);
+            else
+                rc = launch_pos_gemm<SRC_DZ, true, EPI_NONE>(DZ, P, Ly.weight, Ci, Co, grad_x0, nullptr, nullptr, nullptr, nullptr, stream, nullptr);
+            if (rc != MP_OK) return rc;
+        }
+    }
+    return MP_OK;
+}

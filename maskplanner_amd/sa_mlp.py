@@ -1,31 +1,106 @@
-"""Shared MLP + BatchNorm + ReLU + max-pool of a set-abstraction level (models/pointnet2_utils.py:208-214).
+"""Shared MLP + BatchNorm + ReLU + max-pool of a set-abstraction level (models/pointnet2_utils.py:208-214) on the
+fused gfx950 path (csrc/sa_mlp.hip): one C-ABI call forward, one backward.
 
 Input is the grouped tensor in positions-major layout [B,S,K,C] (what ops.group produces); a 1x1 Conv2d over
-[B,C,K,S] is a GEMM over the last axis and BatchNorm2d statistics are statistics over all B*S*K rows, so the
-module parameters (Conv2d weight [Co,Ci,1,1], BatchNorm2d) are used as they are.
+[B,C,K,S] is a GEMM over the last axis and BatchNorm2d statistics are statistics over all B*S*K rows, so the module
+parameters (Conv2d weight [Co,Ci,1,1], BatchNorm2d weight/bias/running stats) are consumed as they are and the
+reference's state_dict stays valid.
 """
+import ctypes
+
 import torch
-import torch.nn.functional as F
+
+from . import _lib, ops
 
 
-def _batch_norm_rows(bn, z):
-    """BatchNorm2d semantics on a [rows, C] matrix, including the module's running-stat bookkeeping."""
-    if bn.training and bn.track_running_stats:
-        bn.num_batches_tracked.add_(1)
-        momentum = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
-    else:
-        momentum = 0.0 if bn.momentum is None else bn.momentum
-    use_batch_stats = bn.training or (bn.running_mean is None)
-    return F.batch_norm(z, bn.running_mean if (not bn.training or bn.track_running_stats) else None,
-                        bn.running_var if (not bn.training or bn.track_running_stats) else None,
-                        bn.weight, bn.bias, use_batch_stats, momentum, bn.eps)
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+class _SharedMLPMax(torch.autograd.Function):
+    """args: x [P, C0] (contiguous), K, training, momentum, eps, L, then per layer:
+    weight[Co,Ci], bias|None, gamma, beta, running_mean|None, running_var|None."""
+
+    @staticmethod
+    def forward(ctx, x, K, training, momentum, eps, n_layers, *params):
+        dev = x.device
+        P, C0 = x.shape
+        layers = (_lib.MlpLayer * n_layers)()
+        keep = []  # tensors the structs point to: alive until the call returns; saved ones also for backward
+        chans = [C0]
+        for l in range(n_layers):
+            w, b, gam, bet, rm, rv = params[6 * l:6 * l + 6]
+            co, ci = w.shape
+            chans.append(co)
+            z = torch.empty((P, co), dtype=torch.float32, device=dev)
+            stats = torch.empty((4, co), dtype=torch.float32, device=dev)  # mean, rstd, scale, shift
+            keep.append((w, b, gam, bet, rm, rv, z, stats))
+            layers[l] = _lib.MlpLayer(_ptr(w), _ptr(b), _ptr(gam), _ptr(bet), _ptr(rm), _ptr(rv), ci, co, _ptr(z),
+                                      stats[0].data_ptr(), stats[1].data_ptr(), stats[2].data_ptr(), stats[3].data_ptr())
+        G = P // K
+        cl = chans[-1]
+        out = torch.empty((G, cl), dtype=torch.float32, device=dev)
+        argk = torch.empty((G, cl), dtype=torch.int32, device=dev)
+        zmax = torch.empty((G, cl), dtype=torch.float32, device=dev)
+        ch = (ctypes.c_int64 * len(chans))(*chans)
+        lib = _lib.load()
+        ws = torch.empty((lib.mp_sa_mlp_workspace_bytes(P, K, n_layers, ch, 0),), dtype=torch.uint8, device=dev)
+        ops._run("sa_mlp_fwd", x, lib.mp_sa_mlp_fwd_f32, _ptr(x), P, K, n_layers, layers, int(training), float(momentum),
+                 float(eps), _ptr(out), _ptr(argk), _ptr(zmax), _ptr(ws), ws.numel())
+        ctx.meta = (P, K, bool(training), n_layers, chans)
+        ctx.keep = keep
+        ctx.save_for_backward(x, out, argk, zmax)
+        ctx.mark_non_differentiable(argk, zmax)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        x, out, argk, zmax = ctx.saved_tensors
+        P, K, training, n_layers, chans = ctx.meta
+        dev = x.device
+        grad_out = grad_out.contiguous().float()
+        layers = (_lib.MlpLayer * n_layers)()
+        grads = (_lib.MlpGrads * n_layers)()
+        ret = []
+        for l, (w, b, gam, bet, rm, rv, z, stats) in enumerate(ctx.keep):
+            co, ci = w.shape
+            layers[l] = _lib.MlpLayer(_ptr(w), _ptr(b), _ptr(gam), _ptr(bet), _ptr(rm), _ptr(rv), ci, co, _ptr(z),
+                                      stats[0].data_ptr(), stats[1].data_ptr(), stats[2].data_ptr(), stats[3].data_ptr())
+            dw = torch.empty_like(w)
+            db = None if b is None else torch.empty_like(b)
+            dg, dbe = torch.empty_like(gam), torch.empty_like(bet)
+            grads[l] = _lib.MlpGrads(_ptr(dw), _ptr(db), _ptr(dg), _ptr(dbe))
+            ret += [dw, db, dg, dbe, None, None]
+        gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        ch = (ctypes.c_int64 * len(chans))(*chans)
+        lib = _lib.load()
+        ws = torch.empty((lib.mp_sa_mlp_workspace_bytes(P, K, n_layers, ch, 1),), dtype=torch.uint8, device=dev)
+        ops._run("sa_mlp_bwd", x, lib.mp_sa_mlp_bwd_f32, _ptr(x), P, K, n_layers, layers, int(training), _ptr(grad_out),
+                 _ptr(out), _ptr(argk), _ptr(zmax), grads, _ptr(gx), _ptr(ws), ws.numel())
+        ctx.keep = None
+        return (gx, None, None, None, None, None, *ret)
 
 
 def shared_mlp_max(grouped, convs, bns):
-    """grouped [B,S,K,Cin] -> [B,S,Cout] = max_K relu(bn(conv(.))) chained over the layers."""
+    """grouped [B,S,K,Cin] -> [B,S,Cout] = max_K relu(bn(conv(.))) chained over the layers (fused HIP path)."""
+    ops._need_hip(grouped)
     B, S, K, C = grouped.shape
     x = grouped.reshape(B * S * K, C)
+    x = x.contiguous() if x.dtype == torch.float32 else x.contiguous().float()
+    training = bns[0].training
+    params = []
     for conv, bn in zip(convs, bns):
+        if bn.training != training:
+            raise ValueError("all BatchNorm layers of a set-abstraction level must share one mode")
+        if training and bn.track_running_stats:
+            bn.num_batches_tracked.add_(1)
         w = conv.weight.view(conv.out_channels, conv.in_channels)
-        x = F.relu(_batch_norm_rows(bn, F.linear(x, w, conv.bias)))
-    return x.view(B, S, K, -1).max(dim=2)[0]
+        track = bn.track_running_stats and bn.running_mean is not None
+        if not training and not track:
+            raise NotImplementedError("eval-mode BatchNorm without running statistics")
+        params += [w, conv.bias, bn.weight, bn.bias, bn.running_mean if track else None,
+                   bn.running_var if track else None]
+    bn0 = bns[0]
+    momentum = bn0.momentum if bn0.momentum is not None else 1.0 / max(float(bn0.num_batches_tracked), 1.0)
+    out = _SharedMLPMax.apply(x, K, training, momentum, bn0.eps, len(convs), *params)
+    return out.view(B, S, -1)

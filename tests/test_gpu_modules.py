@@ -204,9 +204,15 @@ def test_chamfer_other_flags_vs_torch_algebra():
         dd, ii = nn_d(a, b, 2)
         return torch.where(ii[..., 0] != seq, dd[..., 0], dd[..., 1]).sum(1)
     close(d, (attr(s, e) + attr(e, s)).mean(), "attraction", rtol=1e-5, atol=1e-6)
-    d, _ = chamfer_distance(s, e, avoid_in_sequence_collapsing=True, soft_attraction=True, point_reduction=None,
+    e2 = torch.rand(2, 30, 3, generator=g).cuda()  # unrelated clouds: most nearest neighbours are NOT the own index
+    d, _ = chamfer_distance(s, e2, avoid_in_sequence_collapsing=True, soft_attraction=True, point_reduction=None,
                             batch_reduction=None)
-    assert d.ndim == 0 and torch.isfinite(d)
+
+    def soft(a, b):
+        dd, ii = nn_d(a, b, 2)
+        m = ii[..., 0] != seq
+        return ((dd[..., 0] * m).sum(1) / m.sum(1)).mean()
+    close(d, soft(s, e2) + soft(e2, s), "soft attraction", rtol=1e-5, atol=1e-6)
     # weights and normals
     w = torch.tensor([0.5, 2.0]).cuda()
     nx, ny = F_normalize(torch.rand(2, 40, 3, generator=g)).cuda(), F_normalize(torch.rand(2, 40, 3, generator=g)).cuda()
@@ -302,6 +308,80 @@ def test_full_size_forward_loss_backward_vs_oracle(oracle):
     o_loss.backward()
     close(out, o_out, "out", rtol=1e-4, atol=1e-4)       # train-mode BN over B=4 amplifies rounding: looser than 1e-5
     close(loss, o_loss, "loss", rtol=1e-4)
+    # Gradients: BatchNorm1d over 4 samples in the heads makes d(loss)/d(early weights) ill-conditioned, so they
+    # are compared in relative L2 norm; the tight per-element check of the same kernels is the golden-vector test
+    # above and the GPU-vs-GPU comparison below.
     for name in ("sa1.mlp_convs.0.weight", "sa2.mlp_convs.2.weight", "sa3.mlp_bns.1.weight", "fc3.weight", "sm_fc3.bias"):
-        gp = dict(model.named_parameters())[name].grad
-        close(gp, sd_ref[name].grad, name, rtol=2e-3, atol=2e-4)
+        gp = dict(model.named_parameters())[name].grad.cpu()
+        gr = sd_ref[name].grad
+        rel = float((gp - gr).norm() / gr.norm())
+        assert rel < 1e-2, f"{name}: relative L2 error {rel:.3e}"
+
+
+def _torch_shared_mlp_max(grouped, convs, bns):
+    """The same level written with stock torch ops on the GPU (test-only second opinion for the fused kernels)."""
+    import torch.nn.functional as F
+    B, S, K, C = grouped.shape
+    x = grouped.reshape(B * S * K, C)
+    for conv, bn in zip(convs, bns):
+        z = F.linear(x, conv.weight.view(conv.out_channels, conv.in_channels), conv.bias)
+        x = F.relu(F.batch_norm(z, None if bn.training else bn.running_mean, None if bn.training else bn.running_var,
+                                bn.weight, bn.bias, bn.training, 0.0, bn.eps))
+    return x.view(B, S, K, -1).max(dim=2)[0]
+
+
+@pytest.mark.parametrize("shape", [(8, 512, 32, 3, [64, 64, 128]), (8, 128, 64, 131, [128, 128, 256]),
+                                   (32, 1, 128, 259, [256, 512, 1024]), (2, 40, 16, 19, [16, 24, 48])])
+@pytest.mark.parametrize("train", [True, False])
+def test_fused_sa_mlp_vs_torch_ops_full_width(shape, train):
+    """MaskPlanner's real channel widths (SA1/SA2/SA3) and an odd MSG-like shape: fused HIP level vs torch ops."""
+    from maskplanner_amd import sa_mlp
+    B, S, K, C0, mlp = shape
+    torch.manual_seed(B * S + C0)
+    convs, bns = torch.nn.ModuleList(), torch.nn.ModuleList()
+    last = C0
+    for c in mlp:
+        convs.append(torch.nn.Conv2d(last, c, 1))
+        bns.append(torch.nn.BatchNorm2d(c))
+        last = c
+    convs, bns = convs.cuda(), bns.cuda()
+    with torch.no_grad():
+        for bn in bns:
+            # both signs (max- and min-pool branches of BN->ReLU->max), but away from 0: with gamma ~ 0 every group
+            # member ties within an ulp and the arg-max (hence where the gradient lands) is decided by rounding
+            bn.weight.uniform_(0.4, 1.5).mul_(torch.where(torch.rand_like(bn.weight) < 0.25, -1.0, 1.0))
+            bn.bias.uniform_(-0.3, 0.3)
+            bn.running_mean.uniform_(-0.2, 0.2)
+            bn.running_var.uniform_(0.5, 1.5)
+    bns.train(train)
+    x = torch.randn(B, S, K, C0).cuda()
+    x[:, :, K // 2:] = x[:, :, :1]  # duplicated group members, as ball-query padding produces
+    gout = torch.randn(B, S, mlp[-1]).cuda()
+    res = []
+    for fn in (sa_mlp.shared_mlp_max, _torch_shared_mlp_max):
+        xi = x.clone().requires_grad_(True)
+        for p in list(convs.parameters()) + list(bns.parameters()):
+            p.grad = None
+        rm = [bn.running_mean.clone() for bn in bns]
+        y = fn(xi, convs, bns)
+        (y * gout).sum().backward()
+        res.append((y.detach(), xi.grad, [p.grad.clone() for p in convs.parameters()], [p.grad.clone() for p in bns.parameters()]))
+        for bn, r in zip(bns, rm):
+            bn.running_mean.copy_(r)
+    (y0, gx0, gw0, gb0), (y1, gx1, gw1, gb1) = res
+    close(y0, y1, "out", rtol=1e-5, atol=1e-5)
+    # Gradients: two fp32 implementations of BN round y differently in the last bit, so once in ~1e7 (group, channel)
+    # pairs the arg-max of two nearly equal members flips and that one gradient lands on another member.  Compare
+    # element-wise but allow a handful of such flips; weight gradients (sums over everything) in relative L2 norm.
+    h = K // 2  # members h.. duplicate member 0: only the SUM over the duplicates is defined
+    parts = [(gx0[:, :, 1:h], gx1[:, :, 1:h]),
+             (gx0[:, :, 0] + gx0[:, :, h:].sum(2), gx1[:, :, 0] + gx1[:, :, h:].sum(2))]
+    for a, b in parts:
+        bad = ((a - b).abs() > 1e-4 * max(float(b.abs().max()), 1.0) + 1e-5)
+        bad_groups = int(bad.reshape(B * S, -1).any(dim=1).sum())
+        assert bad_groups <= 4, f"grad_x differs in {bad_groups} of {B * S} groups"
+    for i, (a, b) in enumerate(zip(gw0 + gb0, gw1 + gb1)):
+        if train and i < len(gw0) and a.ndim == 1:
+            continue  # conv bias: exactly 0 in the fused path, rounding noise in torch
+        rel = float((a - b).norm() / b.norm().clamp_min(1e-6))
+        assert rel < 2e-3, f"param grad {i}: relative L2 error {rel:.2e}"
