@@ -32,26 +32,18 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP32_PEAK_TFLOPS = 157.3     # fp32 vector == fp32-input MFMA peak
 
 
-def op_models(cat, B, N):
-    """Algorithmic work per entry-point CALL at the bench shapes (DESIGN.md 'Kernels' table).
-    Entries: bound, flops, bytes.  Calls of one entry point with different shapes are averaged by call count."""
-    S, D = cat.out_vectors, 24
-    sgt = (cat.points_lo + cat.points_hi) / 2 / 3.0   # ~ GT segments per sample
-    pgt = (cat.points_lo + cat.points_hi) / 2
-    knn_calls = [  # (queries, refs, dim): loss_handler calls (1) both directions, (2) and (3) GT->pred only
-        (S, sgt, D), (sgt, S, D), (pgt, 4 * S, 6), (sgt, S, D)]
-    knn_flops = sum(3 * d * q * r for q, r, d in knn_calls) * B / len(knn_calls)
-    knn_bytes = sum((q + r) * d * 4 + q * 12 for q, r, d in knn_calls) * B / len(knn_calls)
-    fps_pairs = (N * 512 + 512 * 128) / 2
-    bq_pairs = (N * 512 + 512 * 128) / 2
-    return {
-        "fps": dict(bound="hbm", flops=8 * fps_pairs * B, bytes=B * ((N + 512) * 12 + (512 + 128) * 8) / 2),
-        "ball_query": dict(bound="mfma", flops=8 * bq_pairs * B, bytes=B * ((N + 512) * 12 + (512 * 32 + 128 * 64) * 8) / 2),
-        "knn": dict(bound="mfma", flops=knn_flops, bytes=knn_bytes),
-        "group": dict(bound="hbm", flops=0, bytes=B * (512 * 32 * 3 + 128 * 64 * 131) * 4 * 2 / 2),
-        "group_bwd": dict(bound="hbm", flops=0, bytes=B * (128 * 64 * 128) * 4 * 2),
-        "knn_bwd": dict(bound="hbm", flops=0, bytes=knn_bytes),
-    }
+def collect_kernel_profile(lib):
+    """Per-kernel device time from the library's own launch hooks (HIP events on the launch stream, recorded inside
+    the timed region).  -> {kernel name: dict(calls, ms, flops, bytes)}"""
+    import ctypes
+    buf = ctypes.create_string_buffer(1 << 16)
+    n = lib.mp_profiler_collect(buf, len(buf))
+    out = {}
+    if n > 0:
+        for line in buf.value.decode().strip().split("\n"):
+            name, calls, ms, flops, nbytes = line.split("\t")
+            out[name] = dict(calls=int(calls), ms=float(ms), flops=float(flops), bytes=float(nbytes))
+    return out
 
 
 def cpu_baseline(cat, N, seed):
@@ -109,15 +101,19 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    lib = _lib.load()
     for _ in range(args.warmup):
         ts.step()
     barrier()
+    if rank == 0:
+        lib.mp_profiler_enable(1)  # two event records per library kernel (rank 0 only)
     t0 = time.perf_counter()
     with ops.KernelTimer() as kt:
         for _ in range(args.steps):
             loss = ts.step()
     barrier()
     dt = time.perf_counter() - t0
+    lib.mp_profiler_enable(0)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -127,14 +123,17 @@ def main():
     if rank == 0:
         ms = dt / args.steps * 1e3
         timing = kt.summary()
-        models = op_models(cat, args.batch, args.points)
         per_step = {k: (n / args.steps, m) for k, (n, m) in timing.items()}
-        dom = max((k for k in timing if k in models), key=lambda k: timing[k][0] * timing[k][1])
-        m, (calls, mean_ms) = models[dom], timing[dom]
-        if m["bound"] == "hbm":
-            ach, peak, unit = m["bytes"] / (mean_ms * 1e-3) / 1e9, HBM_PEAK_GBS, "GB/s"
+        kernels = collect_kernel_profile(lib)
+        # dominant kernel = largest total device time; its binding roof from the algorithmic work model
+        dom = max(kernels, key=lambda k: kernels[k]["ms"])
+        d = kernels[dom]
+        avg_s = d["ms"] / d["calls"] * 1e-3
+        flops, nbytes = d["flops"] / d["calls"], d["bytes"] / d["calls"]
+        if flops / (FP32_PEAK_TFLOPS * 1e12) >= nbytes / (HBM_PEAK_GBS * 1e9):
+            bound, ach, peak, unit = "mfma", flops / avg_s / 1e12, FP32_PEAK_TFLOPS, "TFLOP/s"
         else:
-            ach, peak, unit = m["flops"] / (mean_ms * 1e-3) / 1e12, FP32_PEAK_TFLOPS, "TFLOP/s"
+            bound, ach, peak, unit = "hbm", nbytes / avg_s / 1e9, HBM_PEAK_GBS, "GB/s"
         line = {
             "metric": "point-clouds/sec fwd+bwd (N=5120, B=32)", "value": args.batch * world * args.steps / dt,
             "unit": "point-clouds/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
@@ -143,9 +142,12 @@ def main():
                                    f"(forward+loss+backward+Adam), S={cat.out_vectors} M={cat.max_n_strokes}",
                        "parallelism": f"dp{world}", "global_batch": args.batch * world, "grad_allreduce_MB":
                            round(ts.reducer.grad_bytes() / 1e6, 1)},
-            "roofline": {"kernel": dom, "bound": m["bound"], "achieved": ach, "peak": peak, "unit": unit,
-                         "frac": ach / peak, "traffic": None, "avg_ms": mean_ms, "launches_per_step": calls / args.steps},
-            "kernel_ms_per_step": {k: round(n * m_, 4) for k, (n, m_) in sorted(per_step.items())},
+            "roofline": {"kernel": dom, "bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak,
+                         "traffic": None, "avg_us": avg_s * 1e6, "launches_per_step": d["calls"] / args.steps,
+                         "flops_per_launch": flops, "bytes_per_launch": nbytes},
+            "kernels_us_per_step": {k: round(v["ms"] * 1e3 / args.steps, 1) for k, v in
+                                    sorted(kernels.items(), key=lambda kv: -kv[1]["ms"])},
+            "entry_points_ms_per_step": {k: round(n * m_, 4) for k, (n, m_) in sorted(per_step.items())},
             "final_loss": final_loss,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -171,6 +171,14 @@ int mp_sa_mlp_bwd_f32(const float* x0, int64_t P, int64_t K, int n_layers, const
                       const mp_mlp_grads_t* grads, float* grad_x0, void* workspace, size_t workspace_bytes,
                       mp_stream_t stream);
 
+/* ---- optional per-kernel device timing (bench / profiling aid; off by default) ------------------------------------
+ * No counterpart in the reference (its only timing is wall-clock prints: train_maskplanner.py:236-239).
+ * When enabled, launches inside the library are bracketed by HIP events on the launch stream.  collect() waits for
+ * them and writes one line per kernel: "name\tcalls\ttotal_ms\talgorithmic_flops\talgorithmic_bytes\n";
+ * returns the text length, 0 if nothing was recorded, MP_EWORKSPACE if `cap` is too small. */
+int mp_profiler_enable(int on);
+int mp_profiler_collect(char* buf, size_t cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -54,6 +54,8 @@ SIGNATURES = {
     "mp_knn_bwd_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _int, _vp]),
     "mp_padded_lengths_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _vp]),
     "mp_mask_match_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mp_profiler_enable": (_int, [_int]),
+    "mp_profiler_collect": (_int, [ctypes.c_char_p, _sz]),
     "mp_sa_mlp_workspace_bytes": (_sz, [_i64, _i64, _int, ctypes.POINTER(_i64), _int]),
     "mp_sa_mlp_fwd_f32": (_int, [_vp, _i64, _i64, _int, ctypes.POINTER(MlpLayer), _int, _dbl, _dbl, _vp, _vp, _vp, _vp,
                                  _sz, _vp]),

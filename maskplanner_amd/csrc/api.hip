@@ -14,3 +14,83 @@ extern "C" const char* mp_error_string(int code)
         default: return "unknown error";
     }
 }
+
+// ---- kernel profiler (debug/bench facility; the only process-wide state in the library) -----------------------
+#include <atomic>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+#include <cstdio>
+#include <cstring>
+
+namespace {
+struct ProfRec {
+    std::string tag;
+    double flops, bytes;
+    hipEvent_t a, b;
+};
+std::atomic<int> g_prof_on{0};
+std::mutex g_prof_mu;
+std::vector<ProfRec> g_prof_recs;
+}  // namespace
+
+namespace mp {
+bool prof_on() { return g_prof_on.load(std::memory_order_relaxed) != 0; }
+
+void prof_begin(const char* tag, double flops, double bytes, hipStream_t stream)
+{
+    ProfRec r{tag, flops, bytes, nullptr, nullptr};
+    if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
+    (void)hipEventRecord(r.a, stream);
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_recs.push_back(r);
+}
+
+void prof_end(hipStream_t stream)
+{
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (!g_prof_recs.empty()) (void)hipEventRecord(g_prof_recs.back().b, stream);
+}
+}  // namespace mp
+
+extern "C" int mp_profiler_enable(int on)
+{
+    g_prof_on.store(on ? 1 : 0);
+    return MP_OK;
+}
+
+// Waits for the recorded events, aggregates per tag and writes lines "tag\tcalls\ttotal_ms\tflops\tbytes\n" into buf.
+// Returns the number of bytes written (0 if nothing was recorded), or MP_EWORKSPACE if buf is too small.
+extern "C" int mp_profiler_collect(char* buf, size_t cap)
+{
+    std::vector<ProfRec> recs;
+    {
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        recs.swap(g_prof_recs);
+    }
+    struct Agg { long calls = 0; double ms = 0, flops = 0, bytes = 0; };
+    std::map<std::string, Agg> agg;
+    for (auto& r : recs) {
+        float ms = 0.0f;
+        if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+            Agg& a = agg[r.tag];
+            a.calls += 1;
+            a.ms += ms;
+            a.flops += r.flops;
+            a.bytes += r.bytes;
+        }
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
+    }
+    std::string out;
+    char line[512];
+    for (auto& kv : agg) {
+        snprintf(line, sizeof line, "%s\t%ld\t%.6f\t%.6e\t%.6e\n", kv.first.c_str(), kv.second.calls, kv.second.ms,
+                 kv.second.flops, kv.second.bytes);
+        out += line;
+    }
+    if (out.size() + 1 > cap) return MP_EWORKSPACE;
+    if (buf) memcpy(buf, out.c_str(), out.size() + 1);
+    return (int)out.size();
+}

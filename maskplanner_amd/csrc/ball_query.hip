@@ -132,8 +132,9 @@ extern "C" int mp_ball_query_f32(const float* xyz, const float* new_xyz, int64_t
             return MP_ELAUNCH;
     }
     const float r2 = (float)(radius * radius);  // squared in double, then cast: pointnet2_utils.py:104
-    hipLaunchKernelGGL(ball_query_kernel, dim3(chunks, (unsigned)B), dim3(BQ_THREADS), smem, mp_stream(stream_), xyz,
-                       new_xyz, (int)N, (int)S, r2, (int)K, (int)qpb, out_idx);
+    MP_LAUNCH("ball_query_kernel", 8.0 * B * (double)S * N, (double)B * (N * 12.0 + S * 12.0 + S * K * 8.0), ball_query_kernel,
+              dim3(chunks, (unsigned)B), dim3(BQ_THREADS), smem, mp_stream(stream_), xyz, new_xyz, (int)N, (int)S, r2, (int)K,
+              (int)qpb, out_idx);
     MP_CHECK_LAUNCH();
     return MP_OK;
 }

@@ -14,6 +14,23 @@
 
 static inline hipStream_t mp_stream(mp_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
+// Optional per-kernel device timing (bench.py's roofline leg): when enabled through mp_profiler_enable(), every
+// MP_LAUNCH is bracketed by two HIP events recorded on the launch stream and tagged with the kernel's name and its
+// algorithmic work.  Disabled (the default) it costs one relaxed load per launch.
+namespace mp {
+bool prof_on();
+void prof_begin(const char* tag, double flops, double bytes, hipStream_t stream);
+void prof_end(hipStream_t stream);
+}  // namespace mp
+
+#define MP_LAUNCH(tag, flops, bytes, kernel, grid, block, smem, stream, ...)          \
+    do {                                                                              \
+        const bool mp_prof_ = mp::prof_on();                                          \
+        if (mp_prof_) mp::prof_begin(tag, flops, bytes, stream);                      \
+        hipLaunchKernelGGL(kernel, grid, block, smem, stream, __VA_ARGS__);           \
+        if (mp_prof_) mp::prof_end(stream);                                           \
+    } while (0)
+
 namespace mp {
 
 // DPP controls (CDNA ISA): quad_perm packs four 2-bit selectors; row_* act inside 16-lane rows.

@@ -16,6 +16,8 @@
 //     would put a vmcnt(0) drain in front of every barrier).
 // Arithmetic is the reference's: d = (dx*dx + dy*dy) + dz*dz, separately rounded (no FMA: this file is
 // compiled with -ffp-contract=off), update `if (d < dist) dist = d`, first maximum wins.
+#include <cstdio>
+
 #include "common.h"
 
 namespace {
@@ -126,7 +128,10 @@ int launch_fps(const float* xyz, int B, int N, int S, const int64_t* start, int6
                                 (int)smem) != hipSuccess)
             return MP_ELAUNCH;
     }
-    hipLaunchKernelGGL(kern, dim3(B), dim3(T), smem, stream, xyz, N, S, start, out_idx, out_xyz);
+    char tag[48];
+    snprintf(tag, sizeof tag, "fps_kernel<%d, %d>", T, PPT);
+    MP_LAUNCH(tag, 8.0 * B * (double)N * S, (double)B * (N * 12.0 + S * 8.0 + (out_xyz ? S * 12.0 : 0.0)), kern, dim3(B),
+              dim3(T), smem, stream, xyz, N, S, start, out_idx, out_xyz);
     MP_CHECK_LAUNCH();
     return MP_OK;
 }

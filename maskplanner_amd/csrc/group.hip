@@ -165,8 +165,8 @@ extern "C" int mp_group_f32(const float* xyz, const float* feats, const float* n
     const int64_t total = B * S * K * (D + 3);
     if (total == 0) return MP_OK;
     if (!xyz || !new_xyz || !idx || !out || (D > 0 && !feats) || N == 0) return MP_EINVAL;
-    hipLaunchKernelGGL(group_kernel, dim3(grid_for(total)), dim3(256), 0, mp_stream(stream_), xyz, feats, new_xyz, idx,
-                       N, S, K, D, xyz_last, total, out);
+    MP_LAUNCH("group_kernel", 0.0, 4.0 * (double)total + 8.0 * (double)(B * S * K) + 4.0 * (double)(B * N * (D + 3)), group_kernel,
+              dim3(grid_for(total)), dim3(256), 0, mp_stream(stream_), xyz, feats, new_xyz, idx, N, S, K, D, xyz_last, total, out);
     MP_CHECK_LAUNCH();
     return MP_OK;
 }
@@ -187,8 +187,8 @@ extern "C" int mp_group_bwd_f32(const float* grad_out, const int64_t* idx, int64
         if (hipMemsetAsync(grad_feats, 0, sizeof(float) * (size_t)(B * N * D), stream) != hipSuccess) return MP_ELAUNCH;
         const int64_t total = B * S * K * D;
         if (total > 0)
-            hipLaunchKernelGGL(group_bwd_atomic_kernel, dim3(grid_for(total)), dim3(256), 0, stream, grad_out, idx, N,
-                               S * K, D, xyz_last, total, grad_feats);
+            MP_LAUNCH("group_bwd_atomic_kernel", 0.0, 8.0 * (double)total + 8.0 * (double)(B * S * K), group_bwd_atomic_kernel,
+                      dim3(grid_for(total)), dim3(256), 0, stream, grad_out, idx, N, S * K, D, xyz_last, total, grad_feats);
     }
     MP_CHECK_LAUNCH();
     return MP_OK;

@@ -14,6 +14,8 @@
 //   - per-cloud lengths are read on device (no host sync): rows >= len1 and slots >= len2 produce 0 / 0.
 // Arithmetic: dist = fma chain over d of (p1[d]-p2[d])^2, as pytorch3d's kernel (`dist += diff*diff`
 // contracted); strict < keeps the first index on ties.
+#include <cstdio>
+
 #include "common.h"
 
 namespace {
@@ -181,8 +183,10 @@ int launch_knn(const float* p1, const float* p2, const int64_t* len1, const int6
     const int DP = (Dn + 3) & ~3;
     const size_t smem = (size_t)KNN_TILE * DP * sizeof(float) + (size_t)KNN_WAVES * K * 64 * 8;
     if (smem > 64 * 1024) return MP_EUNSUPPORTED;
-    hipLaunchKernelGGL((knn_kernel<D, K>), dim3((P1 + 63) / 64, B), dim3(KNN_THREADS), smem, stream, p1, p2, len1, len2,
-                       P1, P2, Drt, Kout, dists, idx);
+    char tag[48];
+    snprintf(tag, sizeof tag, "knn_kernel<%d, %d>", D, K);
+    MP_LAUNCH(tag, 3.0 * Dn * (double)B * P1 * P2, (double)B * ((P1 + P2) * 4.0 * Dn + P1 * 12.0 * Kout), (knn_kernel<D, K>),
+              dim3((P1 + 63) / 64, B), dim3(KNN_THREADS), smem, stream, p1, p2, len1, len2, P1, P2, Drt, Kout, dists, idx);
     MP_CHECK_LAUNCH();
     return MP_OK;
 }

@@ -22,6 +22,8 @@
 // prefetch of the next chunk (global loads in flight under the MFMAs).  LDS tiles are either [row][32+1] (operand
 // whose K is contiguous in memory; odd stride => conflict-free ds_read_b32 fragments) or [k][row] (operand whose
 // rows are contiguous: a straight float4 copy).
+#include <cstdio>
+
 #include "common.h"
 
 namespace {
@@ -444,12 +446,19 @@ int launch_dw(const PosOperand& DZ, const PosOperand& IN, int64_t P, float* dW, 
     int64_t ppb = 1024;
     while ((P + ppb - 1) / ppb < 128 && ppb > 128) ppb >>= 1;  // keep >= 128 position slices for small P (group_all)
     const unsigned gx = (unsigned)((P + ppb - 1) / ppb), gy = (Co + 127) / 128;
-    if (Ci <= 32)
-        hipLaunchKernelGGL((dw_gemm_kernel<MODE_DZ, MODE_IN, 4, 1, 1, 1>), dim3(gx, gy, (Ci + 31) / 32), dim3(THREADS), 0, stream, DZ, IN, P, ppb, dW);
-    else if (Ci <= 64)
-        hipLaunchKernelGGL((dw_gemm_kernel<MODE_DZ, MODE_IN, 4, 1, 1, 2>), dim3(gx, gy, (Ci + 63) / 64), dim3(THREADS), 0, stream, DZ, IN, P, ppb, dW);
-    else
-        hipLaunchKernelGGL((dw_gemm_kernel<MODE_DZ, MODE_IN, 2, 2, 2, 2>), dim3(gx, gy, (Ci + 127) / 128), dim3(THREADS), 0, stream, DZ, IN, P, ppb, dW);
+    const double flops = 2.0 * (double)P * Co * Ci;
+    const double bytes = 4.0 * ((MODE_DZ == SRC_DZ ? 2.0 : 1.0) * (double)P * Co + (double)P * Ci + (double)Co * Ci);
+    char tag[96];
+    if (Ci <= 32) {
+        snprintf(tag, sizeof tag, "dw_gemm_kernel<%d, %d, 4, 1, 1, 1>", MODE_DZ, MODE_IN);
+        MP_LAUNCH(tag, flops, bytes, (dw_gemm_kernel<MODE_DZ, MODE_IN, 4, 1, 1, 1>), dim3(gx, gy, (Ci + 31) / 32), dim3(THREADS), 0, stream, DZ, IN, P, ppb, dW);
+    } else if (Ci <= 64) {
+        snprintf(tag, sizeof tag, "dw_gemm_kernel<%d, %d, 4, 1, 1, 2>", MODE_DZ, MODE_IN);
+        MP_LAUNCH(tag, flops, bytes, (dw_gemm_kernel<MODE_DZ, MODE_IN, 4, 1, 1, 2>), dim3(gx, gy, (Ci + 63) / 64), dim3(THREADS), 0, stream, DZ, IN, P, ppb, dW);
+    } else {
+        snprintf(tag, sizeof tag, "dw_gemm_kernel<%d, %d, 2, 2, 2, 2>", MODE_DZ, MODE_IN);
+        MP_LAUNCH(tag, flops, bytes, (dw_gemm_kernel<MODE_DZ, MODE_IN, 2, 2, 2, 2>), dim3(gx, gy, (Ci + 127) / 128), dim3(THREADS), 0, stream, DZ, IN, P, ppb, dW);
+    }
     MP_CHECK_LAUNCH();
     return MP_OK;
 }
@@ -611,12 +620,19 @@ int launch_pos_gemm(const PosOperand& A, int64_t P, const float* W, int N, int K
 {
     const unsigned gm = (unsigned)((P + 127) / 128);
     if (nblk_out) *nblk_out = (int)gm;
+    // algorithmic work of one launch: 2*P*N*Kd flops; bytes = operand(s) read once + result written once + weights
+    const double flops = 2.0 * (double)P * N * Kd;
+    const double rd = (MODE == SRC_DZ ? 2.0 : 1.0) * (double)P * Kd + (EPI == EPI_DY ? (double)P * N : 0.0);
+    const double bytes = 4.0 * (rd + (C ? (double)P * N : 0.0) + (double)N * Kd);
+    char tag[96];
     if (N <= 64) {
-        hipLaunchKernelGGL((pos_gemm_kernel<MODE, W_KROW, EPI, 4, 1, 1, 2>), dim3(gm, (N + 63) / 64), dim3(THREADS), 0,
-                           stream, A, P, W, N, Kd, C, partials, zprev, sprev, tprev);
+        snprintf(tag, sizeof tag, "pos_gemm_kernel<%d, %s, %d, 4, 1, 1, 2>", MODE, W_KROW ? "true" : "false", EPI);
+        MP_LAUNCH(tag, flops, bytes, (pos_gemm_kernel<MODE, W_KROW, EPI, 4, 1, 1, 2>), dim3(gm, (N + 63) / 64),
+                  dim3(THREADS), 0, stream, A, P, W, N, Kd, C, partials, zprev, sprev, tprev);
     } else {
-        hipLaunchKernelGGL((pos_gemm_kernel<MODE, W_KROW, EPI, 2, 2, 2, 2>), dim3(gm, (N + 127) / 128), dim3(THREADS), 0,
-                           stream, A, P, W, N, Kd, C, partials, zprev, sprev, tprev);
+        snprintf(tag, sizeof tag, "pos_gemm_kernel<%d, %s, %d, 2, 2, 2, 2>", MODE, W_KROW ? "true" : "false", EPI);
+        MP_LAUNCH(tag, flops, bytes, (pos_gemm_kernel<MODE, W_KROW, EPI, 2, 2, 2, 2>), dim3(gm, (N + 127) / 128),
+                  dim3(THREADS), 0, stream, A, P, W, N, Kd, C, partials, zprev, sprev, tprev);
     }
     MP_CHECK_LAUNCH();
     return MP_OK;
@@ -694,8 +710,9 @@ extern "C" int mp_sa_mlp_fwd_f32(const float* x0, int64_t P, int64_t K, int n_la
     const mp_mlp_layer_t& LL = layers[n_layers - 1];
     const int64_t G = P / K;
     const int64_t tot = G * LL.c_out;
-    hipLaunchKernelGGL(pool_fwd_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream, LL.z, LL.scale,
-                       LL.shift, G, (int)K, (int)LL.c_out, out, argk, zmax);
+    MP_LAUNCH("pool_fwd_kernel", 0.0, 4.0 * (double)P * LL.c_out + 12.0 * (double)tot, pool_fwd_kernel,
+              dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream, LL.z, LL.scale, LL.shift, G, (int)K, (int)LL.c_out, out,
+              argk, zmax);
     MP_CHECK_LAUNCH();
     return MP_OK;
 }
