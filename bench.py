@@ -32,6 +32,17 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP32_PEAK_TFLOPS = 157.3     # fp32 vector == fp32-input MFMA peak
 
 
+def measured_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the most recent committed PMC passes (profiles/rNN_traffic.json, made
+    by tools/make_profile_summary.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this bench)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+    if not files:
+        return None
+    k = json.load(open(files[-1]))["kernels"].get(kernel)
+    return None if k is None else k["hbm_bytes"]
+
+
 def collect_kernel_profile(lib):
     """Per-kernel device time from the library's own launch hooks (HIP events on the launch stream, recorded inside
     the timed region).  -> {kernel name: dict(calls, ms, flops, bytes)}"""
@@ -143,7 +154,7 @@ def main():
                        "parallelism": f"dp{world}", "global_batch": args.batch * world, "grad_allreduce_MB":
                            round(ts.reducer.grad_bytes() / 1e6, 1)},
             "roofline": {"kernel": dom, "bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak,
-                         "traffic": None, "avg_us": avg_s * 1e6, "launches_per_step": d["calls"] / args.steps,
+                         "traffic": measured_traffic(dom), "avg_us": avg_s * 1e6, "launches_per_step": d["calls"] / args.steps,
                          "flops_per_launch": flops, "bytes_per_launch": nbytes},
             "kernels_us_per_step": {k: round(v["ms"] * 1e3 / args.steps, 1) for k, v in
                                     sorted(kernels.items(), key=lambda kv: -kv[1]["ms"])},

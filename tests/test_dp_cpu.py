@@ -1,0 +1,92 @@
+"""Data-parallel gradient averaging (maskplanner_amd/dp.py) with world_size 2 on the gloo backend (CPU).
+
+The N>1 path of bench.py is: shard the batch by sample, backward locally, bucketed all-reduce of the flat gradient
+buffers overlapped with backward, average, optimizer step.  Here the same reducer runs on two CPU processes and
+must reproduce the single-process gradient of the mean loss over the global batch, and keep replicas identical
+after optimizer steps.
+"""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _model():
+    torch.manual_seed(7)
+    return torch.nn.Sequential(torch.nn.Linear(6, 32), torch.nn.ReLU(), torch.nn.Linear(32, 32), torch.nn.ReLU(),
+                               torch.nn.Linear(32, 5))
+
+
+def _data():
+    g = torch.Generator().manual_seed(11)
+    return torch.randn(8, 6, generator=g), torch.randn(8, 5, generator=g)
+
+
+def _worker(rank, world, port, bucket_bytes, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from maskplanner_amd import dp
+    r, _, w = dp.init_from_env(backend="gloo")
+    assert (r, w) == (rank, world)
+    model = _model()
+    red = dp.BucketedGradAllReduce(model.parameters(), bucket_bytes=bucket_bytes)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-2)
+    x, y = _data()
+    shard = slice(rank * 4, rank * 4 + 4)
+    grads = None
+    for step in range(3):
+        red.zero_grad()
+        loss = ((model(x[shard]) - y[shard]) ** 2).mean()
+        loss.backward()
+        red.finish()
+        if step == 0:
+            grads = [p.grad.clone() for p in model.parameters()]
+        opt.step()
+    out[rank] = dict(n_buckets=len(red.buckets), grads=grads, params=[p.detach().clone() for p in model.parameters()])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("bucket_bytes", [256, 1 << 20])
+def test_bucketed_allreduce_matches_global_batch_gradient(bucket_bytes):
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), bucket_bytes, out), nprocs=world, join=True)
+    # single-process reference: mean over the global batch == average of the per-shard means (equal shard sizes)
+    model = _model()
+    x, y = _data()
+    (0.5 * (((model(x[:4]) - y[:4]) ** 2).mean() + ((model(x[4:]) - y[4:]) ** 2).mean())).backward()
+    want = [p.grad for p in model.parameters()]
+    assert out[0]["n_buckets"] == out[1]["n_buckets"]
+    assert out[0]["n_buckets"] > 1 if bucket_bytes == 256 else out[0]["n_buckets"] == 1
+    for r in range(world):
+        for g, w in zip(out[r]["grads"], want):
+            torch.testing.assert_close(g, w, rtol=1e-6, atol=1e-7)
+    for a, b in zip(out[0]["params"], out[1]["params"]):
+        assert torch.equal(a, b), "replicas diverged after optimizer steps"
+
+
+def test_single_process_reducer_is_a_noop():
+    from maskplanner_amd import dp
+    model = _model()
+    red = dp.BucketedGradAllReduce(model.parameters(), bucket_bytes=512)
+    x, y = _data()
+    red.zero_grad()
+    ((model(x) - y) ** 2).mean().backward()
+    red.finish()
+    ref = _model()
+    ((ref(x) - y) ** 2).mean().backward()
+    for p, q in zip(model.parameters(), ref.parameters()):
+        torch.testing.assert_close(p.grad, q.grad)
+        assert p.grad.data_ptr() >= red.buckets[0][0].data_ptr() or len(red.buckets) > 1  # grads live in the flat buffers
+    assert red.grad_bytes() == sum(p.numel() * 4 for p in model.parameters())

@@ -1,0 +1,118 @@
+"""Host-side logic that needs no GPU: synthetic collated-batch contract, config plumbing, checkpoint-key
+compatibility, drop-in aliasing, argument validation of the reference-shaped wrappers."""
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+
+def test_synthetic_batch_contract():
+    """utils/dataset/paintnet_ODv1.py:824-845: everything f32, -100 / -1 padding, segment layout lambda*6."""
+    from maskplanner_amd import synthetic as syn
+    b = syn.make_batch(3, 4, 1024, "cuboids", "cuboid")
+    assert b["point_cloud"].shape == (4, 1024, 3) and b["point_cloud"].dtype == torch.float32
+    assert b["traj"].shape[2] == 24 and b["traj_as_pc"].shape[2] == 6 and b["stroke_ids"].dtype == torch.float32
+    for i in range(4):
+        ns, npnt = int(b["n_segments"][i]), int(b["n_points"][i])
+        assert (b["traj"][i, ns:] == -100).all() and (b["traj"][i, :ns] != -100).any(dim=1).all()
+        assert (b["stroke_ids"][i, ns:] == -1).all() and (b["stroke_ids"][i, :ns] >= 0).all()
+        assert (b["traj_as_pc"][i, npnt:] == -100).all()
+        # a segment is lambda=4 consecutive poses of one stroke, stride lambda-overlap=3
+        seg0 = b["traj"][i, 0].view(4, 6)
+        assert torch.equal(seg0, b["traj_as_pc"][i, :4])
+        assert torch.equal(b["traj"][i, 1].view(4, 6)[0], b["traj_as_pc"][i, 3])
+    assert b["traj"].shape[1] == int(b["n_segments"].max()) and b["traj_as_pc"].shape[1] == int(b["n_points"].max())
+    for cat, c in syn.CATEGORIES.items():
+        bb = syn.make_batch(1, 2, 256, cat, "ucube")
+        assert 0 < int(bb["n_points"].min()) and int(bb["n_points"].max()) <= c.points_hi
+    with pytest.raises(ValueError):
+        syn.point_cloud(np.random.default_rng(0), 1, 8, "sphere")
+
+
+def test_pose_dims_and_config_adapter():
+    from maskplanner_amd import loss_handler as lh
+    assert lh.get_dim_traj_points([]) == 3 and lh.get_dim_traj_points(["orientnorm"]) == 6
+    assert lh.get_dim_traj_points(["orientquat"]) == 7
+    with pytest.raises(ValueError):
+        lh.get_dim_traj_points(["vel", "orientnorm"])
+    cfg = lh._Config({"a": 1, "nested": 2})
+    assert cfg["a"] == 1 and cfg.a == 1 and cfg.get("zzz", 5) == 5 and "a" in cfg.keys()
+
+    class AttrCfg(dict):
+        def __getattr__(self, k):
+            return self[k]
+    assert lh._Config(AttrCfg(x=3)).x == 3
+
+
+def test_loss_handler_rejects_terms_outside_the_hot_path():
+    from maskplanner_amd.loss_handler import LossHandler, maskplanner_loss_config
+    cfg = maskplanner_loss_config()
+    LossHandler(["asymm_v6_chamfer_with_stroke_masks"], cfg)
+    with pytest.raises(NotImplementedError):
+        LossHandler(["repulsion"], cfg)
+    with pytest.raises(AssertionError):  # weight_<name> must exist, as in the reference (loss_handler.py:179-181)
+        LossHandler(["emd"], cfg)
+
+
+def test_state_dict_keys_match_the_reference(golden):
+    """Checkpoint compatibility (test_maskplanner.py:162-188): same keys, shapes and registration order."""
+    from maskplanner_amd import pointnet2_cls_ssg as pc
+    g = golden("g5_model")
+    m = pc.PointNet2Regressor_StrokeMasks(outdim=12, outdim_orient=12, weight_orient=0.25, out_vectors=99, hidden_size=(64, 64),
+                                          pred_stroke_masks=True, n_stroke_masks=6, mask_confidence_scores=True)
+    sd = m.state_dict()
+    ref = [k[3:] for k in g.files if k.startswith("sd_")]
+    assert list(sd.keys()) == ref  # np.savez preserves insertion order == the reference's registration order
+    for k in ref:
+        assert tuple(sd[k].shape) == tuple(g["sd_" + k].shape), k
+    from maskplanner_amd import synthetic
+    full = pc.maskplanner_model(synthetic.CATEGORIES["cuboids"])
+    n = sum(p.numel() for p in full.parameters())
+    assert abs(n - 35.74e6) < 0.02e6  # 35.74 M parameters for cuboids
+
+
+def test_dropin_aliases_reference_module_names():
+    from maskplanner_amd import dropin
+    saved = {k: sys.modules.get(k) for k in list(dropin._ALIASES) + ["pytorch3d", "pytorch3d.ops"]}
+    try:
+        done = dropin.install()
+        assert set(done) == set(dropin._ALIASES)
+        import maskplanner_amd.pointnet2_utils as pu
+        assert sys.modules["models.pointnet2_utils"] is pu
+        from pytorch3d.ops.knn import knn_gather, knn_points  # the import line of pytorch3d_chamfer.py:12
+        from pytorch3d.structures.pointclouds import Pointclouds  # noqa: F401  (:13)
+        assert callable(knn_points) and callable(knn_gather)
+        for name in ("square_distance", "index_points", "farthest_point_sample", "query_ball_point", "sample_and_group",
+                     "sample_and_group_all", "PointNetSetAbstraction", "PointNetSetAbstractionMsg"):
+            assert hasattr(pu, name)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+
+
+def test_wrappers_validate_like_the_reference_before_touching_the_device():
+    from maskplanner_amd.pytorch3d_chamfer import chamfer_distance
+    x = torch.rand(2, 5, 3)
+    with pytest.raises(ValueError, match="batch_reduction"):
+        chamfer_distance(x, x, batch_reduction="max")
+    with pytest.raises(ValueError, match="Expected points"):
+        chamfer_distance(x[0], x)
+    with pytest.raises(ValueError, match="should be either"):
+        chamfer_distance([1, 2], x)
+    from maskplanner_amd import knn
+    with pytest.raises(ValueError, match="batch dimension"):
+        knn.knn_points(torch.rand(2, 3, 3), torch.rand(3, 3, 3))
+
+
+def test_set_abstraction_modules_have_reference_parameters():
+    from maskplanner_amd import pointnet2_utils as pu
+    sa = pu.PointNetSetAbstraction(512, 0.2, 32, 3, [64, 64, 128], False)
+    assert [tuple(c.weight.shape) for c in sa.mlp_convs] == [(64, 3, 1, 1), (64, 64, 1, 1), (128, 64, 1, 1)]
+    assert list(sa.state_dict())[:2] == ["mlp_convs.0.weight", "mlp_convs.0.bias"]
+    msg = pu.PointNetSetAbstractionMsg(512, [0.1, 0.2, 0.4], [16, 32, 128], 0, [[32, 32, 64], [64, 64, 128], [64, 96, 128]])
+    assert "conv_blocks.2.1.weight" in msg.state_dict() and "bn_blocks.0.0.running_var" in msg.state_dict()
+    assert tuple(msg.conv_blocks[0][0].weight.shape) == (32, 3, 1, 1)
