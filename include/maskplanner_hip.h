@@ -78,14 +78,16 @@ int mp_index_points_bwd_f32(const float* grad_out, const int64_t* idx, int64_t B
  * replaces: models/pointnet2_utils.py:133-143 (sample_and_group tail) and :258-262 (MSG variant)
  *   out [B,S,K,3+D] = cat(xyz[idx] - new_xyz, feats[idx])   (xyz_last == 0, SSG order, :138)
  *                   = cat(feats[idx], xyz[idx] - new_xyz)   (xyz_last != 0, MSG order, :262)
- *   feats [B,N,D] may be NULL with D == 0.
- *   backward: grad_feats [B,N,D] = scatter-add of the feature channels of grad_out (overwritten). */
+ *   feats [B,N,D] may be NULL with D == 0.  out_stride (floats, 0 = 3+D): distance between output rows; columns
+ *   beyond 3+D are zero-filled (the fused MLP wants rows of a multiple of 4 floats).
+ *   backward: grad_feats [B,N,D] = scatter-add of the feature channels of grad_out (rows grad_stride apart;
+ *   overwritten). */
 int mp_group_f32(const float* xyz, const float* feats, const float* new_xyz, const int64_t* idx,
-                 int64_t B, int64_t N, int64_t S, int64_t K, int64_t D, int xyz_last, float* out,
-                 mp_stream_t stream);
+                 int64_t B, int64_t N, int64_t S, int64_t K, int64_t D, int xyz_last, int64_t out_stride,
+                 float* out, mp_stream_t stream);
 int mp_group_bwd_f32(const float* grad_out, const int64_t* idx, int64_t B, int64_t N, int64_t S,
-                     int64_t K, int64_t D, int xyz_last, float* grad_feats, int deterministic,
-                     mp_stream_t stream);
+                     int64_t K, int64_t D, int xyz_last, int64_t grad_stride, float* grad_feats,
+                     int deterministic, mp_stream_t stream);
 
 /* ---- K nearest neighbours (brute force) and backward ------------------------------------------------
  * replaces: pytorch3d.ops.knn.knn_points (third party; call sites pytorch3d_chamfer.py:182-183,
@@ -138,6 +140,8 @@ int mp_mask_match_f32(const float* pred_masks, const float* target_ids, int64_t 
  *   backward: grad_out [P/K, c_L] -> d_weight [c_out,c_in], d_bias (zeros in training: the bias cancels inside
  *   BN), d_gamma, d_beta per layer, and grad_x0 [P, c_0] (NULL = not needed).  d_weight is accumulated with fp32
  *   atomics over position slices (not bitwise reproducible).
+ *   Every channel count must be a multiple of 4 (zero-pad the input columns / first weight otherwise:
+ *   maskplanner_amd/sa_mlp.py does) and P * max(c) < 2^31, else MP_EUNSUPPORTED.
  *   workspace: mp_sa_mlp_workspace_bytes(P, K, L, channels[L+1], backward). */
 typedef struct {
     const float* weight;

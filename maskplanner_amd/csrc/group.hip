@@ -75,13 +75,15 @@ __global__ __launch_bounds__(256) void scatter_rows_ordered_kernel(const float* 
 __global__ __launch_bounds__(256) void group_kernel(const float* __restrict__ xyz, const float* __restrict__ feats,
                                                     const float* __restrict__ new_xyz,
                                                     const int64_t* __restrict__ idx, int64_t N, int64_t S, int64_t K,
-                                                    int64_t D, int xyz_last, int64_t total, float* __restrict__ out)
+                                                    int64_t D, int xyz_last, int64_t Cs, int64_t total,
+                                                    float* __restrict__ out)
 {
-    const int64_t C = D + 3;
+    const int64_t C = D + 3;  // logical channels; rows are Cs >= C floats apart, the tail zero-filled
     const int64_t xoff = xyz_last ? D : 0;
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
-        const int64_t row = e / C;  // (b*S + s)*K + k
-        const int64_t c = e - row * C;
+        const int64_t row = e / Cs;  // (b*S + s)*K + k
+        const int64_t c = e - row * Cs;
+        if (c >= C) { out[e] = 0.0f; continue; }
         const int64_t bs = row / K;
         const int64_t b = bs / S;
         int64_t i = idx[row];
@@ -98,10 +100,10 @@ __global__ __launch_bounds__(256) void group_kernel(const float* __restrict__ xy
 
 __global__ __launch_bounds__(256) void group_bwd_atomic_kernel(const float* __restrict__ grad_out,
                                                                const int64_t* __restrict__ idx, int64_t N, int64_t SK,
-                                                               int64_t D, int xyz_last, int64_t total,
+                                                               int64_t D, int xyz_last, int64_t Cs, int64_t total,
                                                                float* __restrict__ grad_feats)
 {
-    const int64_t C = D + 3;
+    const int64_t C = Cs;
     const int64_t foff = xyz_last ? 0 : 3;
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
         const int64_t row = e / D;
@@ -158,37 +160,41 @@ extern "C" int mp_index_points_bwd_f32(const float* grad_out, const int64_t* idx
 }
 
 extern "C" int mp_group_f32(const float* xyz, const float* feats, const float* new_xyz, const int64_t* idx,
-                            int64_t B, int64_t N, int64_t S, int64_t K, int64_t D, int xyz_last, float* out,
-                            mp_stream_t stream_)
+                            int64_t B, int64_t N, int64_t S, int64_t K, int64_t D, int xyz_last, int64_t out_stride,
+                            float* out, mp_stream_t stream_)
 {
     if (B < 0 || N < 0 || S < 0 || K < 0 || D < 0) return MP_EINVAL;
-    const int64_t total = B * S * K * (D + 3);
+    if (out_stride == 0) out_stride = D + 3;
+    if (out_stride < D + 3) return MP_EINVAL;
+    const int64_t total = B * S * K * out_stride;
     if (total == 0) return MP_OK;
     if (!xyz || !new_xyz || !idx || !out || (D > 0 && !feats) || N == 0) return MP_EINVAL;
     MP_LAUNCH("group_kernel", 0.0, 4.0 * (double)total + 8.0 * (double)(B * S * K) + 4.0 * (double)(B * N * (D + 3)), group_kernel,
-              dim3(grid_for(total)), dim3(256), 0, mp_stream(stream_), xyz, feats, new_xyz, idx, N, S, K, D, xyz_last, total, out);
+              dim3(grid_for(total)), dim3(256), 0, mp_stream(stream_), xyz, feats, new_xyz, idx, N, S, K, D, xyz_last, out_stride, total, out);
     MP_CHECK_LAUNCH();
     return MP_OK;
 }
 
 extern "C" int mp_group_bwd_f32(const float* grad_out, const int64_t* idx, int64_t B, int64_t N, int64_t S,
-                                int64_t K, int64_t D, int xyz_last, float* grad_feats, int deterministic,
-                                mp_stream_t stream_)
+                                int64_t K, int64_t D, int xyz_last, int64_t grad_stride, float* grad_feats,
+                                int deterministic, mp_stream_t stream_)
 {
     if (B < 0 || N < 0 || S < 0 || K < 0 || D < 0) return MP_EINVAL;
+    if (grad_stride == 0) grad_stride = D + 3;
+    if (grad_stride < D + 3) return MP_EINVAL;
     if (B * N * D == 0) return MP_OK;
     if (!grad_feats || (B * S * K > 0 && (!grad_out || !idx))) return MP_EINVAL;
     hipStream_t stream = mp_stream(stream_);
     if (deterministic) {
         const int64_t rows = B * N;
         hipLaunchKernelGGL(scatter_rows_ordered_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream,
-                           grad_out, idx, N, D, S * K, D + 3, (int64_t)(xyz_last ? 0 : 3), rows, grad_feats);
+                           grad_out, idx, N, D, S * K, grad_stride, (int64_t)(xyz_last ? 0 : 3), rows, grad_feats);
     } else {
         if (hipMemsetAsync(grad_feats, 0, sizeof(float) * (size_t)(B * N * D), stream) != hipSuccess) return MP_ELAUNCH;
         const int64_t total = B * S * K * D;
         if (total > 0)
             MP_LAUNCH("group_bwd_atomic_kernel", 0.0, 8.0 * (double)total + 8.0 * (double)(B * S * K), group_bwd_atomic_kernel,
-                      dim3(grid_for(total)), dim3(256), 0, stream, grad_out, idx, N, S * K, D, xyz_last, total, grad_feats);
+                      dim3(grid_for(total)), dim3(256), 0, stream, grad_out, idx, N, S * K, D, xyz_last, grad_stride, total, grad_feats);
     }
     MP_CHECK_LAUNCH();
     return MP_OK;

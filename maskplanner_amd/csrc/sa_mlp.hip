@@ -23,6 +23,7 @@
 // whose K is contiguous in memory; odd stride => conflict-free ds_read_b32 fragments) or [k][row] (operand whose
 // rows are contiguous: a straight float4 copy).
 #include <cstdio>
+#include <type_traits>
 
 #include "common.h"
 
@@ -36,7 +37,10 @@ constexpr int LDK = BK + 1;  // [row][k] tiles: odd stride
 
 enum SrcMode { SRC_ID = 0, SRC_ACT = 1, SRC_DZ = 2, SRC_DZ_POOLED = 3 };
 
-// A positions-major operand: rows = positions, columns = channels (contiguous).
+// A positions-major operand: rows = positions, columns = channels (contiguous).  Every channel count is a multiple
+// of 4 (checked on the host; the Python layer zero-pads 3 -> 4, 131 -> 132, 259 -> 260), so a float4 of channels is
+// either entirely inside or entirely outside and every global access is an aligned 16-byte one.  Element offsets
+// fit 32 bits (P * C < 2^31, checked on the host).
 struct PosOperand {
     const float* x;      // X (SRC_ID) or raw Z [P, C]
     const float* g;      // SRC_DZ: G [P, C];  SRC_DZ_POOLED: pooled grad (relu-masked) [P/K, C]
@@ -52,118 +56,97 @@ struct PosOperand {
 
 // Per-channel constants of 4 consecutive channels, loaded ONCE per thread and tile (not per element).
 struct ChanConst {
-    float s[4], t[4], a[4], e[4], f[4];
+    float4 s, t, a, e, f;
 };
 
-__device__ __forceinline__ void load4(const float* base, int c, int C, float out[4])
-{
-    if (c + 3 < C && (reinterpret_cast<uintptr_t>(base + c) & 15) == 0) {
-        const float4 v = *reinterpret_cast<const float4*>(base + c);
-        out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
-    } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) out[j] = (c + j < C) ? base[c + j] : 0.0f;
-    }
-}
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float comp(const float4& v, int j) { return j == 0 ? v.x : (j == 1 ? v.y : (j == 2 ? v.z : v.w)); }
 
 template <int MODE>
 __device__ __forceinline__ void load_consts(const PosOperand& o, int c, ChanConst& k)
 {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) k.s[j] = k.t[j] = k.a[j] = k.e[j] = k.f[j] = 0.0f;
+    const int cc = c < o.C ? c : 0;  // clamped: out-of-range channels are zeroed by the `ok` flag of their data
     if constexpr (MODE != SRC_ID) {
-        if (c < o.C) {
-            load4(o.s, c, o.C, k.s);
-            load4(o.t, c, o.C, k.t);
-            if constexpr (MODE == SRC_DZ || MODE == SRC_DZ_POOLED) {
-                load4(o.a, c, o.C, k.a);
-                load4(o.e, c, o.C, k.e);
-                load4(o.f, c, o.C, k.f);
-            }
-        }
+        k.s = ld4(o.s + cc);
+        k.t = ld4(o.t + cc);
     }
-}
-
-template <int MODE>
-__device__ __forceinline__ float xform(const ChanConst& k, int j, float z, float g)
-{
-    if constexpr (MODE == SRC_ID) {
-        return z;
-    } else if constexpr (MODE == SRC_ACT) {
-        const float y = z * k.s[j] + k.t[j];
-        return y > 0.0f ? y : 0.0f;
-    } else {
-        const float y = z * k.s[j] + k.t[j];
-        const float dy = y > 0.0f ? g : 0.0f;
-        return k.a[j] * dy + (k.e[j] * z + k.f[j]);
+    if constexpr (MODE == SRC_DZ || MODE == SRC_DZ_POOLED) {
+        k.a = ld4(o.a + cc);
+        k.e = ld4(o.e + cc);
+        k.f = ld4(o.f + cc);
     }
 }
 
 // Staging is split in two so that global-load latency hides under the MFMAs of the current K chunk:
-//   raw_load : issues the loads of 4 consecutive channels (c .. c+3) of row p into registers, no arithmetic;
+//   raw_load : issues the (unconditional, address-clamped) loads of 4 channels of one row, no arithmetic;
 //   finish   : BN / ReLU / dZ algebra on those registers, executed when the tile is written to LDS (after the MFMAs).
 template <int MODE>
 struct Raw4 {
-    float z[4];
-    float g[(MODE == SRC_DZ || MODE == SRC_DZ_POOLED) ? 4 : 1];
-    int ak[MODE == SRC_DZ_POOLED ? 4 : 1];
-    int kk;      // position inside its group (pooled)
+    float4 z;
+    float4 g;
+    int4 ak;
+    int kk;   // position inside its group (pooled)
     bool ok;
 };
 
 template <int MODE>
-__device__ __forceinline__ void raw_load(const PosOperand& o, int64_t P, int64_t p, int c, Raw4<MODE>& r)
+__device__ __forceinline__ void raw_load(const PosOperand& o, int P, int p, int c, Raw4<MODE>& r)
 {
     r.ok = (p < P) && (c < o.C);
-    r.kk = 0;
-    if (!r.ok) return;
-    load4(o.x + p * o.C, c, o.C, r.z);
+    const int pp = r.ok ? p : 0, cc = r.ok ? c : 0;
+    r.z = ld4(o.x + (size_t)((unsigned)pp * (unsigned)o.C + (unsigned)cc));
     if constexpr (MODE == SRC_DZ) {
-        load4(o.g + p * o.C, c, o.C, r.g);
+        r.g = ld4(o.g + (size_t)((unsigned)pp * (unsigned)o.C + (unsigned)cc));
     } else if constexpr (MODE == SRC_DZ_POOLED) {
-        const unsigned pu = (unsigned)p;
-        const unsigned grp = pu / (unsigned)o.K;
-        r.kk = (int)(pu - grp * (unsigned)o.K);
-        load4(o.g + (int64_t)grp * o.C, c, o.C, r.g);
-        const int* ak = o.argk + (int64_t)grp * o.C + c;
-        if (c + 3 < o.C && (reinterpret_cast<uintptr_t>(ak) & 15) == 0) {
-            const int4 av = *reinterpret_cast<const int4*>(ak);
-            r.ak[0] = av.x; r.ak[1] = av.y; r.ak[2] = av.z; r.ak[3] = av.w;
-        } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) r.ak[j] = (c + j < o.C) ? ak[j] : -1;
-        }
+        const unsigned grp = (unsigned)pp / (unsigned)o.K;
+        r.kk = pp - (int)(grp * (unsigned)o.K);
+        const size_t off = (size_t)(grp * (unsigned)o.C + (unsigned)cc);
+        r.g = ld4(o.g + off);
+        r.ak = *reinterpret_cast<const int4*>(o.argk + off);
     }
 }
 
 template <int MODE>
-__device__ __forceinline__ void finish(const Raw4<MODE>& r, const ChanConst& k, float out[4])
+__device__ __forceinline__ float xf1(float z, float g, float s, float t, float a, float e, float f)
 {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        float g = 0.0f;
-        if constexpr (MODE == SRC_DZ) g = r.g[j];
-        if constexpr (MODE == SRC_DZ_POOLED) g = (r.ak[j] == r.kk) ? r.g[j] : 0.0f;
-        // channels beyond C carry zero constants and zero data (load4 zero-fills), so they come out as 0 except for
-        // SRC_ID/ACT where z == 0 and shift may be non-zero: masked by `ok` per row and by zero-filled W columns
-        out[j] = r.ok ? xform<MODE>(k, j, r.z[j], g) : 0.0f;
+    if constexpr (MODE == SRC_ID) {
+        return z;
+    } else if constexpr (MODE == SRC_ACT) {
+        const float y = z * s + t;
+        return y > 0.0f ? y : 0.0f;
+    } else {
+        const float y = z * s + t;
+        const float dy = y > 0.0f ? g : 0.0f;
+        return a * dy + (e * z + f);
     }
 }
 
-// Plain matrix rows (weights): row-major [R, C], no transform.
-__device__ __forceinline__ void fetch4_plain(const float* m, int R, int C, int r, int c, float out[4])
+template <int MODE>
+__device__ __forceinline__ float4 finish(const Raw4<MODE>& r, const ChanConst& k)
 {
-    out[0] = out[1] = out[2] = out[3] = 0.0f;
-    if (r >= R || c >= C) return;
-    const float* src = m + (int64_t)r * C + c;
-    if (c + 3 < C && (C & 3) == 0) {
-        const float4 v = *reinterpret_cast<const float4*>(src);
-        out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
-    } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (c + j < C) out[j] = src[j];
+    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (MODE == SRC_DZ) g = r.g;
+    if constexpr (MODE == SRC_DZ_POOLED) {
+        g.x = r.ak.x == r.kk ? r.g.x : 0.0f;
+        g.y = r.ak.y == r.kk ? r.g.y : 0.0f;
+        g.z = r.ak.z == r.kk ? r.g.z : 0.0f;
+        g.w = r.ak.w == r.kk ? r.g.w : 0.0f;
     }
+    float4 o;
+    o.x = xf1<MODE>(r.z.x, g.x, k.s.x, k.t.x, k.a.x, k.e.x, k.f.x);
+    o.y = xf1<MODE>(r.z.y, g.y, k.s.y, k.t.y, k.a.y, k.e.y, k.f.y);
+    o.z = xf1<MODE>(r.z.z, g.z, k.s.z, k.t.z, k.a.z, k.e.z, k.f.z);
+    o.w = xf1<MODE>(r.z.w, g.w, k.s.w, k.t.w, k.a.w, k.e.w, k.f.w);
+    if (!r.ok) o = make_float4(0.f, 0.f, 0.f, 0.f);
+    return o;
+}
+
+// Plain matrix rows (weights): row-major [R, C] with C % 4 == 0, no transform, zero outside.
+__device__ __forceinline__ float4 ld4_plain(const float* m, int R, int C, int r, int c)
+{
+    const bool ok = r < R && c < C;
+    const float4 v = ld4(m + (size_t)((unsigned)(ok ? r : 0) * (unsigned)C + (unsigned)(ok ? c : 0)));
+    return ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
 // ---- MFMA chunk: acc += A_tile(BM x BK) * B_tile(BK x BN) for this wave's TM x TN sub-tiles ------------------
@@ -194,11 +177,8 @@ __device__ __forceinline__ void mma_chunk(const float* sA, const float* sB, int 
     }
 }
 
-// accumulator element (mi, ni, r) of this lane -> (row, col) inside the block tile
-__device__ __forceinline__ int acc_row(int wrow0, int mi, int r)
-{
-    return wrow0 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * ((threadIdx.x & 63) >> 5);
-}
+// accumulator register r of this lane -> row inside a 32-row MFMA tile
+__device__ __forceinline__ int acc_row_in_tile(int r) { return (r & 3) + 8 * (r >> 2) + 4 * ((threadIdx.x & 63) >> 5); }
 
 // =================================================================================================================
 // Kernel 1/2: C[M=P, N] = posop(A)[P, Kd] * Wmat   with per-column epilogue sums.
@@ -211,7 +191,7 @@ __device__ __forceinline__ int acc_row(int wrow0, int mi, int r)
 enum Epi { EPI_NONE = 0, EPI_SQ = 1, EPI_DY = 2 };
 
 template <int MODE, bool W_KROW, int EPI, int WAVES_M, int WAVES_N, int TM, int TN>
-__global__ __launch_bounds__(THREADS) void pos_gemm_kernel(PosOperand A, int64_t P, const float* __restrict__ W, int N,
+__global__ __launch_bounds__(THREADS) void pos_gemm_kernel(PosOperand A, int P, const float* __restrict__ W, int N,
                                                            int Kd, float* __restrict__ C, float* __restrict__ partials,
                                                            const float* __restrict__ zprev,
                                                            const float* __restrict__ sprev,
@@ -231,7 +211,7 @@ __global__ __launch_bounds__(THREADS) void pos_gemm_kernel(PosOperand A, int64_t
     const int wave = tid >> 6, lane = tid & 63;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int wrow0 = wm * TM * 32, wcol0 = wn * TN * 32;
-    const int64_t m0 = (int64_t)blockIdx.x * BM;
+    const int m0 = blockIdx.x * BM;
     const int n0 = blockIdx.y * BN;
 
     f32x16 acc[TM][TN];
@@ -243,43 +223,37 @@ __global__ __launch_bounds__(THREADS) void pos_gemm_kernel(PosOperand A, int64_t
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
 
     Raw4<MODE> ra[A_PASSES];
-    float rb[B_PASSES][4];
+    float4 rb[B_PASSES];
     ChanConst kc;
+    const int arow = tid >> 3, acol = (tid & 7) * 4;
     auto gload = [&](int k0) {
-        load_consts<MODE>(A, k0 + (tid & 7) * 4, kc);
+        load_consts<MODE>(A, k0 + acol, kc);
 #pragma unroll
-        for (int ps = 0; ps < A_PASSES; ++ps) {
-            const int r = ps * 32 + (tid >> 3);
-            raw_load<MODE>(A, P, m0 + r, k0 + (tid & 7) * 4, ra[ps]);
-        }
+        for (int ps = 0; ps < A_PASSES; ++ps) raw_load<MODE>(A, P, m0 + ps * 32 + arow, k0 + acol, ra[ps]);
 #pragma unroll
         for (int ps = 0; ps < B_PASSES; ++ps) {
             if constexpr (W_KROW) {  // slab [BK][BN] of W[Kd, N]
                 const int e = (ps * THREADS + tid) * 4;
-                const int k = e / BN, c = e - k * BN;
-                fetch4_plain(W, Kd, N, k0 + k, n0 + c, rb[ps]);
+                rb[ps] = ld4_plain(W, Kd, N, k0 + e / BN, n0 + e % BN);
             } else {                 // rows of W[N, Kd], K contiguous
-                const int r = ps * 32 + (tid >> 3);
-                fetch4_plain(W, N, Kd, n0 + r, k0 + (tid & 7) * 4, rb[ps]);
+                rb[ps] = ld4_plain(W, N, Kd, n0 + ps * 32 + arow, k0 + acol);
             }
         }
     };
     auto sstore = [&](int buf) {
 #pragma unroll
         for (int ps = 0; ps < A_PASSES; ++ps) {
-            float v[4];
-            finish<MODE>(ra[ps], kc, v);
-            float* d = &sA[buf][(ps * 32 + (tid >> 3)) * LDK + (tid & 7) * 4];
-            d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+            const float4 v = finish<MODE>(ra[ps], kc);
+            float* d = &sA[buf][(ps * 32 + arow) * LDK + acol];
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
         }
 #pragma unroll
         for (int ps = 0; ps < B_PASSES; ++ps) {
             if constexpr (W_KROW) {
-                const int e = (ps * THREADS + tid) * 4;
-                *reinterpret_cast<float4*>(&sB[buf][e]) = make_float4(rb[ps][0], rb[ps][1], rb[ps][2], rb[ps][3]);
+                *reinterpret_cast<float4*>(&sB[buf][(ps * THREADS + tid) * 4]) = rb[ps];
             } else {
-                float* d = &sB[buf][(ps * 32 + (tid >> 3)) * LDK + (tid & 7) * 4];
-                d[0] = rb[ps][0]; d[1] = rb[ps][1]; d[2] = rb[ps][2]; d[3] = rb[ps][3];
+                float* d = &sB[buf][(ps * 32 + arow) * LDK + acol];
+                d[0] = rb[ps].x; d[1] = rb[ps].y; d[2] = rb[ps].z; d[3] = rb[ps].w;
             }
         }
     };
@@ -288,54 +262,65 @@ __global__ __launch_bounds__(THREADS) void pos_gemm_kernel(PosOperand A, int64_t
     gload(0);
     sstore(0);
     __syncthreads();
-    for (int kc = 0; kc < nchunks; ++kc) {
-        const int cur = kc & 1;
-        if (kc + 1 < nchunks) gload((kc + 1) * BK);
+    for (int kc_ = 0; kc_ < nchunks; ++kc_) {
+        const int cur = kc_ & 1;
+        if (kc_ + 1 < nchunks) gload((kc_ + 1) * BK);
         mma_chunk<false, W_KROW, LDK, LDB, TM, TN>(sA[cur], sB[cur], wrow0, wcol0, acc);
-        if (kc + 1 < nchunks) sstore(cur ^ 1);
+        if (kc_ + 1 < nchunks) sstore(cur ^ 1);
         __syncthreads();
     }
 
-    // ---- epilogue: store C, per-column sums --------------------------------------------------------------------
+    // ---- epilogue: store C, per-column sums.  One uniform branch selects the unchecked body for interior tiles. ----
     const int l31 = lane & 31;
+    const bool interior = (m0 + BM <= P) && (n0 + BN <= N);
+    auto epilogue = [&](auto checked_tag) {
+        constexpr bool CHECKED = decltype(checked_tag)::value;
 #pragma unroll
-    for (int ni = 0; ni < TN; ++ni) {
-        const int col = n0 + wcol0 + ni * 32 + l31;
-        const bool cok = col < N;
-        float s1 = 0.0f, s2 = 0.0f;
-        float sp = 0.0f, tp = 0.0f;
-        if constexpr (EPI == EPI_DY) {
-            if (cok) { sp = sprev[col]; tp = tprev[col]; }
-        }
+        for (int ni = 0; ni < TN; ++ni) {
+            const int col = n0 + wcol0 + ni * 32 + l31;
+            const bool cok = !CHECKED || col < N;
+            float s1 = 0.0f, s2 = 0.0f, sp = 0.0f, tp = 0.0f;
+            if constexpr (EPI == EPI_DY) {
+                if (cok) { sp = sprev[col]; tp = tprev[col]; }
+            }
 #pragma unroll
-        for (int mi = 0; mi < TM; ++mi) {
+            for (int mi = 0; mi < TM; ++mi) {
+                const int rbase = m0 + wrow0 + mi * 32;
+                float zp[16];
+                if constexpr (EPI == EPI_DY) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int64_t row = m0 + acc_row(wrow0, mi, r);
-                const float v = acc[mi][ni][r];
-                if (cok && row < P) {
-                    if (C) C[row * N + col] = v;
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = rbase + acc_row_in_tile(r);
+                        const bool ok = cok && (!CHECKED || row < P);
+                        zp[r] = ok ? zprev[(size_t)((unsigned)row * (unsigned)N + (unsigned)col)] : 0.0f;
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = rbase + acc_row_in_tile(r);
+                    const bool ok = cok && (!CHECKED || row < P);
+                    const float v = acc[mi][ni][r];
+                    if (ok && C) C[(size_t)((unsigned)row * (unsigned)N + (unsigned)col)] = v;
                     if constexpr (EPI == EPI_SQ) {
-                        s1 += v;
-                        s2 += v * v;
+                        if (ok) { s1 += v; s2 += v * v; }
                     } else if constexpr (EPI == EPI_DY) {
-                        const float zp = zprev[row * N + col];
-                        const float dy = (zp * sp + tp > 0.0f) ? v : 0.0f;
+                        const float dy = (ok && zp[r] * sp + tp > 0.0f) ? v : 0.0f;
                         s1 += dy;
-                        s2 += dy * zp;
+                        s2 += dy * zp[r];
                     }
                 }
             }
-        }
-        if constexpr (EPI != EPI_NONE) {
-            s1 += __shfl_xor(s1, 32, 64);
-            s2 += __shfl_xor(s2, 32, 64);
-            if (lane < 32) {
-                red[wm][0][wcol0 + ni * 32 + lane] = s1;
-                red[wm][1][wcol0 + ni * 32 + lane] = s2;
+            if constexpr (EPI != EPI_NONE) {
+                s1 += __shfl_xor(s1, 32, 64);
+                s2 += __shfl_xor(s2, 32, 64);
+                if (lane < 32) {
+                    red[wm][0][wcol0 + ni * 32 + lane] = s1;
+                    red[wm][1][wcol0 + ni * 32 + lane] = s2;
+                }
             }
         }
-    }
+    };
+    if (interior) epilogue(std::false_type{}); else epilogue(std::true_type{});
     if constexpr (EPI != EPI_NONE) {
         __syncthreads();
         for (int e = tid; e < 2 * BN; e += THREADS) {
@@ -343,7 +328,7 @@ __global__ __launch_bounds__(THREADS) void pos_gemm_kernel(PosOperand A, int64_t
             float v = 0.0f;
 #pragma unroll
             for (int w = 0; w < WAVES_M; ++w) v += red[w][st][c];
-            if (n0 + c < N) partials[((int64_t)blockIdx.x * 2 + st) * N + n0 + c] = v;
+            if (n0 + c < N) partials[((size_t)blockIdx.x * 2 + st) * N + n0 + c] = v;
         }
     }
 }
@@ -353,7 +338,7 @@ __global__ __launch_bounds__(THREADS) void pos_gemm_kernel(PosOperand A, int64_t
 //   both operands are positions-major slabs [BK positions][channels] -> LDS [k][row] layout, straight copies.
 // =================================================================================================================
 template <int MODE_DZ, int MODE_IN, int WAVES_M, int WAVES_N, int TM, int TN>
-__global__ __launch_bounds__(THREADS) void dw_gemm_kernel(PosOperand DZ, PosOperand IN, int64_t P, int64_t p_per_block,
+__global__ __launch_bounds__(THREADS) void dw_gemm_kernel(PosOperand DZ, PosOperand IN, int P, int p_per_block,
                                                           float* __restrict__ dW)
 {
     constexpr int BM = WAVES_M * TM * 32;   // output channels (rows of dW)
@@ -367,8 +352,8 @@ __global__ __launch_bounds__(THREADS) void dw_gemm_kernel(PosOperand DZ, PosOper
     const int wave = tid >> 6, lane = tid & 63;
     const int wrow0 = (wave / WAVES_N) * TM * 32, wcol0 = (wave % WAVES_N) * TN * 32;
     const int co0 = blockIdx.y * BM, ci0 = blockIdx.z * BN;
-    const int64_t p0 = (int64_t)blockIdx.x * p_per_block;
-    const int64_t p1 = min(P, p0 + p_per_block);
+    const int p0 = blockIdx.x * p_per_block;
+    const int p1 = min(P, p0 + p_per_block);
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -380,46 +365,36 @@ __global__ __launch_bounds__(THREADS) void dw_gemm_kernel(PosOperand DZ, PosOper
 
     // K runs over positions here, so every thread keeps the SAME channels for the whole kernel
     const int ca = (tid * 4) % BM, cb = (tid * 4) % BN;
+    const int ka0 = (tid * 4) / BM, kb0 = (tid * 4) / BN;       // first slab row of this thread
+    constexpr int KA_STEP = THREADS * 4 / BM, KB_STEP = THREADS * 4 / BN;
     ChanConst ka, kb;
     load_consts<MODE_DZ>(DZ, co0 + ca, ka);
     load_consts<MODE_IN>(IN, ci0 + cb, kb);
 
     Raw4<MODE_DZ> ra[PA];
     Raw4<MODE_IN> rb[PB];
-    auto gload = [&](int64_t pk) {
+    auto gload = [&](int pk) {
 #pragma unroll
-        for (int ps = 0; ps < PA; ++ps) {
-            const int k = ((ps * THREADS + tid) * 4) / BM;
-            raw_load<MODE_DZ>(DZ, p1, pk + k, co0 + ca, ra[ps]);
-        }
+        for (int ps = 0; ps < PA; ++ps) raw_load<MODE_DZ>(DZ, p1, pk + ka0 + ps * KA_STEP, co0 + ca, ra[ps]);
 #pragma unroll
-        for (int ps = 0; ps < PB; ++ps) {
-            const int k = ((ps * THREADS + tid) * 4) / BN;
-            raw_load<MODE_IN>(IN, p1, pk + k, ci0 + cb, rb[ps]);
-        }
+        for (int ps = 0; ps < PB; ++ps) raw_load<MODE_IN>(IN, p1, pk + kb0 + ps * KB_STEP, ci0 + cb, rb[ps]);
     };
     auto sstore = [&](int buf) {
 #pragma unroll
-        for (int ps = 0; ps < PA; ++ps) {
-            float v[4];
-            finish<MODE_DZ>(ra[ps], ka, v);
-            *reinterpret_cast<float4*>(&sA[buf][(ps * THREADS + tid) * 4]) = make_float4(v[0], v[1], v[2], v[3]);
-        }
+        for (int ps = 0; ps < PA; ++ps)
+            *reinterpret_cast<float4*>(&sA[buf][(ps * THREADS + tid) * 4]) = finish<MODE_DZ>(ra[ps], ka);
 #pragma unroll
-        for (int ps = 0; ps < PB; ++ps) {
-            float v[4];
-            finish<MODE_IN>(rb[ps], kb, v);
-            *reinterpret_cast<float4*>(&sB[buf][(ps * THREADS + tid) * 4]) = make_float4(v[0], v[1], v[2], v[3]);
-        }
+        for (int ps = 0; ps < PB; ++ps)
+            *reinterpret_cast<float4*>(&sB[buf][(ps * THREADS + tid) * 4]) = finish<MODE_IN>(rb[ps], kb);
     };
-    const int nchunks = (int)((p1 - p0 + BK - 1) / BK);
+    const int nchunks = (p1 - p0 + BK - 1) / BK;
     if (nchunks <= 0) return;
     gload(p0);
     sstore(0);
     __syncthreads();
     for (int kc = 0; kc < nchunks; ++kc) {
         const int cur = kc & 1;
-        if (kc + 1 < nchunks) gload(p0 + (int64_t)(kc + 1) * BK);
+        if (kc + 1 < nchunks) gload(p0 + (kc + 1) * BK);
         mma_chunk<true, true, BM, BN, TM, TN>(sA[cur], sB[cur], wrow0, wcol0, acc);
         if (kc + 1 < nchunks) sstore(cur ^ 1);
         __syncthreads();
@@ -433,17 +408,18 @@ __global__ __launch_bounds__(THREADS) void dw_gemm_kernel(PosOperand DZ, PosOper
             const int col = ci0 + wcol0 + ni * 32 + l31;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = co0 + acc_row(wrow0, mi, r);
-                if (row < Co && col < Ci) atomicAdd(dW + (int64_t)row * Ci + col, acc[mi][ni][r]);
+                const int row = co0 + wrow0 + mi * 32 + acc_row_in_tile(r);
+                if (row < Co && col < Ci) atomicAdd(dW + (size_t)((unsigned)row * (unsigned)Ci + (unsigned)col), acc[mi][ni][r]);
             }
         }
 }
 
 template <int MODE_DZ, int MODE_IN>
-int launch_dw(const PosOperand& DZ, const PosOperand& IN, int64_t P, float* dW, hipStream_t stream)
+int launch_dw(const PosOperand& DZ, const PosOperand& IN, int64_t P64, float* dW, hipStream_t stream)
 {
     const int Co = DZ.C, Ci = IN.C;
-    int64_t ppb = 1024;
+    const int P = (int)P64;
+    int ppb = 1024;
     while ((P + ppb - 1) / ppb < 128 && ppb > 128) ppb >>= 1;  // keep >= 128 position slices for small P (group_all)
     const unsigned gx = (unsigned)((P + ppb - 1) / ppb), gy = (Co + 127) / 128;
     const double flops = 2.0 * (double)P * Co * Ci;
@@ -628,11 +604,11 @@ int launch_pos_gemm(const PosOperand& A, int64_t P, const float* W, int N, int K
     if (N <= 64) {
         snprintf(tag, sizeof tag, "pos_gemm_kernel<%d, %s, %d, 4, 1, 1, 2>", MODE, W_KROW ? "true" : "false", EPI);
         MP_LAUNCH(tag, flops, bytes, (pos_gemm_kernel<MODE, W_KROW, EPI, 4, 1, 1, 2>), dim3(gm, (N + 63) / 64),
-                  dim3(THREADS), 0, stream, A, P, W, N, Kd, C, partials, zprev, sprev, tprev);
+                  dim3(THREADS), 0, stream, A, (int)P, W, N, Kd, C, partials, zprev, sprev, tprev);
     } else {
         snprintf(tag, sizeof tag, "pos_gemm_kernel<%d, %s, %d, 2, 2, 2, 2>", MODE, W_KROW ? "true" : "false", EPI);
         MP_LAUNCH(tag, flops, bytes, (pos_gemm_kernel<MODE, W_KROW, EPI, 2, 2, 2, 2>), dim3(gm, (N + 127) / 128),
-                  dim3(THREADS), 0, stream, A, P, W, N, Kd, C, partials, zprev, sprev, tprev);
+                  dim3(THREADS), 0, stream, A, (int)P, W, N, Kd, C, partials, zprev, sprev, tprev);
     }
     MP_CHECK_LAUNCH();
     return MP_OK;
@@ -675,6 +651,8 @@ extern "C" int mp_sa_mlp_fwd_f32(const float* x0, int64_t P, int64_t K, int n_la
         if (!L.weight || !L.gamma || !L.beta || !L.z || !L.mean || !L.rstd || !L.scale || !L.shift) return MP_EINVAL;
         if (!training && (!L.running_mean || !L.running_var)) return MP_EINVAL;
         if (L.c_in != ch[l] || L.c_out <= 0 || L.c_out > 4096 || L.c_in > 4096) return MP_EINVAL;
+        if ((L.c_in & 3) || (L.c_out & 3)) return MP_EUNSUPPORTED;      // float4 granularity: pad channels to x4
+        if (P * (L.c_in > L.c_out ? L.c_in : L.c_out) >= ((int64_t)1 << 31)) return MP_EUNSUPPORTED;  // 32-bit offsets
         ch[l + 1] = L.c_out;
     }
     if (workspace_bytes < mp_sa_mlp_workspace_bytes(P, K, n_layers, ch, 0)) return MP_EWORKSPACE;
@@ -733,7 +711,9 @@ extern "C" int mp_sa_mlp_bwd_f32(const float* x0, int64_t P, int64_t K, int n_la
         ch[l + 1] = layers[l].c_out;
         cmax = ch[l + 1] > cmax ? ch[l + 1] : cmax;
         if (!grads[l].d_weight || !grads[l].d_gamma || !grads[l].d_beta) return MP_EINVAL;
+        if ((layers[l].c_in & 3) || (layers[l].c_out & 3)) return MP_EUNSUPPORTED;
     }
+    if (P * cmax >= ((int64_t)1 << 31)) return MP_EUNSUPPORTED;
     if (workspace_bytes < mp_sa_mlp_workspace_bytes(P, K, n_layers, ch, 1)) return MP_EWORKSPACE;
     hipStream_t stream = mp_stream(stream_);
     // carve the workspace (same order as mp_sa_mlp_workspace_bytes)

@@ -181,37 +181,42 @@ def index_points(points, idx):
 
 class _Group(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, xyz, feats, new_xyz, idx, xyz_last):
+    def forward(ctx, xyz, feats, new_xyz, idx, xyz_last, stride):
         B, N, _ = xyz.shape
         _, S, K = idx.shape
         D = 0 if feats is None else feats.shape[2]
-        out = torch.empty((B, S, K, D + 3), dtype=torch.float32, device=xyz.device)
-        _run("group", xyz, _lib.load().mp_group_f32, _p(xyz), _p(feats), _p(new_xyz), _p(idx), B, N, S, K, D, int(xyz_last), _p(out))
+        out = torch.empty((B, S, K, stride), dtype=torch.float32, device=xyz.device)
+        _run("group", xyz, _lib.load().mp_group_f32, _p(xyz), _p(feats), _p(new_xyz), _p(idx), B, N, S, K, D, int(xyz_last),
+             stride, _p(out))
         ctx.save_for_backward(idx)
-        ctx.dims = (B, N, S, K, D, int(xyz_last))
+        ctx.dims = (B, N, S, K, D, int(xyz_last), stride)
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
         (idx,) = ctx.saved_tensors
-        B, N, S, K, D, xyz_last = ctx.dims
+        B, N, S, K, D, xyz_last, stride = ctx.dims
         if D == 0 or not ctx.needs_input_grad[1]:
-            return None, None, None, None, None
+            return None, None, None, None, None, None
         grad_out = _f32(grad_out)
         grad = torch.empty((B, N, D), dtype=torch.float32, device=grad_out.device)
-        _run("group_bwd", grad_out, _lib.load().mp_group_bwd_f32, _p(grad_out), _p(idx), B, N, S, K, D, xyz_last, _p(grad), int(DETERMINISTIC))
-        return None, grad, None, None, None
+        _run("group_bwd", grad_out, _lib.load().mp_group_bwd_f32, _p(grad_out), _p(idx), B, N, S, K, D, xyz_last, stride,
+             _p(grad), int(DETERMINISTIC))
+        return None, grad, None, None, None, None
 
 
-def group(xyz, feats, new_xyz, idx, xyz_last=False):
+def group(xyz, feats, new_xyz, idx, xyz_last=False, pad_to=1):
     """sample_and_group tail (models/pointnet2_utils.py:133-143; MSG order :258-262 when xyz_last):
     [B,S,K,3+D] = cat(xyz[idx] - new_xyz, feats[idx]).  Differentiable w.r.t. feats (the coordinates are network
-    inputs / FPS selections and carry no gradient on this path)."""
+    inputs / FPS selections and carry no gradient on this path).  pad_to > 1 rounds the row length up to a multiple
+    of it with zero columns (the fused MLP consumes rows of a multiple of 4 floats)."""
     _need_hip(xyz, feats, new_xyz, idx)
     if xyz.requires_grad or new_xyz.requires_grad:
         raise NotImplementedError("group(): gradients w.r.t. coordinates are not part of the hot path; "
                                   "compose index_points() for that")
-    return _Group.apply(_f32(xyz), None if feats is None else _f32(feats), _f32(new_xyz), _i64(idx), bool(xyz_last))
+    C = 3 + (0 if feats is None else feats.shape[2])
+    stride = (C + pad_to - 1) // pad_to * pad_to
+    return _Group.apply(_f32(xyz), None if feats is None else _f32(feats), _f32(new_xyz), _i64(idx), bool(xyz_last), stride)
 
 
 class _Knn(torch.autograd.Function):

@@ -68,18 +68,19 @@ def query_ball_point(radius, nsample, xyz, new_xyz):
     return ops.ball_query(radius, nsample, xyz, new_xyz)
 
 
-def sample_and_group(npoint, radius, nsample, xyz, points, returnfps=False, full_points=None):
+def sample_and_group(npoint, radius, nsample, xyz, points, returnfps=False, full_points=None, _pad_to=1):
     """FPS -> ball query -> gather/centre/concat (:112-148).  xyz [B,N,3], points [B,N,D] or None.
-    Returns new_xyz [B,npoint,3], new_points [B,npoint,nsample,3+D] (xyz channels first)."""
+    Returns new_xyz [B,npoint,3], new_points [B,npoint,nsample,3+D] (xyz channels first).
+    (_pad_to is internal: the set-abstraction modules ask for rows padded to a multiple of 4 floats.)"""
     B, N, _ = xyz.shape
     fps_idx, new_xyz = ops.fps(xyz, npoint, _draw_fps_start(B, N, xyz.device), return_xyz=True)
     idx = ops.ball_query(radius, nsample, xyz, new_xyz)
     if points is not None:
-        new_points = ops.group(xyz, points, new_xyz, idx)
+        new_points = ops.group(xyz, points, new_xyz, idx, pad_to=_pad_to)
     elif full_points is not None:
         new_points = ops.index_points(full_points, idx)  # un-centred full features (:139-141)
     else:
-        new_points = ops.group(xyz, None, new_xyz, idx)
+        new_points = ops.group(xyz, None, new_xyz, idx, pad_to=_pad_to)
     if returnfps:
         return new_xyz, new_points, ops.index_points(xyz, idx), fps_idx
     return new_xyz, new_points
@@ -127,7 +128,7 @@ class PointNetSetAbstraction(nn.Module):
             new_xyz, grouped = sample_and_group_all(xyz, points)
         else:
             new_xyz, grouped = sample_and_group(self.npoint, self.radius, self.nsample, xyz, points,
-                                                full_points=full_points)
+                                                full_points=full_points, _pad_to=4)
         new_points = sa_mlp.shared_mlp_max(grouped, self.mlp_convs, self.mlp_bns)  # [B,S,C']
         return new_xyz.permute(0, 2, 1), new_points.permute(0, 2, 1)
 
@@ -162,6 +163,6 @@ class PointNetSetAbstractionMsg(nn.Module):
         outs = []
         for radius, K, convs, bns in zip(self.radius_list, self.nsample_list, self.conv_blocks, self.bn_blocks):
             idx = ops.ball_query(radius, K, xyz, new_xyz)
-            grouped = ops.group(xyz, points, new_xyz, idx, xyz_last=True)
+            grouped = ops.group(xyz, points, new_xyz, idx, xyz_last=True, pad_to=4)
             outs.append(sa_mlp.shared_mlp_max(grouped, convs, bns))
         return new_xyz.permute(0, 2, 1), torch.cat(outs, dim=-1).permute(0, 2, 1)

@@ -82,19 +82,33 @@ class _SharedMLPMax(torch.autograd.Function):
 
 
 def shared_mlp_max(grouped, convs, bns):
-    """grouped [B,S,K,Cin] -> [B,S,Cout] = max_K relu(bn(conv(.))) chained over the layers (fused HIP path)."""
+    """grouped [B,S,K,Cin (+ zero padding up to a multiple of 4)] -> [B,S,Cout] = max_K relu(bn(conv(.))) chained over
+    the layers (fused HIP path).  The kernels work on float4 channel groups: an input with Cin % 4 != 0 that was not
+    already padded by ops.group(pad_to=4) is zero-padded here, and the first weight gets matching zero columns."""
+    import torch.nn.functional as F
     ops._need_hip(grouped)
     B, S, K, C = grouped.shape
+    cin = convs[0].in_channels
+    cpad = (cin + 3) // 4 * 4
+    if C == cin and cpad != cin:
+        grouped = F.pad(grouped, (0, cpad - cin))
+        C = cpad
+    if C != cpad:
+        raise ValueError(f"grouped has {C} channels, the first conv expects {cin}")
     x = grouped.reshape(B * S * K, C)
     x = x.contiguous() if x.dtype == torch.float32 else x.contiguous().float()
     training = bns[0].training
     params = []
-    for conv, bn in zip(convs, bns):
+    for i, (conv, bn) in enumerate(zip(convs, bns)):
         if bn.training != training:
             raise ValueError("all BatchNorm layers of a set-abstraction level must share one mode")
+        if conv.out_channels % 4:
+            raise NotImplementedError("fused set-abstraction MLP: layer widths must be multiples of 4")
         if training and bn.track_running_stats:
             bn.num_batches_tracked.add_(1)
         w = conv.weight.view(conv.out_channels, conv.in_channels)
+        if i == 0 and cpad != cin:
+            w = F.pad(w, (0, cpad - cin))
         track = bn.track_running_stats and bn.running_mean is not None
         if not training and not track:
             raise NotImplementedError("eval-mode BatchNorm without running statistics")
