@@ -21,8 +21,12 @@ class BucketedGradAllReduce:
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         params = [p for p in params if p.requires_grad]
+        self.params = params
+        self.buckets = []
+        self._handles, self._pending, self._hooks = [], [], []
+        if self.world == 1:
+            return  # nothing to exchange: let autograd write .grad directly (no flat buffers, no extra add/zero passes)
         order = list(reversed(params))  # heads first == the order gradients become ready in backward
-        self.buckets = []  # (flat, [params])
         cur, cur_bytes = [], 0
         for p in order:
             nbytes = p.numel() * p.element_size()
@@ -60,6 +64,10 @@ class BucketedGradAllReduce:
 
     def zero_grad(self):
         """Replaces optimizer.zero_grad(): keeps the grad views alive."""
+        if self.world == 1:
+            for p in self.params:
+                p.grad = None
+            return
         for flat, _ in self.buckets:
             flat.zero_()
         self._pending = [len(ps) for _, ps in self.buckets]
@@ -80,7 +88,7 @@ class BucketedGradAllReduce:
             flat.div_(self.world)
 
     def grad_bytes(self):
-        return sum(f.numel() * f.element_size() for f, _ in self.buckets)
+        return sum(p.numel() * p.element_size() for p in self.params)
 
 
 def init_from_env(backend=None):
