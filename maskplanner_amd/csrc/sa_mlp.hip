@@ -188,18 +188,33 @@ __device__ __forceinline__ int acc_row_in_tile(int r) { return (r & 3) + 8 * (r 
 //   EPI_SQ : (sum c, sum c^2)                                  (BatchNorm forward statistics)
 //   EPI_DY : with dy = relu'(zp*s+t) ? c : 0 : (sum dy, sum dy*zp)   zp = previous layer's raw Z (same shape as C)
 // =================================================================================================================
-enum Epi { EPI_NONE = 0, EPI_SQ = 1, EPI_DY = 2 };
+enum Epi { EPI_NONE = 0, EPI_SQ = 1, EPI_DY = 2, EPI_SQ_POOL = 3 };
+
+// EPI_SQ_POOL (last forward layer, group size K in {32, 64, 128}): besides Z and the BatchNorm sums the epilogue
+// reduces every group of K rows to (max, argmax, min, argmin) of the RAW z per channel -- the max-pool commutes with
+// the monotone map z -> relu(z*scale + shift), max for scale >= 0, min for scale < 0 -- so the pooled output needs no
+// second pass over Z once the batch statistics are known (pool_select_kernel).
+struct PoolOut {
+    float* vmax;  // [P/K, N]
+    float* vmin;
+    int* imax;
+    int* imin;
+    int K;
+};
 
 template <int MODE, bool W_KROW, int EPI, int WAVES_M, int WAVES_N, int TM, int TN>
 __global__ __launch_bounds__(THREADS) void pos_gemm_kernel(PosOperand A, int P, const float* __restrict__ W, int N,
                                                            int Kd, float* __restrict__ C, float* __restrict__ partials,
                                                            const float* __restrict__ zprev,
                                                            const float* __restrict__ sprev,
-                                                           const float* __restrict__ tprev)
+                                                           const float* __restrict__ tprev, PoolOut po)
 {
     constexpr int BM = WAVES_M * TM * 32;
     constexpr int BN = WAVES_N * TN * 32;
     constexpr int LDB = W_KROW ? BN : LDK;
+    constexpr bool SUMS = (EPI == EPI_SQ || EPI == EPI_DY || EPI == EPI_SQ_POOL);
+    __shared__ float pool_v[EPI == EPI_SQ_POOL ? 2 : 1][BM / 32][EPI == EPI_SQ_POOL ? BN : 1];
+    __shared__ int pool_i[EPI == EPI_SQ_POOL ? 2 : 1][BM / 32][EPI == EPI_SQ_POOL ? BN : 1];
     constexpr int A_PASSES = BM / 32;                 // 8 threads x float4 per row, 32 rows per pass
     constexpr int B_PASSES = W_KROW ? (BK * BN / 4 / THREADS) : (BN / 32);
     static_assert(WAVES_M * WAVES_N == 4, "4 waves");
@@ -301,7 +316,7 @@ __global__ __launch_bounds__(THREADS) void pos_gemm_kernel(PosOperand A, int P, 
                     const bool ok = cok && (!CHECKED || row < P);
                     const float v = acc[mi][ni][r];
                     if (ok && C) C[(size_t)((unsigned)row * (unsigned)N + (unsigned)col)] = v;
-                    if constexpr (EPI == EPI_SQ) {
+                    if constexpr (EPI == EPI_SQ || EPI == EPI_SQ_POOL) {
                         if (ok) { s1 += v; s2 += v * v; }
                     } else if constexpr (EPI == EPI_DY) {
                         const float dy = (ok && zp[r] * sp + tp > 0.0f) ? v : 0.0f;
@@ -310,7 +325,31 @@ __global__ __launch_bounds__(THREADS) void pos_gemm_kernel(PosOperand A, int P, 
                     }
                 }
             }
-            if constexpr (EPI != EPI_NONE) {
+            if constexpr (EPI == EPI_SQ_POOL) {
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi) {
+                    // registers ascend with the row for a fixed half-wave: strict compares keep the first extremum
+                    float bmax = acc[mi][ni][0], bmin = acc[mi][ni][0];
+                    int imax = acc_row_in_tile(0), imin = imax;
+#pragma unroll
+                    for (int r = 1; r < 16; ++r) {
+                        const float v = acc[mi][ni][r];
+                        const int ri = acc_row_in_tile(r);
+                        if (v > bmax) { bmax = v; imax = ri; }
+                        if (v < bmin) { bmin = v; imin = ri; }
+                    }
+                    const float omax = __shfl_xor(bmax, 32, 64), omin = __shfl_xor(bmin, 32, 64);
+                    const int oimax = __shfl_xor(imax, 32, 64), oimin = __shfl_xor(imin, 32, 64);
+                    if (omax > bmax || (omax == bmax && oimax < imax)) { bmax = omax; imax = oimax; }
+                    if (omin < bmin || (omin == bmin && oimin < imin)) { bmin = omin; imin = oimin; }
+                    if (lane < 32) {
+                        const int tr = wrow0 / 32 + mi, cc = wcol0 + ni * 32 + lane;
+                        pool_v[0][tr][cc] = bmax; pool_i[0][tr][cc] = imax;
+                        pool_v[1][tr][cc] = bmin; pool_i[1][tr][cc] = imin;
+                    }
+                }
+            }
+            if constexpr (SUMS) {
                 s1 += __shfl_xor(s1, 32, 64);
                 s2 += __shfl_xor(s2, 32, 64);
                 if (lane < 32) {
@@ -321,7 +360,7 @@ __global__ __launch_bounds__(THREADS) void pos_gemm_kernel(PosOperand A, int P, 
         }
     };
     if (interior) epilogue(std::false_type{}); else epilogue(std::true_type{});
-    if constexpr (EPI != EPI_NONE) {
+    if constexpr (SUMS) {
         __syncthreads();
         for (int e = tid; e < 2 * BN; e += THREADS) {
             const int st = e / BN, c = e - st * BN;
@@ -331,6 +370,46 @@ __global__ __launch_bounds__(THREADS) void pos_gemm_kernel(PosOperand A, int P, 
             if (n0 + c < N) partials[((size_t)blockIdx.x * 2 + st) * N + n0 + c] = v;
         }
     }
+    if constexpr (EPI == EPI_SQ_POOL) {
+        // combine the 32-row tiles of each group (ascending rows; strict compares keep the first extremum)
+        const int tpg = po.K / 32;            // tiles per group: 1, 2 or 4
+        const int groups = BM / po.K;
+        for (int e = tid; e < groups * BN; e += THREADS) {
+            const int gl = e / BN, c = e - gl * BN;
+            const int t0 = gl * tpg;
+            float bmax = pool_v[0][t0][c], bmin = pool_v[1][t0][c];
+            int imax = pool_i[0][t0][c], imin = pool_i[1][t0][c];
+            for (int t = 1; t < tpg; ++t) {
+                const float vx = pool_v[0][t0 + t][c], vn = pool_v[1][t0 + t][c];
+                if (vx > bmax) { bmax = vx; imax = t * 32 + pool_i[0][t0 + t][c]; }
+                if (vn < bmin) { bmin = vn; imin = t * 32 + pool_i[1][t0 + t][c]; }
+            }
+            const int grow = m0 / po.K + gl;
+            if ((grow + 1) * po.K <= P && n0 + c < N) {
+                const size_t o = (size_t)((unsigned)grow * (unsigned)N + (unsigned)(n0 + c));
+                po.vmax[o] = bmax; po.imax[o] = imax;
+                po.vmin[o] = bmin; po.imin[o] = imin;
+            }
+        }
+    }
+}
+
+// out = relu(z* * scale + shift) with z* = group max (scale >= 0) or group min (scale < 0) of the raw activations
+__global__ __launch_bounds__(256) void pool_select_kernel(PoolOut po, const float* __restrict__ s,
+                                                          const float* __restrict__ t, int64_t G, int C,
+                                                          float* __restrict__ out, int* __restrict__ argk,
+                                                          float* __restrict__ zmax)
+{
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= G * C) return;
+    const int c = (int)(e % C);
+    const float sc = s[c];
+    const bool up = sc >= 0.0f;
+    const float z = up ? po.vmax[e] : po.vmin[e];
+    const float y = z * sc + t[c];
+    out[e] = y > 0.0f ? y : 0.0f;
+    argk[e] = up ? po.imax[e] : po.imin[e];
+    zmax[e] = z;
 }
 
 // =================================================================================================================
@@ -592,7 +671,8 @@ __global__ __launch_bounds__(256) void pool_bwd_prep_kernel(const float* __restr
 
 template <int MODE, bool W_KROW, int EPI>
 int launch_pos_gemm(const PosOperand& A, int64_t P, const float* W, int N, int Kd, float* C, float* partials,
-                    const float* zprev, const float* sprev, const float* tprev, hipStream_t stream, int* nblk_out)
+                    const float* zprev, const float* sprev, const float* tprev, hipStream_t stream, int* nblk_out,
+                    PoolOut po = PoolOut{})
 {
     const unsigned gm = (unsigned)((P + 127) / 128);
     if (nblk_out) *nblk_out = (int)gm;
@@ -604,11 +684,11 @@ int launch_pos_gemm(const PosOperand& A, int64_t P, const float* W, int N, int K
     if (N <= 64) {
         snprintf(tag, sizeof tag, "pos_gemm_kernel<%d, %s, %d, 4, 1, 1, 2>", MODE, W_KROW ? "true" : "false", EPI);
         MP_LAUNCH(tag, flops, bytes, (pos_gemm_kernel<MODE, W_KROW, EPI, 4, 1, 1, 2>), dim3(gm, (N + 63) / 64),
-                  dim3(THREADS), 0, stream, A, (int)P, W, N, Kd, C, partials, zprev, sprev, tprev);
+                  dim3(THREADS), 0, stream, A, (int)P, W, N, Kd, C, partials, zprev, sprev, tprev, po);
     } else {
         snprintf(tag, sizeof tag, "pos_gemm_kernel<%d, %s, %d, 2, 2, 2, 2>", MODE, W_KROW ? "true" : "false", EPI);
         MP_LAUNCH(tag, flops, bytes, (pos_gemm_kernel<MODE, W_KROW, EPI, 2, 2, 2, 2>), dim3(gm, (N + 127) / 128),
-                  dim3(THREADS), 0, stream, A, (int)P, W, N, Kd, C, partials, zprev, sprev, tprev);
+                  dim3(THREADS), 0, stream, A, (int)P, W, N, Kd, C, partials, zprev, sprev, tprev, po);
     }
     MP_CHECK_LAUNCH();
     return MP_OK;
@@ -629,6 +709,7 @@ extern "C" size_t mp_sa_mlp_workspace_bytes(int64_t P, int64_t K, int n_layers, 
     const size_t nblk = (size_t)((P + 127) / 128);
     size_t bytes = align_up(nblk * 2 * (size_t)cmax * sizeof(float), 256);  // epilogue partials
     bytes += 3 * align_up((size_t)cmax * sizeof(float), 256);              // dZ constants a, e, f
+    if (!backward) bytes += 4 * align_up((size_t)(P / (K > 0 ? K : 1)) * (size_t)channels[n_layers] * sizeof(float), 256);  // fused pool
     if (backward) {
         bytes += 2 * align_up((size_t)P * (size_t)cmax * sizeof(float), 256);            // G ping-pong
         bytes += align_up((size_t)(P / (K > 0 ? K : 1)) * (size_t)channels[n_layers] * sizeof(float), 256);  // gp
@@ -658,6 +739,22 @@ extern "C" int mp_sa_mlp_fwd_f32(const float* x0, int64_t P, int64_t K, int n_la
     if (workspace_bytes < mp_sa_mlp_workspace_bytes(P, K, n_layers, ch, 0)) return MP_EWORKSPACE;
     hipStream_t stream = mp_stream(stream_);
     float* partials = reinterpret_cast<float*>(workspace);
+    // fused max-pool: group size a multiple of the 32-row MFMA tile that divides the 128-row block tile
+    const bool fused_pool = (K == 32 || K == 64 || K == 128);
+    PoolOut po{};
+    {
+        int64_t cmax = 0;
+        for (int l = 0; l <= n_layers; ++l) cmax = ch[l] > cmax ? ch[l] : cmax;
+        unsigned char* w = reinterpret_cast<unsigned char*>(workspace);
+        w += align_up((size_t)((P + 127) / 128) * 2 * (size_t)cmax * sizeof(float), 256);
+        w += 3 * align_up((size_t)cmax * sizeof(float), 256);
+        const size_t pb = align_up((size_t)(P / K) * (size_t)ch[n_layers] * sizeof(float), 256);
+        po.vmax = reinterpret_cast<float*>(w);
+        po.vmin = reinterpret_cast<float*>(w + pb);
+        po.imax = reinterpret_cast<int*>(w + 2 * pb);
+        po.imin = reinterpret_cast<int*>(w + 3 * pb);
+        po.K = (int)K;
+    }
 
     PosOperand A{};
     A.x = x0;
@@ -666,7 +763,15 @@ extern "C" int mp_sa_mlp_fwd_f32(const float* x0, int64_t P, int64_t K, int n_la
     for (int l = 0; l < n_layers; ++l) {
         const mp_mlp_layer_t& L = layers[l];
         int nblk = 0, rc;
-        if (l == 0)
+        const bool fuse_pool = (l == n_layers - 1) && fused_pool;
+        if (fuse_pool) {
+            if (l == 0)
+                rc = launch_pos_gemm<SRC_ID, false, EPI_SQ_POOL>(A, P, L.weight, (int)L.c_out, (int)L.c_in, L.z, partials,
+                                                                 nullptr, nullptr, nullptr, stream, &nblk, po);
+            else
+                rc = launch_pos_gemm<SRC_ACT, false, EPI_SQ_POOL>(A, P, L.weight, (int)L.c_out, (int)L.c_in, L.z, partials,
+                                                                  nullptr, nullptr, nullptr, stream, &nblk, po);
+        } else if (l == 0)
             rc = launch_pos_gemm<SRC_ID, false, EPI_SQ>(A, P, L.weight, (int)L.c_out, (int)L.c_in, L.z, partials, nullptr,
                                                         nullptr, nullptr, stream, &nblk);
         else
@@ -688,6 +793,12 @@ extern "C" int mp_sa_mlp_fwd_f32(const float* x0, int64_t P, int64_t K, int n_la
     const mp_mlp_layer_t& LL = layers[n_layers - 1];
     const int64_t G = P / K;
     const int64_t tot = G * LL.c_out;
+    if (fused_pool) {
+        MP_LAUNCH("pool_select_kernel", 0.0, 28.0 * (double)tot, pool_select_kernel, dim3((unsigned)((tot + 255) / 256)),
+                  dim3(256), 0, stream, po, LL.scale, LL.shift, G, (int)LL.c_out, out, argk, zmax);
+        MP_CHECK_LAUNCH();
+        return MP_OK;
+    }
     MP_LAUNCH("pool_fwd_kernel", 0.0, 4.0 * (double)P * LL.c_out + 12.0 * (double)tot, pool_fwd_kernel,
               dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream, LL.z, LL.scale, LL.shift, G, (int)K, (int)LL.c_out, out,
               argk, zmax);
