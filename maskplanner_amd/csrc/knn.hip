@@ -175,6 +175,125 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_kernel(const float* __restric
     }
 }
 
+
+// ---- K = 1 fast path (every chamfer call of the MaskPlanner loss) ---------------------------------------------------
+// QPL queries per lane share each broadcast reference read (halves LDS traffic per pair and gives the fma chains
+// independent work to interleave); WAVES waves split every tile, so even 999-segment query sets put two waves on each
+// SIMD.  Same arithmetic and tie rule as knn_kernel.
+template <int D, int QPL, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void knn1_kernel(const float* __restrict__ p1, const float* __restrict__ p2,
+                                                          const int64_t* __restrict__ len1,
+                                                          const int64_t* __restrict__ len2, int P1, int P2,
+                                                          float* __restrict__ dists, int64_t* __restrict__ idx)
+{
+    constexpr int DP = (D + 3) & ~3;
+    constexpr int QB = 64 * QPL;                 // queries per block
+    constexpr int RPW = KNN_TILE / WAVES;        // references per wave and tile
+    __shared__ __attribute__((aligned(16))) float tile[KNN_TILE * DP];
+    __shared__ float md[WAVES][QPL][64];
+    __shared__ int mi[WAVES][QPL][64];
+
+    const int b = blockIdx.y;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int qbase = blockIdx.x * QB;
+    const int l1 = len1 ? (int)min((int64_t)P1, len1[b]) : P1;
+    const int l2 = len2 ? (int)min((int64_t)P2, len2[b]) : P2;
+
+    float a[QPL][D];
+    float best[QPL];
+    int bidx[QPL];
+#pragma unroll
+    for (int u = 0; u < QPL; ++u) {
+        const int q = qbase + u * 64 + lane;
+        const float* ap = p1 + ((size_t)b * P1 + (q < l1 ? q : 0)) * D;
+#pragma unroll
+        for (int t = 0; t < D; ++t) a[u][t] = ap[t];
+        best[u] = __builtin_inff();
+        bidx[u] = 0x7fffffff;
+    }
+    const float* refs = p2 + (size_t)b * P2 * D;
+    const bool any_valid = qbase < l1;
+    for (int base = 0; any_valid && base < l2; base += KNN_TILE) {
+        const int nt = min(KNN_TILE, l2 - base);
+        __syncthreads();
+        if (DP == D && ((reinterpret_cast<uintptr_t>(refs + (size_t)base * D) & 15) == 0)) {
+            const float4* src = reinterpret_cast<const float4*>(refs + (size_t)base * D);
+            float4* dst = reinterpret_cast<float4*>(tile);
+            for (int v = tid; v < nt * D / 4; v += WAVES * 64) dst[v] = src[v];
+        } else {
+            for (int v = tid; v < nt * D; v += WAVES * 64) {
+                const int r = v / D, t = v - r * D;
+                tile[r * DP + t] = refs[(size_t)base * D + v];
+            }
+        }
+        __syncthreads();
+        const int j0 = wave * RPW;
+        const int j1 = min(nt, j0 + RPW);
+        for (int j = j0; j < j1; ++j) {
+            const float* r = tile + j * DP;
+            float d[QPL];
+#pragma unroll
+            for (int u = 0; u < QPL; ++u) d[u] = 0.0f;
+#pragma unroll
+            for (int t4 = 0; t4 < DP / 4; ++t4) {
+                const float4 rv = *reinterpret_cast<const float4*>(r + 4 * t4);
+                const float rr[4] = {rv.x, rv.y, rv.z, rv.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (4 * t4 + e < D) {
+#pragma unroll
+                        for (int u = 0; u < QPL; ++u) {
+                            const float diff = a[u][4 * t4 + e] - rr[e];
+                            d[u] = __builtin_fmaf(diff, diff, d[u]);
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < QPL; ++u)
+                if (d[u] < best[u]) { best[u] = d[u]; bidx[u] = base + j; }   // ascending j inside a wave: first wins
+        }
+    }
+    // merge the waves: lexicographic (distance, index) == first index of a serial scan
+#pragma unroll
+    for (int u = 0; u < QPL; ++u) { md[wave][u][lane] = best[u]; mi[wave][u][lane] = bidx[u]; }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int u = 0; u < QPL; ++u) {
+            float bd = best[u];
+            int bi = bidx[u];
+#pragma unroll
+            for (int w = 1; w < WAVES; ++w) {
+                const float od = md[w][u][lane];
+                const int oi = mi[w][u][lane];
+                if (od < bd || (od == bd && oi < bi)) { bd = od; bi = oi; }
+            }
+            const int q = qbase + u * 64 + lane;
+            if (q < P1) {
+                const bool ok = q < l1 && l2 > 0;
+                dists[(size_t)b * P1 + q] = ok ? bd : 0.0f;
+                idx[(size_t)b * P1 + q] = ok ? (int64_t)bi : 0;
+            }
+        }
+    }
+}
+
+template <int D>
+int launch_knn1(const float* p1, const float* p2, const int64_t* len1, const int64_t* len2, int B, int P1, int P2,
+                float* dists, int64_t* idx, hipStream_t stream)
+{
+    char tag[48];
+    snprintf(tag, sizeof tag, "knn1_kernel<%d>", D);
+    const double flops = 3.0 * D * (double)B * P1 * P2, bytes = (double)B * ((P1 + P2) * 4.0 * D + P1 * 12.0);
+    MP_LAUNCH(tag, flops, bytes, (knn1_kernel<D, 2, 8>), dim3((P1 + 127) / 128, B), dim3(512), 0, stream, p1, p2, len1, len2,
+              P1, P2, dists, idx);
+    MP_CHECK_LAUNCH();
+    return MP_OK;
+}
+
 template <int D, int K>
 int launch_knn(const float* p1, const float* p2, const int64_t* len1, const int64_t* len2, int B, int P1, int P2,
                int Drt, int Kout, float* dists, int64_t* idx, hipStream_t stream)
@@ -313,7 +432,15 @@ extern "C" int mp_knn_f32(const float* p1, const float* p2, const int64_t* len1,
     if (K > 8 || D > 1024 || B > 65535 || P1 > (1 << 30) || P2 > (1 << 30)) return MP_EUNSUPPORTED;
     hipStream_t stream = mp_stream(stream_);
     const int b = (int)B, n1 = (int)P1, n2 = (int)P2, d = (int)D, k = (int)K;
-    if (k == 1) return dispatch_d<1>(p1, p2, len1, len2, b, n1, n2, d, k, dists, idx, stream);
+    if (k == 1) {
+        switch (d) {
+            case 3: return launch_knn1<3>(p1, p2, len1, len2, b, n1, n2, dists, idx, stream);
+            case 6: return launch_knn1<6>(p1, p2, len1, len2, b, n1, n2, dists, idx, stream);
+            case 12: return launch_knn1<12>(p1, p2, len1, len2, b, n1, n2, dists, idx, stream);
+            case 24: return launch_knn1<24>(p1, p2, len1, len2, b, n1, n2, dists, idx, stream);
+            default: return dispatch_d<1>(p1, p2, len1, len2, b, n1, n2, d, k, dists, idx, stream);
+        }
+    }
     if (k == 2) return dispatch_d<2>(p1, p2, len1, len2, b, n1, n2, d, k, dists, idx, stream);
     if (k <= 4) return dispatch_d<4>(p1, p2, len1, len2, b, n1, n2, d, k, dists, idx, stream);
     return dispatch_d<8>(p1, p2, len1, len2, b, n1, n2, d, k, dists, idx, stream);
