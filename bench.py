@@ -116,15 +116,20 @@ def main():
     for _ in range(args.warmup):
         ts.step()
     barrier()
-    if rank == 0:
-        lib.mp_profiler_enable(1)  # two event records per library kernel (rank 0 only)
     t0 = time.perf_counter()
-    with ops.KernelTimer() as kt:
-        for _ in range(args.steps):
-            loss = ts.step()
+    profiled_steps = 0
+    for i in range(args.steps):
+        # per-kernel HIP events (two records per library launch) on every 4th timed step, rank 0 only: the hooks
+        # cost ~0.5 ms per profiled step, so sampling keeps the headline number honest
+        prof = rank == 0 and i % 4 == 0
+        if prof:
+            lib.mp_profiler_enable(1)
+            profiled_steps += 1
+        loss = ts.step()
+        if prof:
+            lib.mp_profiler_enable(0)
     barrier()
     dt = time.perf_counter() - t0
-    lib.mp_profiler_enable(0)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -133,8 +138,6 @@ def main():
 
     if rank == 0:
         ms = dt / args.steps * 1e3
-        timing = kt.summary()
-        per_step = {k: (n / args.steps, m) for k, (n, m) in timing.items()}
         kernels = collect_kernel_profile(lib)
         # dominant kernel = largest total device time; its binding roof from the algorithmic work model
         dom = max(kernels, key=lambda k: kernels[k]["ms"])
@@ -154,11 +157,10 @@ def main():
                        "parallelism": f"dp{world}", "global_batch": args.batch * world, "grad_allreduce_MB":
                            round(ts.reducer.grad_bytes() / 1e6, 1)},
             "roofline": {"kernel": dom, "bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak,
-                         "traffic": measured_traffic(dom), "avg_us": avg_s * 1e6, "launches_per_step": d["calls"] / args.steps,
+                         "traffic": measured_traffic(dom), "avg_us": avg_s * 1e6, "launches_per_step": d["calls"] / profiled_steps,
                          "flops_per_launch": flops, "bytes_per_launch": nbytes},
-            "kernels_us_per_step": {k: round(v["ms"] * 1e3 / args.steps, 1) for k, v in
+            "kernels_us_per_step": {k: round(v["ms"] * 1e3 / profiled_steps, 1) for k, v in
                                     sorted(kernels.items(), key=lambda kv: -kv[1]["ms"])},
-            "entry_points_ms_per_step": {k: round(n * m_, 4) for k, (n, m_) in sorted(per_step.items())},
             "final_loss": final_loss,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -31,7 +31,12 @@ namespace {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
-constexpr int BK = 32;
+#ifndef MP_BK
+#define MP_BK 32
+#endif
+constexpr int BK = MP_BK;          // K chunk staged through LDS
+constexpr int TPR = BK / 4;        // threads per staged row (float4 each)
+constexpr int RPP = 256 / TPR;     // rows per staging pass
 constexpr int THREADS = 256;
 constexpr int LDK = BK + 1;  // [row][k] tiles: odd stride
 
@@ -150,13 +155,13 @@ __device__ __forceinline__ float4 ld4_plain(const float* m, int R, int C, int r,
 }
 
 // ---- MFMA chunk: acc += A_tile(BM x BK) * B_tile(BK x BN) for this wave's TM x TN sub-tiles ------------------
-template <bool A_KROW, bool B_KROW, int LDA, int LDB, int TM, int TN>
+template <bool A_KROW, bool B_KROW, int LDA, int LDB, int TM, int TN, int KC>
 __device__ __forceinline__ void mma_chunk(const float* sA, const float* sB, int wrow0, int wcol0, f32x16 (&acc)[TM][TN])
 {
     const int lane = threadIdx.x & 63;
     const int l31 = lane & 31, hi = lane >> 5;
 #pragma unroll
-    for (int kk = 0; kk < BK; kk += 2) {
+    for (int kk = 0; kk < KC; kk += 2) {
         const int k = kk + hi;
         float a[TM], b[TN];
 #pragma unroll
@@ -215,8 +220,8 @@ __global__ __launch_bounds__(THREADS) void pos_gemm_kernel(PosOperand A, int P, 
     constexpr bool SUMS = (EPI == EPI_SQ || EPI == EPI_DY || EPI == EPI_SQ_POOL);
     __shared__ float pool_v[EPI == EPI_SQ_POOL ? 2 : 1][BM / 32][EPI == EPI_SQ_POOL ? BN : 1];
     __shared__ int pool_i[EPI == EPI_SQ_POOL ? 2 : 1][BM / 32][EPI == EPI_SQ_POOL ? BN : 1];
-    constexpr int A_PASSES = BM / 32;                 // 8 threads x float4 per row, 32 rows per pass
-    constexpr int B_PASSES = W_KROW ? (BK * BN / 4 / THREADS) : (BN / 32);
+    constexpr int A_PASSES = BM / RPP;                // TPR threads x float4 per row, RPP rows per pass
+    constexpr int B_PASSES = W_KROW ? (BK * BN / 4 / THREADS) : (BN / RPP);
     static_assert(WAVES_M * WAVES_N == 4, "4 waves");
     __shared__ float sA[2][BM * LDK];
     __shared__ float sB[2][W_KROW ? BK * BN : BN * LDK];
@@ -240,18 +245,18 @@ __global__ __launch_bounds__(THREADS) void pos_gemm_kernel(PosOperand A, int P, 
     Raw4<MODE> ra[A_PASSES];
     float4 rb[B_PASSES];
     ChanConst kc;
-    const int arow = tid >> 3, acol = (tid & 7) * 4;
+    const int arow = tid / TPR, acol = (tid % TPR) * 4;
     auto gload = [&](int k0) {
         load_consts<MODE>(A, k0 + acol, kc);
 #pragma unroll
-        for (int ps = 0; ps < A_PASSES; ++ps) raw_load<MODE>(A, P, m0 + ps * 32 + arow, k0 + acol, ra[ps]);
+        for (int ps = 0; ps < A_PASSES; ++ps) raw_load<MODE>(A, P, m0 + ps * RPP + arow, k0 + acol, ra[ps]);
 #pragma unroll
         for (int ps = 0; ps < B_PASSES; ++ps) {
             if constexpr (W_KROW) {  // slab [BK][BN] of W[Kd, N]
                 const int e = (ps * THREADS + tid) * 4;
                 rb[ps] = ld4_plain(W, Kd, N, k0 + e / BN, n0 + e % BN);
             } else {                 // rows of W[N, Kd], K contiguous
-                rb[ps] = ld4_plain(W, N, Kd, n0 + ps * 32 + arow, k0 + acol);
+                rb[ps] = ld4_plain(W, N, Kd, n0 + ps * RPP + arow, k0 + acol);
             }
         }
     };
@@ -259,7 +264,7 @@ __global__ __launch_bounds__(THREADS) void pos_gemm_kernel(PosOperand A, int P, 
 #pragma unroll
         for (int ps = 0; ps < A_PASSES; ++ps) {
             const float4 v = finish<MODE>(ra[ps], kc);
-            float* d = &sA[buf][(ps * 32 + arow) * LDK + acol];
+            float* d = &sA[buf][(ps * RPP + arow) * LDK + acol];
             d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
         }
 #pragma unroll
@@ -267,7 +272,7 @@ __global__ __launch_bounds__(THREADS) void pos_gemm_kernel(PosOperand A, int P, 
             if constexpr (W_KROW) {
                 *reinterpret_cast<float4*>(&sB[buf][(ps * THREADS + tid) * 4]) = rb[ps];
             } else {
-                float* d = &sB[buf][(ps * 32 + arow) * LDK + acol];
+                float* d = &sB[buf][(ps * RPP + arow) * LDK + acol];
                 d[0] = rb[ps].x; d[1] = rb[ps].y; d[2] = rb[ps].z; d[3] = rb[ps].w;
             }
         }
@@ -280,7 +285,7 @@ __global__ __launch_bounds__(THREADS) void pos_gemm_kernel(PosOperand A, int P, 
     for (int kc_ = 0; kc_ < nchunks; ++kc_) {
         const int cur = kc_ & 1;
         if (kc_ + 1 < nchunks) gload((kc_ + 1) * BK);
-        mma_chunk<false, W_KROW, LDK, LDB, TM, TN>(sA[cur], sB[cur], wrow0, wcol0, acc);
+        mma_chunk<false, W_KROW, LDK, LDB, TM, TN, BK>(sA[cur], sB[cur], wrow0, wcol0, acc);
         if (kc_ + 1 < nchunks) sstore(cur ^ 1);
         __syncthreads();
     }
@@ -420,13 +425,14 @@ template <int MODE_DZ, int MODE_IN, int WAVES_M, int WAVES_N, int TM, int TN>
 __global__ __launch_bounds__(THREADS) void dw_gemm_kernel(PosOperand DZ, PosOperand IN, int P, int p_per_block,
                                                           float* __restrict__ dW)
 {
+    constexpr int DBK = 32;                 // positions per K chunk
     constexpr int BM = WAVES_M * TM * 32;   // output channels (rows of dW)
     constexpr int BN = WAVES_N * TN * 32;   // input channels  (cols of dW)
-    constexpr int PA = BK * BM / 4 / THREADS;
-    constexpr int PB = BK * BN / 4 / THREADS;
+    constexpr int PA = DBK * BM / 4 / THREADS;
+    constexpr int PB = DBK * BN / 4 / THREADS;
     static_assert(WAVES_M * WAVES_N == 4 && PA >= 1 && PB >= 1, "tile");
-    __shared__ float sA[2][BK * BM];
-    __shared__ float sB[2][BK * BN];
+    __shared__ float sA[2][DBK * BM];
+    __shared__ float sB[2][DBK * BN];
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     const int wrow0 = (wave / WAVES_N) * TM * 32, wcol0 = (wave % WAVES_N) * TN * 32;
@@ -466,15 +472,15 @@ __global__ __launch_bounds__(THREADS) void dw_gemm_kernel(PosOperand DZ, PosOper
         for (int ps = 0; ps < PB; ++ps)
             *reinterpret_cast<float4*>(&sB[buf][(ps * THREADS + tid) * 4]) = finish<MODE_IN>(rb[ps], kb);
     };
-    const int nchunks = (p1 - p0 + BK - 1) / BK;
+    const int nchunks = (p1 - p0 + DBK - 1) / DBK;
     if (nchunks <= 0) return;
     gload(p0);
     sstore(0);
     __syncthreads();
     for (int kc = 0; kc < nchunks; ++kc) {
         const int cur = kc & 1;
-        if (kc + 1 < nchunks) gload(p0 + (kc + 1) * BK);
-        mma_chunk<true, true, BM, BN, TM, TN>(sA[cur], sB[cur], wrow0, wcol0, acc);
+        if (kc + 1 < nchunks) gload(p0 + (kc + 1) * DBK);
+        mma_chunk<true, true, BM, BN, TM, TN, DBK>(sA[cur], sB[cur], wrow0, wcol0, acc);
         if (kc + 1 < nchunks) sstore(cur ^ 1);
         __syncthreads();
     }

@@ -13,7 +13,7 @@ from .pointnet2_cls_ssg import maskplanner_model
 
 class TrainStep:
     def __init__(self, category="cuboids", B=32, N=5120, device="cuda", seed=1235, hidden_size=(1024, 1024), lr=1e-3,
-                 dist_points="cuboid", rank=0, loss_overrides=None):
+                 dist_points="cuboid", rank=0, loss_overrides=None, prefetch_sampling=False):
         self.cat = synthetic.CATEGORIES[category] if isinstance(category, str) else category
         self.device = torch.device(device)
         torch.manual_seed(seed)  # identical initial weights on every rank
@@ -26,11 +26,22 @@ class TrainStep:
         b = synthetic.make_batch(seed + 1000 * rank, B, N, self.cat.name, dist_points)  # a different shard per rank
         self.batch = {k: (v.to(self.device) if torch.is_tensor(v) else [t.to(self.device) for t in v])
                       for k, v in b.items()}
-        self.point_cloud = self.batch["point_cloud"].permute(0, 2, 1).contiguous()  # [B,3,N] as the loop feeds it (:207)
+        # [B,3,N] as the loop feeds it (:207-208): a permuted VIEW of the collated [B,N,3] tensor, so the encoder's
+        # permute back to points-major is free
+        self.point_cloud = self.batch["point_cloud"].permute(0, 2, 1)
+        self.prefetch = bool(prefetch_sampling) and self.device.type == "cuda"
 
     def forward_loss(self):
-        with pu.fps_start_override(self.batch["fps_start"]):
+        # sa1's start is consumed only when its sampling was not prefetched; sa2's always
+        sa1 = self.model.sa1
+        ready = self.prefetch and pu.has_prefetched(self.batch["point_cloud"], sa1.npoint, sa1.radius, sa1.nsample)
+        starts = self.batch["fps_start"][1:] if ready else self.batch["fps_start"]
+        with pu.fps_start_override(starts):
             out, sm_out, mask_conf, seg_conf = self.model(self.point_cloud)
+        if self.prefetch:
+            # the next batch (here: the same synthetic one) is already resident: run ITS first-level FPS + ball query
+            # on the side stream while this step's loss / backward / optimizer occupy the main stream
+            pu.prefetch_sampling(self.batch["point_cloud"], sa1.npoint, sa1.radius, sa1.nsample, self.batch["fps_start"][0])
         return self.loss_handler.compute(return_list=False, y_pred=out, y=self.batch["traj"], pred_stroke_masks=sm_out,
                                          mask_scores=mask_conf, seg_logits=seg_conf, stroke_ids=self.batch["stroke_ids"],
                                          traj_as_pc=self.batch["traj_as_pc"])

@@ -14,6 +14,7 @@ g5_model models/pointnet2_cls_ssg.py:233-344 PointNet2Regressor_StrokeMasks full
 g6_cham  pytorch3d_chamfer.py:76-344 chamfer_distance (pytorch3d stand-in = oracle knn: contract-derived)
 g7_mask  loss_handler.py:596-666,816-935  asymm_v6 loss + stroke-mask loss
 g8_hung  models/hungarianMatcher.py:31-63 HungarianMatcher
+g9_seg   models/pointnet2_seg.py:14-96,258-339 PointNet2Segmenter_v1 / _PaintNet_v1 (eval forward)
 """
 import os
 import sys
@@ -362,12 +363,50 @@ def g8_hung():
     save("g8_hung", **cases)
 
 
+def g9_seg():
+    """models/pointnet2_seg.py:14-96, 258-339: the two instantiable segmenters (SA stack + per-point Conv1d head)."""
+    print("g9_seg")
+    sg = R.pointnet2_seg()
+    rng = np.random.default_rng(909)
+    cases = {}
+    B, N = 2, 1024
+    # PaintNet_v1: 3-D points in, lambda poses out
+    torch.manual_seed(9)
+    m = sg.PointNet2Segmenter_PaintNet_v1(inputdim=3, outdim_trasl=3, outdim_orient=3, weight_orient=0.25, lambda_points=2)
+    m.eval()
+    xyz = syn.point_cloud(rng, B, N, "cuboid")
+    torch.manual_seed(51)
+    s1 = torch.randint(0, N, (B,)).numpy()
+    s2 = torch.randint(0, 512, (B,)).numpy()
+    torch.manual_seed(51)
+    with torch.no_grad():
+        out = m(torch.from_numpy(xyz).permute(0, 2, 1))
+    # weights are regenerated from the seed by the test (same module registration order => same RNG stream); the
+    # fixture keeps per-tensor checksums instead of 5 MB of state_dict
+    cases.update({"pn_ck_" + k: np.float64(v.double().abs().sum()) for k, v in m.state_dict().items()})
+    cases.update(pn_xyz=xyz, pn_fps_start1=s1, pn_fps_start2=s2, pn_out=out.numpy())
+    # Segmenter_v1 with ball_in_xyz_space: FPS / ball query on segment centroids, full 24-D segments as features
+    torch.manual_seed(10)
+    m2 = sg.PointNet2Segmenter_v1(outdim=5, input_orient_dim=3, lambda_points=4, ball_in_xyz_space=True)
+    m2.eval()
+    segs = rng.uniform(-0.5, 0.5, size=(B, 24, N)).astype(np.float32)
+    torch.manual_seed(52)
+    t1 = torch.randint(0, N, (B,)).numpy()
+    t2 = torch.randint(0, 512, (B,)).numpy()
+    torch.manual_seed(52)
+    with torch.no_grad():
+        out2 = m2(torch.from_numpy(segs))
+    cases.update({"sg_ck_" + k: np.float64(v.double().abs().sum()) for k, v in m2.state_dict().items()})
+    cases.update(sg_in=segs, sg_fps_start1=t1, sg_fps_start2=t2, sg_out=out2.numpy())
+    save("g9_seg", **cases)
+
+
 def main():
     if not R.available():
         raise SystemExit("reference checkout not found; fixtures can only be generated in the build container")
     torch.set_num_threads(8)
     pu = R.pointnet2_utils()
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9"]
     if "g1" in which: g1_fps(pu)
     if "g2" in which: g2_bq(pu)
     if "g3" in which: g3_sa(pu)
@@ -376,6 +415,7 @@ def main():
     if "g6" in which: g6_cham()
     if "g7" in which: g7_mask()
     if "g8" in which: g8_hung()
+    if "g9" in which: g9_seg()
 
 
 if __name__ == "__main__":

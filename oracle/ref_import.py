@@ -79,6 +79,18 @@ def pointnet2_cls_ssg():
     return _load("mp_ref_models.pointnet2_cls_ssg", "models/pointnet2_cls_ssg.py")
 
 
+def pointnet2_seg():
+    """models/pointnet2_seg.py: imports `models.pointnet2_utils` absolutely -> alias it to the loaded reference file."""
+    if "mp_ref_models.pointnet2_seg" in sys.modules:
+        return sys.modules["mp_ref_models.pointnet2_seg"]
+    pu = pointnet2_utils()
+    if "models" not in sys.modules:
+        pkg = _stub("models")
+        pkg.__path__ = []
+    sys.modules["models.pointnet2_utils"] = pu
+    return _load("mp_ref_models.pointnet2_seg", "models/pointnet2_seg.py")
+
+
 def hungarian_matcher():
     if "mp_ref_models.hungarianMatcher" in sys.modules:
         return sys.modules["mp_ref_models.hungarianMatcher"]
