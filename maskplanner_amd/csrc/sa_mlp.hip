@@ -529,34 +529,41 @@ int launch_dw(const PosOperand& DZ, const PosOperand& IN, int64_t P64, float* dW
 // =================================================================================================================
 // Reduce per-block partial sums [nblk][2][C] in fp64: a block owns FIN_CH channels, FIN_SL threads per channel walk
 // the partial rows strided (coalesced across channels), then combine through LDS.  Result valid in threads < FIN_CH.
-constexpr int FIN_CH = 32, FIN_SL = 32;
+constexpr int FIN_CH = 16, FIN_SL = 64;
 __device__ __forceinline__ void reduce_partials(const float* __restrict__ partials, int nblk, int C, double& s1, double& s2)
 {
     __shared__ double red[2][FIN_SL][FIN_CH];
     const int cl = threadIdx.x % FIN_CH, sl = threadIdx.x / FIN_CH;
     const int c = blockIdx.x * FIN_CH + cl;
-    double a1 = 0.0, a2 = 0.0, b1 = 0.0, b2 = 0.0;
+    double a1[4] = {0.0, 0.0, 0.0, 0.0}, a2[4] = {0.0, 0.0, 0.0, 0.0};
     if (c < C) {
         int i = sl;
-        for (; i + FIN_SL < nblk; i += 2 * FIN_SL) {
-            a1 += (double)partials[((int64_t)i * 2 + 0) * C + c];
-            a2 += (double)partials[((int64_t)i * 2 + 1) * C + c];
-            b1 += (double)partials[((int64_t)(i + FIN_SL) * 2 + 0) * C + c];
-            b2 += (double)partials[((int64_t)(i + FIN_SL) * 2 + 1) * C + c];
+        for (; i + 3 * FIN_SL < nblk; i += 4 * FIN_SL) {   // four independent loads in flight per sum
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                a1[u] += (double)partials[((size_t)(i + u * FIN_SL) * 2 + 0) * C + c];
+                a2[u] += (double)partials[((size_t)(i + u * FIN_SL) * 2 + 1) * C + c];
+            }
         }
-        if (i < nblk) {
-            a1 += (double)partials[((int64_t)i * 2 + 0) * C + c];
-            a2 += (double)partials[((int64_t)i * 2 + 1) * C + c];
+        for (; i < nblk; i += FIN_SL) {
+            a1[0] += (double)partials[((size_t)i * 2 + 0) * C + c];
+            a2[0] += (double)partials[((size_t)i * 2 + 1) * C + c];
         }
     }
-    red[0][sl][cl] = a1 + b1;
-    red[1][sl][cl] = a2 + b2;
+    red[0][sl][cl] = (a1[0] + a1[1]) + (a1[2] + a1[3]);
+    red[1][sl][cl] = (a2[0] + a2[1]) + (a2[2] + a2[3]);
     __syncthreads();
+    // tree over the slices: 64 -> 1
+    for (int h = FIN_SL / 2; h > 0; h >>= 1) {
+        if (sl < h) {
+            red[0][sl][cl] += red[0][sl + h][cl];
+            red[1][sl][cl] += red[1][sl + h][cl];
+        }
+        __syncthreads();
+    }
     if (threadIdx.x < FIN_CH) {
-        double t1 = 0.0, t2 = 0.0;
-        for (int j = 0; j < FIN_SL; ++j) { t1 += red[0][j][cl]; t2 += red[1][j][cl]; }
-        s1 = t1;
-        s2 = t2;
+        s1 = red[0][0][cl];
+        s2 = red[1][0][cl];
     }
 }
 
@@ -653,26 +660,26 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(const float* __restrict__
     zmax[e] = bz;
 }
 
-// gp = g * [out > 0]; per-block partial sums (sum gp, sum gp*zmax) per channel.  grid.x blocks of 256 threads,
-// each handling `rows_per_block` groups x all channels.
+// gp = g * [out > 0]; per-block partial sums (sum gp, sum gp*zmax) per channel.
+// grid (ceil(G / POOL_ROWS), ceil(C / 256)): a block handles POOL_ROWS groups x 256 channels, lanes along channels.
+constexpr int POOL_ROWS = 16;
 __global__ __launch_bounds__(256) void pool_bwd_prep_kernel(const float* __restrict__ gout, const float* __restrict__ out,
                                                             const float* __restrict__ zmax, int64_t G, int C,
-                                                            int rows_per_block, float* __restrict__ gp,
-                                                            float* __restrict__ partials)
+                                                            float* __restrict__ gp, float* __restrict__ partials)
 {
-    const int64_t g0 = (int64_t)blockIdx.x * rows_per_block;
-    const int64_t g1 = min(G, g0 + rows_per_block);
-    for (int c = threadIdx.x; c < C; c += 256) {
-        float s1 = 0.0f, s2 = 0.0f;
-        for (int64_t g = g0; g < g1; ++g) {
-            const float v = out[g * C + c] > 0.0f ? gout[g * C + c] : 0.0f;
-            gp[g * C + c] = v;
-            s1 += v;
-            s2 += v * zmax[g * C + c];
-        }
-        partials[((int64_t)blockIdx.x * 2 + 0) * C + c] = s1;
-        partials[((int64_t)blockIdx.x * 2 + 1) * C + c] = s2;
+    const int c = blockIdx.y * 256 + threadIdx.x;
+    if (c >= C) return;
+    const int64_t g0 = (int64_t)blockIdx.x * POOL_ROWS;
+    const int64_t g1 = min(G, g0 + POOL_ROWS);
+    float s1 = 0.0f, s2 = 0.0f;
+    for (int64_t g = g0; g < g1; ++g) {
+        const float v = out[g * C + c] > 0.0f ? gout[g * C + c] : 0.0f;
+        gp[g * C + c] = v;
+        s1 += v;
+        s2 += v * zmax[g * C + c];
     }
+    partials[((int64_t)blockIdx.x * 2 + 0) * C + c] = s1;
+    partials[((int64_t)blockIdx.x * 2 + 1) * C + c] = s2;
 }
 
 template <int MODE, bool W_KROW, int EPI>
@@ -856,13 +863,9 @@ extern "C" int mp_sa_mlp_bwd_f32(const float* x0, int64_t P, int64_t K, int n_la
     // pooled gradient through the last ReLU + its BatchNorm-backward sums
     {
         const int C = (int)last.c_out;
-        const int rows = 64;
-        const int nb = (int)((G + rows - 1) / rows);
-        if ((size_t)nb > nblk_max * 1) {
-            // partials buffer holds nblk_max*2*cmax floats: nb <= G/64+1 <= P/128+1 whenever K >= 2; K == 1 falls here
-            return MP_EUNSUPPORTED;
-        }
-        hipLaunchKernelGGL(pool_bwd_prep_kernel, dim3(nb), dim3(256), 0, stream, grad_out, out, zmax, G, C, rows, gp,
+        const int nb = (int)((G + POOL_ROWS - 1) / POOL_ROWS);
+        if ((size_t)nb > nblk_max) return MP_EUNSUPPORTED;  // partials hold P/128 rows: needs K >= 8
+        hipLaunchKernelGGL(pool_bwd_prep_kernel, dim3(nb, (C + 255) / 256), dim3(256), 0, stream, grad_out, out, zmax, G, C, gp,
                            partials);
         MP_CHECK_LAUNCH();
         hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_SL), 0, stream, partials, nb, C,
