@@ -172,8 +172,8 @@ int mp_sa_mlp_fwd_f32(const float* x0, int64_t P, int64_t K, int n_layers, const
                       size_t workspace_bytes, mp_stream_t stream);
 int mp_sa_mlp_bwd_f32(const float* x0, int64_t P, int64_t K, int n_layers, const mp_mlp_layer_t* layers, int training,
                       const float* grad_out, const float* out, const int32_t* argk, const float* zmax,
-                      const mp_mlp_grads_t* grads, float* grad_x0, void* workspace, size_t workspace_bytes,
-                      mp_stream_t stream);
+                      const mp_mlp_grads_t* grads, float* grad_x0, int64_t grad_x0_cols, void* workspace,
+                      size_t workspace_bytes, mp_stream_t stream);
 
 /* ---- optional per-kernel device timing (bench / profiling aid; off by default) ------------------------------------
  * No counterpart in the reference (its only timing is wall-clock prints: train_maskplanner.py:236-239).

@@ -147,10 +147,10 @@ __device__ __forceinline__ float4 finish(const Raw4<MODE>& r, const ChanConst& k
 }
 
 // Plain matrix rows (weights): row-major [R, C] with C % 4 == 0, no transform, zero outside.
-__device__ __forceinline__ float4 ld4_plain(const float* m, int R, int C, int r, int c)
+__device__ __forceinline__ float4 ld4_plain(const float* m, int R, int C, int ld, int r, int c)
 {
-    const bool ok = r < R && c < C;
-    const float4 v = ld4(m + (size_t)((unsigned)(ok ? r : 0) * (unsigned)C + (unsigned)(ok ? c : 0)));
+    const bool ok = r < R && c < C;   // C = valid columns, ld = row stride (both multiples of 4)
+    const float4 v = ld4(m + (size_t)((unsigned)(ok ? r : 0) * (unsigned)ld + (unsigned)(ok ? c : 0)));
     return ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
@@ -212,8 +212,9 @@ __global__ __launch_bounds__(THREADS) void pos_gemm_kernel(PosOperand A, int P, 
                                                            int Kd, float* __restrict__ C, float* __restrict__ partials,
                                                            const float* __restrict__ zprev,
                                                            const float* __restrict__ sprev,
-                                                           const float* __restrict__ tprev, PoolOut po)
-{
+                                                           const float* __restrict__ tprev, PoolOut po, int ldw,
+                                                           int ldc)
+{   // ldw: row stride of W in the NN form (>= N: only the first N columns are produced); ldc: row stride of C
     constexpr int BM = WAVES_M * TM * 32;
     constexpr int BN = WAVES_N * TN * 32;
     constexpr int LDB = W_KROW ? BN : LDK;
@@ -254,9 +255,9 @@ __global__ __launch_bounds__(THREADS) void pos_gemm_kernel(PosOperand A, int P, 
         for (int ps = 0; ps < B_PASSES; ++ps) {
             if constexpr (W_KROW) {  // slab [BK][BN] of W[Kd, N]
                 const int e = (ps * THREADS + tid) * 4;
-                rb[ps] = ld4_plain(W, Kd, N, k0 + e / BN, n0 + e % BN);
+                rb[ps] = ld4_plain(W, Kd, N, ldw, k0 + e / BN, n0 + e % BN);
             } else {                 // rows of W[N, Kd], K contiguous
-                rb[ps] = ld4_plain(W, N, Kd, n0 + ps * RPP + arow, k0 + acol);
+                rb[ps] = ld4_plain(W, N, Kd, Kd, n0 + ps * RPP + arow, k0 + acol);
             }
         }
     };
@@ -320,7 +321,7 @@ __global__ __launch_bounds__(THREADS) void pos_gemm_kernel(PosOperand A, int P, 
                     const int row = rbase + acc_row_in_tile(r);
                     const bool ok = cok && (!CHECKED || row < P);
                     const float v = acc[mi][ni][r];
-                    if (ok && C) C[(size_t)((unsigned)row * (unsigned)N + (unsigned)col)] = v;
+                    if (ok && C) C[(size_t)((unsigned)row * (unsigned)ldc + (unsigned)col)] = v;
                     if constexpr (EPI == EPI_SQ || EPI == EPI_SQ_POOL) {
                         if (ok) { s1 += v; s2 += v * v; }
                     } else if constexpr (EPI == EPI_DY) {
@@ -423,7 +424,7 @@ __global__ __launch_bounds__(256) void pool_select_kernel(PoolOut po, const floa
 // =================================================================================================================
 template <int MODE_DZ, int MODE_IN, int WAVES_M, int WAVES_N, int TM, int TN>
 __global__ __launch_bounds__(THREADS) void dw_gemm_kernel(PosOperand DZ, PosOperand IN, int P, int p_per_block,
-                                                          float* __restrict__ dW)
+                                                          float* __restrict__ dW, int ci_base)
 {
     constexpr int DBK = 32;                 // positions per K chunk
     constexpr int BM = WAVES_M * TM * 32;   // output channels (rows of dW)
@@ -436,7 +437,7 @@ __global__ __launch_bounds__(THREADS) void dw_gemm_kernel(PosOperand DZ, PosOper
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     const int wrow0 = (wave / WAVES_N) * TM * 32, wcol0 = (wave % WAVES_N) * TN * 32;
-    const int co0 = blockIdx.y * BM, ci0 = blockIdx.z * BN;
+    const int co0 = blockIdx.y * BM, ci0 = ci_base + blockIdx.z * BN;
     const int p0 = blockIdx.x * p_per_block;
     const int p1 = min(P, p0 + p_per_block);
 
@@ -507,18 +508,31 @@ int launch_dw(const PosOperand& DZ, const PosOperand& IN, int64_t P64, float* dW
     int ppb = 1024;
     while ((P + ppb - 1) / ppb < 128 && ppb > 128) ppb >>= 1;  // keep >= 128 position slices for small P (group_all)
     const unsigned gx = (unsigned)((P + ppb - 1) / ppb), gy = (Co + 127) / 128;
-    const double flops = 2.0 * (double)P * Co * Ci;
-    const double bytes = 4.0 * ((MODE_DZ == SRC_DZ ? 2.0 : 1.0) * (double)P * Co + (double)P * Ci + (double)Co * Ci);
+    // input-channel tiling: 128-wide tiles, a narrow remainder (132 = 128 + 4, 260 = 2*128 + 4) gets 32-wide tiles so
+    // that it does not pay for a whole 128-column MFMA tile of zeros
+    const int main_ci = (Ci > 128 && Ci % 128 != 0 && Ci % 128 <= 32) ? (Ci / 128) * 128 : Ci;
     char tag[96];
-    if (Ci <= 32) {
+    auto work = [&](int cols, double& flops, double& bytes) {
+        flops = 2.0 * (double)P * Co * cols;
+        bytes = 4.0 * ((MODE_DZ == SRC_DZ ? 2.0 : 1.0) * (double)P * Co + (double)P * cols + (double)Co * cols);
+    };
+    double flops, bytes;
+    work(main_ci, flops, bytes);
+    if (main_ci <= 32) {
         snprintf(tag, sizeof tag, "dw_gemm_kernel<%d, %d, 4, 1, 1, 1>", MODE_DZ, MODE_IN);
-        MP_LAUNCH(tag, flops, bytes, (dw_gemm_kernel<MODE_DZ, MODE_IN, 4, 1, 1, 1>), dim3(gx, gy, (Ci + 31) / 32), dim3(THREADS), 0, stream, DZ, IN, P, ppb, dW);
-    } else if (Ci <= 64) {
+        MP_LAUNCH(tag, flops, bytes, (dw_gemm_kernel<MODE_DZ, MODE_IN, 4, 1, 1, 1>), dim3(gx, gy, (main_ci + 31) / 32), dim3(THREADS), 0, stream, DZ, IN, P, ppb, dW, 0);
+    } else if (main_ci <= 64) {
         snprintf(tag, sizeof tag, "dw_gemm_kernel<%d, %d, 4, 1, 1, 2>", MODE_DZ, MODE_IN);
-        MP_LAUNCH(tag, flops, bytes, (dw_gemm_kernel<MODE_DZ, MODE_IN, 4, 1, 1, 2>), dim3(gx, gy, (Ci + 63) / 64), dim3(THREADS), 0, stream, DZ, IN, P, ppb, dW);
+        MP_LAUNCH(tag, flops, bytes, (dw_gemm_kernel<MODE_DZ, MODE_IN, 4, 1, 1, 2>), dim3(gx, gy, (main_ci + 63) / 64), dim3(THREADS), 0, stream, DZ, IN, P, ppb, dW, 0);
     } else {
         snprintf(tag, sizeof tag, "dw_gemm_kernel<%d, %d, 2, 2, 2, 2>", MODE_DZ, MODE_IN);
-        MP_LAUNCH(tag, flops, bytes, (dw_gemm_kernel<MODE_DZ, MODE_IN, 2, 2, 2, 2>), dim3(gx, gy, (Ci + 127) / 128), dim3(THREADS), 0, stream, DZ, IN, P, ppb, dW);
+        MP_LAUNCH(tag, flops, bytes, (dw_gemm_kernel<MODE_DZ, MODE_IN, 2, 2, 2, 2>), dim3(gx, gy, (main_ci + 127) / 128), dim3(THREADS), 0, stream, DZ, IN, P, ppb, dW, 0);
+    }
+    MP_CHECK_LAUNCH();
+    if (main_ci < Ci) {
+        work(Ci - main_ci, flops, bytes);
+        snprintf(tag, sizeof tag, "dw_gemm_kernel<%d, %d, 4, 1, 1, 1>", MODE_DZ, MODE_IN);
+        MP_LAUNCH(tag, flops, bytes, (dw_gemm_kernel<MODE_DZ, MODE_IN, 4, 1, 1, 1>), dim3(gx, gy, (Ci - main_ci + 31) / 32), dim3(THREADS), 0, stream, DZ, IN, P, ppb, dW, main_ci);
     }
     MP_CHECK_LAUNCH();
     return MP_OK;
@@ -685,8 +699,10 @@ __global__ __launch_bounds__(256) void pool_bwd_prep_kernel(const float* __restr
 template <int MODE, bool W_KROW, int EPI>
 int launch_pos_gemm(const PosOperand& A, int64_t P, const float* W, int N, int Kd, float* C, float* partials,
                     const float* zprev, const float* sprev, const float* tprev, hipStream_t stream, int* nblk_out,
-                    PoolOut po = PoolOut{})
+                    PoolOut po = PoolOut{}, int ldw = 0, int ldc = 0)
 {
+    if (ldw == 0) ldw = N;
+    if (ldc == 0) ldc = N;
     const unsigned gm = (unsigned)((P + 127) / 128);
     if (nblk_out) *nblk_out = (int)gm;
     // algorithmic work of one launch: 2*P*N*Kd flops; bytes = operand(s) read once + result written once + weights
@@ -697,11 +713,11 @@ int launch_pos_gemm(const PosOperand& A, int64_t P, const float* W, int N, int K
     if (N <= 64) {
         snprintf(tag, sizeof tag, "pos_gemm_kernel<%d, %s, %d, 4, 1, 1, 2>", MODE, W_KROW ? "true" : "false", EPI);
         MP_LAUNCH(tag, flops, bytes, (pos_gemm_kernel<MODE, W_KROW, EPI, 4, 1, 1, 2>), dim3(gm, (N + 63) / 64),
-                  dim3(THREADS), 0, stream, A, (int)P, W, N, Kd, C, partials, zprev, sprev, tprev, po);
+                  dim3(THREADS), 0, stream, A, (int)P, W, N, Kd, C, partials, zprev, sprev, tprev, po, ldw, ldc);
     } else {
         snprintf(tag, sizeof tag, "pos_gemm_kernel<%d, %s, %d, 2, 2, 2, 2>", MODE, W_KROW ? "true" : "false", EPI);
         MP_LAUNCH(tag, flops, bytes, (pos_gemm_kernel<MODE, W_KROW, EPI, 2, 2, 2, 2>), dim3(gm, (N + 127) / 128),
-                  dim3(THREADS), 0, stream, A, (int)P, W, N, Kd, C, partials, zprev, sprev, tprev, po);
+                  dim3(THREADS), 0, stream, A, (int)P, W, N, Kd, C, partials, zprev, sprev, tprev, po, ldw, ldc);
     }
     MP_CHECK_LAUNCH();
     return MP_OK;
@@ -821,8 +837,8 @@ extern "C" int mp_sa_mlp_fwd_f32(const float* x0, int64_t P, int64_t K, int n_la
 
 extern "C" int mp_sa_mlp_bwd_f32(const float* x0, int64_t P, int64_t K, int n_layers, const mp_mlp_layer_t* layers,
                                  int training, const float* grad_out, const float* out, const int32_t* argk,
-                                 const float* zmax, const mp_mlp_grads_t* grads, float* grad_x0, void* workspace,
-                                 size_t workspace_bytes, mp_stream_t stream_)
+                                 const float* zmax, const mp_mlp_grads_t* grads, float* grad_x0, int64_t grad_x0_cols,
+                                 void* workspace, size_t workspace_bytes, mp_stream_t stream_)
 {
     if (P < 0 || K <= 0 || n_layers <= 0 || !layers || !grads) return MP_EINVAL;
     if (P == 0) return MP_OK;
@@ -921,11 +937,14 @@ extern "C" int mp_sa_mlp_bwd_f32(const float* x0, int64_t P, int64_t K, int n_la
             MP_CHECK_LAUNCH();
             G_cur = Gn;
         } else if (grad_x0) {
+            // only the first grad_x0_cols input channels need a gradient (the features; the centred coordinates that
+            // follow them are not differentiated): skip the N tiles beyond them.  Rows of grad_x0 stay Ci apart.
+            int ncols = (grad_x0_cols > 0 && grad_x0_cols < Ci) ? (int)((grad_x0_cols + 3) / 4 * 4) : Ci;
             int rc;
             if (pooled)
-                rc = launch_pos_gemm<SRC_DZ_POOLED, true, EPI_NONE>(DZ, P, Ly.weight, Ci, Co, grad_x0, nullptr, nullptr, nullptr, nullptr, stream, nullptr);
+                rc = launch_pos_gemm<SRC_DZ_POOLED, true, EPI_NONE>(DZ, P, Ly.weight, ncols, Co, grad_x0, nullptr, nullptr, nullptr, nullptr, stream, nullptr, PoolOut{}, Ci, Ci);
             else
-                rc = launch_pos_gemm<SRC_DZ, true, EPI_NONE>(DZ, P, Ly.weight, Ci, Co, grad_x0, nullptr, nullptr, nullptr, nullptr, stream, nullptr);
+                rc = launch_pos_gemm<SRC_DZ, true, EPI_NONE>(DZ, P, Ly.weight, ncols, Co, grad_x0, nullptr, nullptr, nullptr, nullptr, stream, nullptr, PoolOut{}, Ci, Ci);
             if (rc != MP_OK) return rc;
         }
     }

@@ -114,7 +114,8 @@ def query_ball_point(radius, nsample, xyz, new_xyz):
     return ops.ball_query(radius, nsample, xyz, new_xyz)
 
 
-def sample_and_group(npoint, radius, nsample, xyz, points, returnfps=False, full_points=None, _pad_to=1):
+def sample_and_group(npoint, radius, nsample, xyz, points, returnfps=False, full_points=None, _pad_to=1,
+                     _xyz_last=False):
     """FPS -> ball query -> gather/centre/concat (:112-148).  xyz [B,N,3], points [B,N,D] or None.
     Returns new_xyz [B,npoint,3], new_points [B,npoint,nsample,3+D] (xyz channels first).
     (_pad_to is internal: the set-abstraction modules ask for rows padded to a multiple of 4 floats.)"""
@@ -126,7 +127,7 @@ def sample_and_group(npoint, radius, nsample, xyz, points, returnfps=False, full
         fps_idx, new_xyz = ops.fps(xyz, npoint, _draw_fps_start(B, N, xyz.device), return_xyz=True)
         idx = ops.ball_query(radius, nsample, xyz, new_xyz)
     if points is not None:
-        new_points = ops.group(xyz, points, new_xyz, idx, pad_to=_pad_to)
+        new_points = ops.group(xyz, points, new_xyz, idx, xyz_last=_xyz_last, pad_to=_pad_to)
     elif full_points is not None:
         new_points = ops.index_points(full_points, idx)  # un-centred full features (:139-141)
     else:
@@ -174,12 +175,21 @@ class PointNetSetAbstraction(nn.Module):
         xyz = _points_major(xyz)
         points = None if points is None else _points_major(points)
         full_points = None if full_points is None else _points_major(full_points)
+        # internal channel order: features first, coordinates last, rows padded to a multiple of 4 floats (sa_mlp.py)
+        layout = "feats_first" if (points is not None and full_points is None) else "xyz_first"
         if self.group_all:
-            new_xyz, grouped = sample_and_group_all(xyz, points)
+            B, N, C = xyz.shape
+            new_xyz = torch.zeros(B, 1, C, device=xyz.device)
+            if points is None:
+                grouped = xyz.view(B, 1, N, C)
+            else:
+                pad = (-(C + points.shape[2])) % 4
+                parts = [points, xyz] + ([xyz.new_zeros(B, N, pad)] if pad else [])
+                grouped = torch.cat(parts, dim=-1).view(B, 1, N, -1)
         else:
             new_xyz, grouped = sample_and_group(self.npoint, self.radius, self.nsample, xyz, points,
-                                                full_points=full_points, _pad_to=4)
-        new_points = sa_mlp.shared_mlp_max(grouped, self.mlp_convs, self.mlp_bns)  # [B,S,C']
+                                                full_points=full_points, _pad_to=4, _xyz_last=True)
+        new_points = sa_mlp.shared_mlp_max(grouped, self.mlp_convs, self.mlp_bns, layout=layout)  # [B,S,C']
         return new_xyz.permute(0, 2, 1), new_points.permute(0, 2, 1)
 
 

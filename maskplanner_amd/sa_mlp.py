@@ -22,7 +22,7 @@ class _SharedMLPMax(torch.autograd.Function):
     weight[Co,Ci], bias|None, gamma, beta, running_mean|None, running_var|None."""
 
     @staticmethod
-    def forward(ctx, x, K, training, momentum, eps, n_layers, *params):
+    def forward(ctx, x, K, training, momentum, eps, n_layers, grad_cols, *params):
         dev = x.device
         P, C0 = x.shape
         layers = (_lib.MlpLayer * n_layers)()
@@ -47,7 +47,7 @@ class _SharedMLPMax(torch.autograd.Function):
         ws = torch.empty((lib.mp_sa_mlp_workspace_bytes(P, K, n_layers, ch, 0),), dtype=torch.uint8, device=dev)
         ops._run("sa_mlp_fwd", x, lib.mp_sa_mlp_fwd_f32, _ptr(x), P, K, n_layers, layers, int(training), float(momentum),
                  float(eps), _ptr(out), _ptr(argk), _ptr(zmax), _ptr(ws), ws.numel())
-        ctx.meta = (P, K, bool(training), n_layers, chans)
+        ctx.meta = (P, K, bool(training), n_layers, chans, int(grad_cols))
         ctx.keep = keep
         ctx.save_for_backward(x, out, argk, zmax)
         ctx.mark_non_differentiable(argk, zmax)
@@ -56,7 +56,7 @@ class _SharedMLPMax(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out):
         x, out, argk, zmax = ctx.saved_tensors
-        P, K, training, n_layers, chans = ctx.meta
+        P, K, training, n_layers, chans, grad_cols = ctx.meta
         dev = x.device
         grad_out = grad_out.contiguous().float()
         layers = (_lib.MlpLayer * n_layers)()
@@ -71,20 +71,33 @@ class _SharedMLPMax(torch.autograd.Function):
             dg, dbe = torch.empty_like(gam), torch.empty_like(bet)
             grads[l] = _lib.MlpGrads(_ptr(dw), _ptr(db), _ptr(dg), _ptr(dbe))
             ret += [dw, db, dg, dbe, None, None]
-        gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        # with grad_cols only the leading (feature) columns are produced: the others are never read downstream, but
+        # zero them once so that a stray consumer can never see uninitialised memory
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty_like(x)
+            if 0 < grad_cols < x.shape[1]:
+                gx[:, (grad_cols + 3) // 4 * 4:].zero_()
         ch = (ctypes.c_int64 * len(chans))(*chans)
         lib = _lib.load()
         ws = torch.empty((lib.mp_sa_mlp_workspace_bytes(P, K, n_layers, ch, 1),), dtype=torch.uint8, device=dev)
         ops._run("sa_mlp_bwd", x, lib.mp_sa_mlp_bwd_f32, _ptr(x), P, K, n_layers, layers, int(training), _ptr(grad_out),
-                 _ptr(out), _ptr(argk), _ptr(zmax), grads, _ptr(gx), _ptr(ws), ws.numel())
+                 _ptr(out), _ptr(argk), _ptr(zmax), grads, _ptr(gx), grad_cols, _ptr(ws), ws.numel())
         ctx.keep = None
-        return (gx, None, None, None, None, None, *ret)
+        return (gx, None, None, None, None, None, None, *ret)
 
 
-def shared_mlp_max(grouped, convs, bns):
-    """grouped [B,S,K,Cin (+ zero padding up to a multiple of 4)] -> [B,S,Cout] = max_K relu(bn(conv(.))) chained over
-    the layers (fused HIP path).  The kernels work on float4 channel groups: an input with Cin % 4 != 0 that was not
-    already padded by ops.group(pad_to=4) is zero-padded here, and the first weight gets matching zero columns."""
+def shared_mlp_max(grouped, convs, bns, layout="xyz_first"):
+    """grouped [B,S,K,C (+ zero padding up to a multiple of 4)] -> [B,S,Cout] = max_K relu(bn(conv(.))) chained over the
+    layers (fused HIP path).
+
+    layout describes the channel order of `grouped` relative to the first conv's input channels:
+      "xyz_first"   : as the module's weight expects them (reference order, models/pointnet2_utils.py:138);
+      "feats_first" : [features (Cin-3), centred xyz (3), zero pad] -- what the set-abstraction modules of this package
+                      produce internally.  The first weight's columns are rotated to match, and backward computes the
+                      input gradient of the feature columns only (coordinates carry no gradient on this path), which
+                      drops the near-empty second 128-column tile of a 131-channel input.
+    The kernels work on float4 channel groups: an input with C % 4 != 0 is zero-padded here."""
     import torch.nn.functional as F
     ops._need_hip(grouped)
     B, S, K, C = grouped.shape
@@ -107,8 +120,11 @@ def shared_mlp_max(grouped, convs, bns):
         if training and bn.track_running_stats:
             bn.num_batches_tracked.add_(1)
         w = conv.weight.view(conv.out_channels, conv.in_channels)
-        if i == 0 and cpad != cin:
-            w = F.pad(w, (0, cpad - cin))
+        if i == 0:
+            if layout == "feats_first" and cin > 3:
+                w = torch.cat([w[:, 3:], w[:, :3]], dim=1)
+            if cpad != cin:
+                w = F.pad(w, (0, cpad - cin))
         track = bn.track_running_stats and bn.running_mean is not None
         if not training and not track:
             raise NotImplementedError("eval-mode BatchNorm without running statistics")
@@ -116,5 +132,6 @@ def shared_mlp_max(grouped, convs, bns):
                    bn.running_var if track else None]
     bn0 = bns[0]
     momentum = bn0.momentum if bn0.momentum is not None else 1.0 / max(float(bn0.num_batches_tracked), 1.0)
-    out = _SharedMLPMax.apply(x, K, training, momentum, bn0.eps, len(convs), *params)
+    grad_cols = cin - 3 if (layout == "feats_first" and cin > 3) else 0
+    out = _SharedMLPMax.apply(x, K, training, momentum, bn0.eps, len(convs), grad_cols, *params)
     return out.view(B, S, -1)
