@@ -65,7 +65,7 @@ def cpu_baseline(cat, N, seed):
     from oracle import oracle as O
     from oracle import torch_ref as T
     O.build()
-    Bc = 4
+    Bc = 16  # ~10 s of host work
     batch = syn.make_batch(seed, Bc, N, cat.name, "cuboid")
     torch.manual_seed(seed)
     sd = {k: v.detach().clone().requires_grad_(v.dtype.is_floating_point and "running" not in k)

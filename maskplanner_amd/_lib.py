@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libmaskplanner_hip.so")
+LIB_PATH = os.environ.get("MASKPLANNER_HIP_LIB") or os.path.join(_HERE, "lib", "libmaskplanner_hip.so")  # env: diagnostic builds
 ABI_VERSION = 1
 
 MP_OK = 0

@@ -249,6 +249,9 @@ __global__ __launch_bounds__(THREADS) void pos_gemm_kernel(PosOperand A, int P, 
     const int arow = tid / TPR, acol = (tid % TPR) * 4;
     auto gload = [&](int k0) {
         load_consts<MODE>(A, k0 + acol, kc);
+#ifdef MP_ABLATE_LOAD
+        if (k0 > 0) return;   // only the first chunk is really loaded
+#endif
 #pragma unroll
         for (int ps = 0; ps < A_PASSES; ++ps) raw_load<MODE>(A, P, m0 + ps * RPP + arow, k0 + acol, ra[ps]);
 #pragma unroll
@@ -286,7 +289,9 @@ __global__ __launch_bounds__(THREADS) void pos_gemm_kernel(PosOperand A, int P, 
     for (int kc_ = 0; kc_ < nchunks; ++kc_) {
         const int cur = kc_ & 1;
         if (kc_ + 1 < nchunks) gload((kc_ + 1) * BK);
+#ifndef MP_ABLATE_MFMA
         mma_chunk<false, W_KROW, LDK, LDB, TM, TN, BK>(sA[cur], sB[cur], wrow0, wcol0, acc);
+#endif
         if (kc_ + 1 < nchunks) sstore(cur ^ 1);
         __syncthreads();
     }
@@ -365,7 +370,11 @@ __global__ __launch_bounds__(THREADS) void pos_gemm_kernel(PosOperand A, int P, 
             }
         }
     };
+#ifdef MP_ABLATE_EPI
+    if (acc[0][0][0] == 12345.678f) epilogue(std::true_type{});   // keeps acc alive, never taken
+#else
     if (interior) epilogue(std::false_type{}); else epilogue(std::true_type{});
+#endif
     if constexpr (SUMS) {
         __syncthreads();
         for (int e = tid; e < 2 * BN; e += THREADS) {

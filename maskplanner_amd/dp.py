@@ -9,8 +9,10 @@ are laid out in reverse registration order so those big buckets are on the wire 
 xGMI is point-to-point (7 links x ~153 GB/s per GPU), so a ring all-reduce is bound by one link; buckets are
 kept large (default 64 MB) to stay in the bandwidth regime and few enough that per-collective latency is noise.
 
-Gradients live in flat per-bucket buffers: every `param.grad` is a view into its bucket, autograd accumulates in
-place, and the all-reduce runs on the flat buffer directly (no pack/unpack copies).
+Each bucket owns one flat buffer.  Autograd writes gradients as usual (no pre-existing .grad, so no accumulate pass);
+when the last gradient of a bucket is ready its members are packed into the flat buffer with ONE multi-tensor copy,
+`param.grad` is re-pointed at views of that buffer, and the all-reduce (average) is started on the flat buffer: no
+unpack copy afterwards, the optimizer reads the reduced values in place.
 """
 import torch
 import torch.distributed as dist
@@ -23,7 +25,9 @@ class BucketedGradAllReduce:
         params = [p for p in params if p.requires_grad]
         self.params = params
         self.buckets = []
+        self._views = []
         self._handles, self._pending, self._hooks = [], [], []
+        self._avg = dist.is_initialized() and dist.get_backend(process_group) == "nccl"  # gloo has no AVG
         if self.world == 1:
             return  # nothing to exchange: let autograd write .grad directly (no flat buffers, no extra add/zero passes)
         order = list(reversed(params))  # heads first == the order gradients become ready in backward
@@ -37,9 +41,8 @@ class BucketedGradAllReduce:
             cur_bytes += nbytes
         if cur:
             self._close(cur)
-        self._handles = []
         self._pending = [len(ps) for _, ps in self.buckets]
-        self._hooks = []
+        self._done = [False] * len(self.buckets)
         if self.world > 1:
             for bi, (_, ps) in enumerate(self.buckets):
                 for p in ps:
@@ -47,19 +50,33 @@ class BucketedGradAllReduce:
 
     def _close(self, ps):
         flat = torch.zeros(sum(p.numel() for p in ps), dtype=ps[0].dtype, device=ps[0].device)
-        off = 0
+        views, off = [], 0
         for p in ps:
-            p.grad = flat[off:off + p.numel()].view_as(p)
+            views.append(flat[off:off + p.numel()].view_as(p))
             off += p.numel()
         self.buckets.append((flat, ps))
+        self._views.append(views)
+
+    def _reduce_bucket(self, bi):
+        flat, ps = self.buckets[bi]
+        views = self._views[bi]
+        have = [(v, p.grad) for v, p in zip(views, ps) if p.grad is not None]
+        if len(have) != len(ps):
+            flat.zero_()  # a parameter without gradient this step contributes zeros
+        if have:
+            torch._foreach_copy_([v for v, _ in have], [g for _, g in have])  # one fused pack kernel per bucket
+        for p, v in zip(ps, views):
+            p.grad = v
+        # RCCL runs on its own stream and is ordered after everything already queued on the compute stream
+        op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
+        self._handles.append(dist.all_reduce(flat, op=op, group=self.group, async_op=True))
+        self._done[bi] = True
 
     def _make_hook(self, bi):
         def hook(_param):
             self._pending[bi] -= 1
             if self._pending[bi] == 0:
-                flat = self.buckets[bi][0]
-                # RCCL runs on its own stream and is ordered after everything already queued on the compute stream
-                self._handles.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                self._reduce_bucket(bi)
         return hook
 
     def zero_grad(self):
@@ -68,24 +85,25 @@ class BucketedGradAllReduce:
             for p in self.params:
                 p.grad = None
             return
-        for flat, _ in self.buckets:
-            flat.zero_()
+        for p in self.params:
+            p.grad = None  # autograd then WRITES the next gradients instead of accumulating into the flat views
         self._pending = [len(ps) for _, ps in self.buckets]
+        self._done = [False] * len(self.buckets)
 
     def finish(self):
         """Wait for the in-flight all-reduces (the compute stream waits, not the host) and average."""
         if self.world == 1:
             return
         # a parameter that received no gradient this step never fired its hook: reduce its bucket now
-        for bi, left in enumerate(self._pending):
-            if left > 0:
-                self._handles.append(dist.all_reduce(self.buckets[bi][0], op=dist.ReduceOp.SUM, group=self.group,
-                                                     async_op=True))
+        for bi, done in enumerate(self._done):
+            if not done:
+                self._reduce_bucket(bi)
         for h in self._handles:
             h.wait()
         self._handles = []
-        for flat, _ in self.buckets:
-            flat.div_(self.world)
+        if not self._avg:
+            for flat, _ in self.buckets:
+                flat.div_(self.world)
 
     def grad_bytes(self):
         return sum(p.numel() * p.element_size() for p in self.params)

@@ -117,8 +117,6 @@ def shared_mlp_max(grouped, convs, bns, layout="xyz_first"):
             raise ValueError("all BatchNorm layers of a set-abstraction level must share one mode")
         if conv.out_channels % 4:
             raise NotImplementedError("fused set-abstraction MLP: layer widths must be multiples of 4")
-        if training and bn.track_running_stats:
-            bn.num_batches_tracked.add_(1)
         w = conv.weight.view(conv.out_channels, conv.in_channels)
         if i == 0:
             if layout == "feats_first" and cin > 3:
@@ -130,6 +128,10 @@ def shared_mlp_max(grouped, convs, bns, layout="xyz_first"):
             raise NotImplementedError("eval-mode BatchNorm without running statistics")
         params += [w, conv.bias, bn.weight, bn.bias, bn.running_mean if track else None,
                    bn.running_var if track else None]
+    if training:
+        counters = [bn.num_batches_tracked for bn in bns if bn.track_running_stats and bn.num_batches_tracked is not None]
+        if counters:
+            torch._foreach_add_(counters, 1)  # one launch for the level instead of one per BatchNorm
     bn0 = bns[0]
     momentum = bn0.momentum if bn0.momentum is not None else 1.0 / max(float(bn0.num_batches_tracked), 1.0)
     grad_cols = cin - 3 if (layout == "feats_first" and cin > 3) else 0
