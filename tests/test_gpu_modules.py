@@ -414,3 +414,48 @@ def test_segmenters_match_reference(golden):
     with pu.fps_start_override([g["sg_fps_start1"], g["sg_fps_start2"]]), torch.no_grad():
         out2 = m2(dev(g["sg_in"]))
     close(out2, g["sg_out"], "Segmenter_v1 out")
+
+
+# ------------------------------------------------------------------------------------------------ other BASELINE configs
+@pytest.mark.parametrize("category", ["windows", "shelves", "containers"])
+def test_categories_forward_loss_vs_oracle(category):
+    """BASELINE configs 3-5 output shapes (windows S=449 M=22, shelves S=1266 M=41, containers S=1333 M=33): full model
+    + asymm_v6 loss with the mask terms on, eval-mode BatchNorm, against the CPU restatement; then one train step."""
+    from maskplanner_amd.harness import TrainStep
+    from oracle import torch_ref as T
+    ts = TrainStep(category, B=2, N=1024, hidden_size=(128, 128))
+    ts.model.dropout.p = 0.0
+    sd = {k: v.detach().cpu().clone() for k, v in ts.model.state_dict().items()}
+    b = {k: (v.cpu() if torch.is_tensor(v) else [t.cpu() for t in v]) for k, v in ts.batch.items()}
+    ts.model.eval()
+    with torch.no_grad():
+        got = float(ts.forward_loss())
+    o_out, o_sm, o_conf = T.strokemasks_forward(sd, b["point_cloud"], [s.numpy() for s in b["fps_start"]], train=False,
+                                                out_vectors=ts.cat.out_vectors, n_masks=ts.cat.max_n_strokes)
+    ref = float(T.asymm_v6_loss(o_out, b["traj"], o_sm, o_conf, b["stroke_ids"], b["traj_as_pc"], ts.cfg))
+    assert abs(got - ref) <= 1e-5 * max(1.0, abs(ref)), (got, ref)
+    ts.model.train()
+    assert torch.isfinite(ts.step())
+
+
+def test_msg_encoder_full_size_vs_oracle(oracle):
+    """BASELINE config 5: multi-scale grouping at N=10240 (three radii / group sizes, upstream PointNet++ MSG widths),
+    train-mode BatchNorm, against the CPU restatement with the same weights and FPS starts."""
+    from maskplanner_amd import pointnet2_utils as pu
+    from maskplanner_amd import synthetic as syn
+    from oracle import torch_ref as T
+    B, N = 2, 10240
+    rng = np.random.default_rng(55)
+    xyz = syn.point_cloud(rng, B, N, "cuboid")
+    torch.manual_seed(5)
+    msg = pu.PointNetSetAbstractionMsg(512, [0.1, 0.2, 0.4], [16, 32, 128], 0, [[32, 32, 64], [64, 64, 128], [64, 96, 128]])
+    sd = {k: v.detach().clone() for k, v in msg.state_dict().items()}
+    start = rng.integers(0, N, size=B)
+    msg = msg.cuda().train()
+    with pu.fps_start_override([start]):
+        new_xyz, out = msg(dev(xyz).permute(0, 2, 1), None)
+    blocks = [T.layers_from_state(sd, "", convs=f"conv_blocks.{i}", bns=f"bn_blocks.{i}") for i in range(3)]
+    o_xyz, o_out = T.set_abstraction_msg(torch.from_numpy(xyz), None, blocks, 512, [0.1, 0.2, 0.4], [16, 32, 128], start, True)
+    assert out.shape == (B, 320, 512)
+    close(new_xyz.permute(0, 2, 1), o_xyz, "new_xyz", atol=0, rtol=0)
+    close(out.permute(0, 2, 1), o_out, "msg features", rtol=1e-4, atol=1e-4)   # train-mode BN at small B: a little above 1e-5
