@@ -1,5 +1,10 @@
 """Turn gpurun_out/<tag>_{bench,fetch,write} rocprofv3 CSVs into profiles/<tag>_*.md / .csv (committed evidence)."""
 import collections, csv, glob, json, os, sys
+
+
+def newest(pattern):
+    return max(glob.glob(pattern), key=os.path.getmtime)
+
 tag = sys.argv[1]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 go = os.path.join(root, "gpurun_out")
@@ -9,7 +14,7 @@ os.makedirs(out, exist_ok=True)
 def short(n):
     return n.replace("(anonymous namespace)::", "").replace("void ", "")
 
-stats = list(csv.DictReader(open(glob.glob(f"{go}/{tag}_bench/*/*_kernel_stats.csv")[0])))
+stats = list(csv.DictReader(open(newest(f"{go}/{tag}_bench/*/*_kernel_stats.csv"))))
 with open(f"{out}/{tag}_bench_kernel_stats.csv", "w") as f:
     w = csv.writer(f)
     w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
@@ -17,7 +22,7 @@ with open(f"{out}/{tag}_bench_kernel_stats.csv", "w") as f:
         w.writerow([short(r["Name"])[:160], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]])
 
 def pmc(kind):
-    rows = list(csv.DictReader(open(glob.glob(f"{go}/{tag}_{kind}/*/*_counter_collection.csv")[0])))
+    rows = list(csv.DictReader(open(newest(f"{go}/{tag}_{kind}/*/*_counter_collection.csv"))))
     agg = collections.defaultdict(list)
     for r in rows:
         agg[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
