@@ -175,6 +175,22 @@ int mp_sa_mlp_bwd_f32(const float* x0, int64_t P, int64_t K, int n_layers, const
                       const mp_mlp_grads_t* grads, float* grad_x0, int64_t grad_x0_cols, void* workspace,
                       size_t workspace_bytes, mp_stream_t stream);
 
+/* ---- fused "gradient from rank-B factors + Adam" for the head matrices (scope table row f1, "next") -----------------
+ * replaces, for a Linear weight W [O, I] whose gradient is dW = g^T x (g = dLoss/dy [Bg,O], x = input [Bg,I]):
+ *   the dW GEMM of autograd (models/pointnet2_cls_ssg.py:311,336,327 fc3 / fc_normals / sm_fc3) + the Adam update of
+ *   torch.optim.Adam (train_maskplanner.py:159, defaults: no amsgrad / weight decay).  dW is never materialised; under
+ *   data parallelism the factors (x, g) are gathered instead of all-reducing dW (grad_scale = 1/world).
+ *   param / exp_avg / exp_avg_sq [O, I] updated in place; step = 1-based update count. */
+int mp_adam_lowrank_f32(float* param, float* exp_avg, float* exp_avg_sq, const float* x, const float* g, int64_t Bg,
+                        int64_t O, int64_t I, double grad_scale, double lr, double beta1, double beta2, double eps,
+                        int64_t step, mp_stream_t stream);
+
+/* input gradient of the same layers: grad_x [B, I] = g [B, O] * W [O, I] for B <= 32 (one streaming read of W; the
+ * library GEMM rocBLAS selects for this skinny shape reaches ~0.6 TB/s).  I % 4 == 0.  grad_x is overwritten. */
+size_t mp_linear_dx_skinny_workspace_bytes(int64_t B, int64_t O, int64_t I);
+int mp_linear_dx_skinny_f32(const float* g, const float* weight, int64_t B, int64_t O, int64_t I, float* grad_x,
+                            void* workspace, size_t workspace_bytes, mp_stream_t stream);
+
 /* ---- optional per-kernel device timing (bench / profiling aid; off by default) ------------------------------------
  * No counterpart in the reference (its only timing is wall-clock prints: train_maskplanner.py:236-239).
  * When enabled, launches inside the library are bracketed by HIP events on the launch stream.  collect() waits for

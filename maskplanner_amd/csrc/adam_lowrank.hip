@@ -1,0 +1,222 @@
+// Fused "gradient from factors + Adam" update for the weight-heavy regression heads.
+//
+// Context ("next" row of the scope table): in MaskPlanner 97 % of the parameters sit in three
+// Linear layers fed by a [B,1024] feature (fc3, fc_normals, sm_fc3: models/pointnet2_cls_ssg.py:270-290).  Their
+// weight gradient is an outer-product sum of rank B:  dW[o,i] = sum_b g[b,o] * x[b,i]  with g = dLoss/dy [B,O] and
+// x the layer input [B,I].  The reference materialises dW (143 MB), torch.optim.Adam (train_maskplanner.py:159) reads
+// it back, and a data-parallel run would all-reduce it.  Here the factors (x, g) -- 1.5 MB -- are what gets exchanged
+// between GPUs, and this kernel forms each gradient element on the fly inside the Adam update, so dW never exists:
+// per step and parameter it moves 24 B (p, m, v read + write) instead of 28 B + a GEMM that writes another 4 B.
+//
+// Arithmetic = torch's Adam (no amsgrad / weight decay / maximize):
+//   m = lerp(m, grad, 1-beta1);  v = beta2*v + (1-beta2)*grad^2;
+//   p -= (lr / (1-beta1^t)) * m / (sqrt(v) / sqrt(1-beta2^t) + eps)
+// with grad accumulated in fp32 over b in ascending order (fma chain).
+#include "common.h"
+
+namespace {
+
+constexpr int AL_TO = 64, AL_TI = 64, AL_BC = 32;
+
+__global__ __launch_bounds__(256) void adam_lowrank_kernel(float* __restrict__ p, float* __restrict__ m,
+                                                           float* __restrict__ v, const float* __restrict__ x,
+                                                           const float* __restrict__ g, int Bg, int O, int I,
+                                                           float gscale, float lr_c1, float beta1, float beta2,
+                                                           float inv_sqrt_c2, float eps)
+{
+    __shared__ __attribute__((aligned(16))) float sg[AL_BC][AL_TO];
+    __shared__ __attribute__((aligned(16))) float sx[AL_BC][AL_TI];
+    const int tid = threadIdx.x;
+    const int to = tid >> 4, ti = tid & 15;
+    const int o0 = blockIdx.y * AL_TO, i0 = blockIdx.x * AL_TI;
+    float acc[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[r][c] = 0.0f;
+
+    for (int b0 = 0; b0 < Bg; b0 += AL_BC) {
+        __syncthreads();
+        // stage [AL_BC x 64] slabs of g and x (row-major in memory: coalesced along the 64 columns)
+        for (int e = tid; e < AL_BC * 16; e += 256) {
+            const int b = e >> 4, q = (e & 15) * 4;
+            float4 gv = make_float4(0.f, 0.f, 0.f, 0.f), xv = gv;
+            if (b0 + b < Bg) {
+                const float* gp = g + (size_t)(b0 + b) * O + o0 + q;
+                const float* xp = x + (size_t)(b0 + b) * I + i0 + q;
+                if (o0 + q + 3 < O && (O & 3) == 0) gv = *reinterpret_cast<const float4*>(gp);   // rows 16-B aligned
+                else if (o0 + q + 3 < O) { gv.x = gp[0]; gv.y = gp[1]; gv.z = gp[2]; gv.w = gp[3]; }
+                else { if (o0 + q < O) gv.x = gp[0]; if (o0 + q + 1 < O) gv.y = gp[1]; if (o0 + q + 2 < O) gv.z = gp[2]; }
+                if (i0 + q + 3 < I && (I & 3) == 0) xv = *reinterpret_cast<const float4*>(xp);
+                else if (i0 + q + 3 < I) { xv.x = xp[0]; xv.y = xp[1]; xv.z = xp[2]; xv.w = xp[3]; }
+                else { if (i0 + q < I) xv.x = xp[0]; if (i0 + q + 1 < I) xv.y = xp[1]; if (i0 + q + 2 < I) xv.z = xp[2]; }
+            }
+            *reinterpret_cast<float4*>(&sg[b][q]) = gv;
+            *reinterpret_cast<float4*>(&sx[b][q]) = xv;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int b = 0; b < AL_BC; ++b) {
+            const float4 gv = *reinterpret_cast<const float4*>(&sg[b][to * 4]);
+            const float4 xv = *reinterpret_cast<const float4*>(&sx[b][ti * 4]);
+            const float ga[4] = {gv.x, gv.y, gv.z, gv.w};
+            const float xa[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[r][c] = __builtin_fmaf(ga[r], xa[c], acc[r][c]);
+        }
+    }
+    const int i = i0 + ti * 4;
+    auto upd = [&](float grad, float& pp, float& mm, float& vv) {
+        mm = mm + (1.0f - beta1) * (grad - mm);                 // lerp form, as torch's fused Adam
+        vv = beta2 * vv + (1.0f - beta2) * grad * grad;
+        pp -= lr_c1 * (mm / (sqrtf(vv) * inv_sqrt_c2 + eps));
+    };
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int o = o0 + to * 4 + r;
+        if (o >= O) continue;
+        const size_t off = (size_t)o * I + i;
+        if (i + 3 < I && (I & 3) == 0) {   // whole float4 inside the row, rows 16-byte aligned
+            float4 p4 = *reinterpret_cast<float4*>(p + off), m4 = *reinterpret_cast<float4*>(m + off),
+                   v4 = *reinterpret_cast<float4*>(v + off);
+            upd(acc[r][0] * gscale, p4.x, m4.x, v4.x);
+            upd(acc[r][1] * gscale, p4.y, m4.y, v4.y);
+            upd(acc[r][2] * gscale, p4.z, m4.z, v4.z);
+            upd(acc[r][3] * gscale, p4.w, m4.w, v4.w);
+            *reinterpret_cast<float4*>(p + off) = p4;
+            *reinterpret_cast<float4*>(m + off) = m4;
+            *reinterpret_cast<float4*>(v + off) = v4;
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (i + c < I) upd(acc[r][c] * gscale, p[off + c], m[off + c], v[off + c]);
+        }
+    }
+}
+
+// Skinny input gradient of a Linear layer: out[b, i] = sum_o g[b, o] * W[o, i]  (B <= 32 rows, O up to tens of
+// thousands).  rocBLAS picks a 0.6 TB/s kernel for this shape; the product is bound by ONE read of W, so each block
+// streams a slab of SK_ROWS weight rows (coalesced float4 across the 256 threads), keeps the [B, 4] partial sums of
+// its 4 columns in registers and writes them as float4 rows of a per-block partial [nblk][B][I]; a second tiny kernel
+// sums the partials in block order (deterministic; 16-byte-strided float atomics would run at a fraction of the
+// atomic rate).
+constexpr int SK_ROWS = 64, SK_B = 32;
+__global__ __launch_bounds__(256) void linear_dx_skinny_kernel(const float* __restrict__ g, const float* __restrict__ W,
+                                                               int B, int O, int I, float* __restrict__ partial)
+{
+    __shared__ __attribute__((aligned(16))) float sg[SK_ROWS][SK_B];   // g^T slab: [o][b]
+    const int tid = threadIdx.x;
+    const int o0 = blockIdx.y * SK_ROWS;
+    const int i = (blockIdx.x * 256 + tid) * 4;
+    for (int e = tid; e < SK_ROWS * SK_B; e += 256) {
+        const int b = e / SK_ROWS, o = e - b * SK_ROWS;      // coalesced along o in global memory
+        sg[o][b] = (b < B && o0 + o < O) ? g[(size_t)b * O + o0 + o] : 0.0f;
+    }
+    __syncthreads();
+    if (i >= I) return;
+    float acc[SK_B][4];
+#pragma unroll
+    for (int b = 0; b < SK_B; ++b) acc[b][0] = acc[b][1] = acc[b][2] = acc[b][3] = 0.0f;
+    const int rows = min(SK_ROWS, O - o0);
+    constexpr int U = 8;   // weight rows in flight per thread: the loop is bound by HBM latency otherwise
+    for (int ob = 0; ob < rows; ob += U) {
+        float4 w[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int o = min(ob + u, rows - 1);   // clamped: the duplicate rows are skipped below
+            w[u] = *reinterpret_cast<const float4*>(W + (size_t)(o0 + o) * I + i);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (ob + u < rows) {
+#pragma unroll
+            for (int b4 = 0; b4 < SK_B; b4 += 4) {
+                const float4 gv = *reinterpret_cast<const float4*>(&sg[ob + u][b4]);   // broadcast read of 4 batch rows
+                const float gb[4] = {gv.x, gv.y, gv.z, gv.w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    acc[b4 + q][0] = __builtin_fmaf(gb[q], w[u].x, acc[b4 + q][0]);
+                    acc[b4 + q][1] = __builtin_fmaf(gb[q], w[u].y, acc[b4 + q][1]);
+                    acc[b4 + q][2] = __builtin_fmaf(gb[q], w[u].z, acc[b4 + q][2]);
+                    acc[b4 + q][3] = __builtin_fmaf(gb[q], w[u].w, acc[b4 + q][3]);
+                }
+            }
+            }
+        }
+    }
+    float* pb = partial + (size_t)blockIdx.y * B * I;
+#pragma unroll   // compile-time register indices: a run-time loop bound would push acc[][] to scratch
+    for (int b = 0; b < SK_B; ++b) {
+        if (b < B) *reinterpret_cast<float4*>(pb + (size_t)b * I + i) = make_float4(acc[b][0], acc[b][1], acc[b][2], acc[b][3]);
+    }
+}
+
+__global__ __launch_bounds__(64) void sum_partials_kernel(const float* __restrict__ partial, int nblk, int n4,
+                                                          float* __restrict__ out)
+{
+    const int e = blockIdx.x * 64 + threadIdx.x;   // one float4 of the [B, I] result
+    if (e >= n4) return;
+    // fixed summation order (block 0, 1, 2, ...), 8 independent loads in flight per thread
+    const float4* src = reinterpret_cast<const float4*>(partial) + e;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    int k = 0;
+    for (; k + 8 <= nblk; k += 8) {
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(k + u) * n4];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { a.x += v[u].x; a.y += v[u].y; a.z += v[u].z; a.w += v[u].w; }
+    }
+    for (; k < nblk; ++k) {
+        const float4 v = src[(size_t)k * n4];
+        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    reinterpret_cast<float4*>(out)[e] = a;
+}
+
+}  // namespace
+
+extern "C" int mp_adam_lowrank_f32(float* param, float* exp_avg, float* exp_avg_sq, const float* x, const float* g,
+                                   int64_t Bg, int64_t O, int64_t I, double grad_scale, double lr, double beta1,
+                                   double beta2, double eps, int64_t step, mp_stream_t stream_)
+{
+    if (Bg < 0 || O < 0 || I < 0 || step <= 0) return MP_EINVAL;
+    if (O == 0 || I == 0) return MP_OK;
+    if (!param || !exp_avg || !exp_avg_sq || (Bg > 0 && (!x || !g))) return MP_EINVAL;
+    const double c1 = 1.0 - pow(beta1, (double)step), c2 = 1.0 - pow(beta2, (double)step);
+    const dim3 grid((unsigned)((I + AL_TI - 1) / AL_TI), (unsigned)((O + AL_TO - 1) / AL_TO));
+    MP_LAUNCH("adam_lowrank_kernel", 2.0 * (double)Bg * O * I, 24.0 * (double)O * I + 4.0 * Bg * (double)(O + I),
+              adam_lowrank_kernel, grid, dim3(256), 0, mp_stream(stream_), param, exp_avg, exp_avg_sq, x, g, (int)Bg, (int)O,
+              (int)I, (float)grad_scale, (float)(lr / c1), (float)beta1, (float)beta2, (float)(1.0 / sqrt(c2)), (float)eps);
+    MP_CHECK_LAUNCH();
+    return MP_OK;
+}
+
+extern "C" size_t mp_linear_dx_skinny_workspace_bytes(int64_t B, int64_t O, int64_t I)
+{
+    return (size_t)((O + SK_ROWS - 1) / SK_ROWS) * (size_t)B * (size_t)I * sizeof(float);
+}
+
+extern "C" int mp_linear_dx_skinny_f32(const float* g, const float* weight, int64_t B, int64_t O, int64_t I, float* grad_x,
+                                       void* workspace, size_t workspace_bytes, mp_stream_t stream_)
+{
+    if (B < 0 || O < 0 || I < 0) return MP_EINVAL;
+    if (B == 0 || I == 0) return MP_OK;
+    if (!grad_x || (O > 0 && (!g || !weight || !workspace))) return MP_EINVAL;
+    if (B > SK_B || (I & 3)) return MP_EUNSUPPORTED;
+    if (workspace_bytes < mp_linear_dx_skinny_workspace_bytes(B, O, I)) return MP_EWORKSPACE;
+    hipStream_t stream = mp_stream(stream_);
+    if (O == 0) return hipMemsetAsync(grad_x, 0, sizeof(float) * (size_t)(B * I), stream) == hipSuccess ? MP_OK : MP_ELAUNCH;
+    const int nblk = (int)((O + SK_ROWS - 1) / SK_ROWS);
+    const dim3 grid((unsigned)((I / 4 + 255) / 256), (unsigned)nblk);
+    MP_LAUNCH("linear_dx_skinny_kernel", 2.0 * (double)B * O * I, 4.0 * ((double)O * I + (double)B * (O + I)), linear_dx_skinny_kernel,
+              grid, dim3(256), 0, stream, g, weight, (int)B, (int)O, (int)I, reinterpret_cast<float*>(workspace));
+    MP_CHECK_LAUNCH();
+    const int n4 = (int)(B * I / 4);
+    MP_LAUNCH("sum_partials_kernel", 0.0, 4.0 * (double)nblk * B * I, sum_partials_kernel, dim3((n4 + 63) / 64), dim3(64), 0, stream,
+              reinterpret_cast<const float*>(workspace), nblk, n4, grad_x);
+    MP_CHECK_LAUNCH();
+    return MP_OK;
+}

@@ -6,6 +6,7 @@ batches come from maskplanner_amd.synthetic with the collated-tensor contract of
 import torch
 
 from . import dp, synthetic
+from .factor_heads import FactorAdam
 from . import pointnet2_utils as pu
 from .loss_handler import LossHandler, maskplanner_loss_config
 from .pointnet2_cls_ssg import maskplanner_model
@@ -13,16 +14,25 @@ from .pointnet2_cls_ssg import maskplanner_model
 
 class TrainStep:
     def __init__(self, category="cuboids", B=32, N=5120, device="cuda", seed=1235, hidden_size=(1024, 1024), lr=1e-3,
-                 dist_points="cuboid", rank=0, loss_overrides=None, prefetch_sampling=False):
+                 dist_points="cuboid", rank=0, loss_overrides=None, prefetch_sampling=False, factor_heads=True):
         self.cat = synthetic.CATEGORIES[category] if isinstance(category, str) else category
         self.device = torch.device(device)
         torch.manual_seed(seed)  # identical initial weights on every rank
         self.model = maskplanner_model(self.cat, hidden_size=hidden_size).to(self.device).train()
         self.cfg = maskplanner_loss_config(**(loss_overrides or {}))
         self.loss_handler = LossHandler(["asymm_v6_chamfer_with_stroke_masks"], self.cfg)
-        self.reducer = dp.BucketedGradAllReduce(self.model.parameters())
         fused = self.device.type == "cuda"
-        self.opt = torch.optim.Adam(self.model.parameters(), lr=lr, fused=fused)  # train_maskplanner.py:159
+        self.factor_opt = None
+        dense = list(self.model.parameters())
+        if factor_heads and fused:
+            # the three matrices that hold 97 % of the parameters: gradient kept as rank-B factors, Adam fused with its
+            # reconstruction (factor_heads.py); everything else goes through autograd + torch.optim.Adam as upstream
+            self.model.factor_store = {}
+            big = {n: p for n, p in self.model.named_parameters() if n in ("fc3.weight", "fc_normals.weight", "sm_fc3.weight")}
+            self.factor_opt = FactorAdam(big, self.model.factor_store, lr=lr)
+            dense = [p for p in dense if all(p is not q for q in big.values())]
+        self.reducer = dp.BucketedGradAllReduce(dense)
+        self.opt = torch.optim.Adam(dense, lr=lr, fused=fused)  # train_maskplanner.py:159
         b = synthetic.make_batch(seed + 1000 * rank, B, N, self.cat.name, dist_points)  # a different shard per rank
         self.batch = {k: (v.to(self.device) if torch.is_tensor(v) else [t.to(self.device) for t in v])
                       for k, v in b.items()}
@@ -53,4 +63,6 @@ class TrainStep:
         loss.backward()
         self.reducer.finish()
         self.opt.step()
+        if self.factor_opt is not None:
+            self.factor_opt.step()
         return loss

@@ -11,6 +11,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .factor_heads import factor_linear
 from .pointnet2_utils import PointNetSetAbstraction
 
 
@@ -116,12 +117,17 @@ class PointNet2Regressor_StrokeMasks(_SSGEncoder):
             if mask_confidence_scores:
                 self.mask_conf_out = nn.Linear(h1, n_stroke_masks)
 
+    # set to a dict by a training harness that uses factor_heads.FactorAdam: the three big head matrices then keep
+    # their gradient as rank-B factors instead of materialising dW (default None: plain nn.Linear behaviour)
+    factor_store = None
+
     def forward(self, xyz):
         B = xyz.shape[0]
+        fs = self.factor_store
         feat = self.encode(xyz)
         x = self.dropout(F.relu(self.bn1(self.fc1(feat))))
         final = self.dropout(F.relu(self.bn2(self.fc2(x))))
-        x = self.fc3(final)
+        x = factor_linear(final, self.fc3, fs, "fc3.weight")
 
         seg_conf = None
         if self.segment_confidence_scores:
@@ -133,12 +139,13 @@ class PointNet2Regressor_StrokeMasks(_SSGEncoder):
         if self.pred_stroke_masks:
             s1 = self.dropout(F.relu(self.sm_bn1(self.sm_fc1(feat))))
             s2 = self.dropout(F.relu(self.sm_bn2(self.sm_fc2(s1))))
-            sm_out = self.sm_fc3(s2).view(B, self.n_stroke_masks, -1)
+            sm_out = factor_linear(s2, self.sm_fc3, fs, "sm_fc3.weight").view(B, self.n_stroke_masks, -1)
             if self.mask_confidence_scores:
                 mask_conf = self.mask_conf_out(s2)
 
         if self.outdim_orient > 0:
-            out = _pose_output(x, self.fc_normals(final), B, self.out_vectors, self.weight_orient)
+            out = _pose_output(x, factor_linear(final, self.fc_normals, fs, "fc_normals.weight"), B, self.out_vectors,
+                               self.weight_orient)
         else:
             out = x.view(B, self.out_vectors, self.outdim)
         return out, sm_out, mask_conf, seg_conf

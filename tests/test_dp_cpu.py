@@ -92,3 +92,36 @@ def test_single_process_reducer_is_a_noop():
     red.zero_grad()
     assert all(p.grad is None for p in model.parameters())
     assert red.grad_bytes() == sum(p.numel() * 4 for p in model.parameters())
+
+
+def _gather_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from maskplanner_amd import dp
+    from maskplanner_amd.factor_heads import FactorAdam
+    dp.init_from_env(backend="gloo")
+    fa = FactorAdam({}, {}, lr=1e-3)
+    g = torch.Generator().manual_seed(100 + rank)
+    x = torch.randn(3, 8, generator=g)
+    ga = torch.randn(3, 5, generator=g)
+    gb = torch.randn(3, 7, generator=g)
+    got = fa._gather([x, ga, gb])
+    out[rank] = [t.clone() for t in got] + [x, ga, gb]
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_factor_gather_concatenates_rank_rows():
+    """Under DP the head gradient dW = sum_r g_r^T x_r is rebuilt from ALL ranks' factors: one all-gather of the
+    packed (x, g) rows; every rank must see rank 0's rows first, then rank 1's, split back into the original widths."""
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_gather_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    for k in range(3):
+        want = torch.cat([out[0][3 + k], out[1][3 + k]], dim=0)
+        for r in range(world):
+            assert torch.equal(out[r][k], want)
+    # the product of the gathered factors is the sum of the per-rank gradients
+    x, g = out[0][0], out[0][1]
+    want = out[0][4].t() @ out[0][3] + out[1][4].t() @ out[1][3]
+    torch.testing.assert_close(g.t() @ x, want)
