@@ -82,6 +82,9 @@ def cpu_baseline(cat, N, seed):
 
 
 def main():
+    if os.environ.get("MASKPLANNER_FAULT_DUMP"):   # debugging aid: dump all stacks and exit if the run hangs
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["MASKPLANNER_FAULT_DUMP"]), exit=True)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -98,6 +101,7 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the MaskPlanner hot path has no CPU fallback")
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    local = local % torch.cuda.device_count()   # (several ranks per GPU only happen in the gloo dry run)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 

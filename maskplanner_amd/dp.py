@@ -119,8 +119,10 @@ def init_from_env(backend=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"  # "nccl" is RCCL on ROCm
-        if backend == "nccl":
-            torch.cuda.set_device(local)
+            # "nccl" is RCCL on ROCm.  MASKPLANNER_DIST_BACKEND=gloo lets several ranks share one GPU for a functional
+            # dry run of the multi-rank control flow where RCCL (one GPU per rank) cannot run.
+            backend = os.environ.get("MASKPLANNER_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local % torch.cuda.device_count())
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local, world
