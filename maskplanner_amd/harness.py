@@ -48,10 +48,6 @@ class TrainStep:
         starts = self.batch["fps_start"][1:] if ready else self.batch["fps_start"]
         with pu.fps_start_override(starts):
             out, sm_out, mask_conf, seg_conf = self.model(self.point_cloud)
-        if self.prefetch:
-            # the next batch (here: the same synthetic one) is already resident: run ITS first-level FPS + ball query
-            # on the side stream while this step's loss / backward / optimizer occupy the main stream
-            pu.prefetch_sampling(self.batch["point_cloud"], sa1.npoint, sa1.radius, sa1.nsample, self.batch["fps_start"][0])
         return self.loss_handler.compute(return_list=False, y_pred=out, y=self.batch["traj"], pred_stroke_masks=sm_out,
                                          mask_scores=mask_conf, seg_logits=seg_conf, stroke_ids=self.batch["stroke_ids"],
                                          traj_as_pc=self.batch["traj_as_pc"])
@@ -62,6 +58,11 @@ class TrainStep:
         loss = self.forward_loss()
         loss.backward()
         self.reducer.finish()
+        if self.prefetch:
+            # the next batch (here: the same synthetic one) is already resident: run ITS first-level FPS + ball query on
+            # the side stream while the optimizer's bandwidth-bound streaming kernels occupy the main stream
+            sa1 = self.model.sa1
+            pu.prefetch_sampling(self.batch["point_cloud"], sa1.npoint, sa1.radius, sa1.nsample, self.batch["fps_start"][0])
         self.opt.step()
         if self.factor_opt is not None:
             self.factor_opt.step()
