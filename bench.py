@@ -163,6 +163,15 @@ def main():
             "roofline": {"kernel": dom, "bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak,
                          "traffic": measured_traffic(dom), "avg_us": avg_s * 1e6, "launches_per_step": d["calls"] / profiled_steps,
                          "flops_per_launch": flops, "bytes_per_launch": nbytes},
+            # the kernels BASELINE.json names, each against BOTH roofs (algorithmic flops vs the fp32 peak, algorithmic
+            # bytes vs HBM): FPS is latency-bound, ball query / kNN are fp32-VALU bound, grouping is the HBM-bound one
+            "named_kernels": {k: {"us_per_launch": round(v["ms"] * 1e3 / v["calls"], 1),
+                                  "tflops": round(v["flops"] / v["calls"] / (v["ms"] / v["calls"] * 1e-3) / 1e12, 2),
+                                  "frac_fp32_peak": round(v["flops"] / v["calls"] / (v["ms"] / v["calls"] * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4),
+                                  "alg_GBps": round(v["bytes"] / v["calls"] / (v["ms"] / v["calls"] * 1e-3) / 1e9, 1),
+                                  "frac_hbm": round(v["bytes"] / v["calls"] / (v["ms"] / v["calls"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+                              for k, v in kernels.items() if k.split("<")[0] in
+                              ("fps_kernel", "ball_query_kernel", "knn1_kernel", "knn_kernel", "group_kernel", "group_bwd_atomic_kernel")},
             "kernels_us_per_step": {k: round(v["ms"] * 1e3 / profiled_steps, 1) for k, v in
                                     sorted(kernels.items(), key=lambda kv: -kv[1]["ms"])},
             "final_loss": final_loss,

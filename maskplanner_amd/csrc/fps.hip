@@ -34,8 +34,8 @@ __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, i
     float* sx = reinterpret_cast<float*>(smem_raw);
     float* sy = sx + NPAD;
     float* sz = sy + NPAD;
-    uint2* slots = reinterpret_cast<uint2*>(sz + NPAD);  // [2][NW]
-    int* sel = reinterpret_cast<int*>(slots + 2 * NW);   // [S]
+    unsigned long long* slots = reinterpret_cast<unsigned long long*>(sz + NPAD);  // [4] rotating block arg-max keys
+    int* sel = reinterpret_cast<int*>(slots + 4);                                   // [S]
 
     const int b = blockIdx.x;
     const int tid = threadIdx.x;
@@ -51,6 +51,7 @@ __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, i
         (c == 0 ? sx : (c == 1 ? sy : sz))[pt] = v;
     }
     for (int i = N + tid; i < NPAD; i += T) { sx[i] = 0.f; sy[i] = 0.f; sz[i] = 0.f; }
+    if (tid < 4) slots[tid] = 0ull;
     __syncthreads();
 
     float px[PPT], py[PPT], pz[PPT], dist[PPT];
@@ -78,8 +79,7 @@ __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, i
             const float dy = py[j] - cy;
             const float dz = pz[j] - cz;
             const float d = (dx * dx + dy * dy) + dz * dz;
-            float cur = dist[j];
-            if (d < cur) cur = d;
+            const float cur = __builtin_fminf(dist[j], d);   // == `if (d < dist) dist = d` for non-NaN distances
             dist[j] = cur;
             if (cur > best) { best = cur; bj = j; }
         }
@@ -91,16 +91,16 @@ __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, i
         if constexpr (NW == 1) {
             far = widx;
         } else {
-            uint2* slot = slots + (s & 1) * NW;
-            if (lane == 0) slot[wave] = make_uint2(wmax, (unsigned)widx);
+            // key = (distance bits, ~index): a 64-bit max is "largest distance, lowest index".  One LDS atomic per wave,
+            // one barrier, one broadcast read.  Three slots rotate so that the slot being cleared was last read two
+            // barriers ago.
+            unsigned long long* slot = slots + (s % 3);
+            if (lane == 0) {
+                atomicMax(slot, ((unsigned long long)wmax << 32) | (unsigned long long)(~(unsigned)widx));
+                if (wave == 0) slots[(s + 1) % 3] = 0ull;
+            }
             __syncthreads();
-            uint2 e = make_uint2(0u, 0u);
-            if (lane < NW) e = slot[lane];
-            unsigned r = mp::row16_max_u32(e.x);  // NW <= 16: all slots sit in row 0
-            const unsigned bmax = (unsigned)__builtin_amdgcn_readlane((int)r, 0);
-            const unsigned long long m2 = __ballot(lane < NW && e.x == bmax);
-            const int w = (int)__builtin_ctzll(m2);  // lowest wave == lowest index range
-            far = __builtin_amdgcn_readlane((int)e.y, w);
+            far = (int)(~(unsigned)(*slot));
         }
     }
     __syncthreads();
@@ -120,8 +120,8 @@ template <int T, int PPT>
 int launch_fps(const float* xyz, int B, int N, int S, const int64_t* start, int64_t* out_idx, float* out_xyz,
                hipStream_t stream)
 {
-    constexpr int NW = T / MP_WAVE;
-    const size_t smem = (size_t)3 * T * PPT * sizeof(float) + 2 * NW * sizeof(uint2) + (size_t)S * sizeof(int);
+
+    const size_t smem = (size_t)3 * T * PPT * sizeof(float) + 4 * sizeof(unsigned long long) + (size_t)S * sizeof(int);
     if (smem > 160 * 1024) return MP_EUNSUPPORTED;
     auto kern = fps_kernel<T, PPT>;
     if (smem > 64 * 1024) {
@@ -164,10 +164,12 @@ extern "C" int mp_fps_f32(const float* xyz, int64_t B, int64_t N, int64_t S, con
     MP_FPS_CASE(256, 4);
     MP_FPS_CASE(256, 6);
     MP_FPS_CASE(256, 8);
-    MP_FPS_CASE(1024, 3);
-    MP_FPS_CASE(1024, 4);
-    MP_FPS_CASE(1024, 5);
-    MP_FPS_CASE(1024, 6);
+    // [r1] N = 5120: 256 threads x 20 points 339 us, 512 x 10 350 us, 1024 x 5 366 us (one LDS atomic + barrier per step)
+    MP_FPS_CASE(256, 12);
+    MP_FPS_CASE(256, 16);
+    MP_FPS_CASE(256, 20);
+    MP_FPS_CASE(512, 12);
+    MP_FPS_CASE(512, 16);
     MP_FPS_CASE(1024, 8);
     MP_FPS_CASE(1024, 10);
     MP_FPS_CASE(1024, 13);
