@@ -170,6 +170,8 @@ extern "C" int mp_fps_f32(const float* xyz, int64_t B, int64_t N, int64_t S, con
     MP_FPS_CASE(256, 20);
     MP_FPS_CASE(512, 12);
     MP_FPS_CASE(512, 16);
+    MP_FPS_CASE(512, 20);
+    MP_FPS_CASE(512, 24);
     MP_FPS_CASE(1024, 8);
     MP_FPS_CASE(1024, 10);
     MP_FPS_CASE(1024, 13);
