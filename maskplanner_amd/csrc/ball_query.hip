@@ -126,10 +126,12 @@ extern "C" int mp_ball_query_f32(const float* xyz, const float* new_xyz, int64_t
     qpb = ((qpb + BQ_WAVES - 1) / BQ_WAVES) * BQ_WAVES;
     if (qpb < BQ_WAVES) qpb = BQ_WAVES;
     const int chunks = (int)((S + qpb - 1) / qpb);
-    if (smem > 64 * 1024) {
+    static size_t configured = 64 * 1024;   // see fps.hip
+    if (smem > configured) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(ball_query_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
             return MP_ELAUNCH;
+        configured = smem;
     }
     const float r2 = (float)(radius * radius);  // squared in double, then cast: pointnet2_utils.py:104
     MP_LAUNCH("ball_query_kernel", 8.0 * B * (double)S * N, (double)B * (N * 12.0 + S * 12.0 + S * K * 8.0), ball_query_kernel,

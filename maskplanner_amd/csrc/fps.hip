@@ -124,10 +124,13 @@ int launch_fps(const float* xyz, int B, int N, int S, const int64_t* start, int6
     const size_t smem = (size_t)3 * T * PPT * sizeof(float) + 4 * sizeof(unsigned long long) + (size_t)S * sizeof(int);
     if (smem > 160 * 1024) return MP_EUNSUPPORTED;
     auto kern = fps_kernel<T, PPT>;
-    if (smem > 64 * 1024) {
+    // opt-in to > 64 KB of dynamic LDS once per size (not a stream operation: it must not run inside a graph capture)
+    static size_t configured = 64 * 1024;
+    if (smem > configured) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)smem) != hipSuccess)
             return MP_ELAUNCH;
+        configured = smem;
     }
     char tag[48];
     snprintf(tag, sizeof tag, "fps_kernel<%d, %d>", T, PPT);

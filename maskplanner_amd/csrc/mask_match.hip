@@ -231,10 +231,12 @@ extern "C" int mp_mask_match_f32(const float* pred_masks, const float* target_id
     if (M > CAP || S > 16384) return MP_EUNSUPPORTED;
     const size_t smem = sizeof(double) * (CAP * CAP + CAP) + sizeof(float) * (CAP * CAP + CAP + MM_THREADS / 64) +
                         sizeof(int) * (CAP + (size_t)S);
-    if (smem > 64 * 1024) {
+    static size_t configured = 64 * 1024;   // see fps.hip
+    if (smem > configured) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(mask_match_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
             return MP_ELAUNCH;
+        configured = smem;
     }
     hipLaunchKernelGGL(mask_match_kernel, dim3((unsigned)B), dim3(MM_THREADS), smem, mp_stream(stream_), pred_masks,
                        target_ids, (int)M, (int)S, match_col, uniq_ids, n_targets, cost, status);
