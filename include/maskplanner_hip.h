@@ -74,6 +74,23 @@ int mp_index_points_f32(const float* points, const int64_t* idx, int64_t B, int6
 int mp_index_points_bwd_f32(const float* grad_out, const int64_t* idx, int64_t B, int64_t N, int64_t C,
                             int64_t M, float* grad_points, int deterministic, mp_stream_t stream);
 
+/* ---- feature propagation: 3 nearest neighbours + inverse-distance interpolation -------------------
+ * replaces: models/pointnet2_utils.py:310-317 (PointNetFeaturePropagation.forward: square_distance, sort, [:3],
+ *           1/(d+1e-8) weights, index_points + weighted sum)
+ *   three_nn: xyz1 [B,N,3], xyz2 [B,S,3] (S >= 3) -> dist [B,N,3] (ascending, may be NULL), idx [B,N,3] i64,
+ *             weight [B,N,3] (may be NULL).  Expanded-form distances, bit-exact; lowest index first on ties
+ *             (the reference's sort is not stable, so its order on exact ties is unspecified).
+ *   three_interpolate: points2 [B,S,D] -> out [B,N,D] = (p[i0]*w0 + p[i1]*w1) + p[i2]*w2.
+ *   three_interpolate_bwd: grad_points2 [B,S,D] = scatter of grad_out [B,N,D] * weight (overwritten);
+ *             deterministic != 0 sums in ascending (n,k) order instead of using atomics. */
+int mp_three_nn_f32(const float* xyz1, const float* xyz2, int64_t B, int64_t N, int64_t S, float* dist,
+                    int64_t* idx, float* weight, mp_stream_t stream);
+int mp_three_interpolate_f32(const float* points2, const int64_t* idx, const float* weight, int64_t B, int64_t N,
+                             int64_t S, int64_t D, float* out, mp_stream_t stream);
+int mp_three_interpolate_bwd_f32(const float* grad_out, const int64_t* idx, const float* weight, int64_t B,
+                                 int64_t N, int64_t S, int64_t D, float* grad_points2, int deterministic,
+                                 mp_stream_t stream);
+
 /* ---- grouping (gather + centre + concat) -----------------------------------------------------
  * replaces: models/pointnet2_utils.py:133-143 (sample_and_group tail) and :258-262 (MSG variant)
  *   out [B,S,K,3+D] = cat(xyz[idx] - new_xyz, feats[idx])   (xyz_last == 0, SSG order, :138)

@@ -179,6 +179,56 @@ def index_points(points, idx):
     return _IndexPoints.apply(_f32(points), _i64(idx))
 
 
+@torch.no_grad()
+def three_nn(xyz1, xyz2, return_dist=False):
+    """models/pointnet2_utils.py:310-316: for every xyz1 [B,N,3] point its 3 nearest xyz2 [B,S,3] points (S >= 3) and the
+    normalised inverse-distance weights.  -> (idx i64 [B,N,3], weight [B,N,3][, dist [B,N,3]]).  No autograd: point
+    coordinates carry no gradient on this path."""
+    _need_hip(xyz1, xyz2)
+    xyz1, xyz2 = _f32(xyz1), _f32(xyz2)
+    if xyz1.ndim != 3 or xyz2.ndim != 3 or xyz1.shape[2] != 3 or xyz2.shape[2] != 3 or xyz1.shape[0] != xyz2.shape[0]:
+        raise ValueError("xyz1 must be [B,N,3] and xyz2 [B,S,3]")
+    B, N, _ = xyz1.shape
+    S = xyz2.shape[1]
+    if S < 3:
+        raise ValueError("three_nn needs at least 3 source points")
+    idx = torch.empty((B, N, 3), dtype=torch.int64, device=xyz1.device)
+    w = torch.empty((B, N, 3), dtype=torch.float32, device=xyz1.device)
+    dist = torch.empty((B, N, 3), dtype=torch.float32, device=xyz1.device) if return_dist else None
+    _run("three_nn", xyz1, _lib.load().mp_three_nn_f32, _p(xyz1), _p(xyz2), B, N, S, _p(dist), _p(idx), _p(w))
+    return (idx, w, dist) if return_dist else (idx, w)
+
+
+class _ThreeInterpolate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, points2, idx, weight):
+        B, S, D = points2.shape
+        N = idx.shape[1]
+        out = torch.empty((B, N, D), dtype=torch.float32, device=points2.device)
+        _run("three_interpolate", points2, _lib.load().mp_three_interpolate_f32, _p(points2), _p(idx), _p(weight), B, N, S, D, _p(out))
+        ctx.save_for_backward(idx, weight)
+        ctx.dims = (B, N, S, D)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        idx, weight = ctx.saved_tensors
+        B, N, S, D = ctx.dims
+        grad_out = _f32(grad_out)
+        grad = torch.empty((B, S, D), dtype=torch.float32, device=grad_out.device)
+        _run("three_interpolate_bwd", grad_out, _lib.load().mp_three_interpolate_bwd_f32, _p(grad_out), _p(idx), _p(weight), B, N, S, D,
+             _p(grad), int(DETERMINISTIC))
+        return grad, None, None
+
+
+def three_interpolate(points2, idx, weight):
+    """models/pointnet2_utils.py:317: sum_k points2[b, idx[b,n,k], :] * weight[b,n,k]; grad w.r.t. points2."""
+    _need_hip(points2, idx, weight)
+    if points2.ndim != 3 or idx.ndim != 3 or idx.shape[2] != 3 or tuple(weight.shape) != tuple(idx.shape):
+        raise ValueError("points2 must be [B,S,D], idx and weight [B,N,3]")
+    return _ThreeInterpolate.apply(_f32(points2), _i64(idx), _f32(weight))
+
+
 class _Group(torch.autograd.Function):
     @staticmethod
     def forward(ctx, xyz, feats, new_xyz, idx, xyz_last, stride):

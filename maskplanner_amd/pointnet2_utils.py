@@ -226,3 +226,54 @@ class PointNetSetAbstractionMsg(nn.Module):
             grouped = ops.group(xyz, points, new_xyz, idx, xyz_last=True, pad_to=4)
             outs.append(sa_mlp.shared_mlp_max(grouped, convs, bns))
         return new_xyz.permute(0, 2, 1), torch.cat(outs, dim=-1).permute(0, 2, 1)
+
+
+class PointNetFeaturePropagation(nn.Module):
+    """Feature propagation (:279-329): 3-NN inverse-distance interpolation of the coarse features onto the dense points,
+    concatenation with the dense skip features, then Conv1d + BatchNorm1d + ReLU layers.  Same constructor, parameters
+    and state_dict keys as the reference (mlp_convs.{i}.{weight[Co,Ci,1],bias}, mlp_bns.{i}.*).  The interpolation is the
+    HIP part (ops.three_nn / ops.three_interpolate); the per-point MLP is a plain GEMM chain and stays on rocBLAS.
+    Gradients flow to points1 / points2 and the parameters, not to the coordinates."""
+
+    def __init__(self, in_channel, mlp):
+        super().__init__()
+        self.mlp_convs = nn.ModuleList()
+        self.mlp_bns = nn.ModuleList()
+        last = in_channel
+        for out_channel in mlp:
+            self.mlp_convs.append(nn.Conv1d(last, out_channel, 1))
+            self.mlp_bns.append(nn.BatchNorm1d(out_channel))
+            last = out_channel
+
+    def forward(self, xyz1, xyz2, points1, points2):
+        """xyz1 [B,3,N], xyz2 [B,3,S], points1 [B,D1,N] or None, points2 [B,D2,S] -> [B,D',N]."""
+        xyz1 = _points_major(xyz1)
+        xyz2 = _points_major(xyz2)
+        points2 = _points_major(points2)
+        B, N, _ = xyz1.shape
+        S = xyz2.shape[1]
+        if S == 1:
+            interpolated = points2.repeat(1, N, 1)                      # :307-308
+        else:
+            idx, weight = ops.three_nn(xyz1, xyz2)
+            interpolated = ops.three_interpolate(points2, idx, weight)
+        x = interpolated if points1 is None else torch.cat([_points_major(points1), interpolated], dim=-1)
+        x = x.reshape(B * N, -1)
+        for conv, bn in zip(self.mlp_convs, self.mlp_bns):             # Conv1d(k=1) over [B,C,N] == Linear over rows
+            x = torch.relu(bn(torch.nn.functional.linear(x, conv.weight.squeeze(-1), conv.bias)))
+        return x.view(B, N, -1).permute(0, 2, 1)
+
+
+def timeit(tag, t):
+    """models/pointnet2_utils.py:9-11."""
+    import time
+    print("{}: {}s".format(tag, time.time() - t))
+    return time.time()
+
+
+def pc_normalize(pc):
+    """models/pointnet2_utils.py:13-19 (numpy, host): centre and scale into the unit sphere."""
+    import numpy as np
+    pc = pc - np.mean(pc, axis=0)
+    return pc / np.max(np.sqrt(np.sum(pc ** 2, axis=1)))
+

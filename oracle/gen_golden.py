@@ -15,6 +15,7 @@ g6_cham  pytorch3d_chamfer.py:76-344 chamfer_distance (pytorch3d stand-in = orac
 g7_mask  loss_handler.py:596-666,816-935  asymm_v6 loss + stroke-mask loss
 g8_hung  models/hungarianMatcher.py:31-63 HungarianMatcher
 g9_seg   models/pointnet2_seg.py:14-96,258-339 PointNet2Segmenter_v1 / _PaintNet_v1 (eval forward)
+g10_fp   models/pointnet2_utils.py:279-329 PointNetFeaturePropagation      3-NN interpolation + MLP fwd/bwd (train+eval)
 """
 import os
 import sys
@@ -401,12 +402,77 @@ def g9_seg():
     save("g9_seg", **cases)
 
 
+def g10_fp(pu):
+    """models/pointnet2_utils.py:279-329: feature propagation (3-NN inverse-distance interpolation + Conv1d/BN1d MLP).
+    xyz2 is an FPS subset of xyz1 (as in a real decoder), so coincident points -- distances of 0 +- rounding noise in the
+    expanded form, i.e. huge and possibly negative reciprocals -- are part of the fixture."""
+    print("g10_fp")
+    rng = np.random.default_rng(1010)
+    cases = {}
+    specs = {"a": dict(B=2, N=1024, S=256, D1=6, D2=32, mlp=[32, 16]),     # points1 present
+             "b": dict(B=2, N=700, S=64, D1=0, D2=24, mlp=[16]),           # points1 = None (fp1 of the v3 decoder)
+             "c": dict(B=2, N=300, S=1, D1=4, D2=8, mlp=[8])}              # S == 1: the repeat branch (:307-308)
+    for tag, sp in specs.items():
+        B, N, S = sp["B"], sp["N"], sp["S"]
+        xyz1 = syn.point_cloud(rng, B, N, "cuboid")
+        if S > 1:
+            _, fidx = ref_fps(pu, xyz1, S, 1000 + S)
+            xyz2 = np.take_along_axis(xyz1, fidx[..., None], 1).copy()
+        else:
+            xyz2 = xyz1[:, :1].copy()
+        p1 = rng.normal(size=(B, sp["D1"], N)).astype(np.float32) if sp["D1"] else None
+        p2 = rng.normal(size=(B, sp["D2"], S)).astype(np.float32)
+        torch.manual_seed(77)
+        m = pu.PointNetFeaturePropagation(sp["D1"] + sp["D2"], sp["mlp"])
+        with torch.no_grad():   # non-trivial BN affine + running stats
+            for bn in m.mlp_bns:
+                bn.weight.uniform_(0.5, 1.5)
+                bn.bias.uniform_(-0.3, 0.3)
+                bn.running_mean.uniform_(-0.2, 0.2)
+                bn.running_var.uniform_(0.5, 1.5)
+        sd0 = {k: v.clone() for k, v in m.state_dict().items()}
+        cases.update({f"{tag}_sd_{k}": v.numpy() for k, v in sd0.items()})
+        t = lambda a: None if a is None else torch.from_numpy(a)
+        if S > 1:   # the interpolation alone (reference lines 310-317)
+            d = pu.square_distance(t(xyz1), t(xyz2))
+            ds, di = d.sort(dim=-1)
+            ds, di = ds[:, :, :3], di[:, :, :3]
+            rc = 1.0 / (ds + 1e-8)
+            w = rc / rc.sum(dim=2, keepdim=True)
+            interp = torch.sum(pu.index_points(t(p2).permute(0, 2, 1), di) * w.view(B, N, 3, 1), dim=2)
+            cases.update({f"{tag}_nn_dist": ds.numpy(), f"{tag}_nn_idx": di.numpy(), f"{tag}_nn_weight": w.numpy(),
+                          f"{tag}_interp": interp.numpy()})
+        m.eval()
+        with torch.no_grad():
+            oe = m(t(xyz1).permute(0, 2, 1), t(xyz2).permute(0, 2, 1), t(p1), t(p2))
+        m.train()
+        p1t = None if p1 is None else t(p1).requires_grad_(True)
+        p2t = t(p2).requires_grad_(True)
+        ot = m(t(xyz1).permute(0, 2, 1), t(xyz2).permute(0, 2, 1), p1t, p2t)
+        go = rng.normal(size=tuple(ot.shape)).astype(np.float32)
+        params = list(m.parameters())
+        grads = torch.autograd.grad(ot, ([p1t] if p1t is not None else []) + [p2t] + params, t(go))
+        k = 0
+        if p1t is not None:
+            cases[f"{tag}_g_points1"] = grads[0].numpy()
+            k = 1
+        cases[f"{tag}_g_points2"] = grads[k].numpy()
+        for (name, _), g in zip(m.named_parameters(), grads[k + 1:]):
+            cases[f"{tag}_g_{name}"] = g.numpy()
+        cases.update({f"{tag}_after_{k2}": v.numpy() for k2, v in m.state_dict().items() if "running" in k2})
+        cases.update({f"{tag}_xyz1": xyz1, f"{tag}_xyz2": xyz2, f"{tag}_points2": p2, f"{tag}_out_eval": oe.numpy(),
+                      f"{tag}_out_train": ot.detach().numpy(), f"{tag}_grad_out": go})
+        if p1 is not None:
+            cases[f"{tag}_points1"] = p1
+    save("g10_fp", **cases)
+
+
 def main():
     if not R.available():
         raise SystemExit("reference checkout not found; fixtures can only be generated in the build container")
     torch.set_num_threads(8)
     pu = R.pointnet2_utils()
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10"]
     if "g1" in which: g1_fps(pu)
     if "g2" in which: g2_bq(pu)
     if "g3" in which: g3_sa(pu)
@@ -416,6 +482,7 @@ def main():
     if "g7" in which: g7_mask()
     if "g8" in which: g8_hung()
     if "g9" in which: g9_seg()
+    if "g10" in which: g10_fp(pu)
 
 
 if __name__ == "__main__":

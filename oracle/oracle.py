@@ -107,6 +107,42 @@ def index_points_bwd(grad_out, idx, N):
     return out
 
 
+def three_nn(xyz1, xyz2):
+    """models/pointnet2_utils.py:310-316: 3 nearest xyz2 points of every xyz1 point (expanded-form distances,
+    lowest index first on ties) and the normalised inverse-distance weights.  -> (dist, idx, weight), each [B,N,3]."""
+    xyz1, xyz2 = _f32(xyz1), _f32(xyz2)
+    B, N, _ = xyz1.shape
+    S = xyz2.shape[1]
+    dist = np.empty((B, N, 3), dtype=np.float32)
+    idx = np.empty((B, N, 3), dtype=np.int64)
+    w = np.empty((B, N, 3), dtype=np.float32)
+    _check(lib().mpo_three_nn_f32(_p(xyz1, _f32p), _p(xyz2, _f32p), _i64(B), _i64(N), _i64(S), _p(dist, _f32p), _p(idx, _i64p),
+                                  _p(w, _f32p)), "three_nn")
+    return dist, idx, w
+
+
+def three_interpolate(points2, idx, weight):
+    """models/pointnet2_utils.py:317: sum_k points2[b, idx[b,n,k], :] * weight[b,n,k]."""
+    points2, weight = _f32(points2), _f32(weight)
+    idx = _i64a(idx)
+    B, S, D = points2.shape
+    N = idx.shape[1]
+    out = np.empty((B, N, D), dtype=np.float32)
+    _check(lib().mpo_three_interpolate_f32(_p(points2, _f32p), _p(idx, _i64p), _p(weight, _f32p), _i64(B), _i64(N), _i64(S), _i64(D),
+                                           _p(out, _f32p)), "three_interpolate")
+    return out
+
+
+def three_interpolate_bwd(grad_out, idx, weight, S):
+    grad_out, weight = _f32(grad_out), _f32(weight)
+    idx = _i64a(idx)
+    B, N, D = grad_out.shape
+    out = np.empty((B, S, D), dtype=np.float32)
+    _check(lib().mpo_three_interpolate_bwd_f32(_p(grad_out, _f32p), _p(idx, _i64p), _p(weight, _f32p), _i64(B), _i64(N), _i64(S),
+                                               _i64(D), _p(out, _f32p)), "three_interpolate_bwd")
+    return out
+
+
 def group(xyz, feats, new_xyz, idx):
     """models/pointnet2_utils.py:133-143: cat([xyz[idx]-new_xyz, feats[idx]], -1)."""
     xyz, new_xyz = _f32(xyz), _f32(new_xyz)

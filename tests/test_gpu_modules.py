@@ -95,6 +95,38 @@ def test_msg_matches_reference(golden, train):
         close(p.grad, g[f"{tag}_grad_{name}"], name, atol=2e-4, rtol=1e-4)
 
 
+@pytest.mark.parametrize("tag,ctor", [("a", dict(in_channel=38, mlp=[32, 16])), ("b", dict(in_channel=24, mlp=[16])),
+                                      ("c", dict(in_channel=12, mlp=[8]))])
+def test_feature_propagation_matches_reference(golden, tag, ctor):
+    """models/pointnet2_utils.py:279-329 -- with points1, without (fp1 of the v3 decoder) and the S == 1 repeat branch."""
+    from maskplanner_amd import pointnet2_utils as pu
+    g = golden("g10_fp")
+    m = load_sd(pu.PointNetFeaturePropagation(**ctor), g, f"{tag}_sd_")
+    xyz1 = dev(g[tag + "_xyz1"]).permute(0, 2, 1)
+    xyz2 = dev(g[tag + "_xyz2"]).permute(0, 2, 1)
+    has1 = (tag + "_points1") in g.files
+    m.eval()
+    with torch.no_grad():
+        oe = m(xyz1, xyz2, dev(g[tag + "_points1"]) if has1 else None, dev(g[tag + "_points2"]))
+    close(oe, g[tag + "_out_eval"], "eval")
+    m.train()
+    p1 = dev(g[tag + "_points1"]).requires_grad_(True) if has1 else None
+    p2 = dev(g[tag + "_points2"]).requires_grad_(True)
+    ot = m(xyz1, xyz2, p1, p2)
+    close(ot, g[tag + "_out_train"], "train")
+    (ot * dev(g[tag + "_grad_out"])).sum().backward()
+    if has1:
+        close(p1.grad, g[tag + "_g_points1"], "dpoints1", atol=2e-4, rtol=1e-4)
+    close(p2.grad, g[tag + "_g_points2"], "dpoints2", atol=2e-4, rtol=1e-4)
+    for name, p in m.named_parameters():
+        if name.endswith("bias") and "conv" in name:
+            continue  # cancels inside train-mode BN
+        close(p.grad, g[f"{tag}_g_{name}"], name, atol=2e-4, rtol=1e-4)
+    for k, v in m.state_dict().items():
+        if "running" in k:
+            close(v, g[f"{tag}_after_{k}"], k)
+
+
 def test_full_model_eval_matches_reference(golden):
     from maskplanner_amd import pointnet2_cls_ssg as pc
     from maskplanner_amd import pointnet2_utils as pu

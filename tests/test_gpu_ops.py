@@ -263,3 +263,70 @@ def test_mask_match_ties_follow_scipy(ops):
         want = np.full(9, -1)
         want[r] = cc
         assert np.array_equal(match[b].cpu().numpy(), want)
+
+
+# ------------------------------------------------------------------------------------------------ 3-NN interpolation
+def test_three_nn_golden_bit_exact(golden, ops):
+    g = golden("g10_fp")
+    for t in "ab":
+        idx, w, d = ops.three_nn(dev(g[t + "_xyz1"]), dev(g[t + "_xyz2"]), return_dist=True)
+        assert np.array_equal(idx.cpu().numpy(), g[t + "_nn_idx"]), t
+        assert np.array_equal(d.cpu().numpy().view(np.int32), g[t + "_nn_dist"].view(np.int32)), t
+        assert np.array_equal(w.cpu().numpy().view(np.int32), g[t + "_nn_weight"].view(np.int32)), t
+        p2 = dev(g[t + "_points2"].transpose(0, 2, 1))
+        out = ops.three_interpolate(p2, idx, w)
+        assert np.array_equal(out.cpu().numpy().view(np.int32), g[t + "_interp"].view(np.int32)), t
+
+
+@pytest.mark.parametrize("B,N,S,D", [(32, 5120, 1024, 64), (4, 1024, 256, 128), (3, 777, 3, 5), (2, 3000, 2500, 1030), (2, 1, 5, 4)])
+def test_three_nn_vs_oracle(oracle, ops, B, N, S, D):
+    from maskplanner_amd import synthetic as syn
+    rng = np.random.default_rng(N + S)
+    xyz1 = syn.point_cloud(rng, B, N, "cuboid")
+    # sources = a subset of the queries (coincident points) when possible, else independent points
+    xyz2 = xyz1[:, rng.permutation(N)[:S]].copy() if S <= N else rng.uniform(-1, 1, (B, S, 3)).astype(np.float32)
+    d0, i0, w0 = oracle.three_nn(xyz1, xyz2)
+    idx, w, d = ops.three_nn(dev(xyz1), dev(xyz2), return_dist=True)
+    assert np.array_equal(d.cpu().numpy().view(np.int32), d0.view(np.int32))   # distances first: indices may tie
+    ties = (d0[..., 0] == d0[..., 1]) | (d0[..., 1] == d0[..., 2])
+    assert np.array_equal(idx.cpu().numpy()[~ties], i0[~ties])
+    assert np.array_equal(idx.cpu().numpy(), i0)                               # same first-index rule on ties
+    assert np.array_equal(w.cpu().numpy().view(np.int32), w0.view(np.int32))
+    p2 = rng.normal(size=(B, S, D)).astype(np.float32)
+    out = ops.three_interpolate(dev(p2), idx, w)
+    assert np.array_equal(out.cpu().numpy().view(np.int32), oracle.three_interpolate(p2, i0, w0).view(np.int32))
+
+
+@pytest.mark.parametrize("det", [False, True])
+def test_three_interpolate_backward(oracle, ops, det):
+    import maskplanner_amd.ops as O
+    rng = np.random.default_rng(11)
+    B, N, S, D = 3, 900, 70, 37
+    xyz1 = rng.uniform(-1, 1, (B, N, 3)).astype(np.float32)
+    xyz2 = rng.uniform(-1, 1, (B, S, 3)).astype(np.float32)
+    _, i0, w0 = oracle.three_nn(xyz1, xyz2)
+    p2 = dev(rng.normal(size=(B, S, D)).astype(np.float32)).requires_grad_(True)
+    go = rng.normal(size=(B, N, D)).astype(np.float32)
+    old = O.DETERMINISTIC
+    O.DETERMINISTIC = det
+    try:
+        out = ops.three_interpolate(p2, dev(i0), dev(w0))
+        (g,) = torch.autograd.grad(out, [p2], dev(go))
+        g = g.cpu().numpy()
+        want = oracle.three_interpolate_bwd(go, i0, w0, S)
+        if det:
+            assert np.array_equal(g.view(np.int32), want.view(np.int32))       # same summation order as the oracle
+            (g2,) = torch.autograd.grad(ops.three_interpolate(p2, dev(i0), dev(w0)), [p2], dev(go))
+            assert np.array_equal(g2.cpu().numpy(), g)
+        else:
+            np.testing.assert_allclose(g, want, rtol=1e-4, atol=1e-4)
+    finally:
+        O.DETERMINISTIC = old
+
+
+def test_three_nn_rejects_bad_input(ops):
+    with pytest.raises(ValueError):
+        ops.three_nn(torch.zeros(1, 4, 3, device="cuda"), torch.zeros(1, 2, 3, device="cuda"))
+    with pytest.raises((ValueError, RuntimeError)):
+        ops.three_nn(torch.zeros(1, 4, 3), torch.zeros(1, 5, 3))   # CPU tensors are refused
+

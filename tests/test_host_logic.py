@@ -83,9 +83,12 @@ def test_dropin_aliases_reference_module_names():
         from pytorch3d.ops.knn import knn_gather, knn_points  # the import line of pytorch3d_chamfer.py:12
         from pytorch3d.structures.pointclouds import Pointclouds  # noqa: F401  (:13)
         assert callable(knn_points) and callable(knn_gather)
-        for name in ("square_distance", "index_points", "farthest_point_sample", "query_ball_point", "sample_and_group",
-                     "sample_and_group_all", "PointNetSetAbstraction", "PointNetSetAbstractionMsg"):
-            assert hasattr(pu, name)
+        # every module-level def / class of models/pointnet2_utils.py (:9-279); models/pointnet2_seg.py:12 imports
+        # PointNetFeaturePropagation by name, so a missing one breaks `import models` under the alias
+        for name in ("timeit", "pc_normalize", "square_distance", "index_points", "farthest_point_sample", "query_ball_point",
+                     "sample_and_group", "sample_and_group_all", "PointNetSetAbstraction", "PointNetSetAbstractionMsg",
+                     "PointNetFeaturePropagation"):
+            assert hasattr(pu, name), name
     finally:
         for k, v in saved.items():
             if v is None:
@@ -116,3 +119,5 @@ def test_set_abstraction_modules_have_reference_parameters():
     msg = pu.PointNetSetAbstractionMsg(512, [0.1, 0.2, 0.4], [16, 32, 128], 0, [[32, 32, 64], [64, 64, 128], [64, 96, 128]])
     assert "conv_blocks.2.1.weight" in msg.state_dict() and "bn_blocks.0.0.running_var" in msg.state_dict()
     assert tuple(msg.conv_blocks[0][0].weight.shape) == (32, 3, 1, 1)
+    fp = pu.PointNetFeaturePropagation(384, [256, 256])
+    assert tuple(fp.mlp_convs[0].weight.shape) == (256, 384, 1) and "mlp_bns.1.num_batches_tracked" in fp.state_dict()

@@ -204,3 +204,33 @@ def test_lsap_matches_scipy(oracle):
             assert np.array_equal(a, r) and np.array_equal(b, cc), (shape, kind)
     a, b = oracle.linear_sum_assignment(np.ones((7, 7)))
     assert np.array_equal(b, np.arange(7))
+
+
+def test_three_nn_interpolation_bit_exact(golden, oracle):
+    """PointNetFeaturePropagation's interpolation (models/pointnet2_utils.py:310-317): indices, distances, weights and the
+    interpolated features reproduce the reference bit for bit -- including the coincident points of an FPS subset, whose
+    expanded-form distance is 0 +- rounding noise (negative for some), i.e. huge / negative reciprocals."""
+    g = golden("g10_fp")
+    for t in "ab":
+        d, i, w = oracle.three_nn(g[t + "_xyz1"], g[t + "_xyz2"])
+        assert np.array_equal(i, g[t + "_nn_idx"]), t
+        assert np.array_equal(d.view(np.int32), g[t + "_nn_dist"].view(np.int32)), t
+        assert np.array_equal(w.view(np.int32), g[t + "_nn_weight"].view(np.int32)), t
+        p2 = np.ascontiguousarray(g[t + "_points2"].transpose(0, 2, 1))
+        out = oracle.three_interpolate(p2, i, w)
+        assert np.array_equal(out.view(np.int32), g[t + "_interp"].view(np.int32)), t
+    assert (g["a_nn_dist"] < 0).any()   # the fixture does contain the negative-distance case
+
+
+def test_three_interpolate_backward_is_the_adjoint(oracle):
+    rng = np.random.default_rng(5)
+    B, N, S, D = 2, 200, 40, 7
+    xyz1 = rng.uniform(-1, 1, (B, N, 3)).astype(np.float32)
+    xyz2 = rng.uniform(-1, 1, (B, S, 3)).astype(np.float32)
+    _, idx, w = oracle.three_nn(xyz1, xyz2)
+    p2 = rng.normal(size=(B, S, D)).astype(np.float32)
+    go = rng.normal(size=(B, N, D)).astype(np.float32)
+    lhs = (oracle.three_interpolate(p2, idx, w).astype(np.float64) * go).sum()
+    rhs = (oracle.three_interpolate_bwd(go, idx, w, S).astype(np.float64) * p2).sum()
+    assert abs(lhs - rhs) <= 1e-4 * max(1.0, abs(lhs))
+
