@@ -136,12 +136,14 @@ int mp_padded_lengths_f32(const float* y, int64_t B, int64_t P2, int64_t D, int6
  *   pred_masks [B,M,S] f32 logits; target_ids [B,S] f32 = stroke_ids.gather(1, idx_x) (:838).
  *   Per sample: unique ids ascending, -1 skipped (:938-967) -> Kb masks; cost[m,k] = sum_s
  *   BCEWithLogits(pred[m,s], mask[k,s]); LAP solved with scipy's algorithm and tie-breaking.
+ *   target_value [B,S] f32 or NULL: when given (`smooth_target_stroke_masks`, :830,:841-844,:959-964) the masks hold
+ *   target_value[b,s] instead of 1 and the cost is the MSE sum_s (pred[m,s] - mask[k,s])^2 (:810-811).
  *   Outputs: match_col [B,M] i64 = matched mask index k or -1; uniq_ids [B,M_cap] f32 (ascending,
  *   first n_targets[b] valid); n_targets [B] i64; cost [B,M,M_cap] f32 or NULL.  M_cap = 64.
  *   M <= 64 and Kb <= 64, else status[b] (i32, [B]) is set to MP_EUNSUPPORTED (0 otherwise). */
 #define MP_MASK_CAP 64
-int mp_mask_match_f32(const float* pred_masks, const float* target_ids, int64_t B, int64_t M, int64_t S,
-                      int64_t* match_col, float* uniq_ids, int64_t* n_targets, float* cost,
+int mp_mask_match_f32(const float* pred_masks, const float* target_ids, const float* target_value, int64_t B,
+                      int64_t M, int64_t S, int64_t* match_col, float* uniq_ids, int64_t* n_targets, float* cost,
                       int32_t* status, mp_stream_t stream);
 
 /* ---- set-abstraction shared MLP: (1x1 conv -> BatchNorm -> ReLU) x L -> max over the K group members ----------

@@ -115,7 +115,8 @@ __device__ void lsap_wave(const float* cost, int M, int Kb, int* match)
 }
 
 __global__ __launch_bounds__(MM_THREADS) void mask_match_kernel(const float* __restrict__ pred_masks,
-                                                                const float* __restrict__ target_ids, int M, int S,
+                                                                const float* __restrict__ target_ids,
+                                                                const float* __restrict__ target_value, int M, int S,
                                                                 int64_t* __restrict__ match_col,
                                                                 float* __restrict__ uniq_ids,
                                                                 int64_t* __restrict__ n_targets,
@@ -139,6 +140,7 @@ __global__ __launch_bounds__(MM_THREADS) void mask_match_kernel(const float* __r
     const int wave = tid >> 6;
     const float* ids = target_ids + (size_t)b * S;
     const float* pm = pred_masks + (size_t)b * M * S;
+    const float* tv = target_value ? target_value + (size_t)b * S : nullptr;   // smooth targets: MSE cost (:830)
 
     for (int e = tid; e < CAP * CAP + CAP; e += MM_THREADS) accB[e] = 0.0;  // accB and accA are contiguous
     if (tid == 0) { s_last = -__builtin_inff(); s_n = 0; s_bad = (M > CAP) ? 1 : 0; }
@@ -183,15 +185,22 @@ __global__ __launch_bounds__(MM_THREADS) void mask_match_kernel(const float* __r
         rank[s] = r;
     }
     __syncthreads();
-    // 3. cost sums
+    // 3. cost sums.  Binary targets: sum_s BCE(x, t) = sum_s f0(x) - sum_{s in mask k} x.  Smooth targets (target value
+    // c_s inside the mask, 0 outside): sum_s (x - t)^2 = sum_s x^2 - sum_{s in mask k} (2*x*c_s - c_s^2).
     for (int m = 0; m < M; ++m) {
         double a = 0.0;
         for (int s = tid; s < S; s += MM_THREADS) {
             const float x = pm[(size_t)m * S + s];
-            const float f0 = fmaxf(x, 0.0f) + log1pf(expf(-fabsf(x)));
-            a += (double)f0;
             const int r = rank[s];
-            if (r >= 0) atomicAdd(&accB[m * CAP + r], (double)x);
+            if (tv) {
+                a += (double)x * (double)x;
+                const double c = (double)tv[s];
+                if (r >= 0) atomicAdd(&accB[m * CAP + r], 2.0 * (double)x * c - c * c);
+            } else {
+                const float f0 = fmaxf(x, 0.0f) + log1pf(expf(-fabsf(x)));
+                a += (double)f0;
+                if (r >= 0) atomicAdd(&accB[m * CAP + r], (double)x);
+            }
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
@@ -220,7 +229,8 @@ __global__ __launch_bounds__(MM_THREADS) void mask_match_kernel(const float* __r
 
 }  // namespace
 
-extern "C" int mp_mask_match_f32(const float* pred_masks, const float* target_ids, int64_t B, int64_t M, int64_t S,
+extern "C" int mp_mask_match_f32(const float* pred_masks, const float* target_ids, const float* target_value, int64_t B,
+                                 int64_t M, int64_t S,
                                  int64_t* match_col, float* uniq_ids, int64_t* n_targets, float* cost,
                                  int32_t* status, mp_stream_t stream_)
 {
@@ -239,7 +249,7 @@ extern "C" int mp_mask_match_f32(const float* pred_masks, const float* target_id
         configured = smem;
     }
     hipLaunchKernelGGL(mask_match_kernel, dim3((unsigned)B), dim3(MM_THREADS), smem, mp_stream(stream_), pred_masks,
-                       target_ids, (int)M, (int)S, match_col, uniq_ids, n_targets, cost, status);
+                       target_ids, target_value, (int)M, (int)S, match_col, uniq_ids, n_targets, cost, status);
     MP_CHECK_LAUNCH();
     return MP_OK;
 }

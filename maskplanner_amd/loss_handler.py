@@ -67,20 +67,34 @@ def remove_padding_from_tensors(tensors):
     return tensors[~torch.all(tensors == -100, dim=-1)]
 
 
+def segment_distance_to_confidence(distance):
+    """loss_handler.py:554-563: distance to the nearest GT segment -> a confidence in [0, 1]."""
+    c, d = 2.17, -4.63
+    return -1 * (1 / (1 + torch.exp(-c * torch.log10(distance) + d))) + 1
+
+
 def stroke_masks_loss(pred_to_gt_match, pred_stroke_masks, scores, stroke_ids, w_masks, w_conf, no_stroke_weight,
-                      return_matching=False):
-    """get_stroke_masks_loss (loss_handler.py:816-935), binary targets.
+                      return_matching=False, nn_distance=None, smooth_targets=False):
+    """get_stroke_masks_loss (loss_handler.py:816-935).
 
     pred_to_gt_match i64 [B,S] (nearest GT segment of every predicted segment), pred_stroke_masks [B,M,S] logits,
-    scores [B,M] logits, stroke_ids [B,Sgt] f32 (-1 = padding).
+    scores [B,M] logits, stroke_ids [B,Sgt] f32 (-1 = padding).  smooth_targets (:841-844, :959-964): the 1s of the
+    target masks become f(nn_distance [B,S]) and both the matching cost and the loss are MSE instead of BCE (:830).
     """
     dev = pred_stroke_masks.device
     target_ids = stroke_ids.to(dev, dtype=torch.float32).gather(1, pred_to_gt_match)          # :838
-    match, uniq, _, _ = ops.mask_match(pred_stroke_masks.detach(), target_ids)                # :847-875, on device
+    conf = segment_distance_to_confidence(nn_distance) if smooth_targets else None            # [B,S], carries grad
+    match, uniq, _, _ = ops.mask_match(pred_stroke_masks.detach(), target_ids,                # :847-875, on device
+                                       target_value=None if conf is None else conf.detach())
     matched = match >= 0                                                                      # [B,M]
     uid = uniq.gather(1, match.clamp(min=0))                                                  # id matched to each pred mask
-    target_masks = (target_ids[:, None, :] == uid[:, :, None]).to(pred_stroke_masks.dtype)    # [B,M,S]
-    per_mask = F.binary_cross_entropy_with_logits(pred_stroke_masks, target_masks, reduction="none").sum(-1)
+    in_mask = target_ids[:, None, :] == uid[:, :, None]                                       # [B,M,S]
+    if smooth_targets:
+        target_masks = torch.where(in_mask, conf[:, None, :], torch.zeros((), device=dev, dtype=conf.dtype))
+        per_mask = (pred_stroke_masks - target_masks).square().sum(-1)                        # :810-811
+    else:
+        per_mask = F.binary_cross_entropy_with_logits(pred_stroke_masks, in_mask.to(pred_stroke_masks.dtype),
+                                                      reduction="none").sum(-1)
     n_matched = matched.sum()
     mask_loss = (per_mask * matched).sum() / n_matched                                        # .sum(-1).mean() over matched pairs (:906)
     target_scores = matched.to(scores.dtype)                                                  # :917-918
@@ -186,17 +200,14 @@ class LossHandler:
     # stroke masks
     def get_stroke_masks_loss(self, pred_to_gt_match, pred_stroke_masks, scores, stroke_ids, nn_distance=None,
                               smooth_targets=False, **kwargs):
-        if smooth_targets:
-            raise NotImplementedError("smooth_target_stroke_masks (off in every shipped config, default.yaml:117)")
         cfg = self._cfg()
         return stroke_masks_loss(pred_to_gt_match, pred_stroke_masks, scores, stroke_ids,
                                  cfg["explicit_weight_stroke_masks"], cfg["explicit_weight_stroke_masks_confidence"],
-                                 cfg["explicit_no_stroke_weight"])
+                                 cfg["explicit_no_stroke_weight"], nn_distance=nn_distance, smooth_targets=bool(smooth_targets))
 
     @staticmethod
     def _transform_segment_distance_to_confidence(distance):
-        c, d = 2.17, -4.63  # loss_handler.py:554-563
-        return -1 * (1 / (1 + torch.exp(-c * torch.log10(distance) + d))) + 1
+        return segment_distance_to_confidence(distance)
 
     def _get_per_segment_confidence_loss(self, nn_distance, logits):
         targets = self._transform_segment_distance_to_confidence(nn_distance)

@@ -129,20 +129,25 @@ def padded_lengths(y):
 
 
 @torch.no_grad()
-def mask_match(pred_masks, target_ids, return_cost=False):
+def mask_match(pred_masks, target_ids, return_cost=False, target_value=None):
     """loss_handler.py:838-875 on device.  pred_masks [B,M,S] logits, target_ids [B,S] f32.
     Returns match_col i64 [B,M] (-1 = unmatched), uniq_ids f32 [B,64], n_targets i64 [B], status i32 [B]
-    (and the fp32 cost [B,M,64] when asked)."""
+    (and the fp32 cost [B,M,64] when asked).  target_value [B,S]: smooth targets, MSE cost (:830, :959-964)."""
     _need_hip(pred_masks, target_ids)
     pred_masks, target_ids = _f32(pred_masks), _f32(target_ids)
     B, M, S = pred_masks.shape
+    if target_value is not None:
+        _need_hip(target_value)
+        target_value = _f32(target_value)
+        if tuple(target_value.shape) != (B, S):
+            raise ValueError("target_value must be [B,S]")
     dev = pred_masks.device
     match = torch.empty((B, M), dtype=torch.int64, device=dev)
     uniq = torch.empty((B, _lib.MASK_CAP), dtype=torch.float32, device=dev)
     nt = torch.empty((B,), dtype=torch.int64, device=dev)
     status = torch.empty((B,), dtype=torch.int32, device=dev)
     cost = torch.empty((B, M, _lib.MASK_CAP), dtype=torch.float32, device=dev) if return_cost else None
-    _run("mask_match", pred_masks, _lib.load().mp_mask_match_f32, _p(pred_masks), _p(target_ids), B, M, S, _p(match),
+    _run("mask_match", pred_masks, _lib.load().mp_mask_match_f32, _p(pred_masks), _p(target_ids), _p(target_value), B, M, S, _p(match),
          _p(uniq), _p(nt), _p(cost), _p(status))
     return (match, uniq, nt, status, cost) if return_cost else (match, uniq, nt, status)
 

@@ -16,6 +16,7 @@ g7_mask  loss_handler.py:596-666,816-935  asymm_v6 loss + stroke-mask loss
 g8_hung  models/hungarianMatcher.py:31-63 HungarianMatcher
 g9_seg   models/pointnet2_seg.py:14-96,258-339 PointNet2Segmenter_v1 / _PaintNet_v1 (eval forward)
 g10_fp   models/pointnet2_utils.py:279-329 PointNetFeaturePropagation      3-NN interpolation + MLP fwd/bwd (train+eval)
+g11_smooth loss_handler.py:830,841-844,959-964 smooth_target_stroke_masks  MSE mask matching + loss on g7's inputs
 """
 import os
 import sys
@@ -467,12 +468,49 @@ def g10_fp(pu):
     save("g10_fp", **cases)
 
 
+def g11_smooth():
+    """The `smooth_target_stroke_masks` variant of the stroke-mask loss (loss_handler.py:830, 841-844, 889-893, 959-964;
+    off in the shipped configs, default.yaml:117) on the inputs of g7_mask: target masks hold f(nn_distance) instead of 1,
+    matching cost and loss are MSE, and the gradient reaches nn_distance."""
+    print("g11_smooth")
+    lh = R.loss_handler_module()
+    ch = R.chamfer_module()
+    g7 = np.load(os.path.join(OUT, "g7_mask.npz"))
+    cases = {}
+    for tag in ("cub", "win"):
+        y_pred, traj, stroke_ids = g7[tag + "_y_pred"], g7[tag + "_traj"], g7[tag + "_stroke_ids"]
+        masks, scores = g7[tag + "_masks"], g7[tag + "_scores"]
+        handler = object.__new__(lh.LossHandler)
+        handler.config = R.maskplanner_loss_config(explicit_no_stroke_weight=float(g7[tag + "_no_stroke_weight"]),
+                                                   smooth_target_stroke_masks=True)
+        d1, _, idx_x, _ = ch.chamfer_distance(torch.from_numpy(y_pred), torch.from_numpy(traj), padded=True, asymmetric=True,
+                                              return_matching=True, point_reduction=None, batch_reduction=None)
+        dl = d1.detach().clone().requires_grad_(True)
+        mk = torch.from_numpy(masks).requires_grad_(True)
+        sc = torch.from_numpy(scores).requires_grad_(True)
+        ml = handler.get_stroke_masks_loss(idx_x, mk, sc, torch.from_numpy(stroke_ids), nn_distance=dl, smooth_targets=True)
+        gm = torch.autograd.grad(ml, [mk, sc, dl])
+        # the whole asymm_v6 loss with the switch on (gradient through the chamfer distances into y_pred)
+        yp = torch.from_numpy(y_pred).requires_grad_(True)
+        mk2 = torch.from_numpy(masks).requires_grad_(True)
+        sc2 = torch.from_numpy(scores).requires_grad_(True)
+        loss = handler.get_asymm_v6_chamfer_with_stroke_masks(
+            y_pred=yp, y=torch.from_numpy(traj), pred_stroke_masks=mk2, mask_scores=sc2, seg_logits=None,
+            stroke_ids=torch.from_numpy(stroke_ids), traj_as_pc=torch.from_numpy(g7[tag + "_traj_as_pc"]))
+        g = torch.autograd.grad(loss, [yp, mk2, sc2])
+        cases.update({tag + "_nn_distance": d1.detach().numpy(), tag + "_idx_x": idx_x.numpy(),
+                      tag + "_mask_loss": ml.detach().numpy(), tag + "_gm_masks": gm[0].numpy(), tag + "_gm_scores": gm[1].numpy(),
+                      tag + "_gm_distance": gm[2].numpy(), tag + "_loss": loss.detach().numpy(), tag + "_g_y_pred": g[0].numpy(),
+                      tag + "_g_masks": g[1].numpy(), tag + "_g_scores": g[2].numpy()})
+    save("g11_smooth", **cases)
+
+
 def main():
     if not R.available():
         raise SystemExit("reference checkout not found; fixtures can only be generated in the build container")
     torch.set_num_threads(8)
     pu = R.pointnet2_utils()
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"]
     if "g1" in which: g1_fps(pu)
     if "g2" in which: g2_bq(pu)
     if "g3" in which: g3_sa(pu)
@@ -483,6 +521,7 @@ def main():
     if "g8" in which: g8_hung()
     if "g9" in which: g9_seg()
     if "g10" in which: g10_fp(pu)
+    if "g11" in which: g11_smooth()
 
 
 if __name__ == "__main__":

@@ -299,6 +299,35 @@ def test_asymm_v6_loss_matches_reference(golden, tag):
     assert float(l0) < float(loss)
 
 
+@pytest.mark.parametrize("tag", ["cub", "win"])
+def test_smooth_target_mask_loss_matches_reference(golden, tag):
+    """`smooth_target_stroke_masks` (loss_handler.py:830, 841-844, 959-964; off in the shipped configs): MSE matching cost
+    and loss with f(nn_distance) targets, gradient reaching the distances."""
+    from maskplanner_amd.loss_handler import LossHandler, maskplanner_loss_config
+    g7, g = golden("g7_mask"), golden("g11_smooth")
+    cfg = maskplanner_loss_config(explicit_no_stroke_weight=float(g7[tag + "_no_stroke_weight"]), smooth_target_stroke_masks=True)
+    lh = LossHandler(["asymm_v6_chamfer_with_stroke_masks"], cfg)
+    mk = dev(g7[tag + "_masks"]).requires_grad_(True)
+    sc = dev(g7[tag + "_scores"]).requires_grad_(True)
+    dl = dev(g[tag + "_nn_distance"]).requires_grad_(True)
+    ml = lh.get_stroke_masks_loss(dev(g[tag + "_idx_x"]), mk, sc, dev(g7[tag + "_stroke_ids"]), nn_distance=dl, smooth_targets=True)
+    close(ml, g[tag + "_mask_loss"], "mask_loss", rtol=1e-5)
+    ml.backward()
+    close(mk.grad, g[tag + "_gm_masks"], "gm_masks", rtol=1e-5, atol=1e-6)
+    close(sc.grad, g[tag + "_gm_scores"], "gm_scores", rtol=1e-5, atol=1e-6)
+    close(dl.grad, g[tag + "_gm_distance"], "gm_distance", rtol=1e-4, atol=1e-6)
+    yp = dev(g7[tag + "_y_pred"]).requires_grad_(True)
+    mk2 = dev(g7[tag + "_masks"]).requires_grad_(True)
+    sc2 = dev(g7[tag + "_scores"]).requires_grad_(True)
+    loss = lh.compute(return_list=False, y_pred=yp, y=dev(g7[tag + "_traj"]), pred_stroke_masks=mk2, mask_scores=sc2, seg_logits=None,
+                      stroke_ids=dev(g7[tag + "_stroke_ids"]), traj_as_pc=dev(g7[tag + "_traj_as_pc"]))
+    close(loss, g[tag + "_loss"], "loss", rtol=1e-5)
+    loss.backward()
+    close(yp.grad, g[tag + "_g_y_pred"], "g_y_pred", rtol=1e-4, atol=1e-6)
+    close(mk2.grad, g[tag + "_g_masks"], "g_masks", rtol=1e-5, atol=1e-6)
+    close(sc2.grad, g[tag + "_g_scores"], "g_scores", rtol=1e-5, atol=1e-6)
+
+
 def test_hungarian_matcher_matches_reference(golden):
     from maskplanner_amd.hungarianMatcher import HungarianMatcher
     g = golden("g8_hung")

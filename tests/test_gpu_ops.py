@@ -242,6 +242,28 @@ def test_mask_match_vs_scipy(oracle, ops, B, M, S, n_ids):
         assert abs(tot - want_cost[r2, c2].sum()) <= 1e-5 * abs(tot)
 
 
+def test_mask_match_smooth_targets_mse_cost(ops):
+    """target_value given: cost[m,k] = sum_s (pred - value*[id == uid_k])^2 (loss_handler.py:810-811, 959-964)."""
+    from scipy.optimize import linear_sum_assignment
+    rng = np.random.default_rng(77)
+    B, M, S = 3, 22, 449
+    pred = rng.normal(size=(B, M, S)).astype(np.float32)
+    ids = rng.integers(0, 15, size=(B, S)).astype(np.float32)
+    val = rng.uniform(0, 1, size=(B, S)).astype(np.float32)
+    match, uniq, nt, status, cost = ops.mask_match(dev(pred), dev(ids), return_cost=True, target_value=dev(val))
+    match, uniq, nt, cost = match.cpu().numpy(), uniq.cpu().numpy(), nt.cpu().numpy(), cost.cpu().numpy()
+    assert (status.cpu().numpy() == 0).all()
+    for b in range(B):
+        u = np.unique(ids[b])
+        assert nt[b] == len(u) and np.array_equal(uniq[b, :len(u)], u)
+        tm = (ids[b][None, :] == u[:, None]) * val[b][None, :].astype(np.float64)                    # [Kb,S]
+        want = ((pred[b][:, None, :].astype(np.float64) - tm[None]) ** 2).sum(-1)                     # [M,Kb]
+        np.testing.assert_allclose(cost[b, :, :len(u)], want, rtol=1e-5)
+        r, c = linear_sum_assignment(cost[b, :, :len(u)])
+        got = match[b]
+        assert np.array_equal(np.nonzero(got >= 0)[0], r) and np.array_equal(got[r], c)
+
+
 def test_mask_match_ties_follow_scipy(ops):
     """All-equal logits => a constant cost matrix: scipy's tie-breaking yields the identity."""
     from scipy.optimize import linear_sum_assignment
