@@ -14,8 +14,22 @@ when the last gradient of a bucket is ready its members are packed into the flat
 `param.grad` is re-pointed at views of that buffer, and the all-reduce (average) is started on the flat buffer: no
 unpack copy afterwards, the optimizer reads the reduced values in place.
 """
+import os
+
 import torch
 import torch.distributed as dist
+
+# Test hook: run the collectives even in a 1-rank process group.  A gpurun box has one GPU and RCCL refuses two ranks
+# on one device, so this is the only way to execute the bucket / stream / RCCL code on real hardware before the
+# multi-GPU bench does (tests/test_gpu_modules.py::test_rccl_single_rank_collectives_do_not_change_the_step).
+FORCE_COLLECTIVES = bool(os.environ.get("MASKPLANNER_FORCE_COLLECTIVES"))
+
+
+def exchanging(process_group=None):
+    """True when gradients / factors have to go through a collective."""
+    if not dist.is_initialized():
+        return False
+    return dist.get_world_size(process_group) > 1 or FORCE_COLLECTIVES
 
 
 class BucketedGradAllReduce:
@@ -28,7 +42,8 @@ class BucketedGradAllReduce:
         self._views = []
         self._handles, self._pending, self._hooks = [], [], []
         self._avg = dist.is_initialized() and dist.get_backend(process_group) == "nccl"  # gloo has no AVG
-        if self.world == 1:
+        self.active = exchanging(process_group)
+        if not self.active:
             return  # nothing to exchange: let autograd write .grad directly (no flat buffers, no extra add/zero passes)
         order = list(reversed(params))  # heads first == the order gradients become ready in backward
         cur, cur_bytes = [], 0
@@ -43,7 +58,7 @@ class BucketedGradAllReduce:
             self._close(cur)
         self._pending = [len(ps) for _, ps in self.buckets]
         self._done = [False] * len(self.buckets)
-        if self.world > 1:
+        if self.active:
             for bi, (_, ps) in enumerate(self.buckets):
                 for p in ps:
                     self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(bi)))
@@ -81,7 +96,7 @@ class BucketedGradAllReduce:
 
     def zero_grad(self):
         """Replaces optimizer.zero_grad(): keeps the grad views alive."""
-        if self.world == 1:
+        if not self.active:
             for p in self.params:
                 p.grad = None
             return
@@ -92,7 +107,7 @@ class BucketedGradAllReduce:
 
     def finish(self):
         """Wait for the in-flight all-reduces (the compute stream waits, not the host) and average."""
-        if self.world == 1:
+        if not self.active:
             return
         # a parameter that received no gradient this step never fired its hook: reduce its bucket now
         for bi, done in enumerate(self._done):
@@ -111,7 +126,6 @@ class BucketedGradAllReduce:
 
 def init_from_env(backend=None):
     """torchrun-style rendezvous (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*).  Returns (rank, local_rank, world)."""
-    import os
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))

@@ -12,7 +12,7 @@ import torch
 import torch.distributed as dist
 import torch.nn.functional as F
 
-from . import _lib, ops
+from . import _lib, dp, ops
 
 
 class _FactorLinear(torch.autograd.Function):
@@ -81,7 +81,7 @@ class FactorAdam:
         world = dist.get_world_size(self.group) if dist.is_initialized() else 1
         xs = [self.store[k][0] for k in keys]
         gs = [self.store[k][1] for k in keys]
-        if world > 1:
+        if dp.exchanging(self.group):
             # distinct input tensors only (fc3 and fc_normals share theirs)
             uniq = {}
             for x in xs:
