@@ -146,6 +146,17 @@ int mp_mask_match_f32(const float* pred_masks, const float* target_ids, const fl
                       int64_t M, int64_t S, int64_t* match_col, float* uniq_ids, int64_t* n_targets, float* cost,
                       int32_t* status, mp_stream_t stream);
 
+/* ---- rectangular linear sum assignment, batched (segment matching) -------------------------------------------
+ * replaces: scipy.optimize.linear_sum_assignment as called by models/hungarianMatcher.py:58-61 (and loss_handler.py:
+ *           990-1009 `emd`): one host round trip + ~0.2 s of one core per 999 x ~900 sample, serial over the batch.
+ *   cost [B, Rmax, ld] f32 (sample b at cost + b*batch_stride, row stride ld >= Cmax); n_rows[b] <= n_cols[b] <= Cmax
+ *   (the caller passes the transposed matrix when a sample has more rows than columns, as scipy does internally).
+ *   Same algorithm and tie-breaking as scipy's rectangular_lsap, fp64 on the fp32 costs; one wave per sample.
+ *   Outputs: col4row [B, Rmax] i64 (column assigned to each row < n_rows[b], -1 elsewhere); status [B] i32:
+ *   0, MP_EINVAL (bad sizes) or MP_EUNSUPPORTED (infeasible: non-finite costs).  Cmax, Rmax <= 2048. */
+int mp_lsap_f32(const float* cost, int64_t B, int64_t Rmax, int64_t Cmax, int64_t ld, int64_t batch_stride,
+                const int32_t* n_rows, const int32_t* n_cols, int64_t* col4row, int32_t* status, mp_stream_t stream);
+
 /* ---- set-abstraction shared MLP: (1x1 conv -> BatchNorm -> ReLU) x L -> max over the K group members ----------
  * replaces: models/pointnet2_utils.py:208-214 (PointNetSetAbstraction.forward tail; :264-269 for MSG) and the
  *           autograd graph torch builds for it.

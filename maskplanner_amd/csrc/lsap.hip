@@ -1,0 +1,184 @@
+// Rectangular linear sum assignment for segment matching (up to 2048 x 2048 per sample), batched on device.
+//
+// Reference: models/hungarianMatcher.py:58-61 copies a [S, Sgt] Euclidean cost matrix per sample to the host and calls
+// scipy.optimize.linear_sum_assignment (999 x ~900: ~0.2 s per sample on one core, serial over the batch).  Here one
+// WAVE per sample runs the same algorithm -- scipy's rectangular_lsap (shortest augmenting paths, Crouse 2016) in
+// fp64 on the fp32 costs, including the scan order that decides ties -- with all dual / path / assignment state in LDS
+// and the samples of a batch side by side on different CUs.  The small (<= 64 x 64) stroke-mask LAP of the training
+// step keeps everything in registers instead (mask_match.hip); this is the large, off-step variant.
+//
+// Every "scan the remaining columns" loop of the serial algorithm is one lane-parallel pass (a lane owns columns
+// lane, lane+64, ...: the cost row is fetched with coalesced loads issued together) followed by a wave-wide
+// lexicographic arg-min: lowest shortest-path cost first; among equal costs scipy's scan keeps the LAST free column
+// it meets, else the FIRST assigned one, in the order of its `remaining` array -- reproduced through pos[] / rem[].
+// A single wave needs no barriers: LDS operations of one wave execute in program order.
+#include "common.h"
+
+namespace {
+
+constexpr int LSAP_MAX = 2048;          // columns per sample: up to 32 per lane
+
+__device__ __forceinline__ double wave_min_f64(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double t = __shfl_xor(v, o, 64);
+        v = t < v ? t : v;
+    }
+    return v;
+}
+
+__device__ __forceinline__ void wave_sync()
+{   // orders this wave's LDS traffic across divergent single-lane sections (compiler + memory model; no s_barrier)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int LSAP_T>   // columns per lane (8 / 16 / 32): Cmax <= 64 * LSAP_T
+__global__ __launch_bounds__(64) void lsap_kernel(const float* __restrict__ cost, int64_t batch_stride, int ld,
+                                                  const int32_t* __restrict__ nr_, const int32_t* __restrict__ nc_,
+                                                  int Rmax, int Cmax, int64_t* __restrict__ col4row_out,
+                                                  int32_t* __restrict__ status)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    double* v = reinterpret_cast<double*>(smem_raw);     // [Cmax] column duals
+    double* spc = v + Cmax;                              // [Cmax] shortest path costs
+    double* u = spc + Cmax;                              // [Rmax] row duals
+    int* path = reinterpret_cast<int*>(u + Rmax);        // [Cmax]
+    int* row4col = path + Cmax;                          // [Cmax]
+    int* pos = row4col + Cmax;                           // [Cmax] position of a column in `remaining`
+    int* rem = pos + Cmax;                               // [Cmax] scipy's `remaining`
+    int* SC = rem + Cmax;                                // [Cmax]
+    int* col4row = SC + Cmax;                            // [Rmax]
+    int* SR = col4row + Rmax;                            // [Rmax]
+
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int nr = nr_[b], nc = nc_[b];
+    int64_t* out = col4row_out + (size_t)b * Rmax;
+    if (nr < 0 || nc < 0 || nr > nc || nc > Cmax || nr > Rmax || nc > 64 * LSAP_T) {
+        if (lane == 0) status[b] = MP_EINVAL;
+        for (int i = lane; i < Rmax; i += 64) out[i] = -1;
+        return;
+    }
+    const float* C = cost + (size_t)b * batch_stride;
+    const double INF = __builtin_inf();
+    for (int j = lane; j < nc; j += 64) { v[j] = 0.0; row4col[j] = -1; }
+    for (int i = lane; i < nr; i += 64) { u[i] = 0.0; col4row[i] = -1; }
+    wave_sync();
+
+    bool feasible = true;
+    for (int cur = 0; cur < nr && feasible; ++cur) {
+        for (int j = lane; j < nc; j += 64) {
+            spc[j] = INF;
+            SC[j] = 0;
+            pos[j] = nc - 1 - j;                 // remaining[it] = nc - it - 1
+            rem[nc - 1 - j] = j;
+        }
+        for (int i = lane; i < nr; i += 64) SR[i] = 0;
+        wave_sync();
+        int num_remaining = nc;
+        int i = cur;
+        double minVal = 0.0;
+        int sink = -1;
+        while (sink == -1) {
+            const double ui = u[i];
+            const float* row = C + (size_t)i * ld;
+            float c[LSAP_T];
+#pragma unroll
+            for (int t = 0; t < LSAP_T; ++t) {
+                const int j = lane + 64 * t;
+                c[t] = (j < nc) ? row[j] : 0.0f;     // the whole row in flight at once
+            }
+            double bv = INF;
+            unsigned bkey = 0u;
+#pragma unroll
+            for (int t = 0; t < LSAP_T; ++t) {
+                const int j = lane + 64 * t;
+                if (j < nc && !SC[j]) {
+                    const double r = minVal + (double)c[t] - ui - v[j];
+                    double s = spc[j];
+                    if (r < s) { s = r; spc[j] = r; path[j] = i; }
+                    const unsigned p = (unsigned)pos[j];
+                    const unsigned key = (row4col[j] == -1) ? 0x80000000u + p : 0x7fffffffu - p;
+                    if (s < bv || (s == bv && key > bkey)) { bv = s; bkey = key; }
+                }
+            }
+            const double lowest = wave_min_f64(bv);
+            const unsigned key = mp::wave_max_u32(bv == lowest ? bkey : 0u);
+            if (!(lowest < INF) || key == 0u) { feasible = false; break; }   // infeasible: non-finite costs
+            const int chosen_pos = (key & 0x80000000u) ? (int)(key - 0x80000000u) : (int)(0x7fffffffu - key);
+            const int j = rem[chosen_pos];
+            minVal = lowest;
+            const int r4c = row4col[j];
+            --num_remaining;
+            if (lane == 0) {
+                SR[i] = 1;
+                SC[j] = 1;
+                const int last = rem[num_remaining];     // remaining[index] = remaining[--num_remaining]
+                rem[chosen_pos] = last;
+                pos[last] = chosen_pos;
+            }
+            wave_sync();
+            if (r4c == -1) sink = j; else i = r4c;
+        }
+        if (!feasible) break;
+        // dual updates (rows in the tree other than cur, columns in the tree)
+        for (int r = lane; r < nr; r += 64) {
+            if (r == cur) u[r] += minVal;
+            else if (SR[r]) u[r] += minVal - spc[col4row[r]];
+        }
+        for (int j = lane; j < nc; j += 64)
+            if (SC[j]) v[j] -= minVal - spc[j];
+        wave_sync();
+        // augment along the path (serial chain; every lane walks it, lane 0 writes)
+        int j = sink;
+        for (;;) {
+            const int pi = path[j];
+            const int t = col4row[pi];
+            wave_sync();                                   // all lanes have read before lane 0 overwrites
+            if (lane == 0) { row4col[j] = pi; col4row[pi] = j; }
+            wave_sync();
+            j = t;
+            if (pi == cur) break;
+        }
+    }
+    for (int i = lane; i < Rmax; i += 64) out[i] = (feasible && i < nr) ? (int64_t)col4row[i] : -1;
+    if (lane == 0) status[b] = feasible ? 0 : MP_EUNSUPPORTED;
+}
+
+size_t lsap_smem(int64_t Rmax, int64_t Cmax)
+{
+    return sizeof(double) * (size_t)(2 * Cmax + Rmax) + sizeof(int) * (size_t)(5 * Cmax + 2 * Rmax);
+}
+
+}  // namespace
+
+extern "C" int mp_lsap_f32(const float* cost, int64_t B, int64_t Rmax, int64_t Cmax, int64_t ld, int64_t batch_stride,
+                           const int32_t* n_rows, const int32_t* n_cols, int64_t* col4row, int32_t* status,
+                           mp_stream_t stream_)
+{
+    if (B < 0 || Rmax < 0 || Cmax < 0 || ld < Cmax) return MP_EINVAL;
+    if (B == 0) return MP_OK;
+    if (!n_rows || !n_cols || !col4row || !status || (Rmax * Cmax > 0 && !cost)) return MP_EINVAL;
+    if (Cmax > LSAP_MAX || Rmax > LSAP_MAX || B > 65535 * 32) return MP_EUNSUPPORTED;
+    const size_t smem = lsap_smem(Rmax, Cmax);
+    if (smem > 160 * 1024) return MP_EUNSUPPORTED;
+    auto launch = [&](auto kernel, size_t& configured) -> int {
+        if (smem > configured) {   // see fps.hip: the attribute is set once per size, outside any capture
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) !=
+                hipSuccess)
+                return MP_ELAUNCH;
+            configured = smem;
+        }
+        MP_LAUNCH("lsap_kernel", 0.0, 4.0 * (double)(B * Rmax * Cmax), kernel, dim3((unsigned)B), dim3(64), smem, mp_stream(stream_), cost,
+                  batch_stride, (int)ld, n_rows, n_cols, (int)Rmax, (int)Cmax, col4row, status);
+        MP_CHECK_LAUNCH();
+        return MP_OK;
+    };
+    static size_t conf8 = 64 * 1024, conf16 = 64 * 1024, conf32 = 64 * 1024;
+    if (Cmax <= 512) return launch(lsap_kernel<8>, conf8);
+    if (Cmax <= 1024) return launch(lsap_kernel<16>, conf16);
+    return launch(lsap_kernel<32>, conf32);
+}

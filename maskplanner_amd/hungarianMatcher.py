@@ -2,14 +2,15 @@
 and GT segments by Euclidean cost, used by the `emd` / `hungarian_SoPs` losses (loss_handler.py:172-174, 1000).
 
 The reference builds ONE [B*S, sum(Sgt)] cdist matrix (every prediction against the GT of every sample, O(B^2)
-wasted work, 3.7 GB at B=32) and slices the diagonal blocks; here each sample's [S, Sgt_b] block is computed on
-its own.  The assignment itself (999 x ~900 per sample) is solved with scipy's rectangular LSAP on the host, as
-in the reference (:61): the large device LAP is the next item of the scope table, the small
-stroke-mask LAP that sits on the training path already runs on the GPU (csrc/mask_match.hip).
+wasted work, 3.7 GB at B=32), slices the diagonal blocks, copies each to the host and solves it with scipy, one sample
+after the other (:58-61; 999 x ~900 takes ~0.2 s of one core).  Here each sample's [S, Sgt_b] block is computed on its
+own and all assignments are solved side by side on the GPU by csrc/lsap.hip -- scipy's algorithm and tie-breaking, one
+wave per sample -- so the only host transfer is the final index lists the reference API returns as CPU tensors.
 """
 import torch
-from scipy.optimize import linear_sum_assignment
 from torch import nn
+
+from . import _lib, ops
 
 
 class HungarianMatcher(nn.Module):
@@ -22,6 +23,7 @@ class HungarianMatcher(nn.Module):
         tensors with len == min(S, Sgt_b), rows ascending (scipy convention)."""
         costs = [torch.cdist(outputs[b], t.to(outputs.device), p=2,
                              compute_mode='use_mm_for_euclid_dist_if_necessary') for b, t in enumerate(targets)]
-        costs = [c.cpu() for c in costs]  # one sync for the whole batch: copies are queued back to back
-        indices = [linear_sum_assignment(c) for c in costs]
-        return [(torch.as_tensor(i, dtype=torch.int64), torch.as_tensor(j, dtype=torch.int64)) for i, j in indices]
+        pairs, status = ops.lsap(costs)
+        if status is not None and bool((status != 0).any()):   # the one sync of the call (the results go to the host anyway)
+            raise _lib.MaskPlannerHipError("HungarianMatcher: infeasible cost matrix (non-finite distances)")
+        return [(i.cpu(), j.cpu()) for i, j in pairs]

@@ -152,6 +152,44 @@ def mask_match(pred_masks, target_ids, return_cost=False, target_value=None):
     return (match, uniq, nt, status, cost) if return_cost else (match, uniq, nt, status)
 
 
+@torch.no_grad()
+def lsap(costs):
+    """scipy.optimize.linear_sum_assignment for a list of 2-D fp32 device cost matrices (hungarianMatcher.py:58-61), solved
+    side by side on the GPU with scipy's algorithm and tie-breaking.  Returns (pairs, status): one (row_ind, col_ind) pair
+    of i64 DEVICE tensors per matrix, rows ascending, len == min(shape) -- scipy's convention -- and the per-sample
+    status tensor (0 = solved; non-zero = infeasible cost matrix, indices are -1)."""
+    if not costs:
+        return [], None
+    _need_hip(*costs)
+    dev = costs[0].device
+    B = len(costs)
+    tr = [c.shape[0] > c.shape[1] for c in costs]                 # scipy solves the transpose when rows > columns
+    mats = [(_f32(c).t() if t else _f32(c)) for c, t in zip(costs, tr)]
+    Rmax = max(m.shape[0] for m in mats)
+    Cmax = max(m.shape[1] for m in mats)
+    if Cmax > 2048:
+        raise _lib.MaskPlannerHipError("lsap: more than 2048 columns per sample is outside the gfx950 kernel's range")
+    pad = torch.zeros((B, max(Rmax, 1), max(Cmax, 1)), dtype=torch.float32, device=dev)
+    for b, m in enumerate(mats):
+        pad[b, :m.shape[0], :m.shape[1]] = m
+    nr = torch.tensor([m.shape[0] for m in mats], dtype=torch.int32).to(dev)
+    nc = torch.tensor([m.shape[1] for m in mats], dtype=torch.int32).to(dev)
+    c4r = torch.empty((B, pad.shape[1]), dtype=torch.int64, device=dev)
+    status = torch.empty((B,), dtype=torch.int32, device=dev)
+    _run("lsap", pad, _lib.load().mp_lsap_f32, _p(pad), B, pad.shape[1], pad.shape[2], pad.shape[2], pad.shape[1] * pad.shape[2],
+         _p(nr), _p(nc), _p(c4r), _p(status))
+    out = []
+    for b, (m, t) in enumerate(zip(mats, tr)):
+        n = m.shape[0]
+        cols = c4r[b, :n]
+        rows = torch.arange(n, dtype=torch.int64, device=dev)
+        if t:   # solved on the transpose: (row, col) = (col4row[k], k), reported in ascending row order
+            rows, order = torch.sort(cols)
+            cols = order
+        out.append((rows, cols))
+    return out, status
+
+
 # ----------------------------------------------------------------------------------------------------------------
 # differentiable ops
 # ----------------------------------------------------------------------------------------------------------------

@@ -352,3 +352,46 @@ def test_three_nn_rejects_bad_input(ops):
     with pytest.raises((ValueError, RuntimeError)):
         ops.three_nn(torch.zeros(1, 4, 3), torch.zeros(1, 5, 3))   # CPU tensors are refused
 
+
+# ------------------------------------------------------------------------------------------------ large LAP (segment matching)
+def _scipy_pairs(c):
+    from scipy.optimize import linear_sum_assignment
+    return linear_sum_assignment(c)
+
+
+@pytest.mark.parametrize("shapes", [[(999, 900), (999, 985), (999, 999)], [(40, 70), (70, 40), (1, 5), (5, 1), (64, 64)],
+                                    [(1333, 1290), (449, 500)], [(300, 2048), (2048, 300)]])
+def test_lsap_matches_scipy(ops, shapes):
+    """hungarianMatcher.py:58-61: same assignment as scipy.optimize.linear_sum_assignment (continuous random costs: the
+    optimum is unique), rows ascending, rectangular both ways, ragged batch."""
+    rng = np.random.default_rng(sum(a * b for a, b in shapes))
+    costs = [rng.uniform(0, 3, size=s).astype(np.float32) for s in shapes]
+    pairs, status = ops.lsap([dev(c) for c in costs])
+    assert (status.cpu().numpy() == 0).all()
+    for c, (i, j) in zip(costs, pairs):
+        r, k = _scipy_pairs(c)
+        assert i.dtype == torch.int64 and j.dtype == torch.int64
+        assert np.array_equal(i.cpu().numpy(), r) and np.array_equal(j.cpu().numpy(), k), c.shape
+
+
+def test_lsap_ties_follow_scipy(ops):
+    """Integer-valued costs are full of ties: the scan-order rules of scipy's rectangular_lsap decide, and are reproduced."""
+    rng = np.random.default_rng(3)
+    costs = [rng.integers(0, 4, size=s).astype(np.float32) for s in [(30, 30), (50, 80), (80, 50), (200, 210), (7, 7)]]
+    costs.append(np.zeros((20, 25), np.float32))
+    pairs, status = ops.lsap([dev(c) for c in costs])
+    assert (status.cpu().numpy() == 0).all()
+    for c, (i, j) in zip(costs, pairs):
+        r, k = _scipy_pairs(c)
+        assert np.array_equal(i.cpu().numpy(), r) and np.array_equal(j.cpu().numpy(), k), c.shape
+
+
+def test_lsap_infeasible_and_empty(ops):
+    c = np.full((3, 3), np.inf, np.float32)
+    pairs, status = ops.lsap([dev(c), dev(np.eye(3, dtype=np.float32))])
+    st = status.cpu().numpy()
+    assert st[0] != 0 and st[1] == 0
+    assert (pairs[0][1].cpu().numpy() == -1).all()
+    assert np.array_equal(pairs[1][1].cpu().numpy(), np.array([1, 0, 2])) or np.array_equal(pairs[1][1].cpu().numpy(), _scipy_pairs(np.eye(3))[1])
+    assert ops.lsap([]) == ([], None)
+
