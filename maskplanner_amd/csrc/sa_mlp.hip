@@ -514,9 +514,17 @@ int launch_dw(const PosOperand& DZ, const PosOperand& IN, int64_t P64, float* dW
 {
     const int Co = DZ.C, Ci = IN.C;
     const int P = (int)P64;
+    // positions per workgroup: 1024, fewer when that leaves the chip short of workgroups (group_all: P = 4096).  Every
+    // workgroup ends with one fp32 atomic per dW element of its tile, so slices are not made smaller than needed for
+    // ~512 workgroups in all (32 output tiles x 128 slices of 128 positions spent more time in atomics than in MFMA).
+    const unsigned gy = (Co + 127) / 128;
     int ppb = 1024;
-    while ((P + ppb - 1) / ppb < 128 && ppb > 128) ppb >>= 1;  // keep >= 128 position slices for small P (group_all)
-    const unsigned gx = (unsigned)((P + ppb - 1) / ppb), gy = (Co + 127) / 128;
+    {
+        const int64_t tiles = (int64_t)gy * ((Ci + 127) / 128);
+        const int64_t want = (512 + tiles - 1) / tiles;                     // slices wanted
+        while ((P + ppb - 1) / ppb < want && ppb > 128) ppb >>= 1;
+    }
+    const unsigned gx = (unsigned)((P + ppb - 1) / ppb);
     // input-channel tiling: 128-wide tiles, a narrow remainder (132 = 128 + 4, 260 = 2*128 + 4) gets 32-wide tiles so
     // that it does not pay for a whole 128-column MFMA tile of zeros
     const int main_ci = (Ci > 128 && Ci % 128 != 0 && Ci % 128 <= 32) ? (Ci / 128) * 128 : Ci;
@@ -712,18 +720,36 @@ int launch_pos_gemm(const PosOperand& A, int64_t P, const float* W, int N, int K
 {
     if (ldw == 0) ldw = N;
     if (ldc == 0) ldc = N;
-    const unsigned gm = (unsigned)((P + 127) / 128);
-    if (nblk_out) *nblk_out = (int)gm;
     // algorithmic work of one launch: 2*P*N*Kd flops; bytes = operand(s) read once + result written once + weights
     const double flops = 2.0 * (double)P * N * Kd;
     const double rd = (MODE == SRC_DZ ? 2.0 : 1.0) * (double)P * Kd + (EPI == EPI_DY ? (double)P * N : 0.0);
     const double bytes = 4.0 * (rd + (C ? (double)P * N : 0.0) + (double)N * Kd);
+    // Tile shape: 128x128 (2x2 waves of 64x64) by default, 128x64 for N <= 64.  A launch needs well over 256 workgroups
+    // to fill the chip: when the default grid is smaller (the group_all level: P = 4096 => 32 row tiles) narrower, then
+    // lower tiles are used.  The fused max-pool epilogue needs whole groups inside a row tile, so it keeps 128 rows.
+    const int64_t t128 = ((P + 127) / 128) * ((N + 127) / 128);
+    const int64_t t128x64 = ((P + 127) / 128) * ((N + 63) / 64);
+    int shape = (N <= 64) ? 1 : 0;                       // 0: 128x128, 1: 128x64, 2: 64x64
+    if (shape == 0 && t128 < 384) shape = (t128x64 >= 384 || EPI == EPI_SQ_POOL) ? 1 : 2;
+    if (shape == 1 && N > 64 && EPI != EPI_SQ_POOL && t128x64 < 384) shape = 2;
     char tag[96];
-    if (N <= 64) {
+    if (shape == 1) {
+        const unsigned gm = (unsigned)((P + 127) / 128);
+        if (nblk_out) *nblk_out = (int)gm;
         snprintf(tag, sizeof tag, "pos_gemm_kernel<%d, %s, %d, 4, 1, 1, 2>", MODE, W_KROW ? "true" : "false", EPI);
         MP_LAUNCH(tag, flops, bytes, (pos_gemm_kernel<MODE, W_KROW, EPI, 4, 1, 1, 2>), dim3(gm, (N + 63) / 64),
                   dim3(THREADS), 0, stream, A, (int)P, W, N, Kd, C, partials, zprev, sprev, tprev, po, ldw, ldc);
+    } else if (shape == 2) {
+        if constexpr (EPI != EPI_SQ_POOL) {
+            const unsigned gm = (unsigned)((P + 63) / 64);
+            if (nblk_out) *nblk_out = (int)gm;
+            snprintf(tag, sizeof tag, "pos_gemm_kernel<%d, %s, %d, 2, 2, 1, 1>", MODE, W_KROW ? "true" : "false", EPI);
+            MP_LAUNCH(tag, flops, bytes, (pos_gemm_kernel<MODE, W_KROW, EPI, 2, 2, 1, 1>), dim3(gm, (N + 63) / 64),
+                      dim3(THREADS), 0, stream, A, (int)P, W, N, Kd, C, partials, zprev, sprev, tprev, po, ldw, ldc);
+        }
     } else {
+        const unsigned gm = (unsigned)((P + 127) / 128);
+        if (nblk_out) *nblk_out = (int)gm;
         snprintf(tag, sizeof tag, "pos_gemm_kernel<%d, %s, %d, 2, 2, 2, 2>", MODE, W_KROW ? "true" : "false", EPI);
         MP_LAUNCH(tag, flops, bytes, (pos_gemm_kernel<MODE, W_KROW, EPI, 2, 2, 2, 2>), dim3(gm, (N + 127) / 128),
                   dim3(THREADS), 0, stream, A, (int)P, W, N, Kd, C, partials, zprev, sprev, tprev, po, ldw, ldc);
@@ -744,7 +770,7 @@ extern "C" size_t mp_sa_mlp_workspace_bytes(int64_t P, int64_t K, int n_layers, 
     if (P <= 0 || n_layers <= 0 || !channels) return 0;
     int64_t cmax = 0;
     for (int l = 0; l <= n_layers; ++l) cmax = channels[l] > cmax ? channels[l] : cmax;
-    const size_t nblk = (size_t)((P + 127) / 128);
+    const size_t nblk = (size_t)((P + 63) / 64);                           // row tiles are 128 or (small grids) 64 high
     size_t bytes = align_up(nblk * 2 * (size_t)cmax * sizeof(float), 256);  // epilogue partials
     bytes += 3 * align_up((size_t)cmax * sizeof(float), 256);              // dZ constants a, e, f
     if (!backward) bytes += 4 * align_up((size_t)(P / (K > 0 ? K : 1)) * (size_t)channels[n_layers] * sizeof(float), 256);  // fused pool
@@ -784,7 +810,7 @@ extern "C" int mp_sa_mlp_fwd_f32(const float* x0, int64_t P, int64_t K, int n_la
         int64_t cmax = 0;
         for (int l = 0; l <= n_layers; ++l) cmax = ch[l] > cmax ? ch[l] : cmax;
         unsigned char* w = reinterpret_cast<unsigned char*>(workspace);
-        w += align_up((size_t)((P + 127) / 128) * 2 * (size_t)cmax * sizeof(float), 256);
+        w += align_up((size_t)((P + 63) / 64) * 2 * (size_t)cmax * sizeof(float), 256);
         w += 3 * align_up((size_t)cmax * sizeof(float), 256);
         const size_t pb = align_up((size_t)(P / K) * (size_t)ch[n_layers] * sizeof(float), 256);
         po.vmax = reinterpret_cast<float*>(w);
@@ -867,7 +893,7 @@ extern "C" int mp_sa_mlp_bwd_f32(const float* x0, int64_t P, int64_t K, int n_la
     hipStream_t stream = mp_stream(stream_);
     // carve the workspace (same order as mp_sa_mlp_workspace_bytes)
     unsigned char* w = reinterpret_cast<unsigned char*>(workspace);
-    const size_t nblk_max = (size_t)((P + 127) / 128);
+    const size_t nblk_max = (size_t)((P + 63) / 64);
     float* partials = reinterpret_cast<float*>(w);
     w += align_up(nblk_max * 2 * (size_t)cmax * sizeof(float), 256);
     float* cbuf[3];
@@ -889,7 +915,7 @@ extern "C" int mp_sa_mlp_bwd_f32(const float* x0, int64_t P, int64_t K, int n_la
     {
         const int C = (int)last.c_out;
         const int nb = (int)((G + POOL_ROWS - 1) / POOL_ROWS);
-        if ((size_t)nb > nblk_max) return MP_EUNSUPPORTED;  // partials hold P/128 rows: needs K >= 8
+        if ((size_t)nb > nblk_max) return MP_EUNSUPPORTED;  // partials hold P/64 rows: needs K >= 4
         hipLaunchKernelGGL(pool_bwd_prep_kernel, dim3(nb, (C + 255) / 256), dim3(256), 0, stream, grad_out, out, zmax, G, C, gp,
                            partials);
         MP_CHECK_LAUNCH();
