@@ -216,7 +216,7 @@ class LossHandler:
     def _segment_term(self, y_pred, y, seg_logits):
         """Term 1 of the asymmetric losses: pred->GT segment chamfer, unreduced, with the matching (:604-621)."""
         d, _, match, _ = chamfer_distance(y_pred, y, padded=True, asymmetric=True, return_matching=True,
-                                          point_reduction=None, batch_reduction=None)
+                                          point_reduction=None, batch_reduction=None, _matching_y=False)
         conf = 0
         if self._cfg().get("per_segment_confidence", False):
             conf = self._get_per_segment_confidence_loss(nn_distance=d, logits=seg_logits)
@@ -253,14 +253,14 @@ class LossHandler:
                                               traj_as_pc, **kwargs):
         self._no_extras()
         cfg = self._cfg()
-        seg, _, match, _ = chamfer_distance(y_pred, y, padded=True, return_matching=True)
+        seg, _, match, _ = chamfer_distance(y_pred, y, padded=True, return_matching=True, _matching_y=False)
         pts = self.get_symm_point_chamfer(y_pred, y, traj_as_pc)
         masks = self.get_stroke_masks_loss(match, pred_stroke_masks, mask_scores, stroke_ids, **kwargs)
         return cfg["weight_symm_segment_chamfer"] * (100 * seg) + cfg["weight_symm_point_chamfer"] * pts + masks
 
     def get_chamfer_with_stroke_masks(self, y_pred, y, pred_stroke_masks, mask_scores, stroke_ids, **kwargs):
         self._no_extras()
-        chamfer, _, match, _ = chamfer_distance(y_pred, y, padded=True, return_matching=True)
+        chamfer, _, match, _ = chamfer_distance(y_pred, y, padded=True, return_matching=True, _matching_y=False)
         return 100 * chamfer + self.get_stroke_masks_loss(match, pred_stroke_masks, mask_scores, stroke_ids, **kwargs)
 
 

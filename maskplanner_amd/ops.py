@@ -347,3 +347,35 @@ def knn(p1, p2, lengths1=None, lengths2=None, K=1):
     l1 = None if lengths1 is None else _i64(lengths1)
     l2 = None if lengths2 is None else _i64(lengths2)
     return _Knn.apply(_f32(p1), _f32(p2), l1, l2, int(K))
+
+
+class _ChamferReduce(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, cham, lengths, point_mean, batch_mode, div):
+        N, P = cham.shape
+        out = torch.empty((N,) if batch_mode == 0 else (), dtype=torch.float32, device=cham.device)
+        _run("chamfer_reduce", cham, _lib.load().mp_chamfer_reduce_f32, _p(cham), _p(lengths), N, P, int(point_mean), int(batch_mode),
+             float(div), _p(out))
+        ctx.save_for_backward(lengths)
+        ctx.meta = (N, P, int(point_mean), int(batch_mode), float(div))
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (lengths,) = ctx.saved_tensors
+        N, P, point_mean, batch_mode, div = ctx.meta
+        grad_out = _f32(grad_out)
+        grad = torch.empty((N, P), dtype=torch.float32, device=grad_out.device)
+        _run("chamfer_reduce_bwd", grad_out, _lib.load().mp_chamfer_reduce_bwd_f32, _p(grad_out), _p(lengths), N, P, point_mean,
+             batch_mode, div, _p(grad))
+        return grad, None, None, None, None
+
+
+def chamfer_reduce(cham, lengths, point_reduction, batch_reduction):
+    """pytorch3d_chamfer.py:295-326 in one launch: cham [N,P] (rows beyond a cloud's length already zero) -> sum or mean over
+    the points (mean divides by lengths [N] i64), then None / sum / mean over the batch."""
+    _need_hip(cham, lengths)
+    N = cham.shape[0]
+    batch_mode = {None: 0, "sum": 1, "mean": 2}[batch_reduction]
+    return _ChamferReduce.apply(_f32(cham), _i64(lengths), point_reduction == "mean", batch_mode, float(N))
+

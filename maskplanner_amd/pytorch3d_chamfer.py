@@ -50,12 +50,16 @@ def _row_mask(lengths, P):
 def chamfer_distance(x, y, x_lengths=None, y_lengths=None, x_normals=None, y_normals=None, weights=None,
                      batch_reduction: Union[str, None] = "mean", point_reduction: Union[str, None] = "mean",
                      velocities=False, min_centroids=False, padded=False, avoid_in_sequence_collapsing=False,
-                     soft_attraction=False, asymmetric=False, reverse_asymmetric=False, return_matching=False):
+                     soft_attraction=False, asymmetric=False, reverse_asymmetric=False, return_matching=False,
+                     _matching_y=True):
     """Chamfer distance between point sets x [N,P1,D] and y [N,P2,D]; see the reference docstring (:95-129) and the
     custom flags (:84-93).  Returns (dist, normals_dist_or_None) and, with return_matching, also the nearest
-    neighbour indices (idx_x [N,P1], idx_y [N,P2])."""
+    neighbour indices (idx_x [N,P1], idx_y [N,P2]).  `_matching_y=False` (not a reference argument; used by this
+    package's LossHandler, which only consumes idx_x) returns None for idx_y and skips the y->x search when the distance
+    does not need it."""
     if not soft_attraction:
         _validate_chamfer_reduction_inputs(batch_reduction, point_reduction)
+    y_lengths_given = y_lengths is not None
     x, x_lengths, x_normals = _handle_pointcloud_input(x, x_lengths, x_normals)
     y, y_lengths, y_normals = _handle_pointcloud_input(y, y_lengths, y_normals)
     return_normals = x_normals is not None and y_normals is not None
@@ -66,8 +70,11 @@ def chamfer_distance(x, y, x_lengths=None, y_lengths=None, x_normals=None, y_nor
 
     if padded:  # -100 sentinel in the leading coordinate marks fake GT rows (:138-149)
         found = ops.padded_lengths(y)
-        # the reference overwrites y_lengths only if at least one sample is padded (:140); decided on device
-        y_lengths.copy_(torch.where((found != P2).any(), found, y_lengths))
+        if y_lengths_given:
+            # the reference overwrites y_lengths only if at least one sample is padded (:140); decided on device
+            y_lengths.copy_(torch.where((found != P2).any(), found, y_lengths))
+        else:
+            y_lengths = found   # default lengths are P2 everywhere, which is also what `found` holds for unpadded samples
 
     if weights is not None:
         if weights.size(0) != N:
@@ -83,7 +90,7 @@ def chamfer_distance(x, y, x_lengths=None, y_lengths=None, x_normals=None, y_nor
             return z, z.clone()
 
     need_x = asymmetric or not reverse_asymmetric or return_matching or return_normals
-    need_y = (not asymmetric) or return_matching or return_normals
+    need_y = (not asymmetric) or (return_matching and _matching_y) or return_normals
     idx_x = idx_y = None
 
     if velocities:
@@ -125,6 +132,19 @@ def chamfer_distance(x, y, x_lengths=None, y_lengths=None, x_normals=None, y_nor
         if need_y:
             dy, idx_y = ops.knn(y, x, y_lengths, x_lengths, 1)
             cham_y = dy[..., 0]
+        if weights is None and not return_normals and point_reduction is not None:
+            # the training-step case: one fused reduction per direction that reaches the result (ops.chamfer_reduce)
+            rx = ops.chamfer_reduce(cham_x, x_lengths, point_reduction, batch_reduction) if (asymmetric or not reverse_asymmetric) else None
+            ry = ops.chamfer_reduce(cham_y, y_lengths, point_reduction, batch_reduction) if not asymmetric else None
+            cham_dist = rx if asymmetric else (ry if reverse_asymmetric else rx + ry)
+            if return_matching:
+                return cham_dist, None, idx_x.flatten(1, 2), (None if idx_y is None else idx_y.flatten(1, 2))
+            return cham_dist, None
+        if weights is None and not return_normals and point_reduction is None:
+            cham_dist = cham_x if asymmetric else (cham_y if reverse_asymmetric else cham_x + cham_y)   # unreduced (:329-334)
+            if return_matching:
+                return cham_dist, None, idx_x.flatten(1, 2), (None if idx_y is None else idx_y.flatten(1, 2))
+            return cham_dist, None
         # a skipped direction never reaches the result; keep the algebra below uniform
         if cham_x is None:
             cham_x = x.new_zeros((N, P1))
@@ -177,5 +197,5 @@ def chamfer_distance(x, y, x_lengths=None, y_lengths=None, x_normals=None, y_nor
     cham_normals = cham_norm_x + cham_norm_y if return_normals else None
 
     if return_matching:
-        return cham_dist, cham_normals, idx_x.flatten(1, 2), idx_y.flatten(1, 2)
+        return cham_dist, cham_normals, idx_x.flatten(1, 2), (None if idx_y is None else idx_y.flatten(1, 2))
     return cham_dist, cham_normals

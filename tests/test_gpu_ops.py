@@ -395,3 +395,33 @@ def test_lsap_infeasible_and_empty(ops):
     assert np.array_equal(pairs[1][1].cpu().numpy(), np.array([1, 0, 2])) or np.array_equal(pairs[1][1].cpu().numpy(), _scipy_pairs(np.eye(3))[1])
     assert ops.lsap([]) == ([], None)
 
+
+# ------------------------------------------------------------------------------------------------ chamfer reductions
+@pytest.mark.parametrize("point,batch", [("mean", "mean"), ("sum", "mean"), ("mean", "sum"), ("sum", None), ("mean", None)])
+def test_chamfer_reduce_matches_torch_algebra(ops, point, batch):
+    """pytorch3d_chamfer.py:295-326 as one kernel forward / one backward, against the same algebra in torch (fp64)."""
+    rng = np.random.default_rng(17)
+    N, P = 32, 999
+    lengths = rng.integers(500, P + 1, size=N)
+    cham = rng.uniform(0, 2, size=(N, P)).astype(np.float32)
+    cham[np.arange(P)[None] >= lengths[:, None]] = 0.0            # what the kNN kernel leaves beyond a cloud's length
+    c = dev(cham).requires_grad_(True)
+    out = ops.chamfer_reduce(c, dev(lengths), point, batch)
+    c64 = torch.from_numpy(cham).double().requires_grad_(True)
+    ref = c64.sum(1)
+    if point == "mean":
+        ref = ref / torch.from_numpy(lengths)
+    if batch is not None:
+        ref = ref.sum()
+        if batch == "mean":
+            ref = ref / N
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), rtol=2e-6)
+    g = rng.normal(size=tuple(ref.shape)).astype(np.float32)
+    out.backward(torch.tensor(g).cuda())
+    ref.backward(torch.tensor(g).double())
+    want = c64.grad.numpy().copy()
+    want[np.arange(P)[None] >= lengths[:, None]] = 0.0            # no gradient into the padded rows
+    np.testing.assert_allclose(c.grad.cpu().numpy(), want, rtol=2e-6, atol=1e-12)
+    out2 = ops.chamfer_reduce(dev(cham), dev(lengths), point, batch)
+    assert torch.equal(out2, out.detach())                          # deterministic
+

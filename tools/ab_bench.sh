@@ -1,5 +1,6 @@
+# alternate the working tree and ab_prev/ (tools/ab_setup.sh) on the same box: ms per step of each, three rounds
 for i in 1 2 3; do
 for v in cur prev; do
-  if [ $v = prev ]; then export MASKPLANNER_HIP_LIB=$GRAFT_REPO_ROOT/maskplanner_amd/lib/ablate/lib_prev.so; else unset MASKPLANNER_HIP_LIB; fi
-  python bench.py --steps 60 --warmup 10 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads([l for l in sys.stdin if l.startswith(chr(123))][0]); print('$v', round(d['ms_per_step'],3))"
+  if [ $v = prev ]; then d=$GRAFT_REPO_ROOT/ab_prev; else d=$GRAFT_REPO_ROOT; fi
+  (cd $d && python bench.py --steps 60 --warmup 10 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads([l for l in sys.stdin if l.startswith(chr(123))][0]); print('$v', round(d['ms_per_step'],3), 'median', round(d.get('step_ms_median', 0),3), 'min', round(d.get('step_ms_min', 0),3))")
 done; done
