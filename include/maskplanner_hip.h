@@ -91,6 +91,11 @@ int mp_three_interpolate_bwd_f32(const float* grad_out, const int64_t* idx, cons
                                  int64_t N, int64_t S, int64_t D, float* grad_points2, int deterministic,
                                  mp_stream_t stream);
 
+/* ---- column permutation with zero fill (host-side helper of the fused MLP: first-layer weight in the internal column order)
+ *   dst [R,Cd] : dst[r,c] = src[r, perm[c]] for perm[c] >= 0, else 0;  src [R,Cs], perm i32 [Cd]. */
+int mp_permute_cols_f32(const float* src, const int32_t* perm, int64_t R, int64_t Cs, int64_t Cd, float* dst,
+                        mp_stream_t stream);
+
 /* ---- grouping (gather + centre + concat) -----------------------------------------------------
  * replaces: models/pointnet2_utils.py:133-143 (sample_and_group tail) and :258-262 (MSG variant)
  *   out [B,S,K,3+D] = cat(xyz[idx] - new_xyz, feats[idx])   (xyz_last == 0, SSG order, :138)
@@ -168,6 +173,24 @@ int mp_mask_match_f32(const float* pred_masks, const float* target_ids, const fl
  *   0, MP_EINVAL (bad sizes) or MP_EUNSUPPORTED (infeasible: non-finite costs).  Cmax, Rmax <= 2048. */
 int mp_lsap_f32(const float* cost, int64_t B, int64_t Rmax, int64_t Cmax, int64_t ld, int64_t batch_stride,
                 const int32_t* n_rows, const int32_t* n_cols, int64_t* col4row, int32_t* status, mp_stream_t stream);
+
+/* ---- fused tails: pose output and stroke-mask loss ---------------------------------------------------------------
+ * mp_pose_output: replaces models/pointnet2_cls_ssg.py:332-339 (tanh -> view(B,-1,3) -> F.normalize * weight_orient, cat with
+ *   the positions): pos, raw [n_pose*3] -> out [n_pose, 6]; the backward writes grad_pos / grad_raw (either may be NULL).
+ * mp_mask_loss: replaces loss_handler.py:877-934 for binary targets, after mp_mask_match_f32: matched BCE-with-logits
+ *   .sum(-1).mean() + weighted confidence BCE .mean(): out [1] = w_masks*mask_loss + w_conf*conf_loss.  per_mask [B*M] and
+ *   n_matched [1] are scratch / saved for the backward, which writes grad_masks [B,M,S] and grad_scores [B,M] (or NULL).
+ *   All sums run in a fixed order. */
+int mp_pose_output_f32(const float* pos, const float* raw, int64_t n_pose, double weight_orient, float* out, mp_stream_t stream);
+int mp_pose_output_bwd_f32(const float* grad_out, const float* raw, int64_t n_pose, double weight_orient, float* grad_pos,
+                           float* grad_raw, mp_stream_t stream);
+int mp_mask_loss_f32(const float* pred_masks, const float* scores, const float* target_ids, const int64_t* match_col,
+                     const float* uniq_ids, int64_t B, int64_t M, int64_t S, double w_masks, double w_conf,
+                     double no_stroke_weight, float* per_mask, float* out, float* n_matched, mp_stream_t stream);
+int mp_mask_loss_bwd_f32(const float* grad_out, const float* pred_masks, const float* scores, const float* target_ids,
+                         const int64_t* match_col, const float* uniq_ids, const float* n_matched, int64_t B, int64_t M, int64_t S,
+                         double w_masks, double w_conf, double no_stroke_weight, float* grad_masks, float* grad_scores,
+                         mp_stream_t stream);
 
 /* ---- set-abstraction shared MLP: (1x1 conv -> BatchNorm -> ReLU) x L -> max over the K group members ----------
  * replaces: models/pointnet2_utils.py:208-214 (PointNetSetAbstraction.forward tail; :264-269 for MSG) and the

@@ -55,6 +55,11 @@ SIGNATURES = {
     "mp_lsap_f32": (_int, [_vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
     "mp_chamfer_reduce_f32": (_int, [_vp, _vp, _i64, _i64, _int, _int, ctypes.c_double, _vp, _vp]),
     "mp_chamfer_reduce_bwd_f32": (_int, [_vp, _vp, _i64, _i64, _int, _int, ctypes.c_double, _vp, _vp]),
+    "mp_permute_cols_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp]),
+    "mp_pose_output_f32": (_int, [_vp, _vp, _i64, _dbl, _vp, _vp]),
+    "mp_pose_output_bwd_f32": (_int, [_vp, _vp, _i64, _dbl, _vp, _vp, _vp]),
+    "mp_mask_loss_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _dbl, _dbl, _dbl, _vp, _vp, _vp, _vp]),
+    "mp_mask_loss_bwd_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _dbl, _dbl, _dbl, _vp, _vp, _vp]),
     "mp_knn_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "mp_knn_f32": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _sz, _vp]),
     "mp_knn_bwd_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _int, _vp]),

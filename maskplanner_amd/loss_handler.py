@@ -86,6 +86,9 @@ def stroke_masks_loss(pred_to_gt_match, pred_stroke_masks, scores, stroke_ids, w
     conf = segment_distance_to_confidence(nn_distance) if smooth_targets else None            # [B,S], carries grad
     match, uniq, _, _ = ops.mask_match(pred_stroke_masks.detach(), target_ids,                # :847-875, on device
                                        target_value=None if conf is None else conf.detach())
+    if not smooth_targets and not return_matching and pred_stroke_masks.dtype == torch.float32:
+        # binary targets: the rest of the function as three launches (ops.mask_loss); same algebra, fixed summation order
+        return ops.mask_loss(pred_stroke_masks, scores, target_ids, match, uniq, w_masks, w_conf, no_stroke_weight)
     matched = match >= 0                                                                      # [B,M]
     uid = uniq.gather(1, match.clamp(min=0))                                                  # id matched to each pred mask
     in_mask = target_ids[:, None, :] == uid[:, :, None]                                       # [B,M,S]

@@ -379,3 +379,67 @@ def chamfer_reduce(cham, lengths, point_reduction, batch_reduction):
     batch_mode = {None: 0, "sum": 1, "mean": 2}[batch_reduction]
     return _ChamferReduce.apply(_f32(cham), _i64(lengths), point_reduction == "mean", batch_mode, float(N))
 
+
+class _PoseOutput(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pos, raw, weight_orient):
+        n = pos.numel() // 3
+        out = torch.empty((n, 6), dtype=torch.float32, device=pos.device)
+        _run("pose_output", pos, _lib.load().mp_pose_output_f32, _p(pos), _p(raw), n, float(weight_orient), _p(out))
+        ctx.save_for_backward(raw)
+        ctx.meta = (n, float(weight_orient), tuple(pos.shape), tuple(raw.shape))
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (raw,) = ctx.saved_tensors
+        n, w, pshape, rshape = ctx.meta
+        grad_out = _f32(grad_out)
+        gp = torch.empty(pshape, dtype=torch.float32, device=raw.device) if ctx.needs_input_grad[0] else None
+        gr = torch.empty(rshape, dtype=torch.float32, device=raw.device) if ctx.needs_input_grad[1] else None
+        _run("pose_output_bwd", raw, _lib.load().mp_pose_output_bwd_f32, _p(grad_out), _p(raw), n, w, _p(gp), _p(gr))
+        return gp, gr, None
+
+
+def pose_output(pos, raw, weight_orient):
+    """models/pointnet2_cls_ssg.py:332-339 in one launch: pos, raw [B, n_pose*3] -> [B*n_pose, 6] rows
+    (position, weight_orient * unit(tanh(raw)))."""
+    _need_hip(pos, raw)
+    if pos.shape != raw.shape or pos.numel() % 3:
+        raise ValueError("pose_output: positions and raw normals must have the same shape, a multiple of 3 values")
+    return _PoseOutput.apply(_f32(pos), _f32(raw), float(weight_orient))
+
+
+class _MaskLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, scores, target_ids, match, uniq, w_masks, w_conf, no_stroke_weight):
+        B, M, S = pred.shape
+        dev = pred.device
+        per_mask = torch.empty((B * M,), dtype=torch.float32, device=dev)
+        out = torch.empty((), dtype=torch.float32, device=dev)
+        n_matched = torch.empty((1,), dtype=torch.float32, device=dev)
+        _run("mask_loss", pred, _lib.load().mp_mask_loss_f32, _p(pred), _p(scores), _p(target_ids), _p(match), _p(uniq), B, M, S,
+             float(w_masks), float(w_conf), float(no_stroke_weight), _p(per_mask), _p(out), _p(n_matched))
+        ctx.save_for_backward(pred, scores, target_ids, match, uniq, n_matched)
+        ctx.meta = (B, M, S, float(w_masks), float(w_conf), float(no_stroke_weight))
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        pred, scores, target_ids, match, uniq, n_matched = ctx.saved_tensors
+        B, M, S, w_masks, w_conf, nsw = ctx.meta
+        grad_out = _f32(grad_out)
+        gm = torch.empty_like(pred)
+        gs = torch.empty_like(scores) if ctx.needs_input_grad[1] else None
+        _run("mask_loss_bwd", pred, _lib.load().mp_mask_loss_bwd_f32, _p(grad_out), _p(pred), _p(scores), _p(target_ids), _p(match),
+             _p(uniq), _p(n_matched), B, M, S, w_masks, w_conf, nsw, _p(gm), _p(gs))
+        return gm, gs, None, None, None, None, None, None
+
+
+def mask_loss(pred_masks, scores, target_ids, match, uniq, w_masks, w_conf, no_stroke_weight):
+    """loss_handler.py:877-934 (binary targets) after mask_match: w_masks * matched-BCE.sum(-1).mean() +
+    w_conf * weighted confidence BCE.mean(), forward in two launches, backward in one."""
+    _need_hip(pred_masks, scores, target_ids, match, uniq)
+    return _MaskLoss.apply(_f32(pred_masks), _f32(scores), _f32(target_ids), _i64(match), _f32(uniq), w_masks, w_conf,
+                           no_stroke_weight)
+

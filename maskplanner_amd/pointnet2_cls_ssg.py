@@ -11,6 +11,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import ops
 from .factor_heads import factor_linear
 from .pointnet2_utils import PointNetSetAbstraction
 
@@ -46,6 +47,8 @@ class _SSGEncoder(nn.Module):
 
 def _pose_output(x, normals_raw, B, out_vectors, weight_orient):
     """cat(position, weight_orient * unit normal) per pose, poses interleaved per output vector (:332-339)."""
+    if x.is_cuda and x.dtype == torch.float32 and x.shape == normals_raw.shape:
+        return ops.pose_output(x, normals_raw, weight_orient).view(B, out_vectors, -1)       # one launch (and one backward)
     normals = F.normalize(torch.tanh(normals_raw).view(B, -1, 3), dim=-1) * weight_orient
     return torch.cat((x.view(B, -1, 3), normals), dim=-1).view(B, out_vectors, -1)
 

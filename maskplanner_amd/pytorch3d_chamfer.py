@@ -26,6 +26,20 @@ def _validate_chamfer_reduction_inputs(batch_reduction: Union[str, None], point_
         raise ValueError('point_reduction must be one of ["mean", "sum"] if batch_reduction is not None')
 
 
+_FULL_LENGTHS = {}
+
+
+def _full_lengths(N, P, device):
+    """[N] int64 tensor filled with P, cached per (N, P, device): three chamfer calls per step asked for six fills.
+    Never written to (an explicit y_lengths is the caller's tensor; the default one is replaced, not updated)."""
+    key = (N, P, device)
+    t = _FULL_LENGTHS.get(key)
+    if t is None:
+        t = torch.full((N,), P, dtype=torch.int64, device=device)
+        _FULL_LENGTHS[key] = t
+    return t
+
+
 def _handle_pointcloud_input(points, lengths, normals):
     """Tensor inputs only (pytorch3d's Pointclouds container is not part of this build): :38-73."""
     if not torch.is_tensor(points):
@@ -36,7 +50,7 @@ def _handle_pointcloud_input(points, lengths, normals):
     if lengths is not None and (lengths.ndim != 1 or lengths.shape[0] != points.shape[0]):
         raise ValueError("Expected lengths to be of shape (N,)")
     if lengths is None:
-        lengths = torch.full((points.shape[0],), points.shape[1], dtype=torch.int64, device=points.device)
+        lengths = _full_lengths(points.shape[0], points.shape[1], points.device)
     if normals is not None and normals.ndim != 3:
         raise ValueError("Expected normals to be of shape (N, P, 3")
     return points, lengths, normals

@@ -87,6 +87,44 @@ class _SharedMLPMax(torch.autograd.Function):
         return (gx, None, None, None, None, None, None, *ret)
 
 
+class _PermuteCols(torch.autograd.Function):
+    """dst[:, c] = src[:, perm[c]] (zero where perm[c] < 0); perm / inv are cached int32 device tensors."""
+
+    @staticmethod
+    def forward(ctx, src, perm, inv):
+        R, Cs = src.shape
+        dst = torch.empty((R, perm.numel()), dtype=torch.float32, device=src.device)
+        ops._run("permute_cols", src, _lib.load().mp_permute_cols_f32, _ptr(src), _ptr(perm), R, Cs, perm.numel(), _ptr(dst))
+        ctx.save_for_backward(perm, inv)
+        return dst
+
+    @staticmethod
+    def backward(ctx, grad):
+        perm, inv = ctx.saved_tensors
+        grad = grad.contiguous()
+        R = grad.shape[0]
+        out = torch.empty((R, inv.numel()), dtype=torch.float32, device=grad.device)
+        ops._run("permute_cols", grad, _lib.load().mp_permute_cols_f32, _ptr(grad), _ptr(inv), R, perm.numel(), inv.numel(), _ptr(out))
+        return out, None, None
+
+
+_PERMS = {}
+
+
+def _first_weight_perm(cin, cpad, rotate, device):
+    """Column maps of the first layer's weight: reference order [xyz(3) | feats] -> internal [feats | xyz | zero pad]
+    (rotate) or just the zero padding; cached per shape and device."""
+    key = (cin, cpad, rotate, device)
+    if key not in _PERMS:
+        order = (list(range(3, cin)) + [0, 1, 2]) if rotate else list(range(cin))
+        perm = order + [-1] * (cpad - cin)
+        inv = [0] * cin
+        for c, j in enumerate(order):
+            inv[j] = c
+        _PERMS[key] = (torch.tensor(perm, dtype=torch.int32).to(device), torch.tensor(inv, dtype=torch.int32).to(device))
+    return _PERMS[key]
+
+
 def shared_mlp_max(grouped, convs, bns, layout="xyz_first"):
     """grouped [B,S,K,C (+ zero padding up to a multiple of 4)] -> [B,S,Cout] = max_K relu(bn(conv(.))) chained over the
     layers (fused HIP path).
@@ -119,10 +157,9 @@ def shared_mlp_max(grouped, convs, bns, layout="xyz_first"):
             raise NotImplementedError("fused set-abstraction MLP: layer widths must be multiples of 4")
         w = conv.weight.view(conv.out_channels, conv.in_channels)
         if i == 0:
-            if layout == "feats_first" and cin > 3:
-                w = torch.cat([w[:, 3:], w[:, :3]], dim=1)
-            if cpad != cin:
-                w = F.pad(w, (0, cpad - cin))
+            rotate = layout == "feats_first" and cin > 3
+            if rotate or cpad != cin:   # one launch (and one in backward) instead of cat + pad and their autograd
+                w = _PermuteCols.apply(w, *_first_weight_perm(cin, cpad, rotate, w.device))
         track = bn.track_running_stats and bn.running_mean is not None
         if not training and not track:
             raise NotImplementedError("eval-mode BatchNorm without running statistics")

@@ -425,3 +425,54 @@ def test_chamfer_reduce_matches_torch_algebra(ops, point, batch):
     out2 = ops.chamfer_reduce(dev(cham), dev(lengths), point, batch)
     assert torch.equal(out2, out.detach())                          # deterministic
 
+
+# ------------------------------------------------------------------------------------------------ fused tails
+def test_pose_output_matches_torch_algebra(ops):
+    """models/pointnet2_cls_ssg.py:332-339 as one kernel, against the reference's op chain (values and both gradients);
+    includes an all-zero raw normal (tanh(0) = 0: the F.normalize eps branch)."""
+    import torch.nn.functional as F
+    rng = np.random.default_rng(23)
+    B, S, lam, w = 4, 99, 4, 0.25
+    pos = rng.normal(size=(B, S * lam * 3)).astype(np.float32)
+    raw = rng.normal(size=(B, S * lam * 3)).astype(np.float32) * 2
+    raw[0, :3] = 0.0
+    p1, r1 = dev(pos).requires_grad_(True), dev(raw).requires_grad_(True)
+    out = ops.pose_output(p1, r1, w).view(B, S, -1)
+    p2, r2 = dev(pos).requires_grad_(True), dev(raw).requires_grad_(True)
+    normals = F.normalize(torch.tanh(r2).view(B, -1, 3), dim=-1) * w
+    ref = torch.cat((p2.view(B, -1, 3), normals), dim=-1).view(B, S, -1)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().cpu().numpy(), rtol=1e-6, atol=1e-7)
+    g = dev(rng.normal(size=tuple(ref.shape)).astype(np.float32))
+    out.backward(g)
+    ref.backward(g)
+    np.testing.assert_allclose(p1.grad.cpu().numpy(), p2.grad.cpu().numpy(), rtol=0, atol=0)
+    np.testing.assert_allclose(r1.grad.cpu().numpy(), r2.grad.cpu().numpy(), rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("B,M,S,n_ids,nsw", [(4, 6, 999, 6, 1.0), (3, 22, 449, 15, 0.5), (2, 41, 1266, 30, 0.1)])
+def test_mask_loss_matches_torch_algebra(ops, B, M, S, n_ids, nsw):
+    """loss_handler.py:877-934 (binary targets) fused, against the same algebra in torch ops."""
+    import torch.nn.functional as F
+    rng = np.random.default_rng(B * M + S)
+    pred = rng.normal(size=(B, M, S)).astype(np.float32)
+    scores = rng.normal(size=(B, M)).astype(np.float32)
+    ids = rng.integers(0, n_ids, size=(B, S)).astype(np.float32)
+    match, uniq, nt, status = ops.mask_match(dev(pred), dev(ids))
+    w_masks, w_conf = 1.0, 100.0
+    a, sa = dev(pred).requires_grad_(True), dev(scores).requires_grad_(True)
+    out = ops.mask_loss(a, sa, dev(ids), match, uniq, w_masks, w_conf, nsw)
+    b, sb = dev(pred).requires_grad_(True), dev(scores).requires_grad_(True)
+    matched = match >= 0
+    uid = uniq.gather(1, match.clamp(min=0))
+    tm = (dev(ids)[:, None, :] == uid[:, :, None]).float()
+    per_mask = F.binary_cross_entropy_with_logits(b, tm, reduction="none").sum(-1)
+    mask_loss = (per_mask * matched).sum() / matched.sum()
+    weights = torch.where(matched, torch.ones_like(sb), torch.full_like(sb, nsw))
+    conf = F.binary_cross_entropy_with_logits(sb, matched.float(), weight=weights, reduction="none").mean()
+    ref = w_masks * mask_loss + w_conf * conf
+    np.testing.assert_allclose(float(out), float(ref), rtol=2e-6)
+    out.backward()
+    ref.backward()
+    np.testing.assert_allclose(a.grad.cpu().numpy(), b.grad.cpu().numpy(), rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(sa.grad.cpu().numpy(), sb.grad.cpu().numpy(), rtol=1e-5, atol=1e-8)
+

@@ -13,7 +13,8 @@ ts = TrainStep("cuboids", B=32, N=5120)
 for _ in range(3):
     ts.step()
 torch.cuda.synchronize()
-with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CPU, torch.profiler.ProfilerActivity.CUDA], with_stack=True) as prof:
+with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CPU, torch.profiler.ProfilerActivity.CUDA], with_stack=True,
+                            experimental_config=torch._C._profiler._ExperimentalConfig(verbose=True)) as prof:
     ts.step()
     torch.cuda.synchronize()
 ev = prof.events()
@@ -24,10 +25,11 @@ for e in ev:
     # only leaf ops (those that directly own kernels)
     where = "?"
     for fr in (e.stack or []):
-        if "maskplanner_amd" in fr or "torch/optim" in fr or "autograd" in fr:
-            where = fr.split("/")[-1] if "maskplanner_amd" in fr else fr[-60:]
-            if "maskplanner_amd" in fr:
-                break
+        if "maskplanner_amd" in fr:
+            where = fr.split("/")[-1][:70]
+            break
+    if where == "?" and e.stack:
+        where = "[autograd/other] " + e.stack[0][-50:]
     dev_us = sum(k.duration for k in e.kernels)
     key = (e.name, where)
     by[key][0] += len(e.kernels)
