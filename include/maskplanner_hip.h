@@ -192,6 +192,17 @@ int mp_mask_loss_bwd_f32(const float* grad_out, const float* pred_masks, const f
                          double w_masks, double w_conf, double no_stroke_weight, float* grad_masks, float* grad_scores,
                          mp_stream_t stream);
 
+/* ---- BatchNorm1d + ReLU over a skinny batch (regression heads) -------------------------------------------------------
+ * replaces: F.relu(bn(x)) of models/pointnet2_cls_ssg.py:309-327 for x [B, C] with a small B (nn.BatchNorm1d semantics:
+ *   biased batch variance normalises, running_var gets the unbiased one, momentum update; eval uses the running stats).
+ *   Forward: y [B,C], save_mean / save_rstd [C].  Backward: grad_x [B,C], grad_gamma / grad_beta [C] (any may be NULL). */
+int mp_bn_relu_rows_f32(const float* x, int64_t B, int64_t C, int training, double momentum, double eps, const float* gamma,
+                        const float* beta, float* running_mean, float* running_var, float* y, float* save_mean,
+                        float* save_rstd, mp_stream_t stream);
+int mp_bn_relu_rows_bwd_f32(const float* grad_y, const float* y, const float* x, int64_t B, int64_t C, int training,
+                            const float* gamma, const float* save_mean, const float* save_rstd, float* grad_x,
+                            float* grad_gamma, float* grad_beta, mp_stream_t stream);
+
 /* ---- set-abstraction shared MLP: (1x1 conv -> BatchNorm -> ReLU) x L -> max over the K group members ----------
  * replaces: models/pointnet2_utils.py:208-214 (PointNetSetAbstraction.forward tail; :264-269 for MSG) and the
  *           autograd graph torch builds for it.

@@ -60,6 +60,8 @@ SIGNATURES = {
     "mp_pose_output_bwd_f32": (_int, [_vp, _vp, _i64, _dbl, _vp, _vp, _vp]),
     "mp_mask_loss_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _dbl, _dbl, _dbl, _vp, _vp, _vp, _vp]),
     "mp_mask_loss_bwd_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _dbl, _dbl, _dbl, _vp, _vp, _vp]),
+    "mp_bn_relu_rows_f32": (_int, [_vp, _i64, _i64, _int, _dbl, _dbl, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mp_bn_relu_rows_bwd_f32": (_int, [_vp, _vp, _vp, _i64, _i64, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mp_knn_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "mp_knn_f32": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _sz, _vp]),
     "mp_knn_bwd_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _int, _vp]),

@@ -185,3 +185,156 @@ extern "C" int mp_mask_loss_bwd_f32(const float* grad_out, const float* pred_mas
     MP_CHECK_LAUNCH();
     return MP_OK;
 }
+
+// ---- BatchNorm1d + ReLU over a skinny batch (the regression heads: [B=32, 1024] activations) ------------------------------
+// torch runs this as collect-statistics + transform + running-stat update + clamp_min (4 launches, 3 more in backward) on
+// 128 KB of data.  One thread per channel walks the B rows (coalesced across channels): statistics, normalisation, ReLU and
+// the running-stat update in one launch; the backward (ReLU mask, dgamma / dbeta, dx) in another.
+namespace {
+
+// RB: rows held in registers (all B <= RB rows of a channel are fetched with independent loads: one memory latency for the
+// whole kernel); RB == 0: any B, rows re-read per pass.
+template <int RB>
+__global__ __launch_bounds__(64) void bn_relu_rows_kernel(const float* __restrict__ x, int B, int C, int training,
+                                                          float momentum, float eps, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float* __restrict__ running_mean,
+                                                          float* __restrict__ running_var, float* __restrict__ y,
+                                                          float* __restrict__ save_mean, float* __restrict__ save_rstd)
+{
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= C) return;
+    constexpr int NR = RB > 0 ? RB : 1;
+    float xv[NR];
+    if constexpr (RB > 0) {
+#pragma unroll
+        for (int r = 0; r < RB; ++r) xv[r] = r < B ? x[(size_t)r * C + c] : 0.0f;
+    }
+    auto at = [&](int r) { if constexpr (RB > 0) return xv[r]; else return x[(size_t)r * C + c]; };
+    float mean, rstd;
+    if (training) {
+        float s = 0.0f;
+        if constexpr (RB > 0) {
+#pragma unroll
+            for (int r = 0; r < RB; ++r) s += xv[r];          // rows beyond B hold 0
+        } else {
+            for (int r = 0; r < B; ++r) s += at(r);
+        }
+        mean = s / (float)B;
+        float v = 0.0f;
+        if constexpr (RB > 0) {
+#pragma unroll
+            for (int r = 0; r < RB; ++r) { const float d = xv[r] - mean; v += r < B ? d * d : 0.0f; }
+        } else {
+            for (int r = 0; r < B; ++r) { const float d = at(r) - mean; v += d * d; }
+        }
+        const float var = v / (float)B;                       // biased: what normalises
+        rstd = 1.0f / sqrtf(var + eps);
+        if (running_mean) {
+            running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * mean;
+            running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (B > 1 ? v / (float)(B - 1) : var);   // unbiased
+        }
+    } else {
+        mean = running_mean[c];
+        rstd = 1.0f / sqrtf(running_var[c] + eps);
+    }
+    save_mean[c] = mean;
+    save_rstd[c] = rstd;
+    const float g = gamma ? gamma[c] : 1.0f, b = beta ? beta[c] : 0.0f;
+    if constexpr (RB > 0) {
+#pragma unroll
+        for (int r = 0; r < RB; ++r)
+            if (r < B) { const float v = (xv[r] - mean) * rstd * g + b; y[(size_t)r * C + c] = v > 0.0f ? v : 0.0f; }
+    } else {
+        for (int r = 0; r < B; ++r) { const float v = (at(r) - mean) * rstd * g + b; y[(size_t)r * C + c] = v > 0.0f ? v : 0.0f; }
+    }
+}
+
+template <int RB>
+__global__ __launch_bounds__(64) void bn_relu_rows_bwd_kernel(const float* __restrict__ grad_y, const float* __restrict__ y,
+                                                              const float* __restrict__ x, int B, int C, int training,
+                                                              const float* __restrict__ gamma, const float* __restrict__ save_mean,
+                                                              const float* __restrict__ save_rstd, float* __restrict__ grad_x,
+                                                              float* __restrict__ grad_gamma, float* __restrict__ grad_beta)
+{
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= C) return;
+    const float mean = save_mean[c], rstd = save_rstd[c];
+    const float g = gamma ? gamma[c] : 1.0f;
+    constexpr int NR = RB > 0 ? RB : 1;
+    float dyv[NR], xh[NR];
+    float db = 0.0f, dg = 0.0f;
+    if constexpr (RB > 0) {
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            const size_t o = (size_t)(r < B ? r : 0) * C + c;
+            const float yy = y[o], gy = grad_y[o], xx = x[o];
+            dyv[r] = (r < B && yy > 0.0f) ? gy : 0.0f;
+            xh[r] = r < B ? (xx - mean) * rstd : 0.0f;
+        }
+#pragma unroll
+        for (int r = 0; r < RB; ++r) { db += dyv[r]; dg += dyv[r] * xh[r]; }
+    } else {
+        for (int r = 0; r < B; ++r) {
+            const size_t o = (size_t)r * C + c;
+            const float dy = y[o] > 0.0f ? grad_y[o] : 0.0f;
+            db += dy;
+            dg += dy * ((x[o] - mean) * rstd);
+        }
+    }
+    if (grad_beta) grad_beta[c] = db;
+    if (grad_gamma) grad_gamma[c] = dg;
+    if (!grad_x) return;
+    const float inv = 1.0f / (float)B;
+    if constexpr (RB > 0) {
+#pragma unroll
+        for (int r = 0; r < RB; ++r)
+            if (r < B) grad_x[(size_t)r * C + c] = training ? g * rstd * (dyv[r] - db * inv - xh[r] * dg * inv) : g * rstd * dyv[r];
+    } else {
+        for (int r = 0; r < B; ++r) {
+            const size_t o = (size_t)r * C + c;
+            const float dy = y[o] > 0.0f ? grad_y[o] : 0.0f;
+            const float xhat = (x[o] - mean) * rstd;
+            grad_x[o] = training ? g * rstd * (dy - db * inv - xhat * dg * inv) : g * rstd * dy;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int mp_bn_relu_rows_f32(const float* x, int64_t B, int64_t C, int training, double momentum, double eps,
+                                   const float* gamma, const float* beta, float* running_mean, float* running_var, float* y,
+                                   float* save_mean, float* save_rstd, mp_stream_t stream_)
+{
+    if (B <= 0 || C < 0) return MP_EINVAL;
+    if (C == 0) return MP_OK;
+    if (!x || !y || !save_mean || !save_rstd || (!training && (!running_mean || !running_var))) return MP_EINVAL;
+    if (B > 4096 || C > (1 << 24)) return MP_EUNSUPPORTED;   // a thread walks the rows: made for skinny batches
+    const dim3 grid((unsigned)((C + 63) / 64));   // 64 channels per workgroup: 16 workgroups for the 1024-wide heads
+    if (B <= 32)
+        hipLaunchKernelGGL(bn_relu_rows_kernel<32>, grid, dim3(64), 0, mp_stream(stream_), x, (int)B, (int)C, training, (float)momentum,
+                           (float)eps, gamma, beta, running_mean, running_var, y, save_mean, save_rstd);
+    else
+        hipLaunchKernelGGL(bn_relu_rows_kernel<0>, grid, dim3(64), 0, mp_stream(stream_), x, (int)B, (int)C, training, (float)momentum,
+                           (float)eps, gamma, beta, running_mean, running_var, y, save_mean, save_rstd);
+    MP_CHECK_LAUNCH();
+    return MP_OK;
+}
+
+extern "C" int mp_bn_relu_rows_bwd_f32(const float* grad_y, const float* y, const float* x, int64_t B, int64_t C, int training,
+                                       const float* gamma, const float* save_mean, const float* save_rstd, float* grad_x,
+                                       float* grad_gamma, float* grad_beta, mp_stream_t stream_)
+{
+    if (B <= 0 || C < 0) return MP_EINVAL;
+    if (C == 0) return MP_OK;
+    if (!grad_y || !y || !x || !save_mean || !save_rstd) return MP_EINVAL;
+    if (B > 4096 || C > (1 << 24)) return MP_EUNSUPPORTED;
+    const dim3 grid((unsigned)((C + 63) / 64));
+    if (B <= 32)
+        hipLaunchKernelGGL(bn_relu_rows_bwd_kernel<32>, grid, dim3(64), 0, mp_stream(stream_), grad_y, y, x, (int)B, (int)C, training, gamma,
+                           save_mean, save_rstd, grad_x, grad_gamma, grad_beta);
+    else
+        hipLaunchKernelGGL(bn_relu_rows_bwd_kernel<0>, grid, dim3(64), 0, mp_stream(stream_), grad_y, y, x, (int)B, (int)C, training, gamma,
+                           save_mean, save_rstd, grad_x, grad_gamma, grad_beta);
+    MP_CHECK_LAUNCH();
+    return MP_OK;
+}

@@ -443,3 +443,42 @@ def mask_loss(pred_masks, scores, target_ids, match, uniq, w_masks, w_conf, no_s
     return _MaskLoss.apply(_f32(pred_masks), _f32(scores), _f32(target_ids), _i64(match), _f32(uniq), w_masks, w_conf,
                            no_stroke_weight)
 
+
+class _BnReluRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps):
+        B, C = x.shape
+        y = torch.empty_like(x)
+        stats = torch.empty((2, C), dtype=torch.float32, device=x.device)
+        _run("bn_relu_rows", x, _lib.load().mp_bn_relu_rows_f32, _p(x), B, C, int(training), float(momentum), float(eps), _p(gamma),
+             _p(beta), _p(running_mean), _p(running_var), _p(y), stats[0].data_ptr(), stats[1].data_ptr())
+        ctx.save_for_backward(x, y, gamma, stats)
+        ctx.training = bool(training)
+        return y
+
+    @staticmethod
+    def backward(ctx, grad_y):
+        x, y, gamma, stats = ctx.saved_tensors
+        B, C = x.shape
+        grad_y = _f32(grad_y)
+        gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        gg = torch.empty((C,), dtype=torch.float32, device=x.device) if (gamma is not None and ctx.needs_input_grad[1]) else None
+        gb = torch.empty((C,), dtype=torch.float32, device=x.device) if ctx.needs_input_grad[2] else None
+        _run("bn_relu_rows_bwd", x, _lib.load().mp_bn_relu_rows_bwd_f32, _p(grad_y), _p(y), _p(x), B, C, int(ctx.training), _p(gamma),
+             stats[0].data_ptr(), stats[1].data_ptr(), _p(gx), _p(gg), _p(gb))
+        return gx, gg, gb, None, None, None, None, None
+
+
+def bn_relu_rows(x, bn):
+    """F.relu(bn(x)) for an nn.BatchNorm1d `bn` and x [B, C] with a small batch (models/pointnet2_cls_ssg.py:309-327): one
+    launch forward, one backward.  Updates running statistics like the module does; the caller advances
+    `num_batches_tracked` (heads batch that into one launch)."""
+    _need_hip(x)
+    if x.ndim != 2 or x.shape[1] != bn.num_features:
+        raise ValueError("bn_relu_rows expects [B, C] input matching the BatchNorm width")
+    training = bn.training or bn.running_mean is None
+    track = bn.track_running_stats and bn.running_mean is not None
+    momentum = bn.momentum if bn.momentum is not None else 1.0 / max(float(bn.num_batches_tracked), 1.0)
+    return _BnReluRows.apply(_f32(x), bn.weight, bn.bias, bn.running_mean if track else None, bn.running_var if track else None,
+                             training, momentum, bn.eps)
+

@@ -45,6 +45,21 @@ class _SSGEncoder(nn.Module):
         return l3_points.reshape(B, 1024)
 
 
+def _bn_relu(x, bn):
+    """F.relu(bn(x)) of the head blocks (:309-327); on the GPU one fused launch (ops.bn_relu_rows) instead of BatchNorm's
+    statistics / transform / running-stat kernels + clamp.  The caller has advanced num_batches_tracked (_tick)."""
+    if x.is_cuda and x.dtype == torch.float32 and x.ndim == 2:
+        return ops.bn_relu_rows(x, bn)
+    return F.relu(bn(x))
+
+
+def _tick(*bns):
+    """num_batches_tracked += 1 for train-mode BatchNorm layers, one launch for all of them (nn.BatchNorm does it per layer)."""
+    counters = [bn.num_batches_tracked for bn in bns if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None]
+    if counters:
+        torch._foreach_add_(counters, 1)
+
+
 def _pose_output(x, normals_raw, B, out_vectors, weight_orient):
     """cat(position, weight_orient * unit normal) per pose, poses interleaved per output vector (:332-339)."""
     if x.is_cuda and x.dtype == torch.float32 and x.shape == normals_raw.shape:
@@ -75,8 +90,12 @@ class PointNet2Regressor(_SSGEncoder):
     def forward(self, xyz):
         B = xyz.shape[0]
         feat = self.encode(xyz)
-        x = self.dropout(F.relu(self.bn1(self.fc1(feat))))
-        final = self.dropout(F.relu(self.bn2(self.fc2(x))))
+        fused = feat.is_cuda
+        if fused:
+            _tick(self.bn1, self.bn2)
+        act = _bn_relu if fused else (lambda t, bn: F.relu(bn(t)))
+        x = self.dropout(act(self.fc1(feat), self.bn1))
+        final = self.dropout(act(self.fc2(x), self.bn2))
         x = self.fc3(final)
         if self.outdim_orient > 0:
             return _pose_output(x, self.fc_normals(final), B, self.out_vectors, self.weight_orient)
@@ -128,8 +147,12 @@ class PointNet2Regressor_StrokeMasks(_SSGEncoder):
         B = xyz.shape[0]
         fs = self.factor_store
         feat = self.encode(xyz)
-        x = self.dropout(F.relu(self.bn1(self.fc1(feat))))
-        final = self.dropout(F.relu(self.bn2(self.fc2(x))))
+        fused = feat.is_cuda
+        if fused:
+            _tick(*([self.bn1, self.bn2] + ([self.sm_bn1, self.sm_bn2] if self.pred_stroke_masks else [])))
+        act = _bn_relu if fused else (lambda t, bn: F.relu(bn(t)))
+        x = self.dropout(act(self.fc1(feat), self.bn1))
+        final = self.dropout(act(self.fc2(x), self.bn2))
         x = factor_linear(final, self.fc3, fs, "fc3.weight")
 
         seg_conf = None
@@ -140,8 +163,8 @@ class PointNet2Regressor_StrokeMasks(_SSGEncoder):
 
         sm_out, mask_conf = None, None
         if self.pred_stroke_masks:
-            s1 = self.dropout(F.relu(self.sm_bn1(self.sm_fc1(feat))))
-            s2 = self.dropout(F.relu(self.sm_bn2(self.sm_fc2(s1))))
+            s1 = self.dropout(act(self.sm_fc1(feat), self.sm_bn1))
+            s2 = self.dropout(act(self.sm_fc2(s1), self.sm_bn2))
             sm_out = factor_linear(s2, self.sm_fc3, fs, "sm_fc3.weight").view(B, self.n_stroke_masks, -1)
             if self.mask_confidence_scores:
                 mask_conf = self.mask_conf_out(s2)

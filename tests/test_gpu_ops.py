@@ -476,3 +476,33 @@ def test_mask_loss_matches_torch_algebra(ops, B, M, S, n_ids, nsw):
     np.testing.assert_allclose(a.grad.cpu().numpy(), b.grad.cpu().numpy(), rtol=1e-5, atol=1e-8)
     np.testing.assert_allclose(sa.grad.cpu().numpy(), sb.grad.cpu().numpy(), rtol=1e-5, atol=1e-8)
 
+
+@pytest.mark.parametrize("train", [True, False])
+@pytest.mark.parametrize("B,C", [(32, 1024), (4, 64), (2, 1000)])
+def test_bn_relu_rows_matches_batchnorm1d(ops, train, B, C):
+    """F.relu(nn.BatchNorm1d(x)) fused for skinny batches: outputs, gradients and running statistics against torch's own."""
+    import torch.nn.functional as F
+    torch.manual_seed(B * C)
+    bn_a, bn_b = torch.nn.BatchNorm1d(C).cuda(), torch.nn.BatchNorm1d(C).cuda()
+    with torch.no_grad():
+        for bn in (bn_a, bn_b):
+            bn.weight.copy_(torch.linspace(0.5, 1.5, C))
+            bn.bias.copy_(torch.linspace(-0.3, 0.3, C))
+            bn.running_mean.copy_(torch.linspace(-0.2, 0.2, C))
+            bn.running_var.copy_(torch.linspace(0.5, 1.5, C))
+    bn_a.train(train)
+    bn_b.train(train)
+    x = torch.randn(B, C, device="cuda") * 2 + 0.5
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    ya = ops.bn_relu_rows(xa, bn_a)
+    yb = F.relu(bn_b(xb))
+    np.testing.assert_allclose(ya.detach().cpu().numpy(), yb.detach().cpu().numpy(), rtol=1e-5, atol=1e-6)
+    g = torch.randn(B, C, device="cuda")
+    ya.backward(g)
+    yb.backward(g)
+    np.testing.assert_allclose(xa.grad.cpu().numpy(), xb.grad.cpu().numpy(), rtol=1e-4, atol=2e-6)
+    np.testing.assert_allclose(bn_a.weight.grad.cpu().numpy(), bn_b.weight.grad.cpu().numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(bn_a.bias.grad.cpu().numpy(), bn_b.bias.grad.cpu().numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(bn_a.running_mean.cpu().numpy(), bn_b.running_mean.cpu().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(bn_a.running_var.cpu().numpy(), bn_b.running_var.cpu().numpy(), rtol=1e-5, atol=1e-6)
+
