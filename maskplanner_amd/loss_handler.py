@@ -171,12 +171,13 @@ class LossHandler:
     def get_asymm_segment_chamfer(self, y_pred, y, **args):
         return 100 * chamfer_distance(y_pred, y, padded=True, asymmetric=True)[0]
 
-    def get_reverse_asymm_point_chamfer(self, y_pred, y, traj_as_pc, **args):
-        return 100 * chamfer_distance(self._pose_cloud(y_pred), self._on_device(traj_as_pc, y_pred), padded=True,
-                                      reverse_asymmetric=True)[0]
+    # `_w` (internal): a constant the composite losses fold into the reduction kernel together with the 100 (no scalar launches)
+    def get_reverse_asymm_point_chamfer(self, y_pred, y, traj_as_pc, _w=1.0, **args):
+        return chamfer_distance(self._pose_cloud(y_pred), self._on_device(traj_as_pc, y_pred), padded=True,
+                                reverse_asymmetric=True, _scale=100.0 * float(_w))[0]
 
-    def get_reverse_asymm_segment_chamfer(self, y_pred, y, **args):
-        return 100 * chamfer_distance(y_pred, y, padded=True, reverse_asymmetric=True)[0]
+    def get_reverse_asymm_segment_chamfer(self, y_pred, y, _w=1.0, **args):
+        return chamfer_distance(y_pred, y, padded=True, reverse_asymmetric=True, _scale=100.0 * float(_w))[0]
 
     def get_attraction_chamfer(self, y_pred, **args):
         return 100 * chamfer_distance(y_pred[:, :, :3], y_pred[:, :, -3:], padded=False)[0]
@@ -216,36 +217,40 @@ class LossHandler:
         targets = self._transform_segment_distance_to_confidence(nn_distance)
         return self._cfg()["explicit_weight_segments_confidence"] * (logits - targets).square().sum(-1).mean()
 
-    def _segment_term(self, y_pred, y, seg_logits):
-        """Term 1 of the asymmetric losses: pred->GT segment chamfer, unreduced, with the matching (:604-621)."""
+    def _segment_term(self, y_pred, y, seg_logits, _w=1.0):
+        """Term 1 of the asymmetric losses: pred->GT segment chamfer, unreduced, with the matching (:604-621);
+        returns _w * 100 * d.mean() (one reduction launch: every predicted cloud has the same length)."""
         d, _, match, _ = chamfer_distance(y_pred, y, padded=True, asymmetric=True, return_matching=True,
                                           point_reduction=None, batch_reduction=None, _matching_y=False)
         conf = 0
         if self._cfg().get("per_segment_confidence", False):
             conf = self._get_per_segment_confidence_loss(nn_distance=d, logits=seg_logits)
-        return 100 * d.mean(), conf, match, d
+        if d.is_cuda:
+            from .pytorch3d_chamfer import _full_lengths
+            seg = ops.chamfer_reduce(d, _full_lengths(d.shape[0], d.shape[1], d.device), "mean", "mean", 100.0 * float(_w))
+        else:
+            seg = float(_w) * 100 * d.mean()
+        return seg, conf, match, d
 
     def get_asymm_v6_chamfer_with_stroke_masks(self, y_pred, y, pred_stroke_masks, mask_scores, seg_logits, stroke_ids,
                                                traj_as_pc, **kwargs):
         cfg = self._cfg()
-        seg, conf, match, d = self._segment_term(y_pred, y, seg_logits)
-        pts = self.get_reverse_asymm_point_chamfer(y_pred, y, traj_as_pc)          # :623-637
-        rev = self.get_reverse_asymm_segment_chamfer(y_pred, y)                    # :641-645
+        # the term weights of :660-664 travel into the reduction kernels (_w)
+        seg, conf, match, d = self._segment_term(y_pred, y, seg_logits, _w=cfg["weight_asymm_segment_chamfer"])
+        pts = self.get_reverse_asymm_point_chamfer(y_pred, y, traj_as_pc, _w=cfg["weight_reverse_asymm_point_chamfer"])     # :623-637
+        rev = self.get_reverse_asymm_segment_chamfer(y_pred, y, _w=cfg["weight_reverse_asymm_segment_chamfer"])             # :641-645
         masks = self.get_stroke_masks_loss(match, pred_stroke_masks, mask_scores, stroke_ids, nn_distance=d,
                                            smooth_targets=cfg.get("smooth_target_stroke_masks", False), **kwargs)
-        return (cfg["weight_asymm_segment_chamfer"] * seg + conf
-                + cfg["weight_reverse_asymm_point_chamfer"] * pts
-                + cfg["weight_reverse_asymm_segment_chamfer"] * rev + masks)       # :660-664
+        return seg + conf + pts + rev + masks                                      # :660-664
 
     def get_asymm_v11_chamfer_with_stroke_masks(self, y_pred, y, pred_stroke_masks, mask_scores, seg_logits,
                                                 stroke_ids, traj_as_pc, **kwargs):
         cfg = self._cfg()
-        seg, conf, match, d = self._segment_term(y_pred, y, seg_logits)
-        pts = self.get_reverse_asymm_point_chamfer(y_pred, y, traj_as_pc)
+        seg, conf, match, d = self._segment_term(y_pred, y, seg_logits, _w=cfg["weight_asymm_segment_chamfer"])
+        pts = self.get_reverse_asymm_point_chamfer(y_pred, y, traj_as_pc, _w=cfg["weight_reverse_asymm_point_chamfer"])
         masks = self.get_stroke_masks_loss(match, pred_stroke_masks, mask_scores, stroke_ids, nn_distance=d,
                                            smooth_targets=cfg.get("smooth_target_stroke_masks", False), **kwargs)
-        return (cfg["weight_asymm_segment_chamfer"] * seg + conf
-                + cfg["weight_reverse_asymm_point_chamfer"] * pts + masks)
+        return seg + conf + pts + masks
 
     def _no_extras(self):
         cfg = self._cfg()

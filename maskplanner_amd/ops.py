@@ -351,33 +351,33 @@ def knn(p1, p2, lengths1=None, lengths2=None, K=1):
 
 class _ChamferReduce(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, cham, lengths, point_mean, batch_mode, div):
+    def forward(ctx, cham, lengths, point_mean, batch_mode, div, scale):
         N, P = cham.shape
         out = torch.empty((N,) if batch_mode == 0 else (), dtype=torch.float32, device=cham.device)
         _run("chamfer_reduce", cham, _lib.load().mp_chamfer_reduce_f32, _p(cham), _p(lengths), N, P, int(point_mean), int(batch_mode),
-             float(div), _p(out))
+             float(div), float(scale), _p(out))
         ctx.save_for_backward(lengths)
-        ctx.meta = (N, P, int(point_mean), int(batch_mode), float(div))
+        ctx.meta = (N, P, int(point_mean), int(batch_mode), float(div), float(scale))
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
         (lengths,) = ctx.saved_tensors
-        N, P, point_mean, batch_mode, div = ctx.meta
+        N, P, point_mean, batch_mode, div, scale = ctx.meta
         grad_out = _f32(grad_out)
         grad = torch.empty((N, P), dtype=torch.float32, device=grad_out.device)
         _run("chamfer_reduce_bwd", grad_out, _lib.load().mp_chamfer_reduce_bwd_f32, _p(grad_out), _p(lengths), N, P, point_mean,
-             batch_mode, div, _p(grad))
-        return grad, None, None, None, None
+             batch_mode, div, scale, _p(grad))
+        return grad, None, None, None, None, None
 
 
-def chamfer_reduce(cham, lengths, point_reduction, batch_reduction):
+def chamfer_reduce(cham, lengths, point_reduction, batch_reduction, scale=1.0):
     """pytorch3d_chamfer.py:295-326 in one launch: cham [N,P] (rows beyond a cloud's length already zero) -> sum or mean over
-    the points (mean divides by lengths [N] i64), then None / sum / mean over the batch."""
+    the points (mean divides by lengths [N] i64), then None / sum / mean over the batch, times the constant `scale`."""
     _need_hip(cham, lengths)
     N = cham.shape[0]
     batch_mode = {None: 0, "sum": 1, "mean": 2}[batch_reduction]
-    return _ChamferReduce.apply(_f32(cham), _i64(lengths), point_reduction == "mean", batch_mode, float(N))
+    return _ChamferReduce.apply(_f32(cham), _i64(lengths), point_reduction == "mean", batch_mode, float(N), float(scale))
 
 
 class _PoseOutput(torch.autograd.Function):

@@ -406,9 +406,10 @@ def test_chamfer_reduce_matches_torch_algebra(ops, point, batch):
     cham = rng.uniform(0, 2, size=(N, P)).astype(np.float32)
     cham[np.arange(P)[None] >= lengths[:, None]] = 0.0            # what the kNN kernel leaves beyond a cloud's length
     c = dev(cham).requires_grad_(True)
-    out = ops.chamfer_reduce(c, dev(lengths), point, batch)
+    scale = 2.5 if point == "mean" else 1.0                        # constant factor folded into the kernel
+    out = ops.chamfer_reduce(c, dev(lengths), point, batch, scale)
     c64 = torch.from_numpy(cham).double().requires_grad_(True)
-    ref = c64.sum(1)
+    ref = c64.sum(1) * scale
     if point == "mean":
         ref = ref / torch.from_numpy(lengths)
     if batch is not None:
@@ -422,7 +423,7 @@ def test_chamfer_reduce_matches_torch_algebra(ops, point, batch):
     want = c64.grad.numpy().copy()
     want[np.arange(P)[None] >= lengths[:, None]] = 0.0            # no gradient into the padded rows
     np.testing.assert_allclose(c.grad.cpu().numpy(), want, rtol=2e-6, atol=1e-12)
-    out2 = ops.chamfer_reduce(dev(cham), dev(lengths), point, batch)
+    out2 = ops.chamfer_reduce(dev(cham), dev(lengths), point, batch, scale)
     assert torch.equal(out2, out.detach())                          # deterministic
 
 
