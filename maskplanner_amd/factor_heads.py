@@ -31,7 +31,9 @@ class _FactorLinear(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             B, O = g.shape
             I = weight.shape[1]
-            if g.is_cuda and B <= 32 and I % 4 == 0 and g.dtype == torch.float32 and weight.is_contiguous():
+            # the streaming kernel pays off on the wide heads (O ~ 6000-12000 rows of W); the 1024 x 1024 layers have too few
+            # row slabs to fill the chip and stay on rocBLAS
+            if g.is_cuda and B <= 32 and O >= 4096 and I % 4 == 0 and g.dtype == torch.float32 and weight.is_contiguous():
                 gx = torch.empty((B, I), dtype=torch.float32, device=g.device)   # one streaming pass over W
                 lib = _lib.load()
                 ws = torch.empty((lib.mp_linear_dx_skinny_workspace_bytes(B, O, I),), dtype=torch.uint8, device=g.device)

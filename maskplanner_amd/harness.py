@@ -25,10 +25,11 @@ class TrainStep:
         self.factor_opt = None
         dense = list(self.model.parameters())
         if factor_heads and fused:
-            # the three matrices that hold 97 % of the parameters: gradient kept as rank-B factors, Adam fused with its
-            # reconstruction (factor_heads.py); everything else goes through autograd + torch.optim.Adam as upstream
+            # the head matrices (99 % of the parameters, all fed by a [B, 1024] feature): gradient kept as rank-B factors, Adam
+            # fused with its reconstruction (factor_heads.py); everything else goes through autograd + torch.optim.Adam
             self.model.factor_store = {}
-            big = {n: p for n, p in self.model.named_parameters() if n in ("fc3.weight", "fc_normals.weight", "sm_fc3.weight")}
+            big = {n: p for n, p in self.model.named_parameters()
+                   if n in ("fc1.weight", "fc2.weight", "fc3.weight", "fc_normals.weight", "sm_fc1.weight", "sm_fc2.weight", "sm_fc3.weight")}
             self.factor_opt = FactorAdam(big, self.model.factor_store, lr=lr)
             dense = [p for p in dense if all(p is not q for q in big.values())]
         self.reducer = dp.BucketedGradAllReduce(dense)

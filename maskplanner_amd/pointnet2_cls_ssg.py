@@ -139,8 +139,9 @@ class PointNet2Regressor_StrokeMasks(_SSGEncoder):
             if mask_confidence_scores:
                 self.mask_conf_out = nn.Linear(h1, n_stroke_masks)
 
-    # set to a dict by a training harness that uses factor_heads.FactorAdam: the three big head matrices then keep
-    # their gradient as rank-B factors instead of materialising dW (default None: plain nn.Linear behaviour)
+    # set to a dict by a training harness that uses factor_heads.FactorAdam: the head matrices fed by a [B, 1024] feature
+    # (fc1/fc2/fc3/fc_normals and the sm_ twins) then keep their gradient as rank-B factors instead of materialising dW
+    # (default None: plain nn.Linear behaviour)
     factor_store = None
 
     def forward(self, xyz):
@@ -151,8 +152,8 @@ class PointNet2Regressor_StrokeMasks(_SSGEncoder):
         if fused:
             _tick(*([self.bn1, self.bn2] + ([self.sm_bn1, self.sm_bn2] if self.pred_stroke_masks else [])))
         act = _bn_relu if fused else (lambda t, bn: F.relu(bn(t)))
-        x = self.dropout(act(self.fc1(feat), self.bn1))
-        final = self.dropout(act(self.fc2(x), self.bn2))
+        x = self.dropout(act(factor_linear(feat, self.fc1, fs, "fc1.weight"), self.bn1))
+        final = self.dropout(act(factor_linear(x, self.fc2, fs, "fc2.weight"), self.bn2))
         x = factor_linear(final, self.fc3, fs, "fc3.weight")
 
         seg_conf = None
@@ -163,8 +164,8 @@ class PointNet2Regressor_StrokeMasks(_SSGEncoder):
 
         sm_out, mask_conf = None, None
         if self.pred_stroke_masks:
-            s1 = self.dropout(act(self.sm_fc1(feat), self.sm_bn1))
-            s2 = self.dropout(act(self.sm_fc2(s1), self.sm_bn2))
+            s1 = self.dropout(act(factor_linear(feat, self.sm_fc1, fs, "sm_fc1.weight"), self.sm_bn1))
+            s2 = self.dropout(act(factor_linear(s1, self.sm_fc2, fs, "sm_fc2.weight"), self.sm_bn2))
             sm_out = factor_linear(s2, self.sm_fc3, fs, "sm_fc3.weight").view(B, self.n_stroke_masks, -1)
             if self.mask_confidence_scores:
                 mask_conf = self.mask_conf_out(s2)

@@ -555,7 +555,7 @@ def test_factor_adam_matches_torch_adam():
 
 def test_train_step_with_and_without_factor_heads_agree():
     """Same model, same batch: the factor path must leave the SAME gradient information as plain autograd -- dense
-    parameters get identical gradients, the three head matrices get factors whose product is the dense gradient."""
+    parameters get identical gradients, the seven head matrices get factors whose product is the dense gradient."""
     from maskplanner_amd.harness import TrainStep
     a = TrainStep("cuboids", B=4, N=1024, hidden_size=(128, 128), factor_heads=True)
     b = TrainStep("cuboids", B=4, N=1024, hidden_size=(128, 128), factor_heads=False)
@@ -571,7 +571,7 @@ def test_train_step_with_and_without_factor_heads_agree():
     pa, pb = dict(a.model.named_parameters()), dict(b.model.named_parameters())
     gmax = max(float(p.grad.abs().mean()) for p in pb.values())
     for n in pa:
-        if n in ("fc3.weight", "fc_normals.weight", "sm_fc3.weight"):
+        if n in ("fc1.weight", "fc2.weight", "fc3.weight", "fc_normals.weight", "sm_fc1.weight", "sm_fc2.weight", "sm_fc3.weight"):
             assert pa[n].grad is None
             x, g = a.model.factor_store[n]
             dense = g.t() @ x
