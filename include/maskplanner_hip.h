@@ -139,12 +139,13 @@ int mp_padded_lengths_f32(const float* y, int64_t B, int64_t P2, int64_t D, int6
  * replaces: pytorch3d_chamfer.py:295-326 (cham.sum(1) [/ lengths], then .sum() [/ N]) and its autograd backward
  *   cham [N,P] f32 nearest-neighbour distances, rows >= lengths[n] already zero (mp_knn_f32 output).
  *   point_mean != 0: per-cloud sums are divided by lengths[n] (i64 [N], required then).
- *   batch_mode 0: out [N] per-cloud values; 1: out [1] = their sum; 2: out [1] = sum / div.  Every output is multiplied by
+ *   batch_mode 0: out [N] per-cloud values; 1: out [1] = their sum; 2: out [1] = sum / div (per_cloud [N]: scratch for modes
+ *   1 and 2).  Every output is multiplied by
  *   `scale` (the loss's constant factors, e.g. 100 * term weight, folded in instead of separate scalar launches).
  *   Deterministic (fixed summation order).  The backward writes grad_cham [N,P] (zero at p >= lengths[n] when lengths
  *   is given) from grad_out ([N] for batch_mode 0, [1] otherwise). */
 int mp_chamfer_reduce_f32(const float* cham, const int64_t* lengths, int64_t N, int64_t P, int point_mean, int batch_mode,
-                          double div, double scale, float* out, mp_stream_t stream);
+                          double div, double scale, float* per_cloud, float* out, mp_stream_t stream);
 int mp_chamfer_reduce_bwd_f32(const float* grad_out, const int64_t* lengths, int64_t N, int64_t P, int point_mean,
                               int batch_mode, double div, double scale, float* grad_cham, mp_stream_t stream);
 

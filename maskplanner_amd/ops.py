@@ -354,8 +354,9 @@ class _ChamferReduce(torch.autograd.Function):
     def forward(ctx, cham, lengths, point_mean, batch_mode, div, scale):
         N, P = cham.shape
         out = torch.empty((N,) if batch_mode == 0 else (), dtype=torch.float32, device=cham.device)
+        scratch = torch.empty((N,), dtype=torch.float32, device=cham.device) if batch_mode != 0 else None
         _run("chamfer_reduce", cham, _lib.load().mp_chamfer_reduce_f32, _p(cham), _p(lengths), N, P, int(point_mean), int(batch_mode),
-             float(div), float(scale), _p(out))
+             float(div), float(scale), _p(scratch), _p(out))
         ctx.save_for_backward(lengths)
         ctx.meta = (N, P, int(point_mean), int(batch_mode), float(div), float(scale))
         return out
