@@ -433,20 +433,29 @@ __global__ __launch_bounds__(256) void pool_select_kernel(PoolOut po, const floa
 // =================================================================================================================
 template <int MODE_DZ, int MODE_IN, int WAVES_M, int WAVES_N, int TM, int TN>
 __global__ __launch_bounds__(THREADS) void dw_gemm_kernel(PosOperand DZ, PosOperand IN, int P, int p_per_block,
-                                                          float* __restrict__ dW, int ci_base)
-{
+                                                          float* __restrict__ dW, int ci_base, int tail_ci)
+{   // tail_ci >= 0: the 4 input channels [tail_ci, tail_ci + 4) (132 = 128 + 4, 260 = 256 + 4: the centred xyz + pad of a
+    // grouped input) are handled by the workgroups of the LAST column tile with plain FMAs on the staged dZ tile, instead of
+    // a second launch that would stream dZ from HBM again for a 97 % empty MFMA tile
     constexpr int DBK = 32;                 // positions per K chunk
     constexpr int BM = WAVES_M * TM * 32;   // output channels (rows of dW)
     constexpr int BN = WAVES_N * TN * 32;   // input channels  (cols of dW)
     constexpr int PA = DBK * BM / 4 / THREADS;
     constexpr int PB = DBK * BN / 4 / THREADS;
     static_assert(WAVES_M * WAVES_N == 4 && PA >= 1 && PB >= 1, "tile");
+    static_assert(BM == 128, "the tail-column path maps 256 threads onto 128 rows x 2 column pairs");
     __shared__ float sA[2][DBK * BM];
     __shared__ float sB[2][DBK * BN];
+    __shared__ __attribute__((aligned(16))) float sT[2][DBK * 4];
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     const int wrow0 = (wave / WAVES_N) * TM * 32, wcol0 = (wave % WAVES_N) * TN * 32;
     const int co0 = blockIdx.y * BM, ci0 = ci_base + blockIdx.z * BN;
+    const bool do_tail = tail_ci >= 0 && blockIdx.z == gridDim.z - 1;
+    float tacc0 = 0.0f, tacc1 = 0.0f;
+    ChanConst kt;
+    Raw4<MODE_IN> rt;
+    if (do_tail) load_consts<MODE_IN>(IN, tail_ci, kt);
     const int p0 = blockIdx.x * p_per_block;
     const int p1 = min(P, p0 + p_per_block);
 
@@ -473,6 +482,7 @@ __global__ __launch_bounds__(THREADS) void dw_gemm_kernel(PosOperand DZ, PosOper
         for (int ps = 0; ps < PA; ++ps) raw_load<MODE_DZ>(DZ, p1, pk + ka0 + ps * KA_STEP, co0 + ca, ra[ps]);
 #pragma unroll
         for (int ps = 0; ps < PB; ++ps) raw_load<MODE_IN>(IN, p1, pk + kb0 + ps * KB_STEP, ci0 + cb, rb[ps]);
+        if (do_tail && tid < DBK) raw_load<MODE_IN>(IN, p1, pk + tid, tail_ci, rt);
     };
     auto sstore = [&](int buf) {
 #pragma unroll
@@ -481,6 +491,7 @@ __global__ __launch_bounds__(THREADS) void dw_gemm_kernel(PosOperand DZ, PosOper
 #pragma unroll
         for (int ps = 0; ps < PB; ++ps)
             *reinterpret_cast<float4*>(&sB[buf][(ps * THREADS + tid) * 4]) = finish<MODE_IN>(rb[ps], kb);
+        if (do_tail && tid < DBK) *reinterpret_cast<float4*>(&sT[buf][tid * 4]) = finish<MODE_IN>(rt, kt);
     };
     const int nchunks = (p1 - p0 + DBK - 1) / DBK;
     if (nchunks <= 0) return;
@@ -491,11 +502,28 @@ __global__ __launch_bounds__(THREADS) void dw_gemm_kernel(PosOperand DZ, PosOper
         const int cur = kc & 1;
         if (kc + 1 < nchunks) gload(p0 + (kc + 1) * DBK);
         mma_chunk<true, true, BM, BN, TM, TN, DBK>(sA[cur], sB[cur], wrow0, wcol0, acc);
+        if (do_tail) {   // thread = (output channel tid & 127, column pair tid >> 7)
+            const float* a = sA[cur] + (tid & (BM - 1));
+            const float* t = sT[cur] + 2 * (tid >> 7);
+#pragma unroll
+            for (int k = 0; k < DBK; ++k) {
+                const float av = a[k * BM];
+                tacc0 = __builtin_fmaf(av, t[k * 4], tacc0);
+                tacc1 = __builtin_fmaf(av, t[k * 4 + 1], tacc1);
+            }
+        }
         if (kc + 1 < nchunks) sstore(cur ^ 1);
         __syncthreads();
     }
     const int l31 = lane & 31;
     const int Co = DZ.C, Ci = IN.C;
+    if (do_tail) {
+        const int row = co0 + (tid & (BM - 1)), col = tail_ci + 2 * (tid >> 7);
+        if (row < Co) {
+            if (col < Ci) atomicAdd(dW + (size_t)((unsigned)row * (unsigned)Ci + (unsigned)col), tacc0);
+            if (col + 1 < Ci) atomicAdd(dW + (size_t)((unsigned)row * (unsigned)Ci + (unsigned)(col + 1)), tacc1);
+        }
+    }
 #pragma unroll
     for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
@@ -528,28 +556,29 @@ int launch_dw(const PosOperand& DZ, const PosOperand& IN, int64_t P64, float* dW
     // input-channel tiling: 128-wide tiles, a narrow remainder (132 = 128 + 4, 260 = 2*128 + 4) gets 32-wide tiles so
     // that it does not pay for a whole 128-column MFMA tile of zeros
     const int main_ci = (Ci > 128 && Ci % 128 != 0 && Ci % 128 <= 32) ? (Ci / 128) * 128 : Ci;
+    const int tail_ci = (main_ci < Ci && Ci - main_ci == 4) ? main_ci : -1;   // 4 leftover columns ride along (see the kernel)
     char tag[96];
     auto work = [&](int cols, double& flops, double& bytes) {
         flops = 2.0 * (double)P * Co * cols;
         bytes = 4.0 * ((MODE_DZ == SRC_DZ ? 2.0 : 1.0) * (double)P * Co + (double)P * cols + (double)Co * cols);
     };
     double flops, bytes;
-    work(main_ci, flops, bytes);
+    work(tail_ci >= 0 ? Ci : main_ci, flops, bytes);
     if (main_ci <= 32) {
         snprintf(tag, sizeof tag, "dw_gemm_kernel<%d, %d, 4, 1, 1, 1>", MODE_DZ, MODE_IN);
-        MP_LAUNCH(tag, flops, bytes, (dw_gemm_kernel<MODE_DZ, MODE_IN, 4, 1, 1, 1>), dim3(gx, gy, (main_ci + 31) / 32), dim3(THREADS), 0, stream, DZ, IN, P, ppb, dW, 0);
+        MP_LAUNCH(tag, flops, bytes, (dw_gemm_kernel<MODE_DZ, MODE_IN, 4, 1, 1, 1>), dim3(gx, gy, (main_ci + 31) / 32), dim3(THREADS), 0, stream, DZ, IN, P, ppb, dW, 0, tail_ci);
     } else if (main_ci <= 64) {
         snprintf(tag, sizeof tag, "dw_gemm_kernel<%d, %d, 4, 1, 1, 2>", MODE_DZ, MODE_IN);
-        MP_LAUNCH(tag, flops, bytes, (dw_gemm_kernel<MODE_DZ, MODE_IN, 4, 1, 1, 2>), dim3(gx, gy, (main_ci + 63) / 64), dim3(THREADS), 0, stream, DZ, IN, P, ppb, dW, 0);
+        MP_LAUNCH(tag, flops, bytes, (dw_gemm_kernel<MODE_DZ, MODE_IN, 4, 1, 1, 2>), dim3(gx, gy, (main_ci + 63) / 64), dim3(THREADS), 0, stream, DZ, IN, P, ppb, dW, 0, tail_ci);
     } else {
         snprintf(tag, sizeof tag, "dw_gemm_kernel<%d, %d, 2, 2, 2, 2>", MODE_DZ, MODE_IN);
-        MP_LAUNCH(tag, flops, bytes, (dw_gemm_kernel<MODE_DZ, MODE_IN, 2, 2, 2, 2>), dim3(gx, gy, (main_ci + 127) / 128), dim3(THREADS), 0, stream, DZ, IN, P, ppb, dW, 0);
+        MP_LAUNCH(tag, flops, bytes, (dw_gemm_kernel<MODE_DZ, MODE_IN, 2, 2, 2, 2>), dim3(gx, gy, (main_ci + 127) / 128), dim3(THREADS), 0, stream, DZ, IN, P, ppb, dW, 0, tail_ci);
     }
     MP_CHECK_LAUNCH();
-    if (main_ci < Ci) {
+    if (main_ci < Ci && tail_ci < 0) {
         work(Ci - main_ci, flops, bytes);
         snprintf(tag, sizeof tag, "dw_gemm_kernel<%d, %d, 4, 1, 1, 1>", MODE_DZ, MODE_IN);
-        MP_LAUNCH(tag, flops, bytes, (dw_gemm_kernel<MODE_DZ, MODE_IN, 4, 1, 1, 1>), dim3(gx, gy, (Ci - main_ci + 31) / 32), dim3(THREADS), 0, stream, DZ, IN, P, ppb, dW, main_ci);
+        MP_LAUNCH(tag, flops, bytes, (dw_gemm_kernel<MODE_DZ, MODE_IN, 4, 1, 1, 1>), dim3(gx, gy, (Ci - main_ci + 31) / 32), dim3(THREADS), 0, stream, DZ, IN, P, ppb, dW, main_ci, -1);
     }
     MP_CHECK_LAUNCH();
     return MP_OK;
