@@ -258,10 +258,11 @@ int mp_sa_mlp_bwd_f32(const float* x0, int64_t P, int64_t K, int n_layers, const
  *   the dW GEMM of autograd (models/pointnet2_cls_ssg.py:311,336,327 fc3 / fc_normals / sm_fc3) + the Adam update of
  *   torch.optim.Adam (train_maskplanner.py:159, defaults: no amsgrad / weight decay).  dW is never materialised; under
  *   data parallelism the factors (x, g) are gathered instead of all-reducing dW (grad_scale = 1/world).
- *   param / exp_avg / exp_avg_sq [O, I] updated in place; step = 1-based update count. */
+ *   param / exp_avg / exp_avg_sq [O, I] updated in place; step = 1-based update count, or -- for launches recorded into a
+ *   hipGraph, where a host-side count would be frozen -- step_dev: device pointer to the count as one f32 (step ignored). */
 int mp_adam_lowrank_f32(float* param, float* exp_avg, float* exp_avg_sq, const float* x, const float* g, int64_t Bg,
                         int64_t O, int64_t I, double grad_scale, double lr, double beta1, double beta2, double eps,
-                        int64_t step, mp_stream_t stream);
+                        int64_t step, const float* step_dev, mp_stream_t stream);
 
 /* input gradient of the same layers: grad_x [B, I] = g [B, O] * W [O, I] for B <= 32 (one streaming read of W; the
  * library GEMM rocBLAS selects for this skinny shape reaches ~0.6 TB/s).  I % 4 == 0.  grad_x is overwritten. */

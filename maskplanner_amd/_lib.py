@@ -67,7 +67,7 @@ SIGNATURES = {
     "mp_knn_bwd_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _int, _vp]),
     "mp_padded_lengths_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _vp]),
     "mp_mask_match_f32": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "mp_adam_lowrank_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _dbl, _dbl, _dbl, _dbl, _dbl, _i64, _vp]),
+    "mp_adam_lowrank_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _dbl, _dbl, _dbl, _dbl, _dbl, _i64, _vp, _vp]),
     "mp_linear_dx_skinny_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "mp_linear_dx_skinny_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _sz, _vp]),
     "mp_profiler_enable": (_int, [_int]),

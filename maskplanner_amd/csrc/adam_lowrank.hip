@@ -22,8 +22,14 @@ __global__ __launch_bounds__(256) void adam_lowrank_kernel(float* __restrict__ p
                                                            float* __restrict__ v, const float* __restrict__ x,
                                                            const float* __restrict__ g, int Bg, int O, int I,
                                                            float gscale, float lr_c1, float beta1, float beta2,
-                                                           float inv_sqrt_c2, float eps)
+                                                           float inv_sqrt_c2, float eps, const float* __restrict__ step_dev,
+                                                           float lr)
 {
+    if (step_dev) {   // graph-capturable form: the step count lives on the device, bias corrections are formed here (fp64)
+        const double st = (double)step_dev[0];
+        lr_c1 = (float)((double)lr / (1.0 - pow((double)beta1, st)));
+        inv_sqrt_c2 = (float)(1.0 / sqrt(1.0 - pow((double)beta2, st)));
+    }
     __shared__ __attribute__((aligned(16))) float sg[AL_BC][AL_TO];
     __shared__ __attribute__((aligned(16))) float sx[AL_BC][AL_TI];
     const int tid = threadIdx.x;
@@ -180,16 +186,18 @@ __global__ __launch_bounds__(64) void sum_partials_kernel(const float* __restric
 
 extern "C" int mp_adam_lowrank_f32(float* param, float* exp_avg, float* exp_avg_sq, const float* x, const float* g,
                                    int64_t Bg, int64_t O, int64_t I, double grad_scale, double lr, double beta1,
-                                   double beta2, double eps, int64_t step, mp_stream_t stream_)
+                                   double beta2, double eps, int64_t step, const float* step_dev, mp_stream_t stream_)
 {
-    if (Bg < 0 || O < 0 || I < 0 || step <= 0) return MP_EINVAL;
+    if (Bg < 0 || O < 0 || I < 0 || (step <= 0 && !step_dev)) return MP_EINVAL;
     if (O == 0 || I == 0) return MP_OK;
     if (!param || !exp_avg || !exp_avg_sq || (Bg > 0 && (!x || !g))) return MP_EINVAL;
-    const double c1 = 1.0 - pow(beta1, (double)step), c2 = 1.0 - pow(beta2, (double)step);
+    const double sh = step > 0 ? (double)step : 1.0;   // placeholders when the device-side count is used
+    const double c1 = 1.0 - pow(beta1, sh), c2 = 1.0 - pow(beta2, sh);
     const dim3 grid((unsigned)((I + AL_TI - 1) / AL_TI), (unsigned)((O + AL_TO - 1) / AL_TO));
     MP_LAUNCH("adam_lowrank_kernel", 2.0 * (double)Bg * O * I, 24.0 * (double)O * I + 4.0 * Bg * (double)(O + I),
               adam_lowrank_kernel, grid, dim3(256), 0, mp_stream(stream_), param, exp_avg, exp_avg_sq, x, g, (int)Bg, (int)O,
-              (int)I, (float)grad_scale, (float)(lr / c1), (float)beta1, (float)beta2, (float)(1.0 / sqrt(c2)), (float)eps);
+              (int)I, (float)grad_scale, (float)(lr / c1), (float)beta1, (float)beta2, (float)(1.0 / sqrt(c2)), (float)eps, step_dev,
+              (float)lr);
     MP_CHECK_LAUNCH();
     return MP_OK;
 }

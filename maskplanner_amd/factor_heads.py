@@ -56,11 +56,18 @@ class FactorAdam:
     """Adam (torch defaults: betas (0.9, 0.999), eps 1e-8, no weight decay / amsgrad) for weights whose gradient is kept
     as factors.  step() consumes `store[key] = (x [B,I], g [B,O])` for every registered weight."""
 
-    def __init__(self, named_weights, store, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, process_group=None):
+    def __init__(self, named_weights, store, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, process_group=None, capturable=False):
         self.weights = dict(named_weights)       # key -> nn.Parameter [O, I]
         self.store = store
         self.lr, self.betas, self.eps = lr, betas, eps
         self.group = process_group
+        # capturable: the update count lives in ONE device scalar shared by all weights (they always step together), advanced
+        # by a device op, so that a step recorded into a hipGraph keeps counting when it is replayed
+        self.capturable = bool(capturable)
+        self.step_dev = None
+        if self.capturable and self.weights:
+            dev = next(iter(self.weights.values())).device
+            self.step_dev = torch.zeros((), dtype=torch.float32, device=dev)
         self.state = {k: dict(step=0, exp_avg=torch.zeros_like(w), exp_avg_sq=torch.zeros_like(w))
                       for k, w in self.weights.items()}
 
@@ -93,11 +100,13 @@ class FactorAdam:
             xs = [xmap[x.data_ptr()] for x in xs]
             gs = gathered[len(uniq):]
         lib = _lib.load()
+        if self.step_dev is not None:
+            self.step_dev.add_(1.0)
         for k, x, g in zip(keys, xs, gs):
             w, st = self.weights[k], self.state[k]
             st["step"] += 1
             O, I = w.shape
             ops._run("adam_lowrank", w, lib.mp_adam_lowrank_f32, w.data_ptr(), st["exp_avg"].data_ptr(),
                      st["exp_avg_sq"].data_ptr(), x.data_ptr(), g.data_ptr(), x.shape[0], O, I, 1.0 / world, self.lr,
-                     self.betas[0], self.betas[1], self.eps, st["step"])
+                     self.betas[0], self.betas[1], self.eps, st["step"], None if self.step_dev is None else self.step_dev.data_ptr())
             del self.store[k]

@@ -3,6 +3,8 @@
 Used by bench.py, __graft_entry__.smoke() and the full-size tests; the reference's dataset is not public, so
 batches come from maskplanner_amd.synthetic with the collated-tensor contract of the reference.
 """
+import os
+
 import torch
 
 from . import dp, synthetic
@@ -14,7 +16,7 @@ from .pointnet2_cls_ssg import maskplanner_model
 
 class TrainStep:
     def __init__(self, category="cuboids", B=32, N=5120, device="cuda", seed=1235, hidden_size=(1024, 1024), lr=1e-3,
-                 dist_points="cuboid", rank=0, loss_overrides=None, prefetch_sampling=False, factor_heads=True):
+                 dist_points="cuboid", rank=0, loss_overrides=None, prefetch_sampling=False, factor_heads=True, graph=None):
         self.cat = synthetic.CATEGORIES[category] if isinstance(category, str) else category
         self.device = torch.device(device)
         torch.manual_seed(seed)  # identical initial weights on every rank
@@ -22,6 +24,13 @@ class TrainStep:
         self.cfg = maskplanner_loss_config(**(loss_overrides or {}))
         self.loss_handler = LossHandler(["asymm_v6_chamfer_with_stroke_masks"], self.cfg)
         fused = self.device.type == "cuda"
+        # hipGraph replay of the whole step (single-process runs): the step is ~190 launches and the Python side needs
+        # ~3.5 ms to enqueue them against ~4.6 ms of device time -- on a busy host the enqueue becomes the bottleneck.
+        # The step is recorded once after a few eager steps and replayed; any failure to record falls back to eager.
+        if graph is None:
+            graph = os.environ.get("MASKPLANNER_GRAPH", "1") != "0"
+        self.use_graph = bool(graph) and fused and not dp.exchanging() and not prefetch_sampling
+        self._graph, self._graph_loss, self._eager_steps, self._side = None, None, 0, None
         self.factor_opt = None
         dense = list(self.model.parameters())
         if factor_heads and fused:
@@ -30,10 +39,10 @@ class TrainStep:
             self.model.factor_store = {}
             big = {n: p for n, p in self.model.named_parameters()
                    if n in ("fc1.weight", "fc2.weight", "fc3.weight", "fc_normals.weight", "sm_fc1.weight", "sm_fc2.weight", "sm_fc3.weight")}
-            self.factor_opt = FactorAdam(big, self.model.factor_store, lr=lr)
+            self.factor_opt = FactorAdam(big, self.model.factor_store, lr=lr, capturable=self.use_graph)
             dense = [p for p in dense if all(p is not q for q in big.values())]
         self.reducer = dp.BucketedGradAllReduce(dense)
-        self.opt = torch.optim.Adam(dense, lr=lr, fused=fused)  # train_maskplanner.py:159
+        self.opt = torch.optim.Adam(dense, lr=lr, fused=fused, capturable=self.use_graph)  # train_maskplanner.py:159
         b = synthetic.make_batch(seed + 1000 * rank, B, N, self.cat.name, dist_points)  # a different shard per rank
         self.batch = {k: (v.to(self.device) if torch.is_tensor(v) else [t.to(self.device) for t in v])
                       for k, v in b.items()}
@@ -53,8 +62,52 @@ class TrainStep:
                                          mask_scores=mask_conf, seg_logits=seg_conf, stroke_ids=self.batch["stroke_ids"],
                                          traj_as_pc=self.batch["traj_as_pc"])
 
+    GRAPH_AFTER = 3   # eager steps before recording (allocator warm, lazy kernel attributes set, optimizer state created)
+
     def step(self):
         """One optimisation step; returns the (device) loss tensor without synchronising."""
+        if self._graph is not None:
+            self._graph.replay()
+            return self._graph_loss
+        if not self.use_graph:
+            return self._eager_step()
+        if self._eager_steps < self.GRAPH_AFTER:
+            # torch's recipe for capturing a training step: the iterations before the capture run on a side stream, so that
+            # the autograd accumulator nodes and the caching allocator's blocks belong to a non-default stream
+            self._eager_steps += 1
+            if self._side is None:
+                self._side = torch.cuda.Stream()
+            self._side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self._side):
+                loss = self._eager_step()
+            torch.cuda.current_stream().wait_stream(self._side)
+            return loss
+        self._record()
+        return self._graph_loss if self._graph is not None else self._eager_step()
+
+    def _record(self):
+        """Record one full step into a hipGraph (torch.cuda.graph: private memory pool, graph-safe Philox offsets for the
+        dropout layers).  The batch tensors, parameters and optimizer state are the static inputs.  Capture only records,
+        so the graph is replayed once right away: this call performs exactly one optimisation step."""
+        try:
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                loss = self._eager_step()
+            self._graph, self._graph_loss = g, loss
+            g.replay()
+        except Exception as exc:   # stay correct: eager from here on
+            import warnings
+            warnings.warn(f"hipGraph capture of the training step failed ({type(exc).__name__}: {exc}); running eagerly")
+            self._graph, self.use_graph = None, False
+            torch.cuda.synchronize()
+
+    def eager_step(self):
+        """One step launched kernel by kernel even when a recorded graph exists (bench.py's per-kernel timing hooks live in
+        the launch path).  Shares parameters and optimizer state with the graph, so the two can be interleaved."""
+        return self._eager_step()
+
+    def _eager_step(self):
         self.reducer.zero_grad()
         loss = self.forward_loss()
         loss.backward()
@@ -67,4 +120,4 @@ class TrainStep:
         self.opt.step()
         if self.factor_opt is not None:
             self.factor_opt.step()
-        return loss
+        return loss.detach()   # callers never keep the autograd graph (and its accumulator nodes) alive across steps

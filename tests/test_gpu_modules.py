@@ -605,3 +605,30 @@ def test_rccl_single_rank_collectives_do_not_change_the_step():
     assert np.isfinite(f).all() and f[0] == p[0], res           # same initial loss; later steps differ by atomics noise only
     assert np.abs(f - p).max() <= 2e-2 * np.abs(p).max(), res
     assert f[-1] < f[0]
+
+
+def test_graph_replay_of_the_training_step_tracks_the_eager_path():
+    """harness.TrainStep records the whole step (forward + loss + backward + both optimizers) into a hipGraph after three
+    eager steps.  The recorded step must be statistically indistinguishable from launching kernel by kernel: two trainers
+    with identical seeds, one replaying and one eager, end as close to each other as two eager trainers do (the dW GEMMs
+    use fp32 atomics and Adam turns last-bit gradient noise into lr-sized steps, so exact equality is not available)."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("graph_check", os.path.join(root, "tools", "graph_check.py"))
+    gc = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gc)
+    base_g, base_p = gc.pair(record=False)
+    rep_g, rep_p = gc.pair(record=True)
+    assert rep_p <= 3.0 * base_p + 1e-3, (rep_p, base_p)
+    assert rep_g <= 3.0 * base_g + 1e-3, (rep_g, base_g)
+    from maskplanner_amd.harness import TrainStep
+    ts = TrainStep("cuboids", B=4, N=1024, seed=99, graph=True)
+    losses = [float(ts.step()) for _ in range(12)]
+    assert ts._graph is not None, "the step was not recorded"
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0]
+    before = float(ts.step())
+    eager = float(ts.eager_step())            # interleaving eager steps with replays shares all state
+    after = float(ts.step())
+    assert np.isfinite([before, eager, after]).all() and after < losses[0]
+
