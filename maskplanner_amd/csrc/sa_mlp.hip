@@ -537,6 +537,164 @@ __global__ __launch_bounds__(THREADS) void dw_gemm_kernel(PosOperand DZ, PosOper
         }
 }
 
+// =================================================================================================================
+// Kernel 4: dX and dW of one layer in ONE pass over dZ_l, for layers whose channels fit a single tile (CO in {64, 128}
+// outputs, 64 inputs: the HBM-bound layers of the first set-abstraction level).  Separately, dX streams (Z_l, G_l), reads
+// Z_{l-1} and writes G_{l-1}; dW streams (Z_l, G_l, Z_{l-1}) again: 7 tensor passes.  Here a workgroup walks 1024 positions
+// in chunks of 32: the dZ chunk [32][CO] and the activated input chunk [32][64] are staged once and feed both
+//   dW[CO,64]  += dZ^T * act(Z_{l-1})          (K = positions; accumulated in registers, atomics at the end) and
+//   G_{l-1}[32,64] = dZ * W_l                   (K = CO; W_l resident in LDS), whose epilogue also forms the
+// BatchNorm-backward sums of layer l-1 from the raw Z_{l-1} chunk kept beside the activated one: 4 tensor passes.
+// The dX tile of a chunk is computed as eight 16x16 MFMA tiles, two per wave.
+// =================================================================================================================
+template <int MODE_DZ, int CO>
+__global__ __launch_bounds__(THREADS) void bwd_fused_kernel(PosOperand DZ, PosOperand IN, int P, int p_per_block,
+                                                            const float* __restrict__ W, float* __restrict__ dW,
+                                                            float* __restrict__ G, float* __restrict__ partials)
+{
+    constexpr int CI = 64, DBK = 32;
+    constexpr int LDA = CO + 1;                 // odd: conflict-free both as [k][row] (dW) and as [row][k] (dX)
+    constexpr int TMW = CO / 64;                // 32-row dW tiles per wave (waves 2 x 2)
+    constexpr int PA = DBK * CO / 4 / THREADS, PB = DBK * CI / 4 / THREADS;
+    static_assert(CO == 64 || CO == 128, "tile");
+    __shared__ float sA[2][DBK * LDA];
+    __shared__ __attribute__((aligned(16))) float sB[2][DBK * CI];
+    __shared__ __attribute__((aligned(16))) float sZ[2][DBK * CI];
+    __shared__ __attribute__((aligned(16))) float sW[CO * CI];
+    __shared__ float red[2][2][CI];
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int wrow0 = (wave >> 1) * TMW * 32, wcol0 = (wave & 1) * 32;
+    const int p0 = blockIdx.x * p_per_block;
+    const int p1 = min(P, p0 + p_per_block);
+    const int nchunks = (p1 - p0 + DBK - 1) / DBK;
+    if (nchunks <= 0) return;
+
+    for (int e = tid; e < CO * CI / 4; e += THREADS) reinterpret_cast<float4*>(sW)[e] = ld4(W + 4 * e);
+
+    f32x16 accW[TMW];
+#pragma unroll
+    for (int mi = 0; mi < TMW; ++mi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accW[mi][r] = 0.0f;
+
+    // every thread keeps the same channels for the whole kernel
+    const int ca = (tid % (CO / 4)) * 4, cb = (tid % (CI / 4)) * 4;
+    const int ka0 = tid / (CO / 4), kb0 = tid / (CI / 4);
+    constexpr int KA_STEP = THREADS / (CO / 4), KB_STEP = THREADS / (CI / 4);
+    ChanConst ka, kb;
+    load_consts<MODE_DZ>(DZ, ca, ka);
+    load_consts<SRC_ACT>(IN, cb, kb);
+    Raw4<MODE_DZ> ra[PA];
+    Raw4<SRC_ACT> rb[PB];
+    auto gload = [&](int pk) {
+#pragma unroll
+        for (int ps = 0; ps < PA; ++ps) raw_load<MODE_DZ>(DZ, p1, pk + ka0 + ps * KA_STEP, ca, ra[ps]);
+#pragma unroll
+        for (int ps = 0; ps < PB; ++ps) raw_load<SRC_ACT>(IN, p1, pk + kb0 + ps * KB_STEP, cb, rb[ps]);
+    };
+    auto sstore = [&](int buf) {
+#pragma unroll
+        for (int ps = 0; ps < PA; ++ps) {
+            const float4 v = finish<MODE_DZ>(ra[ps], ka);
+            float* d = &sA[buf][(ka0 + ps * KA_STEP) * LDA + ca];
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+#pragma unroll
+        for (int ps = 0; ps < PB; ++ps) {
+            const int o = (kb0 + ps * KB_STEP) * CI + cb;
+            *reinterpret_cast<float4*>(&sB[buf][o]) = finish<SRC_ACT>(rb[ps], kb);
+            *reinterpret_cast<float4*>(&sZ[buf][o]) = rb[ps].ok ? rb[ps].z : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+
+    const int l31 = lane & 31;
+    float spx[2], tpx[2], s1x[2] = {0.0f, 0.0f}, s2x[2] = {0.0f, 0.0f};   // this lane's two G columns
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int col = (wave & 1) * 32 + 16 * h + (lane & 15);
+        spx[h] = IN.s[col];
+        tpx[h] = IN.t[col];
+    }
+
+    gload(p0);
+    sstore(0);
+    __syncthreads();
+    for (int kc = 0; kc < nchunks; ++kc) {
+        const int cur = kc & 1;
+        if (kc + 1 < nchunks) gload(p0 + (kc + 1) * DBK);
+        {   // dW += dZ^T * act(Z_{l-1})
+            f32x16 acc2[TMW][1];
+#pragma unroll
+            for (int mi = 0; mi < TMW; ++mi) acc2[mi][0] = accW[mi];
+            mma_chunk<true, true, LDA, CI, TMW, 1, DBK>(sA[cur], sB[cur], wrow0, wcol0, acc2);
+#pragma unroll
+            for (int mi = 0; mi < TMW; ++mi) accW[mi] = acc2[mi][0];
+        }
+        {   // G_{l-1} chunk [32 x 64] = dZ [32 x CO] * W_l [CO x 64] as eight 16x16 tiles, two per wave (v_mfma_f32_16x16x4_f32:
+            // with 32x32 tiles only two waves would have work).  Wave w: rows 16*(w>>1).., columns 32*(w&1) + {0..15, 16..31}.
+            typedef float f32x4 __attribute__((ext_vector_type(4)));
+            f32x4 ax0 = {0.f, 0.f, 0.f, 0.f}, ax1 = {0.f, 0.f, 0.f, 0.f};
+            const int l15 = lane & 15, kq = lane >> 4;
+            const float* arow = sA[cur] + ((wave >> 1) * 16 + l15) * LDA + kq;      // A[row][k], k = 4*step + kq
+            const float* bcol = sW + kq * CI + (wave & 1) * 32 + l15;              // B[k][col]
+#pragma unroll
+            for (int k4 = 0; k4 < CO; k4 += 4) {
+                const float av = arow[k4];
+                const float b0 = bcol[k4 * CI], b1 = bcol[k4 * CI + 16];
+                ax0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b0, ax0, 0, 0, 0);
+                ax1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b1, ax1, 0, 0, 0);
+            }
+            const int pk = p0 + kc * DBK;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = (wave >> 1) * 16 + 4 * kq + i;          // accumulator i of this lane: row 4*(lane/16) + i of the tile
+                const int pp = pk + row;
+                if (pp < p1) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int col = (wave & 1) * 32 + 16 * h + l15;
+                        const float v = h == 0 ? ax0[i] : ax1[i];
+                        const float zp = sZ[cur][row * CI + col];
+                        const float dy = (zp * spx[h] + tpx[h] > 0.0f) ? v : 0.0f;
+                        s1x[h] += dy;
+                        s2x[h] += dy * zp;
+                        G[(size_t)((unsigned)pp * (unsigned)CI + (unsigned)col)] = v;
+                    }
+                }
+            }
+        }
+        if (kc + 1 < nchunks) sstore(cur ^ 1);
+        __syncthreads();
+    }
+    // BatchNorm-backward partial sums of layer l-1: the four 16-lane row groups of a wave, then the two waves of a column half
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        s1x[h] += __shfl_xor(s1x[h], 16, 64); s1x[h] += __shfl_xor(s1x[h], 32, 64);
+        s2x[h] += __shfl_xor(s2x[h], 16, 64); s2x[h] += __shfl_xor(s2x[h], 32, 64);
+        if (lane < 16) {
+            const int col = (wave & 1) * 32 + 16 * h + lane;
+            red[wave >> 1][0][col] = s1x[h];
+            red[wave >> 1][1][col] = s2x[h];
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < 2 * CI; e += THREADS) {
+        const int st = e / CI, c = e - st * CI;
+        partials[((size_t)blockIdx.x * 2 + st) * CI + c] = red[0][st][c] + red[1][st][c];
+    }
+    // dW
+#pragma unroll
+    for (int mi = 0; mi < TMW; ++mi) {
+        const int col = wcol0 + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = wrow0 + mi * 32 + acc_row_in_tile(r);
+            atomicAdd(dW + (size_t)(row * CI + col), accW[mi][r]);
+        }
+    }
+}
+
 template <int MODE_DZ, int MODE_IN>
 int launch_dw(const PosOperand& DZ, const PosOperand& IN, int64_t P64, float* dW, hipStream_t stream)
 {
@@ -789,6 +947,13 @@ int launch_pos_gemm(const PosOperand& A, int64_t P, const float* W, int N, int K
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// MP_FUSED_BWD=0 keeps the separate dX / dW kernels for the single-tile layers (A/B timing)
+inline bool fused_bwd_enabled()
+{
+    static const bool on = !(getenv("MP_FUSED_BWD") && atoi(getenv("MP_FUSED_BWD")) == 0);
+    return on;
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -975,6 +1140,29 @@ extern "C" int mp_sa_mlp_bwd_f32(const float* x0, int64_t P, int64_t K, int n_la
 
         // dW_l = dZ_l^T * act(Z_{l-1})
         if (hipMemsetAsync(grads[l].d_weight, 0, sizeof(float) * (size_t)Co * Ci, stream) != hipSuccess) return MP_ELAUNCH;
+        if (l > 0 && Ci == 64 && Co == 64 && fused_bwd_enabled()) {
+            // single-tile layer: dX, dW and the BatchNorm-backward sums of layer l-1 in one pass over dZ_l (bwd_fused_kernel)
+            const mp_mlp_layer_t& Pv = layers[l - 1];
+            float* Gn = gbuf[l & 1];
+            const int ppb = 1024;
+            const unsigned gx = (unsigned)((P + ppb - 1) / ppb);
+            if ((size_t)gx > nblk_max) return MP_EUNSUPPORTED;
+            const double fl = 4.0 * (double)P * Co * Ci;
+            const double by = 4.0 * ((pooled ? 1.0 : 2.0) * (double)P * Co + 2.0 * (double)P * Ci);
+            if (pooled)
+                MP_LAUNCH("bwd_fused_kernel<3, 64>", fl, by, (bwd_fused_kernel<SRC_DZ_POOLED, 64>), dim3(gx), dim3(THREADS), 0, stream, DZ, IN, (int)P,
+                          ppb, Ly.weight, grads[l].d_weight, Gn, partials);
+            else
+                MP_LAUNCH("bwd_fused_kernel<2, 64>", fl, by, (bwd_fused_kernel<SRC_DZ, 64>), dim3(gx), dim3(THREADS), 0, stream, DZ, IN, (int)P,
+                          ppb, Ly.weight, grads[l].d_weight, Gn, partials);
+            MP_CHECK_LAUNCH();
+            hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((Ci + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_SL), 0, stream, partials, (int)gx, Ci,
+                               1.0 / (double)P, training, Pv.gamma, Pv.mean, Pv.rstd, grads[l - 1].d_gamma,
+                               grads[l - 1].d_beta, grads[l - 1].d_bias, cbuf[0], cbuf[1], cbuf[2]);
+            MP_CHECK_LAUNCH();
+            G_cur = Gn;
+            continue;
+        }
         {
             int rc;
             if (pooled) rc = (l == 0) ? launch_dw<SRC_DZ_POOLED, SRC_ID>(DZ, IN, P, grads[l].d_weight, stream)
