@@ -552,7 +552,9 @@ __global__ __launch_bounds__(THREADS) void bwd_fused_kernel(PosOperand DZ, PosOp
                                                             const float* __restrict__ W, float* __restrict__ dW,
                                                             float* __restrict__ G, float* __restrict__ partials)
 {
-    constexpr int CI = 64, DBK = 32;
+    constexpr int CI = 64;
+    constexpr int DBK = CO == 64 ? 32 : 16;     // positions per chunk: sized so that two workgroups fit a CU's LDS
+    constexpr int HT = DBK / 16;                // 16x16 dX tiles per wave and chunk (the chunk's dX tile is [DBK x 64])
     constexpr int LDA = CO + 1;                 // odd: conflict-free both as [k][row] (dW) and as [row][k] (dX)
     constexpr int TMW = CO / 64;                // 32-row dW tiles per wave (waves 2 x 2)
     constexpr int PA = DBK * CO / 4 / THREADS, PB = DBK * CI / 4 / THREADS;
@@ -609,12 +611,17 @@ __global__ __launch_bounds__(THREADS) void bwd_fused_kernel(PosOperand DZ, PosOp
     };
 
     const int l31 = lane & 31;
-    float spx[2], tpx[2], s1x[2] = {0.0f, 0.0f}, s2x[2] = {0.0f, 0.0f};   // this lane's two G columns
+    // dX tiles of this wave: HT == 2: rows 16*(wave>>1).., columns 32*(wave&1) + {0..15, 16..31}; HT == 1: rows 0..15, columns 16*wave..
+    const int xrow0 = HT == 2 ? (wave >> 1) * 16 : 0;
+    const int xcol0 = HT == 2 ? (wave & 1) * 32 : wave * 16;
+    float spx[HT], tpx[HT], s1x[HT], s2x[HT];   // this lane's G columns
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int col = (wave & 1) * 32 + 16 * h + (lane & 15);
+    for (int h = 0; h < HT; ++h) {
+        const int col = xcol0 + 16 * h + (lane & 15);
         spx[h] = IN.s[col];
         tpx[h] = IN.t[col];
+        s1x[h] = 0.0f;
+        s2x[h] = 0.0f;
     }
 
     gload(p0);
@@ -631,30 +638,31 @@ __global__ __launch_bounds__(THREADS) void bwd_fused_kernel(PosOperand DZ, PosOp
 #pragma unroll
             for (int mi = 0; mi < TMW; ++mi) accW[mi] = acc2[mi][0];
         }
-        {   // G_{l-1} chunk [32 x 64] = dZ [32 x CO] * W_l [CO x 64] as eight 16x16 tiles, two per wave (v_mfma_f32_16x16x4_f32:
-            // with 32x32 tiles only two waves would have work).  Wave w: rows 16*(w>>1).., columns 32*(w&1) + {0..15, 16..31}.
+        {   // G_{l-1} chunk [DBK x 64] = dZ [DBK x CO] * W_l [CO x 64] as 16x16 tiles, HT per wave (v_mfma_f32_16x16x4_f32:
+            // with 32x32 tiles only one or two waves would have work)
             typedef float f32x4 __attribute__((ext_vector_type(4)));
-            f32x4 ax0 = {0.f, 0.f, 0.f, 0.f}, ax1 = {0.f, 0.f, 0.f, 0.f};
+            f32x4 ax[HT];
+#pragma unroll
+            for (int h = 0; h < HT; ++h) ax[h] = f32x4{0.f, 0.f, 0.f, 0.f};
             const int l15 = lane & 15, kq = lane >> 4;
-            const float* arow = sA[cur] + ((wave >> 1) * 16 + l15) * LDA + kq;      // A[row][k], k = 4*step + kq
-            const float* bcol = sW + kq * CI + (wave & 1) * 32 + l15;              // B[k][col]
+            const float* arow = sA[cur] + (xrow0 + l15) * LDA + kq;      // A[row][k], k = 4*step + kq
+            const float* bcol = sW + kq * CI + xcol0 + l15;             // B[k][col]
 #pragma unroll
             for (int k4 = 0; k4 < CO; k4 += 4) {
                 const float av = arow[k4];
-                const float b0 = bcol[k4 * CI], b1 = bcol[k4 * CI + 16];
-                ax0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b0, ax0, 0, 0, 0);
-                ax1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b1, ax1, 0, 0, 0);
+#pragma unroll
+                for (int h = 0; h < HT; ++h) ax[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bcol[k4 * CI + 16 * h], ax[h], 0, 0, 0);
             }
             const int pk = p0 + kc * DBK;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int row = (wave >> 1) * 16 + 4 * kq + i;          // accumulator i of this lane: row 4*(lane/16) + i of the tile
+                const int row = xrow0 + 4 * kq + i;          // accumulator i of this lane: row 4*(lane/16) + i of the tile
                 const int pp = pk + row;
                 if (pp < p1) {
 #pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const int col = (wave & 1) * 32 + 16 * h + l15;
-                        const float v = h == 0 ? ax0[i] : ax1[i];
+                    for (int h = 0; h < HT; ++h) {
+                        const int col = xcol0 + 16 * h + l15;
+                        const float v = ax[h][i];
                         const float zp = sZ[cur][row * CI + col];
                         const float dy = (zp * spx[h] + tpx[h] > 0.0f) ? v : 0.0f;
                         s1x[h] += dy;
@@ -667,15 +675,18 @@ __global__ __launch_bounds__(THREADS) void bwd_fused_kernel(PosOperand DZ, PosOp
         if (kc + 1 < nchunks) sstore(cur ^ 1);
         __syncthreads();
     }
-    // BatchNorm-backward partial sums of layer l-1: the four 16-lane row groups of a wave, then the two waves of a column half
+    // BatchNorm-backward partial sums of layer l-1: the four 16-lane row groups of a wave, then (HT == 2) the two waves that
+    // share a column half
+    for (int e = tid; e < 2 * 2 * CI; e += THREADS) (&red[0][0][0])[e] = 0.0f;
+    __syncthreads();
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < HT; ++h) {
         s1x[h] += __shfl_xor(s1x[h], 16, 64); s1x[h] += __shfl_xor(s1x[h], 32, 64);
         s2x[h] += __shfl_xor(s2x[h], 16, 64); s2x[h] += __shfl_xor(s2x[h], 32, 64);
         if (lane < 16) {
-            const int col = (wave & 1) * 32 + 16 * h + lane;
-            red[wave >> 1][0][col] = s1x[h];
-            red[wave >> 1][1][col] = s2x[h];
+            const int col = xcol0 + 16 * h + lane;
+            red[HT == 2 ? (wave >> 1) : 0][0][col] = s1x[h];
+            red[HT == 2 ? (wave >> 1) : 0][1][col] = s2x[h];
         }
     }
     __syncthreads();
@@ -1140,7 +1151,7 @@ extern "C" int mp_sa_mlp_bwd_f32(const float* x0, int64_t P, int64_t K, int n_la
 
         // dW_l = dZ_l^T * act(Z_{l-1})
         if (hipMemsetAsync(grads[l].d_weight, 0, sizeof(float) * (size_t)Co * Ci, stream) != hipSuccess) return MP_ELAUNCH;
-        if (l > 0 && Ci == 64 && Co == 64 && fused_bwd_enabled()) {
+        if (l > 0 && Ci == 64 && (Co == 64 || Co == 128) && fused_bwd_enabled()) {
             // single-tile layer: dX, dW and the BatchNorm-backward sums of layer l-1 in one pass over dZ_l (bwd_fused_kernel)
             const mp_mlp_layer_t& Pv = layers[l - 1];
             float* Gn = gbuf[l & 1];
@@ -1149,11 +1160,17 @@ extern "C" int mp_sa_mlp_bwd_f32(const float* x0, int64_t P, int64_t K, int n_la
             if ((size_t)gx > nblk_max) return MP_EUNSUPPORTED;
             const double fl = 4.0 * (double)P * Co * Ci;
             const double by = 4.0 * ((pooled ? 1.0 : 2.0) * (double)P * Co + 2.0 * (double)P * Ci);
-            if (pooled)
+            if (pooled && Co == 64)
                 MP_LAUNCH("bwd_fused_kernel<3, 64>", fl, by, (bwd_fused_kernel<SRC_DZ_POOLED, 64>), dim3(gx), dim3(THREADS), 0, stream, DZ, IN, (int)P,
                           ppb, Ly.weight, grads[l].d_weight, Gn, partials);
-            else
+            else if (pooled)
+                MP_LAUNCH("bwd_fused_kernel<3, 128>", fl, by, (bwd_fused_kernel<SRC_DZ_POOLED, 128>), dim3(gx), dim3(THREADS), 0, stream, DZ, IN, (int)P,
+                          ppb, Ly.weight, grads[l].d_weight, Gn, partials);
+            else if (Co == 64)
                 MP_LAUNCH("bwd_fused_kernel<2, 64>", fl, by, (bwd_fused_kernel<SRC_DZ, 64>), dim3(gx), dim3(THREADS), 0, stream, DZ, IN, (int)P,
+                          ppb, Ly.weight, grads[l].d_weight, Gn, partials);
+            else
+                MP_LAUNCH("bwd_fused_kernel<2, 128>", fl, by, (bwd_fused_kernel<SRC_DZ, 128>), dim3(gx), dim3(THREADS), 0, stream, DZ, IN, (int)P,
                           ppb, Ly.weight, grads[l].d_weight, Gn, partials);
             MP_CHECK_LAUNCH();
             hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((Ci + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_SL), 0, stream, partials, (int)gx, Ci,
