@@ -547,38 +547,37 @@ __global__ __launch_bounds__(THREADS) void dw_gemm_kernel(PosOperand DZ, PosOper
 // BatchNorm-backward sums of layer l-1 from the raw Z_{l-1} chunk kept beside the activated one: 4 tensor passes.
 // The dX tile of a chunk is computed as eight 16x16 MFMA tiles, two per wave.
 // =================================================================================================================
-template <int MODE_DZ, int CO>
-__global__ __launch_bounds__(THREADS) void bwd_fused_kernel(PosOperand DZ, PosOperand IN, int P, int p_per_block,
+template <int MODE_DZ, int CO, int CI>
+__global__ __launch_bounds__(THREADS, 2) void bwd_fused_kernel(PosOperand DZ, PosOperand IN, int P, int p_per_block,
                                                             const float* __restrict__ W, float* __restrict__ dW,
                                                             float* __restrict__ G, float* __restrict__ partials)
 {
-    constexpr int CI = 64;
-    constexpr int DBK = CO == 64 ? 32 : 16;     // positions per chunk: sized so that two workgroups fit a CU's LDS
-    constexpr int HT = DBK / 16;                // 16x16 dX tiles per wave and chunk (the chunk's dX tile is [DBK x 64])
+    constexpr int DBK = CI == 128 ? 16 : 32;   // positions per chunk (LDS and registers: at least two workgroups per CU)
+    constexpr int XW = DBK == 32 ? CI / 2 : CI / 4;         // dX columns per wave (the chunk's dX tile is [DBK x CI])
+    constexpr int HT = XW / 16;                             // 16x16 dX tiles per wave and chunk
     constexpr int LDA = CO + 1;                 // odd: conflict-free both as [k][row] (dW) and as [row][k] (dX)
-    constexpr int TMW = CO / 64;                // 32-row dW tiles per wave (waves 2 x 2)
+    constexpr int TMW = CO / 64, TNW = CI / 64; // 32x32 dW tiles per wave (waves 2 x 2)
     constexpr int PA = DBK * CO / 4 / THREADS, PB = DBK * CI / 4 / THREADS;
-    static_assert(CO == 64 || CO == 128, "tile");
+    static_assert((CO == 64 || CO == 128) && (CI == 64 || CI == 128), "tile");
     __shared__ float sA[2][DBK * LDA];
     __shared__ __attribute__((aligned(16))) float sB[2][DBK * CI];
     __shared__ __attribute__((aligned(16))) float sZ[2][DBK * CI];
-    __shared__ __attribute__((aligned(16))) float sW[CO * CI];
     __shared__ float red[2][2][CI];
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
-    const int wrow0 = (wave >> 1) * TMW * 32, wcol0 = (wave & 1) * 32;
+    const int wrow0 = (wave >> 1) * TMW * 32, wcol0 = (wave & 1) * TNW * 32;
     const int p0 = blockIdx.x * p_per_block;
     const int p1 = min(P, p0 + p_per_block);
     const int nchunks = (p1 - p0 + DBK - 1) / DBK;
     if (nchunks <= 0) return;
 
-    for (int e = tid; e < CO * CI / 4; e += THREADS) reinterpret_cast<float4*>(sW)[e] = ld4(W + 4 * e);
-
-    f32x16 accW[TMW];
+    f32x16 accW[TMW][TNW];
 #pragma unroll
     for (int mi = 0; mi < TMW; ++mi)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) accW[mi][r] = 0.0f;
+        for (int ni = 0; ni < TNW; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accW[mi][ni][r] = 0.0f;
 
     // every thread keeps the same channels for the whole kernel
     const int ca = (tid % (CO / 4)) * 4, cb = (tid % (CI / 4)) * 4;
@@ -611,9 +610,16 @@ __global__ __launch_bounds__(THREADS) void bwd_fused_kernel(PosOperand DZ, PosOp
     };
 
     const int l31 = lane & 31;
-    // dX tiles of this wave: HT == 2: rows 16*(wave>>1).., columns 32*(wave&1) + {0..15, 16..31}; HT == 1: rows 0..15, columns 16*wave..
-    const int xrow0 = HT == 2 ? (wave >> 1) * 16 : 0;
-    const int xcol0 = HT == 2 ? (wave & 1) * 32 : wave * 16;
+    // dX tiles of this wave: 32-position chunks: rows 16*(wave>>1).., columns (CI/2)*(wave&1)..; 16-position chunks: rows 0..15,
+    // columns (CI/4)*wave..  The W_l fragments of those columns never change: they live in registers for the whole kernel
+    // (v_mfma_f32_16x16x4_f32 B operand: lane (l15, kq) holds W[4*step + kq][col]), so W_l costs no LDS.
+    const int xrow0 = DBK == 32 ? (wave >> 1) * 16 : 0;
+    const int xcol0 = DBK == 32 ? (wave & 1) * XW : wave * XW;
+    float wfrag[HT][CO / 4];
+#pragma unroll
+    for (int h = 0; h < HT; ++h)
+#pragma unroll
+        for (int st = 0; st < CO / 4; ++st) wfrag[h][st] = W[(size_t)(4 * st + (lane >> 4)) * CI + xcol0 + 16 * h + (lane & 15)];
     float spx[HT], tpx[HT], s1x[HT], s2x[HT];   // this lane's G columns
 #pragma unroll
     for (int h = 0; h < HT; ++h) {
@@ -630,14 +636,7 @@ __global__ __launch_bounds__(THREADS) void bwd_fused_kernel(PosOperand DZ, PosOp
     for (int kc = 0; kc < nchunks; ++kc) {
         const int cur = kc & 1;
         if (kc + 1 < nchunks) gload(p0 + (kc + 1) * DBK);
-        {   // dW += dZ^T * act(Z_{l-1})
-            f32x16 acc2[TMW][1];
-#pragma unroll
-            for (int mi = 0; mi < TMW; ++mi) acc2[mi][0] = accW[mi];
-            mma_chunk<true, true, LDA, CI, TMW, 1, DBK>(sA[cur], sB[cur], wrow0, wcol0, acc2);
-#pragma unroll
-            for (int mi = 0; mi < TMW; ++mi) accW[mi] = acc2[mi][0];
-        }
+        mma_chunk<true, true, LDA, CI, TMW, TNW, DBK>(sA[cur], sB[cur], wrow0, wcol0, accW);   // dW += dZ^T * act(Z_{l-1})
         {   // G_{l-1} chunk [DBK x 64] = dZ [DBK x CO] * W_l [CO x 64] as 16x16 tiles, HT per wave (v_mfma_f32_16x16x4_f32:
             // with 32x32 tiles only one or two waves would have work)
             typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -646,12 +645,11 @@ __global__ __launch_bounds__(THREADS) void bwd_fused_kernel(PosOperand DZ, PosOp
             for (int h = 0; h < HT; ++h) ax[h] = f32x4{0.f, 0.f, 0.f, 0.f};
             const int l15 = lane & 15, kq = lane >> 4;
             const float* arow = sA[cur] + (xrow0 + l15) * LDA + kq;      // A[row][k], k = 4*step + kq
-            const float* bcol = sW + kq * CI + xcol0 + l15;             // B[k][col]
 #pragma unroll
-            for (int k4 = 0; k4 < CO; k4 += 4) {
-                const float av = arow[k4];
+            for (int st = 0; st < CO / 4; ++st) {
+                const float av = arow[4 * st];
 #pragma unroll
-                for (int h = 0; h < HT; ++h) ax[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bcol[k4 * CI + 16 * h], ax[h], 0, 0, 0);
+                for (int h = 0; h < HT; ++h) ax[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wfrag[h][st], ax[h], 0, 0, 0);
             }
             const int pk = p0 + kc * DBK;
 #pragma unroll
@@ -675,8 +673,8 @@ __global__ __launch_bounds__(THREADS) void bwd_fused_kernel(PosOperand DZ, PosOp
         if (kc + 1 < nchunks) sstore(cur ^ 1);
         __syncthreads();
     }
-    // BatchNorm-backward partial sums of layer l-1: the four 16-lane row groups of a wave, then (HT == 2) the two waves that
-    // share a column half
+    // BatchNorm-backward partial sums of layer l-1: the four 16-lane row groups of a wave, then (32-position chunks) the two
+    // waves that share a column half
     for (int e = tid; e < 2 * 2 * CI; e += THREADS) (&red[0][0][0])[e] = 0.0f;
     __syncthreads();
 #pragma unroll
@@ -685,8 +683,8 @@ __global__ __launch_bounds__(THREADS) void bwd_fused_kernel(PosOperand DZ, PosOp
         s2x[h] += __shfl_xor(s2x[h], 16, 64); s2x[h] += __shfl_xor(s2x[h], 32, 64);
         if (lane < 16) {
             const int col = xcol0 + 16 * h + lane;
-            red[HT == 2 ? (wave >> 1) : 0][0][col] = s1x[h];
-            red[HT == 2 ? (wave >> 1) : 0][1][col] = s2x[h];
+            red[DBK == 32 ? (wave >> 1) : 0][0][col] = s1x[h];
+            red[DBK == 32 ? (wave >> 1) : 0][1][col] = s2x[h];
         }
     }
     __syncthreads();
@@ -696,14 +694,16 @@ __global__ __launch_bounds__(THREADS) void bwd_fused_kernel(PosOperand DZ, PosOp
     }
     // dW
 #pragma unroll
-    for (int mi = 0; mi < TMW; ++mi) {
-        const int col = wcol0 + l31;
+    for (int mi = 0; mi < TMW; ++mi)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = wrow0 + mi * 32 + acc_row_in_tile(r);
-            atomicAdd(dW + (size_t)(row * CI + col), accW[mi][r]);
+        for (int ni = 0; ni < TNW; ++ni) {
+            const int col = wcol0 + ni * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wrow0 + mi * 32 + acc_row_in_tile(r);
+                atomicAdd(dW + (size_t)(row * CI + col), accW[mi][ni][r]);
+            }
         }
-    }
 }
 
 template <int MODE_DZ, int MODE_IN>
@@ -1151,7 +1151,7 @@ extern "C" int mp_sa_mlp_bwd_f32(const float* x0, int64_t P, int64_t K, int n_la
 
         // dW_l = dZ_l^T * act(Z_{l-1})
         if (hipMemsetAsync(grads[l].d_weight, 0, sizeof(float) * (size_t)Co * Ci, stream) != hipSuccess) return MP_ELAUNCH;
-        if (l > 0 && Ci == 64 && (Co == 64 || Co == 128) && fused_bwd_enabled()) {
+        if (l > 0 && (Ci == 64 || Ci == 128) && (Co == 64 || Co == 128) && fused_bwd_enabled()) {
             // single-tile layer: dX, dW and the BatchNorm-backward sums of layer l-1 in one pass over dZ_l (bwd_fused_kernel)
             const mp_mlp_layer_t& Pv = layers[l - 1];
             float* Gn = gbuf[l & 1];
@@ -1160,18 +1160,23 @@ extern "C" int mp_sa_mlp_bwd_f32(const float* x0, int64_t P, int64_t K, int n_la
             if ((size_t)gx > nblk_max) return MP_EUNSUPPORTED;
             const double fl = 4.0 * (double)P * Co * Ci;
             const double by = 4.0 * ((pooled ? 1.0 : 2.0) * (double)P * Co + 2.0 * (double)P * Ci);
-            if (pooled && Co == 64)
-                MP_LAUNCH("bwd_fused_kernel<3, 64>", fl, by, (bwd_fused_kernel<SRC_DZ_POOLED, 64>), dim3(gx), dim3(THREADS), 0, stream, DZ, IN, (int)P,
-                          ppb, Ly.weight, grads[l].d_weight, Gn, partials);
-            else if (pooled)
-                MP_LAUNCH("bwd_fused_kernel<3, 128>", fl, by, (bwd_fused_kernel<SRC_DZ_POOLED, 128>), dim3(gx), dim3(THREADS), 0, stream, DZ, IN, (int)P,
-                          ppb, Ly.weight, grads[l].d_weight, Gn, partials);
-            else if (Co == 64)
-                MP_LAUNCH("bwd_fused_kernel<2, 64>", fl, by, (bwd_fused_kernel<SRC_DZ, 64>), dim3(gx), dim3(THREADS), 0, stream, DZ, IN, (int)P,
-                          ppb, Ly.weight, grads[l].d_weight, Gn, partials);
-            else
-                MP_LAUNCH("bwd_fused_kernel<2, 128>", fl, by, (bwd_fused_kernel<SRC_DZ, 128>), dim3(gx), dim3(THREADS), 0, stream, DZ, IN, (int)P,
-                          ppb, Ly.weight, grads[l].d_weight, Gn, partials);
+            char tg[64];
+            snprintf(tg, sizeof tg, "bwd_fused_kernel<%d, %d, %d>", pooled ? 3 : 2, Co, Ci);
+#define MP_FUSED(MODE, CO_, CI_)                                                                                              \
+    MP_LAUNCH(tg, fl, by, (bwd_fused_kernel<MODE, CO_, CI_>), dim3(gx), dim3(THREADS), 0, stream, DZ, IN, (int)P, ppb, Ly.weight, \
+              grads[l].d_weight, Gn, partials)
+            if (pooled) {
+                if (Co == 64 && Ci == 64) MP_FUSED(SRC_DZ_POOLED, 64, 64);
+                else if (Co == 128 && Ci == 64) MP_FUSED(SRC_DZ_POOLED, 128, 64);
+                else if (Co == 64 && Ci == 128) MP_FUSED(SRC_DZ_POOLED, 64, 128);
+                else MP_FUSED(SRC_DZ_POOLED, 128, 128);
+            } else {
+                if (Co == 64 && Ci == 64) MP_FUSED(SRC_DZ, 64, 64);
+                else if (Co == 128 && Ci == 64) MP_FUSED(SRC_DZ, 128, 64);
+                else if (Co == 64 && Ci == 128) MP_FUSED(SRC_DZ, 64, 128);
+                else MP_FUSED(SRC_DZ, 128, 128);
+            }
+#undef MP_FUSED
             MP_CHECK_LAUNCH();
             hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((Ci + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_SL), 0, stream, partials, (int)gx, Ci,
                                1.0 / (double)P, training, Pv.gamma, Pv.mean, Pv.rstd, grads[l - 1].d_gamma,
