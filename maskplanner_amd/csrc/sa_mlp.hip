@@ -706,6 +706,64 @@ __global__ __launch_bounds__(THREADS, 2) void bwd_fused_kernel(PosOperand DZ, Po
         }
 }
 
+// dW for a 4-channel input (the first layer of the first level: xyz + pad): a [CO x 4] result is no MFMA shape (a 128 x 32
+// tile would be 1/16 full), and the kernel is a pure stream over dZ = (Z_1, G_1).  Thread (position lane, channel quad):
+// 64 position lanes x (CO/4) quads; every thread walks positions lane, lane+PL, ... of its workgroup's slice with float4
+// loads of dZ and of the input row, 16 FMAs each; lanes are combined through LDS and added to dW with atomics.
+template <int MODE_DZ, int MODE_IN>
+__global__ __launch_bounds__(256) void dw_ci4_kernel(PosOperand DZ, PosOperand IN, int P, int p_per_block, float* __restrict__ dW)
+{
+    __shared__ float red[256][16 + 1];
+    const int tid = threadIdx.x;
+    const int Co = DZ.C;
+    const int nq = Co / 4;                        // channel quads (Co % 4 == 0): 16 for Co = 64
+    const int q = tid % nq, pl = tid / nq;        // this thread's quad and position lane
+    const int PL = 256 / nq;                      // position lanes per workgroup
+    const int p0 = blockIdx.x * p_per_block, p1 = min(P, p0 + p_per_block);
+    ChanConst ka, kb;
+    load_consts<MODE_DZ>(DZ, 4 * q, ka);
+    load_consts<MODE_IN>(IN, 0, kb);
+    float acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = 0.0f;
+    if (pl < PL) {
+        for (int p = p0 + pl; p < p1; p += 4 * PL) {
+            Raw4<MODE_DZ> rz[4];
+            Raw4<MODE_IN> rx[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {          // four positions in flight
+                raw_load<MODE_DZ>(DZ, p1, p + u * PL, 4 * q, rz[u]);
+                raw_load<MODE_IN>(IN, p1, p + u * PL, 0, rx[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float4 dz = finish<MODE_DZ>(rz[u], ka);
+                const float4 xv = finish<MODE_IN>(rx[u], kb);
+                const float d[4] = {dz.x, dz.y, dz.z, dz.w}, x[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_fmaf(d[a], x[b], acc[a][b]);
+            }
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) red[tid][4 * a + b] = acc[a][b];
+    __syncthreads();
+    // element e = (quad, a, b): sum over the position lanes, fixed order
+    for (int e = tid; e < nq * 16; e += 256) {
+        const int qq = e / 16, ab = e - qq * 16;
+        float s = 0.0f;
+        for (int l = 0; l < PL; ++l) s += red[l * nq + qq][ab];
+        const int co = 4 * qq + ab / 4, ci = ab & 3;
+        if (ci < IN.C) atomicAdd(dW + (size_t)co * IN.C + ci, s);
+    }
+}
+
 template <int MODE_DZ, int MODE_IN>
 int launch_dw(const PosOperand& DZ, const PosOperand& IN, int64_t P64, float* dW, hipStream_t stream)
 {
@@ -724,6 +782,14 @@ int launch_dw(const PosOperand& DZ, const PosOperand& IN, int64_t P64, float* dW
     const unsigned gx = (unsigned)((P + ppb - 1) / ppb);
     // input-channel tiling: 128-wide tiles, a narrow remainder (132 = 128 + 4, 260 = 2*128 + 4) gets 32-wide tiles so
     // that it does not pay for a whole 128-column MFMA tile of zeros
+    if (Ci == 4 && (Co & 3) == 0 && Co <= 1024 && 256 % (Co / 4) == 0) {
+        double fl = 2.0 * (double)P * Co * Ci, by = 4.0 * ((MODE_DZ == SRC_DZ ? 2.0 : 1.0) * (double)P * Co + (double)P * Ci);
+        char tg[64];
+        snprintf(tg, sizeof tg, "dw_ci4_kernel<%d, %d>", MODE_DZ, MODE_IN);
+        MP_LAUNCH(tg, fl, by, (dw_ci4_kernel<MODE_DZ, MODE_IN>), dim3((unsigned)((P + 1023) / 1024)), dim3(256), 0, stream, DZ, IN, P, 1024, dW);
+        MP_CHECK_LAUNCH();
+        return MP_OK;
+    }
     const int main_ci = (Ci > 128 && Ci % 128 != 0 && Ci % 128 <= 32) ? (Ci / 128) * 128 : Ci;
     const int tail_ci = (main_ci < Ci && Ci - main_ci == 4) ? main_ci : -1;   // 4 leftover columns ride along (see the kernel)
     char tag[96];
