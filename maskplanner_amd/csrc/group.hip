@@ -98,6 +98,36 @@ __global__ __launch_bounds__(256) void group_kernel(const float* __restrict__ xy
     }
 }
 
+// Fast path of group_kernel for the internal layout of the set-abstraction modules: features first (D % 4 == 0), then the
+// centred xyz and one zero pad column (row stride D + 4).  One wave per output row, a float4 per lane: the source row is read
+// and the output row written as whole 16-byte pieces (the generic kernel does a 64-bit divide and a 4-byte access per
+// element); 32-bit index arithmetic.
+__global__ __launch_bounds__(256) void group_rows4_kernel(const float* __restrict__ xyz, const float* __restrict__ feats,
+                                                          const float* __restrict__ new_xyz, const int64_t* __restrict__ idx,
+                                                          int N, int S, int K, int D, int rows, float* __restrict__ out)
+{
+    const int lane = threadIdx.x & 63;
+    const int nq = D / 4 + 1;                       // float4 pieces per row
+    const int Cs = D + 4;
+    for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += gridDim.x * 4) {
+        const int bs = row / K, b = bs / S;
+        int64_t i64 = idx[row];
+        int i = (int)(i64 < 0 ? 0 : (i64 >= N ? N - 1 : i64));
+        const size_t src = (size_t)b * N + i;
+        for (int q = lane; q < nq; q += 64) {
+            float4 v;
+            if (q < D / 4) {
+                v = *reinterpret_cast<const float4*>(feats + src * D + 4 * q);
+            } else {
+                const float* p = xyz + src * 3;
+                const float* c = new_xyz + (size_t)bs * 3;
+                v = make_float4(p[0] - c[0], p[1] - c[1], p[2] - c[2], 0.0f);
+            }
+            *reinterpret_cast<float4*>(out + (size_t)row * Cs + 4 * q) = v;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void group_bwd_atomic_kernel(const float* __restrict__ grad_out,
                                                                const int64_t* __restrict__ idx, int64_t N, int64_t SK,
                                                                int64_t D, int xyz_last, int64_t Cs, int64_t total,
@@ -111,6 +141,99 @@ __global__ __launch_bounds__(256) void group_bwd_atomic_kernel(const float* __re
         const int64_t b = row / SK;
         const int64_t i = idx[row];
         if (i >= 0 && i < N) atomicAdd(grad_feats + (b * N + i) * D + c, grad_out[row * C + foff + c]);
+    }
+}
+
+// Backward of the grouping gather without global atomics, for the internal layout (features first, D % 4 == 0, row stride
+// D + 4).  A workgroup owns GP consecutive source points of one cloud: it scans the cloud's S*K neighbour indices once,
+// collecting for each of its points the rows that gathered it (LDS lists of GCAP rows per point plus a shared overflow list;
+// beyond both the workgroup falls back to atomics), then every wave sums the gradient rows of its points with float4 loads -- each 512-byte gradient row is
+// read once, coalesced, and every destination row is written once.  (Summation order follows the LDS list order, i.e. it
+// is not fixed: this is the non-deterministic variant's replacement; the ordered kernel above stays for deterministic runs.)
+constexpr int GP = 16, GCAP = 1024, GOVF = 2048;
+__global__ __launch_bounds__(256) void group_bwd_gather_kernel(const float* __restrict__ grad_out, const int64_t* __restrict__ idx,
+                                                               int N, int M, int D, float* __restrict__ grad_feats)
+{
+    __shared__ int cnt[GP];
+    __shared__ int novf;
+    __shared__ unsigned short lists[GP][GCAP];      // 32 KB
+    __shared__ unsigned short ovf_m[GOVF];          // rows beyond a full list (ball-query padding repeats one index up to K
+    __shared__ unsigned char ovf_r[GOVF];           // times per group, so a few points collect hundreds of rows)
+    const int b = blockIdx.y, n0 = blockIdx.x * GP;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int Cs = D + 4;
+    const int64_t* bi = idx + (size_t)b * M;
+    const float* gb = grad_out + (size_t)b * M * Cs;
+    float* dst = grad_feats + ((size_t)b * N + n0) * D;
+    const int npts = min(GP, N - n0);
+    if (tid < GP) cnt[tid] = 0;
+    if (tid == 0) novf = 0;
+    __syncthreads();
+    for (int m = tid; m < M; m += 256) {
+        const int64_t i = bi[m];
+        const int r = (int)(i - n0);
+        if (i >= n0 && r < npts) {
+            const int slot = atomicAdd(&cnt[r], 1);
+            if (slot < GCAP) lists[r][slot] = (unsigned short)m;
+            else {
+                const int o = atomicAdd(&novf, 1);
+                if (o < GOVF) { ovf_m[o] = (unsigned short)m; ovf_r[o] = (unsigned char)r; }
+            }
+        }
+    }
+    __syncthreads();
+    if (novf > GOVF) {
+        // pathological skew (more than GCAP + GOVF rows on this workgroup's points): plain atomics for the whole workgroup
+        for (int e = tid; e < npts * D; e += 256) dst[e] = 0.0f;
+        __syncthreads();
+        for (int m = tid; m < M; m += 256) {
+            const int64_t i = bi[m];
+            const int r = (int)(i - n0);
+            if (i >= n0 && r < npts) {
+                const float* g = gb + (size_t)m * Cs;
+                for (int c = 0; c < D; ++c) atomicAdd(dst + (size_t)r * D + c, g[c]);
+            }
+        }
+        return;
+    }
+    const int q = D / 4;                       // float4 pieces per row (<= 64)
+    const int rpw = 64 / q;                    // rows a wave reads at once (2 for D = 128)
+    const int sub = lane / q, ql = lane - sub * q;
+    const int no = novf;
+    for (int r = wave; r < npts; r += 4) {
+        const int n = min(cnt[r], GCAP);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        {   // eight row loads in flight per lane group: a hot point (hundreds of rows) is otherwise one latency per row
+            int j = sub;
+            for (; j + 7 * rpw < n; j += 8 * rpw) {
+                float4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(gb + (size_t)lists[r][j + u * rpw] * Cs + 4 * ql);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+            }
+            for (; j < n; j += rpw) {
+                const float4 v = *reinterpret_cast<const float4*>(gb + (size_t)lists[r][j] * Cs + 4 * ql);
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
+        }
+        // rows that did not fit the list (rare), still without global atomics
+        if (cnt[r] > GCAP)
+            for (int o = sub; o < no; o += rpw)
+                if (ovf_r[o] == r) {
+                    const float4 v = *reinterpret_cast<const float4*>(gb + (size_t)ovf_m[o] * Cs + 4 * ql);
+                    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+                }
+        // combine the row slots of the wave (lanes ql, ql + q, ...): only rpw in {1, 2, 4} are dispatched
+        if (rpw >= 2) {
+            acc.x += __shfl_down(acc.x, q, 64); acc.y += __shfl_down(acc.y, q, 64);
+            acc.z += __shfl_down(acc.z, q, 64); acc.w += __shfl_down(acc.w, q, 64);
+        }
+        if (rpw == 4) {
+            acc.x += __shfl_down(acc.x, 2 * q, 64); acc.y += __shfl_down(acc.y, 2 * q, 64);
+            acc.z += __shfl_down(acc.z, 2 * q, 64); acc.w += __shfl_down(acc.w, 2 * q, 64);
+        }
+        if (lane < q) reinterpret_cast<float4*>(dst + (size_t)r * D)[ql] = acc;
     }
 }
 
@@ -197,7 +320,18 @@ extern "C" int mp_group_f32(const float* xyz, const float* feats, const float* n
     const int64_t total = B * S * K * out_stride;
     if (total == 0) return MP_OK;
     if (!xyz || !new_xyz || !idx || !out || (D > 0 && !feats) || N == 0) return MP_EINVAL;
-    MP_LAUNCH("group_kernel", 0.0, 4.0 * (double)total + 8.0 * (double)(B * S * K) + 4.0 * (double)(B * N * (D + 3)), group_kernel,
+    const double bytes = 4.0 * (double)total + 8.0 * (double)(B * S * K) + 4.0 * (double)(B * N * (D + 3));
+    if (xyz_last && D > 0 && (D & 3) == 0 && out_stride == D + 4 && B * S * K < ((int64_t)1 << 31) && N < ((int64_t)1 << 31) &&
+        (reinterpret_cast<uintptr_t>(feats) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
+        const int64_t rows = B * S * K;
+        int64_t g = (rows + 3) / 4;
+        if (g > 256 * 64) g = 256 * 64;
+        MP_LAUNCH("group_kernel", 0.0, bytes, group_rows4_kernel, dim3((unsigned)g), dim3(256), 0, mp_stream(stream_), xyz, feats, new_xyz, idx,
+                  (int)N, (int)S, (int)K, (int)D, (int)rows, out);
+        MP_CHECK_LAUNCH();
+        return MP_OK;
+    }
+    MP_LAUNCH("group_kernel", 0.0, bytes, group_kernel,
               dim3(grid_for(total)), dim3(256), 0, mp_stream(stream_), xyz, feats, new_xyz, idx, N, S, K, D, xyz_last, out_stride, total, out);
     MP_CHECK_LAUNCH();
     return MP_OK;
@@ -217,6 +351,12 @@ extern "C" int mp_group_bwd_f32(const float* grad_out, const int64_t* idx, int64
         const int64_t rows = B * N;
         hipLaunchKernelGGL(scatter_rows_ordered_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream,
                            grad_out, idx, N, D, S * K, grad_stride, (int64_t)(xyz_last ? 0 : 3), rows, grad_feats);
+    } else if (xyz_last && D > 0 && (D == 64 || D == 128 || D == 256) && grad_stride == D + 4 && S * K < 65536 && B < 65536 &&
+               N < ((int64_t)1 << 30) && (reinterpret_cast<uintptr_t>(grad_out) & 15) == 0 &&
+               (reinterpret_cast<uintptr_t>(grad_feats) & 15) == 0) {
+        // rpw = 64 / (D/4) in {4, 2, 1}: the shuffle combine of the gather kernel covers exactly these
+        MP_LAUNCH("group_bwd_gather_kernel", 0.0, 4.0 * (double)(B * S * K) * (D + 2) + 4.0 * (double)(B * N * D), group_bwd_gather_kernel,
+                  dim3((unsigned)((N + GP - 1) / GP), (unsigned)B), dim3(256), 0, stream, grad_out, idx, (int)N, (int)(S * K), (int)D, grad_feats);
     } else {
         if (hipMemsetAsync(grad_feats, 0, sizeof(float) * (size_t)(B * N * D), stream) != hipSuccess) return MP_ELAUNCH;
         const int64_t total = B * S * K * D;

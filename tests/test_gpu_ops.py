@@ -121,7 +121,7 @@ def test_index_points_and_backward(oracle, ops, det):
         np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-6)
 
 
-@pytest.mark.parametrize("D,xyz_last", [(0, False), (13, False), (128, False), (13, True)])
+@pytest.mark.parametrize("D,xyz_last", [(0, False), (13, False), (128, False), (13, True), (128, True), (64, True), (256, True)])
 def test_group_and_backward(oracle, ops, D, xyz_last):
     rng = np.random.default_rng(6 + D)
     B, N, S, K = 2, 200, 16, 8
@@ -150,6 +150,38 @@ def test_group_and_backward(oracle, ops, D, xyz_last):
                 assert np.array_equal(f.grad.cpu().numpy(), want_g)
             else:
                 np.testing.assert_allclose(f.grad.cpu().numpy(), want_g, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("D,S,K,every", [(64, 64, 32, 3), (128, 64, 32, 3), (256, 64, 32, 3), (128, 128, 64, 3), (128, 128, 64, 1)])
+def test_group_internal_layout_fast_paths(oracle, ops, D, S, K, every):
+    """The set-abstraction modules group with features first and rows padded to D + 4 floats: float4 row gather forward,
+    atomic-free gather-reduce backward (csrc/group.hip).  One source point of cloud 1 is gathered by every `every`-th row:
+    ~680 rows (fits its list), ~2700 rows (list + overflow list) or all 8192 rows (the workgroup's atomic fallback)."""
+    rng = np.random.default_rng(60 + D + S)
+    B, N = 3, 300
+    xyz = rng.normal(size=(B, N, 3)).astype(np.float32)
+    feats = rng.normal(size=(B, N, D)).astype(np.float32)
+    new_xyz = xyz[:, :S].copy()
+    idx = rng.integers(0, N, size=(B, S, K))
+    idx[1].reshape(-1)[::every] = 7
+    want = oracle.group(xyz, feats, new_xyz, idx)
+    want = np.concatenate([want[..., 3:], want[..., :3], np.zeros(want.shape[:-1] + (1,), np.float32)], -1)
+    f = dev(feats).requires_grad_(True)
+    out = ops.group(dev(xyz), f, dev(new_xyz), dev(idx), xyz_last=True, pad_to=4)
+    assert out.shape[-1] == D + 4 and np.array_equal(out.detach().cpu().numpy(), want)
+    g = rng.normal(size=out.shape).astype(np.float32)
+    want_g = oracle.index_points_bwd(np.ascontiguousarray(g[..., :D]).reshape(B, -1, D), idx.reshape(B, -1), N)
+    out.backward(dev(g))
+    got = f.grad.cpu().numpy()
+    scale = np.abs(want_g).max()
+    assert np.abs(got - want_g).max() <= 5e-5 * scale          # summation order differs (thousands of terms for the hot point)
+    ops.DETERMINISTIC = True
+    try:
+        f.grad = None
+        ops.group(dev(xyz), f, dev(new_xyz), dev(idx), xyz_last=True, pad_to=4).backward(dev(g))
+        assert np.array_equal(f.grad.cpu().numpy(), want_g)
+    finally:
+        ops.DETERMINISTIC = False
 
 
 # ------------------------------------------------------------------------------------------------ kNN
