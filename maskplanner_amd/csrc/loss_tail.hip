@@ -192,109 +192,133 @@ extern "C" int mp_mask_loss_bwd_f32(const float* grad_out, const float* pred_mas
 // the running-stat update in one launch; the backward (ReLU mask, dgamma / dbeta, dx) in another.
 namespace {
 
-// RB: rows held in registers (all B <= RB rows of a channel are fetched with independent loads: one memory latency for the
-// whole kernel); RB == 0: any B, rows re-read per pass.
-template <int RB>
-__global__ __launch_bounds__(64) void bn_relu_rows_kernel(const float* __restrict__ x, int B, int C, int training,
-                                                          float momentum, float eps, const float* __restrict__ gamma,
-                                                          const float* __restrict__ beta, float* __restrict__ running_mean,
-                                                          float* __restrict__ running_var, float* __restrict__ y,
-                                                          float* __restrict__ save_mean, float* __restrict__ save_rstd)
+// Workgroup = 64 channels x 4 row groups (256 threads): thread (c, g) keeps rows g, g+4, ... of channel c in registers (RPT of
+// them, all fetched with independent loads: one memory latency), the four row groups are combined through LDS.
+// RPT == 0: any B, rows re-read per pass.
+template <int RPT>
+__global__ __launch_bounds__(256) void bn_relu_rows_kernel(const float* __restrict__ x, int B, int C, int training,
+                                                           float momentum, float eps, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float* __restrict__ running_mean,
+                                                           float* __restrict__ running_var, float* __restrict__ y,
+                                                           float* __restrict__ save_mean, float* __restrict__ save_rstd)
 {
-    const int c = blockIdx.x * 64 + threadIdx.x;
-    if (c >= C) return;
-    constexpr int NR = RB > 0 ? RB : 1;
+    __shared__ float red[4][64];
+    const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    const bool live = c < C;
+    constexpr int NR = RPT > 0 ? RPT : 1;
     float xv[NR];
-    if constexpr (RB > 0) {
+    if constexpr (RPT > 0) {
 #pragma unroll
-        for (int r = 0; r < RB; ++r) xv[r] = r < B ? x[(size_t)r * C + c] : 0.0f;
+        for (int k = 0; k < RPT; ++k) { const int r = g + 4 * k; xv[k] = (live && r < B) ? x[(size_t)r * C + c] : 0.0f; }
     }
-    auto at = [&](int r) { if constexpr (RB > 0) return xv[r]; else return x[(size_t)r * C + c]; };
-    float mean, rstd;
+    float mean = 0.0f, rstd = 0.0f;
     if (training) {
         float s = 0.0f;
-        if constexpr (RB > 0) {
+        if constexpr (RPT > 0) {
 #pragma unroll
-            for (int r = 0; r < RB; ++r) s += xv[r];          // rows beyond B hold 0
+            for (int k = 0; k < RPT; ++k) s += xv[k];          // rows beyond B hold 0
         } else {
-            for (int r = 0; r < B; ++r) s += at(r);
+            if (live) for (int r = g; r < B; r += 4) s += x[(size_t)r * C + c];
         }
-        mean = s / (float)B;
+        red[g][cl] = s;
+        __syncthreads();
+        mean = ((red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl])) / (float)B;
+        __syncthreads();
         float v = 0.0f;
-        if constexpr (RB > 0) {
+        if constexpr (RPT > 0) {
 #pragma unroll
-            for (int r = 0; r < RB; ++r) { const float d = xv[r] - mean; v += r < B ? d * d : 0.0f; }
+            for (int k = 0; k < RPT; ++k) { const float d = xv[k] - mean; v += (g + 4 * k < B) ? d * d : 0.0f; }
         } else {
-            for (int r = 0; r < B; ++r) { const float d = at(r) - mean; v += d * d; }
+            if (live) for (int r = g; r < B; r += 4) { const float d = x[(size_t)r * C + c] - mean; v += d * d; }
         }
+        red[g][cl] = v;
+        __syncthreads();
+        v = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
         const float var = v / (float)B;                       // biased: what normalises
         rstd = 1.0f / sqrtf(var + eps);
-        if (running_mean) {
+        if (live && g == 0 && running_mean) {
             running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * mean;
             running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (B > 1 ? v / (float)(B - 1) : var);   // unbiased
         }
-    } else {
+    } else if (live) {
         mean = running_mean[c];
         rstd = 1.0f / sqrtf(running_var[c] + eps);
     }
-    save_mean[c] = mean;
-    save_rstd[c] = rstd;
-    const float g = gamma ? gamma[c] : 1.0f, b = beta ? beta[c] : 0.0f;
-    if constexpr (RB > 0) {
+    if (!live) return;
+    if (g == 0) { save_mean[c] = mean; save_rstd[c] = rstd; }
+    const float ga = gamma ? gamma[c] : 1.0f, be = beta ? beta[c] : 0.0f;
+    if constexpr (RPT > 0) {
 #pragma unroll
-        for (int r = 0; r < RB; ++r)
-            if (r < B) { const float v = (xv[r] - mean) * rstd * g + b; y[(size_t)r * C + c] = v > 0.0f ? v : 0.0f; }
+        for (int k = 0; k < RPT; ++k) {
+            const int r = g + 4 * k;
+            if (r < B) { const float v = (xv[k] - mean) * rstd * ga + be; y[(size_t)r * C + c] = v > 0.0f ? v : 0.0f; }
+        }
     } else {
-        for (int r = 0; r < B; ++r) { const float v = (at(r) - mean) * rstd * g + b; y[(size_t)r * C + c] = v > 0.0f ? v : 0.0f; }
+        for (int r = g; r < B; r += 4) { const float v = (x[(size_t)r * C + c] - mean) * rstd * ga + be; y[(size_t)r * C + c] = v > 0.0f ? v : 0.0f; }
     }
 }
 
-template <int RB>
-__global__ __launch_bounds__(64) void bn_relu_rows_bwd_kernel(const float* __restrict__ grad_y, const float* __restrict__ y,
-                                                              const float* __restrict__ x, int B, int C, int training,
-                                                              const float* __restrict__ gamma, const float* __restrict__ save_mean,
-                                                              const float* __restrict__ save_rstd, float* __restrict__ grad_x,
-                                                              float* __restrict__ grad_gamma, float* __restrict__ grad_beta)
+template <int RPT>
+__global__ __launch_bounds__(256) void bn_relu_rows_bwd_kernel(const float* __restrict__ grad_y, const float* __restrict__ y,
+                                                               const float* __restrict__ x, int B, int C, int training,
+                                                               const float* __restrict__ gamma, const float* __restrict__ save_mean,
+                                                               const float* __restrict__ save_rstd, float* __restrict__ grad_x,
+                                                               float* __restrict__ grad_gamma, float* __restrict__ grad_beta)
 {
-    const int c = blockIdx.x * 64 + threadIdx.x;
-    if (c >= C) return;
-    const float mean = save_mean[c], rstd = save_rstd[c];
-    const float g = gamma ? gamma[c] : 1.0f;
-    constexpr int NR = RB > 0 ? RB : 1;
+    __shared__ float red[2][4][64];
+    const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    const bool live = c < C;
+    const float mean = live ? save_mean[c] : 0.0f, rstd = live ? save_rstd[c] : 0.0f;
+    const float ga = (live && gamma) ? gamma[c] : 1.0f;
+    constexpr int NR = RPT > 0 ? RPT : 1;
     float dyv[NR], xh[NR];
     float db = 0.0f, dg = 0.0f;
-    if constexpr (RB > 0) {
+    if constexpr (RPT > 0) {
 #pragma unroll
-        for (int r = 0; r < RB; ++r) {
-            const size_t o = (size_t)(r < B ? r : 0) * C + c;
+        for (int k = 0; k < RPT; ++k) {
+            const int r = g + 4 * k;
+            const bool ok = live && r < B;
+            const size_t o = ok ? (size_t)r * C + c : 0;
             const float yy = y[o], gy = grad_y[o], xx = x[o];
-            dyv[r] = (r < B && yy > 0.0f) ? gy : 0.0f;
-            xh[r] = r < B ? (xx - mean) * rstd : 0.0f;
+            dyv[k] = (ok && yy > 0.0f) ? gy : 0.0f;
+            xh[k] = ok ? (xx - mean) * rstd : 0.0f;
         }
 #pragma unroll
-        for (int r = 0; r < RB; ++r) { db += dyv[r]; dg += dyv[r] * xh[r]; }
-    } else {
-        for (int r = 0; r < B; ++r) {
+        for (int k = 0; k < RPT; ++k) { db += dyv[k]; dg += dyv[k] * xh[k]; }
+    } else if (live) {
+        for (int r = g; r < B; r += 4) {
             const size_t o = (size_t)r * C + c;
             const float dy = y[o] > 0.0f ? grad_y[o] : 0.0f;
             db += dy;
             dg += dy * ((x[o] - mean) * rstd);
         }
     }
-    if (grad_beta) grad_beta[c] = db;
-    if (grad_gamma) grad_gamma[c] = dg;
+    red[0][g][cl] = db;
+    red[1][g][cl] = dg;
+    __syncthreads();
+    db = (red[0][0][cl] + red[0][1][cl]) + (red[0][2][cl] + red[0][3][cl]);
+    dg = (red[1][0][cl] + red[1][1][cl]) + (red[1][2][cl] + red[1][3][cl]);
+    if (!live) return;
+    if (g == 0) {
+        if (grad_beta) grad_beta[c] = db;
+        if (grad_gamma) grad_gamma[c] = dg;
+    }
     if (!grad_x) return;
     const float inv = 1.0f / (float)B;
-    if constexpr (RB > 0) {
+    if constexpr (RPT > 0) {
 #pragma unroll
-        for (int r = 0; r < RB; ++r)
-            if (r < B) grad_x[(size_t)r * C + c] = training ? g * rstd * (dyv[r] - db * inv - xh[r] * dg * inv) : g * rstd * dyv[r];
+        for (int k = 0; k < RPT; ++k) {
+            const int r = g + 4 * k;
+            if (r < B) grad_x[(size_t)r * C + c] = training ? ga * rstd * (dyv[k] - db * inv - xh[k] * dg * inv) : ga * rstd * dyv[k];
+        }
     } else {
-        for (int r = 0; r < B; ++r) {
+        for (int r = g; r < B; r += 4) {
             const size_t o = (size_t)r * C + c;
             const float dy = y[o] > 0.0f ? grad_y[o] : 0.0f;
             const float xhat = (x[o] - mean) * rstd;
-            grad_x[o] = training ? g * rstd * (dy - db * inv - xhat * dg * inv) : g * rstd * dy;
+            grad_x[o] = training ? ga * rstd * (dy - db * inv - xhat * dg * inv) : ga * rstd * dy;
         }
     }
 }
@@ -311,10 +335,10 @@ extern "C" int mp_bn_relu_rows_f32(const float* x, int64_t B, int64_t C, int tra
     if (B > 4096 || C > (1 << 24)) return MP_EUNSUPPORTED;   // a thread walks the rows: made for skinny batches
     const dim3 grid((unsigned)((C + 63) / 64));   // 64 channels per workgroup: 16 workgroups for the 1024-wide heads
     if (B <= 32)
-        hipLaunchKernelGGL(bn_relu_rows_kernel<32>, grid, dim3(64), 0, mp_stream(stream_), x, (int)B, (int)C, training, (float)momentum,
+        hipLaunchKernelGGL(bn_relu_rows_kernel<8>, grid, dim3(256), 0, mp_stream(stream_), x, (int)B, (int)C, training, (float)momentum,
                            (float)eps, gamma, beta, running_mean, running_var, y, save_mean, save_rstd);
     else
-        hipLaunchKernelGGL(bn_relu_rows_kernel<0>, grid, dim3(64), 0, mp_stream(stream_), x, (int)B, (int)C, training, (float)momentum,
+        hipLaunchKernelGGL(bn_relu_rows_kernel<0>, grid, dim3(256), 0, mp_stream(stream_), x, (int)B, (int)C, training, (float)momentum,
                            (float)eps, gamma, beta, running_mean, running_var, y, save_mean, save_rstd);
     MP_CHECK_LAUNCH();
     return MP_OK;
@@ -330,10 +354,10 @@ extern "C" int mp_bn_relu_rows_bwd_f32(const float* grad_y, const float* y, cons
     if (B > 4096 || C > (1 << 24)) return MP_EUNSUPPORTED;
     const dim3 grid((unsigned)((C + 63) / 64));
     if (B <= 32)
-        hipLaunchKernelGGL(bn_relu_rows_bwd_kernel<32>, grid, dim3(64), 0, mp_stream(stream_), grad_y, y, x, (int)B, (int)C, training, gamma,
+        hipLaunchKernelGGL(bn_relu_rows_bwd_kernel<8>, grid, dim3(256), 0, mp_stream(stream_), grad_y, y, x, (int)B, (int)C, training, gamma,
                            save_mean, save_rstd, grad_x, grad_gamma, grad_beta);
     else
-        hipLaunchKernelGGL(bn_relu_rows_bwd_kernel<0>, grid, dim3(64), 0, mp_stream(stream_), grad_y, y, x, (int)B, (int)C, training, gamma,
+        hipLaunchKernelGGL(bn_relu_rows_bwd_kernel<0>, grid, dim3(256), 0, mp_stream(stream_), grad_y, y, x, (int)B, (int)C, training, gamma,
                            save_mean, save_rstd, grad_x, grad_gamma, grad_beta);
     MP_CHECK_LAUNCH();
     return MP_OK;
