@@ -538,6 +538,145 @@ __global__ __launch_bounds__(THREADS) void dw_gemm_kernel(PosOperand DZ, PosOper
 }
 
 // =================================================================================================================
+// Kernel 1b: forward layer as a position stream, for the layers behind the first one (CI in {64, 128} inputs, CO in
+// {64, 128, 256} outputs).  A workgroup walks p_per_block positions in chunks of 32: the activated input chunk is staged
+// in LDS, every wave owns CO / waves output columns whose weight fragments stay in registers for the whole kernel
+// (v_mfma_f32_16x16x4_f32: 2 row tiles x HT column tiles per wave and chunk), and the epilogue of a chunk -- raw Z store,
+// per-column BatchNorm sums, running max / min of the groups for the fused pool -- is 8 rows per lane, interleaved with the
+// other waves' MFMAs instead of being a separate phase of a 128 x 128 tile.  One partial-sum row per workgroup
+// (P / p_per_block rows instead of P / 128) also makes the BatchNorm finalize kernel 8x shorter.
+// =================================================================================================================
+template <int CI, int CO, bool POOL>
+__global__ __launch_bounds__(CO > 128 ? 512 : 256) void fwd_chunk_kernel(PosOperand A, int P, int p_per_block,
+                                                                         const float* __restrict__ W, float* __restrict__ Z,
+                                                                         float* __restrict__ partials, PoolOut po)
+{
+    constexpr int NT = CO > 128 ? 512 : 256, NW = NT / 64;
+    constexpr int CW = CO / NW, HT = CW / 16;          // columns / 16-column tiles per wave
+    constexpr int DBK = 32, LDA = CI + 4;             // 16-byte aligned rows; stride = 4 mod 32 banks
+    constexpr int PA = DBK * CI / 4 / NT;             // float4 loads per thread and chunk
+    static_assert(HT >= 1 && PA >= 1, "shape");
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    __shared__ __attribute__((aligned(16))) float sA[2][DBK * LDA];
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
+    const int col0 = wave * CW;
+    const int p0 = blockIdx.x * p_per_block;
+    const int p1 = min(P, p0 + p_per_block);
+    const int nchunks = (p1 - p0 + DBK - 1) / DBK;
+    if (nchunks <= 0) return;
+
+    float wfrag[HT][CI / 4];      // B[k][n] = W[n][k]: lane (l15, kq) holds W[col0 + 16h + l15][4*st + kq]
+#pragma unroll
+    for (int h = 0; h < HT; ++h)
+#pragma unroll
+        for (int st = 0; st < CI / 4; ++st) wfrag[h][st] = W[(size_t)(col0 + 16 * h + l15) * CI + 4 * st + kq];
+
+    const int ca = (tid % (CI / 4)) * 4, ka0 = tid / (CI / 4);
+    constexpr int KA_STEP = NT / (CI / 4);
+    ChanConst kc;
+    load_consts<SRC_ACT>(A, ca, kc);
+    Raw4<SRC_ACT> ra[PA];
+    auto gload = [&](int pk) {
+#pragma unroll
+        for (int ps = 0; ps < PA; ++ps) raw_load<SRC_ACT>(A, p1, pk + ka0 + ps * KA_STEP, ca, ra[ps]);
+    };
+    auto sstore = [&](int buf) {
+#pragma unroll
+        for (int ps = 0; ps < PA; ++ps)
+            *reinterpret_cast<float4*>(&sA[buf][(ka0 + ps * KA_STEP) * LDA + ca]) = finish<SRC_ACT>(ra[ps], kc);
+    };
+
+    double s1[HT], s2[HT];       // the chunk's 8 values are summed in fp32, the 32+ chunks of a workgroup in fp64
+    float gmax[HT], gmin[HT];
+    int gimax[HT], gimin[HT];
+#pragma unroll
+    for (int h = 0; h < HT; ++h) { s1[h] = 0.0; s2[h] = 0.0; gmax[h] = 0.0f; gmin[h] = 0.0f; gimax[h] = 0; gimin[h] = 0; }
+    const int cpg = POOL ? po.K / DBK : 1;            // chunks per group (1, 2 or 4)
+
+    gload(p0);
+    sstore(0);
+    __syncthreads();
+    for (int kcn = 0; kcn < nchunks; ++kcn) {
+        const int cur = kcn & 1;
+        if (kcn + 1 < nchunks) gload(p0 + (kcn + 1) * DBK);
+        f32x4 acc[2][HT];
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int h = 0; h < HT; ++h) acc[rt][h] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float* a0p = sA[cur] + l15 * LDA + kq;
+        const float* a1p = a0p + 16 * LDA;
+#pragma unroll
+        for (int st = 0; st < CI / 4; ++st) {
+            const float a0 = a0p[4 * st], a1 = a1p[4 * st];
+#pragma unroll
+            for (int h = 0; h < HT; ++h) {
+                acc[0][h] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, wfrag[h][st], acc[0][h], 0, 0, 0);
+                acc[1][h] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, wfrag[h][st], acc[1][h], 0, 0, 0);
+            }
+        }
+        const int pk = p0 + kcn * DBK;
+#pragma unroll
+        for (int h = 0; h < HT; ++h) {
+            const int col = col0 + 16 * h + l15;
+            float lmax = -__builtin_inff(), lmin = __builtin_inff();
+            int limax = 0, limin = 0;
+            float c1 = 0.0f, c2 = 0.0f;
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int row = 16 * rt + 4 * kq + i;      // ascending in (rt, i) for this lane
+                    const int pp = pk + row;
+                    if (pp < p1) {
+                        const float v = acc[rt][h][i];
+                        Z[(size_t)((unsigned)pp * (unsigned)CO + (unsigned)col)] = v;
+                        c1 += v;
+                        c2 += v * v;
+                        if constexpr (POOL) {
+                            if (v > lmax) { lmax = v; limax = row; }   // strict: the first extremum stays
+                            if (v < lmin) { lmin = v; limin = row; }
+                        }
+                    }
+                }
+            s1[h] += (double)c1;
+            s2[h] += (double)c2;
+            if constexpr (POOL) {
+                // the four kq lane groups hold interleaved rows: lexicographic (value, row) combine
+#pragma unroll
+                for (int d = 16; d <= 32; d <<= 1) {
+                    const float ox = __shfl_xor(lmax, d, 64), on = __shfl_xor(lmin, d, 64);
+                    const int oix = __shfl_xor(limax, d, 64), oin = __shfl_xor(limin, d, 64);
+                    if (ox > lmax || (ox == lmax && oix < limax)) { lmax = ox; limax = oix; }
+                    if (on < lmin || (on == lmin && oin < limin)) { lmin = on; limin = oin; }
+                }
+                const int cig = kcn % cpg;                // chunk inside its group (p0 is a multiple of K)
+                if (cig == 0 || lmax > gmax[h]) { gmax[h] = lmax; gimax[h] = cig * DBK + limax; }   // earlier chunk wins ties
+                if (cig == 0 || lmin < gmin[h]) { gmin[h] = lmin; gimin[h] = cig * DBK + limin; }
+                if (cig == cpg - 1 && kq == 0) {
+                    const size_t o = (size_t)((unsigned)(pk / po.K) * (unsigned)CO + (unsigned)col);
+                    po.vmax[o] = gmax[h]; po.imax[o] = gimax[h];
+                    po.vmin[o] = gmin[h]; po.imin[o] = gimin[h];
+                }
+            }
+        }
+        if (kcn + 1 < nchunks) sstore(cur ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int h = 0; h < HT; ++h) {
+        s1[h] += __shfl_xor(s1[h], 16, 64); s1[h] += __shfl_xor(s1[h], 32, 64);
+        s2[h] += __shfl_xor(s2[h], 16, 64); s2[h] += __shfl_xor(s2[h], 32, 64);
+        if (kq == 0) {
+            const int col = col0 + 16 * h + l15;
+            partials[((size_t)blockIdx.x * 2 + 0) * CO + col] = (float)s1[h];
+            partials[((size_t)blockIdx.x * 2 + 1) * CO + col] = (float)s2[h];
+        }
+    }
+}
+
+// =================================================================================================================
 // Kernel 4: dX and dW of one layer in ONE pass over dZ_l, for layers whose channels fit a single tile (CO in {64, 128}
 // outputs, 64 inputs: the HBM-bound layers of the first set-abstraction level).  Separately, dX streams (Z_l, G_l), reads
 // Z_{l-1} and writes G_{l-1}; dW streams (Z_l, G_l, Z_{l-1}) again: 7 tensor passes.  Here a workgroup walks 1024 positions
@@ -1024,6 +1163,13 @@ int launch_pos_gemm(const PosOperand& A, int64_t P, const float* W, int N, int K
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// MP_CHUNK_FWD=0 keeps the tiled GEMM kernel for every forward layer (A/B timing)
+inline bool chunk_fwd_enabled()
+{
+    static const bool on = !(getenv("MP_CHUNK_FWD") && atoi(getenv("MP_CHUNK_FWD")) == 0);
+    return on;
+}
+
 // MP_FUSED_BWD=0 keeps the separate dX / dW kernels for the single-tile layers (A/B timing)
 inline bool fused_bwd_enabled()
 {
@@ -1097,9 +1243,33 @@ extern "C" int mp_sa_mlp_fwd_f32(const float* x0, int64_t P, int64_t K, int n_la
     A.K = (int)K;
     for (int l = 0; l < n_layers; ++l) {
         const mp_mlp_layer_t& L = layers[l];
-        int nblk = 0, rc;
+        int nblk = 0, rc = MP_OK;
         const bool fuse_pool = (l == n_layers - 1) && fused_pool;
-        if (fuse_pool) {
+        const int Ci_ = (int)L.c_in, Co_ = (int)L.c_out;
+        const bool last_unfused = (l == n_layers - 1) && !fused_pool;
+        if (l > 0 && (Ci_ == 64 || Ci_ == 128) && (Co_ == 64 || Co_ == 128 || Co_ == 256) && (P % K) == 0 && (1024 % K == 0 || !fuse_pool) &&
+            chunk_fwd_enabled() && !(fuse_pool && (K % 32) != 0)) {
+            (void)last_unfused;
+            int ppb = 1024;
+            while ((P + ppb - 1) / ppb < 512 && ppb > 128 && (!fuse_pool || (ppb / 2) % K == 0)) ppb >>= 1;   // >= 512 workgroups when P allows
+            const unsigned gx = (unsigned)((P + ppb - 1) / ppb);
+            const double fl = 2.0 * (double)P * Co_ * Ci_, by = 4.0 * ((double)P * (Ci_ + Co_) + (double)Co_ * Ci_);
+            char tg[64];
+            snprintf(tg, sizeof tg, "fwd_chunk_kernel<%d, %d, %s>", Ci_, Co_, fuse_pool ? "pool" : "plain");
+#define MP_FWD(CI, CO, PL)                                                                                                     \
+    MP_LAUNCH(tg, fl, by, (fwd_chunk_kernel<CI, CO, PL>), dim3(gx), dim3(CO > 128 ? 512 : 256), 0, stream, A, (int)P, ppb, L.weight, L.z, \
+              partials, po)
+#define MP_FWD_CO(CI, PL)                                  \
+    if (Co_ == 64) MP_FWD(CI, 64, PL);                     \
+    else if (Co_ == 128) MP_FWD(CI, 128, PL);              \
+    else MP_FWD(CI, 256, PL)
+            if (fuse_pool) { if (Ci_ == 64) { MP_FWD_CO(64, true); } else { MP_FWD_CO(128, true); } }
+            else { if (Ci_ == 64) { MP_FWD_CO(64, false); } else { MP_FWD_CO(128, false); } }
+#undef MP_FWD_CO
+#undef MP_FWD
+            MP_CHECK_LAUNCH();
+            nblk = (int)gx;
+        } else if (fuse_pool) {
             if (l == 0)
                 rc = launch_pos_gemm<SRC_ID, false, EPI_SQ_POOL>(A, P, L.weight, (int)L.c_out, (int)L.c_in, L.z, partials,
                                                                  nullptr, nullptr, nullptr, stream, &nblk, po);
