@@ -687,17 +687,19 @@ __global__ __launch_bounds__(CO > 128 ? 512 : 256) void fwd_chunk_kernel(PosOper
 // The dX tile of a chunk is computed as eight 16x16 MFMA tiles, two per wave.
 // =================================================================================================================
 template <int MODE_DZ, int CO, int CI>
-__global__ __launch_bounds__(THREADS, 2) void bwd_fused_kernel(PosOperand DZ, PosOperand IN, int P, int p_per_block,
+__global__ __launch_bounds__((CO > 128 ? 512 : 256), (CO > 128 ? 1 : 2)) void bwd_fused_kernel(PosOperand DZ, PosOperand IN, int P, int p_per_block,
                                                             const float* __restrict__ W, float* __restrict__ dW,
                                                             float* __restrict__ G, float* __restrict__ partials)
 {
+    constexpr int NT = CO > 128 ? 512 : 256, NW = NT / 64;   // 8 waves for 256 output channels (register budget per wave)
     constexpr int DBK = CI == 128 ? 16 : 32;   // positions per chunk (LDS and registers: at least two workgroups per CU)
-    constexpr int XW = DBK == 32 ? CI / 2 : CI / 4;         // dX columns per wave (the chunk's dX tile is [DBK x CI])
+    constexpr int XW = DBK == 32 ? CI / 2 : CI / NW;        // dX columns per wave (the chunk's dX tile is [DBK x CI])
     constexpr int HT = XW / 16;                             // 16x16 dX tiles per wave and chunk
     constexpr int LDA = CO + 1;                 // odd: conflict-free both as [k][row] (dW) and as [row][k] (dX)
-    constexpr int TMW = CO / 64, TNW = CI / 64; // 32x32 dW tiles per wave (waves 2 x 2)
-    constexpr int PA = DBK * CO / 4 / THREADS, PB = DBK * CI / 4 / THREADS;
-    static_assert((CO == 64 || CO == 128) && (CI == 64 || CI == 128), "tile");
+    constexpr int TMW = CO / (32 * (NW / 2)), TNW = CI / 64; // 32x32 dW tiles per wave (waves (NW/2) x 2)
+    static_assert(NW == 4 || DBK == 16, "eight waves split the columns of a 16-position chunk");
+    constexpr int PA = DBK * CO / 4 / NT, PB = DBK * CI / 4 / NT;
+    static_assert((CO == 64 || CO == 128 || CO == 256) && (CI == 64 || CI == 128) && PA >= 1 && PB >= 1 && HT >= 1, "tile");
     __shared__ float sA[2][DBK * LDA];
     __shared__ __attribute__((aligned(16))) float sB[2][DBK * CI];
     __shared__ __attribute__((aligned(16))) float sZ[2][DBK * CI];
@@ -721,7 +723,7 @@ __global__ __launch_bounds__(THREADS, 2) void bwd_fused_kernel(PosOperand DZ, Po
     // every thread keeps the same channels for the whole kernel
     const int ca = (tid % (CO / 4)) * 4, cb = (tid % (CI / 4)) * 4;
     const int ka0 = tid / (CO / 4), kb0 = tid / (CI / 4);
-    constexpr int KA_STEP = THREADS / (CO / 4), KB_STEP = THREADS / (CI / 4);
+    constexpr int KA_STEP = NT / (CO / 4), KB_STEP = NT / (CI / 4);
     ChanConst ka, kb;
     load_consts<MODE_DZ>(DZ, ca, ka);
     load_consts<SRC_ACT>(IN, cb, kb);
@@ -814,7 +816,7 @@ __global__ __launch_bounds__(THREADS, 2) void bwd_fused_kernel(PosOperand DZ, Po
     }
     // BatchNorm-backward partial sums of layer l-1: the four 16-lane row groups of a wave, then (32-position chunks) the two
     // waves that share a column half
-    for (int e = tid; e < 2 * 2 * CI; e += THREADS) (&red[0][0][0])[e] = 0.0f;
+    for (int e = tid; e < 2 * 2 * CI; e += NT) (&red[0][0][0])[e] = 0.0f;
     __syncthreads();
 #pragma unroll
     for (int h = 0; h < HT; ++h) {
@@ -827,7 +829,7 @@ __global__ __launch_bounds__(THREADS, 2) void bwd_fused_kernel(PosOperand DZ, Po
         }
     }
     __syncthreads();
-    for (int e = tid; e < 2 * CI; e += THREADS) {
+    for (int e = tid; e < 2 * CI; e += NT) {
         const int st = e / CI, c = e - st * CI;
         partials[((size_t)blockIdx.x * 2 + st) * CI + c] = red[0][st][c] + red[1][st][c];
     }
@@ -1387,7 +1389,7 @@ extern "C" int mp_sa_mlp_bwd_f32(const float* x0, int64_t P, int64_t K, int n_la
 
         // dW_l = dZ_l^T * act(Z_{l-1})
         if (hipMemsetAsync(grads[l].d_weight, 0, sizeof(float) * (size_t)Co * Ci, stream) != hipSuccess) return MP_ELAUNCH;
-        if (l > 0 && (Ci == 64 || Ci == 128) && (Co == 64 || Co == 128) && fused_bwd_enabled()) {
+        if (l > 0 && (Ci == 64 || Ci == 128) && (Co == 64 || Co == 128 || (Co == 256 && Ci == 128)) && fused_bwd_enabled()) {
             // single-tile layer: dX, dW and the BatchNorm-backward sums of layer l-1 in one pass over dZ_l (bwd_fused_kernel)
             const mp_mlp_layer_t& Pv = layers[l - 1];
             float* Gn = gbuf[l & 1];
@@ -1399,9 +1401,11 @@ extern "C" int mp_sa_mlp_bwd_f32(const float* x0, int64_t P, int64_t K, int n_la
             char tg[64];
             snprintf(tg, sizeof tg, "bwd_fused_kernel<%d, %d, %d>", pooled ? 3 : 2, Co, Ci);
 #define MP_FUSED(MODE, CO_, CI_)                                                                                              \
-    MP_LAUNCH(tg, fl, by, (bwd_fused_kernel<MODE, CO_, CI_>), dim3(gx), dim3(THREADS), 0, stream, DZ, IN, (int)P, ppb, Ly.weight, \
+    MP_LAUNCH(tg, fl, by, (bwd_fused_kernel<MODE, CO_, CI_>), dim3(gx), dim3(CO_ > 128 ? 512 : 256), 0, stream, DZ, IN, (int)P, ppb, Ly.weight, \
               grads[l].d_weight, Gn, partials)
-            if (pooled) {
+            if (Co == 256) {
+                if (pooled) MP_FUSED(SRC_DZ_POOLED, 256, 128); else MP_FUSED(SRC_DZ, 256, 128);
+            } else if (pooled) {
                 if (Co == 64 && Ci == 64) MP_FUSED(SRC_DZ_POOLED, 64, 64);
                 else if (Co == 128 && Ci == 64) MP_FUSED(SRC_DZ_POOLED, 128, 64);
                 else if (Co == 64 && Ci == 128) MP_FUSED(SRC_DZ_POOLED, 64, 128);
