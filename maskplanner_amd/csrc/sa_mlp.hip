@@ -1257,7 +1257,7 @@ extern "C" int mp_sa_mlp_fwd_f32(const float* x0, int64_t P, int64_t K, int n_la
             const unsigned gx = (unsigned)((P + ppb - 1) / ppb);
             const double fl = 2.0 * (double)P * Co_ * Ci_, by = 4.0 * ((double)P * (Ci_ + Co_) + (double)Co_ * Ci_);
             char tg[64];
-            snprintf(tg, sizeof tg, "fwd_chunk_kernel<%d, %d, %s>", Ci_, Co_, fuse_pool ? "pool" : "plain");
+            snprintf(tg, sizeof tg, "fwd_chunk_kernel<%d, %d, %s>", Ci_, Co_, fuse_pool ? "true" : "false");
 #define MP_FWD(CI, CO, PL)                                                                                                     \
     MP_LAUNCH(tg, fl, by, (fwd_chunk_kernel<CI, CO, PL>), dim3(gx), dim3(CO > 128 ? 512 : 256), 0, stream, A, (int)P, ppb, L.weight, L.z, \
               partials, po)

@@ -46,7 +46,7 @@ with open(f"{out}/{tag}_bench_kernel_stats.md", "w") as f:
 traffic = {}
 for k, fz in fetch.items():
     wz = write.get(k)
-    if wz is not None and ("gemm" in k or "knn" in k or "fps" in k or "ball" in k or "pool" in k or "group" in k):
+    if wz is not None and any(t in k for t in ("gemm", "knn", "fps", "ball", "pool", "group", "fused", "chunk", "adam", "dw_ci4")):
         traffic[k.split("(")[0]] = dict(fetch_kib=fz, write_kib=wz, hbm_bytes=(2 * fz + wz) * 1024)
 json.dump(dict(source=f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes ({tag}), bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch",
                kernels=traffic), open(f"{out}/{tag}_traffic.json", "w"), indent=1)
