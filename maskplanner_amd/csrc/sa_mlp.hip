@@ -552,25 +552,29 @@ __global__ __launch_bounds__(CO > 128 ? 512 : 256) void fwd_chunk_kernel(PosOper
                                                                          float* __restrict__ partials, PoolOut po)
 {
     constexpr int NT = CO > 128 ? 512 : 256, NW = NT / 64;
-    constexpr int CW = CO / NW, HT = CW / 16;          // columns / 16-column tiles per wave
+    constexpr int CW = CO / NW;                       // columns per wave: 32 (one 32x32 MFMA tile) or 16 (two 16x16 tiles)
+    constexpr bool BIG = CW == 32;                    // v_mfma_f32_32x32x2_f32: a lane's 32 consecutive columns = whole 128-B lines
     constexpr int DBK = 32, LDA = CI + 4;             // 16-byte aligned rows; stride = 4 mod 32 banks
     constexpr int PA = DBK * CI / 4 / NT;             // float4 loads per thread and chunk
-    static_assert(HT >= 1 && PA >= 1, "shape");
+    constexpr int NFR = BIG ? CI / 2 : CI / 4;        // weight fragment registers per lane
+    constexpr int NV = BIG ? 16 : 8;                  // rows of the chunk held by one lane
+    static_assert((CW == 32 || CW == 16) && PA >= 1, "shape");
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     __shared__ __attribute__((aligned(16))) float sA[2][DBK * LDA];
     const int tid = threadIdx.x;
-    const int wave = tid >> 6, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
-    const int col0 = wave * CW;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int lc = BIG ? (lane & 31) : (lane & 15);   // column of this lane inside the wave's tile
+    const int kq = BIG ? (lane >> 5) : (lane >> 4);   // k sub-index / row group of this lane
+    const int col = wave * CW + lc;
     const int p0 = blockIdx.x * p_per_block;
     const int p1 = min(P, p0 + p_per_block);
     const int nchunks = (p1 - p0 + DBK - 1) / DBK;
     if (nchunks <= 0) return;
 
-    float wfrag[HT][CI / 4];      // B[k][n] = W[n][k]: lane (l15, kq) holds W[col0 + 16h + l15][4*st + kq]
+    // B[k][n] = W[n][k]: 32x32x2 lane (n, kq) holds W[col][2*st + kq]; 16x16x4 lane (n, kq) holds W[col][4*st + kq]
+    float wfrag[NFR];
 #pragma unroll
-    for (int h = 0; h < HT; ++h)
-#pragma unroll
-        for (int st = 0; st < CI / 4; ++st) wfrag[h][st] = W[(size_t)(col0 + 16 * h + l15) * CI + 4 * st + kq];
+    for (int st = 0; st < NFR; ++st) wfrag[st] = W[(size_t)col * CI + (BIG ? 2 : 4) * st + kq];
 
     const int ca = (tid % (CI / 4)) * 4, ka0 = tid / (CI / 4);
     constexpr int KA_STEP = NT / (CI / 4);
@@ -587,11 +591,9 @@ __global__ __launch_bounds__(CO > 128 ? 512 : 256) void fwd_chunk_kernel(PosOper
             *reinterpret_cast<float4*>(&sA[buf][(ka0 + ps * KA_STEP) * LDA + ca]) = finish<SRC_ACT>(ra[ps], kc);
     };
 
-    double s1[HT], s2[HT];       // the chunk's 8 values are summed in fp32, the 32+ chunks of a workgroup in fp64
-    float gmax[HT], gmin[HT];
-    int gimax[HT], gimin[HT];
-#pragma unroll
-    for (int h = 0; h < HT; ++h) { s1[h] = 0.0; s2[h] = 0.0; gmax[h] = 0.0f; gmin[h] = 0.0f; gimax[h] = 0; gimin[h] = 0; }
+    double s1 = 0.0, s2 = 0.0;     // the chunk's values are summed in fp32, the 16-32 chunks of a workgroup in fp64
+    float gmax = 0.0f, gmin = 0.0f;
+    int gimax = 0, gimin = 0;
     const int cpg = POOL ? po.K / DBK : 1;            // chunks per group (1, 2 or 4)
 
     gload(p0);
@@ -600,79 +602,77 @@ __global__ __launch_bounds__(CO > 128 ? 512 : 256) void fwd_chunk_kernel(PosOper
     for (int kcn = 0; kcn < nchunks; ++kcn) {
         const int cur = kcn & 1;
         if (kcn + 1 < nchunks) gload(p0 + (kcn + 1) * DBK);
-        f32x4 acc[2][HT];
+        float v[NV];
+        int vrow[NV];
+        if constexpr (BIG) {
+            f32x16 acc;
 #pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
+            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+            const float* ap = sA[cur] + (lane & 31) * LDA + kq;       // A[row = lane & 31][k = 2*st + kq]
 #pragma unroll
-            for (int h = 0; h < HT; ++h) acc[rt][h] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const float* a0p = sA[cur] + l15 * LDA + kq;
-        const float* a1p = a0p + 16 * LDA;
+            for (int st = 0; st < NFR; ++st) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * st], wfrag[st], acc, 0, 0, 0);
 #pragma unroll
-        for (int st = 0; st < CI / 4; ++st) {
-            const float a0 = a0p[4 * st], a1 = a1p[4 * st];
+            for (int r = 0; r < 16; ++r) { v[r] = acc[r]; vrow[r] = acc_row_in_tile(r); }   // ascending in r for this lane
+        } else {
+            f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+            const float* a0p = sA[cur] + lc * LDA + kq;               // A[row = 16*rt + lc][k = 4*st + kq]
+            const float* a1p = a0p + 16 * LDA;
 #pragma unroll
-            for (int h = 0; h < HT; ++h) {
-                acc[0][h] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, wfrag[h][st], acc[0][h], 0, 0, 0);
-                acc[1][h] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, wfrag[h][st], acc[1][h], 0, 0, 0);
+            for (int st = 0; st < NFR; ++st) {
+                a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0p[4 * st], wfrag[st], a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1p[4 * st], wfrag[st], a1, 0, 0, 0);
             }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { v[i] = a0[i]; vrow[i] = 4 * kq + i; v[4 + i] = a1[i]; vrow[4 + i] = 16 + 4 * kq + i; }
         }
         const int pk = p0 + kcn * DBK;
+        float lmax = -__builtin_inff(), lmin = __builtin_inff();
+        int limax = 0, limin = 0;
+        float c1 = 0.0f, c2 = 0.0f;
 #pragma unroll
-        for (int h = 0; h < HT; ++h) {
-            const int col = col0 + 16 * h + l15;
-            float lmax = -__builtin_inff(), lmin = __builtin_inff();
-            int limax = 0, limin = 0;
-            float c1 = 0.0f, c2 = 0.0f;
-#pragma unroll
-            for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int row = 16 * rt + 4 * kq + i;      // ascending in (rt, i) for this lane
-                    const int pp = pk + row;
-                    if (pp < p1) {
-                        const float v = acc[rt][h][i];
-                        Z[(size_t)((unsigned)pp * (unsigned)CO + (unsigned)col)] = v;
-                        c1 += v;
-                        c2 += v * v;
-                        if constexpr (POOL) {
-                            if (v > lmax) { lmax = v; limax = row; }   // strict: the first extremum stays
-                            if (v < lmin) { lmin = v; limin = row; }
-                        }
-                    }
+        for (int r = 0; r < NV; ++r) {
+            const int pp = pk + vrow[r];
+            if (pp < p1) {
+                Z[(size_t)((unsigned)pp * (unsigned)CO + (unsigned)col)] = v[r];
+                c1 += v[r];
+                c2 += v[r] * v[r];
+                if constexpr (POOL) {
+                    if (v[r] > lmax) { lmax = v[r]; limax = vrow[r]; }   // strict: the first extremum stays
+                    if (v[r] < lmin) { lmin = v[r]; limin = vrow[r]; }
                 }
-            s1[h] += (double)c1;
-            s2[h] += (double)c2;
-            if constexpr (POOL) {
-                // the four kq lane groups hold interleaved rows: lexicographic (value, row) combine
+            }
+        }
+        s1 += (double)c1;
+        s2 += (double)c2;
+        if constexpr (POOL) {
+            // the lane groups of a column hold interleaved rows: lexicographic (value, row) combine
 #pragma unroll
-                for (int d = 16; d <= 32; d <<= 1) {
-                    const float ox = __shfl_xor(lmax, d, 64), on = __shfl_xor(lmin, d, 64);
-                    const int oix = __shfl_xor(limax, d, 64), oin = __shfl_xor(limin, d, 64);
-                    if (ox > lmax || (ox == lmax && oix < limax)) { lmax = ox; limax = oix; }
-                    if (on < lmin || (on == lmin && oin < limin)) { lmin = on; limin = oin; }
-                }
-                const int cig = kcn % cpg;                // chunk inside its group (p0 is a multiple of K)
-                if (cig == 0 || lmax > gmax[h]) { gmax[h] = lmax; gimax[h] = cig * DBK + limax; }   // earlier chunk wins ties
-                if (cig == 0 || lmin < gmin[h]) { gmin[h] = lmin; gimin[h] = cig * DBK + limin; }
-                if (cig == cpg - 1 && kq == 0) {
-                    const size_t o = (size_t)((unsigned)(pk / po.K) * (unsigned)CO + (unsigned)col);
-                    po.vmax[o] = gmax[h]; po.imax[o] = gimax[h];
-                    po.vmin[o] = gmin[h]; po.imin[o] = gimin[h];
-                }
+            for (int d = BIG ? 32 : 16; d <= 32; d <<= 1) {
+                const float ox = __shfl_xor(lmax, d, 64), on = __shfl_xor(lmin, d, 64);
+                const int oix = __shfl_xor(limax, d, 64), oin = __shfl_xor(limin, d, 64);
+                if (ox > lmax || (ox == lmax && oix < limax)) { lmax = ox; limax = oix; }
+                if (on < lmin || (on == lmin && oin < limin)) { lmin = on; limin = oin; }
+            }
+            const int cig = kcn % cpg;                // chunk inside its group (p0 is a multiple of K)
+            if (cig == 0 || lmax > gmax) { gmax = lmax; gimax = cig * DBK + limax; }   // earlier chunk wins ties
+            if (cig == 0 || lmin < gmin) { gmin = lmin; gimin = cig * DBK + limin; }
+            if (cig == cpg - 1 && kq == 0) {
+                const size_t o = (size_t)((unsigned)(pk / po.K) * (unsigned)CO + (unsigned)col);
+                po.vmax[o] = gmax; po.imax[o] = gimax;
+                po.vmin[o] = gmin; po.imin[o] = gimin;
             }
         }
         if (kcn + 1 < nchunks) sstore(cur ^ 1);
         __syncthreads();
     }
 #pragma unroll
-    for (int h = 0; h < HT; ++h) {
-        s1[h] += __shfl_xor(s1[h], 16, 64); s1[h] += __shfl_xor(s1[h], 32, 64);
-        s2[h] += __shfl_xor(s2[h], 16, 64); s2[h] += __shfl_xor(s2[h], 32, 64);
-        if (kq == 0) {
-            const int col = col0 + 16 * h + l15;
-            partials[((size_t)blockIdx.x * 2 + 0) * CO + col] = (float)s1[h];
-            partials[((size_t)blockIdx.x * 2 + 1) * CO + col] = (float)s2[h];
-        }
+    for (int d = BIG ? 32 : 16; d <= 32; d <<= 1) {
+        s1 += __shfl_xor(s1, d, 64);
+        s2 += __shfl_xor(s2, d, 64);
+    }
+    if (kq == 0) {
+        partials[((size_t)blockIdx.x * 2 + 0) * CO + col] = (float)s1;
+        partials[((size_t)blockIdx.x * 2 + 1) * CO + col] = (float)s2;
     }
 }
 
