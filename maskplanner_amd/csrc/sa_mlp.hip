@@ -851,6 +851,116 @@ __global__ __launch_bounds__((CO > 128 ? 512 : 256), (CO > 128 ? 1 : 2)) void bw
 // tile would be 1/16 full), and the kernel is a pure stream over dZ = (Z_1, G_1).  Thread (position lane, channel quad):
 // 64 position lanes x (CO/4) quads; every thread walks positions lane, lane+PL, ... of its workgroup's slice with float4
 // loads of dZ and of the input row, 16 FMAs each; lanes are combined through LDS and added to dW with atomics.
+// Kernel 4b: the same single pass for the FIRST layer of a level whose grouped input is [128 features | xyz | pad] (132
+// columns): dW [128 x 132] (128 columns by MFMA, the 4 coordinate columns by plain FMAs on the staged tiles) and the
+// feature part of grad_x0 (128 columns; coordinates carry no gradient), no BatchNorm sums (there is no layer below).
+template <int MODE_DZ>
+__global__ __launch_bounds__(512) void bwd_first_kernel(PosOperand DZ, PosOperand IN, int P, int p_per_block,
+                                                           const float* __restrict__ W, float* __restrict__ dW,
+                                                           float* __restrict__ G)
+{
+    constexpr int CO = 128, CIW = 132, CIX = 128, DBK = 16, LDA = CO + 1, LDB = CIW;
+    constexpr int NT = 512;                             // eight waves: half the accumulators / weight fragments per wave
+    constexpr int PA = DBK * CO / 4 / NT;               // 1
+    constexpr int NB4 = DBK * CIW / 4;                  // 528 float4 of the input chunk
+    constexpr int PB = (NB4 + NT - 1) / NT;             // 2 (the last pass has 16 live threads)
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    __shared__ float sA[2][DBK * LDA];
+    __shared__ __attribute__((aligned(16))) float sB[2][DBK * LDB];
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63, l15 = lane & 15, kq = lane >> 4, l31 = lane & 31;
+    const int wrow0 = (wave >> 1) * 32, wcol0 = (wave & 1) * 64;   // dW tiles: waves 4 x 2, 1 x 2 tiles of 32 x 32 each
+    const int p0 = blockIdx.x * p_per_block;
+    const int p1 = min(P, p0 + p_per_block);
+    const int nchunks = (p1 - p0 + DBK - 1) / DBK;
+    if (nchunks <= 0) return;
+
+    f32x16 accW[1][2];
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accW[0][ni][r] = 0.0f;
+    float tacc = 0.0f;                                  // dW[tid & 127][128 + (tid >> 7)]
+
+    const int xcol0 = wave * 16;                        // this wave's 16 grad_x0 columns (one 16x16 tile)
+    float wfrag[CO / 4];
+#pragma unroll
+    for (int st = 0; st < CO / 4; ++st) wfrag[st] = W[(size_t)(4 * st + kq) * CIW + xcol0 + l15];
+
+    const int ca = (tid % (CO / 4)) * 4, ka0 = tid / (CO / 4);
+    constexpr int KA_STEP = NT / (CO / 4);
+    ChanConst ka, kb;
+    load_consts<MODE_DZ>(DZ, ca, ka);
+    Raw4<MODE_DZ> ra[PA];
+    Raw4<SRC_ID> rb[PB];
+    int brow[PB], bcol[PB];                              // this thread's (row, column) of the input chunk, per pass
+#pragma unroll
+    for (int ps = 0; ps < PB; ++ps) {
+        const int e = ps * NT + tid;
+        brow[ps] = e / (CIW / 4);
+        bcol[ps] = (e - brow[ps] * (CIW / 4)) * 4;
+    }
+    auto gload = [&](int pk) {
+#pragma unroll
+        for (int ps = 0; ps < PA; ++ps) raw_load<MODE_DZ>(DZ, p1, pk + ka0 + ps * KA_STEP, ca, ra[ps]);
+#pragma unroll
+        for (int ps = 0; ps < PB; ++ps)
+            if (ps * NT + tid < NB4) raw_load<SRC_ID>(IN, p1, pk + brow[ps], bcol[ps], rb[ps]);
+    };
+    auto sstore = [&](int buf) {
+#pragma unroll
+        for (int ps = 0; ps < PA; ++ps) {
+            const float4 v = finish<MODE_DZ>(ra[ps], ka);
+            float* d = &sA[buf][(ka0 + ps * KA_STEP) * LDA + ca];
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+#pragma unroll
+        for (int ps = 0; ps < PB; ++ps) {
+            const int e = ps * NT + tid;
+            if (e < NB4) *reinterpret_cast<float4*>(&sB[buf][e * 4]) = finish<SRC_ID>(rb[ps], kb);
+        }
+    };
+
+    gload(p0);
+    sstore(0);
+    __syncthreads();
+    for (int kc = 0; kc < nchunks; ++kc) {
+        const int cur = kc & 1;
+        if (kc + 1 < nchunks) gload(p0 + (kc + 1) * DBK);
+        mma_chunk<true, true, LDA, LDB, 1, 2, DBK>(sA[cur], sB[cur], wrow0, wcol0, accW);   // dW[:, 0:128] += dZ^T * X
+        {   // the 4 coordinate columns of dW
+            const float* a = sA[cur] + (tid & 127);
+            const float* t = sB[cur] + CIX + (tid >> 7);
+#pragma unroll
+            for (int k = 0; k < DBK; ++k) tacc = __builtin_fmaf(a[k * LDA], t[k * LDB], tacc);
+        }
+        {   // grad_x0 chunk [16 x 128] = dZ [16 x 128] * W[:, 0:128]
+            f32x4 ax = {0.f, 0.f, 0.f, 0.f};
+            const float* arow = sA[cur] + l15 * LDA + kq;
+#pragma unroll
+            for (int st = 0; st < CO / 4; ++st) ax = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[4 * st], wfrag[st], ax, 0, 0, 0);
+            const int pk = p0 + kc * DBK;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int pp = pk + 4 * kq + i;
+                if (pp < p1) G[(size_t)((unsigned)pp * (unsigned)CIW + (unsigned)(xcol0 + l15))] = ax[i];
+            }
+        }
+        if (kc + 1 < nchunks) sstore(cur ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        const int col = wcol0 + ni * 32 + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = wrow0 + acc_row_in_tile(r);
+            atomicAdd(dW + (size_t)(row * CIW + col), accW[0][ni][r]);
+        }
+    }
+    atomicAdd(dW + (size_t)((tid & 127) * CIW + CIX + (tid >> 7)), tacc);
+}
+
 template <int MODE_DZ, int MODE_IN>
 __global__ __launch_bounds__(256) void dw_ci4_kernel(PosOperand DZ, PosOperand IN, int P, int p_per_block, float* __restrict__ dW)
 {
@@ -1423,6 +1533,20 @@ extern "C" int mp_sa_mlp_bwd_f32(const float* x0, int64_t P, int64_t K, int n_la
                                grads[l - 1].d_beta, grads[l - 1].d_bias, cbuf[0], cbuf[1], cbuf[2]);
             MP_CHECK_LAUNCH();
             G_cur = Gn;
+            continue;
+        }
+        if (l == 0 && grad_x0 && Co == 128 && Ci == 132 && grad_x0_cols == 128 && fused_bwd_enabled()) {
+            // first layer of a level with a [128 features | xyz | pad] input: dW and the feature columns of grad_x0 in one pass
+            const int ppb = 1024;
+            const unsigned gx = (unsigned)((P + ppb - 1) / ppb);
+            const double fl = 2.0 * (double)P * Co * (Ci + 128), by = 4.0 * ((pooled ? 1.0 : 2.0) * (double)P * Co + (double)P * (Ci + 128));
+            if (pooled)
+                MP_LAUNCH("bwd_first_kernel<3>", fl, by, (bwd_first_kernel<SRC_DZ_POOLED>), dim3(gx), dim3(512), 0, stream, DZ, IN, (int)P, ppb,
+                          Ly.weight, grads[l].d_weight, grad_x0);
+            else
+                MP_LAUNCH("bwd_first_kernel<2>", fl, by, (bwd_first_kernel<SRC_DZ>), dim3(gx), dim3(512), 0, stream, DZ, IN, (int)P, ppb, Ly.weight,
+                          grads[l].d_weight, grad_x0);
+            MP_CHECK_LAUNCH();
             continue;
         }
         {
