@@ -687,17 +687,17 @@ __global__ __launch_bounds__(CO > 128 ? 512 : 256) void fwd_chunk_kernel(PosOper
 // The dX tile of a chunk is computed as eight 16x16 MFMA tiles, two per wave.
 // =================================================================================================================
 template <int MODE_DZ, int CO, int CI>
-__global__ __launch_bounds__((CO > 128 ? 512 : 256), (CO > 128 ? 1 : 2)) void bwd_fused_kernel(PosOperand DZ, PosOperand IN, int P, int p_per_block,
+__global__ __launch_bounds__((CO >= 128 && CI == 128 ? 512 : 256), (CO >= 128 && CI == 128 ? 1 : 2)) void bwd_fused_kernel(PosOperand DZ, PosOperand IN, int P, int p_per_block,
                                                             const float* __restrict__ W, float* __restrict__ dW,
                                                             float* __restrict__ G, float* __restrict__ partials)
 {
-    constexpr int NT = CO > 128 ? 512 : 256, NW = NT / 64;   // 8 waves for 256 output channels (register budget per wave)
+    constexpr int NT = (CO >= 128 && CI == 128) ? 512 : 256, NW = NT / 64;  // 8 waves for the 128-input layers (registers per wave)
     constexpr int DBK = CI == 128 ? 16 : 32;   // positions per chunk (LDS and registers: at least two workgroups per CU)
-    constexpr int XW = DBK == 32 ? CI / 2 : CI / NW;        // dX columns per wave (the chunk's dX tile is [DBK x CI])
+    constexpr int XW = DBK == 32 ? CI / (NW / 2) : CI / NW; // dX columns per wave (the chunk's dX tile is [DBK x CI])
     constexpr int HT = XW / 16;                             // 16x16 dX tiles per wave and chunk
     constexpr int LDA = CO + 1;                 // odd: conflict-free both as [k][row] (dW) and as [row][k] (dX)
     constexpr int TMW = CO / (32 * (NW / 2)), TNW = CI / 64; // 32x32 dW tiles per wave (waves (NW/2) x 2)
-    static_assert(NW == 4 || DBK == 16, "eight waves split the columns of a 16-position chunk");
+
     constexpr int PA = DBK * CO / 4 / NT, PB = DBK * CI / 4 / NT;
     static_assert((CO == 64 || CO == 128 || CO == 256) && (CI == 64 || CI == 128) && PA >= 1 && PB >= 1 && HT >= 1, "tile");
     __shared__ float sA[2][DBK * LDA];
@@ -751,11 +751,11 @@ __global__ __launch_bounds__((CO > 128 ? 512 : 256), (CO > 128 ? 1 : 2)) void bw
     };
 
     const int l31 = lane & 31;
-    // dX tiles of this wave: 32-position chunks: rows 16*(wave>>1).., columns (CI/2)*(wave&1)..; 16-position chunks: rows 0..15,
-    // columns (CI/4)*wave..  The W_l fragments of those columns never change: they live in registers for the whole kernel
+    // dX tiles of this wave: 32-position chunks: two row tiles x NW/2 column groups; 16-position chunks: rows 0..15, columns
+    // (CI/NW)*wave..  The W_l fragments of those columns never change: they live in registers for the whole kernel
     // (v_mfma_f32_16x16x4_f32 B operand: lane (l15, kq) holds W[4*step + kq][col]), so W_l costs no LDS.
-    const int xrow0 = DBK == 32 ? (wave >> 1) * 16 : 0;
-    const int xcol0 = DBK == 32 ? (wave & 1) * XW : wave * XW;
+    const int xrow0 = DBK == 32 ? (wave / (NW / 2)) * 16 : 0;
+    const int xcol0 = DBK == 32 ? (wave % (NW / 2)) * XW : wave * XW;
     float wfrag[HT][CO / 4];
 #pragma unroll
     for (int h = 0; h < HT; ++h)
@@ -824,8 +824,8 @@ __global__ __launch_bounds__((CO > 128 ? 512 : 256), (CO > 128 ? 1 : 2)) void bw
         s2x[h] += __shfl_xor(s2x[h], 16, 64); s2x[h] += __shfl_xor(s2x[h], 32, 64);
         if (lane < 16) {
             const int col = xcol0 + 16 * h + lane;
-            red[DBK == 32 ? (wave >> 1) : 0][0][col] = s1x[h];
-            red[DBK == 32 ? (wave >> 1) : 0][1][col] = s2x[h];
+            red[DBK == 32 ? (wave / (NW / 2)) : 0][0][col] = s1x[h];
+            red[DBK == 32 ? (wave / (NW / 2)) : 0][1][col] = s2x[h];
         }
     }
     __syncthreads();
@@ -1511,7 +1511,7 @@ extern "C" int mp_sa_mlp_bwd_f32(const float* x0, int64_t P, int64_t K, int n_la
             char tg[64];
             snprintf(tg, sizeof tg, "bwd_fused_kernel<%d, %d, %d>", pooled ? 3 : 2, Co, Ci);
 #define MP_FUSED(MODE, CO_, CI_)                                                                                              \
-    MP_LAUNCH(tg, fl, by, (bwd_fused_kernel<MODE, CO_, CI_>), dim3(gx), dim3(CO_ > 128 ? 512 : 256), 0, stream, DZ, IN, (int)P, ppb, Ly.weight, \
+    MP_LAUNCH(tg, fl, by, (bwd_fused_kernel<MODE, CO_, CI_>), dim3(gx), dim3((CO_ >= 128 && CI_ == 128) ? 512 : 256), 0, stream, DZ, IN, (int)P, ppb, Ly.weight, \
               grads[l].d_weight, Gn, partials)
             if (Co == 256) {
                 if (pooled) MP_FUSED(SRC_DZ_POOLED, 256, 128); else MP_FUSED(SRC_DZ, 256, 128);
