@@ -122,64 +122,95 @@ __global__ __launch_bounds__(256) void linear_dx_skinny_kernel(const float* __re
     }
     __syncthreads();
     if (i >= I) return;
-    float acc[SK_B][4];
+    // two-wide accumulators: the inner product is VALU-bound with scalar FMAs (128 per weight row per thread), and
+    // v_pk_fma_f32 retires two per lane per pass
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 acc[SK_B][2];
 #pragma unroll
-    for (int b = 0; b < SK_B; ++b) acc[b][0] = acc[b][1] = acc[b][2] = acc[b][3] = 0.0f;
+    for (int b = 0; b < SK_B; ++b) acc[b][0] = acc[b][1] = f2{0.0f, 0.0f};
     const int rows = min(SK_ROWS, O - o0);
-    constexpr int U = 8;   // weight rows in flight per thread: the loop is bound by HBM latency otherwise
-    for (int ob = 0; ob < rows; ob += U) {
-        float4 w[U];
+    // Software pipeline: one wave per SIMD runs here (188 workgroups of 64 rows for the 11988-row heads), so nothing
+    // else hides the HBM latency -- the next 8 weight rows are requested before the current 8 are consumed.
+    constexpr int U = 8;
+    const float* Wc = W + (size_t)o0 * I + i;
+    auto fetch = [&](float4 (&w)[U], int ob) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int o = min(ob + u, rows - 1);   // clamped: the duplicate rows are skipped below
-            w[u] = *reinterpret_cast<const float4*>(W + (size_t)(o0 + o) * I + i);
+            const int o = min(ob + u, rows - 1);   // clamped: the duplicate rows are skipped in consume()
+            w[u] = *reinterpret_cast<const float4*>(Wc + (size_t)o * I);
         }
+    };
+    auto consume = [&](const float4 (&w)[U], int ob) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (ob + u < rows) {
+                const f2 wlo = {w[u].x, w[u].y}, whi = {w[u].z, w[u].w};
 #pragma unroll
-            for (int b4 = 0; b4 < SK_B; b4 += 4) {
-                const float4 gv = *reinterpret_cast<const float4*>(&sg[ob + u][b4]);   // broadcast read of 4 batch rows
-                const float gb[4] = {gv.x, gv.y, gv.z, gv.w};
+                for (int b4 = 0; b4 < SK_B; b4 += 4) {
+                    const float4 gv = *reinterpret_cast<const float4*>(&sg[ob + u][b4]);   // broadcast read of 4 batch rows
+                    const float gb[4] = {gv.x, gv.y, gv.z, gv.w};
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    acc[b4 + q][0] = __builtin_fmaf(gb[q], w[u].x, acc[b4 + q][0]);
-                    acc[b4 + q][1] = __builtin_fmaf(gb[q], w[u].y, acc[b4 + q][1]);
-                    acc[b4 + q][2] = __builtin_fmaf(gb[q], w[u].z, acc[b4 + q][2]);
-                    acc[b4 + q][3] = __builtin_fmaf(gb[q], w[u].w, acc[b4 + q][3]);
+                    for (int q = 0; q < 4; ++q) {
+                        const f2 gg = {gb[q], gb[q]};
+                        acc[b4 + q][0] = __builtin_elementwise_fma(gg, wlo, acc[b4 + q][0]);
+                        acc[b4 + q][1] = __builtin_elementwise_fma(gg, whi, acc[b4 + q][1]);
+                    }
                 }
             }
-            }
         }
+    };
+    float4 wa[U], wb[U];
+    fetch(wa, 0);
+    for (int ob = 0; ob < rows; ob += 2 * U) {
+        fetch(wb, ob + U);
+        consume(wa, ob);
+        fetch(wa, ob + 2 * U);
+        consume(wb, ob + U);
     }
     float* pb = partial + (size_t)blockIdx.y * B * I;
 #pragma unroll   // compile-time register indices: a run-time loop bound would push acc[][] to scratch
     for (int b = 0; b < SK_B; ++b) {
-        if (b < B) *reinterpret_cast<float4*>(pb + (size_t)b * I + i) = make_float4(acc[b][0], acc[b][1], acc[b][2], acc[b][3]);
+        if (b < B) *reinterpret_cast<float4*>(pb + (size_t)b * I + i) = make_float4(acc[b][0].x, acc[b][0].y, acc[b][1].x, acc[b][1].y);
     }
 }
 
-__global__ __launch_bounds__(64) void sum_partials_kernel(const float* __restrict__ partial, int nblk, int n4,
-                                                          float* __restrict__ out)
+__global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ partial, int nblk, int n4,
+                                                           float* __restrict__ out)
 {
-    const int e = blockIdx.x * 64 + threadIdx.x;   // one float4 of the [B, I] result
-    if (e >= n4) return;
-    // fixed summation order (block 0, 1, 2, ...), 8 independent loads in flight per thread
-    const float4* src = reinterpret_cast<const float4*>(partial) + e;
+    // 64 float4 elements of the [B, I] result per workgroup; the nblk partials of an element are split into four
+    // contiguous slices (one per wave, 8 loads in flight each) and the slice sums are added in slice order, so the
+    // summation tree is fixed: the result does not depend on scheduling.
+    __shared__ float4 part[4][64];
+    const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + lane;
+    const int per = (nblk + 3) / 4;
+    const int k0 = min(slice * per, nblk), k1 = min(k0 + per, nblk);
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-    int k = 0;
-    for (; k + 8 <= nblk; k += 8) {
-        float4 v[8];
+    if (e < n4) {
+        const float4* src = reinterpret_cast<const float4*>(partial) + e;
+        int k = k0;
+        for (; k + 8 <= k1; k += 8) {
+            float4 v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(k + u) * n4];
+            for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(k + u) * n4];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { a.x += v[u].x; a.y += v[u].y; a.z += v[u].z; a.w += v[u].w; }
+            for (int u = 0; u < 8; ++u) { a.x += v[u].x; a.y += v[u].y; a.z += v[u].z; a.w += v[u].w; }
+        }
+        for (; k < k1; ++k) {
+            const float4 v = src[(size_t)k * n4];
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
     }
-    for (; k < nblk; ++k) {
-        const float4 v = src[(size_t)k * n4];
-        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    part[slice][lane] = a;
+    __syncthreads();
+    if (slice == 0 && e < n4) {
+#pragma unroll
+        for (int q = 1; q < 4; ++q) {
+            const float4 v = part[q][lane];
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+        reinterpret_cast<float4*>(out)[e] = a;
     }
-    reinterpret_cast<float4*>(out)[e] = a;
 }
 
 }  // namespace
@@ -216,14 +247,14 @@ extern "C" int mp_linear_dx_skinny_f32(const float* g, const float* weight, int6
     if (B > SK_B || (I & 3)) return MP_EUNSUPPORTED;
     if (workspace_bytes < mp_linear_dx_skinny_workspace_bytes(B, O, I)) return MP_EWORKSPACE;
     hipStream_t stream = mp_stream(stream_);
-    if (O == 0) return hipMemsetAsync(grad_x, 0, sizeof(float) * (size_t)(B * I), stream) == hipSuccess ? MP_OK : MP_ELAUNCH;
+    if (O == 0) return mp::zero_async(grad_x, (size_t)(B * I), stream) ? MP_OK : MP_ELAUNCH;
     const int nblk = (int)((O + SK_ROWS - 1) / SK_ROWS);
     const dim3 grid((unsigned)((I / 4 + 255) / 256), (unsigned)nblk);
     MP_LAUNCH("linear_dx_skinny_kernel", 2.0 * (double)B * O * I, 4.0 * ((double)O * I + (double)B * (O + I)), linear_dx_skinny_kernel,
               grid, dim3(256), 0, stream, g, weight, (int)B, (int)O, (int)I, reinterpret_cast<float*>(workspace));
     MP_CHECK_LAUNCH();
     const int n4 = (int)(B * I / 4);
-    MP_LAUNCH("sum_partials_kernel", 0.0, 4.0 * (double)nblk * B * I, sum_partials_kernel, dim3((n4 + 63) / 64), dim3(64), 0, stream,
+    MP_LAUNCH("sum_partials_kernel", 0.0, 4.0 * (double)nblk * B * I, sum_partials_kernel, dim3((n4 + 63) / 64), dim3(256), 0, stream,
               reinterpret_cast<const float*>(workspace), nblk, n4, grad_x);
     MP_CHECK_LAUNCH();
     return MP_OK;

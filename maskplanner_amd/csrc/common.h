@@ -107,3 +107,27 @@ __device__ __forceinline__ float wave_sum_f32(float v)
 }
 
 }  // namespace mp
+
+// Zero fill as an ordinary kernel.  hipMemsetAsync must not be used on the compute path: recorded into a hipGraph it
+// becomes a memset node, and on ROCm 7.2 replays were observed (tools/graph_nan_check.py) to run the following kernel
+// against the buffer's stale contents now and then -- a dW accumulated by atomics on top of garbage.  A kernel node
+// keeps the plain stream order.
+namespace mp {
+static __global__ __launch_bounds__(256) void zero_fill_kernel(float* __restrict__ p, size_t n4, size_t n)
+{
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride)
+        reinterpret_cast<float4*>(p)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (size_t i = n4 * 4 + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) p[i] = 0.0f;
+}
+
+static inline bool zero_async(float* p, size_t n, hipStream_t stream)
+{
+    if (n == 0) return true;
+    const size_t n4 = (reinterpret_cast<uintptr_t>(p) & 15) ? 0 : n / 4;   // float4 stores need 16-byte alignment
+    size_t blocks = ((n4 ? n4 : n) + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, p, n4, n);
+    return hipGetLastError() == hipSuccess;
+}
+}  // namespace mp

@@ -300,7 +300,7 @@ extern "C" int mp_index_points_bwd_f32(const float* grad_out, const int64_t* idx
         hipLaunchKernelGGL(scatter_rows_ordered_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream,
                            grad_out, idx, N, C, M, C, (int64_t)0, rows, grad_points);
     } else {
-        if (hipMemsetAsync(grad_points, 0, sizeof(float) * (size_t)(B * N * C), stream) != hipSuccess) return MP_ELAUNCH;
+        if (!mp::zero_async(grad_points, (size_t)(B * N * C), stream)) return MP_ELAUNCH;
         const int64_t total = B * M * C;
         if (total > 0)
             hipLaunchKernelGGL(scatter_rows_atomic_kernel, dim3(grid_for(total)), dim3(256), 0, stream, grad_out, idx,
@@ -358,7 +358,7 @@ extern "C" int mp_group_bwd_f32(const float* grad_out, const int64_t* idx, int64
         MP_LAUNCH("group_bwd_gather_kernel", 0.0, 4.0 * (double)(B * S * K) * (D + 2) + 4.0 * (double)(B * N * D), group_bwd_gather_kernel,
                   dim3((unsigned)((N + GP - 1) / GP), (unsigned)B), dim3(256), 0, stream, grad_out, idx, (int)N, (int)(S * K), (int)D, grad_feats);
     } else {
-        if (hipMemsetAsync(grad_feats, 0, sizeof(float) * (size_t)(B * N * D), stream) != hipSuccess) return MP_ELAUNCH;
+        if (!mp::zero_async(grad_feats, (size_t)(B * N * D), stream)) return MP_ELAUNCH;
         const int64_t total = B * S * K * D;
         if (total > 0)
             MP_LAUNCH("group_bwd_atomic_kernel", 0.0, 8.0 * (double)total + 8.0 * (double)(B * S * K), group_bwd_atomic_kernel,

@@ -456,10 +456,10 @@ extern "C" int mp_knn_bwd_f32(const float* p1, const float* p2, const int64_t* l
     if (P1 > 0 && P2 > 0 && (!p1 || !p2 || !idx || !grad_dists)) return MP_EINVAL;
     hipStream_t stream = mp_stream(stream_);
     if (grad_p2 && P2 > 0 && (P1 == 0 || !deterministic)) {
-        if (hipMemsetAsync(grad_p2, 0, sizeof(float) * (size_t)(B * P2 * D), stream) != hipSuccess) return MP_ELAUNCH;
+        if (!mp::zero_async(grad_p2, (size_t)(B * P2 * D), stream)) return MP_ELAUNCH;
     }
     if (P1 == 0 || P2 == 0) {
-        if (grad_p1 && P1 > 0 && hipMemsetAsync(grad_p1, 0, sizeof(float) * (size_t)(B * P1 * D), stream) != hipSuccess)
+        if (grad_p1 && P1 > 0 && !mp::zero_async(grad_p1, (size_t)(B * P1 * D), stream))
             return MP_ELAUNCH;
         return MP_OK;
     }

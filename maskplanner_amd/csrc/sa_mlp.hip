@@ -1498,7 +1498,7 @@ extern "C" int mp_sa_mlp_bwd_f32(const float* x0, int64_t P, int64_t K, int n_la
         if (l == 0) { IN.x = x0; } else { IN.x = layers[l - 1].z; IN.s = layers[l - 1].scale; IN.t = layers[l - 1].shift; }
 
         // dW_l = dZ_l^T * act(Z_{l-1})
-        if (hipMemsetAsync(grads[l].d_weight, 0, sizeof(float) * (size_t)Co * Ci, stream) != hipSuccess) return MP_ELAUNCH;
+        if (!mp::zero_async(grads[l].d_weight, (size_t)Co * Ci, stream)) return MP_ELAUNCH;
         if (l > 0 && (Ci == 64 || Ci == 128) && (Co == 64 || Co == 128 || (Co == 256 && Ci == 128)) && fused_bwd_enabled()) {
             // single-tile layer: dX, dW and the BatchNorm-backward sums of layer l-1 in one pass over dZ_l (bwd_fused_kernel)
             const mp_mlp_layer_t& Pv = layers[l - 1];

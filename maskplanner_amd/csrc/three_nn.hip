@@ -194,7 +194,7 @@ extern "C" int mp_three_interpolate_bwd_f32(const float* grad_out, const int64_t
         hipLaunchKernelGGL(three_interp_bwd_ordered_kernel, dim3((unsigned)(B * S)), dim3(256), 0, stream, grad_out, idx, weight, (int)N,
                            (int)S, (int)D, grad_points2);
     } else {
-        if (hipMemsetAsync(grad_points2, 0, sizeof(float) * (size_t)(B * S * D), stream) != hipSuccess) return MP_ELAUNCH;
+        if (!mp::zero_async(grad_points2, (size_t)(B * S * D), stream)) return MP_ELAUNCH;
         const int64_t total = B * N * D;
         if (total > 0)
             MP_LAUNCH("three_interp_bwd_atomic_kernel", 6.0 * (double)total, 16.0 * (double)total, three_interp_bwd_atomic_kernel,

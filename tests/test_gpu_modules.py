@@ -643,3 +643,23 @@ def test_graph_replay_of_the_training_step_tracks_the_eager_path():
     after = float(ts.step())
     assert np.isfinite([before, eager, after]).all() and after < losses[0]
 
+
+
+def test_graph_replays_never_accumulate_on_stale_buffers():
+    """Regression: the dW / scatter buffers used to be cleared with hipMemsetAsync, which a stream capture records as a
+    memset NODE; replays then now and then ran the accumulating kernel against the buffer's previous contents (whole
+    columns of +inf in a weight gradient within ~10 replays at the bench size, silently wrong sums elsewhere).  The library
+    clears with an ordinary kernel now (common.h: zero_async).  80 replays at the bench size, every gradient and parameter
+    checked after every replay."""
+    from maskplanner_amd.harness import TrainStep
+    ts = TrainStep("cuboids", B=32, N=5120, graph=True)
+    params = [p for p in ts.model.parameters()]
+    losses = []
+    for s in range(80):
+        losses.append(ts.step())
+        bad = [i for i, p in enumerate(params) if p.grad is not None and not bool(torch.isfinite(p.grad).all())]
+        assert not bad, (s, bad)
+        assert all(bool(torch.isfinite(p).all()) for p in params), s
+    assert ts._graph is not None
+    losses = [float(l) for l in losses]
+    assert np.isfinite(losses).all() and min(losses[-10:]) < losses[0], losses[::10]
