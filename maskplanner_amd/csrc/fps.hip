@@ -54,15 +54,25 @@ __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, i
     if (tid < 4) slots[tid] = 0ull;
     __syncthreads();
 
-    float px[PPT], py[PPT], pz[PPT], dist[PPT];
+    // Points are held two to a register pair so that the distance runs on packed fp32 (v_pk_add_f32 / v_pk_mul_f32: two
+    // IEEE operations per lane and issue slot -- the step is VALU-bound, ~10 instructions per point before packing);
+    // every operation is still separately rounded, so the result is bit-identical to the scalar form.
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    constexpr int PP2 = (PPT + 1) / 2;
+    f2 px[PP2], py[PP2], pz[PP2], dist[PP2];
     const int base = tid * PPT;
 #pragma unroll
-    for (int j = 0; j < PPT; ++j) {
-        px[j] = sx[base + j];
-        py[j] = sy[base + j];
-        pz[j] = sz[base + j];
-        // padded slots hold 0 forever: min(0, d>=0) == 0 and a real point of lower index wins every tie
-        dist[j] = (base + j < N) ? 1e10f : 0.0f;
+    for (int j = 0; j < PP2; ++j) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int q = 2 * j + h;
+            const bool own = q < PPT;            // odd PPT: the spare half-slot behaves like a padded point
+            px[j][h] = own ? sx[base + q] : 0.0f;
+            py[j][h] = own ? sy[base + q] : 0.0f;
+            pz[j][h] = own ? sz[base + q] : 0.0f;
+            // padded slots hold 0 forever: min(0, d>=0) == 0 and a real point of lower index wins every tie
+            dist[j][h] = (own && base + q < N) ? 1e10f : 0.0f;
+        }
     }
 
     int far = (int)start_idx[b];
@@ -70,18 +80,20 @@ __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, i
     for (int s = 0; s < S; ++s) {
         if (tid == 0) sel[s] = far;
         if (s == S - 1) break;
-        const float cx = sx[far], cy = sy[far], cz = sz[far];
+        const float cxs = sx[far], cys = sy[far], czs = sz[far];
+        const f2 cx = {cxs, cxs}, cy = {cys, cys}, cz = {czs, czs};
         float best = -1.0f;
         int bj = 0;
 #pragma unroll
-        for (int j = 0; j < PPT; ++j) {
-            const float dx = px[j] - cx;
-            const float dy = py[j] - cy;
-            const float dz = pz[j] - cz;
-            const float d = (dx * dx + dy * dy) + dz * dz;
-            const float cur = __builtin_fminf(dist[j], d);   // == `if (d < dist) dist = d` for non-NaN distances
+        for (int j = 0; j < PP2; ++j) {
+            const f2 dx = px[j] - cx;
+            const f2 dy = py[j] - cy;
+            const f2 dz = pz[j] - cz;
+            const f2 d = (dx * dx + dy * dy) + dz * dz;
+            const f2 cur = {__builtin_fminf(dist[j].x, d.x), __builtin_fminf(dist[j].y, d.y)};   // == `if (d < dist) dist = d`
             dist[j] = cur;
-            if (cur > best) { best = cur; bj = j; }
+            if (cur.x > best) { best = cur.x; bj = 2 * j; }
+            if (2 * j + 1 < PPT && cur.y > best) { best = cur.y; bj = 2 * j + 1; }
         }
         const unsigned key = __float_as_uint(best);
         const unsigned wmax = mp::wave_max_u32(key);
