@@ -94,6 +94,7 @@ def main():
     ap.add_argument("--category", default="cuboids")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every step kernel by kernel (no hipGraph replay)")
+    ap.add_argument("--overlap-sampling", type=int, default=None, help="1/0: next batch's FPS + ball query on a second stream")
     args = ap.parse_args()
 
     from maskplanner_amd import dp
@@ -110,7 +111,8 @@ def main():
     from maskplanner_amd.harness import TrainStep
     _lib.load()  # fail loudly if the HIP library is missing
     cat = synthetic.CATEGORIES[args.category]
-    ts = TrainStep(cat, B=args.batch, N=args.points, device=dev, rank=rank, graph=False if args.no_graph else None)
+    ts = TrainStep(cat, B=args.batch, N=args.points, device=dev, rank=rank, graph=False if args.no_graph else None,
+                   overlap_sampling=None if args.overlap_sampling is None else bool(args.overlap_sampling))
 
     def barrier():
         if world > 1:
@@ -150,8 +152,11 @@ def main():
     if rank == 0:
         ms = dt / args.steps * 1e3
         kernels = collect_kernel_profile(lib)
-        # dominant kernel = largest total device time; its binding roof from the algorithmic work model
-        dom = max(kernels, key=lambda k: kernels[k]["ms"])
+        # dominant kernel = largest total device time on the step's own stream; its binding roof from the algorithmic work
+        # model.  (With pipelined sampling the first-level FPS -- a latency-bound chain of dependent arg-max steps, one
+        # workgroup per cloud -- runs on the second stream underneath the step and is not on the critical path.)
+        on_path = [k for k in kernels if not (ts.overlap and k.startswith("fps_kernel"))] or list(kernels)
+        dom = max(on_path, key=lambda k: kernels[k]["ms"])
         d = kernels[dom]
         avg_s = d["ms"] / d["calls"] * 1e-3
         flops, nbytes = d["flops"] / d["calls"], d["bytes"] / d["calls"]
@@ -167,7 +172,9 @@ def main():
                                    f"(forward+loss+backward+Adam), S={cat.out_vectors} M={cat.max_n_strokes}",
                        "parallelism": f"dp{world}", "global_batch": args.batch * world, "grad_allreduce_MB":
                            round(ts.reducer.grad_bytes() / 1e6, 1),
-                       "launch": "hipGraph replay of the recorded step" if ts._graph is not None else "eager (kernel by kernel)"},
+                       "launch": "hipGraph replay of the recorded step" if ts._graph is not None else "eager (kernel by kernel)",
+                       "sampling": "next batch's first-level FPS + ball query on a second stream, under the step" if ts.overlap
+                       else "in line"},
             "roofline": {"kernel": dom, "bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak,
                          "traffic": measured_traffic(dom), "avg_us": avg_s * 1e6, "launches_per_step": d["calls"] / profiled_steps,
                          "flops_per_launch": flops, "bytes_per_launch": nbytes},

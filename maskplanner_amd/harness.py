@@ -16,7 +16,8 @@ from .pointnet2_cls_ssg import maskplanner_model
 
 class TrainStep:
     def __init__(self, category="cuboids", B=32, N=5120, device="cuda", seed=1235, hidden_size=(1024, 1024), lr=1e-3,
-                 dist_points="cuboid", rank=0, loss_overrides=None, prefetch_sampling=False, factor_heads=True, graph=None):
+                 dist_points="cuboid", rank=0, loss_overrides=None, prefetch_sampling=False, factor_heads=True, graph=None,
+                 overlap_sampling=None):
         self.cat = synthetic.CATEGORIES[category] if isinstance(category, str) else category
         self.device = torch.device(device)
         torch.manual_seed(seed)  # identical initial weights on every rank
@@ -31,6 +32,13 @@ class TrainStep:
             graph = os.environ.get("MASKPLANNER_GRAPH", "1") != "0"
         self.use_graph = bool(graph) and fused and not dp.exchanging() and not prefetch_sampling
         self._graph, self._graph_loss, self._eager_steps, self._side = None, None, 0, None
+        # Pipelined first-level sampling (see _eager_step): FPS can occupy only one workgroup per cloud -- 32 of 256 CUs for
+        # ~0.35 ms at B=32 -- and depends on nothing but the input cloud, so the step computes the NEXT batch's FPS + ball
+        # query on a second stream underneath its own work (_pipeline_sampling).
+        if overlap_sampling is None:
+            overlap_sampling = os.environ.get("MASKPLANNER_OVERLAP_SAMPLING", "1") != "0"
+        self.overlap = bool(overlap_sampling) and fused and not prefetch_sampling
+        self._plan_next, self._plan_cur, self._plan_stream, self._plan_ev = None, None, None, None
         self.factor_opt = None
         dense = list(self.model.parameters())
         if factor_heads and fused:
@@ -54,7 +62,7 @@ class TrainStep:
     def forward_loss(self):
         # sa1's start is consumed only when its sampling was not prefetched; sa2's always
         sa1 = self.model.sa1
-        ready = self.prefetch and pu.has_prefetched(self.batch["point_cloud"], sa1.npoint, sa1.radius, sa1.nsample)
+        ready = (self.prefetch or self.overlap) and pu.has_prefetched(self.batch["point_cloud"], sa1.npoint, sa1.radius, sa1.nsample)
         starts = self.batch["fps_start"][1:] if ready else self.batch["fps_start"]
         with pu.fps_start_override(starts):
             out, sm_out, mask_conf, seg_conf = self.model(self.point_cloud)
@@ -66,6 +74,8 @@ class TrainStep:
 
     def step(self):
         """One optimisation step; returns the (device) loss tensor without synchronising."""
+        if self.overlap:
+            self._pipeline_sampling()
         if self._graph is not None:
             self._graph.replay()
             return self._graph_loss
@@ -105,9 +115,56 @@ class TrainStep:
     def eager_step(self):
         """One step launched kernel by kernel even when a recorded graph exists (bench.py's per-kernel timing hooks live in
         the launch path).  Shares parameters and optimizer state with the graph, so the two can be interleaved."""
+        if self.overlap:
+            self._pipeline_sampling()
         return self._eager_step()
 
+    def _plan_views(self, buf):
+        """(fps_idx i64 [B,S], new_xyz f32 [B,S,3], idx i64 [B,S,K]) as views of one flat int64 buffer."""
+        sa1 = self.model.sa1
+        B, S, K = self.batch["point_cloud"].shape[0], sa1.npoint, sa1.nsample
+        n0, n1 = B * S, (B * S * 3 + 1) // 2
+        return (buf[:n0].view(B, S), buf[n0:n0 + n1].view(torch.float32)[:B * S * 3].view(B, S, 3),
+                buf[n0 + n1:n0 + n1 + B * S * K].view(B, S, K))
+
+    def _sample_first_level(self, buf):
+        from . import ops
+        sa1 = self.model.sa1
+        xyz = self.batch["point_cloud"]
+        fps_idx, new_xyz, idx = self._plan_views(buf)
+        start = torch.as_tensor(self.batch["fps_start"][0], dtype=torch.long).to(xyz.device)
+        ops.fps(xyz, sa1.npoint, start, out=(fps_idx, new_xyz))
+        ops.ball_query(sa1.radius, sa1.nsample, xyz, new_xyz, out=idx)
+
+    def _pipeline_sampling(self):
+        """Launched eagerly in front of every step (never recorded: a second branch inside the hipGraph made the replay
+        insert ~7 us synchronisation gaps all along the main chain, 26 per step): the plan computed during the previous step
+        becomes this step's with one copy kernel, then the next batch's sampling (here: the same resident synthetic batch,
+        recomputed every step) starts on the second stream and runs underneath the step."""
+        sa1 = self.model.sa1
+        main = torch.cuda.current_stream()
+        if self._plan_next is None:
+            B, S, K = self.batch["point_cloud"].shape[0], sa1.npoint, sa1.nsample
+            self._plan_next = torch.zeros(B * S + (B * S * 3 + 1) // 2 + B * S * K, dtype=torch.int64, device=self.device)
+            self._plan_cur = torch.zeros_like(self._plan_next)
+            self._sample_first_level(self._plan_next)
+            self._plan_stream = torch.cuda.Stream()
+        if self._plan_ev is not None:
+            main.wait_event(self._plan_ev)                       # the previous step's sampling is complete
+        torch.add(self._plan_next, 0, out=self._plan_cur)        # an elementwise kernel into the step's static buffer
+        side = self._plan_stream
+        side.wait_stream(main)                                   # ... and only then may the next plan be overwritten
+        with torch.cuda.stream(side):
+            self._sample_first_level(self._plan_next)
+            self._plan_ev = torch.cuda.Event()
+            self._plan_ev.record(side)
+
     def _eager_step(self):
+        if self.overlap:
+            if self._plan_cur is None:
+                self._pipeline_sampling()
+            sa1 = self.model.sa1
+            pu.supply_sampling(self.batch["point_cloud"], sa1.npoint, sa1.radius, sa1.nsample, self._plan_views(self._plan_cur))
         self.reducer.zero_grad()
         loss = self.forward_loss()
         loss.backward()

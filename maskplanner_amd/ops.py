@@ -88,29 +88,46 @@ def _run(op, ref, fn, *args):
 # ----------------------------------------------------------------------------------------------------------------
 # index-producing ops (no autograd)
 # ----------------------------------------------------------------------------------------------------------------
+def _check_out(t, shape, dtype, like):
+    if tuple(t.shape) != tuple(shape) or t.dtype != dtype or t.device != like.device or not t.is_contiguous():
+        raise ValueError(f"out tensor must be a contiguous {dtype} tensor of shape {tuple(shape)} on {like.device}")
+
+
 @torch.no_grad()
-def fps(xyz, npoint, start_idx, return_xyz=False):
-    """farthest_point_sample with an explicit start (models/pointnet2_utils.py:65-86).  xyz [B,N,3]."""
+def fps(xyz, npoint, start_idx, return_xyz=False, out=None):
+    """farthest_point_sample with an explicit start (models/pointnet2_utils.py:65-86).  xyz [B,N,3].
+    out=(idx i64 [B,npoint], new_xyz f32 [B,npoint,3] or None): write into existing contiguous tensors."""
     _need_hip(xyz, start_idx)
     xyz = _f32(xyz)
     if xyz.ndim != 3 or xyz.shape[2] != 3:
         raise ValueError("xyz must be [B,N,3]")
     B, N, _ = xyz.shape
     start_idx = _i64(start_idx)
-    idx = torch.empty((B, npoint), dtype=torch.int64, device=xyz.device)
-    new_xyz = torch.empty((B, npoint, 3), dtype=torch.float32, device=xyz.device) if return_xyz else None
+    if out is not None:
+        idx, new_xyz = out
+        _check_out(idx, (B, npoint), torch.int64, xyz)
+        if new_xyz is not None:
+            _check_out(new_xyz, (B, npoint, 3), torch.float32, xyz)
+        return_xyz = new_xyz is not None
+    else:
+        idx = torch.empty((B, npoint), dtype=torch.int64, device=xyz.device)
+        new_xyz = torch.empty((B, npoint, 3), dtype=torch.float32, device=xyz.device) if return_xyz else None
     _run("fps", xyz, _lib.load().mp_fps_f32, _p(xyz), B, N, npoint, _p(start_idx), _p(idx), _p(new_xyz))
     return (idx, new_xyz) if return_xyz else idx
 
 
 @torch.no_grad()
-def ball_query(radius, nsample, xyz, new_xyz):
+def ball_query(radius, nsample, xyz, new_xyz, out=None):
     """query_ball_point (models/pointnet2_utils.py:89-109).  xyz [B,N,3], new_xyz [B,S,3] -> i64 [B,S,nsample]."""
     _need_hip(xyz, new_xyz)
     xyz, new_xyz = _f32(xyz), _f32(new_xyz)
     B, N, _ = xyz.shape
     S = new_xyz.shape[1]
-    idx = torch.empty((B, S, nsample), dtype=torch.int64, device=xyz.device)
+    if out is not None:
+        idx = out
+        _check_out(idx, (B, S, nsample), torch.int64, xyz)
+    else:
+        idx = torch.empty((B, S, nsample), dtype=torch.int64, device=xyz.device)
     _run("ball_query", xyz, _lib.load().mp_ball_query_f32, _p(xyz), _p(new_xyz), B, N, S, float(radius), nsample, _p(idx))
     return idx
 

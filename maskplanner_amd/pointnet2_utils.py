@@ -67,6 +67,12 @@ def prefetch_sampling(xyz, npoint, radius, nsample, fps_start):
     _prefetched.setdefault((xyz.data_ptr(), npoint, float(radius), nsample), []).append((ev, fps_idx, new_xyz, idx))
 
 
+def supply_sampling(xyz, npoint, radius, nsample, plan):
+    """Hand sample_and_group() a finished first-level sampling (fps_idx, new_xyz, idx) of `xyz`, already ordered on the
+    current stream (the pipelined step of harness.TrainStep: the plan was computed during the previous step)."""
+    _prefetched.setdefault((xyz.data_ptr(), npoint, float(radius), nsample), []).append((None,) + tuple(plan))
+
+
 def has_prefetched(xyz, npoint, radius, nsample):
     return bool(_prefetched.get((xyz.data_ptr(), npoint, float(radius), nsample)))
 
@@ -79,7 +85,8 @@ def _take_prefetched(xyz, npoint, radius, nsample):
     ev, fps_idx, new_xyz, idx = q.pop(0)
     if not q:
         del _prefetched[key]
-    torch.cuda.current_stream(xyz.device).wait_event(ev)
+    if ev is not None:
+        torch.cuda.current_stream(xyz.device).wait_event(ev)
     return fps_idx, new_xyz, idx
 
 

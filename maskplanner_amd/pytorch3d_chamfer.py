@@ -90,7 +90,7 @@ def chamfer_distance(x, y, x_lengths=None, y_lengths=None, x_normals=None, y_nor
         found = ops.padded_lengths(y)
         if y_lengths_given:
             # the reference overwrites y_lengths only if at least one sample is padded (:140); decided on device
-            y_lengths.copy_(torch.where((found != P2).any(), found, y_lengths))
+            torch.where((found != P2).any(), found, y_lengths, out=y_lengths)   # (copy_ would be a memcpy node in a recorded step)
         else:
             y_lengths = found   # default lengths are P2 everywhere, which is also what `found` holds for unpadded samples
 

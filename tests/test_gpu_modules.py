@@ -663,3 +663,29 @@ def test_graph_replays_never_accumulate_on_stale_buffers():
     assert ts._graph is not None
     losses = [float(l) for l in losses]
     assert np.isfinite(losses).all() and min(losses[-10:]) < losses[0], losses[::10]
+
+
+def test_pipelined_first_level_sampling_changes_nothing_but_the_schedule():
+    """harness.TrainStep(overlap_sampling=True) computes the next batch's first-level FPS + ball query on a second stream
+    and hands the finished plan to set abstraction 1 (pointnet2_utils.supply_sampling).  Same kernels, same inputs: the plan
+    equals what the in-line path computes, the first loss is bit-identical and training tracks the in-line run."""
+    from maskplanner_amd import ops
+    from maskplanner_amd.harness import TrainStep
+    a = TrainStep("cuboids", B=4, N=1024, seed=7, graph=False, overlap_sampling=False)   # (the constructor seeds torch: dropout)
+    la = [float(a.step()) for _ in range(6)]
+    b = TrainStep("cuboids", B=4, N=1024, seed=7, graph=False, overlap_sampling=True)
+    lb = [float(b.step()) for _ in range(6)]
+    assert la[0] == lb[0], (la, lb)
+    assert np.allclose(la, lb, rtol=2e-2), (la, lb)
+    sa1 = b.model.sa1
+    xyz = b.batch["point_cloud"]
+    fps_idx, new_xyz = ops.fps(xyz, sa1.npoint, torch.as_tensor(b.batch["fps_start"][0]).to(xyz.device), return_xyz=True)
+    idx = ops.ball_query(sa1.radius, sa1.nsample, xyz, new_xyz)
+    torch.cuda.synchronize()
+    for got, want in zip(b._plan_views(b._plan_cur), (fps_idx, new_xyz, idx)):
+        assert torch.equal(got, want)
+    for got, want in zip(b._plan_views(b._plan_next), (fps_idx, new_xyz, idx)):
+        assert torch.equal(got, want)
+    c = TrainStep("cuboids", B=4, N=1024, seed=7, graph=True, overlap_sampling=True)   # replay + eagerly launched pipeline
+    lc = [float(c.step()) for _ in range(6)]
+    assert c._graph is not None and lc[0] == la[0] and np.allclose(la, lc, rtol=2e-2), (la, lc)

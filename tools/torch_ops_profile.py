@@ -9,7 +9,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from maskplanner_amd.harness import TrainStep  # noqa: E402
 
-ts = TrainStep("cuboids", B=32, N=5120)
+ts = TrainStep("cuboids", B=32, N=5120, graph=False)
 for _ in range(3):
     ts.step()
 torch.cuda.synchronize()
@@ -31,7 +31,8 @@ for e in ev:
     if where == "?" and e.stack:
         where = "[autograd/other] " + e.stack[0][-50:]
     dev_us = sum(k.duration for k in e.kernels)
-    key = (e.name, where)
+    kn = ",".join(sorted({k.name[:24] for k in e.kernels if "Mem" in k.name}))
+    key = (e.name + (" [" + kn + "]" if kn else ""), where)
     by[key][0] += len(e.kernels)
     by[key][1] += dev_us
 tot = sum(v[0] for v in by.values())
