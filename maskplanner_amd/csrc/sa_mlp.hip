@@ -1477,6 +1477,15 @@ extern "C" int mp_sa_mlp_bwd_f32(const float* x0, int64_t P, int64_t K, int n_la
                            grads[L - 1].d_beta, grads[L - 1].d_bias, cbuf[0], cbuf[1], cbuf[2]);
         MP_CHECK_LAUNCH();
     }
+    // dW is accumulated with atomics and must start from zero: one clear for the whole level when the caller laid the
+    // layers' buffers out back to back (the Python layer does), one per layer otherwise
+    bool dw_joint = L > 1;
+    size_t dw_total = 0;
+    for (int l = 0; l < L; ++l) {
+        if (l + 1 < L && grads[l + 1].d_weight != grads[l].d_weight + (size_t)layers[l].c_out * layers[l].c_in) dw_joint = false;
+        dw_total += (size_t)layers[l].c_out * layers[l].c_in;
+    }
+    if (dw_joint && !mp::zero_async(grads[0].d_weight, dw_total, stream)) return MP_ELAUNCH;
     const float* G_cur = nullptr;  // dense gradient w.r.t. the activation output of layer l (l < L-1)
     for (int l = L - 1; l >= 0; --l) {
         const mp_mlp_layer_t& Ly = layers[l];
@@ -1498,7 +1507,7 @@ extern "C" int mp_sa_mlp_bwd_f32(const float* x0, int64_t P, int64_t K, int n_la
         if (l == 0) { IN.x = x0; } else { IN.x = layers[l - 1].z; IN.s = layers[l - 1].scale; IN.t = layers[l - 1].shift; }
 
         // dW_l = dZ_l^T * act(Z_{l-1})
-        if (!mp::zero_async(grads[l].d_weight, (size_t)Co * Ci, stream)) return MP_ELAUNCH;
+        if (!dw_joint && !mp::zero_async(grads[l].d_weight, (size_t)Co * Ci, stream)) return MP_ELAUNCH;
         if (l > 0 && (Ci == 64 || Ci == 128) && (Co == 64 || Co == 128 || (Co == 256 && Ci == 128)) && fused_bwd_enabled()) {
             // single-tile layer: dX, dW and the BatchNorm-backward sums of layer l-1 in one pass over dZ_l (bwd_fused_kernel)
             const mp_mlp_layer_t& Pv = layers[l - 1];

@@ -62,11 +62,16 @@ class _SharedMLPMax(torch.autograd.Function):
         layers = (_lib.MlpLayer * n_layers)()
         grads = (_lib.MlpGrads * n_layers)()
         ret = []
+        # the weight gradients of a level share one allocation, in layer order: the library then clears them with a single
+        # launch (they are accumulated with atomics) instead of one per layer
+        dw_all = torch.empty((sum(k[0].numel() for k in ctx.keep),), dtype=torch.float32, device=dev)
+        dw_off = 0
         for l, (w, b, gam, bet, rm, rv, z, stats) in enumerate(ctx.keep):
             co, ci = w.shape
             layers[l] = _lib.MlpLayer(_ptr(w), _ptr(b), _ptr(gam), _ptr(bet), _ptr(rm), _ptr(rv), ci, co, _ptr(z),
                                       stats[0].data_ptr(), stats[1].data_ptr(), stats[2].data_ptr(), stats[3].data_ptr())
-            dw = torch.empty_like(w)
+            dw = dw_all[dw_off:dw_off + w.numel()].view_as(w)
+            dw_off += w.numel()
             db = None if b is None else torch.empty_like(b)
             dg, dbe = torch.empty_like(gam), torch.empty_like(bet)
             grads[l] = _lib.MlpGrads(_ptr(dw), _ptr(db), _ptr(dg), _ptr(dbe))
