@@ -130,9 +130,9 @@ def main():
     profiled_steps = 0
     for i in range(args.steps):
         marks[i].record()
-        # per-kernel HIP events (two records per library launch) on every 10th timed step, rank 0 only: the hooks
+        # per-kernel HIP events (two records per library launch) on every 20th timed step, rank 0 only: the hooks
         # cost ~0.5 ms per profiled step, so sampling keeps the headline number honest
-        prof = rank == 0 and i % 10 == 0
+        prof = rank == 0 and i % 20 == 0
         if prof:
             lib.mp_profiler_enable(1)
             profiled_steps += 1
