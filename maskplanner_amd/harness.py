@@ -64,6 +64,8 @@ class TrainStep:
         sa1 = self.model.sa1
         ready = (self.prefetch or self.overlap) and pu.has_prefetched(self.batch["point_cloud"], sa1.npoint, sa1.radius, sa1.nsample)
         starts = self.batch["fps_start"][1:] if ready else self.batch["fps_start"]
+        if ready and self.overlap:
+            starts = self.batch["fps_start"][len(self._plan_levels()):]   # every sampling level comes from the plan
         with pu.fps_start_override(starts):
             out, sm_out, mask_conf, seg_conf = self.model(self.point_cloud)
         return self.loss_handler.compute(return_list=False, y_pred=out, y=self.batch["traj"], pred_stroke_masks=sm_out,
@@ -119,35 +121,48 @@ class TrainStep:
             self._pipeline_sampling()
         return self._eager_step()
 
-    def _plan_views(self, buf):
-        """(fps_idx i64 [B,S], new_xyz f32 [B,S,3], idx i64 [B,S,K]) as views of one flat int64 buffer."""
-        sa1 = self.model.sa1
-        B, S, K = self.batch["point_cloud"].shape[0], sa1.npoint, sa1.nsample
-        n0, n1 = B * S, (B * S * 3 + 1) // 2
-        return (buf[:n0].view(B, S), buf[n0:n0 + n1].view(torch.float32)[:B * S * 3].view(B, S, 3),
-                buf[n0 + n1:n0 + n1 + B * S * K].view(B, S, K))
+    def _plan_levels(self):
+        """The sampling levels of the encoder (set abstractions that are not group_all), in order."""
+        return [m for m in (self.model.sa1, self.model.sa2, self.model.sa3) if not m.group_all]
 
-    def _sample_first_level(self, buf):
+    def _plan_size(self):
+        B, n = self.batch["point_cloud"].shape[0], 0
+        for m in self._plan_levels():
+            n += B * m.npoint + (B * m.npoint * 3 + 1) // 2 + B * m.npoint * m.nsample
+        return n
+
+    def _plan_views(self, buf):
+        """Per level (fps_idx i64 [B,S], new_xyz f32 [B,S,3], idx i64 [B,S,K]) as views of one flat int64 buffer."""
+        B, o, out = self.batch["point_cloud"].shape[0], 0, []
+        for m in self._plan_levels():
+            S, K = m.npoint, m.nsample
+            n0, n1, n2 = B * S, (B * S * 3 + 1) // 2, B * S * K
+            out.append((buf[o:o + n0].view(B, S), buf[o + n0:o + n0 + n1].view(torch.float32)[:B * S * 3].view(B, S, 3),
+                        buf[o + n0 + n1:o + n0 + n1 + n2].view(B, S, K)))
+            o += n0 + n1 + n2
+        return out
+
+    def _sample_levels(self, buf):
+        """FPS + ball query of every level: each level samples the previous level's centroids, nothing else -- the whole
+        plan depends on the input cloud only."""
         from . import ops
-        sa1 = self.model.sa1
         xyz = self.batch["point_cloud"]
-        fps_idx, new_xyz, idx = self._plan_views(buf)
-        start = torch.as_tensor(self.batch["fps_start"][0], dtype=torch.long).to(xyz.device)
-        ops.fps(xyz, sa1.npoint, start, out=(fps_idx, new_xyz))
-        ops.ball_query(sa1.radius, sa1.nsample, xyz, new_xyz, out=idx)
+        for m, start, (fps_idx, new_xyz, idx) in zip(self._plan_levels(), self.batch["fps_start"], self._plan_views(buf)):
+            start = torch.as_tensor(start, dtype=torch.long).to(xyz.device)
+            ops.fps(xyz, m.npoint, start, out=(fps_idx, new_xyz))
+            ops.ball_query(m.radius, m.nsample, xyz, new_xyz, out=idx)
+            xyz = new_xyz
 
     def _pipeline_sampling(self):
         """Launched eagerly in front of every step (never recorded: a second branch inside the hipGraph made the replay
         insert ~7 us synchronisation gaps all along the main chain, 26 per step): the plan computed during the previous step
         becomes this step's with one copy kernel, then the next batch's sampling (here: the same resident synthetic batch,
         recomputed every step) starts on the second stream and runs underneath the step."""
-        sa1 = self.model.sa1
         main = torch.cuda.current_stream()
         if self._plan_next is None:
-            B, S, K = self.batch["point_cloud"].shape[0], sa1.npoint, sa1.nsample
-            self._plan_next = torch.zeros(B * S + (B * S * 3 + 1) // 2 + B * S * K, dtype=torch.int64, device=self.device)
+            self._plan_next = torch.zeros(self._plan_size(), dtype=torch.int64, device=self.device)
             self._plan_cur = torch.zeros_like(self._plan_next)
-            self._sample_first_level(self._plan_next)
+            self._sample_levels(self._plan_next)
             self._plan_stream = torch.cuda.Stream()
         if self._plan_ev is not None:
             main.wait_event(self._plan_ev)                       # the previous step's sampling is complete
@@ -155,7 +170,7 @@ class TrainStep:
         side = self._plan_stream
         side.wait_stream(main)                                   # ... and only then may the next plan be overwritten
         with torch.cuda.stream(side):
-            self._sample_first_level(self._plan_next)
+            self._sample_levels(self._plan_next)
             self._plan_ev = torch.cuda.Event()
             self._plan_ev.record(side)
 
@@ -163,8 +178,10 @@ class TrainStep:
         if self.overlap:
             if self._plan_cur is None:
                 self._pipeline_sampling()
-            sa1 = self.model.sa1
-            pu.supply_sampling(self.batch["point_cloud"], sa1.npoint, sa1.radius, sa1.nsample, self._plan_views(self._plan_cur))
+            xyz = self.batch["point_cloud"]
+            for m, plan in zip(self._plan_levels(), self._plan_views(self._plan_cur)):
+                pu.supply_sampling(xyz, m.npoint, m.radius, m.nsample, plan)
+                xyz = plan[1]    # the next level's cloud IS this level's centroid tensor (same storage: the lookup key)
         self.reducer.zero_grad()
         loss = self.forward_loss()
         loss.backward()
