@@ -245,6 +245,11 @@ typedef struct {
 } mp_mlp_grads_t;
 
 size_t mp_sa_mlp_workspace_bytes(int64_t P, int64_t K, int n_layers, const int64_t* channels, int backward);
+/* 1 if the first layer of the chain can be RECOMPUTED instead of stored: pass layers[0].z = NULL to mp_sa_mlp_fwd_f32 and
+ * mp_sa_mlp_bwd_f32 (no grad_x0 then) and Z_0 [P, 64] is never written -- a 4-channel input (xyz + pad) makes it four FMAs per
+ * element.  channels[n_layers + 1] as for the workspace query.  (Reference: the first Conv2d of sa1, pointnet2_utils.py:208-213;
+ * the reference stores every activation for autograd.) */
+int mp_sa_mlp_recompute_first(int n_layers, const int64_t* channels, int64_t K);
 int mp_sa_mlp_fwd_f32(const float* x0, int64_t P, int64_t K, int n_layers, const mp_mlp_layer_t* layers, int training,
                       double momentum, double eps, float* out, int32_t* argk, float* zmax, void* workspace,
                       size_t workspace_bytes, mp_stream_t stream);

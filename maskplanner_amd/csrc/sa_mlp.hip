@@ -40,7 +40,12 @@ constexpr int RPP = 256 / TPR;     // rows per staging pass
 constexpr int THREADS = 256;
 constexpr int LDK = BK + 1;  // [row][k] tiles: odd stride
 
-enum SrcMode { SRC_ID = 0, SRC_ACT = 1, SRC_DZ = 2, SRC_DZ_POOLED = 3 };
+enum SrcMode { SRC_ID = 0, SRC_ACT = 1, SRC_DZ = 2, SRC_DZ_POOLED = 3, SRC_ACT_RC = 4, SRC_DZ_RC = 5 };
+// *_RC ("recompute"): the raw Z of this operand is not in memory -- it is the first layer of a level with a 4-channel input
+// (xyz + pad), z[p][c] = X0[p][0:4] . W0[c][0:4], four FMAs per element: cheaper to recompute from the 16-byte input row than
+// to write [P, C] floats once and read them back three times (next layer forward, next layer backward, its own dW).
+constexpr bool is_rc(int m) { return m == SRC_ACT_RC || m == SRC_DZ_RC; }
+constexpr bool is_dz(int m) { return m == SRC_DZ || m == SRC_DZ_POOLED || m == SRC_DZ_RC; }
 
 // A positions-major operand: rows = positions, columns = channels (contiguous).  Every channel count is a multiple
 // of 4 (checked on the host; the Python layer zero-pads 3 -> 4, 131 -> 132, 259 -> 260), so a float4 of channels is
@@ -57,11 +62,14 @@ struct PosOperand {
     const float* f;
     int C;
     int K;               // group size (pooled)
+    const float* rx;     // *_RC: the level's input rows X0 [P, 4]
+    const float* rw;     // *_RC: the first layer's weight W0 [C, 4]
 };
 
 // Per-channel constants of 4 consecutive channels, loaded ONCE per thread and tile (not per element).
 struct ChanConst {
     float4 s, t, a, e, f;
+    float4 w[4];         // *_RC: W0 rows of the thread's 4 channels
 };
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
@@ -75,10 +83,14 @@ __device__ __forceinline__ void load_consts(const PosOperand& o, int c, ChanCons
         k.s = ld4(o.s + cc);
         k.t = ld4(o.t + cc);
     }
-    if constexpr (MODE == SRC_DZ || MODE == SRC_DZ_POOLED) {
+    if constexpr (is_dz(MODE)) {
         k.a = ld4(o.a + cc);
         k.e = ld4(o.e + cc);
         k.f = ld4(o.f + cc);
+    }
+    if constexpr (is_rc(MODE)) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) k.w[j] = ld4(o.rw + (size_t)(cc + j) * 4);
     }
 }
 
@@ -99,8 +111,9 @@ __device__ __forceinline__ void raw_load(const PosOperand& o, int P, int p, int 
 {
     r.ok = (p < P) && (c < o.C);
     const int pp = r.ok ? p : 0, cc = r.ok ? c : 0;
-    r.z = ld4(o.x + (size_t)((unsigned)pp * (unsigned)o.C + (unsigned)cc));
-    if constexpr (MODE == SRC_DZ) {
+    if constexpr (is_rc(MODE)) r.z = ld4(o.rx + (size_t)pp * 4);   // the input row; raw_z() turns it into 4 channels of z
+    else r.z = ld4(o.x + (size_t)((unsigned)pp * (unsigned)o.C + (unsigned)cc));
+    if constexpr (MODE == SRC_DZ || MODE == SRC_DZ_RC) {
         r.g = ld4(o.g + (size_t)((unsigned)pp * (unsigned)o.C + (unsigned)cc));
     } else if constexpr (MODE == SRC_DZ_POOLED) {
         const unsigned grp = (unsigned)pp / (unsigned)o.K;
@@ -116,7 +129,7 @@ __device__ __forceinline__ float xf1(float z, float g, float s, float t, float a
 {
     if constexpr (MODE == SRC_ID) {
         return z;
-    } else if constexpr (MODE == SRC_ACT) {
+    } else if constexpr (MODE == SRC_ACT || MODE == SRC_ACT_RC) {
         const float y = z * s + t;
         return y > 0.0f ? y : 0.0f;
     } else {
@@ -126,11 +139,26 @@ __device__ __forceinline__ float xf1(float z, float g, float s, float t, float a
     }
 }
 
+// the k-ordered FMA chain of the MFMA kernels (which start from a zero accumulator): bit-identical to a stored Z
+__device__ __forceinline__ float dot4_rc(const float4& x, const float4& w)
+{
+    return __builtin_fmaf(x.w, w.w, __builtin_fmaf(x.z, w.z, __builtin_fmaf(x.y, w.y, x.x * w.x)));
+}
+
+// raw pre-BatchNorm z of the operand's 4 channels
+template <int MODE>
+__device__ __forceinline__ float4 raw_z(const Raw4<MODE>& r, const ChanConst& k)
+{
+    if constexpr (is_rc(MODE)) return make_float4(dot4_rc(r.z, k.w[0]), dot4_rc(r.z, k.w[1]), dot4_rc(r.z, k.w[2]), dot4_rc(r.z, k.w[3]));
+    else return r.z;
+}
+
 template <int MODE>
 __device__ __forceinline__ float4 finish(const Raw4<MODE>& r, const ChanConst& k)
 {
     float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
-    if constexpr (MODE == SRC_DZ) g = r.g;
+    const float4 z = raw_z<MODE>(r, k);
+    if constexpr (MODE == SRC_DZ || MODE == SRC_DZ_RC) g = r.g;
     if constexpr (MODE == SRC_DZ_POOLED) {
         g.x = r.ak.x == r.kk ? r.g.x : 0.0f;
         g.y = r.ak.y == r.kk ? r.g.y : 0.0f;
@@ -138,10 +166,10 @@ __device__ __forceinline__ float4 finish(const Raw4<MODE>& r, const ChanConst& k
         g.w = r.ak.w == r.kk ? r.g.w : 0.0f;
     }
     float4 o;
-    o.x = xf1<MODE>(r.z.x, g.x, k.s.x, k.t.x, k.a.x, k.e.x, k.f.x);
-    o.y = xf1<MODE>(r.z.y, g.y, k.s.y, k.t.y, k.a.y, k.e.y, k.f.y);
-    o.z = xf1<MODE>(r.z.z, g.z, k.s.z, k.t.z, k.a.z, k.e.z, k.f.z);
-    o.w = xf1<MODE>(r.z.w, g.w, k.s.w, k.t.w, k.a.w, k.e.w, k.f.w);
+    o.x = xf1<MODE>(z.x, g.x, k.s.x, k.t.x, k.a.x, k.e.x, k.f.x);
+    o.y = xf1<MODE>(z.y, g.y, k.s.y, k.t.y, k.a.y, k.e.y, k.f.y);
+    o.z = xf1<MODE>(z.z, g.z, k.s.z, k.t.z, k.a.z, k.e.z, k.f.z);
+    o.w = xf1<MODE>(z.w, g.w, k.s.w, k.t.w, k.a.w, k.e.w, k.f.w);
     if (!r.ok) o = make_float4(0.f, 0.f, 0.f, 0.f);
     return o;
 }
@@ -546,7 +574,7 @@ __global__ __launch_bounds__(THREADS) void dw_gemm_kernel(PosOperand DZ, PosOper
 // other waves' MFMAs instead of being a separate phase of a 128 x 128 tile.  One partial-sum row per workgroup
 // (P / p_per_block rows instead of P / 128) also makes the BatchNorm finalize kernel 8x shorter.
 // =================================================================================================================
-template <int CI, int CO, bool POOL>
+template <int CI, int CO, bool POOL, int MODE_A = SRC_ACT>
 __global__ __launch_bounds__(CO > 128 ? 512 : 256) void fwd_chunk_kernel(PosOperand A, int P, int p_per_block,
                                                                          const float* __restrict__ W, float* __restrict__ Z,
                                                                          float* __restrict__ partials, PoolOut po)
@@ -579,16 +607,16 @@ __global__ __launch_bounds__(CO > 128 ? 512 : 256) void fwd_chunk_kernel(PosOper
     const int ca = (tid % (CI / 4)) * 4, ka0 = tid / (CI / 4);
     constexpr int KA_STEP = NT / (CI / 4);
     ChanConst kc;
-    load_consts<SRC_ACT>(A, ca, kc);
-    Raw4<SRC_ACT> ra[PA];
+    load_consts<MODE_A>(A, ca, kc);
+    Raw4<MODE_A> ra[PA];
     auto gload = [&](int pk) {
 #pragma unroll
-        for (int ps = 0; ps < PA; ++ps) raw_load<SRC_ACT>(A, p1, pk + ka0 + ps * KA_STEP, ca, ra[ps]);
+        for (int ps = 0; ps < PA; ++ps) raw_load<MODE_A>(A, p1, pk + ka0 + ps * KA_STEP, ca, ra[ps]);
     };
     auto sstore = [&](int buf) {
 #pragma unroll
         for (int ps = 0; ps < PA; ++ps)
-            *reinterpret_cast<float4*>(&sA[buf][(ka0 + ps * KA_STEP) * LDA + ca]) = finish<SRC_ACT>(ra[ps], kc);
+            *reinterpret_cast<float4*>(&sA[buf][(ka0 + ps * KA_STEP) * LDA + ca]) = finish<MODE_A>(ra[ps], kc);
     };
 
     double s1 = 0.0, s2 = 0.0;     // the chunk's values are summed in fp32, the 16-32 chunks of a workgroup in fp64
@@ -686,7 +714,7 @@ __global__ __launch_bounds__(CO > 128 ? 512 : 256) void fwd_chunk_kernel(PosOper
 // BatchNorm-backward sums of layer l-1 from the raw Z_{l-1} chunk kept beside the activated one: 4 tensor passes.
 // The dX tile of a chunk is computed as eight 16x16 MFMA tiles, two per wave.
 // =================================================================================================================
-template <int MODE_DZ, int CO, int CI>
+template <int MODE_DZ, int CO, int CI, int MODE_IN = SRC_ACT>
 __global__ __launch_bounds__((CO >= 128 && CI == 128 ? 512 : 256), (CO >= 128 && CI == 128 ? 1 : 2)) void bwd_fused_kernel(PosOperand DZ, PosOperand IN, int P, int p_per_block,
                                                             const float* __restrict__ W, float* __restrict__ dW,
                                                             float* __restrict__ G, float* __restrict__ partials)
@@ -726,14 +754,14 @@ __global__ __launch_bounds__((CO >= 128 && CI == 128 ? 512 : 256), (CO >= 128 &&
     constexpr int KA_STEP = NT / (CO / 4), KB_STEP = NT / (CI / 4);
     ChanConst ka, kb;
     load_consts<MODE_DZ>(DZ, ca, ka);
-    load_consts<SRC_ACT>(IN, cb, kb);
+    load_consts<MODE_IN>(IN, cb, kb);
     Raw4<MODE_DZ> ra[PA];
-    Raw4<SRC_ACT> rb[PB];
+    Raw4<MODE_IN> rb[PB];
     auto gload = [&](int pk) {
 #pragma unroll
         for (int ps = 0; ps < PA; ++ps) raw_load<MODE_DZ>(DZ, p1, pk + ka0 + ps * KA_STEP, ca, ra[ps]);
 #pragma unroll
-        for (int ps = 0; ps < PB; ++ps) raw_load<SRC_ACT>(IN, p1, pk + kb0 + ps * KB_STEP, cb, rb[ps]);
+        for (int ps = 0; ps < PB; ++ps) raw_load<MODE_IN>(IN, p1, pk + kb0 + ps * KB_STEP, cb, rb[ps]);
     };
     auto sstore = [&](int buf) {
 #pragma unroll
@@ -745,8 +773,8 @@ __global__ __launch_bounds__((CO >= 128 && CI == 128 ? 512 : 256), (CO >= 128 &&
 #pragma unroll
         for (int ps = 0; ps < PB; ++ps) {
             const int o = (kb0 + ps * KB_STEP) * CI + cb;
-            *reinterpret_cast<float4*>(&sB[buf][o]) = finish<SRC_ACT>(rb[ps], kb);
-            *reinterpret_cast<float4*>(&sZ[buf][o]) = rb[ps].ok ? rb[ps].z : make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4*>(&sB[buf][o]) = finish<MODE_IN>(rb[ps], kb);
+            *reinterpret_cast<float4*>(&sZ[buf][o]) = rb[ps].ok ? raw_z<MODE_IN>(rb[ps], kb) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
 
@@ -845,6 +873,46 @@ __global__ __launch_bounds__((CO >= 128 && CI == 128 ? 512 : 256), (CO >= 128 &&
                 atomicAdd(dW + (size_t)(row * CI + col), accW[mi][ni][r]);
             }
         }
+}
+
+// BatchNorm statistics of a RECOMPUTED first layer (SRC_*_RC): per workgroup the sums of z and z^2 of its positions, in the
+// partials layout of the GEMM epilogues ([block][2][C]) -- the layer's forward pass is this kernel and nothing else.
+// A wave loads 64 input rows with one coalesced access (lane i: position base + i) and every lane (= channel) walks them
+// through v_readlane; sums run in fp32 over the 64 positions and in fp64 across them.
+__global__ __launch_bounds__(256) void rc_stats_kernel(const float* __restrict__ x0, const float* __restrict__ W0, int P, int p_per_block,
+                                                       float* __restrict__ partials)
+{
+    constexpr int C = 64;
+    __shared__ double red[4][2][C];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const float4 w = ld4(W0 + (size_t)lane * 4);
+    const int p0 = blockIdx.x * p_per_block, p1 = min(P, p0 + p_per_block);
+    double S1 = 0.0, S2 = 0.0;
+    for (int base = p0 + wave * 64; base < p1; base += 256) {
+        const int pos = base + lane;
+        const float4 xr = pos < p1 ? ld4(x0 + (size_t)pos * 4) : make_float4(0.f, 0.f, 0.f, 0.f);   // rows past the end give z = 0
+        float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 64; ++j) {
+            float4 x;
+            x.x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xr.x), j));
+            x.y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xr.y), j));
+            x.z = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xr.z), j));
+            x.w = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xr.w), j));
+            const float z = dot4_rc(x, w);
+            s1 += z;
+            s2 = __builtin_fmaf(z, z, s2);
+        }
+        S1 += (double)s1;
+        S2 += (double)s2;
+    }
+    red[wave][0][lane] = S1;
+    red[wave][1][lane] = S2;
+    __syncthreads();
+    if (tid < 2 * C) {
+        const int st = tid / C, c = tid - st * C;
+        partials[((size_t)blockIdx.x * 2 + st) * C + c] = (float)(((red[0][st][c] + red[1][st][c]) + red[2][st][c]) + red[3][st][c]);
+    }
 }
 
 // dW for a 4-channel input (the first layer of the first level: xyz + pad): a [CO x 4] result is no MFMA shape (a 128 x 32
@@ -1310,6 +1378,18 @@ extern "C" size_t mp_sa_mlp_workspace_bytes(int64_t P, int64_t K, int n_layers, 
     return bytes;
 }
 
+// Can the first layer of this chain be recomputed instead of stored (layers[0].z = NULL in forward AND backward)?  Yes for a
+// 4-channel input into 64 channels followed by a 64 -> 64 / 128 layer that is not the pooled one, with the position-stream
+// kernels enabled; the caller must not need grad_x0.  MP_RECOMPUTE_FIRST=0 switches it off (read on every call).
+extern "C" int mp_sa_mlp_recompute_first(int n_layers, const int64_t* channels, int64_t K)
+{
+    if (!channels || n_layers < 3) return 0;
+    const char* e = getenv("MP_RECOMPUTE_FIRST");
+    if (e && atoi(e) == 0) return 0;
+    if (!chunk_fwd_enabled() || !fused_bwd_enabled()) return 0;
+    return channels[0] == 4 && channels[1] == 64 && (channels[2] == 64 || channels[2] == 128) && K > 0;
+}
+
 extern "C" int mp_sa_mlp_fwd_f32(const float* x0, int64_t P, int64_t K, int n_layers, const mp_mlp_layer_t* layers,
                                  int training, double momentum, double eps, float* out, int32_t* argk, float* zmax,
                                  void* workspace, size_t workspace_bytes, mp_stream_t stream_)
@@ -1322,7 +1402,7 @@ extern "C" int mp_sa_mlp_fwd_f32(const float* x0, int64_t P, int64_t K, int n_la
     ch[0] = layers[0].c_in;
     for (int l = 0; l < n_layers; ++l) {
         const mp_mlp_layer_t& L = layers[l];
-        if (!L.weight || !L.gamma || !L.beta || !L.z || !L.mean || !L.rstd || !L.scale || !L.shift) return MP_EINVAL;
+        if (!L.weight || !L.gamma || !L.beta || (!L.z && l > 0) || !L.mean || !L.rstd || !L.scale || !L.shift) return MP_EINVAL;
         if (!training && (!L.running_mean || !L.running_var)) return MP_EINVAL;
         if (L.c_in != ch[l] || L.c_out <= 0 || L.c_out > 4096 || L.c_in > 4096) return MP_EINVAL;
         if ((L.c_in & 3) || (L.c_out & 3)) return MP_EUNSUPPORTED;      // float4 granularity: pad channels to x4
@@ -1330,6 +1410,9 @@ extern "C" int mp_sa_mlp_fwd_f32(const float* x0, int64_t P, int64_t K, int n_la
         ch[l + 1] = L.c_out;
     }
     if (workspace_bytes < mp_sa_mlp_workspace_bytes(P, K, n_layers, ch, 0)) return MP_EWORKSPACE;
+    // layers[0].z == NULL: the caller asks for the first layer to be recomputed instead of stored (mp_sa_mlp_recompute_first)
+    const bool rc_first = layers[0].z == nullptr;
+    if (rc_first && !mp_sa_mlp_recompute_first(n_layers, ch, K)) return MP_EINVAL;
     hipStream_t stream = mp_stream(stream_);
     float* partials = reinterpret_cast<float*>(workspace);
     // fused max-pool: group size a multiple of the 32-row MFMA tile that divides the 128-row block tile
@@ -1359,7 +1442,26 @@ extern "C" int mp_sa_mlp_fwd_f32(const float* x0, int64_t P, int64_t K, int n_la
         const bool fuse_pool = (l == n_layers - 1) && fused_pool;
         const int Ci_ = (int)L.c_in, Co_ = (int)L.c_out;
         const bool last_unfused = (l == n_layers - 1) && !fused_pool;
-        if (l > 0 && (Ci_ == 64 || Ci_ == 128) && (Co_ == 64 || Co_ == 128 || Co_ == 256) && (P % K) == 0 && (1024 % K == 0 || !fuse_pool) &&
+        if (l == 0 && rc_first) {
+            const int ppb = 1024;
+            nblk = (int)((P + ppb - 1) / ppb);
+            MP_LAUNCH("rc_stats_kernel", 8.0 * (double)P * Co_, 16.0 * (double)P, rc_stats_kernel, dim3((unsigned)nblk), dim3(256), 0, stream, x0,
+                      L.weight, (int)P, ppb, partials);
+            MP_CHECK_LAUNCH();
+        } else if (l == 1 && rc_first) {
+            int ppb = 1024;
+            while ((P + ppb - 1) / ppb < 512 && ppb > 128) ppb >>= 1;
+            const unsigned gx = (unsigned)((P + ppb - 1) / ppb);
+            const double fl = 2.0 * (double)P * Co_ * Ci_, by = 4.0 * ((double)P * (4 + Co_) + (double)Co_ * Ci_);
+            char tg[64];
+            snprintf(tg, sizeof tg, "fwd_chunk_kernel<%d, %d, false, 4>", Ci_, Co_);
+            if (Co_ == 64)
+                MP_LAUNCH(tg, fl, by, (fwd_chunk_kernel<64, 64, false, SRC_ACT_RC>), dim3(gx), dim3(256), 0, stream, A, (int)P, ppb, L.weight, L.z, partials, po);
+            else
+                MP_LAUNCH(tg, fl, by, (fwd_chunk_kernel<64, 128, false, SRC_ACT_RC>), dim3(gx), dim3(256), 0, stream, A, (int)P, ppb, L.weight, L.z, partials, po);
+            MP_CHECK_LAUNCH();
+            nblk = (int)gx;
+        } else if (l > 0 && (Ci_ == 64 || Ci_ == 128) && (Co_ == 64 || Co_ == 128 || Co_ == 256) && (P % K) == 0 && (1024 % K == 0 || !fuse_pool) &&
             chunk_fwd_enabled() && !(fuse_pool && (K % 32) != 0)) {
             (void)last_unfused;
             int ppb = 1024;
@@ -1406,6 +1508,7 @@ extern "C" int mp_sa_mlp_fwd_f32(const float* x0, int64_t P, int64_t K, int n_la
         A.t = L.shift;
         A.C = C;
         A.K = (int)K;
+        if (l == 0 && rc_first) { A.rx = x0; A.rw = L.weight; }
     }
     const mp_mlp_layer_t& LL = layers[n_layers - 1];
     const int64_t G = P / K;
@@ -1443,6 +1546,10 @@ extern "C" int mp_sa_mlp_bwd_f32(const float* x0, int64_t P, int64_t K, int n_la
     }
     if (P * cmax >= ((int64_t)1 << 31)) return MP_EUNSUPPORTED;
     if (workspace_bytes < mp_sa_mlp_workspace_bytes(P, K, n_layers, ch, 1)) return MP_EWORKSPACE;
+    const bool rc_first = layers[0].z == nullptr;   // the forward pass did not store Z_0 (mp_sa_mlp_recompute_first)
+    if (rc_first && (grad_x0 || !mp_sa_mlp_recompute_first(n_layers, ch, K))) return MP_EINVAL;
+    for (int l = 1; l < n_layers; ++l)
+        if (!layers[l].z) return MP_EINVAL;
     hipStream_t stream = mp_stream(stream_);
     // carve the workspace (same order as mp_sa_mlp_workspace_bytes)
     unsigned char* w = reinterpret_cast<unsigned char*>(workspace);
@@ -1505,6 +1612,8 @@ extern "C" int mp_sa_mlp_bwd_f32(const float* x0, int64_t P, int64_t K, int n_la
         IN.C = Ci;
         IN.K = (int)K;
         if (l == 0) { IN.x = x0; } else { IN.x = layers[l - 1].z; IN.s = layers[l - 1].scale; IN.t = layers[l - 1].shift; }
+        if (rc_first && l == 1) { IN.rx = x0; IN.rw = layers[0].weight; }   // act(Z_0) and raw Z_0 from the input rows
+        if (rc_first && l == 0) { DZ.rx = x0; DZ.rw = Ly.weight; }          // dZ_0 = f(Z_0, G_0) likewise
 
         // dW_l = dZ_l^T * act(Z_{l-1})
         if (!dw_joint && !mp::zero_async(grads[l].d_weight, (size_t)Co * Ci, stream)) return MP_ELAUNCH;
@@ -1522,7 +1631,15 @@ extern "C" int mp_sa_mlp_bwd_f32(const float* x0, int64_t P, int64_t K, int n_la
 #define MP_FUSED(MODE, CO_, CI_)                                                                                              \
     MP_LAUNCH(tg, fl, by, (bwd_fused_kernel<MODE, CO_, CI_>), dim3(gx), dim3((CO_ >= 128 && CI_ == 128) ? 512 : 256), 0, stream, DZ, IN, (int)P, ppb, Ly.weight, \
               grads[l].d_weight, Gn, partials)
-            if (Co == 256) {
+            if (rc_first && l == 1) {   // (never the pooled layer: n_layers >= 3)
+                snprintf(tg, sizeof tg, "bwd_fused_kernel<2, %d, 64, 4>", Co);
+                if (Co == 64)
+                    MP_LAUNCH(tg, fl, by - 4.0 * (double)P * (Ci - 4), (bwd_fused_kernel<SRC_DZ, 64, 64, SRC_ACT_RC>), dim3(gx), dim3(256), 0, stream, DZ, IN,
+                              (int)P, ppb, Ly.weight, grads[l].d_weight, Gn, partials);
+                else
+                    MP_LAUNCH(tg, fl, by - 4.0 * (double)P * (Ci - 4), (bwd_fused_kernel<SRC_DZ, 128, 64, SRC_ACT_RC>), dim3(gx), dim3(256), 0, stream, DZ, IN,
+                              (int)P, ppb, Ly.weight, grads[l].d_weight, Gn, partials);
+            } else if (Co == 256) {
                 if (pooled) MP_FUSED(SRC_DZ_POOLED, 256, 128); else MP_FUSED(SRC_DZ, 256, 128);
             } else if (pooled) {
                 if (Co == 64 && Ci == 64) MP_FUSED(SRC_DZ_POOLED, 64, 64);
@@ -1555,6 +1672,13 @@ extern "C" int mp_sa_mlp_bwd_f32(const float* x0, int64_t P, int64_t K, int n_la
             else
                 MP_LAUNCH("bwd_first_kernel<2>", fl, by, (bwd_first_kernel<SRC_DZ>), dim3(gx), dim3(512), 0, stream, DZ, IN, (int)P, ppb, Ly.weight,
                           grads[l].d_weight, grad_x0);
+            MP_CHECK_LAUNCH();
+            continue;
+        }
+        if (rc_first && l == 0) {
+            const double fl = 2.0 * (double)P * Co * Ci, by = 4.0 * ((double)P * Co + 2.0 * (double)P * Ci);
+            MP_LAUNCH("dw_ci4_kernel<5, 0>", fl, by, (dw_ci4_kernel<SRC_DZ_RC, SRC_ID>), dim3((unsigned)((P + 1023) / 1024)), dim3(256), 0, stream, DZ, IN,
+                      (int)P, 1024, grads[l].d_weight);
             MP_CHECK_LAUNCH();
             continue;
         }

@@ -27,12 +27,16 @@ class _SharedMLPMax(torch.autograd.Function):
         P, C0 = x.shape
         layers = (_lib.MlpLayer * n_layers)()
         keep = []  # tensors the structs point to: alive until the call returns; saved ones also for backward
-        chans = [C0]
+        chans = [C0] + [params[6 * l].shape[0] for l in range(n_layers)]
+        lib = _lib.load()
+        ch = (ctypes.c_int64 * len(chans))(*chans)
+        # first layer of a level fed by bare coordinates (4 input channels): Z_0 is recomputed by its consumers instead of being
+        # written once and read three times (sa_mlp.hip, SRC_*_RC) -- no buffer for it at all
+        recompute_first = (not x.requires_grad) and bool(lib.mp_sa_mlp_recompute_first(n_layers, ch, K))
         for l in range(n_layers):
             w, b, gam, bet, rm, rv = params[6 * l:6 * l + 6]
             co, ci = w.shape
-            chans.append(co)
-            z = torch.empty((P, co), dtype=torch.float32, device=dev)
+            z = None if (l == 0 and recompute_first) else torch.empty((P, co), dtype=torch.float32, device=dev)
             stats = torch.empty((4, co), dtype=torch.float32, device=dev)  # mean, rstd, scale, shift
             keep.append((w, b, gam, bet, rm, rv, z, stats))
             layers[l] = _lib.MlpLayer(_ptr(w), _ptr(b), _ptr(gam), _ptr(bet), _ptr(rm), _ptr(rv), ci, co, _ptr(z),
@@ -42,8 +46,6 @@ class _SharedMLPMax(torch.autograd.Function):
         out = torch.empty((G, cl), dtype=torch.float32, device=dev)
         argk = torch.empty((G, cl), dtype=torch.int32, device=dev)
         zmax = torch.empty((G, cl), dtype=torch.float32, device=dev)
-        ch = (ctypes.c_int64 * len(chans))(*chans)
-        lib = _lib.load()
         ws = torch.empty((lib.mp_sa_mlp_workspace_bytes(P, K, n_layers, ch, 0),), dtype=torch.uint8, device=dev)
         ops._run("sa_mlp_fwd", x, lib.mp_sa_mlp_fwd_f32, _ptr(x), P, K, n_layers, layers, int(training), float(momentum),
                  float(eps), _ptr(out), _ptr(argk), _ptr(zmax), _ptr(ws), ws.numel())

@@ -694,3 +694,32 @@ def test_pipelined_first_level_sampling_changes_nothing_but_the_schedule():
     c = TrainStep("cuboids", B=4, N=1024, seed=7, graph=True, overlap_sampling=True)   # replay + eagerly launched pipeline
     lc = [float(c.step()) for _ in range(6)]
     assert c._graph is not None and lc[0] == la[0] and np.allclose(la[:3], lc[:3], rtol=1e-2) and np.allclose(la, lc, rtol=8e-2), (la, lc)
+
+
+def test_recomputed_first_layer_matches_the_stored_one(monkeypatch):
+    """Set abstraction 1 feeds bare coordinates (4 input channels) into its first 1x1 convolution; the library recomputes that
+    layer's pre-BatchNorm output wherever it is consumed instead of storing it (sa_mlp.hip, SRC_*_RC; mp_sa_mlp_recompute_first).
+    Same FMA chain as the stored path (the BatchNorm sums are formed in a different order): outputs and every parameter
+    gradient agree to rounding."""
+    from maskplanner_amd import _lib
+    from maskplanner_amd.pointnet2_utils import PointNetSetAbstraction
+    import ctypes
+    lib = _lib.load()
+    ch = (ctypes.c_int64 * 4)(4, 64, 64, 128)
+    torch.manual_seed(3)
+    sa = PointNetSetAbstraction(npoint=64, radius=0.3, nsample=32, in_channel=3, mlp=[64, 64, 128], group_all=False).cuda().train()
+    xyz = torch.rand(3, 3, 700, device="cuda")
+    res = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("MP_RECOMPUTE_FIRST", flag)
+        assert bool(lib.mp_sa_mlp_recompute_first(3, ch, 32)) == (flag == "1")
+        sa.zero_grad()
+        from maskplanner_amd import pointnet2_utils as pu
+        with pu.fps_start_override([torch.zeros(3, dtype=torch.long)]):
+            new_xyz, feat = sa(xyz, None)
+        (feat * torch.linspace(-1, 1, feat.numel(), device="cuda").view_as(feat)).sum().backward()
+        res[flag] = [feat.detach().clone()] + [p.grad.detach().clone() for p in sa.parameters()]
+        for m in sa.mlp_bns:                      # identical running statistics updates on both passes
+            m.reset_running_stats()
+    for a, b in zip(res["1"], res["0"]):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-6 * float(b.abs().max())), float((a - b).abs().max())
