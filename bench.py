@@ -120,6 +120,10 @@ def main():
         torch.cuda.synchronize()
 
     lib = _lib.load()
+    # set-up, before the contract's warmup: the steps TrainStep needs to create optimizer state and record its hipGraph (three
+    # eager steps + the recording one), so that even --warmup 0 times replays and not the recording
+    while ts.use_graph and ts._graph is None:
+        ts.step()
     for _ in range(args.warmup):
         ts.step()
     barrier()
