@@ -723,3 +723,46 @@ def test_recomputed_first_layer_matches_the_stored_one(monkeypatch):
             m.reset_running_stats()
     for a, b in zip(res["1"], res["0"]):
         assert torch.allclose(a, b, rtol=1e-5, atol=1e-6 * float(b.abs().max())), float((a - b).abs().max())
+
+
+def _np_chamfer(x, y, asymmetric=False):
+    """Brute-force chamfer of two single clouds in float64: mean_x min_y |x-y|^2 (+ mean_y min_x)."""
+    d = ((x[:, None, :].astype(np.float64) - y[None, :, :].astype(np.float64)) ** 2).sum(-1)
+    cx = d.min(1).mean()
+    return cx if asymmetric else cx + d.min(0).mean()
+
+
+def test_metrics_handler_chamfer_metrics_against_brute_force():
+    """maskplanner_amd.metrics_handler (reference metrics_handler.py:226-282, 445-496): pcd with -100 padded GT, chamfer_original,
+    stroke_chamfer -- each against a float64 numpy restatement of what the reference computes; bookkeeping as the reference."""
+    from maskplanner_amd.metrics_handler import MetricsHandler
+    rng = np.random.default_rng(5)
+    B, S, lam, D = 3, 40, 4, 6
+    cfg = {"extra_data": ["orientnorm"], "lambda_points": lam, "normalization": "none"}
+    mh = MetricsHandler(cfg, metrics=["pcd", "chamfer_original"])
+    y_pred = rng.normal(size=(B, S, lam * D)).astype(np.float32)
+    n_valid = [150, 97, 160]
+    gt = np.full((B, 160, D), -100.0, dtype=np.float32)
+    for b, n in enumerate(n_valid):
+        gt[b, :n] = rng.normal(size=(n, D))
+    got = mh.compute(y_pred=torch.from_numpy(y_pred).cuda(), y=None, traj_as_pc=torch.from_numpy(gt), traj_pc=torch.from_numpy(gt[:, :97].copy()))
+    want_pcd = 1e4 * np.mean([_np_chamfer(y_pred[b].reshape(-1, D), gt[b, :n]) for b, n in enumerate(n_valid)])
+    want_orig = 1e4 * np.mean([_np_chamfer(y_pred[b].reshape(-1, D), gt[b, :97]) for b in range(B)])
+    assert got.shape == (2,) and mh.tot_num_of_metrics() == 2
+    assert abs(got[0] - want_pcd) <= 1e-5 * want_pcd and abs(got[1] - want_orig) <= 1e-5 * want_orig, (got, want_pcd, want_orig)
+    # stroke chamfer: GT strokes as contiguous id runs; predicted vectors of lam poses each
+    ids = np.stack([np.sort(rng.integers(0, 4, size=97)) for _ in range(B)])
+    for b in range(B):
+        ids[b] = np.unique(ids[b], return_inverse=True)[1]
+    pc = gt[:, :97].copy()
+    sc = mh.get_eval_metric("stroke_chamfer", y_pred=torch.from_numpy(y_pred), y=None, traj_pc=torch.from_numpy(pc), stroke_ids=ids)
+    want = np.mean([np.mean([min(1e4 * _np_chamfer(y_pred[b, i].reshape(-1, D), pc[b, ids[b] == k], asymmetric=True)
+                                 for k in range(ids[b, -1] + 1)) for i in range(S)]) for b in range(B)])
+    assert abs(sc - want) <= 1e-5 * want, (sc, want)
+    with pytest.raises(NotImplementedError):
+        mh.get_eval_metric("clustering_metrics")
+    # renormalisation leaves the -100 padding rows alone (:199-217)
+    mh2 = MetricsHandler({**cfg, "normalization": "per-dataset"}, metrics=["pcd"], renormalize_output_config={"active": True, "from": 2.0, "to": 4.0})
+    t = torch.from_numpy(gt.copy())
+    r = mh2.renormalize_traj(t.clone())
+    assert torch.equal(r[0, 150:], t[0, 150:]) and torch.allclose(r[0, :150, :3], t[0, :150, :3] * 0.5) and torch.equal(r[..., 3:], t[..., 3:])
