@@ -283,6 +283,13 @@ int mp_linear_dx_skinny_f32(const float* g, const float* weight, int64_t B, int6
 int mp_profiler_enable(int on);
 int mp_profiler_collect(char* buf, size_t cap);
 
+/* Batch collation: out[b, r, :] = r < len_b ? flat[offsets[b] + r, :] : fill, len_b = offsets[b+1] - offsets[b]; flat
+ * [offsets[B], D], offsets i64 [B+1] on the device, out [B, R, D] (rows beyond R are dropped).  Replaces the per-sample numpy
+ * concatenate + torch.stack of utils/dataset/paintnet_ODv1.py:738-748 (add_fake_vectors_v2 :887-904: fill -100;
+ * add_fake_values_v2 :907-925: fill -1, D = 1). */
+int mp_pad_ragged_f32(const float* flat, const int64_t* offsets, int64_t B, int64_t R, int64_t D, float fill, float* out,
+                      mp_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

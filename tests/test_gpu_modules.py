@@ -766,3 +766,40 @@ def test_metrics_handler_chamfer_metrics_against_brute_force():
     t = torch.from_numpy(gt.copy())
     r = mh2.renormalize_traj(t.clone())
     assert torch.equal(r[0, 150:], t[0, 150:]) and torch.allclose(r[0, :150, :3], t[0, :150, :3] * 0.5) and torch.equal(r[..., 3:], t[..., 3:])
+
+
+def test_device_collate_matches_the_reference_padding():
+    """maskplanner_amd.collate (utils/dataset/paintnet_ODv1.py:726-847): ragged traj / traj_as_pc padded with -100 rows, stroke ids
+    with -1, everything float32, against the reference's per-sample numpy recipe (add_fake_vectors_v2 :887-904,
+    add_fake_values_v2 :907-925) restated inline; an empty sample and the equal-length (stack) case included."""
+    from maskplanner_amd.collate import Paintnet_ODv1_CollateBatch, pad_ragged
+    rng = np.random.default_rng(11)
+    data = []
+    for n_seg, n_pts in [(5, 40), (9, 71), (0, 0), (9, 64)]:
+        data.append({"point_cloud": rng.normal(size=(128, 3)), "traj": rng.normal(size=(n_seg, 24)), "traj_as_pc": rng.normal(size=(n_pts, 6)),
+                     "stroke_ids": np.sort(rng.integers(0, 3, size=n_seg)), "stroke_ids_as_pc": np.sort(rng.integers(0, 3, size=n_pts)),
+                     "dirname": f"s{n_seg}", "n_strokes": 3, "stroke_masks": rng.integers(0, 2, size=(3, max(n_seg, 1)))})
+    batch = Paintnet_ODv1_CollateBatch({"load_extra_data": ["stroke_masks"], "traj_with_equally_spaced_points": True})(data)
+
+    def ref_pad(a, total, fill):
+        a = np.asarray(a, dtype=np.float64)
+        n = total - a.shape[0]
+        pad = fill * np.ones((n,) + a.shape[1:])
+        return np.concatenate((a, pad), axis=0) if n > 0 else a
+    for key, fill in [("traj", -100), ("traj_as_pc", -100), ("stroke_ids", -1), ("stroke_ids_as_pc", -1)]:
+        total = max(len(d[key]) for d in data)
+        want = torch.stack([torch.as_tensor(ref_pad(d[key], total, fill), dtype=torch.float) for d in data])
+        got = batch[key]
+        assert got.is_cuda and got.dtype == torch.float32 and got.shape == want.shape, key
+        assert torch.equal(got.cpu(), want), key
+    assert torch.equal(batch["point_cloud"].cpu(), torch.stack([torch.as_tensor(d["point_cloud"], dtype=torch.float) for d in data]))
+    assert batch["dirname"] == ["s5", "s9", "s0", "s9"] and batch["n_strokes"] == [3] * 4 and len(batch["stroke_masks"]) == 4
+    assert batch["stacked_segments_per_stroke"] is None
+    same = [rng.normal(size=(7, 6)) for _ in range(3)]
+    assert torch.equal(pad_ragged(same, -100.0).cpu(), torch.as_tensor(np.stack(same), dtype=torch.float))
+    assert pad_ragged(same, -100.0, total_needed=10).shape == (3, 10, 6)
+    with pytest.raises(NotImplementedError):
+        Paintnet_ODv1_CollateBatch({"load_extra_data": ["segments_per_stroke"]})
+    # the collated batch feeds the loss as the synthetic one does: padding rows are recognised downstream
+    from maskplanner_amd import ops
+    assert ops.padded_lengths(batch["traj_as_pc"]).tolist() == [40, 71, 0, 64]
