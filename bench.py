@@ -176,7 +176,9 @@ def main():
                                    f"(forward+loss+backward+Adam), S={cat.out_vectors} M={cat.max_n_strokes}",
                        "parallelism": f"dp{world}", "global_batch": args.batch * world, "grad_allreduce_MB":
                            round(ts.reducer.grad_bytes() / 1e6, 1),
-                       "launch": "hipGraph replay of the recorded step" if ts._graph is not None else "eager (kernel by kernel)",
+                       "launch": ("hipGraph replay of the recorded step" + (" (two graphs; head optimizer on its own stream under the next encoder forward)"
+                                                                             if ts._graph_b is not None else ""))
+                       if ts._graph is not None else "eager (kernel by kernel)",
                        "sampling": "next batch's first-level FPS + ball query on a second stream, under the step" if ts.overlap
                        else "in line"},
             "roofline": {"kernel": dom, "bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak,

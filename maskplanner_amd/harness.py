@@ -39,6 +39,12 @@ class TrainStep:
             overlap_sampling = os.environ.get("MASKPLANNER_OVERLAP_SAMPLING", "1") != "0"
         self.overlap = bool(overlap_sampling) and fused and not prefetch_sampling
         self._plan_next, self._plan_cur, self._plan_stream, self._plan_ev = None, None, None, None
+        # Deferred head optimizer (see _record_split): the step is recorded as TWO graphs, encoder forward | everything else, and
+        # the factor Adam of the seven head matrices (0.97 GB of HBM traffic, bandwidth-bound) is launched eagerly on its own
+        # stream after the second graph: it then runs underneath the NEXT step's encoder forward (MFMA-bound), which does not
+        # touch the head weights; the next step's second graph waits for it.
+        self._graph_b, self._factor_args, self._adam_stream, self._adam_ev = None, None, None, None
+        self._split_adam_wanted = os.environ.get("MASKPLANNER_SPLIT_ADAM", "1") != "0"
         self.factor_opt = None
         dense = list(self.model.parameters())
         if factor_heads and fused:
@@ -60,6 +66,9 @@ class TrainStep:
         self.prefetch = bool(prefetch_sampling) and self.device.type == "cuda"
 
     def forward_loss(self):
+        return self._heads_loss(self._encode())
+
+    def _encode(self):
         # sa1's start is consumed only when its sampling was not prefetched; sa2's always
         sa1 = self.model.sa1
         ready = (self.prefetch or self.overlap) and pu.has_prefetched(self.batch["point_cloud"], sa1.npoint, sa1.radius, sa1.nsample)
@@ -67,7 +76,10 @@ class TrainStep:
         if ready and self.overlap:
             starts = self.batch["fps_start"][len(self._plan_levels()):]   # every sampling level comes from the plan
         with pu.fps_start_override(starts):
-            out, sm_out, mask_conf, seg_conf = self.model(self.point_cloud)
+            return self.model.encode(self.point_cloud)
+
+    def _heads_loss(self, feat):
+        out, sm_out, mask_conf, seg_conf = self.model.heads(feat)
         return self.loss_handler.compute(return_list=False, y_pred=out, y=self.batch["traj"], pred_stroke_masks=sm_out,
                                          mask_scores=mask_conf, seg_logits=seg_conf, stroke_ids=self.batch["stroke_ids"],
                                          traj_as_pc=self.batch["traj_as_pc"])
@@ -80,6 +92,11 @@ class TrainStep:
             self._pipeline_sampling()
         if self._graph is not None:
             self._graph.replay()
+            if self._graph_b is not None:
+                if self._adam_ev is not None:
+                    torch.cuda.current_stream().wait_event(self._adam_ev)   # the head weights of the previous step are final
+                self._graph_b.replay()
+                self._launch_factor_adam()
             return self._graph_loss
         if not self.use_graph:
             return self._eager_step()
@@ -101,6 +118,8 @@ class TrainStep:
         """Record one full step into a hipGraph (torch.cuda.graph: private memory pool, graph-safe Philox offsets for the
         dropout layers).  The batch tensors, parameters and optimizer state are the static inputs.  Capture only records,
         so the graph is replayed once right away: this call performs exactly one optimisation step."""
+        if self._split_adam_wanted and self.factor_opt is not None:
+            return self._record_split()
         try:
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
@@ -114,11 +133,54 @@ class TrainStep:
             self._graph, self.use_graph = None, False
             torch.cuda.synchronize()
 
+    def _record_split(self):
+        """Two graphs on one capture stream and one memory pool (the autograd graph built while recording the first is walked
+        while recording the second): A = encoder forward, B = heads + loss + backward + dense Adam.  The factor Adam is not
+        recorded; its (x, g) factor buffers are static tensors of the pool, remembered here."""
+        try:
+            torch.cuda.synchronize()
+            cap = torch.cuda.Stream()
+            ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            self.model.factor_store.clear()
+            with torch.cuda.graph(ga, stream=cap):
+                self._supply_plan()
+                self.reducer.zero_grad()
+                feat = self._encode()
+            with torch.cuda.graph(gb, pool=ga.pool(), stream=cap):
+                loss = self._heads_loss(feat)
+                loss.backward()
+                self.reducer.finish()
+                self.opt.step()
+                loss = loss.detach()
+            self._factor_args = dict(self.model.factor_store)
+            self.model.factor_store.clear()
+            self._adam_stream = torch.cuda.Stream()
+            self._graph, self._graph_b, self._graph_loss = ga, gb, loss
+            ga.replay()
+            gb.replay()
+            self._launch_factor_adam()
+        except Exception as exc:   # stay correct: eager from here on
+            import warnings
+            warnings.warn(f"hipGraph capture of the training step failed ({type(exc).__name__}: {exc}); running eagerly")
+            self._graph, self._graph_b, self.use_graph = None, None, False
+            torch.cuda.synchronize()
+
+    def _launch_factor_adam(self):
+        side = self._adam_stream
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            self.model.factor_store.update(self._factor_args)
+            self.factor_opt.step()
+            self._adam_ev = torch.cuda.Event()
+            self._adam_ev.record(side)
+
     def eager_step(self):
         """One step launched kernel by kernel even when a recorded graph exists (bench.py's per-kernel timing hooks live in
         the launch path).  Shares parameters and optimizer state with the graph, so the two can be interleaved."""
         if self.overlap:
             self._pipeline_sampling()
+        if self._adam_ev is not None:
+            torch.cuda.current_stream().wait_event(self._adam_ev)
         return self._eager_step()
 
     def _plan_levels(self):
@@ -174,7 +236,7 @@ class TrainStep:
             self._plan_ev = torch.cuda.Event()
             self._plan_ev.record(side)
 
-    def _eager_step(self):
+    def _supply_plan(self):
         if self.overlap:
             if self._plan_cur is None:
                 self._pipeline_sampling()
@@ -182,6 +244,9 @@ class TrainStep:
             for m, plan in zip(self._plan_levels(), self._plan_views(self._plan_cur)):
                 pu.supply_sampling(xyz, m.npoint, m.radius, m.nsample, plan)
                 xyz = plan[1]    # the next level's cloud IS this level's centroid tensor (same storage: the lookup key)
+
+    def _eager_step(self):
+        self._supply_plan()
         self.reducer.zero_grad()
         loss = self.forward_loss()
         loss.backward()

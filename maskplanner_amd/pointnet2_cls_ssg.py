@@ -145,9 +145,13 @@ class PointNet2Regressor_StrokeMasks(_SSGEncoder):
     factor_store = None
 
     def forward(self, xyz):
-        B = xyz.shape[0]
+        return self.heads(self.encode(xyz))
+
+    def heads(self, feat):
+        """Global feature [B,1024] -> (out, sm_out, mask_conf, seg_conf): everything behind the encoder (:309-341).  Split from
+        forward() so that a harness can schedule the two halves separately (harness.TrainStep records them as two graphs)."""
+        B = feat.shape[0]
         fs = self.factor_store
-        feat = self.encode(xyz)
         fused = feat.is_cuda
         if fused:
             _tick(*([self.bn1, self.bn2] + ([self.sm_bn1, self.sm_bn2] if self.pred_stroke_masks else [])))

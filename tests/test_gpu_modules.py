@@ -803,3 +803,43 @@ def test_device_collate_matches_the_reference_padding():
     # the collated batch feeds the loss as the synthetic one does: padding rows are recognised downstream
     from maskplanner_amd import ops
     assert ops.padded_lengths(batch["traj_as_pc"]).tolist() == [40, 71, 0, 64]
+
+
+def test_two_graph_step_with_deferred_head_optimizer(monkeypatch):
+    """harness.TrainStep records the step as two graphs (encoder forward | heads + loss + backward + dense Adam) and launches the
+    factor Adam of the head matrices eagerly on its own stream, where it overlaps the next step's encoder forward; the next
+    step's second graph waits for it.  Same arithmetic as the single-graph step: identical first losses, training that tracks
+    it, identical head weights after one step, and interleaved eager steps see finished head weights."""
+    from maskplanner_amd.harness import TrainStep
+    monkeypatch.setenv("MASKPLANNER_SPLIT_ADAM", "0")
+    a = TrainStep("cuboids", B=4, N=1024, seed=21, graph=True)
+    w_init = a.model.fc3.weight.detach().clone()
+    la = [float(a.step()) for _ in range(8)]
+    assert a._graph is not None and a._graph_b is None
+    monkeypatch.setenv("MASKPLANNER_SPLIT_ADAM", "1")
+    b = TrainStep("cuboids", B=4, N=1024, seed=21, graph=True)
+    lb = [float(b.step()) for _ in range(8)]
+    assert b._graph is not None and b._graph_b is not None, "the step was not recorded as two graphs"
+    assert la[0] == lb[0] and np.allclose(la[:3], lb[:3], rtol=1e-2) and np.allclose(la, lb, rtol=8e-2), (la, lb)
+    torch.cuda.synchronize()
+    da, db = (a.model.fc3.weight.detach() - w_init).flatten(), (b.model.fc3.weight.detach() - w_init).flatten()
+    # eight Adam steps of the 12 M head weights: the same walk up to sign flips of near-zero gradients (atomics noise)
+    monkeypatch.setenv("MASKPLANNER_SPLIT_ADAM", "0")
+    a2 = TrainStep("cuboids", B=4, N=1024, seed=21, graph=True)
+    for _ in range(8):
+        a2.step()
+    torch.cuda.synchronize()
+    da2 = (a2.model.fc3.weight.detach() - w_init).flatten()
+    cos = lambda u, v: float(torch.dot(u, v) / (u.norm() * v.norm()))
+    noise = cos(da, da2)                     # two single-graph runs against each other: the floor set by the atomics
+    assert float(da.abs().mean()) > 1e-3 and cos(da, db) > min(0.8, noise - 0.05), (cos(da, db), noise)
+    monkeypatch.setenv("MASKPLANNER_SPLIT_ADAM", "1")
+    before = float(b.step())
+    eager = float(b.eager_step())
+    after = float(b.step())
+    assert np.isfinite([before, eager, after]).all() and after < lb[0]
+    # every head matrix really moves every step (the deferred optimizer is launched after each replay)
+    w0 = b.model.sm_fc3.weight.detach().clone()
+    b.step()
+    torch.cuda.synchronize()
+    assert float((b.model.sm_fc3.weight - w0).abs().max()) > 0
