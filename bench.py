@@ -124,6 +124,8 @@ def main():
     # eager steps + the recording one), so that even --warmup 0 times replays and not the recording
     while ts.use_graph and ts._graph is None:
         ts.step()
+    if ts._graph is not None:
+        ts.eager_step()   # the profiled steps of the timed region launch eagerly on this stream: warm its allocator blocks too
     for _ in range(args.warmup):
         ts.step()
     barrier()
