@@ -574,7 +574,7 @@ __global__ __launch_bounds__(THREADS) void dw_gemm_kernel(PosOperand DZ, PosOper
 // other waves' MFMAs instead of being a separate phase of a 128 x 128 tile.  One partial-sum row per workgroup
 // (P / p_per_block rows instead of P / 128) also makes the BatchNorm finalize kernel 8x shorter.
 // =================================================================================================================
-template <int CI, int CO, bool POOL, int MODE_A = SRC_ACT>
+template <int CI, int CO, bool POOL, int MODE_A = SRC_ACT, int TAIL = 0>   // TAIL = 4: input rows are [CI | 4] wide (features | xyz + pad)
 __global__ __launch_bounds__(CO > 128 ? 512 : 256) void fwd_chunk_kernel(PosOperand A, int P, int p_per_block,
                                                                          const float* __restrict__ W, float* __restrict__ Z,
                                                                          float* __restrict__ partials, PoolOut po)
@@ -589,6 +589,7 @@ __global__ __launch_bounds__(CO > 128 ? 512 : 256) void fwd_chunk_kernel(PosOper
     static_assert((CW == 32 || CW == 16) && PA >= 1, "shape");
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     __shared__ __attribute__((aligned(16))) float sA[2][DBK * LDA];
+    __shared__ float4 sT[2][TAIL ? DBK : 1];           // TAIL: the 4 extra input columns of the chunk's rows
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     const int lc = BIG ? (lane & 31) : (lane & 15);   // column of this lane inside the wave's tile
@@ -602,21 +603,26 @@ __global__ __launch_bounds__(CO > 128 ? 512 : 256) void fwd_chunk_kernel(PosOper
     // B[k][n] = W[n][k]: 32x32x2 lane (n, kq) holds W[col][2*st + kq]; 16x16x4 lane (n, kq) holds W[col][4*st + kq]
     float wfrag[NFR];
 #pragma unroll
-    for (int st = 0; st < NFR; ++st) wfrag[st] = W[(size_t)col * CI + (BIG ? 2 : 4) * st + kq];
+    for (int st = 0; st < NFR; ++st) wfrag[st] = W[(size_t)col * (CI + TAIL) + (BIG ? 2 : 4) * st + kq];
+    float4 wt = make_float4(0.f, 0.f, 0.f, 0.f);     // TAIL: this lane's column of the 4 extra weight columns (VALU, not MFMA:
+    if constexpr (TAIL != 0) wt = ld4(W + (size_t)col * (CI + TAIL) + CI);   // a 32-wide k tile would be 1/8 full)
 
     const int ca = (tid % (CI / 4)) * 4, ka0 = tid / (CI / 4);
     constexpr int KA_STEP = NT / (CI / 4);
     ChanConst kc;
     load_consts<MODE_A>(A, ca, kc);
     Raw4<MODE_A> ra[PA];
+    Raw4<MODE_A> rt;
     auto gload = [&](int pk) {
 #pragma unroll
         for (int ps = 0; ps < PA; ++ps) raw_load<MODE_A>(A, p1, pk + ka0 + ps * KA_STEP, ca, ra[ps]);
+        if constexpr (TAIL != 0) { if (tid < DBK) raw_load<MODE_A>(A, p1, pk + tid, CI, rt); }
     };
     auto sstore = [&](int buf) {
 #pragma unroll
         for (int ps = 0; ps < PA; ++ps)
             *reinterpret_cast<float4*>(&sA[buf][(ka0 + ps * KA_STEP) * LDA + ca]) = finish<MODE_A>(ra[ps], kc);
+        if constexpr (TAIL != 0) { if (tid < DBK) sT[buf][tid] = finish<MODE_A>(rt, kc); }
     };
 
     double s1 = 0.0, s2 = 0.0;     // the chunk's values are summed in fp32, the 16-32 chunks of a workgroup in fp64
@@ -652,6 +658,13 @@ __global__ __launch_bounds__(CO > 128 ? 512 : 256) void fwd_chunk_kernel(PosOper
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) { v[i] = a0[i]; vrow[i] = 4 * kq + i; v[4 + i] = a1[i]; vrow[4 + i] = 16 + 4 * kq + i; }
+        }
+        if constexpr (TAIL != 0) {   // k = CI .. CI+3 appended to each element's FMA chain, in k order
+#pragma unroll
+            for (int r = 0; r < NV; ++r) {
+                const float4 xt = sT[cur][vrow[r]];
+                v[r] = __builtin_fmaf(xt.w, wt.w, __builtin_fmaf(xt.z, wt.z, __builtin_fmaf(xt.y, wt.y, __builtin_fmaf(xt.x, wt.x, v[r]))));
+            }
         }
         const int pk = p0 + kcn * DBK;
         float lmax = -__builtin_inff(), lmin = __builtin_inff();
@@ -1448,6 +1461,17 @@ extern "C" int mp_sa_mlp_fwd_f32(const float* x0, int64_t P, int64_t K, int n_la
             MP_LAUNCH("rc_stats_kernel", 8.0 * (double)P * Co_, 16.0 * (double)P, rc_stats_kernel, dim3((unsigned)nblk), dim3(256), 0, stream, x0,
                       L.weight, (int)P, ppb, partials);
             MP_CHECK_LAUNCH();
+        } else if (l == 0 && Ci_ == 132 && Co_ == 128 && !fuse_pool && chunk_fwd_enabled()) {
+            // first layer of a level with a [128 features | xyz | pad] input: the position-stream kernel with the 4 extra columns
+            // on the VALU (the tiled kernel pays a whole 32-wide k tile for them)
+            int ppb = 1024;
+            while ((P + ppb - 1) / ppb < 512 && ppb > 128) ppb >>= 1;
+            const unsigned gx = (unsigned)((P + ppb - 1) / ppb);
+            const double fl = 2.0 * (double)P * Co_ * Ci_, by = 4.0 * ((double)P * (Ci_ + Co_) + (double)Co_ * Ci_);
+            MP_LAUNCH("fwd_chunk_kernel<128, 128, false, 0, 4>", fl, by, (fwd_chunk_kernel<128, 128, false, SRC_ID, 4>), dim3(gx), dim3(256), 0, stream, A,
+                      (int)P, ppb, L.weight, L.z, partials, po);
+            MP_CHECK_LAUNCH();
+            nblk = (int)gx;
         } else if (l == 1 && rc_first) {
             int ppb = 1024;
             while ((P + ppb - 1) / ppb < 512 && ppb > 128) ppb >>= 1;
