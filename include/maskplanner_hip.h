@@ -283,6 +283,15 @@ int mp_linear_dx_skinny_f32(const float* g, const float* weight, int64_t B, int6
 int mp_profiler_enable(int on);
 int mp_profiler_collect(char* buf, size_t cap);
 
+/* Adam (torch defaults, no weight decay / amsgrad) for `count` dense tensors in as few launches as their pointers fit into kernel
+ * arguments (48 per launch).  params / grads / exp_avg / exp_avg_sq: HOST arrays of device pointers, numels their lengths; grad_scale
+ * multiplies every gradient (1/world under data parallelism when the sum was not averaged).  step > 0: host-side step count; step
+ * <= 0: the count is read from step_dev (device float, graph-capturable).  Replaces torch.optim.Adam.step() on the non-factored
+ * parameters (train_maskplanner.py:159). */
+int mp_adam_multi_f32(int64_t count, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                      const int64_t* numels, double grad_scale, double lr, double beta1, double beta2, double eps, int64_t step,
+                      const float* step_dev, mp_stream_t stream);
+
 /* Batch collation: out[b, r, :] = r < len_b ? flat[offsets[b] + r, :] : fill, len_b = offsets[b+1] - offsets[b]; flat
  * [offsets[B], D], offsets i64 [B+1] on the device, out [B, R, D] (rows beyond R are dropped).  Replaces the per-sample numpy
  * concatenate + torch.stack of utils/dataset/paintnet_ODv1.py:738-748 (add_fake_vectors_v2 :887-904: fill -100;

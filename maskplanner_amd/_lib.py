@@ -74,6 +74,8 @@ SIGNATURES = {
     "mp_profiler_collect": (_int, [ctypes.c_char_p, _sz]),
     "mp_sa_mlp_workspace_bytes": (_sz, [_i64, _i64, _int, ctypes.POINTER(_i64), _int]),
     "mp_sa_mlp_recompute_first": (_int, [_int, ctypes.POINTER(_i64), _i64]),
+    "mp_adam_multi_f32": (_int, [_i64, _vp, _vp, _vp, _vp, ctypes.POINTER(_i64), ctypes.c_double, ctypes.c_double, ctypes.c_double,
+                                 ctypes.c_double, ctypes.c_double, _i64, _vp, _vp]),
     "mp_pad_ragged_f32": (_int, [_vp, _vp, _i64, _i64, _i64, ctypes.c_float, _vp, _vp]),
     "mp_sa_mlp_fwd_f32": (_int, [_vp, _i64, _i64, _int, ctypes.POINTER(MlpLayer), _int, _dbl, _dbl, _vp, _vp, _vp, _vp,
                                  _sz, _vp]),

@@ -8,6 +8,8 @@ all-gathered (a few MB) instead of all-reducing 137 MB of dW.
 
 Opt-in: the drop-in modules behave like plain nn.Linear unless a model's `factor_store` is set (the harness does).
 """
+import ctypes
+
 import torch
 import torch.distributed as dist
 import torch.nn.functional as F
@@ -110,3 +112,61 @@ class FactorAdam:
                      st["exp_avg_sq"].data_ptr(), x.data_ptr(), g.data_ptr(), x.shape[0], O, I, 1.0 / world, self.lr,
                      self.betas[0], self.betas[1], self.eps, st["step"], None if self.step_dev is None else self.step_dev.data_ptr())
             del self.store[k]
+
+
+class DenseAdam:
+    """torch.optim.Adam (defaults: betas (0.9, 0.999), eps 1e-8, no weight decay / amsgrad; train_maskplanner.py:159) for the
+    parameters that keep a dense gradient -- the encoder, BatchNorm affine parameters, biases: ~150 tensors, 0.9 M elements --
+    as csrc/adam_multi.hip: up to 48 tensors per launch with their pointers in the kernel arguments, instead of torch's
+    multi_tensor_apply with per-tensor device step counters (60-90 us per step when capturable).  `state[p]` holds `exp_avg`
+    and `exp_avg_sq` like torch's optimizer state.  capturable: the step count is one device float advanced by a device op."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, capturable=False):
+        self.params = [p for p in params]
+        for p in self.params:
+            if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()):
+                raise ValueError("DenseAdam drives contiguous float32 parameters on the GPU")
+        self.lr, self.betas, self.eps = lr, betas, eps
+        self.steps = 0
+        self.step_dev = torch.zeros((), dtype=torch.float32, device=self.params[0].device) if (capturable and self.params) else None
+        self.state = {p: dict(exp_avg=torch.zeros_like(p), exp_avg_sq=torch.zeros_like(p)) for p in self.params}
+        n = len(self.params)
+        arr = ctypes.c_void_p * n
+        self._p = arr(*[p.data_ptr() for p in self.params])
+        self._m = arr(*[self.state[p]["exp_avg"].data_ptr() for p in self.params])
+        self._v = arr(*[self.state[p]["exp_avg_sq"].data_ptr() for p in self.params])
+        self._g = arr()
+        self._n = (ctypes.c_int64 * n)()
+        self._numel = [p.numel() for p in self.params]
+
+    @torch.no_grad()
+    def step(self):
+        if not self.params:
+            return
+        live = 0
+        for i, p in enumerate(self.params):     # a parameter without a gradient this step is skipped (length 0), like torch does
+            g = p.grad
+            if g is None:
+                self._n[i] = 0
+                self._g[i] = None
+                continue
+            if not (g.is_contiguous() and g.dtype == torch.float32):
+                g = p.grad = g.contiguous().float()
+            self._g[i] = g.data_ptr()
+            self._n[i] = self._numel[i]
+            live += 1
+        if not live:
+            return
+        self.steps += 1
+        if self.step_dev is not None:
+            self.step_dev.add_(1.0)
+        ops._run("adam_multi", self.params[0], _lib.load().mp_adam_multi_f32, len(self.params), self._p, self._g, self._m, self._v, self._n,
+                 1.0, self.lr, self.betas[0], self.betas[1], self.eps, 0 if self.step_dev is not None else self.steps,
+                 None if self.step_dev is None else self.step_dev.data_ptr())
+
+    def zero_grad(self, set_to_none=True):
+        for p in self.params:
+            if set_to_none:
+                p.grad = None
+            elif p.grad is not None:
+                p.grad.zero_()

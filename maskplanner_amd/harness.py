@@ -8,7 +8,7 @@ import os
 import torch
 
 from . import dp, synthetic
-from .factor_heads import FactorAdam
+from .factor_heads import DenseAdam, FactorAdam
 from . import pointnet2_utils as pu
 from .loss_handler import LossHandler, maskplanner_loss_config
 from .pointnet2_cls_ssg import maskplanner_model
@@ -56,7 +56,12 @@ class TrainStep:
             self.factor_opt = FactorAdam(big, self.model.factor_store, lr=lr, capturable=self.use_graph)
             dense = [p for p in dense if all(p is not q for q in big.values())]
         self.reducer = dp.BucketedGradAllReduce(dense)
-        self.opt = torch.optim.Adam(dense, lr=lr, fused=fused, capturable=self.use_graph)  # train_maskplanner.py:159
+        # train_maskplanner.py:159.  On the GPU the dense parameters go through csrc/adam_multi.hip (same update, ~150 tensors in four
+        # launches); MASKPLANNER_TORCH_ADAM=1 keeps torch's fused Adam.
+        if fused and os.environ.get("MASKPLANNER_TORCH_ADAM", "0") == "0":
+            self.opt = DenseAdam(dense, lr=lr, capturable=self.use_graph)
+        else:
+            self.opt = torch.optim.Adam(dense, lr=lr, fused=fused, capturable=self.use_graph)
         b = synthetic.make_batch(seed + 1000 * rank, B, N, self.cat.name, dist_points)  # a different shard per rank
         self.batch = {k: (v.to(self.device) if torch.is_tensor(v) else [t.to(self.device) for t in v])
                       for k, v in b.items()}

@@ -843,3 +843,31 @@ def test_two_graph_step_with_deferred_head_optimizer(monkeypatch):
     b.step()
     torch.cuda.synchronize()
     assert float((b.model.sm_fc3.weight - w0).abs().max()) > 0
+
+
+@pytest.mark.parametrize("capturable", [False, True])
+def test_dense_adam_matches_torch_adam(capturable):
+    """factor_heads.DenseAdam (csrc/adam_multi.hip) against torch.optim.Adam on 130 tensors of mixed sizes (several launches of 48,
+    multi-chunk tensors, lengths that are not multiples of 4, a parameter without gradient): five steps."""
+    from maskplanner_amd.factor_heads import DenseAdam
+    g = torch.Generator().manual_seed(0)
+    sizes = [(64,), (128,), (3,), (1,), (64, 4), (128, 132), (256, 260), (1024, 512), (5000,), (4097,)] * 13
+    ours = [torch.nn.Parameter(torch.randn(*s, generator=g).cuda()) for s in sizes]
+    ref = [torch.nn.Parameter(p.detach().clone()) for p in ours]
+    skip = 7                                                   # never receives a gradient
+    oa = DenseAdam(ours, lr=1e-3, capturable=capturable)
+    ob = torch.optim.Adam(ref, lr=1e-3)
+    for step in range(5):
+        for i, (p, q) in enumerate(zip(ours, ref)):
+            if i == skip:
+                continue
+            gr = torch.randn(p.shape, generator=g).cuda() * (10.0 ** ((i % 5) - 2))
+            p.grad, q.grad = gr.clone(), gr.clone()
+        oa.step()
+        ob.step()
+    for i, (p, q) in enumerate(zip(ours, ref)):
+        assert torch.allclose(p, q, rtol=2e-6, atol=2e-7), (i, float((p - q).abs().max()))
+    assert torch.equal(ours[skip], ref[skip]) and oa.steps == 5
+    st = ob.state[ref[5]]
+    assert torch.allclose(oa.state[ours[5]]["exp_avg"], st["exp_avg"], rtol=1e-5, atol=1e-8)
+    assert torch.allclose(oa.state[ours[5]]["exp_avg_sq"], st["exp_avg_sq"], rtol=1e-5, atol=1e-10)
