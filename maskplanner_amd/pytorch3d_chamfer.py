@@ -146,10 +146,10 @@ def chamfer_distance(x, y, x_lengths=None, y_lengths=None, x_normals=None, y_nor
         cham_x = cham_y = None
         if need_x:
             dx, idx_x = ops.knn(x, y, x_lengths, y_lengths, 1)
-            cham_x = dx[..., 0]
+            cham_x = dx.view(N, P1)      # K = 1: a view both ways (dx[..., 0] costs a fill + a memcpy in backward)
         if need_y:
             dy, idx_y = ops.knn(y, x, y_lengths, x_lengths, 1)
-            cham_y = dy[..., 0]
+            cham_y = dy.view(N, P2)
         if weights is None and not return_normals and point_reduction is not None:
             # the training-step case: one fused reduction per direction that reaches the result (ops.chamfer_reduce)
             sc = 1.0 if _scale is None else float(_scale)
