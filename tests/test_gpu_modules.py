@@ -377,7 +377,7 @@ def test_full_size_forward_loss_backward_vs_oracle(oracle):
         _, l3 = T.set_abstraction(l2x, l2, T.layers_from_state(sd, "sa3."), None, None, None, None, True, group_all=True)
     close(feat, l3.reshape(B, -1), "encoder feature", rtol=2e-5, atol=2e-5)
     # The heads normalise with BatchNorm1d over these FOUR samples, which amplifies fp32 rounding ~30x: across data seeds and
-    # kernel variants the output error is 2e-4 .. 3.6e-4 (tools/fullsize_err.py), hence the 5e-4 (+ 5e-4 relative) bound here.
+    # kernel variants the output error is 2e-4 .. 3.6e-4 (tests/tools/fullsize_err.py), hence the 5e-4 (+ 5e-4 relative) bound here.
     close(out, o_out, "out", rtol=5e-4, atol=5e-4)
     close(loss, o_loss, "loss", rtol=3e-4)
     # Gradients: BatchNorm1d over 4 samples in the heads makes d(loss)/d(early weights) ill-conditioned, so they

@@ -2,7 +2,7 @@
 tests/test_gpu_modules.py::test_full_size_forward_loss_backward_vs_oracle bounds."""
 import os, sys
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from maskplanner_amd import pointnet2_cls_ssg as pc, pointnet2_utils as pu, synthetic as syn
 from oracle import torch_ref as T
 B, N = 4, 5120
