@@ -121,3 +121,30 @@ def test_set_abstraction_modules_have_reference_parameters():
     assert tuple(msg.conv_blocks[0][0].weight.shape) == (32, 3, 1, 1)
     fp = pu.PointNetFeaturePropagation(384, [256, 256])
     assert tuple(fp.mlp_convs[0].weight.shape) == (256, 384, 1) and "mlp_bns.1.num_batches_tracked" in fp.state_dict()
+
+
+def test_metrics_handler_bookkeeping_and_collate_validation_without_a_gpu(capsys):
+    """The host side of the optional callers (metrics_handler.py:24-196; paintnet_ODv1.py:713-724): metric registry, output names,
+    pretty printing, pose dimensionality, the renormalisation switch, and the extras a MaskPlanner collate does not take."""
+    from maskplanner_amd.metrics_handler import MetricsHandler, get_dim_traj_points
+    assert [get_dim_traj_points(e) for e in ([], ["vel"], ["orientnorm"], ["orientrotvec"], ["orientquat"])] == [3, 6, 6, 6, 7]
+    with pytest.raises(ValueError):
+        get_dim_traj_points(["vel", "orientnorm"])
+    cfg = {"extra_data": ["orientnorm"], "lambda_points": 4, "normalization": "per-dataset"}
+    mh = MetricsHandler(cfg, metrics=["pcd", "stroke_chamfer"])
+    assert mh.tot_num_of_metrics() == 2 and mh.num_of_metrics("pcd") == 1 and mh.metric_index["chamfer_original"] == 1
+    mh.pprint(np.array([1.234567, 2.0]), prefix="val")
+    out = capsys.readouterr().out
+    assert "point-wise chamfer distance: 1.23457" in out and "stroke chamfer distance: 2.0" in out
+    assert MetricsHandler(cfg).compute() == 0                                   # no metrics requested (:126-127)
+    with pytest.raises(AssertionError):
+        mh.get_eval_metric("no_such_metric")
+    with pytest.raises(NotImplementedError):
+        mh.get_eval_metric("sop_metrics")
+    assert not mh.renormalize_output and MetricsHandler(cfg, renormalize_output_config={"active": True, "from": 1, "to": 2}).renormalize_output
+    with pytest.raises(AssertionError):                                         # renormalisation needs per-dataset normalisation (:113)
+        MetricsHandler({**cfg, "normalization": "none"}, renormalize_output_config={"active": True})
+    from maskplanner_amd.collate import Paintnet_ODv1_CollateBatch
+    assert Paintnet_ODv1_CollateBatch({"load_extra_data": ["stroke_masks"]}).load_extra_data == ["stroke_masks"]
+    with pytest.raises(NotImplementedError, match="stroke_prototypes"):
+        Paintnet_ODv1_CollateBatch({"load_extra_data": ["stroke_prototypes"]})
