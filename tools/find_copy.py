@@ -1,4 +1,6 @@
-import sys; sys.path.insert(0, "/root/repo")
+"""Find device-to-device memcpy operations inside one training step (they become memcpy NODES in a recorded step) and print
+the shapes they move -- used to track down `dists[..., 0]`, whose backward is a fill + a memcpy."""
+import sys; sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import torch
 from maskplanner_amd.harness import TrainStep
 ts = TrainStep("cuboids", B=32, N=5120, graph=False)
