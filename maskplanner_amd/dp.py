@@ -41,6 +41,7 @@ class BucketedGradAllReduce:
         self.buckets = []
         self._views = []
         self._handles, self._pending, self._hooks = [], [], []
+        self.deferred = False   # True: no exchange from the gradient hooks, everything in finish()
         self._avg = dist.is_initialized() and dist.get_backend(process_group) == "nccl"  # gloo has no AVG
         self.active = exchanging(process_group)
         if not self.active:
@@ -89,6 +90,8 @@ class BucketedGradAllReduce:
 
     def _make_hook(self, bi):
         def hook(_param):
+            if self.deferred:        # all buckets are exchanged in finish() (steps replayed from a graph fire no hooks at all)
+                return
             self._pending[bi] -= 1
             if self._pending[bi] == 0:
                 self._reduce_bucket(bi)
@@ -104,6 +107,15 @@ class BucketedGradAllReduce:
             p.grad = None  # autograd then WRITES the next gradients instead of accumulating into the flat views
         self._pending = [len(ps) for _, ps in self.buckets]
         self._done = [False] * len(self.buckets)
+
+    def rearm(self, grads):
+        """For a backward pass that ran WITHOUT Python (a replayed graph): `grads` = [(param, its static gradient tensor)];
+        point .grad back at them and mark every bucket as not yet exchanged, so that finish() packs and reduces them all."""
+        for p, g in grads:
+            p.grad = g
+        if self.active:
+            self._pending = [len(ps) for _, ps in self.buckets]
+            self._done = [False] * len(self.buckets)
 
     def finish(self):
         """Wait for the in-flight all-reduces (the compute stream waits, not the host) and average."""

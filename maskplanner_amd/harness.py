@@ -30,7 +30,11 @@ class TrainStep:
         # The step is recorded once after a few eager steps and replayed; any failure to record falls back to eager.
         if graph is None:
             graph = os.environ.get("MASKPLANNER_GRAPH", "1") != "0"
-        self.use_graph = bool(graph) and fused and not dp.exchanging() and not prefetch_sampling
+        # data-parallel runs: opt-in (MASKPLANNER_DP_GRAPH=1; validated with one RCCL rank and two gloo ranks only, hence not the
+        # default): the two graphs are recorded WITHOUT collectives and optimizers; the bucketed all-reduce, DenseAdam and the
+        # factor all-gather + Adam are launched eagerly after graph B (~20 launches per step instead of ~170)
+        self.dp_graph = dp.exchanging() and os.environ.get("MASKPLANNER_DP_GRAPH", "0") == "1"
+        self.use_graph = bool(graph) and fused and (not dp.exchanging() or self.dp_graph) and not prefetch_sampling
         self._graph, self._graph_loss, self._eager_steps, self._side = None, None, 0, None
         # Pipelined first-level sampling (see _eager_step): FPS can occupy only one workgroup per cloud -- 32 of 256 CUs for
         # ~0.35 ms at B=32 -- and depends on nothing but the input cloud, so the step computes the NEXT batch's FPS + ball
@@ -56,6 +60,8 @@ class TrainStep:
             self.factor_opt = FactorAdam(big, self.model.factor_store, lr=lr, capturable=self.use_graph)
             dense = [p for p in dense if all(p is not q for q in big.values())]
         self.reducer = dp.BucketedGradAllReduce(dense)
+        self.reducer.deferred = self.dp_graph and self.use_graph
+        self._static_grads = None
         # train_maskplanner.py:159.  On the GPU the dense parameters go through csrc/adam_multi.hip (same update, ~150 tensors in four
         # launches); MASKPLANNER_TORCH_ADAM=1 keeps torch's fused Adam.
         if fused and os.environ.get("MASKPLANNER_TORCH_ADAM", "0") == "0":
@@ -101,7 +107,7 @@ class TrainStep:
                 if self._adam_ev is not None:
                     torch.cuda.current_stream().wait_event(self._adam_ev)   # the head weights of the previous step are final
                 self._graph_b.replay()
-                self._launch_factor_adam()
+                self._after_graph_b()
             return self._graph_loss
         if not self.use_graph:
             return self._eager_step()
@@ -123,7 +129,7 @@ class TrainStep:
         """Record one full step into a hipGraph (torch.cuda.graph: private memory pool, graph-safe Philox offsets for the
         dropout layers).  The batch tensors, parameters and optimizer state are the static inputs.  Capture only records,
         so the graph is replayed once right away: this call performs exactly one optimisation step."""
-        if self._split_adam_wanted and self.factor_opt is not None:
+        if (self._split_adam_wanted and self.factor_opt is not None) or self.dp_graph:
             return self._record_split()
         try:
             torch.cuda.synchronize()
@@ -146,7 +152,8 @@ class TrainStep:
             torch.cuda.synchronize()
             cap = torch.cuda.Stream()
             ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            self.model.factor_store.clear()
+            if self.factor_opt is not None:
+                self.model.factor_store.clear()
             with torch.cuda.graph(ga, stream=cap):
                 self._supply_plan()
                 self.reducer.zero_grad()
@@ -154,21 +161,33 @@ class TrainStep:
             with torch.cuda.graph(gb, pool=ga.pool(), stream=cap):
                 loss = self._heads_loss(feat)
                 loss.backward()
-                self.reducer.finish()
-                self.opt.step()
+                if not self.dp_graph:
+                    self.reducer.finish()
+                    self.opt.step()
                 loss = loss.detach()
-            self._factor_args = dict(self.model.factor_store)
-            self.model.factor_store.clear()
+            if self.dp_graph:
+                self._static_grads = [(p, p.grad) for p in self.reducer.params if p.grad is not None]
+            self._factor_args = dict(self.model.factor_store) if self.factor_opt is not None else {}
+            if self.factor_opt is not None:
+                self.model.factor_store.clear()
             self._adam_stream = torch.cuda.Stream()
             self._graph, self._graph_b, self._graph_loss = ga, gb, loss
             ga.replay()
             gb.replay()
-            self._launch_factor_adam()
+            self._after_graph_b()
         except Exception as exc:   # stay correct: eager from here on
             import warnings
             warnings.warn(f"hipGraph capture of the training step failed ({type(exc).__name__}: {exc}); running eagerly")
             self._graph, self._graph_b, self.use_graph = None, None, False
             torch.cuda.synchronize()
+
+    def _after_graph_b(self):
+        if self.dp_graph:      # the exchange and the dense optimizer of a data-parallel step, eagerly on the step's stream
+            self.reducer.rearm(self._static_grads)
+            self.reducer.finish()
+            self.opt.step()
+        if self.factor_opt is not None:
+            self._launch_factor_adam()
 
     def _launch_factor_adam(self):
         side = self._adam_stream

@@ -616,6 +616,11 @@ def test_rccl_single_rank_collectives_do_not_change_the_step():
     assert np.isfinite(f).all() and f[0] == p[0], res           # same initial loss; later steps differ by atomics noise only
     assert np.abs(f - p).max() <= 2e-2 * np.abs(p).max(), res
     assert f[-1] < f[0]
+    # opt-in data-parallel replay (MASKPLANNER_DP_GRAPH=1): two graphs without collectives, the exchange and both optimizers
+    # launched eagerly between replays -- same training as the plain step up to atomics noise amplified by Adam
+    p8, g8 = np.array(res["plain8"]), np.array(res["forced_graph8"])
+    assert np.isfinite(g8).all() and g8[0] == p8[0] and np.allclose(g8[:3], p8[:3], rtol=1e-2) and np.allclose(g8, p8, rtol=8e-2), res
+    assert g8[-1] < 0.75 * g8[0]
 
 
 def test_graph_replay_of_the_training_step_tracks_the_eager_path():
