@@ -125,3 +125,50 @@ def test_factor_gather_concatenates_rank_rows():
     x, g = out[0][0], out[0][1]
     want = out[0][4].t() @ out[0][3] + out[1][4].t() @ out[1][3]
     torch.testing.assert_close(g.t() @ x, want)
+
+
+def _worker_deferred(rank, world, port, out):
+    """The replayed-graph protocol of harness.TrainStep (MASKPLANNER_DP_GRAPH=1) on CPU: gradients appear in STATIC tensors
+    without any hook firing; rearm() points .grad at them and finish() exchanges every bucket."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from maskplanner_amd import dp
+    dp.init_from_env(backend="gloo")
+    model = _model()
+    red = dp.BucketedGradAllReduce(model.parameters(), bucket_bytes=256)
+    red.deferred = True
+    x, y = _data()
+    shard = slice(rank * 4, rank * 4 + 4)
+    # "recording": one backward whose gradient tensors become the static ones (hooks are no-ops)
+    red.zero_grad()
+    ((model(x[shard]) - y[shard]) ** 2).mean().backward()
+    static = [(p, p.grad) for p in model.parameters()]
+    first = None
+    for step in range(2):
+        # "replay": the static tensors are overwritten in place, Python sees nothing; .grad may point anywhere (the flat views)
+        fresh = torch.autograd.grad(((model(x[shard]) - y[shard]) ** 2).mean(), list(model.parameters()))
+        with torch.no_grad():
+            for (_, g), f in zip(static, fresh):
+                g.copy_(f)
+        red.rearm(static)
+        red.finish()
+        if step == 0:
+            first = [p.grad.clone() for p in model.parameters()]
+    out[rank] = dict(grads=first, again=[p.grad.clone() for p in model.parameters()])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_deferred_exchange_of_static_gradients_matches_global_batch_gradient():
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker_deferred, args=(world, _free_port(), out), nprocs=world, join=True)
+    model = _model()
+    x, y = _data()
+    (0.5 * (((model(x[:4]) - y[:4]) ** 2).mean() + ((model(x[4:]) - y[4:]) ** 2).mean())).backward()
+    want = [p.grad for p in model.parameters()]
+    for r in range(world):
+        for key in ("grads", "again"):       # the second round starts from .grad pointing at the flat views: rearm() resets that
+            for g, w in zip(out[r][key], want):
+                torch.testing.assert_close(g, w, rtol=1e-6, atol=1e-7)
