@@ -159,8 +159,14 @@ int mp_chamfer_reduce_bwd_f32(const float* grad_out, const int64_t* lengths, int
  *   target_value[b,s] instead of 1 and the cost is the MSE sum_s (pred[m,s] - mask[k,s])^2 (:810-811).
  *   Outputs: match_col [B,M] i64 = matched mask index k or -1; uniq_ids [B,M_cap] f32 (ascending,
  *   first n_targets[b] valid); n_targets [B] i64; cost [B,M,M_cap] f32 or NULL.  M_cap = 64.
- *   M <= 64 and Kb <= 64, else status[b] (i32, [B]) is set to MP_EUNSUPPORTED (0 otherwise). */
+ *   status [B] i32: 0, or a bit set of the conditions the reference asserts on / raises for (match_col = -1 then):
+ *   MP_MATCH_TOO_MANY_IDS (M > 64 or Kb > 64), MP_MATCH_PADDING_ID (a target id is the padding id -1: the assertion of
+ *   loss_handler.py:852), MP_MATCH_INFEASIBLE (non-finite costs: scipy's ValueError at :875).  mp_mask_loss_f32 takes this
+ *   array and turns the loss into NaN when any entry is non-zero, so a bad batch cannot pass silently. */
 #define MP_MASK_CAP 64
+#define MP_MATCH_TOO_MANY_IDS 1
+#define MP_MATCH_PADDING_ID 2
+#define MP_MATCH_INFEASIBLE 4
 int mp_mask_match_f32(const float* pred_masks, const float* target_ids, const float* target_value, int64_t B,
                       int64_t M, int64_t S, int64_t* match_col, float* uniq_ids, int64_t* n_targets, float* cost,
                       int32_t* status, mp_stream_t stream);
@@ -182,13 +188,15 @@ int mp_lsap_f32(const float* cost, int64_t B, int64_t Rmax, int64_t Cmax, int64_
  * mp_mask_loss: replaces loss_handler.py:877-934 for binary targets, after mp_mask_match_f32: matched BCE-with-logits
  *   .sum(-1).mean() + weighted confidence BCE .mean(): out [1] = w_masks*mask_loss + w_conf*conf_loss.  per_mask [B*M] and
  *   n_matched [1] are scratch / saved for the backward, which writes grad_masks [B,M,S] and grad_scores [B,M] (or NULL).
+ *   status: mp_mask_match_f32's per-sample status (or NULL): any non-zero entry makes out NaN.
  *   All sums run in a fixed order. */
 int mp_pose_output_f32(const float* pos, const float* raw, int64_t n_pose, double weight_orient, float* out, mp_stream_t stream);
 int mp_pose_output_bwd_f32(const float* grad_out, const float* raw, int64_t n_pose, double weight_orient, float* grad_pos,
                            float* grad_raw, mp_stream_t stream);
 int mp_mask_loss_f32(const float* pred_masks, const float* scores, const float* target_ids, const int64_t* match_col,
                      const float* uniq_ids, int64_t B, int64_t M, int64_t S, double w_masks, double w_conf,
-                     double no_stroke_weight, float* per_mask, float* out, float* n_matched, mp_stream_t stream);
+                     double no_stroke_weight, float* per_mask, float* out, float* n_matched, const int32_t* status /* [B] or NULL */,
+                     mp_stream_t stream);
 int mp_mask_loss_bwd_f32(const float* grad_out, const float* pred_masks, const float* scores, const float* target_ids,
                          const int64_t* match_col, const float* uniq_ids, const float* n_matched, int64_t B, int64_t M, int64_t S,
                          double w_masks, double w_conf, double no_stroke_weight, float* grad_masks, float* grad_scores,

@@ -58,7 +58,7 @@ SIGNATURES = {
     "mp_permute_cols_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp]),
     "mp_pose_output_f32": (_int, [_vp, _vp, _i64, _dbl, _vp, _vp]),
     "mp_pose_output_bwd_f32": (_int, [_vp, _vp, _i64, _dbl, _vp, _vp, _vp]),
-    "mp_mask_loss_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _dbl, _dbl, _dbl, _vp, _vp, _vp, _vp]),
+    "mp_mask_loss_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _dbl, _dbl, _dbl, _vp, _vp, _vp, _vp, _vp]),
     "mp_mask_loss_bwd_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _dbl, _dbl, _dbl, _vp, _vp, _vp]),
     "mp_bn_relu_rows_f32": (_int, [_vp, _i64, _i64, _int, _dbl, _dbl, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mp_bn_relu_rows_bwd_f32": (_int, [_vp, _vp, _vp, _i64, _i64, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

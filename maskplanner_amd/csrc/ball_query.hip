@@ -126,13 +126,8 @@ extern "C" int mp_ball_query_f32(const float* xyz, const float* new_xyz, int64_t
     qpb = ((qpb + BQ_WAVES - 1) / BQ_WAVES) * BQ_WAVES;
     if (qpb < BQ_WAVES) qpb = BQ_WAVES;
     const int chunks = (int)((S + qpb - 1) / qpb);
-    static size_t configured = 64 * 1024;   // see fps.hip
-    if (smem > configured) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(ball_query_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
-            return MP_ELAUNCH;
-        configured = smem;
-    }
+    static mp::DynLds lds;   // see common.h
+    if (!lds.ensure(reinterpret_cast<const void*>(ball_query_kernel), smem)) return MP_ELAUNCH;
     const float r2 = (float)(radius * radius);  // squared in double, then cast: pointnet2_utils.py:104
     MP_LAUNCH("ball_query_kernel", 8.0 * B * (double)S * N, (double)B * (N * 12.0 + S * 12.0 + S * K * 8.0), ball_query_kernel,
               dim3(chunks, (unsigned)B), dim3(BQ_THREADS), smem, mp_stream(stream_), xyz, new_xyz, (int)N, (int)S, r2, (int)K,

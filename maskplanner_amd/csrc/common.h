@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "../../include/maskplanner_hip.h"
 
 #define MP_WAVE 64
@@ -106,6 +108,33 @@ __device__ __forceinline__ float wave_sum_f32(float v)
     return v;
 }
 
+}  // namespace mp
+
+// Opt-in to more than 64 KB of dynamic LDS for one kernel.  hipFuncSetAttribute applies to the CURRENT device's function
+// object, so the largest size configured so far is tracked per device (a process that drives several GPUs -- or a test that
+// maps ranks onto `local % device_count` -- must set it on each); atomics because callers may come from several threads.
+// Not a stream operation: a size is configured the first time it is seen, which for a recorded step is one of the eager
+// warm-up steps before the capture.
+namespace mp {
+struct DynLds {
+    static constexpr int MAX_DEV = 64;
+    std::atomic<size_t> configured[MAX_DEV];
+    DynLds() { for (auto& c : configured) c.store(64 * 1024, std::memory_order_relaxed); }
+    bool ensure(const void* kernel, size_t smem)
+    {
+        if (smem <= 64 * 1024) return true;
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return false;
+        const bool tracked = dev >= 0 && dev < MAX_DEV;
+        if (tracked && smem <= configured[dev].load(std::memory_order_acquire)) return true;
+        if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return false;
+        if (tracked) {
+            size_t cur = configured[dev].load(std::memory_order_relaxed);
+            while (cur < smem && !configured[dev].compare_exchange_weak(cur, smem, std::memory_order_release)) {}
+        }
+        return true;
+    }
+};
 }  // namespace mp
 
 // Zero fill as an ordinary kernel.  hipMemsetAsync must not be used on the compute path: recorded into a hipGraph it

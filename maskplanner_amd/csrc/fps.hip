@@ -137,13 +137,8 @@ int launch_fps(const float* xyz, int B, int N, int S, const int64_t* start, int6
     if (smem > 160 * 1024) return MP_EUNSUPPORTED;
     auto kern = fps_kernel<T, PPT>;
     // opt-in to > 64 KB of dynamic LDS once per size (not a stream operation: it must not run inside a graph capture)
-    static size_t configured = 64 * 1024;
-    if (smem > configured) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)smem) != hipSuccess)
-            return MP_ELAUNCH;
-        configured = smem;
-    }
+    static mp::DynLds lds;      // per kernel instantiation, per device
+    if (!lds.ensure(reinterpret_cast<const void*>(kern), smem)) return MP_ELAUNCH;
     char tag[48];
     snprintf(tag, sizeof tag, "fps_kernel<%d, %d>", T, PPT);
     MP_LAUNCH(tag, 8.0 * B * (double)N * S, (double)B * (N * 12.0 + S * 8.0 + (out_xyz ? S * 12.0 : 0.0)), kern, dim3(B),

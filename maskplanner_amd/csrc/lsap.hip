@@ -165,19 +165,14 @@ extern "C" int mp_lsap_f32(const float* cost, int64_t B, int64_t Rmax, int64_t C
     if (Cmax > LSAP_MAX || Rmax > LSAP_MAX || B > 65535 * 32) return MP_EUNSUPPORTED;
     const size_t smem = lsap_smem(Rmax, Cmax);
     if (smem > 160 * 1024) return MP_EUNSUPPORTED;
-    auto launch = [&](auto kernel, size_t& configured) -> int {
-        if (smem > configured) {   // see fps.hip: the attribute is set once per size, outside any capture
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) !=
-                hipSuccess)
-                return MP_ELAUNCH;
-            configured = smem;
-        }
+    auto launch = [&](auto kernel, mp::DynLds& lds) -> int {
+        if (!lds.ensure(reinterpret_cast<const void*>(kernel), smem)) return MP_ELAUNCH;   // see common.h
         MP_LAUNCH("lsap_kernel", 0.0, 4.0 * (double)(B * Rmax * Cmax), kernel, dim3((unsigned)B), dim3(64), smem, mp_stream(stream_), cost,
                   batch_stride, (int)ld, n_rows, n_cols, (int)Rmax, (int)Cmax, col4row, status);
         MP_CHECK_LAUNCH();
         return MP_OK;
     };
-    static size_t conf8 = 64 * 1024, conf16 = 64 * 1024, conf32 = 64 * 1024;
+    static mp::DynLds conf8, conf16, conf32;
     if (Cmax <= 512) return launch(lsap_kernel<8>, conf8);
     if (Cmax <= 1024) return launch(lsap_kernel<16>, conf16);
     return launch(lsap_kernel<32>, conf32);

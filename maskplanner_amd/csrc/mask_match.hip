@@ -42,8 +42,9 @@ __device__ __forceinline__ double readlane_f64(double v, int l)
     return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 
-// One wave.  cost: LDS [M][CAP] fp32.  Returns through match[m] (LDS int [CAP]).
-__device__ void lsap_wave(const float* cost, int M, int Kb, int* match)
+// One wave.  cost: LDS [M][CAP] fp32.  Returns through match[m] (LDS int [CAP]); false when the cost matrix is infeasible
+// (non-finite entries: scipy raises "cost matrix is infeasible" / "matrix contains invalid numeric entries").
+__device__ bool lsap_wave(const float* cost, int M, int Kb, int* match)
 {
     const int lane = threadIdx.x & 63;
     const bool transpose = Kb < M;  // scipy solves the transposed problem when there are more rows than columns
@@ -94,7 +95,10 @@ __device__ void lsap_wave(const float* cost, int M, int Kb, int* match)
             if (active && pos == num_remaining) pos = chosen_pos;
             if (lane == j) SC = true;
         }
-        if (sink < 0) break;
+        if (sink < 0) {
+            if (lane < M) match[lane] = -1;
+            return false;
+        }
         // dual updates
         const double spc_of_row = __shfl(spc, col4row < 0 ? 0 : col4row, 64);
         if (lane == cur) u += minVal;
@@ -112,6 +116,7 @@ __device__ void lsap_wave(const float* cost, int M, int Kb, int* match)
         }
     }
     if (lane < M) match[lane] = transpose ? row4col : col4row;
+    return true;
 }
 
 __global__ __launch_bounds__(MM_THREADS) void mask_match_kernel(const float* __restrict__ pred_masks,
@@ -132,7 +137,7 @@ __global__ __launch_bounds__(MM_THREADS) void mask_match_kernel(const float* __r
     int* match = reinterpret_cast<int*>(red + MM_THREADS / 64);  // [CAP]
     int* rank = match + CAP;                                   // [S]
     __shared__ float s_last;
-    __shared__ int s_n, s_bad;
+    __shared__ int s_n, s_bad, s_pad, s_nan;
 
     const int b = blockIdx.x;
     const int tid = threadIdx.x;
@@ -143,7 +148,7 @@ __global__ __launch_bounds__(MM_THREADS) void mask_match_kernel(const float* __r
     const float* tv = target_value ? target_value + (size_t)b * S : nullptr;   // smooth targets: MSE cost (:830)
 
     for (int e = tid; e < CAP * CAP + CAP; e += MM_THREADS) accB[e] = 0.0;  // accB and accA are contiguous
-    if (tid == 0) { s_last = -__builtin_inff(); s_n = 0; s_bad = (M > CAP) ? 1 : 0; }
+    if (tid == 0) { s_last = -__builtin_inff(); s_n = 0; s_bad = (M > CAP) ? 1 : 0; s_pad = 0; s_nan = 0; }
     __syncthreads();
 
     // 1. unique ids ascending (torch.unique), -1 skipped: repeated "smallest value above the last one"
@@ -173,16 +178,18 @@ __global__ __launch_bounds__(MM_THREADS) void mask_match_kernel(const float* __r
     const int Kb = min(s_n, CAP);
     const bool bad = s_bad != 0;
     if (bad) {
-        if (tid == 0) { status[b] = MP_EUNSUPPORTED; n_targets[b] = s_n; }
+        if (tid == 0) { status[b] = MP_MATCH_TOO_MANY_IDS; n_targets[b] = s_n; }
         for (int m = tid; m < M; m += MM_THREADS) match_col[(size_t)b * M + m] = -1;
         return;
     }
-    // 2. rank of every segment's id among the unique ids (-1 for the padding id)
+    // 2. rank of every segment's id among the unique ids (-1 for the padding id, which the reference asserts is never a
+    // target: loss_handler.py:852)
     for (int s = tid; s < S; s += MM_THREADS) {
         const float x = ids[s];
         int r = -1;
         for (int k = 0; k < Kb; ++k) r = (uniq[k] == x) ? k : r;
         rank[s] = r;
+        if (r < 0) s_pad = 1;      // benign race: every writer stores 1
     }
     __syncthreads();
     // 3. cost sums.  Binary targets: sum_s BCE(x, t) = sum_s f0(x) - sum_{s in mask k} x.  Smooth targets (target value
@@ -211,19 +218,24 @@ __global__ __launch_bounds__(MM_THREADS) void mask_match_kernel(const float* __r
         const int m = e / CAP, k = e - m * CAP;
         const float c = k < Kb ? (float)(accA[m] - accB[m * CAP + k]) : 0.0f;
         cost[e] = c;
+        if (c != c) s_nan = 1;
         if (cost_out) cost_out[((size_t)b * M + m) * CAP + k] = c;
     }
     for (int k = tid; k < CAP; k += MM_THREADS) uniq_ids[(size_t)b * CAP + k] = k < Kb ? uniq[k] : 0.0f;
     __syncthreads();
     // 4. LAP on one wave
     if (wave == 0) {
-        if (Kb > 0) lsap_wave(cost, M, Kb, match);
+        bool feasible = s_nan == 0;          // scipy: NaN entries are rejected before the solve
+        if (Kb > 0 && feasible) feasible = lsap_wave(cost, M, Kb, match);
         else if (lane < M) match[lane] = -1;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if (lane < M) match_col[(size_t)b * M + lane] = (int64_t)match[lane];
-        if (lane == 0) { n_targets[b] = Kb; status[b] = 0; }
+        if (lane == 0) {
+            n_targets[b] = Kb;
+            status[b] = (feasible ? 0 : MP_MATCH_INFEASIBLE) | (s_pad ? MP_MATCH_PADDING_ID : 0);
+        }
     }
 }
 
@@ -241,13 +253,8 @@ extern "C" int mp_mask_match_f32(const float* pred_masks, const float* target_id
     if (M > CAP || S > 16384) return MP_EUNSUPPORTED;
     const size_t smem = sizeof(double) * (CAP * CAP + CAP) + sizeof(float) * (CAP * CAP + CAP + MM_THREADS / 64) +
                         sizeof(int) * (CAP + (size_t)S);
-    static size_t configured = 64 * 1024;   // see fps.hip
-    if (smem > configured) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(mask_match_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
-            return MP_ELAUNCH;
-        configured = smem;
-    }
+    static mp::DynLds lds;   // see common.h
+    if (!lds.ensure(reinterpret_cast<const void*>(mask_match_kernel), smem)) return MP_ELAUNCH;
     hipLaunchKernelGGL(mask_match_kernel, dim3((unsigned)B), dim3(MM_THREADS), smem, mp_stream(stream_), pred_masks,
                        target_ids, target_value, (int)M, (int)S, match_col, uniq_ids, n_targets, cost, status);
     MP_CHECK_LAUNCH();

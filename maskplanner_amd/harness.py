@@ -95,6 +95,7 @@ class TrainStep:
                                          mask_scores=mask_conf, seg_logits=seg_conf, stroke_ids=self.batch["stroke_ids"],
                                          traj_as_pc=self.batch["traj_as_pc"])
 
+    _adam_delay_cycles = 0
     GRAPH_AFTER = 3   # eager steps before recording (allocator warm, lazy kernel attributes set, optimizer state created)
 
     def step(self):
@@ -158,6 +159,12 @@ class TrainStep:
                 self._supply_plan()
                 self.reducer.zero_grad()
                 feat = self._encode()
+            # The head optimizer runs OUTSIDE the graphs on its own stream, concurrently with the next replay of graph A.  Its
+            # inputs therefore must not live in the graphs' memory pool: `feat` (the x factor of fc1 / sm_fc1) is rewritten by
+            # graph A, and any pool block B allocated may be one A freed while it was recorded.  Graph B ends by copying the
+            # factors (~5 MB) into buffers allocated here, outside the pool; only graph B writes them and it waits for the
+            # optimizer's event before it is replayed.
+            persist = self._alloc_factor_buffers() if self.factor_opt is not None else {}
             with torch.cuda.graph(gb, pool=ga.pool(), stream=cap):
                 loss = self._heads_loss(feat)
                 loss.backward()
@@ -165,9 +172,21 @@ class TrainStep:
                     self.reducer.finish()
                     self.opt.step()
                 loss = loss.detach()
+                if persist:
+                    srcs, dsts, seen = [], [], {}
+                    for k, (px, pg) in persist.items():
+                        x, g = self.model.factor_store[k]
+                        for s_, d_ in ((x, px), (g, pg)):
+                            if d_.data_ptr() not in seen:
+                                seen[d_.data_ptr()] = s_.data_ptr()
+                                srcs.append(s_)
+                                dsts.append(d_)
+                            elif seen[d_.data_ptr()] != s_.data_ptr():
+                                raise RuntimeError(f"factor {k}: expected to share its input activation")
+                    torch._foreach_copy_(dsts, srcs)
             if self.dp_graph:
                 self._static_grads = [(p, p.grad) for p in self.reducer.params if p.grad is not None]
-            self._factor_args = dict(self.model.factor_store) if self.factor_opt is not None else {}
+            self._factor_args = persist
             if self.factor_opt is not None:
                 self.model.factor_store.clear()
             self._adam_stream = torch.cuda.Stream()
@@ -181,6 +200,20 @@ class TrainStep:
             self._graph, self._graph_b, self.use_graph = None, None, False
             torch.cuda.synchronize()
 
+    def _alloc_factor_buffers(self):
+        """{key: (x [B,I], g [B,O])} persistent factor buffers for the deferred head optimizer, allocated by the ordinary
+        caching allocator (call this outside any capture).  Weights that are fed by the same activation (fc3 / fc_normals,
+        fc1 / sm_fc1) share one x buffer, as their factors in model.factor_store do (the all-gather de-duplicates by pointer)."""
+        B = self.batch["point_cloud"].shape[0]
+        shared_x = {"fc_normals.weight": "fc3.weight", "sm_fc1.weight": "fc1.weight"}
+        out = {}
+        for k, w in self.factor_opt.weights.items():
+            O, I = w.shape
+            src = shared_x.get(k)
+            px = out[src][0] if src in out else torch.empty((B, I), dtype=torch.float32, device=self.device)
+            out[k] = (px, torch.empty((B, O), dtype=torch.float32, device=self.device))
+        return out
+
     def _after_graph_b(self):
         if self.dp_graph:      # the exchange and the dense optimizer of a data-parallel step, eagerly on the step's stream
             self.reducer.rearm(self._static_grads)
@@ -193,6 +226,8 @@ class TrainStep:
         side = self._adam_stream
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
+            if self._adam_delay_cycles:      # test hook: hold the optimizer back so that it overlaps the next replay of graph A
+                torch.cuda._sleep(int(self._adam_delay_cycles))
             self.model.factor_store.update(self._factor_args)
             self.factor_opt.step()
             self._adam_ev = torch.cuda.Event()
@@ -262,6 +297,7 @@ class TrainStep:
 
     def _supply_plan(self):
         if self.overlap:
+            pu.clear_prefetched()    # nothing of an earlier (possibly aborted) step may survive into this one
             if self._plan_cur is None:
                 self._pipeline_sampling()
             xyz = self.batch["point_cloud"]
@@ -270,6 +306,13 @@ class TrainStep:
                 xyz = plan[1]    # the next level's cloud IS this level's centroid tensor (same storage: the lookup key)
 
     def _eager_step(self):
+        try:
+            return self._eager_step_body()
+        except BaseException:
+            pu.clear_prefetched()    # a plan queued for this step must not outlive it
+            raise
+
+    def _eager_step_body(self):
         self._supply_plan()
         self.reducer.zero_grad()
         loss = self.forward_loss()

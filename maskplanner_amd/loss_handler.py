@@ -84,11 +84,16 @@ def stroke_masks_loss(pred_to_gt_match, pred_stroke_masks, scores, stroke_ids, w
     dev = pred_stroke_masks.device
     target_ids = stroke_ids.to(dev, dtype=torch.float32).gather(1, pred_to_gt_match)          # :838
     conf = segment_distance_to_confidence(nn_distance) if smooth_targets else None            # [B,S], carries grad
-    match, uniq, _, _ = ops.mask_match(pred_stroke_masks.detach(), target_ids,                # :847-875, on device
-                                       target_value=None if conf is None else conf.detach())
+    match, uniq, _, status = ops.mask_match(pred_stroke_masks.detach(), target_ids,           # :847-875, on device
+                                            target_value=None if conf is None else conf.detach())
+    # The reference asserts that no predicted segment is matched to the padding id and that the masks are exclusive
+    # (:852-854), and scipy raises on an infeasible cost (:875).  Here nothing synchronises with the host, so a failed sample
+    # poisons the loss instead (NaN) and its status is kept for callers that do synchronise (LossHandler.compute).
+    _last_status.append(status)
+    del _last_status[:-1]
     if not smooth_targets and not return_matching and pred_stroke_masks.dtype == torch.float32:
         # binary targets: the rest of the function as three launches (ops.mask_loss); same algebra, fixed summation order
-        return ops.mask_loss(pred_stroke_masks, scores, target_ids, match, uniq, w_masks, w_conf, no_stroke_weight)
+        return ops.mask_loss(pred_stroke_masks, scores, target_ids, match, uniq, w_masks, w_conf, no_stroke_weight, status=status)
     matched = match >= 0                                                                      # [B,M]
     uid = uniq.gather(1, match.clamp(min=0))                                                  # id matched to each pred mask
     in_mask = target_ids[:, None, :] == uid[:, :, None]                                       # [B,M,S]
@@ -104,7 +109,27 @@ def stroke_masks_loss(pred_to_gt_match, pred_stroke_masks, scores, stroke_ids, w
     weights = torch.where(matched, torch.ones_like(scores), torch.full_like(scores, float(no_stroke_weight)))
     conf_loss = F.binary_cross_entropy_with_logits(scores, target_scores, weight=weights, reduction="none").mean()
     loss = w_masks * mask_loss + w_conf * conf_loss                                           # :934
+    loss = torch.where((status != 0).any(), torch.full_like(loss, float("nan")), loss)
     return (loss, match) if return_matching else loss
+
+
+_last_status = []     # the most recent mask_match status tensor (device, i32 [B])
+
+
+def check_mask_matching():
+    """Raise if the most recent stroke-mask matching failed on any sample (this reads a device tensor: one host sync).
+    LossHandler.compute(return_list=True) calls it, since that call synchronises anyway."""
+    if not _last_status:
+        return
+    st = _last_status[-1]
+    bad = st.nonzero().flatten().tolist()
+    if bad:
+        code = int(st[bad[0]])
+        why = [w for bit, w in ((ops.MATCH_TOO_MANY_IDS, "more than 64 pred masks or distinct target strokes"),
+                                (ops.MATCH_PADDING_ID, "a predicted segment is associated with the fake stroke id -1 "
+                                                       "(loss_handler.py:852 sanity check)"),
+                                (ops.MATCH_INFEASIBLE, "cost matrix is infeasible / contains invalid numeric entries")) if code & bit]
+        raise AssertionError(f"stroke-mask matching failed for samples {bad}: " + "; ".join(why))
 
 
 class LossHandler:
@@ -142,7 +167,9 @@ class LossHandler:
             total = total + cfg["weight_" + name] * value
             values.append(value.detach())
         if return_list:
-            return total, torch.stack(values).cpu().numpy()
+            array = torch.stack(values).cpu().numpy()
+            check_mask_matching()
+            return total, array
         return total
 
     # ---------------------------------------------------------------------------------------------------------

@@ -9,6 +9,8 @@ import torch
 
 from . import _lib
 
+MATCH_TOO_MANY_IDS, MATCH_PADDING_ID, MATCH_INFEASIBLE = 1, 2, 4     # include/maskplanner_hip.h MP_MATCH_*
+
 # Scatter-add backwards use float atomics by default; set True for the fixed-order (bitwise reproducible) kernels.
 DETERMINISTIC = False
 
@@ -161,7 +163,8 @@ def padded_lengths(y):
 def mask_match(pred_masks, target_ids, return_cost=False, target_value=None):
     """loss_handler.py:838-875 on device.  pred_masks [B,M,S] logits, target_ids [B,S] f32.
     Returns match_col i64 [B,M] (-1 = unmatched), uniq_ids f32 [B,64], n_targets i64 [B], status i32 [B]
-    (and the fp32 cost [B,M,64] when asked).  target_value [B,S]: smooth targets, MSE cost (:830, :959-964)."""
+    (0, or bits MATCH_TOO_MANY_IDS / MATCH_PADDING_ID / MATCH_INFEASIBLE: what the reference asserts on or scipy raises for;
+    and the fp32 cost [B,M,64] when asked).  target_value [B,S]: smooth targets, MSE cost (:830, :959-964)."""
     _need_hip(pred_masks, target_ids)
     pred_masks, target_ids = _f32(pred_masks), _f32(target_ids)
     B, M, S = pred_masks.shape
@@ -442,14 +445,14 @@ def pose_output(pos, raw, weight_orient):
 
 class _MaskLoss(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, pred, scores, target_ids, match, uniq, w_masks, w_conf, no_stroke_weight):
+    def forward(ctx, pred, scores, target_ids, match, uniq, w_masks, w_conf, no_stroke_weight, status):
         B, M, S = pred.shape
         dev = pred.device
         per_mask = torch.empty((B * M,), dtype=torch.float32, device=dev)
         out = torch.empty((), dtype=torch.float32, device=dev)
         n_matched = torch.empty((1,), dtype=torch.float32, device=dev)
         _run("mask_loss", pred, _lib.load().mp_mask_loss_f32, _p(pred), _p(scores), _p(target_ids), _p(match), _p(uniq), B, M, S,
-             float(w_masks), float(w_conf), float(no_stroke_weight), _p(per_mask), _p(out), _p(n_matched))
+             float(w_masks), float(w_conf), float(no_stroke_weight), _p(per_mask), _p(out), _p(n_matched), _p(status))
         ctx.save_for_backward(pred, scores, target_ids, match, uniq, n_matched)
         ctx.meta = (B, M, S, float(w_masks), float(w_conf), float(no_stroke_weight))
         return out
@@ -463,15 +466,18 @@ class _MaskLoss(torch.autograd.Function):
         gs = torch.empty_like(scores) if ctx.needs_input_grad[1] else None
         _run("mask_loss_bwd", pred, _lib.load().mp_mask_loss_bwd_f32, _p(grad_out), _p(pred), _p(scores), _p(target_ids), _p(match),
              _p(uniq), _p(n_matched), B, M, S, w_masks, w_conf, nsw, _p(gm), _p(gs))
-        return gm, gs, None, None, None, None, None, None
+        return gm, gs, None, None, None, None, None, None, None
 
 
-def mask_loss(pred_masks, scores, target_ids, match, uniq, w_masks, w_conf, no_stroke_weight):
+def mask_loss(pred_masks, scores, target_ids, match, uniq, w_masks, w_conf, no_stroke_weight, status=None):
     """loss_handler.py:877-934 (binary targets) after mask_match: w_masks * matched-BCE.sum(-1).mean() +
-    w_conf * weighted confidence BCE.mean(), forward in two launches, backward in one."""
-    _need_hip(pred_masks, scores, target_ids, match, uniq)
+    w_conf * weighted confidence BCE.mean(), forward in two launches, backward in one.  status: mask_match's per-sample
+    status i32 [B]; a non-zero entry (conditions the reference asserts on / scipy raises for) makes the loss NaN."""
+    _need_hip(pred_masks, scores, target_ids, match, uniq, status)
+    if status is not None and (status.dtype != torch.int32 or not status.is_contiguous()):
+        status = status.to(torch.int32).contiguous()
     return _MaskLoss.apply(_f32(pred_masks), _f32(scores), _f32(target_ids), _i64(match), _f32(uniq), w_masks, w_conf,
-                           no_stroke_weight)
+                           no_stroke_weight, status)
 
 
 class _BnReluRows(torch.autograd.Function):

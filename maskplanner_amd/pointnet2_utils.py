@@ -73,6 +73,12 @@ def supply_sampling(xyz, npoint, radius, nsample, plan):
     _prefetched.setdefault((xyz.data_ptr(), npoint, float(radius), nsample), []).append((None,) + tuple(plan))
 
 
+def clear_prefetched():
+    """Drop every queued sampling plan.  Plans are keyed by the cloud's storage address: one left behind by an aborted or
+    skipped step could otherwise be consumed by a different cloud that the allocator later placed at the same address."""
+    _prefetched.clear()
+
+
 def has_prefetched(xyz, npoint, radius, nsample):
     return bool(_prefetched.get((xyz.data_ptr(), npoint, float(radius), nsample)))
 
@@ -183,7 +189,8 @@ class PointNetSetAbstraction(nn.Module):
         points = None if points is None else _points_major(points)
         full_points = None if full_points is None else _points_major(full_points)
         # internal channel order: features first, coordinates last, rows padded to a multiple of 4 floats (sa_mlp.py)
-        layout = "feats_first" if (points is not None and full_points is None) else "xyz_first"
+        # derived from the branch sample_and_group actually takes: `points` wins over `full_points` (:136-141)
+        layout = "feats_first" if points is not None else "xyz_first"
         if self.group_all:
             B, N, C = xyz.shape
             new_xyz = torch.zeros(B, 1, C, device=xyz.device)

@@ -850,6 +850,42 @@ def test_two_graph_step_with_deferred_head_optimizer(monkeypatch):
     assert float((b.model.sm_fc3.weight - w0).abs().max()) > 0
 
 
+def test_deferred_head_optimizer_reads_its_own_copy_of_the_factors(monkeypatch):
+    """The factor Adam of the two-graph step runs on its own stream while the NEXT step's graph A replays: its (x, g) factors
+    must be the persistent copies graph B makes, not tensors of the graphs' memory pool (`feat` is rewritten by graph A).
+    The input cloud alternates between two batches so that consecutive steps have different factors, the optimizer is held
+    back by ~2 ms on its stream so that it really overlaps the next replay, and nothing synchronises with the host between
+    steps.  With the encoder frozen (dense lr 0), dropout off and the fixed-order scatter kernels the head weights must walk
+    exactly like those of the single-graph step, where the optimizer runs in line."""
+    from maskplanner_amd import ops, synthetic
+    from maskplanner_amd.harness import TrainStep
+    monkeypatch.setattr(ops, "DETERMINISTIC", True)
+    other = torch.from_numpy(synthetic.point_cloud(np.random.default_rng(5), 8, 1024)).cuda()
+
+    def run(split, delay):
+        monkeypatch.setenv("MASKPLANNER_SPLIT_ADAM", split)
+        ts = TrainStep("cuboids", B=8, N=1024, seed=33, graph=True, overlap_sampling=False)
+        ts.model.dropout.p = 0.0
+        ts.opt.lr = 0.0                       # encoder / BatchNorm / biases frozen: the forward pass is then reproducible
+        ts._adam_delay_cycles = delay
+        clouds = [ts.batch["point_cloud"].clone(), other]
+        for i in range(14):
+            ts.batch["point_cloud"].copy_(clouds[i % 2])
+            ts.step()
+        assert ts._graph is not None and (ts._graph_b is not None) == (split == "1")
+        torch.cuda.synchronize()
+        return {k: w.detach().clone() for k, w in ts.factor_opt.weights.items()}
+
+    ref = run("0", 0)
+    got = run("1", 4_000_000)
+    lr = 1e-3
+    for k in ref:
+        d = (ref[k] - got[k]).abs()
+        # a factor read from the wrong step moves whole matrices by O(lr) per step; what is left here is rocBLAS / reduction-
+        # order noise on gradients that are ~0 (Adam turns a sign flip into a 2*lr step)
+        assert float(d.mean()) < 0.02 * lr and float((d > 0.5 * lr).float().mean()) < 2e-3, (k, float(d.mean()), float(d.max()))
+
+
 @pytest.mark.parametrize("capturable", [False, True])
 def test_dense_adam_matches_torch_adam(capturable):
     """factor_heads.DenseAdam (csrc/adam_multi.hip) against torch.optim.Adam on 130 tensors of mixed sizes (several launches of 48,

@@ -296,6 +296,41 @@ def test_mask_match_smooth_targets_mse_cost(ops):
         assert np.array_equal(np.nonzero(got >= 0)[0], r) and np.array_equal(got[r], c)
 
 
+def test_mask_match_failures_are_reported_and_poison_the_loss(ops):
+    """What the reference asserts on (loss_handler.py:852: a predicted segment associated with the fake stroke id -1) or
+    scipy raises for (non-finite costs), and more distinct strokes than the kernel holds, are reported per sample in `status`;
+    the fused loss turns NaN instead of silently dropping the sample, and LossHandler.compute(return_list=True) raises."""
+    from maskplanner_amd import loss_handler as LH
+    rng = np.random.default_rng(3)
+    B, M, S = 4, 6, 200
+    pred = rng.normal(size=(B, M, S)).astype(np.float32)
+    ids = rng.integers(0, 5, size=(B, S)).astype(np.float32)
+    ids[1, 17] = -1.0                                   # padding id among the targets
+    pred[2, 3, 11] = np.nan                             # invalid numeric entry in the cost
+    big = rng.integers(0, 70, size=(S,)).astype(np.float32)
+    big[:70] = np.arange(70)                            # 70 distinct strokes > MP_MASK_CAP
+    ids[3] = big
+    match, uniq, nt, status = ops.mask_match(dev(pred), dev(ids))
+    st = status.cpu().numpy()
+    assert st[0] == 0 and st[1] == ops.MATCH_PADDING_ID and st[2] == ops.MATCH_INFEASIBLE and st[3] == ops.MATCH_TOO_MANY_IDS, st
+    m = match.cpu().numpy()
+    assert (m[0] >= 0).sum() == 5 and (m[2] == -1).all() and (m[3] == -1).all()
+    scores = dev(rng.normal(size=(B, M)).astype(np.float32))
+    loss = ops.mask_loss(dev(pred), scores, dev(ids), match, uniq, 1.0, 100.0, 1.0, status=status)
+    assert torch.isnan(loss)
+    ok = ops.mask_loss(dev(pred[:1]), scores[:1], dev(ids[:1]), match[:1], uniq[:1], 1.0, 100.0, 1.0, status=status[:1])
+    assert torch.isfinite(ok)
+    # through the loss handler: the value is poisoned without a host sync, the synchronising call raises
+    idx = torch.arange(S).repeat(B, 1).cuda()
+    bad = LH.stroke_masks_loss(idx, dev(pred), scores, dev(ids), 1.0, 100.0, 1.0)
+    assert torch.isnan(bad)
+    with pytest.raises(AssertionError, match="stroke-mask matching failed"):
+        LH.check_mask_matching()
+    good = LH.stroke_masks_loss(idx[:1], dev(pred[:1]), scores[:1], dev(ids[:1]), 1.0, 100.0, 1.0)
+    assert torch.isfinite(good)
+    LH.check_mask_matching()
+
+
 def test_mask_match_ties_follow_scipy(ops):
     """All-equal logits => a constant cost matrix: scipy's tie-breaking yields the identity."""
     from scipy.optimize import linear_sum_assignment
