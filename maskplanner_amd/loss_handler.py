@@ -133,23 +133,66 @@ def check_mask_matching():
 
 
 class LossHandler:
+    """The reference's `LossHandler` surface (loss_handler.py:37-257): `loss_names` / `loss_methods` / `loss_index`, the mutable
+    `loss` list and `config` (the training loop re-attaches a modified config: train_maskplanner.py:298, 305, 501),
+    `compute`, `log_on_wandb`, `pprint`.  Terms outside the MaskPlanner hot path are known by name (so that the reference's
+    "non-valid names" assertion keeps its meaning) but raise NotImplementedError when configured."""
+
     IMPLEMENTED = ("chamfer", "symm_segment_chamfer", "symm_point_chamfer", "asymm_segment_chamfer",
                    "reverse_asymm_point_chamfer", "reverse_asymm_segment_chamfer", "attraction_chamfer", "emd",
                    "chamfer_with_stroke_masks", "asymm_v6_chamfer_with_stroke_masks",
                    "asymm_v11_chamfer_with_stroke_masks", "symm_v1_chamfer_with_stroke_masks")
+    # the reference's registry, in its order (:45-76); get_<name> is the method of each (one exception, see _method_name)
+    LOSS_NAMES = ("chamfer", "repulsion", "mse", "align", "velcosine", "intra_align", "discriminator", "wdiscriminator",
+                  "attraction_chamfer", "rich_attraction_chamfer", "contrastive_v1", "asymm_segment_chamfer",
+                  "reverse_asymm_point_chamfer", "stoch_reverse_asymm_segment_chamfer", "reverse_asymm_segment_chamfer",
+                  "chamfer_bbox", "mse_strokes", "chamfer_strokes", "asymm_v6_chamfer_strokes", "masked_mse_strokes",
+                  "masked_mse_strokes_v2", "symm_segment_chamfer", "symm_point_chamfer", "mse_nexttoken", "mse_nexttoken_v2",
+                  "emd", "chamfer_with_stroke_masks", "asymm_v6_chamfer_with_stroke_masks",
+                  "asymm_v11_chamfer_with_stroke_masks", "symm_v1_chamfer_with_stroke_masks",
+                  "masked_mse_strokes_from_segments", "hungarian_SoPs")
+    # with lambda_points > 1 only these may be configured (:185-186)
+    _LAMBDA_OK = {"hungarian_SoPs", "masked_mse_strokes_from_segments", "asymm_v6_chamfer_with_stroke_masks",
+                  "symm_v1_chamfer_with_stroke_masks", "asymm_v11_chamfer_with_stroke_masks", "chamfer_with_stroke_masks", "emd",
+                  "chamfer", "symm_segment_chamfer", "symm_point_chamfer", "intra_align", "attraction_chamfer",
+                  "rich_attraction_chamfer", "repulsion", "contrastive_v1", "asymm_segment_chamfer",
+                  "reverse_asymm_point_chamfer", "stoch_reverse_asymm_segment_chamfer", "reverse_asymm_segment_chamfer",
+                  "chamfer_strokes", "mse_nexttoken", "mse_nexttoken_v2"}
 
     def __init__(self, loss, config=None):
-        self.loss = [loss] if isinstance(loss, str) else list(loss)
+        loss = [loss] if isinstance(loss, str) else list(loss)
+        self.loss_names = list(self.LOSS_NAMES)
+        self.loss_methods = [getattr(self, "get_" + n, None) or self._out_of_scope(n) for n in self.loss_names]
+        self.loss_index = {n: i for i, n in enumerate(self.loss_names)}
+        assert set(loss) <= set(self.loss_names), f"Specified loss list {loss} contains non-valid names ({self.loss_names})"
+        self.loss = loss
         self.config = config
         for name in self.loss:
             if name not in self.IMPLEMENTED:
                 raise NotImplementedError(f"loss term {name!r} is outside the MaskPlanner hot path of this build")
             assert "weight_" + name in self._cfg().keys(), \
-                f"weight parameter does not exist in the current config for loss {name}."
+                f"weight parameter does not exist in the current config for loss {name}. " \
+                f"Make sure to include a --weight_<loss_name> arg par for each loss you use."
+        cfg = self._cfg()
+        lam = cfg.get("lambda_points", 1)
+        # loss compatibility (:177-208)
         assert not ("chamfer" in self.loss and "mse" in self.loss), "Incompatible losses: chamfer with mse"
+        if lam > 1:
+            assert set(self.loss) <= self._LAMBDA_OK, "Losses must be one of the following when lambda > 1."
+        if {"attraction_chamfer", "asymm_segment_chamfer", "reverse_asymm_point_chamfer", "reverse_asymm_segment_chamfer"} & set(self.loss):
+            assert lam > 1
+        if "symm_point_chamfer" in self.loss:
+            assert lam > 1, "symm_point_chamfer is designed for weight scheduling which progressively give more importance " \
+                            "to segments predictions. Why are you using it with lambda=1?"
         if "emd" in self.loss:
             from .hungarianMatcher import HungarianMatcher
             self.matcher = HungarianMatcher()
+
+    @staticmethod
+    def _out_of_scope(name):
+        def method(**_):
+            raise NotImplementedError(f"loss term {name!r} is outside the MaskPlanner hot path of this build")
+        return method
 
     def _cfg(self):
         return _Config(self.config)
@@ -163,7 +206,7 @@ class LossHandler:
         total = 0
         values = []
         for name in self.loss:
-            value = getattr(self, "get_" + name)(**loss_args)
+            value = self.loss_methods[self.loss_index[name]](**loss_args)
             total = total + cfg["weight_" + name] * value
             values.append(value.detach())
         if return_list:
@@ -171,6 +214,18 @@ class LossHandler:
             check_mask_matching()
             return total, array
         return total
+
+    def log_on_wandb(self, loss_list, wandb, epoch, suffix="_train_loss"):
+        """One wandb.log call per configured term (loss_handler.py:234-244; no discriminator terms on this path)."""
+        for loss_term, value in zip(list(self.loss), loss_list):
+            wandb.log({str(loss_term) + str(suffix): value, "epoch": (epoch + 1)})
+
+    def pprint(self, loss_values, prefix=""):
+        """loss_handler.py:246-251."""
+        print(prefix)
+        for name, value in zip(self.loss, loss_values):
+            print(f"{name}:\t{round(value, 3)}")
+        print("------------")
 
     # ---------------------------------------------------------------------------------------------------------
     # plain chamfer terms

@@ -2,7 +2,9 @@
 get_chamfer_original :265-282, get_stroke_chamfer :445-496): the three metrics whose arithmetic is `chamfer_distance`, i.e. the
 kNN hot path, run on the HIP kernels through `maskplanner_amd.pytorch3d_chamfer`.  The remaining reference metrics
 (clustering scores via scikit-learn, start-of-path and stroke-count statistics) are host-side numpy post-processing of a few
-hundred integers per sample; they are outside SURVEY 8 and raise NotImplementedError here.
+hundred integers per sample; they are outside SURVEY 8 and raise NotImplementedError here -- except `stroke_masks_metrics`
+(:285-308), the second default evaluation metric of the maskplanner configs (configs/maskplanner/default.yaml:14-16), which
+is a confidence filter + arg-max over the predicted masks and is evaluated on the device.
 
 Same constructor, metric names, output names and compute() / get_eval_metric() / pprint() behaviour as the reference class.
 """
@@ -28,13 +30,28 @@ def to_numpy(tensor):
 
 
 class MetricsHandler:
-    HOST_ONLY = ("clustering_metrics", "sop_metrics", "sop_metrics_v2", "stroke_masks_metrics", "strokewise_num_of_strokes_metrics")
+    # host-side numpy / scikit-learn statistics outside SURVEY 8 (clustering scores, start-of-path counts)
+    HOST_ONLY = ("clustering_metrics", "sop_metrics", "sop_metrics_v2", "strokewise_num_of_strokes_metrics")
+    _N_STROKES = ("perc_correct_n_strokes", "avg_num_of_pred_strokes", "avg_num_of_gt_strokes", "mean_absolute_error_NoP")
 
     def __init__(self, config, metrics=[], renormalize_output_config={}):
         self.metrics = metrics
-        self.metrics_names = ["pcd", "chamfer_original", "stroke_chamfer"] + list(self.HOST_ONLY)
-        self.output_metrics_names = [("point-wise chamfer distance",), ("chamfer original",), ("stroke chamfer distance",)]
-        self.metric_functions = [self.get_pcd, self.get_chamfer_original, self.get_stroke_chamfer]
+        # the reference's registry, in its order (:42-100)
+        self.metrics_names = ["pcd", "chamfer_original", "stroke_chamfer", "clustering_metrics", "sop_metrics", "sop_metrics_v2",
+                              "stroke_masks_metrics", "strokewise_num_of_strokes_metrics"]
+        self.output_metrics_names = [
+            ("point-wise chamfer distance",), ("chamfer original",), ("stroke chamfer distance",),
+            ("v_measure", "adjusted_rand_score", "avg_num_of_outliers"),
+            ("avg_num_of_pred_sops", "avg_num_of_gt_sops", "avg_ratio_pred_over_gt_sops", "avg_num_of_pred_sops_if_higher_threshold",
+             "avg_num_of_pred_sops_if_lower_threshold", "avg_ratio_pred_over_gt_sops_if_higher_threshold",
+             "avg_ratio_pred_over_gt_sops_if_lower_threshold"),
+            self._N_STROKES + ("avg_num_of_pred_strokes_if_higher_threshold",
+                                                         "avg_num_of_pred_strokes_if_lower_threshold",
+                                                         "mean_absolute_error_NoP_if_higher_threshold",
+                                                         "mean_absolute_error_NoP_if_lower_threshold"),
+            self._N_STROKES, self._N_STROKES]
+        self.metric_functions = [self.get_pcd, self.get_chamfer_original, self.get_stroke_chamfer, None, None, None,
+                                 self.stroke_masks_metrics, None]
         self.metric_index = {m: i for i, m in enumerate(self.metrics_names)}
         self.config = config
         self.renormalize_output_config = renormalize_output_config
@@ -108,6 +125,19 @@ class MetricsHandler:
             if self.renormalize_output:
                 pred, traj_as_pc = self.renormalize_traj(pred), self.renormalize_traj(traj_as_pc)
             return (10 ** 4) * chamfer_distance(pred, traj_as_pc, padded=True)[0]
+
+    def stroke_masks_metrics(self, n_strokes, pred_stroke_masks, mask_scores, confidence_threshold=0.5, **kwargs):
+        """Stroke-count statistics of the predicted masks (:285-308 with utils/postprocessing.py:92-152): masks whose
+        confidence sigmoid is below the threshold get probability 0, every segment goes to its arg-max mask (first mask on
+        ties -- all-zero columns included), the number of distinct masks chosen is the predicted stroke count."""
+        with torch.no_grad():
+            keep = torch.sigmoid(mask_scores.detach().float()) >= confidence_threshold                          # [B,M]
+            prob = torch.sigmoid(pred_stroke_masks.detach().float()) * keep[:, :, None]
+            chosen = prob.argmax(dim=1)                                                                          # [B,S]
+            used = torch.zeros(prob.shape[:2], dtype=torch.bool, device=prob.device).scatter_(1, chosen, True)
+            n_pred = used.sum(1).cpu().numpy().astype(int)
+        n_gt = np.array(to_numpy(n_strokes)).astype(int)
+        return [np.mean((n_gt == n_pred).astype(int)), np.mean(n_pred), np.mean(n_gt), np.mean(np.abs(n_pred - n_gt))]
 
     def get_chamfer_original(self, y_pred, y, traj_pc, **kwargs):
         """Chamfer (x 1e4) against the full, untrimmed ground-truth cloud (:265-282)."""

@@ -1,7 +1,8 @@
 """MaskPlanner backbones on top of the MI355X set-abstraction stack.
 
-Mirrors `models/pointnet2_cls_ssg.py` of the reference: same class names, constructor arguments, forward
-signature/outputs and -- for checkpoint compatibility (test_maskplanner.py:162-188) -- identical `state_dict`
+Mirrors `models/pointnet2_cls_ssg.py` of the reference -- all six classes `models/__init__.py:20` imports
+(PointNet2Regressor :12, _SoPs :85, _3Dbbox :177, _StrokeMasks :233, _StrokeMasks_RetroCompatible :348, _StrokeWise :463):
+same class names, constructor arguments, forward signature/outputs and -- for checkpoint compatibility (test_maskplanner.py:162-188) -- identical `state_dict`
 keys and shapes: sa{1,2,3}.mlp_convs/mlp_bns.*, fc1/fc2/fc3, bn1/bn2, fc_normals, sm_fc1..3, sm_bn1/2,
 mask_conf_out, seg_conf_fc1/2, seg_conf_out.  The encoder (`sa1..sa3`) is the hot path and runs the HIP
 kernels; the regression heads are a handful of dense layers on a [B,1024] feature and stay on rocBLAS via torch
@@ -137,7 +138,9 @@ class PointNet2Regressor_StrokeMasks(_SSGEncoder):
             self.sm_bn1 = nn.BatchNorm1d(h0)
             self.sm_bn2 = nn.BatchNorm1d(h1)
             if mask_confidence_scores:
-                self.mask_conf_out = nn.Linear(h1, n_stroke_masks)
+                setattr(self, self._CONF_LAYER, nn.Linear(h1, n_stroke_masks))
+
+    _CONF_LAYER = "mask_conf_out"      # `out_confidence` in checkpoints older than the rename (RetroCompatible, :410)
 
     # set to a dict by a training harness that uses factor_heads.FactorAdam: the head matrices fed by a [B, 1024] feature
     # (fc1/fc2/fc3/fc_normals and the sm_ twins) then keep their gradient as rank-B factors instead of materialising dW
@@ -172,7 +175,7 @@ class PointNet2Regressor_StrokeMasks(_SSGEncoder):
             s2 = self.dropout(act(factor_linear(s1, self.sm_fc2, fs, "sm_fc2.weight"), self.sm_bn2))
             sm_out = factor_linear(s2, self.sm_fc3, fs, "sm_fc3.weight").view(B, self.n_stroke_masks, -1)
             if self.mask_confidence_scores:
-                mask_conf = self.mask_conf_out(s2)
+                mask_conf = getattr(self, self._CONF_LAYER)(s2)
 
         if self.outdim_orient > 0:
             out = _pose_output(x, factor_linear(final, self.fc_normals, fs, "fc_normals.weight"), B, self.out_vectors,
@@ -180,6 +183,107 @@ class PointNet2Regressor_StrokeMasks(_SSGEncoder):
         else:
             out = x.view(B, self.out_vectors, self.outdim)
         return out, sm_out, mask_conf, seg_conf
+
+
+class PointNet2Regressor_StrokeMasks_RetroCompatible(PointNet2Regressor_StrokeMasks):
+    """models/pointnet2_cls_ssg.py:348-459 (`backbone: pointnet2_strokemasks_retrocompatible`): the same network with the
+    mask-confidence layer under its old state_dict name `out_confidence` (test_maskplanner.py:180-189 falls back to it for
+    checkpoints written before the rename)."""
+    _CONF_LAYER = "out_confidence"
+
+
+class _TrunkRegressor(_SSGEncoder):
+    """What the remaining siblings share (:116-131, :197-207, :506-518): the SSG encoder and the fc1/bn1 -> fc2/bn2 -> fc3
+    trunk on the global feature.  Registration order == the reference's, so state_dict keys come out in the same order."""
+
+    def _build_trunk(self, normal_channel, inputdim, hidden_size, n_out, n_out_orient=0):
+        self._build_encoder(normal_channel, inputdim)
+        self.fc1 = nn.Linear(1024, hidden_size[0])
+        self.fc2 = nn.Linear(hidden_size[0], hidden_size[1])
+        self.fc3 = nn.Linear(hidden_size[1], n_out)
+        self.dropout = nn.Dropout(p=0.3)
+        self.bn1 = nn.BatchNorm1d(hidden_size[0])
+        self.bn2 = nn.BatchNorm1d(hidden_size[1])
+        if n_out_orient > 0:
+            self.fc_normals = nn.Linear(hidden_size[1], n_out_orient)
+            self.tanh = nn.Tanh()
+
+    def _trunk(self, xyz):
+        """-> (global feature [B,1024], last hidden activation [B,h1], fc3 output)."""
+        feat = self.encode(xyz)
+        fused = feat.is_cuda
+        if fused:
+            _tick(self.bn1, self.bn2)
+        act = _bn_relu if fused else (lambda t, bn: F.relu(bn(t)))
+        last = self.dropout(act(self.fc2(self.dropout(act(self.fc1(feat), self.bn1))), self.bn2))
+        return feat, last, self.fc3(last)
+
+    def _poses(self, x, last, B):
+        if self.outdim_orient > 0:
+            return _pose_output(x, self.fc_normals(last), B, self.out_vectors, self.weight_orient)
+        return x.view(B, self.out_vectors, self.outdim)
+
+
+class PointNet2Regressor_SoPs(_TrunkRegressor):
+    """models/pointnet2_cls_ssg.py:85-174 (`backbone: pointnet2_sops`): start-of-path poses + optional per-pose confidence.
+    forward(xyz, return_object_features=False) -> (out [B,V,D], sop_conf [B,V] | None[, global feature])."""
+
+    def __init__(self, out_vectors=10, outdim=3, outdim_orient=3, weight_orient=1., normal_channel=False,
+                 hidden_size=(1024, 1024), inputdim=None, sop_confidence_scores=False):
+        super().__init__()
+        self.outdim, self.outdim_orient = outdim, outdim_orient
+        self.out_vectors, self.weight_orient = out_vectors, weight_orient
+        self.sop_confidence_scores = sop_confidence_scores
+        self._build_trunk(normal_channel, inputdim, hidden_size, out_vectors * outdim, out_vectors * outdim_orient)
+        if sop_confidence_scores:
+            self.sop_conf_out = nn.Linear(hidden_size[1], out_vectors)
+
+    def forward(self, xyz, return_object_features=False):
+        feat, last, x = self._trunk(xyz)
+        conf = self.sop_conf_out(last) if self.sop_confidence_scores else None
+        out = self._poses(x, last, xyz.shape[0])
+        return (out, conf, feat) if return_object_features else (out, conf)
+
+
+class PointNet2Regressor_3Dbbox(_TrunkRegressor):
+    """models/pointnet2_cls_ssg.py:177-229 (`backbone: pointnet2_3dbbox`): out_bboxes boxes as (centre xyz, size whd)."""
+
+    def __init__(self, out_bboxes=10, normal_channel=False, hidden_size=(1024, 1024), inputdim=None):
+        super().__init__()
+        self.out_bboxes, self.outdim = out_bboxes, 6
+        self._build_trunk(normal_channel, inputdim, hidden_size, out_bboxes * 6)
+
+    def forward(self, xyz):
+        return self._trunk(xyz)[2].view(xyz.shape[0], self.out_bboxes, self.outdim)
+
+
+class PointNet2Regressor_StrokeWise(_TrunkRegressor):
+    """models/pointnet2_cls_ssg.py:463-556 (`backbone: pointnet2_strokewise`): one output vector per stroke + optional
+    per-stroke and per-point confidences.  forward -> (out [B,V,D], point_conf [B,V,n] | None, stroke_conf [B,V] | None).
+    (With point_confidence_scores=False the reference's forward stops on an unbound local at :556; None is returned here.)"""
+
+    def __init__(self, outdim=3, outdim_orient=3, weight_orient=1., normal_channel=False, out_vectors=1500,
+                 hidden_size=(1024, 1024), inputdim=None, stroke_confidence_scores=False, point_confidence_scores=False,
+                 n_points_per_out_vector=None):
+        super().__init__()
+        self.outdim, self.outdim_orient = outdim, outdim_orient
+        self.out_vectors, self.weight_orient = out_vectors, weight_orient
+        self.stroke_confidence_scores, self.point_confidence_scores = stroke_confidence_scores, point_confidence_scores
+        self.n_points_per_out_vector = n_points_per_out_vector
+        self._build_trunk(normal_channel, inputdim, hidden_size, out_vectors * outdim, out_vectors * outdim_orient)
+        if stroke_confidence_scores:
+            self.stroke_conf_out = nn.Linear(hidden_size[1], out_vectors)
+        if point_confidence_scores:
+            self.point_conf_out = nn.Linear(hidden_size[1], out_vectors * n_points_per_out_vector)
+
+    def forward(self, xyz):
+        B = xyz.shape[0]
+        _, last, x = self._trunk(xyz)
+        stroke_conf = self.stroke_conf_out(last) if self.stroke_confidence_scores else None
+        point_conf = None
+        if self.point_confidence_scores:
+            point_conf = self.point_conf_out(last).view(B, self.out_vectors, self.n_points_per_out_vector)
+        return self._poses(x, last, B), point_conf, stroke_conf
 
 
 def maskplanner_model(category, lambda_points=4, overlapping=1, outdim=6, orient_outdim=3, weight_orient=0.25,

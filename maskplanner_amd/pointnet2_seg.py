@@ -102,3 +102,16 @@ class PointNet2Segmenter_PaintNet_v1(_SegBase):
         normals = torch.tanh(self.conv4_orient(last)).permute(0, 2, 1).reshape(B, N, self.lambda_points, -1)
         normals = F.normalize(normals, dim=-1) * self.weight_orient
         return torch.cat((x, normals), dim=-1).reshape(B, N, -1)
+
+
+def _not_implemented(name, line, msg):
+    """The reference's constructors of these variants raise before building anything (models/pointnet2_seg.py:120,193,252)."""
+    def __init__(self, *args, **kwargs):
+        nn.Module.__init__(self)
+        raise NotImplementedError(msg)
+    return type(name, (nn.Module,), {"__init__": __init__, "__doc__": f"models/pointnet2_seg.py:{line}: raises NotImplementedError upstream as well."})
+
+
+PointNet2Segmenter_v2 = _not_implemented("PointNet2Segmenter_v2", 99, "TODO: SetAbstraction with sample_all_as_centroids=True flag")
+PointNet2Segmenter_v3 = _not_implemented("PointNet2Segmenter_v3", 181, "TODO")
+PointNet2Segmenter_v4 = _not_implemented("PointNet2Segmenter_v4", 239, "TODO")
