@@ -3,44 +3,65 @@
 (N=5120 points, B=32 per GPU, PointNet++ SSG encoder + asymm_chamfer_v9 loss) -- BASELINE.json configs[1].
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
 
-One process per GPU; the batch is sharded by sample (weak scaling: 32 clouds per GPU), gradients are averaged with
-a bucketed RCCL all-reduce overlapped with backward (maskplanner_amd/dp.py).  Inputs are synthetic (the reference's
-dataset is not public) and resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+With N > 1 and no torchrun environment the script launches its own workers (`python -m torch.distributed.run --nnodes=1
+--nproc-per-node N --master-addr 127.0.0.1 ...` of itself, before anything touches the GPU); under torchrun it reads
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment.  One process per GPU; the batch is sharded by sample (weak
+scaling: 32 clouds per GPU), gradients are exchanged over RCCL (maskplanner_amd/dp.py).  Inputs are synthetic (the
+reference's dataset is not public) and resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
 
-Extra objects in the line:
-  roofline     -- the entry point with the largest device time among the library's kernels, timed with HIP events
-                  on the launch stream inside the timed region; algorithmic bytes / flops per launch from DESIGN.md.
-  cpu_baseline -- the CPU restatement of the same step (oracle/: C for FPS / ball query / kNN / LAP + torch fp32
-                  for the MLP algebra) timed on this box's host cores on a bounded sample (rank 0, N=1 only).
+`value` is the training step of `harness.TrainStep` (the path's ceiling: resident batch, hipGraph replay, factor heads).
+Extra objects in the line (rank 0, N=1):
+  roofline     -- the library kernel with the largest device time, timed with HIP events on its launch stream inside the
+                  timed region; algorithmic bytes / flops per launch from DESIGN.md; `traffic` from the committed PMC passes.
+  named_kernels-- FPS / ball query / kNN / grouping against both roofs, `effective_scan_GBps`, and for FPS
+                  the measured latency floor (the same kernel without distance arithmetic) and the fraction of it.
+  dropin_path  -- the reference's own loop body (train_maskplanner.py:182-227) on the drop-in modules: torch.optim.Adam over
+                  all parameters, a fresh host batch per step, compute() -> numpy, loss.item().  `--path dropin` makes this
+                  the headline `value` instead.
+  ucube        -- the same step on U[-1,1]^3 clouds (sparse balls: full-scan ball query, heavy padding).
+  cpu_baseline -- the CPU restatement of the same step (oracle/) on this box's host cores, bounded sample.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP32_PEAK_TFLOPS = 157.3     # fp32 vector == fp32-input MFMA peak
+BF16_PEAK_TFLOPS = 2500.0    # dense bf16 MFMA
+
+
+def _split_template(name):
+    base, _, rest = name.partition("<")
+    args = [a.strip() for a in rest.rstrip(">").split(",")] if rest else []
+    return base.strip(), args
 
 
 def measured_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the most recent committed PMC passes (profiles/rNN_traffic.json, made
-    by tools/make_profile_summary.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this bench)."""
+    """HBM bytes per launch of `kernel` from the most recent committed PMC passes (profiles/rNN_traffic.json, made by
+    tools/make_profile_summary.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this bench).  The library
+    tags a launch with the template arguments it chose; rocprofv3 prints every argument including defaulted ones, so a
+    tag matches the profile name whose argument list it is a prefix of."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
     if not files:
         return None
-    k = json.load(open(files[-1]))["kernels"].get(kernel)
-    return None if k is None else k["hbm_bytes"]
+    table = json.load(open(files[-1]))["kernels"]
+    if kernel in table:
+        return table[kernel]["hbm_bytes"]
+    base, args = _split_template(kernel)
+    hits = []
+    for name, v in table.items():
+        b, a = _split_template(name)
+        if b == base and a[:len(args)] == args:
+            hits.append(v["hbm_bytes"])
+    return hits[0] if len(hits) == 1 else None
 
 
 def collect_kernel_profile(lib):
@@ -59,6 +80,7 @@ def collect_kernel_profile(lib):
 
 def cpu_baseline(cat, N, seed):
     """The oracle's restatement of ONE training step (forward + loss + backward) on the host cores."""
+    import torch
     from maskplanner_amd import synthetic as syn
     from maskplanner_amd.loss_handler import maskplanner_loss_config
     from maskplanner_amd.pointnet2_cls_ssg import maskplanner_model
@@ -81,6 +103,95 @@ def cpu_baseline(cat, N, seed):
             "sample": f"1 step of forward+loss+backward on {Bc} clouds of N={N} (no optimizer step), {dt:.1f} s"}
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` typed as is: start one worker per GPU with torch.distributed.run.  Nothing in this process
+    has touched the GPU yet (device_count() does not initialise it); the workers inherit HSA_ENABLE_IPC_MODE_LEGACY=0, which
+    RCCL's dmabuf IPC needs on this driver."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def kernel_tables(kernels, profiled_steps, floors):
+    """named_kernels (the kernels BASELINE.json names, each against BOTH roofs + SURVEY 8d's effective scan rate) and the
+    per-step time of every tagged kernel."""
+    scan_bytes_per_flop = {"fps_kernel": 20.0 / 8.0, "ball_query_kernel": 12.0 / 8.0, "knn1_kernel": 4.0 / 3.0, "knn_kernel": 4.0 / 3.0}
+    named = {}
+    for k, v in kernels.items():
+        base = k.split("<")[0]
+        if base not in ("fps_kernel", "ball_query_kernel", "knn1_kernel", "knn_kernel", "group_kernel", "group_bwd_atomic_kernel"):
+            continue
+        t = v["ms"] / v["calls"] * 1e-3
+        fl, by = v["flops"] / v["calls"], v["bytes"] / v["calls"]
+        e = {"us_per_launch": round(t * 1e6, 1), "tflops": round(fl / t / 1e12, 2), "frac_fp32_peak": round(fl / t / 1e12 / FP32_PEAK_TFLOPS, 4),
+             "alg_GBps": round(by / t / 1e9, 1), "frac_hbm": round(by / t / 1e9 / HBM_PEAK_GBS, 4)}
+        if base in scan_bytes_per_flop:
+            # bytes_scan = pairs x operand bytes (each pair touches its operand once): > 100 % of HBM is expected (LDS reuse)
+            e["effective_scan_GBps"] = round(fl * scan_bytes_per_flop[base] / t / 1e9, 1)
+        if k in floors:
+            e["latency_floor_us"] = round(floors[k], 1)
+            e["frac_latency_floor"] = round(floors[k] / (t * 1e6), 4)
+        named[k] = e
+    per_step = {k: round(v["ms"] * 1e3 / profiled_steps, 1) for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]["ms"])}
+    return named, per_step
+
+
+def fps_floors(ts, lib):
+    """S * t_iter for the two FPS launches of the encoder: mp_fps_floor_f32 (the same kernel, same launch shape and per-step
+    reduce + barrier chain, no distance arithmetic), median of 9 launches each, HIP events on the launch stream."""
+    import torch
+    from maskplanner_amd import ops
+    out = {}
+    xyz = ts.batch["point_cloud"]
+    B = xyz.shape[0]
+    for m in ts._plan_levels():
+        N = xyz.shape[1]
+        S = m.npoint
+        start = torch.zeros(B, dtype=torch.long, device=xyz.device)
+        idx = torch.empty(B, S, dtype=torch.long, device=xyz.device)
+        new_xyz = torch.empty(B, S, 3, device=xyz.device)
+        times = []
+        for _ in range(12):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            ops._run("fps_floor", xyz, lib.mp_fps_floor_f32, xyz.data_ptr(), B, N, S, start.data_ptr(), idx.data_ptr(), new_xyz.data_ptr())
+            b.record()
+            times.append((a, b))
+        torch.cuda.synchronize()
+        us = sorted(a.elapsed_time(b) * 1e3 for a, b in times[3:])
+        tag = {5120: "fps_kernel<256, 20>", 512: "fps_kernel<64, 8>", 10240: "fps_kernel<512, 20>"}.get(N)
+        if tag:
+            out[tag] = us[len(us) // 2]
+        xyz = new_xyz
+    return out
+
+
+def time_steps(step, steps, warmup, barrier, profile=None):
+    """The contract's timing: W untimed steps, then exactly K steps bracketed by barrier + synchronize.  Returns (seconds,
+    per-step device milliseconds of the unprofiled steps, last loss)."""
+    import torch
+    for _ in range(warmup):
+        step(False)
+    barrier()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    t0 = time.perf_counter()
+    loss = None
+    for i in range(steps):
+        marks[i].record()
+        loss = step(profile is not None and profile(i))
+    marks[-1].record()
+    barrier()
+    dt = time.perf_counter() - t0
+    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(steps) if not (profile is not None and profile(i)))
+    return dt, per_step, loss
+
+
 def main():
     if os.environ.get("MASKPLANNER_FAULT_DUMP"):   # debugging aid: dump all stacks and exit if the run hangs
         import faulthandler
@@ -92,118 +203,160 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="clouds per GPU")
     ap.add_argument("--points", type=int, default=5120)
     ap.add_argument("--category", default="cuboids")
+    ap.add_argument("--dist", default="cuboid", choices=["cuboid", "ucube"], help="point distribution of the synthetic clouds")
+    ap.add_argument("--path", default="harness", choices=["harness", "dropin"],
+                    help="harness: TrainStep (resident batch, graph replay, factor heads); dropin: the reference's own loop body")
+    ap.add_argument("--encoder", default="ssg", choices=["ssg", "msg"], help="msg: two multi-scale set abstractions (BASELINE configs[4])")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"], help="operand type of the grouped-MLP MFMAs (accumulation is fp32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-side-legs", action="store_true", help="skip the dropin_path / ucube legs of the default run")
     ap.add_argument("--no-graph", action="store_true", help="launch every step kernel by kernel (no hipGraph replay)")
     ap.add_argument("--overlap-sampling", type=int, default=None, help="1/0: next batch's FPS + ball query on a second stream")
+    ap.add_argument("--sync-bn", action="store_true", help="data-parallel runs: BatchNorm statistics over the global batch")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))
+
+    import torch
+    import torch.distributed as dist
     from maskplanner_amd import dp
     rank, local, world = dp.init_from_env()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the MaskPlanner hot path has no CPU fallback")
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     local = local % torch.cuda.device_count()   # (several ranks per GPU only happen in the gloo dry run)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
-    from maskplanner_amd import _lib, ops, synthetic
-    from maskplanner_amd.harness import TrainStep
-    _lib.load()  # fail loudly if the HIP library is missing
+    from maskplanner_amd import _lib, synthetic
+    from maskplanner_amd.harness import DropInLoop, TrainStep
+    lib = _lib.load()  # fail loudly if the HIP library is missing
     cat = synthetic.CATEGORIES[args.category]
-    ts = TrainStep(cat, B=args.batch, N=args.points, device=dev, rank=rank, graph=False if args.no_graph else None,
-                   overlap_sampling=None if args.overlap_sampling is None else bool(args.overlap_sampling))
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    lib = _lib.load()
-    # set-up, before the contract's warmup: the steps TrainStep needs to create optimizer state and record its hipGraph (three
-    # eager steps + the recording one), so that even --warmup 0 times replays and not the recording
-    while ts.use_graph and ts._graph is None:
-        ts.step()
-    if ts._graph is not None:
-        ts.eager_step()   # the profiled steps of the timed region launch eagerly on this stream: warm its allocator blocks too
-    for _ in range(args.warmup):
-        ts.step()
-    barrier()
-    # one event per step on the compute stream: the median step time is reported beside the contract's mean (a shared
-    # host makes the mean jittery; nothing is synchronised inside the timed region)
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
-    t0 = time.perf_counter()
-    profiled_steps = 0
-    for i in range(args.steps):
-        marks[i].record()
-        # per-kernel HIP events (two records per library launch) on every 20th timed step, rank 0 only: the hooks
-        # cost ~0.5 ms per profiled step, so sampling keeps the headline number honest
-        prof = rank == 0 and i % 20 == 0
-        if prof:
-            lib.mp_profiler_enable(1)
-            profiled_steps += 1
-        loss = ts.eager_step() if prof else ts.step()   # the timing hooks sit in the launch path, which a graph replay skips
-        if prof:
-            lib.mp_profiler_enable(0)
-    if marks:
-        marks[-1].record()
-    barrier()
-    dt = time.perf_counter() - t0
+    def make_harness(dist_points):
+        kw = {}
+        if args.encoder != "ssg" or args.dtype != "f32":
+            kw.update(encoder=args.encoder, mlp_dtype=args.dtype)
+        if args.sync_bn:
+            kw.update(sync_bn=True)
+        ts = TrainStep(cat, B=args.batch, N=args.points, device=dev, rank=rank, graph=False if args.no_graph else None,
+                       overlap_sampling=None if args.overlap_sampling is None else bool(args.overlap_sampling),
+                       dist_points=dist_points, **kw)
+        # set-up, before the contract's warmup: the steps TrainStep needs to create optimizer state and record its hipGraph
+        # (three eager steps + the recording one), so that even --warmup 0 times replays and not the recording
+        while ts.use_graph and ts._graph is None:
+            ts.step()
+        if ts._graph is not None:
+            ts.eager_step()   # the profiled steps of the timed region launch eagerly on this stream: warm its allocator blocks too
+        return ts
+
+    def run_harness(ts, steps, warmup, profile_every=20):
+        def step(prof):
+            if prof:
+                lib.mp_profiler_enable(1)
+            loss = ts.eager_step() if prof else ts.step()   # the timing hooks sit in the launch path, which a graph replay skips
+            if prof:
+                lib.mp_profiler_enable(0)
+            return loss
+        # per-kernel HIP events (two records per library launch) on every 20th timed step, rank 0 only: the hooks cost
+        # ~0.5 ms per profiled step, so sampling keeps the headline number honest
+        prof = (lambda i: i % profile_every == 0) if rank == 0 else None
+        dt, per_step, loss = time_steps(step, steps, warmup, barrier, prof)
+        n_prof = len([i for i in range(steps) if prof is not None and prof(i)])
+        return dt, per_step, float(loss.detach()), n_prof
+
+    def run_dropin(steps, warmup, dist_points="cuboid"):
+        loop = DropInLoop(cat, B=args.batch, N=args.points, device=dev, rank=rank, dist_points=dist_points)
+        last = [0.0]
+
+        def step(_prof):
+            last[0] = loop.step()
+            return torch.tensor(last[0])
+        for _ in range(3):
+            step(False)     # optimizer state, allocator
+        dt, per_step, _ = time_steps(step, steps, warmup, barrier)
+        return dt, per_step, last[0]
+
+    line = None
+    if args.path == "harness":
+        ts = make_harness(args.dist)
+        dt, per_step, final_loss, profiled_steps = run_harness(ts, args.steps, args.warmup)
+    else:
+        dt, per_step, final_loss = run_dropin(args.steps, args.warmup, args.dist)
+        ts, profiled_steps = None, 0
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    final_loss = float(loss.detach())
 
     if rank == 0:
         ms = dt / args.steps * 1e3
-        kernels = collect_kernel_profile(lib)
-        # dominant kernel = largest total device time on the step's own stream; its binding roof from the algorithmic work
-        # model.  (With pipelined sampling the first-level FPS -- a latency-bound chain of dependent arg-max steps, one
-        # workgroup per cloud -- runs on the second stream underneath the step and is not on the critical path.)
-        on_path = [k for k in kernels if not (ts.overlap and k.startswith("fps_kernel"))] or list(kernels)
-        dom = max(on_path, key=lambda k: kernels[k]["ms"])
-        d = kernels[dom]
-        avg_s = d["ms"] / d["calls"] * 1e-3
-        flops, nbytes = d["flops"] / d["calls"], d["bytes"] / d["calls"]
-        if flops / (FP32_PEAK_TFLOPS * 1e12) >= nbytes / (HBM_PEAK_GBS * 1e9):
-            bound, ach, peak, unit = "mfma", flops / avg_s / 1e12, FP32_PEAK_TFLOPS, "TFLOP/s"
-        else:
-            bound, ach, peak, unit = "hbm", nbytes / avg_s / 1e9, HBM_PEAK_GBS, "GB/s"
+        enc = "SSG encoder" if args.encoder == "ssg" else "MSG encoder (two multi-radius set abstractions)"
         line = {
             "metric": "point-clouds/sec fwd+bwd (N=5120, B=32)", "value": args.batch * world * args.steps / dt,
             "unit": "point-clouds/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{cat.name}_v2 N={args.points} B={args.batch}/GPU SSG encoder + asymm_chamfer_v9 loss "
-                                   f"(forward+loss+backward+Adam), S={cat.out_vectors} M={cat.max_n_strokes}",
-                       "parallelism": f"dp{world}", "global_batch": args.batch * world, "grad_allreduce_MB":
-                           round(ts.reducer.grad_bytes() / 1e6, 1),
-                       "launch": ("hipGraph replay of the recorded step" + (" (two graphs; head optimizer on its own stream under the next encoder forward)"
-                                                                             if ts._graph_b is not None else ""))
-                       if ts._graph is not None else "eager (kernel by kernel)",
-                       "sampling": "next batch's first-level FPS + ball query on a second stream, under the step" if ts.overlap
-                       else "in line"},
-            "roofline": {"kernel": dom, "bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak,
-                         "traffic": measured_traffic(dom), "avg_us": avg_s * 1e6, "launches_per_step": d["calls"] / profiled_steps,
-                         "flops_per_launch": flops, "bytes_per_launch": nbytes},
-            # the kernels BASELINE.json names, each against BOTH roofs (algorithmic flops vs the fp32 peak, algorithmic
-            # bytes vs HBM): FPS is latency-bound, ball query / kNN are fp32-VALU bound, grouping is the HBM-bound one
-            "named_kernels": {k: {"us_per_launch": round(v["ms"] * 1e3 / v["calls"], 1),
-                                  "tflops": round(v["flops"] / v["calls"] / (v["ms"] / v["calls"] * 1e-3) / 1e12, 2),
-                                  "frac_fp32_peak": round(v["flops"] / v["calls"] / (v["ms"] / v["calls"] * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4),
-                                  "alg_GBps": round(v["bytes"] / v["calls"] / (v["ms"] / v["calls"] * 1e-3) / 1e9, 1),
-                                  "frac_hbm": round(v["bytes"] / v["calls"] / (v["ms"] / v["calls"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
-                              for k, v in kernels.items() if k.split("<")[0] in
-                              ("fps_kernel", "ball_query_kernel", "knn1_kernel", "knn_kernel", "group_kernel", "group_bwd_atomic_kernel")},
-            "kernels_us_per_step": {k: round(v["ms"] * 1e3 / profiled_steps, 1) for k, v in
-                                    sorted(kernels.items(), key=lambda kv: -kv[1]["ms"])},
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"{cat.name}_v2 N={args.points} B={args.batch}/GPU {enc} + asymm_chamfer_v9 loss "
+                                   f"(forward+loss+backward+Adam), S={cat.out_vectors} M={cat.max_n_strokes}, {args.dist} clouds",
+                       "parallelism": f"dp{world}", "global_batch": args.batch * world, "path": args.path},
             "final_loss": final_loss,
         }
-        if marks:
-            per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps) if i % 10 != 0)  # unprofiled steps
-            if per_step:
-                line["step_ms_median"] = per_step[len(per_step) // 2]
-                line["step_ms_min"] = per_step[0]
+        if per_step:
+            line["step_ms_median"] = per_step[len(per_step) // 2]
+            line["step_ms_min"] = per_step[0]
+        if ts is not None:
+            line["config"].update({
+                "grad_allreduce_MB": round(ts.reducer.grad_bytes() / 1e6, 1),
+                "launch": ("hipGraph replay of the recorded step" + (" (two graphs; head optimizer on its own stream under the next encoder forward)"
+                                                                      if ts._graph_b is not None else ""))
+                if ts._graph is not None else "eager (kernel by kernel)",
+                "sampling": "next batch's first-level FPS + ball query on a second stream, under the step" if ts.overlap else "in line",
+                "batchnorm": "global-batch statistics (SyncBN)" if getattr(ts, "sync_bn", False) else "per-replica statistics"})
+            kernels = collect_kernel_profile(lib)
+            # dominant kernel = largest total device time on the step's own stream; its binding roof from the algorithmic work
+            # model.  (With pipelined sampling the first-level FPS -- a latency-bound chain of dependent arg-max steps, one
+            # workgroup per cloud -- runs on the second stream underneath the step and is not on the critical path.)
+            on_path = [k for k in kernels if not (ts.overlap and k.startswith("fps_kernel"))] or list(kernels)
+            dom = max(on_path, key=lambda k: kernels[k]["ms"])
+            d = kernels[dom]
+            avg_s = d["ms"] / d["calls"] * 1e-3
+            flops, nbytes = d["flops"] / d["calls"], d["bytes"] / d["calls"]
+            mfma_peak = BF16_PEAK_TFLOPS if "bf16" in dom else FP32_PEAK_TFLOPS
+            if flops / (mfma_peak * 1e12) >= nbytes / (HBM_PEAK_GBS * 1e9):
+                bound, ach, peak, unit = "mfma", flops / avg_s / 1e12, mfma_peak, "TFLOP/s"
+            else:
+                bound, ach, peak, unit = "hbm", nbytes / avg_s / 1e9, HBM_PEAK_GBS, "GB/s"
+            line["roofline"] = {"kernel": dom, "bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak,
+                                "traffic": measured_traffic(dom), "avg_us": avg_s * 1e6, "launches_per_step": d["calls"] / max(profiled_steps, 1),
+                                "flops_per_launch": flops, "bytes_per_launch": nbytes}
+            floors = fps_floors(ts, lib) if world == 1 else {}
+            line["named_kernels"], line["kernels_us_per_step"] = kernel_tables(kernels, max(profiled_steps, 1), floors)
+        side = world == 1 and not args.no_side_legs and args.path == "harness" and args.dist == "cuboid" and args.encoder == "ssg"
+        if side:
+            # the drop-in figure next to the harness figure
+            k = max(10, min(args.steps, 30))
+            ddt, dper, dloss = run_dropin(k, 3)
+            line["dropin_path"] = {"value": args.batch * k / ddt, "unit": "point-clouds/s", "ms_per_step": ddt / k * 1e3, "steps": k,
+                                   "step_ms_median": dper[len(dper) // 2], "final_loss": dloss,
+                                   "what": "train_maskplanner.py:182-227 loop body on the drop-in modules: torch.optim.Adam on all parameters, "
+                                           "fresh host batch per step (H2D inside the step), FPS starts drawn per call, compute() -> numpy, loss.item()"}
+            # U-cube clouds: sparse balls => full-scan ball query and heavy padding
+            del ts
+            torch.cuda.empty_cache()
+            tu = make_harness("ucube")
+            lib.mp_profiler_collect(None, 0)
+            udt, uper, uloss, uprof = run_harness(tu, k, 3, profile_every=10)
+            uk = collect_kernel_profile(lib)
+            unamed, _ = kernel_tables(uk, max(uprof, 1), {})
+            line["ucube"] = {"value": args.batch * k / udt, "unit": "point-clouds/s", "ms_per_step": udt / k * 1e3, "steps": k,
+                             "step_ms_median": uper[len(uper) // 2] if uper else None, "final_loss": uloss, "named_kernels": unamed}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cat, args.points, 1235)
         print(json.dumps(line))

@@ -49,6 +49,11 @@ const char* mp_error_string(int code);
  *   argmax with lowest index on ties.  N <= 13312 (cloud resident in LDS), else MP_EUNSUPPORTED. */
 int mp_fps_f32(const float* xyz, int64_t B, int64_t N, int64_t S, const int64_t* start_idx,
                int64_t* out_idx, float* out_xyz, mp_stream_t stream);
+/* Measurement aid: the latency floor of mp_fps_f32 for the same arguments -- the kernel it would launch with the per-point
+ * distance arithmetic removed (same launch shape, same dependent reduce + barrier chain per step; SURVEY 8d "S * t_iter").
+ * Outputs are written but meaningless.  Supported for N <= 10240. */
+int mp_fps_floor_f32(const float* xyz, int64_t B, int64_t N, int64_t S, const int64_t* start_idx,
+                     int64_t* out_idx, float* out_xyz, mp_stream_t stream);
 
 /* ---- ball query ------------------------------------------------------------------------------
  * replaces: models/pointnet2_utils.py:89-109 query_ball_point(radius, nsample, xyz, new_xyz)

@@ -43,6 +43,7 @@ SIGNATURES = {
     "mp_abi_version": (_int, []),
     "mp_error_string": (ctypes.c_char_p, [_int]),
     "mp_fps_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp]),
+    "mp_fps_floor_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp]),
     "mp_ball_query_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _dbl, _i64, _vp, _vp]),
     "mp_square_distance_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp]),
     "mp_index_points_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),

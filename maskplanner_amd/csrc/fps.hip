@@ -23,7 +23,10 @@
 
 namespace {
 
-template <int T, int PPT>
+// FLOOR = true: the measurement variant behind mp_fps_floor_f32 -- the same dependent chain per step (centroid read from
+// LDS, wave arg-max, LDS atomic, barrier, broadcast read) with the per-point distance work removed: S * t_iter of it is
+// the latency floor this design cannot go below, which bench.py reports the real kernel against.
+template <int T, int PPT, bool FLOOR = false>
 __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, int N, int S,
                                                 const int64_t* __restrict__ start_idx,
                                                 int64_t* __restrict__ out_idx, float* __restrict__ out_xyz)
@@ -84,8 +87,9 @@ __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, i
         const f2 cx = {cxs, cxs}, cy = {cys, cys}, cz = {czs, czs};
         float best = -1.0f;
         int bj = 0;
+        if constexpr (FLOOR) best = __builtin_fabsf((cxs + cys) + czs) + (float)(tid ^ s);   // depends on the LDS read, varies per step
 #pragma unroll
-        for (int j = 0; j < PP2; ++j) {
+        for (int j = 0; j < (FLOOR ? 0 : PP2); ++j) {
             const f2 dx = px[j] - cx;
             const f2 dy = py[j] - cy;
             const f2 dz = pz[j] - cz;
@@ -128,19 +132,19 @@ __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, i
     }
 }
 
-template <int T, int PPT>
+template <int T, int PPT, bool FLOOR = false>
 int launch_fps(const float* xyz, int B, int N, int S, const int64_t* start, int64_t* out_idx, float* out_xyz,
                hipStream_t stream)
 {
 
     const size_t smem = (size_t)3 * T * PPT * sizeof(float) + 4 * sizeof(unsigned long long) + (size_t)S * sizeof(int);
     if (smem > 160 * 1024) return MP_EUNSUPPORTED;
-    auto kern = fps_kernel<T, PPT>;
+    auto kern = fps_kernel<T, PPT, FLOOR>;
     // opt-in to > 64 KB of dynamic LDS once per size (not a stream operation: it must not run inside a graph capture)
     static mp::DynLds lds;      // per kernel instantiation, per device
     if (!lds.ensure(reinterpret_cast<const void*>(kern), smem)) return MP_ELAUNCH;
     char tag[48];
-    snprintf(tag, sizeof tag, "fps_kernel<%d, %d>", T, PPT);
+    snprintf(tag, sizeof tag, FLOOR ? "fps_floor_kernel<%d, %d>" : "fps_kernel<%d, %d>", T, PPT);
     MP_LAUNCH(tag, 8.0 * B * (double)N * S, (double)B * (N * 12.0 + S * 8.0 + (out_xyz ? S * 12.0 : 0.0)), kern, dim3(B),
               dim3(T), smem, stream, xyz, N, S, start, out_idx, out_xyz);
     MP_CHECK_LAUNCH();
@@ -186,5 +190,22 @@ extern "C" int mp_fps_f32(const float* xyz, int64_t B, int64_t N, int64_t S, con
     MP_FPS_CASE(1024, 10);
     MP_FPS_CASE(1024, 13);
 #undef MP_FPS_CASE
+    return MP_EUNSUPPORTED;
+}
+
+// Measurement aid (bench.py): the latency floor of the kernel mp_fps_f32 would pick for this size -- identical launch shape and
+// per-step synchronisation, no distance arithmetic.  Output contents are meaningless (in-range indices).
+extern "C" int mp_fps_floor_f32(const float* xyz, int64_t B, int64_t N, int64_t S, const int64_t* start_idx,
+                                int64_t* out_idx, float* out_xyz, mp_stream_t stream_)
+{
+    if (B < 0 || N <= 0 || S < 0) return MP_EINVAL;
+    if (B == 0 || S == 0) return MP_OK;
+    if (!xyz || !start_idx || !out_idx) return MP_EINVAL;
+    hipStream_t stream = mp_stream(stream_);
+    const int b = (int)B, n = (int)N, s = (int)S;
+    if (S > 8192) return MP_EUNSUPPORTED;
+    if (n <= 512) return launch_fps<64, 8, true>(xyz, b, n, s, start_idx, out_idx, out_xyz, stream);
+    if (n <= 5120) return launch_fps<256, 20, true>(xyz, b, n, s, start_idx, out_idx, out_xyz, stream);
+    if (n <= 10240) return launch_fps<512, 20, true>(xyz, b, n, s, start_idx, out_idx, out_xyz, stream);
     return MP_EUNSUPPORTED;
 }

@@ -327,3 +327,52 @@ class TrainStep:
         if self.factor_opt is not None:
             self.factor_opt.step()
         return loss.detach()   # callers never keep the autograd graph (and its accumulator nodes) alive across steps
+
+
+class DropInLoop:
+    """The reference's own hot loop (train_maskplanner.py:182-227), statement for statement, on the drop-in modules -- what an
+    UNCHANGED train_maskplanner.py executes per batch once `dropin.install()` has aliased the modules: the model the
+    reference's factory builds (models/__init__.py:111-122), `torch.optim.Adam` over ALL parameters (:159), a fresh collated
+    HOST batch every step (copied to the device inside the loop, :207-208; the GT tensors inside the loss, loss_handler.py:
+    629, 838), FPS start indices drawn from the CPU generator per call (pointnet2_utils.py:77), `compute()` returning the
+    numpy list of terms and `loss.item()` (:212-224) -- two host synchronisations per step.  No graph replay, no factor heads,
+    no pipelined sampling: this is the drop-in figure, `TrainStep` is the path's ceiling."""
+
+    def __init__(self, category="cuboids", B=32, N=5120, device="cuda", seed=1235, lr=1e-3, dist_points="cuboid", n_batches=4,
+                 rank=0):
+        self.cat = synthetic.CATEGORIES[category] if isinstance(category, str) else category
+        self.device = torch.device(device)
+        torch.manual_seed(seed)
+        self.model = maskplanner_model(self.cat).to(self.device)
+        self.opt = torch.optim.Adam(self.model.parameters(), lr=lr)                       # :159
+        self.cfg = maskplanner_loss_config()
+        self.loss_handler = LossHandler(["asymm_v6_chamfer_with_stroke_masks"], self.cfg)  # :163
+        self.host_batches = [synthetic.make_batch(seed + 1000 * rank + 7 * i, B, N, self.cat.name, dist_points) for i in range(n_batches)]
+        self._i = 0
+        self.tot_loss, self.tot_loss_list = 0.0, 0.0
+
+    def step(self):
+        """One iteration of the loop body; returns the host float `loss.item()`."""
+        import numpy as np
+        data = self.host_batches[self._i % len(self.host_batches)]
+        self._i += 1
+        model, device = self.model, self.device
+        model.train()
+        model.zero_grad()
+        point_cloud, traj = data["point_cloud"], data["traj"]
+        traj_as_pc, stroke_ids = data["traj_as_pc"], data["stroke_ids"]
+        B = point_cloud.shape[0]
+        point_cloud = point_cloud.permute(0, 2, 1)
+        point_cloud, traj = point_cloud.to(device, dtype=torch.float), traj.to(device, dtype=torch.float)
+        traj_pred, pred_stroke_masks, mask_scores, seg_logits = model(point_cloud)
+        loss, loss_list = self.loss_handler.compute(y_pred=traj_pred, y=traj, pred_stroke_masks=pred_stroke_masks,
+                                                    mask_scores=mask_scores, seg_logits=seg_logits, stroke_ids=stroke_ids,
+                                                    traj_as_pc=traj_as_pc)
+        loss.backward()
+        self.opt.step()
+        value = loss.item()
+        self.tot_loss += value * B
+        self.tot_loss_list = self.tot_loss_list + np.asarray(loss_list) * B
+        del point_cloud, traj, traj_pred, mask_scores, seg_logits, pred_stroke_masks
+        model.zero_grad()
+        return value

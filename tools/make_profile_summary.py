@@ -51,3 +51,36 @@ for k, fz in fetch.items():
 json.dump(dict(source=f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes ({tag}), bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch",
                kernels=traffic), open(f"{out}/{tag}_traffic.json", "w"), indent=1)
 print("wrote", len(traffic), "traffic entries")
+
+# ---- MFMA utilisation of the hot grouped-MLP kernels (its own --pmc pass) ------------------------------------------------------
+import glob as _g
+mf = _g.glob(f"{go}/{tag}_mfma/*/*_counter_collection.csv")
+if mf:
+    rows = list(csv.DictReader(open(max(mf, key=os.path.getmtime))))
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in rows:
+        agg[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    dur = {short(r["Name"]): float(r["AverageNs"]) for r in stats}
+    with open(f"{out}/{tag}_mfma_util.md", "w") as f:
+        f.write(f"# {tag}: MFMA utilisation of the grouped-MLP kernels\n\n"
+                "`rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES --kernel-trace -- python3 bench.py --steps 3 "
+                "--warmup 1 --no-cpu-baseline --no-side-legs` (counters only, own pass), per-launch averages.\n\n"
+                "* `GRBM_GUI_ACTIVE` is summed over the 8 XCDs: busy shader cycles per XCD = GUI/8; held clock = GUI/8 / duration "
+                "(duration from the separate `--kernel-trace --stats` run of the same command).\n"
+                "* `SQ_VALU_MFMA_BUSY_CYCLES` is summed over the chip's 1024 SIMDs: **MFMA utilisation = BUSY / (1024 x GUI/8)**.\n"
+                "* fp32 MFMA (`v_mfma_f32_32x32x2_f32`, 2048 MACs) holds a SIMD's matrix pipe for 64 cycles, `16x16x4` (1024 MACs) for 32: "
+                "the fp32 peak of 157.3 TFLOP/s is 1024 SIMDs x 32 MAC/cycle x 2.4 GHz; at the held clock the peak scales down "
+                "with it, so `util x held/2.4` is the fraction of the nominal peak the MFMA pipe was busy for.\n\n"
+                "| kernel | launches | avg us | GUI_ACTIVE/8 (cycles) | held clock GHz | MFMA_BUSY (SIMD-cycles) | MFMA util | util x clk/2.4 |\n|---|---|---|---|---|---|---|---|\n")
+        names = sorted(agg, key=lambda n: -dur.get(n, 0.0) * len(agg[n].get("GRBM_GUI_ACTIVE", [])))
+        for n in names:
+            if not any(t in n for t in ("fused", "chunk", "gemm", "bwd_first", "dw_ci4", "rc_stats", "bf16")):
+                continue
+            c = agg[n]
+            gui = sum(c["GRBM_GUI_ACTIVE"]) / max(len(c["GRBM_GUI_ACTIVE"]), 1) / 8.0
+            busy = sum(c["SQ_VALU_MFMA_BUSY_CYCLES"]) / max(len(c["SQ_VALU_MFMA_BUSY_CYCLES"]), 1)
+            us = dur.get(n, 0.0) / 1e3
+            clk = gui / (us * 1e3) if us else 0.0
+            util = busy / (1024.0 * gui) if gui else 0.0
+            f.write(f"| `{n[:90]}` | {len(c['GRBM_GUI_ACTIVE'])} | {us:.1f} | {gui:.0f} | {clk:.2f} | {busy:.3e} | {100 * util:.1f} % | {100 * util * clk / 2.4:.1f} % |\n")
+    print("wrote mfma util")
