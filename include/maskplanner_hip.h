@@ -270,6 +270,20 @@ int mp_sa_mlp_bwd_f32(const float* x0, int64_t P, int64_t K, int n_layers, const
                       const float* grad_out, const float* out, const int32_t* argk, const float* zmax,
                       const mp_mlp_grads_t* grads, float* grad_x0, int64_t grad_x0_cols, void* workspace,
                       size_t workspace_bytes, mp_stream_t stream);
+/* The same two calls with every contraction on the bf16 matrix cores (BASELINE configs[4]: containers, N = 10240, MSG
+ * encoder, "bf16 MFMA grouped-MLP"): both operands of each GEMM -- act(Z_{l-1}) and W_l forward; dZ_l, W_l and
+ * act(Z_{l-1}) backward -- are rounded to bf16 (round-to-nearest-even) as they are staged, v_mfma_f32_32x32x16_bf16
+ * accumulates in fp32, and everything else stays fp32: stored raw activations, BatchNorm statistics and affine folding,
+ * ReLU masks, pooling, dW accumulation, all outputs.  Same arguments, workspace and layouts as the _f32 calls; layers[0].z
+ * must not be NULL (no recomputed first layer).  Reference: models/pointnet2_utils.py:208-214, 265-271 (the reference has
+ * no reduced-precision mode; this is the build's option for config 5). */
+int mp_sa_mlp_fwd_bf16(const float* x0, int64_t P, int64_t K, int n_layers, const mp_mlp_layer_t* layers, int training,
+                       double momentum, double eps, float* out, int32_t* argk, float* zmax, void* workspace,
+                       size_t workspace_bytes, mp_stream_t stream);
+int mp_sa_mlp_bwd_bf16(const float* x0, int64_t P, int64_t K, int n_layers, const mp_mlp_layer_t* layers, int training,
+                       const float* grad_out, const float* out, const int32_t* argk, const float* zmax,
+                       const mp_mlp_grads_t* grads, float* grad_x0, int64_t grad_x0_cols, void* workspace,
+                       size_t workspace_bytes, mp_stream_t stream);
 
 /* ---- fused "gradient from rank-B factors + Adam" for the head matrices (scope table row f1, "next") -----------------
  * replaces, for a Linear weight W [O, I] whose gradient is dW = g^T x (g = dLoss/dy [Bg,O], x = input [Bg,I]):

@@ -82,6 +82,10 @@ SIGNATURES = {
                                  _sz, _vp]),
     "mp_sa_mlp_bwd_f32": (_int, [_vp, _i64, _i64, _int, ctypes.POINTER(MlpLayer), _int, _vp, _vp, _vp, _vp,
                                  ctypes.POINTER(MlpGrads), _vp, _i64, _vp, _sz, _vp]),
+    "mp_sa_mlp_fwd_bf16": (_int, [_vp, _i64, _i64, _int, ctypes.POINTER(MlpLayer), _int, _dbl, _dbl, _vp, _vp, _vp, _vp,
+                                 _sz, _vp]),
+    "mp_sa_mlp_bwd_bf16": (_int, [_vp, _i64, _i64, _int, ctypes.POINTER(MlpLayer), _int, _vp, _vp, _vp, _vp,
+                                 ctypes.POINTER(MlpGrads), _vp, _i64, _vp, _sz, _vp]),
 }
 
 _lib = None

@@ -210,6 +210,68 @@ __device__ __forceinline__ void mma_chunk(const float* sA, const float* sB, int 
     }
 }
 
+// ---- bf16 operands (BASELINE configs[4]: "bf16 MFMA grouped-MLP") ------------------------------------------------------
+// The same GEMMs with both operands rounded to bf16 (round-to-nearest-even, v_cvt_pk_bf16_f32) as they are staged into LDS and
+// v_mfma_f32_32x32x16_bf16 accumulating in fp32: 16x the fp32 MFMA rate.  Everything around the contraction stays fp32: the
+// stored raw activations Z, BatchNorm / ReLU / dZ algebra (applied BEFORE the rounding, while staging), the per-column sums,
+// the pool, dW accumulation.  LDS tiles are straight images of the memory layout -- [row][k] where k is contiguous in memory
+// (fragment = one ds_read_b128 of 8 consecutive k), [k][col] where the columns are (fragment = two ds_read_b64_tr_b16
+// hardware-transposed reads of 4 k each) -- so staging is the same coalesced float4 traffic as the fp32 path.
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
+
+__device__ __forceinline__ bf16x4 to_bf16x4(const float4& v)
+{
+    bf16x4 r = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+    return r;
+}
+
+// row stride (in elements) of a [k][col] bf16 tile read with ds_read_b64_tr_b16: >= n, 8-byte aligned rows, and the four rows
+// of a transposed block land in four disjoint 16-dword bank windows (stride/2 = 16 or 48 mod 64)
+constexpr int tr_ld(int n) { return (n % 128 <= 32) ? (n / 128 * 128 + 32) : (n % 128 <= 96 ? n / 128 * 128 + 96 : n / 128 * 128 + 160); }
+
+// Fragment of a 32x32x16 MFMA operand from a [k][col] tile: lane (c = lane & 31, h = lane >> 5) gets rows k0 + 8h .. + 7 of
+// column c0 + c.  Per 16-lane group one ds_read_b64_tr_b16 takes a 4-row x 16-column block and hands lane i column i;
+// lane 4q + p supplies the address of row q, columns 4p .. 4p+3.  EXEC must be full (it is: no divergence in the main loops).
+__device__ __forceinline__ bf16x8 tr_frag(const __bf16* tile, int ld, int k0, int c0)
+{
+    const int lane = threadIdx.x & 63;
+    const int i = lane & 15, q = i >> 2, pp = i & 3, nh = (lane >> 4) & 1, h = lane >> 5;
+    const __bf16* p = tile + (k0 + 8 * h + q) * ld + c0 + 16 * nh + 4 * pp;
+    typedef __attribute__((address_space(3))) bf16x4* lds_ptr;
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_ptr)(p));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_ptr)(p + 4 * ld));
+    bf16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return r;
+}
+
+// acc += A * B over one K chunk.  A_TR / B_TR: the operand's tile is [k][row or col] (transposed reads) instead of [row][k].
+template <bool A_TR, bool B_TR, int LDA, int LDB, int TM, int TN, int KC>
+__device__ __forceinline__ void mma_chunk_bf16(const __bf16* sA, const __bf16* sB, int wrow0, int wcol0, f32x16 (&acc)[TM][TN])
+{
+    const int lane = threadIdx.x & 63;
+    const int l31 = lane & 31, hi = lane >> 5;
+#pragma unroll
+    for (int ks = 0; ks < KC; ks += 16) {
+        bf16x8 a[TM], b[TN];
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) {
+            if constexpr (A_TR) a[mi] = tr_frag(sA, LDA, ks, wrow0 + mi * 32);
+            else a[mi] = *reinterpret_cast<const bf16x8*>(sA + (wrow0 + mi * 32 + l31) * LDA + ks + 8 * hi);
+        }
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) {
+            if constexpr (B_TR) b[ni] = tr_frag(sB, LDB, ks, wcol0 + ni * 32);
+            else b[ni] = *reinterpret_cast<const bf16x8*>(sB + (wcol0 + ni * 32 + l31) * LDB + ks + 8 * hi);
+        }
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni)
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+    }
+}
+
 // accumulator register r of this lane -> row inside a 32-row MFMA tile
 __device__ __forceinline__ int acc_row_in_tile(int r) { return (r & 3) + 8 * (r >> 2) + 4 * ((threadIdx.x & 63) >> 5); }
 
@@ -235,7 +297,7 @@ struct PoolOut {
     int K;
 };
 
-template <int MODE, bool W_KROW, int EPI, int WAVES_M, int WAVES_N, int TM, int TN>
+template <int MODE, bool W_KROW, int EPI, int WAVES_M, int WAVES_N, int TM, int TN, bool BF16 = false>
 __global__ __launch_bounds__(THREADS) void pos_gemm_kernel(PosOperand A, int P, const float* __restrict__ W, int N,
                                                            int Kd, float* __restrict__ C, float* __restrict__ partials,
                                                            const float* __restrict__ zprev,
@@ -245,15 +307,17 @@ __global__ __launch_bounds__(THREADS) void pos_gemm_kernel(PosOperand A, int P, 
 {   // ldw: row stride of W in the NN form (>= N: only the first N columns are produced); ldc: row stride of C
     constexpr int BM = WAVES_M * TM * 32;
     constexpr int BN = WAVES_N * TN * 32;
-    constexpr int LDB = W_KROW ? BN : LDK;
+    using TL = std::conditional_t<BF16, __bf16, float>;           // element type of the LDS tiles
+    constexpr int LDA = BF16 ? BK + 8 : LDK;                      // bf16: 80-byte rows (16-byte aligned, conflict-free b128 reads)
+    constexpr int LDB = BF16 ? (W_KROW ? tr_ld(BN) : BK + 8) : (W_KROW ? BN : LDK);
     constexpr bool SUMS = (EPI == EPI_SQ || EPI == EPI_DY || EPI == EPI_SQ_POOL);
     __shared__ float pool_v[EPI == EPI_SQ_POOL ? 2 : 1][BM / 32][EPI == EPI_SQ_POOL ? BN : 1];
     __shared__ int pool_i[EPI == EPI_SQ_POOL ? 2 : 1][BM / 32][EPI == EPI_SQ_POOL ? BN : 1];
     constexpr int A_PASSES = BM / RPP;                // TPR threads x float4 per row, RPP rows per pass
     constexpr int B_PASSES = W_KROW ? (BK * BN / 4 / THREADS) : (BN / RPP);
     static_assert(WAVES_M * WAVES_N == 4, "4 waves");
-    __shared__ float sA[2][BM * LDK];
-    __shared__ float sB[2][W_KROW ? BK * BN : BN * LDK];
+    __shared__ __attribute__((aligned(16))) TL sA[2][BM * LDA];
+    __shared__ __attribute__((aligned(16))) TL sB[2][W_KROW ? BK * LDB : BN * LDB];
     __shared__ float red[WAVES_M][2][BN];
 
     const int tid = threadIdx.x;
@@ -296,15 +360,26 @@ __global__ __launch_bounds__(THREADS) void pos_gemm_kernel(PosOperand A, int P, 
 #pragma unroll
         for (int ps = 0; ps < A_PASSES; ++ps) {
             const float4 v = finish<MODE>(ra[ps], kc);
-            float* d = &sA[buf][(ps * RPP + arow) * LDK + acol];
-            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+            if constexpr (BF16) {
+                *reinterpret_cast<bf16x4*>(&sA[buf][(ps * RPP + arow) * LDA + acol]) = to_bf16x4(v);
+            } else {
+                float* d = &sA[buf][(ps * RPP + arow) * LDA + acol];
+                d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+            }
         }
 #pragma unroll
         for (int ps = 0; ps < B_PASSES; ++ps) {
-            if constexpr (W_KROW) {
+            if constexpr (BF16) {
+                if constexpr (W_KROW) {   // slab element e = row k, column n of the [BK][BN] slab
+                    const int e = (ps * THREADS + tid) * 4;
+                    *reinterpret_cast<bf16x4*>(&sB[buf][(e / BN) * LDB + e % BN]) = to_bf16x4(rb[ps]);
+                } else {
+                    *reinterpret_cast<bf16x4*>(&sB[buf][(ps * RPP + arow) * LDB + acol]) = to_bf16x4(rb[ps]);
+                }
+            } else if constexpr (W_KROW) {
                 *reinterpret_cast<float4*>(&sB[buf][(ps * THREADS + tid) * 4]) = rb[ps];
             } else {
-                float* d = &sB[buf][(ps * RPP + arow) * LDK + acol];
+                float* d = &sB[buf][(ps * RPP + arow) * LDB + acol];
                 d[0] = rb[ps].x; d[1] = rb[ps].y; d[2] = rb[ps].z; d[3] = rb[ps].w;
             }
         }
@@ -318,7 +393,8 @@ __global__ __launch_bounds__(THREADS) void pos_gemm_kernel(PosOperand A, int P, 
         const int cur = kc_ & 1;
         if (kc_ + 1 < nchunks) gload((kc_ + 1) * BK);
 #ifndef MP_ABLATE_MFMA
-        mma_chunk<false, W_KROW, LDK, LDB, TM, TN, BK>(sA[cur], sB[cur], wrow0, wcol0, acc);
+        if constexpr (BF16) mma_chunk_bf16<false, W_KROW, LDA, LDB, TM, TN, BK>(sA[cur], sB[cur], wrow0, wcol0, acc);
+        else mma_chunk<false, W_KROW, LDA, LDB, TM, TN, BK>(sA[cur], sB[cur], wrow0, wcol0, acc);
 #endif
         if (kc_ + 1 < nchunks) sstore(cur ^ 1);
         __syncthreads();
@@ -459,7 +535,7 @@ __global__ __launch_bounds__(256) void pool_select_kernel(PoolOut po, const floa
 // Kernel 3: dW[Co, Ci] += sum_p dZ[p, Co] * act(Zin)[p, Ci]   (split over P, fp32 atomics)
 //   both operands are positions-major slabs [BK positions][channels] -> LDS [k][row] layout, straight copies.
 // =================================================================================================================
-template <int MODE_DZ, int MODE_IN, int WAVES_M, int WAVES_N, int TM, int TN>
+template <int MODE_DZ, int MODE_IN, int WAVES_M, int WAVES_N, int TM, int TN, bool BF16 = false>
 __global__ __launch_bounds__(THREADS) void dw_gemm_kernel(PosOperand DZ, PosOperand IN, int P, int p_per_block,
                                                           float* __restrict__ dW, int ci_base, int tail_ci)
 {   // tail_ci >= 0: the 4 input channels [tail_ci, tail_ci + 4) (132 = 128 + 4, 260 = 256 + 4: the centred xyz + pad of a
@@ -472,8 +548,10 @@ __global__ __launch_bounds__(THREADS) void dw_gemm_kernel(PosOperand DZ, PosOper
     constexpr int PB = DBK * BN / 4 / THREADS;
     static_assert(WAVES_M * WAVES_N == 4 && PA >= 1 && PB >= 1, "tile");
     static_assert(BM == 128, "the tail-column path maps 256 threads onto 128 rows x 2 column pairs");
-    __shared__ float sA[2][DBK * BM];
-    __shared__ float sB[2][DBK * BN];
+    using TL = std::conditional_t<BF16, __bf16, float>;
+    constexpr int LDA = BF16 ? tr_ld(BM) : BM, LDB = BF16 ? tr_ld(BN) : BN;   // bf16: [k][row] tiles read through ds_read_b64_tr_b16
+    __shared__ __attribute__((aligned(16))) TL sA[2][DBK * LDA];
+    __shared__ __attribute__((aligned(16))) TL sB[2][DBK * LDB];
     __shared__ __attribute__((aligned(16))) float sT[2][DBK * 4];
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
@@ -514,12 +592,20 @@ __global__ __launch_bounds__(THREADS) void dw_gemm_kernel(PosOperand DZ, PosOper
     };
     auto sstore = [&](int buf) {
 #pragma unroll
-        for (int ps = 0; ps < PA; ++ps)
-            *reinterpret_cast<float4*>(&sA[buf][(ps * THREADS + tid) * 4]) = finish<MODE_DZ>(ra[ps], ka);
+        for (int ps = 0; ps < PA; ++ps) {
+            if constexpr (BF16) *reinterpret_cast<bf16x4*>(&sA[buf][(ka0 + ps * KA_STEP) * LDA + ca]) = to_bf16x4(finish<MODE_DZ>(ra[ps], ka));
+            else *reinterpret_cast<float4*>(&sA[buf][(ps * THREADS + tid) * 4]) = finish<MODE_DZ>(ra[ps], ka);
+        }
 #pragma unroll
-        for (int ps = 0; ps < PB; ++ps)
-            *reinterpret_cast<float4*>(&sB[buf][(ps * THREADS + tid) * 4]) = finish<MODE_IN>(rb[ps], kb);
-        if (do_tail && tid < DBK) *reinterpret_cast<float4*>(&sT[buf][tid * 4]) = finish<MODE_IN>(rt, kt);
+        for (int ps = 0; ps < PB; ++ps) {
+            if constexpr (BF16) *reinterpret_cast<bf16x4*>(&sB[buf][(kb0 + ps * KB_STEP) * LDB + cb]) = to_bf16x4(finish<MODE_IN>(rb[ps], kb));
+            else *reinterpret_cast<float4*>(&sB[buf][(ps * THREADS + tid) * 4]) = finish<MODE_IN>(rb[ps], kb);
+        }
+        if (do_tail && tid < DBK) {
+            float4 v = finish<MODE_IN>(rt, kt);
+            if constexpr (BF16) { const bf16x4 h = to_bf16x4(v); v = make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]); }
+            *reinterpret_cast<float4*>(&sT[buf][tid * 4]) = v;
+        }
     };
     const int nchunks = (p1 - p0 + DBK - 1) / DBK;
     if (nchunks <= 0) return;
@@ -529,13 +615,14 @@ __global__ __launch_bounds__(THREADS) void dw_gemm_kernel(PosOperand DZ, PosOper
     for (int kc = 0; kc < nchunks; ++kc) {
         const int cur = kc & 1;
         if (kc + 1 < nchunks) gload(p0 + (kc + 1) * DBK);
-        mma_chunk<true, true, BM, BN, TM, TN, DBK>(sA[cur], sB[cur], wrow0, wcol0, acc);
-        if (do_tail) {   // thread = (output channel tid & 127, column pair tid >> 7)
-            const float* a = sA[cur] + (tid & (BM - 1));
+        if constexpr (BF16) mma_chunk_bf16<true, true, LDA, LDB, TM, TN, DBK>(sA[cur], sB[cur], wrow0, wcol0, acc);
+        else mma_chunk<true, true, LDA, LDB, TM, TN, DBK>(sA[cur], sB[cur], wrow0, wcol0, acc);
+        if (do_tail) {   // thread = (output channel tid & 127, column pair tid >> 7); bf16: the rounded dZ, fp32 coordinates
+            const TL* a = sA[cur] + (tid & (BM - 1));
             const float* t = sT[cur] + 2 * (tid >> 7);
 #pragma unroll
             for (int k = 0; k < DBK; ++k) {
-                const float av = a[k * BM];
+                const float av = (float)a[k * LDA];
                 tacc0 = __builtin_fmaf(av, t[k * 4], tacc0);
                 tacc1 = __builtin_fmaf(av, t[k * 4 + 1], tacc1);
             }
@@ -1096,7 +1183,7 @@ __global__ __launch_bounds__(256) void dw_ci4_kernel(PosOperand DZ, PosOperand I
     }
 }
 
-template <int MODE_DZ, int MODE_IN>
+template <int MODE_DZ, int MODE_IN, bool BF16 = false>
 int launch_dw(const PosOperand& DZ, const PosOperand& IN, int64_t P64, float* dW, hipStream_t stream)
 {
     const int Co = DZ.C, Ci = IN.C;
@@ -1114,7 +1201,7 @@ int launch_dw(const PosOperand& DZ, const PosOperand& IN, int64_t P64, float* dW
     const unsigned gx = (unsigned)((P + ppb - 1) / ppb);
     // input-channel tiling: 128-wide tiles, a narrow remainder (132 = 128 + 4, 260 = 2*128 + 4) gets 32-wide tiles so
     // that it does not pay for a whole 128-column MFMA tile of zeros
-    if (Ci == 4 && (Co & 3) == 0 && Co <= 1024 && 256 % (Co / 4) == 0) {
+    if (!BF16 && Ci == 4 && (Co & 3) == 0 && Co <= 1024 && 256 % (Co / 4) == 0) {
         double fl = 2.0 * (double)P * Co * Ci, by = 4.0 * ((MODE_DZ == SRC_DZ ? 2.0 : 1.0) * (double)P * Co + (double)P * Ci);
         char tg[64];
         snprintf(tg, sizeof tg, "dw_ci4_kernel<%d, %d>", MODE_DZ, MODE_IN);
@@ -1131,21 +1218,22 @@ int launch_dw(const PosOperand& DZ, const PosOperand& IN, int64_t P64, float* dW
     };
     double flops, bytes;
     work(tail_ci >= 0 ? Ci : main_ci, flops, bytes);
+    const char* kn = BF16 ? "dw_gemm_bf16_kernel" : "dw_gemm_kernel";
     if (main_ci <= 32) {
-        snprintf(tag, sizeof tag, "dw_gemm_kernel<%d, %d, 4, 1, 1, 1>", MODE_DZ, MODE_IN);
-        MP_LAUNCH(tag, flops, bytes, (dw_gemm_kernel<MODE_DZ, MODE_IN, 4, 1, 1, 1>), dim3(gx, gy, (main_ci + 31) / 32), dim3(THREADS), 0, stream, DZ, IN, P, ppb, dW, 0, tail_ci);
+        snprintf(tag, sizeof tag, "%s<%d, %d, 4, 1, 1, 1>", kn, MODE_DZ, MODE_IN);
+        MP_LAUNCH(tag, flops, bytes, (dw_gemm_kernel<MODE_DZ, MODE_IN, 4, 1, 1, 1, BF16>), dim3(gx, gy, (main_ci + 31) / 32), dim3(THREADS), 0, stream, DZ, IN, P, ppb, dW, 0, tail_ci);
     } else if (main_ci <= 64) {
-        snprintf(tag, sizeof tag, "dw_gemm_kernel<%d, %d, 4, 1, 1, 2>", MODE_DZ, MODE_IN);
-        MP_LAUNCH(tag, flops, bytes, (dw_gemm_kernel<MODE_DZ, MODE_IN, 4, 1, 1, 2>), dim3(gx, gy, (main_ci + 63) / 64), dim3(THREADS), 0, stream, DZ, IN, P, ppb, dW, 0, tail_ci);
+        snprintf(tag, sizeof tag, "%s<%d, %d, 4, 1, 1, 2>", kn, MODE_DZ, MODE_IN);
+        MP_LAUNCH(tag, flops, bytes, (dw_gemm_kernel<MODE_DZ, MODE_IN, 4, 1, 1, 2, BF16>), dim3(gx, gy, (main_ci + 63) / 64), dim3(THREADS), 0, stream, DZ, IN, P, ppb, dW, 0, tail_ci);
     } else {
-        snprintf(tag, sizeof tag, "dw_gemm_kernel<%d, %d, 2, 2, 2, 2>", MODE_DZ, MODE_IN);
-        MP_LAUNCH(tag, flops, bytes, (dw_gemm_kernel<MODE_DZ, MODE_IN, 2, 2, 2, 2>), dim3(gx, gy, (main_ci + 127) / 128), dim3(THREADS), 0, stream, DZ, IN, P, ppb, dW, 0, tail_ci);
+        snprintf(tag, sizeof tag, "%s<%d, %d, 2, 2, 2, 2>", kn, MODE_DZ, MODE_IN);
+        MP_LAUNCH(tag, flops, bytes, (dw_gemm_kernel<MODE_DZ, MODE_IN, 2, 2, 2, 2, BF16>), dim3(gx, gy, (main_ci + 127) / 128), dim3(THREADS), 0, stream, DZ, IN, P, ppb, dW, 0, tail_ci);
     }
     MP_CHECK_LAUNCH();
     if (main_ci < Ci && tail_ci < 0) {
         work(Ci - main_ci, flops, bytes);
-        snprintf(tag, sizeof tag, "dw_gemm_kernel<%d, %d, 4, 1, 1, 1>", MODE_DZ, MODE_IN);
-        MP_LAUNCH(tag, flops, bytes, (dw_gemm_kernel<MODE_DZ, MODE_IN, 4, 1, 1, 1>), dim3(gx, gy, (Ci - main_ci + 31) / 32), dim3(THREADS), 0, stream, DZ, IN, P, ppb, dW, main_ci, -1);
+        snprintf(tag, sizeof tag, "%s<%d, %d, 4, 1, 1, 1>", kn, MODE_DZ, MODE_IN);
+        MP_LAUNCH(tag, flops, bytes, (dw_gemm_kernel<MODE_DZ, MODE_IN, 4, 1, 1, 1, BF16>), dim3(gx, gy, (Ci - main_ci + 31) / 32), dim3(THREADS), 0, stream, DZ, IN, P, ppb, dW, main_ci, -1);
     }
     MP_CHECK_LAUNCH();
     return MP_OK;
@@ -1309,7 +1397,7 @@ __global__ __launch_bounds__(256) void pool_bwd_prep_kernel(const float* __restr
     partials[((int64_t)blockIdx.x * 2 + 1) * C + c] = s2;
 }
 
-template <int MODE, bool W_KROW, int EPI>
+template <int MODE, bool W_KROW, int EPI, bool BF16 = false>
 int launch_pos_gemm(const PosOperand& A, int64_t P, const float* W, int N, int Kd, float* C, float* partials,
                     const float* zprev, const float* sprev, const float* tprev, hipStream_t stream, int* nblk_out,
                     PoolOut po = PoolOut{}, int ldw = 0, int ldc = 0)
@@ -1329,25 +1417,26 @@ int launch_pos_gemm(const PosOperand& A, int64_t P, const float* W, int N, int K
     if (shape == 0 && t128 < 384) shape = (t128x64 >= 384 || EPI == EPI_SQ_POOL) ? 1 : 2;
     if (shape == 1 && N > 64 && EPI != EPI_SQ_POOL && t128x64 < 384) shape = 2;
     char tag[96];
+    const char* kn = BF16 ? "pos_gemm_bf16_kernel" : "pos_gemm_kernel";
     if (shape == 1) {
         const unsigned gm = (unsigned)((P + 127) / 128);
         if (nblk_out) *nblk_out = (int)gm;
-        snprintf(tag, sizeof tag, "pos_gemm_kernel<%d, %s, %d, 4, 1, 1, 2>", MODE, W_KROW ? "true" : "false", EPI);
-        MP_LAUNCH(tag, flops, bytes, (pos_gemm_kernel<MODE, W_KROW, EPI, 4, 1, 1, 2>), dim3(gm, (N + 63) / 64),
+        snprintf(tag, sizeof tag, "%s<%d, %s, %d, 4, 1, 1, 2>", kn, MODE, W_KROW ? "true" : "false", EPI);
+        MP_LAUNCH(tag, flops, bytes, (pos_gemm_kernel<MODE, W_KROW, EPI, 4, 1, 1, 2, BF16>), dim3(gm, (N + 63) / 64),
                   dim3(THREADS), 0, stream, A, (int)P, W, N, Kd, C, partials, zprev, sprev, tprev, po, ldw, ldc);
     } else if (shape == 2) {
         if constexpr (EPI != EPI_SQ_POOL) {
             const unsigned gm = (unsigned)((P + 63) / 64);
             if (nblk_out) *nblk_out = (int)gm;
-            snprintf(tag, sizeof tag, "pos_gemm_kernel<%d, %s, %d, 2, 2, 1, 1>", MODE, W_KROW ? "true" : "false", EPI);
-            MP_LAUNCH(tag, flops, bytes, (pos_gemm_kernel<MODE, W_KROW, EPI, 2, 2, 1, 1>), dim3(gm, (N + 63) / 64),
+            snprintf(tag, sizeof tag, "%s<%d, %s, %d, 2, 2, 1, 1>", kn, MODE, W_KROW ? "true" : "false", EPI);
+            MP_LAUNCH(tag, flops, bytes, (pos_gemm_kernel<MODE, W_KROW, EPI, 2, 2, 1, 1, BF16>), dim3(gm, (N + 63) / 64),
                       dim3(THREADS), 0, stream, A, (int)P, W, N, Kd, C, partials, zprev, sprev, tprev, po, ldw, ldc);
         }
     } else {
         const unsigned gm = (unsigned)((P + 127) / 128);
         if (nblk_out) *nblk_out = (int)gm;
-        snprintf(tag, sizeof tag, "pos_gemm_kernel<%d, %s, %d, 2, 2, 2, 2>", MODE, W_KROW ? "true" : "false", EPI);
-        MP_LAUNCH(tag, flops, bytes, (pos_gemm_kernel<MODE, W_KROW, EPI, 2, 2, 2, 2>), dim3(gm, (N + 127) / 128),
+        snprintf(tag, sizeof tag, "%s<%d, %s, %d, 2, 2, 2, 2>", kn, MODE, W_KROW ? "true" : "false", EPI);
+        MP_LAUNCH(tag, flops, bytes, (pos_gemm_kernel<MODE, W_KROW, EPI, 2, 2, 2, 2, BF16>), dim3(gm, (N + 127) / 128),
                   dim3(THREADS), 0, stream, A, (int)P, W, N, Kd, C, partials, zprev, sprev, tprev, po, ldw, ldc);
     }
     MP_CHECK_LAUNCH();
@@ -1403,9 +1492,16 @@ extern "C" int mp_sa_mlp_recompute_first(int n_layers, const int64_t* channels, 
     return channels[0] == 4 && channels[1] == 64 && (channels[2] == 64 || channels[2] == 128) && K > 0;
 }
 
-extern "C" int mp_sa_mlp_fwd_f32(const float* x0, int64_t P, int64_t K, int n_layers, const mp_mlp_layer_t* layers,
-                                 int training, double momentum, double eps, float* out, int32_t* argk, float* zmax,
-                                 void* workspace, size_t workspace_bytes, mp_stream_t stream_)
+#define MP_POS_GEMM(MODE, KROW, EPI, ...) \
+    (bf16 ? launch_pos_gemm<MODE, KROW, EPI, true>(__VA_ARGS__) : launch_pos_gemm<MODE, KROW, EPI, false>(__VA_ARGS__))
+#define MP_DW_GEMM(MODE_DZ, MODE_IN, ...) \
+    (bf16 ? launch_dw<MODE_DZ, MODE_IN, true>(__VA_ARGS__) : launch_dw<MODE_DZ, MODE_IN, false>(__VA_ARGS__))
+
+// bf16 = true: every contraction runs on v_mfma_f32_32x32x16_bf16 with both operands rounded to bf16 while they are staged
+// (the generic tiled kernels; the fp32 position-stream / recompute specialisations are not used), everything else as in fp32.
+static int sa_mlp_fwd(const float* x0, int64_t P, int64_t K, int n_layers, const mp_mlp_layer_t* layers,
+                      int training, double momentum, double eps, float* out, int32_t* argk, float* zmax,
+                      void* workspace, size_t workspace_bytes, mp_stream_t stream_, bool bf16)
 {
     if (P < 0 || K <= 0 || n_layers <= 0 || !layers) return MP_EINVAL;
     if (P == 0) return MP_OK;
@@ -1425,7 +1521,7 @@ extern "C" int mp_sa_mlp_fwd_f32(const float* x0, int64_t P, int64_t K, int n_la
     if (workspace_bytes < mp_sa_mlp_workspace_bytes(P, K, n_layers, ch, 0)) return MP_EWORKSPACE;
     // layers[0].z == NULL: the caller asks for the first layer to be recomputed instead of stored (mp_sa_mlp_recompute_first)
     const bool rc_first = layers[0].z == nullptr;
-    if (rc_first && !mp_sa_mlp_recompute_first(n_layers, ch, K)) return MP_EINVAL;
+    if (rc_first && (bf16 || !mp_sa_mlp_recompute_first(n_layers, ch, K))) return MP_EINVAL;
     hipStream_t stream = mp_stream(stream_);
     float* partials = reinterpret_cast<float*>(workspace);
     // fused max-pool: group size a multiple of the 32-row MFMA tile that divides the 128-row block tile
@@ -1461,7 +1557,7 @@ extern "C" int mp_sa_mlp_fwd_f32(const float* x0, int64_t P, int64_t K, int n_la
             MP_LAUNCH("rc_stats_kernel", 8.0 * (double)P * Co_, 16.0 * (double)P, rc_stats_kernel, dim3((unsigned)nblk), dim3(256), 0, stream, x0,
                       L.weight, (int)P, ppb, partials);
             MP_CHECK_LAUNCH();
-        } else if (l == 0 && Ci_ == 132 && Co_ == 128 && !fuse_pool && chunk_fwd_enabled()) {
+        } else if (!bf16 && l == 0 && Ci_ == 132 && Co_ == 128 && !fuse_pool && chunk_fwd_enabled()) {
             // first layer of a level with a [128 features | xyz | pad] input: the position-stream kernel with the 4 extra columns
             // on the VALU (the tiled kernel pays a whole 32-wide k tile for them)
             int ppb = 1024;
@@ -1485,7 +1581,7 @@ extern "C" int mp_sa_mlp_fwd_f32(const float* x0, int64_t P, int64_t K, int n_la
                 MP_LAUNCH(tg, fl, by, (fwd_chunk_kernel<64, 128, false, SRC_ACT_RC>), dim3(gx), dim3(256), 0, stream, A, (int)P, ppb, L.weight, L.z, partials, po);
             MP_CHECK_LAUNCH();
             nblk = (int)gx;
-        } else if (l > 0 && (Ci_ == 64 || Ci_ == 128) && (Co_ == 64 || Co_ == 128 || Co_ == 256) && (P % K) == 0 && (1024 % K == 0 || !fuse_pool) &&
+        } else if (!bf16 && l > 0 && (Ci_ == 64 || Ci_ == 128) && (Co_ == 64 || Co_ == 128 || Co_ == 256) && (P % K) == 0 && (1024 % K == 0 || !fuse_pool) &&
             chunk_fwd_enabled() && !(fuse_pool && (K % 32) != 0)) {
             (void)last_unfused;
             int ppb = 1024;
@@ -1509,17 +1605,17 @@ extern "C" int mp_sa_mlp_fwd_f32(const float* x0, int64_t P, int64_t K, int n_la
             nblk = (int)gx;
         } else if (fuse_pool) {
             if (l == 0)
-                rc = launch_pos_gemm<SRC_ID, false, EPI_SQ_POOL>(A, P, L.weight, (int)L.c_out, (int)L.c_in, L.z, partials,
-                                                                 nullptr, nullptr, nullptr, stream, &nblk, po);
+                rc = MP_POS_GEMM(SRC_ID, false, EPI_SQ_POOL, A, P, L.weight, (int)L.c_out, (int)L.c_in, L.z, partials,
+                                 nullptr, nullptr, nullptr, stream, &nblk, po);
             else
-                rc = launch_pos_gemm<SRC_ACT, false, EPI_SQ_POOL>(A, P, L.weight, (int)L.c_out, (int)L.c_in, L.z, partials,
-                                                                  nullptr, nullptr, nullptr, stream, &nblk, po);
+                rc = MP_POS_GEMM(SRC_ACT, false, EPI_SQ_POOL, A, P, L.weight, (int)L.c_out, (int)L.c_in, L.z, partials,
+                                 nullptr, nullptr, nullptr, stream, &nblk, po);
         } else if (l == 0)
-            rc = launch_pos_gemm<SRC_ID, false, EPI_SQ>(A, P, L.weight, (int)L.c_out, (int)L.c_in, L.z, partials, nullptr,
-                                                        nullptr, nullptr, stream, &nblk);
+            rc = MP_POS_GEMM(SRC_ID, false, EPI_SQ, A, P, L.weight, (int)L.c_out, (int)L.c_in, L.z, partials, nullptr,
+                             nullptr, nullptr, stream, &nblk);
         else
-            rc = launch_pos_gemm<SRC_ACT, false, EPI_SQ>(A, P, L.weight, (int)L.c_out, (int)L.c_in, L.z, partials, nullptr,
-                                                         nullptr, nullptr, stream, &nblk);
+            rc = MP_POS_GEMM(SRC_ACT, false, EPI_SQ, A, P, L.weight, (int)L.c_out, (int)L.c_in, L.z, partials, nullptr,
+                             nullptr, nullptr, stream, &nblk);
         if (rc != MP_OK) return rc;
         const int C = (int)L.c_out;
         hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_SL), 0, stream, partials, nblk, C,
@@ -1550,10 +1646,24 @@ extern "C" int mp_sa_mlp_fwd_f32(const float* x0, int64_t P, int64_t K, int n_la
     return MP_OK;
 }
 
-extern "C" int mp_sa_mlp_bwd_f32(const float* x0, int64_t P, int64_t K, int n_layers, const mp_mlp_layer_t* layers,
-                                 int training, const float* grad_out, const float* out, const int32_t* argk,
-                                 const float* zmax, const mp_mlp_grads_t* grads, float* grad_x0, int64_t grad_x0_cols,
-                                 void* workspace, size_t workspace_bytes, mp_stream_t stream_)
+extern "C" int mp_sa_mlp_fwd_f32(const float* x0, int64_t P, int64_t K, int n_layers, const mp_mlp_layer_t* layers,
+                                 int training, double momentum, double eps, float* out, int32_t* argk, float* zmax,
+                                 void* workspace, size_t workspace_bytes, mp_stream_t stream)
+{
+    return sa_mlp_fwd(x0, P, K, n_layers, layers, training, momentum, eps, out, argk, zmax, workspace, workspace_bytes, stream, false);
+}
+
+extern "C" int mp_sa_mlp_fwd_bf16(const float* x0, int64_t P, int64_t K, int n_layers, const mp_mlp_layer_t* layers,
+                                  int training, double momentum, double eps, float* out, int32_t* argk, float* zmax,
+                                  void* workspace, size_t workspace_bytes, mp_stream_t stream)
+{
+    return sa_mlp_fwd(x0, P, K, n_layers, layers, training, momentum, eps, out, argk, zmax, workspace, workspace_bytes, stream, true);
+}
+
+static int sa_mlp_bwd(const float* x0, int64_t P, int64_t K, int n_layers, const mp_mlp_layer_t* layers,
+                      int training, const float* grad_out, const float* out, const int32_t* argk,
+                      const float* zmax, const mp_mlp_grads_t* grads, float* grad_x0, int64_t grad_x0_cols,
+                      void* workspace, size_t workspace_bytes, mp_stream_t stream_, bool bf16)
 {
     if (P < 0 || K <= 0 || n_layers <= 0 || !layers || !grads) return MP_EINVAL;
     if (P == 0) return MP_OK;
@@ -1571,7 +1681,7 @@ extern "C" int mp_sa_mlp_bwd_f32(const float* x0, int64_t P, int64_t K, int n_la
     if (P * cmax >= ((int64_t)1 << 31)) return MP_EUNSUPPORTED;
     if (workspace_bytes < mp_sa_mlp_workspace_bytes(P, K, n_layers, ch, 1)) return MP_EWORKSPACE;
     const bool rc_first = layers[0].z == nullptr;   // the forward pass did not store Z_0 (mp_sa_mlp_recompute_first)
-    if (rc_first && (grad_x0 || !mp_sa_mlp_recompute_first(n_layers, ch, K))) return MP_EINVAL;
+    if (rc_first && (bf16 || grad_x0 || !mp_sa_mlp_recompute_first(n_layers, ch, K))) return MP_EINVAL;
     for (int l = 1; l < n_layers; ++l)
         if (!layers[l].z) return MP_EINVAL;
     hipStream_t stream = mp_stream(stream_);
@@ -1641,7 +1751,7 @@ extern "C" int mp_sa_mlp_bwd_f32(const float* x0, int64_t P, int64_t K, int n_la
 
         // dW_l = dZ_l^T * act(Z_{l-1})
         if (!dw_joint && !mp::zero_async(grads[l].d_weight, (size_t)Co * Ci, stream)) return MP_ELAUNCH;
-        if (l > 0 && (Ci == 64 || Ci == 128) && (Co == 64 || Co == 128 || (Co == 256 && Ci == 128)) && fused_bwd_enabled()) {
+        if (!bf16 && l > 0 && (Ci == 64 || Ci == 128) && (Co == 64 || Co == 128 || (Co == 256 && Ci == 128)) && fused_bwd_enabled()) {
             // single-tile layer: dX, dW and the BatchNorm-backward sums of layer l-1 in one pass over dZ_l (bwd_fused_kernel)
             const mp_mlp_layer_t& Pv = layers[l - 1];
             float* Gn = gbuf[l & 1];
@@ -1685,7 +1795,7 @@ extern "C" int mp_sa_mlp_bwd_f32(const float* x0, int64_t P, int64_t K, int n_la
             G_cur = Gn;
             continue;
         }
-        if (l == 0 && grad_x0 && Co == 128 && Ci == 132 && grad_x0_cols == 128 && fused_bwd_enabled()) {
+        if (!bf16 && l == 0 && grad_x0 && Co == 128 && Ci == 132 && grad_x0_cols == 128 && fused_bwd_enabled()) {
             // first layer of a level with a [128 features | xyz | pad] input: dW and the feature columns of grad_x0 in one pass
             const int ppb = 1024;
             const unsigned gx = (unsigned)((P + ppb - 1) / ppb);
@@ -1708,10 +1818,10 @@ extern "C" int mp_sa_mlp_bwd_f32(const float* x0, int64_t P, int64_t K, int n_la
         }
         {
             int rc;
-            if (pooled) rc = (l == 0) ? launch_dw<SRC_DZ_POOLED, SRC_ID>(DZ, IN, P, grads[l].d_weight, stream)
-                                      : launch_dw<SRC_DZ_POOLED, SRC_ACT>(DZ, IN, P, grads[l].d_weight, stream);
-            else rc = (l == 0) ? launch_dw<SRC_DZ, SRC_ID>(DZ, IN, P, grads[l].d_weight, stream)
-                               : launch_dw<SRC_DZ, SRC_ACT>(DZ, IN, P, grads[l].d_weight, stream);
+            if (pooled) rc = (l == 0) ? MP_DW_GEMM(SRC_DZ_POOLED, SRC_ID, DZ, IN, P, grads[l].d_weight, stream)
+                                      : MP_DW_GEMM(SRC_DZ_POOLED, SRC_ACT, DZ, IN, P, grads[l].d_weight, stream);
+            else rc = (l == 0) ? MP_DW_GEMM(SRC_DZ, SRC_ID, DZ, IN, P, grads[l].d_weight, stream)
+                               : MP_DW_GEMM(SRC_DZ, SRC_ACT, DZ, IN, P, grads[l].d_weight, stream);
             if (rc != MP_OK) return rc;
         }
         // G_{l-1} = dZ_l * W_l  (+ BN-backward sums of layer l-1)
@@ -1720,9 +1830,9 @@ extern "C" int mp_sa_mlp_bwd_f32(const float* x0, int64_t P, int64_t K, int n_la
             float* Gn = gbuf[l & 1];
             int nblk = 0, rc;
             if (pooled)
-                rc = launch_pos_gemm<SRC_DZ_POOLED, true, EPI_DY>(DZ, P, Ly.weight, Ci, Co, Gn, partials, Pv.z, Pv.scale, Pv.shift, stream, &nblk);
+                rc = MP_POS_GEMM(SRC_DZ_POOLED, true, EPI_DY, DZ, P, Ly.weight, Ci, Co, Gn, partials, Pv.z, Pv.scale, Pv.shift, stream, &nblk);
             else
-                rc = launch_pos_gemm<SRC_DZ, true, EPI_DY>(DZ, P, Ly.weight, Ci, Co, Gn, partials, Pv.z, Pv.scale, Pv.shift, stream, &nblk);
+                rc = MP_POS_GEMM(SRC_DZ, true, EPI_DY, DZ, P, Ly.weight, Ci, Co, Gn, partials, Pv.z, Pv.scale, Pv.shift, stream, &nblk);
             if (rc != MP_OK) return rc;
             // the constants of layer l are still being read by the kernels above: they are stream-ordered, so
             // overwriting cbuf for layer l-1 here is safe.
@@ -1737,11 +1847,29 @@ extern "C" int mp_sa_mlp_bwd_f32(const float* x0, int64_t P, int64_t K, int n_la
             int ncols = (grad_x0_cols > 0 && grad_x0_cols < Ci) ? (int)((grad_x0_cols + 3) / 4 * 4) : Ci;
             int rc;
             if (pooled)
-                rc = launch_pos_gemm<SRC_DZ_POOLED, true, EPI_NONE>(DZ, P, Ly.weight, ncols, Co, grad_x0, nullptr, nullptr, nullptr, nullptr, stream, nullptr, PoolOut{}, Ci, Ci);
+                rc = MP_POS_GEMM(SRC_DZ_POOLED, true, EPI_NONE, DZ, P, Ly.weight, ncols, Co, grad_x0, nullptr, nullptr, nullptr, nullptr, stream, nullptr, PoolOut{}, Ci, Ci);
             else
-                rc = launch_pos_gemm<SRC_DZ, true, EPI_NONE>(DZ, P, Ly.weight, ncols, Co, grad_x0, nullptr, nullptr, nullptr, nullptr, stream, nullptr, PoolOut{}, Ci, Ci);
+                rc = MP_POS_GEMM(SRC_DZ, true, EPI_NONE, DZ, P, Ly.weight, ncols, Co, grad_x0, nullptr, nullptr, nullptr, nullptr, stream, nullptr, PoolOut{}, Ci, Ci);
             if (rc != MP_OK) return rc;
         }
     }
     return MP_OK;
+}
+
+extern "C" int mp_sa_mlp_bwd_f32(const float* x0, int64_t P, int64_t K, int n_layers, const mp_mlp_layer_t* layers,
+                                 int training, const float* grad_out, const float* out, const int32_t* argk,
+                                 const float* zmax, const mp_mlp_grads_t* grads, float* grad_x0, int64_t grad_x0_cols,
+                                 void* workspace, size_t workspace_bytes, mp_stream_t stream)
+{
+    return sa_mlp_bwd(x0, P, K, n_layers, layers, training, grad_out, out, argk, zmax, grads, grad_x0, grad_x0_cols, workspace,
+                      workspace_bytes, stream, false);
+}
+
+extern "C" int mp_sa_mlp_bwd_bf16(const float* x0, int64_t P, int64_t K, int n_layers, const mp_mlp_layer_t* layers,
+                                  int training, const float* grad_out, const float* out, const int32_t* argk,
+                                  const float* zmax, const mp_mlp_grads_t* grads, float* grad_x0, int64_t grad_x0_cols,
+                                  void* workspace, size_t workspace_bytes, mp_stream_t stream)
+{
+    return sa_mlp_bwd(x0, P, K, n_layers, layers, training, grad_out, out, argk, zmax, grads, grad_x0, grad_x0_cols, workspace,
+                      workspace_bytes, stream, true);
 }

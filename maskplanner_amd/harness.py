@@ -17,11 +17,13 @@ from .pointnet2_cls_ssg import maskplanner_model
 class TrainStep:
     def __init__(self, category="cuboids", B=32, N=5120, device="cuda", seed=1235, hidden_size=(1024, 1024), lr=1e-3,
                  dist_points="cuboid", rank=0, loss_overrides=None, prefetch_sampling=False, factor_heads=True, graph=None,
-                 overlap_sampling=None):
+                 overlap_sampling=None, encoder="ssg", mlp_dtype="f32"):
         self.cat = synthetic.CATEGORIES[category] if isinstance(category, str) else category
         self.device = torch.device(device)
         torch.manual_seed(seed)  # identical initial weights on every rank
-        self.model = maskplanner_model(self.cat, hidden_size=hidden_size).to(self.device).train()
+        # encoder "msg" + mlp_dtype "bf16": BASELINE configs[4] (containers, N = 10240, multi-radius grouping, bf16 matrix cores)
+        self.encoder, self.mlp_dtype = encoder, mlp_dtype
+        self.model = maskplanner_model(self.cat, hidden_size=hidden_size, encoder=encoder, mlp_dtype=mlp_dtype).to(self.device).train()
         self.cfg = maskplanner_loss_config(**(loss_overrides or {}))
         self.loss_handler = LossHandler(["asymm_v6_chamfer_with_stroke_masks"], self.cfg)
         fused = self.device.type == "cuda"
@@ -41,7 +43,8 @@ class TrainStep:
         # query on a second stream underneath its own work (_pipeline_sampling).
         if overlap_sampling is None:
             overlap_sampling = os.environ.get("MASKPLANNER_OVERLAP_SAMPLING", "1") != "0"
-        self.overlap = bool(overlap_sampling) and fused and not prefetch_sampling
+        # (the pipelined plan holds one ball query per level: the multi-radius encoder samples in line)
+        self.overlap = bool(overlap_sampling) and fused and not prefetch_sampling and encoder == "ssg"
         self._plan_next, self._plan_cur, self._plan_stream, self._plan_ev = None, None, None, None
         # Deferred head optimizer (see _record_split): the step is recorded as TWO graphs, encoder forward | everything else, and
         # the factor Adam of the seven head matrices (0.97 GB of HBM traffic, bandwidth-bound) is launched eagerly on its own
@@ -244,7 +247,7 @@ class TrainStep:
 
     def _plan_levels(self):
         """The sampling levels of the encoder (set abstractions that are not group_all), in order."""
-        return [m for m in (self.model.sa1, self.model.sa2, self.model.sa3) if not m.group_all]
+        return [m for m in (self.model.sa1, self.model.sa2, self.model.sa3) if not getattr(m, "group_all", False)]
 
     def _plan_size(self):
         B, n = self.batch["point_cloud"].shape[0], 0

@@ -14,7 +14,7 @@ import torch.nn.functional as F
 
 from . import ops
 from .factor_heads import factor_linear
-from .pointnet2_utils import PointNetSetAbstraction
+from .pointnet2_utils import PointNetSetAbstraction, PointNetSetAbstractionMsg
 
 
 class _SSGEncoder(nn.Module):
@@ -286,11 +286,58 @@ class PointNet2Regressor_StrokeWise(_TrunkRegressor):
         return self._poses(x, last, B), point_conf, stroke_conf
 
 
+class PointNet2Regressor_StrokeMasks_MSG(PointNet2Regressor_StrokeMasks):
+    """The MaskPlanner heads on a multi-scale-grouping encoder (BASELINE configs[4]: "MSG encoder (multi-radius ball-query)").
+    The reference ships the layer -- `PointNetSetAbstractionMsg`, models/pointnet2_utils.py:219-276 -- but no model that
+    stacks it (models/__init__.py:66-217 has no MSG backbone), so the stack follows the layer's upstream home
+    (yanx27 pointnet2_cls_msg): 512 centroids x radii (.1, .2, .4) x (16, 32, 128) neighbours -> 320 channels, 128 centroids x
+    (.2, .4, .8) x (32, 64, 128) -> 640 channels, then the reference's group_all level (643 -> 256 -> 512 -> 1024).  Heads,
+    outputs and head state_dict keys are PointNet2Regressor_StrokeMasks'."""
+    MSG1 = dict(npoint=512, radius_list=[0.1, 0.2, 0.4], nsample_list=[16, 32, 128],
+                mlp_list=[[32, 32, 64], [64, 64, 128], [64, 96, 128]])
+    MSG2 = dict(npoint=128, radius_list=[0.2, 0.4, 0.8], nsample_list=[32, 64, 128],
+                mlp_list=[[64, 64, 128], [128, 128, 256], [128, 128, 256]])
+
+    def _build_encoder(self, normal_channel, inputdim):
+        if normal_channel or inputdim not in (None, 3):
+            raise NotImplementedError("the MSG encoder of this build takes bare coordinates")
+        self.normal_channel = False
+        self.sa1 = PointNetSetAbstractionMsg(in_channel=0, **self.MSG1)
+        self.sa2 = PointNetSetAbstractionMsg(in_channel=320, **self.MSG2)
+        self.sa3 = PointNetSetAbstraction(npoint=None, radius=None, nsample=None, in_channel=640 + 3,
+                                          mlp=[256, 512, 1024], group_all=True)
+
+    def encode(self, xyz):
+        B = xyz.shape[0]
+        l1_xyz, l1_points = self.sa1(xyz, None)
+        l2_xyz, l2_points = self.sa2(l1_xyz, l1_points)
+        _, l3_points = self.sa3(l2_xyz, l2_points)
+        return l3_points.reshape(B, 1024)
+
+
+def set_mlp_dtype(model, dtype):
+    """Operand type ("f32" | "bf16") of the grouped-MLP contractions of every set-abstraction level of `model`."""
+    if dtype not in ("f32", "bf16"):
+        raise ValueError("dtype must be 'f32' or 'bf16'")
+    for m in model.modules():
+        if isinstance(m, (PointNetSetAbstraction, PointNetSetAbstractionMsg)):
+            m.mlp_dtype = dtype
+    return model
+
+
 def maskplanner_model(category, lambda_points=4, overlapping=1, outdim=6, orient_outdim=3, weight_orient=0.25,
-                      hidden_size=(1024, 1024)):
+                      hidden_size=(1024, 1024), encoder="ssg", mlp_dtype="f32"):
     """The model `get_model(config, which='pointnet2_strokemasks', io_type='MaskPlanner')` builds
-    (models/__init__.py:111-122, 295-318) for a synthetic.Category."""
-    return PointNet2Regressor_StrokeMasks(
+    (models/__init__.py:111-122, 295-318) for a synthetic.Category.  encoder="msg": the same heads on the multi-scale
+    encoder (PointNet2Regressor_StrokeMasks_MSG); mlp_dtype: see set_mlp_dtype."""
+    if encoder not in ("ssg", "msg"):
+        raise ValueError("encoder must be 'ssg' or 'msg'")
+    cls = PointNet2Regressor_StrokeMasks if encoder == "ssg" else PointNet2Regressor_StrokeMasks_MSG
+    return set_mlp_dtype(_build_maskplanner(cls, category, lambda_points, outdim, orient_outdim, weight_orient, hidden_size), mlp_dtype)
+
+
+def _build_maskplanner(cls, category, lambda_points, outdim, orient_outdim, weight_orient, hidden_size):
+    return cls(
         out_vectors=category.out_vectors, outdim=(outdim - orient_outdim) * lambda_points,
         outdim_orient=orient_outdim * lambda_points, weight_orient=weight_orient, hidden_size=hidden_size,
         pred_stroke_masks=True, n_stroke_masks=category.max_n_strokes, mask_confidence_scores=True,

@@ -22,7 +22,7 @@ class _SharedMLPMax(torch.autograd.Function):
     weight[Co,Ci], bias|None, gamma, beta, running_mean|None, running_var|None."""
 
     @staticmethod
-    def forward(ctx, x, K, training, momentum, eps, n_layers, grad_cols, *params):
+    def forward(ctx, x, K, training, momentum, eps, n_layers, grad_cols, bf16, *params):
         dev = x.device
         P, C0 = x.shape
         layers = (_lib.MlpLayer * n_layers)()
@@ -32,7 +32,7 @@ class _SharedMLPMax(torch.autograd.Function):
         ch = (ctypes.c_int64 * len(chans))(*chans)
         # first layer of a level fed by bare coordinates (4 input channels): Z_0 is recomputed by its consumers instead of being
         # written once and read three times (sa_mlp.hip, SRC_*_RC) -- no buffer for it at all
-        recompute_first = (not x.requires_grad) and bool(lib.mp_sa_mlp_recompute_first(n_layers, ch, K))
+        recompute_first = (not bf16) and (not x.requires_grad) and bool(lib.mp_sa_mlp_recompute_first(n_layers, ch, K))
         for l in range(n_layers):
             w, b, gam, bet, rm, rv = params[6 * l:6 * l + 6]
             co, ci = w.shape
@@ -47,9 +47,9 @@ class _SharedMLPMax(torch.autograd.Function):
         argk = torch.empty((G, cl), dtype=torch.int32, device=dev)
         zmax = torch.empty((G, cl), dtype=torch.float32, device=dev)
         ws = torch.empty((lib.mp_sa_mlp_workspace_bytes(P, K, n_layers, ch, 0),), dtype=torch.uint8, device=dev)
-        ops._run("sa_mlp_fwd", x, lib.mp_sa_mlp_fwd_f32, _ptr(x), P, K, n_layers, layers, int(training), float(momentum),
+        ops._run("sa_mlp_fwd", x, lib.mp_sa_mlp_fwd_bf16 if bf16 else lib.mp_sa_mlp_fwd_f32, _ptr(x), P, K, n_layers, layers, int(training), float(momentum),
                  float(eps), _ptr(out), _ptr(argk), _ptr(zmax), _ptr(ws), ws.numel())
-        ctx.meta = (P, K, bool(training), n_layers, chans, int(grad_cols))
+        ctx.meta = (P, K, bool(training), n_layers, chans, int(grad_cols), bool(bf16))
         ctx.keep = keep
         ctx.save_for_backward(x, out, argk, zmax)
         ctx.mark_non_differentiable(argk, zmax)
@@ -58,7 +58,7 @@ class _SharedMLPMax(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out):
         x, out, argk, zmax = ctx.saved_tensors
-        P, K, training, n_layers, chans, grad_cols = ctx.meta
+        P, K, training, n_layers, chans, grad_cols, bf16 = ctx.meta
         dev = x.device
         grad_out = grad_out.contiguous().float()
         layers = (_lib.MlpLayer * n_layers)()
@@ -88,10 +88,10 @@ class _SharedMLPMax(torch.autograd.Function):
         ch = (ctypes.c_int64 * len(chans))(*chans)
         lib = _lib.load()
         ws = torch.empty((lib.mp_sa_mlp_workspace_bytes(P, K, n_layers, ch, 1),), dtype=torch.uint8, device=dev)
-        ops._run("sa_mlp_bwd", x, lib.mp_sa_mlp_bwd_f32, _ptr(x), P, K, n_layers, layers, int(training), _ptr(grad_out),
+        ops._run("sa_mlp_bwd", x, lib.mp_sa_mlp_bwd_bf16 if bf16 else lib.mp_sa_mlp_bwd_f32, _ptr(x), P, K, n_layers, layers, int(training), _ptr(grad_out),
                  _ptr(out), _ptr(argk), _ptr(zmax), grads, _ptr(gx), grad_cols, _ptr(ws), ws.numel())
         ctx.keep = None
-        return (gx, None, None, None, None, None, None, *ret)
+        return (gx, None, None, None, None, None, None, None, *ret)
 
 
 class _PermuteCols(torch.autograd.Function):
@@ -132,7 +132,7 @@ def _first_weight_perm(cin, cpad, rotate, device):
     return _PERMS[key]
 
 
-def shared_mlp_max(grouped, convs, bns, layout="xyz_first"):
+def shared_mlp_max(grouped, convs, bns, layout="xyz_first", dtype="f32"):
     """grouped [B,S,K,C (+ zero padding up to a multiple of 4)] -> [B,S,Cout] = max_K relu(bn(conv(.))) chained over the
     layers (fused HIP path).
 
@@ -142,7 +142,11 @@ def shared_mlp_max(grouped, convs, bns, layout="xyz_first"):
                       produce internally.  The first weight's columns are rotated to match, and backward computes the
                       input gradient of the feature columns only (coordinates carry no gradient on this path), which
                       drops the near-empty second 128-column tile of a 131-channel input.
-    The kernels work on float4 channel groups: an input with C % 4 != 0 is zero-padded here."""
+    The kernels work on float4 channel groups: an input with C % 4 != 0 is zero-padded here.
+    dtype "bf16": the contractions run on the bf16 matrix cores (operands rounded to bf16 as they are staged, fp32 accumulation;
+    stored activations, BatchNorm, pooling and all outputs stay fp32) -- mp_sa_mlp_{fwd,bwd}_bf16."""
+    if dtype not in ("f32", "bf16"):
+        raise ValueError("dtype must be 'f32' or 'bf16'")
     import torch.nn.functional as F
     ops._need_hip(grouped)
     B, S, K, C = grouped.shape
@@ -179,5 +183,5 @@ def shared_mlp_max(grouped, convs, bns, layout="xyz_first"):
     bn0 = bns[0]
     momentum = bn0.momentum if bn0.momentum is not None else 1.0 / max(float(bn0.num_batches_tracked), 1.0)
     grad_cols = cin - 3 if (layout == "feats_first" and cin > 3) else 0
-    out = _SharedMLPMax.apply(x, K, training, momentum, bn0.eps, len(convs), grad_cols, *params)
+    out = _SharedMLPMax.apply(x, K, training, momentum, bn0.eps, len(convs), grad_cols, dtype == "bf16", *params)
     return out.view(B, S, -1)

@@ -41,11 +41,36 @@ def _bn_eval(z, gamma, beta, rm, rv):
     return (z - rm) / torch.sqrt(rv + BN_EPS) * gamma + beta
 
 
-def shared_mlp_max(x, layers, train):
+def _r16(t):
+    """Round to bf16 (nearest even) and back: the value a bf16 matrix-core operand carries."""
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+class _Bf16Matmul(torch.autograd.Function):
+    """a [..., Ci] x w [Co, Ci] -> [..., Co] as the bf16 grouped-MLP variant defines it (mp_sa_mlp_*_bf16): BOTH operands of
+    every contraction rounded to bf16, products and sums in fp32 (a product of two bf16 values is exact in fp32) --
+    forward a.w^T, backward g.w (input gradient) and g^T.a (weight gradient), each with its two operands rounded."""
+
+    @staticmethod
+    def forward(ctx, a, w):
+        ctx.save_for_backward(a, w)
+        return _r16(a) @ _r16(w).t()
+
+    @staticmethod
+    def backward(ctx, g):
+        a, w = ctx.saved_tensors
+        g16 = _r16(g)
+        ga = g16 @ _r16(w)
+        gw = g16.reshape(-1, g16.shape[-1]).t() @ _r16(a).reshape(-1, a.shape[-1])
+        return ga, gw
+
+
+def shared_mlp_max(x, layers, train, bf16=False):
     """x [B,S,K,Cin] -> [B,S,Cout]: (1x1 conv, BN, ReLU) x len(layers), then max over K.
-    layers: list of dict(weight[Co,Ci], bias[Co], gamma, beta, running_mean, running_var)."""
+    layers: list of dict(weight[Co,Ci], bias[Co], gamma, beta, running_mean, running_var).
+    bf16: the contraction of every layer with bf16-rounded operands (_Bf16Matmul); everything else fp32."""
     for L in layers:
-        z = x @ L["weight"].t() + L["bias"]
+        z = (_Bf16Matmul.apply(x, L["weight"]) if bf16 else x @ L["weight"].t()) + L["bias"]
         if train:
             z = _bn_train(z, L["gamma"], L["beta"], (L["running_mean"], L["running_var"]))
         else:
@@ -68,12 +93,12 @@ def layers_from_state(sd, prefix, convs="mlp_convs", bns="mlp_bns"):
     return out
 
 
-def set_abstraction(xyz, feats, layers, npoint, radius, nsample, fps_start, train, group_all=False):
+def set_abstraction(xyz, feats, layers, npoint, radius, nsample, fps_start, train, group_all=False, bf16=False):
     """xyz [B,N,3], feats [B,N,D] or None (points-major).  Returns new_xyz [B,S,3], new_feats [B,S,C']."""
     B, N, _ = xyz.shape
     if group_all:  # sample_and_group_all :151-168 -- xyz NOT centred, new_xyz = 0
         x = xyz if feats is None else torch.cat([xyz, feats], -1)
-        return torch.zeros(B, 1, 3), shared_mlp_max(x[:, None], layers, train)
+        return torch.zeros(B, 1, 3), shared_mlp_max(x[:, None], layers, train, bf16)
     xyz_np = xyz.detach().numpy()
     fidx = O.fps(xyz_np, npoint, fps_start)
     new_xyz_np = O.index_points(xyz_np, fidx)
@@ -83,10 +108,10 @@ def set_abstraction(xyz, feats, layers, npoint, radius, nsample, fps_start, trai
     g = xyz[bidx, gidx] - new_xyz[:, :, None]
     if feats is not None:
         g = torch.cat([g, feats[bidx, gidx]], -1)  # xyz channels first (:138)
-    return new_xyz, shared_mlp_max(g, layers, train)
+    return new_xyz, shared_mlp_max(g, layers, train, bf16)
 
 
-def set_abstraction_msg(xyz, feats, blocks, npoint, radii, nsamples, fps_start, train):
+def set_abstraction_msg(xyz, feats, blocks, npoint, radii, nsamples, fps_start, train, bf16=False):
     """PointNetSetAbstractionMsg (:219-276): one FPS, per-radius ball query; channel order FEATS first, xyz last."""
     B = xyz.shape[0]
     xyz_np = xyz.detach().numpy()
@@ -100,7 +125,7 @@ def set_abstraction_msg(xyz, feats, blocks, npoint, radii, nsamples, fps_start, 
         g = xyz[bidx, gidx] - new_xyz[:, :, None]
         if feats is not None:
             g = torch.cat([feats[bidx, gidx], g], -1)
-        outs.append(shared_mlp_max(g, layers, train))
+        outs.append(shared_mlp_max(g, layers, train, bf16))
     return new_xyz, torch.cat(outs, -1)
 
 
@@ -114,14 +139,42 @@ def _bn1d(x, sd, name, train):
     return _bn_eval(x, g, b, sd[name + ".running_mean"], sd[name + ".running_var"])
 
 
-def strokemasks_forward(sd, xyz, fps_starts, train, out_vectors, n_masks, weight_orient=0.25, dropout_masks=None):
-    """sd: reference-layout state_dict of tensors; xyz [B,N,3].  dropout_masks: optional list of 4
-    pre-scaled keep masks (train mode) so dropout is reproducible; None = no dropout."""
+def msg_blocks_from_state(sd, prefix):
+    """The per-scale layer lists of a PointNetSetAbstractionMsg (state_dict keys conv_blocks.{i}.{j}.*, bn_blocks.{i}.{j}.*)."""
+    out = []
+    i = 0
+    while f"{prefix}conv_blocks.{i}.0.weight" in sd:
+        out.append(layers_from_state(sd, prefix, convs=f"conv_blocks.{i}", bns=f"bn_blocks.{i}"))
+        i += 1
+    return out
+
+
+# the multi-scale encoder of pointnet2_cls_ssg.PointNet2Regressor_StrokeMasks_MSG (upstream pointnet2_cls_msg widths)
+MSG_LEVELS = ((512, (0.1, 0.2, 0.4), (16, 32, 128)), (128, (0.2, 0.4, 0.8), (32, 64, 128)))
+
+
+def encoder_forward(sd, xyz, fps_starts, train, encoder="ssg", bf16=False):
+    """xyz [B,N,3] -> global feature [B,1024]: sa1 -> sa2 -> sa3 of the SSG (models/pointnet2_cls_ssg.py:266-268, 299-307) or
+    the multi-scale encoder; bf16: the grouped-MLP contractions with bf16-rounded operands."""
     B = xyz.shape[0]
-    l1_xyz, l1 = set_abstraction(xyz, None, layers_from_state(sd, "sa1."), 512, 0.2, 32, fps_starts[0], train)
-    l2_xyz, l2 = set_abstraction(l1_xyz, l1, layers_from_state(sd, "sa2."), 128, 0.4, 64, fps_starts[1], train)
-    _, l3 = set_abstraction(l2_xyz, l2, layers_from_state(sd, "sa3."), None, None, None, None, train, group_all=True)
-    feat = l3.reshape(B, -1)
+    if encoder == "msg":
+        (n1, r1, k1), (n2, r2, k2) = MSG_LEVELS
+        l1_xyz, l1 = set_abstraction_msg(xyz, None, msg_blocks_from_state(sd, "sa1."), n1, r1, k1, fps_starts[0], train, bf16)
+        l2_xyz, l2 = set_abstraction_msg(l1_xyz, l1, msg_blocks_from_state(sd, "sa2."), n2, r2, k2, fps_starts[1], train, bf16)
+    else:
+        l1_xyz, l1 = set_abstraction(xyz, None, layers_from_state(sd, "sa1."), 512, 0.2, 32, fps_starts[0], train, bf16=bf16)
+        l2_xyz, l2 = set_abstraction(l1_xyz, l1, layers_from_state(sd, "sa2."), 128, 0.4, 64, fps_starts[1], train, bf16=bf16)
+    _, l3 = set_abstraction(l2_xyz, l2, layers_from_state(sd, "sa3."), None, None, None, None, train, group_all=True, bf16=bf16)
+    return l3.reshape(B, -1)
+
+
+def strokemasks_forward(sd, xyz, fps_starts, train, out_vectors, n_masks, weight_orient=0.25, dropout_masks=None,
+                        encoder="ssg", bf16=False):
+    """sd: reference-layout state_dict of tensors; xyz [B,N,3].  dropout_masks: optional list of 4
+    pre-scaled keep masks (train mode) so dropout is reproducible; None = no dropout.
+    encoder "msg": two multi-scale levels + group_all; bf16: the grouped-MLP contractions with bf16-rounded operands."""
+    B = xyz.shape[0]
+    feat = encoder_forward(sd, xyz, fps_starts, train, encoder, bf16)
     dm = dropout_masks or [1.0, 1.0, 1.0, 1.0]
     x = torch.relu(_bn1d(feat @ sd["fc1.weight"].t() + sd["fc1.bias"], sd, "bn1", train)) * dm[0]
     final = torch.relu(_bn1d(x @ sd["fc2.weight"].t() + sd["fc2.bias"], sd, "bn2", train)) * dm[1]

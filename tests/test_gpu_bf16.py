@@ -1,0 +1,221 @@
+"""The bf16 matrix-core variant of the grouped MLP (mp_sa_mlp_{fwd,bwd}_bf16) and the multi-scale encoder of BASELINE
+configs[4] (containers, N = 10240, MSG, bf16).
+
+Contract of the variant: both operands of every contraction are rounded to bf16 (nearest even) as they are staged, products and
+sums are fp32, everything else (stored activations, BatchNorm, ReLU, pooling, dW accumulation) is fp32.  Checks:
+
+  * layer by layer, on the kernel's OWN stored activations: Z_l == bf16(act(Z_{l-1})) . bf16(W_l)^T recomputed in fp32 torch
+    from the bit-identical rounded operands  =>  1e-5 holds element-wise (accumulation order is the only difference);
+  * the chain end to end against the CPU oracle with pre-rounded operands (oracle/torch_ref.py: _Bf16Matmul).  Element-wise
+    1e-5 cannot hold there: the two sides evaluate BatchNorm with differently rounded fp32 expressions, and an activation that
+    lands within ~1e-7 of a bf16 rounding boundary is rounded the other way (one bf16 ulp = 2^-7 relative) in ~3e-5 of the
+    operand elements.  The test therefore bounds the relative L2 error and the share of outlying elements, and holds the
+    reductions over all positions (BatchNorm statistics, dW, dgamma, dbeta) to the fp32 path's tolerances;
+  * against the fp32 path: same result up to bf16 operand precision.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+
+
+def r16(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def rel_l2(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def outlier_share(a, b, tol):
+    a, b = a.detach().cpu(), b.detach().cpu()
+    return float(((a - b).abs() > tol * b.abs().max().clamp_min(1.0)).float().mean())
+
+
+def _chain(cin, widths, seed):
+    torch.manual_seed(seed)
+    convs = torch.nn.ModuleList()
+    bns = torch.nn.ModuleList()
+    last = cin
+    for w in widths:
+        convs.append(torch.nn.Conv2d(last, w, 1))
+        bns.append(torch.nn.BatchNorm2d(w))
+        last = w
+    for bn in bns:                       # non-trivial affine parameters, some negative scales (pool takes the group minimum then)
+        bn.weight.data.uniform_(-0.5, 1.5)
+        bn.bias.data.uniform_(-0.3, 0.3)
+    return convs, bns
+
+
+def _layers(convs, bns):
+    return [dict(weight=c.weight.detach().cpu().reshape(c.out_channels, c.in_channels).clone().requires_grad_(True),
+                 bias=c.bias.detach().cpu().clone(), gamma=b.weight.detach().cpu().clone().requires_grad_(True),
+                 beta=b.bias.detach().cpu().clone().requires_grad_(True), running_mean=torch.zeros(c.out_channels),
+                 running_var=torch.ones(c.out_channels)) for c, b in zip(convs, bns)]
+
+
+CASES = [
+    # (B, S, K, Cin, widths): SSG sa1 / sa2 shapes, MSG widths (32, 96), K = 16 (unfused pool), group_all, a ragged tail
+    (2, 64, 32, 3, [64, 64, 128]),
+    (2, 32, 64, 131, [128, 128, 256]),
+    (2, 48, 16, 3, [32, 32, 64]),
+    (2, 16, 128, 3, [64, 96, 128]),
+    (2, 24, 32, 323, [64, 64, 128]),
+    (3, 1, 100, 643, [256, 512, 1024]),
+]
+
+
+@pytest.mark.parametrize("B,S,K,cin,widths", CASES)
+def test_bf16_layers_are_exact_products_of_the_rounded_operands(B, S, K, cin, widths):
+    from maskplanner_amd import sa_mlp
+    convs, bns = _chain(cin, widths, seed=cin + K)
+    convs.cuda(), bns.cuda().train()
+    g = torch.Generator().manual_seed(K)
+    x = (torch.randn(B, S, K, cin, generator=g) * 0.2).cuda()
+    out = sa_mlp.shared_mlp_max(x, convs, bns, dtype="bf16")
+    keep = out.grad_fn.next_functions[0][0].keep                      # per layer: (w, b, gamma, beta, rm, rv, z, stats[mean, rstd, scale, shift])
+    a = torch.nn.functional.pad(x.reshape(-1, cin), (0, (-cin) % 4))
+    for l, (w, b, gam, bet, rm, rv, z, stats) in enumerate(keep):
+        assert z is not None
+        want = r16(a) @ r16(w.detach().reshape(w.shape[0], -1)).t()          # fp32 sums of exact products
+        err = float((z - want).abs().max())
+        assert err <= 1e-5 * max(1.0, float(want.abs().max())), (l, err)
+        # BatchNorm folding of THIS layer, as the kernels apply it while staging: relu(z * scale + shift), mul and add rounded
+        # separately -- bit-identical to what the next contraction rounded
+        a = torch.relu(z * stats[2] + stats[3])
+    pooled = a.view(B * S, K, -1).max(dim=1)[0].view(B, S, -1)
+    assert torch.equal(out, pooled)
+
+
+@pytest.mark.parametrize("B,S,K,cin,widths", CASES[:5])
+def test_bf16_chain_forward_backward_vs_prerounded_oracle(B, S, K, cin, widths):
+    from maskplanner_amd import sa_mlp
+    from oracle import torch_ref as T
+    convs, bns = _chain(cin, widths, seed=7 * cin + K)
+    layers = _layers(convs, bns)
+    convs.cuda(), bns.cuda().train()
+    g = torch.Generator().manual_seed(K + 1)
+    x = torch.randn(B, S, K, cin, generator=g) * 0.2
+    gout = torch.randn(B, S, widths[-1], generator=g)
+    xd = x.cuda().requires_grad_(cin > 4)
+    out = sa_mlp.shared_mlp_max(xd, convs, bns, dtype="bf16")
+    (out * gout.cuda()).sum().backward()
+    xo = x.clone().requires_grad_(cin > 4)
+    ref = T.shared_mlp_max(xo, layers, True, bf16=True)
+    (ref * gout).sum().backward()
+    assert rel_l2(out, ref) < 2e-4 and outlier_share(out, ref, 1e-4) < 5e-3, (rel_l2(out, ref), outlier_share(out, ref, 1e-4))
+    for i, (c, bn, L) in enumerate(zip(convs, bns, layers)):
+        # reductions over all positions: single flipped roundings average out
+        dw = c.weight.grad.reshape(c.out_channels, -1)
+        assert rel_l2(dw, L["weight"].grad) < 1e-3, (i, rel_l2(dw, L["weight"].grad))
+        assert rel_l2(bn.weight.grad, L["gamma"].grad) < 1e-3 and rel_l2(bn.bias.grad, L["beta"].grad) < 1e-3, i
+        np.testing.assert_allclose(bn.running_mean.cpu().numpy(), L["running_mean"].numpy(), rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(bn.running_var.cpu().numpy(), L["running_var"].numpy(), rtol=1e-4, atol=1e-5)
+    if cin > 4:
+        assert rel_l2(xd.grad, xo.grad) < 5e-4 and outlier_share(xd.grad, xo.grad, 2e-3) < 5e-3
+
+
+@pytest.mark.parametrize("B,S,K,cin,widths", [CASES[0], CASES[1], CASES[3]])
+@pytest.mark.parametrize("train", [True, False])
+def test_bf16_tracks_the_fp32_path(B, S, K, cin, widths, train):
+    from maskplanner_amd import sa_mlp
+    convs, bns = _chain(cin, widths, seed=3 * cin)
+    convs.cuda(), bns.cuda().train(train)
+    g = torch.Generator().manual_seed(2)
+    x = (torch.randn(B, S, K, cin, generator=g) * 0.2).cuda()
+    res = {}
+    for dt in ("f32", "bf16"):
+        for p in list(convs.parameters()) + list(bns.parameters()):
+            p.grad = None
+        out = sa_mlp.shared_mlp_max(x, convs, bns, dtype=dt)
+        out.square().sum().backward()
+        res[dt] = (out.detach().clone(), [c.weight.grad.clone() for c in convs])
+    assert rel_l2(res["bf16"][0], res["f32"][0]) < 2e-2
+    for a, b in zip(res["bf16"][1], res["f32"][1]):
+        # the weight gradient in front of a BatchNorm is a sum of cancelling terms: bf16 operand noise (2^-9 per element) shows
+        # up amplified; direction and size must still agree
+        cos = float(torch.dot(a.flatten(), b.flatten()) / (a.norm() * b.norm()))
+        assert cos > 0.98 and 0.9 < float(a.norm() / b.norm()) < 1.1, (cos, float(a.norm() / b.norm()))
+
+
+def test_msg_model_bf16_forward_loss_backward_vs_oracle(oracle):
+    """BASELINE configs[4] shapes on two clouds: containers (S = 1333, M = 33), N = 10240, MSG encoder, bf16 grouped MLP,
+    against the CPU restatement (the same FPS / ball-query indices by construction; bf16-rounded contractions in the encoder).
+    Predictions and loss of the whole model; gradients of the ENCODER under a fixed linear functional of its output -- behind
+    the loss the nearest-neighbour matching turns a 1e-5 difference of the predictions into a different gradient for a few
+    segments, which says nothing about the kernels under test."""
+    from maskplanner_amd import pointnet2_utils as pu, synthetic
+    from maskplanner_amd.loss_handler import LossHandler, maskplanner_loss_config
+    from maskplanner_amd.pointnet2_cls_ssg import maskplanner_model
+    from oracle import torch_ref as T
+    cat = synthetic.CATEGORIES["containers"]
+    B, N = 2, 10240
+    torch.manual_seed(3)
+    model = maskplanner_model(cat, hidden_size=(256, 256), encoder="msg", mlp_dtype="bf16")
+    model.dropout.p = 0.0
+    sd = {k: v.detach().clone().requires_grad_(v.dtype.is_floating_point and "running" not in k) for k, v in model.state_dict().items()}
+    batch = synthetic.make_batch(11, B, N, "containers", "cuboid")
+    starts = [s.numpy() for s in batch["fps_start"]]
+    cfg = maskplanner_loss_config()
+    # (a) eval mode end to end (BatchNorm1d of the heads over 2 samples would amplify rounding noise in train mode)
+    model.cuda().eval()
+    with pu.fps_start_override([s.cuda() for s in batch["fps_start"]]), torch.no_grad():
+        out, sm, conf, _ = model(batch["point_cloud"].cuda().permute(0, 2, 1))
+        loss = LossHandler(["asymm_v6_chamfer_with_stroke_masks"], cfg).compute(
+            return_list=False, y_pred=out, y=batch["traj"].cuda(), pred_stroke_masks=sm, mask_scores=conf, seg_logits=None,
+            stroke_ids=batch["stroke_ids"], traj_as_pc=batch["traj_as_pc"])
+    with torch.no_grad():
+        o_out, o_sm, o_conf = T.strokemasks_forward(sd, batch["point_cloud"], starts, train=False, out_vectors=cat.out_vectors,
+                                                    n_masks=cat.max_n_strokes, encoder="msg", bf16=True)
+        o_loss = T.asymm_v6_loss(o_out, batch["traj"], o_sm, o_conf, batch["stroke_ids"], batch["traj_as_pc"], cfg)
+    assert rel_l2(out, o_out) < 2e-4 and rel_l2(sm, o_sm) < 2e-4, (rel_l2(out, o_out), rel_l2(sm, o_sm))
+    assert abs(float(loss) - float(o_loss)) <= 2e-4 * abs(float(o_loss)), (float(loss), float(o_loss))
+    # (b) the encoder's gradients under a fixed linear functional of the global feature, eval-mode BatchNorm.  A gradient
+    # through max-pools is discontinuous in the forward values: where the two largest of K = 16..128 group members are closer
+    # than the forward difference of the two implementations the gradient takes another route, so its error goes with the
+    # square root of the forward noise (fp32 pair: forward 2e-7, gradients ~1e-3; bf16 pair: 2e-4 and ~5e-2, measured).
+    # Direction and size are what can be compared; element-wise parity of the backward is test_bf16_chain_*'s job.
+    w = torch.randn(B, 1024, generator=torch.Generator().manual_seed(1))
+    with pu.fps_start_override([s.cuda() for s in batch["fps_start"]]):
+        feat = model.encode(batch["point_cloud"].cuda().permute(0, 2, 1))
+    (feat * w.cuda()).sum().backward()
+    o_feat = T.encoder_forward(sd, batch["point_cloud"], starts, False, "msg", True)
+    (o_feat * w).sum().backward()
+    assert rel_l2(feat, o_feat) < 2e-3, rel_l2(feat, o_feat)
+    for name, p in model.named_parameters():
+        gref = sd[name].grad
+        if gref is None or p.grad is None or float(gref.norm()) < 1e-3:
+            continue
+        a, b = p.grad.detach().cpu().flatten().double(), gref.flatten().double()
+        cos = float(torch.dot(a, b) / (a.norm() * b.norm()))
+        assert cos > 0.98 and 0.9 < float(a.norm() / b.norm()) < 1.1, (name, cos, float(a.norm() / b.norm()))
+    # (c) train-mode forward (batch statistics over 2 x 512 x K positions per layer, 256 rows in the group-all level)
+    model.train()
+    with pu.fps_start_override([s.cuda() for s in batch["fps_start"]]), torch.no_grad():
+        feat = model.encode(batch["point_cloud"].cuda().permute(0, 2, 1))
+    with torch.no_grad():
+        o_feat = T.encoder_forward(sd, batch["point_cloud"], starts, True, "msg", True)
+    assert rel_l2(feat, o_feat) < 2e-2, rel_l2(feat, o_feat)
+
+
+def test_config5_training_step_runs_and_learns():
+    """containers, N = 10240, B = 8, MSG encoder + bf16 grouped MLP through harness.TrainStep (graph replay included): finite
+    parameters, loss going down, and the fp32 run of the same configuration stays within bf16 distance for the first step."""
+    from maskplanner_amd.harness import TrainStep
+    ts = TrainStep("containers", B=8, N=10240, seed=5, encoder="msg", mlp_dtype="bf16")
+    losses = [float(ts.step()) for _ in range(12)]
+    assert np.isfinite(losses).all() and losses[-1] < losses[0], losses
+    assert ts._graph is not None, "the step was not recorded"
+    for p in ts.model.parameters():
+        assert torch.isfinite(p).all()
+    ref = TrainStep("containers", B=8, N=10240, seed=5, encoder="msg", mlp_dtype="f32", graph=False)
+    l0 = float(ref.step())
+    assert abs(l0 - losses[0]) < 2e-2 * abs(l0), (l0, losses[0])
