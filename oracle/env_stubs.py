@@ -180,6 +180,13 @@ def install():
         m.listconfig, m.dictconfig = lc, dc
         sys.modules.update({"omegaconf": m, "omegaconf.listconfig": lc, "omegaconf.dictconfig": dc})
         done.append("omegaconf")
+    try:   # utils/cluster.py:7 imports a class that newer networkx releases dropped (used by offline post-processing only)
+        import networkx.algorithms.tree as _nxt
+        if not hasattr(_nxt, "Edmonds"):
+            _nxt.Edmonds = type("Edmonds", (), {})
+            done.append("networkx.algorithms.tree.Edmonds")
+    except ImportError:
+        pass
     for name in ("wandb", "seaborn", "point_cloud_utils", "pyvista"):
         if name not in sys.modules and importlib.util.find_spec(name) is None:
             sys.modules[name] = _Inert(name)

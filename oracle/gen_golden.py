@@ -17,6 +17,12 @@ g8_hung  models/hungarianMatcher.py:31-63 HungarianMatcher
 g9_seg   models/pointnet2_seg.py:14-96,258-339 PointNet2Segmenter_v1 / _PaintNet_v1 (eval forward)
 g10_fp   models/pointnet2_utils.py:279-329 PointNetFeaturePropagation      3-NN interpolation + MLP fwd/bwd (train+eval)
 g11_smooth loss_handler.py:830,841-844,959-964 smooth_target_stroke_masks  MSE mask matching + loss on g7's inputs
+g12_flags pytorch3d_chamfer.py:180-291  chamfer_distance: velocities / min_centroids / avoid_in_sequence_collapsing /
+                                         soft_attraction / normals / weights (values + gradients)
+g13_losses loss_handler.py:521-552,566-593,669-801,990-1009 + metrics_handler.py:285-308: the sibling loss terms
+                                         (asymm_v11, symm_v1, chamfer_with_stroke_masks, chamfer, symm_point, attraction, emd,
+                                         per_segment_confidence) and stroke_masks_metrics
+g14_collate utils/dataset/paintnet_ODv1.py:726-847 Paintnet_ODv1_CollateBatch.__call__ on ragged synthetic samples
 """
 import os
 import sys
@@ -505,12 +511,164 @@ def g11_smooth():
     save("g11_smooth", **cases)
 
 
+
+def g12_flags():
+    """Every remaining branch of the reference chamfer wrapper (pytorch3d_chamfer.py:180-291), run through the imported
+    reference file itself (kNN stand-in = the oracle's, as for g6)."""
+    print("g12_flags")
+    ch = R.chamfer_module()
+    rng = np.random.default_rng(1212)
+    cases = {}
+
+    def call(tag, x, y, grad=True, **kw):
+        xt = torch.from_numpy(x.copy()).requires_grad_(grad)
+        yt = torch.from_numpy(y.copy()).requires_grad_(grad)
+        tk = {k: (torch.from_numpy(v.copy()) if isinstance(v, np.ndarray) else v) for k, v in kw.items()}
+        d, dn = ch.chamfer_distance(xt, yt, **tk)[:2]
+        cases[tag + "_dist"] = d.detach().numpy()
+        if dn is not None:
+            cases[tag + "_normals"] = dn.detach().numpy()
+        if grad:
+            tot = d.sum() if dn is None else d.sum() + 0.5 * dn.sum()
+            gx, gy = torch.autograd.grad(tot, [xt, yt])
+            cases[tag + "_gx"], cases[tag + "_gy"] = gx.numpy(), gy.numpy()
+
+    x6 = rng.uniform(0, 1, size=(2, 40, 6)).astype(np.float32)
+    y6 = rng.uniform(0, 1, size=(2, 40, 6)).astype(np.float32)
+    xs = rng.uniform(0, 1, size=(2, 30, 24)).astype(np.float32)
+    ys = rng.uniform(0, 1, size=(2, 30, 24)).astype(np.float32)
+    s3 = xs[..., :3].copy()
+    e3 = (s3 + 0.01 * rng.uniform(0, 1, size=s3.shape)).astype(np.float32)      # mostly in-sequence nearest neighbours
+    e3b = rng.uniform(0, 1, size=s3.shape).astype(np.float32)                    # unrelated: mostly out-of-sequence
+    nx = rng.normal(size=(2, 40, 3)).astype(np.float32)
+    ny = rng.normal(size=(2, 40, 3)).astype(np.float32)
+    w = np.array([0.5, 2.0], dtype=np.float32)
+    cases.update(x6=x6, y6=y6, xs=xs, ys=ys, s3=s3, e3=e3, e3b=e3b, nx=nx, ny=ny, w=w)
+    call("vel", x6, y6, velocities=True)                                          # :180-199 (the reference's in-place writes
+    call("minc", xs, ys, min_centroids=True)                                      #  into fresh tensors keep autograd intact)
+    call("attr", s3, e3, avoid_in_sequence_collapsing=True)                       # :201-222
+    call("soft", s3, e3b, avoid_in_sequence_collapsing=True, soft_attraction=True, point_reduction=None, batch_reduction=None)
+    call("wn", x6[..., :3].copy(), y6[..., :3].copy(), x_normals=nx, y_normals=ny, weights=w)
+    call("wn_sum", x6[..., :3].copy(), y6[..., :3].copy(), x_normals=nx, y_normals=ny, weights=w, batch_reduction="sum", point_reduction="sum")
+    call("w0", x6, y6, grad=False, weights=np.zeros(2, dtype=np.float32))         # :160-175 early return
+    save("g12_flags", **cases)
+
+
+def g13_losses():
+    """The loss terms of the maskplanner path that g7 / g11 do not reach, through the imported reference LossHandler."""
+    print("g13_losses")
+    lh = R.loss_handler_module()
+    rng = np.random.default_rng(1313)
+    B, S, M = 3, 99, 6
+    cat = syn.Category("t", S, M, 6, 6, 150, 300)
+    traj, traj_as_pc, stroke_ids, n_seg, n_pts = syn.ground_truth(rng, B, cat)
+    y_pred = np.empty((B, S, 24), dtype=np.float32)
+    for b in range(B):
+        pick = rng.integers(0, n_seg[b], size=S)
+        y_pred[b] = traj[b, pick] + rng.normal(scale=0.02, size=(S, 24)).astype(np.float32)
+    masks = rng.normal(size=(B, M, S)).astype(np.float32)
+    scores = rng.normal(size=(B, M)).astype(np.float32)
+    seg_logits = rng.uniform(0, 1, size=(B, S)).astype(np.float32)
+    cases = dict(y_pred=y_pred, traj=traj, traj_as_pc=traj_as_pc, stroke_ids=stroke_ids, masks=masks, scores=scores,
+                 seg_logits=seg_logits)
+    cfg_extra = dict(weight_symm_segment_chamfer=0.7, weight_symm_point_chamfer=30.0, soft_attraction=False)
+
+    def run(tag, method, per_segment_confidence=False, wants=("y_pred", "masks", "scores")):
+        handler = object.__new__(lh.LossHandler)
+        handler.config = R.maskplanner_loss_config(per_segment_confidence=per_segment_confidence, **cfg_extra)
+        if method == "get_emd":
+            handler.matcher = R.hungarian_matcher().HungarianMatcher()
+        t = dict(y_pred=torch.from_numpy(y_pred).requires_grad_(True), masks=torch.from_numpy(masks).requires_grad_(True),
+                 scores=torch.from_numpy(scores).requires_grad_(True), seg=torch.from_numpy(seg_logits).requires_grad_(True))
+        loss = getattr(handler, method)(y_pred=t["y_pred"], y=torch.from_numpy(traj), pred_stroke_masks=t["masks"],
+                                         mask_scores=t["scores"], seg_logits=t["seg"] if per_segment_confidence else None,
+                                         stroke_ids=torch.from_numpy(stroke_ids), traj_as_pc=torch.from_numpy(traj_as_pc))
+        cases[tag + "_loss"] = loss.detach().numpy()
+        names = list(wants) + (["seg"] if per_segment_confidence else [])
+        grads = torch.autograd.grad(loss, [t[n] for n in names], allow_unused=True)
+        for n, g in zip(names, grads):
+            cases[f"{tag}_g_{n}"] = np.zeros(tuple(t[n].shape), np.float32) if g is None else g.numpy()
+
+    run("v11", "get_asymm_v11_chamfer_with_stroke_masks")                        # :669-730
+    run("v11c", "get_asymm_v11_chamfer_with_stroke_masks", per_segment_confidence=True)
+    run("v6c", "get_asymm_v6_chamfer_with_stroke_masks", per_segment_confidence=True)   # :596-666 with :566-593
+    run("symm", "get_symm_v1_chamfer_with_stroke_masks")                         # :733-777
+    run("cwm", "get_chamfer_with_stroke_masks")                                  # :780-801
+    run("chamfer", "get_chamfer", wants=("y_pred",))                             # :534-552
+    run("sympt", "get_symm_point_chamfer", wants=("y_pred",))                    # :1044-1068
+    run("attr", "get_attraction_chamfer", wants=("y_pred",))                     # :521-531
+    run("emd", "get_emd", wants=("y_pred",))                                     # :990-1009
+    # stroke_masks_metrics (metrics_handler.py:285-308 + utils/postprocessing.py:92-152) through the reference's own
+    # MetricsHandler, in a fresh interpreter: the real `utils` package must not meet the stand-ins loss_handler_module() installed
+    import subprocess
+    import tempfile
+    tmp = tempfile.mkdtemp(prefix="mp_g13_")
+    np.savez(os.path.join(tmp, "in.npz"), masks=masks, scores=scores)
+    code = f"""
+import sys, numpy as np, torch
+sys.path.insert(0, {ROOT!r})
+from oracle import env_stubs, ref_import as R
+env_stubs.install(); R.install_pytorch3d_stub(); R.neutralise_cuda()
+sys.path.insert(0, {R.REF_ROOT!r})
+from metrics_handler import MetricsHandler
+d = np.load({os.path.join(tmp, 'in.npz')!r})
+mh = MetricsHandler(config=dict(extra_data=['orientnorm'], lambda_points=4), metrics=['stroke_masks_metrics'])
+out = mh.compute(n_strokes=[6, 5, 6], pred_stroke_masks=torch.from_numpy(d['masks']), mask_scores=torch.from_numpy(d['scores']))
+np.save({os.path.join(tmp, 'out.npy')!r}, np.asarray(out, dtype=np.float64))
+"""
+    subprocess.run([sys.executable, "-c", code], check=True, cwd=R.REF_ROOT)
+    metric_values = np.load(os.path.join(tmp, "out.npy"))
+    cases.update(metric_n_strokes=np.array([6, 5, 6]), metric_values=metric_values)
+    save("g13_losses", **cases)
+
+
+def g14_collate():
+    """The reference collate function (utils/dataset/paintnet_ODv1.py:713-847) on ragged synthetic samples: the padded
+    MaskPlanner tensors the training loop consumes."""
+    print("g14_collate")
+    from oracle import env_stubs
+    env_stubs.install()
+    sys.path.insert(0, R.REF_ROOT)
+    try:
+        from utils.dataset.paintnet_ODv1 import Paintnet_ODv1_CollateBatch
+    finally:
+        sys.path.remove(R.REF_ROOT)
+    rng = np.random.default_rng(1414)
+    cfg = R.AttrDict(lambda_points=4, overlapping=1, extra_data=["orientnorm"], task_name="MaskPlanner", out_prototypes=None,
+                     load_extra_data=["stroke_masks"], traj_with_equally_spaced_points=True)      # traj_sampling_v2.yaml
+    collate = Paintnet_ODv1_CollateBatch(cfg)
+    samples, cases = [], {}
+    for i, (n_pts, n_seg, n_str) in enumerate([(40, 12, 3), (71, 21, 5), (1, 1, 1), (64, 20, 4)]):
+        smp = dict(point_cloud=rng.normal(size=(256, 3)).astype(np.float32),
+                   traj=rng.normal(size=(n_seg, 24)).astype(np.float32),
+                   traj_as_pc=rng.normal(size=(n_pts, 6)).astype(np.float32),
+                   stroke_ids=np.sort(rng.integers(0, n_str, size=n_seg)).astype(np.float32),
+                   stroke_ids_as_pc=np.sort(rng.integers(0, n_str, size=n_pts)).astype(np.float32),
+                   stroke_masks=(rng.uniform(size=(n_str, n_seg)) > 0.5).astype(np.float32),
+                   dirname=f"sample_{i}", n_strokes=n_str)
+        samples.append(smp)
+        for k, v in smp.items():
+            if isinstance(v, np.ndarray):
+                cases[f"in{i}_{k}"] = v
+    out = collate([dict(s) for s in samples])
+    for k, v in out.items():
+        if torch.is_tensor(v):
+            cases["out_" + k] = v.numpy()
+        elif k == "stroke_masks":
+            for i, m in enumerate(v):
+                cases[f"out_stroke_masks{i}"] = m.numpy()
+    cases["none_keys"] = np.array(sorted(k for k, v in out.items() if v is None))
+    cases["n_strokes"] = np.array(out["n_strokes"])
+    cases["n_samples"] = np.int64(len(samples))
+    save("g14_collate", **cases)
+
+
 def main():
     if not R.available():
         raise SystemExit("reference checkout not found; fixtures can only be generated in the build container")
     torch.set_num_threads(8)
     pu = R.pointnet2_utils()
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14"]
     if "g1" in which: g1_fps(pu)
     if "g2" in which: g2_bq(pu)
     if "g3" in which: g3_sa(pu)
@@ -522,6 +680,9 @@ def main():
     if "g9" in which: g9_seg()
     if "g10" in which: g10_fp(pu)
     if "g11" in which: g11_smooth()
+    if "g12" in which: g12_flags()
+    if "g13" in which: g13_losses()
+    if "g14" in which: g14_collate()
 
 
 if __name__ == "__main__":

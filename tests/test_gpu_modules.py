@@ -912,3 +912,110 @@ def test_dense_adam_matches_torch_adam(capturable):
     st = ob.state[ref[5]]
     assert torch.allclose(oa.state[ours[5]]["exp_avg"], st["exp_avg"], rtol=1e-5, atol=1e-8)
     assert torch.allclose(oa.state[ours[5]]["exp_avg_sq"], st["exp_avg_sq"], rtol=1e-5, atol=1e-10)
+
+
+# ------------------------------------------------------------------------------------------------ reference fixtures g12-g14
+def test_chamfer_flag_variants_match_the_reference_wrapper(golden):
+    """velocities / min_centroids / avoid_in_sequence_collapsing / soft_attraction / normals / weights (pytorch3d_chamfer.py:
+    180-291) against the outputs of the reference wrapper itself (g12; its kNN = the oracle's, as for g6): values and the
+    gradients w.r.t. both clouds."""
+    from maskplanner_amd.pytorch3d_chamfer import chamfer_distance
+    g = golden("g12_flags")
+
+    def check(tag, x, y, grad=True, **kw):
+        xt, yt = dev(g[x]).requires_grad_(grad), dev(g[y]).requires_grad_(grad)
+        kw = {k: (dev(g[v]) if isinstance(v, str) else v) for k, v in kw.items()}
+        d, dn = chamfer_distance(xt, yt, **kw)[:2]
+        close(d, g[tag + "_dist"], tag + " dist", rtol=1e-5, atol=1e-6)
+        if (tag + "_normals") in g.files:
+            close(dn, g[tag + "_normals"], tag + " normals", rtol=1e-5, atol=1e-6)
+        if grad:
+            tot = d.sum() if dn is None else d.sum() + 0.5 * dn.sum()
+            gx, gy = torch.autograd.grad(tot, [xt, yt])
+            close(gx, g[tag + "_gx"], tag + " gx", rtol=1e-4, atol=1e-6)
+            close(gy, g[tag + "_gy"], tag + " gy", rtol=1e-4, atol=1e-6)
+
+    check("vel", "x6", "y6", velocities=True)
+    check("minc", "xs", "ys", min_centroids=True)
+    check("attr", "s3", "e3", avoid_in_sequence_collapsing=True)
+    check("soft", "s3", "e3b", avoid_in_sequence_collapsing=True, soft_attraction=True, point_reduction=None, batch_reduction=None)
+    x3, y3 = np.ascontiguousarray(g["x6"][..., :3]), np.ascontiguousarray(g["y6"][..., :3])
+    for tag, kw in (("wn", {}), ("wn_sum", dict(batch_reduction="sum", point_reduction="sum"))):
+        xt, yt = dev(x3).requires_grad_(True), dev(y3).requires_grad_(True)
+        d, dn = chamfer_distance(xt, yt, x_normals=dev(g["nx"]), y_normals=dev(g["ny"]), weights=dev(g["w"]), **kw)
+        close(d, g[tag + "_dist"], tag, rtol=1e-5, atol=1e-6)
+        close(dn, g[tag + "_normals"], tag + " normals", rtol=1e-5, atol=1e-6)
+        gx, gy = torch.autograd.grad(d.sum() + 0.5 * dn.sum(), [xt, yt])
+        close(gx, g[tag + "_gx"], tag + " gx", rtol=1e-4, atol=1e-6)
+        close(gy, g[tag + "_gy"], tag + " gy", rtol=1e-4, atol=1e-6)
+    z, zn = chamfer_distance(dev(g["x6"]), dev(g["y6"]), weights=torch.zeros(2).cuda())
+    close(z, g["w0_dist"], "zero weights", atol=0, rtol=0)
+
+
+@pytest.mark.parametrize("tag,method,conf,wants", [
+    ("v11", "get_asymm_v11_chamfer_with_stroke_masks", False, ("y_pred", "masks", "scores")),
+    ("v11c", "get_asymm_v11_chamfer_with_stroke_masks", True, ("y_pred", "masks", "scores")),
+    ("v6c", "get_asymm_v6_chamfer_with_stroke_masks", True, ("y_pred", "masks", "scores")),
+    ("symm", "get_symm_v1_chamfer_with_stroke_masks", False, ("y_pred", "masks", "scores")),
+    ("cwm", "get_chamfer_with_stroke_masks", False, ("y_pred", "masks", "scores")),
+    ("chamfer", "get_chamfer", False, ("y_pred",)),
+    ("sympt", "get_symm_point_chamfer", False, ("y_pred",)),
+    ("attr", "get_attraction_chamfer", False, ("y_pred",)),
+    ("emd", "get_emd", False, ("y_pred",)),
+])
+def test_sibling_loss_terms_match_the_reference(golden, tag, method, conf, wants):
+    """loss_handler.py:521-552, 566-593, 669-801, 990-1009 through the reference LossHandler (g13): loss values and gradients
+    of the terms next to asymm_v6 -- v11, symm_v1, chamfer_with_stroke_masks, chamfer, symm_point, attraction, emd -- and the
+    per_segment_confidence branch of v6 / v11."""
+    from maskplanner_amd.loss_handler import LossHandler, maskplanner_loss_config
+    g = golden("g13_losses")
+    name = method[len("get_"):]
+    extra = {"weight_" + name: 1.0}
+    extra.update(per_segment_confidence=conf, weight_symm_segment_chamfer=0.7, weight_symm_point_chamfer=30.0, soft_attraction=False)
+    cfg = maskplanner_loss_config(**extra)
+    lh = LossHandler([name], cfg)
+    t = dict(y_pred=dev(g["y_pred"]).requires_grad_(True), masks=dev(g["masks"]).requires_grad_(True),
+             scores=dev(g["scores"]).requires_grad_(True), seg=dev(g["seg_logits"]).requires_grad_(True))
+    loss = getattr(lh, method)(y_pred=t["y_pred"], y=dev(g["traj"]), pred_stroke_masks=t["masks"], mask_scores=t["scores"],
+                               seg_logits=t["seg"] if conf else None, stroke_ids=dev(g["stroke_ids"]), traj_as_pc=dev(g["traj_as_pc"]))
+    close(loss, g[tag + "_loss"], tag + " loss", rtol=1e-5, atol=1e-5)
+    names = list(wants) + (["seg"] if conf else [])
+    grads = torch.autograd.grad(loss, [t[n] for n in names], allow_unused=True)
+    for n, gr in zip(names, grads):
+        want = g[f"{tag}_g_{n}"]
+        gr = torch.zeros_like(t[n]) if gr is None else gr
+        close(gr, want, f"{tag} d{n}", rtol=2e-4, atol=2e-6)
+
+
+def test_stroke_masks_metrics_match_the_reference(golden):
+    """metrics_handler.py:285-308 (+ utils/postprocessing.py:92-152), the second default evaluation metric: g13."""
+    from maskplanner_amd.metrics_handler import MetricsHandler
+    g = golden("g13_losses")
+    mh = MetricsHandler(config=dict(extra_data=["orientnorm"], lambda_points=4), metrics=["stroke_masks_metrics"])
+    out = mh.compute(n_strokes=g["metric_n_strokes"].tolist(), pred_stroke_masks=dev(g["masks"]), mask_scores=dev(g["scores"]))
+    np.testing.assert_allclose(np.asarray(out, dtype=np.float64), g["metric_values"], rtol=0, atol=1e-12)
+    assert mh.tot_num_of_metrics() == 4
+
+
+def test_device_collate_matches_the_reference_collate(golden):
+    """utils/dataset/paintnet_ODv1.py:726-847 on ragged samples (g14): every tensor of the batch the reference's collate_fn
+    returns, bit for bit, from the device collate; same None keys and lists."""
+    from maskplanner_amd.collate import Paintnet_ODv1_CollateBatch
+    g = golden("g14_collate")
+    n = int(g["n_samples"])
+    samples = []
+    for i in range(n):
+        smp = {k[len(f"in{i}_"):]: g[k] for k in g.files if k.startswith(f"in{i}_")}
+        smp.update(dirname=f"sample_{i}", n_strokes=int(g["n_strokes"][i]))
+        samples.append(smp)
+    cfg = dict(load_extra_data=["stroke_masks"], traj_with_equally_spaced_points=True, out_prototypes=None)
+    batch = Paintnet_ODv1_CollateBatch(cfg, device="cuda")(samples)
+    for k in ("point_cloud", "traj", "traj_as_pc", "stroke_ids", "stroke_ids_as_pc"):
+        want = g["out_" + k]
+        assert batch[k].dtype == torch.float32 and tuple(batch[k].shape) == want.shape, k
+        assert np.array_equal(batch[k].cpu().numpy(), want), k
+    for i in range(n):
+        assert batch["stroke_masks"][i].dtype == torch.int64
+        assert np.array_equal(batch["stroke_masks"][i].cpu().numpy(), g[f"out_stroke_masks{i}"])
+    assert sorted(k for k, v in batch.items() if v is None) == g["none_keys"].tolist()
+    assert batch["n_strokes"] == g["n_strokes"].tolist() and batch["dirname"] == [f"sample_{i}" for i in range(n)]
