@@ -285,6 +285,32 @@ int mp_sa_mlp_bwd_bf16(const float* x0, int64_t P, int64_t K, int n_layers, cons
                        const mp_mlp_grads_t* grads, float* grad_x0, int64_t grad_x0_cols, void* workspace,
                        size_t workspace_bytes, mp_stream_t stream);
 
+/* ---- the same calls with options: operand type and SyncBN --------------------------------------------------------------
+ * Data-parallel training shards the batch over the GPUs of a node; the reference's train-mode BatchNorm2d
+ * (models/pointnet2_utils.py:208-213) then sees per-replica statistics.  With `sync` non-NULL every train-mode BatchNorm of the
+ * chain uses GLOBAL-batch statistics instead: per layer the library writes this rank's fp64 sums (sum z, sum z^2 forward;
+ * sum dy, sum dy*z backward: 2 * c_out doubles) into `exchange` and calls `allreduce(user, exchange, 2 * c_out, stream)`,
+ * which must SUM the buffer over all ranks in place, ordered on `stream` (under PyTorch: torch.distributed.all_reduce on a
+ * tensor wrapping the buffer; in a C host: ncclAllReduce on `stream`) and return 0.  Statistics, running-stat updates and the
+ * dZ constants then use the global sums and the global count P * world; d_gamma / d_beta stay this rank's contribution (the
+ * gradient exchange averages them).  `exchange`: caller-owned device buffer of >= 4 * max(c_out) doubles.  One small
+ * collective per BatchNorm layer and pass: 2 x 9 of them per step for the SSG encoder.  Eval mode ignores `sync`.
+ * bf16 != 0: the _bf16 variant above. */
+typedef int (*mp_allreduce_f64_fn)(void* user, double* device_buffer, int64_t count, mp_stream_t stream);
+typedef struct {
+    mp_allreduce_f64_fn allreduce;
+    void* user;
+    int64_t world;      /* number of ranks, each with the same P */
+    double* exchange;   /* device, >= 4 * max(c_out) doubles */
+} mp_syncbn_t;
+int mp_sa_mlp_fwd_ex(const float* x0, int64_t P, int64_t K, int n_layers, const mp_mlp_layer_t* layers, int training,
+                     double momentum, double eps, float* out, int32_t* argk, float* zmax, void* workspace,
+                     size_t workspace_bytes, int bf16, const mp_syncbn_t* sync, mp_stream_t stream);
+int mp_sa_mlp_bwd_ex(const float* x0, int64_t P, int64_t K, int n_layers, const mp_mlp_layer_t* layers, int training,
+                     const float* grad_out, const float* out, const int32_t* argk, const float* zmax,
+                     const mp_mlp_grads_t* grads, float* grad_x0, int64_t grad_x0_cols, void* workspace,
+                     size_t workspace_bytes, int bf16, const mp_syncbn_t* sync, mp_stream_t stream);
+
 /* ---- fused "gradient from rank-B factors + Adam" for the head matrices (scope table row f1, "next") -----------------
  * replaces, for a Linear weight W [O, I] whose gradient is dW = g^T x (g = dLoss/dy [Bg,O], x = input [Bg,I]):
  *   the dW GEMM of autograd (models/pointnet2_cls_ssg.py:311,336,327 fc3 / fc_normals / sm_fc3) + the Adam update of

@@ -38,6 +38,15 @@ class MlpGrads(ctypes.Structure):
     _fields_ = [("d_weight", _vp), ("d_bias", _vp), ("d_gamma", _vp), ("d_beta", _vp)]
 
 
+# mp_allreduce_f64_fn / mp_syncbn_t: the caller-supplied collective of the SyncBN option (mp_sa_mlp_{fwd,bwd}_ex)
+ALLREDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p)
+
+
+class SyncBN(ctypes.Structure):
+    """mp_syncbn_t"""
+    _fields_ = [("allreduce", ALLREDUCE_FN), ("user", _vp), ("world", _i64), ("exchange", _vp)]
+
+
 # name -> (restype, argtypes).  One entry per symbol declared in include/maskplanner_hip.h.
 SIGNATURES = {
     "mp_abi_version": (_int, []),
@@ -82,6 +91,10 @@ SIGNATURES = {
                                  _sz, _vp]),
     "mp_sa_mlp_bwd_f32": (_int, [_vp, _i64, _i64, _int, ctypes.POINTER(MlpLayer), _int, _vp, _vp, _vp, _vp,
                                  ctypes.POINTER(MlpGrads), _vp, _i64, _vp, _sz, _vp]),
+    "mp_sa_mlp_fwd_ex": (_int, [_vp, _i64, _i64, _int, ctypes.POINTER(MlpLayer), _int, _dbl, _dbl, _vp, _vp, _vp, _vp,
+                                _sz, _int, ctypes.POINTER(SyncBN), _vp]),
+    "mp_sa_mlp_bwd_ex": (_int, [_vp, _i64, _i64, _int, ctypes.POINTER(MlpLayer), _int, _vp, _vp, _vp, _vp,
+                                ctypes.POINTER(MlpGrads), _vp, _i64, _vp, _sz, _int, ctypes.POINTER(SyncBN), _vp]),
     "mp_sa_mlp_fwd_bf16": (_int, [_vp, _i64, _i64, _int, ctypes.POINTER(MlpLayer), _int, _dbl, _dbl, _vp, _vp, _vp, _vp,
                                  _sz, _vp]),
     "mp_sa_mlp_bwd_bf16": (_int, [_vp, _i64, _i64, _int, ctypes.POINTER(MlpLayer), _int, _vp, _vp, _vp, _vp,

@@ -12,12 +12,21 @@
 //   m = lerp(m, grad, 1-beta1);  v = beta2*v + (1-beta2)*grad^2;
 //   p -= (lr / (1-beta1^t)) * m / (sqrt(v) / sqrt(1-beta2^t) + eps)
 // with grad accumulated in fp32 over b in ascending order (fma chain).
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
 
 constexpr int AL_TO = 64, AL_TI = 64, AL_BC = 32;
+using f32x16 = __attribute__((ext_vector_type(16))) float;
 
+// MFMA = false: each thread rebuilds a 4 x 4 patch of the 64 x 64 gradient tile with scalar FMAs (16 per factor row): fine for
+// one GPU's 32 factor rows, where the kernel is bound by the Adam stream.  MFMA = true (data-parallel runs: the all-gathered
+// factors have 32 * world rows, 256 on a full node): the tile is four 32 x 32 v_mfma_f32_32x32x2_f32 accumulators, one per wave,
+// K = factor rows -- the same k-ordered fp32 fma chain, so both forms give bit-identical gradients, but the rebuild stays under
+// the kernel's HBM time instead of growing with the world size.
+template <bool MFMA>
 __global__ __launch_bounds__(256) void adam_lowrank_kernel(float* __restrict__ p, float* __restrict__ m,
                                                            float* __restrict__ v, const float* __restrict__ x,
                                                            const float* __restrict__ g, int Bg, int O, int I,
@@ -35,11 +44,16 @@ __global__ __launch_bounds__(256) void adam_lowrank_kernel(float* __restrict__ p
     const int tid = threadIdx.x;
     const int to = tid >> 4, ti = tid & 15;
     const int o0 = blockIdx.y * AL_TO, i0 = blockIdx.x * AL_TI;
+    const int lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+    const int wo = (wave >> 1) * 32, wi = (wave & 1) * 32;        // this wave's 32 x 32 sub-tile (MFMA form)
     float acc[4][4];
+    f32x16 macc;
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc[r][c] = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) macc[r] = 0.0f;
 
     for (int b0 = 0; b0 < Bg; b0 += AL_BC) {
         __syncthreads();
@@ -61,24 +75,47 @@ __global__ __launch_bounds__(256) void adam_lowrank_kernel(float* __restrict__ p
             *reinterpret_cast<float4*>(&sx[b][q]) = xv;
         }
         __syncthreads();
+        if constexpr (MFMA) {
+            // A[m = o][k = b] = g[b][o], B[k = b][n = i] = x[b][i]: lane (l31, hi) feeds k = 2 * s + hi (rows past Bg are zero)
+#pragma unroll
+            for (int kk = 0; kk < AL_BC; kk += 2)
+                macc = __builtin_amdgcn_mfma_f32_32x32x2f32(sg[kk + hi][wo + l31], sx[kk + hi][wi + l31], macc, 0, 0, 0);
+        } else {
 #pragma unroll 8
-        for (int b = 0; b < AL_BC; ++b) {
-            const float4 gv = *reinterpret_cast<const float4*>(&sg[b][to * 4]);
-            const float4 xv = *reinterpret_cast<const float4*>(&sx[b][ti * 4]);
-            const float ga[4] = {gv.x, gv.y, gv.z, gv.w};
-            const float xa[4] = {xv.x, xv.y, xv.z, xv.w};
+            for (int b = 0; b < AL_BC; ++b) {
+                const float4 gv = *reinterpret_cast<const float4*>(&sg[b][to * 4]);
+                const float4 xv = *reinterpret_cast<const float4*>(&sx[b][ti * 4]);
+                const float ga[4] = {gv.x, gv.y, gv.z, gv.w};
+                const float xa[4] = {xv.x, xv.y, xv.z, xv.w};
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
+                for (int r = 0; r < 4; ++r)
 #pragma unroll
-                for (int c = 0; c < 4; ++c) acc[r][c] = __builtin_fmaf(ga[r], xa[c], acc[r][c]);
+                    for (int c = 0; c < 4; ++c) acc[r][c] = __builtin_fmaf(ga[r], xa[c], acc[r][c]);
+            }
         }
     }
-    const int i = i0 + ti * 4;
     auto upd = [&](float grad, float& pp, float& mm, float& vv) {
         mm = mm + (1.0f - beta1) * (grad - mm);                 // lerp form, as torch's fused Adam
         vv = beta2 * vv + (1.0f - beta2) * grad * grad;
         pp -= lr_c1 * (mm / (sqrtf(vv) * inv_sqrt_c2 + eps));
     };
+    if constexpr (MFMA) {
+        // accumulator register r of this lane: row (r & 3) + 8 * (r >> 2) + 4 * hi, column l31 of the wave's sub-tile: a half-wave
+        // covers 32 consecutive floats of one weight row (128-byte segments of p, m, v)
+        const int i = i0 + wi + l31;
+        if (i < I) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int o = o0 + wo + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                if (o < O) {
+                    const size_t off = (size_t)o * I + i;
+                    upd(macc[r] * gscale, p[off], m[off], v[off]);
+                }
+            }
+        }
+        return;
+    }
+    const int i = i0 + ti * 4;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int o = o0 + to * 4 + r;
@@ -225,10 +262,19 @@ extern "C" int mp_adam_lowrank_f32(float* param, float* exp_avg, float* exp_avg_
     const double sh = step > 0 ? (double)step : 1.0;   // placeholders when the device-side count is used
     const double c1 = 1.0 - pow(beta1, sh), c2 = 1.0 - pow(beta2, sh);
     const dim3 grid((unsigned)((I + AL_TI - 1) / AL_TI), (unsigned)((O + AL_TO - 1) / AL_TO));
-    MP_LAUNCH("adam_lowrank_kernel", 2.0 * (double)Bg * O * I, 24.0 * (double)O * I + 4.0 * Bg * (double)(O + I),
-              adam_lowrank_kernel, grid, dim3(256), 0, mp_stream(stream_), param, exp_avg, exp_avg_sq, x, g, (int)Bg, (int)O,
-              (int)I, (float)grad_scale, (float)(lr / c1), (float)beta1, (float)beta2, (float)(1.0 / sqrt(c2)), (float)eps, step_dev,
-              (float)lr);
+    // more factor rows than one GPU's batch (all-gathered factors of a data-parallel run): rebuild on the matrix cores
+    static const int force = getenv("MP_ADAM_LOWRANK_MFMA") ? atoi(getenv("MP_ADAM_LOWRANK_MFMA")) : -1;   // A/B knob
+    const bool mfma = force >= 0 ? force != 0 : Bg > 32;
+    if (mfma)
+        MP_LAUNCH("adam_lowrank_kernel<mfma>", 2.0 * (double)Bg * O * I, 24.0 * (double)O * I + 4.0 * Bg * (double)(O + I),
+                  adam_lowrank_kernel<true>, grid, dim3(256), 0, mp_stream(stream_), param, exp_avg, exp_avg_sq, x, g, (int)Bg, (int)O,
+                  (int)I, (float)grad_scale, (float)(lr / c1), (float)beta1, (float)beta2, (float)(1.0 / sqrt(c2)), (float)eps, step_dev,
+                  (float)lr);
+    else
+        MP_LAUNCH("adam_lowrank_kernel", 2.0 * (double)Bg * O * I, 24.0 * (double)O * I + 4.0 * Bg * (double)(O + I),
+                  adam_lowrank_kernel<false>, grid, dim3(256), 0, mp_stream(stream_), param, exp_avg, exp_avg_sq, x, g, (int)Bg, (int)O,
+                  (int)I, (float)grad_scale, (float)(lr / c1), (float)beta1, (float)beta2, (float)(1.0 / sqrt(c2)), (float)eps, step_dev,
+                  (float)lr);
     MP_CHECK_LAUNCH();
     return MP_OK;
 }

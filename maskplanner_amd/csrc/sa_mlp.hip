@@ -1282,18 +1282,35 @@ __device__ __forceinline__ void reduce_partials(const float* __restrict__ partia
     }
 }
 
+// SyncBN (data-parallel runs with global-batch statistics): the per-channel sums of THIS rank in fp64, written
+// to an exchange buffer [2][C] (and a second copy that stays local); the caller all-reduces the buffer and the finalize
+// kernels below take the global sums from it instead of reducing the partials themselves.
+__global__ void bn_sums_kernel(const float* __restrict__ partials, int nblk, int C, double* __restrict__ out_a,
+                               double* __restrict__ out_b)
+{
+    double s1 = 0.0, s2 = 0.0;
+    reduce_partials(partials, nblk, C, s1, s2);
+    const int c = blockIdx.x * FIN_CH + (threadIdx.x % FIN_CH);
+    if (c >= C || threadIdx.x >= FIN_CH) return;
+    out_a[c] = s1;
+    out_a[C + c] = s2;
+    if (out_b) { out_b[c] = s1; out_b[C + c] = s2; }
+}
+
 // BatchNorm forward statistics -> affine (scale, shift); running-stat update; saves mean / rstd.
+// gsums != NULL: the (all-reduced) sums [2][C] over the global batch; invP / unbias then refer to the global position count.
 __global__ void bn_fwd_finalize_kernel(const float* __restrict__ partials, int nblk, int C, double invP, double unbias,
                                        int training, double momentum, double eps, const float* __restrict__ gamma,
                                        const float* __restrict__ beta, const float* __restrict__ bias,
                                        float* __restrict__ running_mean, float* __restrict__ running_var,
                                        float* __restrict__ mean_out, float* __restrict__ rstd_out,
-                                       float* __restrict__ scale, float* __restrict__ shift)
+                                       float* __restrict__ scale, float* __restrict__ shift, const double* __restrict__ gsums)
 {
     double s1 = 0.0, s2 = 0.0;
-    if (training) reduce_partials(partials, nblk, C, s1, s2);
+    if (training && !gsums) reduce_partials(partials, nblk, C, s1, s2);
     const int c = blockIdx.x * FIN_CH + (threadIdx.x % FIN_CH);
     if (c >= C || threadIdx.x >= FIN_CH) return;
+    if (training && gsums) { s1 = gsums[c]; s2 = gsums[C + c]; }
     const float b = bias ? bias[c] : 0.0f;
     if (training) {
         const double mean = s1 * invP;
@@ -1320,21 +1337,26 @@ __global__ void bn_fwd_finalize_kernel(const float* __restrict__ partials, int n
 }
 
 // BatchNorm backward sums (sum dy, sum dy*z) -> dgamma, dbeta, dbias and the dZ constants (a, e, f).
+// SyncBN (gsums / lsums != NULL, both [2][C]): dgamma / dbeta are this rank's contribution (local sums; the gradient exchange
+// averages them like every other parameter gradient), the dZ constants come from the global sums and the global count.
 __global__ void bn_bwd_finalize_kernel(const float* __restrict__ partials, int nblk, int C, double invP, int training,
                                        const float* __restrict__ gamma, const float* __restrict__ mean,
                                        const float* __restrict__ rstd, float* __restrict__ dgamma,
                                        float* __restrict__ dbeta, float* __restrict__ dbias, float* __restrict__ ca,
-                                       float* __restrict__ ce, float* __restrict__ cf)
+                                       float* __restrict__ ce, float* __restrict__ cf, const double* __restrict__ gsums,
+                                       const double* __restrict__ lsums)
 {
     double s1 = 0.0, s2 = 0.0;
-    reduce_partials(partials, nblk, C, s1, s2);
+    if (!gsums) reduce_partials(partials, nblk, C, s1, s2);
     const int c = blockIdx.x * FIN_CH + (threadIdx.x % FIN_CH);
     if (c >= C || threadIdx.x >= FIN_CH) return;
     const double mu = mean[c], rs = rstd[c], g = gamma[c];
-    const double dbe = s1;
-    const double dga = rs * (s2 - mu * s1);
+    if (gsums) { s1 = lsums[c]; s2 = lsums[C + c]; }
+    double dbe = s1;
+    double dga = rs * (s2 - mu * s1);
     dbeta[c] = (float)dbe;
     dgamma[c] = (float)dga;
+    if (gsums) { dbe = gsums[c]; dga = rs * (gsums[C + c] - mu * gsums[c]); }
     const double a = g * rs;
     if (training) {
         const double c1 = dbe * invP, c2 = dga * invP;
@@ -1501,8 +1523,10 @@ extern "C" int mp_sa_mlp_recompute_first(int n_layers, const int64_t* channels, 
 // (the generic tiled kernels; the fp32 position-stream / recompute specialisations are not used), everything else as in fp32.
 static int sa_mlp_fwd(const float* x0, int64_t P, int64_t K, int n_layers, const mp_mlp_layer_t* layers,
                       int training, double momentum, double eps, float* out, int32_t* argk, float* zmax,
-                      void* workspace, size_t workspace_bytes, mp_stream_t stream_, bool bf16)
+                      void* workspace, size_t workspace_bytes, mp_stream_t stream_, bool bf16, const mp_syncbn_t* sync)
 {
+    if (sync && (!sync->allreduce || !sync->exchange || sync->world < 1)) return MP_EINVAL;
+    if (!training) sync = nullptr;      // running statistics: nothing to exchange
     if (P < 0 || K <= 0 || n_layers <= 0 || !layers) return MP_EINVAL;
     if (P == 0) return MP_OK;
     if (!x0 || !out || !argk || !zmax || !workspace || (P % K) != 0) return MP_EINVAL;
@@ -1618,9 +1642,19 @@ static int sa_mlp_fwd(const float* x0, int64_t P, int64_t K, int n_layers, const
                              nullptr, nullptr, stream, &nblk);
         if (rc != MP_OK) return rc;
         const int C = (int)L.c_out;
+        double Pg = (double)P;
+        const double* gsums = nullptr;
+        if (sync) {     // global-batch statistics: local fp64 sums -> all-reduce (the caller's collective) -> finalize
+            hipLaunchKernelGGL(bn_sums_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_SL), 0, stream, partials, nblk, C,
+                               sync->exchange, (double*)nullptr);
+            MP_CHECK_LAUNCH();
+            if (sync->allreduce(sync->user, sync->exchange, 2 * (int64_t)C, stream_) != 0) return MP_ELAUNCH;
+            Pg = (double)P * (double)sync->world;
+            gsums = sync->exchange;
+        }
         hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_SL), 0, stream, partials, nblk, C,
-                           1.0 / (double)P, P > 1 ? (double)P / (double)(P - 1) : 1.0, training, momentum, eps, L.gamma,
-                           L.beta, L.bias, L.running_mean, L.running_var, L.mean, L.rstd, L.scale, L.shift);
+                           1.0 / Pg, Pg > 1.0 ? Pg / (Pg - 1.0) : 1.0, training, momentum, eps, L.gamma,
+                           L.beta, L.bias, L.running_mean, L.running_var, L.mean, L.rstd, L.scale, L.shift, gsums);
         MP_CHECK_LAUNCH();
         A = PosOperand{};
         A.x = L.z;
@@ -1650,21 +1684,30 @@ extern "C" int mp_sa_mlp_fwd_f32(const float* x0, int64_t P, int64_t K, int n_la
                                  int training, double momentum, double eps, float* out, int32_t* argk, float* zmax,
                                  void* workspace, size_t workspace_bytes, mp_stream_t stream)
 {
-    return sa_mlp_fwd(x0, P, K, n_layers, layers, training, momentum, eps, out, argk, zmax, workspace, workspace_bytes, stream, false);
+    return sa_mlp_fwd(x0, P, K, n_layers, layers, training, momentum, eps, out, argk, zmax, workspace, workspace_bytes, stream, false, nullptr);
 }
 
 extern "C" int mp_sa_mlp_fwd_bf16(const float* x0, int64_t P, int64_t K, int n_layers, const mp_mlp_layer_t* layers,
                                   int training, double momentum, double eps, float* out, int32_t* argk, float* zmax,
                                   void* workspace, size_t workspace_bytes, mp_stream_t stream)
 {
-    return sa_mlp_fwd(x0, P, K, n_layers, layers, training, momentum, eps, out, argk, zmax, workspace, workspace_bytes, stream, true);
+    return sa_mlp_fwd(x0, P, K, n_layers, layers, training, momentum, eps, out, argk, zmax, workspace, workspace_bytes, stream, true, nullptr);
+}
+
+extern "C" int mp_sa_mlp_fwd_ex(const float* x0, int64_t P, int64_t K, int n_layers, const mp_mlp_layer_t* layers,
+                                int training, double momentum, double eps, float* out, int32_t* argk, float* zmax,
+                                void* workspace, size_t workspace_bytes, int bf16, const mp_syncbn_t* sync, mp_stream_t stream)
+{
+    return sa_mlp_fwd(x0, P, K, n_layers, layers, training, momentum, eps, out, argk, zmax, workspace, workspace_bytes, stream, bf16 != 0, sync);
 }
 
 static int sa_mlp_bwd(const float* x0, int64_t P, int64_t K, int n_layers, const mp_mlp_layer_t* layers,
                       int training, const float* grad_out, const float* out, const int32_t* argk,
                       const float* zmax, const mp_mlp_grads_t* grads, float* grad_x0, int64_t grad_x0_cols,
-                      void* workspace, size_t workspace_bytes, mp_stream_t stream_, bool bf16)
+                      void* workspace, size_t workspace_bytes, mp_stream_t stream_, bool bf16, const mp_syncbn_t* sync)
 {
+    if (sync && (!sync->allreduce || !sync->exchange || sync->world < 1)) return MP_EINVAL;
+    if (!training) sync = nullptr;
     if (P < 0 || K <= 0 || n_layers <= 0 || !layers || !grads) return MP_EINVAL;
     if (P == 0) return MP_OK;
     if (!x0 || !grad_out || !out || !argk || !zmax || !workspace || (P % K) != 0) return MP_EINVAL;
@@ -1705,6 +1748,25 @@ static int sa_mlp_bwd(const float* x0, int64_t P, int64_t K, int n_layers, const
     const int64_t G = P / K;
     const int L = n_layers;
     const mp_mlp_layer_t& last = layers[L - 1];
+    // BatchNorm-backward finalize of layer `li` from `nb` partial rows (SyncBN: local sums kept, global sums exchanged)
+    auto finalize_bwd = [&](int li, int nb, int C) -> int {
+        const mp_mlp_layer_t& Lf = layers[li];
+        double Pg = (double)P;
+        const double *gs = nullptr, *ls = nullptr;
+        if (sync) {
+            hipLaunchKernelGGL(bn_sums_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_SL), 0, stream, partials, nb, C,
+                               sync->exchange, sync->exchange + 2 * (size_t)C);
+            if (hipGetLastError() != hipSuccess) return MP_ELAUNCH;
+            if (sync->allreduce(sync->user, sync->exchange, 2 * (int64_t)C, stream_) != 0) return MP_ELAUNCH;
+            Pg = (double)P * (double)sync->world;
+            gs = sync->exchange;
+            ls = sync->exchange + 2 * (size_t)C;
+        }
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_SL), 0, stream, partials, nb, C,
+                           1.0 / Pg, training, Lf.gamma, Lf.mean, Lf.rstd, grads[li].d_gamma, grads[li].d_beta, grads[li].d_bias,
+                           cbuf[0], cbuf[1], cbuf[2], gs, ls);
+        return hipGetLastError() == hipSuccess ? MP_OK : MP_ELAUNCH;
+    };
     // pooled gradient through the last ReLU + its BatchNorm-backward sums
     {
         const int C = (int)last.c_out;
@@ -1713,10 +1775,7 @@ static int sa_mlp_bwd(const float* x0, int64_t P, int64_t K, int n_layers, const
         hipLaunchKernelGGL(pool_bwd_prep_kernel, dim3(nb, (C + 255) / 256), dim3(256), 0, stream, grad_out, out, zmax, G, C, gp,
                            partials);
         MP_CHECK_LAUNCH();
-        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_SL), 0, stream, partials, nb, C,
-                           1.0 / (double)P, training, last.gamma, last.mean, last.rstd, grads[L - 1].d_gamma,
-                           grads[L - 1].d_beta, grads[L - 1].d_bias, cbuf[0], cbuf[1], cbuf[2]);
-        MP_CHECK_LAUNCH();
+        if (int rc = finalize_bwd(L - 1, nb, C)) return rc;
     }
     // dW is accumulated with atomics and must start from zero: one clear for the whole level when the caller laid the
     // layers' buffers out back to back (the Python layer does), one per layer otherwise
@@ -1788,10 +1847,8 @@ static int sa_mlp_bwd(const float* x0, int64_t P, int64_t K, int n_layers, const
             }
 #undef MP_FUSED
             MP_CHECK_LAUNCH();
-            hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((Ci + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_SL), 0, stream, partials, (int)gx, Ci,
-                               1.0 / (double)P, training, Pv.gamma, Pv.mean, Pv.rstd, grads[l - 1].d_gamma,
-                               grads[l - 1].d_beta, grads[l - 1].d_bias, cbuf[0], cbuf[1], cbuf[2]);
-            MP_CHECK_LAUNCH();
+            (void)Pv;
+            if (int rc = finalize_bwd(l - 1, (int)gx, Ci)) return rc;
             G_cur = Gn;
             continue;
         }
@@ -1836,10 +1893,7 @@ static int sa_mlp_bwd(const float* x0, int64_t P, int64_t K, int n_layers, const
             if (rc != MP_OK) return rc;
             // the constants of layer l are still being read by the kernels above: they are stream-ordered, so
             // overwriting cbuf for layer l-1 here is safe.
-            hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((Ci + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_SL), 0, stream, partials, nblk, Ci,
-                               1.0 / (double)P, training, Pv.gamma, Pv.mean, Pv.rstd, grads[l - 1].d_gamma,
-                               grads[l - 1].d_beta, grads[l - 1].d_bias, cbuf[0], cbuf[1], cbuf[2]);
-            MP_CHECK_LAUNCH();
+            if (int rc2 = finalize_bwd(l - 1, nblk, Ci)) return rc2;
             G_cur = Gn;
         } else if (grad_x0) {
             // only the first grad_x0_cols input channels need a gradient (the features; the centred coordinates that
@@ -1862,7 +1916,7 @@ extern "C" int mp_sa_mlp_bwd_f32(const float* x0, int64_t P, int64_t K, int n_la
                                  void* workspace, size_t workspace_bytes, mp_stream_t stream)
 {
     return sa_mlp_bwd(x0, P, K, n_layers, layers, training, grad_out, out, argk, zmax, grads, grad_x0, grad_x0_cols, workspace,
-                      workspace_bytes, stream, false);
+                      workspace_bytes, stream, false, nullptr);
 }
 
 extern "C" int mp_sa_mlp_bwd_bf16(const float* x0, int64_t P, int64_t K, int n_layers, const mp_mlp_layer_t* layers,
@@ -1871,5 +1925,14 @@ extern "C" int mp_sa_mlp_bwd_bf16(const float* x0, int64_t P, int64_t K, int n_l
                                   void* workspace, size_t workspace_bytes, mp_stream_t stream)
 {
     return sa_mlp_bwd(x0, P, K, n_layers, layers, training, grad_out, out, argk, zmax, grads, grad_x0, grad_x0_cols, workspace,
-                      workspace_bytes, stream, true);
+                      workspace_bytes, stream, true, nullptr);
+}
+
+extern "C" int mp_sa_mlp_bwd_ex(const float* x0, int64_t P, int64_t K, int n_layers, const mp_mlp_layer_t* layers,
+                                int training, const float* grad_out, const float* out, const int32_t* argk,
+                                const float* zmax, const mp_mlp_grads_t* grads, float* grad_x0, int64_t grad_x0_cols,
+                                void* workspace, size_t workspace_bytes, int bf16, const mp_syncbn_t* sync, mp_stream_t stream)
+{
+    return sa_mlp_bwd(x0, P, K, n_layers, layers, training, grad_out, out, argk, zmax, grads, grad_x0, grad_x0_cols, workspace,
+                      workspace_bytes, stream, bf16 != 0, sync);
 }

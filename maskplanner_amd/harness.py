@@ -17,13 +17,19 @@ from .pointnet2_cls_ssg import maskplanner_model
 class TrainStep:
     def __init__(self, category="cuboids", B=32, N=5120, device="cuda", seed=1235, hidden_size=(1024, 1024), lr=1e-3,
                  dist_points="cuboid", rank=0, loss_overrides=None, prefetch_sampling=False, factor_heads=True, graph=None,
-                 overlap_sampling=None, encoder="ssg", mlp_dtype="f32"):
+                 overlap_sampling=None, encoder="ssg", mlp_dtype="f32", sync_bn=False):
         self.cat = synthetic.CATEGORIES[category] if isinstance(category, str) else category
         self.device = torch.device(device)
         torch.manual_seed(seed)  # identical initial weights on every rank
         # encoder "msg" + mlp_dtype "bf16": BASELINE configs[4] (containers, N = 10240, multi-radius grouping, bf16 matrix cores)
         self.encoder, self.mlp_dtype = encoder, mlp_dtype
         self.model = maskplanner_model(self.cat, hidden_size=hidden_size, encoder=encoder, mlp_dtype=mlp_dtype).to(self.device).train()
+        # SyncBN (opt-in): train-mode BatchNorm statistics over the global batch, so that a data-parallel run reproduces the
+        # single-device run on the concatenated batch; its per-layer collectives rule out graph replay
+        self.sync_bn = bool(sync_bn) and dp.exchanging()
+        if self.sync_bn:
+            from . import sync_bn as _sbn
+            _sbn.enable(self.model)
         self.cfg = maskplanner_loss_config(**(loss_overrides or {}))
         self.loss_handler = LossHandler(["asymm_v6_chamfer_with_stroke_masks"], self.cfg)
         fused = self.device.type == "cuda"
@@ -32,11 +38,12 @@ class TrainStep:
         # The step is recorded once after a few eager steps and replayed; any failure to record falls back to eager.
         if graph is None:
             graph = os.environ.get("MASKPLANNER_GRAPH", "1") != "0"
-        # data-parallel runs: opt-in (MASKPLANNER_DP_GRAPH=1; validated with one RCCL rank and two gloo ranks only, hence not the
-        # default): the two graphs are recorded WITHOUT collectives and optimizers; the bucketed all-reduce, DenseAdam and the
-        # factor all-gather + Adam are launched eagerly after graph B (~20 launches per step instead of ~170)
-        self.dp_graph = dp.exchanging() and os.environ.get("MASKPLANNER_DP_GRAPH", "0") == "1"
-        self.use_graph = bool(graph) and fused and (not dp.exchanging() or self.dp_graph) and not prefetch_sampling
+        # data-parallel runs (default; MASKPLANNER_DP_GRAPH=0 launches kernel by kernel): the two graphs are recorded WITHOUT
+        # collectives and optimizers; the bucketed all-reduce, DenseAdam and the factor all-gather + Adam are launched eagerly after
+        # graph B (~20 launches per step instead of ~170, so eight ranks sharing one host do not become host-bound).  Replayed
+        # with two ranks on one GPU (tests/test_gpu_dp.py) and with one RCCL rank (tools/rccl_single_rank.py).
+        self.dp_graph = dp.exchanging() and os.environ.get("MASKPLANNER_DP_GRAPH", "1") != "0"
+        self.use_graph = bool(graph) and fused and (not dp.exchanging() or self.dp_graph) and not prefetch_sampling and not self.sync_bn
         self._graph, self._graph_loss, self._eager_steps, self._side = None, None, 0, None
         # Pipelined first-level sampling (see _eager_step): FPS can occupy only one workgroup per cloud -- 32 of 256 CUs for
         # ~0.35 ms at B=32 -- and depends on nothing but the input cloud, so the step computes the NEXT batch's FPS + ball

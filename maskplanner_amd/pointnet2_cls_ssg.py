@@ -49,6 +49,14 @@ class _SSGEncoder(nn.Module):
 def _bn_relu(x, bn):
     """F.relu(bn(x)) of the head blocks (:309-327); on the GPU one fused launch (ops.bn_relu_rows) instead of BatchNorm's
     statistics / transform / running-stat kernels + clamp.  The caller has advanced num_batches_tracked (_tick)."""
+    sync = getattr(bn, "sync_bn", None)
+    if sync is not None and bn.training:
+        from . import sync_bn
+        group = sync_bn.resolve(sync)
+        if group is not False:
+            if not x.is_cuda:     # (on the GPU the caller advanced the counters of all its BatchNorm layers in one launch: _tick)
+                _tick(bn)
+            return sync_bn.bn_relu_rows_sync(x, bn, group)
     if x.is_cuda and x.dtype == torch.float32 and x.ndim == 2:
         return ops.bn_relu_rows(x, bn)
     return F.relu(bn(x))
@@ -94,7 +102,7 @@ class PointNet2Regressor(_SSGEncoder):
         fused = feat.is_cuda
         if fused:
             _tick(self.bn1, self.bn2)
-        act = _bn_relu if fused else (lambda t, bn: F.relu(bn(t)))
+        act = _bn_relu
         x = self.dropout(act(self.fc1(feat), self.bn1))
         final = self.dropout(act(self.fc2(x), self.bn2))
         x = self.fc3(final)
@@ -158,7 +166,7 @@ class PointNet2Regressor_StrokeMasks(_SSGEncoder):
         fused = feat.is_cuda
         if fused:
             _tick(*([self.bn1, self.bn2] + ([self.sm_bn1, self.sm_bn2] if self.pred_stroke_masks else [])))
-        act = _bn_relu if fused else (lambda t, bn: F.relu(bn(t)))
+        act = _bn_relu
         x = self.dropout(act(factor_linear(feat, self.fc1, fs, "fc1.weight"), self.bn1))
         final = self.dropout(act(factor_linear(x, self.fc2, fs, "fc2.weight"), self.bn2))
         x = factor_linear(final, self.fc3, fs, "fc3.weight")
@@ -214,7 +222,7 @@ class _TrunkRegressor(_SSGEncoder):
         fused = feat.is_cuda
         if fused:
             _tick(self.bn1, self.bn2)
-        act = _bn_relu if fused else (lambda t, bn: F.relu(bn(t)))
+        act = _bn_relu
         last = self.dropout(act(self.fc2(self.dropout(act(self.fc1(feat), self.bn1))), self.bn2))
         return feat, last, self.fc3(last)
 

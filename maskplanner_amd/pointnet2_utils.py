@@ -171,6 +171,7 @@ class PointNetSetAbstraction(nn.Module):
     `mlp_dtype` ("f32" | "bf16", not a constructor argument: set it on the instance) selects the operand type of the grouped
     MLP's matrix-core contractions (sa_mlp.shared_mlp_max)."""
     mlp_dtype = "f32"
+    sync_bn = None        # True / a process group: train-mode statistics over the global batch (sync_bn.enable)
 
     def __init__(self, npoint, radius, nsample, in_channel, mlp, group_all):
         super().__init__()
@@ -206,7 +207,7 @@ class PointNetSetAbstraction(nn.Module):
         else:
             new_xyz, grouped = sample_and_group(self.npoint, self.radius, self.nsample, xyz, points,
                                                 full_points=full_points, _pad_to=4, _xyz_last=True)
-        new_points = sa_mlp.shared_mlp_max(grouped, self.mlp_convs, self.mlp_bns, layout=layout, dtype=self.mlp_dtype)  # [B,S,C']
+        new_points = sa_mlp.shared_mlp_max(grouped, self.mlp_convs, self.mlp_bns, layout=layout, dtype=self.mlp_dtype, sync_bn=self.sync_bn)  # [B,S,C']
         return new_xyz.permute(0, 2, 1), new_points.permute(0, 2, 1)
 
 
@@ -215,6 +216,7 @@ class PointNetSetAbstractionMsg(nn.Module):
     Channel order inside a group is FEATURES first, centred xyz last (:262).  state_dict keys conv_blocks.{i}.{j}.*,
     bn_blocks.{i}.{j}.* as in the reference.  `mlp_dtype` as for PointNetSetAbstraction."""
     mlp_dtype = "f32"
+    sync_bn = None
 
     def __init__(self, npoint, radius_list, nsample_list, in_channel, mlp_list):
         super().__init__()
@@ -242,7 +244,7 @@ class PointNetSetAbstractionMsg(nn.Module):
         for radius, K, convs, bns in zip(self.radius_list, self.nsample_list, self.conv_blocks, self.bn_blocks):
             idx = ops.ball_query(radius, K, xyz, new_xyz)
             grouped = ops.group(xyz, points, new_xyz, idx, xyz_last=True, pad_to=4)
-            outs.append(sa_mlp.shared_mlp_max(grouped, convs, bns, dtype=self.mlp_dtype))
+            outs.append(sa_mlp.shared_mlp_max(grouped, convs, bns, dtype=self.mlp_dtype, sync_bn=self.sync_bn))
         return new_xyz.permute(0, 2, 1), torch.cat(outs, dim=-1).permute(0, 2, 1)
 
 

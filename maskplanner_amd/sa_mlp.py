@@ -22,7 +22,7 @@ class _SharedMLPMax(torch.autograd.Function):
     weight[Co,Ci], bias|None, gamma, beta, running_mean|None, running_var|None."""
 
     @staticmethod
-    def forward(ctx, x, K, training, momentum, eps, n_layers, grad_cols, bf16, *params):
+    def forward(ctx, x, K, training, momentum, eps, n_layers, grad_cols, bf16, sync_group, *params):
         dev = x.device
         P, C0 = x.shape
         layers = (_lib.MlpLayer * n_layers)()
@@ -47,8 +47,19 @@ class _SharedMLPMax(torch.autograd.Function):
         argk = torch.empty((G, cl), dtype=torch.int32, device=dev)
         zmax = torch.empty((G, cl), dtype=torch.float32, device=dev)
         ws = torch.empty((lib.mp_sa_mlp_workspace_bytes(P, K, n_layers, ch, 0),), dtype=torch.uint8, device=dev)
-        ops._run("sa_mlp_fwd", x, lib.mp_sa_mlp_fwd_bf16 if bf16 else lib.mp_sa_mlp_fwd_f32, _ptr(x), P, K, n_layers, layers, int(training), float(momentum),
-                 float(eps), _ptr(out), _ptr(argk), _ptr(zmax), _ptr(ws), ws.numel())
+        if sync_group is not False and training:
+            # global-batch BatchNorm statistics: the library calls back once per layer to all-reduce its fp64 sums (sync_bn.py)
+            from . import sync_bn
+            ex = sync_bn.Exchange(sync_group, max(chans), dev)
+            ops._run("sa_mlp_fwd", x, lib.mp_sa_mlp_fwd_ex, _ptr(x), P, K, n_layers, layers, int(training), float(momentum),
+                     float(eps), _ptr(out), _ptr(argk), _ptr(zmax), _ptr(ws), ws.numel(), int(bool(bf16)), ctypes.byref(ex.struct))
+            if ex.error is not None:
+                raise ex.error
+        else:
+            sync_group = False
+            ops._run("sa_mlp_fwd", x, lib.mp_sa_mlp_fwd_bf16 if bf16 else lib.mp_sa_mlp_fwd_f32, _ptr(x), P, K, n_layers, layers, int(training), float(momentum),
+                     float(eps), _ptr(out), _ptr(argk), _ptr(zmax), _ptr(ws), ws.numel())
+        ctx.sync_group = sync_group
         ctx.meta = (P, K, bool(training), n_layers, chans, int(grad_cols), bool(bf16))
         ctx.keep = keep
         ctx.save_for_backward(x, out, argk, zmax)
@@ -88,10 +99,19 @@ class _SharedMLPMax(torch.autograd.Function):
         ch = (ctypes.c_int64 * len(chans))(*chans)
         lib = _lib.load()
         ws = torch.empty((lib.mp_sa_mlp_workspace_bytes(P, K, n_layers, ch, 1),), dtype=torch.uint8, device=dev)
-        ops._run("sa_mlp_bwd", x, lib.mp_sa_mlp_bwd_bf16 if bf16 else lib.mp_sa_mlp_bwd_f32, _ptr(x), P, K, n_layers, layers, int(training), _ptr(grad_out),
-                 _ptr(out), _ptr(argk), _ptr(zmax), grads, _ptr(gx), grad_cols, _ptr(ws), ws.numel())
+        if ctx.sync_group is not False:
+            from . import sync_bn
+            ex = sync_bn.Exchange(ctx.sync_group, max(chans), dev)
+            ops._run("sa_mlp_bwd", x, lib.mp_sa_mlp_bwd_ex, _ptr(x), P, K, n_layers, layers, int(training), _ptr(grad_out),
+                     _ptr(out), _ptr(argk), _ptr(zmax), grads, _ptr(gx), grad_cols, _ptr(ws), ws.numel(), int(bool(bf16)),
+                     ctypes.byref(ex.struct))
+            if ex.error is not None:
+                raise ex.error
+        else:
+            ops._run("sa_mlp_bwd", x, lib.mp_sa_mlp_bwd_bf16 if bf16 else lib.mp_sa_mlp_bwd_f32, _ptr(x), P, K, n_layers, layers, int(training), _ptr(grad_out),
+                     _ptr(out), _ptr(argk), _ptr(zmax), grads, _ptr(gx), grad_cols, _ptr(ws), ws.numel())
         ctx.keep = None
-        return (gx, None, None, None, None, None, None, None, *ret)
+        return (gx, None, None, None, None, None, None, None, None, *ret)
 
 
 class _PermuteCols(torch.autograd.Function):
@@ -132,7 +152,7 @@ def _first_weight_perm(cin, cpad, rotate, device):
     return _PERMS[key]
 
 
-def shared_mlp_max(grouped, convs, bns, layout="xyz_first", dtype="f32"):
+def shared_mlp_max(grouped, convs, bns, layout="xyz_first", dtype="f32", sync_bn=None):
     """grouped [B,S,K,C (+ zero padding up to a multiple of 4)] -> [B,S,Cout] = max_K relu(bn(conv(.))) chained over the
     layers (fused HIP path).
 
@@ -147,6 +167,9 @@ def shared_mlp_max(grouped, convs, bns, layout="xyz_first", dtype="f32"):
     stored activations, BatchNorm, pooling and all outputs stay fp32) -- mp_sa_mlp_{fwd,bwd}_bf16."""
     if dtype not in ("f32", "bf16"):
         raise ValueError("dtype must be 'f32' or 'bf16'")
+    # sync_bn: None / False = per-replica statistics; True or a process group = train-mode statistics over that group's ranks
+    from .sync_bn import resolve
+    sync_group = resolve(sync_bn)
     import torch.nn.functional as F
     ops._need_hip(grouped)
     B, S, K, C = grouped.shape
@@ -183,5 +206,5 @@ def shared_mlp_max(grouped, convs, bns, layout="xyz_first", dtype="f32"):
     bn0 = bns[0]
     momentum = bn0.momentum if bn0.momentum is not None else 1.0 / max(float(bn0.num_batches_tracked), 1.0)
     grad_cols = cin - 3 if (layout == "feats_first" and cin > 3) else 0
-    out = _SharedMLPMax.apply(x, K, training, momentum, bn0.eps, len(convs), grad_cols, dtype == "bf16", *params)
+    out = _SharedMLPMax.apply(x, K, training, momentum, bn0.eps, len(convs), grad_cols, dtype == "bf16", sync_group, *params)
     return out.view(B, S, -1)

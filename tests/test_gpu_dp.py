@@ -1,0 +1,93 @@
+"""The data-parallel path with TWO ranks on the GPU box's single MI355X (gloo backend between them; tests/dp_worker.py).
+
+RCCL needs one GPU per rank, so the multi-GPU bench cannot be run here; what can be run is everything around the collective:
+the rank-sharded batch, SyncBN's per-layer exchanges inside the fused kernels' calls, the bucketed gradient all-reduce, the
+factor all-gather and the two-graph step with the exchange outside the graphs.
+"""
+import os
+import socket
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+
+
+def _run(mode, world):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = str(s.getsockname()[1])
+    tmp = tempfile.mkdtemp(prefix="mp_dp_")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dp_worker.py"), mode, str(r), str(world), port,
+                               os.path.join(tmp, f"r{r}.pt")], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for r in range(world)]
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o[-3000:]
+    return [torch.load(os.path.join(tmp, f"r{r}.pt")) for r in range(world)]
+
+
+def _close(a, b, what, rtol, atol):
+    err = float((a - b).abs().max())
+    scale = max(float(b.abs().max()), 1.0)
+    assert err <= atol + rtol * scale, f"{what}: {err:.3e} (scale {scale:.3e})"
+
+
+def test_syncbn_two_ranks_reproduce_the_single_process_global_batch():
+    """north_star: loss parity of the data-parallel run with the single-device run.  16 clouds in one process (plain train-mode
+    BatchNorm over the whole batch) vs 2 ranks x 8 clouds with SyncBN: predictions of every sample within 1e-5, running
+    statistics equal, rank-averaged parameter gradients equal up to the max-pool routing noise."""
+    (one,) = _run("syncbn", 1)
+    two = _run("syncbn", 2)
+    for r in two:
+        a, b = r["sl"]
+        _close(r["feat"], one["feat"][a:b], "encoder feature", 1e-5, 1e-5)
+        # behind the heads' BatchNorm1d layers (statistics over 16 rows of near-identical cuboid features: channels with a tiny
+        # variance amplify the 1e-7 differences of the encoder feature) a little more is allowed
+        _close(r["out"], one["out"][a:b], "out", 2e-4, 1e-5)
+        _close(r["sm"], one["sm"][a:b], "sm_out", 2e-4, 1e-5)
+        _close(r["conf"], one["conf"][a:b], "mask_conf", 2e-4, 1e-5)
+        for n, v in one["running"].items():
+            _close(r["running"][n], v, n, 1e-5, 1e-6)
+    def noise_only(n):      # a bias in front of a train-mode BatchNorm: its gradient is rounding noise
+        return n.endswith("bias") and ("mlp_convs" in n or n in ("fc1.bias", "fc2.bias", "sm_fc1.bias", "sm_fc2.bias"))
+    # the encoder's gradients under a linear functional of its output: the SyncBN backward (global sums in the dZ constants,
+    # local sums in dgamma / dbeta, then the average over ranks) reproduces the single-process gradient
+    errs = {n: float((two[0]["enc_grads"][n] - g).norm() / g.norm().clamp_min(1e-12)) for n, g in one["enc_grads"].items()
+            if not noise_only(n)}
+    # (gradients through max-pools are discontinuous in the forward values: a 1e-6 forward difference re-routes the gradient of
+    # the few groups whose two largest members are that close, which shows as ~2e-3 here -- the same floor as between the HIP
+    # path and the CPU oracle, tests/test_gpu_bf16.py; a wrong SyncBN constant would show as O(1))
+    bad = {n: e for n, e in errs.items() if e > 2e-2}
+    assert not bad and sorted(errs.values())[len(errs) // 2] < 5e-3, (bad, sorted(errs.values())[len(errs) // 2])
+    # through the heads (their BatchNorm1d amplification included): direction and size
+    for n, g in one["grads"].items():
+        if noise_only(n):
+            continue
+        _close(two[0]["grads"][n], g, "grad " + n, 2e-2, 2e-5)
+        assert torch.equal(two[0]["grads"][n], two[1]["grads"][n])
+
+
+def test_two_graph_step_replays_under_data_parallelism():
+    """The default N > 1 launch path: graphs A (encoder forward) and B (heads, loss, backward) replayed, gradient all-reduce,
+    dense Adam and the factor all-gather + Adam launched eagerly after B.  Replicas stay identical and the trajectory tracks
+    the kernel-by-kernel data-parallel run."""
+    g = _run("dp_graph", 2)
+    e = _run("dp_eager", 2)
+    assert all(r["graph"] for r in g) and not any(r["graph"] for r in e)
+    assert max(r["replica_diff"] for r in g) == 0.0 and max(r["replica_diff"] for r in e) == 0.0
+    lg, le = np.array(g[0]["losses"]), np.array(e[0]["losses"])
+    assert np.isfinite(lg).all() and lg[-1] < lg[0]
+    assert abs(lg[0] - le[0]) <= 1e-4 * abs(le[0]) and np.allclose(lg, le, rtol=5e-2), (lg, le)

@@ -534,11 +534,14 @@ def test_msg_encoder_full_size_vs_oracle(oracle):
 
 
 # ------------------------------------------------------------------------------------------------ factor heads
-def test_factor_adam_matches_torch_adam():
-    """FactorLinear + FactorAdam (gradient rebuilt from (x, g) inside the fused kernel) vs nn.Linear + torch.optim.Adam."""
+@pytest.mark.parametrize("B", [32, 96, 250])
+def test_factor_adam_matches_torch_adam(B):
+    """FactorLinear + FactorAdam (gradient rebuilt from (x, g) inside the fused kernel) vs nn.Linear + torch.optim.Adam.
+    B = 32: one GPU's factors (scalar-FMA rebuild); B = 96 / 250: as many factor rows as the all-gathered factors of a 3- / 8-rank
+    data-parallel run have (rebuild on the matrix cores, adam_lowrank_kernel<mfma>; 250: a ragged last slab)."""
     from maskplanner_amd.factor_heads import FactorAdam, factor_linear
     torch.manual_seed(0)
-    B, I, O = 32, 1024, 5994                      # sm_fc3 of cuboids: O % 4 != 0 exercises the unaligned path
+    I, O = 1024, 5994                             # sm_fc3 of cuboids: O % 4 != 0 exercises the unaligned path
     ref = torch.nn.Linear(I, O).cuda()
     mine = torch.nn.Linear(I, O).cuda()
     mine.load_state_dict(ref.state_dict())
