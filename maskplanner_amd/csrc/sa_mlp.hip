@@ -272,6 +272,42 @@ __device__ __forceinline__ void mma_chunk_bf16(const __bf16* sA, const __bf16* s
     }
 }
 
+// The same chunk product with the operand fetch software-pipelined: the fragments of k-step s+1 are requested from LDS before
+// the MFMAs of step s are issued.  (Left to itself the compiler emits "ds_read; s_waitcnt lgkmcnt(0); MFMA x TM*TN" per step,
+// i.e. every group of MFMAs waits out a full LDS round trip -- visible as ~60 % MFMA utilisation of the fused backward
+// kernels in profiles/r02_mfma_util.md.)  Same products in the same k order: bit-identical results.
+template <bool A_KROW, bool B_KROW, int LDA, int LDB, int TM, int TN, int KC>
+__device__ __forceinline__ void mma_chunk_pipelined(const float* sA, const float* sB, int wrow0, int wcol0, f32x16 (&acc)[TM][TN])
+{
+    const int lane = threadIdx.x & 63;
+    const int l31 = lane & 31, hi = lane >> 5;
+    float a[2][TM], b[2][TN];
+    auto fetch = [&](int kk, float (&av)[TM], float (&bv)[TN]) {
+        const int k = kk + hi;
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) {
+            const int r = wrow0 + mi * 32 + l31;
+            av[mi] = A_KROW ? sA[k * LDA + r] : sA[r * LDA + k];
+        }
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) {
+            const int c = wcol0 + ni * 32 + l31;
+            bv[ni] = B_KROW ? sB[k * LDB + c] : sB[c * LDB + k];
+        }
+    };
+    fetch(0, a[0], b[0]);
+#pragma unroll
+    for (int kk = 0; kk < KC; kk += 2) {
+        const int cur = (kk >> 1) & 1;
+        if (kk + 2 < KC) fetch(kk + 2, a[cur ^ 1], b[cur ^ 1]);
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni)
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][mi], b[cur][ni], acc[mi][ni], 0, 0, 0);
+    }
+}
+
 // accumulator register r of this lane -> row inside a 32-row MFMA tile
 __device__ __forceinline__ int acc_row_in_tile(int r) { return (r & 3) + 8 * (r >> 2) + 4 * ((threadIdx.x & 63) >> 5); }
 
@@ -664,8 +700,10 @@ __global__ __launch_bounds__(THREADS) void dw_gemm_kernel(PosOperand DZ, PosOper
 template <int CI, int CO, bool POOL, int MODE_A = SRC_ACT, int TAIL = 0>   // TAIL = 4: input rows are [CI | 4] wide (features | xyz + pad)
 __global__ __launch_bounds__(CO > 128 ? 512 : 256) void fwd_chunk_kernel(PosOperand A, int P, int p_per_block,
                                                                          const float* __restrict__ W, float* __restrict__ Z,
-                                                                         float* __restrict__ partials, PoolOut po)
-{
+                                                                         float* __restrict__ partials, PoolOut po,
+                                                                         const float* __restrict__ gamma)
+{   // gamma (POOL): this layer's BatchNorm weight -- its sign is the sign of the affine scale, i.e. whether the pool of a column
+    // takes the group's largest or smallest raw value, so every lane tracks ONE extremum
     constexpr int NT = CO > 128 ? 512 : 256, NW = NT / 64;
     constexpr int CW = CO / NW;                       // columns per wave: 32 (one 32x32 MFMA tile) or 16 (two 16x16 tiles)
     constexpr bool BIG = CW == 32;                    // v_mfma_f32_32x32x2_f32: a lane's 32 consecutive columns = whole 128-B lines
@@ -713,9 +751,22 @@ __global__ __launch_bounds__(CO > 128 ? 512 : 256) void fwd_chunk_kernel(PosOper
     };
 
     double s1 = 0.0, s2 = 0.0;     // the chunk's values are summed in fp32, the 16-32 chunks of a workgroup in fp64
-    float gmax = 0.0f, gmin = 0.0f;
-    int gimax = 0, gimin = 0;
+    float gbest = 0.0f;
+    int gibest = 0;
     const int cpg = POOL ? po.K / DBK : 1;            // chunks per group (1, 2 or 4)
+    // fp32 MFMAs run on the SIMD's own FMA lanes: every other vector instruction of the wave pair takes time away from them
+    // (profiles/r02: MFMA busy + VALU busy + LDS ~ 100 %), so the epilogue is written for instruction count:
+    //  * raw Z goes out through buffer stores: the row part that is uniform over the wave sits in the scalar offset, the lane
+    //    part in one VGPR advanced once per chunk, and rows past the workgroup's last position are dropped by the hardware's
+    //    range check -- no 64-bit address arithmetic, no EXEC masking per row;
+    //  * the BatchNorm sums run on register pairs (v_pk_add_f32 / v_pk_mul_f32); rows past P are exact zeros and need no mask;
+    //  * the pool tracks one extremum per column (sign of gamma), as a maximum of the sign-flipped value.
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const __amdgpu_buffer_rsrc_t zrsrc = __builtin_amdgcn_make_buffer_rsrc(Z + (size_t)p0 * CO, 0, (p1 - p0) * CO * 4, 0x00020000);
+    int zoff = ((BIG ? 4 * kq : 4 * kq) * CO + col) * 4;     // byte offset of this lane's first row inside the workgroup's slab
+    bool neg = false;
+    if constexpr (POOL) neg = gamma[col] < 0.0f;
+    const unsigned smask = neg ? 0x80000000u : 0u;
 
     gload(p0);
     sstore(0);
@@ -724,7 +775,6 @@ __global__ __launch_bounds__(CO > 128 ? 512 : 256) void fwd_chunk_kernel(PosOper
         const int cur = kcn & 1;
         if (kcn + 1 < nchunks) gload(p0 + (kcn + 1) * DBK);
         float v[NV];
-        int vrow[NV];
         if constexpr (BIG) {
             f32x16 acc;
 #pragma unroll
@@ -733,7 +783,7 @@ __global__ __launch_bounds__(CO > 128 ? 512 : 256) void fwd_chunk_kernel(PosOper
 #pragma unroll
             for (int st = 0; st < NFR; ++st) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * st], wfrag[st], acc, 0, 0, 0);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { v[r] = acc[r]; vrow[r] = acc_row_in_tile(r); }   // ascending in r for this lane
+            for (int r = 0; r < 16; ++r) v[r] = acc[r];               // rows (r & 3) + 8 * (r >> 2) + 4 * kq: ascending in r
         } else {
             f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
             const float* a0p = sA[cur] + lc * LDA + kq;               // A[row = 16*rt + lc][k = 4*st + kq]
@@ -744,50 +794,55 @@ __global__ __launch_bounds__(CO > 128 ? 512 : 256) void fwd_chunk_kernel(PosOper
                 a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1p[4 * st], wfrag[st], a1, 0, 0, 0);
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { v[i] = a0[i]; vrow[i] = 4 * kq + i; v[4 + i] = a1[i]; vrow[4 + i] = 16 + 4 * kq + i; }
+            for (int i = 0; i < 4; ++i) { v[i] = a0[i]; v[4 + i] = a1[i]; }   // rows 4 * kq + i and 16 + 4 * kq + i
         }
+        // row of accumulator r relative to the lane part (4 * kq): uniform over the wave
+        auto rowc = [](int r) { return BIG ? (r & 3) + 8 * (r >> 2) : (r < 4 ? r : 16 + (r - 4)); };
         if constexpr (TAIL != 0) {   // k = CI .. CI+3 appended to each element's FMA chain, in k order
 #pragma unroll
             for (int r = 0; r < NV; ++r) {
-                const float4 xt = sT[cur][vrow[r]];
+                const float4 xt = sT[cur][4 * kq + rowc(r)];
                 v[r] = __builtin_fmaf(xt.w, wt.w, __builtin_fmaf(xt.z, wt.z, __builtin_fmaf(xt.y, wt.y, __builtin_fmaf(xt.x, wt.x, v[r]))));
             }
         }
-        const int pk = p0 + kcn * DBK;
-        float lmax = -__builtin_inff(), lmin = __builtin_inff();
-        int limax = 0, limin = 0;
-        float c1 = 0.0f, c2 = 0.0f;
+        f2 c1 = {0.0f, 0.0f}, c2 = {0.0f, 0.0f};
+        float lbest = -__builtin_inff();
+        int libest = 0;
 #pragma unroll
-        for (int r = 0; r < NV; ++r) {
-            const int pp = pk + vrow[r];
-            if (pp < p1) {
-                Z[(size_t)((unsigned)pp * (unsigned)CO + (unsigned)col)] = v[r];
-                c1 += v[r];
-                c2 += v[r] * v[r];
-                if constexpr (POOL) {
-                    if (v[r] > lmax) { lmax = v[r]; limax = vrow[r]; }   // strict: the first extremum stays
-                    if (v[r] < lmin) { lmin = v[r]; limin = vrow[r]; }
+        for (int r = 0; r < NV; r += 2) {
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[r]), zrsrc, zoff, rowc(r) * CO * 4, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[r + 1]), zrsrc, zoff, rowc(r + 1) * CO * 4, 0);
+            const f2 x = {v[r], v[r + 1]};
+            c1 += x;
+            c2 += x * x;
+            if constexpr (POOL) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const float t = __uint_as_float(__float_as_uint(v[r + u]) ^ smask);   // -x where the column pools its minimum
+                    if (t > lbest) { lbest = t; libest = rowc(r + u); }                    // strict: the first extremum stays
                 }
             }
         }
-        s1 += (double)c1;
-        s2 += (double)c2;
+        zoff += DBK * CO * 4;
+        s1 += (double)(c1.x + c1.y);
+        s2 += (double)(c2.x + c2.y);
         if constexpr (POOL) {
+            libest += 4 * kq;
             // the lane groups of a column hold interleaved rows: lexicographic (value, row) combine
 #pragma unroll
             for (int d = BIG ? 32 : 16; d <= 32; d <<= 1) {
-                const float ox = __shfl_xor(lmax, d, 64), on = __shfl_xor(lmin, d, 64);
-                const int oix = __shfl_xor(limax, d, 64), oin = __shfl_xor(limin, d, 64);
-                if (ox > lmax || (ox == lmax && oix < limax)) { lmax = ox; limax = oix; }
-                if (on < lmin || (on == lmin && oin < limin)) { lmin = on; limin = oin; }
+                const float ox = __shfl_xor(lbest, d, 64);
+                const int oix = __shfl_xor(libest, d, 64);
+                if (ox > lbest || (ox == lbest && oix < libest)) { lbest = ox; libest = oix; }
             }
             const int cig = kcn % cpg;                // chunk inside its group (p0 is a multiple of K)
-            if (cig == 0 || lmax > gmax) { gmax = lmax; gimax = cig * DBK + limax; }   // earlier chunk wins ties
-            if (cig == 0 || lmin < gmin) { gmin = lmin; gimin = cig * DBK + limin; }
+            if (cig == 0 || lbest > gbest) { gbest = lbest; gibest = cig * DBK + libest; }   // earlier chunk wins ties
             if (cig == cpg - 1 && kq == 0) {
+                const int pk = p0 + kcn * DBK;
                 const size_t o = (size_t)((unsigned)(pk / po.K) * (unsigned)CO + (unsigned)col);
-                po.vmax[o] = gmax; po.imax[o] = gimax;
-                po.vmin[o] = gmin; po.imin[o] = gimin;
+                const float val = __uint_as_float(__float_as_uint(gbest) ^ smask);
+                if (neg) { po.vmin[o] = val; po.imin[o] = gibest; }
+                else { po.vmax[o] = val; po.imax[o] = gibest; }
             }
         }
         if (kcn + 1 < nchunks) sstore(cur ^ 1);
@@ -823,12 +878,13 @@ __global__ __launch_bounds__((CO >= 128 && CI == 128 ? 512 : 256), (CO >= 128 &&
     constexpr int DBK = CI == 128 ? 16 : 32;   // positions per chunk (LDS and registers: at least two workgroups per CU)
     constexpr int XW = DBK == 32 ? CI / (NW / 2) : CI / NW; // dX columns per wave (the chunk's dX tile is [DBK x CI])
     constexpr int HT = XW / 16;                             // 16x16 dX tiles per wave and chunk
-    constexpr int LDA = CO + 1;                 // odd: conflict-free both as [k][row] (dW) and as [row][k] (dX)
+    constexpr int LDA = CO + 4;                 // 16-byte aligned rows: one ds_write_b128 per staged float4, ds_read_b128 dX fragments
+    constexpr int KPL = CO / 4;                 // dX: k values per lane group kq, CONTIGUOUS (k = kq * KPL + s), see below
     constexpr int TMW = CO / (32 * (NW / 2)), TNW = CI / 64; // 32x32 dW tiles per wave (waves (NW/2) x 2)
 
     constexpr int PA = DBK * CO / 4 / NT, PB = DBK * CI / 4 / NT;
     static_assert((CO == 64 || CO == 128 || CO == 256) && (CI == 64 || CI == 128) && PA >= 1 && PB >= 1 && HT >= 1, "tile");
-    __shared__ float sA[2][DBK * LDA];
+    __shared__ __attribute__((aligned(16))) float sA[2][DBK * LDA];
     __shared__ __attribute__((aligned(16))) float sB[2][DBK * CI];
     __shared__ __attribute__((aligned(16))) float sZ[2][DBK * CI];
     __shared__ float red[2][2][CI];
@@ -865,11 +921,8 @@ __global__ __launch_bounds__((CO >= 128 && CI == 128 ? 512 : 256), (CO >= 128 &&
     };
     auto sstore = [&](int buf) {
 #pragma unroll
-        for (int ps = 0; ps < PA; ++ps) {
-            const float4 v = finish<MODE_DZ>(ra[ps], ka);
-            float* d = &sA[buf][(ka0 + ps * KA_STEP) * LDA + ca];
-            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-        }
+        for (int ps = 0; ps < PA; ++ps)
+            *reinterpret_cast<float4*>(&sA[buf][(ka0 + ps * KA_STEP) * LDA + ca]) = finish<MODE_DZ>(ra[ps], ka);
 #pragma unroll
         for (int ps = 0; ps < PB; ++ps) {
             const int o = (kb0 + ps * KB_STEP) * CI + cb;
@@ -881,14 +934,17 @@ __global__ __launch_bounds__((CO >= 128 && CI == 128 ? 512 : 256), (CO >= 128 &&
     const int l31 = lane & 31;
     // dX tiles of this wave: 32-position chunks: two row tiles x NW/2 column groups; 16-position chunks: rows 0..15, columns
     // (CI/NW)*wave..  The W_l fragments of those columns never change: they live in registers for the whole kernel
-    // (v_mfma_f32_16x16x4_f32 B operand: lane (l15, kq) holds W[4*step + kq][col]), so W_l costs no LDS.
+    // (v_mfma_f32_16x16x4_f32 B operand: lane (l15, kq) holds W[k][col]), so W_l costs no LDS.  The contraction index is
+    // PERMUTED: step s of lane group kq covers k = kq * KPL + s instead of 4 * s + kq, so that a lane's A values of consecutive
+    // steps are consecutive floats of its dZ row -- four steps per ds_read_b128, fetched a batch ahead of the MFMAs that use
+    // them.  (The sum over k is the same set of products in another order: G differs from the k-ordered chain by rounding.)
     const int xrow0 = DBK == 32 ? (wave / (NW / 2)) * 16 : 0;
     const int xcol0 = DBK == 32 ? (wave % (NW / 2)) * XW : wave * XW;
     float wfrag[HT][CO / 4];
 #pragma unroll
     for (int h = 0; h < HT; ++h)
 #pragma unroll
-        for (int st = 0; st < CO / 4; ++st) wfrag[h][st] = W[(size_t)(4 * st + (lane >> 4)) * CI + xcol0 + 16 * h + (lane & 15)];
+        for (int st = 0; st < CO / 4; ++st) wfrag[h][st] = W[(size_t)((lane >> 4) * KPL + st) * CI + xcol0 + 16 * h + (lane & 15)];
     float spx[HT], tpx[HT], s1x[HT], s2x[HT];   // this lane's G columns
 #pragma unroll
     for (int h = 0; h < HT; ++h) {
@@ -905,7 +961,7 @@ __global__ __launch_bounds__((CO >= 128 && CI == 128 ? 512 : 256), (CO >= 128 &&
     for (int kc = 0; kc < nchunks; ++kc) {
         const int cur = kc & 1;
         if (kc + 1 < nchunks) gload(p0 + (kc + 1) * DBK);
-        mma_chunk<true, true, LDA, CI, TMW, TNW, DBK>(sA[cur], sB[cur], wrow0, wcol0, accW);   // dW += dZ^T * act(Z_{l-1})
+        mma_chunk_pipelined<true, true, LDA, CI, TMW, TNW, DBK>(sA[cur], sB[cur], wrow0, wcol0, accW);   // dW += dZ^T * act(Z_{l-1})
         {   // G_{l-1} chunk [DBK x 64] = dZ [DBK x CO] * W_l [CO x 64] as 16x16 tiles, HT per wave (v_mfma_f32_16x16x4_f32:
             // with 32x32 tiles only one or two waves would have work)
             typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -913,12 +969,30 @@ __global__ __launch_bounds__((CO >= 128 && CI == 128 ? 512 : 256), (CO >= 128 &&
 #pragma unroll
             for (int h = 0; h < HT; ++h) ax[h] = f32x4{0.f, 0.f, 0.f, 0.f};
             const int l15 = lane & 15, kq = lane >> 4;
-            const float* arow = sA[cur] + (xrow0 + l15) * LDA + kq;      // A[row][k], k = 4*step + kq
+            const float4* arow = reinterpret_cast<const float4*>(sA[cur] + (xrow0 + l15) * LDA + kq * KPL);   // A[row][k = kq*KPL + s]
+            constexpr int AB = 2, NB = KPL / (4 * AB);      // batches of AB float4 = 8 steps, fetched one batch ahead
+            float4 abuf[2][AB];
 #pragma unroll
-            for (int st = 0; st < CO / 4; ++st) {
-                const float av = arow[4 * st];
+            for (int j = 0; j < AB; ++j) abuf[0][j] = arow[j];
 #pragma unroll
-                for (int h = 0; h < HT; ++h) ax[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wfrag[h][st], ax[h], 0, 0, 0);
+            for (int bt = 0; bt < NB; ++bt) {
+                if (bt + 1 < NB) {
+#pragma unroll
+                    for (int j = 0; j < AB; ++j) abuf[(bt + 1) & 1][j] = arow[(bt + 1) * AB + j];
+                }
+#pragma unroll
+                for (int j = 0; j < AB; ++j) {
+                    const float4 a4 = abuf[bt & 1][j];
+                    const int st = (bt * AB + j) * 4;
+#pragma unroll
+                    for (int h = 0; h < HT; ++h) ax[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, wfrag[h][st], ax[h], 0, 0, 0);
+#pragma unroll
+                    for (int h = 0; h < HT; ++h) ax[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, wfrag[h][st + 1], ax[h], 0, 0, 0);
+#pragma unroll
+                    for (int h = 0; h < HT; ++h) ax[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, wfrag[h][st + 2], ax[h], 0, 0, 0);
+#pragma unroll
+                    for (int h = 0; h < HT; ++h) ax[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, wfrag[h][st + 3], ax[h], 0, 0, 0);
+                }
             }
             const int pk = p0 + kc * DBK;
 #pragma unroll
@@ -1589,7 +1663,7 @@ static int sa_mlp_fwd(const float* x0, int64_t P, int64_t K, int n_layers, const
             const unsigned gx = (unsigned)((P + ppb - 1) / ppb);
             const double fl = 2.0 * (double)P * Co_ * Ci_, by = 4.0 * ((double)P * (Ci_ + Co_) + (double)Co_ * Ci_);
             MP_LAUNCH("fwd_chunk_kernel<128, 128, false, 0, 4>", fl, by, (fwd_chunk_kernel<128, 128, false, SRC_ID, 4>), dim3(gx), dim3(256), 0, stream, A,
-                      (int)P, ppb, L.weight, L.z, partials, po);
+                      (int)P, ppb, L.weight, L.z, partials, po, L.gamma);
             MP_CHECK_LAUNCH();
             nblk = (int)gx;
         } else if (l == 1 && rc_first) {
@@ -1600,9 +1674,9 @@ static int sa_mlp_fwd(const float* x0, int64_t P, int64_t K, int n_layers, const
             char tg[64];
             snprintf(tg, sizeof tg, "fwd_chunk_kernel<%d, %d, false, 4>", Ci_, Co_);
             if (Co_ == 64)
-                MP_LAUNCH(tg, fl, by, (fwd_chunk_kernel<64, 64, false, SRC_ACT_RC>), dim3(gx), dim3(256), 0, stream, A, (int)P, ppb, L.weight, L.z, partials, po);
+                MP_LAUNCH(tg, fl, by, (fwd_chunk_kernel<64, 64, false, SRC_ACT_RC>), dim3(gx), dim3(256), 0, stream, A, (int)P, ppb, L.weight, L.z, partials, po, L.gamma);
             else
-                MP_LAUNCH(tg, fl, by, (fwd_chunk_kernel<64, 128, false, SRC_ACT_RC>), dim3(gx), dim3(256), 0, stream, A, (int)P, ppb, L.weight, L.z, partials, po);
+                MP_LAUNCH(tg, fl, by, (fwd_chunk_kernel<64, 128, false, SRC_ACT_RC>), dim3(gx), dim3(256), 0, stream, A, (int)P, ppb, L.weight, L.z, partials, po, L.gamma);
             MP_CHECK_LAUNCH();
             nblk = (int)gx;
         } else if (!bf16 && l > 0 && (Ci_ == 64 || Ci_ == 128) && (Co_ == 64 || Co_ == 128 || Co_ == 256) && (P % K) == 0 && (1024 % K == 0 || !fuse_pool) &&
@@ -1616,7 +1690,7 @@ static int sa_mlp_fwd(const float* x0, int64_t P, int64_t K, int n_layers, const
             snprintf(tg, sizeof tg, "fwd_chunk_kernel<%d, %d, %s>", Ci_, Co_, fuse_pool ? "true" : "false");
 #define MP_FWD(CI, CO, PL)                                                                                                     \
     MP_LAUNCH(tg, fl, by, (fwd_chunk_kernel<CI, CO, PL>), dim3(gx), dim3(CO > 128 ? 512 : 256), 0, stream, A, (int)P, ppb, L.weight, L.z, \
-              partials, po)
+              partials, po, L.gamma)
 #define MP_FWD_CO(CI, PL)                                  \
     if (Co_ == 64) MP_FWD(CI, 64, PL);                     \
     else if (Co_ == 128) MP_FWD(CI, 128, PL);              \
