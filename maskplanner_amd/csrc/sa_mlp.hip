@@ -945,15 +945,20 @@ __global__ __launch_bounds__((CO >= 128 && CI == 128 ? 512 : 256), (CO >= 128 &&
     for (int h = 0; h < HT; ++h)
 #pragma unroll
         for (int st = 0; st < CO / 4; ++st) wfrag[h][st] = W[(size_t)((lane >> 4) * KPL + st) * CI + xcol0 + 16 * h + (lane & 15)];
-    float spx[HT], tpx[HT], s1x[HT], s2x[HT];   // this lane's G columns
+    typedef float f2_ __attribute__((ext_vector_type(2)));
+    float spx[HT], tpx[HT];                     // this lane's G columns
+    f2_ sx1[HT], sx2[HT];                       // BatchNorm-backward sums of those columns, two row slots each
 #pragma unroll
     for (int h = 0; h < HT; ++h) {
         const int col = xcol0 + 16 * h + (lane & 15);
         spx[h] = IN.s[col];
         tpx[h] = IN.t[col];
-        s1x[h] = 0.0f;
-        s2x[h] = 0.0f;
+        sx1[h] = f2_{0.0f, 0.0f};
+        sx2[h] = f2_{0.0f, 0.0f};
     }
+    // G_{l-1} rows of this workgroup through a buffer resource: lane part of the offset in one VGPR, row part as immediates
+    const __amdgpu_buffer_rsrc_t grsrc = __builtin_amdgcn_make_buffer_rsrc(G + (size_t)p0 * CI, 0, (p1 - p0) * CI * 4, 0x00020000);
+    int goff = ((xrow0 + 4 * (lane >> 4)) * CI + xcol0 + (lane & 15)) * 4;
 
     gload(p0);
     sstore(0);
@@ -994,24 +999,25 @@ __global__ __launch_bounds__((CO >= 128 && CI == 128 ? 512 : 256), (CO >= 128 &&
                     for (int h = 0; h < HT; ++h) ax[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, wfrag[h][st + 3], ax[h], 0, 0, 0);
                 }
             }
-            const int pk = p0 + kc * DBK;
+            // epilogue written for instruction count (see fwd_chunk_kernel): buffer stores (rows past the workgroup's last
+            // position are dropped by the range check; their dZ rows were staged as zeros, so they add nothing to the sums),
+            // the four rows of a lane as two register pairs
+            typedef float f2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int row = xrow0 + 4 * kq + i;          // accumulator i of this lane: row 4*(lane/16) + i of the tile
-                const int pp = pk + row;
-                if (pp < p1) {
+            for (int h = 0; h < HT; ++h) {
+                const float* zr = sZ[cur] + (xrow0 + 4 * kq) * CI + xcol0 + 16 * h + l15;
 #pragma unroll
-                    for (int h = 0; h < HT; ++h) {
-                        const int col = xcol0 + 16 * h + l15;
-                        const float v = ax[h][i];
-                        const float zp = sZ[cur][row * CI + col];
-                        const float dy = (zp * spx[h] + tpx[h] > 0.0f) ? v : 0.0f;
-                        s1x[h] += dy;
-                        s2x[h] += dy * zp;
-                        G[(size_t)((unsigned)pp * (unsigned)CI + (unsigned)col)] = v;
-                    }
+                for (int i = 0; i < 4; i += 2) {
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ax[h][i]), grsrc, goff + 16 * h * 4, i * CI * 4, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ax[h][i + 1]), grsrc, goff + 16 * h * 4, (i + 1) * CI * 4, 0);
+                    const f2 zp = {zr[i * CI], zr[(i + 1) * CI]};
+                    const f2 y = zp * f2{spx[h], spx[h]} + f2{tpx[h], tpx[h]};
+                    const f2 dy = {y.x > 0.0f ? ax[h][i] : 0.0f, y.y > 0.0f ? ax[h][i + 1] : 0.0f};
+                    sx1[h] += dy;
+                    sx2[h] += dy * zp;
                 }
             }
+            goff += DBK * CI * 4;
         }
         if (kc + 1 < nchunks) sstore(cur ^ 1);
         __syncthreads();
@@ -1022,12 +1028,13 @@ __global__ __launch_bounds__((CO >= 128 && CI == 128 ? 512 : 256), (CO >= 128 &&
     __syncthreads();
 #pragma unroll
     for (int h = 0; h < HT; ++h) {
-        s1x[h] += __shfl_xor(s1x[h], 16, 64); s1x[h] += __shfl_xor(s1x[h], 32, 64);
-        s2x[h] += __shfl_xor(s2x[h], 16, 64); s2x[h] += __shfl_xor(s2x[h], 32, 64);
+        float s1x = sx1[h].x + sx1[h].y, s2x = sx2[h].x + sx2[h].y;
+        s1x += __shfl_xor(s1x, 16, 64); s1x += __shfl_xor(s1x, 32, 64);
+        s2x += __shfl_xor(s2x, 16, 64); s2x += __shfl_xor(s2x, 32, 64);
         if (lane < 16) {
             const int col = xcol0 + 16 * h + lane;
-            red[DBK == 32 ? (wave / (NW / 2)) : 0][0][col] = s1x[h];
-            red[DBK == 32 ? (wave / (NW / 2)) : 0][1][col] = s2x[h];
+            red[DBK == 32 ? (wave / (NW / 2)) : 0][0][col] = s1x;
+            red[DBK == 32 ? (wave / (NW / 2)) : 0][1][col] = s2x;
         }
     }
     __syncthreads();
@@ -1101,13 +1108,13 @@ __global__ __launch_bounds__(512) void bwd_first_kernel(PosOperand DZ, PosOperan
                                                            const float* __restrict__ W, float* __restrict__ dW,
                                                            float* __restrict__ G)
 {
-    constexpr int CO = 128, CIW = 132, CIX = 128, DBK = 16, LDA = CO + 1, LDB = CIW;
+    constexpr int CO = 128, CIW = 132, CIX = 128, DBK = 16, LDA = CO + 4, LDB = CIW, KPL = CO / 4;   // LDA, KPL: see bwd_fused_kernel
     constexpr int NT = 512;                             // eight waves: half the accumulators / weight fragments per wave
     constexpr int PA = DBK * CO / 4 / NT;               // 1
     constexpr int NB4 = DBK * CIW / 4;                  // 528 float4 of the input chunk
     constexpr int PB = (NB4 + NT - 1) / NT;             // 2 (the last pass has 16 live threads)
     typedef float f32x4 __attribute__((ext_vector_type(4)));
-    __shared__ float sA[2][DBK * LDA];
+    __shared__ __attribute__((aligned(16))) float sA[2][DBK * LDA];
     __shared__ __attribute__((aligned(16))) float sB[2][DBK * LDB];
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63, l15 = lane & 15, kq = lane >> 4, l31 = lane & 31;
@@ -1127,7 +1134,9 @@ __global__ __launch_bounds__(512) void bwd_first_kernel(PosOperand DZ, PosOperan
     const int xcol0 = wave * 16;                        // this wave's 16 grad_x0 columns (one 16x16 tile)
     float wfrag[CO / 4];
 #pragma unroll
-    for (int st = 0; st < CO / 4; ++st) wfrag[st] = W[(size_t)(4 * st + kq) * CIW + xcol0 + l15];
+    for (int st = 0; st < CO / 4; ++st) wfrag[st] = W[(size_t)(kq * KPL + st) * CIW + xcol0 + l15];   // permuted k: k = kq * KPL + st
+    const __amdgpu_buffer_rsrc_t grsrc = __builtin_amdgcn_make_buffer_rsrc(G + (size_t)p0 * CIW, 0, (p1 - p0) * CIW * 4, 0x00020000);
+    int goff = (4 * kq * CIW + xcol0 + l15) * 4;
 
     const int ca = (tid % (CO / 4)) * 4, ka0 = tid / (CO / 4);
     constexpr int KA_STEP = NT / (CO / 4);
@@ -1151,11 +1160,8 @@ __global__ __launch_bounds__(512) void bwd_first_kernel(PosOperand DZ, PosOperan
     };
     auto sstore = [&](int buf) {
 #pragma unroll
-        for (int ps = 0; ps < PA; ++ps) {
-            const float4 v = finish<MODE_DZ>(ra[ps], ka);
-            float* d = &sA[buf][(ka0 + ps * KA_STEP) * LDA + ca];
-            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-        }
+        for (int ps = 0; ps < PA; ++ps)
+            *reinterpret_cast<float4*>(&sA[buf][(ka0 + ps * KA_STEP) * LDA + ca]) = finish<MODE_DZ>(ra[ps], ka);
 #pragma unroll
         for (int ps = 0; ps < PB; ++ps) {
             const int e = ps * NT + tid;
@@ -1169,7 +1175,7 @@ __global__ __launch_bounds__(512) void bwd_first_kernel(PosOperand DZ, PosOperan
     for (int kc = 0; kc < nchunks; ++kc) {
         const int cur = kc & 1;
         if (kc + 1 < nchunks) gload(p0 + (kc + 1) * DBK);
-        mma_chunk<true, true, LDA, LDB, 1, 2, DBK>(sA[cur], sB[cur], wrow0, wcol0, accW);   // dW[:, 0:128] += dZ^T * X
+        mma_chunk_pipelined<true, true, LDA, LDB, 1, 2, DBK>(sA[cur], sB[cur], wrow0, wcol0, accW);   // dW[:, 0:128] += dZ^T * X
         {   // the 4 coordinate columns of dW
             const float* a = sA[cur] + (tid & 127);
             const float* t = sB[cur] + CIX + (tid >> 7);
@@ -1178,15 +1184,31 @@ __global__ __launch_bounds__(512) void bwd_first_kernel(PosOperand DZ, PosOperan
         }
         {   // grad_x0 chunk [16 x 128] = dZ [16 x 128] * W[:, 0:128]
             f32x4 ax = {0.f, 0.f, 0.f, 0.f};
-            const float* arow = sA[cur] + l15 * LDA + kq;
+            const float4* arow = reinterpret_cast<const float4*>(sA[cur] + l15 * LDA + kq * KPL);
+            constexpr int AB = 2, NB = KPL / (4 * AB);
+            float4 abuf[2][AB];
 #pragma unroll
-            for (int st = 0; st < CO / 4; ++st) ax = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[4 * st], wfrag[st], ax, 0, 0, 0);
-            const int pk = p0 + kc * DBK;
+            for (int j = 0; j < AB; ++j) abuf[0][j] = arow[j];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int pp = pk + 4 * kq + i;
-                if (pp < p1) G[(size_t)((unsigned)pp * (unsigned)CIW + (unsigned)(xcol0 + l15))] = ax[i];
+            for (int bt = 0; bt < NB; ++bt) {
+                if (bt + 1 < NB) {
+#pragma unroll
+                    for (int j = 0; j < AB; ++j) abuf[(bt + 1) & 1][j] = arow[(bt + 1) * AB + j];
+                }
+#pragma unroll
+                for (int j = 0; j < AB; ++j) {
+                    const float4 a4 = abuf[bt & 1][j];
+                    const int st = (bt * AB + j) * 4;
+                    ax = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, wfrag[st], ax, 0, 0, 0);
+                    ax = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, wfrag[st + 1], ax, 0, 0, 0);
+                    ax = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, wfrag[st + 2], ax, 0, 0, 0);
+                    ax = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, wfrag[st + 3], ax, 0, 0, 0);
+                }
             }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)      // rows past the workgroup's last position: dropped by the buffer's range check
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ax[i]), grsrc, goff, i * CIW * 4, 0);
+            goff += DBK * CIW * 4;
         }
         if (kc + 1 < nchunks) sstore(cur ^ 1);
         __syncthreads();
