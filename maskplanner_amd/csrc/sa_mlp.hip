@@ -62,6 +62,7 @@ struct PosOperand {
     const float* f;
     int C;
     int K;               // group size (pooled)
+    int kshift;          // log2(K) when K is a power of two (every sampled level), else -1: position -> (group, member) by shift / mask
     const float* rx;     // *_RC: the level's input rows X0 [P, 4]
     const float* rw;     // *_RC: the first layer's weight W0 [C, 4]
 };
@@ -116,8 +117,9 @@ __device__ __forceinline__ void raw_load(const PosOperand& o, int P, int p, int 
     if constexpr (MODE == SRC_DZ || MODE == SRC_DZ_RC) {
         r.g = ld4(o.g + (size_t)((unsigned)pp * (unsigned)o.C + (unsigned)cc));
     } else if constexpr (MODE == SRC_DZ_POOLED) {
-        const unsigned grp = (unsigned)pp / (unsigned)o.K;
-        r.kk = pp - (int)(grp * (unsigned)o.K);
+        unsigned grp;
+        if (o.kshift >= 0) { grp = (unsigned)pp >> o.kshift; r.kk = pp & (o.K - 1); }      // (a division by a run-time K is ~20 VALU instructions)
+        else { grp = (unsigned)pp / (unsigned)o.K; r.kk = pp - (int)(grp * (unsigned)o.K); }
         const size_t off = (size_t)(grp * (unsigned)o.C + (unsigned)cc);
         r.g = ld4(o.g + off);
         r.ak = *reinterpret_cast<const int4*>(o.argk + off);
@@ -132,6 +134,10 @@ __device__ __forceinline__ float xf1(float z, float g, float s, float t, float a
     } else if constexpr (MODE == SRC_ACT || MODE == SRC_ACT_RC) {
         const float y = z * s + t;
         return y > 0.0f ? y : 0.0f;
+    } else if constexpr (MODE == SRC_DZ_POOLED) {
+        // g is the pooled gradient at the group's arg-max member and 0 elsewhere, already masked by [pooled output > 0]
+        // (pool_bwd_prep_kernel) -- and the pooled output IS relu(z * s + t) of that member, so the ReLU mask is in g
+        return a * g + (e * z + f);
     } else {
         const float y = z * s + t;
         const float dy = y > 0.0f ? g : 0.0f;
@@ -1562,6 +1568,13 @@ int launch_pos_gemm(const PosOperand& A, int64_t P, const float* W, int N, int K
 }
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+inline int log2_or_neg(int64_t k)
+{
+    if (k <= 0 || (k & (k - 1))) return -1;
+    int s = 0;
+    while ((int64_t(1) << s) < k) ++s;
+    return s;
+}
 
 // MP_CHUNK_FWD=0 keeps the tiled GEMM kernel for every forward layer (A/B timing)
 inline bool chunk_fwd_enabled()
@@ -1665,6 +1678,7 @@ static int sa_mlp_fwd(const float* x0, int64_t P, int64_t K, int n_layers, const
     A.x = x0;
     A.C = (int)ch[0];
     A.K = (int)K;
+    A.kshift = log2_or_neg(K);
     for (int l = 0; l < n_layers; ++l) {
         const mp_mlp_layer_t& L = layers[l];
         int nblk = 0, rc = MP_OK;
@@ -1758,6 +1772,7 @@ static int sa_mlp_fwd(const float* x0, int64_t P, int64_t K, int n_layers, const
         A.t = L.shift;
         A.C = C;
         A.K = (int)K;
+        A.kshift = log2_or_neg(K);
         if (l == 0 && rc_first) { A.rx = x0; A.rw = L.weight; }
     }
     const mp_mlp_layer_t& LL = layers[n_layers - 1];
@@ -1896,10 +1911,12 @@ static int sa_mlp_bwd(const float* x0, int64_t P, int64_t K, int n_layers, const
         DZ.f = cbuf[2];
         DZ.C = Co;
         DZ.K = (int)K;
+        DZ.kshift = log2_or_neg(K);
         if (pooled) { DZ.g = gp; DZ.argk = argk; } else { DZ.g = G_cur; }
         PosOperand IN{};
         IN.C = Ci;
         IN.K = (int)K;
+        IN.kshift = log2_or_neg(K);
         if (l == 0) { IN.x = x0; } else { IN.x = layers[l - 1].z; IN.s = layers[l - 1].scale; IN.t = layers[l - 1].shift; }
         if (rc_first && l == 1) { IN.rx = x0; IN.rw = layers[0].weight; }   // act(Z_0) and raw Z_0 from the input rows
         if (rc_first && l == 0) { DZ.rx = x0; DZ.rw = Ly.weight; }          // dZ_0 = f(Z_0, G_0) likewise
