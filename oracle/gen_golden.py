@@ -23,6 +23,8 @@ g13_losses loss_handler.py:521-552,566-593,669-801,990-1009 + metrics_handler.py
                                          (asymm_v11, symm_v1, chamfer_with_stroke_masks, chamfer, symm_point, attraction, emd,
                                          per_segment_confidence) and stroke_masks_metrics
 g14_collate utils/dataset/paintnet_ODv1.py:726-847 Paintnet_ODv1_CollateBatch.__call__ on ragged synthetic samples
+g15_train models/pointnet2_cls_ssg.py:233-344 the full model of g5 (same weights) in TRAIN mode (dropout p = 0) on 8 clouds:
+                                         outputs, running statistics after the pass, gradients of a linear functional
 """
 import os
 import sys
@@ -663,12 +665,43 @@ def g14_collate():
     save("g14_collate", **cases)
 
 
+def g15_train():
+    print("g15_train")
+    pc = R.pointnet2_cls_ssg()
+    pu = R.pointnet2_utils()
+    g5 = np.load(os.path.join(OUT, "g5_model.npz"))
+    model = pc.PointNet2Regressor_StrokeMasks(outdim=12, outdim_orient=12, weight_orient=0.25, out_vectors=99,
+                                              hidden_size=(64, 64), pred_stroke_masks=True, n_stroke_masks=6,
+                                              mask_confidence_scores=True, segment_confidence_scores=False)
+    model.load_state_dict({k[3:]: torch.from_numpy(g5[k].copy()) for k in g5.files if k.startswith("sd_")}, strict=True)
+    model.train()
+    model.dropout.p = 0.0                      # train-mode BatchNorm everywhere, no dropout draw
+    rng = np.random.default_rng(1515)
+    B = 8
+    xyz = syn.point_cloud(rng, B, 1024, "cuboid")
+    s1, _ = ref_fps(pu, xyz, 512, 77)
+    torch.manual_seed(77)
+    _ = torch.randint(0, 1024, (B,))
+    s2 = torch.randint(0, 512, (B,)).numpy()
+    w_out = rng.normal(size=(B, 99, 24)).astype(np.float32)
+    w_sm = rng.normal(size=(B, 6, 99)).astype(np.float32)
+    torch.manual_seed(77)
+    out, sm_out, mask_conf, _ = model(torch.from_numpy(xyz).permute(0, 2, 1))
+    ((out * torch.from_numpy(w_out)).sum() + (sm_out * torch.from_numpy(w_sm)).sum() + mask_conf.sum()).backward()
+    grads = {"grad_" + n: p.grad.numpy().copy() for n, p in model.named_parameters()
+             if n in ("sa1.mlp_convs.1.weight", "sa1.mlp_bns.2.weight", "sa2.mlp_convs.2.weight", "sa2.mlp_bns.0.bias", "sa3.mlp_convs.0.weight",
+                      "sa3.mlp_bns.1.weight", "fc1.weight", "bn2.weight", "fc3.weight", "fc_normals.bias", "sm_fc3.bias", "mask_conf_out.weight")}
+    after = {"after_" + k: v.numpy().copy() for k, v in model.state_dict().items() if "running" in k or "num_batches" in k}
+    save("g15_train", xyz=xyz, fps_start1=s1, fps_start2=s2, w_out=w_out, w_sm=w_sm, out=out.detach().numpy(),
+         sm_out=sm_out.detach().numpy(), mask_conf=mask_conf.detach().numpy(), **grads, **after)
+
+
 def main():
     if not R.available():
         raise SystemExit("reference checkout not found; fixtures can only be generated in the build container")
     torch.set_num_threads(8)
     pu = R.pointnet2_utils()
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15"]
     if "g1" in which: g1_fps(pu)
     if "g2" in which: g2_bq(pu)
     if "g3" in which: g3_sa(pu)
@@ -683,6 +716,7 @@ def main():
     if "g12" in which: g12_flags()
     if "g13" in which: g13_losses()
     if "g14" in which: g14_collate()
+    if "g15" in which: g15_train()
 
 
 if __name__ == "__main__":

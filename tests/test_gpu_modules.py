@@ -1022,3 +1022,129 @@ def test_device_collate_matches_the_reference_collate(golden):
         assert np.array_equal(batch["stroke_masks"][i].cpu().numpy(), g[f"out_stroke_masks{i}"])
     assert sorted(k for k, v in batch.items() if v is None) == g["none_keys"].tolist()
     assert batch["n_strokes"] == g["n_strokes"].tolist() and batch["dirname"] == [f"sample_{i}" for i in range(n)]
+
+
+# ------------------------------------------------------------------------------------------------ whole model, train mode, at size
+def test_full_model_train_mode_matches_reference(golden):
+    """g15: the reference model of g5 (same weights) in TRAIN mode -- batch statistics in all 13 BatchNorm layers, dropout
+    p = 0 -- on 8 clouds: outputs, running statistics after the pass, gradients of a linear functional of the outputs."""
+    from maskplanner_amd import pointnet2_cls_ssg as pc
+    from maskplanner_amd import pointnet2_utils as pu
+    g5, g = golden("g5_model"), golden("g15_train")
+    model = pc.PointNet2Regressor_StrokeMasks(outdim=12, outdim_orient=12, weight_orient=0.25, out_vectors=99,
+                                              hidden_size=(64, 64), pred_stroke_masks=True, n_stroke_masks=6,
+                                              mask_confidence_scores=True, segment_confidence_scores=False)
+    load_sd(model, g5, "sd_").train()
+    model.dropout.p = 0.0
+    with pu.fps_start_override([g["fps_start1"], g["fps_start2"]]):
+        out, sm_out, mask_conf, _ = model(dev(g["xyz"]).permute(0, 2, 1))
+    # BatchNorm1d over 8 rows in the heads amplifies the encoder's 1e-6 rounding differences ~10x
+    close(out, g["out"], "out", rtol=1e-4, atol=1e-5)
+    close(sm_out, g["sm_out"], "sm_out", rtol=1e-4, atol=1e-5)
+    close(mask_conf, g["mask_conf"], "mask_conf", rtol=1e-4, atol=1e-5)
+    ((out * dev(g["w_out"])).sum() + (sm_out * dev(g["w_sm"])).sum() + mask_conf.sum()).backward()
+    for k, v in model.state_dict().items():
+        if "running" in k:
+            close(v, g["after_" + k], k, rtol=2e-5, atol=1e-6)
+        elif "num_batches" in k:
+            assert int(v) == int(g["after_" + k]), k
+    params = dict(model.named_parameters())
+    for k in g.files:
+        if k.startswith("grad_"):
+            got, want = params[k[5:]].grad.cpu(), torch.from_numpy(g[k])
+            rel = float((got - want).norm() / want.norm())
+            assert rel < 1e-2, (k, rel)      # max-pool routing + small-batch BatchNorm1d: see tests/test_gpu_bf16.py
+
+
+@pytest.mark.parametrize("category", ["windows", "shelves"])
+def test_windows_shelves_at_bench_size(category, oracle):
+    """BASELINE configs[2], [3]: windows (S = 449, M = 22) and shelves (S = 1266, M = 41) at N = 5120, B = 32 per GPU with
+    the mask terms on.  80 replayed training steps: finite gradients and parameters, no failed stroke-mask matching, loss
+    going down; and the first 4 clouds' eval-mode forward + loss against the CPU oracle at 1e-5."""
+    from maskplanner_amd import loss_handler as LH
+    from maskplanner_amd.harness import TrainStep
+    from oracle import torch_ref as T
+    ts = TrainStep(category, B=32, N=5120, graph=True)
+    assert ts.cfg["explicit_weight_stroke_masks"] == 1.0 and ts.cfg["explicit_weight_stroke_masks_confidence"] == 100.0
+    sd = {k: v.detach().cpu().clone() for k, v in ts.model.state_dict().items()}
+    b = {k: (v[:4].cpu() if torch.is_tensor(v) else [t[:4].cpu() for t in v]) for k, v in ts.batch.items()}
+    # oracle on a 4-cloud slice, eval-mode BatchNorm (initial running statistics), before any training step
+    ts.model.eval()
+    full = ts.batch
+    ts.batch = {k: (v[:4].contiguous() if torch.is_tensor(v) else [t[:4].contiguous() for t in v]) for k, v in full.items()}
+    ts.point_cloud = ts.batch["point_cloud"].permute(0, 2, 1)
+    overlap, ts.overlap = ts.overlap, False
+    with torch.no_grad():
+        got = float(ts.forward_loss())
+    ts.batch, ts.overlap = full, overlap
+    ts.point_cloud = full["point_cloud"].permute(0, 2, 1)
+    o_out, o_sm, o_conf = T.strokemasks_forward(sd, b["point_cloud"], [s.numpy() for s in b["fps_start"]], train=False,
+                                                out_vectors=ts.cat.out_vectors, n_masks=ts.cat.max_n_strokes)
+    ref = float(T.asymm_v6_loss(o_out, b["traj"], o_sm, o_conf, b["stroke_ids"], b["traj_as_pc"], ts.cfg))
+    assert abs(got - ref) <= 1e-5 * max(1.0, abs(ref)), (got, ref)
+    ts.model.train()
+    params = list(ts.model.parameters())
+    losses = []
+    for s in range(80):
+        losses.append(ts.step())
+        if s % 8 == 0:
+            assert all(bool(torch.isfinite(p).all()) for p in params), s
+            assert all(bool(torch.isfinite(p.grad).all()) for p in params if p.grad is not None), s
+    assert ts._graph is not None
+    LH.check_mask_matching()
+    losses = [float(l) for l in losses]
+    assert np.isfinite(losses).all() and min(losses[-10:]) < losses[0], losses[::10]
+
+
+def test_full_size_train_step_b32_vs_oracle(oracle):
+    """BASELINE configs[1] exactly -- cuboids, N = 5120, B = 32, train-mode BatchNorm, dropout off -- forward, loss and
+    backward against the CPU oracle.  The encoder's global feature meets the contract's 1e-5.  Behind it the heads normalise
+    [32, 1024] activations with BatchNorm1d: the synthetic cuboid clouds give near-identical features, so channels whose
+    variance over the 32 samples is tiny amplify the 1e-6 differences of the feature (2.3e-4 of the output scale measured; the
+    eval-mode model, where nothing is amplified, is held to 1e-5 by g5 and by test_windows_shelves_at_bench_size).  Gradients
+    agree up to the max-pool routing noise (a 1e-7 forward difference re-routes the gradient of the few groups whose two largest
+    members are that close); parameters whose gradient is a near-total cancellation are not compared."""
+    from maskplanner_amd import ops
+    from maskplanner_amd import pointnet2_cls_ssg as pc
+    from maskplanner_amd import pointnet2_utils as pu
+    from maskplanner_amd import synthetic as syn
+    from maskplanner_amd.loss_handler import LossHandler, maskplanner_loss_config
+    from oracle import torch_ref as T
+    B, N = 32, 5120
+    cat = syn.CATEGORIES["cuboids"]
+    batch = syn.make_batch(17, B, N, "cuboids", "cuboid")
+    torch.manual_seed(4)
+    model = pc.maskplanner_model(cat, hidden_size=(256, 256))
+    model.dropout.p = 0.0
+    sd = {k: v.detach().clone().requires_grad_(v.dtype.is_floating_point and "running" not in k) for k, v in model.state_dict().items()}
+    model = model.cuda().train()
+    cfg = maskplanner_loss_config()
+    lh = LossHandler(["asymm_v6_chamfer_with_stroke_masks"], cfg)
+    det, ops.DETERMINISTIC = ops.DETERMINISTIC, True
+    try:
+        with pu.fps_start_override(batch["fps_start"]):
+            feat = model.encode(batch["point_cloud"].cuda().permute(0, 2, 1))
+            out, sm, conf, _ = model.heads(feat)
+        loss = lh.compute(return_list=False, y_pred=out, y=batch["traj"].cuda(), pred_stroke_masks=sm, mask_scores=conf,
+                          seg_logits=None, stroke_ids=batch["stroke_ids"], traj_as_pc=batch["traj_as_pc"])
+        loss.backward()
+    finally:
+        ops.DETERMINISTIC = det
+    starts = [s.numpy() for s in batch["fps_start"]]
+    o_feat = T.encoder_forward(sd, batch["point_cloud"], starts, True)
+    o_out, o_sm, o_conf = T.strokemasks_forward(sd, batch["point_cloud"], starts, train=True, out_vectors=cat.out_vectors,
+                                                n_masks=cat.max_n_strokes)
+    o_loss = T.asymm_v6_loss(o_out, batch["traj"], o_sm, o_conf, batch["stroke_ids"], batch["traj_as_pc"], cfg)
+    o_loss.backward()
+    close(feat, o_feat, "encoder feature", rtol=1e-5, atol=1e-5)
+    close(out, o_out, "out", rtol=6e-4, atol=1e-5)
+    close(sm, o_sm, "sm_out", rtol=6e-4, atol=1e-5)
+    close(loss, o_loss, "loss", rtol=2e-4)
+    params = dict(model.named_parameters())
+    for name, bound in (("sa1.mlp_convs.0.weight", 5e-2), ("sa1.mlp_bns.1.weight", 2e-2), ("sa2.mlp_convs.2.weight", 2e-2),
+                        ("sa2.mlp_bns.0.bias", 2e-2), ("sa3.mlp_convs.1.weight", 2e-2), ("sa3.mlp_bns.1.weight", 2e-2),
+                        ("fc1.weight", 2e-2), ("fc3.weight", 2e-2), ("fc_normals.weight", 2e-2), ("sm_fc3.weight", 2e-2),
+                        ("sm_fc3.bias", 2e-2), ("mask_conf_out.weight", 2e-2)):
+        gp, gr = params[name].grad.cpu(), sd[name].grad
+        rel = float((gp - gr).norm() / gr.norm())
+        assert rel < bound, f"{name}: relative L2 error {rel:.3e}"

@@ -234,3 +234,17 @@ def test_three_interpolate_backward_is_the_adjoint(oracle):
     rhs = (oracle.three_interpolate_bwd(go, idx, w, S).astype(np.float64) * p2).sum()
     assert abs(lhs - rhs) <= 1e-4 * max(1.0, abs(lhs))
 
+
+
+def test_full_model_train_mode_matches_reference(golden):
+    """g15: the reference model of g5 in train mode (dropout p = 0) on 8 clouds -- the oracle's train-mode restatement
+    (batch statistics in every BatchNorm, running-stat updates) against the imported reference's outputs."""
+    g5, g = golden("g5_model"), golden("g15_train")
+    sd = _sd(g5, "")
+    out, sm_out, mask_conf = T.strokemasks_forward(sd, torch.from_numpy(g["xyz"]), [g["fps_start1"], g["fps_start2"]],
+                                                   train=True, out_vectors=99, n_masks=6)
+    _close(out, g["out"], "out", rtol=1e-4, atol=1e-5)          # BatchNorm1d over 8 rows amplifies rounding ~10x
+    _close(sm_out, g["sm_out"], "sm_out", rtol=1e-4, atol=1e-5)
+    _close(mask_conf, g["mask_conf"], "mask_conf", rtol=1e-4, atol=1e-5)
+    for k in ("sa1.mlp_bns.0.running_mean", "sa2.mlp_bns.2.running_var", "sa3.mlp_bns.1.running_mean", "bn1.running_var"):
+        _close(sd[k], g["after_" + k], k, rtol=2e-5, atol=1e-6)
