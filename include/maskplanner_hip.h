@@ -352,6 +352,21 @@ int mp_adam_multi_f32(int64_t count, float* const* params, const float* const* g
 int mp_pad_ragged_f32(const float* flat, const int64_t* offsets, int64_t B, int64_t R, int64_t D, float fill, float* out,
                       mp_stream_t stream);
 
+/* ---- lambda-segments of a batch on the device ---------------------------------------------------------------------------
+ * replaces: utils/pointcloud.py:294-413 get_sequences_of_lambda_points (+ add_padding :98-105) as the dataset calls it per
+ *           sample (utils/dataset/paintnet_ODv1.py:294) followed by the collate function's padding (:738-748).
+ *   poses [T, D] f32: the poses of all samples back to back; stroke_ids [T] f32 (per sample ascending 0, 0, .., 1, ..);
+ *   offsets [B+1] i64: sample b owns rows offsets[b] .. offsets[b+1].  Per stroke of L >= lambda poses: with overlapping > 0
+ *   (L - lambda) / (lambda - overlapping) + 1 windows of lambda consecutive poses, stride lambda - overlapping; with
+ *   overlapping = 0, L / lambda windows starting at pose (L % lambda) / 2.  Shorter strokes are dropped and the others
+ *   renumbered.  out_traj [B, R, lambda*D] (rows behind a sample's last window: -100), out_ids [B, R] (-1); the caller picks
+ *   R >= the largest window count (the reference pads each sample to (n - lambda) / (lambda - overlapping) + 1 rows, resp.
+ *   n / lambda, and the batch to the largest of those).  status [B] i32: MP_OK, MP_EINVAL (ids not ascending / not contiguous,
+ *   or more windows than R), MP_EUNSUPPORTED (more than 1024 strokes in a sample). */
+int mp_lambda_segments_f32(const float* poses, const float* stroke_ids, const int64_t* offsets, int64_t B, int64_t D,
+                           int64_t lambda, int64_t overlapping, int64_t R, float* out_traj, float* out_ids, int32_t* status,
+                           mp_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

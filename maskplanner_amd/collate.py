@@ -41,6 +41,34 @@ def pad_ragged(arrays, fill, device="cuda", total_needed=None):
     return out[..., 0] if one_d else out
 
 
+def lambda_segments(poses, stroke_ids, lmbda, overlapping=0, device="cuda"):
+    """get_sequences_of_lambda_points (utils/pointcloud.py:294-413, padding=True) for a whole batch, on the device.
+
+    poses: B numpy arrays [n_b, D] (one pose per row, strokes back to back); stroke_ids: B arrays [n_b] (ascending 0, 0, .., 1, ..).
+    -> (traj f32 [B, R, lmbda*D] padded with -100, ids f32 [B, R] padded with -1) with R = the largest per-sample row count the
+    reference pads to ((n - lmbda) // (lmbda - overlapping) + 1, resp. n // lmbda), i.e. the tensors its dataset + collate
+    function produce together (utils/dataset/paintnet_ODv1.py:294, 738-748).  One flat host-to-device copy per key."""
+    poses = [np.asarray(p, dtype=np.float32) for p in poses]
+    ids = [np.asarray(i, dtype=np.float32).reshape(-1) for i in stroke_ids]
+    D = poses[0].shape[1]
+    lens = [p.shape[0] for p in poses]
+    if any(p.ndim != 2 or p.shape[1] != D for p in poses) or [i.shape[0] for i in ids] != lens:
+        raise ValueError("poses must be [n_b, D] arrays with one stroke id per pose")
+    rows = [((n - lmbda) // (lmbda - overlapping) + 1 if overlapping else n // lmbda) if n >= lmbda else 0 for n in lens]
+    B, R = len(poses), max(rows + [0])
+    dev = torch.device(device)
+    flat = torch.from_numpy(np.concatenate(poses, axis=0)).to(dev, non_blocking=True)
+    fid = torch.from_numpy(np.concatenate(ids, axis=0)).to(dev, non_blocking=True)
+    offsets = torch.from_numpy(np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)).to(dev, non_blocking=True)
+    traj = torch.empty((B, R, lmbda * D), dtype=torch.float32, device=dev)
+    out_ids = torch.empty((B, R), dtype=torch.float32, device=dev)
+    status = torch.empty((B,), dtype=torch.int32, device=dev)
+    ops._run("lambda_segments", traj, _lib.load().mp_lambda_segments_f32, flat.data_ptr() if flat.numel() else None,
+             fid.data_ptr() if fid.numel() else None, offsets.data_ptr(), B, D, int(lmbda), int(overlapping), R, traj.data_ptr(),
+             out_ids.data_ptr(), status.data_ptr())
+    return traj, out_ids, status
+
+
 class Paintnet_ODv1_CollateBatch:
     """collate_fn for torch.utils.data.DataLoader: a list of dataset items -> the batch dict of the reference, on `device`."""
 

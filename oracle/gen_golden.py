@@ -23,6 +23,7 @@ g13_losses loss_handler.py:521-552,566-593,669-801,990-1009 + metrics_handler.py
                                          (asymm_v11, symm_v1, chamfer_with_stroke_masks, chamfer, symm_point, attraction, emd,
                                          per_segment_confidence) and stroke_masks_metrics
 g14_collate utils/dataset/paintnet_ODv1.py:726-847 Paintnet_ODv1_CollateBatch.__call__ on ragged synthetic samples
+g16_lambda utils/pointcloud.py:294-413 get_sequences_of_lambda_points (+ add_padding) on ragged synthetic strokes
 g15_train models/pointnet2_cls_ssg.py:233-344 the full model of g5 (same weights) in TRAIN mode (dropout p = 0) on 8 clouds:
                                          outputs, running statistics after the pass, gradients of a linear functional
 """
@@ -696,12 +697,50 @@ def g15_train():
          sm_out=sm_out.detach().numpy(), mask_conf=mask_conf.detach().numpy(), **grads, **after)
 
 
+def g16_lambda():
+    """The reference's segment builder on ragged strokes (one dropped for being shorter than lambda), overlapping 1 (the
+    maskplanner configs) and 0 (centred windows), in a fresh interpreter with the real `utils` package."""
+    print("g16_lambda")
+    import subprocess
+    import tempfile
+    rng = np.random.default_rng(1616)
+    cases = {}
+    samples = []
+    for i, lens in enumerate([(9, 4, 13), (3, 17, 6, 5), (25,), (7, 7, 2, 11, 4)]):
+        n = sum(lens)
+        poses = rng.normal(size=(n, 6)).astype(np.float32)
+        ids = np.concatenate([np.full(L, s, dtype=np.float32) for s, L in enumerate(lens)])
+        samples.append((poses, ids))
+        cases[f"poses{i}"], cases[f"ids{i}"] = poses, ids
+    tmp = tempfile.mkdtemp(prefix="mp_g16_")
+    np.savez(os.path.join(tmp, "in.npz"), **cases)
+    code = f"""
+import sys, numpy as np
+sys.path.insert(0, {ROOT!r})
+from oracle import env_stubs
+env_stubs.install()
+sys.path.insert(0, {R.REF_ROOT!r})
+from utils.pointcloud import get_sequences_of_lambda_points
+d = np.load({os.path.join(tmp, 'in.npz')!r})
+out = {{}}
+for i in range({len(samples)}):
+    for lam, ov in ((4, 1), (4, 0), (3, 2)):
+        t, s = get_sequences_of_lambda_points(d[f'poses{{i}}'].copy(), d[f'ids{{i}}'].copy(), lam, 'x', overlapping=ov, extra_data=['orientnorm'])
+        out[f'traj{{i}}_{{lam}}_{{ov}}'], out[f'sid{{i}}_{{lam}}_{{ov}}'] = t.astype(np.float32), s.astype(np.float32)
+np.savez({os.path.join(tmp, 'out.npz')!r}, **out)
+"""
+    subprocess.run([sys.executable, "-c", code], check=True, cwd=R.REF_ROOT)
+    cases.update(dict(np.load(os.path.join(tmp, "out.npz"))))
+    cases["n_samples"] = np.int64(len(samples))
+    save("g16_lambda", **cases)
+
+
 def main():
     if not R.available():
         raise SystemExit("reference checkout not found; fixtures can only be generated in the build container")
     torch.set_num_threads(8)
     pu = R.pointnet2_utils()
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16"]
     if "g1" in which: g1_fps(pu)
     if "g2" in which: g2_bq(pu)
     if "g3" in which: g3_sa(pu)
@@ -717,6 +756,7 @@ def main():
     if "g13" in which: g13_losses()
     if "g14" in which: g14_collate()
     if "g15" in which: g15_train()
+    if "g16" in which: g16_lambda()
 
 
 if __name__ == "__main__":

@@ -1148,3 +1148,30 @@ def test_full_size_train_step_b32_vs_oracle(oracle):
         gp, gr = params[name].grad.cpu(), sd[name].grad
         rel = float((gp - gr).norm() / gr.norm())
         assert rel < bound, f"{name}: relative L2 error {rel:.3e}"
+
+
+def test_device_lambda_segments_match_the_reference(golden):
+    """utils/pointcloud.py:294-413 (get_sequences_of_lambda_points + add_padding) on ragged strokes -- g16, produced by the
+    imported reference: lambda 4 / overlap 1 (the maskplanner configs), lambda 4 / overlap 0 (centred windows), lambda 3 /
+    overlap 2; one stroke per sample set shorter than lambda (dropped, the rest renumbered).  The device kernel builds the
+    whole batch at once, padded to the batch maximum: every sample's rows equal the reference's, bit for bit."""
+    from maskplanner_amd.collate import lambda_segments
+    g = golden("g16_lambda")
+    n = int(g["n_samples"])
+    poses = [g[f"poses{i}"] for i in range(n)]
+    ids = [g[f"ids{i}"] for i in range(n)]
+    for lam, ov in ((4, 1), (4, 0), (3, 2)):
+        traj, sid, status = lambda_segments(poses, ids, lam, ov)
+        assert (status.cpu().numpy() == 0).all()
+        traj, sid = traj.cpu().numpy(), sid.cpu().numpy()
+        R = max(g[f"traj{i}_{lam}_{ov}"].shape[0] for i in range(n))
+        assert traj.shape == (n, R, lam * 6) and sid.shape == (n, R)
+        for i in range(n):
+            want_t, want_s = g[f"traj{i}_{lam}_{ov}"], g[f"sid{i}_{lam}_{ov}"]
+            r = want_t.shape[0]
+            assert np.array_equal(traj[i, :r], want_t) and np.array_equal(sid[i, :r], want_s), (i, lam, ov)
+            assert (traj[i, r:] == -100).all() and (sid[i, r:] == -1).all()
+    # malformed ids are reported, not silently mis-segmented
+    bad = [np.array([0, 0, 2, 2, 2, 2], dtype=np.float32), np.array([0, 0, 0, 0, 1, 1, 1, 1], dtype=np.float32)]
+    _, _, status = lambda_segments([np.zeros((6, 6), np.float32), np.zeros((8, 6), np.float32)], bad, 4, 1)
+    assert status.cpu().tolist()[0] != 0 and status.cpu().tolist()[1] == 0
