@@ -19,6 +19,8 @@ Extra objects in the line (rank 0, N=1):
   dropin_path  -- the reference's own loop body (train_maskplanner.py:182-227) on the drop-in modules: torch.optim.Adam over
                   all parameters, a fresh host batch per step, compute() -> numpy, loss.item().  `--path dropin` makes this
                   the headline `value` instead.
+  streamed_inputs -- the harness step fed a fresh HOST batch every step (PCIe-inclusive): batch k+1 is collated onto the device
+                  and sampled on the second stream during step k.  `--stream-batches K` makes this the headline run.
   ucube        -- the same step on U[-1,1]^3 clouds (sparse balls: full-scan ball query, heavy padding).
   cpu_baseline -- the CPU restatement of the same step (oracle/) on this box's host cores, bounded sample.
 """
@@ -213,6 +215,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch every step kernel by kernel (no hipGraph replay)")
     ap.add_argument("--overlap-sampling", type=int, default=None, help="1/0: next batch's FPS + ball query on a second stream")
     ap.add_argument("--sync-bn", action="store_true", help="data-parallel runs: BatchNorm statistics over the global batch")
+    ap.add_argument("--stream-batches", type=int, default=0,
+                    help="K > 0: rotate K host batches through the step, each collated onto the device during the previous step")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -240,8 +244,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def make_harness(dist_points):
+    def make_harness(dist_points, stream=None):
         kw = {}
+        if (args.stream_batches if stream is None else stream):
+            kw.update(stream_batches=args.stream_batches if stream is None else stream)
         if args.encoder != "ssg" or args.dtype != "f32":
             kw.update(encoder=args.encoder, mlp_dtype=args.dtype)
         if args.sync_bn:
@@ -267,7 +273,7 @@ def main():
             return loss
         # per-kernel HIP events (two records per library launch) on every 20th timed step, rank 0 only: the hooks cost
         # ~0.5 ms per profiled step, so sampling keeps the headline number honest
-        prof = (lambda i: i % profile_every == 0) if rank == 0 else None
+        prof = (lambda i: i % profile_every == 0) if (rank == 0 and profile_every) else None
         dt, per_step, loss = time_steps(step, steps, warmup, barrier, prof)
         n_prof = len([i for i in range(steps) if prof is not None and prof(i)])
         return dt, per_step, float(loss.detach()), n_prof
@@ -318,7 +324,9 @@ def main():
                                                                       if ts._graph_b is not None else ""))
                 if ts._graph is not None else "eager (kernel by kernel)",
                 "sampling": "next batch's first-level FPS + ball query on a second stream, under the step" if ts.overlap else "in line",
-                "batchnorm": "global-batch statistics (SyncBN)" if getattr(ts, "sync_bn", False) else "per-replica statistics"})
+                "batchnorm": "global-batch statistics (SyncBN)" if getattr(ts, "sync_bn", False) else "per-replica statistics",
+                "inputs": ("a fresh host batch per step, collated onto the device during the previous step" if getattr(ts, "_stream", None)
+                           else "one batch resident in HBM")})
             kernels = collect_kernel_profile(lib)
             # dominant kernel = largest total device time on the step's own stream; its binding roof from the algorithmic work
             # model.  (With pipelined sampling the first-level FPS -- a latency-bound chain of dependent arg-max steps, one
@@ -347,10 +355,19 @@ def main():
                                    "step_ms_median": dper[len(dper) // 2], "final_loss": dloss,
                                    "what": "train_maskplanner.py:182-227 loop body on the drop-in modules: torch.optim.Adam on all parameters, "
                                            "fresh host batch per step (H2D inside the step), FPS starts drawn per call, compute() -> numpy, loss.item()"}
-            # U-cube clouds (SURVEY 8d): sparse balls => full-scan ball query and heavy padding
+            # PCIe-inclusive: a fresh host batch every step, collated + sampled on the second stream under the previous step
             del ts
             torch.cuda.empty_cache()
-            tu = make_harness("ucube")
+            tsx = make_harness("cuboid", stream=4)
+            sdt, sper, sloss, _ = run_harness(tsx, k, 3, profile_every=None)
+            line["streamed_inputs"] = {"value": args.batch * k / sdt, "unit": "point-clouds/s", "ms_per_step": sdt / k * 1e3, "steps": k,
+                                       "step_ms_median": sper[len(sper) // 2] if sper else None, "final_loss": sloss,
+                                       "what": "4 host batches of ragged dataset items in rotation; batch k+1 goes through the device collate "
+                                               "(pinned flat copy per key + pad kernel) and its FPS / ball query on the second stream during step k"}
+            del tsx
+            # U-cube clouds (SURVEY 8d): sparse balls => full-scan ball query and heavy padding
+            torch.cuda.empty_cache()
+            tu = make_harness("ucube", stream=0)
             lib.mp_profiler_collect(None, 0)
             udt, uper, uloss, uprof = run_harness(tu, k, 3, profile_every=10)
             uk = collect_kernel_profile(lib)

@@ -17,7 +17,7 @@ from .pointnet2_cls_ssg import maskplanner_model
 class TrainStep:
     def __init__(self, category="cuboids", B=32, N=5120, device="cuda", seed=1235, hidden_size=(1024, 1024), lr=1e-3,
                  dist_points="cuboid", rank=0, loss_overrides=None, prefetch_sampling=False, factor_heads=True, graph=None,
-                 overlap_sampling=None, encoder="ssg", mlp_dtype="f32", sync_bn=False):
+                 overlap_sampling=None, encoder="ssg", mlp_dtype="f32", sync_bn=False, stream_batches=0):
         self.cat = synthetic.CATEGORIES[category] if isinstance(category, str) else category
         self.device = torch.device(device)
         torch.manual_seed(seed)  # identical initial weights on every rank
@@ -81,6 +81,16 @@ class TrainStep:
         b = synthetic.make_batch(seed + 1000 * rank, B, N, self.cat.name, dist_points)  # a different shard per rank
         self.batch = {k: (v.to(self.device) if torch.is_tensor(v) else [t.to(self.device) for t in v])
                       for k, v in b.items()}
+        # Streamed inputs (stream_batches = K > 0): K different host batches of ragged dataset items rotate through the step; batch
+        # k+1 is collated onto the device (maskplanner_amd.collate: one flat copy per key + the pad kernel) and its sampling plan
+        # computed on the second stream WHILE step k runs (_pipeline_sampling).  The step's own tensors keep fixed shapes (ground
+        # truth padded to the category's maximum, per-sample lengths come from the -100 sentinel anyway), so the recorded graphs
+        # stay valid.  0: the same resident batch every step (the headline bench: inputs resident in HBM).
+        self._stream = None
+        if stream_batches and fused and not prefetch_sampling and encoder == "ssg":
+            self._stream = _BatchStream(self, [synthetic.make_samples(seed + 1000 * rank + 17 * i, B, N, self.cat.name, dist_points)
+                                               for i in range(int(stream_batches))])
+            self.overlap = True      # the next batch's sampling rides on the same side stream as its collation
         # [B,3,N] as the loop feeds it (:207-208): a permuted VIEW of the collated [B,N,3] tensor, so the encoder's
         # permute back to points-major is free
         self.point_cloud = self.batch["point_cloud"].permute(0, 2, 1)
@@ -273,12 +283,13 @@ class TrainStep:
             o += n0 + n1 + n2
         return out
 
-    def _sample_levels(self, buf):
+    def _sample_levels(self, buf, xyz=None, starts=None):
         """FPS + ball query of every level: each level samples the previous level's centroids, nothing else -- the whole
         plan depends on the input cloud only."""
         from . import ops
-        xyz = self.batch["point_cloud"]
-        for m, start, (fps_idx, new_xyz, idx) in zip(self._plan_levels(), self.batch["fps_start"], self._plan_views(buf)):
+        xyz = self.batch["point_cloud"] if xyz is None else xyz
+        starts = self.batch["fps_start"] if starts is None else starts
+        for m, start, (fps_idx, new_xyz, idx) in zip(self._plan_levels(), starts, self._plan_views(buf)):
             start = torch.as_tensor(start, dtype=torch.long).to(xyz.device)
             ops.fps(xyz, m.npoint, start, out=(fps_idx, new_xyz))
             ops.ball_query(m.radius, m.nsample, xyz, new_xyz, out=idx)
@@ -293,15 +304,25 @@ class TrainStep:
         if self._plan_next is None:
             self._plan_next = torch.zeros(self._plan_size(), dtype=torch.int64, device=self.device)
             self._plan_cur = torch.zeros_like(self._plan_next)
-            self._sample_levels(self._plan_next)
+            if self._stream is not None:
+                xyz, starts = self._stream.collate_next()
+                self._sample_levels(self._plan_next, xyz, starts)
+            else:
+                self._sample_levels(self._plan_next)
             self._plan_stream = torch.cuda.Stream()
         if self._plan_ev is not None:
-            main.wait_event(self._plan_ev)                       # the previous step's sampling is complete
+            main.wait_event(self._plan_ev)                       # the previous step's sampling (and collation) is complete
         torch.add(self._plan_next, 0, out=self._plan_cur)        # an elementwise kernel into the step's static buffer
+        if self._stream is not None:
+            self._stream.publish()                               # the collated next batch becomes the step's batch
         side = self._plan_stream
-        side.wait_stream(main)                                   # ... and only then may the next plan be overwritten
+        side.wait_stream(main)                                   # ... and only then may the next plan / staging be overwritten
         with torch.cuda.stream(side):
-            self._sample_levels(self._plan_next)
+            if self._stream is not None:
+                xyz, starts = self._stream.collate_next()        # host items -> device staging tensors, on the side stream
+                self._sample_levels(self._plan_next, xyz, starts)
+            else:
+                self._sample_levels(self._plan_next)
             self._plan_ev = torch.cuda.Event()
             self._plan_ev.record(side)
 
@@ -337,6 +358,70 @@ class TrainStep:
         if self.factor_opt is not None:
             self.factor_opt.step()
         return loss.detach()   # callers never keep the autograd graph (and its accumulator nodes) alive across steps
+
+
+class _BatchStream:
+    """Host dataset items -> the step's device batch, one batch ahead (TrainStep(stream_batches=K)).  Staging tensors on the
+    device have the step's fixed shapes; collate_next() fills them on the CURRENT (side) stream from pinned host buffers (one
+    copy per key, then csrc/collate.hip's pad kernel); publish() copies them into the step's static tensors on the main stream."""
+    KEYS = (("traj", -100.0), ("traj_as_pc", -100.0), ("stroke_ids", -1.0))
+
+    def __init__(self, ts, batches):
+        self.ts, self.batches, self.i = ts, batches, 0
+        dev = ts.device
+        B, N = ts.batch["point_cloud"].shape[:2]
+        self.width = {k: max(max(it[k].shape[0] for it in b) for b in batches) for k, _ in self.KEYS}
+        self.dim = {k: (batches[0][0][k].shape[1] if batches[0][0][k].ndim == 2 else 1) for k, _ in self.KEYS}
+        # the step's static tensors get the fixed widths (before anything is recorded)
+        for k, fill in self.KEYS:
+            shape = (B, self.width[k]) + ((self.dim[k],) if batches[0][0][k].ndim == 2 else ())
+            ts.batch[k] = torch.full(shape, fill, dtype=torch.float32, device=dev)
+        self.stage = {k: torch.empty_like(ts.batch[k]) for k, _ in self.KEYS}
+        self.stage["point_cloud"] = torch.empty_like(ts.batch["point_cloud"])
+        self.stage_starts = [torch.zeros(B, dtype=torch.long, device=dev) for _ in ts.batch["fps_start"]]
+        cap = {k: B * self.width[k] * self.dim[k] for k, _ in self.KEYS}
+        self.pin = {k: torch.empty(cap[k], dtype=torch.float32).pin_memory() for k, _ in self.KEYS}
+        self.pin["point_cloud"] = torch.empty(B * N * 3, dtype=torch.float32).pin_memory()
+        self.pin_off = {k: torch.empty(B + 1, dtype=torch.int64).pin_memory() for k, _ in self.KEYS}
+        self.pin_starts = [torch.empty(B, dtype=torch.long).pin_memory() for _ in ts.batch["fps_start"]]
+        self.dev_flat = {k: torch.empty(cap[k], dtype=torch.float32, device=dev) for k, _ in self.KEYS}
+        self.dev_off = {k: torch.empty(B + 1, dtype=torch.int64, device=dev) for k, _ in self.KEYS}
+        self.host_ev = None        # the previous collation's copies out of the pinned buffers are complete
+        self.levels_n = [N] + [m.npoint for m in ts._plan_levels()][:-1]
+
+    def collate_next(self):
+        import numpy as np
+        from . import _lib, ops
+        items = self.batches[self.i % len(self.batches)]
+        self.i += 1
+        if self.host_ev is not None:
+            self.host_ev.synchronize()      # (long done: a whole step has passed) before the pinned buffers are rewritten
+        B = len(items)
+        np.stack([it["point_cloud"] for it in items], out=self.pin["point_cloud"].numpy().reshape(B, -1, 3))
+        self.stage["point_cloud"].copy_(self.pin["point_cloud"].view_as(self.stage["point_cloud"]), non_blocking=True)
+        lib = _lib.load()
+        for k, fill in self.KEYS:
+            arrs = [np.asarray(it[k], dtype=np.float32).reshape(it[k].shape[0], -1) for it in items]
+            lens = [a.shape[0] for a in arrs]
+            tot = sum(lens)
+            np.concatenate(arrs, axis=0, out=self.pin[k].numpy()[:tot * self.dim[k]].reshape(tot, self.dim[k]))
+            off = self.pin_off[k].numpy()
+            off[0] = 0
+            np.cumsum(lens, out=off[1:])
+            self.dev_flat[k][:tot * self.dim[k]].copy_(self.pin[k][:tot * self.dim[k]], non_blocking=True)
+            self.dev_off[k].copy_(self.pin_off[k], non_blocking=True)
+            ops._run("pad_ragged", self.stage[k], lib.mp_pad_ragged_f32, self.dev_flat[k].data_ptr(), self.dev_off[k].data_ptr(), B,
+                     self.width[k], self.dim[k], float(fill), self.stage[k].data_ptr())
+        for pin, dst, n in zip(self.pin_starts, self.stage_starts, self.levels_n):    # the reference's draw (pointnet2_utils.py:77)
+            pin.copy_(torch.randint(0, n, (B,), dtype=torch.long))
+            dst.copy_(pin, non_blocking=True)
+        self.host_ev = torch.cuda.Event()
+        self.host_ev.record()
+        return self.stage["point_cloud"], self.stage_starts
+
+    def publish(self):
+        b = self.ts.batch
+        torch._foreach_copy_([b["point_cloud"]] + [b[k] for k, _ in self.KEYS], [self.stage["point_cloud"]] + [self.stage[k] for k, _ in self.KEYS])
 
 
 class DropInLoop:

@@ -108,6 +108,23 @@ def ground_truth(rng, B, cat):
     return traj, traj_as_pc, stroke_ids, n_seg, n_pts
 
 
+def make_samples(seed, B, N, cat="cuboids", dist="cuboid"):
+    """B dataset items as the reference's dataset yields them before collation (utils/dataset/paintnet_ODv1.py:470-484): ragged
+    numpy arrays per sample -- point_cloud [N,3], traj [n_seg, lambda*6], traj_as_pc [n_pts, 6], stroke_ids [n_seg],
+    stroke_ids_as_pc [n_pts] -- for the collate / streaming paths."""
+    b = make_batch(seed, B, N, cat, dist)
+    out = []
+    for i in range(B):
+        ns, npts = int(b["n_segments"][i]), int(b["n_points"][i])
+        ids = b["stroke_ids"][i, :ns].numpy()
+        # pose-level stroke ids: the segments of stroke s cover its (len - LAMBDA) // stride * stride + LAMBDA first poses
+        out.append({"point_cloud": b["point_cloud"][i].numpy(), "traj": b["traj"][i, :ns].numpy(),
+                    "traj_as_pc": b["traj_as_pc"][i, :npts].numpy(), "stroke_ids": ids,
+                    "stroke_ids_as_pc": np.zeros((npts,), dtype=np.float32), "dirname": f"synthetic_{seed}_{i}",
+                    "n_strokes": int(ids.max()) + 1 if ns else 0})
+    return out
+
+
 def make_batch(seed, B, N, cat="cuboids", dist="cuboid", device="cpu"):
     """One collated batch as torch tensors (reference dict keys)."""
     rng = np.random.default_rng(seed)

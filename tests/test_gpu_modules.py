@@ -1175,3 +1175,31 @@ def test_device_lambda_segments_match_the_reference(golden):
     bad = [np.array([0, 0, 2, 2, 2, 2], dtype=np.float32), np.array([0, 0, 0, 0, 1, 1, 1, 1], dtype=np.float32)]
     _, _, status = lambda_segments([np.zeros((6, 6), np.float32), np.zeros((8, 6), np.float32)], bad, 4, 1)
     assert status.cpu().tolist()[0] != 0 and status.cpu().tolist()[1] == 0
+
+
+def test_streamed_batches_feed_the_step_what_the_collate_produces():
+    """TrainStep(stream_batches=K): every step consumes a different host batch that was collated (and sampled) on the second
+    stream during the previous step.  The static tensors the recorded step reads must hold exactly the collated batch, the
+    sampling plan must be that batch's, and training on the rotating batches must stay finite and make progress."""
+    from maskplanner_amd import ops, synthetic
+    from maskplanner_amd.collate import pad_ragged
+    from maskplanner_amd.harness import TrainStep
+    ts = TrainStep("cuboids", B=8, N=1024, seed=3, stream_batches=3)
+    assert ts._stream is not None and ts.overlap
+    losses = []
+    for step in range(9):
+        losses.append(ts.step())
+        torch.cuda.synchronize()
+        items = ts._stream.batches[step % 3]           # the batch this step consumed
+        want_pc = torch.from_numpy(np.stack([it["point_cloud"] for it in items])).cuda()
+        assert torch.equal(ts.batch["point_cloud"], want_pc), step
+        for k, fill in (("traj", -100.0), ("traj_as_pc", -100.0), ("stroke_ids", -1.0)):
+            want = pad_ragged([it[k] for it in items], fill, "cuda", total_needed=ts.batch[k].shape[1])
+            assert torch.equal(ts.batch[k], want), (step, k)
+        # the plan the step used (plan_cur) is the FPS / ball query of THIS cloud from the drawn starts: first index = the start
+        fps_idx, new_xyz, idx = ts._plan_views(ts._plan_cur)[0]
+        redo = ops.fps(ts.batch["point_cloud"], 512, fps_idx[:, 0].contiguous())
+        assert torch.equal(redo, fps_idx), step
+    assert ts._graph is not None
+    losses = [float(l) for l in losses]
+    assert np.isfinite(losses).all()
