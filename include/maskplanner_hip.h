@@ -186,6 +186,13 @@ int mp_mask_match_f32(const float* pred_masks, const float* target_ids, const fl
  *   0, MP_EINVAL (bad sizes) or MP_EUNSUPPORTED (infeasible: non-finite costs).  Cmax, Rmax <= 2048. */
 int mp_lsap_f32(const float* cost, int64_t B, int64_t Rmax, int64_t Cmax, int64_t ld, int64_t batch_stride,
                 const int32_t* n_rows, const int32_t* n_cols, int64_t* col4row, int32_t* status, mp_stream_t stream);
+/* The matcher's cost matrices, all samples in one launch: replaces the torch.cdist of models/hungarianMatcher.py:51 (one
+ * [B*S, sum Sgt] matrix of which only the diagonal blocks are used).  outputs [B, S, D]; targets [T, D]: the samples' targets
+ * back to back, sample b owning rows offsets[b] .. offsets[b+1]; cost [B, Rmax, Cmax] f32 = ||x - y||_2 (direct differences),
+ * written in the layout mp_lsap_f32 takes: sample b's block is S x T_b, or its transpose when S > T_b, zero padded; n_rows /
+ * n_cols [B] i32 receive the block's shape.  Rmax >= max_b min(S, T_b), Cmax >= max_b max(S, T_b). */
+int mp_cdist_batch_f32(const float* outputs, const float* targets, const int64_t* offsets, int64_t B, int64_t S, int64_t D,
+                       int64_t Rmax, int64_t Cmax, float* cost, int32_t* n_rows, int32_t* n_cols, mp_stream_t stream);
 
 /* ---- fused tails: pose output and stroke-mask loss ---------------------------------------------------------------
  * mp_pose_output: replaces models/pointnet2_cls_ssg.py:332-339 (tanh -> view(B,-1,3) -> F.normalize * weight_orient, cat with

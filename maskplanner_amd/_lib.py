@@ -63,6 +63,7 @@ SIGNATURES = {
     "mp_three_interpolate_f32": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),
     "mp_three_interpolate_bwd_f32": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _int, _vp]),
     "mp_lsap_f32": (_int, [_vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "mp_cdist_batch_f32": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp]),
     "mp_chamfer_reduce_f32": (_int, [_vp, _vp, _i64, _i64, _int, _int, _dbl, _dbl, _vp, _vp, _vp]),
     "mp_chamfer_reduce_bwd_f32": (_int, [_vp, _vp, _i64, _i64, _int, _int, _dbl, _dbl, _vp, _vp]),
     "mp_permute_cols_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp]),

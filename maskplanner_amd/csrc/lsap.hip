@@ -177,3 +177,53 @@ extern "C" int mp_lsap_f32(const float* cost, int64_t B, int64_t Rmax, int64_t C
     if (Cmax <= 1024) return launch(lsap_kernel<16>, conf16);
     return launch(lsap_kernel<32>, conf32);
 }
+
+// ---- batched Euclidean cost for the segment matcher ---------------------------------------------------------------------
+// models/hungarianMatcher.py:44-55: the reference builds ONE torch.cdist matrix [B*S, sum Sgt] (every prediction against the
+// ground truth of EVERY sample) and slices the diagonal blocks.  Here the B blocks are computed directly, in one launch, into the
+// padded layout mp_lsap_f32 reads -- transposed where a sample has more predictions than targets, as scipy transposes then.
+// cost = sqrt(sum_d (x_d - y_d)^2), direct differences in fp32 (fma chain over d).
+namespace {
+__global__ __launch_bounds__(256) void cdist_batch_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                          const int64_t* __restrict__ offsets, int S, int D, int Rmax, int Cmax,
+                                                          float* __restrict__ cost, int32_t* __restrict__ n_rows,
+                                                          int32_t* __restrict__ n_cols)
+{
+    const int b = blockIdx.z;
+    const int64_t o0 = offsets[b];
+    const int T = (int)(offsets[b + 1] - o0);
+    const bool tr = S > T;                       // rows > columns: the solver works on the transpose
+    const int nr = tr ? T : S, nc = tr ? S : T;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { n_rows[b] = nr; n_cols[b] = nc; }
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int r = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (r >= Rmax || c >= Cmax) return;
+    float v = 0.0f;                              // padding of the [Rmax, Cmax] slab
+    if (r < nr && c < nc) {
+        const float* xp = x + ((size_t)b * S + (tr ? c : r)) * D;
+        const float* yp = y + (size_t)(o0 + (tr ? r : c)) * D;
+        float acc = 0.0f;
+        for (int d = 0; d < D; ++d) {
+            const float df = xp[d] - yp[d];
+            acc = __builtin_fmaf(df, df, acc);
+        }
+        v = __builtin_sqrtf(acc);
+    }
+    cost[((size_t)b * Rmax + r) * Cmax + c] = v;
+}
+}  // namespace
+
+extern "C" int mp_cdist_batch_f32(const float* outputs, const float* targets, const int64_t* offsets, int64_t B, int64_t S, int64_t D,
+                                  int64_t Rmax, int64_t Cmax, float* cost, int32_t* n_rows, int32_t* n_cols, mp_stream_t stream_)
+{
+    if (B < 0 || S < 0 || D <= 0 || Rmax < 0 || Cmax < 0) return MP_EINVAL;
+    if (B == 0 || Rmax == 0 || Cmax == 0) return MP_OK;
+    if (!offsets || !cost || !n_rows || !n_cols || (S > 0 && !outputs)) return MP_EINVAL;
+    if (B > 65535 || Rmax > (1 << 20) || Cmax > (1 << 20)) return MP_EUNSUPPORTED;
+    MP_LAUNCH("cdist_batch_kernel", 3.0 * (double)B * Rmax * Cmax * D, 4.0 * (double)B * Rmax * Cmax, cdist_batch_kernel,
+              dim3((unsigned)((Cmax + 63) / 64), (unsigned)((Rmax + 3) / 4), (unsigned)B), dim3(256), 0, mp_stream(stream_), outputs, targets,
+              offsets, (int)S, (int)D, (int)Rmax, (int)Cmax, cost, n_rows, n_cols);
+    MP_CHECK_LAUNCH();
+    return MP_OK;
+}
+

@@ -3,8 +3,8 @@ and GT segments by Euclidean cost, used by the `emd` / `hungarian_SoPs` losses (
 
 The reference builds ONE [B*S, sum(Sgt)] cdist matrix (every prediction against the GT of every sample, O(B^2)
 wasted work, 3.7 GB at B=32), slices the diagonal blocks, copies each to the host and solves it with scipy, one sample
-after the other (:58-61; 999 x ~900 takes ~0.2 s of one core).  Here each sample's [S, Sgt_b] block is computed on its
-own and all assignments are solved side by side on the GPU by csrc/lsap.hip -- scipy's algorithm and tie-breaking, one
+after the other (:58-61; 999 x ~900 takes ~0.2 s of one core).  Here only the B diagonal blocks are computed, in one launch
+(mp_cdist_batch_f32), and all assignments are solved side by side on the GPU by csrc/lsap.hip -- scipy's algorithm and tie-breaking, one
 wave per sample -- so the only host transfer is the final index lists the reference API returns as CPU tensors.
 """
 import torch
@@ -21,9 +21,7 @@ class HungarianMatcher(nn.Module):
     def forward(self, outputs, targets):
         """outputs [B,S,D]; targets: list of B tensors [Sgt_b, D].  Returns a list of (index_i, index_j) int64 CPU
         tensors with len == min(S, Sgt_b), rows ascending (scipy convention)."""
-        costs = [torch.cdist(outputs[b], t.to(outputs.device), p=2,
-                             compute_mode='use_mm_for_euclid_dist_if_necessary') for b, t in enumerate(targets)]
-        pairs, status = ops.lsap(costs)
+        pairs, status = ops.match_segments(outputs, [t.to(outputs.device) for t in targets])   # one cost launch + one LAP launch
         if status is not None and bool((status != 0).any()):   # the one sync of the call (the results go to the host anyway)
             raise _lib.MaskPlannerHipError("HungarianMatcher: infeasible cost matrix (non-finite distances)")
         return [(i.cpu(), j.cpu()) for i, j in pairs]

@@ -222,6 +222,43 @@ def lsap(costs):
     return out, status
 
 
+@torch.no_grad()
+def match_segments(outputs, targets):
+    """models/hungarianMatcher.py:44-61 on the device: Euclidean cost of every sample's [S, Sgt_b] block in ONE launch
+    (mp_cdist_batch_f32, straight into the solver's padded layout) + the batched LAP.  outputs [B,S,D]; targets: list of B
+    tensors [Sgt_b, D].  Returns (pairs, status) like lsap()."""
+    _need_hip(outputs, *targets)
+    outputs = _f32(outputs)
+    B, S, D = outputs.shape
+    dev = outputs.device
+    sizes = [int(t.shape[0]) for t in targets]
+    flat = _f32(torch.cat([t.reshape(-1, D) for t in targets], dim=0)) if sum(sizes) else torch.zeros((0, D), device=dev)
+    offsets = torch.tensor([0] + list(torch.tensor(sizes).cumsum(0).tolist()), dtype=torch.int64).to(dev)
+    Rmax = max(max(min(S, t) for t in sizes), 1)
+    Cmax = max(max(max(S, t) for t in sizes), 1)
+    if Cmax > 2048:
+        raise _lib.MaskPlannerHipError("lsap: more than 2048 columns per sample is outside the gfx950 kernel's range")
+    cost = torch.empty((B, Rmax, Cmax), dtype=torch.float32, device=dev)
+    nr = torch.empty((B,), dtype=torch.int32, device=dev)
+    nc = torch.empty((B,), dtype=torch.int32, device=dev)
+    lib = _lib.load()
+    _run("cdist_batch", outputs, lib.mp_cdist_batch_f32, _p(outputs), _p(flat) if flat.numel() else None, _p(offsets), B, S, D, Rmax, Cmax,
+         _p(cost), _p(nr), _p(nc))
+    c4r = torch.empty((B, Rmax), dtype=torch.int64, device=dev)
+    status = torch.empty((B,), dtype=torch.int32, device=dev)
+    _run("lsap", cost, lib.mp_lsap_f32, _p(cost), B, Rmax, Cmax, Cmax, Rmax * Cmax, _p(nr), _p(nc), _p(c4r), _p(status))
+    out = []
+    for b, t in enumerate(sizes):
+        n = min(S, t)
+        cols = c4r[b, :n]
+        rows = torch.arange(n, dtype=torch.int64, device=dev)
+        if S > t:   # solved on the transpose: (row, col) = (col4row[k], k), reported in ascending row order
+            rows, order = torch.sort(cols)
+            cols = order
+        out.append((rows, cols))
+    return out, status
+
+
 # ----------------------------------------------------------------------------------------------------------------
 # differentiable ops
 # ----------------------------------------------------------------------------------------------------------------

@@ -574,3 +574,22 @@ def test_bn_relu_rows_matches_batchnorm1d(ops, train, B, C):
     np.testing.assert_allclose(bn_a.running_mean.cpu().numpy(), bn_b.running_mean.cpu().numpy(), rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(bn_a.running_var.cpu().numpy(), bn_b.running_var.cpu().numpy(), rtol=1e-5, atol=1e-6)
 
+
+
+def test_match_segments_cost_layout_and_assignment(oracle):
+    """mp_cdist_batch_f32 + mp_lsap_f32 (ops.match_segments): per-sample Euclidean cost blocks in one launch, transposed where a
+    sample has more predictions than targets, against the oracle's cdist and scipy on it -- more targets than predictions, fewer,
+    equal, and an empty target list."""
+    from scipy.optimize import linear_sum_assignment
+    from maskplanner_amd import ops
+    rng = np.random.default_rng(12)
+    B, S, D = 4, 40, 24
+    x = rng.normal(size=(B, S, D)).astype(np.float32)
+    sizes = [55, 40, 17, 33]
+    ys = [rng.normal(size=(t, D)).astype(np.float32) for t in sizes]
+    pairs, status = ops.match_segments(dev(x), [dev(y) for y in ys])
+    assert (status.cpu().numpy() == 0).all()
+    for b, (i, j) in enumerate(pairs):
+        c = oracle.cdist(x[b], ys[b])
+        ri, cj = linear_sum_assignment(c.astype(np.float64))
+        assert np.array_equal(i.cpu().numpy(), ri) and np.array_equal(j.cpu().numpy(), cj), b
