@@ -148,9 +148,11 @@ int mp_padded_lengths_f32(const float* y, int64_t B, int64_t P2, int64_t D, int6
  *   1 and 2).  Every output is multiplied by
  *   `scale` (the loss's constant factors, e.g. 100 * term weight, folded in instead of separate scalar launches).
  *   Deterministic (fixed summation order).  The backward writes grad_cham [N,P] (zero at p >= lengths[n] when lengths
- *   is given) from grad_out ([N] for batch_mode 0, [1] otherwise). */
+ *   is given) from grad_out ([N] for batch_mode 0, [1] otherwise).
+ *   add_to (modes 1, 2; NULL otherwise): a device scalar added to the reduced value -- the composite losses
+ *   (loss_handler.py:660-664) chain their weighted terms through it instead of launching an elementwise add per term. */
 int mp_chamfer_reduce_f32(const float* cham, const int64_t* lengths, int64_t N, int64_t P, int point_mean, int batch_mode,
-                          double div, double scale, float* per_cloud, float* out, mp_stream_t stream);
+                          double div, double scale, float* per_cloud, float* out, const float* add_to, mp_stream_t stream);
 int mp_chamfer_reduce_bwd_f32(const float* grad_out, const int64_t* lengths, int64_t N, int64_t P, int point_mean,
                               int batch_mode, double div, double scale, float* grad_cham, mp_stream_t stream);
 
@@ -208,7 +210,7 @@ int mp_pose_output_bwd_f32(const float* grad_out, const float* raw, int64_t n_po
 int mp_mask_loss_f32(const float* pred_masks, const float* scores, const float* target_ids, const int64_t* match_col,
                      const float* uniq_ids, int64_t B, int64_t M, int64_t S, double w_masks, double w_conf,
                      double no_stroke_weight, float* per_mask, float* out, float* n_matched, const int32_t* status /* [B] or NULL */,
-                     mp_stream_t stream);
+                     const float* add_to /* device scalar added to out, or NULL */, mp_stream_t stream);
 int mp_mask_loss_bwd_f32(const float* grad_out, const float* pred_masks, const float* scores, const float* target_ids,
                          const int64_t* match_col, const float* uniq_ids, const float* n_matched, int64_t B, int64_t M, int64_t S,
                          double w_masks, double w_conf, double no_stroke_weight, float* grad_masks, float* grad_scores,
@@ -351,6 +353,11 @@ int mp_profiler_collect(char* buf, size_t cap);
 int mp_adam_multi_f32(int64_t count, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
                       const int64_t* numels, double grad_scale, double lr, double beta1, double beta2, double eps, int64_t step,
                       const float* step_dev, mp_stream_t stream);
+/* Column sums of `count` skinny matrices g[i] [rows, cols[i]] -> out[i] [cols[i]] in one launch: the bias gradients of the
+ * head Linears (db = dy.sum(0); models/pointnet2_cls_ssg.py:270-295), which autograd would produce with one reduce launch
+ * each.  g / out / cols are HOST arrays (device pointers and widths travel in the kernel arguments). */
+int mp_colsum_multi_f32(int64_t count, const void* const* g, void* const* out, const int64_t* cols, int64_t rows,
+                        mp_stream_t stream);
 
 /* Batch collation: out[b, r, :] = r < len_b ? flat[offsets[b] + r, :] : fill, len_b = offsets[b+1] - offsets[b]; flat
  * [offsets[B], D], offsets i64 [B+1] on the device, out [B, R, D] (rows beyond R are dropped).  Replaces the per-sample numpy

@@ -64,12 +64,12 @@ SIGNATURES = {
     "mp_three_interpolate_bwd_f32": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _int, _vp]),
     "mp_lsap_f32": (_int, [_vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
     "mp_cdist_batch_f32": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp]),
-    "mp_chamfer_reduce_f32": (_int, [_vp, _vp, _i64, _i64, _int, _int, _dbl, _dbl, _vp, _vp, _vp]),
+    "mp_chamfer_reduce_f32": (_int, [_vp, _vp, _i64, _i64, _int, _int, _dbl, _dbl, _vp, _vp, _vp, _vp]),
     "mp_chamfer_reduce_bwd_f32": (_int, [_vp, _vp, _i64, _i64, _int, _int, _dbl, _dbl, _vp, _vp]),
     "mp_permute_cols_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp]),
     "mp_pose_output_f32": (_int, [_vp, _vp, _i64, _dbl, _vp, _vp]),
     "mp_pose_output_bwd_f32": (_int, [_vp, _vp, _i64, _dbl, _vp, _vp, _vp]),
-    "mp_mask_loss_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _dbl, _dbl, _dbl, _vp, _vp, _vp, _vp, _vp]),
+    "mp_mask_loss_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _dbl, _dbl, _dbl, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mp_mask_loss_bwd_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _dbl, _dbl, _dbl, _vp, _vp, _vp]),
     "mp_bn_relu_rows_f32": (_int, [_vp, _i64, _i64, _int, _dbl, _dbl, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mp_bn_relu_rows_bwd_f32": (_int, [_vp, _vp, _vp, _i64, _i64, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -87,6 +87,7 @@ SIGNATURES = {
     "mp_sa_mlp_recompute_first": (_int, [_int, ctypes.POINTER(_i64), _i64]),
     "mp_adam_multi_f32": (_int, [_i64, _vp, _vp, _vp, _vp, ctypes.POINTER(_i64), ctypes.c_double, ctypes.c_double, ctypes.c_double,
                                  ctypes.c_double, ctypes.c_double, _i64, _vp, _vp]),
+    "mp_colsum_multi_f32": (_int, [_i64, _vp, _vp, ctypes.POINTER(_i64), _i64, _vp]),
     "mp_pad_ragged_f32": (_int, [_vp, _vp, _i64, _i64, _i64, ctypes.c_float, _vp, _vp]),
     "mp_lambda_segments_f32": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp]),
     "mp_sa_mlp_fwd_f32": (_int, [_vp, _i64, _i64, _int, ctypes.POINTER(MlpLayer), _int, _dbl, _dbl, _vp, _vp, _vp, _vp,

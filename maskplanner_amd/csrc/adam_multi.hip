@@ -111,3 +111,63 @@ extern "C" int mp_adam_multi_f32(int64_t count, float* const* params, const floa
     }
     return MP_OK;
 }
+
+// ---- column sums of several skinny matrices in one launch: the bias gradients of the head Linears ------------------------------
+// db = g.sum(0) for g [rows, cols] (rows = batch): seven heads would be seven reduce launches of a few microseconds each
+// (models/pointnet2_cls_ssg.py:270-295: fc1/fc2/fc3/fc_normals and the sm_ twins + mask_conf_out).  Pointers travel in the kernel
+// arguments like adam_multi's; a thread owns one column and walks the rows (coalesced across columns, fixed order).
+namespace {
+constexpr int CS_MAX = 16;
+struct ColsumArgs {
+    const float* g[CS_MAX];
+    float* out[CS_MAX];
+    int cols[CS_MAX];
+    int blk0[CS_MAX + 1];
+    int count, rows;
+};
+__global__ __launch_bounds__(256) void colsum_multi_kernel(ColsumArgs a)
+{
+    int t = 0;
+    while (t + 1 < a.count && (int)blockIdx.x >= a.blk0[t + 1]) ++t;
+    const int c = ((int)blockIdx.x - a.blk0[t]) * 256 + threadIdx.x;
+    const int C = a.cols[t];
+    if (c >= C) return;
+    const float* g = a.g[t] + c;
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+    int r = 0;
+    for (; r + 3 < a.rows; r += 4) {      // four independent loads in flight
+        s0 += g[(size_t)r * C]; s1 += g[(size_t)(r + 1) * C]; s2 += g[(size_t)(r + 2) * C]; s3 += g[(size_t)(r + 3) * C];
+    }
+    for (; r < a.rows; ++r) s0 += g[(size_t)r * C];
+    a.out[t][c] = (s0 + s1) + (s2 + s3);
+}
+}  // namespace
+
+extern "C" int mp_colsum_multi_f32(int64_t count, const void* const* g, void* const* out, const int64_t* cols, int64_t rows,
+                                   mp_stream_t stream_)
+{
+    if (count < 0 || rows < 0) return MP_EINVAL;
+    if (count == 0) return MP_OK;
+    if (!g || !out || !cols) return MP_EINVAL;
+    hipStream_t stream = mp_stream(stream_);
+    for (int64_t base = 0; base < count; base += CS_MAX) {
+        ColsumArgs a;
+        a.count = (int)((count - base) < CS_MAX ? (count - base) : CS_MAX);
+        a.rows = (int)rows;
+        int blocks = 0;
+        for (int i = 0; i < a.count; ++i) {
+            if (!g[base + i] || !out[base + i] || cols[base + i] < 0 || cols[base + i] > (1 << 30)) return MP_EINVAL;
+            a.g[i] = static_cast<const float*>(g[base + i]);
+            a.out[i] = static_cast<float*>(out[base + i]);
+            a.cols[i] = (int)cols[base + i];
+            a.blk0[i] = blocks;
+            blocks += (int)((cols[base + i] + 255) / 256);
+        }
+        a.blk0[a.count] = blocks;
+        if (blocks == 0) continue;
+        hipLaunchKernelGGL(colsum_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a);
+        MP_CHECK_LAUNCH();
+    }
+    return MP_OK;
+}
+

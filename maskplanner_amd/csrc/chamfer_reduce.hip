@@ -32,12 +32,14 @@ __global__ __launch_bounds__(256) void chamfer_rows_kernel(const float* __restri
 
 // clouds combined in index order by one wave (lane l takes clouds l, l+64, ...; lanes then summed in a fixed tree)
 __global__ __launch_bounds__(64) void chamfer_batch_kernel(const float* __restrict__ per_cloud, int N, int batch_mode, float div,
-                                                           float* __restrict__ out)
+                                                           float* __restrict__ out, const float* __restrict__ add_to)
 {
     float s = 0.0f;
     for (int n = threadIdx.x; n < N; n += 64) s += per_cloud[n];
     s = mp::wave_sum_f32(s);
-    if (threadIdx.x == 0) out[0] = batch_mode == 2 ? s / div : s;
+    // add_to: a running total of loss terms (device scalar) the reduced value is added to -- the composite losses chain their
+    // terms through it instead of launching one elementwise add per term
+    if (threadIdx.x == 0) out[0] = (batch_mode == 2 ? s / div : s) + (add_to ? add_to[0] : 0.0f);
 }
 
 // grad_cham[n,p] = g(n) * scale / (len_n if point mean) / (div if batch mean) for p < len_n (when lengths are given), else 0
@@ -60,7 +62,7 @@ __global__ __launch_bounds__(256) void chamfer_reduce_bwd_kernel(const float* __
 }  // namespace
 
 extern "C" int mp_chamfer_reduce_f32(const float* cham, const int64_t* lengths, int64_t N, int64_t P, int point_mean,
-                                     int batch_mode, double div, double scale, float* per_cloud, float* out, mp_stream_t stream_)
+                                     int batch_mode, double div, double scale, float* per_cloud, float* out, const float* add_to, mp_stream_t stream_)
 {
     if (N < 0 || P < 0 || batch_mode < 0 || batch_mode > 2) return MP_EINVAL;
     if (N == 0) return MP_OK;
@@ -71,7 +73,7 @@ extern "C" int mp_chamfer_reduce_f32(const float* cham, const int64_t* lengths, 
               lengths, (int)P, point_mean, (float)scale, batch_mode == 0 ? out : per_cloud);
     MP_CHECK_LAUNCH();
     if (batch_mode != 0) {
-        hipLaunchKernelGGL(chamfer_batch_kernel, dim3(1), dim3(64), 0, stream, per_cloud, (int)N, batch_mode, (float)div, out);
+        hipLaunchKernelGGL(chamfer_batch_kernel, dim3(1), dim3(64), 0, stream, per_cloud, (int)N, batch_mode, (float)div, out, add_to);
         MP_CHECK_LAUNCH();
     }
     return MP_OK;

@@ -80,7 +80,8 @@ __global__ __launch_bounds__(256) void mask_loss_final_kernel(const float* __res
                                                               const int64_t* __restrict__ match, int BM, float w_masks, float w_conf,
                                                               float no_stroke_weight, float* __restrict__ out,
                                                               float* __restrict__ n_matched_out,
-                                                              const int32_t* __restrict__ status, int B)
+                                                              const int32_t* __restrict__ status, int B,
+                                                              const float* __restrict__ add_to)
 {
     __shared__ float r0[4], r1[4], r2[4];
     __shared__ int s_bad;
@@ -103,7 +104,7 @@ __global__ __launch_bounds__(256) void mask_loss_final_kernel(const float* __res
         const float tm = (r0[0] + r0[1]) + (r0[2] + r0[3]);
         const float tc = (r1[0] + r1[1]) + (r1[2] + r1[3]);
         const float tn = (r2[0] + r2[1]) + (r2[2] + r2[3]);
-        out[0] = s_bad ? __builtin_nanf("") : w_masks * (tm / tn) + w_conf * (tc / (float)BM);
+        out[0] = s_bad ? __builtin_nanf("") : (w_masks * (tm / tn) + w_conf * (tc / (float)BM)) + (add_to ? add_to[0] : 0.0f);
         n_matched_out[0] = tn;
     }
 }
@@ -163,7 +164,7 @@ extern "C" int mp_pose_output_bwd_f32(const float* grad_out, const float* raw, i
 extern "C" int mp_mask_loss_f32(const float* pred_masks, const float* scores, const float* target_ids, const int64_t* match_col,
                                 const float* uniq_ids, int64_t B, int64_t M, int64_t S, double w_masks, double w_conf,
                                 double no_stroke_weight, float* per_mask, float* out, float* n_matched, const int32_t* status,
-                                mp_stream_t stream_)
+                                const float* add_to, mp_stream_t stream_)
 {
     if (B < 0 || M < 0 || S < 0) return MP_EINVAL;
     if (B * M == 0) return MP_EINVAL;
@@ -174,7 +175,7 @@ extern "C" int mp_mask_loss_f32(const float* pred_masks, const float* scores, co
                        (int)M, (int)S, MP_MASK_CAP, per_mask);
     MP_CHECK_LAUNCH();
     hipLaunchKernelGGL(mask_loss_final_kernel, dim3(1), dim3(256), 0, stream, per_mask, scores, match_col, (int)(B * M), (float)w_masks,
-                       (float)w_conf, (float)no_stroke_weight, out, n_matched, status, (int)B);
+                       (float)w_conf, (float)no_stroke_weight, out, n_matched, status, (int)B, add_to);
     MP_CHECK_LAUNCH();
     return MP_OK;
 }

@@ -1214,6 +1214,8 @@ __global__ __launch_bounds__(512) void bwd_first_kernel(PosOperand DZ, PosOperan
 #pragma unroll
             for (int i = 0; i < 4; ++i)      // rows past the workgroup's last position: dropped by the buffer's range check
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ax[i]), grsrc, goff, i * CIW * 4, 0);
+            // the 4 coordinate / padding columns of grad_x0 carry no gradient: written as zeros so that the buffer is fully defined
+            if (tid < DBK * 4) __builtin_amdgcn_raw_buffer_store_b32(0u, grsrc, ((kc * DBK + (tid >> 2)) * CIW + CIX + (tid & 3)) * 4, 0, 0);
             goff += DBK * CIW * 4;
         }
         if (kc + 1 < nchunks) sstore(cur ^ 1);
@@ -1472,6 +1474,14 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ partials, int n
         cf[c] = 0.0f;
         if (dbias) dbias[c] = (float)(a * dbe);
     }
+}
+
+__global__ __launch_bounds__(256) void zero_cols_kernel(float* __restrict__ x, int64_t P, int C, int c0)
+{
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int w = C - c0;
+    if (e >= P * w) return;
+    x[(e / w) * C + c0 + (int)(e % w)] = 0.0f;
 }
 
 // out[g,c] = max_k relu(z[g*K+k, c]*s+t); first maximum wins; keeps arg-max and the raw z there.
@@ -2018,6 +2028,10 @@ static int sa_mlp_bwd(const float* x0, int64_t P, int64_t K, int n_layers, const
             else
                 rc = MP_POS_GEMM(SRC_DZ, true, EPI_NONE, DZ, P, Ly.weight, ncols, Co, grad_x0, nullptr, nullptr, nullptr, nullptr, stream, nullptr, PoolOut{}, Ci, Ci);
             if (rc != MP_OK) return rc;
+            if (ncols < Ci) {   // the columns that carry no gradient: defined (zero), so that no consumer can read garbage
+                hipLaunchKernelGGL(zero_cols_kernel, dim3((unsigned)((P * (Ci - ncols) + 255) / 256)), dim3(256), 0, stream, grad_x0, P, Ci, ncols);
+                MP_CHECK_LAUNCH();
+            }
         }
     }
     return MP_OK;

@@ -22,6 +22,7 @@ class _FactorLinear(torch.autograd.Function):
     def forward(ctx, x, weight, bias, store, key):
         ctx.save_for_backward(x, weight)
         ctx.store, ctx.key, ctx.has_bias = store, key, bias is not None
+        ctx.bias = bias
         return F.linear(x, weight, bias)
 
     @staticmethod
@@ -43,8 +44,37 @@ class _FactorLinear(torch.autograd.Function):
                          gx.data_ptr(), ws.data_ptr(), ws.numel())
             else:
                 gx = g @ weight
-        gb = g.sum(0) if ctx.has_bias else None
+        gb = None
+        if ctx.has_bias:
+            pending = ctx.store.get(BIAS_QUEUE)
+            if pending is not None and g.is_cuda:
+                pending.append((ctx.bias, g))     # all bias gradients of the step in one launch: flush_bias_grads()
+            else:
+                gb = g.sum(0)
         return gx, None, gb, None, None
+
+
+BIAS_QUEUE = "__bias_grads__"     # store[BIAS_QUEUE] = []: FactorLinear queues (bias, dy) pairs instead of reducing each one
+
+
+@torch.no_grad()
+def flush_bias_grads(store):
+    """bias.grad = dy.sum(0) for every queued head Linear, one launch (csrc/adam_multi.hip: mp_colsum_multi_f32).  Call after
+    backward() and before the gradients are exchanged / consumed."""
+    queue = store.get(BIAS_QUEUE)
+    if not queue:
+        return
+    n = len(queue)
+    rows = queue[0][1].shape[0]
+    outs = [torch.empty_like(b) for b, _ in queue]
+    arr = ctypes.c_void_p * n
+    gp = arr(*[g.data_ptr() for _, g in queue])
+    op = arr(*[o.data_ptr() for o in outs])
+    cols = (ctypes.c_int64 * n)(*[g.shape[1] for _, g in queue])
+    ops._run("colsum_multi", outs[0], _lib.load().mp_colsum_multi_f32, n, gp, op, cols, rows)
+    for (b, _), o in zip(queue, outs):
+        b.grad = o if b.grad is None else b.grad + o
+    del queue[:]
 
 
 def factor_linear(x, linear, store, key):

@@ -8,7 +8,7 @@ import os
 import torch
 
 from . import dp, synthetic
-from .factor_heads import DenseAdam, FactorAdam
+from .factor_heads import BIAS_QUEUE, DenseAdam, FactorAdam, flush_bias_grads
 from . import pointnet2_utils as pu
 from .loss_handler import LossHandler, maskplanner_loss_config
 from .pointnet2_cls_ssg import maskplanner_model
@@ -71,6 +71,8 @@ class TrainStep:
             dense = [p for p in dense if all(p is not q for q in big.values())]
         self.reducer = dp.BucketedGradAllReduce(dense)
         self.reducer.deferred = self.dp_graph and self.use_graph
+        if self.factor_opt is not None:
+            self._reset_factor_store()
         self._static_grads = None
         # train_maskplanner.py:159.  On the GPU the dense parameters go through csrc/adam_multi.hip (same update, ~150 tensors in four
         # launches); MASKPLANNER_TORCH_ADAM=1 keeps torch's fused Adam.
@@ -98,6 +100,19 @@ class TrainStep:
 
     def forward_loss(self):
         return self._heads_loss(self._encode())
+
+    class _Ticks:
+        """Collect the num_batches_tracked counters of every train-mode BatchNorm the enclosed forward passes touch and advance
+        them with one launch on exit (instead of one per set-abstraction level and one for the heads)."""
+
+        def __enter__(self):
+            from . import sa_mlp
+            self.prev, sa_mlp.DEFERRED_TICKS = sa_mlp.DEFERRED_TICKS, []
+
+        def __exit__(self, *exc):
+            from . import sa_mlp
+            sa_mlp.flush_ticks()
+            sa_mlp.DEFERRED_TICKS = self.prev
 
     def _encode(self):
         # sa1's start is consumed only when its sampling was not prefetched; sa2's always
@@ -174,7 +189,7 @@ class TrainStep:
             cap = torch.cuda.Stream()
             ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
             if self.factor_opt is not None:
-                self.model.factor_store.clear()
+                self._reset_factor_store()
             with torch.cuda.graph(ga, stream=cap):
                 self._supply_plan()
                 self.reducer.zero_grad()
@@ -208,7 +223,7 @@ class TrainStep:
                 self._static_grads = [(p, p.grad) for p in self.reducer.params if p.grad is not None]
             self._factor_args = persist
             if self.factor_opt is not None:
-                self.model.factor_store.clear()
+                self._reset_factor_store()
             self._adam_stream = torch.cuda.Stream()
             self._graph, self._graph_b, self._graph_loss = ga, gb, loss
             ga.replay()
@@ -219,6 +234,13 @@ class TrainStep:
             warnings.warn(f"hipGraph capture of the training step failed ({type(exc).__name__}: {exc}); running eagerly")
             self._graph, self._graph_b, self.use_graph = None, None, False
             torch.cuda.synchronize()
+
+    def _reset_factor_store(self):
+        self.model.factor_store.clear()
+        # head bias gradients: queued per Linear, reduced in one launch after backward().  Not when gradient hooks exchange
+        # buckets DURING backward (eager data parallelism): a bucket would leave before its queued bias gradients exist.
+        if not self.reducer.active or self.reducer.deferred:
+            self.model.factor_store[BIAS_QUEUE] = []
 
     def _alloc_factor_buffers(self):
         """{key: (x [B,I], g [B,O])} persistent factor buffers for the deferred head optimizer, allocated by the ordinary
@@ -346,8 +368,11 @@ class TrainStep:
     def _eager_step_body(self):
         self._supply_plan()
         self.reducer.zero_grad()
-        loss = self.forward_loss()
+        with self._Ticks():
+            loss = self.forward_loss()
         loss.backward()
+        if self.factor_opt is not None:
+            flush_bias_grads(self.model.factor_store)
         self.reducer.finish()
         if self.prefetch:
             # the next batch (here: the same synthetic one) is already resident: run ITS first-level FPS + ball query on

@@ -74,7 +74,7 @@ def segment_distance_to_confidence(distance):
 
 
 def stroke_masks_loss(pred_to_gt_match, pred_stroke_masks, scores, stroke_ids, w_masks, w_conf, no_stroke_weight,
-                      return_matching=False, nn_distance=None, smooth_targets=False):
+                      return_matching=False, nn_distance=None, smooth_targets=False, add=None):
     """get_stroke_masks_loss (loss_handler.py:816-935).
 
     pred_to_gt_match i64 [B,S] (nearest GT segment of every predicted segment), pred_stroke_masks [B,M,S] logits,
@@ -93,7 +93,8 @@ def stroke_masks_loss(pred_to_gt_match, pred_stroke_masks, scores, stroke_ids, w
     del _last_status[:-1]
     if not smooth_targets and not return_matching and pred_stroke_masks.dtype == torch.float32:
         # binary targets: the rest of the function as three launches (ops.mask_loss); same algebra, fixed summation order
-        return ops.mask_loss(pred_stroke_masks, scores, target_ids, match, uniq, w_masks, w_conf, no_stroke_weight, status=status)
+        return ops.mask_loss(pred_stroke_masks, scores, target_ids, match, uniq, w_masks, w_conf, no_stroke_weight, status=status,
+                             add=add)      # `add`: the running total of the composite loss, added inside the final launch
     matched = match >= 0                                                                      # [B,M]
     uid = uniq.gather(1, match.clamp(min=0))                                                  # id matched to each pred mask
     in_mask = target_ids[:, None, :] == uid[:, :, None]                                       # [B,M,S]
@@ -110,6 +111,8 @@ def stroke_masks_loss(pred_to_gt_match, pred_stroke_masks, scores, stroke_ids, w
     conf_loss = F.binary_cross_entropy_with_logits(scores, target_scores, weight=weights, reduction="none").mean()
     loss = w_masks * mask_loss + w_conf * conf_loss                                           # :934
     loss = torch.where((status != 0).any(), torch.full_like(loss, float("nan")), loss)
+    if add is not None:
+        loss = loss + add
     return (loss, match) if return_matching else loss
 
 
@@ -207,7 +210,9 @@ class LossHandler:
         values = []
         for name in self.loss:
             value = self.loss_methods[self.loss_index[name]](**loss_args)
-            total = total + cfg["weight_" + name] * value
+            w = cfg["weight_" + name]
+            term = value if (isinstance(w, (int, float)) and w == 1) else w * value      # (a launch saved for the usual weight 1)
+            total = term if (isinstance(total, int) and total == 0) else total + term
             values.append(value.detach())
         if return_list:
             array = torch.stack(values).cpu().numpy()
@@ -254,12 +259,12 @@ class LossHandler:
         return 100 * chamfer_distance(y_pred, y, padded=True, asymmetric=True)[0]
 
     # `_w` (internal): a constant the composite losses fold into the reduction kernel together with the 100 (no scalar launches)
-    def get_reverse_asymm_point_chamfer(self, y_pred, y, traj_as_pc, _w=1.0, **args):
+    def get_reverse_asymm_point_chamfer(self, y_pred, y, traj_as_pc, _w=1.0, _add=None, **args):
         return chamfer_distance(self._pose_cloud(y_pred), self._on_device(traj_as_pc, y_pred), padded=True,
-                                reverse_asymmetric=True, _scale=100.0 * float(_w))[0]
+                                reverse_asymmetric=True, _scale=100.0 * float(_w), _add=_add)[0]
 
-    def get_reverse_asymm_segment_chamfer(self, y_pred, y, _w=1.0, **args):
-        return chamfer_distance(y_pred, y, padded=True, reverse_asymmetric=True, _scale=100.0 * float(_w))[0]
+    def get_reverse_asymm_segment_chamfer(self, y_pred, y, _w=1.0, _add=None, **args):
+        return chamfer_distance(y_pred, y, padded=True, reverse_asymmetric=True, _scale=100.0 * float(_w), _add=_add)[0]
 
     def get_attraction_chamfer(self, y_pred, **args):
         return 100 * chamfer_distance(y_pred[:, :, :3], y_pred[:, :, -3:], padded=False)[0]
@@ -285,11 +290,12 @@ class LossHandler:
     # ---------------------------------------------------------------------------------------------------------
     # stroke masks
     def get_stroke_masks_loss(self, pred_to_gt_match, pred_stroke_masks, scores, stroke_ids, nn_distance=None,
-                              smooth_targets=False, **kwargs):
+                              smooth_targets=False, _add=None, **kwargs):
         cfg = self._cfg()
         return stroke_masks_loss(pred_to_gt_match, pred_stroke_masks, scores, stroke_ids,
                                  cfg["explicit_weight_stroke_masks"], cfg["explicit_weight_stroke_masks_confidence"],
-                                 cfg["explicit_no_stroke_weight"], nn_distance=nn_distance, smooth_targets=bool(smooth_targets))
+                                 cfg["explicit_no_stroke_weight"], nn_distance=nn_distance, smooth_targets=bool(smooth_targets),
+                                 add=_add)
 
     @staticmethod
     def _transform_segment_distance_to_confidence(distance):
@@ -317,13 +323,19 @@ class LossHandler:
     def get_asymm_v6_chamfer_with_stroke_masks(self, y_pred, y, pred_stroke_masks, mask_scores, seg_logits, stroke_ids,
                                                traj_as_pc, **kwargs):
         cfg = self._cfg()
-        # the term weights of :660-664 travel into the reduction kernels (_w)
+        # the term weights of :660-664 travel into the reduction kernels (_w), and on the GPU the terms are chained through the
+        # kernels' `add` input (each reduction adds the running total): the sum of :660-664 costs no launch of its own
         seg, conf, match, d = self._segment_term(y_pred, y, seg_logits, _w=cfg["weight_asymm_segment_chamfer"])
-        pts = self.get_reverse_asymm_point_chamfer(y_pred, y, traj_as_pc, _w=cfg["weight_reverse_asymm_point_chamfer"])     # :623-637
-        rev = self.get_reverse_asymm_segment_chamfer(y_pred, y, _w=cfg["weight_reverse_asymm_segment_chamfer"])             # :641-645
+        chain = y_pred.is_cuda
+        run = seg + conf if (chain and not isinstance(conf, int)) else seg
+        pts = self.get_reverse_asymm_point_chamfer(y_pred, y, traj_as_pc, _w=cfg["weight_reverse_asymm_point_chamfer"],
+                                                   _add=run if chain else None)                                            # :623-637
+        rev = self.get_reverse_asymm_segment_chamfer(y_pred, y, _w=cfg["weight_reverse_asymm_segment_chamfer"],
+                                                     _add=pts if chain else None)                                           # :641-645
         masks = self.get_stroke_masks_loss(match, pred_stroke_masks, mask_scores, stroke_ids, nn_distance=d,
-                                           smooth_targets=cfg.get("smooth_target_stroke_masks", False), **kwargs)
-        return seg + conf + pts + rev + masks                                      # :660-664
+                                           smooth_targets=cfg.get("smooth_target_stroke_masks", False),
+                                           _add=rev if chain else None, **kwargs)
+        return masks if chain else seg + conf + pts + rev + masks                  # :660-664
 
     def get_asymm_v11_chamfer_with_stroke_masks(self, y_pred, y, pred_stroke_masks, mask_scores, seg_logits,
                                                 stroke_ids, traj_as_pc, **kwargs):

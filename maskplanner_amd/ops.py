@@ -420,12 +420,12 @@ def knn(p1, p2, lengths1=None, lengths2=None, K=1):
 
 class _ChamferReduce(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, cham, lengths, point_mean, batch_mode, div, scale):
+    def forward(ctx, cham, lengths, point_mean, batch_mode, div, scale, add):
         N, P = cham.shape
         out = torch.empty((N,) if batch_mode == 0 else (), dtype=torch.float32, device=cham.device)
         scratch = torch.empty((N,), dtype=torch.float32, device=cham.device) if batch_mode != 0 else None
         _run("chamfer_reduce", cham, _lib.load().mp_chamfer_reduce_f32, _p(cham), _p(lengths), N, P, int(point_mean), int(batch_mode),
-             float(div), float(scale), _p(scratch), _p(out))
+             float(div), float(scale), _p(scratch), _p(out), _p(add))
         ctx.save_for_backward(lengths)
         ctx.meta = (N, P, int(point_mean), int(batch_mode), float(div), float(scale))
         return out
@@ -438,16 +438,19 @@ class _ChamferReduce(torch.autograd.Function):
         grad = torch.empty((N, P), dtype=torch.float32, device=grad_out.device)
         _run("chamfer_reduce_bwd", grad_out, _lib.load().mp_chamfer_reduce_bwd_f32, _p(grad_out), _p(lengths), N, P, point_mean,
              batch_mode, div, scale, _p(grad))
-        return grad, None, None, None, None, None
+        return grad, None, None, None, None, None, (grad_out if ctx.needs_input_grad[6] else None)   # d(out)/d(add) = 1
 
 
-def chamfer_reduce(cham, lengths, point_reduction, batch_reduction, scale=1.0):
+def chamfer_reduce(cham, lengths, point_reduction, batch_reduction, scale=1.0, add=None):
     """pytorch3d_chamfer.py:295-326 in one launch: cham [N,P] (rows beyond a cloud's length already zero) -> sum or mean over
-    the points (mean divides by lengths [N] i64), then None / sum / mean over the batch, times the constant `scale`."""
-    _need_hip(cham, lengths)
+    the points (mean divides by lengths [N] i64), then None / sum / mean over the batch, times the constant `scale`.
+    add: a device scalar (a running total of loss terms) added to a batch-reduced result inside the same launch."""
+    _need_hip(cham, lengths, add)
     N = cham.shape[0]
     batch_mode = {None: 0, "sum": 1, "mean": 2}[batch_reduction]
-    return _ChamferReduce.apply(_f32(cham), _i64(lengths), point_reduction == "mean", batch_mode, float(N), float(scale))
+    if add is not None and (batch_mode == 0 or add.numel() != 1 or add.dtype != torch.float32):
+        raise ValueError("add must be a float32 scalar and needs a batch reduction")
+    return _ChamferReduce.apply(_f32(cham), _i64(lengths), point_reduction == "mean", batch_mode, float(N), float(scale), add)
 
 
 class _PoseOutput(torch.autograd.Function):
@@ -482,14 +485,14 @@ def pose_output(pos, raw, weight_orient):
 
 class _MaskLoss(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, pred, scores, target_ids, match, uniq, w_masks, w_conf, no_stroke_weight, status):
+    def forward(ctx, pred, scores, target_ids, match, uniq, w_masks, w_conf, no_stroke_weight, status, add):
         B, M, S = pred.shape
         dev = pred.device
         per_mask = torch.empty((B * M,), dtype=torch.float32, device=dev)
         out = torch.empty((), dtype=torch.float32, device=dev)
         n_matched = torch.empty((1,), dtype=torch.float32, device=dev)
         _run("mask_loss", pred, _lib.load().mp_mask_loss_f32, _p(pred), _p(scores), _p(target_ids), _p(match), _p(uniq), B, M, S,
-             float(w_masks), float(w_conf), float(no_stroke_weight), _p(per_mask), _p(out), _p(n_matched), _p(status))
+             float(w_masks), float(w_conf), float(no_stroke_weight), _p(per_mask), _p(out), _p(n_matched), _p(status), _p(add))
         ctx.save_for_backward(pred, scores, target_ids, match, uniq, n_matched)
         ctx.meta = (B, M, S, float(w_masks), float(w_conf), float(no_stroke_weight))
         return out
@@ -503,18 +506,20 @@ class _MaskLoss(torch.autograd.Function):
         gs = torch.empty_like(scores) if ctx.needs_input_grad[1] else None
         _run("mask_loss_bwd", pred, _lib.load().mp_mask_loss_bwd_f32, _p(grad_out), _p(pred), _p(scores), _p(target_ids), _p(match),
              _p(uniq), _p(n_matched), B, M, S, w_masks, w_conf, nsw, _p(gm), _p(gs))
-        return gm, gs, None, None, None, None, None, None, None
+        return gm, gs, None, None, None, None, None, None, None, (grad_out if ctx.needs_input_grad[9] else None)
 
 
-def mask_loss(pred_masks, scores, target_ids, match, uniq, w_masks, w_conf, no_stroke_weight, status=None):
+def mask_loss(pred_masks, scores, target_ids, match, uniq, w_masks, w_conf, no_stroke_weight, status=None, add=None):
     """loss_handler.py:877-934 (binary targets) after mask_match: w_masks * matched-BCE.sum(-1).mean() +
     w_conf * weighted confidence BCE.mean(), forward in two launches, backward in one.  status: mask_match's per-sample
     status i32 [B]; a non-zero entry (conditions the reference asserts on / scipy raises for) makes the loss NaN."""
     _need_hip(pred_masks, scores, target_ids, match, uniq, status)
     if status is not None and (status.dtype != torch.int32 or not status.is_contiguous()):
         status = status.to(torch.int32).contiguous()
+    if add is not None and (add.numel() != 1 or add.dtype != torch.float32):
+        raise ValueError("add must be a float32 scalar")
     return _MaskLoss.apply(_f32(pred_masks), _f32(scores), _f32(target_ids), _i64(match), _f32(uniq), w_masks, w_conf,
-                           no_stroke_weight, status)
+                           no_stroke_weight, status, add)
 
 
 class _BnReluRows(torch.autograd.Function):

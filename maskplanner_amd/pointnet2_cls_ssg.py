@@ -66,7 +66,11 @@ def _tick(*bns):
     """num_batches_tracked += 1 for train-mode BatchNorm layers, one launch for all of them (nn.BatchNorm does it per layer)."""
     counters = [bn.num_batches_tracked for bn in bns if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None]
     if counters:
-        torch._foreach_add_(counters, 1)
+        from . import sa_mlp
+        if sa_mlp.DEFERRED_TICKS is not None:
+            sa_mlp.DEFERRED_TICKS.extend(counters)
+        else:
+            torch._foreach_add_(counters, 1)
 
 
 def _pose_output(x, normals_raw, B, out_vectors, weight_orient):

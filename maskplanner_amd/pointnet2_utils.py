@@ -24,6 +24,17 @@ from . import ops
 from . import sa_mlp
 
 _fps_start_queue = []
+_ZEROS = {}
+
+
+def _zeros(shape, device):
+    """A cached all-zero fp32 tensor (read-only by convention): the group-all level needs `new_xyz = 0` and a zero padding
+    column every step; a fill launch each would cost more than the data."""
+    key = (tuple(shape), device)
+    t = _ZEROS.get(key)
+    if t is None:
+        t = _ZEROS[key] = torch.zeros(shape, dtype=torch.float32, device=device)
+    return t
 
 
 @contextlib.contextmanager
@@ -197,12 +208,12 @@ class PointNetSetAbstraction(nn.Module):
         layout = "feats_first" if points is not None else "xyz_first"
         if self.group_all:
             B, N, C = xyz.shape
-            new_xyz = torch.zeros(B, 1, C, device=xyz.device)
+            new_xyz = _zeros((B, 1, C), xyz.device)
             if points is None:
                 grouped = xyz.view(B, 1, N, C)
             else:
                 pad = (-(C + points.shape[2])) % 4
-                parts = [points, xyz] + ([xyz.new_zeros(B, N, pad)] if pad else [])
+                parts = [points, xyz] + ([_zeros((B, N, pad), xyz.device)] if pad else [])
                 grouped = torch.cat(parts, dim=-1).view(B, 1, N, -1)
         else:
             new_xyz, grouped = sample_and_group(self.npoint, self.radius, self.nsample, xyz, points,

@@ -65,13 +65,14 @@ def chamfer_distance(x, y, x_lengths=None, y_lengths=None, x_normals=None, y_nor
                      batch_reduction: Union[str, None] = "mean", point_reduction: Union[str, None] = "mean",
                      velocities=False, min_centroids=False, padded=False, avoid_in_sequence_collapsing=False,
                      soft_attraction=False, asymmetric=False, reverse_asymmetric=False, return_matching=False,
-                     _matching_y=True, _scale=None):
+                     _matching_y=True, _scale=None, _add=None):
     """Chamfer distance between point sets x [N,P1,D] and y [N,P2,D]; see the reference docstring (:95-129) and the
     custom flags (:84-93).  Returns (dist, normals_dist_or_None) and, with return_matching, also the nearest
     neighbour indices (idx_x [N,P1], idx_y [N,P2]).  `_matching_y=False` (not a reference argument; used by this
     package's LossHandler, which only consumes idx_x) returns None for idx_y and skips the y->x search when the distance
     does not need it; `_scale` (likewise internal) multiplies a REDUCED distance by a constant inside the reduction
-    kernel (the loss folds its `100 * weight` factors in there instead of launching scalar multiplies)."""
+    kernel (the loss folds its `100 * weight` factors in there instead of launching scalar multiplies); `_add` (internal, one
+    direction + batch reduction only) is a device scalar -- the running total of a composite loss -- added in the same launch."""
     if not soft_attraction:
         _validate_chamfer_reduction_inputs(batch_reduction, point_reduction)
     if _scale is not None and (point_reduction is None or weights is not None or x_normals is not None or avoid_in_sequence_collapsing
@@ -153,8 +154,10 @@ def chamfer_distance(x, y, x_lengths=None, y_lengths=None, x_normals=None, y_nor
         if weights is None and not return_normals and point_reduction is not None:
             # the training-step case: one fused reduction per direction that reaches the result (ops.chamfer_reduce)
             sc = 1.0 if _scale is None else float(_scale)
-            rx = ops.chamfer_reduce(cham_x, x_lengths, point_reduction, batch_reduction, sc) if (asymmetric or not reverse_asymmetric) else None
-            ry = ops.chamfer_reduce(cham_y, y_lengths, point_reduction, batch_reduction, sc) if not asymmetric else None
+            if _add is not None and not (asymmetric or reverse_asymmetric):
+                raise ValueError("_add needs a single direction")
+            rx = ops.chamfer_reduce(cham_x, x_lengths, point_reduction, batch_reduction, sc, add=_add) if (asymmetric or not reverse_asymmetric) else None
+            ry = ops.chamfer_reduce(cham_y, y_lengths, point_reduction, batch_reduction, sc, add=_add) if not asymmetric else None
             cham_dist = rx if asymmetric else (ry if reverse_asymmetric else rx + ry)
             if return_matching:
                 return cham_dist, None, idx_x.flatten(1, 2), (None if idx_y is None else idx_y.flatten(1, 2))

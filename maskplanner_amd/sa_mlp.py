@@ -17,6 +17,17 @@ def _ptr(t):
     return None if t is None else t.data_ptr()
 
 
+# None: every level advances its BatchNorm counters (num_batches_tracked) itself.  A list: the counters are collected here
+# instead and the owner (harness.TrainStep) advances all of them -- set-abstraction levels and heads -- in one launch per step.
+DEFERRED_TICKS = None
+
+
+def flush_ticks():
+    if DEFERRED_TICKS:
+        torch._foreach_add_(list(DEFERRED_TICKS), 1)
+        del DEFERRED_TICKS[:]
+
+
 class _SharedMLPMax(torch.autograd.Function):
     """args: x [P, C0] (contiguous), K, training, momentum, eps, L, then per layer:
     weight[Co,Ci], bias|None, gamma, beta, running_mean|None, running_var|None."""
@@ -89,13 +100,8 @@ class _SharedMLPMax(torch.autograd.Function):
             dg, dbe = torch.empty_like(gam), torch.empty_like(bet)
             grads[l] = _lib.MlpGrads(_ptr(dw), _ptr(db), _ptr(dg), _ptr(dbe))
             ret += [dw, db, dg, dbe, None, None]
-        # with grad_cols only the leading (feature) columns are produced: the others are never read downstream, but
-        # zero them once so that a stray consumer can never see uninitialised memory
-        gx = None
-        if ctx.needs_input_grad[0]:
-            gx = torch.empty_like(x)
-            if 0 < grad_cols < x.shape[1]:
-                gx[:, (grad_cols + 3) // 4 * 4:].zero_()
+        # with grad_cols only the leading (feature) columns carry a gradient; the library writes zeros into the others
+        gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         ch = (ctypes.c_int64 * len(chans))(*chans)
         lib = _lib.load()
         ws = torch.empty((lib.mp_sa_mlp_workspace_bytes(P, K, n_layers, ch, 1),), dtype=torch.uint8, device=dev)
@@ -202,7 +208,10 @@ def shared_mlp_max(grouped, convs, bns, layout="xyz_first", dtype="f32", sync_bn
     if training:
         counters = [bn.num_batches_tracked for bn in bns if bn.track_running_stats and bn.num_batches_tracked is not None]
         if counters:
-            torch._foreach_add_(counters, 1)  # one launch for the level instead of one per BatchNorm
+            if DEFERRED_TICKS is not None:
+                DEFERRED_TICKS.extend(counters)   # a training harness advances every counter of the step with ONE launch
+            else:
+                torch._foreach_add_(counters, 1)  # one launch for the level instead of one per BatchNorm
     bn0 = bns[0]
     momentum = bn0.momentum if bn0.momentum is not None else 1.0 / max(float(bn0.num_batches_tracked), 1.0)
     grad_cols = cin - 3 if (layout == "feats_first" and cin > 3) else 0

@@ -77,8 +77,15 @@ elif mode in ("dp_graph", "dp_eager"):
     flat = torch.cat([p.detach().reshape(-1) for p in ts.model.parameters()])
     ref = flat.clone()
     dist.broadcast(ref, src=0)
+    worst = {}
+    for n, p_ in ts.model.named_parameters():
+        r0 = p_.detach().clone()
+        dist.broadcast(r0, src=0)
+        d = float((p_.detach() - r0).abs().max())
+        if d > 0:
+            worst[n] = d
     result = dict(losses=losses, replica_diff=float((flat - ref).abs().max()), graph=ts._graph is not None and ts._graph_b is not None,
-                  params=flat.cpu())
+                  params=flat.cpu(), diverged=worst)
 else:
     raise SystemExit(f"unknown mode {mode}")
 

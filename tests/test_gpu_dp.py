@@ -87,7 +87,7 @@ def test_two_graph_step_replays_under_data_parallelism():
     g = _run("dp_graph", 2)
     e = _run("dp_eager", 2)
     assert all(r["graph"] for r in g) and not any(r["graph"] for r in e)
-    assert max(r["replica_diff"] for r in g) == 0.0 and max(r["replica_diff"] for r in e) == 0.0
+    assert max(r["replica_diff"] for r in g) == 0.0 and max(r["replica_diff"] for r in e) == 0.0, (g[1]["diverged"], e[1]["diverged"])
     lg, le = np.array(g[0]["losses"]), np.array(e[0]["losses"])
     assert np.isfinite(lg).all() and lg[-1] < lg[0]
     assert abs(lg[0] - le[0]) <= 1e-4 * abs(le[0]) and np.allclose(lg, le, rtol=5e-2), (lg, le)
