@@ -57,8 +57,9 @@ class TrainStep:
         # the factor Adam of the seven head matrices (0.97 GB of HBM traffic, bandwidth-bound) is launched eagerly on its own
         # stream after the second graph: it then runs underneath the NEXT step's encoder forward (MFMA-bound), which does not
         # touch the head weights; the next step's second graph waits for it.
-        self._graph_b, self._factor_args, self._adam_stream, self._adam_ev = None, None, None, None
+        self._graph_b, self._graph_b2, self._factor_args, self._adam_stream, self._adam_ev = None, None, None, None, None
         self._split_adam_wanted = os.environ.get("MASKPLANNER_SPLIT_ADAM", "1") != "0"
+        self._plan_late = os.environ.get("MASKPLANNER_PLAN_AFTER_FORWARD", "0") != "0"
         self.factor_opt = None
         dense = list(self.model.parameters())
         if factor_heads and fused:
@@ -135,15 +136,20 @@ class TrainStep:
 
     def step(self):
         """One optimisation step; returns the (device) loss tensor without synchronising."""
+        # MASKPLANNER_PLAN_AFTER_FORWARD=1: the next batch's sampling starts BEHIND the encoder forward (graph A), underneath the
+        # heads / loss part of graph B, instead of at the start of the step.  [r2] measured: the same step time either way (FPS then
+        # stretches the loss's kNN kernels by what it no longer costs the forward), so the switch is off.
+        late = self.overlap and self._graph_b is not None and self._plan_late
         if self.overlap:
-            self._pipeline_sampling()
+            self._pipeline_sampling(launch=not late)
         if self._graph is not None:
             self._graph.replay()
+            if late:
+                self._launch_sampling()
             if self._graph_b is not None:
                 if self._adam_ev is not None:
                     torch.cuda.current_stream().wait_event(self._adam_ev)   # the head weights of the previous step are final
-                self._graph_b.replay()
-                self._after_graph_b()
+                self._replay_b()
             return self._graph_loss
         if not self.use_graph:
             return self._eager_step()
@@ -200,10 +206,23 @@ class TrainStep:
             # factors (~5 MB) into buffers allocated here, outside the pool; only graph B writes them and it waits for the
             # optimizer's event before it is replayed.
             persist = self._alloc_factor_buffers() if self.factor_opt is not None else {}
+            # With the head optimizer outside the graphs, B itself is recorded in two parts: B1 = heads + loss + the heads' own
+            # backward (down to the gradient of the global feature), B2 = the encoder's backward + dense Adam.  The head
+            # optimizer then starts right behind B1 and streams its ~1 GB underneath the encoder backward's matrix-core-bound
+            # kernels instead of next to the HBM-bound first level of the following forward.
+            split_bwd = bool(persist) and os.environ.get("MASKPLANNER_SPLIT_BACKWARD", "1") != "0"
+            gb2 = torch.cuda.CUDAGraph() if split_bwd else None
             with torch.cuda.graph(gb, pool=ga.pool(), stream=cap):
-                loss = self._heads_loss(feat)
-                loss.backward()
-                if not self.dp_graph:
+                if split_bwd:
+                    leaf = feat.detach().requires_grad_(True)
+                    loss = self._heads_loss(leaf)
+                    loss.backward()
+                else:
+                    loss = self._heads_loss(feat)
+                    loss.backward()
+                if self.factor_opt is not None:
+                    flush_bias_grads(self.model.factor_store)
+                if not self.dp_graph and not split_bwd:
                     self.reducer.finish()
                     self.opt.step()
                 loss = loss.detach()
@@ -219,20 +238,25 @@ class TrainStep:
                             elif seen[d_.data_ptr()] != s_.data_ptr():
                                 raise RuntimeError(f"factor {k}: expected to share its input activation")
                     torch._foreach_copy_(dsts, srcs)
+            if split_bwd:
+                with torch.cuda.graph(gb2, pool=ga.pool(), stream=cap):
+                    feat.backward(leaf.grad)
+                    if not self.dp_graph:
+                        self.reducer.finish()
+                        self.opt.step()
             if self.dp_graph:
                 self._static_grads = [(p, p.grad) for p in self.reducer.params if p.grad is not None]
             self._factor_args = persist
             if self.factor_opt is not None:
                 self._reset_factor_store()
             self._adam_stream = torch.cuda.Stream()
-            self._graph, self._graph_b, self._graph_loss = ga, gb, loss
+            self._graph, self._graph_b, self._graph_b2, self._graph_loss = ga, gb, gb2, loss
             ga.replay()
-            gb.replay()
-            self._after_graph_b()
+            self._replay_b()
         except Exception as exc:   # stay correct: eager from here on
             import warnings
             warnings.warn(f"hipGraph capture of the training step failed ({type(exc).__name__}: {exc}); running eagerly")
-            self._graph, self._graph_b, self.use_graph = None, None, False
+            self._graph, self._graph_b, self._graph_b2, self.use_graph = None, None, None, False
             torch.cuda.synchronize()
 
     def _reset_factor_store(self):
@@ -256,12 +280,17 @@ class TrainStep:
             out[k] = (px, torch.empty((B, O), dtype=torch.float32, device=self.device))
         return out
 
-    def _after_graph_b(self):
+    def _replay_b(self):
+        """Graph B (or B1, head optimizer, B2) and what follows it eagerly."""
+        self._graph_b.replay()
+        if self._graph_b2 is not None:
+            self._launch_factor_adam()          # behind B1: underneath the encoder backward
+            self._graph_b2.replay()
         if self.dp_graph:      # the exchange and the dense optimizer of a data-parallel step, eagerly on the step's stream
             self.reducer.rearm(self._static_grads)
             self.reducer.finish()
             self.opt.step()
-        if self.factor_opt is not None:
+        if self.factor_opt is not None and self._graph_b2 is None:
             self._launch_factor_adam()
 
     def _launch_factor_adam(self):
@@ -317,11 +346,12 @@ class TrainStep:
             ops.ball_query(m.radius, m.nsample, xyz, new_xyz, out=idx)
             xyz = new_xyz
 
-    def _pipeline_sampling(self):
+    def _pipeline_sampling(self, launch=True):
         """Launched eagerly in front of every step (never recorded: a second branch inside the hipGraph made the replay
         insert ~7 us synchronisation gaps all along the main chain, 26 per step): the plan computed during the previous step
         becomes this step's with one copy kernel, then the next batch's sampling (here: the same resident synthetic batch,
-        recomputed every step) starts on the second stream and runs underneath the step."""
+        recomputed every step) starts on the second stream and runs underneath the step.  launch=False: only the hand-over;
+        the caller starts the next sampling itself (_launch_sampling) at the point of the step it should run under."""
         main = torch.cuda.current_stream()
         if self._plan_next is None:
             self._plan_next = torch.zeros(self._plan_size(), dtype=torch.int64, device=self.device)
@@ -337,8 +367,14 @@ class TrainStep:
         torch.add(self._plan_next, 0, out=self._plan_cur)        # an elementwise kernel into the step's static buffer
         if self._stream is not None:
             self._stream.publish()                               # the collated next batch becomes the step's batch
+        if launch:
+            self._launch_sampling()
+
+    def _launch_sampling(self):
+        """The next batch's collation + sampling plan on the second stream, ordered after everything the step's stream holds so
+        far (at least the hand-over copy: only then may the next plan / the staging tensors be overwritten)."""
         side = self._plan_stream
-        side.wait_stream(main)                                   # ... and only then may the next plan / staging be overwritten
+        side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             if self._stream is not None:
                 xyz, starts = self._stream.collate_next()        # host items -> device staging tensors, on the side stream

@@ -1206,3 +1206,37 @@ def test_streamed_batches_feed_the_step_what_the_collate_produces():
     assert ts._graph is not None
     losses = [float(l) for l in losses]
     assert np.isfinite(losses).all()
+
+
+@pytest.mark.gpu
+def test_every_launch_mode_updates_the_same_parameters(monkeypatch):
+    """Regression: the recorded step once left the head biases without gradient (their batched reduction was only called on the
+    eager path) and nothing noticed -- losses still fell.  Whatever the launch mode (kernel by kernel, one graph, two graphs
+    with the deferred head optimizer, three graphs with the backward split behind the heads), one step must move exactly the
+    parameters the eager step moves, by steps of the same size (Adam: |delta| ~ lr)."""
+    from maskplanner_amd.harness import TrainStep
+
+    def moved(graph, split_adam, split_bwd):
+        monkeypatch.setenv("MASKPLANNER_SPLIT_ADAM", split_adam)
+        monkeypatch.setenv("MASKPLANNER_SPLIT_BACKWARD", split_bwd)
+        ts = TrainStep("cuboids", B=4, N=1024, seed=3, graph=graph)
+        for _ in range(5):
+            ts.step()
+        torch.cuda.synchronize()
+        before = {n: p.detach().clone() for n, p in ts.model.named_parameters()}
+        ts.step()
+        if graph:
+            ts.step()     # the deferred head optimizer of a step is only guaranteed complete behind the next one
+        torch.cuda.synchronize()
+        shape = (ts._graph is not None, ts._graph_b is not None, ts._graph_b2 is not None)
+        return {n: float((p.detach() - before[n]).abs().max()) for n, p in ts.model.named_parameters()}, shape
+
+    want, shape = moved(False, "1", "1")
+    assert shape == (False, False, False)
+    assert all(want[n] > 0 for n in want if n.startswith(("fc", "sm_", "bn", "mask_conf"))), {n: v for n, v in want.items() if v == 0}
+    for mode, expect in ((("0", "0"), (True, False, False)), (("1", "0"), (True, True, False)), (("1", "1"), (True, True, True))):
+        got, shape = moved(True, *mode)
+        assert shape == expect, (mode, shape)
+        frozen = [n for n in want if (want[n] > 0) != (got[n] > 0)]
+        assert not frozen, (mode, frozen)
+        assert all(got[n] < 10 * 2 * 1e-3 + 1e-6 for n in got), mode     # two steps of at most ~lr each
