@@ -251,6 +251,34 @@ __device__ __forceinline__ bf16x8 tr_frag(const __bf16* tile, int ld, int k0, in
     return r;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// fp32 contraction on the bf16 matrix cores ("split" kernels): x = h + m + l with three bf16 numbers (8 + 8 + 8 significant
+// bits: the differences x - h and (x - h) - m are exact in fp32, so only l is rounded, at 2^-25 |x|), and
+//   x * w  =  h_x h_w + (h_x m_w + m_x h_w) + (m_x m_w + h_x l_w + l_x h_w)  +  O(2^-24 |x w|)
+// -- the six products of order <= 2^-16, each EXACT in the fp32 accumulate of v_mfma_f32_32x32x16_bf16.  What is dropped
+// (m l, l m, l l) is of the size of ONE fp32 rounding of the product, i.e. the result carries the same error as the fp32 FMA
+// chain it replaces (tests/test_gpu_split.py measures both against fp64).  Six bf16 MFMAs of K = 16 take 6 x 8 passes where
+// the eight v_mfma_f32_32x32x2_f32 they replace take 8 x 16 -- and, unlike the fp32 MFMA, they run beside the VALU instead
+// of on it.
+// ---------------------------------------------------------------------------------------------------------------
+struct Split4 { bf16x4 h, m, l; };
+__device__ __forceinline__ Split4 split3(const float4& v)
+{
+    Split4 r;
+    const float x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const __bf16 h = (__bf16)x[i];
+        const float r1 = x[i] - (float)h;
+        const __bf16 m = (__bf16)r1;
+        const float r2 = r1 - (float)m;
+        r.h[i] = h;
+        r.m[i] = m;
+        r.l[i] = (__bf16)r2;
+    }
+    return r;
+}
+
 // acc += A * B over one K chunk.  A_TR / B_TR: the operand's tile is [k][row or col] (transposed reads) instead of [row][k].
 template <bool A_TR, bool B_TR, int LDA, int LDB, int TM, int TN, int KC>
 __device__ __forceinline__ void mma_chunk_bf16(const __bf16* sA, const __bf16* sB, int wrow0, int wcol0, f32x16 (&acc)[TM][TN])
@@ -703,7 +731,7 @@ __global__ __launch_bounds__(THREADS) void dw_gemm_kernel(PosOperand DZ, PosOper
 // other waves' MFMAs instead of being a separate phase of a 128 x 128 tile.  One partial-sum row per workgroup
 // (P / p_per_block rows instead of P / 128) also makes the BatchNorm finalize kernel 8x shorter.
 // =================================================================================================================
-template <int CI, int CO, bool POOL, int MODE_A = SRC_ACT, int TAIL = 0>   // TAIL = 4: input rows are [CI | 4] wide (features | xyz + pad)
+template <int CI, int CO, bool POOL, int MODE_A = SRC_ACT, int TAIL = 0, bool SPLIT = false>   // TAIL = 4: input rows are [CI | 4] wide (features | xyz + pad)
 __global__ __launch_bounds__(CO > 128 ? 512 : 256) void fwd_chunk_kernel(PosOperand A, int P, int p_per_block,
                                                                          const float* __restrict__ W, float* __restrict__ Z,
                                                                          float* __restrict__ partials, PoolOut po,
@@ -718,8 +746,12 @@ __global__ __launch_bounds__(CO > 128 ? 512 : 256) void fwd_chunk_kernel(PosOper
     constexpr int NFR = BIG ? CI / 2 : CI / 4;        // weight fragment registers per lane
     constexpr int NV = BIG ? 16 : 8;                  // rows of the chunk held by one lane
     static_assert((CW == 32 || CW == 16) && PA >= 1, "shape");
+    static_assert(!SPLIT || BIG, "the split kernels use the 32x32x16 bf16 MFMA");
     typedef float f32x4 __attribute__((ext_vector_type(4)));
-    __shared__ __attribute__((aligned(16))) float sA[2][DBK * LDA];
+    // SPLIT: the chunk as three bf16 planes [plane][row][k] (rows 16-byte aligned, stride = 4 dwords mod 64 banks)
+    constexpr int LDH = CI + 8;
+    __shared__ __attribute__((aligned(16))) float sA[2][SPLIT ? 4 : DBK * LDA];
+    __shared__ __attribute__((aligned(16))) __bf16 sH[2][3][SPLIT ? DBK * LDH : 8];
     __shared__ float4 sT[2][TAIL ? DBK : 1];           // TAIL: the 4 extra input columns of the chunk's rows
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
@@ -732,9 +764,24 @@ __global__ __launch_bounds__(CO > 128 ? 512 : 256) void fwd_chunk_kernel(PosOper
     if (nchunks <= 0) return;
 
     // B[k][n] = W[n][k]: 32x32x2 lane (n, kq) holds W[col][2*st + kq]; 16x16x4 lane (n, kq) holds W[col][4*st + kq]
-    float wfrag[NFR];
+    float wfrag[SPLIT ? 1 : NFR];
+    bf16x8 wsp[SPLIT ? 3 : 1][SPLIT ? CI / 16 : 1];  // SPLIT: lane (n, kq) holds W[col][16*st + 8*kq .. + 7] as (h, m, l) planes
+    if constexpr (SPLIT) {
 #pragma unroll
-    for (int st = 0; st < NFR; ++st) wfrag[st] = W[(size_t)col * (CI + TAIL) + (BIG ? 2 : 4) * st + kq];
+        for (int st = 0; st < CI / 16; ++st) {
+            const float* wp = W + (size_t)col * (CI + TAIL) + 16 * st + 8 * kq;
+            const Split4 lo = split3(ld4(wp)), hi = split3(ld4(wp + 4));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                wsp[0][st][i] = lo.h[i]; wsp[0][st][4 + i] = hi.h[i];
+                wsp[1][st][i] = lo.m[i]; wsp[1][st][4 + i] = hi.m[i];
+                wsp[2][st][i] = lo.l[i]; wsp[2][st][4 + i] = hi.l[i];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int st = 0; st < NFR; ++st) wfrag[st] = W[(size_t)col * (CI + TAIL) + (BIG ? 2 : 4) * st + kq];
+    }
     float4 wt = make_float4(0.f, 0.f, 0.f, 0.f);     // TAIL: this lane's column of the 4 extra weight columns (VALU, not MFMA:
     if constexpr (TAIL != 0) wt = ld4(W + (size_t)col * (CI + TAIL) + CI);   // a 32-wide k tile would be 1/8 full)
 
@@ -751,8 +798,17 @@ __global__ __launch_bounds__(CO > 128 ? 512 : 256) void fwd_chunk_kernel(PosOper
     };
     auto sstore = [&](int buf) {
 #pragma unroll
-        for (int ps = 0; ps < PA; ++ps)
-            *reinterpret_cast<float4*>(&sA[buf][(ka0 + ps * KA_STEP) * LDA + ca]) = finish<MODE_A>(ra[ps], kc);
+        for (int ps = 0; ps < PA; ++ps) {
+            if constexpr (SPLIT) {
+                const Split4 sp = split3(finish<MODE_A>(ra[ps], kc));
+                const int o = (ka0 + ps * KA_STEP) * LDH + ca;
+                *reinterpret_cast<bf16x4*>(&sH[buf][0][o]) = sp.h;
+                *reinterpret_cast<bf16x4*>(&sH[buf][1][o]) = sp.m;
+                *reinterpret_cast<bf16x4*>(&sH[buf][2][o]) = sp.l;
+            } else {
+                *reinterpret_cast<float4*>(&sA[buf][(ka0 + ps * KA_STEP) * LDA + ca]) = finish<MODE_A>(ra[ps], kc);
+            }
+        }
         if constexpr (TAIL != 0) { if (tid < DBK) sT[buf][tid] = finish<MODE_A>(rt, kc); }
     };
 
@@ -781,7 +837,28 @@ __global__ __launch_bounds__(CO > 128 ? 512 : 256) void fwd_chunk_kernel(PosOper
         const int cur = kcn & 1;
         if (kcn + 1 < nchunks) gload(p0 + (kcn + 1) * DBK);
         float v[NV];
-        if constexpr (BIG) {
+        if constexpr (SPLIT) {
+            // two accumulators: the leading products and the five corrections (summed among themselves first, and two
+            // independent MFMA chains instead of one)
+            f32x16 acc, cor;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[r] = 0.0f; cor[r] = 0.0f; }
+            const int ao = (lane & 31) * LDH + 8 * kq;                // A[row = lane & 31][k = 16*st + 8*kq .. + 7]
+#pragma unroll
+            for (int st = 0; st < CI / 16; ++st) {
+                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(&sH[cur][0][ao + 16 * st]);
+                const bf16x8 am = *reinterpret_cast<const bf16x8*>(&sH[cur][1][ao + 16 * st]);
+                const bf16x8 al = *reinterpret_cast<const bf16x8*>(&sH[cur][2][ao + 16 * st]);
+                cor = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, wsp[0][st], cor, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wsp[0][st], acc, 0, 0, 0);
+                cor = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wsp[2][st], cor, 0, 0, 0);
+                cor = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, wsp[1][st], cor, 0, 0, 0);
+                cor = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, wsp[0][st], cor, 0, 0, 0);
+                cor = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wsp[1][st], cor, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = acc[r] + cor[r];
+        } else if constexpr (BIG) {
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
@@ -1587,6 +1664,13 @@ inline int log2_or_neg(int64_t k)
 }
 
 // MP_CHUNK_FWD=0 keeps the tiled GEMM kernel for every forward layer (A/B timing)
+// MP_SA_SPLIT=1: the fp32 contractions of the position-stream kernels as six bf16 MFMAs on (h, m, l) operand planes (split3)
+inline bool split_enabled()
+{
+    static const bool on = getenv("MP_SA_SPLIT") && atoi(getenv("MP_SA_SPLIT")) != 0;
+    return on;
+}
+
 inline bool chunk_fwd_enabled()
 {
     static const bool on = !(getenv("MP_CHUNK_FWD") && atoi(getenv("MP_CHUNK_FWD")) == 0);
@@ -1708,8 +1792,12 @@ static int sa_mlp_fwd(const float* x0, int64_t P, int64_t K, int n_layers, const
             while ((P + ppb - 1) / ppb < 512 && ppb > 128) ppb >>= 1;
             const unsigned gx = (unsigned)((P + ppb - 1) / ppb);
             const double fl = 2.0 * (double)P * Co_ * Ci_, by = 4.0 * ((double)P * (Ci_ + Co_) + (double)Co_ * Ci_);
-            MP_LAUNCH("fwd_chunk_kernel<128, 128, false, 0, 4>", fl, by, (fwd_chunk_kernel<128, 128, false, SRC_ID, 4>), dim3(gx), dim3(256), 0, stream, A,
-                      (int)P, ppb, L.weight, L.z, partials, po, L.gamma);
+            if (split_enabled())
+                MP_LAUNCH("fwd_chunk_kernel<128, 128, false, 0, 4, split>", fl, by, (fwd_chunk_kernel<128, 128, false, SRC_ID, 4, true>), dim3(gx), dim3(256), 0, stream, A,
+                          (int)P, ppb, L.weight, L.z, partials, po, L.gamma);
+            else
+                MP_LAUNCH("fwd_chunk_kernel<128, 128, false, 0, 4>", fl, by, (fwd_chunk_kernel<128, 128, false, SRC_ID, 4>), dim3(gx), dim3(256), 0, stream, A,
+                          (int)P, ppb, L.weight, L.z, partials, po, L.gamma);
             MP_CHECK_LAUNCH();
             nblk = (int)gx;
         } else if (l == 1 && rc_first) {
@@ -1721,6 +1809,8 @@ static int sa_mlp_fwd(const float* x0, int64_t P, int64_t K, int n_layers, const
             snprintf(tg, sizeof tg, "fwd_chunk_kernel<%d, %d, false, 4>", Ci_, Co_);
             if (Co_ == 64)
                 MP_LAUNCH(tg, fl, by, (fwd_chunk_kernel<64, 64, false, SRC_ACT_RC>), dim3(gx), dim3(256), 0, stream, A, (int)P, ppb, L.weight, L.z, partials, po, L.gamma);
+            else if (split_enabled())
+                MP_LAUNCH(tg, fl, by, (fwd_chunk_kernel<64, 128, false, SRC_ACT_RC, 0, true>), dim3(gx), dim3(256), 0, stream, A, (int)P, ppb, L.weight, L.z, partials, po, L.gamma);
             else
                 MP_LAUNCH(tg, fl, by, (fwd_chunk_kernel<64, 128, false, SRC_ACT_RC>), dim3(gx), dim3(256), 0, stream, A, (int)P, ppb, L.weight, L.z, partials, po, L.gamma);
             MP_CHECK_LAUNCH();
@@ -1737,13 +1827,17 @@ static int sa_mlp_fwd(const float* x0, int64_t P, int64_t K, int n_layers, const
 #define MP_FWD(CI, CO, PL)                                                                                                     \
     MP_LAUNCH(tg, fl, by, (fwd_chunk_kernel<CI, CO, PL>), dim3(gx), dim3(CO > 128 ? 512 : 256), 0, stream, A, (int)P, ppb, L.weight, L.z, \
               partials, po, L.gamma)
+#define MP_FWD_SPLIT(CI, CO, PL)                                                                                               \
+    MP_LAUNCH(tg, fl, by, (fwd_chunk_kernel<CI, CO, PL, SRC_ACT, 0, true>), dim3(gx), dim3(CO > 128 ? 512 : 256), 0, stream, A, (int)P, ppb, \
+              L.weight, L.z, partials, po, L.gamma)
 #define MP_FWD_CO(CI, PL)                                  \
     if (Co_ == 64) MP_FWD(CI, 64, PL);                     \
-    else if (Co_ == 128) MP_FWD(CI, 128, PL);              \
-    else MP_FWD(CI, 256, PL)
+    else if (Co_ == 128) { if (split_enabled()) MP_FWD_SPLIT(CI, 128, PL); else MP_FWD(CI, 128, PL); }              \
+    else { if (split_enabled()) MP_FWD_SPLIT(CI, 256, PL); else MP_FWD(CI, 256, PL); }
             if (fuse_pool) { if (Ci_ == 64) { MP_FWD_CO(64, true); } else { MP_FWD_CO(128, true); } }
             else { if (Ci_ == 64) { MP_FWD_CO(64, false); } else { MP_FWD_CO(128, false); } }
 #undef MP_FWD_CO
+#undef MP_FWD_SPLIT
 #undef MP_FWD
             MP_CHECK_LAUNCH();
             nblk = (int)gx;

@@ -1,0 +1,65 @@
+"""Accuracy and time of the set-abstraction MLP against an fp64 torch evaluation of the same layers; run once per setting of
+MP_SA_SPLIT (the library reads it once per process):   for v in 0 1; do MP_SA_SPLIT=$v python tools/split_check.py; done"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from maskplanner_amd import sa_mlp
+
+torch.manual_seed(0)
+shapes = [(32, 512, 32, 3, [64, 64, 128]), (32, 128, 64, 131, [128, 128, 256])]
+
+
+def ref64(x, convs, bns):
+    h = x.double()
+    B, S, K, C = h.shape
+    h = h.reshape(-1, C)
+    for conv, bn in zip(convs, bns):
+        w = conv.weight.double().view(conv.out_channels, -1)
+        z = h @ w.t() + conv.bias.double()
+        mean, var = z.mean(0), z.var(0, unbiased=False)
+        h = torch.relu((z - mean) / torch.sqrt(var + bn.eps) * bn.weight.double() + bn.bias.double())
+    return h.view(B, S, K, -1).max(2).values
+
+
+print("MP_SA_SPLIT =", os.environ.get("MP_SA_SPLIT", "0"))
+for B, S, K, C0, mlp in shapes:
+    convs, bns = torch.nn.ModuleList(), torch.nn.ModuleList()
+    last = C0
+    for c in mlp:
+        convs.append(torch.nn.Conv2d(last, c, 1)); bns.append(torch.nn.BatchNorm2d(c)); last = c
+    convs, bns = convs.cuda(), bns.cuda()
+    for bn in bns:
+        torch.nn.init.uniform_(bn.weight, -1.0, 1.0)
+        torch.nn.init.normal_(bn.bias, 0.0, 0.3)
+    x = torch.randn(B, S, K, C0).cuda()
+    if C0 != 3:
+        x = torch.cat([torch.relu(x[..., :-3]), 0.2 * x[..., -3:]], -1)       # features, then centred xyz
+    x.requires_grad_(C0 != 3)
+    g = torch.randn(B, S, mlp[-1]).cuda()
+    layout = "xyz_first" if C0 == 3 else "feats_first"
+    xin = x if C0 == 3 else x
+    y = sa_mlp.shared_mlp_max(xin, convs, bns, layout=layout)
+    (y * g).sum().backward()
+    grads = [p.grad.clone() for p in list(convs.parameters()) + list(bns.parameters())]
+    # fp64 reference (reference channel order: xyz first)
+    xr = x.detach() if C0 == 3 else torch.cat([x.detach()[..., -3:], x.detach()[..., :-3]], -1)
+    xr = xr.double().requires_grad_(True)
+    for p in list(convs.parameters()) + list(bns.parameters()):
+        p.grad = None
+    y64 = ref64(xr, convs, bns)
+    (y64 * g.double()).sum().backward()
+    g64 = [p.grad.clone() for p in list(convs.parameters()) + list(bns.parameters())]
+    err = float((y.double() - y64).abs().max() / y64.abs().max())
+    gerr = max(float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30)) for a, b in zip(grads, g64) if b.abs().max() > 1e-6)
+    for p in list(convs.parameters()) + list(bns.parameters()):
+        p.grad = None
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    for _ in range(3):
+        y = sa_mlp.shared_mlp_max(xin, convs, bns, layout=layout); (y * g).sum().backward()
+    torch.cuda.synchronize()
+    tf = tb = 0.0
+    for _ in range(10):
+        ev[0].record(); y = sa_mlp.shared_mlp_max(xin, convs, bns, layout=layout); ev[1].record(); (y * g).sum().backward(); ev[2].record()
+        torch.cuda.synchronize()
+        tf += ev[0].elapsed_time(ev[1]); tb += ev[1].elapsed_time(ev[2])
+    print(f"level C0={C0} mlp={mlp}: fwd max err / max |y| = {err:.2e}; worst param-grad rel-L2 vs fp64 = {gerr:.2e}; fwd {tf * 100:.0f} us, bwd {tb * 100:.0f} us")
