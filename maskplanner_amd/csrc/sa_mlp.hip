@@ -279,6 +279,25 @@ __device__ __forceinline__ Split4 split3(const float4& v)
     return r;
 }
 
+// K-packed bf16 tile for the split backward kernel: element (row, c) of a [rows][C] chunk sits at (c / 8) * GS + row * 8 + c % 8
+// (GS = rows * 8 + 32 halves: 16-byte groups of 8 channels, rows of one group contiguous, groups 16 dwords apart mod 64 banks:
+// the transposed read's 16 lanes -- 4 rows x 2 half-groups x 2 groups -- then cover 32 distinct banks, 32 lanes all 64).
+// One image serves both contractions that read the chunk:
+//   * as A[row][k = c] of a 16x16x32 MFMA: lane (row, kq) reads the 16 bytes of group 4*st + kq -- 16 lanes = 256 contiguous bytes;
+//   * as [k = row][col = c] of a 32x32x16 MFMA through ds_read_b64_tr_b16: lane 4q + p supplies row q, columns 4p .. 4p+3.
+template <int GS>
+__device__ __forceinline__ bf16x8 tr_frag_packed(const __bf16* tile, int k0, int c0)
+{
+    const int lane = threadIdx.x & 63;
+    const int i = lane & 15, q = i >> 2, pp = i & 3, nh = (lane >> 4) & 1, h = lane >> 5;
+    const __bf16* p = tile + ((c0 >> 3) + 2 * nh + (pp >> 1)) * GS + (k0 + 8 * h + q) * 8 + 4 * (pp & 1);
+    typedef __attribute__((address_space(3))) bf16x4* lds_ptr;
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_ptr)(p));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_ptr)(p + 4 * 8));
+    bf16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return r;
+}
+
 // acc += A * B over one K chunk.  A_TR / B_TR: the operand's tile is [k][row or col] (transposed reads) instead of [row][k].
 template <bool A_TR, bool B_TR, int LDA, int LDB, int TM, int TN, int KC>
 __device__ __forceinline__ void mma_chunk_bf16(const __bf16* sA, const __bf16* sB, int wrow0, int wcol0, f32x16 (&acc)[TM][TN])
@@ -952,13 +971,13 @@ __global__ __launch_bounds__(CO > 128 ? 512 : 256) void fwd_chunk_kernel(PosOper
 // BatchNorm-backward sums of layer l-1 from the raw Z_{l-1} chunk kept beside the activated one: 4 tensor passes.
 // The dX tile of a chunk is computed as eight 16x16 MFMA tiles, two per wave.
 // =================================================================================================================
-template <int MODE_DZ, int CO, int CI, int MODE_IN = SRC_ACT>
+template <int MODE_DZ, int CO, int CI, int MODE_IN = SRC_ACT, bool SPLIT = false>
 __global__ __launch_bounds__((CO >= 128 && CI == 128 ? 512 : 256), (CO >= 128 && CI == 128 ? 1 : 2)) void bwd_fused_kernel(PosOperand DZ, PosOperand IN, int P, int p_per_block,
                                                             const float* __restrict__ W, float* __restrict__ dW,
                                                             float* __restrict__ G, float* __restrict__ partials)
 {
     constexpr int NT = (CO >= 128 && CI == 128) ? 512 : 256, NW = NT / 64;  // 8 waves for the 128-input layers (registers per wave)
-    constexpr int DBK = CI == 128 ? 16 : 32;   // positions per chunk (LDS and registers: at least two workgroups per CU)
+    constexpr int DBK = (CI == 128 || SPLIT) ? 16 : 32;   // positions per chunk (LDS and registers: at least two workgroups per CU)
     constexpr int XW = DBK == 32 ? CI / (NW / 2) : CI / NW; // dX columns per wave (the chunk's dX tile is [DBK x CI])
     constexpr int HT = XW / 16;                             // 16x16 dX tiles per wave and chunk
     constexpr int LDA = CO + 4;                 // 16-byte aligned rows: one ds_write_b128 per staged float4, ds_read_b128 dX fragments
@@ -967,8 +986,12 @@ __global__ __launch_bounds__((CO >= 128 && CI == 128 ? 512 : 256), (CO >= 128 &&
 
     constexpr int PA = DBK * CO / 4 / NT, PB = DBK * CI / 4 / NT;
     static_assert((CO == 64 || CO == 128 || CO == 256) && (CI == 64 || CI == 128) && PA >= 1 && PB >= 1 && HT >= 1, "tile");
-    __shared__ __attribute__((aligned(16))) float sA[2][DBK * LDA];
-    __shared__ __attribute__((aligned(16))) float sB[2][DBK * CI];
+    static_assert(!SPLIT || DBK == 16, "split: one 32x32x16 k-step of positions per chunk");
+    constexpr int GS = DBK * 8 + 32;            // SPLIT: K-packed planes (tr_frag_packed), group stride in halves: 16 dwords mod 64 banks
+    __shared__ __attribute__((aligned(16))) float sA[2][SPLIT ? 4 : DBK * LDA];
+    __shared__ __attribute__((aligned(16))) float sB[2][SPLIT ? 4 : DBK * CI];
+    __shared__ __attribute__((aligned(16))) __bf16 hA[2][3][SPLIT ? (CO / 8) * GS : 8];   // dZ chunk as (h, m, l) planes
+    __shared__ __attribute__((aligned(16))) __bf16 hB[2][3][SPLIT ? (CI / 8) * GS : 8];   // activated input chunk
     __shared__ __attribute__((aligned(16))) float sZ[2][DBK * CI];
     __shared__ float red[2][2][CI];
     const int tid = threadIdx.x;
@@ -987,13 +1010,27 @@ __global__ __launch_bounds__((CO >= 128 && CI == 128 ? 512 : 256), (CO >= 128 &&
 #pragma unroll
             for (int r = 0; r < 16; ++r) accW[mi][ni][r] = 0.0f;
 
-    // every thread keeps the same channels for the whole kernel
-    const int ca = (tid % (CO / 4)) * 4, cb = (tid % (CI / 4)) * 4;
-    const int ka0 = tid / (CO / 4), kb0 = tid / (CI / 4);
-    constexpr int KA_STEP = NT / (CO / 4), KB_STEP = NT / (CI / 4);
+    // every thread keeps the same channels for the whole kernel.  SPLIT: a wave stages 4 positions x 64 channels per pass (16 lanes x
+    // 16 bytes of one row: 256-byte global segments), so that its ds_write_b64 into the K-packed planes touch every bank twice
+    constexpr int NBA = CO / 64, NBB = CI / 64;
+    const int ca = SPLIT ? ((tid >> 6) % NBA) * 64 + 4 * (tid & 15) : (tid % (CO / 4)) * 4;
+    const int cb = SPLIT ? ((tid >> 6) % NBB) * 64 + 4 * (tid & 15) : (tid % (CI / 4)) * 4;
+    const int ka0 = SPLIT ? ((tid >> 6) / NBA) * 4 + ((tid & 63) >> 4) : tid / (CO / 4);
+    const int kb0 = SPLIT ? ((tid >> 6) / NBB) * 4 + ((tid & 63) >> 4) : tid / (CI / 4);
+    constexpr int KA_STEP = SPLIT ? 4 * (NW / NBA) : NT / (CO / 4), KB_STEP = SPLIT ? 4 * (NW / NBB) : NT / (CI / 4);
+    static_assert(!SPLIT || (PA * KA_STEP == DBK && PB * KB_STEP == DBK), "split staging covers the chunk");
     ChanConst ka, kb;
     load_consts<MODE_DZ>(DZ, ca, ka);
     load_consts<MODE_IN>(IN, cb, kb);
+    // SPLIT, 256-output layer: the registers hold 96 weight-plane and 64 dW-accumulator values per lane; the per-channel constants of
+    // the staging arithmetic wait in LDS between chunks instead (five ds_read_b128 per chunk, no spill code in the loop)
+    constexpr bool LDS_CONSTS = SPLIT && CO == 256 && !is_rc(MODE_IN) && !is_rc(MODE_DZ);
+    __shared__ float4 sKA[LDS_CONSTS ? 5 : 1][LDS_CONSTS ? CO / 4 : 1];
+    __shared__ float4 sKB[LDS_CONSTS ? 2 : 1][LDS_CONSTS ? CI / 4 : 1];
+    if constexpr (LDS_CONSTS) {
+        sKA[0][ca >> 2] = ka.s; sKA[1][ca >> 2] = ka.t; sKA[2][ca >> 2] = ka.a; sKA[3][ca >> 2] = ka.e; sKA[4][ca >> 2] = ka.f;
+        sKB[0][cb >> 2] = kb.s; sKB[1][cb >> 2] = kb.t;
+    }
     Raw4<MODE_DZ> ra[PA];
     Raw4<MODE_IN> rb[PB];
     auto gload = [&](int pk) {
@@ -1003,13 +1040,34 @@ __global__ __launch_bounds__((CO >= 128 && CI == 128 ? 512 : 256), (CO >= 128 &&
         for (int ps = 0; ps < PB; ++ps) raw_load<MODE_IN>(IN, p1, pk + kb0 + ps * KB_STEP, cb, rb[ps]);
     };
     auto sstore = [&](int buf) {
+        if constexpr (LDS_CONSTS) {
+            ka.s = sKA[0][ca >> 2]; ka.t = sKA[1][ca >> 2]; ka.a = sKA[2][ca >> 2]; ka.e = sKA[3][ca >> 2]; ka.f = sKA[4][ca >> 2];
+            kb.s = sKB[0][cb >> 2]; kb.t = sKB[1][cb >> 2];
+        }
 #pragma unroll
-        for (int ps = 0; ps < PA; ++ps)
-            *reinterpret_cast<float4*>(&sA[buf][(ka0 + ps * KA_STEP) * LDA + ca]) = finish<MODE_DZ>(ra[ps], ka);
+        for (int ps = 0; ps < PA; ++ps) {
+            if constexpr (SPLIT) {
+                const Split4 sp = split3(finish<MODE_DZ>(ra[ps], ka));
+                const int o = (ca >> 3) * GS + (ka0 + ps * KA_STEP) * 8 + (ca & 7);
+                *reinterpret_cast<bf16x4*>(&hA[buf][0][o]) = sp.h;
+                *reinterpret_cast<bf16x4*>(&hA[buf][1][o]) = sp.m;
+                *reinterpret_cast<bf16x4*>(&hA[buf][2][o]) = sp.l;
+            } else {
+                *reinterpret_cast<float4*>(&sA[buf][(ka0 + ps * KA_STEP) * LDA + ca]) = finish<MODE_DZ>(ra[ps], ka);
+            }
+        }
 #pragma unroll
         for (int ps = 0; ps < PB; ++ps) {
             const int o = (kb0 + ps * KB_STEP) * CI + cb;
-            *reinterpret_cast<float4*>(&sB[buf][o]) = finish<MODE_IN>(rb[ps], kb);
+            if constexpr (SPLIT) {
+                const Split4 sp = split3(finish<MODE_IN>(rb[ps], kb));
+                const int oh = (cb >> 3) * GS + (kb0 + ps * KB_STEP) * 8 + (cb & 7);
+                *reinterpret_cast<bf16x4*>(&hB[buf][0][oh]) = sp.h;
+                *reinterpret_cast<bf16x4*>(&hB[buf][1][oh]) = sp.m;
+                *reinterpret_cast<bf16x4*>(&hB[buf][2][oh]) = sp.l;
+            } else {
+                *reinterpret_cast<float4*>(&sB[buf][o]) = finish<MODE_IN>(rb[ps], kb);
+            }
             *reinterpret_cast<float4*>(&sZ[buf][o]) = rb[ps].ok ? raw_z<MODE_IN>(rb[ps], kb) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
@@ -1023,11 +1081,29 @@ __global__ __launch_bounds__((CO >= 128 && CI == 128 ? 512 : 256), (CO >= 128 &&
     // them.  (The sum over k is the same set of products in another order: G differs from the k-ordered chain by rounding.)
     const int xrow0 = DBK == 32 ? (wave / (NW / 2)) * 16 : 0;
     const int xcol0 = DBK == 32 ? (wave % (NW / 2)) * XW : wave * XW;
-    float wfrag[HT][CO / 4];
+    float wfrag[SPLIT ? 1 : HT][SPLIT ? 1 : CO / 4];
+    bf16x8 wsp[SPLIT ? HT : 1][SPLIT ? CO / 32 : 1][3];   // SPLIT (16x16x32): lane (col, kq) holds W[32*st + 8*kq .. + 7][col] as planes
+    if constexpr (SPLIT) {
 #pragma unroll
-    for (int h = 0; h < HT; ++h)
+        for (int h = 0; h < HT; ++h)
 #pragma unroll
-        for (int st = 0; st < CO / 4; ++st) wfrag[h][st] = W[(size_t)((lane >> 4) * KPL + st) * CI + xcol0 + 16 * h + (lane & 15)];
+            for (int st = 0; st < CO / 32; ++st) {
+                const float* wp = W + (size_t)(32 * st + 8 * (lane >> 4)) * CI + xcol0 + 16 * h + (lane & 15);
+                const Split4 lo = split3(make_float4(wp[0], wp[CI], wp[2 * CI], wp[3 * CI]));
+                const Split4 hi = split3(make_float4(wp[4 * CI], wp[5 * CI], wp[6 * CI], wp[7 * CI]));
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    wsp[h][st][0][i] = lo.h[i]; wsp[h][st][0][4 + i] = hi.h[i];
+                    wsp[h][st][1][i] = lo.m[i]; wsp[h][st][1][4 + i] = hi.m[i];
+                    wsp[h][st][2][i] = lo.l[i]; wsp[h][st][2][4 + i] = hi.l[i];
+                }
+            }
+    } else {
+#pragma unroll
+        for (int h = 0; h < HT; ++h)
+#pragma unroll
+            for (int st = 0; st < CO / 4; ++st) wfrag[h][st] = W[(size_t)((lane >> 4) * KPL + st) * CI + xcol0 + 16 * h + (lane & 15)];
+    }
     typedef float f2_ __attribute__((ext_vector_type(2)));
     float spx[HT], tpx[HT];                     // this lane's G columns
     f2_ sx1[HT], sx2[HT];                       // BatchNorm-backward sums of those columns, two row slots each
@@ -1049,7 +1125,43 @@ __global__ __launch_bounds__((CO >= 128 && CI == 128 ? 512 : 256), (CO >= 128 &&
     for (int kc = 0; kc < nchunks; ++kc) {
         const int cur = kc & 1;
         if (kc + 1 < nchunks) gload(p0 + (kc + 1) * DBK);
-        mma_chunk_pipelined<true, true, LDA, CI, TMW, TNW, DBK>(sA[cur], sB[cur], wrow0, wcol0, accW);   // dW += dZ^T * act(Z_{l-1})
+        auto do_dw = [&]() {
+        if constexpr (SPLIT) {   // dW += dZ^T * act(Z_{l-1}): one k-step of 16 positions, six plane products per tile
+            // fragments in the order they are consumed (one dZ plane live at a time): l*h, h*l, h*m, h*h, m*m, m*h
+            bf16x8 fb[3][TNW], fa[TMW];
+#pragma unroll
+            for (int ni = 0; ni < TNW; ++ni) fb[0][ni] = tr_frag_packed<GS>(hB[cur][0], 0, wcol0 + ni * 32);
+#pragma unroll
+            for (int mi = 0; mi < TMW; ++mi) fa[mi] = tr_frag_packed<GS>(hA[cur][2], 0, wrow0 + mi * 32);
+#pragma unroll
+            for (int mi = 0; mi < TMW; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < TNW; ++ni) accW[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mi], fb[0][ni], accW[mi][ni], 0, 0, 0);
+#pragma unroll
+            for (int mi = 0; mi < TMW; ++mi) fa[mi] = tr_frag_packed<GS>(hA[cur][0], 0, wrow0 + mi * 32);
+#pragma unroll
+            for (int pl = 2; pl >= 1; --pl)
+#pragma unroll
+                for (int ni = 0; ni < TNW; ++ni) fb[pl][ni] = tr_frag_packed<GS>(hB[cur][pl], 0, wcol0 + ni * 32);
+#pragma unroll
+            for (int pl = 2; pl >= 0; --pl)
+#pragma unroll
+                for (int mi = 0; mi < TMW; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < TNW; ++ni) accW[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mi], fb[pl][ni], accW[mi][ni], 0, 0, 0);
+#pragma unroll
+            for (int mi = 0; mi < TMW; ++mi) fa[mi] = tr_frag_packed<GS>(hA[cur][1], 0, wrow0 + mi * 32);
+#pragma unroll
+            for (int pl = 1; pl >= 0; --pl)
+#pragma unroll
+                for (int mi = 0; mi < TMW; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < TNW; ++ni) accW[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mi], fb[pl][ni], accW[mi][ni], 0, 0, 0);
+        } else {
+            mma_chunk_pipelined<true, true, LDA, CI, TMW, TNW, DBK>(sA[cur], sB[cur], wrow0, wcol0, accW);   // dW += dZ^T * act(Z_{l-1})
+        }
+        };
+        auto do_g = [&]() {
         {   // G_{l-1} chunk [DBK x 64] = dZ [DBK x CO] * W_l [CO x 64] as 16x16 tiles, HT per wave (v_mfma_f32_16x16x4_f32:
             // with 32x32 tiles only one or two waves would have work)
             typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -1057,11 +1169,39 @@ __global__ __launch_bounds__((CO >= 128 && CI == 128 ? 512 : 256), (CO >= 128 &&
 #pragma unroll
             for (int h = 0; h < HT; ++h) ax[h] = f32x4{0.f, 0.f, 0.f, 0.f};
             const int l15 = lane & 15, kq = lane >> 4;
-            const float4* arow = reinterpret_cast<const float4*>(sA[cur] + (xrow0 + l15) * LDA + kq * KPL);   // A[row][k = kq*KPL + s]
-            constexpr int AB = 2, NB = KPL / (4 * AB);      // batches of AB float4 = 8 steps, fetched one batch ahead
+            if constexpr (SPLIT) {   // v_mfma_f32_16x16x32_bf16: lane (row, kq) holds dZ[row][32*st + 8*kq .. + 7] -- one packed group
+                f32x4 cx[HT];
+#pragma unroll
+                for (int h = 0; h < HT; ++h) cx[h] = f32x4{0.f, 0.f, 0.f, 0.f};
+                const int ao = kq * GS + (xrow0 + l15) * 8;
+                bf16x8 af[2][3];       // the fragments of k-step st + 1 are requested before the MFMAs of step st are issued
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) af[0][pl] = *reinterpret_cast<const bf16x8*>(&hA[cur][pl][ao]);
+#pragma unroll
+                for (int st = 0; st < CO / 32; ++st) {
+                    if (st + 1 < CO / 32) {
+#pragma unroll
+                        for (int pl = 0; pl < 3; ++pl) af[(st + 1) & 1][pl] = *reinterpret_cast<const bf16x8*>(&hA[cur][pl][ao + 4 * (st + 1) * GS]);
+                    }
+                    const bf16x8 ah = af[st & 1][0], am = af[st & 1][1], al = af[st & 1][2];
+#pragma unroll
+                    for (int h = 0; h < HT; ++h) {
+                        cx[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, wsp[h][st][0], cx[h], 0, 0, 0);
+                        ax[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wsp[h][st][0], ax[h], 0, 0, 0);
+                        cx[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wsp[h][st][2], cx[h], 0, 0, 0);
+                        cx[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, wsp[h][st][1], cx[h], 0, 0, 0);
+                        cx[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, wsp[h][st][0], cx[h], 0, 0, 0);
+                        cx[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wsp[h][st][1], cx[h], 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int h = 0; h < HT; ++h) ax[h] += cx[h];
+            }
+            const float4* arow = reinterpret_cast<const float4*>(sA[cur] + (SPLIT ? 0 : (xrow0 + l15) * LDA + kq * KPL));   // A[row][k = kq*KPL + s]
+            constexpr int AB = 2, NB = SPLIT ? 0 : KPL / (4 * AB);      // batches of AB float4 = 8 steps, fetched one batch ahead
             float4 abuf[2][AB];
 #pragma unroll
-            for (int j = 0; j < AB; ++j) abuf[0][j] = arow[j];
+            for (int j = 0; j < (SPLIT ? 0 : AB); ++j) abuf[0][j] = arow[j];
 #pragma unroll
             for (int bt = 0; bt < NB; ++bt) {
                 if (bt + 1 < NB) {
@@ -1102,6 +1242,11 @@ __global__ __launch_bounds__((CO >= 128 && CI == 128 ? 512 : 256), (CO >= 128 &&
             }
             goff += DBK * CI * 4;
         }
+        };
+        // (tried: the two halves of the workgroup walking the two products in opposite order, so that only four waves at a time
+        // read the dZ planes for G -- 254 -> 315 us on the 256-output layer: twice the loop code, spills again)
+        do_dw();
+        do_g();
         if (kc + 1 < nchunks) sstore(cur ^ 1);
         __syncthreads();
     }
@@ -2039,28 +2184,38 @@ static int sa_mlp_bwd(const float* x0, int64_t P, int64_t K, int n_layers, const
             char tg[64];
             snprintf(tg, sizeof tg, "bwd_fused_kernel<%d, %d, %d>", pooled ? 3 : 2, Co, Ci);
 #define MP_FUSED(MODE, CO_, CI_)                                                                                              \
-    MP_LAUNCH(tg, fl, by, (bwd_fused_kernel<MODE, CO_, CI_>), dim3(gx), dim3((CO_ >= 128 && CI_ == 128) ? 512 : 256), 0, stream, DZ, IN, (int)P, ppb, Ly.weight, \
-              grads[l].d_weight, Gn, partials)
+    if (split_enabled())                                                                                                      \
+        MP_LAUNCH(tg, fl, by, (bwd_fused_kernel<MODE, CO_, CI_, SRC_ACT, true>), dim3(gx), dim3((CO_ >= 128 && CI_ == 128) ? 512 : 256), 0, stream, DZ, IN, (int)P, \
+                  ppb, Ly.weight, grads[l].d_weight, Gn, partials);                                                           \
+    else                                                                                                                      \
+        MP_LAUNCH(tg, fl, by, (bwd_fused_kernel<MODE, CO_, CI_>), dim3(gx), dim3((CO_ >= 128 && CI_ == 128) ? 512 : 256), 0, stream, DZ, IN, (int)P, ppb, Ly.weight, \
+                  grads[l].d_weight, Gn, partials)
             if (rc_first && l == 1) {   // (never the pooled layer: n_layers >= 3)
                 snprintf(tg, sizeof tg, "bwd_fused_kernel<2, %d, 64, 4>", Co);
-                if (Co == 64)
+                if (Co == 64 && split_enabled())
+                    MP_LAUNCH(tg, fl, by - 4.0 * (double)P * (Ci - 4), (bwd_fused_kernel<SRC_DZ, 64, 64, SRC_ACT_RC, true>), dim3(gx), dim3(256), 0, stream, DZ, IN,
+                              (int)P, ppb, Ly.weight, grads[l].d_weight, Gn, partials);
+                else if (Co == 64)
                     MP_LAUNCH(tg, fl, by - 4.0 * (double)P * (Ci - 4), (bwd_fused_kernel<SRC_DZ, 64, 64, SRC_ACT_RC>), dim3(gx), dim3(256), 0, stream, DZ, IN,
+                              (int)P, ppb, Ly.weight, grads[l].d_weight, Gn, partials);
+                else if (split_enabled())
+                    MP_LAUNCH(tg, fl, by - 4.0 * (double)P * (Ci - 4), (bwd_fused_kernel<SRC_DZ, 128, 64, SRC_ACT_RC, true>), dim3(gx), dim3(256), 0, stream, DZ, IN,
                               (int)P, ppb, Ly.weight, grads[l].d_weight, Gn, partials);
                 else
                     MP_LAUNCH(tg, fl, by - 4.0 * (double)P * (Ci - 4), (bwd_fused_kernel<SRC_DZ, 128, 64, SRC_ACT_RC>), dim3(gx), dim3(256), 0, stream, DZ, IN,
                               (int)P, ppb, Ly.weight, grads[l].d_weight, Gn, partials);
             } else if (Co == 256) {
-                if (pooled) MP_FUSED(SRC_DZ_POOLED, 256, 128); else MP_FUSED(SRC_DZ, 256, 128);
+                if (pooled) { MP_FUSED(SRC_DZ_POOLED, 256, 128); } else { MP_FUSED(SRC_DZ, 256, 128); }
             } else if (pooled) {
-                if (Co == 64 && Ci == 64) MP_FUSED(SRC_DZ_POOLED, 64, 64);
-                else if (Co == 128 && Ci == 64) MP_FUSED(SRC_DZ_POOLED, 128, 64);
-                else if (Co == 64 && Ci == 128) MP_FUSED(SRC_DZ_POOLED, 64, 128);
-                else MP_FUSED(SRC_DZ_POOLED, 128, 128);
+                if (Co == 64 && Ci == 64) { MP_FUSED(SRC_DZ_POOLED, 64, 64); }
+                else if (Co == 128 && Ci == 64) { MP_FUSED(SRC_DZ_POOLED, 128, 64); }
+                else if (Co == 64 && Ci == 128) { MP_FUSED(SRC_DZ_POOLED, 64, 128); }
+                else { MP_FUSED(SRC_DZ_POOLED, 128, 128); }
             } else {
-                if (Co == 64 && Ci == 64) MP_FUSED(SRC_DZ, 64, 64);
-                else if (Co == 128 && Ci == 64) MP_FUSED(SRC_DZ, 128, 64);
-                else if (Co == 64 && Ci == 128) MP_FUSED(SRC_DZ, 64, 128);
-                else MP_FUSED(SRC_DZ, 128, 128);
+                if (Co == 64 && Ci == 64) { MP_FUSED(SRC_DZ, 64, 64); }
+                else if (Co == 128 && Ci == 64) { MP_FUSED(SRC_DZ, 128, 64); }
+                else if (Co == 64 && Ci == 128) { MP_FUSED(SRC_DZ, 64, 128); }
+                else { MP_FUSED(SRC_DZ, 128, 128); }
             }
 #undef MP_FUSED
             MP_CHECK_LAUNCH();
