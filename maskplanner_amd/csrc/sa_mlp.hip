@@ -1331,7 +1331,7 @@ __global__ __launch_bounds__(256) void rc_stats_kernel(const float* __restrict__
 // Kernel 4b: the same single pass for the FIRST layer of a level whose grouped input is [128 features | xyz | pad] (132
 // columns): dW [128 x 132] (128 columns by MFMA, the 4 coordinate columns by plain FMAs on the staged tiles) and the
 // feature part of grad_x0 (128 columns; coordinates carry no gradient), no BatchNorm sums (there is no layer below).
-template <int MODE_DZ>
+template <int MODE_DZ, bool SPLIT = false>
 __global__ __launch_bounds__(512) void bwd_first_kernel(PosOperand DZ, PosOperand IN, int P, int p_per_block,
                                                            const float* __restrict__ W, float* __restrict__ dW,
                                                            float* __restrict__ G)
@@ -1342,8 +1342,14 @@ __global__ __launch_bounds__(512) void bwd_first_kernel(PosOperand DZ, PosOperan
     constexpr int NB4 = DBK * CIW / 4;                  // 528 float4 of the input chunk
     constexpr int PB = (NB4 + NT - 1) / NT;             // 2 (the last pass has 16 live threads)
     typedef float f32x4 __attribute__((ext_vector_type(4)));
+    // SPLIT: dZ and the 128 feature columns of the input as (h, m, l) bf16 planes in the K-packed layout of bwd_fused_kernel; the
+    // fp32 dZ chunk and the 4 coordinate columns stay beside them for the four coordinate columns of dW (plain FMAs)
+    constexpr int GS = DBK * 8 + 32;
     __shared__ __attribute__((aligned(16))) float sA[2][DBK * LDA];
-    __shared__ __attribute__((aligned(16))) float sB[2][DBK * LDB];
+    __shared__ __attribute__((aligned(16))) float sB[2][SPLIT ? 4 : DBK * LDB];
+    __shared__ __attribute__((aligned(16))) __bf16 hA[2][3][SPLIT ? (CO / 8) * GS : 8];
+    __shared__ __attribute__((aligned(16))) __bf16 hB[2][3][SPLIT ? (CIX / 8) * GS : 8];
+    __shared__ float4 sT[2][SPLIT ? DBK : 1];
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63, l15 = lane & 15, kq = lane >> 4, l31 = lane & 31;
     const int wrow0 = (wave >> 1) * 32, wcol0 = (wave & 1) * 64;   // dW tiles: waves 4 x 2, 1 x 2 tiles of 32 x 32 each
@@ -1360,13 +1366,31 @@ __global__ __launch_bounds__(512) void bwd_first_kernel(PosOperand DZ, PosOperan
     float tacc = 0.0f;                                  // dW[tid & 127][128 + (tid >> 7)]
 
     const int xcol0 = wave * 16;                        // this wave's 16 grad_x0 columns (one 16x16 tile)
-    float wfrag[CO / 4];
+    float wfrag[SPLIT ? 1 : CO / 4];
+    bf16x8 wsp[SPLIT ? CO / 32 : 1][3];                 // SPLIT (16x16x32): lane (col, kq) holds W[32*st + 8*kq .. + 7][col] as planes
+    if constexpr (SPLIT) {
 #pragma unroll
-    for (int st = 0; st < CO / 4; ++st) wfrag[st] = W[(size_t)(kq * KPL + st) * CIW + xcol0 + l15];   // permuted k: k = kq * KPL + st
+        for (int st = 0; st < CO / 32; ++st) {
+            const float* wp = W + (size_t)(32 * st + 8 * kq) * CIW + xcol0 + l15;
+            const Split4 lo = split3(make_float4(wp[0], wp[CIW], wp[2 * CIW], wp[3 * CIW]));
+            const Split4 hi = split3(make_float4(wp[4 * CIW], wp[5 * CIW], wp[6 * CIW], wp[7 * CIW]));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                wsp[st][0][i] = lo.h[i]; wsp[st][0][4 + i] = hi.h[i];
+                wsp[st][1][i] = lo.m[i]; wsp[st][1][4 + i] = hi.m[i];
+                wsp[st][2][i] = lo.l[i]; wsp[st][2][4 + i] = hi.l[i];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int st = 0; st < CO / 4; ++st) wfrag[st] = W[(size_t)(kq * KPL + st) * CIW + xcol0 + l15];   // permuted k: k = kq * KPL + st
+    }
     const __amdgpu_buffer_rsrc_t grsrc = __builtin_amdgcn_make_buffer_rsrc(G + (size_t)p0 * CIW, 0, (p1 - p0) * CIW * 4, 0x00020000);
     int goff = (4 * kq * CIW + xcol0 + l15) * 4;
 
-    const int ca = (tid % (CO / 4)) * 4, ka0 = tid / (CO / 4);
+    // SPLIT: a wave stages 4 positions x 64 channels (see bwd_fused_kernel): all 16 positions of dZ and of the features in one pass
+    const int ca = SPLIT ? (wave & 1) * 64 + 4 * (tid & 15) : (tid % (CO / 4)) * 4;
+    const int ka0 = SPLIT ? (wave >> 1) * 4 + (lane >> 4) : tid / (CO / 4);
     constexpr int KA_STEP = NT / (CO / 4);
     ChanConst ka, kb;
     load_consts<MODE_DZ>(DZ, ca, ka);
@@ -1379,21 +1403,43 @@ __global__ __launch_bounds__(512) void bwd_first_kernel(PosOperand DZ, PosOperan
         brow[ps] = e / (CIW / 4);
         bcol[ps] = (e - brow[ps] * (CIW / 4)) * 4;
     }
+    if constexpr (SPLIT) {      // pass 0: the features, in the plane mapping; pass 1: threads 0..15 take the coordinate quad of row tid
+        brow[0] = ka0; bcol[0] = ca;
+        brow[1] = tid & 15; bcol[1] = CIX;
+    }
     auto gload = [&](int pk) {
 #pragma unroll
         for (int ps = 0; ps < PA; ++ps) raw_load<MODE_DZ>(DZ, p1, pk + ka0 + ps * KA_STEP, ca, ra[ps]);
 #pragma unroll
         for (int ps = 0; ps < PB; ++ps)
-            if (ps * NT + tid < NB4) raw_load<SRC_ID>(IN, p1, pk + brow[ps], bcol[ps], rb[ps]);
+            if (SPLIT ? (ps == 0 || tid < DBK) : (ps * NT + tid < NB4)) raw_load<SRC_ID>(IN, p1, pk + brow[ps], bcol[ps], rb[ps]);
     };
     auto sstore = [&](int buf) {
 #pragma unroll
-        for (int ps = 0; ps < PA; ++ps)
-            *reinterpret_cast<float4*>(&sA[buf][(ka0 + ps * KA_STEP) * LDA + ca]) = finish<MODE_DZ>(ra[ps], ka);
+        for (int ps = 0; ps < PA; ++ps) {
+            const float4 dz = finish<MODE_DZ>(ra[ps], ka);
+            *reinterpret_cast<float4*>(&sA[buf][(ka0 + ps * KA_STEP) * LDA + ca]) = dz;
+            if constexpr (SPLIT) {
+                const Split4 sp = split3(dz);
+                const int o = (ca >> 3) * GS + ka0 * 8 + (ca & 7);
+                *reinterpret_cast<bf16x4*>(&hA[buf][0][o]) = sp.h;
+                *reinterpret_cast<bf16x4*>(&hA[buf][1][o]) = sp.m;
+                *reinterpret_cast<bf16x4*>(&hA[buf][2][o]) = sp.l;
+            }
+        }
+        if constexpr (SPLIT) {
+            const Split4 sp = split3(finish<SRC_ID>(rb[0], kb));
+            const int o = (ca >> 3) * GS + ka0 * 8 + (ca & 7);
+            *reinterpret_cast<bf16x4*>(&hB[buf][0][o]) = sp.h;
+            *reinterpret_cast<bf16x4*>(&hB[buf][1][o]) = sp.m;
+            *reinterpret_cast<bf16x4*>(&hB[buf][2][o]) = sp.l;
+            if (tid < DBK) sT[buf][tid] = finish<SRC_ID>(rb[1], kb);
+        } else {
 #pragma unroll
-        for (int ps = 0; ps < PB; ++ps) {
-            const int e = ps * NT + tid;
-            if (e < NB4) *reinterpret_cast<float4*>(&sB[buf][e * 4]) = finish<SRC_ID>(rb[ps], kb);
+            for (int ps = 0; ps < PB; ++ps) {
+                const int e = ps * NT + tid;
+                if (e < NB4) *reinterpret_cast<float4*>(&sB[buf][e * 4]) = finish<SRC_ID>(rb[ps], kb);
+            }
         }
     };
 
@@ -1403,20 +1449,71 @@ __global__ __launch_bounds__(512) void bwd_first_kernel(PosOperand DZ, PosOperan
     for (int kc = 0; kc < nchunks; ++kc) {
         const int cur = kc & 1;
         if (kc + 1 < nchunks) gload(p0 + (kc + 1) * DBK);
-        mma_chunk_pipelined<true, true, LDA, LDB, 1, 2, DBK>(sA[cur], sB[cur], wrow0, wcol0, accW);   // dW[:, 0:128] += dZ^T * X
+        if constexpr (SPLIT) {   // dW[:, 0:128] += dZ^T * X: six plane products per tile, one dZ plane live at a time
+            bf16x8 fb[3][2], fa;
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) fb[0][ni] = tr_frag_packed<GS>(hB[cur][0], 0, wcol0 + ni * 32);
+            fa = tr_frag_packed<GS>(hA[cur][2], 0, wrow0);
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) accW[0][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb[0][ni], accW[0][ni], 0, 0, 0);
+            fa = tr_frag_packed<GS>(hA[cur][0], 0, wrow0);
+#pragma unroll
+            for (int pl = 2; pl >= 1; --pl)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) fb[pl][ni] = tr_frag_packed<GS>(hB[cur][pl], 0, wcol0 + ni * 32);
+#pragma unroll
+            for (int pl = 2; pl >= 0; --pl)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) accW[0][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb[pl][ni], accW[0][ni], 0, 0, 0);
+            fa = tr_frag_packed<GS>(hA[cur][1], 0, wrow0);
+#pragma unroll
+            for (int pl = 1; pl >= 0; --pl)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) accW[0][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb[pl][ni], accW[0][ni], 0, 0, 0);
+        } else {
+            mma_chunk_pipelined<true, true, LDA, LDB, 1, 2, DBK>(sA[cur], sB[cur], wrow0, wcol0, accW);   // dW[:, 0:128] += dZ^T * X
+        }
         {   // the 4 coordinate columns of dW
             const float* a = sA[cur] + (tid & 127);
-            const float* t = sB[cur] + CIX + (tid >> 7);
+            if constexpr (SPLIT) {
+                const float* t = reinterpret_cast<const float*>(sT[cur]) + (tid >> 7);
 #pragma unroll
-            for (int k = 0; k < DBK; ++k) tacc = __builtin_fmaf(a[k * LDA], t[k * LDB], tacc);
+                for (int k = 0; k < DBK; ++k) tacc = __builtin_fmaf(a[k * LDA], t[k * 4], tacc);
+            } else {
+                const float* t = sB[cur] + CIX + (tid >> 7);
+#pragma unroll
+                for (int k = 0; k < DBK; ++k) tacc = __builtin_fmaf(a[k * LDA], t[k * LDB], tacc);
+            }
         }
         {   // grad_x0 chunk [16 x 128] = dZ [16 x 128] * W[:, 0:128]
             f32x4 ax = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (SPLIT) {
+                f32x4 cx = {0.f, 0.f, 0.f, 0.f};
+                const int ao = kq * GS + l15 * 8;
+                bf16x8 af[2][3];
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) af[0][pl] = *reinterpret_cast<const bf16x8*>(&hA[cur][pl][ao]);
+#pragma unroll
+                for (int st = 0; st < CO / 32; ++st) {
+                    if (st + 1 < CO / 32) {
+#pragma unroll
+                        for (int pl = 0; pl < 3; ++pl) af[(st + 1) & 1][pl] = *reinterpret_cast<const bf16x8*>(&hA[cur][pl][ao + 4 * (st + 1) * GS]);
+                    }
+                    const bf16x8 ah = af[st & 1][0], am = af[st & 1][1], al = af[st & 1][2];
+                    cx = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, wsp[st][0], cx, 0, 0, 0);
+                    ax = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wsp[st][0], ax, 0, 0, 0);
+                    cx = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wsp[st][2], cx, 0, 0, 0);
+                    cx = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, wsp[st][1], cx, 0, 0, 0);
+                    cx = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, wsp[st][0], cx, 0, 0, 0);
+                    cx = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wsp[st][1], cx, 0, 0, 0);
+                }
+                ax += cx;
+            }
             const float4* arow = reinterpret_cast<const float4*>(sA[cur] + l15 * LDA + kq * KPL);
-            constexpr int AB = 2, NB = KPL / (4 * AB);
+            constexpr int AB = 2, NB = SPLIT ? 0 : KPL / (4 * AB);
             float4 abuf[2][AB];
 #pragma unroll
-            for (int j = 0; j < AB; ++j) abuf[0][j] = arow[j];
+            for (int j = 0; j < (SPLIT ? 0 : AB); ++j) abuf[0][j] = arow[j];
 #pragma unroll
             for (int bt = 0; bt < NB; ++bt) {
                 if (bt + 1 < NB) {
@@ -2229,9 +2326,15 @@ static int sa_mlp_bwd(const float* x0, int64_t P, int64_t K, int n_layers, const
             const int ppb = 1024;
             const unsigned gx = (unsigned)((P + ppb - 1) / ppb);
             const double fl = 2.0 * (double)P * Co * (Ci + 128), by = 4.0 * ((pooled ? 1.0 : 2.0) * (double)P * Co + (double)P * (Ci + 128));
-            if (pooled)
+            if (pooled && split_enabled())
+                MP_LAUNCH("bwd_first_kernel<3>", fl, by, (bwd_first_kernel<SRC_DZ_POOLED, true>), dim3(gx), dim3(512), 0, stream, DZ, IN, (int)P, ppb,
+                          Ly.weight, grads[l].d_weight, grad_x0);
+            else if (pooled)
                 MP_LAUNCH("bwd_first_kernel<3>", fl, by, (bwd_first_kernel<SRC_DZ_POOLED>), dim3(gx), dim3(512), 0, stream, DZ, IN, (int)P, ppb,
                           Ly.weight, grads[l].d_weight, grad_x0);
+            else if (split_enabled())
+                MP_LAUNCH("bwd_first_kernel<2>", fl, by, (bwd_first_kernel<SRC_DZ, true>), dim3(gx), dim3(512), 0, stream, DZ, IN, (int)P, ppb, Ly.weight,
+                          grads[l].d_weight, grad_x0);
             else
                 MP_LAUNCH("bwd_first_kernel<2>", fl, by, (bwd_first_kernel<SRC_DZ>), dim3(gx), dim3(512), 0, stream, DZ, IN, (int)P, ppb, Ly.weight,
                           grads[l].d_weight, grad_x0);

@@ -15,7 +15,7 @@ for B, S, K, C0, mlp in shapes:
     x = torch.randn(B, S, K, C0).cuda().requires_grad_(C0 != 3)
     g = torch.randn(B, S, mlp[-1]).cuda()
     for it in range(3):
-        y = sa_mlp.shared_mlp_max(x, convs, bns)
+        y = sa_mlp.shared_mlp_max(x, convs, bns, layout="xyz_first" if C0 == 3 or C0 == 259 else "feats_first")
         (y * g).sum().backward()
 torch.cuda.synchronize()
 print("done")

@@ -41,6 +41,7 @@ for B, S, K, C0, mlp in shapes:
     y = sa_mlp.shared_mlp_max(xin, convs, bns, layout=layout)
     (y * g).sum().backward()
     grads = [p.grad.clone() for p in list(convs.parameters()) + list(bns.parameters())]
+    gx = None if x.grad is None else x.grad.clone()
     # fp64 reference (reference channel order: xyz first)
     xr = x.detach() if C0 == 3 else torch.cat([x.detach()[..., -3:], x.detach()[..., :-3]], -1)
     xr = xr.double().requires_grad_(True)
@@ -50,6 +51,9 @@ for B, S, K, C0, mlp in shapes:
     (y64 * g.double()).sum().backward()
     g64 = [p.grad.clone() for p in list(convs.parameters()) + list(bns.parameters())]
     err = float((y.double() - y64).abs().max() / y64.abs().max())
+    if gx is not None:    # internal order [features | xyz] vs reference order [xyz | features]; coordinates carry no gradient here
+        g64x = xr.grad[..., 3:]
+        print(f"    input-gradient rel-L2 vs fp64 = {float((gx[..., :-3].double() - g64x).norm() / g64x.norm()):.2e}")
     gerr = max(float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30)) for a, b in zip(grads, g64) if b.abs().max() > 1e-6)
     for p in list(convs.parameters()) + list(bns.parameters()):
         p.grad = None
