@@ -325,6 +325,44 @@ __device__ __forceinline__ void mma_chunk_bf16(const __bf16* sA, const __bf16* s
     }
 }
 
+// The six plane products of the split scheme over one K chunk of the tiled kernels: sA / sB point at plane 0, planes are PSA / PSB
+// elements apart.  One A plane is live at a time (l, then h, then m), the three B planes stay.
+template <bool A_TR, bool B_TR, int LDA, int LDB, int TM, int TN, int KC, int PSA, int PSB>
+__device__ __forceinline__ void mma_chunk_split(const __bf16* sA, const __bf16* sB, int wrow0, int wcol0, f32x16 (&acc)[TM][TN])
+{
+    const int lane = threadIdx.x & 63;
+    const int l31 = lane & 31, hi = lane >> 5;
+    auto afrag = [&](int pl, int ks, int mi) -> bf16x8 {
+        if constexpr (A_TR) return tr_frag(sA + pl * PSA, LDA, ks, wrow0 + mi * 32);
+        else return *reinterpret_cast<const bf16x8*>(sA + pl * PSA + (wrow0 + mi * 32 + l31) * LDA + ks + 8 * hi);
+    };
+    auto bfrag = [&](int pl, int ks, int ni) -> bf16x8 {
+        if constexpr (B_TR) return tr_frag(sB + pl * PSB, LDB, ks, wcol0 + ni * 32);
+        else return *reinterpret_cast<const bf16x8*>(sB + pl * PSB + (wcol0 + ni * 32 + l31) * LDB + ks + 8 * hi);
+    };
+#pragma unroll
+    for (int ks = 0; ks < KC; ks += 16) {
+        bf16x8 a[TM], b[3][TN];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) b[pl][ni] = bfrag(pl, ks, ni);
+        constexpr int APL[3] = {2, 0, 1}, NB[3] = {1, 3, 2};      // A plane l meets B plane h; h meets h, m, l; m meets h, m
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi) a[mi] = afrag(APL[s], ks, mi);
+#pragma unroll
+            for (int pl = NB[s] - 1; pl >= 0; --pl)
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < TN; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[pl][ni], acc[mi][ni], 0, 0, 0);
+        }
+    }
+}
+
 // The same chunk product with the operand fetch software-pipelined: the fragments of k-step s+1 are requested from LDS before
 // the MFMAs of step s are issued.  (Left to itself the compiler emits "ds_read; s_waitcnt lgkmcnt(0); MFMA x TM*TN" per step,
 // i.e. every group of MFMAs waits out a full LDS round trip -- visible as ~60 % MFMA utilisation of the fused backward
@@ -386,7 +424,7 @@ struct PoolOut {
     int K;
 };
 
-template <int MODE, bool W_KROW, int EPI, int WAVES_M, int WAVES_N, int TM, int TN, bool BF16 = false>
+template <int MODE, bool W_KROW, int EPI, int WAVES_M, int WAVES_N, int TM, int TN, int PREC = 0>   // PREC: 0 fp32 MFMA, 1 bf16, 3 split (h, m, l) planes
 __global__ __launch_bounds__(THREADS) void pos_gemm_kernel(PosOperand A, int P, const float* __restrict__ W, int N,
                                                            int Kd, float* __restrict__ C, float* __restrict__ partials,
                                                            const float* __restrict__ zprev,
@@ -396,17 +434,20 @@ __global__ __launch_bounds__(THREADS) void pos_gemm_kernel(PosOperand A, int P, 
 {   // ldw: row stride of W in the NN form (>= N: only the first N columns are produced); ldc: row stride of C
     constexpr int BM = WAVES_M * TM * 32;
     constexpr int BN = WAVES_N * TN * 32;
+    constexpr bool BF16 = PREC != 0;
+    constexpr int NPL = PREC == 3 ? 3 : 1;                        // operand planes in LDS
     using TL = std::conditional_t<BF16, __bf16, float>;           // element type of the LDS tiles
     constexpr int LDA = BF16 ? BK + 8 : LDK;                      // bf16: 80-byte rows (16-byte aligned, conflict-free b128 reads)
     constexpr int LDB = BF16 ? (W_KROW ? tr_ld(BN) : BK + 8) : (W_KROW ? BN : LDK);
+    constexpr int PSA = BM * LDA, PSB = W_KROW ? BK * LDB : BN * LDB;   // plane strides
     constexpr bool SUMS = (EPI == EPI_SQ || EPI == EPI_DY || EPI == EPI_SQ_POOL);
     __shared__ float pool_v[EPI == EPI_SQ_POOL ? 2 : 1][BM / 32][EPI == EPI_SQ_POOL ? BN : 1];
     __shared__ int pool_i[EPI == EPI_SQ_POOL ? 2 : 1][BM / 32][EPI == EPI_SQ_POOL ? BN : 1];
     constexpr int A_PASSES = BM / RPP;                // TPR threads x float4 per row, RPP rows per pass
     constexpr int B_PASSES = W_KROW ? (BK * BN / 4 / THREADS) : (BN / RPP);
     static_assert(WAVES_M * WAVES_N == 4, "4 waves");
-    __shared__ __attribute__((aligned(16))) TL sA[2][BM * LDA];
-    __shared__ __attribute__((aligned(16))) TL sB[2][W_KROW ? BK * LDB : BN * LDB];
+    __shared__ __attribute__((aligned(16))) TL sA[2][NPL * PSA];
+    __shared__ __attribute__((aligned(16))) TL sB[2][NPL * PSB];
     __shared__ float red[WAVES_M][2][BN];
 
     const int tid = threadIdx.x;
@@ -449,7 +490,13 @@ __global__ __launch_bounds__(THREADS) void pos_gemm_kernel(PosOperand A, int P, 
 #pragma unroll
         for (int ps = 0; ps < A_PASSES; ++ps) {
             const float4 v = finish<MODE>(ra[ps], kc);
-            if constexpr (BF16) {
+            if constexpr (PREC == 3) {
+                const Split4 sp = split3(v);
+                const int o = (ps * RPP + arow) * LDA + acol;
+                *reinterpret_cast<bf16x4*>(&sA[buf][o]) = sp.h;
+                *reinterpret_cast<bf16x4*>(&sA[buf][PSA + o]) = sp.m;
+                *reinterpret_cast<bf16x4*>(&sA[buf][2 * PSA + o]) = sp.l;
+            } else if constexpr (BF16) {
                 *reinterpret_cast<bf16x4*>(&sA[buf][(ps * RPP + arow) * LDA + acol]) = to_bf16x4(v);
             } else {
                 float* d = &sA[buf][(ps * RPP + arow) * LDA + acol];
@@ -458,7 +505,14 @@ __global__ __launch_bounds__(THREADS) void pos_gemm_kernel(PosOperand A, int P, 
         }
 #pragma unroll
         for (int ps = 0; ps < B_PASSES; ++ps) {
-            if constexpr (BF16) {
+            if constexpr (PREC == 3) {
+                const int e = (ps * THREADS + tid) * 4;
+                const int o = W_KROW ? (e / BN) * LDB + e % BN : (ps * RPP + arow) * LDB + acol;
+                const Split4 sp = split3(rb[ps]);
+                *reinterpret_cast<bf16x4*>(&sB[buf][o]) = sp.h;
+                *reinterpret_cast<bf16x4*>(&sB[buf][PSB + o]) = sp.m;
+                *reinterpret_cast<bf16x4*>(&sB[buf][2 * PSB + o]) = sp.l;
+            } else if constexpr (BF16) {
                 if constexpr (W_KROW) {   // slab element e = row k, column n of the [BK][BN] slab
                     const int e = (ps * THREADS + tid) * 4;
                     *reinterpret_cast<bf16x4*>(&sB[buf][(e / BN) * LDB + e % BN]) = to_bf16x4(rb[ps]);
@@ -482,7 +536,8 @@ __global__ __launch_bounds__(THREADS) void pos_gemm_kernel(PosOperand A, int P, 
         const int cur = kc_ & 1;
         if (kc_ + 1 < nchunks) gload((kc_ + 1) * BK);
 #ifndef MP_ABLATE_MFMA
-        if constexpr (BF16) mma_chunk_bf16<false, W_KROW, LDA, LDB, TM, TN, BK>(sA[cur], sB[cur], wrow0, wcol0, acc);
+        if constexpr (PREC == 3) mma_chunk_split<false, W_KROW, LDA, LDB, TM, TN, BK, PSA, PSB>(sA[cur], sB[cur], wrow0, wcol0, acc);
+        else if constexpr (BF16) mma_chunk_bf16<false, W_KROW, LDA, LDB, TM, TN, BK>(sA[cur], sB[cur], wrow0, wcol0, acc);
         else mma_chunk<false, W_KROW, LDA, LDB, TM, TN, BK>(sA[cur], sB[cur], wrow0, wcol0, acc);
 #endif
         if (kc_ + 1 < nchunks) sstore(cur ^ 1);
@@ -624,7 +679,7 @@ __global__ __launch_bounds__(256) void pool_select_kernel(PoolOut po, const floa
 // Kernel 3: dW[Co, Ci] += sum_p dZ[p, Co] * act(Zin)[p, Ci]   (split over P, fp32 atomics)
 //   both operands are positions-major slabs [BK positions][channels] -> LDS [k][row] layout, straight copies.
 // =================================================================================================================
-template <int MODE_DZ, int MODE_IN, int WAVES_M, int WAVES_N, int TM, int TN, bool BF16 = false>
+template <int MODE_DZ, int MODE_IN, int WAVES_M, int WAVES_N, int TM, int TN, int PREC = 0>
 __global__ __launch_bounds__(THREADS) void dw_gemm_kernel(PosOperand DZ, PosOperand IN, int P, int p_per_block,
                                                           float* __restrict__ dW, int ci_base, int tail_ci)
 {   // tail_ci >= 0: the 4 input channels [tail_ci, tail_ci + 4) (132 = 128 + 4, 260 = 256 + 4: the centred xyz + pad of a
@@ -637,10 +692,13 @@ __global__ __launch_bounds__(THREADS) void dw_gemm_kernel(PosOperand DZ, PosOper
     constexpr int PB = DBK * BN / 4 / THREADS;
     static_assert(WAVES_M * WAVES_N == 4 && PA >= 1 && PB >= 1, "tile");
     static_assert(BM == 128, "the tail-column path maps 256 threads onto 128 rows x 2 column pairs");
+    constexpr bool BF16 = PREC != 0;
+    constexpr int NPL = PREC == 3 ? 3 : 1;
     using TL = std::conditional_t<BF16, __bf16, float>;
     constexpr int LDA = BF16 ? tr_ld(BM) : BM, LDB = BF16 ? tr_ld(BN) : BN;   // bf16: [k][row] tiles read through ds_read_b64_tr_b16
-    __shared__ __attribute__((aligned(16))) TL sA[2][DBK * LDA];
-    __shared__ __attribute__((aligned(16))) TL sB[2][DBK * LDB];
+    constexpr int PSA = DBK * LDA, PSB = DBK * LDB;
+    __shared__ __attribute__((aligned(16))) TL sA[2][NPL * PSA];
+    __shared__ __attribute__((aligned(16))) TL sB[2][NPL * PSB];
     __shared__ __attribute__((aligned(16))) float sT[2][DBK * 4];
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
@@ -682,17 +740,31 @@ __global__ __launch_bounds__(THREADS) void dw_gemm_kernel(PosOperand DZ, PosOper
     auto sstore = [&](int buf) {
 #pragma unroll
         for (int ps = 0; ps < PA; ++ps) {
-            if constexpr (BF16) *reinterpret_cast<bf16x4*>(&sA[buf][(ka0 + ps * KA_STEP) * LDA + ca]) = to_bf16x4(finish<MODE_DZ>(ra[ps], ka));
+            if constexpr (PREC == 3) {
+                const Split4 sp = split3(finish<MODE_DZ>(ra[ps], ka));
+                const int o = (ka0 + ps * KA_STEP) * LDA + ca;
+                *reinterpret_cast<bf16x4*>(&sA[buf][o]) = sp.h;
+                *reinterpret_cast<bf16x4*>(&sA[buf][PSA + o]) = sp.m;
+                *reinterpret_cast<bf16x4*>(&sA[buf][2 * PSA + o]) = sp.l;
+            }
+            else if constexpr (BF16) *reinterpret_cast<bf16x4*>(&sA[buf][(ka0 + ps * KA_STEP) * LDA + ca]) = to_bf16x4(finish<MODE_DZ>(ra[ps], ka));
             else *reinterpret_cast<float4*>(&sA[buf][(ps * THREADS + tid) * 4]) = finish<MODE_DZ>(ra[ps], ka);
         }
 #pragma unroll
         for (int ps = 0; ps < PB; ++ps) {
-            if constexpr (BF16) *reinterpret_cast<bf16x4*>(&sB[buf][(kb0 + ps * KB_STEP) * LDB + cb]) = to_bf16x4(finish<MODE_IN>(rb[ps], kb));
+            if constexpr (PREC == 3) {
+                const Split4 sp = split3(finish<MODE_IN>(rb[ps], kb));
+                const int o = (kb0 + ps * KB_STEP) * LDB + cb;
+                *reinterpret_cast<bf16x4*>(&sB[buf][o]) = sp.h;
+                *reinterpret_cast<bf16x4*>(&sB[buf][PSB + o]) = sp.m;
+                *reinterpret_cast<bf16x4*>(&sB[buf][2 * PSB + o]) = sp.l;
+            }
+            else if constexpr (BF16) *reinterpret_cast<bf16x4*>(&sB[buf][(kb0 + ps * KB_STEP) * LDB + cb]) = to_bf16x4(finish<MODE_IN>(rb[ps], kb));
             else *reinterpret_cast<float4*>(&sB[buf][(ps * THREADS + tid) * 4]) = finish<MODE_IN>(rb[ps], kb);
         }
         if (do_tail && tid < DBK) {
             float4 v = finish<MODE_IN>(rt, kt);
-            if constexpr (BF16) { const bf16x4 h = to_bf16x4(v); v = make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]); }
+            if constexpr (PREC == 1) { const bf16x4 h = to_bf16x4(v); v = make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]); }
             *reinterpret_cast<float4*>(&sT[buf][tid * 4]) = v;
         }
     };
@@ -704,14 +776,16 @@ __global__ __launch_bounds__(THREADS) void dw_gemm_kernel(PosOperand DZ, PosOper
     for (int kc = 0; kc < nchunks; ++kc) {
         const int cur = kc & 1;
         if (kc + 1 < nchunks) gload(p0 + (kc + 1) * DBK);
-        if constexpr (BF16) mma_chunk_bf16<true, true, LDA, LDB, TM, TN, DBK>(sA[cur], sB[cur], wrow0, wcol0, acc);
+        if constexpr (PREC == 3) mma_chunk_split<true, true, LDA, LDB, TM, TN, DBK, PSA, PSB>(sA[cur], sB[cur], wrow0, wcol0, acc);
+        else if constexpr (BF16) mma_chunk_bf16<true, true, LDA, LDB, TM, TN, DBK>(sA[cur], sB[cur], wrow0, wcol0, acc);
         else mma_chunk<true, true, LDA, LDB, TM, TN, DBK>(sA[cur], sB[cur], wrow0, wcol0, acc);
         if (do_tail) {   // thread = (output channel tid & 127, column pair tid >> 7); bf16: the rounded dZ, fp32 coordinates
             const TL* a = sA[cur] + (tid & (BM - 1));
             const float* t = sT[cur] + 2 * (tid >> 7);
 #pragma unroll
             for (int k = 0; k < DBK; ++k) {
-                const float av = (float)a[k * LDA];
+                float av = (float)a[k * LDA];
+                if constexpr (PREC == 3) av = (av + (float)a[PSA + k * LDA]) + (float)a[2 * PSA + k * LDA];   // h + m + l: the fp32 dZ again
                 tacc0 = __builtin_fmaf(av, t[k * 4], tacc0);
                 tacc1 = __builtin_fmaf(av, t[k * 4 + 1], tacc1);
             }
@@ -1606,7 +1680,7 @@ __global__ __launch_bounds__(256) void dw_ci4_kernel(PosOperand DZ, PosOperand I
     }
 }
 
-template <int MODE_DZ, int MODE_IN, bool BF16 = false>
+template <int MODE_DZ, int MODE_IN, int PREC = 0>
 int launch_dw(const PosOperand& DZ, const PosOperand& IN, int64_t P64, float* dW, hipStream_t stream)
 {
     const int Co = DZ.C, Ci = IN.C;
@@ -1624,7 +1698,7 @@ int launch_dw(const PosOperand& DZ, const PosOperand& IN, int64_t P64, float* dW
     const unsigned gx = (unsigned)((P + ppb - 1) / ppb);
     // input-channel tiling: 128-wide tiles, a narrow remainder (132 = 128 + 4, 260 = 2*128 + 4) gets 32-wide tiles so
     // that it does not pay for a whole 128-column MFMA tile of zeros
-    if (!BF16 && Ci == 4 && (Co & 3) == 0 && Co <= 1024 && 256 % (Co / 4) == 0) {
+    if (PREC != 1 && Ci == 4 && (Co & 3) == 0 && Co <= 1024 && 256 % (Co / 4) == 0) {
         double fl = 2.0 * (double)P * Co * Ci, by = 4.0 * ((MODE_DZ == SRC_DZ ? 2.0 : 1.0) * (double)P * Co + (double)P * Ci);
         char tg[64];
         snprintf(tg, sizeof tg, "dw_ci4_kernel<%d, %d>", MODE_DZ, MODE_IN);
@@ -1641,22 +1715,22 @@ int launch_dw(const PosOperand& DZ, const PosOperand& IN, int64_t P64, float* dW
     };
     double flops, bytes;
     work(tail_ci >= 0 ? Ci : main_ci, flops, bytes);
-    const char* kn = BF16 ? "dw_gemm_bf16_kernel" : "dw_gemm_kernel";
+    const char* kn = PREC == 1 ? "dw_gemm_bf16_kernel" : (PREC == 3 ? "dw_gemm_split_kernel" : "dw_gemm_kernel");
     if (main_ci <= 32) {
         snprintf(tag, sizeof tag, "%s<%d, %d, 4, 1, 1, 1>", kn, MODE_DZ, MODE_IN);
-        MP_LAUNCH(tag, flops, bytes, (dw_gemm_kernel<MODE_DZ, MODE_IN, 4, 1, 1, 1, BF16>), dim3(gx, gy, (main_ci + 31) / 32), dim3(THREADS), 0, stream, DZ, IN, P, ppb, dW, 0, tail_ci);
+        MP_LAUNCH(tag, flops, bytes, (dw_gemm_kernel<MODE_DZ, MODE_IN, 4, 1, 1, 1, PREC>), dim3(gx, gy, (main_ci + 31) / 32), dim3(THREADS), 0, stream, DZ, IN, P, ppb, dW, 0, tail_ci);
     } else if (main_ci <= 64) {
         snprintf(tag, sizeof tag, "%s<%d, %d, 4, 1, 1, 2>", kn, MODE_DZ, MODE_IN);
-        MP_LAUNCH(tag, flops, bytes, (dw_gemm_kernel<MODE_DZ, MODE_IN, 4, 1, 1, 2, BF16>), dim3(gx, gy, (main_ci + 63) / 64), dim3(THREADS), 0, stream, DZ, IN, P, ppb, dW, 0, tail_ci);
+        MP_LAUNCH(tag, flops, bytes, (dw_gemm_kernel<MODE_DZ, MODE_IN, 4, 1, 1, 2, PREC>), dim3(gx, gy, (main_ci + 63) / 64), dim3(THREADS), 0, stream, DZ, IN, P, ppb, dW, 0, tail_ci);
     } else {
         snprintf(tag, sizeof tag, "%s<%d, %d, 2, 2, 2, 2>", kn, MODE_DZ, MODE_IN);
-        MP_LAUNCH(tag, flops, bytes, (dw_gemm_kernel<MODE_DZ, MODE_IN, 2, 2, 2, 2, BF16>), dim3(gx, gy, (main_ci + 127) / 128), dim3(THREADS), 0, stream, DZ, IN, P, ppb, dW, 0, tail_ci);
+        MP_LAUNCH(tag, flops, bytes, (dw_gemm_kernel<MODE_DZ, MODE_IN, 2, 2, 2, 2, PREC>), dim3(gx, gy, (main_ci + 127) / 128), dim3(THREADS), 0, stream, DZ, IN, P, ppb, dW, 0, tail_ci);
     }
     MP_CHECK_LAUNCH();
     if (main_ci < Ci && tail_ci < 0) {
         work(Ci - main_ci, flops, bytes);
         snprintf(tag, sizeof tag, "%s<%d, %d, 4, 1, 1, 1>", kn, MODE_DZ, MODE_IN);
-        MP_LAUNCH(tag, flops, bytes, (dw_gemm_kernel<MODE_DZ, MODE_IN, 4, 1, 1, 1, BF16>), dim3(gx, gy, (Ci - main_ci + 31) / 32), dim3(THREADS), 0, stream, DZ, IN, P, ppb, dW, main_ci, -1);
+        MP_LAUNCH(tag, flops, bytes, (dw_gemm_kernel<MODE_DZ, MODE_IN, 4, 1, 1, 1, PREC>), dim3(gx, gy, (Ci - main_ci + 31) / 32), dim3(THREADS), 0, stream, DZ, IN, P, ppb, dW, main_ci, -1);
     }
     MP_CHECK_LAUNCH();
     return MP_OK;
@@ -1850,7 +1924,7 @@ __global__ __launch_bounds__(256) void pool_bwd_prep_kernel(const float* __restr
     partials[((int64_t)blockIdx.x * 2 + 1) * C + c] = s2;
 }
 
-template <int MODE, bool W_KROW, int EPI, bool BF16 = false>
+template <int MODE, bool W_KROW, int EPI, int PREC = 0>
 int launch_pos_gemm(const PosOperand& A, int64_t P, const float* W, int N, int Kd, float* C, float* partials,
                     const float* zprev, const float* sprev, const float* tprev, hipStream_t stream, int* nblk_out,
                     PoolOut po = PoolOut{}, int ldw = 0, int ldc = 0)
@@ -1870,26 +1944,26 @@ int launch_pos_gemm(const PosOperand& A, int64_t P, const float* W, int N, int K
     if (shape == 0 && t128 < 384) shape = (t128x64 >= 384 || EPI == EPI_SQ_POOL) ? 1 : 2;
     if (shape == 1 && N > 64 && EPI != EPI_SQ_POOL && t128x64 < 384) shape = 2;
     char tag[96];
-    const char* kn = BF16 ? "pos_gemm_bf16_kernel" : "pos_gemm_kernel";
+    const char* kn = PREC == 1 ? "pos_gemm_bf16_kernel" : (PREC == 3 ? "pos_gemm_split_kernel" : "pos_gemm_kernel");
     if (shape == 1) {
         const unsigned gm = (unsigned)((P + 127) / 128);
         if (nblk_out) *nblk_out = (int)gm;
         snprintf(tag, sizeof tag, "%s<%d, %s, %d, 4, 1, 1, 2>", kn, MODE, W_KROW ? "true" : "false", EPI);
-        MP_LAUNCH(tag, flops, bytes, (pos_gemm_kernel<MODE, W_KROW, EPI, 4, 1, 1, 2, BF16>), dim3(gm, (N + 63) / 64),
+        MP_LAUNCH(tag, flops, bytes, (pos_gemm_kernel<MODE, W_KROW, EPI, 4, 1, 1, 2, PREC>), dim3(gm, (N + 63) / 64),
                   dim3(THREADS), 0, stream, A, (int)P, W, N, Kd, C, partials, zprev, sprev, tprev, po, ldw, ldc);
     } else if (shape == 2) {
         if constexpr (EPI != EPI_SQ_POOL) {
             const unsigned gm = (unsigned)((P + 63) / 64);
             if (nblk_out) *nblk_out = (int)gm;
             snprintf(tag, sizeof tag, "%s<%d, %s, %d, 2, 2, 1, 1>", kn, MODE, W_KROW ? "true" : "false", EPI);
-            MP_LAUNCH(tag, flops, bytes, (pos_gemm_kernel<MODE, W_KROW, EPI, 2, 2, 1, 1, BF16>), dim3(gm, (N + 63) / 64),
+            MP_LAUNCH(tag, flops, bytes, (pos_gemm_kernel<MODE, W_KROW, EPI, 2, 2, 1, 1, PREC>), dim3(gm, (N + 63) / 64),
                       dim3(THREADS), 0, stream, A, (int)P, W, N, Kd, C, partials, zprev, sprev, tprev, po, ldw, ldc);
         }
     } else {
         const unsigned gm = (unsigned)((P + 127) / 128);
         if (nblk_out) *nblk_out = (int)gm;
         snprintf(tag, sizeof tag, "%s<%d, %s, %d, 2, 2, 2, 2>", kn, MODE, W_KROW ? "true" : "false", EPI);
-        MP_LAUNCH(tag, flops, bytes, (pos_gemm_kernel<MODE, W_KROW, EPI, 2, 2, 2, 2, BF16>), dim3(gm, (N + 127) / 128),
+        MP_LAUNCH(tag, flops, bytes, (pos_gemm_kernel<MODE, W_KROW, EPI, 2, 2, 2, 2, PREC>), dim3(gm, (N + 127) / 128),
                   dim3(THREADS), 0, stream, A, (int)P, W, N, Kd, C, partials, zprev, sprev, tprev, po, ldw, ldc);
     }
     MP_CHECK_LAUNCH();
@@ -1906,10 +1980,12 @@ inline int log2_or_neg(int64_t k)
 }
 
 // MP_CHUNK_FWD=0 keeps the tiled GEMM kernel for every forward layer (A/B timing)
-// MP_SA_SPLIT=1: the fp32 contractions of the position-stream kernels as six bf16 MFMAs on (h, m, l) operand planes (split3)
+// The fp32 contractions run as six bf16 MFMAs on (h, m, l) operand planes (split3) -- fp32-accurate results at 2.7x the
+// matrix rate of v_mfma_f32_*_f32, and beside the VALU instead of on it.  MP_SA_SPLIT=0 selects the fp32-MFMA kernels (A/B timing,
+// bit-for-bit comparisons with the k-ordered FMA chain).
 inline bool split_enabled()
 {
-    static const bool on = getenv("MP_SA_SPLIT") && atoi(getenv("MP_SA_SPLIT")) != 0;
+    static const bool on = !(getenv("MP_SA_SPLIT") && atoi(getenv("MP_SA_SPLIT")) == 0);
     return on;
 }
 
@@ -1959,10 +2035,12 @@ extern "C" int mp_sa_mlp_recompute_first(int n_layers, const int64_t* channels, 
     return channels[0] == 4 && channels[1] == 64 && (channels[2] == 64 || channels[2] == 128) && K > 0;
 }
 
-#define MP_POS_GEMM(MODE, KROW, EPI, ...) \
-    (bf16 ? launch_pos_gemm<MODE, KROW, EPI, true>(__VA_ARGS__) : launch_pos_gemm<MODE, KROW, EPI, false>(__VA_ARGS__))
-#define MP_DW_GEMM(MODE_DZ, MODE_IN, ...) \
-    (bf16 ? launch_dw<MODE_DZ, MODE_IN, true>(__VA_ARGS__) : launch_dw<MODE_DZ, MODE_IN, false>(__VA_ARGS__))
+#define MP_POS_GEMM(MODE, KROW, EPI, ...)                                                                          \
+    (bf16 ? launch_pos_gemm<MODE, KROW, EPI, 1>(__VA_ARGS__)                                                      \
+          : (split_enabled() ? launch_pos_gemm<MODE, KROW, EPI, 3>(__VA_ARGS__) : launch_pos_gemm<MODE, KROW, EPI, 0>(__VA_ARGS__)))
+#define MP_DW_GEMM(MODE_DZ, MODE_IN, ...)                                                                          \
+    (bf16 ? launch_dw<MODE_DZ, MODE_IN, 1>(__VA_ARGS__)                                                           \
+          : (split_enabled() ? launch_dw<MODE_DZ, MODE_IN, 3>(__VA_ARGS__) : launch_dw<MODE_DZ, MODE_IN, 0>(__VA_ARGS__)))
 
 // bf16 = true: every contraction runs on v_mfma_f32_32x32x16_bf16 with both operands rounded to bf16 while they are staged
 // (the generic tiled kernels; the fp32 position-stream / recompute specialisations are not used), everything else as in fp32.

@@ -1144,7 +1144,9 @@ def test_full_size_train_step_b32_vs_oracle(oracle):
     close(sm, o_sm, "sm_out", rtol=6e-4, atol=1e-5)
     close(loss, o_loss, "loss", rtol=2e-4)
     params = dict(model.named_parameters())
-    for name, bound in (("sa1.mlp_convs.0.weight", 5e-2), ("sa1.mlp_bns.1.weight", 2e-2), ("sa2.mlp_convs.2.weight", 2e-2),
+    # (bounds are a few times the routing noise measured between two fp32 implementations: [r2] 1.5e-2 .. 2.3e-2 for the
+    # first level's BatchNorm weights with either the fp32-MFMA or the split-bf16 kernels)
+    for name, bound in (("sa1.mlp_convs.0.weight", 5e-2), ("sa1.mlp_bns.1.weight", 4e-2), ("sa2.mlp_convs.2.weight", 2e-2),
                         ("sa2.mlp_bns.0.bias", 2e-2), ("sa3.mlp_convs.1.weight", 2e-2), ("sa3.mlp_bns.1.weight", 2e-2),
                         ("fc1.weight", 2e-2), ("fc3.weight", 2e-2), ("fc_normals.weight", 2e-2), ("sm_fc3.weight", 2e-2),
                         ("sm_fc3.bias", 2e-2), ("mask_conf_out.weight", 2e-2)):

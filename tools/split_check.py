@@ -6,7 +6,7 @@ import torch
 from maskplanner_amd import sa_mlp
 
 torch.manual_seed(0)
-shapes = [(32, 512, 32, 3, [64, 64, 128]), (32, 128, 64, 131, [128, 128, 256])]
+shapes = [(32, 512, 32, 3, [64, 64, 128]), (32, 128, 64, 131, [128, 128, 256]), (32, 1, 128, 259, [256, 512, 1024])]
 
 
 def ref64(x, convs, bns):
