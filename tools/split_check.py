@@ -1,6 +1,7 @@
 """Accuracy and time of the set-abstraction MLP against an fp64 torch evaluation of the same layers; run once per setting of
-MP_SA_SPLIT (the library reads it once per process):   for v in 0 1; do MP_SA_SPLIT=$v python tools/split_check.py; done"""
-import os, sys
+MP_SA_SPLIT (the library reads it once per process):   for v in 0 1; do MP_SA_SPLIT=$v python tools/split_check.py; done
+--json: one JSON line with the numbers (tests/test_gpu_split.py)."""
+import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from maskplanner_amd import sa_mlp
@@ -21,7 +22,10 @@ def ref64(x, convs, bns):
     return h.view(B, S, K, -1).max(2).values
 
 
-print("MP_SA_SPLIT =", os.environ.get("MP_SA_SPLIT", "0"))
+as_json = "--json" in sys.argv
+results = []
+if not as_json:
+    print("MP_SA_SPLIT =", os.environ.get("MP_SA_SPLIT", "1"))
 for B, S, K, C0, mlp in shapes:
     convs, bns = torch.nn.ModuleList(), torch.nn.ModuleList()
     last = C0
@@ -51,12 +55,19 @@ for B, S, K, C0, mlp in shapes:
     (y64 * g.double()).sum().backward()
     g64 = [p.grad.clone() for p in list(convs.parameters()) + list(bns.parameters())]
     err = float((y.double() - y64).abs().max() / y64.abs().max())
+    xerr = None
     if gx is not None:    # internal order [features | xyz] vs reference order [xyz | features]; coordinates carry no gradient here
         g64x = xr.grad[..., 3:]
-        print(f"    input-gradient rel-L2 vs fp64 = {float((gx[..., :-3].double() - g64x).norm() / g64x.norm()):.2e}")
+        xerr = float((gx[..., :-3].double() - g64x).norm() / g64x.norm())
     gerr = max(float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30)) for a, b in zip(grads, g64) if b.abs().max() > 1e-6)
     for p in list(convs.parameters()) + list(bns.parameters()):
         p.grad = None
+    results.append(dict(c0=C0, mlp=mlp, fwd_err=err, grad_err=gerr, xgrad_err=xerr, out_sum=float(y.double().sum()),
+                        out=y.detach().flatten()[:4096].cpu().tolist()))
+    if as_json:
+        continue
+    if xerr is not None:
+        print(f"    input-gradient rel-L2 vs fp64 = {xerr:.2e}")
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
     for _ in range(3):
         y = sa_mlp.shared_mlp_max(xin, convs, bns, layout=layout); (y * g).sum().backward()
@@ -67,3 +78,5 @@ for B, S, K, C0, mlp in shapes:
         torch.cuda.synchronize()
         tf += ev[0].elapsed_time(ev[1]); tb += ev[1].elapsed_time(ev[2])
     print(f"level C0={C0} mlp={mlp}: fwd max err / max |y| = {err:.2e}; worst param-grad rel-L2 vs fp64 = {gerr:.2e}; fwd {tf * 100:.0f} us, bwd {tb * 100:.0f} us")
+if as_json:
+    print(json.dumps(results))
