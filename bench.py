@@ -344,6 +344,15 @@ def main():
             line["roofline"] = {"kernel": dom, "bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak,
                                 "traffic": measured_traffic(dom), "avg_us": avg_s * 1e6, "launches_per_step": d["calls"] / max(profiled_steps, 1),
                                 "flops_per_launch": flops, "bytes_per_launch": nbytes}
+            if args.dtype == "f32" and os.environ.get("MP_SA_SPLIT", "1") != "0" and any(t in dom for t in ("fused", "chunk", "bwd_first", "gemm")):
+                # `achieved` / `peak` above price the ALGORITHMIC fp32 flops against the fp32-input MFMA peak.  The kernel executes
+                # each fp32 product as six bf16 MFMA products on (h, m, l) operand planes (sa_mlp.hip: split3), so the matrix cores
+                # see 6x the flops at the bf16 rate; both views and the HBM view of the same launch:
+                line["roofline"]["executed"] = {
+                    "what": "fp32 contraction as 6 bf16 plane products (v_mfma_f32_32x32x16_bf16, fp32 accumulate)",
+                    "mfma_TFLOPs": 6.0 * flops / avg_s / 1e12, "mfma_peak": BF16_PEAK_TFLOPS, "mfma_frac": 6.0 * flops / avg_s / 1e12 / BF16_PEAK_TFLOPS,
+                    "hbm_GBps": nbytes / avg_s / 1e9, "hbm_peak": HBM_PEAK_GBS, "hbm_frac": nbytes / avg_s / 1e9 / HBM_PEAK_GBS}
+                line["config"]["contraction"] = "fp32 operands as three bf16 planes, six plane products per fp32 product on the bf16 matrix cores"
             floors = fps_floors(ts, lib) if world == 1 else {}
             line["named_kernels"], line["kernels_us_per_step"] = kernel_tables(kernels, max(profiled_steps, 1), floors)
         side = world == 1 and not args.no_side_legs and args.path == "harness" and args.dist == "cuboid" and args.encoder == "ssg"

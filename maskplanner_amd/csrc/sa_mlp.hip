@@ -1045,8 +1045,11 @@ __global__ __launch_bounds__(CO > 128 ? 512 : 256) void fwd_chunk_kernel(PosOper
 // BatchNorm-backward sums of layer l-1 from the raw Z_{l-1} chunk kept beside the activated one: 4 tensor passes.
 // The dX tile of a chunk is computed as eight 16x16 MFMA tiles, two per wave.
 // =================================================================================================================
+#ifndef MP_SPLIT_WGS
+#define MP_SPLIT_WGS 2     // (3: a third workgroup of the 64-input layers per CU -- tried: 168-register cap, spills in the loop, 150 -> 370 us)
+#endif
 template <int MODE_DZ, int CO, int CI, int MODE_IN = SRC_ACT, bool SPLIT = false>
-__global__ __launch_bounds__((CO >= 128 && CI == 128 ? 512 : 256), (CO >= 128 && CI == 128 ? 1 : 2)) void bwd_fused_kernel(PosOperand DZ, PosOperand IN, int P, int p_per_block,
+__global__ __launch_bounds__((CO >= 128 && CI == 128 ? 512 : 256), (CO >= 128 && CI == 128 ? 1 : ((SPLIT && CI == 64) ? MP_SPLIT_WGS : 2))) void bwd_fused_kernel(PosOperand DZ, PosOperand IN, int P, int p_per_block,
                                                             const float* __restrict__ W, float* __restrict__ dW,
                                                             float* __restrict__ G, float* __restrict__ partials)
 {
@@ -1061,7 +1064,9 @@ __global__ __launch_bounds__((CO >= 128 && CI == 128 ? 512 : 256), (CO >= 128 &&
     constexpr int PA = DBK * CO / 4 / NT, PB = DBK * CI / 4 / NT;
     static_assert((CO == 64 || CO == 128 || CO == 256) && (CI == 64 || CI == 128) && PA >= 1 && PB >= 1 && HT >= 1, "tile");
     static_assert(!SPLIT || DBK == 16, "split: one 32x32x16 k-step of positions per chunk");
-    constexpr int GS = DBK * 8 + 32;            // SPLIT: K-packed planes (tr_frag_packed), group stride in halves: 16 dwords mod 64 banks
+    // SPLIT: K-packed planes (tr_frag_packed), group stride in halves: 16 dwords mod 64 banks.  The 64-input layers are HBM-bound:
+    // a smaller pad (8 dwords: some 2-way conflicts in the transposed reads) lets a third workgroup onto the CU -- more loads in flight
+    constexpr int GS = DBK * 8 + ((SPLIT && CI == 64 && MP_SPLIT_WGS == 3) ? 16 : 32);
     __shared__ __attribute__((aligned(16))) float sA[2][SPLIT ? 4 : DBK * LDA];
     __shared__ __attribute__((aligned(16))) float sB[2][SPLIT ? 4 : DBK * CI];
     __shared__ __attribute__((aligned(16))) __bf16 hA[2][3][SPLIT ? (CO / 8) * GS : 8];   // dZ chunk as (h, m, l) planes
@@ -1098,7 +1103,7 @@ __global__ __launch_bounds__((CO >= 128 && CI == 128 ? 512 : 256), (CO >= 128 &&
     load_consts<MODE_IN>(IN, cb, kb);
     // SPLIT, 256-output layer: the registers hold 96 weight-plane and 64 dW-accumulator values per lane; the per-channel constants of
     // the staging arithmetic wait in LDS between chunks instead (five ds_read_b128 per chunk, no spill code in the loop)
-    constexpr bool LDS_CONSTS = SPLIT && CO == 256 && !is_rc(MODE_IN) && !is_rc(MODE_DZ);
+    constexpr bool LDS_CONSTS = SPLIT && (CO == 256 || (CI == 64 && MP_SPLIT_WGS == 3)) && !is_rc(MODE_IN) && !is_rc(MODE_DZ);
     __shared__ float4 sKA[LDS_CONSTS ? 5 : 1][LDS_CONSTS ? CO / 4 : 1];
     __shared__ float4 sKB[LDS_CONSTS ? 2 : 1][LDS_CONSTS ? CI / 4 : 1];
     if constexpr (LDS_CONSTS) {
