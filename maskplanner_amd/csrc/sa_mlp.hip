@@ -434,6 +434,10 @@ __global__ __launch_bounds__(THREADS) void pos_gemm_kernel(PosOperand A, int P, 
 {   // ldw: row stride of W in the NN form (>= N: only the first N columns are produced); ldc: row stride of C
     constexpr int BM = WAVES_M * TM * 32;
     constexpr int BN = WAVES_N * TN * 32;
+    // (these shadow the file-level constants) split planes on the 64 x 64 tile: K chunks of 64 -- the six-product chunk of 32 is over
+    // before the next chunk's loads have landed, and a barrier pair per 12 MFMAs is too many
+    constexpr int BK = (PREC == 3 && BM * BN <= 64 * 64) ? 64 : MP_BK;
+    constexpr int TPR = BK / 4, RPP = 256 / TPR, LDK = BK + 1;
     constexpr bool BF16 = PREC != 0;
     constexpr int NPL = PREC == 3 ? 3 : 1;                        // operand planes in LDS
     using TL = std::conditional_t<BF16, __bf16, float>;           // element type of the LDS tiles
@@ -446,8 +450,11 @@ __global__ __launch_bounds__(THREADS) void pos_gemm_kernel(PosOperand A, int P, 
     constexpr int A_PASSES = BM / RPP;                // TPR threads x float4 per row, RPP rows per pass
     constexpr int B_PASSES = W_KROW ? (BK * BN / 4 / THREADS) : (BN / RPP);
     static_assert(WAVES_M * WAVES_N == 4, "4 waves");
-    __shared__ __attribute__((aligned(16))) TL sA[2][NPL * PSA];
-    __shared__ __attribute__((aligned(16))) TL sB[2][NPL * PSB];
+    // split planes: ONE buffer (three planes of each operand are 3x the fp32 tile's bytes; two or three workgroups per CU cover
+    // each other's staging instead of a second buffer)
+    constexpr int NBUF = PREC == 3 ? 1 : 2;
+    __shared__ __attribute__((aligned(16))) TL sA[NBUF][NPL * PSA];
+    __shared__ __attribute__((aligned(16))) TL sB[NBUF][NPL * PSB];
     __shared__ float red[WAVES_M][2][BN];
 
     const int tid = threadIdx.x;
@@ -533,14 +540,15 @@ __global__ __launch_bounds__(THREADS) void pos_gemm_kernel(PosOperand A, int P, 
     sstore(0);
     __syncthreads();
     for (int kc_ = 0; kc_ < nchunks; ++kc_) {
-        const int cur = kc_ & 1;
+        const int cur = NBUF == 1 ? 0 : (kc_ & 1);
         if (kc_ + 1 < nchunks) gload((kc_ + 1) * BK);
 #ifndef MP_ABLATE_MFMA
         if constexpr (PREC == 3) mma_chunk_split<false, W_KROW, LDA, LDB, TM, TN, BK, PSA, PSB>(sA[cur], sB[cur], wrow0, wcol0, acc);
         else if constexpr (BF16) mma_chunk_bf16<false, W_KROW, LDA, LDB, TM, TN, BK>(sA[cur], sB[cur], wrow0, wcol0, acc);
         else mma_chunk<false, W_KROW, LDA, LDB, TM, TN, BK>(sA[cur], sB[cur], wrow0, wcol0, acc);
 #endif
-        if (kc_ + 1 < nchunks) sstore(cur ^ 1);
+        if constexpr (NBUF == 1) __syncthreads();      // every wave is done reading the chunk
+        if (kc_ + 1 < nchunks) sstore(NBUF == 1 ? 0 : (cur ^ 1));
         __syncthreads();
     }
 
@@ -697,9 +705,10 @@ __global__ __launch_bounds__(THREADS) void dw_gemm_kernel(PosOperand DZ, PosOper
     using TL = std::conditional_t<BF16, __bf16, float>;
     constexpr int LDA = BF16 ? tr_ld(BM) : BM, LDB = BF16 ? tr_ld(BN) : BN;   // bf16: [k][row] tiles read through ds_read_b64_tr_b16
     constexpr int PSA = DBK * LDA, PSB = DBK * LDB;
-    __shared__ __attribute__((aligned(16))) TL sA[2][NPL * PSA];
-    __shared__ __attribute__((aligned(16))) TL sB[2][NPL * PSB];
-    __shared__ __attribute__((aligned(16))) float sT[2][DBK * 4];
+    constexpr int NBUF = PREC == 3 ? 1 : 2;       // split planes: one buffer, see pos_gemm_kernel
+    __shared__ __attribute__((aligned(16))) TL sA[NBUF][NPL * PSA];
+    __shared__ __attribute__((aligned(16))) TL sB[NBUF][NPL * PSB];
+    __shared__ __attribute__((aligned(16))) float sT[NBUF][DBK * 4];
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     const int wrow0 = (wave / WAVES_N) * TM * 32, wcol0 = (wave % WAVES_N) * TN * 32;
@@ -774,7 +783,7 @@ __global__ __launch_bounds__(THREADS) void dw_gemm_kernel(PosOperand DZ, PosOper
     sstore(0);
     __syncthreads();
     for (int kc = 0; kc < nchunks; ++kc) {
-        const int cur = kc & 1;
+        const int cur = NBUF == 1 ? 0 : (kc & 1);
         if (kc + 1 < nchunks) gload(p0 + (kc + 1) * DBK);
         if constexpr (PREC == 3) mma_chunk_split<true, true, LDA, LDB, TM, TN, DBK, PSA, PSB>(sA[cur], sB[cur], wrow0, wcol0, acc);
         else if constexpr (BF16) mma_chunk_bf16<true, true, LDA, LDB, TM, TN, DBK>(sA[cur], sB[cur], wrow0, wcol0, acc);
@@ -790,7 +799,8 @@ __global__ __launch_bounds__(THREADS) void dw_gemm_kernel(PosOperand DZ, PosOper
                 tacc1 = __builtin_fmaf(av, t[k * 4 + 1], tacc1);
             }
         }
-        if (kc + 1 < nchunks) sstore(cur ^ 1);
+        if constexpr (NBUF == 1) __syncthreads();
+        if (kc + 1 < nchunks) sstore(NBUF == 1 ? 0 : (cur ^ 1));
         __syncthreads();
     }
     const int l31 = lane & 31;
@@ -1948,6 +1958,10 @@ int launch_pos_gemm(const PosOperand& A, int64_t P, const float* W, int N, int K
     int shape = (N <= 64) ? 1 : 0;                       // 0: 128x128, 1: 128x64, 2: 64x64
     if (shape == 0 && t128 < 384) shape = (t128x64 >= 384 || EPI == EPI_SQ_POOL) ? 1 : 2;
     if (shape == 1 && N > 64 && EPI != EPI_SQ_POOL && t128x64 < 384) shape = 2;
+    // (split planes, [r2]: 64 x 64 tiles on all CUs run at 66-80 TFLOP/s on the group_all level; 128 x 128 tiles on half of them were
+    // tried -- MP_POS_BIG_MIN=128 -- and are slower: 55 -> 93 us, one workgroup's K loop alone does not cover its load latency)
+    static const int big_min = getenv("MP_POS_BIG_MIN") ? atoi(getenv("MP_POS_BIG_MIN")) : (1 << 30);
+    if (PREC == 3 && shape == 2 && t128 >= big_min) shape = 0;
     char tag[96];
     const char* kn = PREC == 1 ? "pos_gemm_bf16_kernel" : (PREC == 3 ? "pos_gemm_split_kernel" : "pos_gemm_kernel");
     if (shape == 1) {
