@@ -133,6 +133,13 @@ int mp_knn_bwd_f32(const float* p1, const float* p2, const int64_t* len1, const 
                    const int64_t* idx, const float* grad_dists, int64_t B, int64_t P1, int64_t P2,
                    int64_t D, int64_t K, float* grad_p1, float* grad_p2, int deterministic,
                    mp_stream_t stream);
+/* The backward of K = 1 distances that went straight into mp_chamfer_reduce_f32 (one loss term = nearest neighbours + reduction,
+ * pytorch3d_chamfer.py:257-334): grad_out is the gradient of the REDUCED value ([1], or [B] when batch_mode == 0) and the per-row
+ * factor scale / div / len1[b] is applied inside the scatter -- no [B,P1] gradient tensor, no mp_chamfer_reduce_bwd_f32 launch. */
+int mp_knn_bwd_reduced_f32(const float* p1, const float* p2, const int64_t* len1, const int64_t* len2,
+                           const int64_t* idx, const float* grad_out, int point_mean, int batch_mode, double div,
+                           double scale, int64_t B, int64_t P1, int64_t P2, int64_t D, float* grad_p1,
+                           float* grad_p2, int deterministic, mp_stream_t stream);
 
 /* ---- padded-length detection -------------------------------------------------------------------
  * replaces: pytorch3d_chamfer.py:138-149 (`padded=True`): lengths[b] = first column c with
@@ -226,6 +233,16 @@ int mp_bn_relu_rows_f32(const float* x, int64_t B, int64_t C, int training, doub
 int mp_bn_relu_rows_bwd_f32(const float* grad_y, const float* y, const float* x, int64_t B, int64_t C, int training,
                             const float* gamma, const float* save_mean, const float* save_rstd, float* grad_x,
                             float* grad_gamma, float* grad_beta, mp_stream_t stream);
+/* The same block with the nn.Dropout(p) behind it (models/pointnet2_cls_ssg.py:309-327: self.dropout(F.relu(self.bn1(.)))) in the same
+ * launch.  rng: device int64 [2] = (seed, step), advanced by the caller once per training step; the keep mask is a counter-based hash of
+ * (seed, step, layer, element) -- Bernoulli(1 - p) like torch's, not the same draws.  Backward: the mask is `y > 0`. */
+int mp_bn_relu_drop_rows_f32(const float* x, int64_t B, int64_t C, int training, double momentum, double eps,
+                             const float* gamma, const float* beta, float* running_mean, float* running_var, float* y,
+                             float* save_mean, float* save_rstd, double drop_p, const int64_t* rng, int layer, mp_stream_t stream);
+int mp_bn_relu_drop_rows_bwd_f32(const float* grad_y, const float* y, const float* x, int64_t B, int64_t C, int training,
+                                 const float* gamma, const float* save_mean, const float* save_rstd, float* grad_x,
+                                 float* grad_gamma, float* grad_beta, double drop_p, mp_stream_t stream);
+
 
 /* ---- set-abstraction shared MLP: (1x1 conv -> BatchNorm -> ReLU) x L -> max over the K group members ----------
  * replaces: models/pointnet2_utils.py:208-214 (PointNetSetAbstraction.forward tail; :264-269 for MSG) and the

@@ -324,13 +324,29 @@ int dispatch_d(const float* p1, const float* p2, const int64_t* len1, const int6
 }
 
 // grad_p1[b,i,t] = sum_k 2*g[i,k]*(p1[i,t]-p2[idx[i,k],t]); optional atomic scatter of the negative into grad_p2
+// Gradient of a REDUCED chamfer term w.r.t. the distance of row (b, i) -- what chamfer_reduce_bwd_kernel (chamfer_reduce.hip) would
+// write into grad_dists, evaluated in place (same operations in the same order): the loss terms of a training step then need no
+// [B, P1] gradient tensor and no launch of their own between the scalar loss gradient and the scatter below.
+struct RowGrad {
+    const float* grad_out;   // [1], or [B] when batch_mode == 0
+    int point_mean, batch_mode;
+    float div, scale;
+    __device__ __forceinline__ float at(int64_t b, int64_t len) const
+    {
+        float g = (batch_mode == 0 ? grad_out[b] : grad_out[0]) * scale;
+        if (batch_mode == 2) g = g / div;
+        if (point_mean) g = g / (float)len;
+        return g;
+    }
+};
+
 __global__ __launch_bounds__(256) void knn_bwd_kernel(const float* __restrict__ p1, const float* __restrict__ p2,
                                                       const int64_t* __restrict__ len1,
                                                       const int64_t* __restrict__ len2,
                                                       const int64_t* __restrict__ idx,
                                                       const float* __restrict__ grad_dists, int64_t P1, int64_t P2,
                                                       int64_t D, int64_t K, int64_t total,
-                                                      float* __restrict__ grad_p1, float* __restrict__ grad_p2_atomic)
+                                                      float* __restrict__ grad_p1, float* __restrict__ grad_p2_atomic, RowGrad rg)
 {
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
         const int64_t row = e / D;  // b*P1 + i
@@ -344,7 +360,7 @@ __global__ __launch_bounds__(256) void knn_bwd_kernel(const float* __restrict__ 
             const float a = p1[e];
             for (int64_t k = 0; k < K && k < l2; ++k) {
                 const int64_t j = idx[row * K + k];
-                const float g = grad_dists[row * K + k];
+                const float g = grad_dists ? grad_dists[row * K + k] : rg.at(b, l1);
                 const float v = 2.0f * g * (a - p2[(b * P2 + j) * D + t]);
                 acc += v;
                 if (grad_p2_atomic) atomicAdd(grad_p2_atomic + (b * P2 + j) * D + t, -v);
@@ -362,7 +378,7 @@ __global__ __launch_bounds__(256) void knn_bwd_p2_ordered_kernel(const float* __
                                                                  const int64_t* __restrict__ idx,
                                                                  const float* __restrict__ grad_dists, int64_t P1,
                                                                  int64_t P2, int64_t D, int64_t K, int64_t rows_total,
-                                                                 float* __restrict__ grad_p2)
+                                                                 float* __restrict__ grad_p2, RowGrad rg)
 {
     const int lane = threadIdx.x & 63;
     const int64_t dest = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -386,7 +402,7 @@ __global__ __launch_bounds__(256) void knn_bwd_p2_ordered_kernel(const float* __
                 const int s = __builtin_ctzll(hit);
                 hit &= hit - 1;
                 const int64_t mm = m0 + s;
-                if (t < D) acc -= 2.0f * bg[mm] * (p1[(b * P1 + mm / K) * D + t] - pj);
+                if (t < D) acc -= 2.0f * (grad_dists ? bg[mm] : rg.at(b, len1 ? len1[b] : P1)) * (p1[(b * P1 + mm / K) * D + t] - pj);
             }
         }
         if (t < D) grad_p2[dest * D + t] = acc;
@@ -446,14 +462,13 @@ extern "C" int mp_knn_f32(const float* p1, const float* p2, const int64_t* len1,
     return dispatch_d<8>(p1, p2, len1, len2, b, n1, n2, d, k, dists, idx, stream);
 }
 
-extern "C" int mp_knn_bwd_f32(const float* p1, const float* p2, const int64_t* len1, const int64_t* len2,
-                              const int64_t* idx, const float* grad_dists, int64_t B, int64_t P1, int64_t P2,
-                              int64_t D, int64_t K, float* grad_p1, float* grad_p2, int deterministic,
-                              mp_stream_t stream_)
+static int knn_bwd(const float* p1, const float* p2, const int64_t* len1, const int64_t* len2, const int64_t* idx,
+                   const float* grad_dists, const RowGrad& rg, int64_t B, int64_t P1, int64_t P2, int64_t D, int64_t K,
+                   float* grad_p1, float* grad_p2, int deterministic, mp_stream_t stream_)
 {
     if (B < 0 || P1 < 0 || P2 < 0 || D <= 0 || K <= 0) return MP_EINVAL;
     if (B == 0) return MP_OK;
-    if (P1 > 0 && P2 > 0 && (!p1 || !p2 || !idx || !grad_dists)) return MP_EINVAL;
+    if (P1 > 0 && P2 > 0 && (!p1 || !p2 || !idx || (!grad_dists && !rg.grad_out))) return MP_EINVAL;
     hipStream_t stream = mp_stream(stream_);
     if (grad_p2 && P2 > 0 && (P1 == 0 || !deterministic)) {
         if (!mp::zero_async(grad_p2, (size_t)(B * P2 * D), stream)) return MP_ELAUNCH;
@@ -467,16 +482,39 @@ extern "C" int mp_knn_bwd_f32(const float* p1, const float* p2, const int64_t* l
     float* atomic_dst = (grad_p2 && !deterministic) ? grad_p2 : nullptr;
     if (grad_p1 || atomic_dst) {
         hipLaunchKernelGGL(knn_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, stream, p1, p2, len1, len2, idx,
-                           grad_dists, P1, P2, D, K, total, grad_p1, atomic_dst);
+                           grad_dists, P1, P2, D, K, total, grad_p1, atomic_dst, rg);
         MP_CHECK_LAUNCH();
     }
     if (grad_p2 && deterministic) {
         const int64_t rows = B * P2;
         hipLaunchKernelGGL(knn_bwd_p2_ordered_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, p1, p2,
-                           len1, len2, idx, grad_dists, P1, P2, D, K, rows, grad_p2);
+                           len1, len2, idx, grad_dists, P1, P2, D, K, rows, grad_p2, rg);
         MP_CHECK_LAUNCH();
     }
     return MP_OK;
+}
+
+extern "C" int mp_knn_bwd_f32(const float* p1, const float* p2, const int64_t* len1, const int64_t* len2,
+                              const int64_t* idx, const float* grad_dists, int64_t B, int64_t P1, int64_t P2,
+                              int64_t D, int64_t K, float* grad_p1, float* grad_p2, int deterministic,
+                              mp_stream_t stream_)
+{
+    if (B > 0 && P1 > 0 && P2 > 0 && !grad_dists) return MP_EINVAL;
+    return knn_bwd(p1, p2, len1, len2, idx, grad_dists, RowGrad{}, B, P1, P2, D, K, grad_p1, grad_p2, deterministic, stream_);
+}
+
+// The same backward for distances that went straight into mp_chamfer_reduce_f32 (K = 1): `grad_out` is the gradient of the reduced
+// value ([1], or [B] when batch_mode == 0), and the per-row factor scale / div / len1[b] is applied here (point_mean, batch_mode,
+// div, scale as given to the reduction) -- mp_chamfer_reduce_bwd_f32 and its [B, P1] output are not needed.
+extern "C" int mp_knn_bwd_reduced_f32(const float* p1, const float* p2, const int64_t* len1, const int64_t* len2,
+                                      const int64_t* idx, const float* grad_out, int point_mean, int batch_mode, double div,
+                                      double scale, int64_t B, int64_t P1, int64_t P2, int64_t D, float* grad_p1,
+                                      float* grad_p2, int deterministic, mp_stream_t stream_)
+{
+    if (batch_mode < 0 || batch_mode > 2 || (point_mean && !len1)) return MP_EINVAL;
+    if (B > 0 && P1 > 0 && P2 > 0 && !grad_out) return MP_EINVAL;
+    RowGrad rg{grad_out, point_mean, batch_mode, (float)div, (float)scale};
+    return knn_bwd(p1, p2, len1, len2, idx, nullptr, rg, B, P1, P2, D, 1, grad_p1, grad_p2, deterministic, stream_);
 }
 
 extern "C" int mp_padded_lengths_f32(const float* y, int64_t B, int64_t P2, int64_t D, int64_t* lengths,

@@ -209,8 +209,11 @@ __global__ __launch_bounds__(256) void bn_relu_rows_kernel(const float* __restri
                                                            float momentum, float eps, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, float* __restrict__ running_mean,
                                                            float* __restrict__ running_var, float* __restrict__ y,
-                                                           float* __restrict__ save_mean, float* __restrict__ save_rstd)
-{
+                                                           float* __restrict__ save_mean, float* __restrict__ save_rstd,
+                                                           float drop_p, const long long* __restrict__ rng, int layer)
+{   // rng != NULL: nn.Dropout(p = drop_p) of the result in the same pass -- element (r, c) is kept when a counter-based hash of
+    // (rng[0] = seed, rng[1] = step, layer, r * C + c) maps to [drop_p, 1), and scaled by 1 / (1 - drop_p).  A dropped element is an
+    // exact 0, a kept one is positive iff the ReLU passed it: the backward kernel needs the scale only, not the mask.
     __shared__ float red[4][64];
     const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cl;
@@ -257,14 +260,31 @@ __global__ __launch_bounds__(256) void bn_relu_rows_kernel(const float* __restri
     if (!live) return;
     if (g == 0) { save_mean[c] = mean; save_rstd[c] = rstd; }
     const float ga = gamma ? gamma[c] : 1.0f, be = beta ? beta[c] : 0.0f;
+    const bool drop = rng != nullptr && drop_p > 0.0f;
+    const unsigned long long key = drop ? (unsigned long long)rng[0] + 0xD1B54A32D192ED03ull * (unsigned long long)rng[1] +
+                                          ((unsigned long long)(unsigned)layer << 48) : 0ull;
+    const float keep_scale = drop ? 1.0f / (1.0f - drop_p) : 1.0f;
+    auto finish_row = [&](int r, float xin) {
+        float v = (xin - mean) * rstd * ga + be;
+        v = v > 0.0f ? v : 0.0f;
+        if (drop) {
+            unsigned long long z = key + 0x9E3779B97F4A7C15ull * ((unsigned long long)r * (unsigned long long)C + (unsigned long long)c + 1ull);
+            z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;          // splitmix64 finaliser: 24 uniform bits per element
+            z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+            z ^= z >> 31;
+            const float u = (float)(z >> 40) * (1.0f / 16777216.0f);
+            v = u >= drop_p ? v * keep_scale : 0.0f;
+        }
+        y[(size_t)r * C + c] = v;
+    };
     if constexpr (RPT > 0) {
 #pragma unroll
         for (int k = 0; k < RPT; ++k) {
             const int r = g + 4 * k;
-            if (r < B) { const float v = (xv[k] - mean) * rstd * ga + be; y[(size_t)r * C + c] = v > 0.0f ? v : 0.0f; }
+            if (r < B) finish_row(r, xv[k]);
         }
     } else {
-        for (int r = g; r < B; r += 4) { const float v = (x[(size_t)r * C + c] - mean) * rstd * ga + be; y[(size_t)r * C + c] = v > 0.0f ? v : 0.0f; }
+        for (int r = g; r < B; r += 4) finish_row(r, x[(size_t)r * C + c]);
     }
 }
 
@@ -273,8 +293,8 @@ __global__ __launch_bounds__(256) void bn_relu_rows_bwd_kernel(const float* __re
                                                                const float* __restrict__ x, int B, int C, int training,
                                                                const float* __restrict__ gamma, const float* __restrict__ save_mean,
                                                                const float* __restrict__ save_rstd, float* __restrict__ grad_x,
-                                                               float* __restrict__ grad_gamma, float* __restrict__ grad_beta)
-{
+                                                               float* __restrict__ grad_gamma, float* __restrict__ grad_beta, float keep_scale)
+{   // keep_scale = 1 / (1 - p) of a dropout fused into the forward (1 without): y > 0 exactly where the element passed ReLU AND dropout
     __shared__ float red[2][4][64];
     const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cl;
@@ -291,7 +311,7 @@ __global__ __launch_bounds__(256) void bn_relu_rows_bwd_kernel(const float* __re
             const bool ok = live && r < B;
             const size_t o = ok ? (size_t)r * C + c : 0;
             const float yy = y[o], gy = grad_y[o], xx = x[o];
-            dyv[k] = (ok && yy > 0.0f) ? gy : 0.0f;
+            dyv[k] = (ok && yy > 0.0f) ? gy * keep_scale : 0.0f;
             xh[k] = ok ? (xx - mean) * rstd : 0.0f;
         }
 #pragma unroll
@@ -299,7 +319,7 @@ __global__ __launch_bounds__(256) void bn_relu_rows_bwd_kernel(const float* __re
     } else if (live) {
         for (int r = g; r < B; r += 4) {
             const size_t o = (size_t)r * C + c;
-            const float dy = y[o] > 0.0f ? grad_y[o] : 0.0f;
+            const float dy = y[o] > 0.0f ? grad_y[o] * keep_scale : 0.0f;
             db += dy;
             dg += dy * ((x[o] - mean) * rstd);
         }
@@ -325,7 +345,7 @@ __global__ __launch_bounds__(256) void bn_relu_rows_bwd_kernel(const float* __re
     } else {
         for (int r = g; r < B; r += 4) {
             const size_t o = (size_t)r * C + c;
-            const float dy = y[o] > 0.0f ? grad_y[o] : 0.0f;
+            const float dy = y[o] > 0.0f ? grad_y[o] * keep_scale : 0.0f;
             const float xhat = (x[o] - mean) * rstd;
             grad_x[o] = training ? ga * rstd * (dy - db * inv - xhat * dg * inv) : ga * rstd * dy;
         }
@@ -334,28 +354,29 @@ __global__ __launch_bounds__(256) void bn_relu_rows_bwd_kernel(const float* __re
 
 }  // namespace
 
-extern "C" int mp_bn_relu_rows_f32(const float* x, int64_t B, int64_t C, int training, double momentum, double eps,
-                                   const float* gamma, const float* beta, float* running_mean, float* running_var, float* y,
-                                   float* save_mean, float* save_rstd, mp_stream_t stream_)
+static int bn_relu_rows_fwd(const float* x, int64_t B, int64_t C, int training, double momentum, double eps,
+                            const float* gamma, const float* beta, float* running_mean, float* running_var, float* y,
+                            float* save_mean, float* save_rstd, double drop_p, const int64_t* rng, int layer, mp_stream_t stream_)
 {
-    if (B <= 0 || C < 0) return MP_EINVAL;
+    if (B <= 0 || C < 0 || drop_p < 0.0 || drop_p >= 1.0) return MP_EINVAL;
     if (C == 0) return MP_OK;
     if (!x || !y || !save_mean || !save_rstd || (!training && (!running_mean || !running_var))) return MP_EINVAL;
     if (B > 4096 || C > (1 << 24)) return MP_EUNSUPPORTED;   // a thread walks the rows: made for skinny batches
     const dim3 grid((unsigned)((C + 63) / 64));   // 64 channels per workgroup: 16 workgroups for the 1024-wide heads
+    const long long* r = reinterpret_cast<const long long*>(rng);
     if (B <= 32)
         hipLaunchKernelGGL(bn_relu_rows_kernel<8>, grid, dim3(256), 0, mp_stream(stream_), x, (int)B, (int)C, training, (float)momentum,
-                           (float)eps, gamma, beta, running_mean, running_var, y, save_mean, save_rstd);
+                           (float)eps, gamma, beta, running_mean, running_var, y, save_mean, save_rstd, (float)drop_p, r, layer);
     else
         hipLaunchKernelGGL(bn_relu_rows_kernel<0>, grid, dim3(256), 0, mp_stream(stream_), x, (int)B, (int)C, training, (float)momentum,
-                           (float)eps, gamma, beta, running_mean, running_var, y, save_mean, save_rstd);
+                           (float)eps, gamma, beta, running_mean, running_var, y, save_mean, save_rstd, (float)drop_p, r, layer);
     MP_CHECK_LAUNCH();
     return MP_OK;
 }
 
-extern "C" int mp_bn_relu_rows_bwd_f32(const float* grad_y, const float* y, const float* x, int64_t B, int64_t C, int training,
-                                       const float* gamma, const float* save_mean, const float* save_rstd, float* grad_x,
-                                       float* grad_gamma, float* grad_beta, mp_stream_t stream_)
+static int bn_relu_rows_bwd(const float* grad_y, const float* y, const float* x, int64_t B, int64_t C, int training,
+                            const float* gamma, const float* save_mean, const float* save_rstd, float* grad_x,
+                            float* grad_gamma, float* grad_beta, double keep_scale, mp_stream_t stream_)
 {
     if (B <= 0 || C < 0) return MP_EINVAL;
     if (C == 0) return MP_OK;
@@ -364,10 +385,46 @@ extern "C" int mp_bn_relu_rows_bwd_f32(const float* grad_y, const float* y, cons
     const dim3 grid((unsigned)((C + 63) / 64));
     if (B <= 32)
         hipLaunchKernelGGL(bn_relu_rows_bwd_kernel<8>, grid, dim3(256), 0, mp_stream(stream_), grad_y, y, x, (int)B, (int)C, training, gamma,
-                           save_mean, save_rstd, grad_x, grad_gamma, grad_beta);
+                           save_mean, save_rstd, grad_x, grad_gamma, grad_beta, (float)keep_scale);
     else
         hipLaunchKernelGGL(bn_relu_rows_bwd_kernel<0>, grid, dim3(256), 0, mp_stream(stream_), grad_y, y, x, (int)B, (int)C, training, gamma,
-                           save_mean, save_rstd, grad_x, grad_gamma, grad_beta);
+                           save_mean, save_rstd, grad_x, grad_gamma, grad_beta, (float)keep_scale);
     MP_CHECK_LAUNCH();
     return MP_OK;
+}
+
+extern "C" int mp_bn_relu_rows_f32(const float* x, int64_t B, int64_t C, int training, double momentum, double eps,
+                                   const float* gamma, const float* beta, float* running_mean, float* running_var, float* y,
+                                   float* save_mean, float* save_rstd, mp_stream_t stream_)
+{
+    return bn_relu_rows_fwd(x, B, C, training, momentum, eps, gamma, beta, running_mean, running_var, y, save_mean, save_rstd, 0.0, nullptr, 0,
+                            stream_);
+}
+
+extern "C" int mp_bn_relu_rows_bwd_f32(const float* grad_y, const float* y, const float* x, int64_t B, int64_t C, int training,
+                                       const float* gamma, const float* save_mean, const float* save_rstd, float* grad_x,
+                                       float* grad_gamma, float* grad_beta, mp_stream_t stream_)
+{
+    return bn_relu_rows_bwd(grad_y, y, x, B, C, training, gamma, save_mean, save_rstd, grad_x, grad_gamma, grad_beta, 1.0, stream_);
+}
+
+// BatchNorm1d + ReLU + Dropout(p) in one launch (models/pointnet2_cls_ssg.py:309-327: `self.dropout(F.relu(self.bn1(...)))`).  rng: device
+// int64 [2] = (seed, step); the caller advances the step once per training step.  The mask is a counter-based hash of (seed, step, layer,
+// element), not torch's Philox stream: same distribution, different draws for a given seed.
+extern "C" int mp_bn_relu_drop_rows_f32(const float* x, int64_t B, int64_t C, int training, double momentum, double eps,
+                                        const float* gamma, const float* beta, float* running_mean, float* running_var, float* y,
+                                        float* save_mean, float* save_rstd, double drop_p, const int64_t* rng, int layer,
+                                        mp_stream_t stream_)
+{
+    if (!rng) return MP_EINVAL;
+    return bn_relu_rows_fwd(x, B, C, training, momentum, eps, gamma, beta, running_mean, running_var, y, save_mean, save_rstd, drop_p, rng, layer,
+                            stream_);
+}
+
+extern "C" int mp_bn_relu_drop_rows_bwd_f32(const float* grad_y, const float* y, const float* x, int64_t B, int64_t C, int training,
+                                            const float* gamma, const float* save_mean, const float* save_rstd, float* grad_x,
+                                            float* grad_gamma, float* grad_beta, double drop_p, mp_stream_t stream_)
+{
+    if (drop_p < 0.0 || drop_p >= 1.0) return MP_EINVAL;
+    return bn_relu_rows_bwd(grad_y, y, x, B, C, training, gamma, save_mean, save_rstd, grad_x, grad_gamma, grad_beta, 1.0 / (1.0 - drop_p), stream_);
 }

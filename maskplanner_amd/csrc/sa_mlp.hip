@@ -34,11 +34,7 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 #ifndef MP_BK
 #define MP_BK 32
 #endif
-constexpr int BK = MP_BK;          // K chunk staged through LDS
-constexpr int TPR = BK / 4;        // threads per staged row (float4 each)
-constexpr int RPP = 256 / TPR;     // rows per staging pass
 constexpr int THREADS = 256;
-constexpr int LDK = BK + 1;  // [row][k] tiles: odd stride
 
 enum SrcMode { SRC_ID = 0, SRC_ACT = 1, SRC_DZ = 2, SRC_DZ_POOLED = 3, SRC_ACT_RC = 4, SRC_DZ_RC = 5 };
 // *_RC ("recompute"): the raw Z of this operand is not in memory -- it is the first layer of a level with a 4-channel input

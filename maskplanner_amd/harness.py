@@ -60,6 +60,14 @@ class TrainStep:
         self._graph_b, self._graph_b2, self._factor_args, self._adam_stream, self._adam_ev = None, None, None, None, None
         self._split_adam_wanted = os.environ.get("MASKPLANNER_SPLIT_ADAM", "1") != "0"
         self._plan_late = os.environ.get("MASKPLANNER_PLAN_AFTER_FORWARD", "0") != "0"
+        self._unit = torch.ones((), dtype=torch.float32, device=self.device)
+        # train-mode dropout of the head blocks inside their BatchNorm + ReLU launches (pointnet2_cls_ssg._block): a device (seed, step)
+        # pair, the step advanced once per training step.  MASKPLANNER_FUSED_DROPOUT=0 keeps nn.Dropout (torch's Philox stream).
+        self._drop_rng = None
+        if fused and os.environ.get("MASKPLANNER_FUSED_DROPOUT", "1") != "0" and hasattr(self.model, "heads"):
+            self._drop_rng = torch.tensor([int(seed) * 0x9E3779B1 + 12345, 0], dtype=torch.int64, device=self.device)
+            self._drop_step = self._drop_rng[1:2]
+            self.model.fused_dropout = self._drop_rng
         self.factor_opt = None
         dense = list(self.model.parameters())
         if factor_heads and fused:
@@ -127,6 +135,12 @@ class TrainStep:
 
     def _heads_loss(self, feat):
         out, sm_out, mask_conf, seg_conf = self.model.heads(feat)
+        if self._drop_rng is not None:      # next step, next dropout masks: the step counter rides in the BatchNorm counters' launch
+            from . import sa_mlp
+            if sa_mlp.DEFERRED_TICKS is not None:
+                sa_mlp.DEFERRED_TICKS.append(self._drop_step)
+            else:
+                self._drop_step.add_(1)
         return self.loss_handler.compute(return_list=False, y_pred=out, y=self.batch["traj"], pred_stroke_masks=sm_out,
                                          mask_scores=mask_conf, seg_logits=seg_conf, stroke_ids=self.batch["stroke_ids"],
                                          traj_as_pc=self.batch["traj_as_pc"])
@@ -196,6 +210,8 @@ class TrainStep:
             ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
             if self.factor_opt is not None:
                 self._reset_factor_store()
+            from . import sa_mlp
+            ticks_prev, sa_mlp.DEFERRED_TICKS = sa_mlp.DEFERRED_TICKS, []      # every BatchNorm counter of the step: one launch, in B
             with torch.cuda.graph(ga, stream=cap):
                 self._supply_plan()
                 self.reducer.zero_grad()
@@ -216,10 +232,13 @@ class TrainStep:
                 if split_bwd:
                     leaf = feat.detach().requires_grad_(True)
                     loss = self._heads_loss(leaf)
-                    loss.backward()
+                    sa_mlp.flush_ticks()
+                    loss.backward(self._unit)     # (a cached 1: no fill launch for the seed gradient)
                 else:
                     loss = self._heads_loss(feat)
-                    loss.backward()
+                    sa_mlp.flush_ticks()
+                    loss.backward(self._unit)     # (a cached 1: no fill launch for the seed gradient)
+                sa_mlp.DEFERRED_TICKS = ticks_prev
                 if self.factor_opt is not None:
                     flush_bias_grads(self.model.factor_store)
                 if not self.dp_graph and not split_bwd:
@@ -255,6 +274,8 @@ class TrainStep:
             self._replay_b()
         except Exception as exc:   # stay correct: eager from here on
             import warnings
+            from . import sa_mlp
+            sa_mlp.DEFERRED_TICKS = None
             warnings.warn(f"hipGraph capture of the training step failed ({type(exc).__name__}: {exc}); running eagerly")
             self._graph, self._graph_b, self._graph_b2, self.use_graph = None, None, None, False
             torch.cuda.synchronize()
@@ -406,7 +427,7 @@ class TrainStep:
         self.reducer.zero_grad()
         with self._Ticks():
             loss = self.forward_loss()
-        loss.backward()
+        loss.backward(self._unit)     # (a cached 1: no fill launch for the seed gradient)
         if self.factor_opt is not None:
             flush_bias_grads(self.model.factor_store)
         self.reducer.finish()

@@ -263,8 +263,8 @@ class LossHandler:
         return chamfer_distance(self._pose_cloud(y_pred), self._on_device(traj_as_pc, y_pred), padded=True,
                                 reverse_asymmetric=True, _scale=100.0 * float(_w), _add=_add)[0]
 
-    def get_reverse_asymm_segment_chamfer(self, y_pred, y, _w=1.0, _add=None, **args):
-        return chamfer_distance(y_pred, y, padded=True, reverse_asymmetric=True, _scale=100.0 * float(_w), _add=_add)[0]
+    def get_reverse_asymm_segment_chamfer(self, y_pred, y, _w=1.0, _add=None, _y_found=None, **args):
+        return chamfer_distance(y_pred, y, padded=True, reverse_asymmetric=True, _scale=100.0 * float(_w), _add=_add, _y_found=_y_found)[0]
 
     def get_attraction_chamfer(self, y_pred, **args):
         return 100 * chamfer_distance(y_pred[:, :, :3], y_pred[:, :, -3:], padded=False)[0]
@@ -308,10 +308,21 @@ class LossHandler:
     def _segment_term(self, y_pred, y, seg_logits, _w=1.0):
         """Term 1 of the asymmetric losses: pred->GT segment chamfer, unreduced, with the matching (:604-621);
         returns _w * 100 * d.mean() (one reduction launch: every predicted cloud has the same length)."""
+        cfg = self._cfg()
+        self._y_found = None
+        if y_pred.is_cuda and not cfg.get("per_segment_confidence", False) and not cfg.get("smooth_target_stroke_masks", False):
+            # nothing differentiates through the unreduced distances: nearest neighbours + reduction as one term (ops.chamfer_term:
+            # a single launch in backward); the padded lengths of `y` are kept for the reverse segment term
+            from .pytorch3d_chamfer import _full_lengths
+            y_dev = self._on_device(y, y_pred)
+            self._y_found = ops.padded_lengths(y_dev)
+            seg, d, match = ops.chamfer_term(y_pred, y_dev, _full_lengths(y_pred.shape[0], y_pred.shape[1], y_pred.device),
+                                             self._y_found, "mean", "mean", 100.0 * float(_w))
+            return seg, 0, match, d
         d, _, match, _ = chamfer_distance(y_pred, y, padded=True, asymmetric=True, return_matching=True,
                                           point_reduction=None, batch_reduction=None, _matching_y=False)
         conf = 0
-        if self._cfg().get("per_segment_confidence", False):
+        if cfg.get("per_segment_confidence", False):
             conf = self._get_per_segment_confidence_loss(nn_distance=d, logits=seg_logits)
         if d.is_cuda:
             from .pytorch3d_chamfer import _full_lengths
@@ -331,7 +342,7 @@ class LossHandler:
         pts = self.get_reverse_asymm_point_chamfer(y_pred, y, traj_as_pc, _w=cfg["weight_reverse_asymm_point_chamfer"],
                                                    _add=run if chain else None)                                            # :623-637
         rev = self.get_reverse_asymm_segment_chamfer(y_pred, y, _w=cfg["weight_reverse_asymm_segment_chamfer"],
-                                                     _add=pts if chain else None)                                           # :641-645
+                                                     _add=pts if chain else None, _y_found=getattr(self, "_y_found", None))  # :641-645
         masks = self.get_stroke_masks_loss(match, pred_stroke_masks, mask_scores, stroke_ids, nn_distance=d,
                                            smooth_targets=cfg.get("smooth_target_stroke_masks", False),
                                            _add=rev if chain else None, **kwargs)

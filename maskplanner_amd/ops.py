@@ -391,11 +391,14 @@ class _Knn(torch.autograd.Function):
         _run("knn", p1, _lib.load().mp_knn_f32, _p(p1), _p(p2), _p(len1), _p(len2), B, P1, P2, D, K, _p(dists), _p(idx), None, 0)
         ctx.save_for_backward(p1, p2, len1, len2, idx)
         ctx.mark_non_differentiable(idx)
+        ctx.set_materialize_grads(False)      # (a zero gradient for the int64 index output would be a fill launch per call)
         ctx.K = K
         return dists, idx
 
     @staticmethod
     def backward(ctx, grad_dists, _grad_idx):
+        if grad_dists is None:
+            return None, None, None, None, None
         p1, p2, len1, len2, idx = ctx.saved_tensors
         B, P1, D = p1.shape
         P2 = p2.shape[1]
@@ -416,6 +419,64 @@ def knn(p1, p2, lengths1=None, lengths2=None, K=1):
     l1 = None if lengths1 is None else _i64(lengths1)
     l2 = None if lengths2 is None else _i64(lengths2)
     return _Knn.apply(_f32(p1), _f32(p2), l1, l2, int(K))
+
+
+class _ChamferTerm(torch.autograd.Function):
+    """One reduced, one-directional chamfer term (pytorch3d_chamfer.py:257-334 with asymmetric / reverse_asymmetric): nearest
+    neighbour of every row of p1 in p2 (K = 1), sum or mean over the rows, sum or mean over the batch, times `scale`, plus the
+    running total `add`.  Forward = the knn launch + the reduction; backward = ONE launch (mp_knn_bwd_reduced_f32: the per-row
+    gradient scale / div / len is formed inside the scatter).  Returns (value, dists [B,P1], idx [B,P1]); the last two carry no
+    gradient."""
+
+    @staticmethod
+    def forward(ctx, p1, p2, len1, len2, point_mean, batch_mode, div, scale, add):
+        B, P1, D = p1.shape
+        P2 = p2.shape[1]
+        lib = _lib.load()
+        dists = torch.empty((B, P1), dtype=torch.float32, device=p1.device)
+        idx = torch.empty((B, P1), dtype=torch.int64, device=p1.device)
+        _run("knn", p1, lib.mp_knn_f32, _p(p1), _p(p2), _p(len1), _p(len2), B, P1, P2, D, 1, _p(dists), _p(idx), None, 0)
+        out = torch.empty((B,) if batch_mode == 0 else (), dtype=torch.float32, device=p1.device)
+        scratch = torch.empty((B,), dtype=torch.float32, device=p1.device) if batch_mode != 0 else None
+        _run("chamfer_reduce", dists, lib.mp_chamfer_reduce_f32, _p(dists), _p(len1), B, P1, int(point_mean), int(batch_mode),
+             float(div), float(scale), _p(scratch), _p(out), _p(add))
+        ctx.save_for_backward(p1, p2, len1, len2, idx)
+        ctx.meta = (int(point_mean), int(batch_mode), float(div), float(scale))
+        ctx.mark_non_differentiable(dists, idx)
+        ctx.set_materialize_grads(False)
+        return out, dists, idx
+
+    @staticmethod
+    def backward(ctx, grad_out, _gd, _gi):
+        if grad_out is None:
+            return (None,) * 9
+        p1, p2, len1, len2, idx = ctx.saved_tensors
+        point_mean, batch_mode, div, scale = ctx.meta
+        B, P1, D = p1.shape
+        P2 = p2.shape[1]
+        need1, need2 = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        g1 = torch.empty_like(p1) if need1 else None
+        g2 = torch.empty_like(p2) if need2 else None
+        if need1 or need2:
+            grad_out = _f32(grad_out)
+            _run("knn_bwd", p1, _lib.load().mp_knn_bwd_reduced_f32, _p(p1), _p(p2), _p(len1), _p(len2), _p(idx), _p(grad_out), point_mean,
+                 batch_mode, div, scale, B, P1, P2, D, _p(g1), _p(g2), int(DETERMINISTIC))
+        return g1, g2, None, None, None, None, None, None, (grad_out if ctx.needs_input_grad[8] else None)
+
+
+def chamfer_term(p1, p2, lengths1, lengths2, point_reduction="mean", batch_reduction="mean", scale=1.0, add=None):
+    """(value, dists [B,P1], idx [B,P1]) of one reduced one-directional chamfer term, see _ChamferTerm; lengths1 is required
+    (the point mean divides by it).  Same numbers as knn(K=1) followed by chamfer_reduce."""
+    _need_hip(p1, p2, lengths1, lengths2, add)
+    if p1.ndim != 3 or p2.ndim != 3 or p1.shape[0] != p2.shape[0] or p1.shape[2] != p2.shape[2]:
+        raise ValueError("pts1 and pts2 must be [B,P,D] with equal batch and feature dimensions")
+    batch_mode = {None: 0, "sum": 1, "mean": 2}[batch_reduction]
+    if add is not None and (batch_mode == 0 or add.numel() != 1 or add.dtype != torch.float32):
+        raise ValueError("add must be a float32 scalar and needs a batch reduction")
+    if point_reduction not in ("mean", "sum"):
+        raise ValueError("point_reduction must be 'mean' or 'sum'")
+    return _ChamferTerm.apply(_f32(p1), _f32(p2), _i64(lengths1), None if lengths2 is None else _i64(lengths2),
+                              point_reduction == "mean", batch_mode, float(p1.shape[0]), float(scale), add)
 
 
 class _ChamferReduce(torch.autograd.Function):
@@ -524,14 +585,19 @@ def mask_loss(pred_masks, scores, target_ids, match, uniq, w_masks, w_conf, no_s
 
 class _BnReluRows(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, drop_p, rng, layer):
         B, C = x.shape
         y = torch.empty_like(x)
         stats = torch.empty((2, C), dtype=torch.float32, device=x.device)
-        _run("bn_relu_rows", x, _lib.load().mp_bn_relu_rows_f32, _p(x), B, C, int(training), float(momentum), float(eps), _p(gamma),
-             _p(beta), _p(running_mean), _p(running_var), _p(y), stats[0].data_ptr(), stats[1].data_ptr())
+        if rng is not None:    # the nn.Dropout behind the block in the same launch
+            _run("bn_relu_rows", x, _lib.load().mp_bn_relu_drop_rows_f32, _p(x), B, C, int(training), float(momentum), float(eps), _p(gamma),
+                 _p(beta), _p(running_mean), _p(running_var), _p(y), stats[0].data_ptr(), stats[1].data_ptr(), float(drop_p), _p(rng), int(layer))
+        else:
+            _run("bn_relu_rows", x, _lib.load().mp_bn_relu_rows_f32, _p(x), B, C, int(training), float(momentum), float(eps), _p(gamma),
+                 _p(beta), _p(running_mean), _p(running_var), _p(y), stats[0].data_ptr(), stats[1].data_ptr())
         ctx.save_for_backward(x, y, gamma, stats)
         ctx.training = bool(training)
+        ctx.drop_p = float(drop_p) if rng is not None else None
         return y
 
     @staticmethod
@@ -542,21 +608,32 @@ class _BnReluRows(torch.autograd.Function):
         gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         gg = torch.empty((C,), dtype=torch.float32, device=x.device) if (gamma is not None and ctx.needs_input_grad[1]) else None
         gb = torch.empty((C,), dtype=torch.float32, device=x.device) if ctx.needs_input_grad[2] else None
-        _run("bn_relu_rows_bwd", x, _lib.load().mp_bn_relu_rows_bwd_f32, _p(grad_y), _p(y), _p(x), B, C, int(ctx.training), _p(gamma),
-             stats[0].data_ptr(), stats[1].data_ptr(), _p(gx), _p(gg), _p(gb))
-        return gx, gg, gb, None, None, None, None, None
+        if ctx.drop_p is not None:
+            _run("bn_relu_rows_bwd", x, _lib.load().mp_bn_relu_drop_rows_bwd_f32, _p(grad_y), _p(y), _p(x), B, C, int(ctx.training), _p(gamma),
+                 stats[0].data_ptr(), stats[1].data_ptr(), _p(gx), _p(gg), _p(gb), ctx.drop_p)
+        else:
+            _run("bn_relu_rows_bwd", x, _lib.load().mp_bn_relu_rows_bwd_f32, _p(grad_y), _p(y), _p(x), B, C, int(ctx.training), _p(gamma),
+                 stats[0].data_ptr(), stats[1].data_ptr(), _p(gx), _p(gg), _p(gb))
+        return gx, gg, gb, None, None, None, None, None, None, None, None
 
 
-def bn_relu_rows(x, bn):
+def bn_relu_rows(x, bn, dropout=None):
     """F.relu(bn(x)) for an nn.BatchNorm1d `bn` and x [B, C] with a small batch (models/pointnet2_cls_ssg.py:309-327): one
     launch forward, one backward.  Updates running statistics like the module does; the caller advances
-    `num_batches_tracked` (heads batch that into one launch)."""
+    `num_batches_tracked` (heads batch that into one launch).
+    dropout = (p, rng, layer): the nn.Dropout(p) that follows the block, in the same launch -- rng is a device int64 [2] tensor
+    (seed, step) whose step the caller advances once per training step; `layer` separates the blocks of one step."""
     _need_hip(x)
     if x.ndim != 2 or x.shape[1] != bn.num_features:
         raise ValueError("bn_relu_rows expects [B, C] input matching the BatchNorm width")
     training = bn.training or bn.running_mean is None
     track = bn.track_running_stats and bn.running_mean is not None
     momentum = bn.momentum if bn.momentum is not None else 1.0 / max(float(bn.num_batches_tracked), 1.0)
+    p, rng, layer = dropout if dropout is not None else (0.0, None, 0)
+    if rng is not None:
+        _need_hip(rng)
+        if rng.dtype != torch.int64 or rng.numel() != 2:
+            raise ValueError("dropout rng must be an int64 tensor (seed, step)")
     return _BnReluRows.apply(_f32(x), bn.weight, bn.bias, bn.running_mean if track else None, bn.running_var if track else None,
-                             training, momentum, bn.eps)
+                             training, momentum, bn.eps, p, rng, layer)
 

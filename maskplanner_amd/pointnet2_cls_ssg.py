@@ -46,6 +46,18 @@ class _SSGEncoder(nn.Module):
         return l3_points.reshape(B, 1024)
 
 
+def _block(model, lin_out, bn, layer):
+    """self.dropout(F.relu(bn(.))) of one head block (:309-327).  With `model.fused_dropout` set (a device int64 (seed, step) tensor, see
+    harness.TrainStep) the train-mode dropout rides in the BatchNorm + ReLU launch (ops.bn_relu_rows(dropout=...)): its own
+    counter-based mask instead of torch's Philox stream, no kernel and no saved mask of its own."""
+    rng = getattr(model, "fused_dropout", None)
+    sync = getattr(bn, "sync_bn", None)
+    if (rng is not None and model.training and bn.training and lin_out.is_cuda and lin_out.dtype == torch.float32 and lin_out.ndim == 2
+            and (sync is None or sync is False)):
+        return ops.bn_relu_rows(lin_out, bn, dropout=(model.dropout.p, rng, layer))
+    return model.dropout(_bn_relu(lin_out, bn))
+
+
 def _bn_relu(x, bn):
     """F.relu(bn(x)) of the head blocks (:309-327); on the GPU one fused launch (ops.bn_relu_rows) instead of BatchNorm's
     statistics / transform / running-stat kernels + clamp.  The caller has advanced num_batches_tracked (_tick)."""
@@ -158,6 +170,9 @@ class PointNet2Regressor_StrokeMasks(_SSGEncoder):
     # (fc1/fc2/fc3/fc_normals and the sm_ twins) then keep their gradient as rank-B factors instead of materialising dW
     # (default None: plain nn.Linear behaviour)
     factor_store = None
+    # set to a device int64 tensor (seed, step) by a training harness: the four train-mode dropouts of the heads are then applied inside
+    # the BatchNorm + ReLU launches (_block); the harness advances the step counter once per step (default None: nn.Dropout)
+    fused_dropout = None
 
     def forward(self, xyz):
         return self.heads(self.encode(xyz))
@@ -170,9 +185,8 @@ class PointNet2Regressor_StrokeMasks(_SSGEncoder):
         fused = feat.is_cuda
         if fused:
             _tick(*([self.bn1, self.bn2] + ([self.sm_bn1, self.sm_bn2] if self.pred_stroke_masks else [])))
-        act = _bn_relu
-        x = self.dropout(act(factor_linear(feat, self.fc1, fs, "fc1.weight"), self.bn1))
-        final = self.dropout(act(factor_linear(x, self.fc2, fs, "fc2.weight"), self.bn2))
+        x = _block(self, factor_linear(feat, self.fc1, fs, "fc1.weight"), self.bn1, 0)
+        final = _block(self, factor_linear(x, self.fc2, fs, "fc2.weight"), self.bn2, 1)
         x = factor_linear(final, self.fc3, fs, "fc3.weight")
 
         seg_conf = None
@@ -183,8 +197,8 @@ class PointNet2Regressor_StrokeMasks(_SSGEncoder):
 
         sm_out, mask_conf = None, None
         if self.pred_stroke_masks:
-            s1 = self.dropout(act(factor_linear(feat, self.sm_fc1, fs, "sm_fc1.weight"), self.sm_bn1))
-            s2 = self.dropout(act(factor_linear(s1, self.sm_fc2, fs, "sm_fc2.weight"), self.sm_bn2))
+            s1 = _block(self, factor_linear(feat, self.sm_fc1, fs, "sm_fc1.weight"), self.sm_bn1, 2)
+            s2 = _block(self, factor_linear(s1, self.sm_fc2, fs, "sm_fc2.weight"), self.sm_bn2, 3)
             sm_out = factor_linear(s2, self.sm_fc3, fs, "sm_fc3.weight").view(B, self.n_stroke_masks, -1)
             if self.mask_confidence_scores:
                 mask_conf = getattr(self, self._CONF_LAYER)(s2)

@@ -65,14 +65,15 @@ def chamfer_distance(x, y, x_lengths=None, y_lengths=None, x_normals=None, y_nor
                      batch_reduction: Union[str, None] = "mean", point_reduction: Union[str, None] = "mean",
                      velocities=False, min_centroids=False, padded=False, avoid_in_sequence_collapsing=False,
                      soft_attraction=False, asymmetric=False, reverse_asymmetric=False, return_matching=False,
-                     _matching_y=True, _scale=None, _add=None):
+                     _matching_y=True, _scale=None, _add=None, _y_found=None):
     """Chamfer distance between point sets x [N,P1,D] and y [N,P2,D]; see the reference docstring (:95-129) and the
     custom flags (:84-93).  Returns (dist, normals_dist_or_None) and, with return_matching, also the nearest
     neighbour indices (idx_x [N,P1], idx_y [N,P2]).  `_matching_y=False` (not a reference argument; used by this
     package's LossHandler, which only consumes idx_x) returns None for idx_y and skips the y->x search when the distance
     does not need it; `_scale` (likewise internal) multiplies a REDUCED distance by a constant inside the reduction
     kernel (the loss folds its `100 * weight` factors in there instead of launching scalar multiplies); `_add` (internal, one
-    direction + batch reduction only) is a device scalar -- the running total of a composite loss -- added in the same launch."""
+    direction + batch reduction only) is a device scalar -- the running total of a composite loss -- added in the same launch;
+    `_y_found` (internal) is ops.padded_lengths(y) when the caller already has it (one GT tensor feeds several terms)."""
     if not soft_attraction:
         _validate_chamfer_reduction_inputs(batch_reduction, point_reduction)
     if _scale is not None and (point_reduction is None or weights is not None or x_normals is not None or avoid_in_sequence_collapsing
@@ -88,7 +89,7 @@ def chamfer_distance(x, y, x_lengths=None, y_lengths=None, x_normals=None, y_nor
         raise ValueError("y does not have the correct shape.")
 
     if padded:  # -100 sentinel in the leading coordinate marks fake GT rows (:138-149)
-        found = ops.padded_lengths(y)
+        found = ops.padded_lengths(y) if _y_found is None else _y_found
         if y_lengths_given:
             # the reference overwrites y_lengths only if at least one sample is padded (:140); decided on device
             torch.where((found != P2).any(), found, y_lengths, out=y_lengths)   # (copy_ would be a memcpy node in a recorded step)
@@ -145,6 +146,16 @@ def chamfer_distance(x, y, x_lengths=None, y_lengths=None, x_normals=None, y_nor
             x = x.reshape(N, P1, lmbda, 3).mean(dim=-2)
             y = y.reshape(N, P1, lmbda, 3).mean(dim=-2)
         cham_x = cham_y = None
+        one_way = (asymmetric or reverse_asymmetric) and not (asymmetric and reverse_asymmetric)
+        if (one_way and x.is_cuda and weights is None and not return_normals and point_reduction is not None
+                and not (return_matching and (reverse_asymmetric or _matching_y))):
+            # the training-step case: one direction, reduced -- knn + reduction forward, ONE launch backward (ops.chamfer_term)
+            sc = 1.0 if _scale is None else float(_scale)
+            if asymmetric:
+                val, _, ix = ops.chamfer_term(x, y, x_lengths, y_lengths, point_reduction, batch_reduction, sc, add=_add)
+                return (val, None, ix, None) if return_matching else (val, None)
+            val, _, _ = ops.chamfer_term(y, x, y_lengths, x_lengths, point_reduction, batch_reduction, sc, add=_add)
+            return val, None
         if need_x:
             dx, idx_x = ops.knn(x, y, x_lengths, y_lengths, 1)
             cham_x = dx.view(N, P1)      # K = 1: a view both ways (dx[..., 0] costs a fill + a memcpy in backward)

@@ -593,3 +593,80 @@ def test_match_segments_cost_layout_and_assignment(oracle):
         c = oracle.cdist(x[b], ys[b])
         ri, cj = linear_sum_assignment(c.astype(np.float64))
         assert np.array_equal(i.cpu().numpy(), ri) and np.array_equal(j.cpu().numpy(), cj), b
+
+
+@pytest.mark.gpu
+def test_chamfer_term_equals_knn_plus_reduction():
+    """ops.chamfer_term = one reduced one-directional chamfer term (knn K=1 + reduction forward, a single knn_bwd launch with the
+    row gradient formed in the kernel).  Same value, distances, indices and -- bit for bit with the fixed-order scatter -- the same
+    gradients as ops.knn followed by ops.chamfer_reduce, for ragged lengths on both sides, every reduction mode and a chained `add`."""
+    from maskplanner_amd import ops
+    torch.manual_seed(3)
+    B, P1, P2, D = 5, 257, 190, 6
+    l1 = torch.tensor([257, 100, 1, 200, 64], device="cuda")
+    l2 = torch.tensor([190, 3, 190, 77, 128], device="cuda")
+    det, ops.DETERMINISTIC = ops.DETERMINISTIC, True
+    try:
+        for pr, br in (("mean", "mean"), ("sum", "mean"), ("mean", "sum"), ("mean", None)):
+            x = torch.randn(B, P1, D, device="cuda", requires_grad=True)
+            y = torch.randn(B, P2, D, device="cuda", requires_grad=True)
+            add = torch.tensor(0.37, device="cuda", requires_grad=True) if br is not None else None
+            d, i = ops.knn(x, y, l1, l2, 1)
+            want = ops.chamfer_reduce(d.view(B, P1), l1, pr, br, 2.5, add=add)
+            w = torch.randn_like(want)
+            (want * w).sum().backward()
+            gx, gy, ga = x.grad.clone(), y.grad.clone(), (None if add is None else add.grad.clone())
+            x.grad = y.grad = None
+            if add is not None:
+                add.grad = None
+            got, dd, ii = ops.chamfer_term(x, y, l1, l2, pr, br, 2.5, add=add)
+            (got * w).sum().backward()
+            assert torch.equal(got, want) and torch.equal(dd, d.view(B, P1)) and torch.equal(ii, i.view(B, P1)), (pr, br)
+            assert torch.equal(x.grad, gx) and torch.equal(y.grad, gy), (pr, br, float((x.grad - gx).abs().max()), float((y.grad - gy).abs().max()))
+            assert add is None or torch.equal(add.grad, ga)
+    finally:
+        ops.DETERMINISTIC = det
+
+
+@pytest.mark.gpu
+def test_fused_dropout_of_the_head_blocks():
+    """ops.bn_relu_rows(dropout=(p, rng, layer)): nn.Dropout(p) inside the BatchNorm + ReLU launch.  Kept elements equal the
+    undropped output / (1 - p), dropped ones are exact zeros, the keep rate is 1 - p, masks differ between steps and layers and
+    repeat for the same (seed, step, layer); the backward is the undropped backward of the masked, rescaled gradient."""
+    from maskplanner_amd import ops
+    torch.manual_seed(0)
+    B, C, p = 32, 1024, 0.3
+    bn = torch.nn.BatchNorm1d(C).cuda().train()
+    x = torch.randn(B, C, device="cuda", requires_grad=True)
+    rng = torch.tensor([1234567, 0], dtype=torch.int64, device="cuda")
+    rm, rv = bn.running_mean.clone(), bn.running_var.clone()
+    base = ops.bn_relu_rows(x, bn)
+    bn.running_mean.copy_(rm); bn.running_var.copy_(rv)
+    y0 = ops.bn_relu_rows(x, bn, dropout=(p, rng, 0))
+    kept = y0 != 0
+    pos = base > 0
+    assert not bool((kept & ~pos).any())
+    rate = float((kept & pos).sum()) / float(pos.sum())
+    assert abs(rate - (1 - p)) < 0.01, rate
+    assert torch.allclose(y0[kept], base[kept] / (1 - p), rtol=1e-6, atol=0)
+    # same (seed, step, layer): the same mask; another layer, another step: other masks
+    assert torch.equal(ops.bn_relu_rows(x, bn, dropout=(p, rng, 0)) != 0, kept)
+    other_layer = ops.bn_relu_rows(x, bn, dropout=(p, rng, 1)) != 0
+    rng[1] += 1
+    other_step = ops.bn_relu_rows(x, bn, dropout=(p, rng, 0)) != 0
+    for m in (other_layer, other_step):
+        agree = float(((m == kept) & pos).sum()) / float(pos.sum())
+        assert abs(agree - ((1 - p) ** 2 + p ** 2)) < 0.02, agree     # independent Bernoulli masks
+    rng[1] -= 1
+    # backward: d/dx of sum(w * dropout(relu(bn(x)))) == the undropped block's backward fed with w * mask / (1 - p)
+    w = torch.randn(B, C, device="cuda")
+    y0 = ops.bn_relu_rows(x, bn, dropout=(p, rng, 0))
+    (y0 * w).sum().backward()
+    gx, gg, gb = x.grad.clone(), bn.weight.grad.clone(), bn.bias.grad.clone()
+    x.grad = None; bn.weight.grad = None; bn.bias.grad = None
+    base = ops.bn_relu_rows(x, bn)
+    (base * (w * kept / (1 - p))).sum().backward()
+    assert torch.allclose(x.grad, gx, rtol=1e-5, atol=1e-6) and torch.allclose(bn.weight.grad, gg, rtol=1e-5, atol=1e-5)
+    assert torch.allclose(bn.bias.grad, gb, rtol=1e-5, atol=1e-5)
+    # p = 0 keeps everything; eval mode is untouched by the harness (the model only takes this path in train mode)
+    assert torch.equal(ops.bn_relu_rows(x, bn, dropout=(0.0, rng, 0)), ops.bn_relu_rows(x, bn))
