@@ -133,6 +133,12 @@ int mp_knn_bwd_f32(const float* p1, const float* p2, const int64_t* len1, const 
                    const int64_t* idx, const float* grad_dists, int64_t B, int64_t P1, int64_t P2,
                    int64_t D, int64_t K, float* grad_p1, float* grad_p2, int deterministic,
                    mp_stream_t stream);
+/* The two K = 1 searches behind mp_knn_f32, by name: screened != 0 -- bf16 matrix cores screen the pairs (three-plane split dot products,
+ * |y|^2 - 2 x.y), the reference's arithmetic is evaluated only on the blocks inside the error window of the minimum; 0 -- the direct scan.
+ * D in {3, 6, 12, 24}.  Identical outputs (distance bits and indices, first index on ties). */
+size_t mp_knn1_workspace_bytes(int64_t B, int64_t P2, int64_t D);   /* 16-byte aligned device bytes for the screened search; 0 = not available */
+int mp_knn1_f32(const float* p1, const float* p2, const int64_t* len1, const int64_t* len2, int64_t B, int64_t P1, int64_t P2,
+                int64_t D, float* dists, int64_t* idx, int screened, void* workspace, size_t workspace_bytes, mp_stream_t stream);
 /* The backward of K = 1 distances that went straight into mp_chamfer_reduce_f32 (one loss term = nearest neighbours + reduction,
  * pytorch3d_chamfer.py:257-334): grad_out is the gradient of the REDUCED value ([1], or [B] when batch_mode == 0) and the per-row
  * factor scale / div / len1[b] is applied inside the scatter -- no [B,P1] gradient tensor, no mp_chamfer_reduce_bwd_f32 launch. */

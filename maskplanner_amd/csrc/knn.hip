@@ -15,6 +15,7 @@
 // Arithmetic: dist = fma chain over d of (p1[d]-p2[d])^2, as pytorch3d's kernel (`dist += diff*diff`
 // contracted); strict < keeps the first index on ties.
 #include <cstdio>
+#include <cstdlib>
 
 #include "common.h"
 
@@ -294,6 +295,397 @@ int launch_knn1(const float* p1, const float* p2, const int64_t* len1, const int
     return MP_OK;
 }
 
+// ---- K = 1, screened on the matrix cores ----------------------------------------------------------------------------
+// The direct kernel above spends 2 VALU instructions per (pair, dimension).  Here the bf16 matrix cores SCREEN the pairs and the
+// direct arithmetic runs only where it can matter:
+//   * every operand is three bf16 planes h + m + l (24 significant bits); the six plane products of order <= 2^-16 give the dot
+//     product x.y to fp32 accuracy on v_mfma_f32_32x32x16_bf16 (the planes are laid along K: 6 x D slots, D padded to 8), and
+//         t(q, j) = |y_j|^2 - 2 x_q.y_j            (= d(q, j) - |x_q|^2 up to E <= c * 2^-24 * (|x|^2 + |y|^2))
+//     is a screening value: a wave takes 32 queries as the MFMA columns, so a lane holds 16 references of ONE query per 32-row block and
+//     the block minimum is an in-register min;
+//   * a lane records (block, block minimum) whenever the minimum is within the error window of its running minimum -- a superset of
+//     the blocks that can hold the exact nearest neighbour; the last three records live in registers;
+//   * at the end the recorded blocks still inside the window of the FINAL minimum (one or two per query) are evaluated with the direct
+//     kernel's arithmetic -- d = fma chain over the dimensions of (x - y)^2 -- each lane over its own 16 rows, and merged with the same
+//     lexicographic (distance, index) rule.  A lane whose window ever held more than three blocks (duplicated references) scans
+//     every block exactly instead: slower than the direct kernel there, never different.
+// The exact minimiser j* satisfies t(j*) <= t_min + 2E + (rounding of the chain), so it is always among the evaluated pairs and the
+// result is bit-identical to knn1_kernel's (tests/test_gpu_ops.py compares them on ties, duplicates and ragged lengths).
+typedef __attribute__((ext_vector_type(8))) __bf16 kbf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 kbf16x4;
+typedef __attribute__((ext_vector_type(16))) float kf32x16;
+
+__device__ __forceinline__ void ksplit3(float x, __bf16& h, __bf16& m, __bf16& l)
+{
+    h = (__bf16)x;
+    const float r1 = x - (float)h;
+    m = (__bf16)r1;
+    l = (__bf16)(r1 - (float)m);
+}
+
+constexpr int KS_RT = 128;      // references per LDS tile (four 32-row MFMA blocks)
+
+// Pre-pass of the screened search: every reference row once as (h, m, l) bf16 planes [row][3][DPAD] + its squared norm, into the
+// caller's workspace (clouds padded to a multiple of KS_RT rows; rows at or beyond the cloud's length: zero planes, infinite norm --
+// never a candidate).  The main kernel's tiles are then plain 16-byte copies.
+template <int D>
+__global__ __launch_bounds__(256) void knn_planes_kernel(const float* __restrict__ p2, const int64_t* __restrict__ len2, int P2, int P2pad,
+                                                         __bf16* __restrict__ planes, float* __restrict__ norms)
+{
+    constexpr int DPAD = (D + 7) & ~7, LDH = 3 * DPAD;
+    const int b = blockIdx.y;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= P2pad) return;
+    const int l2 = len2 ? (int)min((int64_t)P2, len2[b]) : P2;
+    __bf16* out = planes + ((size_t)b * P2pad + j) * LDH;
+    float ny = __builtin_inff();
+    float y[D];
+#pragma unroll
+    for (int t = 0; t < D; ++t) y[t] = 0.0f;
+    if (j < l2) {
+        const float* yr = p2 + ((size_t)b * P2 + j) * D;
+        ny = 0.0f;
+#pragma unroll
+        for (int t = 0; t < D; ++t) { y[t] = yr[t]; ny = __builtin_fmaf(y[t], y[t], ny); }
+    }
+#pragma unroll
+    for (int c = 0; c < DPAD; c += 8) {
+        kbf16x8 h, m, l;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            __bf16 hh = (__bf16)0.0f, mm = (__bf16)0.0f, ll = (__bf16)0.0f;
+            if (c + e < D) ksplit3(y[c + e], hh, mm, ll);
+            h[e] = hh; m[e] = mm; l[e] = ll;
+        }
+        *reinterpret_cast<kbf16x8*>(out + c) = h;
+        *reinterpret_cast<kbf16x8*>(out + DPAD + c) = m;
+        *reinterpret_cast<kbf16x8*>(out + 2 * DPAD + c) = l;
+    }
+    norms[(size_t)b * P2pad + j] = ny;
+    if constexpr (DPAD > D) {
+        // a spare K slot: |y|^2 rides in the MFMA -- its three planes in slot D of the (h, m, l) planes, met by -0.5 on the query side,
+        // so that the accumulator is x.y - |y|^2 / 2 = -t / 2 and the screening needs no norm reads and no fma per pair.  Rows that
+        // are not there get a huge FINITE norm (an infinity would meet the zeros of the other plane pairs: NaN).
+        __bf16 nh, nm, nl;
+        ksplit3(j < l2 ? ny : 1e30f, nh, nm, nl);
+        out[D] = nh;
+        out[DPAD + D] = nm;
+        out[2 * DPAD + D] = nl;
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(512) void knn1_screen_kernel(const float* __restrict__ p1, const float* __restrict__ p2,
+                                                          const int64_t* __restrict__ len1, const int64_t* __restrict__ len2,
+                                                          int P1, int P2, int P2pad, const __bf16* __restrict__ planes,
+                                                          const float* __restrict__ norms, float* __restrict__ dists,
+                                                          int64_t* __restrict__ idx)
+{
+    constexpr int DPAD = (D + 7) & ~7, NB = DPAD / 8;         // dimension blocks of 8 K-slots
+    constexpr int NS = 3 * NB;                                 // MFMA k-steps: 6 plane pairs x NB blocks / 2 per step
+    constexpr int LDH = 3 * DPAD;                              // halves per reference: planes h | m | l
+    constexpr int PCH = KS_RT * LDH / 8;                       // 16-byte chunks of a tile's planes
+    constexpr int NCH = PCH + KS_RT / 4;                       // ... plus its norms
+    constexpr int CPT = (NCH + 511) / 512;                     // chunks per thread
+    constexpr bool FOLD = DPAD > D;                            // |y|^2 folded into the MFMA (knn_planes_kernel): acc = -t / 2
+    constexpr bool ROWMASK = true;                             // records keep which rows of a block are inside the window
+    // plane pair of slot group g: reference plane, query plane -- (h,h) (m,h) (h,m) (m,m) (l,h) (h,l)
+    constexpr int RPL[6] = {0, 1, 0, 1, 2, 0}, QPL[6] = {0, 0, 1, 1, 0, 2};
+    __shared__ __attribute__((aligned(16))) __bf16 refH[2][KS_RT * LDH];
+    __shared__ __attribute__((aligned(16))) float refN[2][KS_RT];
+    __shared__ float xd[4][64];                                // merge of the two waves that share a query group
+    __shared__ int xi[4][64];
+
+    const int b = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int qg = wave & 3, hf = wave >> 2;                   // query group (32 queries) and which row blocks of a tile this wave scans
+    const int col = lane & 31, kh = lane >> 5;
+    const int l1 = len1 ? (int)min((int64_t)P1, len1[b]) : P1;
+    const int l2 = len2 ? (int)min((int64_t)P2, len2[b]) : P2;
+    const int qbase = blockIdx.x * 128;
+    const int q = qbase + qg * 32 + col;
+    const bool qvalid = q < l1;
+
+    // this lane's query: fp32 coordinates (kept for the exact evaluation), |x|^2, the B fragments of every k-step
+    float a[D];
+    {
+        const float* ap = p1 + ((size_t)b * P1 + (qvalid ? q : 0)) * D;
+#pragma unroll
+        for (int t = 0; t < D; ++t) a[t] = ap[t];
+    }
+    float nx = 0.0f;
+#pragma unroll
+    for (int t = 0; t < D; ++t) nx = __builtin_fmaf(a[t], a[t], nx);
+    kbf16x8 bq[NS];
+    {
+        __bf16 pl[3][DPAD];
+#pragma unroll
+        for (int t = 0; t < DPAD; ++t) {
+            if (t < D) ksplit3(a[t], pl[0][t], pl[1][t], pl[2][t]);
+            else { pl[0][t] = (__bf16)0.0f; pl[1][t] = (__bf16)0.0f; pl[2][t] = (__bf16)0.0f; }
+        }
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            kbf16x8 f0, f1;          // slot groups 2s (kh = 0) and 2s + 1 (kh = 1)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                auto slot = [&](int g) -> __bf16 {
+                    const int pt = g / NB, dim = 8 * (g % NB) + e;
+                    if (FOLD && dim == D) return (__bf16)((pt == 0 || pt == 1 || pt == 4) ? -0.5f : 0.0f);   // ref planes h, m, l once each
+                    return pl[QPL[pt]][dim];
+                };
+                f0[e] = slot(2 * s);
+                f1[e] = slot(2 * s + 1);
+            }
+            bq[s] = kh ? f1 : f0;
+        }
+    }
+    // |err of t| <= c 2^-24 (|x|^2 + |y|^2) with |y|^2 <= 2 (|x|^2 + d) for the references that matter; c = 64 covers the dropped
+    // plane products (3), the MFMA's fp32 accumulation over <= 144 slots and the norms; the window is twice that plus the chain's own
+    // rounding.  wnd(b1): window above a running minimum b1 of t (d = b1 + nx).
+    auto wnd = [&](float b1) { const float dd = __builtin_fmaxf(b1 + nx, 0.0f); return 7.7e-6f * (3.0f * nx + 2.0f * dd) + 1e-30f; };
+
+    float b1 = __builtin_inff();
+    float rm0 = __builtin_inff(), rm1 = __builtin_inff(), rm2 = __builtin_inff();
+    int rb0 = 0, rb1 = 0, rb2 = 0;
+    bool overflow = false;
+    const float* refs = p2 + (size_t)b * P2 * D;
+    const bool any_valid = qbase < l1;
+    const int ntiles = any_valid ? (l2 + KS_RT - 1) / KS_RT : 0;
+    // tiles: 16-byte copies of the pre-split planes and norms, fetched one tile ahead into registers, two LDS buffers, one barrier per tile
+    const uint4* gpl = reinterpret_cast<const uint4*>(planes + (size_t)b * P2pad * LDH);
+    const uint4* gno = reinterpret_cast<const uint4*>(norms + (size_t)b * P2pad);
+    uint4 pre[CPT];
+    auto fetch = [&](int t) {
+#pragma unroll
+        for (int u = 0; u < CPT; ++u) {
+            const int e = tid + 512 * u;
+            if (e < PCH) pre[u] = gpl[(size_t)t * PCH + e];
+            else if (e < NCH) pre[u] = gno[(size_t)t * (KS_RT / 4) + (e - PCH)];
+        }
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < CPT; ++u) {
+            const int e = tid + 512 * u;
+            if (e < PCH) reinterpret_cast<uint4*>(refH[buf])[e] = pre[u];
+            else if (e < NCH) reinterpret_cast<uint4*>(refN[buf])[e - PCH] = pre[u];
+        }
+    };
+    if (ntiles > 0) { fetch(0); stash(0); }
+    __syncthreads();
+    for (int t = 0; t < ntiles; ++t) {
+        const int cur = t & 1, base = t * KS_RT;
+        if (t + 1 < ntiles) fetch(t + 1);
+#if defined(KS_ABL) && KS_ABL == 3
+        const int nrb = 0;
+#else
+        const int nrb = min(4, (l2 - base + 31) / 32);
+#endif
+        for (int rb = hf; rb < nrb; rb += 2) {
+            kf32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+            const __bf16* rowp = refH[cur] + (rb * 32 + col) * LDH;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const int g0 = 2 * s, g1 = 2 * s + 1;
+                const int o0 = RPL[g0 / NB] * DPAD + 8 * (g0 % NB), o1 = RPL[g1 / NB] * DPAD + 8 * (g1 % NB);
+                const kbf16x8 ar = *reinterpret_cast<const kbf16x8*>(rowp + (kh ? o1 : o0));
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar, bq[s], acc, 0, 0, 0);
+            }
+            // this lane's 16 references of the block: rows (r & 3) + 8 (r >> 2) + 4 kh.  tv = -t / 2 (FOLD: the accumulator itself)
+            float tv[16];
+            if constexpr (FOLD) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) tv[r] = acc[r];
+            } else {
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const float4 ny = *reinterpret_cast<const float4*>(&refN[cur][rb * 32 + 8 * r4 + 4 * kh]);
+                    tv[4 * r4 + 0] = __builtin_fmaf(-0.5f, ny.x, acc[4 * r4 + 0]);
+                    tv[4 * r4 + 1] = __builtin_fmaf(-0.5f, ny.y, acc[4 * r4 + 1]);
+                    tv[4 * r4 + 2] = __builtin_fmaf(-0.5f, ny.z, acc[4 * r4 + 2]);
+                    tv[4 * r4 + 3] = __builtin_fmaf(-0.5f, ny.w, acc[4 * r4 + 3]);
+                }
+            }
+            float mx = __builtin_fmaxf(__builtin_fmaxf(tv[0], tv[1]), tv[2]);          // (v_max3_f32)
+#pragma unroll
+            for (int r = 3; r < 15; r += 2) mx = __builtin_fmaxf(__builtin_fmaxf(mx, tv[r]), tv[r + 1]);
+            mx = __builtin_fmaxf(mx, tv[15]);
+            const float m = -2.0f * mx;
+            b1 = __builtin_fminf(b1, m);
+#if defined(KS_ABL) && KS_ABL == 2
+            if (false) {
+#else
+            if (qvalid && m <= b1 + wnd(b1)) {        // (always true for the block that sets a new minimum)
+#endif
+                // the last three records of the lane, in registers: (block minimum, block, ROWMASK: which of the 16 rows are inside the
+                // window now -- a superset of those inside the final one).  A record that is pushed out while still inside the window of
+                // the running minimum (four blocks within ~1e-5 |x|^2 of each other: duplicated references) sends the lane to the full scan.
+                const float thr = b1 + wnd(b1);
+                if (rm2 <= thr) overflow = true;
+                unsigned mask = 0xffffu;
+                if constexpr (ROWMASK) {
+                    // bit (15 - r): row r is inside the window, i.e. tv[r] >= -thr / 2: the sign bit of (-thr / 2 - tv[r]) shifted in with one
+                    // v_alignbit_b32 per row (threshold one notch down so that equality counts)
+                    const float ta = -0.5f * thr;
+                    const float ta_dn = ta - __builtin_fabsf(ta) * 1.2e-7f - 1e-37f;
+                    mask = 0;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(ta_dn - tv[r]), 31);
+                }
+                rm2 = rm1; rb2 = rb1;
+                rm1 = rm0; rb1 = rb0;
+                rm0 = m; rb0 = ((base / 32 + rb) << 16) | (int)mask;
+            }
+        }
+        if (t + 1 < ntiles) stash(cur ^ 1);
+        __syncthreads();
+    }
+    // ---- exact evaluation of the surviving blocks: every lane walks its own 16 rows of each block with the direct kernel's chain ----
+    float bd = __builtin_inff();
+    int bi = 0x7fffffff;
+    const float lim = b1 + wnd(b1);
+    auto eval_rows = [&](int blk, unsigned mask) {      // rows i of block blk with bit i of mask set, ascending
+        while (mask) {           // bit (15 - i) <-> row i: highest bit first == ascending rows
+            const int i = __builtin_clz(mask) - 16;
+            mask &= ~(0x8000u >> i);
+            const int j = blk * 32 + (i & 3) + 8 * (i >> 2) + 4 * kh;
+            if (j < l2) {
+                const float* yr = refs + (size_t)j * D;
+                float y[D];           // one row in as few, as wide loads as its alignment allows (every lane reads its own row)
+                if constexpr (D % 4 == 0) {
+#pragma unroll
+                    for (int t = 0; t < D; t += 4) { const float4 v = *reinterpret_cast<const float4*>(yr + t); y[t] = v.x; y[t + 1] = v.y; y[t + 2] = v.z; y[t + 3] = v.w; }
+                } else if constexpr (D % 2 == 0) {
+#pragma unroll
+                    for (int t = 0; t < D; t += 2) { const float2 v = *reinterpret_cast<const float2*>(yr + t); y[t] = v.x; y[t + 1] = v.y; }
+                } else {
+#pragma unroll
+                    for (int t = 0; t < D; ++t) y[t] = yr[t];
+                }
+                float d = 0.0f;
+#pragma unroll
+                for (int t = 0; t < D; ++t) { const float diff = a[t] - y[t]; d = __builtin_fmaf(diff, diff, d); }
+                if (d < bd || (d == bd && j < bi)) { bd = d; bi = j; }
+            }
+        }
+    };
+#if defined(KS_ABL) && KS_ABL >= 1
+    if (false) {
+#else
+    {
+#endif
+        // the rows inside the final window, of at most three blocks: the first four of a lane are fetched TOGETHER (one global latency
+        // for the wave instead of one per row), any further ones -- and the lanes that overflowed -- take the loops
+        const bool live = qvalid && !overflow;
+        unsigned long long cand = 0;
+        if (live && rm0 <= lim) cand |= (unsigned long long)(rb0 & 0xffff);
+        if (live && rm1 <= lim) cand |= (unsigned long long)(rb1 & 0xffff) << 16;
+        if (live && rm2 <= lim) cand |= (unsigned long long)(rb2 & 0xffff) << 32;
+        int cj[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            cj[k] = -1;
+            if (cand) {
+                const int pos = (int)__builtin_ctzll(cand);
+                cand &= cand - 1;
+                const int rec = pos >> 4, i = 15 - (pos & 15);          // bit (15 - i) <-> row i
+                const int blk = (rec == 0 ? rb0 : (rec == 1 ? rb1 : rb2)) >> 16;
+                const int j = blk * 32 + (i & 3) + 8 * (i >> 2) + 4 * kh;
+                cj[k] = j < l2 ? j : -1;
+            }
+        }
+        float cy[4][D];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float* yr = refs + (size_t)(cj[k] >= 0 ? cj[k] : 0) * D;
+            if constexpr (D % 4 == 0) {
+#pragma unroll
+                for (int t = 0; t < D; t += 4) { const float4 v = *reinterpret_cast<const float4*>(yr + t); cy[k][t] = v.x; cy[k][t + 1] = v.y; cy[k][t + 2] = v.z; cy[k][t + 3] = v.w; }
+            } else if constexpr (D % 2 == 0) {
+#pragma unroll
+                for (int t = 0; t < D; t += 2) { const float2 v = *reinterpret_cast<const float2*>(yr + t); cy[k][t] = v.x; cy[k][t + 1] = v.y; }
+            } else {
+#pragma unroll
+                for (int t = 0; t < D; ++t) cy[k][t] = yr[t];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float d = 0.0f;
+#pragma unroll
+            for (int t = 0; t < D; ++t) { const float diff = a[t] - cy[k][t]; d = __builtin_fmaf(diff, diff, d); }
+            if (cj[k] >= 0 && (d < bd || (d == bd && cj[k] < bi))) { bd = d; bi = cj[k]; }
+        }
+        if (__ballot(cand != 0)) {             // more than four rows in the window
+            while (cand) {
+                const int pos = (int)__builtin_ctzll(cand);
+                cand &= cand - 1;
+                const int rec = pos >> 4;
+                eval_rows((rec == 0 ? rb0 : (rec == 1 ? rb1 : rb2)) >> 16, 0x8000u >> (15 - (pos & 15)));
+            }
+        }
+        if (__ballot(qvalid && overflow)) {      // every block this wave scanned, exactly (as slow as the direct kernel; correct)
+            if (qvalid && overflow)
+                for (int blk = 0; blk * 32 < l2; ++blk)
+                    if (((blk & 3) & 1) == hf) eval_rows(blk, 0xffffu);
+        }
+    }
+    // the two row halves of a query, then the two waves of its group
+    {
+        const float od = __shfl_xor(bd, 32, 64);
+        const int oi = __shfl_xor(bi, 32, 64);
+        if (od < bd || (od == bd && oi < bi)) { bd = od; bi = oi; }
+    }
+    if (hf == 1) { xd[qg][lane] = bd; xi[qg][lane] = bi; }
+    __syncthreads();
+    if (hf == 0) {
+        const float od = xd[qg][lane];
+        const int oi = xi[qg][lane];
+        if (od < bd || (od == bd && oi < bi)) { bd = od; bi = oi; }
+        if (kh == 0 && q < P1) {
+            const bool ok = qvalid && l2 > 0;
+            dists[(size_t)b * P1 + q] = ok ? bd : 0.0f;
+            idx[(size_t)b * P1 + q] = ok ? (int64_t)bi : 0;
+        }
+    }
+}
+
+inline size_t knn1_screen_ws(int64_t B, int64_t P2, int64_t D)
+{
+    const int64_t dpad = (D + 7) & ~7, p2pad = (P2 + KS_RT - 1) / KS_RT * KS_RT;
+    return (size_t)(B * p2pad * (3 * dpad * 2 + 4));
+}
+
+template <int D>
+int launch_knn1_screen(const float* p1, const float* p2, const int64_t* len1, const int64_t* len2, int B, int P1, int P2,
+                       float* dists, int64_t* idx, void* ws, size_t ws_bytes, hipStream_t stream)
+{
+    constexpr int DPAD = (D + 7) & ~7;
+    if (!ws || ws_bytes < knn1_screen_ws(B, P2, D) || (reinterpret_cast<uintptr_t>(ws) & 15)) return MP_EINVAL;
+    const int P2pad = (P2 + KS_RT - 1) / KS_RT * KS_RT;
+    __bf16* planes = reinterpret_cast<__bf16*>(ws);
+    float* norms = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + (size_t)B * P2pad * 3 * DPAD * 2);
+    hipLaunchKernelGGL((knn_planes_kernel<D>), dim3((P2pad + 255) / 256, B), dim3(256), 0, stream, p2, len2, P2, P2pad, planes, norms);
+    MP_CHECK_LAUNCH();
+    char tag[48];
+    snprintf(tag, sizeof tag, "knn1_screen_kernel<%d>", D);
+    const double flops = 3.0 * D * (double)B * P1 * P2, bytes = (double)B * ((P1 + P2) * 4.0 * D + P1 * 12.0);
+    MP_LAUNCH(tag, flops, bytes, (knn1_screen_kernel<D>), dim3((P1 + 127) / 128, B), dim3(512), 0, stream, p1, p2, len1, len2, P1, P2,
+              P2pad, planes, norms, dists, idx);
+    MP_CHECK_LAUNCH();
+    return MP_OK;
+}
+
+// MP_KNN_SCREEN=0: the direct kernel for every K = 1 search (A/B timing, and the reference the screened kernel is tested against)
+inline bool knn_screen_enabled()
+{
+    static const bool on = !(getenv("MP_KNN_SCREEN") && atoi(getenv("MP_KNN_SCREEN")) == 0);
+    return on;
+}
+
 template <int D, int K>
 int launch_knn(const float* p1, const float* p2, const int64_t* len1, const int64_t* len2, int B, int P1, int P2,
                int Drt, int Kout, float* dists, int64_t* idx, hipStream_t stream)
@@ -437,9 +829,15 @@ inline unsigned grid_for(int64_t total)
 }  // namespace
 
 extern "C" size_t mp_knn_workspace_bytes(int64_t, int64_t, int64_t) { return 0; }
+// workspace of the screened K = 1 search (bf16 planes + norms of the references); without it mp_knn_f32 uses the direct scan
+extern "C" size_t mp_knn1_workspace_bytes(int64_t B, int64_t P2, int64_t D)
+{
+    if (B <= 0 || P2 <= 0 || !(D == 3 || D == 6 || D == 12 || D == 24)) return 0;
+    return knn1_screen_ws(B, P2, D);
+}
 
 extern "C" int mp_knn_f32(const float* p1, const float* p2, const int64_t* len1, const int64_t* len2, int64_t B,
-                          int64_t P1, int64_t P2, int64_t D, int64_t K, float* dists, int64_t* idx, void*, size_t,
+                          int64_t P1, int64_t P2, int64_t D, int64_t K, float* dists, int64_t* idx, void* ws, size_t ws_bytes,
                           mp_stream_t stream_)
 {
     if (B < 0 || P1 < 0 || P2 < 0 || D <= 0 || K <= 0) return MP_EINVAL;
@@ -448,6 +846,15 @@ extern "C" int mp_knn_f32(const float* p1, const float* p2, const int64_t* len1,
     if (K > 8 || D > 1024 || B > 65535 || P1 > (1 << 30) || P2 > (1 << 30)) return MP_EUNSUPPORTED;
     hipStream_t stream = mp_stream(stream_);
     const int b = (int)B, n1 = (int)P1, n2 = (int)P2, d = (int)D, k = (int)K;
+    if (k == 1 && knn_screen_enabled() && n2 >= 256 && ws && ws_bytes >= mp_knn1_workspace_bytes(B, P2, D) && mp_knn1_workspace_bytes(B, P2, D) > 0) {
+        switch (d) {
+            case 3: return launch_knn1_screen<3>(p1, p2, len1, len2, b, n1, n2, dists, idx, ws, ws_bytes, stream);
+            case 6: return launch_knn1_screen<6>(p1, p2, len1, len2, b, n1, n2, dists, idx, ws, ws_bytes, stream);
+            case 12: return launch_knn1_screen<12>(p1, p2, len1, len2, b, n1, n2, dists, idx, ws, ws_bytes, stream);
+            case 24: return launch_knn1_screen<24>(p1, p2, len1, len2, b, n1, n2, dists, idx, ws, ws_bytes, stream);
+            default: break;
+        }
+    }
     if (k == 1) {
         switch (d) {
             case 3: return launch_knn1<3>(p1, p2, len1, len2, b, n1, n2, dists, idx, stream);
@@ -460,6 +867,26 @@ extern "C" int mp_knn_f32(const float* p1, const float* p2, const int64_t* len1,
     if (k == 2) return dispatch_d<2>(p1, p2, len1, len2, b, n1, n2, d, k, dists, idx, stream);
     if (k <= 4) return dispatch_d<4>(p1, p2, len1, len2, b, n1, n2, d, k, dists, idx, stream);
     return dispatch_d<8>(p1, p2, len1, len2, b, n1, n2, d, k, dists, idx, stream);
+}
+
+// The two K = 1 implementations behind mp_knn_f32, callable by name (tests compare them; tools time them): `screened` != 0 is the
+// matrix-core screened search (D in {3, 6, 12, 24}), 0 the direct VALU scan.  Same outputs, bit for bit.
+extern "C" int mp_knn1_f32(const float* p1, const float* p2, const int64_t* len1, const int64_t* len2, int64_t B, int64_t P1,
+                           int64_t P2, int64_t D, float* dists, int64_t* idx, int screened, void* ws, size_t ws_bytes, mp_stream_t stream_)
+{
+    if (B < 0 || P1 < 0 || P2 < 0 || D <= 0) return MP_EINVAL;
+    if (B == 0 || P1 == 0) return MP_OK;
+    if (!p1 || !dists || !idx || (P2 > 0 && !p2)) return MP_EINVAL;
+    if (B > 65535 || P1 > (1 << 30) || P2 > (1 << 30)) return MP_EUNSUPPORTED;
+    hipStream_t stream = mp_stream(stream_);
+    const int b = (int)B, n1 = (int)P1, n2 = (int)P2;
+    switch ((int)D) {
+        case 3: return screened ? launch_knn1_screen<3>(p1, p2, len1, len2, b, n1, n2, dists, idx, ws, ws_bytes, stream) : launch_knn1<3>(p1, p2, len1, len2, b, n1, n2, dists, idx, stream);
+        case 6: return screened ? launch_knn1_screen<6>(p1, p2, len1, len2, b, n1, n2, dists, idx, ws, ws_bytes, stream) : launch_knn1<6>(p1, p2, len1, len2, b, n1, n2, dists, idx, stream);
+        case 12: return screened ? launch_knn1_screen<12>(p1, p2, len1, len2, b, n1, n2, dists, idx, ws, ws_bytes, stream) : launch_knn1<12>(p1, p2, len1, len2, b, n1, n2, dists, idx, stream);
+        case 24: return screened ? launch_knn1_screen<24>(p1, p2, len1, len2, b, n1, n2, dists, idx, ws, ws_bytes, stream) : launch_knn1<24>(p1, p2, len1, len2, b, n1, n2, dists, idx, stream);
+        default: return MP_EUNSUPPORTED;
+    }
 }
 
 static int knn_bwd(const float* p1, const float* p2, const int64_t* len1, const int64_t* len2, const int64_t* idx,

@@ -381,6 +381,17 @@ def group(xyz, feats, new_xyz, idx, xyz_last=False, pad_to=1):
     return _Group.apply(_f32(xyz), None if feats is None else _f32(feats), _f32(new_xyz), _i64(idx), bool(xyz_last), stride)
 
 
+def _knn_workspace(like, B, P2, D, K):
+    """Device scratch of the screened K = 1 search (bf16 planes + norms of the references, mp_knn1_workspace_bytes); (None, 0) when the
+    library would use the direct scan anyway."""
+    if K != 1:
+        return None, 0
+    n = int(_lib.load().mp_knn1_workspace_bytes(B, P2, D))
+    if n <= 0:
+        return None, 0
+    return torch.empty((n,), dtype=torch.uint8, device=like.device), n
+
+
 class _Knn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, p1, p2, len1, len2, K):
@@ -388,7 +399,8 @@ class _Knn(torch.autograd.Function):
         P2 = p2.shape[1]
         dists = torch.empty((B, P1, K), dtype=torch.float32, device=p1.device)
         idx = torch.empty((B, P1, K), dtype=torch.int64, device=p1.device)
-        _run("knn", p1, _lib.load().mp_knn_f32, _p(p1), _p(p2), _p(len1), _p(len2), B, P1, P2, D, K, _p(dists), _p(idx), None, 0)
+        ws, nws = _knn_workspace(p1, B, P2, D, K)
+        _run("knn", p1, _lib.load().mp_knn_f32, _p(p1), _p(p2), _p(len1), _p(len2), B, P1, P2, D, K, _p(dists), _p(idx), _p(ws), nws)
         ctx.save_for_backward(p1, p2, len1, len2, idx)
         ctx.mark_non_differentiable(idx)
         ctx.set_materialize_grads(False)      # (a zero gradient for the int64 index output would be a fill launch per call)
@@ -435,7 +447,8 @@ class _ChamferTerm(torch.autograd.Function):
         lib = _lib.load()
         dists = torch.empty((B, P1), dtype=torch.float32, device=p1.device)
         idx = torch.empty((B, P1), dtype=torch.int64, device=p1.device)
-        _run("knn", p1, lib.mp_knn_f32, _p(p1), _p(p2), _p(len1), _p(len2), B, P1, P2, D, 1, _p(dists), _p(idx), None, 0)
+        ws, nws = _knn_workspace(p1, B, P2, D, 1)
+        _run("knn", p1, lib.mp_knn_f32, _p(p1), _p(p2), _p(len1), _p(len2), B, P1, P2, D, 1, _p(dists), _p(idx), _p(ws), nws)
         out = torch.empty((B,) if batch_mode == 0 else (), dtype=torch.float32, device=p1.device)
         scratch = torch.empty((B,), dtype=torch.float32, device=p1.device) if batch_mode != 0 else None
         _run("chamfer_reduce", dists, lib.mp_chamfer_reduce_f32, _p(dists), _p(len1), B, P1, int(point_mean), int(batch_mode),

@@ -670,3 +670,50 @@ def test_fused_dropout_of_the_head_blocks():
     assert torch.allclose(bn.bias.grad, gb, rtol=1e-5, atol=1e-5)
     # p = 0 keeps everything; eval mode is untouched by the harness (the model only takes this path in train mode)
     assert torch.equal(ops.bn_relu_rows(x, bn, dropout=(0.0, rng, 0)), ops.bn_relu_rows(x, bn))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("D,P1,P2", [(6, 1500, 3996), (24, 999, 700), (3, 700, 2048), (12, 300, 517)])
+def test_screened_nearest_neighbour_equals_the_direct_scan(D, P1, P2):
+    """mp_knn1_f32(screened=1): the bf16 matrix cores screen the pairs through three-plane split dot products and only the rows inside
+    the error window of the minimum are evaluated with the direct kernel's arithmetic.  The result must be the direct scan's, bit for bit:
+    distances, indices, first index on exact ties -- on random clouds, duplicated references (ties inside and across 32-row blocks),
+    queries that coincide with references (zero distances), collapsed references (every row inside the window: the full-scan path),
+    references far from the origin (large norms, small distances) and ragged lengths on both sides."""
+    from maskplanner_amd import _lib, ops
+    lib = _lib.load()
+
+    def run(p1, p2, l1, l2, screened):
+        B = p1.shape[0]
+        d = torch.empty(B, p1.shape[1], device="cuda")
+        i = torch.empty(B, p1.shape[1], dtype=torch.int64, device="cuda")
+        nb = lib.mp_knn1_workspace_bytes(B, p2.shape[1], D)
+        assert nb > 0
+        ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
+        ops._run("knn1", p1, lib.mp_knn1_f32, p1.data_ptr(), p2.data_ptr(), None if l1 is None else l1.data_ptr(),
+                 None if l2 is None else l2.data_ptr(), B, p1.shape[1], p2.shape[1], D, d.data_ptr(), i.data_ptr(), int(screened),
+                 ws.data_ptr(), ws.numel())
+        return d, i
+
+    torch.manual_seed(D)
+    B = 6
+    p1 = torch.rand(B, P1, D, device="cuda")
+    p2 = torch.rand(B, P2, D, device="cuda")
+    p2[0, 5] = p2[0, 3]                       # a tie inside a block
+    p2[0, 200:264] = p2[0, 100:164]           # ties across blocks and tiles
+    p1[1, 7] = p2[1, 11]                      # zero distance
+    p2[2] = p2[2, :1] + 1e-7 * torch.randn(P2, D, device="cuda")        # collapsed references: everything inside the window
+    p2[3] = p2[3] + 40.0                      # far from the origin: norms ~1e4, distances ~1
+    p1[3] = p1[3] + 40.0
+    p2[4] = p2[4, torch.randint(0, 8, (P2,), device="cuda")]            # eight distinct rows repeated all over: more ties than records
+    l1 = torch.tensor([P1, P1 // 2, P1, 17, P1, 1], device="cuda")
+    l2 = torch.tensor([P2, P2, P2 - 3, P2, P2, 33], device="cuda")
+    for a, bb in ((l1, l2), (None, None)):
+        d0, i0 = run(p1, p2, a, bb, 0)
+        d1, i1 = run(p1, p2, a, bb, 1)
+        assert torch.equal(i0, i1), (int((i0 != i1).sum()), (i0 != i1).nonzero()[:4].tolist())
+        assert torch.equal(d0, d1), int((d0 != d1).sum())
+    # the default entry point takes the screened path when it is handed the workspace: same result through ops.knn
+    dd, ii = ops.knn(p1, p2, l1, l2, 1)
+    d0, i0 = run(p1, p2, l1, l2, 0)
+    assert torch.equal(dd[..., 0], d0) and torch.equal(ii[..., 0], i0)
