@@ -331,7 +331,9 @@ def main():
             # dominant kernel = largest total device time on the step's own stream; its binding roof from the algorithmic work
             # model.  (With pipelined sampling the first-level FPS -- a latency-bound chain of dependent arg-max steps, one
             # workgroup per cloud -- runs on the second stream underneath the step and is not on the critical path.)
-            on_path = [k for k in kernels if not (ts.overlap and k.startswith("fps_kernel"))] or list(kernels)
+            # (likewise the factor Adam of the head matrices: seven launches on its own stream underneath the encoder backward)
+            off_path = lambda k: (ts.overlap and k.startswith("fps_kernel")) or (ts._graph_b is not None and k.startswith("adam_lowrank"))
+            on_path = [k for k in kernels if not off_path(k)] or list(kernels)
             dom = max(on_path, key=lambda k: kernels[k]["ms"])
             d = kernels[dom]
             avg_s = d["ms"] / d["calls"] * 1e-3

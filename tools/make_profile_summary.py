@@ -70,7 +70,11 @@ if mf:
                 "* `SQ_VALU_MFMA_BUSY_CYCLES` is summed over the chip's 1024 SIMDs: **MFMA utilisation = BUSY / (1024 x GUI/8)**.\n"
                 "* fp32 MFMA (`v_mfma_f32_32x32x2_f32`, 2048 MACs) holds a SIMD's matrix pipe for 64 cycles, `16x16x4` (1024 MACs) for 32: "
                 "the fp32 peak of 157.3 TFLOP/s is 1024 SIMDs x 32 MAC/cycle x 2.4 GHz; at the held clock the peak scales down "
-                "with it, so `util x held/2.4` is the fraction of the nominal peak the MFMA pipe was busy for.\n\n"
+                "with it, so `util x held/2.4` is the fraction of the nominal peak the MFMA pipe was busy for.\n"
+                "* the split-plane kernels (names ending `, true>` / `, 3>`) issue `v_mfma_f32_32x32x16_bf16` (16384 MACs, 32 busy cycles) and "
+                "`v_mfma_f32_16x16x32_bf16` (8192 MACs, 16 cycles): six of them per fp32 product tile, so BUSY = 6 x algorithmic MACs / 512 per cycle "
+                "-- e.g. `bwd_fused_kernel<3, 256, 128>`: 2 x 8.6e9 MACs x 6 / 512 = 2.013e8 SIMD-cycles, the counter's value to four digits -- and "
+                "their MFMA utilisation is a fraction of the bf16 dense peak (2.5 PFLOP/s), not of the fp32 one.\n\n"
                 "| kernel | launches | avg us | GUI_ACTIVE/8 (cycles) | held clock GHz | MFMA_BUSY (SIMD-cycles) | MFMA util | util x clk/2.4 |\n|---|---|---|---|---|---|---|---|\n")
         names = sorted(agg, key=lambda n: -dur.get(n, 0.0) * len(agg[n].get("GRBM_GUI_ACTIVE", [])))
         for n in names:
