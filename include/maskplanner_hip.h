@@ -100,6 +100,9 @@ int mp_three_interpolate_bwd_f32(const float* grad_out, const int64_t* idx, cons
  *   dst [R,Cd] : dst[r,c] = src[r, perm[c]] for perm[c] >= 0, else 0;  src [R,Cs], perm i32 [Cd]. */
 int mp_permute_cols_f32(const float* src, const int32_t* perm, int64_t R, int64_t Cs, int64_t Cd, float* dst,
                         mp_stream_t stream);
+/* up to 8 of those in one launch (HOST arrays of device pointers and shapes; they travel in the kernel arguments) */
+int mp_permute_cols_multi_f32(int64_t count, const float* const* src, const int32_t* const* perm, const int64_t* R,
+                              const int64_t* Cs, const int64_t* Cd, float* const* dst, mp_stream_t stream);
 
 /* ---- grouping (gather + centre + concat) -----------------------------------------------------
  * replaces: models/pointnet2_utils.py:133-143 (sample_and_group tail) and :258-262 (MSG variant)
@@ -166,6 +169,11 @@ int mp_padded_lengths_f32(const float* y, int64_t B, int64_t P2, int64_t D, int6
  *   (loss_handler.py:660-664) chain their weighted terms through it instead of launching an elementwise add per term. */
 int mp_chamfer_reduce_f32(const float* cham, const int64_t* lengths, int64_t N, int64_t P, int point_mean, int batch_mode,
                           double div, double scale, float* per_cloud, float* out, const float* add_to, mp_stream_t stream);
+/* the same reduction in one launch: `counter` = device uint32, zero on entry and zero again on exit (the workgroup that finishes last
+ * combines the clouds in cloud order -- identical result bits); one counter per stream that runs reductions */
+int mp_chamfer_reduce1_f32(const float* cham, const int64_t* lengths, int64_t N, int64_t P, int point_mean,
+                           int batch_mode, double div, double scale, float* per_cloud, float* out, const float* add_to,
+                           uint32_t* counter, mp_stream_t stream);
 int mp_chamfer_reduce_bwd_f32(const float* grad_out, const int64_t* lengths, int64_t N, int64_t P, int point_mean,
                               int batch_mode, double div, double scale, float* grad_cham, mp_stream_t stream);
 

@@ -65,8 +65,10 @@ SIGNATURES = {
     "mp_lsap_f32": (_int, [_vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
     "mp_cdist_batch_f32": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp]),
     "mp_chamfer_reduce_f32": (_int, [_vp, _vp, _i64, _i64, _int, _int, _dbl, _dbl, _vp, _vp, _vp, _vp]),
+    "mp_chamfer_reduce1_f32": (_int, [_vp, _vp, _i64, _i64, _int, _int, _dbl, _dbl, _vp, _vp, _vp, _vp, _vp]),
     "mp_chamfer_reduce_bwd_f32": (_int, [_vp, _vp, _i64, _i64, _int, _int, _dbl, _dbl, _vp, _vp]),
     "mp_permute_cols_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp]),
+    "mp_permute_cols_multi_f32": (_int, [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mp_pose_output_f32": (_int, [_vp, _vp, _i64, _dbl, _vp, _vp]),
     "mp_pose_output_bwd_f32": (_int, [_vp, _vp, _i64, _dbl, _vp, _vp, _vp]),
     "mp_mask_loss_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _dbl, _dbl, _dbl, _vp, _vp, _vp, _vp, _vp, _vp]),

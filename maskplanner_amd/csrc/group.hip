@@ -275,6 +275,55 @@ extern "C" int mp_permute_cols_f32(const float* src, const int32_t* perm, int64_
     return MP_OK;
 }
 
+// Several column permutations in one launch (the first-layer weights of all set-abstraction levels at the start of the forward, their
+// gradients at the end of the backward): blockIdx.y = tensor, pointers and shapes travel in the kernel arguments.
+namespace {
+constexpr int PERM_MAX = 8;
+struct PermTable {
+    const float* src[PERM_MAX];
+    const int32_t* perm[PERM_MAX];
+    float* dst[PERM_MAX];
+    int Cs[PERM_MAX], Cd[PERM_MAX];
+    long long total[PERM_MAX];
+};
+__global__ __launch_bounds__(256) void permute_cols_multi_kernel(PermTable t)
+{
+    const int k = blockIdx.y;
+    const int Cd = t.Cd[k], Cs = t.Cs[k];
+    const int32_t* perm = t.perm[k];
+    const float* src = t.src[k];
+    float* dst = t.dst[k];
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < t.total[k]; e += (long long)gridDim.x * 256) {
+        const long long r = e / Cd;
+        const int c = (int)(e - r * Cd);
+        const int j = perm[c];
+        dst[e] = j >= 0 ? src[r * Cs + j] : 0.0f;
+    }
+}
+}  // namespace
+
+extern "C" int mp_permute_cols_multi_f32(int64_t count, const float* const* src, const int32_t* const* perm, const int64_t* R,
+                                         const int64_t* Cs, const int64_t* Cd, float* const* dst, mp_stream_t stream_)
+{
+    if (count < 0 || count > PERM_MAX) return MP_EINVAL;
+    if (count == 0) return MP_OK;
+    if (!src || !perm || !R || !Cs || !Cd || !dst) return MP_EINVAL;
+    PermTable t{};
+    long long most = 0;
+    for (int k = 0; k < (int)count; ++k) {
+        if (R[k] < 0 || Cs[k] < 0 || Cd[k] < 0 || Cs[k] > (1 << 30) || Cd[k] > (1 << 30)) return MP_EINVAL;
+        t.total[k] = (long long)(R[k] * Cd[k]);
+        if (t.total[k] > 0 && (!src[k] || !perm[k] || !dst[k])) return MP_EINVAL;
+        t.src[k] = src[k]; t.perm[k] = perm[k]; t.dst[k] = dst[k];
+        t.Cs[k] = (int)Cs[k]; t.Cd[k] = Cd[k] > 0 ? (int)Cd[k] : 1;
+        most = t.total[k] > most ? t.total[k] : most;
+    }
+    if (most == 0) return MP_OK;
+    hipLaunchKernelGGL(permute_cols_multi_kernel, dim3(grid_for(most), (unsigned)count), dim3(256), 0, mp_stream(stream_), t);
+    MP_CHECK_LAUNCH();
+    return MP_OK;
+}
+
 extern "C" int mp_index_points_f32(const float* points, const int64_t* idx, int64_t B, int64_t N, int64_t C,
                                    int64_t M, float* out, mp_stream_t stream_)
 {

@@ -1918,8 +1918,15 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(const float* __restrict__
 constexpr int POOL_ROWS = 16;
 __global__ __launch_bounds__(256) void pool_bwd_prep_kernel(const float* __restrict__ gout, const float* __restrict__ out,
                                                             const float* __restrict__ zmax, int64_t G, int C,
-                                                            float* __restrict__ gp, float* __restrict__ partials)
+                                                            float* __restrict__ gp, float* __restrict__ partials,
+                                                            float* __restrict__ clear, size_t clear_n)
 {
+    // clear: the level's dW block (accumulated with atomics by the kernels that follow) is zeroed here, in the first launch of the
+    // level's backward, instead of by a launch of its own
+    {
+        const size_t nthreads = (size_t)gridDim.x * gridDim.y * 256;
+        for (size_t i = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x; i < clear_n; i += nthreads) clear[i] = 0.0f;
+    }
     const int c = blockIdx.y * 256 + threadIdx.x;
     if (c >= C) return;
     const int64_t g0 = (int64_t)blockIdx.x * POOL_ROWS;
@@ -2317,25 +2324,24 @@ static int sa_mlp_bwd(const float* x0, int64_t P, int64_t K, int n_layers, const
                            cbuf[0], cbuf[1], cbuf[2], gs, ls);
         return hipGetLastError() == hipSuccess ? MP_OK : MP_ELAUNCH;
     };
-    // pooled gradient through the last ReLU + its BatchNorm-backward sums
-    {
-        const int C = (int)last.c_out;
-        const int nb = (int)((G + POOL_ROWS - 1) / POOL_ROWS);
-        if ((size_t)nb > nblk_max) return MP_EUNSUPPORTED;  // partials hold P/64 rows: needs K >= 4
-        hipLaunchKernelGGL(pool_bwd_prep_kernel, dim3(nb, (C + 255) / 256), dim3(256), 0, stream, grad_out, out, zmax, G, C, gp,
-                           partials);
-        MP_CHECK_LAUNCH();
-        if (int rc = finalize_bwd(L - 1, nb, C)) return rc;
-    }
     // dW is accumulated with atomics and must start from zero: one clear for the whole level when the caller laid the
-    // layers' buffers out back to back (the Python layer does), one per layer otherwise
+    // layers' buffers out back to back (the Python layer does) -- folded into the launch below --, one per layer otherwise
     bool dw_joint = L > 1;
     size_t dw_total = 0;
     for (int l = 0; l < L; ++l) {
         if (l + 1 < L && grads[l + 1].d_weight != grads[l].d_weight + (size_t)layers[l].c_out * layers[l].c_in) dw_joint = false;
         dw_total += (size_t)layers[l].c_out * layers[l].c_in;
     }
-    if (dw_joint && !mp::zero_async(grads[0].d_weight, dw_total, stream)) return MP_ELAUNCH;
+    // pooled gradient through the last ReLU + its BatchNorm-backward sums
+    {
+        const int C = (int)last.c_out;
+        const int nb = (int)((G + POOL_ROWS - 1) / POOL_ROWS);
+        if ((size_t)nb > nblk_max) return MP_EUNSUPPORTED;  // partials hold P/64 rows: needs K >= 4
+        hipLaunchKernelGGL(pool_bwd_prep_kernel, dim3(nb, (C + 255) / 256), dim3(256), 0, stream, grad_out, out, zmax, G, C, gp,
+                           partials, dw_joint ? grads[0].d_weight : nullptr, dw_joint ? dw_total : (size_t)0);
+        MP_CHECK_LAUNCH();
+        if (int rc = finalize_bwd(L - 1, nb, C)) return rc;
+    }
     const float* G_cur = nullptr;  // dense gradient w.r.t. the activation output of layer l (l < L-1)
     for (int l = L - 1; l >= 0; --l) {
         const mp_mlp_layer_t& Ly = layers[l];

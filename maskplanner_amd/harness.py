@@ -226,7 +226,9 @@ class TrainStep:
             # backward (down to the gradient of the global feature), B2 = the encoder's backward + dense Adam.  The head
             # optimizer then starts right behind B1 and streams its ~1 GB underneath the encoder backward's matrix-core-bound
             # kernels instead of next to the HBM-bound first level of the following forward.
-            split_bwd = bool(persist) and os.environ.get("MASKPLANNER_SPLIT_BACKWARD", "1") != "0"
+            # Default: only under data parallelism, where the factor all-gather then overlaps the backward as well.  On one GPU the
+            # optimizer's ~1 GB costs the chain the same wherever it runs and the extra graph boundary costs ~60 us ([r2] 2.83 vs 2.76 ms).
+            split_bwd = bool(persist) and os.environ.get("MASKPLANNER_SPLIT_BACKWARD", "1" if dp.exchanging() else "0") != "0"
             gb2 = torch.cuda.CUDAGraph() if split_bwd else None
             with torch.cuda.graph(gb, pool=ga.pool(), stream=cap):
                 if split_bwd:

@@ -433,6 +433,20 @@ def knn(p1, p2, lengths1=None, lengths2=None, K=1):
     return _Knn.apply(_f32(p1), _f32(p2), l1, l2, int(K))
 
 
+_REDUCE_COUNTERS = {}
+
+
+def _reduce_counter(device):
+    """The zero-on-entry / zero-on-exit device counter of the one-launch reductions: one per device (the loss terms of a step run on
+    one stream, one after the other; created by the first eager call, i.e. before any graph capture)."""
+    key = device
+    t = _REDUCE_COUNTERS.get(key)
+    if t is None:
+        t = torch.zeros((1,), dtype=torch.int32, device=device)
+        _REDUCE_COUNTERS[key] = t
+    return t
+
+
 class _ChamferTerm(torch.autograd.Function):
     """One reduced, one-directional chamfer term (pytorch3d_chamfer.py:257-334 with asymmetric / reverse_asymmetric): nearest
     neighbour of every row of p1 in p2 (K = 1), sum or mean over the rows, sum or mean over the batch, times `scale`, plus the
@@ -451,8 +465,12 @@ class _ChamferTerm(torch.autograd.Function):
         _run("knn", p1, lib.mp_knn_f32, _p(p1), _p(p2), _p(len1), _p(len2), B, P1, P2, D, 1, _p(dists), _p(idx), _p(ws), nws)
         out = torch.empty((B,) if batch_mode == 0 else (), dtype=torch.float32, device=p1.device)
         scratch = torch.empty((B,), dtype=torch.float32, device=p1.device) if batch_mode != 0 else None
-        _run("chamfer_reduce", dists, lib.mp_chamfer_reduce_f32, _p(dists), _p(len1), B, P1, int(point_mean), int(batch_mode),
-             float(div), float(scale), _p(scratch), _p(out), _p(add))
+        if batch_mode != 0:
+            _run("chamfer_reduce", dists, lib.mp_chamfer_reduce1_f32, _p(dists), _p(len1), B, P1, int(point_mean), int(batch_mode),
+                 float(div), float(scale), _p(scratch), _p(out), _p(add), _p(_reduce_counter(p1.device)))
+        else:
+            _run("chamfer_reduce", dists, lib.mp_chamfer_reduce_f32, _p(dists), _p(len1), B, P1, int(point_mean), int(batch_mode),
+                 float(div), float(scale), _p(scratch), _p(out), _p(add))
         ctx.save_for_backward(p1, p2, len1, len2, idx)
         ctx.meta = (int(point_mean), int(batch_mode), float(div), float(scale))
         ctx.mark_non_differentiable(dists, idx)

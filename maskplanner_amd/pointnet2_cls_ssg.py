@@ -12,7 +12,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import ops
+from . import ops, sa_mlp
 from .factor_heads import factor_linear
 from .pointnet2_utils import PointNetSetAbstraction, PointNetSetAbstractionMsg
 
@@ -40,6 +40,10 @@ class _SSGEncoder(nn.Module):
         if self.normal_channel:
             norm = xyz[:, 3:, :]
             xyz = xyz[:, :3, :]
+        if xyz.is_cuda and all(isinstance(m, PointNetSetAbstraction) for m in (self.sa1, self.sa2, self.sa3)):
+            # the three first-layer weights into the fused MLP's column order with one launch (and one for their gradients)
+            sa_mlp.prepermute([(self.sa1.mlp_convs[0], "feats_first" if norm is not None else "xyz_first"),
+                               (self.sa2.mlp_convs[0], "feats_first"), (self.sa3.mlp_convs[0], "feats_first")])
         l1_xyz, l1_points = self.sa1(xyz, norm)
         l2_xyz, l2_points = self.sa2(l1_xyz, l1_points)
         _, l3_points = self.sa3(l2_xyz, l2_points)

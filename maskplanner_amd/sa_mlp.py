@@ -141,7 +141,69 @@ class _PermuteCols(torch.autograd.Function):
         return out, None, None
 
 
+class _PermuteColsMulti(torch.autograd.Function):
+    """_PermuteCols for several weights at once: one launch forward, one launch for all the gradients in backward.
+    args: n, then per weight (src, perm, inv)."""
+
+    @staticmethod
+    def forward(ctx, n, *args):
+        srcs, perms, invs = args[0::3], args[1::3], args[2::3]
+        dsts = [torch.empty((s_.shape[0], p_.numel()), dtype=torch.float32, device=s_.device) for s_, p_ in zip(srcs, perms)]
+        _permute_multi(srcs, perms, [s_.shape[1] for s_ in srcs], dsts)
+        ctx.save_for_backward(*perms, *invs)
+        ctx.n = n
+        return tuple(dsts)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        n = ctx.n
+        perms, invs = ctx.saved_tensors[:n], ctx.saved_tensors[n:]
+        live = [k for k in range(n) if grads[k] is not None]
+        outs = [None] * n
+        if live:
+            gs = [grads[k].contiguous() for k in live]
+            ds = [torch.empty((gs[i].shape[0], invs[k].numel()), dtype=torch.float32, device=gs[i].device) for i, k in enumerate(live)]
+            _permute_multi(gs, [invs[k] for k in live], [perms[k].numel() for k in live], ds)
+            for i, k in enumerate(live):
+                outs[k] = ds[i]
+        ret = [None]
+        for k in range(n):
+            ret += [outs[k], None, None]
+        return tuple(ret)
+
+
+def _permute_multi(srcs, perms, cs, dsts):
+    n = len(srcs)
+    vp, i64 = ctypes.c_void_p * n, ctypes.c_int64 * n
+    ops._run("permute_cols", srcs[0], _lib.load().mp_permute_cols_multi_f32, n, vp(*[t.data_ptr() for t in srcs]), vp(*[t.data_ptr() for t in perms]),
+             i64(*[t.shape[0] for t in srcs]), i64(*cs), i64(*[p_.numel() for p_ in perms]), vp(*[t.data_ptr() for t in dsts]))
+
+
 _PERMS = {}
+_PREPERMUTED = {}     # id(first conv of a level) -> its weight in the internal column order, produced by prepermute() for the next forward
+
+
+def prepermute(levels):
+    """levels: [(first conv of a set-abstraction level, layout)] of every level the coming forward will run.  The first-layer weights of
+    all of them are brought into the internal column order with ONE launch (and their gradients back with one at the end of backward);
+    shared_mlp_max picks the result up instead of permuting its own."""
+    todo = []
+    for conv, layout in levels:
+        cin = conv.in_channels
+        cpad = (cin + 3) // 4 * 4
+        rotate = layout == "feats_first" and cin > 3
+        if (rotate or cpad != cin) and conv.weight.is_cuda:
+            todo.append((conv, cin, cpad, rotate))
+    _PREPERMUTED.clear()
+    if len(todo) < 2:
+        return
+    args = []
+    for conv, cin, cpad, rotate in todo:
+        w = conv.weight.view(conv.out_channels, conv.in_channels)
+        args += [w, *_first_weight_perm(cin, cpad, rotate, w.device)]
+    outs = _PermuteColsMulti.apply(len(todo), *args)
+    for (conv, *_), o in zip(todo, outs):
+        _PREPERMUTED[id(conv)] = (o, conv.weight._version)
 
 
 def _first_weight_perm(cin, cpad, rotate, device):
@@ -199,7 +261,10 @@ def shared_mlp_max(grouped, convs, bns, layout="xyz_first", dtype="f32", sync_bn
         if i == 0:
             rotate = layout == "feats_first" and cin > 3
             if rotate or cpad != cin:   # one launch (and one in backward) instead of cat + pad and their autograd
-                w = _PermuteCols.apply(w, *_first_weight_perm(cin, cpad, rotate, w.device))
+                pre = _PREPERMUTED.pop(id(conv), None)      # (all levels' first weights permuted together: prepermute())
+                if pre is not None and (pre[1] != conv.weight._version or pre[0].shape != (conv.out_channels, cpad)):
+                    pre = None                              # left over from a forward that never reached this level
+                w = pre[0] if pre is not None else _PermuteCols.apply(w, *_first_weight_perm(cin, cpad, rotate, w.device))
         track = bn.track_running_stats and bn.running_mean is not None
         if not training and not track:
             raise NotImplementedError("eval-mode BatchNorm without running statistics")
