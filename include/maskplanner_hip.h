@@ -303,6 +303,17 @@ size_t mp_sa_mlp_workspace_bytes(int64_t P, int64_t K, int n_layers, const int64
  * element.  channels[n_layers + 1] as for the workspace query.  (Reference: the first Conv2d of sa1, pointnet2_utils.py:208-213;
  * the reference stores every activation for autograd.) */
 int mp_sa_mlp_recompute_first(int n_layers, const int64_t* channels, int64_t K);
+/* The grouped input of a level that is NOT materialised: row p = (b, s, k) of x0 is [feats[b, idx[p], 0:CF] | xyz[b, idx[p]] - new_xyz[b, s] | 0]
+ * (models/pointnet2_utils.py:133-143 fused into the consumers).  mp_sa_mlp_gather_supported tells whether a chain qualifies (BASELINE's second
+ * level: CF = 128, first layer 132 -> 128); the gather forms take this descriptor instead of x0, everything else as in the plain calls
+ * (grad_x0 [P, 132] with grad_x0_cols = 128 is still written: the caller scatters it with mp_group_bwd_f32). */
+typedef struct {
+    const float* feats;    /* [B, N, CF] */
+    const float* xyz;      /* [B, N, 3] */
+    const float* new_xyz;  /* [B, S, 3] */
+    const int64_t* idx;    /* [B, S, K] */
+    int64_t N, S, CF;
+} mp_gather_t;
 int mp_sa_mlp_fwd_f32(const float* x0, int64_t P, int64_t K, int n_layers, const mp_mlp_layer_t* layers, int training,
                       double momentum, double eps, float* out, int32_t* argk, float* zmax, void* workspace,
                       size_t workspace_bytes, mp_stream_t stream);
@@ -310,6 +321,14 @@ int mp_sa_mlp_bwd_f32(const float* x0, int64_t P, int64_t K, int n_layers, const
                       const float* grad_out, const float* out, const int32_t* argk, const float* zmax,
                       const mp_mlp_grads_t* grads, float* grad_x0, int64_t grad_x0_cols, void* workspace,
                       size_t workspace_bytes, mp_stream_t stream);
+int mp_sa_mlp_gather_supported(int n_layers, const int64_t* channels, int64_t K, int64_t CF);
+int mp_sa_mlp_fwd_gather_f32(const mp_gather_t* gather, int64_t P, int64_t K, int n_layers, const mp_mlp_layer_t* layers,
+                             int training, double momentum, double eps, float* out, int32_t* argk, float* zmax,
+                             void* workspace, size_t workspace_bytes, mp_stream_t stream);
+int mp_sa_mlp_bwd_gather_f32(const mp_gather_t* gather, int64_t P, int64_t K, int n_layers, const mp_mlp_layer_t* layers,
+                             int training, const float* grad_out, const float* out, const int32_t* argk,
+                             const float* zmax, const mp_mlp_grads_t* grads, float* grad_x0, int64_t grad_x0_cols,
+                             void* workspace, size_t workspace_bytes, mp_stream_t stream);
 /* The same two calls with every contraction on the bf16 matrix cores (BASELINE configs[4]: containers, N = 10240, MSG
  * encoder, "bf16 MFMA grouped-MLP"): both operands of each GEMM -- act(Z_{l-1}) and W_l forward; dZ_l, W_l and
  * act(Z_{l-1}) backward -- are rounded to bf16 (round-to-nearest-even) as they are staged, v_mfma_f32_32x32x16_bf16

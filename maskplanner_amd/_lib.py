@@ -42,6 +42,11 @@ class MlpGrads(ctypes.Structure):
 ALLREDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p)
 
 
+class Gather(ctypes.Structure):
+    """mp_gather_t"""
+    _fields_ = [("feats", _vp), ("xyz", _vp), ("new_xyz", _vp), ("idx", _vp), ("N", _i64), ("S", _i64), ("CF", _i64)]
+
+
 class SyncBN(ctypes.Structure):
     """mp_syncbn_t"""
     _fields_ = [("allreduce", ALLREDUCE_FN), ("user", _vp), ("world", _i64), ("exchange", _vp)]
@@ -97,6 +102,11 @@ SIGNATURES = {
     "mp_colsum_multi_f32": (_int, [_i64, _vp, _vp, ctypes.POINTER(_i64), _i64, _vp]),
     "mp_pad_ragged_f32": (_int, [_vp, _vp, _i64, _i64, _i64, ctypes.c_float, _vp, _vp]),
     "mp_lambda_segments_f32": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp]),
+    "mp_sa_mlp_gather_supported": (_int, [_int, _vp, _i64, _i64]),
+    "mp_sa_mlp_fwd_gather_f32": (_int, [ctypes.POINTER(Gather), _i64, _i64, _int, ctypes.POINTER(MlpLayer), _int, _dbl, _dbl, _vp, _vp, _vp, _vp,
+                                        _sz, _vp]),
+    "mp_sa_mlp_bwd_gather_f32": (_int, [ctypes.POINTER(Gather), _i64, _i64, _int, ctypes.POINTER(MlpLayer), _int, _vp, _vp, _vp, _vp,
+                                        ctypes.POINTER(MlpGrads), _vp, _i64, _vp, _sz, _vp]),
     "mp_sa_mlp_fwd_f32": (_int, [_vp, _i64, _i64, _int, ctypes.POINTER(MlpLayer), _int, _dbl, _dbl, _vp, _vp, _vp, _vp,
                                  _sz, _vp]),
     "mp_sa_mlp_bwd_f32": (_int, [_vp, _i64, _i64, _int, ctypes.POINTER(MlpLayer), _int, _vp, _vp, _vp, _vp,

@@ -36,7 +36,11 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 #endif
 constexpr int THREADS = 256;
 
-enum SrcMode { SRC_ID = 0, SRC_ACT = 1, SRC_DZ = 2, SRC_DZ_POOLED = 3, SRC_ACT_RC = 4, SRC_DZ_RC = 5 };
+enum SrcMode { SRC_ID = 0, SRC_ACT = 1, SRC_DZ = 2, SRC_DZ_POOLED = 3, SRC_ACT_RC = 4, SRC_DZ_RC = 5, SRC_ID_G = 6 };
+// SRC_ID_G ("gathered"): the level's grouped input rows [features | centred xyz | pad] are not in memory -- row p = (b, s, k) is read
+// where it lives: features of point idx[p] of the previous level ([B, N, CF], 512-byte rows of an L2-resident table), coordinates as
+// xyz[idx[p]] - new_xyz[b, s].  Saves the grouping kernel's write of [P, CF + 4] floats and both later reads of it.
+constexpr bool is_id(int m) { return m == SRC_ID || m == SRC_ID_G; }
 // *_RC ("recompute"): the raw Z of this operand is not in memory -- it is the first layer of a level with a 4-channel input
 // (xyz + pad), z[p][c] = X0[p][0:4] . W0[c][0:4], four FMAs per element: cheaper to recompute from the 16-byte input row than
 // to write [P, C] floats once and read them back three times (next layer forward, next layer backward, its own dW).
@@ -61,6 +65,12 @@ struct PosOperand {
     int kshift;          // log2(K) when K is a power of two (every sampled level), else -1: position -> (group, member) by shift / mask
     const float* rx;     // *_RC: the level's input rows X0 [P, 4]
     const float* rw;     // *_RC: the first layer's weight W0 [C, 4]
+    const float* gf;     // SRC_ID_G: features of the previous level [B, gN, gCF]
+    const float* gxyz;   // SRC_ID_G: its coordinates [B, gN, 3]
+    const float* gnew;   // SRC_ID_G: this level's centroids [B, gS, 3]
+    const int64_t* gidx; // SRC_ID_G: ball-query result [B, gS, K] (flat: [P])
+    int gN, gS, gCF;
+    int gshift;          // log2(gS * K) when a power of two, else -1
 };
 
 // Per-channel constants of 4 consecutive channels, loaded ONCE per thread and tile (not per element).
@@ -76,7 +86,7 @@ template <int MODE>
 __device__ __forceinline__ void load_consts(const PosOperand& o, int c, ChanConst& k)
 {
     const int cc = c < o.C ? c : 0;  // clamped: out-of-range channels are zeroed by the `ok` flag of their data
-    if constexpr (MODE != SRC_ID) {
+    if constexpr (!is_id(MODE)) {
         k.s = ld4(o.s + cc);
         k.t = ld4(o.t + cc);
     }
@@ -103,12 +113,33 @@ struct Raw4 {
     bool ok;
 };
 
+// SRC_ID_G: the source row b * N + idx[p] of position p (one int64 load).  Kernels fetch it ONE CHUNK AHEAD of the row itself, so that
+// the dependent feature load does not wait for it.
+__device__ __forceinline__ unsigned gather_row(const PosOperand& o, int P, int p)
+{
+    const int pp = p < P ? p : 0;
+    const unsigned per = (unsigned)o.gS * (unsigned)o.K;
+    const unsigned b = o.gshift >= 0 ? (unsigned)pp >> o.gshift : (unsigned)pp / per;
+    return b * (unsigned)o.gN + (unsigned)o.gidx[pp];
+}
+
 template <int MODE>
-__device__ __forceinline__ void raw_load(const PosOperand& o, int P, int p, int c, Raw4<MODE>& r)
+__device__ __forceinline__ void raw_load(const PosOperand& o, int P, int p, int c, Raw4<MODE>& r, unsigned gsrc = 0xffffffffu)
 {
     r.ok = (p < P) && (c < o.C);
     const int pp = r.ok ? p : 0, cc = r.ok ? c : 0;
     if constexpr (is_rc(MODE)) r.z = ld4(o.rx + (size_t)pp * 4);   // the input row; raw_z() turns it into 4 channels of z
+    else if constexpr (MODE == SRC_ID_G) {
+        const size_t src = gsrc != 0xffffffffu ? (size_t)gsrc : (size_t)gather_row(o, P, p);
+        if (cc < o.gCF) {
+            r.z = ld4(o.gf + src * (unsigned)o.gCF + (unsigned)cc);
+        } else {                    // the coordinate quad: xyz[idx] - new_xyz[group], 0
+            const unsigned grp = o.kshift >= 0 ? (unsigned)pp >> o.kshift : (unsigned)pp / (unsigned)o.K;
+            const float* a = o.gxyz + src * 3;
+            const float* c = o.gnew + (size_t)grp * 3;
+            r.z = make_float4(a[0] - c[0], a[1] - c[1], a[2] - c[2], 0.0f);
+        }
+    }
     else r.z = ld4(o.x + (size_t)((unsigned)pp * (unsigned)o.C + (unsigned)cc));
     if constexpr (MODE == SRC_DZ || MODE == SRC_DZ_RC) {
         r.g = ld4(o.g + (size_t)((unsigned)pp * (unsigned)o.C + (unsigned)cc));
@@ -125,7 +156,7 @@ __device__ __forceinline__ void raw_load(const PosOperand& o, int P, int p, int 
 template <int MODE>
 __device__ __forceinline__ float xf1(float z, float g, float s, float t, float a, float e, float f)
 {
-    if constexpr (MODE == SRC_ID) {
+    if constexpr (is_id(MODE)) {
         return z;
     } else if constexpr (MODE == SRC_ACT || MODE == SRC_ACT_RC) {
         const float y = z * s + t;
@@ -890,10 +921,21 @@ __global__ __launch_bounds__(CO > 128 ? 512 : 256) void fwd_chunk_kernel(PosOper
     load_consts<MODE_A>(A, ca, kc);
     Raw4<MODE_A> ra[PA];
     Raw4<MODE_A> rt;
+    unsigned gs[PA], gst = 0xffffffffu;        // SRC_ID_G: source rows of the chunk that is loaded NEXT (fetched a chunk earlier)
+#pragma unroll
+    for (int ps = 0; ps < PA; ++ps) gs[ps] = 0xffffffffu;
+    auto gidx = [&](int pk) {
+        if constexpr (MODE_A == SRC_ID_G) {
+#pragma unroll
+            for (int ps = 0; ps < PA; ++ps) gs[ps] = gather_row(A, p1, pk + ka0 + ps * KA_STEP);
+            if (TAIL != 0 && tid < DBK) gst = gather_row(A, p1, pk + tid);
+        }
+    };
     auto gload = [&](int pk) {
 #pragma unroll
-        for (int ps = 0; ps < PA; ++ps) raw_load<MODE_A>(A, p1, pk + ka0 + ps * KA_STEP, ca, ra[ps]);
-        if constexpr (TAIL != 0) { if (tid < DBK) raw_load<MODE_A>(A, p1, pk + tid, CI, rt); }
+        for (int ps = 0; ps < PA; ++ps) raw_load<MODE_A>(A, p1, pk + ka0 + ps * KA_STEP, ca, ra[ps], gs[ps]);
+        if constexpr (TAIL != 0) { if (tid < DBK) raw_load<MODE_A>(A, p1, pk + tid, CI, rt, gst); }
+        gidx(pk + DBK);
     };
     auto sstore = [&](int buf) {
 #pragma unroll
@@ -929,6 +971,7 @@ __global__ __launch_bounds__(CO > 128 ? 512 : 256) void fwd_chunk_kernel(PosOper
     if constexpr (POOL) neg = gamma[col] < 0.0f;
     const unsigned smask = neg ? 0x80000000u : 0u;
 
+    gidx(p0);
     gload(p0);
     sstore(0);
     __syncthreads();
@@ -1416,7 +1459,7 @@ __global__ __launch_bounds__(256) void rc_stats_kernel(const float* __restrict__
 // Kernel 4b: the same single pass for the FIRST layer of a level whose grouped input is [128 features | xyz | pad] (132
 // columns): dW [128 x 132] (128 columns by MFMA, the 4 coordinate columns by plain FMAs on the staged tiles) and the
 // feature part of grad_x0 (128 columns; coordinates carry no gradient), no BatchNorm sums (there is no layer below).
-template <int MODE_DZ, bool SPLIT = false>
+template <int MODE_DZ, bool SPLIT = false, int MODE_IN = SRC_ID>
 __global__ __launch_bounds__(512) void bwd_first_kernel(PosOperand DZ, PosOperand IN, int P, int p_per_block,
                                                            const float* __restrict__ W, float* __restrict__ dW,
                                                            float* __restrict__ G)
@@ -1480,7 +1523,7 @@ __global__ __launch_bounds__(512) void bwd_first_kernel(PosOperand DZ, PosOperan
     ChanConst ka, kb;
     load_consts<MODE_DZ>(DZ, ca, ka);
     Raw4<MODE_DZ> ra[PA];
-    Raw4<SRC_ID> rb[PB];
+    Raw4<MODE_IN> rb[PB];
     int brow[PB], bcol[PB];                              // this thread's (row, column) of the input chunk, per pass
 #pragma unroll
     for (int ps = 0; ps < PB; ++ps) {
@@ -1492,12 +1535,23 @@ __global__ __launch_bounds__(512) void bwd_first_kernel(PosOperand DZ, PosOperan
         brow[0] = ka0; bcol[0] = ca;
         brow[1] = tid & 15; bcol[1] = CIX;
     }
+    unsigned gs[PB];                           // SRC_ID_G: source rows of the chunk that is loaded next (fetched a chunk earlier)
+#pragma unroll
+    for (int ps = 0; ps < PB; ++ps) gs[ps] = 0xffffffffu;
+    auto gidx = [&](int pk) {
+        if constexpr (MODE_IN == SRC_ID_G) {
+#pragma unroll
+            for (int ps = 0; ps < PB; ++ps)
+                if (SPLIT ? (ps == 0 || tid < DBK) : (ps * NT + tid < NB4)) gs[ps] = gather_row(IN, p1, pk + brow[ps]);
+        }
+    };
     auto gload = [&](int pk) {
 #pragma unroll
         for (int ps = 0; ps < PA; ++ps) raw_load<MODE_DZ>(DZ, p1, pk + ka0 + ps * KA_STEP, ca, ra[ps]);
 #pragma unroll
         for (int ps = 0; ps < PB; ++ps)
-            if (SPLIT ? (ps == 0 || tid < DBK) : (ps * NT + tid < NB4)) raw_load<SRC_ID>(IN, p1, pk + brow[ps], bcol[ps], rb[ps]);
+            if (SPLIT ? (ps == 0 || tid < DBK) : (ps * NT + tid < NB4)) raw_load<MODE_IN>(IN, p1, pk + brow[ps], bcol[ps], rb[ps], gs[ps]);
+        gidx(pk + DBK);
     };
     auto sstore = [&](int buf) {
 #pragma unroll
@@ -1513,21 +1567,22 @@ __global__ __launch_bounds__(512) void bwd_first_kernel(PosOperand DZ, PosOperan
             }
         }
         if constexpr (SPLIT) {
-            const Split4 sp = split3(finish<SRC_ID>(rb[0], kb));
+            const Split4 sp = split3(finish<MODE_IN>(rb[0], kb));
             const int o = (ca >> 3) * GS + ka0 * 8 + (ca & 7);
             *reinterpret_cast<bf16x4*>(&hB[buf][0][o]) = sp.h;
             *reinterpret_cast<bf16x4*>(&hB[buf][1][o]) = sp.m;
             *reinterpret_cast<bf16x4*>(&hB[buf][2][o]) = sp.l;
-            if (tid < DBK) sT[buf][tid] = finish<SRC_ID>(rb[1], kb);
+            if (tid < DBK) sT[buf][tid] = finish<MODE_IN>(rb[1], kb);
         } else {
 #pragma unroll
             for (int ps = 0; ps < PB; ++ps) {
                 const int e = ps * NT + tid;
-                if (e < NB4) *reinterpret_cast<float4*>(&sB[buf][e * 4]) = finish<SRC_ID>(rb[ps], kb);
+                if (e < NB4) *reinterpret_cast<float4*>(&sB[buf][e * 4]) = finish<MODE_IN>(rb[ps], kb);
             }
         }
     };
 
+    gidx(p0);
     gload(p0);
     sstore(0);
     __syncthreads();
@@ -2057,6 +2112,22 @@ extern "C" int mp_sa_mlp_recompute_first(int n_layers, const int64_t* channels, 
     return channels[0] == 4 && channels[1] == 64 && (channels[2] == 64 || channels[2] == 128) && K > 0;
 }
 
+// The gathered-input form (mp_sa_mlp_{fwd,bwd}_gather_f32) covers what BASELINE's second set-abstraction level is: a first layer of
+// [128 features | xyz | pad] -> 128 behind at least one more layer, fp32 results, fused kernels enabled.
+static bool gather_ok(const mp_gather_t* g, int64_t P, int64_t K, int n_layers, const mp_mlp_layer_t* layers, bool bf16)
+{
+    if (!g || !g->feats || !g->xyz || !g->new_xyz || !g->idx || g->N <= 0 || g->S <= 0) return false;
+    if (bf16 || n_layers < 2 || g->CF != 128 || layers[0].c_in != 132 || layers[0].c_out != 128) return false;
+    if (P % (g->S * K) != 0 || !chunk_fwd_enabled() || !fused_bwd_enabled()) return false;
+    return true;
+}
+static void set_gather(PosOperand& o, const mp_gather_t* g, int64_t K)
+{
+    o.gf = g->feats; o.gxyz = g->xyz; o.gnew = g->new_xyz; o.gidx = g->idx;
+    o.gN = (int)g->N; o.gS = (int)g->S; o.gCF = (int)g->CF;
+    o.gshift = log2_or_neg(g->S * K);
+}
+
 #define MP_POS_GEMM(MODE, KROW, EPI, ...)                                                                          \
     (bf16 ? launch_pos_gemm<MODE, KROW, EPI, 1>(__VA_ARGS__)                                                      \
           : (split_enabled() ? launch_pos_gemm<MODE, KROW, EPI, 3>(__VA_ARGS__) : launch_pos_gemm<MODE, KROW, EPI, 0>(__VA_ARGS__)))
@@ -2068,13 +2139,15 @@ extern "C" int mp_sa_mlp_recompute_first(int n_layers, const int64_t* channels, 
 // (the generic tiled kernels; the fp32 position-stream / recompute specialisations are not used), everything else as in fp32.
 static int sa_mlp_fwd(const float* x0, int64_t P, int64_t K, int n_layers, const mp_mlp_layer_t* layers,
                       int training, double momentum, double eps, float* out, int32_t* argk, float* zmax,
-                      void* workspace, size_t workspace_bytes, mp_stream_t stream_, bool bf16, const mp_syncbn_t* sync)
+                      void* workspace, size_t workspace_bytes, mp_stream_t stream_, bool bf16, const mp_syncbn_t* sync,
+                      const mp_gather_t* gather = nullptr)
 {
     if (sync && (!sync->allreduce || !sync->exchange || sync->world < 1)) return MP_EINVAL;
     if (!training) sync = nullptr;      // running statistics: nothing to exchange
     if (P < 0 || K <= 0 || n_layers <= 0 || !layers) return MP_EINVAL;
     if (P == 0) return MP_OK;
-    if (!x0 || !out || !argk || !zmax || !workspace || (P % K) != 0) return MP_EINVAL;
+    if ((!x0 && !gather) || !out || !argk || !zmax || !workspace || (P % K) != 0) return MP_EINVAL;
+    if (gather && !gather_ok(gather, P, K, n_layers, layers, bf16)) return MP_EUNSUPPORTED;
     if (n_layers > 8 || P > ((int64_t)1 << 31)) return MP_EUNSUPPORTED;
     int64_t ch[9];
     ch[0] = layers[0].c_in;
@@ -2115,6 +2188,7 @@ static int sa_mlp_fwd(const float* x0, int64_t P, int64_t K, int n_layers, const
     A.C = (int)ch[0];
     A.K = (int)K;
     A.kshift = log2_or_neg(K);
+    if (gather) set_gather(A, gather, K);
     for (int l = 0; l < n_layers; ++l) {
         const mp_mlp_layer_t& L = layers[l];
         int nblk = 0, rc = MP_OK;
@@ -2134,7 +2208,13 @@ static int sa_mlp_fwd(const float* x0, int64_t P, int64_t K, int n_layers, const
             while ((P + ppb - 1) / ppb < 512 && ppb > 128) ppb >>= 1;
             const unsigned gx = (unsigned)((P + ppb - 1) / ppb);
             const double fl = 2.0 * (double)P * Co_ * Ci_, by = 4.0 * ((double)P * (Ci_ + Co_) + (double)Co_ * Ci_);
-            if (split_enabled())
+            if (gather && split_enabled())
+                MP_LAUNCH("fwd_chunk_kernel<128, 128, false, gathered, 4, split>", fl, by - 4.0 * (double)P * Ci_, (fwd_chunk_kernel<128, 128, false, SRC_ID_G, 4, true>), dim3(gx),
+                          dim3(256), 0, stream, A, (int)P, ppb, L.weight, L.z, partials, po, L.gamma);
+            else if (gather)
+                MP_LAUNCH("fwd_chunk_kernel<128, 128, false, gathered, 4>", fl, by - 4.0 * (double)P * Ci_, (fwd_chunk_kernel<128, 128, false, SRC_ID_G, 4>), dim3(gx), dim3(256), 0,
+                          stream, A, (int)P, ppb, L.weight, L.z, partials, po, L.gamma);
+            else if (split_enabled())
                 MP_LAUNCH("fwd_chunk_kernel<128, 128, false, 0, 4, split>", fl, by, (fwd_chunk_kernel<128, 128, false, SRC_ID, 4, true>), dim3(gx), dim3(256), 0, stream, A,
                           (int)P, ppb, L.weight, L.z, partials, po, L.gamma);
             else
@@ -2244,6 +2324,21 @@ extern "C" int mp_sa_mlp_fwd_f32(const float* x0, int64_t P, int64_t K, int n_la
     return sa_mlp_fwd(x0, P, K, n_layers, layers, training, momentum, eps, out, argk, zmax, workspace, workspace_bytes, stream, false, nullptr);
 }
 
+extern "C" int mp_sa_mlp_gather_supported(int n_layers, const int64_t* channels, int64_t K, int64_t CF)
+{
+    if (n_layers < 2 || !channels || K <= 0) return 0;
+    return (CF == 128 && channels[0] == 132 && channels[1] == 128 && chunk_fwd_enabled() && fused_bwd_enabled()) ? 1 : 0;
+}
+
+extern "C" int mp_sa_mlp_fwd_gather_f32(const mp_gather_t* gather, int64_t P, int64_t K, int n_layers, const mp_mlp_layer_t* layers,
+                                        int training, double momentum, double eps, float* out, int32_t* argk, float* zmax,
+                                        void* workspace, size_t workspace_bytes, mp_stream_t stream)
+{
+    if (!gather) return MP_EINVAL;
+    return sa_mlp_fwd(nullptr, P, K, n_layers, layers, training, momentum, eps, out, argk, zmax, workspace, workspace_bytes, stream, false, nullptr,
+                      gather);
+}
+
 extern "C" int mp_sa_mlp_fwd_bf16(const float* x0, int64_t P, int64_t K, int n_layers, const mp_mlp_layer_t* layers,
                                   int training, double momentum, double eps, float* out, int32_t* argk, float* zmax,
                                   void* workspace, size_t workspace_bytes, mp_stream_t stream)
@@ -2261,13 +2356,15 @@ extern "C" int mp_sa_mlp_fwd_ex(const float* x0, int64_t P, int64_t K, int n_lay
 static int sa_mlp_bwd(const float* x0, int64_t P, int64_t K, int n_layers, const mp_mlp_layer_t* layers,
                       int training, const float* grad_out, const float* out, const int32_t* argk,
                       const float* zmax, const mp_mlp_grads_t* grads, float* grad_x0, int64_t grad_x0_cols,
-                      void* workspace, size_t workspace_bytes, mp_stream_t stream_, bool bf16, const mp_syncbn_t* sync)
+                      void* workspace, size_t workspace_bytes, mp_stream_t stream_, bool bf16, const mp_syncbn_t* sync,
+                      const mp_gather_t* gather = nullptr)
 {
     if (sync && (!sync->allreduce || !sync->exchange || sync->world < 1)) return MP_EINVAL;
     if (!training) sync = nullptr;
     if (P < 0 || K <= 0 || n_layers <= 0 || !layers || !grads) return MP_EINVAL;
     if (P == 0) return MP_OK;
-    if (!x0 || !grad_out || !out || !argk || !zmax || !workspace || (P % K) != 0) return MP_EINVAL;
+    if ((!x0 && !gather) || !grad_out || !out || !argk || !zmax || !workspace || (P % K) != 0) return MP_EINVAL;
+    if (gather && (!gather_ok(gather, P, K, n_layers, layers, bf16) || !grad_x0 || grad_x0_cols != 128)) return MP_EUNSUPPORTED;
     if (n_layers > 8) return MP_EUNSUPPORTED;
     int64_t ch[9];
     ch[0] = layers[0].c_in;
@@ -2362,7 +2459,8 @@ static int sa_mlp_bwd(const float* x0, int64_t P, int64_t K, int n_layers, const
         IN.C = Ci;
         IN.K = (int)K;
         IN.kshift = log2_or_neg(K);
-        if (l == 0) { IN.x = x0; } else { IN.x = layers[l - 1].z; IN.s = layers[l - 1].scale; IN.t = layers[l - 1].shift; }
+        if (l == 0) { IN.x = x0; if (gather) set_gather(IN, gather, K); }
+        else { IN.x = layers[l - 1].z; IN.s = layers[l - 1].scale; IN.t = layers[l - 1].shift; }
         if (rc_first && l == 1) { IN.rx = x0; IN.rw = layers[0].weight; }   // act(Z_0) and raw Z_0 from the input rows
         if (rc_first && l == 0) { DZ.rx = x0; DZ.rw = Ly.weight; }          // dZ_0 = f(Z_0, G_0) likewise
 
@@ -2425,7 +2523,15 @@ static int sa_mlp_bwd(const float* x0, int64_t P, int64_t K, int n_layers, const
             const int ppb = 1024;
             const unsigned gx = (unsigned)((P + ppb - 1) / ppb);
             const double fl = 2.0 * (double)P * Co * (Ci + 128), by = 4.0 * ((pooled ? 1.0 : 2.0) * (double)P * Co + (double)P * (Ci + 128));
-            if (pooled && split_enabled())
+            if (gather && split_enabled() && !pooled)
+                MP_LAUNCH("bwd_first_kernel<2, gathered>", fl, by - 4.0 * (double)P * Ci, (bwd_first_kernel<SRC_DZ, true, SRC_ID_G>), dim3(gx), dim3(512), 0, stream, DZ, IN,
+                          (int)P, ppb, Ly.weight, grads[l].d_weight, grad_x0);
+            else if (gather && !pooled)
+                MP_LAUNCH("bwd_first_kernel<2, gathered>", fl, by - 4.0 * (double)P * Ci, (bwd_first_kernel<SRC_DZ, false, SRC_ID_G>), dim3(gx), dim3(512), 0, stream, DZ, IN,
+                          (int)P, ppb, Ly.weight, grads[l].d_weight, grad_x0);
+            else if (gather)
+                return MP_EUNSUPPORTED;
+            else if (pooled && split_enabled())
                 MP_LAUNCH("bwd_first_kernel<3>", fl, by, (bwd_first_kernel<SRC_DZ_POOLED, true>), dim3(gx), dim3(512), 0, stream, DZ, IN, (int)P, ppb,
                           Ly.weight, grads[l].d_weight, grad_x0);
             else if (pooled)
@@ -2495,6 +2601,16 @@ extern "C" int mp_sa_mlp_bwd_f32(const float* x0, int64_t P, int64_t K, int n_la
 {
     return sa_mlp_bwd(x0, P, K, n_layers, layers, training, grad_out, out, argk, zmax, grads, grad_x0, grad_x0_cols, workspace,
                       workspace_bytes, stream, false, nullptr);
+}
+
+extern "C" int mp_sa_mlp_bwd_gather_f32(const mp_gather_t* gather, int64_t P, int64_t K, int n_layers, const mp_mlp_layer_t* layers,
+                                        int training, const float* grad_out, const float* out, const int32_t* argk,
+                                        const float* zmax, const mp_mlp_grads_t* grads, float* grad_x0, int64_t grad_x0_cols,
+                                        void* workspace, size_t workspace_bytes, mp_stream_t stream)
+{
+    if (!gather) return MP_EINVAL;
+    return sa_mlp_bwd(nullptr, P, K, n_layers, layers, training, grad_out, out, argk, zmax, grads, grad_x0, grad_x0_cols, workspace,
+                      workspace_bytes, stream, false, nullptr, gather);
 }
 
 extern "C" int mp_sa_mlp_bwd_bf16(const float* x0, int64_t P, int64_t K, int n_layers, const mp_mlp_layer_t* layers,

@@ -15,6 +15,7 @@ Differences that are NOT visible in results:
     channel axis; BatchNorm2d statistics == statistics over all rows).
 """
 import contextlib
+import os
 
 import torch
 import torch.nn as nn
@@ -138,6 +139,18 @@ def query_ball_point(radius, nsample, xyz, new_xyz):
     return ops.ball_query(radius, nsample, xyz, new_xyz)
 
 
+def sample_indices(npoint, radius, nsample, xyz):
+    """The sampling half of sample_and_group: (new_xyz [B,npoint,3], idx i64 [B,npoint,nsample]) from a supplied plan or FPS + ball query."""
+    B, N, _ = xyz.shape
+    plan = _take_prefetched(xyz, npoint, radius, nsample) if _prefetched else None
+    if plan is not None:
+        _, new_xyz, idx = plan
+    else:
+        _, new_xyz = ops.fps(xyz, npoint, _draw_fps_start(B, N, xyz.device), return_xyz=True)
+        idx = ops.ball_query(radius, nsample, xyz, new_xyz)
+    return new_xyz, idx
+
+
 def sample_and_group(npoint, radius, nsample, xyz, points, returnfps=False, full_points=None, _pad_to=1,
                      _xyz_last=False):
     """FPS -> ball query -> gather/centre/concat (:112-148).  xyz [B,N,3], points [B,N,D] or None.
@@ -215,6 +228,14 @@ class PointNetSetAbstraction(nn.Module):
                 pad = (-(C + points.shape[2])) % 4
                 parts = [points, xyz] + ([_zeros((B, N, pad), xyz.device)] if pad else [])
                 grouped = torch.cat(parts, dim=-1).view(B, 1, N, -1)
+        elif (points is not None and full_points is None and os.environ.get("MP_GATHER_FUSED", "0") != "0"
+              and sa_mlp.gathered_supported(points, self.nsample, self.mlp_convs, self.mlp_bns, self.mlp_dtype, self.sync_bn)):
+            # MP_GATHER_FUSED=1: the grouped tensor is never written, the first layer's kernels gather the rows themselves
+            # (sa_mlp.shared_mlp_max_gathered).  [r2] measured: the grouping kernel's 65 us go, the two consumers take 30 + 44 us longer
+            # (dependent index -> row loads inside their chunk loops): no gain, so the switch is off.
+            new_xyz, idx = sample_indices(self.npoint, self.radius, self.nsample, xyz)
+            new_points = sa_mlp.shared_mlp_max_gathered(xyz, points, new_xyz, idx, self.mlp_convs, self.mlp_bns)
+            return new_xyz.permute(0, 2, 1), new_points.permute(0, 2, 1)
         else:
             new_xyz, grouped = sample_and_group(self.npoint, self.radius, self.nsample, xyz, points,
                                                 full_points=full_points, _pad_to=4, _xyz_last=True)

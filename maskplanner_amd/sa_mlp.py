@@ -120,6 +120,132 @@ class _SharedMLPMax(torch.autograd.Function):
         return (gx, None, None, None, None, None, None, None, None, *ret)
 
 
+class _SharedMLPMaxGathered(torch.autograd.Function):
+    """_SharedMLPMax on a grouped input that is never materialised (mp_sa_mlp_{fwd,bwd}_gather_f32): row (b, s, k) of the level's input
+    is read where it lives -- feats[b, idx[b,s,k]] and xyz[b, idx] - new_xyz[b, s] -- by the first layer's forward and backward
+    kernels.  args: feats [B,N,CF], xyz [B,N,3], new_xyz [B,S,3], idx [B,S,K] i64, training, momentum, eps, L, then the layers'
+    parameters as for _SharedMLPMax (first weight already in the internal column order).  Gradient w.r.t. feats (the library writes
+    grad_x0 [P, CF + 4]; the scatter back to the points is ops.group's backward kernel)."""
+
+    @staticmethod
+    def forward(ctx, feats, xyz, new_xyz, idx, training, momentum, eps, n_layers, *params):
+        dev = feats.device
+        B, N, CF = feats.shape
+        _, S, K = idx.shape
+        P = B * S * K
+        layers = (_lib.MlpLayer * n_layers)()
+        keep = []
+        chans = [CF + 4] + [params[6 * l].shape[0] for l in range(n_layers)]
+        lib = _lib.load()
+        for l in range(n_layers):
+            w, b, gam, bet, rm, rv = params[6 * l:6 * l + 6]
+            co, ci = w.shape
+            z = torch.empty((P, co), dtype=torch.float32, device=dev)
+            stats = torch.empty((4, co), dtype=torch.float32, device=dev)
+            keep.append((w, b, gam, bet, rm, rv, z, stats))
+            layers[l] = _lib.MlpLayer(_ptr(w), _ptr(b), _ptr(gam), _ptr(bet), _ptr(rm), _ptr(rv), ci, co, _ptr(z),
+                                      stats[0].data_ptr(), stats[1].data_ptr(), stats[2].data_ptr(), stats[3].data_ptr())
+        G = P // K
+        cl = chans[-1]
+        out = torch.empty((G, cl), dtype=torch.float32, device=dev)
+        argk = torch.empty((G, cl), dtype=torch.int32, device=dev)
+        zmax = torch.empty((G, cl), dtype=torch.float32, device=dev)
+        ch = (ctypes.c_int64 * len(chans))(*chans)
+        ws = torch.empty((lib.mp_sa_mlp_workspace_bytes(P, K, n_layers, ch, 0),), dtype=torch.uint8, device=dev)
+        g = _lib.Gather(_ptr(feats), _ptr(xyz), _ptr(new_xyz), _ptr(idx), N, S, CF)
+        ops._run("sa_mlp_fwd", feats, lib.mp_sa_mlp_fwd_gather_f32, ctypes.byref(g), P, K, n_layers, layers, int(training), float(momentum),
+                 float(eps), _ptr(out), _ptr(argk), _ptr(zmax), _ptr(ws), ws.numel())
+        ctx.meta = (P, K, bool(training), n_layers, chans, (B, N, S, CF))
+        ctx.keep = keep
+        ctx.save_for_backward(feats, xyz, new_xyz, idx, out, argk, zmax)
+        ctx.mark_non_differentiable(argk, zmax)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        feats, xyz, new_xyz, idx, out, argk, zmax = ctx.saved_tensors
+        P, K, training, n_layers, chans, (B, N, S, CF) = ctx.meta
+        dev = feats.device
+        grad_out = grad_out.contiguous().float()
+        layers = (_lib.MlpLayer * n_layers)()
+        grads = (_lib.MlpGrads * n_layers)()
+        ret = []
+        dw_all = torch.empty((sum(k[0].numel() for k in ctx.keep),), dtype=torch.float32, device=dev)
+        dw_off = 0
+        for l, (w, b, gam, bet, rm, rv, z, stats) in enumerate(ctx.keep):
+            co, ci = w.shape
+            layers[l] = _lib.MlpLayer(_ptr(w), _ptr(b), _ptr(gam), _ptr(bet), _ptr(rm), _ptr(rv), ci, co, _ptr(z),
+                                      stats[0].data_ptr(), stats[1].data_ptr(), stats[2].data_ptr(), stats[3].data_ptr())
+            dw = dw_all[dw_off:dw_off + w.numel()].view_as(w)
+            dw_off += w.numel()
+            db = None if b is None else torch.empty_like(b)
+            dg, dbe = torch.empty_like(gam), torch.empty_like(bet)
+            grads[l] = _lib.MlpGrads(_ptr(dw), _ptr(db), _ptr(dg), _ptr(dbe))
+            ret += [dw, db, dg, dbe, None, None]
+        stride = CF + 4
+        gx = torch.empty((P, stride), dtype=torch.float32, device=dev)
+        ch = (ctypes.c_int64 * len(chans))(*chans)
+        lib = _lib.load()
+        ws = torch.empty((lib.mp_sa_mlp_workspace_bytes(P, K, n_layers, ch, 1),), dtype=torch.uint8, device=dev)
+        g = _lib.Gather(_ptr(feats), _ptr(xyz), _ptr(new_xyz), _ptr(idx), N, S, CF)
+        ops._run("sa_mlp_bwd", feats, lib.mp_sa_mlp_bwd_gather_f32, ctypes.byref(g), P, K, n_layers, layers, int(training), _ptr(grad_out),
+                 _ptr(out), _ptr(argk), _ptr(zmax), grads, _ptr(gx), CF, _ptr(ws), ws.numel())
+        ctx.keep = None
+        gf = None
+        if ctx.needs_input_grad[0]:
+            gf = torch.empty((B, N, CF), dtype=torch.float32, device=dev)
+            ops._run("group_bwd", gx, lib.mp_group_bwd_f32, _ptr(gx), _ptr(idx), B, N, S, K, CF, 1, stride, _ptr(gf), int(ops.DETERMINISTIC))
+        return (gf, None, None, None, None, None, None, None, *ret)
+
+
+def gathered_supported(feats, K, convs, bns, dtype="f32", sync_bn=None):
+    """True when shared_mlp_max_gathered can take this level (otherwise group + shared_mlp_max)."""
+    from .sync_bn import resolve
+    if dtype != "f32" or resolve(sync_bn) is not False or feats is None or not feats.is_cuda or feats.dtype != torch.float32:
+        return False
+    if len(convs) < 2 or convs[0].in_channels != feats.shape[2] + 3:
+        return False
+    chans = [feats.shape[2] + 4] + [c.out_channels for c in convs]
+    ch = (ctypes.c_int64 * len(chans))(*chans)
+    return bool(_lib.load().mp_sa_mlp_gather_supported(len(convs), ch, int(K), feats.shape[2]))
+
+
+def shared_mlp_max_gathered(xyz, feats, new_xyz, idx, convs, bns):
+    """shared_mlp_max(ops.group(xyz, feats, new_xyz, idx, xyz_last=True, pad_to=4), ..., layout="feats_first") without the grouped
+    tensor: xyz [B,N,3], feats [B,N,CF], new_xyz [B,S,3], idx [B,S,K] -> [B,S,Cout].  Check gathered_supported() first."""
+    ops._need_hip(xyz, feats, new_xyz, idx)
+    B, S, K = idx.shape
+    cin = convs[0].in_channels
+    cpad = (cin + 3) // 4 * 4
+    training = bns[0].training
+    params = []
+    for i, (conv, bn) in enumerate(zip(convs, bns)):
+        if bn.training != training:
+            raise ValueError("all BatchNorm layers of a set-abstraction level must share one mode")
+        w = conv.weight.view(conv.out_channels, conv.in_channels)
+        if i == 0:
+            pre = _PREPERMUTED.pop(id(conv), None)
+            if pre is not None and (pre[1] != conv.weight._version or pre[0].shape != (conv.out_channels, cpad)):
+                pre = None
+            w = pre[0] if pre is not None else _PermuteCols.apply(w, *_first_weight_perm(cin, cpad, True, w.device))
+        track = bn.track_running_stats and bn.running_mean is not None
+        if not training and not track:
+            raise NotImplementedError("eval-mode BatchNorm without running statistics")
+        params += [w, conv.bias, bn.weight, bn.bias, bn.running_mean if track else None, bn.running_var if track else None]
+    if training:
+        counters = [bn.num_batches_tracked for bn in bns if bn.track_running_stats and bn.num_batches_tracked is not None]
+        if counters:
+            if DEFERRED_TICKS is not None:
+                DEFERRED_TICKS.extend(counters)
+            else:
+                torch._foreach_add_(counters, 1)
+    bn0 = bns[0]
+    momentum = bn0.momentum if bn0.momentum is not None else 1.0 / max(float(bn0.num_batches_tracked), 1.0)
+    out = _SharedMLPMaxGathered.apply(feats.contiguous(), xyz.contiguous().float(), new_xyz.contiguous().float(), idx.contiguous(), training,
+                                      momentum, bn0.eps, len(convs), *params)
+    return out.view(B, S, -1)
+
+
 class _PermuteCols(torch.autograd.Function):
     """dst[:, c] = src[:, perm[c]] (zero where perm[c] < 0); perm / inv are cached int32 device tensors."""
 

@@ -1242,3 +1242,40 @@ def test_every_launch_mode_updates_the_same_parameters(monkeypatch):
         frozen = [n for n in want if (want[n] > 0) != (got[n] > 0)]
         assert not frozen, (mode, frozen)
         assert all(got[n] < 10 * 2 * 1e-3 + 1e-6 for n in got), mode     # two steps of at most ~lr each
+
+
+@pytest.mark.gpu
+def test_gathered_first_layer_equals_the_grouped_one(monkeypatch):
+    """MP_GATHER_FUSED=1: set abstraction 2 never writes its grouped input -- the first layer's forward and backward kernels read row
+    (b, s, k) from the previous level's feature table and the coordinates (mp_sa_mlp_{fwd,bwd}_gather_f32).  Same rows, same kernels
+    otherwise: outputs identical, parameter and input gradients equal up to the atomics' summation order."""
+    from maskplanner_amd import ops
+    from maskplanner_amd.pointnet2_utils import PointNetSetAbstraction, fps_start_override
+    torch.manual_seed(5)
+    B, N, D = 4, 512, 128
+    sa = PointNetSetAbstraction(npoint=128, radius=0.4, nsample=64, in_channel=D + 3, mlp=[128, 128, 256], group_all=False).cuda().train()
+    xyz = torch.rand(B, 3, N, device="cuda")
+    starts = [torch.zeros(B, dtype=torch.long)]
+    res = {}
+    det, ops.DETERMINISTIC = ops.DETERMINISTIC, True
+    try:
+        for mode in ("0", "1"):
+            monkeypatch.setenv("MP_GATHER_FUSED", mode)
+            feats = torch.randn(B, D, N, device="cuda").relu().requires_grad_(True)
+            torch.manual_seed(9)
+            feats.data = torch.randn(B, D, N, device="cuda").relu()
+            for p in sa.parameters():
+                p.grad = None
+            for bn in sa.mlp_bns:
+                bn.reset_running_stats()
+            with fps_start_override(list(starts)):
+                new_xyz, out = sa(xyz, feats)
+            (out * torch.linspace(-1, 1, out.numel(), device="cuda").view_as(out)).sum().backward()
+            res[mode] = (out.detach().clone(), feats.grad.clone(), [p.grad.clone() for p in sa.parameters()])
+    finally:
+        ops.DETERMINISTIC = det
+    (o0, g0, p0), (o1, g1, p1) = res["0"], res["1"]
+    assert torch.equal(o0, o1)
+    assert torch.allclose(g0, g1, rtol=1e-5, atol=1e-6 * float(g0.abs().max()))
+    for a, b in zip(p0, p1):
+        assert torch.allclose(a, b, rtol=1e-4, atol=2e-5 * float(a.abs().max())), float((a - b).abs().max())
