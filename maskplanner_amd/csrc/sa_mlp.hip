@@ -1141,10 +1141,13 @@ __global__ __launch_bounds__((CO >= 128 && CI == 128 ? 512 : 256), (CO >= 128 &&
     // every thread keeps the same channels for the whole kernel.  SPLIT: a wave stages 4 positions x 64 channels per pass (16 lanes x
     // 16 bytes of one row: 256-byte global segments), so that its ds_write_b64 into the K-packed planes touch every bank twice
     constexpr int NBA = CO / 64, NBB = CI / 64;
-    const int ca = SPLIT ? ((tid >> 6) % NBA) * 64 + 4 * (tid & 15) : (tid % (CO / 4)) * 4;
-    const int cb = SPLIT ? ((tid >> 6) % NBB) * 64 + 4 * (tid & 15) : (tid % (CI / 4)) * 4;
-    const int ka0 = SPLIT ? ((tid >> 6) / NBA) * 4 + ((tid & 63) >> 4) : tid / (CO / 4);
-    const int kb0 = SPLIT ? ((tid >> 6) / NBB) * 4 + ((tid & 63) >> 4) : tid / (CI / 4);
+    // lane -> (channel quad cq of the wave's 64-channel block, row pr of its 4): lanes 0..31 take quads 0..7 of all four rows, lanes
+    // 32..63 quads 8..15 -- a 32-lane pass of the ds_write_b64 then covers (4 groups) x (4 rows) x (2 halves) = 32 distinct bank pairs
+    const int cq = (lane & 7) + 8 * (lane >> 5), pr = (lane >> 3) & 3;
+    const int ca = SPLIT ? ((tid >> 6) % NBA) * 64 + 4 * cq : (tid % (CO / 4)) * 4;
+    const int cb = SPLIT ? ((tid >> 6) % NBB) * 64 + 4 * cq : (tid % (CI / 4)) * 4;
+    const int ka0 = SPLIT ? ((tid >> 6) / NBA) * 4 + pr : tid / (CO / 4);
+    const int kb0 = SPLIT ? ((tid >> 6) / NBB) * 4 + pr : tid / (CI / 4);
     constexpr int KA_STEP = SPLIT ? 4 * (NW / NBA) : NT / (CO / 4), KB_STEP = SPLIT ? 4 * (NW / NBB) : NT / (CI / 4);
     static_assert(!SPLIT || (PA * KA_STEP == DBK && PB * KB_STEP == DBK), "split staging covers the chunk");
     ChanConst ka, kb;
@@ -1517,8 +1520,9 @@ __global__ __launch_bounds__(512) void bwd_first_kernel(PosOperand DZ, PosOperan
     int goff = (4 * kq * CIW + xcol0 + l15) * 4;
 
     // SPLIT: a wave stages 4 positions x 64 channels (see bwd_fused_kernel): all 16 positions of dZ and of the features in one pass
-    const int ca = SPLIT ? (wave & 1) * 64 + 4 * (tid & 15) : (tid % (CO / 4)) * 4;
-    const int ka0 = SPLIT ? (wave >> 1) * 4 + (lane >> 4) : tid / (CO / 4);
+    // (lane -> quad / row as in bwd_fused_kernel: conflict-free ds_write_b64 into the K-packed planes)
+    const int ca = SPLIT ? (wave & 1) * 64 + 4 * ((lane & 7) + 8 * (lane >> 5)) : (tid % (CO / 4)) * 4;
+    const int ka0 = SPLIT ? (wave >> 1) * 4 + ((lane >> 3) & 3) : tid / (CO / 4);
     constexpr int KA_STEP = NT / (CO / 4);
     ChanConst ka, kb;
     load_consts<MODE_DZ>(DZ, ca, ka);
