@@ -128,6 +128,50 @@ __global__ __launch_bounds__(256) void group_rows4_kernel(const float* __restric
     }
 }
 
+// The same for D = 128 (set abstraction 2): a 512-byte feature row is exactly 32 lanes of float4, so a wave takes TWO rows per pass and
+// four passes per iteration -- eight rows whose index loads, then feature loads, then stores are issued together (the one-row kernel
+// walks a dependent index -> row -> store chain per row with half its lanes idle).  The coordinate quad of row u of a half-wave is
+// written by lane u of that half.
+__global__ __launch_bounds__(256) void group_rows128_kernel(const float* __restrict__ xyz, const float* __restrict__ feats,
+                                                            const float* __restrict__ new_xyz, const int64_t* __restrict__ idx,
+                                                            int N, int S, int K, int rows, float* __restrict__ out)
+{
+    constexpr int D = 128, Cs = D + 4;
+    const int lane = threadIdx.x & 63, half = lane >> 5, l = lane & 31;
+    for (int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 8; row0 < rows; row0 += gridDim.x * 32) {
+        int r[4];
+        size_t src[4];
+        int bs[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            r[u] = row0 + 2 * u + half;
+            const int rr = r[u] < rows ? r[u] : rows - 1;
+            bs[u] = rr / K;
+            const int64_t i64 = idx[rr];
+            const int i = (int)(i64 < 0 ? 0 : (i64 >= N ? N - 1 : i64));
+            src[u] = (size_t)(bs[u] / S) * N + i;
+        }
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(feats + src[u] * D + 4 * l);
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+        int tr = -1;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (l == u) {
+                const float* p = xyz + src[u] * 3;
+                const float* c = new_xyz + (size_t)bs[u] * 3;
+                t = make_float4(p[0] - c[0], p[1] - c[1], p[2] - c[2], 0.0f);
+                tr = r[u];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (r[u] < rows) *reinterpret_cast<float4*>(out + (size_t)r[u] * Cs + 4 * l) = v[u];
+        if (tr >= 0 && tr < rows) *reinterpret_cast<float4*>(out + (size_t)tr * Cs + D) = t;
+    }
+}
+
 __global__ __launch_bounds__(256) void group_bwd_atomic_kernel(const float* __restrict__ grad_out,
                                                                const int64_t* __restrict__ idx, int64_t N, int64_t SK,
                                                                int64_t D, int xyz_last, int64_t Cs, int64_t total,
@@ -373,6 +417,14 @@ extern "C" int mp_group_f32(const float* xyz, const float* feats, const float* n
     if (xyz_last && D > 0 && (D & 3) == 0 && out_stride == D + 4 && B * S * K < ((int64_t)1 << 31) && N < ((int64_t)1 << 31) &&
         (reinterpret_cast<uintptr_t>(feats) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
         const int64_t rows = B * S * K;
+        if (D == 128 && (reinterpret_cast<uintptr_t>(feats) & 15) == 0) {
+            int64_t g8 = (rows + 31) / 32;
+            if (g8 > 256 * 32) g8 = 256 * 32;
+            MP_LAUNCH("group_kernel", 0.0, bytes, group_rows128_kernel, dim3((unsigned)g8), dim3(256), 0, mp_stream(stream_), xyz, feats, new_xyz, idx,
+                      (int)N, (int)S, (int)K, (int)rows, out);
+            MP_CHECK_LAUNCH();
+            return MP_OK;
+        }
         int64_t g = (rows + 3) / 4;
         if (g > 256 * 64) g = 256 * 64;
         MP_LAUNCH("group_kernel", 0.0, bytes, group_rows4_kernel, dim3((unsigned)g), dim3(256), 0, mp_stream(stream_), xyz, feats, new_xyz, idx,
