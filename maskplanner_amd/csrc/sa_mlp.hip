@@ -1094,6 +1094,12 @@ __global__ __launch_bounds__(CO > 128 ? 512 : 256) void fwd_chunk_kernel(PosOper
 // BatchNorm-backward sums of layer l-1 from the raw Z_{l-1} chunk kept beside the activated one: 4 tensor passes.
 // The dX tile of a chunk is computed as eight 16x16 MFMA tiles, two per wave.
 // =================================================================================================================
+#ifndef MP_BWD_KSPLIT
+#define MP_BWD_KSPLIT 0     // [r2] measured on one box: 234 us without, 287 us with (the extra barrier and 8 spilled registers cost more than the halved LDS reads return)
+#endif
+#ifndef MP_MAP256
+#define MP_MAP256 0         // 1: the conflict-free 8-lane mapping also for the 1 KB dZ rows of the 256-output layer (234 -> 256 us: 128-byte global segments)
+#endif
 #ifndef MP_SPLIT_WGS
 #define MP_SPLIT_WGS 2     // (3: a third workgroup of the 64-input layers per CU -- tried: 168-register cap, spills in the loop, 150 -> 370 us)
 #endif
@@ -1113,6 +1119,11 @@ __global__ __launch_bounds__((CO >= 128 && CI == 128 ? 512 : 256), (CO >= 128 &&
     constexpr int PA = DBK * CO / 4 / NT, PB = DBK * CI / 4 / NT;
     static_assert((CO == 64 || CO == 128 || CO == 256) && (CI == 64 || CI == 128) && PA >= 1 && PB >= 1 && HT >= 1, "tile");
     static_assert(!SPLIT || DBK == 16, "split: one 32x32x16 k-step of positions per chunk");
+    // KSPLIT (256 outputs): in the dX product every wave reads the WHOLE dZ chunk from LDS for its 16 columns -- 192 of the 332 KB of LDS
+    // traffic per chunk.  Here a wave takes 32 columns (two tiles) and HALF of K, its partner (wave ^ 4) the other half; each
+    // finalises one of the two tiles after adding the partner's partial (8 KB through LDS, one extra barrier per chunk).
+    constexpr bool KSPLIT = SPLIT && CO == 256 && CI == 128 && MP_BWD_KSPLIT;
+    constexpr int HTW = KSPLIT ? 2 : HT, NSTW = KSPLIT ? CO / 64 : CO / 32;     // weight-plane tiles / k-steps per wave
     // SPLIT: K-packed planes (tr_frag_packed), group stride in halves: 16 dwords mod 64 banks.  The 64-input layers are HBM-bound:
     // a smaller pad (8 dwords: some 2-way conflicts in the transposed reads) lets a third workgroup onto the CU -- more loads in flight
     constexpr int GS = DBK * 8 + ((SPLIT && CI == 64 && MP_SPLIT_WGS == 3) ? 16 : 32);
@@ -1143,10 +1154,13 @@ __global__ __launch_bounds__((CO >= 128 && CI == 128 ? 512 : 256), (CO >= 128 &&
     constexpr int NBA = CO / 64, NBB = CI / 64;
     // lane -> (channel quad cq of the wave's 64-channel block, row pr of its 4): lanes 0..31 take quads 0..7 of all four rows, lanes
     // 32..63 quads 8..15 -- a 32-lane pass of the ds_write_b64 then covers (4 groups) x (4 rows) x (2 halves) = 32 distinct bank pairs
+    // (the 1 KB dZ rows of the 256-output layer keep 16 lanes = 256 contiguous bytes per row: MP_MAP256)
+    constexpr bool WIDE_A = CO == 256 && !MP_MAP256;
     const int cq = (lane & 7) + 8 * (lane >> 5), pr = (lane >> 3) & 3;
-    const int ca = SPLIT ? ((tid >> 6) % NBA) * 64 + 4 * cq : (tid % (CO / 4)) * 4;
+    const int cqa = WIDE_A ? (lane & 15) : cq, pra = WIDE_A ? (lane >> 4) : pr;
+    const int ca = SPLIT ? ((tid >> 6) % NBA) * 64 + 4 * cqa : (tid % (CO / 4)) * 4;
     const int cb = SPLIT ? ((tid >> 6) % NBB) * 64 + 4 * cq : (tid % (CI / 4)) * 4;
-    const int ka0 = SPLIT ? ((tid >> 6) / NBA) * 4 + pr : tid / (CO / 4);
+    const int ka0 = SPLIT ? ((tid >> 6) / NBA) * 4 + pra : tid / (CO / 4);
     const int kb0 = SPLIT ? ((tid >> 6) / NBB) * 4 + pr : tid / (CI / 4);
     constexpr int KA_STEP = SPLIT ? 4 * (NW / NBA) : NT / (CO / 4), KB_STEP = SPLIT ? 4 * (NW / NBB) : NT / (CI / 4);
     static_assert(!SPLIT || (PA * KA_STEP == DBK && PB * KB_STEP == DBK), "split staging covers the chunk");
@@ -1213,13 +1227,15 @@ __global__ __launch_bounds__((CO >= 128 && CI == 128 ? 512 : 256), (CO >= 128 &&
     const int xrow0 = DBK == 32 ? (wave / (NW / 2)) * 16 : 0;
     const int xcol0 = DBK == 32 ? (wave % (NW / 2)) * XW : wave * XW;
     float wfrag[SPLIT ? 1 : HT][SPLIT ? 1 : CO / 4];
-    bf16x8 wsp[SPLIT ? HT : 1][SPLIT ? CO / 32 : 1][3];   // SPLIT (16x16x32): lane (col, kq) holds W[32*st + 8*kq .. + 7][col] as planes
+    bf16x8 wsp[SPLIT ? HTW : 1][SPLIT ? NSTW : 1][3];   // SPLIT (16x16x32): lane (col, kq) holds W[32*st + 8*kq .. + 7][col] as planes
+    const int gcol0 = KSPLIT ? (wave & 3) * 32 : xcol0;      // first dX column of this wave's tiles
+    const int gst0 = KSPLIT ? (wave >> 2) * NSTW : 0;        // first k-step of its share of K
     if constexpr (SPLIT) {
 #pragma unroll
-        for (int h = 0; h < HT; ++h)
+        for (int h = 0; h < HTW; ++h)
 #pragma unroll
-            for (int st = 0; st < CO / 32; ++st) {
-                const float* wp = W + (size_t)(32 * st + 8 * (lane >> 4)) * CI + xcol0 + 16 * h + (lane & 15);
+            for (int st = 0; st < NSTW; ++st) {
+                const float* wp = W + (size_t)(32 * (gst0 + st) + 8 * (lane >> 4)) * CI + gcol0 + 16 * h + (lane & 15);
                 const Split4 lo = split3(make_float4(wp[0], wp[CI], wp[2 * CI], wp[3 * CI]));
                 const Split4 hi = split3(make_float4(wp[4 * CI], wp[5 * CI], wp[6 * CI], wp[7 * CI]));
 #pragma unroll
@@ -1238,9 +1254,10 @@ __global__ __launch_bounds__((CO >= 128 && CI == 128 ? 512 : 256), (CO >= 128 &&
     typedef float f2_ __attribute__((ext_vector_type(2)));
     float spx[HT], tpx[HT];                     // this lane's G columns
     f2_ sx1[HT], sx2[HT];                       // BatchNorm-backward sums of those columns, two row slots each
+    const int ecol0 = KSPLIT ? gcol0 + 16 * (wave >> 2) : xcol0;   // first column of the tile(s) this wave FINALISES
 #pragma unroll
     for (int h = 0; h < HT; ++h) {
-        const int col = xcol0 + 16 * h + (lane & 15);
+        const int col = ecol0 + 16 * h + (lane & 15);
         spx[h] = IN.s[col];
         tpx[h] = IN.t[col];
         sx1[h] = f2_{0.0f, 0.0f};
@@ -1248,7 +1265,10 @@ __global__ __launch_bounds__((CO >= 128 && CI == 128 ? 512 : 256), (CO >= 128 &&
     }
     // G_{l-1} rows of this workgroup through a buffer resource: lane part of the offset in one VGPR, row part as immediates
     const __amdgpu_buffer_rsrc_t grsrc = __builtin_amdgcn_make_buffer_rsrc(G + (size_t)p0 * CI, 0, (p1 - p0) * CI * 4, 0x00020000);
-    int goff = ((xrow0 + 4 * (lane >> 4)) * CI + xcol0 + (lane & 15)) * 4;
+    int goff = ((xrow0 + 4 * (lane >> 4)) * CI + ecol0 + (lane & 15)) * 4;
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    __shared__ f32x4 xbuf[KSPLIT ? NW : 1][64];      // KSPLIT: the partial of the tile the partner wave finalises
+    f32x4 ax[HT];                                    // the finished dX tile(s) of this wave, between g_mfma and g_epi
 
     gload(p0);
     sstore(0);
@@ -1292,15 +1312,41 @@ __global__ __launch_bounds__((CO >= 128 && CI == 128 ? 512 : 256), (CO >= 128 &&
             mma_chunk_pipelined<true, true, LDA, CI, TMW, TNW, DBK>(sA[cur], sB[cur], wrow0, wcol0, accW);   // dW += dZ^T * act(Z_{l-1})
         }
         };
-        auto do_g = [&]() {
+        auto g_mfma = [&]() {
         {   // G_{l-1} chunk [DBK x 64] = dZ [DBK x CO] * W_l [CO x 64] as 16x16 tiles, HT per wave (v_mfma_f32_16x16x4_f32:
             // with 32x32 tiles only one or two waves would have work)
-            typedef float f32x4 __attribute__((ext_vector_type(4)));
-            f32x4 ax[HT];
 #pragma unroll
             for (int h = 0; h < HT; ++h) ax[h] = f32x4{0.f, 0.f, 0.f, 0.f};
             const int l15 = lane & 15, kq = lane >> 4;
-            if constexpr (SPLIT) {   // v_mfma_f32_16x16x32_bf16: lane (row, kq) holds dZ[row][32*st + 8*kq .. + 7] -- one packed group
+            if constexpr (KSPLIT) {   // two tiles x half of K; the tile this wave does not finalise goes to the partner through LDS
+                f32x4 a2[2], c2[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) { a2[h] = f32x4{0.f, 0.f, 0.f, 0.f}; c2[h] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+                const int ao = (4 * gst0 + kq) * GS + (xrow0 + l15) * 8;
+                bf16x8 af[2][3];
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) af[0][pl] = *reinterpret_cast<const bf16x8*>(&hA[cur][pl][ao]);
+#pragma unroll
+                for (int st = 0; st < NSTW; ++st) {
+                    if (st + 1 < NSTW) {
+#pragma unroll
+                        for (int pl = 0; pl < 3; ++pl) af[(st + 1) & 1][pl] = *reinterpret_cast<const bf16x8*>(&hA[cur][pl][ao + 4 * (st + 1) * GS]);
+                    }
+                    const bf16x8 ah = af[st & 1][0], am = af[st & 1][1], al = af[st & 1][2];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        c2[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, wsp[h][st][0], c2[h], 0, 0, 0);
+                        a2[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wsp[h][st][0], a2[h], 0, 0, 0);
+                        c2[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wsp[h][st][2], c2[h], 0, 0, 0);
+                        c2[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, wsp[h][st][1], c2[h], 0, 0, 0);
+                        c2[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, wsp[h][st][0], c2[h], 0, 0, 0);
+                        c2[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wsp[h][st][1], c2[h], 0, 0, 0);
+                    }
+                }
+                const int mine = wave >> 2;
+                ax[0] = mine ? a2[1] + c2[1] : a2[0] + c2[0];
+                xbuf[wave][lane] = mine ? a2[0] + c2[0] : a2[1] + c2[1];
+            } else if constexpr (SPLIT) {   // v_mfma_f32_16x16x32_bf16: lane (row, kq) holds dZ[row][32*st + 8*kq .. + 7] -- one packed group
                 f32x4 cx[HT];
 #pragma unroll
                 for (int h = 0; h < HT; ++h) cx[h] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1353,13 +1399,19 @@ __global__ __launch_bounds__((CO >= 128 && CI == 128 ? 512 : 256), (CO >= 128 &&
                     for (int h = 0; h < HT; ++h) ax[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, wfrag[h][st + 3], ax[h], 0, 0, 0);
                 }
             }
+        }
+        };
+        auto g_epi = [&]() {
+        {
+            const int l15 = lane & 15, kq = lane >> 4;
+            if constexpr (KSPLIT) ax[0] += xbuf[wave ^ 4][lane];       // (behind the barrier that follows the partner's write)
             // epilogue written for instruction count (see fwd_chunk_kernel): buffer stores (rows past the workgroup's last
             // position are dropped by the range check; their dZ rows were staged as zeros, so they add nothing to the sums),
             // the four rows of a lane as two register pairs
             typedef float f2 __attribute__((ext_vector_type(2)));
 #pragma unroll
             for (int h = 0; h < HT; ++h) {
-                const float* zr = sZ[cur] + (xrow0 + 4 * kq) * CI + xcol0 + 16 * h + l15;
+                const float* zr = sZ[cur] + (xrow0 + 4 * kq) * CI + ecol0 + 16 * h + l15;
 #pragma unroll
                 for (int i = 0; i < 4; i += 2) {
                     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ax[h][i]), grsrc, goff + 16 * h * 4, i * CI * 4, 0);
@@ -1376,8 +1428,16 @@ __global__ __launch_bounds__((CO >= 128 && CI == 128 ? 512 : 256), (CO >= 128 &&
         };
         // (tried: the two halves of the workgroup walking the two products in opposite order, so that only four waves at a time
         // read the dZ planes for G -- 254 -> 315 us on the 256-output layer: twice the loop code, spills again)
-        do_dw();
-        do_g();
+        if constexpr (KSPLIT) {
+            g_mfma();
+            do_dw();
+            __syncthreads();      // every partial is in xbuf
+            g_epi();
+        } else {
+            do_dw();
+            g_mfma();
+            g_epi();
+        }
         if (kc + 1 < nchunks) sstore(cur ^ 1);
         __syncthreads();
     }
@@ -1391,7 +1451,7 @@ __global__ __launch_bounds__((CO >= 128 && CI == 128 ? 512 : 256), (CO >= 128 &&
         s1x += __shfl_xor(s1x, 16, 64); s1x += __shfl_xor(s1x, 32, 64);
         s2x += __shfl_xor(s2x, 16, 64); s2x += __shfl_xor(s2x, 32, 64);
         if (lane < 16) {
-            const int col = xcol0 + 16 * h + lane;
+            const int col = ecol0 + 16 * h + lane;
             red[DBK == 32 ? (wave / (NW / 2)) : 0][0][col] = s1x;
             red[DBK == 32 ? (wave / (NW / 2)) : 0][1][col] = s2x;
         }
