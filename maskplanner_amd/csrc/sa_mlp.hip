@@ -1097,6 +1097,9 @@ __global__ __launch_bounds__(CO > 128 ? 512 : 256) void fwd_chunk_kernel(PosOper
 #ifndef MP_BWD_KSPLIT
 #define MP_BWD_KSPLIT 0     // [r2] measured on one box: 234 us without, 287 us with (the extra barrier and 8 spilled registers cost more than the halved LDS reads return)
 #endif
+#ifndef MP_MAPWIDE
+#define MP_MAPWIDE 0        // 1: 16 lanes per row for every plane write of the fused backward kernels (A/B builds)
+#endif
 #ifndef MP_MAP256
 #define MP_MAP256 0         // 1: the conflict-free 8-lane mapping also for the 1 KB dZ rows of the 256-output layer (234 -> 256 us: 128-byte global segments)
 #endif
@@ -1155,13 +1158,15 @@ __global__ __launch_bounds__((CO >= 128 && CI == 128 ? 512 : 256), (CO >= 128 &&
     // lane -> (channel quad cq of the wave's 64-channel block, row pr of its 4): lanes 0..31 take quads 0..7 of all four rows, lanes
     // 32..63 quads 8..15 -- a 32-lane pass of the ds_write_b64 then covers (4 groups) x (4 rows) x (2 halves) = 32 distinct bank pairs
     // (the 1 KB dZ rows of the 256-output layer keep 16 lanes = 256 contiguous bytes per row: MP_MAP256)
-    constexpr bool WIDE_A = CO == 256 && !MP_MAP256;
+    constexpr bool WIDE_A = (CO == 256 && !MP_MAP256) || MP_MAPWIDE;
+    constexpr bool WIDE_B = WIDE_A;                  // ([r2] same box: 236 -> 225 us with both operands of that layer on the wide mapping)
     const int cq = (lane & 7) + 8 * (lane >> 5), pr = (lane >> 3) & 3;
     const int cqa = WIDE_A ? (lane & 15) : cq, pra = WIDE_A ? (lane >> 4) : pr;
     const int ca = SPLIT ? ((tid >> 6) % NBA) * 64 + 4 * cqa : (tid % (CO / 4)) * 4;
-    const int cb = SPLIT ? ((tid >> 6) % NBB) * 64 + 4 * cq : (tid % (CI / 4)) * 4;
+    const int cqb = WIDE_B ? (lane & 15) : cq, prb = WIDE_B ? (lane >> 4) : pr;
+    const int cb = SPLIT ? ((tid >> 6) % NBB) * 64 + 4 * cqb : (tid % (CI / 4)) * 4;
     const int ka0 = SPLIT ? ((tid >> 6) / NBA) * 4 + pra : tid / (CO / 4);
-    const int kb0 = SPLIT ? ((tid >> 6) / NBB) * 4 + pr : tid / (CI / 4);
+    const int kb0 = SPLIT ? ((tid >> 6) / NBB) * 4 + prb : tid / (CI / 4);
     constexpr int KA_STEP = SPLIT ? 4 * (NW / NBA) : NT / (CO / 4), KB_STEP = SPLIT ? 4 * (NW / NBB) : NT / (CI / 4);
     static_assert(!SPLIT || (PA * KA_STEP == DBK && PB * KB_STEP == DBK), "split staging covers the chunk");
     ChanConst ka, kb;
@@ -1581,8 +1586,8 @@ __global__ __launch_bounds__(512) void bwd_first_kernel(PosOperand DZ, PosOperan
 
     // SPLIT: a wave stages 4 positions x 64 channels (see bwd_fused_kernel): all 16 positions of dZ and of the features in one pass
     // (lane -> quad / row as in bwd_fused_kernel: conflict-free ds_write_b64 into the K-packed planes)
-    const int ca = SPLIT ? (wave & 1) * 64 + 4 * ((lane & 7) + 8 * (lane >> 5)) : (tid % (CO / 4)) * 4;
-    const int ka0 = SPLIT ? (wave >> 1) * 4 + ((lane >> 3) & 3) : tid / (CO / 4);
+    const int ca = SPLIT ? (wave & 1) * 64 + 4 * (MP_MAPWIDE ? (lane & 15) : ((lane & 7) + 8 * (lane >> 5))) : (tid % (CO / 4)) * 4;
+    const int ka0 = SPLIT ? (wave >> 1) * 4 + (MP_MAPWIDE ? (lane >> 4) : ((lane >> 3) & 3)) : tid / (CO / 4);
     constexpr int KA_STEP = NT / (CO / 4);
     ChanConst ka, kb;
     load_consts<MODE_DZ>(DZ, ca, ka);
