@@ -2539,7 +2539,8 @@ static int sa_mlp_bwd(const float* x0, int64_t P, int64_t K, int n_layers, const
             // single-tile layer: dX, dW and the BatchNorm-backward sums of layer l-1 in one pass over dZ_l (bwd_fused_kernel)
             const mp_mlp_layer_t& Pv = layers[l - 1];
             float* Gn = gbuf[l & 1];
-            const int ppb = 1024;
+            static const int ppb_env = getenv("MP_BWD_PPB") ? atoi(getenv("MP_BWD_PPB")) : 1024;     // positions per workgroup (experiments)
+            const int ppb = ppb_env;
             const unsigned gx = (unsigned)((P + ppb - 1) / ppb);
             if ((size_t)gx > nblk_max) return MP_EUNSUPPORTED;
             const double fl = 4.0 * (double)P * Co * Ci;
@@ -2589,7 +2590,8 @@ static int sa_mlp_bwd(const float* x0, int64_t P, int64_t K, int n_layers, const
         }
         if (!bf16 && l == 0 && grad_x0 && Co == 128 && Ci == 132 && grad_x0_cols == 128 && fused_bwd_enabled()) {
             // first layer of a level with a [128 features | xyz | pad] input: dW and the feature columns of grad_x0 in one pass
-            const int ppb = 1024;
+            static const int ppb_env = getenv("MP_BWD_PPB") ? atoi(getenv("MP_BWD_PPB")) : 1024;     // positions per workgroup (experiments)
+            const int ppb = ppb_env;
             const unsigned gx = (unsigned)((P + ppb - 1) / ppb);
             const double fl = 2.0 * (double)P * Co * (Ci + 128), by = 4.0 * ((pooled ? 1.0 : 2.0) * (double)P * Co + (double)P * (Ci + 128));
             if (gather && split_enabled() && !pooled)
