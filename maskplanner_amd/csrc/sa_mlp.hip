@@ -876,7 +876,6 @@ __global__ __launch_bounds__(CO > 128 ? 512 : 256) void fwd_chunk_kernel(PosOper
     constexpr int NFR = BIG ? CI / 2 : CI / 4;        // weight fragment registers per lane
     constexpr int NV = BIG ? 16 : 8;                  // rows of the chunk held by one lane
     static_assert((CW == 32 || CW == 16) && PA >= 1, "shape");
-    static_assert(!SPLIT || BIG, "the split kernels use the 32x32x16 bf16 MFMA");
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     // SPLIT: the chunk as three bf16 planes [plane][row][k] (rows 16-byte aligned, stride = 4 dwords mod 64 banks)
     constexpr int LDH = CI + 8;
@@ -895,11 +894,12 @@ __global__ __launch_bounds__(CO > 128 ? 512 : 256) void fwd_chunk_kernel(PosOper
 
     // B[k][n] = W[n][k]: 32x32x2 lane (n, kq) holds W[col][2*st + kq]; 16x16x4 lane (n, kq) holds W[col][4*st + kq]
     float wfrag[SPLIT ? 1 : NFR];
-    bf16x8 wsp[SPLIT ? 3 : 1][SPLIT ? CI / 16 : 1];  // SPLIT: lane (n, kq) holds W[col][16*st + 8*kq .. + 7] as (h, m, l) planes
+    constexpr int KST = BIG ? 16 : 32;               // K per split MFMA step: 32x32x16 (two k-groups of 8) or 16x16x32 (four)
+    bf16x8 wsp[SPLIT ? 3 : 1][SPLIT ? CI / KST : 1];  // SPLIT: lane (n, kq) holds W[col][KST*st + 8*kq .. + 7] as (h, m, l) planes
     if constexpr (SPLIT) {
 #pragma unroll
-        for (int st = 0; st < CI / 16; ++st) {
-            const float* wp = W + (size_t)col * (CI + TAIL) + 16 * st + 8 * kq;
+        for (int st = 0; st < CI / KST; ++st) {
+            const float* wp = W + (size_t)col * (CI + TAIL) + KST * st + 8 * kq;
             const Split4 lo = split3(ld4(wp)), hi = split3(ld4(wp + 4));
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -979,7 +979,31 @@ __global__ __launch_bounds__(CO > 128 ? 512 : 256) void fwd_chunk_kernel(PosOper
         const int cur = kcn & 1;
         if (kcn + 1 < nchunks) gload(p0 + (kcn + 1) * DBK);
         float v[NV];
-        if constexpr (SPLIT) {
+        if constexpr (SPLIT && !BIG) {
+            // 16 columns per wave: two 16x16 row tiles, v_mfma_f32_16x16x32_bf16 (lane (row, kq) holds A[row][32*st + 8*kq .. + 7])
+            f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f}, c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
+            const int ao = lc * LDH + 8 * kq;
+#pragma unroll
+            for (int st = 0; st < CI / 32; ++st) {
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt) {
+                    const int o = ao + rt * 16 * LDH + 32 * st;
+                    const bf16x8 ah = *reinterpret_cast<const bf16x8*>(&sH[cur][0][o]);
+                    const bf16x8 am = *reinterpret_cast<const bf16x8*>(&sH[cur][1][o]);
+                    const bf16x8 al = *reinterpret_cast<const bf16x8*>(&sH[cur][2][o]);
+                    f32x4& a = rt ? a1 : a0;
+                    f32x4& c = rt ? c1 : c0;
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, wsp[0][st], c, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wsp[0][st], a, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wsp[2][st], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, wsp[1][st], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, wsp[0][st], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wsp[1][st], c, 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { v[i] = a0[i] + c0[i]; v[4 + i] = a1[i] + c1[i]; }   // rows 4 * kq + i and 16 + 4 * kq + i
+        } else if constexpr (SPLIT) {
             // two accumulators: the leading products and the five corrections (summed among themselves first, and two
             // independent MFMA chains instead of one)
             f32x16 acc, cor;
@@ -2298,7 +2322,9 @@ static int sa_mlp_fwd(const float* x0, int64_t P, int64_t K, int n_layers, const
             const double fl = 2.0 * (double)P * Co_ * Ci_, by = 4.0 * ((double)P * (4 + Co_) + (double)Co_ * Ci_);
             char tg[64];
             snprintf(tg, sizeof tg, "fwd_chunk_kernel<%d, %d, false, 4>", Ci_, Co_);
-            if (Co_ == 64)
+            if (Co_ == 64 && split_enabled())
+                MP_LAUNCH(tg, fl, by, (fwd_chunk_kernel<64, 64, false, SRC_ACT_RC, 0, true>), dim3(gx), dim3(256), 0, stream, A, (int)P, ppb, L.weight, L.z, partials, po, L.gamma);
+            else if (Co_ == 64)
                 MP_LAUNCH(tg, fl, by, (fwd_chunk_kernel<64, 64, false, SRC_ACT_RC>), dim3(gx), dim3(256), 0, stream, A, (int)P, ppb, L.weight, L.z, partials, po, L.gamma);
             else if (split_enabled())
                 MP_LAUNCH(tg, fl, by, (fwd_chunk_kernel<64, 128, false, SRC_ACT_RC, 0, true>), dim3(gx), dim3(256), 0, stream, A, (int)P, ppb, L.weight, L.z, partials, po, L.gamma);
