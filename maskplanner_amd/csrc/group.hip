@@ -213,15 +213,24 @@ __global__ __launch_bounds__(256) void group_bwd_gather_kernel(const float* __re
     if (tid < GP) cnt[tid] = 0;
     if (tid == 0) novf = 0;
     __syncthreads();
-    for (int m = tid; m < M; m += 256) {
-        const int64_t i = bi[m];
-        const int r = (int)(i - n0);
-        if (i >= n0 && r < npts) {
-            const int slot = atomicAdd(&cnt[r], 1);
-            if (slot < GCAP) lists[r][slot] = (unsigned short)m;
-            else {
-                const int o = atomicAdd(&novf, 1);
-                if (o < GOVF) { ovf_m[o] = (unsigned short)m; ovf_r[o] = (unsigned char)r; }
+    // the scan: eight index loads in flight per thread (one load, one compare and a rare LDS atomic per index is otherwise a chain of
+    // L2 latencies -- 32 of them per thread at M = 8192)
+    for (int m0 = tid; m0 < M; m0 += 8 * 256) {
+        int64_t iv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) iv[u] = (m0 + u * 256 < M) ? bi[m0 + u * 256] : (int64_t)-1;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int64_t i = iv[u];
+            const int m = m0 + u * 256;
+            const int r = (int)(i - n0);
+            if (i >= n0 && r < npts) {
+                const int slot = atomicAdd(&cnt[r], 1);
+                if (slot < GCAP) lists[r][slot] = (unsigned short)m;
+                else {
+                    const int o = atomicAdd(&novf, 1);
+                    if (o < GOVF) { ovf_m[o] = (unsigned short)m; ovf_r[o] = (unsigned char)r; }
+                }
             }
         }
     }
