@@ -60,6 +60,11 @@ class TrainStep:
         self._graph_b, self._graph_b2, self._factor_args, self._adam_stream, self._adam_ev = None, None, None, None, None
         self._split_adam_wanted = os.environ.get("MASKPLANNER_SPLIT_ADAM", "1") != "0"
         self._plan_late = os.environ.get("MASKPLANNER_PLAN_AFTER_FORWARD", "0") != "0"
+        # MASKPLANNER_ADAM_AFTER_PLAN=1 (experiment): the deferred head optimizer starts only when the next batch's sampling kernels are
+        # done, instead of sharing the first ~0.4 ms of the encoder forward with them.  [r2] measured: +45 us per step (the heads then wait
+        # for the optimizer), so it stays off.
+        self._adam_after_plan = os.environ.get("MASKPLANNER_ADAM_AFTER_PLAN", "0") != "0"
+        self._adam_pending = False
         self._unit = torch.ones((), dtype=torch.float32, device=self.device)
         # train-mode dropout of the head blocks inside their BatchNorm + ReLU launches (pointnet2_cls_ssg._block): a device (seed, step)
         # pair, the step advanced once per training step.  MASKPLANNER_FUSED_DROPOUT=0 keeps nn.Dropout (torch's Philox stream).
@@ -156,6 +161,9 @@ class TrainStep:
         late = self.overlap and self._graph_b is not None and self._plan_late
         if self.overlap:
             self._pipeline_sampling(launch=not late)
+        if self._adam_pending:
+            self._adam_pending = False
+            self._launch_factor_adam(after=self._plan_ev)
         if self._graph is not None:
             self._graph.replay()
             if late:
@@ -314,11 +322,16 @@ class TrainStep:
             self.reducer.finish()
             self.opt.step()
         if self.factor_opt is not None and self._graph_b2 is None:
-            self._launch_factor_adam()
+            if self._adam_after_plan and self.overlap:
+                self._adam_pending = True       # launched by the next step(), behind that step's sampling kernels
+            else:
+                self._launch_factor_adam()
 
-    def _launch_factor_adam(self):
+    def _launch_factor_adam(self, after=None):
         side = self._adam_stream
         side.wait_stream(torch.cuda.current_stream())
+        if after is not None:
+            side.wait_event(after)
         with torch.cuda.stream(side):
             if self._adam_delay_cycles:      # test hook: hold the optimizer back so that it overlaps the next replay of graph A
                 torch.cuda._sleep(int(self._adam_delay_cycles))
