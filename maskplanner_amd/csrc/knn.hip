@@ -810,8 +810,14 @@ __global__ __launch_bounds__(256) void padded_lengths_kernel(const float* __rest
     if (threadIdx.x == 0) smin = P2;
     __syncthreads();
     int first = P2;
-    for (int c = threadIdx.x; c < P2; c += 256)
-        if (y[((size_t)b * P2 + c) * D] == -100.0f) { first = c; break; }
+    for (int c0 = threadIdx.x; c0 < P2 && first == P2; c0 += 4 * 256) {      // four rows in flight (the one-row loop is a chain of latencies)
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = (c0 + u * 256 < P2) ? y[((size_t)b * P2 + c0 + u * 256) * D] : 0.0f;
+#pragma unroll
+        for (int u = 3; u >= 0; --u)
+            if (v[u] == -100.0f) first = c0 + u * 256;          // the lowest hit of the batch wins
+    }
     first = (int)mp::wave_min_u32((unsigned)first);
     if ((threadIdx.x & 63) == 0) atomicMin(&smin, first);
     __syncthreads();
