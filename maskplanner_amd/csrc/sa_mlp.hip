@@ -2159,6 +2159,15 @@ inline bool split_enabled()
     return on;
 }
 
+// workgroups the position-stream forward aims for (MP_FWD_WGS, experiments): positions per workgroup halve from 1024 until there are that many
+// [r2] same-box sweep: 512 for most shapes; the 256-output kernel (512 threads, one workgroup per CU) is best with one round of 256, the
+// HBM-bound 64 -> 64 layer with 2048 small workgroups
+inline int fwd_wgs_wanted(int dflt = 512)
+{
+    static const int n = getenv("MP_FWD_WGS") ? atoi(getenv("MP_FWD_WGS")) : 0;
+    return n > 0 ? n : dflt;
+}
+
 inline bool chunk_fwd_enabled()
 {
     static const bool on = !(getenv("MP_CHUNK_FWD") && atoi(getenv("MP_CHUNK_FWD")) == 0);
@@ -2298,7 +2307,7 @@ static int sa_mlp_fwd(const float* x0, int64_t P, int64_t K, int n_layers, const
             // first layer of a level with a [128 features | xyz | pad] input: the position-stream kernel with the 4 extra columns
             // on the VALU (the tiled kernel pays a whole 32-wide k tile for them)
             int ppb = 1024;
-            while ((P + ppb - 1) / ppb < 512 && ppb > 128) ppb >>= 1;
+            while ((P + ppb - 1) / ppb < fwd_wgs_wanted() && ppb > 128) ppb >>= 1;
             const unsigned gx = (unsigned)((P + ppb - 1) / ppb);
             const double fl = 2.0 * (double)P * Co_ * Ci_, by = 4.0 * ((double)P * (Ci_ + Co_) + (double)Co_ * Ci_);
             if (gather && split_enabled())
@@ -2317,7 +2326,7 @@ static int sa_mlp_fwd(const float* x0, int64_t P, int64_t K, int n_layers, const
             nblk = (int)gx;
         } else if (l == 1 && rc_first) {
             int ppb = 1024;
-            while ((P + ppb - 1) / ppb < 512 && ppb > 128) ppb >>= 1;
+            while ((P + ppb - 1) / ppb < fwd_wgs_wanted(Co_ == 64 ? 2048 : 512) && ppb > 128) ppb >>= 1;
             const unsigned gx = (unsigned)((P + ppb - 1) / ppb);
             const double fl = 2.0 * (double)P * Co_ * Ci_, by = 4.0 * ((double)P * (4 + Co_) + (double)Co_ * Ci_);
             char tg[64];
@@ -2336,7 +2345,7 @@ static int sa_mlp_fwd(const float* x0, int64_t P, int64_t K, int n_layers, const
             chunk_fwd_enabled() && !(fuse_pool && (K % 32) != 0)) {
             (void)last_unfused;
             int ppb = 1024;
-            while ((P + ppb - 1) / ppb < 512 && ppb > 128 && (!fuse_pool || (ppb / 2) % K == 0)) ppb >>= 1;   // >= 512 workgroups when P allows
+            while ((P + ppb - 1) / ppb < fwd_wgs_wanted(Co_ == 256 ? 256 : 512) && ppb > 128 && (!fuse_pool || (ppb / 2) % K == 0)) ppb >>= 1;   // >= 512 workgroups when P allows
             const unsigned gx = (unsigned)((P + ppb - 1) / ppb);
             const double fl = 2.0 * (double)P * Co_ * Ci_, by = 4.0 * ((double)P * (Ci_ + Co_) + (double)Co_ * Ci_);
             char tg[64];
