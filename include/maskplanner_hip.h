@@ -250,6 +250,14 @@ int mp_bn_relu_rows_bwd_f32(const float* grad_y, const float* y, const float* x,
 /* The same block with the nn.Dropout(p) behind it (models/pointnet2_cls_ssg.py:309-327: self.dropout(F.relu(self.bn1(.)))) in the same
  * launch.  rng: device int64 [2] = (seed, step), advanced by the caller once per training step; the keep mask is a counter-based hash of
  * (seed, step, layer, element) -- Bernoulli(1 - p) like torch's, not the same draws.  Backward: the mask is `y > 0`. */
+/* a whole head block -- dropout(relu(bn(linear(x)))), models/pointnet2_cls_ssg.py:309-327 -- in one launch: x [B <= 32, K], weight [N, K]
+ * (K % 128 == 0), lin_out [B, N] = the Linear's output (BatchNorm's input, kept for the backward), y [B, N]; statistics, running-stat update
+ * and dropout as in mp_bn_relu_drop_rows_f32 (rng NULL: no dropout).  The product runs on the bf16 matrix cores with three-plane split
+ * operands (fp32-accurate).  Backward: mp_bn_relu_drop_rows_bwd_f32 on (grad_y, y, lin_out), then the Linear's own backward. */
+int mp_linear_block_f32(const float* x, const float* weight, const float* bias, int64_t B, int64_t N, int64_t K, int training,
+                        double momentum, double eps, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                        float* lin_out, float* y, float* save_mean, float* save_rstd, double drop_p, const int64_t* rng, int layer,
+                        mp_stream_t stream);
 int mp_bn_relu_drop_rows_f32(const float* x, int64_t B, int64_t C, int training, double momentum, double eps,
                              const float* gamma, const float* beta, float* running_mean, float* running_var, float* y,
                              float* save_mean, float* save_rstd, double drop_p, const int64_t* rng, int layer, mp_stream_t stream);

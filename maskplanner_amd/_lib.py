@@ -80,6 +80,7 @@ SIGNATURES = {
     "mp_mask_loss_bwd_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _dbl, _dbl, _dbl, _vp, _vp, _vp]),
     "mp_bn_relu_rows_f32": (_int, [_vp, _i64, _i64, _int, _dbl, _dbl, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mp_bn_relu_rows_bwd_f32": (_int, [_vp, _vp, _vp, _i64, _i64, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mp_linear_block_f32": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _int, _dbl, _dbl, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _dbl, _vp, _int, _vp]),
     "mp_bn_relu_drop_rows_f32": (_int, [_vp, _i64, _i64, _int, _dbl, _dbl, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _dbl, _vp, _int, _vp]),
     "mp_bn_relu_drop_rows_bwd_f32": (_int, [_vp, _vp, _vp, _i64, _i64, _int, _vp, _vp, _vp, _vp, _vp, _vp, _dbl, _vp]),
     "mp_knn_workspace_bytes": (_sz, [_i64, _i64, _i64]),

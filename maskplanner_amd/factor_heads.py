@@ -54,6 +54,71 @@ class _FactorLinear(torch.autograd.Function):
         return gx, None, gb, None, None
 
 
+class _LinearBlock(torch.autograd.Function):
+    """dropout(relu(bn(linear(x)))) of one head block as ONE forward launch (csrc/loss_tail.hip: mp_linear_block_f32) with the weight
+    gradient kept as factors like _FactorLinear.  Backward: the BatchNorm + ReLU + dropout backward kernel, then the Linear's."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, store, key, training, momentum, eps, drop_p, rng, layer):
+        B, K = x.shape
+        N = weight.shape[0]
+        lin = torch.empty((B, N), dtype=torch.float32, device=x.device)
+        y = torch.empty_like(lin)
+        stats = torch.empty((2, N), dtype=torch.float32, device=x.device)
+        p = lambda t: None if t is None else t.data_ptr()
+        ops._run("linear_block", x, _lib.load().mp_linear_block_f32, p(x), p(weight), p(bias), B, N, K, int(training), float(momentum), float(eps),
+                 p(gamma), p(beta), p(running_mean), p(running_var), p(lin), p(y), stats[0].data_ptr(), stats[1].data_ptr(), float(drop_p), p(rng),
+                 int(layer))
+        ctx.save_for_backward(x, weight, lin, y, gamma, stats)
+        ctx.store, ctx.key, ctx.bias = store, key, bias
+        ctx.training, ctx.drop_p = bool(training), (float(drop_p) if rng is not None else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, grad_y):
+        x, weight, lin, y, gamma, stats = ctx.saved_tensors
+        B, N = lin.shape
+        grad_y = grad_y.contiguous().float()
+        g = torch.empty_like(lin)                       # gradient w.r.t. the Linear's output
+        gg = torch.empty((N,), dtype=torch.float32, device=x.device) if ctx.needs_input_grad[3] else None
+        gb = torch.empty((N,), dtype=torch.float32, device=x.device) if ctx.needs_input_grad[4] else None
+        p = lambda t: None if t is None else t.data_ptr()
+        lib = _lib.load()
+        if ctx.drop_p is not None:
+            ops._run("bn_relu_rows_bwd", x, lib.mp_bn_relu_drop_rows_bwd_f32, p(grad_y), p(y), p(lin), B, N, int(ctx.training), p(gamma),
+                     stats[0].data_ptr(), stats[1].data_ptr(), p(g), p(gg), p(gb), ctx.drop_p)
+        else:
+            ops._run("bn_relu_rows_bwd", x, lib.mp_bn_relu_rows_bwd_f32, p(grad_y), p(y), p(lin), B, N, int(ctx.training), p(gamma),
+                     stats[0].data_ptr(), stats[1].data_ptr(), p(g), p(gg), p(gb))
+        ctx.store[ctx.key] = (x.detach(), g)            # the factors of dW = g^T x
+        gx = g @ weight if ctx.needs_input_grad[0] else None
+        gbias = None
+        if ctx.bias is not None:
+            pending = ctx.store.get(BIAS_QUEUE)
+            if pending is not None:
+                pending.append((ctx.bias, g))
+            else:
+                gbias = g.sum(0)
+        return gx, None, gbias, gg, gb, None, None, None, None, None, None, None, None, None, None
+
+
+def linear_block(x, linear, bn, store, key, dropout):
+    """dropout(relu(bn(linear(x)))) in one launch; `store` as for factor_linear, dropout = (p, rng, layer) as for ops.bn_relu_rows
+    (rng None: no dropout).  The caller has advanced bn.num_batches_tracked."""
+    ops._need_hip(x)
+    training = bn.training or bn.running_mean is None
+    track = bn.track_running_stats and bn.running_mean is not None
+    momentum = bn.momentum if bn.momentum is not None else 1.0 / max(float(bn.num_batches_tracked), 1.0)
+    p, rng, layer = dropout
+    return _LinearBlock.apply(x.contiguous(), linear.weight, linear.bias, bn.weight, bn.bias, bn.running_mean if track else None,
+                              bn.running_var if track else None, store, key, training, momentum, bn.eps, p, rng, layer)
+
+
+def linear_block_supported(x, linear, bn, store):
+    return (store is not None and x.is_cuda and x.dtype == torch.float32 and x.ndim == 2 and x.shape[0] <= 32 and linear.in_features % 128 == 0
+            and linear.weight.is_contiguous() and getattr(bn, "sync_bn", None) in (None, False))
+
+
 BIAS_QUEUE = "__bias_grads__"     # store[BIAS_QUEUE] = []: FactorLinear queues (bias, dy) pairs instead of reducing each one
 
 

@@ -8,12 +8,14 @@ mask_conf_out, seg_conf_fc1/2, seg_conf_out.  The encoder (`sa1..sa3`) is the ho
 kernels; the regression heads are a handful of dense layers on a [B,1024] feature and stay on rocBLAS via torch
 (weight-bandwidth bound GEMMs, "next" in the scope table).
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops, sa_mlp
-from .factor_heads import factor_linear
+from .factor_heads import factor_linear, linear_block, linear_block_supported
 from .pointnet2_utils import PointNetSetAbstraction, PointNetSetAbstractionMsg
 
 
@@ -60,6 +62,18 @@ def _block(model, lin_out, bn, layer):
             and (sync is None or sync is False)):
         return ops.bn_relu_rows(lin_out, bn, dropout=(model.dropout.p, rng, layer))
     return model.dropout(_bn_relu(lin_out, bn))
+
+
+def _head_block(model, x, linear, bn, store, key, layer):
+    """One block of the heads: dropout(relu(bn(linear(x)))): Linear, then _block.  MASKPLANNER_FUSED_BLOCK=1 (with a training
+    harness's factor store and fused dropout, on the GPU): ONE launch (factor_heads.linear_block).  [r2] measured: +50 us per step -- the
+    32-workgroup kernel streams its 4 MB of weights in 64-byte pieces and is slower than rocBLAS's 12 us + the 5 us BatchNorm launch --
+    so the switch is off."""
+    rng = getattr(model, "fused_dropout", None)
+    if (rng is not None and model.training and bn.training and os.environ.get("MASKPLANNER_FUSED_BLOCK", "0") != "0"
+            and linear_block_supported(x, linear, bn, store)):
+        return linear_block(x, linear, bn, store, key, (model.dropout.p, rng, layer))
+    return _block(model, factor_linear(x, linear, store, key), bn, layer)
 
 
 def _bn_relu(x, bn):
@@ -189,8 +203,8 @@ class PointNet2Regressor_StrokeMasks(_SSGEncoder):
         fused = feat.is_cuda
         if fused:
             _tick(*([self.bn1, self.bn2] + ([self.sm_bn1, self.sm_bn2] if self.pred_stroke_masks else [])))
-        x = _block(self, factor_linear(feat, self.fc1, fs, "fc1.weight"), self.bn1, 0)
-        final = _block(self, factor_linear(x, self.fc2, fs, "fc2.weight"), self.bn2, 1)
+        x = _head_block(self, feat, self.fc1, self.bn1, fs, "fc1.weight", 0)
+        final = _head_block(self, x, self.fc2, self.bn2, fs, "fc2.weight", 1)
         x = factor_linear(final, self.fc3, fs, "fc3.weight")
 
         seg_conf = None
@@ -201,8 +215,8 @@ class PointNet2Regressor_StrokeMasks(_SSGEncoder):
 
         sm_out, mask_conf = None, None
         if self.pred_stroke_masks:
-            s1 = _block(self, factor_linear(feat, self.sm_fc1, fs, "sm_fc1.weight"), self.sm_bn1, 2)
-            s2 = _block(self, factor_linear(s1, self.sm_fc2, fs, "sm_fc2.weight"), self.sm_bn2, 3)
+            s1 = _head_block(self, feat, self.sm_fc1, self.sm_bn1, fs, "sm_fc1.weight", 2)
+            s2 = _head_block(self, s1, self.sm_fc2, self.sm_bn2, fs, "sm_fc2.weight", 3)
             sm_out = factor_linear(s2, self.sm_fc3, fs, "sm_fc3.weight").view(B, self.n_stroke_masks, -1)
             if self.mask_confidence_scores:
                 mask_conf = getattr(self, self._CONF_LAYER)(s2)
