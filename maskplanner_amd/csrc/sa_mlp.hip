@@ -31,6 +31,9 @@ namespace {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
+#ifndef MP_STORE_AUX
+#define MP_STORE_AUX 0      // cache-policy bits of the raw Z / G buffer stores ([r2] same-box sweep of 0 / nt / sc0 / sc0+sc1: 0 is best)
+#endif
 #ifndef MP_BK
 #define MP_BK 32
 #endif
@@ -1059,8 +1062,8 @@ __global__ __launch_bounds__(CO > 128 ? 512 : 256) void fwd_chunk_kernel(PosOper
         int libest = 0;
 #pragma unroll
         for (int r = 0; r < NV; r += 2) {
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[r]), zrsrc, zoff, rowc(r) * CO * 4, 0);
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[r + 1]), zrsrc, zoff, rowc(r + 1) * CO * 4, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[r]), zrsrc, zoff, rowc(r) * CO * 4, MP_STORE_AUX);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[r + 1]), zrsrc, zoff, rowc(r + 1) * CO * 4, MP_STORE_AUX);
             const f2 x = {v[r], v[r + 1]};
             c1 += x;
             c2 += x * x;
@@ -1443,8 +1446,8 @@ __global__ __launch_bounds__((CO >= 128 && CI == 128 ? 512 : 256), (CO >= 128 &&
                 const float* zr = sZ[cur] + (xrow0 + 4 * kq) * CI + ecol0 + 16 * h + l15;
 #pragma unroll
                 for (int i = 0; i < 4; i += 2) {
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ax[h][i]), grsrc, goff + 16 * h * 4, i * CI * 4, 0);
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ax[h][i + 1]), grsrc, goff + 16 * h * 4, (i + 1) * CI * 4, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ax[h][i]), grsrc, goff + 16 * h * 4, i * CI * 4, MP_STORE_AUX);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ax[h][i + 1]), grsrc, goff + 16 * h * 4, (i + 1) * CI * 4, MP_STORE_AUX);
                     const f2 zp = {zr[i * CI], zr[(i + 1) * CI]};
                     const f2 y = zp * f2{spx[h], spx[h]} + f2{tpx[h], tpx[h]};
                     const f2 dy = {y.x > 0.0f ? ax[h][i] : 0.0f, y.y > 0.0f ? ax[h][i + 1] : 0.0f};
@@ -1765,7 +1768,7 @@ __global__ __launch_bounds__(512) void bwd_first_kernel(PosOperand DZ, PosOperan
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i)      // rows past the workgroup's last position: dropped by the buffer's range check
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ax[i]), grsrc, goff, i * CIW * 4, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ax[i]), grsrc, goff, i * CIW * 4, MP_STORE_AUX);
             // the 4 coordinate / padding columns of grad_x0 carry no gradient: written as zeros so that the buffer is fully defined
             if (tid < DBK * 4) __builtin_amdgcn_raw_buffer_store_b32(0u, grsrc, ((kc * DBK + (tid >> 2)) * CIW + CIX + (tid & 3)) * 4, 0, 0);
             goff += DBK * CIW * 4;
