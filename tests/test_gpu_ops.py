@@ -250,11 +250,13 @@ def test_padded_lengths(oracle, ops):
 # ------------------------------------------------------------------------------------------------ mask matching
 @pytest.mark.parametrize("B,M,S,n_ids", [(4, 6, 999, 6), (3, 22, 449, 15), (3, 41, 1266, 41), (2, 33, 1333, 20),
                                          (2, 6, 99, 9), (2, 64, 500, 64), (2, 5, 64, 1)])
-def test_mask_match_vs_scipy(oracle, ops, B, M, S, n_ids):
+@pytest.mark.parametrize("id_map", [(3.0, 1.0), (0.37, -0.63), (3.0, 5000.0)], ids=["whole", "fractional", "large"])
+def test_mask_match_vs_scipy(oracle, ops, B, M, S, n_ids, id_map):
+    """id_map: whole-number ids below 2048 take the kernel's bitmap route to the unique ids, anything else the general one."""
     from scipy.optimize import linear_sum_assignment
     rng = np.random.default_rng(M * S)
     pred = (rng.normal(size=(B, M, S)) * 2).astype(np.float32)
-    ids = rng.integers(0, n_ids, size=(B, S)).astype(np.float32) * 3.0 + 1.0  # non-contiguous id values
+    ids = rng.integers(0, n_ids, size=(B, S)).astype(np.float32) * np.float32(id_map[0]) + np.float32(id_map[1])
     match, uniq, nt, status, cost = ops.mask_match(dev(pred), dev(ids), return_cost=True)
     match, uniq, nt, status, cost = (t.cpu().numpy() for t in (match, uniq, nt, status, cost))
     assert (status == 0).all()
