@@ -189,7 +189,8 @@ int mp_chamfer_reduce_bwd_f32(const float* grad_out, const int64_t* lengths, int
  *   first n_targets[b] valid); n_targets [B] i64; cost [B,M,M_cap] f32 or NULL.  M_cap = 64.
  *   status [B] i32: 0, or a bit set of the conditions the reference asserts on / raises for (match_col = -1 then):
  *   MP_MATCH_TOO_MANY_IDS (M > 64 or Kb > 64), MP_MATCH_PADDING_ID (a target id is the padding id -1: the assertion of
- *   loss_handler.py:852), MP_MATCH_INFEASIBLE (non-finite costs: scipy's ValueError at :875).  mp_mask_loss_f32 takes this
+ *   loss_handler.py:852), MP_MATCH_INFEASIBLE (non-finite costs: scipy's ValueError at :875; any NaN or infinite logit of
+ *   the sample gives such a cost here, because the masked sums are a product with the one-hot ranks).  mp_mask_loss_f32 takes this
  *   array and turns the loss into NaN when any entry is non-zero, so a bad batch cannot pass silently. */
 #define MP_MASK_CAP 64
 #define MP_MATCH_TOO_MANY_IDS 1
