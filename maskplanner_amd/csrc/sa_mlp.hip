@@ -2065,29 +2065,47 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(const float* __restrict__
 }
 
 // gp = g * [out > 0]; per-block partial sums (sum gp, sum gp*zmax) per channel.
-// grid (ceil(G / POOL_ROWS), ceil(C / 256)): a block handles POOL_ROWS groups x 256 channels, lanes along channels.
+// grid (ceil(G / rows), ceil(C / 256)): a block handles `rows` <= POOL_ROWS groups x 256 channels, lanes along channels; the host
+// picks fewer rows per block when G is small (the group_all level has 32 groups: 8 workgroups of 16 rows took 19 us, most of it
+// the dW clear below on 2048 threads).
 constexpr int POOL_ROWS = 16;
 __global__ __launch_bounds__(256) void pool_bwd_prep_kernel(const float* __restrict__ gout, const float* __restrict__ out,
-                                                            const float* __restrict__ zmax, int64_t G, int C,
+                                                            const float* __restrict__ zmax, int64_t G, int C, int rows,
                                                             float* __restrict__ gp, float* __restrict__ partials,
                                                             float* __restrict__ clear, size_t clear_n)
 {
     // clear: the level's dW block (accumulated with atomics by the kernels that follow) is zeroed here, in the first launch of the
-    // level's backward, instead of by a launch of its own
+    // level's backward, instead of by a launch of its own (16-byte stores when the block is aligned)
     {
         const size_t nthreads = (size_t)gridDim.x * gridDim.y * 256;
-        for (size_t i = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x; i < clear_n; i += nthreads) clear[i] = 0.0f;
+        const size_t me = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x;
+        const size_t n4 = (reinterpret_cast<uintptr_t>(clear) & 15) ? 0 : clear_n / 4;
+        for (size_t i = me; i < n4; i += nthreads) reinterpret_cast<float4*>(clear)[i] = float4{0.0f, 0.0f, 0.0f, 0.0f};
+        for (size_t i = 4 * n4 + me; i < clear_n; i += nthreads) clear[i] = 0.0f;
     }
     const int c = blockIdx.y * 256 + threadIdx.x;
     if (c >= C) return;
-    const int64_t g0 = (int64_t)blockIdx.x * POOL_ROWS;
-    const int64_t g1 = min(G, g0 + POOL_ROWS);
+    const int64_t g0 = (int64_t)blockIdx.x * rows;
+    const int n = (int)(min(G, g0 + rows) - g0);
+    // all of the block's rows in flight at once (3 x 16 independent loads per thread), then the sums in row order
+    float o[POOL_ROWS], gv[POOL_ROWS], zv[POOL_ROWS];
+#pragma unroll
+    for (int r = 0; r < POOL_ROWS; ++r) {
+        const bool in = r < n;
+        const size_t e = (size_t)(g0 + (in ? r : 0)) * C + c;
+        o[r] = in ? out[e] : 0.0f;
+        gv[r] = in ? gout[e] : 0.0f;
+        zv[r] = in ? zmax[e] : 0.0f;
+    }
     float s1 = 0.0f, s2 = 0.0f;
-    for (int64_t g = g0; g < g1; ++g) {
-        const float v = out[g * C + c] > 0.0f ? gout[g * C + c] : 0.0f;
-        gp[g * C + c] = v;
-        s1 += v;
-        s2 += v * zmax[g * C + c];
+#pragma unroll
+    for (int r = 0; r < POOL_ROWS; ++r) {
+        if (r < n) {
+            const float v = o[r] > 0.0f ? gv[r] : 0.0f;
+            gp[(size_t)(g0 + r) * C + c] = v;
+            s1 += v;
+            s2 += v * zv[r];
+        }
     }
     partials[((int64_t)blockIdx.x * 2 + 0) * C + c] = s1;
     partials[((int64_t)blockIdx.x * 2 + 1) * C + c] = s2;
@@ -2539,9 +2557,12 @@ static int sa_mlp_bwd(const float* x0, int64_t P, int64_t K, int n_layers, const
     // pooled gradient through the last ReLU + its BatchNorm-backward sums
     {
         const int C = (int)last.c_out;
-        const int nb = (int)((G + POOL_ROWS - 1) / POOL_ROWS);
+        // rows of pooled groups per workgroup: POOL_ROWS, fewer while that leaves fewer than ~512 workgroups and the partial rows fit
+        int rows = POOL_ROWS;
+        while (rows > 1 && ((G + rows - 1) / rows) * ((C + 255) / 256) < 512 && (size_t)((G + rows / 2 - 1) / (rows / 2)) <= nblk_max) rows >>= 1;
+        const int nb = (int)((G + rows - 1) / rows);
         if ((size_t)nb > nblk_max) return MP_EUNSUPPORTED;  // partials hold P/64 rows: needs K >= 4
-        hipLaunchKernelGGL(pool_bwd_prep_kernel, dim3(nb, (C + 255) / 256), dim3(256), 0, stream, grad_out, out, zmax, G, C, gp,
+        hipLaunchKernelGGL(pool_bwd_prep_kernel, dim3(nb, (C + 255) / 256), dim3(256), 0, stream, grad_out, out, zmax, G, C, rows, gp,
                            partials, dw_joint ? grads[0].d_weight : nullptr, dw_joint ? dw_total : (size_t)0);
         MP_CHECK_LAUNCH();
         if (int rc = finalize_bwd(L - 1, nb, C)) return rc;
