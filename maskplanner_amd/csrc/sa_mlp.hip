@@ -700,6 +700,35 @@ __global__ __launch_bounds__(256) void pool_select_kernel(PoolOut po, const floa
                                                           const float* __restrict__ t, int64_t G, int C,
                                                           float* __restrict__ out, int* __restrict__ argk,
                                                           float* __restrict__ zmax)
+{   // four channels per thread (C % 4 == 0, every buffer 16-byte aligned: the host checks); the min side is only read where a
+    // scale is negative
+    const int64_t e = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (e >= G * C) return;
+    const int c = (int)(e % C);
+    const float4 sc = *reinterpret_cast<const float4*>(s + c), sh = *reinterpret_cast<const float4*>(t + c);
+    float4 z = *reinterpret_cast<const float4*>(po.vmax + e);
+    int4 k = *reinterpret_cast<const int4*>(po.imax + e);
+    if (sc.x < 0.0f || sc.y < 0.0f || sc.z < 0.0f || sc.w < 0.0f) {
+        const float4 zn = *reinterpret_cast<const float4*>(po.vmin + e);
+        const int4 kn = *reinterpret_cast<const int4*>(po.imin + e);
+        if (sc.x < 0.0f) { z.x = zn.x; k.x = kn.x; }
+        if (sc.y < 0.0f) { z.y = zn.y; k.y = kn.y; }
+        if (sc.z < 0.0f) { z.z = zn.z; k.z = kn.z; }
+        if (sc.w < 0.0f) { z.w = zn.w; k.w = kn.w; }
+    }
+    float4 y;
+    y.x = z.x * sc.x + sh.x; y.y = z.y * sc.y + sh.y; y.z = z.z * sc.z + sh.z; y.w = z.w * sc.w + sh.w;
+    y.x = y.x > 0.0f ? y.x : 0.0f; y.y = y.y > 0.0f ? y.y : 0.0f; y.z = y.z > 0.0f ? y.z : 0.0f; y.w = y.w > 0.0f ? y.w : 0.0f;
+    *reinterpret_cast<float4*>(out + e) = y;
+    *reinterpret_cast<int4*>(argk + e) = k;
+    *reinterpret_cast<float4*>(zmax + e) = z;
+}
+
+// the same, one channel per thread: for a channel count or buffers that do not take 16-byte accesses
+__global__ __launch_bounds__(256) void pool_select_scalar_kernel(PoolOut po, const float* __restrict__ s,
+                                                                 const float* __restrict__ t, int64_t G, int C,
+                                                                 float* __restrict__ out, int* __restrict__ argk,
+                                                                 float* __restrict__ zmax)
 {
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (e >= G * C) return;
@@ -2430,8 +2459,15 @@ static int sa_mlp_fwd(const float* x0, int64_t P, int64_t K, int n_layers, const
     const int64_t G = P / K;
     const int64_t tot = G * LL.c_out;
     if (fused_pool) {
-        MP_LAUNCH("pool_select_kernel", 0.0, 28.0 * (double)tot, pool_select_kernel, dim3((unsigned)((tot + 255) / 256)),
-                  dim3(256), 0, stream, po, LL.scale, LL.shift, G, (int)LL.c_out, out, argk, zmax);
+        const bool wide = !(LL.c_out & 3) && !((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(argk) | reinterpret_cast<uintptr_t>(zmax) |
+                                                reinterpret_cast<uintptr_t>(LL.scale) | reinterpret_cast<uintptr_t>(LL.shift) | reinterpret_cast<uintptr_t>(po.vmax) |
+                                                reinterpret_cast<uintptr_t>(po.vmin) | reinterpret_cast<uintptr_t>(po.imax) | reinterpret_cast<uintptr_t>(po.imin)) & 15);
+        if (wide)
+            MP_LAUNCH("pool_select_kernel", 0.0, 28.0 * (double)tot, pool_select_kernel, dim3((unsigned)((tot / 4 + 255) / 256)),
+                      dim3(256), 0, stream, po, LL.scale, LL.shift, G, (int)LL.c_out, out, argk, zmax);
+        else
+            MP_LAUNCH("pool_select_kernel", 0.0, 28.0 * (double)tot, pool_select_scalar_kernel, dim3((unsigned)((tot + 255) / 256)),
+                      dim3(256), 0, stream, po, LL.scale, LL.shift, G, (int)LL.c_out, out, argk, zmax);
         MP_CHECK_LAUNCH();
         return MP_OK;
     }
