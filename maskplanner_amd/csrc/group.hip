@@ -195,8 +195,13 @@ __global__ __launch_bounds__(256) void group_bwd_atomic_kernel(const float* __re
 // read once, coalesced, and every destination row is written once.  (Summation order follows the LDS list order, i.e. it
 // is not fixed: this is the non-deterministic variant's replacement; the ordered kernel above stays for deterministic runs.)
 constexpr int GP = 16, GCAP = 1024, GOVF = 2048;
+// Row widths beyond one wave's reach (D / 4 > 64 float4 pieces: the 320 concatenated features of a multi-scale level) are
+// cut into column slabs of `slab` floats along gridDim.z (the last one may be narrower); every slab's workgroup repeats the index
+// scan.  Narrow slabs also spread a HOT point (ball-query padding repeats one index up to K times per group, so a few points
+// collect thousands of rows and their wave sums them alone) over several workgroups: measured at D = 320, one workgroup looping
+// over the slabs from one scan 577 us, slabs of 128 along the grid 537 us.
 __global__ __launch_bounds__(256) void group_bwd_gather_kernel(const float* __restrict__ grad_out, const int64_t* __restrict__ idx,
-                                                               int N, int M, int D, float* __restrict__ grad_feats)
+                                                               int N, int M, int D, int slab, float* __restrict__ grad_feats)
 {
     __shared__ int cnt[GP];
     __shared__ int novf;
@@ -206,9 +211,10 @@ __global__ __launch_bounds__(256) void group_bwd_gather_kernel(const float* __re
     const int b = blockIdx.y, n0 = blockIdx.x * GP;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int Cs = D + 4;
+    const int c0 = blockIdx.z * slab, Dw = min(slab, D - c0);      // this workgroup's columns [c0, c0 + Dw)
     const int64_t* bi = idx + (size_t)b * M;
-    const float* gb = grad_out + (size_t)b * M * Cs;
-    float* dst = grad_feats + ((size_t)b * N + n0) * D;
+    const float* gb = grad_out + (size_t)b * M * Cs + c0;
+    float* dst = grad_feats + ((size_t)b * N + n0) * D + c0;
     const int npts = min(GP, N - n0);
     if (tid < GP) cnt[tid] = 0;
     if (tid == 0) novf = 0;
@@ -237,22 +243,22 @@ __global__ __launch_bounds__(256) void group_bwd_gather_kernel(const float* __re
     __syncthreads();
     if (novf > GOVF) {
         // pathological skew (more than GCAP + GOVF rows on this workgroup's points): plain atomics for the whole workgroup
-        for (int e = tid; e < npts * D; e += 256) dst[e] = 0.0f;
+        for (int e = tid; e < npts * Dw; e += 256) dst[(size_t)(e / Dw) * D + e % Dw] = 0.0f;
         __syncthreads();
         for (int m = tid; m < M; m += 256) {
             const int64_t i = bi[m];
             const int r = (int)(i - n0);
             if (i >= n0 && r < npts) {
                 const float* g = gb + (size_t)m * Cs;
-                for (int c = 0; c < D; ++c) atomicAdd(dst + (size_t)r * D + c, g[c]);
+                for (int c = 0; c < Dw; ++c) atomicAdd(dst + (size_t)r * D + c, g[c]);
             }
         }
         return;
     }
-    const int q = D / 4;                       // float4 pieces per row (<= 64)
+    const int no = novf;
+    const int q = Dw / 4;                      // float4 pieces per row of the slab (<= 64)
     const int rpw = 64 / q;                    // rows a wave reads at once (2 for D = 128)
     const int sub = lane / q, ql = lane - sub * q;
-    const int no = novf;
     for (int r = wave; r < npts; r += 4) {
         const int n = min(cnt[r], GCAP);
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -461,12 +467,17 @@ extern "C" int mp_group_bwd_f32(const float* grad_out, const int64_t* idx, int64
         const int64_t rows = B * N;
         hipLaunchKernelGGL(scatter_rows_ordered_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream,
                            grad_out, idx, N, D, S * K, grad_stride, (int64_t)(xyz_last ? 0 : 3), rows, grad_feats);
-    } else if (xyz_last && D > 0 && (D == 64 || D == 128 || D == 256) && grad_stride == D + 4 && S * K < 65536 && B < 65536 &&
+    } else if (xyz_last && D > 0 && (D == 64 || D == 128 || D == 256 || (D % 64 == 0 && D <= 1024)) && grad_stride == D + 4 && S * K < 65536 && B < 65536 &&
                N < ((int64_t)1 << 30) && (reinterpret_cast<uintptr_t>(grad_out) & 15) == 0 &&
                (reinterpret_cast<uintptr_t>(grad_feats) & 15) == 0) {
         // rpw = 64 / (D/4) in {4, 2, 1}: the shuffle combine of the gather kernel covers exactly these
+        // one slab for the widths a wave covers by itself, else slabs of 128 columns (+ a 64-wide remainder): every slab width is in {64, 128, 256}
+        static const int slab_env = getenv("MP_GROUP_SLAB") ? atoi(getenv("MP_GROUP_SLAB")) : 0;     // experiments: 64 / 128 / 256
+        int slab = (D == 64 || D == 128 || D == 256) ? (int)D : 128;
+        if (slab_env == 64 || ((slab_env == 128 || slab_env == 256) && D % slab_env % 64 == 0)) slab = slab_env < D ? slab_env : (int)D;
         MP_LAUNCH("group_bwd_gather_kernel", 0.0, 4.0 * (double)(B * S * K) * (D + 2) + 4.0 * (double)(B * N * D), group_bwd_gather_kernel,
-                  dim3((unsigned)((N + GP - 1) / GP), (unsigned)B), dim3(256), 0, stream, grad_out, idx, (int)N, (int)(S * K), (int)D, grad_feats);
+                  dim3((unsigned)((N + GP - 1) / GP), (unsigned)B, (unsigned)((D + slab - 1) / slab)), dim3(256), 0, stream, grad_out, idx, (int)N,
+                  (int)(S * K), (int)D, slab, grad_feats);
     } else {
         if (!mp::zero_async(grad_feats, (size_t)(B * N * D), stream)) return MP_ELAUNCH;
         const int64_t total = B * S * K * D;

@@ -152,7 +152,8 @@ def test_group_and_backward(oracle, ops, D, xyz_last):
                 np.testing.assert_allclose(f.grad.cpu().numpy(), want_g, rtol=1e-5, atol=1e-6)
 
 
-@pytest.mark.parametrize("D,S,K,every", [(64, 64, 32, 3), (128, 64, 32, 3), (256, 64, 32, 3), (128, 128, 64, 3), (128, 128, 64, 1)])
+@pytest.mark.parametrize("D,S,K,every", [(64, 64, 32, 3), (128, 64, 32, 3), (256, 64, 32, 3), (128, 128, 64, 3), (128, 128, 64, 1),
+                                         (320, 64, 32, 3), (192, 128, 64, 1), (320, 128, 64, 1)])   # 320 = the multi-scale level's concatenated features: column slabs
 def test_group_internal_layout_fast_paths(oracle, ops, D, S, K, every):
     """The set-abstraction modules group with features first and rows padded to D + 4 floats: float4 row gather forward,
     atomic-free gather-reduce backward (csrc/group.hip).  One source point of cloud 1 is gathered by every `every`-th row:
