@@ -8,6 +8,8 @@ reference's state_dict stays valid.
 """
 import ctypes
 
+import os
+
 import torch
 
 from . import _lib, ops
@@ -406,5 +408,38 @@ def shared_mlp_max(grouped, convs, bns, layout="xyz_first", dtype="f32", sync_bn
     bn0 = bns[0]
     momentum = bn0.momentum if bn0.momentum is not None else 1.0 / max(float(bn0.num_batches_tracked), 1.0)
     grad_cols = cin - 3 if (layout == "feats_first" and cin > 3) else 0
+    writeback = _widen_interior(params, [c.out_channels for c in convs]) if (dtype == "f32" and sync_group is False and WIDEN_INTERIOR) else []
     out = _SharedMLPMax.apply(x, K, training, momentum, bn0.eps, len(convs), grad_cols, dtype == "bf16", sync_group, *params)
+    if training:
+        for dst, src in writeback:          # running statistics of the real channels back into the module's buffers
+            dst.copy_(src[:dst.numel()])
     return out.view(B, S, -1)
+
+
+# The position-stream kernels (one pass over Z per layer, forward and backward) exist for layer widths 64 / 128 / 256; every other
+# width takes the tiled GEMMs (separate dX and dW passes).  An INTERIOR width between them -- the 96 of the multi-scale level
+# [64, 96, 128] at 2 M positions -- is cheaper carried as 128 with 32 dead channels: zero weight rows / bias, gamma 1, beta 0 give
+# z = 0, BatchNorm maps that to exactly 0, ReLU keeps it, the next layer's zero columns ignore it, and every gradient of the dead
+# channels is exactly 0 (dy = 0 there).  The padding is made of autograd ops, so the parameters keep their shapes and gradients.
+WIDEN_INTERIOR = os.environ.get("MASKPLANNER_WIDEN_INTERIOR", "1") != "0"
+
+
+def _widen_interior(params, widths):
+    """In place on the per-layer [w, bias, gamma, beta, running_mean, running_var] list.  Returns [(module buffer, widened copy)]."""
+    import torch.nn.functional as F
+    writeback = []
+    for i, c in enumerate(widths[:-1]):
+        if not 64 < c < 128:
+            continue
+        p = 128 - c
+        w, bias, gamma, beta, rm, rv = params[6 * i:6 * i + 6]
+        params[6 * i + 0] = F.pad(w, (0, 0, 0, p))
+        params[6 * i + 1] = None if bias is None else F.pad(bias, (0, p))
+        params[6 * i + 2] = F.pad(gamma, (0, p), value=1.0)
+        params[6 * i + 3] = F.pad(beta, (0, p))
+        if rm is not None:
+            rmw, rvw = F.pad(rm.detach(), (0, p)), F.pad(rv.detach(), (0, p), value=1.0)
+            params[6 * i + 4], params[6 * i + 5] = rmw, rvw
+            writeback += [(rm, rmw), (rv, rvw)]
+        params[6 * (i + 1)] = F.pad(params[6 * (i + 1)], (0, p))
+    return writeback

@@ -533,6 +533,52 @@ def test_msg_encoder_full_size_vs_oracle(oracle):
     close(out.permute(0, 2, 1), o_out, "msg features", rtol=1e-4, atol=1e-4)   # train-mode BN at small B: a little above 1e-5
 
 
+@pytest.mark.parametrize("train", [True, False])
+def test_interior_width_96_carried_as_128_changes_nothing(monkeypatch, train):
+    """A [64, 96, 128] level (the multi-scale encoder's third scale) runs its 96-wide layer as 128 with 32 dead channels so that
+    the position-stream kernels take it (sa_mlp._widen_interior).  Against the same level on the tiled kernels: output, every
+    parameter gradient and the running statistics agree, and the parameters keep their shapes."""
+    from maskplanner_amd import sa_mlp
+    import torch.nn as nn
+    rng = np.random.default_rng(96)
+    B, S, K = 2, 64, 32
+    grouped = dev(rng.normal(size=(B, S, K, 4)).astype(np.float32))
+    grouped[..., 3] = 0.0
+    g_out = dev(rng.normal(size=(B, S, 128)).astype(np.float32))
+
+    def build():
+        torch.manual_seed(11)
+        convs, bns, last = nn.ModuleList(), nn.ModuleList(), 3
+        for c in (64, 96, 128):
+            convs.append(nn.Conv2d(last, c, 1))
+            bns.append(nn.BatchNorm2d(c))
+            last = c
+        for bn in bns:
+            with torch.no_grad():
+                bn.weight.uniform_(0.5, 1.5)
+                bn.bias.uniform_(-0.2, 0.2)
+                bn.running_mean.uniform_(-0.1, 0.1)
+                bn.running_var.uniform_(0.5, 1.5)
+        return convs.cuda().train(train), bns.cuda().train(train)
+
+    res = {}
+    for widen in (False, True):
+        monkeypatch.setattr(sa_mlp, "WIDEN_INTERIOR", widen)
+        convs, bns = build()
+        out = sa_mlp.shared_mlp_max(grouped, convs, bns)
+        out.backward(g_out)
+        res[widen] = (out.detach(), [p.grad.clone() for m in (convs, bns) for p in m.parameters()],
+                      [b_.clone() for bn in bns for b_ in (bn.running_mean, bn.running_var)],
+                      [tuple(p.shape) for m in (convs, bns) for p in m.parameters()])
+    assert res[True][3] == res[False][3]
+    close(res[True][0], res[False][0], "output", rtol=2e-5, atol=2e-5)
+    for i, (a, b_) in enumerate(zip(res[True][1], res[False][1])):
+        scale = float(b_.abs().max()) + 1e-6
+        assert float((a - b_).abs().max()) <= 2e-4 * scale + 1e-6, (i, float((a - b_).abs().max()), scale)
+    for a, b_ in zip(res[True][2], res[False][2]):
+        close(a, b_, "running statistics", rtol=1e-5, atol=1e-6)
+
+
 # ------------------------------------------------------------------------------------------------ factor heads
 @pytest.mark.parametrize("B", [32, 96, 250])
 def test_factor_adam_matches_torch_adam(B):
