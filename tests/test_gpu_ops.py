@@ -152,6 +152,20 @@ def test_group_and_backward(oracle, ops, D, xyz_last):
                 np.testing.assert_allclose(f.grad.cpu().numpy(), want_g, rtol=1e-5, atol=1e-6)
 
 
+def test_group_coordinates_only_padded_rows(oracle, ops):
+    """The first level groups coordinates only, rows padded to 4 floats (group_xyz_kernel): [dx, dy, dz, 0] per neighbour, bit-exact,
+    including out-of-range indices (clamped like the generic kernel) and a ragged last block of rows."""
+    rng = np.random.default_rng(40)
+    B, N, S, K = 3, 333, 37, 19
+    xyz = rng.normal(size=(B, N, 3)).astype(np.float32)
+    new_xyz = xyz[:, :S].copy()
+    idx = rng.integers(0, N, size=(B, S, K))
+    want = oracle.group(xyz, None, new_xyz, idx)
+    out = ops.group(dev(xyz), None, dev(new_xyz), dev(idx), xyz_last=True, pad_to=4).cpu().numpy()
+    assert out.shape == (B, S, K, 4)
+    assert np.array_equal(out[..., :3], want) and not out[..., 3].any()
+
+
 @pytest.mark.parametrize("D,S,K,every", [(64, 64, 32, 3), (128, 64, 32, 3), (256, 64, 32, 3), (128, 128, 64, 3), (128, 128, 64, 1),
                                          (320, 64, 32, 3), (192, 128, 64, 1), (320, 128, 64, 1)])   # 320 = the multi-scale level's concatenated features: column slabs
 def test_group_internal_layout_fast_paths(oracle, ops, D, S, K, every):
