@@ -148,3 +148,41 @@ def test_metrics_handler_bookkeeping_and_collate_validation_without_a_gpu(capsys
     assert Paintnet_ODv1_CollateBatch({"load_extra_data": ["stroke_masks"]}).load_extra_data == ["stroke_masks"]
     with pytest.raises(NotImplementedError, match="stroke_prototypes"):
         Paintnet_ODv1_CollateBatch({"load_extra_data": ["stroke_prototypes"]})
+
+
+def test_widen_interior_pads_with_dead_channels_and_keeps_the_parameters():
+    """sa_mlp._widen_interior: an interior width between 64 and 128 becomes 128 -- zero weight rows / bias, gamma 1, beta 0,
+    running (mean 0, var 1), zero columns in the next layer's weight; first / last widths and the other layers stay as they are;
+    the padding is autograd-visible, so the gradients come back in the parameters' own shapes.  (Pure tensor logic: runs without a GPU.)"""
+    import torch
+    from maskplanner_amd import sa_mlp
+    torch.manual_seed(0)
+    widths, cin = [64, 96, 128], 4
+    params, leaves, last = [], [], cin
+    for c in widths:
+        w = torch.randn(c, last, requires_grad=True)
+        bias, gamma, beta = (torch.randn(c, requires_grad=True) for _ in range(3))
+        rm, rv = torch.randn(c), torch.rand(c) + 0.5
+        params += [w, bias, gamma, beta, rm, rv]
+        leaves += [w, bias, gamma, beta]
+        last = c
+    orig = list(params)
+    back = sa_mlp._widen_interior(params, widths)
+    assert [tuple(p.shape) for p in params[0:6]] == [tuple(p.shape) for p in orig[0:6]]          # the 64-wide layer: untouched
+    w1, b1, g1, be1, rm1, rv1 = params[6:12]
+    assert w1.shape == (128, 64) and torch.equal(w1[:96], orig[6]) and not w1[96:].any()
+    assert torch.equal(b1[:96], orig[7]) and not b1[96:].any()
+    assert torch.equal(g1[:96], orig[8]) and torch.equal(g1[96:], torch.ones(32))
+    assert torch.equal(be1[:96], orig[9]) and not be1[96:].any()
+    assert torch.equal(rm1[:96], orig[10]) and not rm1[96:].any() and torch.equal(rv1[96:], torch.ones(32))
+    w2 = params[12]
+    assert w2.shape == (128, 128) and torch.equal(w2[:, :96], orig[12]) and not w2[:, 96:].any()
+    assert [tuple(p.shape) for p in params[13:18]] == [tuple(p.shape) for p in orig[13:18]]      # the last layer's rows: untouched
+    assert len(back) == 2 and back[0][0] is orig[10] and back[1][0] is orig[11]                  # running stats to write back
+    (w1.sum() + g1.sum() * 2.0 + w2.sum() * 3.0 + b1.sum() + be1.sum()).backward()
+    for p_, want in ((orig[6], 1.0), (orig[8], 2.0), (orig[12], 3.0), (orig[7], 1.0), (orig[9], 1.0)):
+        assert p_.grad.shape == p_.shape and torch.equal(p_.grad, torch.full_like(p_, want))
+    # nothing to widen: the list is returned as it was
+    p2 = list(orig[:6]) + list(orig[12:18])
+    same = list(p2)
+    assert sa_mlp._widen_interior(p2, [64, 128]) == [] and all(a is b for a, b in zip(p2, same))
