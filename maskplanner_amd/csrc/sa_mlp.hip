@@ -2266,6 +2266,145 @@ extern "C" int mp_sa_mlp_recompute_first(int n_layers, const int64_t* channels, 
 
 // The gathered-input form (mp_sa_mlp_{fwd,bwd}_gather_f32) covers what BASELINE's second set-abstraction level is: a first layer of
 // [128 features | xyz | pad] -> 128 behind at least one more layer, fp32 results, fused kernels enabled.
+// =================================================================================================================
+// Factorised first layer of a level with input features (models/pointnet2_utils.py:138 + :208-213).  The layer is linear in
+// [f_i ; x_i - c], so  Z_0[p] = A[b, idx[p]] + W_x (x[b, idx[p]] - c[group(p)])  with  A = F W_f^T  computed ONCE per source
+// point by the caller (a [B*N, CF] x [CF, Co] GEMM, 16x fewer rows than the grouped tensor at K = 64 / N = 512 / S = 128): a
+// gather-add instead of a GEMM over the grouped rows, which need not exist.  The gather descriptor then carries A as its
+// `feats` ([B, N, Co], CF == Co) and layers[0] is the coordinate part alone: weight [Co, 4] (W_x | 0), c_in == 4.
+//   forward : this kernel writes the raw Z_0 and the BatchNorm partial sums (one row per workgroup), everything after it is the
+//             ordinary chain (layer 1 reads act(Z_0) like any other layer);
+//   backward: one pass over (Z_0, G_0) writes dZ_0 [P, Co + 4] -- it IS the gradient of the gathered A rows; the caller reduces it
+//             over the gathering rows (mp_group_bwd_f32) and finishes dW_f, dF with two small GEMMs -- and accumulates dW_x from
+//             the gathered coordinates (first_factored_bwd_kernel).
+// Same mathematics as the grouped GEMM, a different fp32 summation order (W_f f is rounded before W_x d is added).
+// =================================================================================================================
+template <int Q>   // Q = Co / 4: lanes per row
+__global__ __launch_bounds__(256) void first_factored_fwd_kernel(const float* __restrict__ A, const float* __restrict__ xyz,
+                                                                 const float* __restrict__ new_xyz, const int64_t* __restrict__ idx,
+                                                                 const float* __restrict__ Wx, int P, int K, int kshift, int N, int per,
+                                                                 int gshift, int ppb, float* __restrict__ Z0, float* __restrict__ partials)
+{
+    constexpr int CO = 4 * Q, RW = 64 / Q, RB = 4 * RW, U = 4;      // rows per wave / per workgroup pass, passes in flight
+    __shared__ float red[2][RB][CO];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ql = lane % Q, slot = wave * RW + lane / Q;
+    float4 w[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w[j] = ld4(Wx + (size_t)(4 * ql + j) * 4);
+    const int p0 = blockIdx.x * ppb, p1 = min(P, p0 + ppb);
+    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+    for (int p = p0 + slot; p < p1; p += RB * U) {
+        float4 a[U];
+        float dx[U], dy[U], dz[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int pp = min(p + u * RB, p1 - 1);
+            const unsigned b = gshift >= 0 ? (unsigned)pp >> gshift : (unsigned)pp / (unsigned)per;
+            const unsigned grp = kshift >= 0 ? (unsigned)pp >> kshift : (unsigned)pp / (unsigned)K;
+            const size_t src = (size_t)b * (unsigned)N + (size_t)idx[pp];
+            a[u] = ld4(A + src * CO + 4 * ql);
+            const float* x = xyz + src * 3;
+            const float* c = new_xyz + (size_t)grp * 3;
+            dx[u] = x[0] - c[0]; dy[u] = x[1] - c[1]; dz[u] = x[2] - c[2];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int pp = p + u * RB;
+            if (pp < p1) {
+                float4 z;
+                z.x = a[u].x + __builtin_fmaf(w[0].z, dz[u], __builtin_fmaf(w[0].y, dy[u], w[0].x * dx[u]));
+                z.y = a[u].y + __builtin_fmaf(w[1].z, dz[u], __builtin_fmaf(w[1].y, dy[u], w[1].x * dx[u]));
+                z.z = a[u].z + __builtin_fmaf(w[2].z, dz[u], __builtin_fmaf(w[2].y, dy[u], w[2].x * dx[u]));
+                z.w = a[u].w + __builtin_fmaf(w[3].z, dz[u], __builtin_fmaf(w[3].y, dy[u], w[3].x * dx[u]));
+                *reinterpret_cast<float4*>(Z0 + (size_t)pp * CO + 4 * ql) = z;
+                s1.x += z.x; s1.y += z.y; s1.z += z.z; s1.w += z.w;
+                s2.x += z.x * z.x; s2.y += z.y * z.y; s2.z += z.z * z.z; s2.w += z.w * z.w;
+            }
+        }
+    }
+    *reinterpret_cast<float4*>(&red[0][slot][4 * ql]) = s1;
+    *reinterpret_cast<float4*>(&red[1][slot][4 * ql]) = s2;
+    __syncthreads();
+    for (int e = tid; e < 2 * CO; e += 256) {
+        const int st = e / CO, c = e - st * CO;
+        float v = 0.0f;
+#pragma unroll
+        for (int r = 0; r < RB; ++r) v += red[st][r][c];
+        partials[((size_t)blockIdx.x * 2 + st) * CO + c] = v;
+    }
+}
+
+// Backward of the factorised first layer in ONE pass over (Z_0, G_0): dZ_0 rows written out [P, Co + 4] (the gradient of the gathered
+// A rows) and dW_x[c, j] += sum_p dZ_0[p, c] * (x[idx[p]] - c[group(p)])_j, reduced over the workgroup's rows in LDS and added to
+// dW [Co, 4] with one atomic per element and workgroup.
+template <int Q>
+__global__ __launch_bounds__(256) void first_factored_bwd_kernel(PosOperand DZ, const float* __restrict__ xyz, const float* __restrict__ new_xyz,
+                                                                 const int64_t* __restrict__ idx, int P, int K, int kshift, int N, int per,
+                                                                 int gshift, int ppb, float* __restrict__ dz_out, float* __restrict__ dW)
+{
+    constexpr int CO = 4 * Q, RW = 64 / Q, RB = 4 * RW, U = 4;
+    __shared__ float red[3][RB][CO];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ql = lane % Q, slot = wave * RW + lane / Q;
+    ChanConst k;
+    load_consts<SRC_DZ>(DZ, 4 * ql, k);
+    const int p0 = blockIdx.x * ppb, p1 = min(P, p0 + ppb);
+    float4 ax = make_float4(0.f, 0.f, 0.f, 0.f), ay = ax, az = ax;
+    for (int p = p0 + slot; p < p1; p += RB * U) {
+        float4 z[U], g[U];
+        float dx[U], dy[U], dzc[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int pp = min(p + u * RB, p1 - 1);
+            const unsigned b = gshift >= 0 ? (unsigned)pp >> gshift : (unsigned)pp / (unsigned)per;
+            const unsigned grp = kshift >= 0 ? (unsigned)pp >> kshift : (unsigned)pp / (unsigned)K;
+            const size_t src = (size_t)b * (unsigned)N + (size_t)idx[pp];
+            z[u] = ld4(DZ.x + (size_t)pp * CO + 4 * ql);
+            g[u] = ld4(DZ.g + (size_t)pp * CO + 4 * ql);
+            const float* x = xyz + src * 3;
+            const float* c = new_xyz + (size_t)grp * 3;
+            dx[u] = x[0] - c[0]; dy[u] = x[1] - c[1]; dzc[u] = x[2] - c[2];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int pp = p + u * RB;
+            if (pp < p1) {
+                float4 d;
+                d.x = xf1<SRC_DZ>(z[u].x, g[u].x, k.s.x, k.t.x, k.a.x, k.e.x, k.f.x);
+                d.y = xf1<SRC_DZ>(z[u].y, g[u].y, k.s.y, k.t.y, k.a.y, k.e.y, k.f.y);
+                d.z = xf1<SRC_DZ>(z[u].z, g[u].z, k.s.z, k.t.z, k.a.z, k.e.z, k.f.z);
+                d.w = xf1<SRC_DZ>(z[u].w, g[u].w, k.s.w, k.t.w, k.a.w, k.e.w, k.f.w);
+                *reinterpret_cast<float4*>(dz_out + (size_t)pp * (CO + 4) + 4 * ql) = d;
+                ax.x = __builtin_fmaf(d.x, dx[u], ax.x); ax.y = __builtin_fmaf(d.y, dx[u], ax.y); ax.z = __builtin_fmaf(d.z, dx[u], ax.z); ax.w = __builtin_fmaf(d.w, dx[u], ax.w);
+                ay.x = __builtin_fmaf(d.x, dy[u], ay.x); ay.y = __builtin_fmaf(d.y, dy[u], ay.y); ay.z = __builtin_fmaf(d.z, dy[u], ay.z); ay.w = __builtin_fmaf(d.w, dy[u], ay.w);
+                az.x = __builtin_fmaf(d.x, dzc[u], az.x); az.y = __builtin_fmaf(d.y, dzc[u], az.y); az.z = __builtin_fmaf(d.z, dzc[u], az.z); az.w = __builtin_fmaf(d.w, dzc[u], az.w);
+            }
+        }
+    }
+    *reinterpret_cast<float4*>(&red[0][slot][4 * ql]) = ax;
+    *reinterpret_cast<float4*>(&red[1][slot][4 * ql]) = ay;
+    *reinterpret_cast<float4*>(&red[2][slot][4 * ql]) = az;
+    __syncthreads();
+    for (int e = tid; e < 3 * CO; e += 256) {
+        const int j = e / CO, c = e - j * CO;
+        float v = 0.0f;
+#pragma unroll
+        for (int r = 0; r < RB; ++r) v += red[j][r][c];
+        atomicAdd(dW + (size_t)c * 4 + j, v);
+    }
+}
+
+// the factorised first layer's shapes: gather descriptor carrying A [B, N, Co], layers[0] = (W_x | 0) [Co, 4]
+static bool factored_ok(const mp_gather_t* g, int64_t P, int64_t K, int n_layers, const mp_mlp_layer_t* layers, bool bf16)
+{
+    if (!g || !g->feats || !g->xyz || !g->new_xyz || !g->idx || g->N <= 0 || g->S <= 0) return false;
+    if (bf16 || n_layers < 2 || layers[0].c_in != 4 || g->CF != layers[0].c_out) return false;
+    if (g->CF != 64 && g->CF != 128 && g->CF != 256) return false;
+    if (P % (g->S * K) != 0 || !layers[0].z) return false;
+    return true;
+}
+
 static bool gather_ok(const mp_gather_t* g, int64_t P, int64_t K, int n_layers, const mp_mlp_layer_t* layers, bool bf16)
 {
     if (!g || !g->feats || !g->xyz || !g->new_xyz || !g->idx || g->N <= 0 || g->S <= 0) return false;
@@ -2299,7 +2438,8 @@ static int sa_mlp_fwd(const float* x0, int64_t P, int64_t K, int n_layers, const
     if (P < 0 || K <= 0 || n_layers <= 0 || !layers) return MP_EINVAL;
     if (P == 0) return MP_OK;
     if ((!x0 && !gather) || !out || !argk || !zmax || !workspace || (P % K) != 0) return MP_EINVAL;
-    if (gather && !gather_ok(gather, P, K, n_layers, layers, bf16)) return MP_EUNSUPPORTED;
+    const bool factored = gather && factored_ok(gather, P, K, n_layers, layers, bf16);
+    if (gather && !factored && !gather_ok(gather, P, K, n_layers, layers, bf16)) return MP_EUNSUPPORTED;
     if (n_layers > 8 || P > ((int64_t)1 << 31)) return MP_EUNSUPPORTED;
     int64_t ch[9];
     ch[0] = layers[0].c_in;
@@ -2340,14 +2480,26 @@ static int sa_mlp_fwd(const float* x0, int64_t P, int64_t K, int n_layers, const
     A.C = (int)ch[0];
     A.K = (int)K;
     A.kshift = log2_or_neg(K);
-    if (gather) set_gather(A, gather, K);
+    if (gather && !factored) set_gather(A, gather, K);
     for (int l = 0; l < n_layers; ++l) {
         const mp_mlp_layer_t& L = layers[l];
         int nblk = 0, rc = MP_OK;
         const bool fuse_pool = (l == n_layers - 1) && fused_pool;
         const int Ci_ = (int)L.c_in, Co_ = (int)L.c_out;
         const bool last_unfused = (l == n_layers - 1) && !fused_pool;
-        if (l == 0 && rc_first) {
+        if (l == 0 && factored) {
+            const int ppb = 256;
+            nblk = (int)((P + ppb - 1) / ppb);
+            const double by = 4.0 * (2.0 * (double)P * Co_ + 5.0 * (double)P);
+            const int per = (int)(gather->S * K);
+#define MP_FACT(Q_)                                                                                                              \
+    MP_LAUNCH("first_factored_fwd_kernel", 8.0 * (double)P * Co_, by, (first_factored_fwd_kernel<Q_>), dim3((unsigned)nblk), dim3(256), 0,   \
+              stream, gather->feats, gather->xyz, gather->new_xyz, gather->idx, L.weight, (int)P, (int)K, log2_or_neg(K), (int)gather->N, per, \
+              log2_or_neg(per), ppb, L.z, partials)
+            if (Co_ == 64) MP_FACT(16); else if (Co_ == 128) MP_FACT(32); else MP_FACT(64);
+#undef MP_FACT
+            MP_CHECK_LAUNCH();
+        } else if (l == 0 && rc_first) {
             const int ppb = 1024;
             nblk = (int)((P + ppb - 1) / ppb);
             MP_LAUNCH("rc_stats_kernel", 8.0 * (double)P * Co_, 16.0 * (double)P, rc_stats_kernel, dim3((unsigned)nblk), dim3(256), 0, stream, x0,
@@ -2525,7 +2677,9 @@ static int sa_mlp_bwd(const float* x0, int64_t P, int64_t K, int n_layers, const
     if (P < 0 || K <= 0 || n_layers <= 0 || !layers || !grads) return MP_EINVAL;
     if (P == 0) return MP_OK;
     if ((!x0 && !gather) || !grad_out || !out || !argk || !zmax || !workspace || (P % K) != 0) return MP_EINVAL;
-    if (gather && (!gather_ok(gather, P, K, n_layers, layers, bf16) || !grad_x0 || grad_x0_cols != 128)) return MP_EUNSUPPORTED;
+    const bool factored = gather && factored_ok(gather, P, K, n_layers, layers, bf16);
+    if (factored && (!grad_x0 || grad_x0_cols != layers[0].c_out)) return MP_EINVAL;
+    if (gather && !factored && (!gather_ok(gather, P, K, n_layers, layers, bf16) || !grad_x0 || grad_x0_cols != 128)) return MP_EUNSUPPORTED;
     if (n_layers > 8) return MP_EUNSUPPORTED;
     int64_t ch[9];
     ch[0] = layers[0].c_in;
@@ -2623,7 +2777,7 @@ static int sa_mlp_bwd(const float* x0, int64_t P, int64_t K, int n_layers, const
         IN.C = Ci;
         IN.K = (int)K;
         IN.kshift = log2_or_neg(K);
-        if (l == 0) { IN.x = x0; if (gather) set_gather(IN, gather, K); }
+        if (l == 0) { IN.x = x0; if (gather && !factored) set_gather(IN, gather, K); }
         else { IN.x = layers[l - 1].z; IN.s = layers[l - 1].scale; IN.t = layers[l - 1].shift; }
         if (rc_first && l == 1) { IN.rx = x0; IN.rw = layers[0].weight; }   // act(Z_0) and raw Z_0 from the input rows
         if (rc_first && l == 0) { DZ.rx = x0; DZ.rw = Ly.weight; }          // dZ_0 = f(Z_0, G_0) likewise
@@ -2709,6 +2863,19 @@ static int sa_mlp_bwd(const float* x0, int64_t P, int64_t K, int n_layers, const
             else
                 MP_LAUNCH("bwd_first_kernel<2>", fl, by, (bwd_first_kernel<SRC_DZ>), dim3(gx), dim3(512), 0, stream, DZ, IN, (int)P, ppb, Ly.weight,
                           grads[l].d_weight, grad_x0);
+            MP_CHECK_LAUNCH();
+            continue;
+        }
+        if (factored && l == 0) {
+            // dW_x from the gathered coordinates, dZ_0 itself (= the gradient of the gathered A rows) out to the caller
+            const double fl = 2.0 * (double)P * Co * 4, by = 4.0 * (2.0 * (double)P * Co + 5.0 * (double)P);
+            const int ppb = 256, per = (int)(gather->S * K);
+            const unsigned gxf = (unsigned)((P + ppb - 1) / ppb);
+#define MP_FACT_B(Q_)                                                                                                            \
+    MP_LAUNCH("first_factored_bwd_kernel", fl, by + 4.0 * (double)P * Co, (first_factored_bwd_kernel<Q_>), dim3(gxf), dim3(256), 0, stream, DZ, gather->xyz, \
+              gather->new_xyz, gather->idx, (int)P, (int)K, log2_or_neg(K), (int)gather->N, per, log2_or_neg(per), ppb, grad_x0, grads[l].d_weight)
+            if (Co == 64) MP_FACT_B(16); else if (Co == 128) MP_FACT_B(32); else MP_FACT_B(64);
+#undef MP_FACT_B
             MP_CHECK_LAUNCH();
             continue;
         }

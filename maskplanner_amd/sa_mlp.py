@@ -200,6 +200,137 @@ class _SharedMLPMaxGathered(torch.autograd.Function):
         return (gf, None, None, None, None, None, None, None, *ret)
 
 
+class _SharedMLPMaxFactored(torch.autograd.Function):
+    """The level with its first layer factorised (sa_mlp.hip, first_factored_fwd_kernel): Z_0[p] = A[b, idx[p]] + W_x (x[idx[p]] - c),
+    A = F W_f^T computed per SOURCE point by the caller.  args: A [B,N,Co] (carries the gradient), xyz [B,N,3], new_xyz [B,S,3],
+    idx [B,S,K] i64, training, momentum, eps, L, then the layers' parameters as for _SharedMLPMax with layer 0 = (W_x | 0) [Co, 4].
+    Backward: the library writes dZ_0 [P, Co + 4]; its reduction over the gathering rows (ops.group's backward kernel) is dA."""
+
+    @staticmethod
+    def forward(ctx, A, xyz, new_xyz, idx, training, momentum, eps, n_layers, *params):
+        dev = A.device
+        B, N, C0 = A.shape
+        _, S, K = idx.shape
+        P = B * S * K
+        layers = (_lib.MlpLayer * n_layers)()
+        keep = []
+        chans = [4] + [params[6 * l].shape[0] for l in range(n_layers)]
+        lib = _lib.load()
+        for l in range(n_layers):
+            w, b, gam, bet, rm, rv = params[6 * l:6 * l + 6]
+            co, ci = w.shape
+            z = torch.empty((P, co), dtype=torch.float32, device=dev)
+            stats = torch.empty((4, co), dtype=torch.float32, device=dev)
+            keep.append((w, b, gam, bet, rm, rv, z, stats))
+            layers[l] = _lib.MlpLayer(_ptr(w), _ptr(b), _ptr(gam), _ptr(bet), _ptr(rm), _ptr(rv), ci, co, _ptr(z),
+                                      stats[0].data_ptr(), stats[1].data_ptr(), stats[2].data_ptr(), stats[3].data_ptr())
+        G = P // K
+        cl = chans[-1]
+        out = torch.empty((G, cl), dtype=torch.float32, device=dev)
+        argk = torch.empty((G, cl), dtype=torch.int32, device=dev)
+        zmax = torch.empty((G, cl), dtype=torch.float32, device=dev)
+        ch = (ctypes.c_int64 * len(chans))(*chans)
+        ws = torch.empty((lib.mp_sa_mlp_workspace_bytes(P, K, n_layers, ch, 0),), dtype=torch.uint8, device=dev)
+        g = _lib.Gather(_ptr(A), _ptr(xyz), _ptr(new_xyz), _ptr(idx), N, S, C0)
+        ops._run("sa_mlp_fwd", A, lib.mp_sa_mlp_fwd_gather_f32, ctypes.byref(g), P, K, n_layers, layers, int(training), float(momentum),
+                 float(eps), _ptr(out), _ptr(argk), _ptr(zmax), _ptr(ws), ws.numel())
+        ctx.meta = (P, K, bool(training), n_layers, chans, (B, N, S, C0))
+        ctx.keep = keep
+        ctx.save_for_backward(A, xyz, new_xyz, idx, out, argk, zmax)
+        ctx.mark_non_differentiable(argk, zmax)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        A, xyz, new_xyz, idx, out, argk, zmax = ctx.saved_tensors
+        P, K, training, n_layers, chans, (B, N, S, C0) = ctx.meta
+        dev = A.device
+        grad_out = grad_out.contiguous().float()
+        layers = (_lib.MlpLayer * n_layers)()
+        grads = (_lib.MlpGrads * n_layers)()
+        ret = []
+        dw_all = torch.empty((sum(k[0].numel() for k in ctx.keep),), dtype=torch.float32, device=dev)
+        dw_off = 0
+        for l, (w, b, gam, bet, rm, rv, z, stats) in enumerate(ctx.keep):
+            co, ci = w.shape
+            layers[l] = _lib.MlpLayer(_ptr(w), _ptr(b), _ptr(gam), _ptr(bet), _ptr(rm), _ptr(rv), ci, co, _ptr(z),
+                                      stats[0].data_ptr(), stats[1].data_ptr(), stats[2].data_ptr(), stats[3].data_ptr())
+            dw = dw_all[dw_off:dw_off + w.numel()].view_as(w)
+            dw_off += w.numel()
+            db = None if b is None else torch.empty_like(b)
+            dg, dbe = torch.empty_like(gam), torch.empty_like(bet)
+            grads[l] = _lib.MlpGrads(_ptr(dw), _ptr(db), _ptr(dg), _ptr(dbe))
+            ret += [dw, db, dg, dbe, None, None]
+        stride = C0 + 4
+        gz = torch.empty((P, stride), dtype=torch.float32, device=dev)       # dZ_0 rows (the pad quad is never read)
+        ch = (ctypes.c_int64 * len(chans))(*chans)
+        lib = _lib.load()
+        ws = torch.empty((lib.mp_sa_mlp_workspace_bytes(P, K, n_layers, ch, 1),), dtype=torch.uint8, device=dev)
+        g = _lib.Gather(_ptr(A), _ptr(xyz), _ptr(new_xyz), _ptr(idx), N, S, C0)
+        ops._run("sa_mlp_bwd", A, lib.mp_sa_mlp_bwd_gather_f32, ctypes.byref(g), P, K, n_layers, layers, int(training), _ptr(grad_out),
+                 _ptr(out), _ptr(argk), _ptr(zmax), grads, _ptr(gz), C0, _ptr(ws), ws.numel())
+        ctx.keep = None
+        gA = None
+        if ctx.needs_input_grad[0]:
+            gA = torch.empty((B, N, C0), dtype=torch.float32, device=dev)
+            ops._run("group_bwd", gz, lib.mp_group_bwd_f32, _ptr(gz), _ptr(idx), B, N, S, K, C0, 1, stride, _ptr(gA), int(ops.DETERMINISTIC))
+        return (gA, None, None, None, None, None, None, None, *ret)
+
+
+# MASKPLANNER_FACTORED_FIRST: which levels with input features run their first layer factorised (linear map per source point, then
+# a gather-add) instead of as a GEMM over the grouped rows.  "msg" (default): the multi-scale levels, whose 323-input first layers
+# are otherwise tiled GEMMs over 935 MB of grouped rows (config 5: 3.5 ms of 11.5); "1": the single-scale levels too (there the
+# grouped route already is one pass forward and one backward: measured +0.05 ms from the extra small launches); "0": none.
+FACTORED_FIRST = os.environ.get("MASKPLANNER_FACTORED_FIRST", "msg")
+
+
+def factored_supported(feats, K, convs, bns, dtype="f32", sync_bn=None):
+    """True when shared_mlp_max_factored can take this level (otherwise group + shared_mlp_max)."""
+    from .sync_bn import resolve
+    if dtype != "f32" or resolve(sync_bn) is not False or feats is None or not feats.is_cuda or feats.dtype != torch.float32:
+        return False
+    if len(convs) < 2 or convs[0].in_channels != feats.shape[2] + 3 or convs[0].out_channels not in (64, 128, 256):
+        return False
+    return all(c.out_channels % 4 == 0 for c in convs)
+
+
+def shared_mlp_max_factored(xyz, feats, new_xyz, idx, convs, bns, weight_order="xyz_first"):
+    """The level's output [B,S,Cout] from xyz [B,N,3], feats [B,N,CF], new_xyz [B,S,3], idx [B,S,K] without a grouped tensor and
+    without a first-layer GEMM over the grouped rows.  weight_order: where the coordinate columns sit in the first conv's weight --
+    "xyz_first" (PointNetSetAbstraction, models/pointnet2_utils.py:138) or "xyz_last" (the multi-scale class, :262).
+    Check factored_supported() first."""
+    import torch.nn.functional as F
+    ops._need_hip(xyz, feats, new_xyz, idx)
+    B, S, K = idx.shape
+    CF = feats.shape[2]
+    training = bns[0].training
+    params = []
+    for i, (conv, bn) in enumerate(zip(convs, bns)):
+        if bn.training != training:
+            raise ValueError("all BatchNorm layers of a set-abstraction level must share one mode")
+        w = conv.weight.view(conv.out_channels, conv.in_channels)
+        if i == 0:
+            wx, wf = (w[:, :3], w[:, 3:]) if weight_order == "xyz_first" else (w[:, CF:], w[:, :CF])
+            A = F.linear(feats, wf)                     # [B, N, Co]: the feature part, once per source point
+            w = F.pad(wx, (0, 1))                       # (W_x | 0) [Co, 4]
+        track = bn.track_running_stats and bn.running_mean is not None
+        if not training and not track:
+            raise NotImplementedError("eval-mode BatchNorm without running statistics")
+        params += [w, conv.bias, bn.weight, bn.bias, bn.running_mean if track else None, bn.running_var if track else None]
+    if training:
+        counters = [bn.num_batches_tracked for bn in bns if bn.track_running_stats and bn.num_batches_tracked is not None]
+        if counters:
+            if DEFERRED_TICKS is not None:
+                DEFERRED_TICKS.extend(counters)
+            else:
+                torch._foreach_add_(counters, 1)
+    bn0 = bns[0]
+    momentum = bn0.momentum if bn0.momentum is not None else 1.0 / max(float(bn0.num_batches_tracked), 1.0)
+    out = _SharedMLPMaxFactored.apply(A.contiguous(), xyz.contiguous().float(), new_xyz.contiguous().float(), idx.contiguous(), training,
+                                      momentum, bn0.eps, len(convs), *params)
+    return out.view(B, S, -1)
+
+
 def gathered_supported(feats, K, convs, bns, dtype="f32", sync_bn=None):
     """True when shared_mlp_max_gathered can take this level (otherwise group + shared_mlp_max)."""
     from .sync_bn import resolve

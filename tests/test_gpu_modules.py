@@ -1325,3 +1325,80 @@ def test_gathered_first_layer_equals_the_grouped_one(monkeypatch):
     assert torch.allclose(g0, g1, rtol=1e-5, atol=1e-6 * float(g0.abs().max()))
     for a, b in zip(p0, p1):
         assert torch.allclose(a, b, rtol=1e-4, atol=2e-5 * float(a.abs().max())), float((a - b).abs().max())
+
+
+@pytest.mark.parametrize("train", [True, False])
+def test_factorised_first_layer_equals_the_grouped_one(monkeypatch, train):
+    """sa_mlp.FACTORED_FIRST: the first layer of a level with input features as a linear map per SOURCE point plus a gather-add
+    (first_factored_fwd_kernel) instead of a GEMM over the grouped rows.  Same mathematics, another fp32 summation order: outputs,
+    running statistics, the input-feature gradient and every parameter gradient (the first conv's weight in its reference shape)
+    agree with the grouped path to rounding."""
+    from maskplanner_amd import ops, sa_mlp
+    from maskplanner_amd.pointnet2_utils import PointNetSetAbstraction, fps_start_override
+    torch.manual_seed(5)
+    B, N, D = 4, 512, 128
+    sa = PointNetSetAbstraction(npoint=128, radius=0.4, nsample=64, in_channel=D + 3, mlp=[128, 128, 256], group_all=False).cuda().train(train)
+    with torch.no_grad():
+        for bn in sa.mlp_bns:
+            bn.running_mean.uniform_(-0.1, 0.1)
+            bn.running_var.uniform_(0.5, 1.5)
+    stats0 = [b_.clone() for bn in sa.mlp_bns for b_ in (bn.running_mean, bn.running_var)]
+    xyz = torch.rand(B, 3, N, device="cuda")
+    starts = [torch.zeros(B, dtype=torch.long)]
+    res = {}
+    for mode in (False, True):
+        monkeypatch.setattr(sa_mlp, "FACTORED_FIRST", "1" if mode else "0")
+        torch.manual_seed(9)
+        feats = torch.randn(B, D, N, device="cuda").relu().requires_grad_(True)
+        for p in sa.parameters():
+            p.grad = None
+        with torch.no_grad():
+            for bn, a, b_ in zip(sa.mlp_bns, stats0[0::2], stats0[1::2]):
+                bn.running_mean.copy_(a)
+                bn.running_var.copy_(b_)
+        with fps_start_override(list(starts)):
+            new_xyz, out = sa(xyz, feats)
+        (out * torch.linspace(-1, 1, out.numel(), device="cuda").view_as(out)).sum().backward()
+        res[mode] = (out.detach().clone(), feats.grad.clone(), [p.grad.clone() for p in sa.parameters()],
+                     [b_.clone() for bn in sa.mlp_bns for b_ in (bn.running_mean, bn.running_var)])
+    (o0, g0, p0, s0), (o1, g1, p1, s1) = res[False], res[True]
+    assert o0.shape == o1.shape
+    close(o1, o0, "output", rtol=2e-5, atol=2e-5)
+    for a, b_ in zip(s1, s0):
+        close(a, b_, "running statistics", rtol=1e-5, atol=1e-6)
+    # max-pool routing: a group whose two largest members differ by less than the rounding difference of the two paths sends its
+    # gradient to another member -- the same sensitivity as every other pair of paths in this file (bounds as there)
+    assert float((g1 - g0).abs().max()) <= 2e-3 * float(g0.abs().max()), float((g1 - g0).abs().max()) / float(g0.abs().max())
+    for i, (a, b_) in enumerate(zip(p1, p0)):
+        assert a.shape == b_.shape
+        assert float((a - b_).abs().max()) <= 2e-3 * float(b_.abs().max()) + 1e-6, (i, float((a - b_).abs().max()), float(b_.abs().max()))
+
+
+def test_factorised_first_layer_of_the_multi_scale_level(monkeypatch):
+    """The second multi-scale level (320 input features, three radii, widths [64,64,128] / [128,128,256] x 2): first layers factorised
+    (the default for this class) against the grouped route: output and gradients to rounding / max-pool routing."""
+    from maskplanner_amd import sa_mlp
+    from maskplanner_amd.pointnet2_utils import PointNetSetAbstractionMsg, fps_start_override
+    torch.manual_seed(3)
+    B, N, D = 2, 512, 320
+    msg = PointNetSetAbstractionMsg(128, [0.2, 0.4, 0.8], [16, 32, 64], D, [[64, 64, 128], [128, 128, 256], [128, 128, 256]]).cuda().train()
+    xyz = torch.rand(B, 3, N, device="cuda")
+    res = {}
+    for mode in ("0", "msg"):
+        monkeypatch.setattr(sa_mlp, "FACTORED_FIRST", mode)
+        torch.manual_seed(9)
+        feats = torch.randn(B, D, N, device="cuda").relu().requires_grad_(True)
+        for p in msg.parameters():
+            p.grad = None
+        for bn in (b_ for blk in msg.bn_blocks for b_ in blk):
+            bn.reset_running_stats()
+        with fps_start_override([torch.zeros(B, dtype=torch.long)]):
+            _, out = msg(xyz, feats)
+        (out * torch.linspace(-1, 1, out.numel(), device="cuda").view_as(out)).sum().backward()
+        res[mode] = (out.detach().clone(), feats.grad.clone(), [p.grad.clone() for p in msg.parameters()])
+    (o0, g0, p0), (o1, g1, p1) = res["0"], res["msg"]
+    close(o1, o0, "output", rtol=2e-5, atol=2e-5)
+    assert float((g1 - g0).abs().max()) <= 2e-3 * float(g0.abs().max())
+    for i, (a, b_) in enumerate(zip(p1, p0)):
+        assert a.shape == b_.shape
+        assert float((a - b_).abs().max()) <= 2e-3 * float(b_.abs().max()) + 1e-6, (i, float((a - b_).abs().max()), float(b_.abs().max()))
