@@ -315,7 +315,13 @@ int mp_sa_mlp_recompute_first(int n_layers, const int64_t* channels, int64_t K);
 /* The grouped input of a level that is NOT materialised: row p = (b, s, k) of x0 is [feats[b, idx[p], 0:CF] | xyz[b, idx[p]] - new_xyz[b, s] | 0]
  * (models/pointnet2_utils.py:133-143 fused into the consumers).  mp_sa_mlp_gather_supported tells whether a chain qualifies (BASELINE's second
  * level: CF = 128, first layer 132 -> 128); the gather forms take this descriptor instead of x0, everything else as in the plain calls
- * (grad_x0 [P, 132] with grad_x0_cols = 128 is still written: the caller scatters it with mp_group_bwd_f32). */
+ * (grad_x0 [P, 132] with grad_x0_cols = 128 is still written: the caller scatters it with mp_group_bwd_f32).
+ * FACTORISED first layer (second form of the same two calls, recognised by layers[0].c_in == 4 and CF == layers[0].c_out in {64, 128,
+ * 256}): the first Conv2d is linear in [f ; x - c] (pointnet2_utils.py:138 / :262 + :208-213), so the caller computes A = F W_f^T once per
+ * SOURCE point and passes it as `feats` [B, N, Co]; layers[0].weight is the coordinate part (W_x | 0) [Co, 4].  The library forms
+ * Z_0[p] = A[b, idx[p]] + W_x (xyz[b, idx[p]] - new_xyz[b, s]) and its BatchNorm statistics, then the ordinary chain; backward it writes
+ * dZ_0 into grad_x0 [P, Co + 4] (grad_x0_cols = Co; mp_group_bwd_f32 over the gathering rows turns it into dA [B, N, Co], from which dW_f
+ * and dF follow by two small GEMMs on the caller's side) and dW_x into grads[0].d_weight [Co, 4].  layers[0].z must be given. */
 typedef struct {
     const float* feats;    /* [B, N, CF] */
     const float* xyz;      /* [B, N, 3] */
