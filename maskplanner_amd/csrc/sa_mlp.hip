@@ -2279,13 +2279,19 @@ extern "C" int mp_sa_mlp_recompute_first(int n_layers, const int64_t* channels, 
 //             the gathered coordinates (first_factored_bwd_kernel).
 // Same mathematics as the grouped GEMM, a different fp32 summation order (W_f f is rounded before W_x d is added).
 // =================================================================================================================
+#ifndef MP_FACT_U
+#define MP_FACT_U 4        // rows in flight per lane group (timing builds: tools/fact_variants.sh)
+#endif
+#ifndef MP_FACT_PPB
+#define MP_FACT_PPB 256    // positions per workgroup of the forward kernel = per BatchNorm partial row (the backward kernel takes twice as many)
+#endif
 template <int Q>   // Q = Co / 4: lanes per row
 __global__ __launch_bounds__(256) void first_factored_fwd_kernel(const float* __restrict__ A, const float* __restrict__ xyz,
                                                                  const float* __restrict__ new_xyz, const int64_t* __restrict__ idx,
                                                                  const float* __restrict__ Wx, int P, int K, int kshift, int N, int per,
                                                                  int gshift, int ppb, float* __restrict__ Z0, float* __restrict__ partials)
 {
-    constexpr int CO = 4 * Q, RW = 64 / Q, RB = 4 * RW, U = 4;      // rows per wave / per workgroup pass, passes in flight
+    constexpr int CO = 4 * Q, RW = 64 / Q, RB = 4 * RW, U = MP_FACT_U;      // rows per wave / per workgroup pass, passes in flight
     __shared__ float red[2][RB][CO];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ql = lane % Q, slot = wave * RW + lane / Q;
@@ -2343,7 +2349,7 @@ __global__ __launch_bounds__(256) void first_factored_bwd_kernel(PosOperand DZ, 
                                                                  const int64_t* __restrict__ idx, int P, int K, int kshift, int N, int per,
                                                                  int gshift, int ppb, float* __restrict__ dz_out, float* __restrict__ dW)
 {
-    constexpr int CO = 4 * Q, RW = 64 / Q, RB = 4 * RW, U = 4;
+    constexpr int CO = 4 * Q, RW = 64 / Q, RB = 4 * RW, U = MP_FACT_U;
     __shared__ float red[3][RB][CO];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ql = lane % Q, slot = wave * RW + lane / Q;
@@ -2488,7 +2494,7 @@ static int sa_mlp_fwd(const float* x0, int64_t P, int64_t K, int n_layers, const
         const int Ci_ = (int)L.c_in, Co_ = (int)L.c_out;
         const bool last_unfused = (l == n_layers - 1) && !fused_pool;
         if (l == 0 && factored) {
-            const int ppb = 256;
+            const int ppb = MP_FACT_PPB;
             nblk = (int)((P + ppb - 1) / ppb);
             const double by = 4.0 * (2.0 * (double)P * Co_ + 5.0 * (double)P);
             const int per = (int)(gather->S * K);
@@ -2869,7 +2875,7 @@ static int sa_mlp_bwd(const float* x0, int64_t P, int64_t K, int n_layers, const
         if (factored && l == 0) {
             // dW_x from the gathered coordinates, dZ_0 itself (= the gradient of the gathered A rows) out to the caller
             const double fl = 2.0 * (double)P * Co * 4, by = 4.0 * (2.0 * (double)P * Co + 5.0 * (double)P);
-            const int ppb = 256, per = (int)(gather->S * K);
+            const int ppb = 2 * MP_FACT_PPB, per = (int)(gather->S * K);      // measured: 512 here (fewer dW_x atomics), 256 forward
             const unsigned gxf = (unsigned)((P + ppb - 1) / ppb);
 #define MP_FACT_B(Q_)                                                                                                            \
     MP_LAUNCH("first_factored_bwd_kernel", fl, by + 4.0 * (double)P * Co, (first_factored_bwd_kernel<Q_>), dim3(gxf), dim3(256), 0, stream, DZ, gather->xyz, \
