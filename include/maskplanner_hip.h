@@ -321,7 +321,9 @@ int mp_sa_mlp_recompute_first(int n_layers, const int64_t* channels, int64_t K);
  * SOURCE point and passes it as `feats` [B, N, Co]; layers[0].weight is the coordinate part (W_x | 0) [Co, 4].  The library forms
  * Z_0[p] = A[b, idx[p]] + W_x (xyz[b, idx[p]] - new_xyz[b, s]) and its BatchNorm statistics, then the ordinary chain; backward it writes
  * dZ_0 into grad_x0 [P, Co + 4] (grad_x0_cols = Co; mp_group_bwd_f32 over the gathering rows turns it into dA [B, N, Co], from which dW_f
- * and dF follow by two small GEMMs on the caller's side) and dW_x into grads[0].d_weight [Co, 4].  layers[0].z must be given. */
+ * and dF follow by two small GEMMs on the caller's side) and dW_x into grads[0].d_weight [Co, 4].  With grad_x0_cols = 0 instead, grad_x0
+ * IS dA [B, N, Co]: the library sorts each cloud's rows by source point and reduces dZ_0 on the fly (no [P, Co + 4] buffer; fp32 atomics,
+ * summation order not fixed; N <= 15000).  layers[0].z must be given. */
 typedef struct {
     const float* feats;    /* [B, N, CF] */
     const float* xyz;      /* [B, N, 3] */

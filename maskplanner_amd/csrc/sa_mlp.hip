@@ -2401,6 +2401,126 @@ __global__ __launch_bounds__(256) void first_factored_bwd_kernel(PosOperand DZ, 
     }
 }
 
+// ---- the same backward without the dZ_0 round trip ---------------------------------------------------------------------------
+// csr_rows_kernel sorts the rows of every cloud by the source point they gathered (counting sort in LDS, one workgroup per cloud;
+// the order inside a point follows the atomics, so the summation order below is not fixed: the non-deterministic mode only).
+// first_factored_reduce_kernel then walks the sorted rows in chunks of `chunk` rows per wave -- perfect balance whatever the hot
+// points are --, forms dZ_0 from (Z_0, G_0) on the fly, keeps a running sum while the point stays the same and adds it to dA with one
+// atomic per channel when the point changes; dW_x as in first_factored_bwd_kernel.  dA must be zero on entry.
+__global__ __launch_bounds__(1024) void csr_rows_kernel(const int64_t* __restrict__ idx, int N, int M, int* __restrict__ order, int* __restrict__ pts)
+{
+    extern __shared__ int csr_lds[];          // [N] histogram -> cursors, [1024] scan scratch
+    int* hist = csr_lds;
+    int* part = csr_lds + N;
+    const int tid = threadIdx.x, b = blockIdx.x;
+    const int64_t* bi = idx + (size_t)b * M;
+    for (int i = tid; i < N; i += 1024) hist[i] = 0;
+    __syncthreads();
+    for (int m = tid; m < M; m += 1024) {
+        const int64_t i64 = bi[m];
+        atomicAdd(&hist[(int)(i64 < 0 ? 0 : (i64 >= N ? N - 1 : i64))], 1);
+    }
+    __syncthreads();
+    // exclusive scan: every thread owns a run of consecutive points, the run totals are scanned over the workgroup
+    const int run = (N + 1023) / 1024, i0 = tid * run, i1 = min(N, i0 + run);
+    int tot = 0;
+    for (int i = i0; i < i1; ++i) tot += hist[i];
+    part[tid] = tot;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const int v = tid >= o ? part[tid - o] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int base = part[tid] - tot;
+    for (int i = i0; i < i1; ++i) { const int c = hist[i]; hist[i] = base; base += c; }
+    __syncthreads();
+    for (int m = tid; m < M; m += 1024) {
+        const int64_t i64 = bi[m];
+        const int i = (int)(i64 < 0 ? 0 : (i64 >= N ? N - 1 : i64));
+        const int pos = atomicAdd(&hist[i], 1);
+        order[(size_t)b * M + pos] = m;
+        pts[(size_t)b * M + pos] = i;
+    }
+}
+
+template <int Q>
+__global__ __launch_bounds__(256) void first_factored_reduce_kernel(PosOperand DZ, const int* __restrict__ order, const int* __restrict__ pts,
+                                                                    const float* __restrict__ xyz, const float* __restrict__ new_xyz, int N, int M,
+                                                                    int K, int kshift, int chunk, float* __restrict__ dA, float* __restrict__ dW)
+{
+#ifndef MP_FACT_RU
+#define MP_FACT_RU 4
+#endif
+    constexpr int CO = 4 * Q, RW = 64 / Q, U = MP_FACT_RU;
+    __shared__ float red[3][4 * RW][CO];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ql = lane % Q, sub = lane / Q;
+    const int b = blockIdx.y;
+    const int j0 = (blockIdx.x * 4 + wave) * chunk, j1 = min(M, j0 + chunk);
+    const int S = M / K;
+    ChanConst k;
+    load_consts<SRC_DZ>(DZ, 4 * ql, k);
+    const int* bo = order + (size_t)b * M;
+    const int* bp = pts + (size_t)b * M;
+    float* dst = dA + (size_t)b * N * CO + 4 * ql;
+    int cur = -1;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), ax = acc, ay = acc, az = acc;
+    auto flush = [&]() {
+        if (cur >= 0) {
+            float* d = dst + (size_t)cur * CO;
+            atomicAdd(d + 0, acc.x); atomicAdd(d + 1, acc.y); atomicAdd(d + 2, acc.z); atomicAdd(d + 3, acc.w);
+        }
+    };
+    for (int j = j0 + sub; j < j1; j += RW * U) {
+        float4 z[U], g[U];
+        float dx[U], dy[U], dzc[U];
+        int pt[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int jj = min(j + u * RW, j1 - 1);
+            const int m = bo[jj];
+            pt[u] = bp[jj];
+            const size_t row = (size_t)b * M + m;
+            z[u] = ld4(DZ.x + row * CO + 4 * ql);
+            g[u] = ld4(DZ.g + row * CO + 4 * ql);
+            const unsigned grp = (unsigned)b * (unsigned)S + (kshift >= 0 ? (unsigned)m >> kshift : (unsigned)m / (unsigned)K);
+            const float* x = xyz + ((size_t)b * N + pt[u]) * 3;
+            const float* c = new_xyz + (size_t)grp * 3;
+            dx[u] = x[0] - c[0]; dy[u] = x[1] - c[1]; dzc[u] = x[2] - c[2];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (j + u * RW < j1) {
+                float4 d;
+                d.x = xf1<SRC_DZ>(z[u].x, g[u].x, k.s.x, k.t.x, k.a.x, k.e.x, k.f.x);
+                d.y = xf1<SRC_DZ>(z[u].y, g[u].y, k.s.y, k.t.y, k.a.y, k.e.y, k.f.y);
+                d.z = xf1<SRC_DZ>(z[u].z, g[u].z, k.s.z, k.t.z, k.a.z, k.e.z, k.f.z);
+                d.w = xf1<SRC_DZ>(z[u].w, g[u].w, k.s.w, k.t.w, k.a.w, k.e.w, k.f.w);
+                if (pt[u] != cur) { flush(); cur = pt[u]; acc = make_float4(0.f, 0.f, 0.f, 0.f); }
+                acc.x += d.x; acc.y += d.y; acc.z += d.z; acc.w += d.w;
+                ax.x = __builtin_fmaf(d.x, dx[u], ax.x); ax.y = __builtin_fmaf(d.y, dx[u], ax.y); ax.z = __builtin_fmaf(d.z, dx[u], ax.z); ax.w = __builtin_fmaf(d.w, dx[u], ax.w);
+                ay.x = __builtin_fmaf(d.x, dy[u], ay.x); ay.y = __builtin_fmaf(d.y, dy[u], ay.y); ay.z = __builtin_fmaf(d.z, dy[u], ay.z); ay.w = __builtin_fmaf(d.w, dy[u], ay.w);
+                az.x = __builtin_fmaf(d.x, dzc[u], az.x); az.y = __builtin_fmaf(d.y, dzc[u], az.y); az.z = __builtin_fmaf(d.z, dzc[u], az.z); az.w = __builtin_fmaf(d.w, dzc[u], az.w);
+            }
+        }
+    }
+    flush();
+    const int slot = wave * RW + sub;
+    *reinterpret_cast<float4*>(&red[0][slot][4 * ql]) = ax;
+    *reinterpret_cast<float4*>(&red[1][slot][4 * ql]) = ay;
+    *reinterpret_cast<float4*>(&red[2][slot][4 * ql]) = az;
+    __syncthreads();
+    for (int e = tid; e < 3 * CO; e += 256) {
+        const int jc = e / CO, c = e - jc * CO;
+        float v = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 4 * RW; ++r) v += red[jc][r][c];
+        atomicAdd(dW + (size_t)c * 4 + jc, v);
+    }
+}
+
 // the factorised first layer's shapes: gather descriptor carrying A [B, N, Co], layers[0] = (W_x | 0) [Co, 4]
 static bool factored_ok(const mp_gather_t* g, int64_t P, int64_t K, int n_layers, const mp_mlp_layer_t* layers, bool bf16)
 {
@@ -2684,7 +2804,9 @@ static int sa_mlp_bwd(const float* x0, int64_t P, int64_t K, int n_layers, const
     if (P == 0) return MP_OK;
     if ((!x0 && !gather) || !grad_out || !out || !argk || !zmax || !workspace || (P % K) != 0) return MP_EINVAL;
     const bool factored = gather && factored_ok(gather, P, K, n_layers, layers, bf16);
-    if (factored && (!grad_x0 || grad_x0_cols != layers[0].c_out)) return MP_EINVAL;
+    // factored: grad_x0_cols == Co: dZ_0 rows [P, Co + 4] for the caller to reduce; grad_x0_cols == 0: grad_x0 IS dA [B, N, Co], reduced here
+    if (factored && (!grad_x0 || (grad_x0_cols != layers[0].c_out && grad_x0_cols != 0))) return MP_EINVAL;
+    if (factored && grad_x0_cols == 0 && (gather->N > 15000 || gather->S * K >= ((int64_t)1 << 24))) return MP_EUNSUPPORTED;
     if (gather && !factored && (!gather_ok(gather, P, K, n_layers, layers, bf16) || !grad_x0 || grad_x0_cols != 128)) return MP_EUNSUPPORTED;
     if (n_layers > 8) return MP_EUNSUPPORTED;
     int64_t ch[9];
@@ -2875,6 +2997,29 @@ static int sa_mlp_bwd(const float* x0, int64_t P, int64_t K, int n_layers, const
         if (factored && l == 0) {
             // dW_x from the gathered coordinates, dZ_0 itself (= the gradient of the gathered A rows) out to the caller
             const double fl = 2.0 * (double)P * Co * 4, by = 4.0 * (2.0 * (double)P * Co + 5.0 * (double)P);
+            if (grad_x0_cols == 0) {
+                // sorted-row reduce: no dZ_0 round trip.  Scratch: the G buffer that is free at this layer (2 ints per position).
+                const int M = (int)(gather->S * K), Np = (int)gather->N;
+                const int64_t Bc = P / M;
+                int* order = reinterpret_cast<int*>(gbuf[0]);
+                int* pts = order + P;
+                static mp::DynLds lds;
+                const size_t smem = sizeof(int) * ((size_t)Np + 1024);
+                if (!lds.ensure(reinterpret_cast<const void*>(csr_rows_kernel), smem)) return MP_ELAUNCH;
+                hipLaunchKernelGGL(csr_rows_kernel, dim3((unsigned)Bc), dim3(1024), smem, stream, gather->idx, Np, M, order, pts);
+                MP_CHECK_LAUNCH();
+                if (!mp::zero_async(grad_x0, (size_t)Bc * Np * Co, stream)) return MP_ELAUNCH;
+                static const int chunk_env = getenv("MP_FACT_CHUNK") ? atoi(getenv("MP_FACT_CHUNK")) : 128;   // rows per wave (measured: 32: 236 us, 64: 160, 128: 122, 256: 126 at the bench shape)
+                const int chunk = chunk_env;
+                const unsigned gxr = (unsigned)((M + 4 * chunk - 1) / (4 * chunk));
+#define MP_FACT_R(Q_)                                                                                                            \
+    MP_LAUNCH("first_factored_reduce_kernel", fl, by, (first_factored_reduce_kernel<Q_>), dim3(gxr, (unsigned)Bc), dim3(256), 0, stream, DZ, order, pts, \
+              gather->xyz, gather->new_xyz, Np, M, (int)K, log2_or_neg(K), chunk, grad_x0, grads[l].d_weight)
+                if (Co == 64) MP_FACT_R(16); else if (Co == 128) MP_FACT_R(32); else MP_FACT_R(64);
+#undef MP_FACT_R
+                MP_CHECK_LAUNCH();
+                continue;
+            }
             const int ppb = 2 * MP_FACT_PPB, per = (int)(gather->S * K);      // measured: 512 here (fewer dW_x atomics), 256 forward
             const unsigned gxf = (unsigned)((P + ppb - 1) / ppb);
 #define MP_FACT_B(Q_)                                                                                                            \

@@ -262,11 +262,20 @@ class _SharedMLPMaxFactored(torch.autograd.Function):
             grads[l] = _lib.MlpGrads(_ptr(dw), _ptr(db), _ptr(dg), _ptr(dbe))
             ret += [dw, db, dg, dbe, None, None]
         stride = C0 + 4
-        gz = torch.empty((P, stride), dtype=torch.float32, device=dev)       # dZ_0 rows (the pad quad is never read)
         ch = (ctypes.c_int64 * len(chans))(*chans)
         lib = _lib.load()
         ws = torch.empty((lib.mp_sa_mlp_workspace_bytes(P, K, n_layers, ch, 1),), dtype=torch.uint8, device=dev)
         g = _lib.Gather(_ptr(A), _ptr(xyz), _ptr(new_xyz), _ptr(idx), N, S, C0)
+        # dA reduced inside the library from rows sorted by source point (no dZ_0 round trip; summation order not fixed), unless a
+        # deterministic run asks for the ordered scatter: then dZ_0 comes back and ops.group's backward kernel reduces it
+        fused = FACTORED_REDUCE and not ops.DETERMINISTIC and N <= 15000 and S * K < (1 << 24)
+        if fused:
+            gA = torch.empty((B, N, C0), dtype=torch.float32, device=dev)
+            ops._run("sa_mlp_bwd", A, lib.mp_sa_mlp_bwd_gather_f32, ctypes.byref(g), P, K, n_layers, layers, int(training), _ptr(grad_out),
+                     _ptr(out), _ptr(argk), _ptr(zmax), grads, _ptr(gA), 0, _ptr(ws), ws.numel())
+            ctx.keep = None
+            return (gA, None, None, None, None, None, None, None, *ret)
+        gz = torch.empty((P, stride), dtype=torch.float32, device=dev)       # dZ_0 rows (the pad quad is never read)
         ops._run("sa_mlp_bwd", A, lib.mp_sa_mlp_bwd_gather_f32, ctypes.byref(g), P, K, n_layers, layers, int(training), _ptr(grad_out),
                  _ptr(out), _ptr(argk), _ptr(zmax), grads, _ptr(gz), C0, _ptr(ws), ws.numel())
         ctx.keep = None
@@ -282,6 +291,7 @@ class _SharedMLPMaxFactored(torch.autograd.Function):
 # are otherwise tiled GEMMs over 935 MB of grouped rows (config 5: 3.5 ms of 11.5); "1": the single-scale levels too (there the
 # grouped route already is one pass forward and one backward: measured +0.05 ms from the extra small launches); "0": none.
 FACTORED_FIRST = os.environ.get("MASKPLANNER_FACTORED_FIRST", "msg")
+FACTORED_REDUCE = os.environ.get("MASKPLANNER_FACTORED_REDUCE", "1") != "0"   # 0: dZ_0 written out and reduced by the grouping backward's kernel
 
 
 def factored_supported(feats, K, convs, bns, dtype="f32", sync_bn=None):

@@ -1327,14 +1327,16 @@ def test_gathered_first_layer_equals_the_grouped_one(monkeypatch):
         assert torch.allclose(a, b, rtol=1e-4, atol=2e-5 * float(a.abs().max())), float((a - b).abs().max())
 
 
+@pytest.mark.parametrize("reduce_in_library", [True, False])
 @pytest.mark.parametrize("train", [True, False])
-def test_factorised_first_layer_equals_the_grouped_one(monkeypatch, train):
+def test_factorised_first_layer_equals_the_grouped_one(monkeypatch, train, reduce_in_library):
     """sa_mlp.FACTORED_FIRST: the first layer of a level with input features as a linear map per SOURCE point plus a gather-add
     (first_factored_fwd_kernel) instead of a GEMM over the grouped rows.  Same mathematics, another fp32 summation order: outputs,
     running statistics, the input-feature gradient and every parameter gradient (the first conv's weight in its reference shape)
     agree with the grouped path to rounding."""
     from maskplanner_amd import ops, sa_mlp
     from maskplanner_amd.pointnet2_utils import PointNetSetAbstraction, fps_start_override
+    monkeypatch.setattr(sa_mlp, "FACTORED_REDUCE", reduce_in_library)   # dA from the sorted-row reduce / from dZ_0 + ops.group's backward
     torch.manual_seed(5)
     B, N, D = 4, 512, 128
     sa = PointNetSetAbstraction(npoint=128, radius=0.4, nsample=64, in_channel=D + 3, mlp=[128, 128, 256], group_all=False).cuda().train(train)

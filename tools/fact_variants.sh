@@ -1,15 +1,14 @@
-# timing builds of the factorised first-layer kernels: rows in flight (MP_FACT_U) and positions per workgroup (MP_FACT_PPB), config 5, one box
+# timing builds of the factorised first layer's sorted-row reduce: rows in flight (MP_FACT_RU, compile time) x rows per wave (MP_FACT_CHUNK), one box
 cd $GRAFT_REPO_ROOT/maskplanner_amd/csrc
-for v in "4 256" "8 256" "4 512" "8 512" "8 1024" "2 256"; do
-  set -- $v; d=/tmp/fa$1_$2; mkdir -p $d
-  hipcc -DMP_FACT_U=$1 -DMP_FACT_PPB=$2 -O3 -std=c++17 -fPIC -ffp-contract=off -munsafe-fp-atomics --offload-arch=gfx950 -Wno-unused-function -I../../include -c sa_mlp.hip -o $d/sa_mlp.o || continue
+for u in 4 8; do
+  d=/tmp/fr$u; mkdir -p $d
+  hipcc -DMP_FACT_RU=$u -O3 -std=c++17 -fPIC -ffp-contract=off -munsafe-fp-atomics --offload-arch=gfx950 -Wno-unused-function -I../../include -c sa_mlp.hip -o $d/sa_mlp.o || continue
   hipcc -shared -fPIC --offload-arch=gfx950 -no-hip-rt -o $d/lib.so $d/sa_mlp.o $(ls ../lib/obj/*.o | grep -v sa_mlp.o)
 done
 cd $GRAFT_REPO_ROOT
-for i in 1 2; do for v in "4 256" "8 256" "4 512" "8 512" "8 1024" "2 256"; do
-  set -- $v; [ -f /tmp/fa$1_$2/lib.so ] || continue
-  echo -n "U=$1 ppb=$2: "; MASKPLANNER_HIP_LIB=/tmp/fa$1_$2/lib.so python bench.py --category containers --points 10240 --encoder msg --dtype f32 --steps 10 --no-cpu-baseline --no-side-legs 2>/dev/null | python -c "
+for i in 1 2; do for u in 4 8; do for c in 32 64 128 256; do
+  echo -n "U=$u chunk=$c: "; MP_FACT_CHUNK=$c MASKPLANNER_FACTORED_FIRST=1 MASKPLANNER_HIP_LIB=/tmp/fr$u/lib.so python bench.py --steps 40 --warmup 8 --no-cpu-baseline --no-side-legs 2>/dev/null | python -c "
 import json,sys
 d=json.loads([l for l in sys.stdin if l.startswith(chr(123))][0]); k=d['kernels_us_per_step']
-print(round(d['ms_per_step'],3), {n[:26]: round(v,1) for n,v in k.items() if 'factored' in n})"
-done; done
+print(round(d['ms_per_step'],3), round(d.get('step_ms_median',0),3), {n[:30]: round(v,1) for n,v in k.items() if 'factored' in n})"
+done; done; done
