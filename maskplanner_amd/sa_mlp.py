@@ -286,11 +286,41 @@ class _SharedMLPMaxFactored(torch.autograd.Function):
         return (gA, None, None, None, None, None, None, None, *ret)
 
 
+class _PerPointFirst(torch.autograd.Function):
+    """The feature half of a factorised first layer and the split of its weight, with a backward that costs four launches:
+    (feats [B,N,CF], w [Co,Cin] in the module's column order, xyz_first) -> A = feats W_f^T [B,N,Co], (W_x | 0) [Co,4].
+    Backward: dF = dA W_f (one GEMM), dW_f = sum_b dA_b^T F_b as a BATCHED GEMM over the clouds + a sum (the flat [Co, B*N] x
+    [B*N, CF] form sends rocBLAS to a 16-tile kernel with a 16 384-long K loop: 93 us at the bench shape), dW assembled with one cat."""
+
+    @staticmethod
+    def forward(ctx, feats, w, xyz_first):
+        CF = feats.shape[2]
+        wx, wf = (w[:, :3], w[:, 3:]) if xyz_first else (w[:, CF:], w[:, :CF])
+        A = torch.matmul(feats, wf.t())
+        wx4 = torch.nn.functional.pad(wx, (0, 1))
+        ctx.save_for_backward(feats, w)
+        ctx.xyz_first = bool(xyz_first)
+        return A, wx4
+
+    @staticmethod
+    def backward(ctx, gA, gwx4):
+        feats, w = ctx.saved_tensors
+        CF = feats.shape[2]
+        wf = w[:, 3:] if ctx.xyz_first else w[:, :CF]
+        gfeats = torch.matmul(gA, wf) if ctx.needs_input_grad[0] else None
+        gw = None
+        if ctx.needs_input_grad[1]:
+            gwf = torch.bmm(gA.transpose(1, 2), feats).sum(0)
+            gwx = gwx4[:, :3] if gwx4 is not None else torch.zeros_like(w[:, :3])
+            gw = torch.cat([gwx, gwf], dim=1) if ctx.xyz_first else torch.cat([gwf, gwx], dim=1)
+        return gfeats, gw, None
+
+
 # MASKPLANNER_FACTORED_FIRST: which levels with input features run their first layer factorised (linear map per source point, then
-# a gather-add) instead of as a GEMM over the grouped rows.  "msg" (default): the multi-scale levels, whose 323-input first layers
-# are otherwise tiled GEMMs over 935 MB of grouped rows (config 5: 3.5 ms of 11.5); "1": the single-scale levels too (there the
-# grouped route already is one pass forward and one backward: measured +0.05 ms from the extra small launches); "0": none.
-FACTORED_FIRST = os.environ.get("MASKPLANNER_FACTORED_FIRST", "msg")
+# a gather-add) instead of as a GEMM over the grouped rows.  "1" (default): every such level -- the bench's second level (2.56 vs
+# 2.64 ms per step) and the multi-scale levels, whose 323-input first layers are otherwise tiled GEMMs over 935 MB of grouped rows
+# (config 5: 11.5 -> 9.0 ms); "msg": the multi-scale levels only; "0": none (the grouped route).
+FACTORED_FIRST = os.environ.get("MASKPLANNER_FACTORED_FIRST", "1")
 FACTORED_REDUCE = os.environ.get("MASKPLANNER_FACTORED_REDUCE", "1") != "0"   # 0: dZ_0 written out and reduced by the grouping backward's kernel
 
 
@@ -320,9 +350,8 @@ def shared_mlp_max_factored(xyz, feats, new_xyz, idx, convs, bns, weight_order="
             raise ValueError("all BatchNorm layers of a set-abstraction level must share one mode")
         w = conv.weight.view(conv.out_channels, conv.in_channels)
         if i == 0:
-            wx, wf = (w[:, :3], w[:, 3:]) if weight_order == "xyz_first" else (w[:, CF:], w[:, :CF])
-            A = F.linear(feats, wf)                     # [B, N, Co]: the feature part, once per source point
-            w = F.pad(wx, (0, 1))                       # (W_x | 0) [Co, 4]
+            # A [B, N, Co]: the feature part, once per source point; w: (W_x | 0) [Co, 4]
+            A, w = _PerPointFirst.apply(feats.contiguous(), w, weight_order == "xyz_first")
         track = bn.track_running_stats and bn.running_mean is not None
         if not training and not track:
             raise NotImplementedError("eval-mode BatchNorm without running statistics")

@@ -1295,8 +1295,9 @@ def test_gathered_first_layer_equals_the_grouped_one(monkeypatch):
     """MP_GATHER_FUSED=1: set abstraction 2 never writes its grouped input -- the first layer's forward and backward kernels read row
     (b, s, k) from the previous level's feature table and the coordinates (mp_sa_mlp_{fwd,bwd}_gather_f32).  Same rows, same kernels
     otherwise: outputs identical, parameter and input gradients equal up to the atomics' summation order."""
-    from maskplanner_amd import ops
+    from maskplanner_amd import ops, sa_mlp
     from maskplanner_amd.pointnet2_utils import PointNetSetAbstraction, fps_start_override
+    monkeypatch.setattr(sa_mlp, "FACTORED_FIRST", "0")      # the grouped route and its gathered variant are what is compared here
     torch.manual_seed(5)
     B, N, D = 4, 512, 128
     sa = PointNetSetAbstraction(npoint=128, radius=0.4, nsample=64, in_channel=D + 3, mlp=[128, 128, 256], group_all=False).cuda().train()
