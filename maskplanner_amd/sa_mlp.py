@@ -286,6 +286,9 @@ class _SharedMLPMaxFactored(torch.autograd.Function):
         return (gA, None, None, None, None, None, None, None, *ret)
 
 
+PER_POINT_DW_SLICES = int(os.environ.get("MP_PER_POINT_DW_SLICES", "8"))
+
+
 class _PerPointFirst(torch.autograd.Function):
     """The feature half of a factorised first layer and the split of its weight, with a backward that costs four launches:
     (feats [B,N,CF], w [Co,Cin] in the module's column order, xyz_first) -> A = feats W_f^T [B,N,Co], (W_x | 0) [Co,4].
@@ -310,7 +313,10 @@ class _PerPointFirst(torch.autograd.Function):
         gfeats = torch.matmul(gA, wf) if ctx.needs_input_grad[0] else None
         gw = None
         if ctx.needs_input_grad[1]:
-            gwf = torch.bmm(gA.transpose(1, 2), feats).sum(0)
+            # (more, shorter K slices than clouds: one 128 x 128 tile per cloud leaves the GEMM on 32 workgroups with a 512-long K loop)
+            B, N, _ = feats.shape
+            sl = next(d for d in (PER_POINT_DW_SLICES, 4, 2, 1) if N % d == 0)
+            gwf = torch.bmm(gA.reshape(B * sl, N // sl, -1).transpose(1, 2), feats.reshape(B * sl, N // sl, CF)).sum(0)
             gwx = gwx4[:, :3] if gwx4 is not None else torch.zeros_like(w[:, :3])
             gw = torch.cat([gwx, gwf], dim=1) if ctx.xyz_first else torch.cat([gwf, gwx], dim=1)
         return gfeats, gw, None
