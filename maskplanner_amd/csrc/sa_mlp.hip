@@ -2473,15 +2473,25 @@ __global__ __launch_bounds__(256) void first_factored_reduce_kernel(PosOperand D
             atomicAdd(d + 0, acc.x); atomicAdd(d + 1, acc.y); atomicAdd(d + 2, acc.z); atomicAdd(d + 3, acc.w);
         }
     };
+    // the sorted (row, point) pairs are fetched one batch AHEAD of the rows they name: the row loads depend on them
+    int nm[U], npt[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int jj = min(j0 + sub + u * RW, max(j1 - 1, j0));
+        nm[u] = bo[jj];
+        npt[u] = bp[jj];
+    }
     for (int j = j0 + sub; j < j1; j += RW * U) {
         float4 z[U], g[U];
         float dx[U], dy[U], dzc[U];
         int pt[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int jj = min(j + u * RW, j1 - 1);
-            const int m = bo[jj];
-            pt[u] = bp[jj];
+            const int m = nm[u];
+            pt[u] = npt[u];
+            const int jn = min(j + (U + u) * RW, j1 - 1);
+            nm[u] = bo[jn];
+            npt[u] = bp[jn];
             const size_t row = (size_t)b * M + m;
             z[u] = ld4(DZ.x + row * CO + 4 * ql);
             g[u] = ld4(DZ.g + row * CO + 4 * ql);
