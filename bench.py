@@ -123,11 +123,15 @@ def self_launch(args):
 def kernel_tables(kernels, profiled_steps, floors):
     """named_kernels (the kernels BASELINE.json names, each against BOTH roofs + SURVEY 8d's effective scan rate) and the
     per-step time of every tagged kernel."""
-    scan_bytes_per_flop = {"fps_kernel": 20.0 / 8.0, "ball_query_kernel": 12.0 / 8.0, "knn1_kernel": 4.0 / 3.0, "knn_kernel": 4.0 / 3.0}
+    scan_bytes_per_flop = {"fps_kernel": 20.0 / 8.0, "ball_query_kernel": 12.0 / 8.0, "knn1_kernel": 4.0 / 3.0, "knn_kernel": 4.0 / 3.0,
+                           "knn1_screen_kernel": 4.0 / 3.0}
     named = {}
     for k, v in kernels.items():
         base = k.split("<")[0]
-        if base not in ("fps_kernel", "ball_query_kernel", "knn1_kernel", "knn_kernel", "group_kernel", "group_bwd_atomic_kernel"):
+        # FPS, ball query, the nearest-neighbour searches of the chamfer terms (every kernel of knn.hip: direct, screened, the
+        # plane pre-pass, the backward scatter) and the grouping gathers
+        if not (base in ("fps_kernel", "ball_query_kernel") or base.startswith("knn") or base.startswith("group_")
+                or base.startswith("chamfer_")):
             continue
         t = v["ms"] / v["calls"] * 1e-3
         fl, by = v["flops"] / v["calls"], v["bytes"] / v["calls"]
@@ -294,6 +298,7 @@ def main():
     if args.path == "harness":
         ts = make_harness(args.dist)
         dt, per_step, final_loss, profiled_steps = run_harness(ts, args.steps, args.warmup)
+        ts.check()      # (outside the timed region) a failed stroke-mask matching or a non-finite loss raises here
     else:
         dt, per_step, final_loss = run_dropin(args.steps, args.warmup, args.dist)
         ts, profiled_steps = None, 0
@@ -335,26 +340,43 @@ def main():
             off_path = lambda k: (ts.overlap and k.startswith("fps_kernel")) or (ts._graph_b is not None and k.startswith("adam_lowrank"))
             on_path = [k for k in kernels if not off_path(k)] or list(kernels)
             dom = max(on_path, key=lambda k: kernels[k]["ms"])
-            d = kernels[dom]
-            avg_s = d["ms"] / d["calls"] * 1e-3
-            flops, nbytes = d["flops"] / d["calls"], d["bytes"] / d["calls"]
-            mfma_peak = BF16_PEAK_TFLOPS if "bf16" in dom else FP32_PEAK_TFLOPS
-            if flops / (mfma_peak * 1e12) >= nbytes / (HBM_PEAK_GBS * 1e9):
-                bound, ach, peak, unit = "mfma", flops / avg_s / 1e12, mfma_peak, "TFLOP/s"
-            else:
-                bound, ach, peak, unit = "hbm", nbytes / avg_s / 1e9, HBM_PEAK_GBS, "GB/s"
-            line["roofline"] = {"kernel": dom, "bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak,
-                                "traffic": measured_traffic(dom), "avg_us": avg_s * 1e6, "launches_per_step": d["calls"] / max(profiled_steps, 1),
-                                "flops_per_launch": flops, "bytes_per_launch": nbytes}
-            if args.dtype == "f32" and os.environ.get("MP_SA_SPLIT", "1") != "0" and any(t in dom for t in ("fused", "chunk", "bwd_first", "gemm")):
-                # `achieved` / `peak` above price the ALGORITHMIC fp32 flops against the fp32-input MFMA peak.  The kernel executes
-                # each fp32 product as six bf16 MFMA products on (h, m, l) operand planes (sa_mlp.hip: split3), so the matrix cores
-                # see 6x the flops at the bf16 rate; both views and the HBM view of the same launch:
-                line["roofline"]["executed"] = {
-                    "what": "fp32 contraction as 6 bf16 plane products (v_mfma_f32_32x32x16_bf16, fp32 accumulate)",
-                    "mfma_TFLOPs": 6.0 * flops / avg_s / 1e12, "mfma_peak": BF16_PEAK_TFLOPS, "mfma_frac": 6.0 * flops / avg_s / 1e12 / BF16_PEAK_TFLOPS,
-                    "hbm_GBps": nbytes / avg_s / 1e9, "hbm_peak": HBM_PEAK_GBS, "hbm_frac": nbytes / avg_s / 1e9 / HBM_PEAK_GBS}
+            split = args.dtype == "f32" and os.environ.get("MP_SA_SPLIT", "1") != "0"
+
+            def roof(k):
+                """One kernel against its roofs.  `achieved` / `peak` / `frac` price the ALGORITHMIC work per launch
+                against the peak of the dtype the path computes in (fp32-input MFMA 157.3 TF, or bf16 with --dtype bf16) or
+                against HBM, whichever the work model says binds.  `executed` is what the hardware actually does for the same launch
+                -- the split-plane kernels run each fp32 product as six bf16 MFMA products (sa_mlp.hip: split3), so the matrix cores see
+                6x the flops at the bf16 rate -- and `binding` names the larger of the executed matrix-core and HBM fractions: the roof
+                the kernel is really under."""
+                d = kernels[k]
+                avg_s = d["ms"] / d["calls"] * 1e-3
+                flops, nbytes = d["flops"] / d["calls"], d["bytes"] / d["calls"]
+                mfma_peak = BF16_PEAK_TFLOPS if "bf16" in k else FP32_PEAK_TFLOPS
+                if flops / (mfma_peak * 1e12) >= nbytes / (HBM_PEAK_GBS * 1e9):
+                    bound, ach, peak, unit = "mfma", flops / avg_s / 1e12, mfma_peak, "TFLOP/s"
+                else:
+                    bound, ach, peak, unit = "hbm", nbytes / avg_s / 1e9, HBM_PEAK_GBS, "GB/s"
+                r = {"kernel": k, "bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak,
+                     "traffic": measured_traffic(k), "avg_us": avg_s * 1e6, "launches_per_step": d["calls"] / max(profiled_steps, 1),
+                     "flops_per_launch": flops, "bytes_per_launch": nbytes}
+                planes = 6.0 if (split and "bf16" not in k and any(t in k for t in ("fused", "chunk", "bwd_first", "gemm", "lean"))) else 1.0
+                ex_peak = BF16_PEAK_TFLOPS if (planes > 1 or "bf16" in k) else FP32_PEAK_TFLOPS
+                ex = {"mfma_TFLOPs": planes * flops / avg_s / 1e12, "mfma_peak": ex_peak, "mfma_frac": planes * flops / avg_s / 1e12 / ex_peak,
+                      "hbm_GBps": nbytes / avg_s / 1e9, "hbm_peak": HBM_PEAK_GBS, "hbm_frac": nbytes / avg_s / 1e9 / HBM_PEAK_GBS}
+                if planes > 1:
+                    ex["what"] = "fp32 contraction as 6 bf16 plane products (v_mfma_f32_32x32x16_bf16, fp32 accumulate)"
+                r["executed"] = ex
+                r["binding"] = {"roof": "mfma" if ex["mfma_frac"] >= ex["hbm_frac"] else "hbm", "frac": max(ex["mfma_frac"], ex["hbm_frac"])}
+                return r
+            line["roofline"] = roof(dom)
+            if split:
                 line["config"]["contraction"] = "fp32 operands as three bf16 planes, six plane products per fp32 product on the bf16 matrix cores"
+            # kernels that run on the other streams underneath the step (not candidates for `roofline.kernel`, which is the largest
+            # kernel of the step's own chain): reported here with their own fractions instead of being dropped
+            side_k = [k for k in kernels if off_path(k)]
+            if side_k:
+                line["side_stream"] = {k: {kk: vv for kk, vv in roof(k).items() if kk != "kernel"} for k in side_k}
             floors = fps_floors(ts, lib) if world == 1 else {}
             line["named_kernels"], line["kernels_us_per_step"] = kernel_tables(kernels, max(profiled_steps, 1), floors)
         side = world == 1 and not args.no_side_legs and args.path == "harness" and args.dist == "cuboid" and args.encoder == "ssg"

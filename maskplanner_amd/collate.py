@@ -45,15 +45,18 @@ def lambda_segments(poses, stroke_ids, lmbda, overlapping=0, device="cuda"):
     """get_sequences_of_lambda_points (utils/pointcloud.py:294-413, padding=True) for a whole batch, on the device.
 
     poses: B numpy arrays [n_b, D] (one pose per row, strokes back to back); stroke_ids: B arrays [n_b] (ascending 0, 0, .., 1, ..).
-    -> (traj f32 [B, R, lmbda*D] padded with -100, ids f32 [B, R] padded with -1) with R = the largest per-sample row count the
+    -> (traj f32 [B, R, lmbda*D] padded with -100, ids f32 [B, R] padded with -1, status i32 [B]: 0, or non-zero for a sample
+    the kernel refuses -- more than 1024 strokes or ids that are not ascending from 0 -- whose rows are then all padding; callers
+    that can afford a host sync check it, see Paintnet_ODv1_CollateBatch) with R = the largest per-sample row count the
     reference pads to ((n - lmbda) // (lmbda - overlapping) + 1, resp. n // lmbda), i.e. the tensors its dataset + collate
     function produce together (utils/dataset/paintnet_ODv1.py:294, 738-748).  One flat host-to-device copy per key."""
     poses = [np.asarray(p, dtype=np.float32) for p in poses]
     ids = [np.asarray(i, dtype=np.float32).reshape(-1) for i in stroke_ids]
+    if not poses or any(p.ndim != 2 for p in poses) or any(p.shape[1] != poses[0].shape[1] for p in poses) \
+            or [i.shape[0] for i in ids] != [p.shape[0] for p in poses]:
+        raise ValueError("poses must be [n_b, D] arrays with one stroke id per pose")
     D = poses[0].shape[1]
     lens = [p.shape[0] for p in poses]
-    if any(p.ndim != 2 or p.shape[1] != D for p in poses) or [i.shape[0] for i in ids] != lens:
-        raise ValueError("poses must be [n_b, D] arrays with one stroke id per pose")
     rows = [((n - lmbda) // (lmbda - overlapping) + 1 if overlapping else n // lmbda) if n >= lmbda else 0 for n in lens]
     B, R = len(poses), max(rows + [0])
     dev = torch.device(device)

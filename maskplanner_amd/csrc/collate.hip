@@ -49,8 +49,11 @@ __global__ __launch_bounds__(256) void lambda_segments_kernel(const float* __res
     if (tid == 0) { s_nstrokes = n > 0 ? (int)id[n - 1] + 1 : 0; s_bad = 0; }
     __syncthreads();
     const int ns = s_nstrokes;
-    if (ns > SEG_MAX_STROKES || ns < 0) {
+    if (ns > SEG_MAX_STROKES || ns < 0) {   // unsupported sample: its rows are all padding (-100 / -1), never uninitialised memory
         if (tid == 0) status[b] = MP_EUNSUPPORTED;
+        const int W = lambda * D;
+        for (int64_t e = tid; e < (int64_t)R * W; e += 256) out_traj[(int64_t)b * R * W + e] = -100.0f;
+        for (int r = tid; r < R; r += 256) out_ids[(int64_t)b * R + r] = -1.0f;
         return;
     }
     for (int s = tid; s <= ns; s += 256) s_start[s] = s == ns ? n : -1;

@@ -43,6 +43,12 @@ class TrainStep:
         # graph B (~20 launches per step instead of ~170, so eight ranks sharing one host do not become host-bound).  Replayed
         # with two ranks on one GPU (tests/test_gpu_dp.py) and with one RCCL rank (tools/rccl_single_rank.py).
         self.dp_graph = dp.exchanging() and os.environ.get("MASKPLANNER_DP_GRAPH", "1") != "0"
+        # Replica guard of that path (it has run with gloo ranks on one GPU and with a single RCCL rank only -- the first real multi-GPU
+        # run is the driver's): after each of the first MASKPLANNER_DP_GUARD_STEPS replayed steps every rank compares a checksum of
+        # ALL its weights with the other ranks' (one small all-gather + one host read); replicas that differ or went non-finite make
+        # every rank drop the graphs, take rank 0's weights and optimizer state, and go on kernel by kernel (_dp_guard).
+        self._guard_left = int(os.environ.get("MASKPLANNER_DP_GUARD_STEPS", "2")) if self.dp_graph else 0
+        self.dp_fell_back = False
         self.use_graph = bool(graph) and fused and (not dp.exchanging() or self.dp_graph) and not prefetch_sampling and not self.sync_bn
         self._graph, self._graph_loss, self._eager_steps, self._side = None, None, 0, None
         # Pipelined first-level sampling (see _eager_step): FPS can occupy only one workgroup per cloud -- 32 of 256 CUs for
@@ -70,7 +76,9 @@ class TrainStep:
         # pair, the step advanced once per training step.  MASKPLANNER_FUSED_DROPOUT=0 keeps nn.Dropout (torch's Philox stream).
         self._drop_rng = None
         if fused and os.environ.get("MASKPLANNER_FUSED_DROPOUT", "1") != "0" and hasattr(self.model, "heads"):
-            self._drop_rng = torch.tensor([int(seed) * 0x9E3779B1 + 12345, 0], dtype=torch.int64, device=self.device)
+            # (the rank is mixed in: the reference's single process draws an independent mask per row of the GLOBAL batch, so
+            # replicas must not share theirs)
+            self._drop_rng = torch.tensor([int(seed) * 0x9E3779B1 + 12345 + int(rank) * 0x632BE5AB, 0], dtype=torch.int64, device=self.device)
             self._drop_step = self._drop_rng[1:2]
             self.model.fused_dropout = self._drop_rng
         self.factor_opt = None
@@ -150,11 +158,30 @@ class TrainStep:
                                          mask_scores=mask_conf, seg_logits=seg_conf, stroke_ids=self.batch["stroke_ids"],
                                          traj_as_pc=self.batch["traj_as_pc"])
 
+    def check(self, loss=None):
+        """What the asynchronous step cannot do without a host sync: raise if the last stroke-mask matching failed (the reference
+        asserts / scipy raises there: loss_handler.py:852-875) or the loss is not finite.  step() calls it every CHECK_EVERY
+        steps; loops that log call it at their logging points."""
+        self.loss_handler.check()
+        loss = self._graph_loss if loss is None else loss
+        if loss is not None and not bool(torch.isfinite(loss.detach()).all()):
+            raise FloatingPointError(f"training loss is not finite ({float(loss.detach())}) after {self._steps_done} steps")
+
+    CHECK_EVERY = int(os.environ.get("MASKPLANNER_CHECK_EVERY", "500"))   # 0: never from step()
+    _steps_done = 0
     _adam_delay_cycles = 0
     GRAPH_AFTER = 3   # eager steps before recording (allocator warm, lazy kernel attributes set, optimizer state created)
 
     def step(self):
-        """One optimisation step; returns the (device) loss tensor without synchronising."""
+        """One optimisation step; returns the (device) loss tensor without synchronising (every CHECK_EVERY-th call reads the
+        matching status and the loss of the step before: see check())."""
+        loss = self._step()
+        self._steps_done += 1
+        if self.CHECK_EVERY and self._steps_done % self.CHECK_EVERY == 0:
+            self.check(loss)
+        return loss
+
+    def _step(self):
         # MASKPLANNER_PLAN_AFTER_FORWARD=1: the next batch's sampling starts BEHIND the encoder forward (graph A), underneath the
         # heads / loss part of graph B, instead of at the start of the step.  [r2] measured: the same step time either way (FPS then
         # stretches the loss's kNN kernels by what it no longer costs the forward), so the switch is off.
@@ -172,6 +199,9 @@ class TrainStep:
                 if self._adam_ev is not None:
                     torch.cuda.current_stream().wait_event(self._adam_ev)   # the head weights of the previous step are final
                 self._replay_b()
+            if self._guard_left > 0 and self.dp_graph:
+                self._guard_left -= 1
+                self._dp_guard()
             return self._graph_loss
         if not self.use_graph:
             return self._eager_step()
@@ -288,7 +318,61 @@ class TrainStep:
             sa_mlp.DEFERRED_TICKS = None
             warnings.warn(f"hipGraph capture of the training step failed ({type(exc).__name__}: {exc}); running eagerly")
             self._graph, self._graph_b, self._graph_b2, self.use_graph = None, None, None, False
+            if self.dp_graph:
+                self.dp_graph, self._guard_left, self.reducer.deferred = False, 0, False
+            if self.factor_opt is not None:
+                self._reset_factor_store()      # queued bias-gradient entries point into the dropped graph pool
             torch.cuda.synchronize()
+
+    @torch.no_grad()
+    def _dp_guard(self):
+        """Replica consistency of the graph-replayed data-parallel step: identical weights on every rank, all finite.  Collective (every
+        rank calls it at the same step and sees the same gathered table, so every rank takes the same decision)."""
+        import torch.distributed as dist
+        if self._adam_ev is not None:
+            torch.cuda.current_stream().wait_event(self._adam_ev)       # the head weights of this step are final
+        ps = list(self.model.parameters())
+        norms = torch.stack(torch._foreach_norm(ps)).double()
+        wts = torch.arange(1, norms.numel() + 1, dtype=torch.float64, device=norms.device)
+        mine = torch.stack([norms.sum(), (norms * wts).sum(), self._graph_loss.detach().double().reshape(())])
+        world = dist.get_world_size()
+        rows = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(rows, mine)                  # (the list form: every backend has it)
+        table = torch.stack(rows).cpu()
+        ok = bool(torch.isfinite(table).all()) and bool((table[:, :2] == table[0, :2]).all())
+        if os.environ.get("MASKPLANNER_DP_GUARD_TRIP") == str(self._guard_left):      # test hook: behave as if the replicas differed
+            ok = False
+        if ok:
+            return
+        import warnings
+        warnings.warn("data-parallel graph replay: replicas differ or are non-finite after a replayed step "
+                      f"(checksums {table[:, 0].tolist()}); taking rank 0's state and continuing with eager launches")
+        self._dp_fallback()
+
+    @torch.no_grad()
+    def _dp_fallback(self):
+        import torch.distributed as dist
+        torch.cuda.synchronize()
+        self._graph, self._graph_b, self._graph_b2, self._graph_loss = None, None, None, None
+        self.use_graph, self.dp_graph, self._guard_left, self.dp_fell_back = False, False, 0, True
+        self.reducer.deferred = False
+        self._static_grads, self._factor_args, self._adam_ev, self._adam_pending = None, None, None, False
+        state = list(self.model.parameters()) + [b for b in self.model.buffers() if b.is_floating_point()]
+        for opt in (self.opt, self.factor_opt):
+            if opt is None:
+                continue
+            for st in opt.state.values():
+                state += [v for v in st.values() if torch.is_tensor(v)]
+            if getattr(opt, "step_dev", None) is not None:
+                state.append(opt.step_dev)
+        for t in state:
+            dist.broadcast(t, src=0)
+        for p in self.model.parameters():
+            p.grad = None
+        self.reducer.zero_grad()
+        if self.factor_opt is not None:
+            self._reset_factor_store()
+        torch.cuda.synchronize()
 
     def _reset_factor_store(self):
         self.model.factor_store.clear()

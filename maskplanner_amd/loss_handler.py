@@ -74,12 +74,14 @@ def segment_distance_to_confidence(distance):
 
 
 def stroke_masks_loss(pred_to_gt_match, pred_stroke_masks, scores, stroke_ids, w_masks, w_conf, no_stroke_weight,
-                      return_matching=False, nn_distance=None, smooth_targets=False, add=None):
+                      return_matching=False, nn_distance=None, smooth_targets=False, add=None, sink=None):
     """get_stroke_masks_loss (loss_handler.py:816-935).
 
     pred_to_gt_match i64 [B,S] (nearest GT segment of every predicted segment), pred_stroke_masks [B,M,S] logits,
     scores [B,M] logits, stroke_ids [B,Sgt] f32 (-1 = padding).  smooth_targets (:841-844, :959-964): the 1s of the
     target masks become f(nn_distance [B,S]) and both the matching cost and the loss are MSE instead of BCE (:830).
+    sink: the object that keeps this call's matching status (`sink.last_match_status`, a device i32 [B]) for a later
+    check_mask_matching(sink); a LossHandler passes itself.  Without one the status goes to this module's slot (direct callers).
     """
     dev = pred_stroke_masks.device
     target_ids = stroke_ids.to(dev, dtype=torch.float32).gather(1, pred_to_gt_match)          # :838
@@ -89,8 +91,11 @@ def stroke_masks_loss(pred_to_gt_match, pred_stroke_masks, scores, stroke_ids, w
     # The reference asserts that no predicted segment is matched to the padding id and that the masks are exclusive
     # (:852-854), and scipy raises on an infeasible cost (:875).  Here nothing synchronises with the host, so a failed sample
     # poisons the loss instead (NaN) and its status is kept for callers that do synchronise (LossHandler.compute).
-    _last_status.append(status)
-    del _last_status[:-1]
+    if sink is not None:
+        sink.last_match_status = status
+    else:
+        _last_status.append(status)
+        del _last_status[:-1]
     if not smooth_targets and not return_matching and pred_stroke_masks.dtype == torch.float32:
         # binary targets: the rest of the function as three launches (ops.mask_loss); same algebra, fixed summation order
         return ops.mask_loss(pred_stroke_masks, scores, target_ids, match, uniq, w_masks, w_conf, no_stroke_weight, status=status,
@@ -116,15 +121,21 @@ def stroke_masks_loss(pred_to_gt_match, pred_stroke_masks, scores, stroke_ids, w
     return (loss, match) if return_matching else loss
 
 
-_last_status = []     # the most recent mask_match status tensor (device, i32 [B])
+_last_status = []     # the most recent mask_match status tensor (device, i32 [B]) of a call without a `sink`
 
 
-def check_mask_matching():
-    """Raise if the most recent stroke-mask matching failed on any sample (this reads a device tensor: one host sync).
-    LossHandler.compute(return_list=True) calls it, since that call synchronises anyway."""
-    if not _last_status:
-        return
-    st = _last_status[-1]
+def check_mask_matching(sink=None):
+    """Raise if the most recent stroke-mask matching (of `sink`, e.g. a LossHandler; of the sink-less direct callers otherwise)
+    failed on any sample.  This reads a device tensor: one host sync.  LossHandler.compute(return_list=True) calls it, since
+    that call synchronises anyway; asynchronous callers (harness.TrainStep) call LossHandler.check() at their logging points."""
+    if sink is not None:
+        st = getattr(sink, "last_match_status", None)
+        if st is None:
+            return
+    else:
+        if not _last_status:
+            return
+        st = _last_status[-1]
     bad = st.nonzero().flatten().tolist()
     if bad:
         code = int(st[bad[0]])
@@ -216,9 +227,16 @@ class LossHandler:
             values.append(value.detach())
         if return_list:
             array = torch.stack(values).cpu().numpy()
-            check_mask_matching()
+            check_mask_matching(self)
             return total, array
         return total
+
+    def check(self):
+        """For callers of compute(return_list=False): raise with the decoded reason if the last stroke-mask matching of THIS
+        handler failed (a predicted segment matched to the -1 padding id, more than 64 masks / stroke ids, an infeasible assignment
+        -- conditions the reference asserts or raises on, loss_handler.py:852-875, and which only turn the asynchronous loss into
+        NaN).  One host sync."""
+        check_mask_matching(self)
 
     def log_on_wandb(self, loss_list, wandb, epoch, suffix="_train_loss"):
         """One wandb.log call per configured term (loss_handler.py:234-244; no discriminator terms on this path)."""
@@ -295,7 +313,7 @@ class LossHandler:
         return stroke_masks_loss(pred_to_gt_match, pred_stroke_masks, scores, stroke_ids,
                                  cfg["explicit_weight_stroke_masks"], cfg["explicit_weight_stroke_masks_confidence"],
                                  cfg["explicit_no_stroke_weight"], nn_distance=nn_distance, smooth_targets=bool(smooth_targets),
-                                 add=_add)
+                                 add=_add, sink=self)
 
     @staticmethod
     def _transform_segment_distance_to_confidence(distance):

@@ -437,9 +437,15 @@ _REDUCE_COUNTERS = {}
 
 
 def _reduce_counter(device):
-    """The zero-on-entry / zero-on-exit device counter of the one-launch reductions: one per device (the loss terms of a step run on
-    one stream, one after the other; created by the first eager call, i.e. before any graph capture)."""
-    key = device
+    """The zero-on-entry / zero-on-exit device counter of the one-launch reductions.  Launches on one stream run one after the other
+    and may share a counter; launches on two streams (evaluation metrics next to the training stream) must not, so eager launches
+    get one counter per (device, stream).  Launches recorded into a hipGraph get the device's "graph" counter: replays of the
+    training step's graphs are ordered among themselves, and the counter is created by the first EAGER call (the harness runs
+    eager steps before it records), so no allocation or fill lands inside a capture."""
+    graph_key = (device, "graph")
+    if graph_key not in _REDUCE_COUNTERS and not torch.cuda.is_current_stream_capturing():
+        _REDUCE_COUNTERS[graph_key] = torch.zeros((1,), dtype=torch.int32, device=device)
+    key = graph_key if torch.cuda.is_current_stream_capturing() else (device, torch.cuda.current_stream(device).cuda_stream)
     t = _REDUCE_COUNTERS.get(key)
     if t is None:
         t = torch.zeros((1,), dtype=torch.int32, device=device)

@@ -16,6 +16,8 @@ g7_mask  loss_handler.py:596-666,816-935  asymm_v6 loss + stroke-mask loss
 g8_hung  models/hungarianMatcher.py:31-63 HungarianMatcher
 g9_seg   models/pointnet2_seg.py:14-96,258-339 PointNet2Segmenter_v1 / _PaintNet_v1 (eval forward)
 g10_fp   models/pointnet2_utils.py:279-329 PointNetFeaturePropagation      3-NN interpolation + MLP fwd/bwd (train+eval)
+                                         (its two `*_g_points2` arrays come out of torch's multi-threaded CPU scatter-add: they
+                                         regenerate equal to ~1e-6, not bit for bit; every other fixture regenerates byte-identical)
 g11_smooth loss_handler.py:830,841-844,959-964 smooth_target_stroke_masks  MSE mask matching + loss on g7's inputs
 g12_flags pytorch3d_chamfer.py:180-291  chamfer_distance: velocities / min_centroids / avoid_in_sequence_collapsing /
                                          soft_attraction / normals / weights (values + gradients)
@@ -26,6 +28,9 @@ g14_collate utils/dataset/paintnet_ODv1.py:726-847 Paintnet_ODv1_CollateBatch.__
 g16_lambda utils/pointcloud.py:294-413 get_sequences_of_lambda_points (+ add_padding) on ragged synthetic strokes
 g15_train models/pointnet2_cls_ssg.py:233-344 the full model of g5 (same weights) in TRAIN mode (dropout p = 0) on 8 clouds:
                                          outputs, running statistics after the pass, gradients of a linear functional
+g17_siblings models/pointnet2_cls_ssg.py:85,177,463 PointNet2Regressor_SoPs / _3Dbbox / _StrokeWise (eval + train, gradients);
+                                         models/pointnet2_seg.py:14-96,258-339 the segmenters' backward;
+                                         models/pointnet2_utils.py:144-145 sample_and_group(returnfps=True)
 """
 import os
 import sys
@@ -631,11 +636,18 @@ def g14_collate():
     print("g14_collate")
     from oracle import env_stubs
     env_stubs.install()
+    # g7 / g11 / g13 load loss_handler.py against STAND-INS for the reference's `utils` / `models` packages (ref_import.
+    # loss_handler_module); this fixture needs the real `utils` package, so the stand-ins step aside while it is imported and come
+    # back afterwards (the all-in-one run `python -m oracle.gen_golden` otherwise died here with ModuleNotFoundError: utils.dataset)
+    parked = {k: sys.modules.pop(k) for k in list(sys.modules) if k == "utils" or k.startswith("utils.")}
     sys.path.insert(0, R.REF_ROOT)
     try:
         from utils.dataset.paintnet_ODv1 import Paintnet_ODv1_CollateBatch
     finally:
         sys.path.remove(R.REF_ROOT)
+        for k in [k for k in sys.modules if k == "utils" or k.startswith("utils.")]:
+            del sys.modules[k]
+        sys.modules.update(parked)
     rng = np.random.default_rng(1414)
     cfg = R.AttrDict(lambda_points=4, overlapping=1, extra_data=["orientnorm"], task_name="MaskPlanner", out_prototypes=None,
                      load_extra_data=["stroke_masks"], traj_with_equally_spaced_points=True)      # traj_sampling_v2.yaml
@@ -735,12 +747,111 @@ np.savez({os.path.join(tmp, 'out.npz')!r}, **out)
     save("g16_lambda", **cases)
 
 
+def _grad_digest(cases, prefix, named_params):
+    """Gradients of a whole module in a small fixture: tensors up to 16 384 elements in full, larger ones as their L2 norm plus the
+    values at 4 096 fixed positions (a seeded draw per tensor, repeated by the test)."""
+    for i, (n, p) in enumerate(named_params):
+        if p.grad is None:
+            continue
+        g = p.grad.detach().reshape(-1)
+        if g.numel() <= 16384:
+            cases[f"{prefix}grad_{n}"] = p.grad.numpy().copy()
+        else:
+            pos = np.random.default_rng(4242 + i).choice(g.numel(), size=4096, replace=False)
+            cases[f"{prefix}gsamp_{n}"] = g.numpy()[pos].copy()
+            cases[f"{prefix}gnorm_{n}"] = np.float64(g.double().norm())
+
+
+def g17_siblings():
+    """What round 2 left without a number: the three sibling regressors of models/pointnet2_cls_ssg.py (:85 SoPs, :177 3Dbbox, :463
+    StrokeWise) in eval AND train mode with gradients, the BACKWARD of the two segmenters (models/pointnet2_seg.py:14-96, 258-339;
+    g9 holds their eval forward), and sample_and_group(returnfps=True) (models/pointnet2_utils.py:144-145)."""
+    print("g17_siblings")
+    pc = R.pointnet2_cls_ssg()
+    pu = R.pointnet2_utils()
+    sg = R.pointnet2_seg()
+    rng = np.random.default_rng(1717)
+    cases = {}
+    B, N = 4, 1024
+    xyz = syn.point_cloud(rng, B, N, "cuboid")
+    cases["xyz"] = xyz
+
+    def draws(seed, n1=N, n2=512):
+        torch.manual_seed(seed)
+        return torch.randint(0, n1, (B,)).numpy(), torch.randint(0, n2, (B,)).numpy()
+
+    models = {
+        "sops": (lambda: pc.PointNet2Regressor_SoPs(out_vectors=7, outdim=3, outdim_orient=3, weight_orient=0.25, hidden_size=(64, 64),
+                                                    sop_confidence_scores=True), 171),
+        "bbox": (lambda: pc.PointNet2Regressor_3Dbbox(out_bboxes=5, hidden_size=(64, 64)), 172),
+        "sw": (lambda: pc.PointNet2Regressor_StrokeWise(outdim=12, outdim_orient=12, weight_orient=0.25, out_vectors=9, hidden_size=(64, 64),
+                                                        stroke_confidence_scores=True, point_confidence_scores=True,
+                                                        n_points_per_out_vector=4), 173),
+    }
+    for tag, (ctor, seed) in models.items():
+        torch.manual_seed(seed)
+        m = ctor()
+        cases.update({f"{tag}_ck_{k}": np.float64(v.double().abs().sum()) for k, v in m.state_dict().items()})
+        x = torch.from_numpy(xyz).permute(0, 2, 1)
+        m.eval()
+        cases[f"{tag}_eval_s1"], cases[f"{tag}_eval_s2"] = draws(seed + 100)
+        torch.manual_seed(seed + 100)
+        with torch.no_grad():
+            outs = m(x)
+        outs = outs if isinstance(outs, tuple) else (outs,)
+        for i, o in enumerate(outs):
+            cases[f"{tag}_eval_out{i}"] = o.numpy()
+        m.train()
+        m.dropout.p = 0.0
+        cases[f"{tag}_train_s1"], cases[f"{tag}_train_s2"] = draws(seed + 200)
+        torch.manual_seed(seed + 200)
+        outs = m(x)
+        outs = outs if isinstance(outs, tuple) else (outs,)
+        total = 0
+        for i, o in enumerate(outs):
+            w = rng.normal(size=tuple(o.shape)).astype(np.float32)
+            cases[f"{tag}_train_out{i}"], cases[f"{tag}_w{i}"] = o.detach().numpy().copy(), w
+            total = total + (o * torch.from_numpy(w)).sum()
+        total.backward()
+        _grad_digest(cases, tag + "_", list(m.named_parameters()))
+        cases.update({f"{tag}_after_{k}": v.detach().numpy().copy() for k, v in m.state_dict().items() if "running" in k})
+
+    # segmenter backward: the modules of g9 (same seeds => same weights), train mode, a linear functional of the per-point output
+    segs = rng.uniform(-0.5, 0.5, size=(B, 24, N)).astype(np.float32)
+    cases["sg_in"] = segs
+    for tag, ctor, seed, inp in (("pn", lambda: sg.PointNet2Segmenter_PaintNet_v1(inputdim=3, outdim_trasl=3, outdim_orient=3,
+                                                                                  weight_orient=0.25, lambda_points=2), 9, xyz.transpose(0, 2, 1)),
+                                 ("sg", lambda: sg.PointNet2Segmenter_v1(outdim=5, input_orient_dim=3, lambda_points=4,
+                                                                         ball_in_xyz_space=True), 10, segs)):
+        torch.manual_seed(seed)
+        m = ctor()
+        m.train()
+        cases.update({f"{tag}_ck_{k}": np.float64(v.double().abs().sum()) for k, v in m.state_dict().items()})
+        cases[f"{tag}_s1"], cases[f"{tag}_s2"] = draws(seed + 300)
+        torch.manual_seed(seed + 300)
+        out = m(torch.from_numpy(np.ascontiguousarray(inp)))
+        w = rng.normal(size=tuple(out.shape)).astype(np.float32)
+        cases[f"{tag}_out"], cases[f"{tag}_w"] = out.detach().numpy().copy(), w
+        (out * torch.from_numpy(w)).sum().backward()
+        _grad_digest(cases, tag + "_", list(m.named_parameters()))
+
+    # sample_and_group(..., returnfps=True): the two extra return values
+    feats = rng.normal(size=(B, N, 5)).astype(np.float32)
+    cases["rf_feats"] = feats
+    torch.manual_seed(77)
+    cases["rf_start"] = torch.randint(0, N, (B,)).numpy()
+    torch.manual_seed(77)
+    new_xyz, new_points, grouped_xyz, fps_idx = pu.sample_and_group(64, 0.3, 16, torch.from_numpy(xyz), torch.from_numpy(feats), returnfps=True)
+    cases.update(rf_new_xyz=new_xyz.numpy(), rf_new_points=new_points.numpy(), rf_grouped_xyz=grouped_xyz.numpy(), rf_fps_idx=fps_idx.numpy())
+    save("g17_siblings", **cases)
+
+
 def main():
     if not R.available():
         raise SystemExit("reference checkout not found; fixtures can only be generated in the build container")
     torch.set_num_threads(8)
     pu = R.pointnet2_utils()
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17"]
     if "g1" in which: g1_fps(pu)
     if "g2" in which: g2_bq(pu)
     if "g3" in which: g3_sa(pu)
@@ -757,6 +868,7 @@ def main():
     if "g14" in which: g14_collate()
     if "g15" in which: g15_train()
     if "g16" in which: g16_lambda()
+    if "g17" in which: g17_siblings()
 
 
 if __name__ == "__main__":

@@ -8,6 +8,11 @@ HIP path at sizes the fixtures do not cover and as bench.py's cpu_baseline ("por
 
 Layout note: activations are kept positions-major [B,S,K,C] (the reference uses [B,C,K,S]); a 1x1
 Conv2d is then a plain matmul over the last axis, and BatchNorm2d statistics are over all leading axes.
+
+fp64 arbiter: every function takes its floating-point type from its inputs.  Called with float64 weights and
+inputs, the algebra runs in double precision while every DISCRETE step (FPS, ball query, nearest neighbours,
+the assignment) is still taken on the float32 values the fp32 paths see -- the same function with ~1e-16
+rounding, against which the fp32 oracle and the HIP path can both be measured (tests/test_gpu_arbiter.py).
 """
 import numpy as np
 import torch
@@ -98,12 +103,12 @@ def set_abstraction(xyz, feats, layers, npoint, radius, nsample, fps_start, trai
     B, N, _ = xyz.shape
     if group_all:  # sample_and_group_all :151-168 -- xyz NOT centred, new_xyz = 0
         x = xyz if feats is None else torch.cat([xyz, feats], -1)
-        return torch.zeros(B, 1, 3), shared_mlp_max(x[:, None], layers, train, bf16)
-    xyz_np = xyz.detach().numpy()
+        return torch.zeros(B, 1, 3, dtype=xyz.dtype), shared_mlp_max(x[:, None], layers, train, bf16)
+    xyz_np = xyz.detach().float().numpy()
     fidx = O.fps(xyz_np, npoint, fps_start)
     new_xyz_np = O.index_points(xyz_np, fidx)
     gidx = torch.from_numpy(O.ball_query(radius, nsample, xyz_np, new_xyz_np))
-    new_xyz = torch.from_numpy(new_xyz_np)
+    new_xyz = torch.from_numpy(new_xyz_np).to(xyz.dtype)
     bidx = torch.arange(B)[:, None, None]
     g = xyz[bidx, gidx] - new_xyz[:, :, None]
     if feats is not None:
@@ -114,10 +119,10 @@ def set_abstraction(xyz, feats, layers, npoint, radius, nsample, fps_start, trai
 def set_abstraction_msg(xyz, feats, blocks, npoint, radii, nsamples, fps_start, train, bf16=False):
     """PointNetSetAbstractionMsg (:219-276): one FPS, per-radius ball query; channel order FEATS first, xyz last."""
     B = xyz.shape[0]
-    xyz_np = xyz.detach().numpy()
+    xyz_np = xyz.detach().float().numpy()
     fidx = O.fps(xyz_np, npoint, fps_start)
     new_xyz_np = O.index_points(xyz_np, fidx)
-    new_xyz = torch.from_numpy(new_xyz_np)
+    new_xyz = torch.from_numpy(new_xyz_np).to(xyz.dtype)
     bidx = torch.arange(B)[:, None, None]
     outs = []
     for layers, r, K in zip(blocks, radii, nsamples):
@@ -169,7 +174,7 @@ def encoder_forward(sd, xyz, fps_starts, train, encoder="ssg", bf16=False):
 
 
 def strokemasks_forward(sd, xyz, fps_starts, train, out_vectors, n_masks, weight_orient=0.25, dropout_masks=None,
-                        encoder="ssg", bf16=False):
+                        encoder="ssg", bf16=False, return_feat=False):
     """sd: reference-layout state_dict of tensors; xyz [B,N,3].  dropout_masks: optional list of 4
     pre-scaled keep masks (train mode) so dropout is reproducible; None = no dropout.
     encoder "msg": two multi-scale levels + group_all; bf16: the grouped-MLP contractions with bf16-rounded operands."""
@@ -186,7 +191,37 @@ def strokemasks_forward(sd, xyz, fps_starts, train, out_vectors, n_masks, weight
     nrm = torch.tanh(final @ sd["fc_normals.weight"].t() + sd["fc_normals.bias"]).view(B, -1, 3)
     nrm = F.normalize(nrm, dim=-1) * weight_orient
     out = torch.cat([pos.view(B, -1, 3), nrm], -1).view(B, out_vectors, -1)
+    if return_feat:
+        return out, sm_out, mask_conf, feat
     return out, sm_out, mask_conf
+
+
+def _pose_out(sd, final, pos, B, out_vectors, weight_orient):
+    """The pose assembly shared by the regressors (e.g. models/pointnet2_cls_ssg.py:159-166): unit normals x weight_orient
+    appended to each predicted position."""
+    nrm = torch.tanh(final @ sd["fc_normals.weight"].t() + sd["fc_normals.bias"]).view(B, -1, 3)
+    nrm = F.normalize(nrm, dim=-1) * weight_orient
+    return torch.cat([pos.view(B, -1, 3), nrm], -1).view(B, out_vectors, -1)
+
+
+def sibling_forward(kind, sd, xyz, fps_starts, train, out_vectors, weight_orient=0.25, n_points=None):
+    """The three sibling regressors that share the StrokeMasks encoder and trunk (dropout off):
+    "sops"  PointNet2Regressor_SoPs       (models/pointnet2_cls_ssg.py:85-174)  -> (out, sop_conf)
+    "bbox"  PointNet2Regressor_3Dbbox     (:177-230)                            -> (out,)
+    "sw"    PointNet2Regressor_StrokeWise (:463-559)                            -> (out, point_conf, stroke_conf)"""
+    B = xyz.shape[0]
+    feat = encoder_forward(sd, xyz, fps_starts, train)
+    x = torch.relu(_bn1d(feat @ sd["fc1.weight"].t() + sd["fc1.bias"], sd, "bn1", train))
+    last = torch.relu(_bn1d(x @ sd["fc2.weight"].t() + sd["fc2.bias"], sd, "bn2", train))
+    pos = last @ sd["fc3.weight"].t() + sd["fc3.bias"]
+    if kind == "bbox":
+        return (pos.view(B, out_vectors, 6),)
+    out = _pose_out(sd, last, pos, B, out_vectors, weight_orient)
+    if kind == "sops":
+        return out, last @ sd["sop_conf_out.weight"].t() + sd["sop_conf_out.bias"]
+    stroke = last @ sd["stroke_conf_out.weight"].t() + sd["stroke_conf_out.bias"]
+    point = (last @ sd["point_conf_out.weight"].t() + sd["point_conf_out.bias"]).view(B, out_vectors, n_points)
+    return out, point, stroke
 
 
 # ------------------------------------------------------------------------------------------------
@@ -209,14 +244,27 @@ class _Knn1(torch.autograd.Function):
         return torch.from_numpy(g1), torch.from_numpy(g2), None, None
 
 
+def _knn1_any_dtype(p1, p2, l1, l2):
+    """The K = 1 search for the fp64 arbiter: the neighbour is chosen on the float32 values (the C oracle's search, i.e. the
+    discrete decision of the fp32 paths), the squared distance to it is plain torch algebra in the inputs' own type."""
+    _, i = O.knn_points(p1.detach().float().numpy(), p2.detach().float().numpy(), l1.numpy(), l2.numpy(), 1)
+    i = torch.from_numpy(i[..., 0].copy())
+    nb = p2.gather(1, i[..., None].expand(-1, -1, p2.shape[2]))
+    d = (p1 - nb).square().sum(-1)
+    valid = (torch.arange(p1.shape[1])[None] < l1[:, None]) & (l2[:, None] > 0)
+    return torch.where(valid, d, torch.zeros((), dtype=d.dtype)), i
+
+
 def chamfer_distance(x, y, padded=False, asymmetric=False, reverse_asymmetric=False, return_matching=False,
                      batch_reduction="mean", point_reduction="mean"):
     B, P1, D = x.shape
     P2 = y.shape[1]
     xl = torch.full((B,), P1, dtype=torch.int64)
-    yl = torch.from_numpy(O.padded_lengths(y.detach().numpy())) if padded else torch.full((B,), P2, dtype=torch.int64)
-    cx, ix = _Knn1.apply(x, y, xl, yl)
-    cy, iy = _Knn1.apply(y, x, yl, xl)
+    yl = torch.from_numpy(O.padded_lengths(y.detach().float().numpy())) if padded else torch.full((B,), P2, dtype=torch.int64)
+    knn1 = _Knn1.apply if x.dtype == torch.float32 else _knn1_any_dtype
+    y = y.to(x.dtype)
+    cx, ix = knn1(x, y, xl, yl)
+    cy, iy = knn1(y, x, yl, xl)
     # rows beyond the length already hold 0 (knn contract) == the reference's masking (:263-266)
     if point_reduction is not None:
         cx, cy = cx.sum(1), cy.sum(1)
@@ -239,15 +287,15 @@ def stroke_masks_loss(idx_x, pred_masks, scores, stroke_ids, w_masks=1.0, w_conf
     tgt_ids = stroke_ids.gather(1, idx_x)
     assert not (tgt_ids == -1).any()
     matched_pred, matched_tgt, pairs = [], [], []
-    tscore = torch.zeros(B, M)
-    wts = torch.full((B, M), float(no_stroke_weight))
+    tscore = torch.zeros(B, M, dtype=pred_masks.dtype)
+    wts = torch.full((B, M), float(no_stroke_weight), dtype=pred_masks.dtype)
     for b in range(B):
-        masks, _ = O.stroke_ids_to_masks(tgt_ids[b].numpy())
-        cost = O.mask_bce_cost(pred_masks[b].detach().numpy(), masks)
+        masks, _ = O.stroke_ids_to_masks(tgt_ids[b].float().numpy())
+        cost = O.mask_bce_cost(pred_masks[b].detach().float().numpy(), masks)
         i, j = O.linear_sum_assignment(cost)
         pairs.append((i, j))
         matched_pred.append(pred_masks[b, torch.from_numpy(i)])
-        matched_tgt.append(torch.from_numpy(masks[j]))
+        matched_tgt.append(torch.from_numpy(masks[j]).to(pred_masks.dtype))
         tscore[b, torch.from_numpy(i)] = 1.0
         wts[b, torch.from_numpy(i)] = 1.0
     mp, mt = torch.cat(matched_pred), torch.cat(matched_tgt)

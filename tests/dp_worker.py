@@ -65,9 +65,11 @@ if mode == "syncbn":
     result = dict(feat=feat.detach().cpu(), out=outp.detach().cpu(), sm=sm.detach().cpu(), conf=conf.detach().cpu(), sl=(sl.start, sl.stop),
                   grads=grads, enc_grads=enc_grads,
                   running=running)
-elif mode in ("dp_graph", "dp_eager"):
+elif mode in ("dp_graph", "dp_eager", "dp_graph_trip"):
     from maskplanner_amd.harness import TrainStep
-    os.environ["MASKPLANNER_DP_GRAPH"] = "1" if mode == "dp_graph" else "0"
+    os.environ["MASKPLANNER_DP_GRAPH"] = "0" if mode == "dp_eager" else "1"
+    if mode == "dp_graph_trip":      # the replica guard's failure branch: the second guarded step pretends the replicas differ
+        os.environ["MASKPLANNER_DP_GUARD_TRIP"] = "0"
     ts = TrainStep("cuboids", B=4, N=1024, hidden_size=(128, 128), rank=rank, seed=9)
     ts.model.dropout.p = 0.0
     losses = []
@@ -85,7 +87,7 @@ elif mode in ("dp_graph", "dp_eager"):
         if d > 0:
             worst[n] = d
     result = dict(losses=losses, replica_diff=float((flat - ref).abs().max()), graph=ts._graph is not None and ts._graph_b is not None,
-                  params=flat.cpu(), diverged=worst)
+                  params=flat.cpu(), diverged=worst, fell_back=ts.dp_fell_back)
 else:
     raise SystemExit(f"unknown mode {mode}")
 

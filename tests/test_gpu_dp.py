@@ -95,3 +95,24 @@ def test_two_graph_step_replays_under_data_parallelism():
     lg, le = np.array(g[0]["losses"]), np.array(e[0]["losses"])
     assert np.isfinite(lg).all() and lg[-1] < lg[0]
     assert abs(lg[0] - le[0]) <= 1e-4 * abs(le[0]) and np.allclose(lg, le, rtol=5e-2), (lg, le)
+
+
+def test_four_ranks_replay_the_two_graph_step():
+    """The same launch path with FOUR ranks on the one GPU (gloo): the first 8-GPU run must not be the first time more than two
+    ranks execute the graph replay + deferred exchange + all-gathered factor Adam."""
+    g = _run("dp_graph", 4)
+    assert all(r["graph"] for r in g) and not any(r["fell_back"] for r in g)
+    assert max(r["replica_diff"] for r in g) == 0.0, g[1]["diverged"]
+    lg = np.array(g[0]["losses"])
+    assert np.isfinite(lg).all() and lg[-1] < lg[0]
+
+
+def test_replica_guard_falls_back_to_eager_launches():
+    """harness.TrainStep._dp_guard: when the replicas of a graph-replayed data-parallel step differ (here: the test hook says so on
+    the second guarded step), every rank drops the graphs, takes rank 0's weights and optimizer state and continues kernel by
+    kernel -- replicas identical afterwards, the loss keeps falling."""
+    g = _run("dp_graph_trip", 2)
+    assert all(r["fell_back"] for r in g) and not any(r["graph"] for r in g)
+    assert max(r["replica_diff"] for r in g) == 0.0, g[1]["diverged"]
+    lg = np.array(g[0]["losses"])
+    assert np.isfinite(lg).all() and lg[-1] < lg[0]

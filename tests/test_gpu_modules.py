@@ -1188,7 +1188,9 @@ def test_full_size_train_step_b32_vs_oracle(oracle):
     close(feat, o_feat, "encoder feature", rtol=1e-5, atol=1e-5)
     close(out, o_out, "out", rtol=6e-4, atol=1e-5)
     close(sm, o_sm, "sm_out", rtol=6e-4, atol=1e-5)
-    close(loss, o_loss, "loss", rtol=2e-4)
+    # (tests/test_gpu_arbiter.py runs the same step a third time in float64: the HIP loss is 1.5e-7 and the oracle's 2.3e-7 from it,
+    # the HIP predictions 9e-6 and the oracle's 3e-5 in relative L2 -- what is compared here is the oracle's distance, not the kernels')
+    close(loss, o_loss, "loss", rtol=2e-6)
     params = dict(model.named_parameters())
     # (bounds are about twice the routing noise measured between two fp32 implementations: [r2] 1.5e-2 .. 2.3e-2 on the encoder's
     # parameters with either the fp32-MFMA or the split-bf16 kernels, and varying from run to run with the dW atomics)

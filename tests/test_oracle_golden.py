@@ -248,3 +248,60 @@ def test_full_model_train_mode_matches_reference(golden):
     _close(mask_conf, g["mask_conf"], "mask_conf", rtol=1e-4, atol=1e-5)
     for k in ("sa1.mlp_bns.0.running_mean", "sa2.mlp_bns.2.running_var", "sa3.mlp_bns.1.running_mean", "bn1.running_var"):
         _close(sd[k], g["after_" + k], k, rtol=2e-5, atol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------------ g17: siblings, returnfps
+SIBLINGS = {
+    "sops": (lambda pc: pc.PointNet2Regressor_SoPs(out_vectors=7, outdim=3, outdim_orient=3, weight_orient=0.25, hidden_size=(64, 64),
+                                                   sop_confidence_scores=True), 171, dict(out_vectors=7)),
+    "bbox": (lambda pc: pc.PointNet2Regressor_3Dbbox(out_bboxes=5, hidden_size=(64, 64)), 172, dict(out_vectors=5)),
+    "sw": (lambda pc: pc.PointNet2Regressor_StrokeWise(outdim=12, outdim_orient=12, weight_orient=0.25, out_vectors=9, hidden_size=(64, 64),
+                                                       stroke_confidence_scores=True, point_confidence_scores=True,
+                                                       n_points_per_out_vector=4), 173, dict(out_vectors=9, n_points=4)),
+}
+
+
+def seeded_module(ctor, seed, g, prefix):
+    """g9 / g17 store per-tensor checksums of the reference module's weights; the same seed and registration order reproduce them."""
+    torch.manual_seed(seed)
+    m = ctor()
+    sd = m.state_dict()
+    keys = [k[len(prefix):] for k in g.files if k.startswith(prefix)]
+    assert list(sd.keys()) == keys          # same keys, same order as the reference module
+    for k in keys:
+        assert abs(float(sd[k].double().abs().sum()) - float(g[prefix + k])) <= 1e-9 * max(1.0, float(g[prefix + k])), k
+    return m
+
+
+@pytest.mark.parametrize("tag", sorted(SIBLINGS))
+def test_sibling_regressors_match_reference(golden, tag):
+    """g17: PointNet2Regressor_SoPs / _3Dbbox / _StrokeWise (models/pointnet2_cls_ssg.py:85, 177, 463): the oracle's restatement
+    against the imported reference, eval mode and train mode (dropout p = 0)."""
+    from maskplanner_amd import pointnet2_cls_ssg as pc
+    g = golden("g17_siblings")
+    ctor, seed, kw = SIBLINGS[tag]
+    m = seeded_module(lambda: ctor(pc), seed, g, tag + "_ck_")
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    xyz = torch.from_numpy(g["xyz"])
+    outs = T.sibling_forward(tag, sd, xyz, [g[tag + "_eval_s1"], g[tag + "_eval_s2"]], False, **kw)
+    for i, o in enumerate(outs):
+        _close(o, g[f"{tag}_eval_out{i}"], f"{tag} eval out{i}", rtol=1e-5, atol=1e-5)
+    outs = T.sibling_forward(tag, sd, xyz, [g[tag + "_train_s1"], g[tag + "_train_s2"]], True, **kw)
+    for i, o in enumerate(outs):
+        _close(o, g[f"{tag}_train_out{i}"], f"{tag} train out{i}", rtol=2e-4, atol=1e-5)   # BatchNorm1d over 4 rows
+    for k in ("sa1.mlp_bns.0.running_mean", "sa2.mlp_bns.2.running_var", "bn2.running_mean"):
+        _close(sd[k], g[f"{tag}_after_{k}"], k, rtol=2e-5, atol=1e-6)
+
+
+def test_sample_and_group_returnfps_matches_reference(golden, oracle):
+    """g17: the two extra return values of sample_and_group(returnfps=True) (models/pointnet2_utils.py:144-145)."""
+    g = golden("g17_siblings")
+    xyz, feats = g["xyz"], g["rf_feats"]
+    fidx = oracle.fps(xyz, 64, g["rf_start"])
+    assert np.array_equal(fidx, g["rf_fps_idx"])
+    new_xyz = oracle.index_points(xyz, fidx)
+    assert np.array_equal(new_xyz, g["rf_new_xyz"])
+    idx = oracle.ball_query(0.3, 16, xyz, new_xyz)
+    assert np.array_equal(oracle.index_points(xyz, idx.reshape(idx.shape[0], -1)).reshape(g["rf_grouped_xyz"].shape), g["rf_grouped_xyz"])
+    grouped = oracle.group(xyz, feats, new_xyz, idx)
+    assert np.array_equal(grouped, g["rf_new_points"])
