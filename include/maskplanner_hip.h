@@ -312,6 +312,13 @@ size_t mp_sa_mlp_workspace_bytes(int64_t P, int64_t K, int n_layers, const int64
  * element.  channels[n_layers + 1] as for the workspace query.  (Reference: the first Conv2d of sa1, pointnet2_utils.py:208-213;
  * the reference stores every activation for autograd.) */
 int mp_sa_mlp_recompute_first(int n_layers, const int64_t* channels, int64_t K);
+/* 1 if the POOLED (last) layer of the chain can run without its stored activation: pass layers[n_layers - 1].z = NULL to
+ * mp_sa_mlp_fwd_f32 / _gather_f32 and to the matching backward call, and Z_L [P, c_out] is neither written nor read.  The backward
+ * pass then never forms the dense dZ_L = a * gm + e * z + f either: with A = act(Z_{L-1}) and a shift m~ near its column means,
+ * G_{L-1} = (A - m~) M + v~ + sparse rows (M = W^T diag(e) W) and dW_L = a .* S + e .* (W Gp) + f~ (x) colsum(A) -- contractions of
+ * width c_in instead of c_out (csrc/sa_lean.hip).  Same results as the stored form up to fp32 rounding; dW_L is bit-reproducible.
+ * (Reference: the last Conv2d + BatchNorm2d + ReLU + max of a level, pointnet2_utils.py:208-214; autograd stores Z_L.) */
+int mp_sa_mlp_lean_last(int n_layers, const int64_t* channels, int64_t K, int64_t P);
 /* The grouped input of a level that is NOT materialised: row p = (b, s, k) of x0 is [feats[b, idx[p], 0:CF] | xyz[b, idx[p]] - new_xyz[b, s] | 0]
  * (models/pointnet2_utils.py:133-143 fused into the consumers).  mp_sa_mlp_gather_supported tells whether a chain qualifies (BASELINE's second
  * level: CF = 128, first layer 132 -> 128); the gather forms take this descriptor instead of x0, everything else as in the plain calls

@@ -26,6 +26,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "sa_lean.h"
 
 namespace {
 
@@ -893,7 +894,7 @@ __global__ __launch_bounds__(THREADS) void dw_gemm_kernel(PosOperand DZ, PosOper
 // other waves' MFMAs instead of being a separate phase of a 128 x 128 tile.  One partial-sum row per workgroup
 // (P / p_per_block rows instead of P / 128) also makes the BatchNorm finalize kernel 8x shorter.
 // =================================================================================================================
-template <int CI, int CO, bool POOL, int MODE_A = SRC_ACT, int TAIL = 0, bool SPLIT = false>   // TAIL = 4: input rows are [CI | 4] wide (features | xyz + pad)
+template <int CI, int CO, bool POOL, int MODE_A = SRC_ACT, int TAIL = 0, bool SPLIT = false, bool STORE = true>   // TAIL = 4: input rows are [CI | 4] wide (features | xyz + pad)
 __global__ __launch_bounds__(CO > 128 ? 512 : 256) void fwd_chunk_kernel(PosOperand A, int P, int p_per_block,
                                                                          const float* __restrict__ W, float* __restrict__ Z,
                                                                          float* __restrict__ partials, PoolOut po,
@@ -1091,8 +1092,10 @@ __global__ __launch_bounds__(CO > 128 ? 512 : 256) void fwd_chunk_kernel(PosOper
         int libest = 0;
 #pragma unroll
         for (int r = 0; r < NV; r += 2) {
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[r]), zrsrc, zoff, rowc(r) * CO * 4, MP_STORE_AUX);
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[r + 1]), zrsrc, zoff, rowc(r + 1) * CO * 4, MP_STORE_AUX);
+            if constexpr (STORE) {
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[r]), zrsrc, zoff, rowc(r) * CO * 4, MP_STORE_AUX);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[r + 1]), zrsrc, zoff, rowc(r + 1) * CO * 4, MP_STORE_AUX);
+            }
             const f2 x = {v[r], v[r + 1]};
             c1 += x;
             c2 += x * x;
@@ -2248,8 +2251,23 @@ extern "C" size_t mp_sa_mlp_workspace_bytes(int64_t P, int64_t K, int n_layers, 
     if (backward) {
         bytes += 2 * align_up((size_t)P * (size_t)cmax * sizeof(float), 256);            // G ping-pong
         bytes += align_up((size_t)(P / (K > 0 ? K : 1)) * (size_t)channels[n_layers] * sizeof(float), 256);  // gp
+        if (n_layers > 1 && K > 0 && mp::lean_supported(P, K, channels[n_layers], channels[n_layers - 1]))
+            bytes += mp::lean_workspace_bytes(P, K, channels[n_layers], channels[n_layers - 1]);                   // lean pooled layer
     }
     return bytes;
+}
+
+// Can the pooled (last) layer of this chain run without its stored activation (layers[n_layers - 1].z = NULL in forward AND
+// backward; sa_lean.hip)?  Needs the position-stream kernels with split planes, a fused pool (K in {32, 64, 128}) and one of the
+// shapes the lean backward kernel is built for.  MP_LEAN_LAST=0 switches it off.
+extern "C" int mp_sa_mlp_lean_last(int n_layers, const int64_t* channels, int64_t K, int64_t P)
+{
+    if (!channels || n_layers < 2 || K <= 0 || P <= 0) return 0;
+    if (!chunk_fwd_enabled() || !fused_bwd_enabled() || !split_enabled()) return 0;
+    if (!(K == 32 || K == 64 || K == 128) || (1024 % K) != 0) return 0;
+    const int64_t Co = channels[n_layers], Ci = channels[n_layers - 1];
+    if (n_layers == 2 && channels[0] == 4) return 0;      // (layer L-1 must have a stored activation: not the recomputed first layer)
+    return mp::lean_supported(P, K, Co, Ci) ? 1 : 0;
 }
 
 // Can the first layer of this chain be recomputed instead of stored (layers[0].z = NULL in forward AND backward)?  Yes for a
@@ -2581,7 +2599,7 @@ static int sa_mlp_fwd(const float* x0, int64_t P, int64_t K, int n_layers, const
     ch[0] = layers[0].c_in;
     for (int l = 0; l < n_layers; ++l) {
         const mp_mlp_layer_t& L = layers[l];
-        if (!L.weight || !L.gamma || !L.beta || (!L.z && l > 0) || !L.mean || !L.rstd || !L.scale || !L.shift) return MP_EINVAL;
+        if (!L.weight || !L.gamma || !L.beta || (!L.z && l > 0 && l != n_layers - 1) || !L.mean || !L.rstd || !L.scale || !L.shift) return MP_EINVAL;
         if (!training && (!L.running_mean || !L.running_var)) return MP_EINVAL;
         if (L.c_in != ch[l] || L.c_out <= 0 || L.c_out > 4096 || L.c_in > 4096) return MP_EINVAL;
         if ((L.c_in & 3) || (L.c_out & 3)) return MP_EUNSUPPORTED;      // float4 granularity: pad channels to x4
@@ -2592,6 +2610,8 @@ static int sa_mlp_fwd(const float* x0, int64_t P, int64_t K, int n_layers, const
     // layers[0].z == NULL: the caller asks for the first layer to be recomputed instead of stored (mp_sa_mlp_recompute_first)
     const bool rc_first = layers[0].z == nullptr;
     if (rc_first && (bf16 || !mp_sa_mlp_recompute_first(n_layers, ch, K))) return MP_EINVAL;
+    // layers[n_layers - 1].z == NULL: the pooled layer's activation is not stored either (mp_sa_mlp_lean_last; sa_lean.hip)
+    if (n_layers > 1 && layers[n_layers - 1].z == nullptr && (bf16 || !mp_sa_mlp_lean_last(n_layers, ch, K, P))) return MP_EINVAL;
     hipStream_t stream = mp_stream(stream_);
     float* partials = reinterpret_cast<float*>(workspace);
     // fused max-pool: group size a multiple of the 32-row MFMA tile that divides the 128-row block tile
@@ -2687,13 +2707,17 @@ static int sa_mlp_fwd(const float* x0, int64_t P, int64_t K, int n_layers, const
             const unsigned gx = (unsigned)((P + ppb - 1) / ppb);
             const double fl = 2.0 * (double)P * Co_ * Ci_, by = 4.0 * ((double)P * (Ci_ + Co_) + (double)Co_ * Ci_);
             char tg[64];
-            snprintf(tg, sizeof tg, "fwd_chunk_kernel<%d, %d, %s>", Ci_, Co_, fuse_pool ? "true" : "false");
+            snprintf(tg, sizeof tg, (fuse_pool && !L.z) ? "fwd_chunk_kernel<%d, %d, %s, lean>" : "fwd_chunk_kernel<%d, %d, %s>", Ci_, Co_, fuse_pool ? "true" : "false");
 #define MP_FWD(CI, CO, PL)                                                                                                     \
     MP_LAUNCH(tg, fl, by, (fwd_chunk_kernel<CI, CO, PL>), dim3(gx), dim3(CO > 128 ? 512 : 256), 0, stream, A, (int)P, ppb, L.weight, L.z, \
               partials, po, L.gamma)
 #define MP_FWD_SPLIT(CI, CO, PL)                                                                                               \
-    MP_LAUNCH(tg, fl, by, (fwd_chunk_kernel<CI, CO, PL, SRC_ACT, 0, true>), dim3(gx), dim3(CO > 128 ? 512 : 256), 0, stream, A, (int)P, ppb, \
-              L.weight, L.z, partials, po, L.gamma)
+    if (PL && !L.z)                                                                                                            \
+        MP_LAUNCH(tg, fl, by - 4.0 * (double)P * Co_, (fwd_chunk_kernel<CI, CO, PL, SRC_ACT, 0, true, !PL>), dim3(gx), dim3(CO > 128 ? 512 : 256), 0, stream, A, (int)P, ppb, \
+                  L.weight, L.z, partials, po, L.gamma);                                                                       \
+    else                                                                                                                       \
+        MP_LAUNCH(tg, fl, by, (fwd_chunk_kernel<CI, CO, PL, SRC_ACT, 0, true>), dim3(gx), dim3(CO > 128 ? 512 : 256), 0, stream, A, (int)P, ppb, \
+                  L.weight, L.z, partials, po, L.gamma)
 #define MP_FWD_CO(CI, PL)                                  \
     if (Co_ == 64) MP_FWD(CI, 64, PL);                     \
     else if (Co_ == 128) { if (split_enabled()) MP_FWD_SPLIT(CI, 128, PL); else MP_FWD(CI, 128, PL); }              \
@@ -2832,7 +2856,9 @@ static int sa_mlp_bwd(const float* x0, int64_t P, int64_t K, int n_layers, const
     if (workspace_bytes < mp_sa_mlp_workspace_bytes(P, K, n_layers, ch, 1)) return MP_EWORKSPACE;
     const bool rc_first = layers[0].z == nullptr;   // the forward pass did not store Z_0 (mp_sa_mlp_recompute_first)
     if (rc_first && (bf16 || grad_x0 || !mp_sa_mlp_recompute_first(n_layers, ch, K))) return MP_EINVAL;
-    for (int l = 1; l < n_layers; ++l)
+    const bool lean = n_layers > 1 && layers[n_layers - 1].z == nullptr;      // the pooled layer without its stored activation (sa_lean.hip)
+    if (lean && (bf16 || !mp_sa_mlp_lean_last(n_layers, ch, K, P))) return MP_EINVAL;
+    for (int l = 1; l < n_layers - (lean ? 1 : 0); ++l)
         if (!layers[l].z) return MP_EINVAL;
     hipStream_t stream = mp_stream(stream_);
     // carve the workspace (same order as mp_sa_mlp_workspace_bytes)
@@ -2851,6 +2877,8 @@ static int sa_mlp_bwd(const float* x0, int64_t P, int64_t K, int n_layers, const
         w += align_up((size_t)P * (size_t)cmax * sizeof(float), 256);
     }
     float* gp = reinterpret_cast<float*>(w);
+    w += align_up((size_t)(P / K) * (size_t)ch[n_layers] * sizeof(float), 256);
+    void* lean_ws = w;
 
     const int64_t G = P / K;
     const int L = n_layers;
@@ -2920,6 +2948,18 @@ static int sa_mlp_bwd(const float* x0, int64_t P, int64_t K, int n_layers, const
         if (rc_first && l == 1) { IN.rx = x0; IN.rw = layers[0].weight; }   // act(Z_0) and raw Z_0 from the input rows
         if (rc_first && l == 0) { DZ.rx = x0; DZ.rw = Ly.weight; }          // dZ_0 = f(Z_0, G_0) likewise
 
+        if (lean && pooled) {
+            // dZ_L is never formed: G_{L-1} = Ac M + v~ + sparse rows, dW_L from Gram / S / column sums (sa_lean.hip)
+            const mp_mlp_layer_t& Pv = layers[l - 1];
+            float* Gn = gbuf[l & 1];
+            int nb = 0;
+            if (int rc = mp::lean_bwd(Pv.z, Pv.scale, Pv.shift, Pv.gamma, Pv.beta, Ly.weight, cbuf[0], cbuf[1], cbuf[2], gp, argk, P, K, Co, Ci, Gn,
+                                      partials, &nb, grads[l].d_weight, lean_ws, stream))
+                return rc;
+            if (int rc = finalize_bwd(l - 1, nb, Ci)) return rc;
+            G_cur = Gn;
+            continue;
+        }
         // dW_l = dZ_l^T * act(Z_{l-1})
         if (!dw_joint && !mp::zero_async(grads[l].d_weight, (size_t)Co * Ci, stream)) return MP_ELAUNCH;
         if (!bf16 && l > 0 && (Ci == 64 || Ci == 128) && (Co == 64 || Co == 128 || (Co == 256 && Ci == 128)) && fused_bwd_enabled()) {

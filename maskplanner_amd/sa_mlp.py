@@ -46,10 +46,13 @@ class _SharedMLPMax(torch.autograd.Function):
         # first layer of a level fed by bare coordinates (4 input channels): Z_0 is recomputed by its consumers instead of being
         # written once and read three times (sa_mlp.hip, SRC_*_RC) -- no buffer for it at all
         recompute_first = (not bf16) and (not x.requires_grad) and bool(lib.mp_sa_mlp_recompute_first(n_layers, ch, K))
+        # the pooled layer without its stored activation (csrc/sa_lean.hip): Z_L [P, Co] is neither written here nor read in backward
+        lean_last = (not bf16) and LEAN_LAST and bool(lib.mp_sa_mlp_lean_last(n_layers, ch, K, P))
         for l in range(n_layers):
             w, b, gam, bet, rm, rv = params[6 * l:6 * l + 6]
             co, ci = w.shape
-            z = None if (l == 0 and recompute_first) else torch.empty((P, co), dtype=torch.float32, device=dev)
+            skip_z = (l == 0 and recompute_first) or (l == n_layers - 1 and lean_last)
+            z = None if skip_z else torch.empty((P, co), dtype=torch.float32, device=dev)
             stats = torch.empty((4, co), dtype=torch.float32, device=dev)  # mean, rstd, scale, shift
             keep.append((w, b, gam, bet, rm, rv, z, stats))
             layers[l] = _lib.MlpLayer(_ptr(w), _ptr(b), _ptr(gam), _ptr(bet), _ptr(rm), _ptr(rv), ci, co, _ptr(z),
@@ -139,10 +142,12 @@ class _SharedMLPMaxGathered(torch.autograd.Function):
         keep = []
         chans = [CF + 4] + [params[6 * l].shape[0] for l in range(n_layers)]
         lib = _lib.load()
+        ch_ = (ctypes.c_int64 * len(chans))(*chans)
+        lean_last = LEAN_LAST and bool(lib.mp_sa_mlp_lean_last(n_layers, ch_, K, P))      # (see _SharedMLPMax)
         for l in range(n_layers):
             w, b, gam, bet, rm, rv = params[6 * l:6 * l + 6]
             co, ci = w.shape
-            z = torch.empty((P, co), dtype=torch.float32, device=dev)
+            z = None if (l == n_layers - 1 and lean_last) else torch.empty((P, co), dtype=torch.float32, device=dev)
             stats = torch.empty((4, co), dtype=torch.float32, device=dev)
             keep.append((w, b, gam, bet, rm, rv, z, stats))
             layers[l] = _lib.MlpLayer(_ptr(w), _ptr(b), _ptr(gam), _ptr(bet), _ptr(rm), _ptr(rv), ci, co, _ptr(z),
@@ -216,10 +221,12 @@ class _SharedMLPMaxFactored(torch.autograd.Function):
         keep = []
         chans = [4] + [params[6 * l].shape[0] for l in range(n_layers)]
         lib = _lib.load()
+        ch_ = (ctypes.c_int64 * len(chans))(*chans)
+        lean_last = LEAN_LAST and bool(lib.mp_sa_mlp_lean_last(n_layers, ch_, K, P))      # (see _SharedMLPMax)
         for l in range(n_layers):
             w, b, gam, bet, rm, rv = params[6 * l:6 * l + 6]
             co, ci = w.shape
-            z = torch.empty((P, co), dtype=torch.float32, device=dev)
+            z = None if (l == n_layers - 1 and lean_last) else torch.empty((P, co), dtype=torch.float32, device=dev)
             stats = torch.empty((4, co), dtype=torch.float32, device=dev)
             keep.append((w, b, gam, bet, rm, rv, z, stats))
             layers[l] = _lib.MlpLayer(_ptr(w), _ptr(b), _ptr(gam), _ptr(bet), _ptr(rm), _ptr(rv), ci, co, _ptr(z),
@@ -287,6 +294,9 @@ class _SharedMLPMaxFactored(torch.autograd.Function):
 
 
 PER_POINT_DW_SLICES = int(os.environ.get("MP_PER_POINT_DW_SLICES", "8"))
+# MASKPLANNER_LEAN_LAST=0: every level stores the raw activation of its pooled layer and backpropagates through the dense dZ_L
+# (the library's own switch MP_LEAN_LAST=0 does the same for every caller)
+LEAN_LAST = os.environ.get("MASKPLANNER_LEAN_LAST", "1") != "0"
 
 
 class _PerPointFirst(torch.autograd.Function):
