@@ -357,9 +357,20 @@ int mp_sa_mlp_bwd_gather_f32(const mp_gather_t* gather, int64_t P, int64_t K, in
  * encoder, "bf16 MFMA grouped-MLP"): both operands of each GEMM -- act(Z_{l-1}) and W_l forward; dZ_l, W_l and
  * act(Z_{l-1}) backward -- are rounded to bf16 (round-to-nearest-even) as they are staged, v_mfma_f32_32x32x16_bf16
  * accumulates in fp32, and everything else stays fp32: stored raw activations, BatchNorm statistics and affine folding,
- * ReLU masks, pooling, dW accumulation, all outputs.  Same arguments, workspace and layouts as the _f32 calls; layers[0].z
- * must not be NULL (no recomputed first layer).  Reference: models/pointnet2_utils.py:208-214, 265-271 (the reference has
- * no reduced-precision mode; this is the build's option for config 5). */
+ * ReLU masks, pooling, dW accumulation, all outputs.  Same arguments, workspace and layouts as the _f32 calls.
+ * Reference: models/pointnet2_utils.py:208-214, 265-271 (the reference has no reduced-precision mode; this is the build's option
+ * for config 5).
+ * [r3] the bf16 calls take the same fast paths as the fp32 ones: the position-stream kernels with ONE bf16 operand plane, the recomputed
+ * first layer (layers[0].z = NULL: pass x0 and layers[0].weight already rounded to bf16 values -- the recomputation is then an exact
+ * product of rounded operands) and, through the _gather_bf16 pair, the factorised first layer (`feats` = A computed from rounded
+ * operands; the library rounds W_x, the centred coordinates and dZ_0 itself). */
+int mp_sa_mlp_fwd_gather_bf16(const mp_gather_t* gather, int64_t P, int64_t K, int n_layers, const mp_mlp_layer_t* layers,
+                              int training, double momentum, double eps, float* out, int32_t* argk, float* zmax,
+                              void* workspace, size_t workspace_bytes, mp_stream_t stream);
+int mp_sa_mlp_bwd_gather_bf16(const mp_gather_t* gather, int64_t P, int64_t K, int n_layers, const mp_mlp_layer_t* layers,
+                              int training, const float* grad_out, const float* out, const int32_t* argk,
+                              const float* zmax, const mp_mlp_grads_t* grads, float* grad_x0, int64_t grad_x0_cols,
+                              void* workspace, size_t workspace_bytes, mp_stream_t stream);
 int mp_sa_mlp_fwd_bf16(const float* x0, int64_t P, int64_t K, int n_layers, const mp_mlp_layer_t* layers, int training,
                        double momentum, double eps, float* out, int32_t* argk, float* zmax, void* workspace,
                        size_t workspace_bytes, mp_stream_t stream);

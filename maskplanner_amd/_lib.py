@@ -107,7 +107,11 @@ SIGNATURES = {
     "mp_sa_mlp_gather_supported": (_int, [_int, _vp, _i64, _i64]),
     "mp_sa_mlp_fwd_gather_f32": (_int, [ctypes.POINTER(Gather), _i64, _i64, _int, ctypes.POINTER(MlpLayer), _int, _dbl, _dbl, _vp, _vp, _vp, _vp,
                                         _sz, _vp]),
+    "mp_sa_mlp_fwd_gather_bf16": (_int, [ctypes.POINTER(Gather), _i64, _i64, _int, ctypes.POINTER(MlpLayer), _int, _dbl, _dbl, _vp, _vp, _vp, _vp,
+                                        _sz, _vp]),
     "mp_sa_mlp_bwd_gather_f32": (_int, [ctypes.POINTER(Gather), _i64, _i64, _int, ctypes.POINTER(MlpLayer), _int, _vp, _vp, _vp, _vp,
+                                        ctypes.POINTER(MlpGrads), _vp, _i64, _vp, _sz, _vp]),
+    "mp_sa_mlp_bwd_gather_bf16": (_int, [ctypes.POINTER(Gather), _i64, _i64, _int, ctypes.POINTER(MlpLayer), _int, _vp, _vp, _vp, _vp,
                                         ctypes.POINTER(MlpGrads), _vp, _i64, _vp, _sz, _vp]),
     "mp_sa_mlp_fwd_f32": (_int, [_vp, _i64, _i64, _int, ctypes.POINTER(MlpLayer), _int, _dbl, _dbl, _vp, _vp, _vp, _vp,
                                  _sz, _vp]),

@@ -211,6 +211,10 @@ __device__ __forceinline__ float4 finish(const Raw4<MODE>& r, const ChanConst& k
     return o;
 }
 
+// bf16 variant of the VALU-side products (factorised / recomputed first layers): an operand rounded to bf16 (nearest even) when `on`
+__device__ __forceinline__ float rb16(float x, int on) { return on ? (float)(__bf16)x : x; }
+__device__ __forceinline__ float4 rb16(const float4& v, int on) { return make_float4(rb16(v.x, on), rb16(v.y, on), rb16(v.z, on), rb16(v.w, on)); }
+
 // Plain matrix rows (weights): row-major [R, C] with C % 4 == 0, no transform, zero outside.
 __device__ __forceinline__ float4 ld4_plain(const float* m, int R, int C, int ld, int r, int c)
 {
@@ -894,7 +898,8 @@ __global__ __launch_bounds__(THREADS) void dw_gemm_kernel(PosOperand DZ, PosOper
 // other waves' MFMAs instead of being a separate phase of a 128 x 128 tile.  One partial-sum row per workgroup
 // (P / p_per_block rows instead of P / 128) also makes the BatchNorm finalize kernel 8x shorter.
 // =================================================================================================================
-template <int CI, int CO, bool POOL, int MODE_A = SRC_ACT, int TAIL = 0, bool SPLIT = false, bool STORE = true>   // TAIL = 4: input rows are [CI | 4] wide (features | xyz + pad)
+// ONE (with SPLIT): the bf16 variant of BASELINE configs[4] -- operands rounded once to bf16 (the h plane alone), one product instead of six
+template <int CI, int CO, bool POOL, int MODE_A = SRC_ACT, int TAIL = 0, bool SPLIT = false, bool STORE = true, bool ONE = false>   // TAIL = 4: input rows are [CI | 4] wide (features | xyz + pad)
 __global__ __launch_bounds__(CO > 128 ? 512 : 256) void fwd_chunk_kernel(PosOperand A, int P, int p_per_block,
                                                                          const float* __restrict__ W, float* __restrict__ Z,
                                                                          float* __restrict__ partials, PoolOut po,
@@ -947,6 +952,7 @@ __global__ __launch_bounds__(CO > 128 ? 512 : 256) void fwd_chunk_kernel(PosOper
     }
     float4 wt = make_float4(0.f, 0.f, 0.f, 0.f);     // TAIL: this lane's column of the 4 extra weight columns (VALU, not MFMA:
     if constexpr (TAIL != 0) wt = ld4(W + (size_t)col * (CI + TAIL) + CI);   // a 32-wide k tile would be 1/8 full)
+    if constexpr (TAIL != 0 && ONE) { wt.x = (float)(__bf16)wt.x; wt.y = (float)(__bf16)wt.y; wt.z = (float)(__bf16)wt.z; wt.w = (float)(__bf16)wt.w; }
 
     const int ca = (tid % (CI / 4)) * 4, ka0 = tid / (CI / 4);
     constexpr int KA_STEP = NT / (CI / 4);
@@ -977,13 +983,21 @@ __global__ __launch_bounds__(CO > 128 ? 512 : 256) void fwd_chunk_kernel(PosOper
                 const Split4 sp = split3(finish<MODE_A>(ra[ps], kc));
                 const int o = (ka0 + ps * KA_STEP) * LDH + ca;
                 *reinterpret_cast<bf16x4*>(&sH[buf][0][o]) = sp.h;
-                *reinterpret_cast<bf16x4*>(&sH[buf][1][o]) = sp.m;
-                *reinterpret_cast<bf16x4*>(&sH[buf][2][o]) = sp.l;
+                if constexpr (!ONE) {
+                    *reinterpret_cast<bf16x4*>(&sH[buf][1][o]) = sp.m;
+                    *reinterpret_cast<bf16x4*>(&sH[buf][2][o]) = sp.l;
+                }
             } else {
                 *reinterpret_cast<float4*>(&sA[buf][(ka0 + ps * KA_STEP) * LDA + ca]) = finish<MODE_A>(ra[ps], kc);
             }
         }
-        if constexpr (TAIL != 0) { if (tid < DBK) sT[buf][tid] = finish<MODE_A>(rt, kc); }
+        if constexpr (TAIL != 0) {
+            if (tid < DBK) {
+                float4 xt = finish<MODE_A>(rt, kc);
+                if constexpr (ONE) { xt.x = (float)(__bf16)xt.x; xt.y = (float)(__bf16)xt.y; xt.z = (float)(__bf16)xt.z; xt.w = (float)(__bf16)xt.w; }
+                sT[buf][tid] = xt;
+            }
+        }
     };
 
     double s1 = 0.0, s2 = 0.0;     // the chunk's values are summed in fp32, the 16-32 chunks of a workgroup in fp64
@@ -1026,12 +1040,14 @@ __global__ __launch_bounds__(CO > 128 ? 512 : 256) void fwd_chunk_kernel(PosOper
                     const bf16x8 al = *reinterpret_cast<const bf16x8*>(&sH[cur][2][o]);
                     f32x4& a = rt ? a1 : a0;
                     f32x4& c = rt ? c1 : c0;
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, wsp[0][st], c, 0, 0, 0);
+                    if constexpr (!ONE) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, wsp[0][st], c, 0, 0, 0);
                     a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wsp[0][st], a, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wsp[2][st], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, wsp[1][st], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, wsp[0][st], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wsp[1][st], c, 0, 0, 0);
+                    if constexpr (!ONE) {
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wsp[2][st], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, wsp[1][st], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, wsp[0][st], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wsp[1][st], c, 0, 0, 0);
+                    }
                 }
             }
 #pragma unroll
@@ -1048,12 +1064,14 @@ __global__ __launch_bounds__(CO > 128 ? 512 : 256) void fwd_chunk_kernel(PosOper
                 const bf16x8 ah = *reinterpret_cast<const bf16x8*>(&sH[cur][0][ao + 16 * st]);
                 const bf16x8 am = *reinterpret_cast<const bf16x8*>(&sH[cur][1][ao + 16 * st]);
                 const bf16x8 al = *reinterpret_cast<const bf16x8*>(&sH[cur][2][ao + 16 * st]);
-                cor = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, wsp[0][st], cor, 0, 0, 0);
+                if constexpr (!ONE) cor = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, wsp[0][st], cor, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wsp[0][st], acc, 0, 0, 0);
-                cor = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wsp[2][st], cor, 0, 0, 0);
-                cor = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, wsp[1][st], cor, 0, 0, 0);
-                cor = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, wsp[0][st], cor, 0, 0, 0);
-                cor = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wsp[1][st], cor, 0, 0, 0);
+                if constexpr (!ONE) {
+                    cor = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wsp[2][st], cor, 0, 0, 0);
+                    cor = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, wsp[1][st], cor, 0, 0, 0);
+                    cor = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, wsp[0][st], cor, 0, 0, 0);
+                    cor = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wsp[1][st], cor, 0, 0, 0);
+                }
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) v[r] = acc[r] + cor[r];
@@ -1165,7 +1183,7 @@ __global__ __launch_bounds__(CO > 128 ? 512 : 256) void fwd_chunk_kernel(PosOper
 #ifndef MP_SPLIT_WGS
 #define MP_SPLIT_WGS 2     // (3: a third workgroup of the 64-input layers per CU -- tried: 168-register cap, spills in the loop, 150 -> 370 us)
 #endif
-template <int MODE_DZ, int CO, int CI, int MODE_IN = SRC_ACT, bool SPLIT = false>
+template <int MODE_DZ, int CO, int CI, int MODE_IN = SRC_ACT, bool SPLIT = false, bool ONE = false>      // ONE: see fwd_chunk_kernel
 __global__ __launch_bounds__((CO >= 128 && CI == 128 ? 512 : 256), (CO >= 128 && CI == 128 ? 1 : ((SPLIT && CI == 64) ? MP_SPLIT_WGS : 2))) void bwd_fused_kernel(PosOperand DZ, PosOperand IN, int P, int p_per_block,
                                                             const float* __restrict__ W, float* __restrict__ dW,
                                                             float* __restrict__ G, float* __restrict__ partials)
@@ -1184,7 +1202,7 @@ __global__ __launch_bounds__((CO >= 128 && CI == 128 ? 512 : 256), (CO >= 128 &&
     // KSPLIT (256 outputs): in the dX product every wave reads the WHOLE dZ chunk from LDS for its 16 columns -- 192 of the 332 KB of LDS
     // traffic per chunk.  Here a wave takes 32 columns (two tiles) and HALF of K, its partner (wave ^ 4) the other half; each
     // finalises one of the two tiles after adding the partner's partial (8 KB through LDS, one extra barrier per chunk).
-    constexpr bool KSPLIT = SPLIT && CO == 256 && CI == 128 && MP_BWD_KSPLIT;
+    constexpr bool KSPLIT = SPLIT && !ONE && CO == 256 && CI == 128 && MP_BWD_KSPLIT;
     constexpr int HTW = KSPLIT ? 2 : HT, NSTW = KSPLIT ? CO / 64 : CO / 32;     // weight-plane tiles / k-steps per wave
     // SPLIT: K-packed planes (tr_frag_packed), group stride in halves: 16 dwords mod 64 banks.  The 64-input layers are HBM-bound:
     // a smaller pad (8 dwords: some 2-way conflicts in the transposed reads) lets a third workgroup onto the CU -- more loads in flight
@@ -1259,8 +1277,10 @@ __global__ __launch_bounds__((CO >= 128 && CI == 128 ? 512 : 256), (CO >= 128 &&
                 const Split4 sp = split3(finish<MODE_DZ>(ra[ps], ka));
                 const int o = (ca >> 3) * GS + (ka0 + ps * KA_STEP) * 8 + (ca & 7);
                 *reinterpret_cast<bf16x4*>(&hA[buf][0][o]) = sp.h;
-                *reinterpret_cast<bf16x4*>(&hA[buf][1][o]) = sp.m;
-                *reinterpret_cast<bf16x4*>(&hA[buf][2][o]) = sp.l;
+                if constexpr (!ONE) {
+                    *reinterpret_cast<bf16x4*>(&hA[buf][1][o]) = sp.m;
+                    *reinterpret_cast<bf16x4*>(&hA[buf][2][o]) = sp.l;
+                }
             } else {
                 *reinterpret_cast<float4*>(&sA[buf][(ka0 + ps * KA_STEP) * LDA + ca]) = finish<MODE_DZ>(ra[ps], ka);
             }
@@ -1272,8 +1292,10 @@ __global__ __launch_bounds__((CO >= 128 && CI == 128 ? 512 : 256), (CO >= 128 &&
                 const Split4 sp = split3(finish<MODE_IN>(rb[ps], kb));
                 const int oh = (cb >> 3) * GS + (kb0 + ps * KB_STEP) * 8 + (cb & 7);
                 *reinterpret_cast<bf16x4*>(&hB[buf][0][oh]) = sp.h;
-                *reinterpret_cast<bf16x4*>(&hB[buf][1][oh]) = sp.m;
-                *reinterpret_cast<bf16x4*>(&hB[buf][2][oh]) = sp.l;
+                if constexpr (!ONE) {
+                    *reinterpret_cast<bf16x4*>(&hB[buf][1][oh]) = sp.m;
+                    *reinterpret_cast<bf16x4*>(&hB[buf][2][oh]) = sp.l;
+                }
             } else {
                 *reinterpret_cast<float4*>(&sB[buf][o]) = finish<MODE_IN>(rb[ps], kb);
             }
@@ -1341,7 +1363,17 @@ __global__ __launch_bounds__((CO >= 128 && CI == 128 ? 512 : 256), (CO >= 128 &&
         const int cur = kc & 1;
         if (kc + 1 < nchunks) gload(p0 + (kc + 1) * DBK);
         auto do_dw = [&]() {
-        if constexpr (SPLIT) {   // dW += dZ^T * act(Z_{l-1}): one k-step of 16 positions, six plane products per tile
+        if constexpr (SPLIT && ONE) {   // one plane: dW += bf16(dZ)^T * bf16(act(Z_{l-1}))
+            bf16x8 fb[TNW], fa[TMW];
+#pragma unroll
+            for (int ni = 0; ni < TNW; ++ni) fb[ni] = tr_frag_packed<GS>(hB[cur][0], 0, wcol0 + ni * 32);
+#pragma unroll
+            for (int mi = 0; mi < TMW; ++mi) fa[mi] = tr_frag_packed<GS>(hA[cur][0], 0, wrow0 + mi * 32);
+#pragma unroll
+            for (int mi = 0; mi < TMW; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < TNW; ++ni) accW[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mi], fb[ni], accW[mi][ni], 0, 0, 0);
+        } else         if constexpr (SPLIT) {   // dW += dZ^T * act(Z_{l-1}): one k-step of 16 positions, six plane products per tile
             // fragments in the order they are consumed (one dZ plane live at a time): l*h, h*l, h*m, h*h, m*m, m*h
             bf16x8 fb[3][TNW], fa[TMW];
 #pragma unroll
@@ -1427,12 +1459,14 @@ __global__ __launch_bounds__((CO >= 128 && CI == 128 ? 512 : 256), (CO >= 128 &&
                     const bf16x8 ah = af[st & 1][0], am = af[st & 1][1], al = af[st & 1][2];
 #pragma unroll
                     for (int h = 0; h < HT; ++h) {
-                        cx[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, wsp[h][st][0], cx[h], 0, 0, 0);
+                        if constexpr (!ONE) cx[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, wsp[h][st][0], cx[h], 0, 0, 0);
                         ax[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wsp[h][st][0], ax[h], 0, 0, 0);
-                        cx[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wsp[h][st][2], cx[h], 0, 0, 0);
-                        cx[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, wsp[h][st][1], cx[h], 0, 0, 0);
-                        cx[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, wsp[h][st][0], cx[h], 0, 0, 0);
-                        cx[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wsp[h][st][1], cx[h], 0, 0, 0);
+                        if constexpr (!ONE) {
+                            cx[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wsp[h][st][2], cx[h], 0, 0, 0);
+                            cx[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, wsp[h][st][1], cx[h], 0, 0, 0);
+                            cx[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, wsp[h][st][0], cx[h], 0, 0, 0);
+                            cx[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wsp[h][st][1], cx[h], 0, 0, 0);
+                        }
                     }
                 }
 #pragma unroll
@@ -1821,8 +1855,8 @@ __global__ __launch_bounds__(512) void bwd_first_kernel(PosOperand DZ, PosOperan
 }
 
 template <int MODE_DZ, int MODE_IN>
-__global__ __launch_bounds__(256) void dw_ci4_kernel(PosOperand DZ, PosOperand IN, int P, int p_per_block, float* __restrict__ dW)
-{
+__global__ __launch_bounds__(256) void dw_ci4_kernel(PosOperand DZ, PosOperand IN, int P, int p_per_block, float* __restrict__ dW, int r16)
+{   // r16: the bf16 variant -- dZ and the input rows rounded to bf16 before the products
     __shared__ float red[256][16 + 1];
     const int tid = threadIdx.x;
     const int Co = DZ.C;
@@ -1849,8 +1883,8 @@ __global__ __launch_bounds__(256) void dw_ci4_kernel(PosOperand DZ, PosOperand I
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const float4 dz = finish<MODE_DZ>(rz[u], ka);
-                const float4 xv = finish<MODE_IN>(rx[u], kb);
+                const float4 dz = rb16(finish<MODE_DZ>(rz[u], ka), r16);
+                const float4 xv = rb16(finish<MODE_IN>(rx[u], kb), r16);
                 const float d[4] = {dz.x, dz.y, dz.z, dz.w}, x[4] = {xv.x, xv.y, xv.z, xv.w};
 #pragma unroll
                 for (int a = 0; a < 4; ++a)
@@ -1892,11 +1926,11 @@ int launch_dw(const PosOperand& DZ, const PosOperand& IN, int64_t P64, float* dW
     const unsigned gx = (unsigned)((P + ppb - 1) / ppb);
     // input-channel tiling: 128-wide tiles, a narrow remainder (132 = 128 + 4, 260 = 2*128 + 4) gets 32-wide tiles so
     // that it does not pay for a whole 128-column MFMA tile of zeros
-    if (PREC != 1 && Ci == 4 && (Co & 3) == 0 && Co <= 1024 && 256 % (Co / 4) == 0) {
+    if (Ci == 4 && (Co & 3) == 0 && Co <= 1024 && 256 % (Co / 4) == 0) {      // (PREC == 1: the same kernel with both operands rounded to bf16)
         double fl = 2.0 * (double)P * Co * Ci, by = 4.0 * ((MODE_DZ == SRC_DZ ? 2.0 : 1.0) * (double)P * Co + (double)P * Ci);
         char tg[64];
         snprintf(tg, sizeof tg, "dw_ci4_kernel<%d, %d>", MODE_DZ, MODE_IN);
-        MP_LAUNCH(tg, fl, by, (dw_ci4_kernel<MODE_DZ, MODE_IN>), dim3((unsigned)((P + 1023) / 1024)), dim3(256), 0, stream, DZ, IN, P, 1024, dW);
+        MP_LAUNCH(tg, fl, by, (dw_ci4_kernel<MODE_DZ, MODE_IN>), dim3((unsigned)((P + 1023) / 1024)), dim3(256), 0, stream, DZ, IN, P, 1024, dW, PREC == 1 ? 1 : 0);
         MP_CHECK_LAUNCH();
         return MP_OK;
     }
@@ -2307,15 +2341,15 @@ template <int Q>   // Q = Co / 4: lanes per row
 __global__ __launch_bounds__(256) void first_factored_fwd_kernel(const float* __restrict__ A, const float* __restrict__ xyz,
                                                                  const float* __restrict__ new_xyz, const int64_t* __restrict__ idx,
                                                                  const float* __restrict__ Wx, int P, int K, int kshift, int N, int per,
-                                                                 int gshift, int ppb, float* __restrict__ Z0, float* __restrict__ partials)
-{
+                                                                 int gshift, int ppb, float* __restrict__ Z0, float* __restrict__ partials, int r16)
+{   // r16: the bf16 variant -- W_x and the centred coordinates rounded to bf16 (A comes from rounded operands already)
     constexpr int CO = 4 * Q, RW = 64 / Q, RB = 4 * RW, U = MP_FACT_U;      // rows per wave / per workgroup pass, passes in flight
     __shared__ float red[2][RB][CO];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ql = lane % Q, slot = wave * RW + lane / Q;
     float4 w[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) w[j] = ld4(Wx + (size_t)(4 * ql + j) * 4);
+    for (int j = 0; j < 4; ++j) w[j] = rb16(ld4(Wx + (size_t)(4 * ql + j) * 4), r16);
     const int p0 = blockIdx.x * ppb, p1 = min(P, p0 + ppb);
     float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
     for (int p = p0 + slot; p < p1; p += RB * U) {
@@ -2330,7 +2364,7 @@ __global__ __launch_bounds__(256) void first_factored_fwd_kernel(const float* __
             a[u] = ld4(A + src * CO + 4 * ql);
             const float* x = xyz + src * 3;
             const float* c = new_xyz + (size_t)grp * 3;
-            dx[u] = x[0] - c[0]; dy[u] = x[1] - c[1]; dz[u] = x[2] - c[2];
+            dx[u] = rb16(x[0] - c[0], r16); dy[u] = rb16(x[1] - c[1], r16); dz[u] = rb16(x[2] - c[2], r16);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -2365,8 +2399,9 @@ __global__ __launch_bounds__(256) void first_factored_fwd_kernel(const float* __
 template <int Q>
 __global__ __launch_bounds__(256) void first_factored_bwd_kernel(PosOperand DZ, const float* __restrict__ xyz, const float* __restrict__ new_xyz,
                                                                  const int64_t* __restrict__ idx, int P, int K, int kshift, int N, int per,
-                                                                 int gshift, int ppb, float* __restrict__ dz_out, float* __restrict__ dW)
-{
+                                                                 int gshift, int ppb, float* __restrict__ dz_out, float* __restrict__ dW, int r16)
+{   // r16: the bf16 variant -- dZ_0 (as written out, too: its reduction over the gathering rows then sums rounded values) and the
+    // centred coordinates rounded to bf16
     constexpr int CO = 4 * Q, RW = 64 / Q, RB = 4 * RW, U = MP_FACT_U;
     __shared__ float red[3][RB][CO];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -2388,7 +2423,7 @@ __global__ __launch_bounds__(256) void first_factored_bwd_kernel(PosOperand DZ, 
             g[u] = ld4(DZ.g + (size_t)pp * CO + 4 * ql);
             const float* x = xyz + src * 3;
             const float* c = new_xyz + (size_t)grp * 3;
-            dx[u] = x[0] - c[0]; dy[u] = x[1] - c[1]; dzc[u] = x[2] - c[2];
+            dx[u] = rb16(x[0] - c[0], r16); dy[u] = rb16(x[1] - c[1], r16); dzc[u] = rb16(x[2] - c[2], r16);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -2399,6 +2434,7 @@ __global__ __launch_bounds__(256) void first_factored_bwd_kernel(PosOperand DZ, 
                 d.y = xf1<SRC_DZ>(z[u].y, g[u].y, k.s.y, k.t.y, k.a.y, k.e.y, k.f.y);
                 d.z = xf1<SRC_DZ>(z[u].z, g[u].z, k.s.z, k.t.z, k.a.z, k.e.z, k.f.z);
                 d.w = xf1<SRC_DZ>(z[u].w, g[u].w, k.s.w, k.t.w, k.a.w, k.e.w, k.f.w);
+                d = rb16(d, r16);
                 *reinterpret_cast<float4*>(dz_out + (size_t)pp * (CO + 4) + 4 * ql) = d;
                 ax.x = __builtin_fmaf(d.x, dx[u], ax.x); ax.y = __builtin_fmaf(d.y, dx[u], ax.y); ax.z = __builtin_fmaf(d.z, dx[u], ax.z); ax.w = __builtin_fmaf(d.w, dx[u], ax.w);
                 ay.x = __builtin_fmaf(d.x, dy[u], ay.x); ay.y = __builtin_fmaf(d.y, dy[u], ay.y); ay.z = __builtin_fmaf(d.z, dy[u], ay.z); ay.w = __builtin_fmaf(d.w, dy[u], ay.w);
@@ -2466,8 +2502,8 @@ __global__ __launch_bounds__(1024) void csr_rows_kernel(const int64_t* __restric
 template <int Q>
 __global__ __launch_bounds__(256) void first_factored_reduce_kernel(PosOperand DZ, const int* __restrict__ order, const int* __restrict__ pts,
                                                                     const float* __restrict__ xyz, const float* __restrict__ new_xyz, int N, int M,
-                                                                    int K, int kshift, int chunk, float* __restrict__ dA, float* __restrict__ dW)
-{
+                                                                    int K, int kshift, int chunk, float* __restrict__ dA, float* __restrict__ dW, int r16)
+{   // r16: see first_factored_bwd_kernel
 #ifndef MP_FACT_RU
 #define MP_FACT_RU 4
 #endif
@@ -2516,7 +2552,7 @@ __global__ __launch_bounds__(256) void first_factored_reduce_kernel(PosOperand D
             const unsigned grp = (unsigned)b * (unsigned)S + (kshift >= 0 ? (unsigned)m >> kshift : (unsigned)m / (unsigned)K);
             const float* x = xyz + ((size_t)b * N + pt[u]) * 3;
             const float* c = new_xyz + (size_t)grp * 3;
-            dx[u] = x[0] - c[0]; dy[u] = x[1] - c[1]; dzc[u] = x[2] - c[2];
+            dx[u] = rb16(x[0] - c[0], r16); dy[u] = rb16(x[1] - c[1], r16); dzc[u] = rb16(x[2] - c[2], r16);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -2526,6 +2562,7 @@ __global__ __launch_bounds__(256) void first_factored_reduce_kernel(PosOperand D
                 d.y = xf1<SRC_DZ>(z[u].y, g[u].y, k.s.y, k.t.y, k.a.y, k.e.y, k.f.y);
                 d.z = xf1<SRC_DZ>(z[u].z, g[u].z, k.s.z, k.t.z, k.a.z, k.e.z, k.f.z);
                 d.w = xf1<SRC_DZ>(z[u].w, g[u].w, k.s.w, k.t.w, k.a.w, k.e.w, k.f.w);
+                d = rb16(d, r16);
                 if (pt[u] != cur) { flush(); cur = pt[u]; acc = make_float4(0.f, 0.f, 0.f, 0.f); }
                 acc.x += d.x; acc.y += d.y; acc.z += d.z; acc.w += d.w;
                 ax.x = __builtin_fmaf(d.x, dx[u], ax.x); ax.y = __builtin_fmaf(d.y, dx[u], ax.y); ax.z = __builtin_fmaf(d.z, dx[u], ax.z); ax.w = __builtin_fmaf(d.w, dx[u], ax.w);
@@ -2553,7 +2590,8 @@ __global__ __launch_bounds__(256) void first_factored_reduce_kernel(PosOperand D
 static bool factored_ok(const mp_gather_t* g, int64_t P, int64_t K, int n_layers, const mp_mlp_layer_t* layers, bool bf16)
 {
     if (!g || !g->feats || !g->xyz || !g->new_xyz || !g->idx || g->N <= 0 || g->S <= 0) return false;
-    if (bf16 || n_layers < 2 || layers[0].c_in != 4 || g->CF != layers[0].c_out) return false;
+    (void)bf16;     // (the bf16 variant rounds W_x, the centred coordinates and dZ_0 inside the factorised kernels; A comes rounded)
+    if (n_layers < 2 || layers[0].c_in != 4 || g->CF != layers[0].c_out) return false;
     if (g->CF != 64 && g->CF != 128 && g->CF != 256) return false;
     if (P % (g->S * K) != 0 || !layers[0].z) return false;
     return true;
@@ -2580,8 +2618,10 @@ static void set_gather(PosOperand& o, const mp_gather_t* g, int64_t K)
     (bf16 ? launch_dw<MODE_DZ, MODE_IN, 1>(__VA_ARGS__)                                                           \
           : (split_enabled() ? launch_dw<MODE_DZ, MODE_IN, 3>(__VA_ARGS__) : launch_dw<MODE_DZ, MODE_IN, 0>(__VA_ARGS__)))
 
-// bf16 = true: every contraction runs on v_mfma_f32_32x32x16_bf16 with both operands rounded to bf16 while they are staged
-// (the generic tiled kernels; the fp32 position-stream / recompute specialisations are not used), everything else as in fp32.
+// bf16 = true: every contraction runs on the bf16 matrix cores with both operands rounded to bf16 while they are staged -- [r3] through the
+// same position-stream kernels as the fp32 path with ONE operand plane instead of three (fwd_chunk / bwd_fused <..., ONE>), the
+// recomputed and the factorised first layers included (their VALU products on rounded operands: rb16); widths outside those
+// kernels take the generic tiled kernels.  Everything else as in fp32.
 static int sa_mlp_fwd(const float* x0, int64_t P, int64_t K, int n_layers, const mp_mlp_layer_t* layers,
                       int training, double momentum, double eps, float* out, int32_t* argk, float* zmax,
                       void* workspace, size_t workspace_bytes, mp_stream_t stream_, bool bf16, const mp_syncbn_t* sync,
@@ -2609,7 +2649,7 @@ static int sa_mlp_fwd(const float* x0, int64_t P, int64_t K, int n_layers, const
     if (workspace_bytes < mp_sa_mlp_workspace_bytes(P, K, n_layers, ch, 0)) return MP_EWORKSPACE;
     // layers[0].z == NULL: the caller asks for the first layer to be recomputed instead of stored (mp_sa_mlp_recompute_first)
     const bool rc_first = layers[0].z == nullptr;
-    if (rc_first && (bf16 || !mp_sa_mlp_recompute_first(n_layers, ch, K))) return MP_EINVAL;
+    if (rc_first && !mp_sa_mlp_recompute_first(n_layers, ch, K)) return MP_EINVAL;      // (bf16: x0 and layers[0].weight come pre-rounded)
     // layers[n_layers - 1].z == NULL: the pooled layer's activation is not stored either (mp_sa_mlp_lean_last; sa_lean.hip)
     if (n_layers > 1 && layers[n_layers - 1].z == nullptr && (bf16 || !mp_sa_mlp_lean_last(n_layers, ch, K, P))) return MP_EINVAL;
     hipStream_t stream = mp_stream(stream_);
@@ -2651,7 +2691,7 @@ static int sa_mlp_fwd(const float* x0, int64_t P, int64_t K, int n_layers, const
 #define MP_FACT(Q_)                                                                                                              \
     MP_LAUNCH("first_factored_fwd_kernel", 8.0 * (double)P * Co_, by, (first_factored_fwd_kernel<Q_>), dim3((unsigned)nblk), dim3(256), 0,   \
               stream, gather->feats, gather->xyz, gather->new_xyz, gather->idx, L.weight, (int)P, (int)K, log2_or_neg(K), (int)gather->N, per, \
-              log2_or_neg(per), ppb, L.z, partials)
+              log2_or_neg(per), ppb, L.z, partials, (int)bf16)
             if (Co_ == 64) MP_FACT(16); else if (Co_ == 128) MP_FACT(32); else MP_FACT(64);
 #undef MP_FACT
             MP_CHECK_LAUNCH();
@@ -2689,7 +2729,11 @@ static int sa_mlp_fwd(const float* x0, int64_t P, int64_t K, int n_layers, const
             const double fl = 2.0 * (double)P * Co_ * Ci_, by = 4.0 * ((double)P * (4 + Co_) + (double)Co_ * Ci_);
             char tg[64];
             snprintf(tg, sizeof tg, "fwd_chunk_kernel<%d, %d, false, 4>", Ci_, Co_);
-            if (Co_ == 64 && split_enabled())
+            if (bf16 && Co_ == 64)
+                MP_LAUNCH("fwd_chunk_bf16_kernel<64, 64, false, 4>", fl, by, (fwd_chunk_kernel<64, 64, false, SRC_ACT_RC, 0, true, true, true>), dim3(gx), dim3(256), 0, stream, A, (int)P, ppb, L.weight, L.z, partials, po, L.gamma);
+            else if (bf16)
+                MP_LAUNCH("fwd_chunk_bf16_kernel<64, 128, false, 4>", fl, by, (fwd_chunk_kernel<64, 128, false, SRC_ACT_RC, 0, true, true, true>), dim3(gx), dim3(256), 0, stream, A, (int)P, ppb, L.weight, L.z, partials, po, L.gamma);
+            else if (Co_ == 64 && split_enabled())
                 MP_LAUNCH(tg, fl, by, (fwd_chunk_kernel<64, 64, false, SRC_ACT_RC, 0, true>), dim3(gx), dim3(256), 0, stream, A, (int)P, ppb, L.weight, L.z, partials, po, L.gamma);
             else if (Co_ == 64)
                 MP_LAUNCH(tg, fl, by, (fwd_chunk_kernel<64, 64, false, SRC_ACT_RC>), dim3(gx), dim3(256), 0, stream, A, (int)P, ppb, L.weight, L.z, partials, po, L.gamma);
@@ -2699,29 +2743,32 @@ static int sa_mlp_fwd(const float* x0, int64_t P, int64_t K, int n_layers, const
                 MP_LAUNCH(tg, fl, by, (fwd_chunk_kernel<64, 128, false, SRC_ACT_RC>), dim3(gx), dim3(256), 0, stream, A, (int)P, ppb, L.weight, L.z, partials, po, L.gamma);
             MP_CHECK_LAUNCH();
             nblk = (int)gx;
-        } else if (!bf16 && l > 0 && (Ci_ == 64 || Ci_ == 128) && (Co_ == 64 || Co_ == 128 || Co_ == 256) && (P % K) == 0 && (1024 % K == 0 || !fuse_pool) &&
-            chunk_fwd_enabled() && !(fuse_pool && (K % 32) != 0)) {
+        } else if (l > 0 && (Ci_ == 64 || Ci_ == 128) && (Co_ == 64 || Co_ == 128 || Co_ == 256) && (P % K) == 0 && (1024 % K == 0 || !fuse_pool) &&
+            chunk_fwd_enabled() && !(fuse_pool && (K % 32) != 0) && !(bf16 && Co_ == 64 && Ci_ == 128)) {
             (void)last_unfused;
             int ppb = 1024;
             while ((P + ppb - 1) / ppb < fwd_wgs_wanted(Co_ == 256 ? 256 : 512) && ppb > 128 && (!fuse_pool || (ppb / 2) % K == 0)) ppb >>= 1;   // >= 512 workgroups when P allows
             const unsigned gx = (unsigned)((P + ppb - 1) / ppb);
             const double fl = 2.0 * (double)P * Co_ * Ci_, by = 4.0 * ((double)P * (Ci_ + Co_) + (double)Co_ * Ci_);
             char tg[64];
-            snprintf(tg, sizeof tg, (fuse_pool && !L.z) ? "fwd_chunk_kernel<%d, %d, %s, lean>" : "fwd_chunk_kernel<%d, %d, %s>", Ci_, Co_, fuse_pool ? "true" : "false");
+            snprintf(tg, sizeof tg, bf16 ? "fwd_chunk_bf16_kernel<%d, %d, %s>" : ((fuse_pool && !L.z) ? "fwd_chunk_kernel<%d, %d, %s, lean>" : "fwd_chunk_kernel<%d, %d, %s>"), Ci_, Co_, fuse_pool ? "true" : "false");
 #define MP_FWD(CI, CO, PL)                                                                                                     \
     MP_LAUNCH(tg, fl, by, (fwd_chunk_kernel<CI, CO, PL>), dim3(gx), dim3(CO > 128 ? 512 : 256), 0, stream, A, (int)P, ppb, L.weight, L.z, \
               partials, po, L.gamma)
 #define MP_FWD_SPLIT(CI, CO, PL)                                                                                               \
-    if (PL && !L.z)                                                                                                            \
+    if (bf16)                                                                                                                  \
+        MP_LAUNCH(tg, fl, by, (fwd_chunk_kernel<CI, CO, PL, SRC_ACT, 0, true, true, true>), dim3(gx), dim3(CO > 128 ? 512 : 256), 0, stream, A, (int)P, ppb, \
+                  L.weight, L.z, partials, po, L.gamma);                                                                       \
+    else if (PL && !L.z)                                                                                                            \
         MP_LAUNCH(tg, fl, by - 4.0 * (double)P * Co_, (fwd_chunk_kernel<CI, CO, PL, SRC_ACT, 0, true, !PL>), dim3(gx), dim3(CO > 128 ? 512 : 256), 0, stream, A, (int)P, ppb, \
                   L.weight, L.z, partials, po, L.gamma);                                                                       \
     else                                                                                                                       \
         MP_LAUNCH(tg, fl, by, (fwd_chunk_kernel<CI, CO, PL, SRC_ACT, 0, true>), dim3(gx), dim3(CO > 128 ? 512 : 256), 0, stream, A, (int)P, ppb, \
                   L.weight, L.z, partials, po, L.gamma)
 #define MP_FWD_CO(CI, PL)                                  \
-    if (Co_ == 64) MP_FWD(CI, 64, PL);                     \
-    else if (Co_ == 128) { if (split_enabled()) MP_FWD_SPLIT(CI, 128, PL); else MP_FWD(CI, 128, PL); }              \
-    else { if (split_enabled()) MP_FWD_SPLIT(CI, 256, PL); else MP_FWD(CI, 256, PL); }
+    if (Co_ == 64) { if (bf16) MP_FWD_SPLIT(CI, 64, PL); else MP_FWD(CI, 64, PL); }                     \
+    else if (Co_ == 128) { if (split_enabled() || bf16) MP_FWD_SPLIT(CI, 128, PL); else MP_FWD(CI, 128, PL); }              \
+    else { if (split_enabled() || bf16) MP_FWD_SPLIT(CI, 256, PL); else MP_FWD(CI, 256, PL); }
             if (fuse_pool) { if (Ci_ == 64) { MP_FWD_CO(64, true); } else { MP_FWD_CO(128, true); } }
             else { if (Ci_ == 64) { MP_FWD_CO(64, false); } else { MP_FWD_CO(128, false); } }
 #undef MP_FWD_CO
@@ -2812,6 +2859,15 @@ extern "C" int mp_sa_mlp_fwd_gather_f32(const mp_gather_t* gather, int64_t P, in
                       gather);
 }
 
+extern "C" int mp_sa_mlp_fwd_gather_bf16(const mp_gather_t* gather, int64_t P, int64_t K, int n_layers, const mp_mlp_layer_t* layers,
+                                         int training, double momentum, double eps, float* out, int32_t* argk, float* zmax,
+                                         void* workspace, size_t workspace_bytes, mp_stream_t stream)
+{
+    if (!gather || n_layers < 1 || !layers || layers[0].c_in != 4) return MP_EINVAL;      // the factorised form only
+    return sa_mlp_fwd(nullptr, P, K, n_layers, layers, training, momentum, eps, out, argk, zmax, workspace, workspace_bytes, stream, true, nullptr,
+                      gather);
+}
+
 extern "C" int mp_sa_mlp_fwd_bf16(const float* x0, int64_t P, int64_t K, int n_layers, const mp_mlp_layer_t* layers,
                                   int training, double momentum, double eps, float* out, int32_t* argk, float* zmax,
                                   void* workspace, size_t workspace_bytes, mp_stream_t stream)
@@ -2855,7 +2911,7 @@ static int sa_mlp_bwd(const float* x0, int64_t P, int64_t K, int n_layers, const
     if (P * cmax >= ((int64_t)1 << 31)) return MP_EUNSUPPORTED;
     if (workspace_bytes < mp_sa_mlp_workspace_bytes(P, K, n_layers, ch, 1)) return MP_EWORKSPACE;
     const bool rc_first = layers[0].z == nullptr;   // the forward pass did not store Z_0 (mp_sa_mlp_recompute_first)
-    if (rc_first && (bf16 || grad_x0 || !mp_sa_mlp_recompute_first(n_layers, ch, K))) return MP_EINVAL;
+    if (rc_first && (grad_x0 || !mp_sa_mlp_recompute_first(n_layers, ch, K))) return MP_EINVAL;
     const bool lean = n_layers > 1 && layers[n_layers - 1].z == nullptr;      // the pooled layer without its stored activation (sa_lean.hip)
     if (lean && (bf16 || !mp_sa_mlp_lean_last(n_layers, ch, K, P))) return MP_EINVAL;
     for (int l = 1; l < n_layers - (lean ? 1 : 0); ++l)
@@ -2962,7 +3018,7 @@ static int sa_mlp_bwd(const float* x0, int64_t P, int64_t K, int n_layers, const
         }
         // dW_l = dZ_l^T * act(Z_{l-1})
         if (!dw_joint && !mp::zero_async(grads[l].d_weight, (size_t)Co * Ci, stream)) return MP_ELAUNCH;
-        if (!bf16 && l > 0 && (Ci == 64 || Ci == 128) && (Co == 64 || Co == 128 || (Co == 256 && Ci == 128)) && fused_bwd_enabled()) {
+        if (l > 0 && (Ci == 64 || Ci == 128) && (Co == 64 || Co == 128 || (Co == 256 && Ci == 128)) && fused_bwd_enabled() && !(bf16 && Co == 64 && Ci == 128)) {
             // single-tile layer: dX, dW and the BatchNorm-backward sums of layer l-1 in one pass over dZ_l (bwd_fused_kernel)
             const mp_mlp_layer_t& Pv = layers[l - 1];
             float* Gn = gbuf[l & 1];
@@ -2973,17 +3029,26 @@ static int sa_mlp_bwd(const float* x0, int64_t P, int64_t K, int n_layers, const
             const double fl = 4.0 * (double)P * Co * Ci;
             const double by = 4.0 * ((pooled ? 1.0 : 2.0) * (double)P * Co + 2.0 * (double)P * Ci);
             char tg[64];
-            snprintf(tg, sizeof tg, "bwd_fused_kernel<%d, %d, %d>", pooled ? 3 : 2, Co, Ci);
+            snprintf(tg, sizeof tg, bf16 ? "bwd_fused_bf16_kernel<%d, %d, %d>" : "bwd_fused_kernel<%d, %d, %d>", pooled ? 3 : 2, Co, Ci);
 #define MP_FUSED(MODE, CO_, CI_)                                                                                              \
-    if (split_enabled())                                                                                                      \
+    if (bf16)                                                                                                                 \
+        MP_LAUNCH(tg, fl, by, (bwd_fused_kernel<MODE, CO_, CI_, SRC_ACT, true, true>), dim3(gx), dim3((CO_ >= 128 && CI_ == 128) ? 512 : 256), 0, stream, DZ, IN, (int)P, \
+                  ppb, Ly.weight, grads[l].d_weight, Gn, partials);                                                           \
+    else if (split_enabled())                                                                                                      \
         MP_LAUNCH(tg, fl, by, (bwd_fused_kernel<MODE, CO_, CI_, SRC_ACT, true>), dim3(gx), dim3((CO_ >= 128 && CI_ == 128) ? 512 : 256), 0, stream, DZ, IN, (int)P, \
                   ppb, Ly.weight, grads[l].d_weight, Gn, partials);                                                           \
     else                                                                                                                      \
         MP_LAUNCH(tg, fl, by, (bwd_fused_kernel<MODE, CO_, CI_>), dim3(gx), dim3((CO_ >= 128 && CI_ == 128) ? 512 : 256), 0, stream, DZ, IN, (int)P, ppb, Ly.weight, \
                   grads[l].d_weight, Gn, partials)
             if (rc_first && l == 1) {   // (never the pooled layer: n_layers >= 3)
-                snprintf(tg, sizeof tg, "bwd_fused_kernel<2, %d, 64, 4>", Co);
-                if (Co == 64 && split_enabled())
+                snprintf(tg, sizeof tg, bf16 ? "bwd_fused_bf16_kernel<2, %d, 64, 4>" : "bwd_fused_kernel<2, %d, 64, 4>", Co);
+                if (bf16 && Co == 64)
+                    MP_LAUNCH(tg, fl, by - 4.0 * (double)P * (Ci - 4), (bwd_fused_kernel<SRC_DZ, 64, 64, SRC_ACT_RC, true, true>), dim3(gx), dim3(256), 0, stream, DZ, IN,
+                              (int)P, ppb, Ly.weight, grads[l].d_weight, Gn, partials);
+                else if (bf16)
+                    MP_LAUNCH(tg, fl, by - 4.0 * (double)P * (Ci - 4), (bwd_fused_kernel<SRC_DZ, 128, 64, SRC_ACT_RC, true, true>), dim3(gx), dim3(256), 0, stream, DZ, IN,
+                              (int)P, ppb, Ly.weight, grads[l].d_weight, Gn, partials);
+                else if (Co == 64 && split_enabled())
                     MP_LAUNCH(tg, fl, by - 4.0 * (double)P * (Ci - 4), (bwd_fused_kernel<SRC_DZ, 64, 64, SRC_ACT_RC, true>), dim3(gx), dim3(256), 0, stream, DZ, IN,
                               (int)P, ppb, Ly.weight, grads[l].d_weight, Gn, partials);
                 else if (Co == 64)
@@ -3064,7 +3129,7 @@ static int sa_mlp_bwd(const float* x0, int64_t P, int64_t K, int n_layers, const
                 const unsigned gxr = (unsigned)((M + 4 * chunk - 1) / (4 * chunk));
 #define MP_FACT_R(Q_)                                                                                                            \
     MP_LAUNCH("first_factored_reduce_kernel", fl, by, (first_factored_reduce_kernel<Q_>), dim3(gxr, (unsigned)Bc), dim3(256), 0, stream, DZ, order, pts, \
-              gather->xyz, gather->new_xyz, Np, M, (int)K, log2_or_neg(K), chunk, grad_x0, grads[l].d_weight)
+              gather->xyz, gather->new_xyz, Np, M, (int)K, log2_or_neg(K), chunk, grad_x0, grads[l].d_weight, (int)bf16)
                 if (Co == 64) MP_FACT_R(16); else if (Co == 128) MP_FACT_R(32); else MP_FACT_R(64);
 #undef MP_FACT_R
                 MP_CHECK_LAUNCH();
@@ -3074,7 +3139,7 @@ static int sa_mlp_bwd(const float* x0, int64_t P, int64_t K, int n_layers, const
             const unsigned gxf = (unsigned)((P + ppb - 1) / ppb);
 #define MP_FACT_B(Q_)                                                                                                            \
     MP_LAUNCH("first_factored_bwd_kernel", fl, by + 4.0 * (double)P * Co, (first_factored_bwd_kernel<Q_>), dim3(gxf), dim3(256), 0, stream, DZ, gather->xyz, \
-              gather->new_xyz, gather->idx, (int)P, (int)K, log2_or_neg(K), (int)gather->N, per, log2_or_neg(per), ppb, grad_x0, grads[l].d_weight)
+              gather->new_xyz, gather->idx, (int)P, (int)K, log2_or_neg(K), (int)gather->N, per, log2_or_neg(per), ppb, grad_x0, grads[l].d_weight, (int)bf16)
             if (Co == 64) MP_FACT_B(16); else if (Co == 128) MP_FACT_B(32); else MP_FACT_B(64);
 #undef MP_FACT_B
             MP_CHECK_LAUNCH();
@@ -3083,7 +3148,7 @@ static int sa_mlp_bwd(const float* x0, int64_t P, int64_t K, int n_layers, const
         if (rc_first && l == 0) {
             const double fl = 2.0 * (double)P * Co * Ci, by = 4.0 * ((double)P * Co + 2.0 * (double)P * Ci);
             MP_LAUNCH("dw_ci4_kernel<5, 0>", fl, by, (dw_ci4_kernel<SRC_DZ_RC, SRC_ID>), dim3((unsigned)((P + 1023) / 1024)), dim3(256), 0, stream, DZ, IN,
-                      (int)P, 1024, grads[l].d_weight);
+                      (int)P, 1024, grads[l].d_weight, (int)bf16);
             MP_CHECK_LAUNCH();
             continue;
         }
@@ -3145,6 +3210,16 @@ extern "C" int mp_sa_mlp_bwd_gather_f32(const mp_gather_t* gather, int64_t P, in
     if (!gather) return MP_EINVAL;
     return sa_mlp_bwd(nullptr, P, K, n_layers, layers, training, grad_out, out, argk, zmax, grads, grad_x0, grad_x0_cols, workspace,
                       workspace_bytes, stream, false, nullptr, gather);
+}
+
+extern "C" int mp_sa_mlp_bwd_gather_bf16(const mp_gather_t* gather, int64_t P, int64_t K, int n_layers, const mp_mlp_layer_t* layers,
+                                         int training, const float* grad_out, const float* out, const int32_t* argk,
+                                         const float* zmax, const mp_mlp_grads_t* grads, float* grad_x0, int64_t grad_x0_cols,
+                                         void* workspace, size_t workspace_bytes, mp_stream_t stream)
+{
+    if (!gather || n_layers < 1 || !layers || layers[0].c_in != 4) return MP_EINVAL;
+    return sa_mlp_bwd(nullptr, P, K, n_layers, layers, training, grad_out, out, argk, zmax, grads, grad_x0, grad_x0_cols, workspace,
+                      workspace_bytes, stream, true, nullptr, gather);
 }
 
 extern "C" int mp_sa_mlp_bwd_bf16(const float* x0, int64_t P, int64_t K, int n_layers, const mp_mlp_layer_t* layers,

@@ -199,10 +199,12 @@ class TrainStep:
                 if self._adam_ev is not None:
                     torch.cuda.current_stream().wait_event(self._adam_ev)   # the head weights of the previous step are final
                 self._replay_b()
+            loss = self._graph_loss
             if self._guard_left > 0 and self.dp_graph:
                 self._guard_left -= 1
+                loss = loss.clone()           # (a fallback drops the graphs and their static loss tensor)
                 self._dp_guard()
-            return self._graph_loss
+            return loss
         if not self.use_graph:
             return self._eager_step()
         if self._eager_steps < self.GRAPH_AFTER:

@@ -19,6 +19,11 @@ def _ptr(t):
     return None if t is None else t.data_ptr()
 
 
+def _r16(t):
+    """The values a bf16 matrix-core operand carries (nearest even), in fp32 storage."""
+    return t.detach().to(torch.bfloat16).to(torch.float32)
+
+
 # None: every level advances its BatchNorm counters (num_batches_tracked) itself.  A list: the counters are collected here
 # instead and the owner (harness.TrainStep) advances all of them -- set-abstraction levels and heads -- in one launch per step.
 DEFERRED_TICKS = None
@@ -45,7 +50,12 @@ class _SharedMLPMax(torch.autograd.Function):
         ch = (ctypes.c_int64 * len(chans))(*chans)
         # first layer of a level fed by bare coordinates (4 input channels): Z_0 is recomputed by its consumers instead of being
         # written once and read three times (sa_mlp.hip, SRC_*_RC) -- no buffer for it at all
-        recompute_first = (not bf16) and (not x.requires_grad) and bool(lib.mp_sa_mlp_recompute_first(n_layers, ch, K))
+        recompute_first = (not x.requires_grad) and bool(lib.mp_sa_mlp_recompute_first(n_layers, ch, K))
+        if bf16 and recompute_first:
+            # the recomputed first layer of the bf16 variant is an exact product of ROUNDED operands: the kernels get x and W_0 as
+            # bf16 values (in fp32 storage); the gradient still goes to the unrounded parameter
+            x = _r16(x)
+            params = (_r16(params[0]),) + tuple(params[1:])
         # the pooled layer without its stored activation (csrc/sa_lean.hip): Z_L [P, Co] is neither written here nor read in backward
         lean_last = (not bf16) and LEAN_LAST and bool(lib.mp_sa_mlp_lean_last(n_layers, ch, K, P))
         for l in range(n_layers):
@@ -212,7 +222,7 @@ class _SharedMLPMaxFactored(torch.autograd.Function):
     Backward: the library writes dZ_0 [P, Co + 4]; its reduction over the gathering rows (ops.group's backward kernel) is dA."""
 
     @staticmethod
-    def forward(ctx, A, xyz, new_xyz, idx, training, momentum, eps, n_layers, *params):
+    def forward(ctx, A, xyz, new_xyz, idx, training, momentum, eps, n_layers, bf16, *params):
         dev = A.device
         B, N, C0 = A.shape
         _, S, K = idx.shape
@@ -222,7 +232,7 @@ class _SharedMLPMaxFactored(torch.autograd.Function):
         chans = [4] + [params[6 * l].shape[0] for l in range(n_layers)]
         lib = _lib.load()
         ch_ = (ctypes.c_int64 * len(chans))(*chans)
-        lean_last = LEAN_LAST and bool(lib.mp_sa_mlp_lean_last(n_layers, ch_, K, P))      # (see _SharedMLPMax)
+        lean_last = (not bf16) and LEAN_LAST and bool(lib.mp_sa_mlp_lean_last(n_layers, ch_, K, P))      # (see _SharedMLPMax)
         for l in range(n_layers):
             w, b, gam, bet, rm, rv = params[6 * l:6 * l + 6]
             co, ci = w.shape
@@ -239,9 +249,9 @@ class _SharedMLPMaxFactored(torch.autograd.Function):
         ch = (ctypes.c_int64 * len(chans))(*chans)
         ws = torch.empty((lib.mp_sa_mlp_workspace_bytes(P, K, n_layers, ch, 0),), dtype=torch.uint8, device=dev)
         g = _lib.Gather(_ptr(A), _ptr(xyz), _ptr(new_xyz), _ptr(idx), N, S, C0)
-        ops._run("sa_mlp_fwd", A, lib.mp_sa_mlp_fwd_gather_f32, ctypes.byref(g), P, K, n_layers, layers, int(training), float(momentum),
+        ops._run("sa_mlp_fwd", A, lib.mp_sa_mlp_fwd_gather_bf16 if bf16 else lib.mp_sa_mlp_fwd_gather_f32, ctypes.byref(g), P, K, n_layers, layers, int(training), float(momentum),
                  float(eps), _ptr(out), _ptr(argk), _ptr(zmax), _ptr(ws), ws.numel())
-        ctx.meta = (P, K, bool(training), n_layers, chans, (B, N, S, C0))
+        ctx.meta = (P, K, bool(training), n_layers, chans, (B, N, S, C0), bool(bf16))
         ctx.keep = keep
         ctx.save_for_backward(A, xyz, new_xyz, idx, out, argk, zmax)
         ctx.mark_non_differentiable(argk, zmax)
@@ -250,7 +260,8 @@ class _SharedMLPMaxFactored(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out):
         A, xyz, new_xyz, idx, out, argk, zmax = ctx.saved_tensors
-        P, K, training, n_layers, chans, (B, N, S, C0) = ctx.meta
+        P, K, training, n_layers, chans, (B, N, S, C0), bf16 = ctx.meta
+        bwd_fn = lambda lib: lib.mp_sa_mlp_bwd_gather_bf16 if bf16 else lib.mp_sa_mlp_bwd_gather_f32
         dev = A.device
         grad_out = grad_out.contiguous().float()
         layers = (_lib.MlpLayer * n_layers)()
@@ -278,19 +289,19 @@ class _SharedMLPMaxFactored(torch.autograd.Function):
         fused = FACTORED_REDUCE and not ops.DETERMINISTIC and N <= 15000 and S * K < (1 << 24)
         if fused:
             gA = torch.empty((B, N, C0), dtype=torch.float32, device=dev)
-            ops._run("sa_mlp_bwd", A, lib.mp_sa_mlp_bwd_gather_f32, ctypes.byref(g), P, K, n_layers, layers, int(training), _ptr(grad_out),
+            ops._run("sa_mlp_bwd", A, bwd_fn(lib), ctypes.byref(g), P, K, n_layers, layers, int(training), _ptr(grad_out),
                      _ptr(out), _ptr(argk), _ptr(zmax), grads, _ptr(gA), 0, _ptr(ws), ws.numel())
             ctx.keep = None
-            return (gA, None, None, None, None, None, None, None, *ret)
+            return (gA, None, None, None, None, None, None, None, None, *ret)
         gz = torch.empty((P, stride), dtype=torch.float32, device=dev)       # dZ_0 rows (the pad quad is never read)
-        ops._run("sa_mlp_bwd", A, lib.mp_sa_mlp_bwd_gather_f32, ctypes.byref(g), P, K, n_layers, layers, int(training), _ptr(grad_out),
+        ops._run("sa_mlp_bwd", A, bwd_fn(lib), ctypes.byref(g), P, K, n_layers, layers, int(training), _ptr(grad_out),
                  _ptr(out), _ptr(argk), _ptr(zmax), grads, _ptr(gz), C0, _ptr(ws), ws.numel())
         ctx.keep = None
         gA = None
         if ctx.needs_input_grad[0]:
             gA = torch.empty((B, N, C0), dtype=torch.float32, device=dev)
             ops._run("group_bwd", gz, lib.mp_group_bwd_f32, _ptr(gz), _ptr(idx), B, N, S, K, C0, 1, stride, _ptr(gA), int(ops.DETERMINISTIC))
-        return (gA, None, None, None, None, None, None, None, *ret)
+        return (gA, None, None, None, None, None, None, None, None, *ret)
 
 
 PER_POINT_DW_SLICES = int(os.environ.get("MP_PER_POINT_DW_SLICES", "8"))
@@ -306,8 +317,10 @@ class _PerPointFirst(torch.autograd.Function):
     [B*N, CF] form sends rocBLAS to a 16-tile kernel with a 16 384-long K loop: 93 us at the bench shape), dW assembled with one cat."""
 
     @staticmethod
-    def forward(ctx, feats, w, xyz_first):
+    def forward(ctx, feats, w, xyz_first, bf16=False):
         CF = feats.shape[2]
+        if bf16:       # the bf16 variant: both operands of the per-point map rounded (exact products, fp32 sums); W_x is rounded by the kernels
+            feats, w = _r16(feats), torch.cat([w[:, :3], _r16(w[:, 3:])], 1) if xyz_first else torch.cat([_r16(w[:, :CF]), w[:, CF:]], 1)
         wx, wf = (w[:, :3], w[:, 3:]) if xyz_first else (w[:, CF:], w[:, :CF])
         A = torch.matmul(feats, wf.t())
         wx4 = torch.nn.functional.pad(wx, (0, 1))
@@ -329,7 +342,7 @@ class _PerPointFirst(torch.autograd.Function):
             gwf = torch.bmm(gA.reshape(B * sl, N // sl, -1).transpose(1, 2), feats.reshape(B * sl, N // sl, CF)).sum(0)
             gwx = gwx4[:, :3] if gwx4 is not None else torch.zeros_like(w[:, :3])
             gw = torch.cat([gwx, gwf], dim=1) if ctx.xyz_first else torch.cat([gwf, gwx], dim=1)
-        return gfeats, gw, None
+        return gfeats, gw, None, None
 
 
 # MASKPLANNER_FACTORED_FIRST: which levels with input features run their first layer factorised (linear map per source point, then
@@ -343,14 +356,14 @@ FACTORED_REDUCE = os.environ.get("MASKPLANNER_FACTORED_REDUCE", "1") != "0"   # 
 def factored_supported(feats, K, convs, bns, dtype="f32", sync_bn=None):
     """True when shared_mlp_max_factored can take this level (otherwise group + shared_mlp_max)."""
     from .sync_bn import resolve
-    if dtype != "f32" or resolve(sync_bn) is not False or feats is None or not feats.is_cuda or feats.dtype != torch.float32:
+    if dtype not in ("f32", "bf16") or resolve(sync_bn) is not False or feats is None or not feats.is_cuda or feats.dtype != torch.float32:
         return False
     if len(convs) < 2 or convs[0].in_channels != feats.shape[2] + 3 or convs[0].out_channels not in (64, 128, 256):
         return False
     return all(c.out_channels % 4 == 0 for c in convs)
 
 
-def shared_mlp_max_factored(xyz, feats, new_xyz, idx, convs, bns, weight_order="xyz_first"):
+def shared_mlp_max_factored(xyz, feats, new_xyz, idx, convs, bns, weight_order="xyz_first", dtype="f32"):
     """The level's output [B,S,Cout] from xyz [B,N,3], feats [B,N,CF], new_xyz [B,S,3], idx [B,S,K] without a grouped tensor and
     without a first-layer GEMM over the grouped rows.  weight_order: where the coordinate columns sit in the first conv's weight --
     "xyz_first" (PointNetSetAbstraction, models/pointnet2_utils.py:138) or "xyz_last" (the multi-scale class, :262).
@@ -367,7 +380,7 @@ def shared_mlp_max_factored(xyz, feats, new_xyz, idx, convs, bns, weight_order="
         w = conv.weight.view(conv.out_channels, conv.in_channels)
         if i == 0:
             # A [B, N, Co]: the feature part, once per source point; w: (W_x | 0) [Co, 4]
-            A, w = _PerPointFirst.apply(feats.contiguous(), w, weight_order == "xyz_first")
+            A, w = _PerPointFirst.apply(feats.contiguous(), w, weight_order == "xyz_first", dtype == "bf16")
         track = bn.track_running_stats and bn.running_mean is not None
         if not training and not track:
             raise NotImplementedError("eval-mode BatchNorm without running statistics")
@@ -381,8 +394,12 @@ def shared_mlp_max_factored(xyz, feats, new_xyz, idx, convs, bns, weight_order="
                 torch._foreach_add_(counters, 1)
     bn0 = bns[0]
     momentum = bn0.momentum if bn0.momentum is not None else 1.0 / max(float(bn0.num_batches_tracked), 1.0)
+    writeback = _widen_interior(params, [c.out_channels for c in convs]) if WIDEN_INTERIOR else []
     out = _SharedMLPMaxFactored.apply(A.contiguous(), xyz.contiguous().float(), new_xyz.contiguous().float(), idx.contiguous(), training,
-                                      momentum, bn0.eps, len(convs), *params)
+                                      momentum, bn0.eps, len(convs), dtype == "bf16", *params)
+    if training:
+        for dst, src in writeback:
+            dst.copy_(src[:dst.numel()])
     return out.view(B, S, -1)
 
 
@@ -594,7 +611,7 @@ def shared_mlp_max(grouped, convs, bns, layout="xyz_first", dtype="f32", sync_bn
     bn0 = bns[0]
     momentum = bn0.momentum if bn0.momentum is not None else 1.0 / max(float(bn0.num_batches_tracked), 1.0)
     grad_cols = cin - 3 if (layout == "feats_first" and cin > 3) else 0
-    writeback = _widen_interior(params, [c.out_channels for c in convs]) if (dtype == "f32" and sync_group is False and WIDEN_INTERIOR) else []
+    writeback = _widen_interior(params, [c.out_channels for c in convs]) if (sync_group is False and WIDEN_INTERIOR) else []
     out = _SharedMLPMax.apply(x, K, training, momentum, bn0.eps, len(convs), grad_cols, dtype == "bf16", sync_group, *params)
     if training:
         for dst, src in writeback:          # running statistics of the real channels back into the module's buffers

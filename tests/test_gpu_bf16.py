@@ -84,8 +84,10 @@ def test_bf16_layers_are_exact_products_of_the_rounded_operands(B, S, K, cin, wi
     keep = out.grad_fn.next_functions[0][0].keep                      # per layer: (w, b, gamma, beta, rm, rv, z, stats[mean, rstd, scale, shift])
     a = torch.nn.functional.pad(x.reshape(-1, cin), (0, (-cin) % 4))
     for l, (w, b, gam, bet, rm, rv, z, stats) in enumerate(keep):
-        assert z is not None
         want = r16(a) @ r16(w.detach().reshape(w.shape[0], -1)).t()          # fp32 sums of exact products
+        if z is None:       # [r3] the recomputed first layer (4 input channels): never stored -- its consumers rebuild exactly these products
+            assert l == 0 and a.shape[1] == 4
+            z = want
         err = float((z - want).abs().max())
         assert err <= 1e-5 * max(1.0, float(want.abs().max())), (l, err)
         # BatchNorm folding of THIS layer, as the kernels apply it while staging: relu(z * scale + shift), mul and add rounded
