@@ -418,6 +418,10 @@ int mp_adam_lowrank_f32(float* param, float* exp_avg, float* exp_avg_sq, const f
 
 /* input gradient of the same layers: grad_x [B, I] = g [B, O] * W [O, I] for B <= 32 (one streaming read of W; the
  * library GEMM rocBLAS selects for this skinny shape reaches ~0.6 TB/s).  I % 4 == 0.  grad_x is overwritten. */
+/* the same product on the matrix cores (fp32 operands as three bf16 planes, fp32 accumulation: fp32-accurate): B <= 32, I % 128 == 0,
+ * no workspace; the K slices meet in grad_x through fp32 atomics, so the summation order is not fixed (mp_linear_dx_skinny_f32 is the
+ * bit-reproducible form).  ~4 TB/s of weight stream against ~1.5 TB/s. */
+int mp_linear_dx_mfma_f32(const float* g, const float* weight, int64_t B, int64_t O, int64_t I, float* grad_x, mp_stream_t stream);
 size_t mp_linear_dx_skinny_workspace_bytes(int64_t B, int64_t O, int64_t I);
 int mp_linear_dx_skinny_f32(const float* g, const float* weight, int64_t B, int64_t O, int64_t I, float* grad_x,
                             void* workspace, size_t workspace_bytes, mp_stream_t stream);

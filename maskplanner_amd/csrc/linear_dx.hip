@@ -1,0 +1,121 @@
+// Input gradient of the weight-heavy head Linears on the matrix cores:  grad_x [B <= 32, I] = g [B, O] * W [O, I].
+//
+// Reference: autograd of nn.Linear for fc3 / fc_normals / sm_fc3 (models/pointnet2_cls_ssg.py:311, 327, 336): a [32, O] x [O, 1024]
+// GEMM with O = 6 000 .. 12 000 -- 25 .. 49 MB of weights read for 0.4 .. 0.8 GF: an HBM stream.  rocBLAS picks a 0.6 TB/s kernel
+// for the shape; linear_dx_skinny_kernel (adam_lowrank.hip: VALU inner products, one wave per SIMD, ordered partial sums) reaches
+// ~1.5 TB/s and stays the deterministic form.  Here the product runs as v_mfma_f32_32x32x16_bf16 on (h, m, l) operand planes (six
+// plane products per fp32 product, fp32 accumulation: fp32-accurate, see sa_mlp.hip split3): the batch is the 32-row side of the
+// tile, a wave owns 32 columns of W and a slice of its rows, and the VALU only splits what streams past.
+//   grid (I / 128, K slices), 256 threads: the four waves of a workgroup share the slice's g rows -- staged once into LDS as
+//   ready-made A fragments -- and take 32 columns each; the weight rows are requested DEPTH k-steps (of 16 rows) ahead, eight
+//   128-byte row segments per k-step and wave; the K slices add their tiles into grad_x with fp32 atomics (two 128-byte segments
+//   per instruction), so grad_x must be zero on entry and the summation order is not fixed.
+#include "common.h"
+
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+
+constexpr int LD_NS_MAX = 12;     // k-steps (of 16 weight rows) per workgroup: ALL of a wave's weight rows are requested up front (96 registers), before
+                                  // the g slice is staged -- a workgroup lives for one memory latency, not one per prefetch round
+
+struct Planes8 { bf16x8 h, m, l; };
+__device__ __forceinline__ Planes8 split8(const float (&x)[8])
+{
+    Planes8 r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const __bf16 h = (__bf16)x[i];
+        const float r1 = x[i] - (float)h;
+        const __bf16 m = (__bf16)r1;
+        r.h[i] = h;
+        r.m[i] = m;
+        r.l[i] = (__bf16)(r1 - (float)m);
+    }
+    return r;
+}
+
+__global__ __launch_bounds__(256, 2) void linear_dx_mfma_kernel(const float* __restrict__ g, const float* __restrict__ W, int B, int O, int I,
+                                                                int ns, float* __restrict__ gx)
+{
+    __shared__ __attribute__((aligned(16))) __bf16 sG[3][LD_NS_MAX][64][8];     // A fragments: [plane][k-step][lane][8 k values]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int k_base = blockIdx.y * ns * 16;
+    // ---- B operand: lane (column c, half h) of k-step s holds W[k_base + 16 s + 8 h + j][col], j = 0..7 (rows past O: clamped --
+    // their g values are zeros).  Requested first: everything below runs under their latency.
+    const int col = blockIdx.x * 128 + wave * 32 + l31;
+    const float* wc = W + col;
+    float wq[LD_NS_MAX][8];
+#pragma unroll
+    for (int s = 0; s < LD_NS_MAX; ++s) {
+        if (s < ns) {
+            const int k0 = k_base + 16 * s + 8 * h;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) wq[s][j] = wc[(size_t)min(k0 + j, O - 1) * I];
+        }
+    }
+    // ---- the slice's g rows as A fragments: lane (batch row r, half h) of k-step s holds g[r][k_base + 16 s + 8 h .. + 7]
+    // (consecutive threads take consecutive 8-float pieces of one batch row: coalesced reads of an L2-resident table)
+    for (int e = tid; e < ns * 64; e += 256) {
+        const int r = e / (2 * ns), sh = e - r * 2 * ns;
+        const int s = sh >> 1, ln = r + 32 * (sh & 1);
+        const int k0 = k_base + 8 * sh;
+        float x[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = (r < B && k0 + j < O) ? g[(size_t)r * O + k0 + j] : 0.0f;
+        const Planes8 p = split8(x);
+        *reinterpret_cast<bf16x8*>(&sG[0][s][ln][0]) = p.h;
+        *reinterpret_cast<bf16x8*>(&sG[1][s][ln][0]) = p.m;
+        *reinterpret_cast<bf16x8*>(&sG[2][s][ln][0]) = p.l;
+    }
+    __syncthreads();
+    f32x16 acc, cor;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[r] = 0.0f; cor[r] = 0.0f; }
+#pragma unroll
+    for (int s = 0; s < LD_NS_MAX; ++s) {
+        if (s < ns) {
+            const Planes8 b = split8(wq[s]);
+            const bf16x8 ah = *reinterpret_cast<const bf16x8*>(&sG[0][s][lane][0]);
+            const bf16x8 am = *reinterpret_cast<const bf16x8*>(&sG[1][s][lane][0]);
+            const bf16x8 al = *reinterpret_cast<const bf16x8*>(&sG[2][s][lane][0]);
+            cor = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, b.h, cor, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b.h, acc, 0, 0, 0);
+            cor = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b.l, cor, 0, 0, 0);
+            cor = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, b.m, cor, 0, 0, 0);
+            cor = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, b.h, cor, 0, 0, 0);
+            cor = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b.m, cor, 0, 0, 0);
+        }
+    }
+    // ---- the slice's tile into grad_x: register r of lane (c, h) is batch row (r & 3) + 8 (r >> 2) + 4 h
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (row < B) atomicAdd(gx + (size_t)row * I + col, acc[r] + cor[r]);
+    }
+}
+
+}  // namespace
+
+extern "C" int mp_linear_dx_mfma_f32(const float* g, const float* weight, int64_t B, int64_t O, int64_t I, float* grad_x, mp_stream_t stream_)
+{
+    if (B < 0 || O < 0 || I < 0) return MP_EINVAL;
+    if (B == 0 || I == 0) return MP_OK;
+    if (!grad_x || (O > 0 && (!g || !weight))) return MP_EINVAL;
+    if (B > 32 || (I % 128) != 0 || O >= ((int64_t)1 << 30)) return MP_EUNSUPPORTED;
+    hipStream_t stream = mp_stream(stream_);
+    if (!mp::zero_async(grad_x, (size_t)(B * I), stream)) return MP_ELAUNCH;
+    if (O == 0) return MP_OK;
+    const int64_t ksteps = (O + 15) / 16, ncol = I / 128;
+    int64_t slices = (768 + ncol - 1) / ncol;                 // ~three workgroups per CU
+    if (slices > ksteps) slices = ksteps;
+    int64_t ns = (ksteps + slices - 1) / slices;
+    if (ns > LD_NS_MAX) { ns = LD_NS_MAX; }
+    slices = (ksteps + ns - 1) / ns;
+    MP_LAUNCH("linear_dx_mfma_kernel", 2.0 * (double)B * O * I, 4.0 * ((double)O * I + (double)B * (O + I)), linear_dx_mfma_kernel,
+              dim3((unsigned)ncol, (unsigned)slices), dim3(256), 0, stream, g, weight, (int)B, (int)O, (int)I, (int)ns, grad_x);
+    MP_CHECK_LAUNCH();
+    return MP_OK;
+}

@@ -14,7 +14,11 @@ import torch
 import torch.distributed as dist
 import torch.nn.functional as F
 
+import os
+
 from . import _lib, dp, ops
+
+DX_MFMA = os.environ.get("MASKPLANNER_DX_MFMA", "1") != "0"      # 0: the VALU form (ordered partial sums) for the wide heads' input gradient
 
 
 class _FactorLinear(torch.autograd.Function):
@@ -36,7 +40,12 @@ class _FactorLinear(torch.autograd.Function):
             I = weight.shape[1]
             # the streaming kernel pays off on the wide heads (O ~ 6000-12000 rows of W); the 1024 x 1024 layers have too few
             # row slabs to fill the chip and stay on rocBLAS
-            if g.is_cuda and B <= 32 and O >= 4096 and I % 4 == 0 and g.dtype == torch.float32 and weight.is_contiguous():
+            if (g.is_cuda and B <= 32 and O >= 4096 and I % 128 == 0 and g.dtype == torch.float32 and weight.is_contiguous()
+                    and not ops.DETERMINISTIC and DX_MFMA):
+                # the stream of W through the matrix cores (csrc/linear_dx.hip; atomics between its K slices: not bit-reproducible)
+                gx = torch.empty((B, I), dtype=torch.float32, device=g.device)
+                ops._run("linear_dx_mfma", g, _lib.load().mp_linear_dx_mfma_f32, g.data_ptr(), weight.data_ptr(), B, O, I, gx.data_ptr())
+            elif g.is_cuda and B <= 32 and O >= 4096 and I % 4 == 0 and g.dtype == torch.float32 and weight.is_contiguous():
                 gx = torch.empty((B, I), dtype=torch.float32, device=g.device)   # one streaming pass over W
                 lib = _lib.load()
                 ws = torch.empty((lib.mp_linear_dx_skinny_workspace_bytes(B, O, I),), dtype=torch.uint8, device=g.device)

@@ -775,3 +775,26 @@ def test_fused_head_block_equals_linear_then_bn_relu_dropout():
             continue
         tol = 2e-5 * float(u.abs().max()) + 1e-6
         assert float((u - v).abs().max()) < tol, (i, float((u - v).abs().max()), tol)
+
+
+@pytest.mark.parametrize("B,O,I", [(32, 11988, 1024), (32, 5994, 1024), (7, 4100, 256), (32, 4097, 128), (1, 16, 128)])
+def test_head_input_gradient_kernels_vs_fp64(ops, B, O, I):
+    """grad_x = g W of the wide head Linears (autograd of nn.Linear, models/pointnet2_cls_ssg.py:311, 327, 336): the matrix-core form
+    (csrc/linear_dx.hip: three bf16 planes per fp32 operand) and the ordered VALU form against an fp64 product -- both at fp32
+    rounding level, ragged row counts (O % 16 != 0) and short batches included."""
+    from maskplanner_amd import _lib
+    lib = _lib.load()
+    gen = torch.Generator().manual_seed(O + B)
+    g = torch.randn(B, O, generator=gen).cuda()
+    W = (torch.randn(O, I, generator=gen) / 32).cuda()
+    want = g.double() @ W.double()
+    scale = float(want.abs().max())
+    gx = torch.full((B, I), float("nan"), device="cuda")
+    ops._run("linear_dx_mfma", g, lib.mp_linear_dx_mfma_f32, g.data_ptr(), W.data_ptr(), B, O, I, gx.data_ptr())
+    err_m = float((gx.double() - want).abs().max()) / scale
+    gy = torch.full((B, I), float("nan"), device="cuda")
+    ws = torch.empty((lib.mp_linear_dx_skinny_workspace_bytes(B, O, I),), dtype=torch.uint8, device="cuda")
+    ops._run("linear_dx_skinny", g, lib.mp_linear_dx_skinny_f32, g.data_ptr(), W.data_ptr(), B, O, I, gy.data_ptr(), ws.data_ptr(), ws.numel())
+    err_s = float((gy.double() - want).abs().max()) / scale
+    assert err_m < 2e-6 and err_s < 2e-6, (err_m, err_s)
+    assert err_m < 3.0 * err_s + 2e-7, (err_m, err_s)
