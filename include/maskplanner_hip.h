@@ -422,6 +422,9 @@ int mp_adam_lowrank_f32(float* param, float* exp_avg, float* exp_avg_sq, const f
  * no workspace; the K slices meet in grad_x through fp32 atomics, so the summation order is not fixed (mp_linear_dx_skinny_f32 is the
  * bit-reproducible form).  ~4 TB/s of weight stream against ~1.5 TB/s. */
 int mp_linear_dx_mfma_f32(const float* g, const float* weight, int64_t B, int64_t O, int64_t I, float* grad_x, mp_stream_t stream);
+/* weight gradient of the same layers, materialised: dW [O, I] = g^T x (B <= 32 rows of factors, I % 4 == 0), b-ordered fma chains, one
+ * streaming write of dW -- for loops that keep torch.optim.Adam on dense gradients (train_maskplanner.py:159) */
+int mp_linear_dw_outer_f32(const float* g, const float* x, int64_t B, int64_t O, int64_t I, float* dW, mp_stream_t stream);
 size_t mp_linear_dx_skinny_workspace_bytes(int64_t B, int64_t O, int64_t I);
 int mp_linear_dx_skinny_f32(const float* g, const float* weight, int64_t B, int64_t O, int64_t I, float* grad_x,
                             void* workspace, size_t workspace_bytes, mp_stream_t stream);

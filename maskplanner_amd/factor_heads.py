@@ -18,6 +18,7 @@ import os
 
 from . import _lib, dp, ops
 
+WIDE_LINEAR = os.environ.get("MASKPLANNER_WIDE_LINEAR", "1") != "0"   # 0: plain nn.Linear (rocBLAS backward) for the wide heads of a model without a factor store
 DX_MFMA = os.environ.get("MASKPLANNER_DX_MFMA", "1") != "0"      # 0: the VALU form (ordered partial sums) for the wide heads' input gradient
 
 
@@ -151,10 +152,53 @@ def flush_bias_grads(store):
     del queue[:]
 
 
+class _WideLinear(torch.autograd.Function):
+    """nn.Linear for the weight-heavy heads of a model WITHOUT a factor store (the drop-in path: torch.optim.Adam on dense
+    gradients): forward = F.linear; backward on the library's streaming kernels instead of the GEMMs rocBLAS selects for a 32-row
+    batch -- grad_x through csrc/linear_dx.hip (107 -> 21 us for the 11988 x 1024 heads), grad_W as a rank-B outer-product stream
+    (85 -> ~15 us), grad_b a column sum."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return F.linear(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        g = g.contiguous()
+        B, O = g.shape
+        I = weight.shape[1]
+        lib = _lib.load()
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty((B, I), dtype=torch.float32, device=g.device)
+            if ops.DETERMINISTIC:
+                ws = torch.empty((lib.mp_linear_dx_skinny_workspace_bytes(B, O, I),), dtype=torch.uint8, device=g.device)
+                ops._run("linear_dx_skinny", g, lib.mp_linear_dx_skinny_f32, g.data_ptr(), weight.data_ptr(), B, O, I, gx.data_ptr(), ws.data_ptr(), ws.numel())
+            else:
+                ops._run("linear_dx_mfma", g, lib.mp_linear_dx_mfma_f32, g.data_ptr(), weight.data_ptr(), B, O, I, gx.data_ptr())
+        if ctx.needs_input_grad[1]:
+            gw = torch.empty_like(weight)
+            xc = x.contiguous()
+            ops._run("linear_dw_outer", g, lib.mp_linear_dw_outer_f32, g.data_ptr(), xc.data_ptr(), B, O, I, gw.data_ptr())
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = g.sum(0)
+        return gx, gw, gb
+
+
+def _wide_ok(x, linear):
+    w = linear.weight
+    return (WIDE_LINEAR and x.is_cuda and x.dtype == torch.float32 and x.ndim == 2 and x.shape[0] <= 32 and w.shape[0] >= 4096
+            and w.shape[1] % 128 == 0 and w.dtype == torch.float32 and w.is_contiguous() and torch.is_grad_enabled())
+
+
 def factor_linear(x, linear, store, key):
-    """y = linear(x); if `store` is a dict the weight gradient is left as factors in store[key]."""
+    """y = linear(x); if `store` is a dict the weight gradient is left as factors in store[key]; without one the wide heads
+    still take the library's backward kernels (_WideLinear), everything else is plain nn.Linear."""
     if store is None:
-        return linear(x)
+        return _WideLinear.apply(x, linear.weight, linear.bias) if _wide_ok(x, linear) else linear(x)
     return _FactorLinear.apply(x, linear.weight, linear.bias, store, key)
 
 

@@ -16,6 +16,8 @@ import torch.nn.functional as F
 
 from . import ops, sa_mlp
 from .factor_heads import factor_linear, linear_block, linear_block_supported
+
+SAMPLE_AHEAD = os.environ.get("MASKPLANNER_SAMPLE_AHEAD", "1") != "0"
 from .pointnet2_utils import PointNetSetAbstraction, PointNetSetAbstractionMsg
 
 
@@ -46,10 +48,44 @@ class _SSGEncoder(nn.Module):
             # the three first-layer weights into the fused MLP's column order with one launch (and one for their gradients)
             sa_mlp.prepermute([(self.sa1.mlp_convs[0], "feats_first" if norm is not None else "xyz_first"),
                                (self.sa2.mlp_convs[0], "feats_first"), (self.sa3.mlp_convs[0], "feats_first")])
+        self._sample_ahead(xyz)
         l1_xyz, l1_points = self.sa1(xyz, norm)
         l2_xyz, l2_points = self.sa2(l1_xyz, l1_points)
         _, l3_points = self.sa3(l2_xyz, l2_points)
         return l3_points.reshape(B, 1024)
+
+    def _sample_ahead(self, xyz):
+        """Eager calls without a supplied sampling plan (an unchanged training loop): the second level samples nothing but the first
+        level's centroids, which exist as soon as the first level's FPS is done -- so both levels are sampled here, the second one on
+        a side stream underneath the first level's grouping + MLP (its FPS is a one-wave-per-cloud latency chain: 60 + 40 us that
+        otherwise sit on the critical path).  The FPS starts are drawn in the reference's order; the levels pick the plans up through
+        pointnet2_utils' plan queue.  MASKPLANNER_SAMPLE_AHEAD=0 switches it off."""
+        from . import pointnet2_utils as pu
+        sa1, sa2 = self.sa1, self.sa2
+        if (not SAMPLE_AHEAD or not xyz.is_cuda or torch.cuda.is_current_stream_capturing() or getattr(sa1, "group_all", True)
+                or getattr(sa2, "group_all", True) or not isinstance(sa1, PointNetSetAbstraction) or not isinstance(sa2, PointNetSetAbstraction)):
+            return
+        pm = pu._points_major(xyz)                     # what sa1.forward computes (the same storage for a permuted [B,N,3] input)
+        if pm.data_ptr() != pu._points_major(xyz).data_ptr() or pu.has_prefetched(pm, sa1.npoint, sa1.radius, sa1.nsample):
+            return                                     # (a fresh copy per call: the plan could not be found again) / a plan is there already
+        B, N, _ = pm.shape
+        dev = pm.device
+        main = torch.cuda.current_stream(dev)
+        s1 = pu._draw_fps_start(B, N, dev)
+        s2 = pu._draw_fps_start(B, sa1.npoint, dev)
+        fps1, new1 = ops.fps(pm, sa1.npoint, s1, return_xyz=True)
+        side = pu._side_stream(dev)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            fps2, new2 = ops.fps(new1, sa2.npoint, s2, return_xyz=True)
+            idx2 = ops.ball_query(sa2.radius, sa2.nsample, new1, new2)
+            ev = torch.cuda.Event()
+            ev.record(side)
+        for t in (fps2, new2, idx2, s2):
+            t.record_stream(main)
+        idx1 = ops.ball_query(sa1.radius, sa1.nsample, pm, new1)
+        pu.supply_sampling(pm, sa1.npoint, sa1.radius, sa1.nsample, (fps1, new1, idx1))
+        pu._prefetched.setdefault((new1.data_ptr(), sa2.npoint, float(sa2.radius), sa2.nsample), []).append((ev, fps2, new2, idx2))
 
 
 def _block(model, lin_out, bn, layer):

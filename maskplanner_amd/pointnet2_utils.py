@@ -59,6 +59,13 @@ _prefetched = {}
 _side_streams = {}
 
 
+def _side_stream(dev):
+    side = _side_streams.get(dev)
+    if side is None:
+        side = _side_streams[dev] = torch.cuda.Stream(device=dev)
+    return side
+
+
 def prefetch_sampling(xyz, npoint, radius, nsample, fps_start):
     """Queue first-level sampling of `xyz` [B,N,3] (points-major, contiguous) on a side stream.  The next
     sample_and_group() call with the same tensor and parameters picks the result up instead of recomputing it."""

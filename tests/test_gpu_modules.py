@@ -1407,3 +1407,32 @@ def test_factorised_first_layer_of_the_multi_scale_level(monkeypatch):
     for i, (a, b_) in enumerate(zip(p1, p0)):
         assert a.shape == b_.shape
         assert float((a - b_).abs().max()) <= 2e-3 * float(b_.abs().max()) + 1e-6, (i, float((a - b_).abs().max()), float(b_.abs().max()))
+
+def test_wide_head_backward_kernels_and_sample_ahead_change_nothing(monkeypatch):
+    """A model WITHOUT a factor store (the drop-in configuration): the wide heads' backward on the library's streaming kernels
+    (factor_heads._WideLinear) and the second level's sampling on a side stream (pointnet2_cls_ssg._sample_ahead) against plain
+    nn.Linear autograd and in-line sampling: same outputs (bit for bit: the forward is untouched, the sampling plans are equal),
+    same gradients up to fp32 summation order."""
+    from maskplanner_amd import factor_heads, pointnet2_cls_ssg as pc, synthetic as syn
+    cat = syn.CATEGORIES["cuboids"]
+    B, N = 8, 2048
+    x = syn.make_batch(5, B, N, "cuboids", "cuboid")["point_cloud"].cuda().permute(0, 2, 1)
+    w = torch.randn(B, cat.out_vectors, 24, device="cuda")
+    res = {}
+    for fast in (False, True):
+        monkeypatch.setattr(factor_heads, "WIDE_LINEAR", fast)
+        monkeypatch.setattr(pc, "SAMPLE_AHEAD", fast)
+        torch.manual_seed(21)
+        m = pc.maskplanner_model(cat).cuda().train()
+        m.dropout.p = 0.0
+        torch.manual_seed(77)                          # the FPS starts: torch's CPU generator, drawn level by level
+        out, sm, conf, _ = m(x)
+        ((out * w).sum() + sm.sum() + conf.sum()).backward()
+        res[fast] = (out.detach(), sm.detach(), {n: p.grad.detach().clone() for n, p in m.named_parameters()})
+    assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
+    for n, g0 in res[False][2].items():
+        g1 = res[True][2][n]
+        if n.endswith("bias") and ("mlp_convs" in n or n in ("fc1.bias", "fc2.bias", "sm_fc1.bias", "sm_fc2.bias", "sa3.mlp_bns.2.bias")):
+            continue                                   # exact gradient 0 (removed by the following train-mode BatchNorm): rounding noise on both sides
+        tol = 2e-5 if n.startswith(("fc", "sm_", "mask_conf", "bn", "sm_bn")) else 5e-3     # encoder: dW atomics + max-pool routing noise
+        assert float((g1 - g0).norm()) <= tol * float(g0.norm()) + 1e-7, (n, float((g1 - g0).norm() / g0.norm().clamp_min(1e-12)))
