@@ -404,6 +404,15 @@ int mp_sa_mlp_bwd_ex(const float* x0, int64_t P, int64_t K, int n_layers, const 
                      const float* grad_out, const float* out, const int32_t* argk, const float* zmax,
                      const mp_mlp_grads_t* grads, float* grad_x0, int64_t grad_x0_cols, void* workspace,
                      size_t workspace_bytes, int bf16, const mp_syncbn_t* sync, mp_stream_t stream);
+/* [r3] The gather forms (mp_sa_mlp_{fwd,bwd}_gather_f32 / _bf16: factorised or gathered first layer) with the same hook: a data-parallel
+ * run with SyncBN keeps the factorised first layer (the level's BatchNorm sums are exchanged exactly as in the _ex calls above). */
+int mp_sa_mlp_fwd_gather_ex(const mp_gather_t* gather, int64_t P, int64_t K, int n_layers, const mp_mlp_layer_t* layers,
+                            int training, double momentum, double eps, float* out, int32_t* argk, float* zmax,
+                            void* workspace, size_t workspace_bytes, int bf16, const mp_syncbn_t* sync, mp_stream_t stream);
+int mp_sa_mlp_bwd_gather_ex(const mp_gather_t* gather, int64_t P, int64_t K, int n_layers, const mp_mlp_layer_t* layers,
+                            int training, const float* grad_out, const float* out, const int32_t* argk,
+                            const float* zmax, const mp_mlp_grads_t* grads, float* grad_x0, int64_t grad_x0_cols,
+                            void* workspace, size_t workspace_bytes, int bf16, const mp_syncbn_t* sync, mp_stream_t stream);
 
 /* ---- fused "gradient from rank-B factors + Adam" for the head matrices (scope table row f1, "next") -----------------
  * replaces, for a Linear weight W [O, I] whose gradient is dW = g^T x (g = dLoss/dy [Bg,O], x = input [Bg,I]):

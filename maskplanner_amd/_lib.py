@@ -119,6 +119,10 @@ SIGNATURES = {
                                  _sz, _vp]),
     "mp_sa_mlp_bwd_f32": (_int, [_vp, _i64, _i64, _int, ctypes.POINTER(MlpLayer), _int, _vp, _vp, _vp, _vp,
                                  ctypes.POINTER(MlpGrads), _vp, _i64, _vp, _sz, _vp]),
+    "mp_sa_mlp_fwd_gather_ex": (_int, [ctypes.POINTER(Gather), _i64, _i64, _int, ctypes.POINTER(MlpLayer), _int, _dbl, _dbl, _vp, _vp, _vp, _vp,
+                                       _sz, _int, ctypes.POINTER(SyncBN), _vp]),
+    "mp_sa_mlp_bwd_gather_ex": (_int, [ctypes.POINTER(Gather), _i64, _i64, _int, ctypes.POINTER(MlpLayer), _int, _vp, _vp, _vp, _vp,
+                                       ctypes.POINTER(MlpGrads), _vp, _i64, _vp, _sz, _int, ctypes.POINTER(SyncBN), _vp]),
     "mp_sa_mlp_fwd_ex": (_int, [_vp, _i64, _i64, _int, ctypes.POINTER(MlpLayer), _int, _dbl, _dbl, _vp, _vp, _vp, _vp,
                                 _sz, _int, ctypes.POINTER(SyncBN), _vp]),
     "mp_sa_mlp_bwd_ex": (_int, [_vp, _i64, _i64, _int, ctypes.POINTER(MlpLayer), _int, _vp, _vp, _vp, _vp,

@@ -320,17 +320,35 @@ __device__ __forceinline__ Split4 split3(const float4& v)
 // One image serves both contractions that read the chunk:
 //   * as A[row][k = c] of a 16x16x32 MFMA: lane (row, kq) reads the 16 bytes of group 4*st + kq -- 16 lanes = 256 contiguous bytes;
 //   * as [k = row][col = c] of a 32x32x16 MFMA through ds_read_b64_tr_b16: lane 4q + p supplies row q, columns 4p .. 4p+3.
-template <int GS>
+// [r3] Swizzled form (SWZ; 16-row chunks, GS = 128 halves: no pad): row r of group g sits at row r ^ S[g & 3], S = {0, 12, 4, 8} (+ low bits, below).
+// ds_read_b128 is served in the lane groups {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} (+32) -- NOT 16 consecutive lanes -- so the
+// A-fragment read above (lane (row, kq) -> group 4 st + kq) met rows {0-3, 12-15} of one group and rows {4-11} of the next in ONE
+// LDS cycle: with groups 16 dwords apart those overlap on 16 banks (the 40-49 % SQ_LDS_BANK_CONFLICT of the fused backward kernels
+// in profiles/r02_sq_counters.md).  With groups a whole 64-bank line apart and the XOR, both reads are conflict-free: the b128
+// lane groups see 16 distinct rows (S[0] ^ S[1] = S[2] ^ S[3] = 12 maps {4..11} onto itself), and the transposed read's four groups
+// x four rows land in four disjoint 16-dword windows (the S values are the four multiples of 4).
+#ifndef MP_KSWZ
+#define MP_KSWZ 1
+#endif
+// The low bits of S (S = {0, 14, 4, 10}) do not move a row out of its 4-row window; they spread the staging writes (ds_write_b64: 16
+// consecutive lanes per LDS cycle, 32 banks) of the four groups over distinct residues of row mod 8.  (S depends on g & 3 only: the
+// lane part of every read address stays one loop-invariant register; a fifth bit for g >> 2 cost address registers the 256-output
+// kernel does not have.)
+__device__ __forceinline__ constexpr int kswz(int g) { return (int)((0xA4E0u >> ((g & 3) * 4)) & 15u); }
+template <int GS, bool SWZ = false>
 __device__ __forceinline__ bf16x8 tr_frag_packed(const __bf16* tile, int k0, int c0)
 {
     const int lane = threadIdx.x & 63;
     const int i = lane & 15, q = i >> 2, pp = i & 3, nh = (lane >> 4) & 1, h = lane >> 5;
-    const __bf16* p = tile + ((c0 >> 3) + 2 * nh + (pp >> 1)) * GS + (k0 + 8 * h + q) * 8 + 4 * (pp & 1);
+    const int g = (c0 >> 3) + 2 * nh + (pp >> 1), r = k0 + 8 * h + q;          // (k0 % 8 == 0: r + 4 == r ^ 4)
+    const int pr = SWZ ? (r ^ kswz(g)) : r;
+    const __bf16* p = tile + g * GS + pr * 8 + 4 * (pp & 1);
+    const __bf16* p2 = SWZ ? tile + g * GS + (pr ^ 4) * 8 + 4 * (pp & 1) : p + 4 * 8;
     typedef __attribute__((address_space(3))) bf16x4* lds_ptr;
     const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_ptr)(p));
-    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_ptr)(p + 4 * 8));
-    bf16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-    return r;
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_ptr)(p2));
+    bf16x8 r8 = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return r8;
 }
 
 // acc += A * B over one K chunk.  A_TR / B_TR: the operand's tile is [k][row or col] (transposed reads) instead of [row][k].
@@ -898,6 +916,18 @@ __global__ __launch_bounds__(THREADS) void dw_gemm_kernel(PosOperand DZ, PosOper
 // other waves' MFMAs instead of being a separate phase of a 128 x 128 tile.  One partial-sum row per workgroup
 // (P / p_per_block rows instead of P / 128) also makes the BatchNorm finalize kernel 8x shorter.
 // =================================================================================================================
+#ifndef MP_BF_ABL
+#define MP_BF_ABL 0         // timing builds of bwd_fused_kernel with parts compiled out (tools/bwd_ablate.sh): 1 dW products, 2 dX products, 4 dX epilogue,
+#endif                      // 8 staging arithmetic, 16 global loads, 32 staging altogether -- results are wrong by construction
+#ifndef MP_PD2
+#define MP_PD2 3            // [r3] fused backward: two chunks of loads in flight (two register sets, loop unrolled by two); bit mask, see PD2
+#endif
+#ifndef MP_FPD2
+#define MP_FPD2 0           // [r3] position-stream forward: two chunks of loads in flight
+#endif
+#ifndef MP_DESYNC
+#define MP_DESYNC 1         // [r3] fused backward, 256-output layer (eight waves): waves 4..7 take the chunk's barrier between the products and the staging
+#endif
 // ONE (with SPLIT): the bf16 variant of BASELINE configs[4] -- operands rounded once to bf16 (the h plane alone), one product instead of six
 template <int CI, int CO, bool POOL, int MODE_A = SRC_ACT, int TAIL = 0, bool SPLIT = false, bool STORE = true, bool ONE = false>   // TAIL = 4: input rows are [CI | 4] wide (features | xyz + pad)
 __global__ __launch_bounds__(CO > 128 ? 512 : 256) void fwd_chunk_kernel(PosOperand A, int P, int p_per_block,
@@ -958,8 +988,8 @@ __global__ __launch_bounds__(CO > 128 ? 512 : 256) void fwd_chunk_kernel(PosOper
     constexpr int KA_STEP = NT / (CI / 4);
     ChanConst kc;
     load_consts<MODE_A>(A, ca, kc);
-    Raw4<MODE_A> ra[PA];
-    Raw4<MODE_A> rt;
+    struct RSet { Raw4<MODE_A> a[PA]; Raw4<MODE_A> t; };
+    RSet rs0, rs1;                             // (rs1: FPD2 only)
     unsigned gs[PA], gst = 0xffffffffu;        // SRC_ID_G: source rows of the chunk that is loaded NEXT (fetched a chunk earlier)
 #pragma unroll
     for (int ps = 0; ps < PA; ++ps) gs[ps] = 0xffffffffu;
@@ -970,13 +1000,15 @@ __global__ __launch_bounds__(CO > 128 ? 512 : 256) void fwd_chunk_kernel(PosOper
             if (TAIL != 0 && tid < DBK) gst = gather_row(A, p1, pk + tid);
         }
     };
-    auto gload = [&](int pk) {
+    auto gload = [&](int pk, RSet& rs) {
 #pragma unroll
-        for (int ps = 0; ps < PA; ++ps) raw_load<MODE_A>(A, p1, pk + ka0 + ps * KA_STEP, ca, ra[ps], gs[ps]);
-        if constexpr (TAIL != 0) { if (tid < DBK) raw_load<MODE_A>(A, p1, pk + tid, CI, rt, gst); }
+        for (int ps = 0; ps < PA; ++ps) raw_load<MODE_A>(A, p1, pk + ka0 + ps * KA_STEP, ca, rs.a[ps], gs[ps]);
+        if constexpr (TAIL != 0) { if (tid < DBK) raw_load<MODE_A>(A, p1, pk + tid, CI, rs.t, gst); }
         gidx(pk + DBK);
     };
-    auto sstore = [&](int buf) {
+    auto sstore = [&](int buf, RSet& rs) {
+        auto& ra = rs.a;
+        auto& rt = rs.t;
 #pragma unroll
         for (int ps = 0; ps < PA; ++ps) {
             if constexpr (SPLIT) {
@@ -1018,13 +1050,20 @@ __global__ __launch_bounds__(CO > 128 ? 512 : 256) void fwd_chunk_kernel(PosOper
     if constexpr (POOL) neg = gamma[col] < 0.0f;
     const unsigned smask = neg ? 0x80000000u : 0u;
 
+    // ([r3] tried: the staggered barrier of bwd_fused_kernel's DESYNC for the 512-thread form -- 110.7 vs 111.0 us, not kept)
+    // FPD2: two chunks of loads in flight (two register sets, the loop unrolled by two), as bwd_fused_kernel's PD2
+    constexpr bool FPD2 = MP_FPD2 && SPLIT && MODE_A != SRC_ID_G;
     gidx(p0);
-    gload(p0);
-    sstore(0);
+    gload(p0, rs0);
+    sstore(0, rs0);
+    if constexpr (FPD2) {
+        if (nchunks > 1) gload(p0 + DBK, rs0);
+        if (nchunks > 2) gload(p0 + 2 * DBK, rs1);
+    }
     __syncthreads();
-    for (int kcn = 0; kcn < nchunks; ++kcn) {
+    auto body = [&](const int kcn, RSet& rs) {
         const int cur = kcn & 1;
-        if (kcn + 1 < nchunks) gload(p0 + (kcn + 1) * DBK);
+        if (!FPD2 && kcn + 1 < nchunks) gload(p0 + (kcn + 1) * DBK, rs);
         float v[NV];
         if constexpr (SPLIT && !BIG) {
             // 16 columns per wave: two 16x16 row tiles, v_mfma_f32_16x16x32_bf16 (lane (row, kq) holds A[row][32*st + 8*kq .. + 7])
@@ -1147,8 +1186,17 @@ __global__ __launch_bounds__(CO > 128 ? 512 : 256) void fwd_chunk_kernel(PosOper
                 else { po.vmax[o] = val; po.imax[o] = gibest; }
             }
         }
-        if (kcn + 1 < nchunks) sstore(cur ^ 1);
+        if (kcn + 1 < nchunks) sstore(cur ^ 1, rs);
+        if (FPD2 && kcn + 3 < nchunks) gload(p0 + (kcn + 3) * DBK, rs);
         __syncthreads();
+    };
+    if constexpr (FPD2) {
+        for (int kcn = 0; kcn < nchunks; kcn += 2) {
+            body(kcn, rs0);
+            if (kcn + 1 < nchunks) body(kcn + 1, rs1);
+        }
+    } else {
+        for (int kcn = 0; kcn < nchunks; ++kcn) body(kcn, rs0);
     }
 #pragma unroll
     for (int d = BIG ? 32 : 16; d <= 32; d <<= 1) {
@@ -1183,12 +1231,21 @@ __global__ __launch_bounds__(CO > 128 ? 512 : 256) void fwd_chunk_kernel(PosOper
 #ifndef MP_SPLIT_WGS
 #define MP_SPLIT_WGS 2     // (3: a third workgroup of the 64-input layers per CU -- tried: 168-register cap, spills in the loop, 150 -> 370 us)
 #endif
+#ifndef MP_BF_NT256
+#define MP_BF_NT256 0       // experiment: the 128-input layers with FOUR waves (one per SIMD, up to 512 registers each) instead of eight; bit 0: 256 outputs, bit 1: 128
+#endif
+// threads of a fused-backward workgroup: eight waves for the 128-input layers (registers per wave), four otherwise
+constexpr int bwd_fused_threads(int CO, int CI, bool SPLIT, bool ONE)
+{
+    if (CO >= 128 && CI == 128) return (SPLIT && !ONE && ((MP_BF_NT256 >> (CO == 256 ? 0 : 1)) & 1)) ? 256 : 512;
+    return 256;
+}
 template <int MODE_DZ, int CO, int CI, int MODE_IN = SRC_ACT, bool SPLIT = false, bool ONE = false>      // ONE: see fwd_chunk_kernel
-__global__ __launch_bounds__((CO >= 128 && CI == 128 ? 512 : 256), (CO >= 128 && CI == 128 ? 1 : ((SPLIT && CI == 64) ? MP_SPLIT_WGS : 2))) void bwd_fused_kernel(PosOperand DZ, PosOperand IN, int P, int p_per_block,
+__global__ __launch_bounds__(bwd_fused_threads(CO, CI, SPLIT, ONE), (CO >= 128 && CI == 128 ? 1 : ((SPLIT && CI == 64) ? MP_SPLIT_WGS : 2))) void bwd_fused_kernel(PosOperand DZ, PosOperand IN, int P, int p_per_block,
                                                             const float* __restrict__ W, float* __restrict__ dW,
                                                             float* __restrict__ G, float* __restrict__ partials)
 {
-    constexpr int NT = (CO >= 128 && CI == 128) ? 512 : 256, NW = NT / 64;  // 8 waves for the 128-input layers (registers per wave)
+    constexpr int NT = bwd_fused_threads(CO, CI, SPLIT, ONE), NW = NT / 64;
     constexpr int DBK = (CI == 128 || SPLIT) ? 16 : 32;   // positions per chunk (LDS and registers: at least two workgroups per CU)
     constexpr int XW = DBK == 32 ? CI / (NW / 2) : CI / NW; // dX columns per wave (the chunk's dX tile is [DBK x CI])
     constexpr int HT = XW / 16;                             // 16x16 dX tiles per wave and chunk
@@ -1206,7 +1263,8 @@ __global__ __launch_bounds__((CO >= 128 && CI == 128 ? 512 : 256), (CO >= 128 &&
     constexpr int HTW = KSPLIT ? 2 : HT, NSTW = KSPLIT ? CO / 64 : CO / 32;     // weight-plane tiles / k-steps per wave
     // SPLIT: K-packed planes (tr_frag_packed), group stride in halves: 16 dwords mod 64 banks.  The 64-input layers are HBM-bound:
     // a smaller pad (8 dwords: some 2-way conflicts in the transposed reads) lets a third workgroup onto the CU -- more loads in flight
-    constexpr int GS = DBK * 8 + ((SPLIT && CI == 64 && MP_SPLIT_WGS == 3) ? 16 : 32);
+    constexpr bool KSWZ = SPLIT && MP_KSWZ;        // row-swizzled image without pad (tr_frag_packed)
+    constexpr int GS = DBK * 8 + (KSWZ ? 0 : ((SPLIT && CI == 64 && MP_SPLIT_WGS == 3) ? 16 : 32));
     __shared__ __attribute__((aligned(16))) float sA[2][SPLIT ? 4 : DBK * LDA];
     __shared__ __attribute__((aligned(16))) float sB[2][SPLIT ? 4 : DBK * CI];
     __shared__ __attribute__((aligned(16))) __bf16 hA[2][3][SPLIT ? (CO / 8) * GS : 8];   // dZ chunk as (h, m, l) planes
@@ -1258,15 +1316,19 @@ __global__ __launch_bounds__((CO >= 128 && CI == 128 ? 512 : 256), (CO >= 128 &&
         sKA[0][ca >> 2] = ka.s; sKA[1][ca >> 2] = ka.t; sKA[2][ca >> 2] = ka.a; sKA[3][ca >> 2] = ka.e; sKA[4][ca >> 2] = ka.f;
         sKB[0][cb >> 2] = kb.s; sKB[1][cb >> 2] = kb.t;
     }
-    Raw4<MODE_DZ> ra[PA];
-    Raw4<MODE_IN> rb[PB];
-    auto gload = [&](int pk) {
+    struct RSet { Raw4<MODE_DZ> a[PA]; Raw4<MODE_IN> b[PB]; };
+    RSet rs0, rs1;            // (rs1: PD2 only)
+    auto gload = [&](int pk, RSet& rs) {
+        if constexpr ((MP_BF_ABL >> 4) & 1) { if (pk != p0) return; }
 #pragma unroll
-        for (int ps = 0; ps < PA; ++ps) raw_load<MODE_DZ>(DZ, p1, pk + ka0 + ps * KA_STEP, ca, ra[ps]);
+        for (int ps = 0; ps < PA; ++ps) raw_load<MODE_DZ>(DZ, p1, pk + ka0 + ps * KA_STEP, ca, rs.a[ps]);
 #pragma unroll
-        for (int ps = 0; ps < PB; ++ps) raw_load<MODE_IN>(IN, p1, pk + kb0 + ps * KB_STEP, cb, rb[ps]);
+        for (int ps = 0; ps < PB; ++ps) raw_load<MODE_IN>(IN, p1, pk + kb0 + ps * KB_STEP, cb, rs.b[ps]);
     };
-    auto sstore = [&](int buf) {
+    auto sstore = [&](int buf, RSet& rs) {
+        auto& ra = rs.a;
+        auto& rb = rs.b;
+        if constexpr ((MP_BF_ABL >> 5) & 1) { if (buf >= 0) return; }
         if constexpr (LDS_CONSTS) {
             ka.s = sKA[0][ca >> 2]; ka.t = sKA[1][ca >> 2]; ka.a = sKA[2][ca >> 2]; ka.e = sKA[3][ca >> 2]; ka.f = sKA[4][ca >> 2];
             kb.s = sKB[0][cb >> 2]; kb.t = sKB[1][cb >> 2];
@@ -1274,8 +1336,10 @@ __global__ __launch_bounds__((CO >= 128 && CI == 128 ? 512 : 256), (CO >= 128 &&
 #pragma unroll
         for (int ps = 0; ps < PA; ++ps) {
             if constexpr (SPLIT) {
-                const Split4 sp = split3(finish<MODE_DZ>(ra[ps], ka));
-                const int o = (ca >> 3) * GS + (ka0 + ps * KA_STEP) * 8 + (ca & 7);
+                Split4 sp;
+                if constexpr ((MP_BF_ABL >> 3) & 1) { const bf16x4 c = to_bf16x4(ra[ps].z); sp.h = c; sp.m = c; sp.l = c; }
+                else sp = split3(finish<MODE_DZ>(ra[ps], ka));
+                const int o = (ca >> 3) * GS + ((ka0 + ps * KA_STEP) ^ (KSWZ ? kswz(ca >> 3) : 0)) * 8 + (ca & 7);
                 *reinterpret_cast<bf16x4*>(&hA[buf][0][o]) = sp.h;
                 if constexpr (!ONE) {
                     *reinterpret_cast<bf16x4*>(&hA[buf][1][o]) = sp.m;
@@ -1289,8 +1353,10 @@ __global__ __launch_bounds__((CO >= 128 && CI == 128 ? 512 : 256), (CO >= 128 &&
         for (int ps = 0; ps < PB; ++ps) {
             const int o = (kb0 + ps * KB_STEP) * CI + cb;
             if constexpr (SPLIT) {
-                const Split4 sp = split3(finish<MODE_IN>(rb[ps], kb));
-                const int oh = (cb >> 3) * GS + (kb0 + ps * KB_STEP) * 8 + (cb & 7);
+                Split4 sp;
+                if constexpr ((MP_BF_ABL >> 3) & 1) { const bf16x4 c = to_bf16x4(rb[ps].z); sp.h = c; sp.m = c; sp.l = c; }
+                else sp = split3(finish<MODE_IN>(rb[ps], kb));
+                const int oh = (cb >> 3) * GS + ((kb0 + ps * KB_STEP) ^ (KSWZ ? kswz(cb >> 3) : 0)) * 8 + (cb & 7);
                 *reinterpret_cast<bf16x4*>(&hB[buf][0][oh]) = sp.h;
                 if constexpr (!ONE) {
                     *reinterpret_cast<bf16x4*>(&hB[buf][1][oh]) = sp.m;
@@ -1356,19 +1422,28 @@ __global__ __launch_bounds__((CO >= 128 && CI == 128 ? 512 : 256), (CO >= 128 &&
     __shared__ f32x4 xbuf[KSPLIT ? NW : 1][64];      // KSPLIT: the partial of the tile the partner wave finalises
     f32x4 ax[HT];                                    // the finished dX tile(s) of this wave, between g_mfma and g_epi
 
-    gload(p0);
-    sstore(0);
+    constexpr bool PD2 = MP_PD2 && SPLIT && !KSPLIT && ((MP_PD2 >> (NT == 512 ? (CO == 256 ? 2 : 1) : 0)) & 1);   // bit 0: 256-thread kernels, 1: <.,128,128>, 2: <.,256,128>
+    constexpr bool DESYNC = MP_DESYNC && NT == 512 && CO == 256 && SPLIT && !KSPLIT && !PD2;   // (<.,128,128>: 128 -> 134 us with it, 124 -> 116 with PD2)
+    const int half = DESYNC ? __builtin_amdgcn_readfirstlane(wave >> 2) : 0;
+    gload(p0, rs0);
+    sstore(0, rs0);
+    if (DESYNC && half && nchunks > 1) { gload(p0 + DBK, rs0); sstore(1, rs0); }
+    if constexpr (PD2) {     // chunks 1 and 2 on their way before the first product
+        if (nchunks > 1) gload(p0 + DBK, rs0);
+        if (nchunks > 2) gload(p0 + 2 * DBK, rs1);
+    }
     __syncthreads();
-    for (int kc = 0; kc < nchunks; ++kc) {
+    // one chunk: products of chunk kc (plane buffer kc & 1), then chunk kc + 1 (held by `rs`) is staged into the other buffer
+    auto body = [&](const int kc, RSet& rs) {
         const int cur = kc & 1;
-        if (kc + 1 < nchunks) gload(p0 + (kc + 1) * DBK);
+        if (!PD2 && kc + 1 + half < nchunks) gload(p0 + (kc + 1 + half) * DBK, rs);
         auto do_dw = [&]() {
         if constexpr (SPLIT && ONE) {   // one plane: dW += bf16(dZ)^T * bf16(act(Z_{l-1}))
             bf16x8 fb[TNW], fa[TMW];
 #pragma unroll
-            for (int ni = 0; ni < TNW; ++ni) fb[ni] = tr_frag_packed<GS>(hB[cur][0], 0, wcol0 + ni * 32);
+            for (int ni = 0; ni < TNW; ++ni) fb[ni] = tr_frag_packed<GS, KSWZ>(hB[cur][0], 0, wcol0 + ni * 32);
 #pragma unroll
-            for (int mi = 0; mi < TMW; ++mi) fa[mi] = tr_frag_packed<GS>(hA[cur][0], 0, wrow0 + mi * 32);
+            for (int mi = 0; mi < TMW; ++mi) fa[mi] = tr_frag_packed<GS, KSWZ>(hA[cur][0], 0, wrow0 + mi * 32);
 #pragma unroll
             for (int mi = 0; mi < TMW; ++mi)
 #pragma unroll
@@ -1377,19 +1452,19 @@ __global__ __launch_bounds__((CO >= 128 && CI == 128 ? 512 : 256), (CO >= 128 &&
             // fragments in the order they are consumed (one dZ plane live at a time): l*h, h*l, h*m, h*h, m*m, m*h
             bf16x8 fb[3][TNW], fa[TMW];
 #pragma unroll
-            for (int ni = 0; ni < TNW; ++ni) fb[0][ni] = tr_frag_packed<GS>(hB[cur][0], 0, wcol0 + ni * 32);
+            for (int ni = 0; ni < TNW; ++ni) fb[0][ni] = tr_frag_packed<GS, KSWZ>(hB[cur][0], 0, wcol0 + ni * 32);
 #pragma unroll
-            for (int mi = 0; mi < TMW; ++mi) fa[mi] = tr_frag_packed<GS>(hA[cur][2], 0, wrow0 + mi * 32);
+            for (int mi = 0; mi < TMW; ++mi) fa[mi] = tr_frag_packed<GS, KSWZ>(hA[cur][2], 0, wrow0 + mi * 32);
 #pragma unroll
             for (int mi = 0; mi < TMW; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < TNW; ++ni) accW[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mi], fb[0][ni], accW[mi][ni], 0, 0, 0);
 #pragma unroll
-            for (int mi = 0; mi < TMW; ++mi) fa[mi] = tr_frag_packed<GS>(hA[cur][0], 0, wrow0 + mi * 32);
+            for (int mi = 0; mi < TMW; ++mi) fa[mi] = tr_frag_packed<GS, KSWZ>(hA[cur][0], 0, wrow0 + mi * 32);
 #pragma unroll
             for (int pl = 2; pl >= 1; --pl)
 #pragma unroll
-                for (int ni = 0; ni < TNW; ++ni) fb[pl][ni] = tr_frag_packed<GS>(hB[cur][pl], 0, wcol0 + ni * 32);
+                for (int ni = 0; ni < TNW; ++ni) fb[pl][ni] = tr_frag_packed<GS, KSWZ>(hB[cur][pl], 0, wcol0 + ni * 32);
 #pragma unroll
             for (int pl = 2; pl >= 0; --pl)
 #pragma unroll
@@ -1397,7 +1472,7 @@ __global__ __launch_bounds__((CO >= 128 && CI == 128 ? 512 : 256), (CO >= 128 &&
 #pragma unroll
                     for (int ni = 0; ni < TNW; ++ni) accW[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mi], fb[pl][ni], accW[mi][ni], 0, 0, 0);
 #pragma unroll
-            for (int mi = 0; mi < TMW; ++mi) fa[mi] = tr_frag_packed<GS>(hA[cur][1], 0, wrow0 + mi * 32);
+            for (int mi = 0; mi < TMW; ++mi) fa[mi] = tr_frag_packed<GS, KSWZ>(hA[cur][1], 0, wrow0 + mi * 32);
 #pragma unroll
             for (int pl = 1; pl >= 0; --pl)
 #pragma unroll
@@ -1418,7 +1493,7 @@ __global__ __launch_bounds__((CO >= 128 && CI == 128 ? 512 : 256), (CO >= 128 &&
                 f32x4 a2[2], c2[2];
 #pragma unroll
                 for (int h = 0; h < 2; ++h) { a2[h] = f32x4{0.f, 0.f, 0.f, 0.f}; c2[h] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-                const int ao = (4 * gst0 + kq) * GS + (xrow0 + l15) * 8;
+                const int ao = (4 * gst0 + kq) * GS + ((xrow0 + l15) ^ (KSWZ ? kswz(kq) : 0)) * 8;
                 bf16x8 af[2][3];
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl) af[0][pl] = *reinterpret_cast<const bf16x8*>(&hA[cur][pl][ao]);
@@ -1446,7 +1521,7 @@ __global__ __launch_bounds__((CO >= 128 && CI == 128 ? 512 : 256), (CO >= 128 &&
                 f32x4 cx[HT];
 #pragma unroll
                 for (int h = 0; h < HT; ++h) cx[h] = f32x4{0.f, 0.f, 0.f, 0.f};
-                const int ao = kq * GS + (xrow0 + l15) * 8;
+                const int ao = kq * GS + ((xrow0 + l15) ^ (KSWZ ? kswz(kq) : 0)) * 8;
                 bf16x8 af[2][3];       // the fragments of k-step st + 1 are requested before the MFMAs of step st are issued
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl) af[0][pl] = *reinterpret_cast<const bf16x8*>(&hA[cur][pl][ao]);
@@ -1531,13 +1606,42 @@ __global__ __launch_bounds__((CO >= 128 && CI == 128 ? 512 : 256), (CO >= 128 &&
             do_dw();
             __syncthreads();      // every partial is in xbuf
             g_epi();
-        } else {
+            if (kc + 1 < nchunks) sstore(cur ^ 1, rs);
+        } else if constexpr (DESYNC) {
+            // [r3] eight waves, two per SIMD (wave w and w + 4), one barrier per chunk: left alone both waves of a SIMD run the matrix
+            // phase together and then the staging arithmetic together -- the matrix pipe idles through the second, the VALU through the
+            // first (profiles/r02_sq_counters.md: MFMA 37 % + VALU 27 % of the cycles, one after the other).  Here waves 4..7 take
+            // their barrier BETWEEN the products and the staging instead of behind both, and stage one chunk further ahead (chunk
+            // kc + 2 into the buffer the products of chunk kc just left): past the first chunk one half's MFMAs run under the
+            // other half's VALU work on every SIMD.  Same arithmetic; every wave still passes one barrier per chunk.
             do_dw();
             g_mfma();
             g_epi();
+            if (half) __syncthreads();
+            if (kc + 1 + half < nchunks) sstore((kc + 1 + half) & 1, rs);
+            if (!half) __syncthreads();
+        } else {
+            if constexpr (!(MP_BF_ABL & 1)) do_dw();
+            if constexpr (!((MP_BF_ABL >> 1) & 1)) g_mfma();
+            else {
+#pragma unroll
+                for (int h = 0; h < HT; ++h) ax[h] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            if constexpr (!((MP_BF_ABL >> 2) & 1)) g_epi();
+            if (kc + 1 < nchunks) sstore(cur ^ 1, rs);
+            // PD2: the set just emptied is refilled at once with the chunk it stages two iterations from now -- two chunks of
+            // loads in flight per workgroup instead of one (an iteration of these kernels lasts about one loaded-HBM round trip)
+            if (PD2 && kc + 3 < nchunks) gload(p0 + (kc + 3) * DBK, rs);
         }
-        if (kc + 1 < nchunks) sstore(cur ^ 1);
-        __syncthreads();
+        if constexpr (!DESYNC) __syncthreads();
+    };
+    if constexpr (PD2) {
+        for (int kc = 0; kc < nchunks; kc += 2) {
+            body(kc, rs0);
+            if (kc + 1 < nchunks) body(kc + 1, rs1);
+        }
+    } else {
+        for (int kc = 0; kc < nchunks; ++kc) body(kc, rs0);
     }
     // BatchNorm-backward partial sums of layer l-1: the four 16-lane row groups of a wave, then (32-position chunks) the two
     // waves that share a column half
@@ -2868,6 +2972,15 @@ extern "C" int mp_sa_mlp_fwd_gather_bf16(const mp_gather_t* gather, int64_t P, i
                       gather);
 }
 
+extern "C" int mp_sa_mlp_fwd_gather_ex(const mp_gather_t* gather, int64_t P, int64_t K, int n_layers, const mp_mlp_layer_t* layers,
+                                       int training, double momentum, double eps, float* out, int32_t* argk, float* zmax,
+                                       void* workspace, size_t workspace_bytes, int bf16, const mp_syncbn_t* sync, mp_stream_t stream)
+{   // the gather forms with the SyncBN hook of mp_sa_mlp_fwd_ex (bf16: the factorised form only, as mp_sa_mlp_fwd_gather_bf16)
+    if (!gather || n_layers < 1 || !layers || (bf16 && layers[0].c_in != 4)) return MP_EINVAL;
+    return sa_mlp_fwd(nullptr, P, K, n_layers, layers, training, momentum, eps, out, argk, zmax, workspace, workspace_bytes, stream, bf16 != 0, sync,
+                      gather);
+}
+
 extern "C" int mp_sa_mlp_fwd_bf16(const float* x0, int64_t P, int64_t K, int n_layers, const mp_mlp_layer_t* layers,
                                   int training, double momentum, double eps, float* out, int32_t* argk, float* zmax,
                                   void* workspace, size_t workspace_bytes, mp_stream_t stream)
@@ -3032,13 +3145,13 @@ static int sa_mlp_bwd(const float* x0, int64_t P, int64_t K, int n_layers, const
             snprintf(tg, sizeof tg, bf16 ? "bwd_fused_bf16_kernel<%d, %d, %d>" : "bwd_fused_kernel<%d, %d, %d>", pooled ? 3 : 2, Co, Ci);
 #define MP_FUSED(MODE, CO_, CI_)                                                                                              \
     if (bf16)                                                                                                                 \
-        MP_LAUNCH(tg, fl, by, (bwd_fused_kernel<MODE, CO_, CI_, SRC_ACT, true, true>), dim3(gx), dim3((CO_ >= 128 && CI_ == 128) ? 512 : 256), 0, stream, DZ, IN, (int)P, \
+        MP_LAUNCH(tg, fl, by, (bwd_fused_kernel<MODE, CO_, CI_, SRC_ACT, true, true>), dim3(gx), dim3(bwd_fused_threads(CO_, CI_, true, true)), 0, stream, DZ, IN, (int)P, \
                   ppb, Ly.weight, grads[l].d_weight, Gn, partials);                                                           \
     else if (split_enabled())                                                                                                      \
-        MP_LAUNCH(tg, fl, by, (bwd_fused_kernel<MODE, CO_, CI_, SRC_ACT, true>), dim3(gx), dim3((CO_ >= 128 && CI_ == 128) ? 512 : 256), 0, stream, DZ, IN, (int)P, \
+        MP_LAUNCH(tg, fl, by, (bwd_fused_kernel<MODE, CO_, CI_, SRC_ACT, true>), dim3(gx), dim3(bwd_fused_threads(CO_, CI_, true, false)), 0, stream, DZ, IN, (int)P, \
                   ppb, Ly.weight, grads[l].d_weight, Gn, partials);                                                           \
     else                                                                                                                      \
-        MP_LAUNCH(tg, fl, by, (bwd_fused_kernel<MODE, CO_, CI_>), dim3(gx), dim3((CO_ >= 128 && CI_ == 128) ? 512 : 256), 0, stream, DZ, IN, (int)P, ppb, Ly.weight, \
+        MP_LAUNCH(tg, fl, by, (bwd_fused_kernel<MODE, CO_, CI_>), dim3(gx), dim3(bwd_fused_threads(CO_, CI_, false, false)), 0, stream, DZ, IN, (int)P, ppb, Ly.weight, \
                   grads[l].d_weight, Gn, partials)
             if (rc_first && l == 1) {   // (never the pooled layer: n_layers >= 3)
                 snprintf(tg, sizeof tg, bf16 ? "bwd_fused_bf16_kernel<2, %d, 64, 4>" : "bwd_fused_kernel<2, %d, 64, 4>", Co);
@@ -3220,6 +3333,16 @@ extern "C" int mp_sa_mlp_bwd_gather_bf16(const mp_gather_t* gather, int64_t P, i
     if (!gather || n_layers < 1 || !layers || layers[0].c_in != 4) return MP_EINVAL;
     return sa_mlp_bwd(nullptr, P, K, n_layers, layers, training, grad_out, out, argk, zmax, grads, grad_x0, grad_x0_cols, workspace,
                       workspace_bytes, stream, true, nullptr, gather);
+}
+
+extern "C" int mp_sa_mlp_bwd_gather_ex(const mp_gather_t* gather, int64_t P, int64_t K, int n_layers, const mp_mlp_layer_t* layers,
+                                       int training, const float* grad_out, const float* out, const int32_t* argk,
+                                       const float* zmax, const mp_mlp_grads_t* grads, float* grad_x0, int64_t grad_x0_cols,
+                                       void* workspace, size_t workspace_bytes, int bf16, const mp_syncbn_t* sync, mp_stream_t stream)
+{
+    if (!gather || n_layers < 1 || !layers || (bf16 && layers[0].c_in != 4)) return MP_EINVAL;
+    return sa_mlp_bwd(nullptr, P, K, n_layers, layers, training, grad_out, out, argk, zmax, grads, grad_x0, grad_x0_cols, workspace,
+                      workspace_bytes, stream, bf16 != 0, sync, gather);
 }
 
 extern "C" int mp_sa_mlp_bwd_bf16(const float* x0, int64_t P, int64_t K, int n_layers, const mp_mlp_layer_t* layers,

@@ -617,12 +617,13 @@ class DropInLoop:
     no pipelined sampling: this is the drop-in figure, `TrainStep` is the path's ceiling."""
 
     def __init__(self, category="cuboids", B=32, N=5120, device="cuda", seed=1235, lr=1e-3, dist_points="cuboid", n_batches=4,
-                 rank=0):
+                 rank=0, adam_kwargs=None):
         self.cat = synthetic.CATEGORIES[category] if isinstance(category, str) else category
         self.device = torch.device(device)
         torch.manual_seed(seed)
         self.model = maskplanner_model(self.cat).to(self.device)
-        self.opt = torch.optim.Adam(self.model.parameters(), lr=lr)                       # :159
+        self.opt = torch.optim.Adam(self.model.parameters(), lr=lr, **(adam_kwargs or {}))    # :159 (adam_kwargs: what a one-word change
+                                                                                          # of that line buys, e.g. fused=True -- tools/dropin_phases.py)
         self.cfg = maskplanner_loss_config()
         self.loss_handler = LossHandler(["asymm_v6_chamfer_with_stroke_masks"], self.cfg)  # :163
         self.host_batches = [synthetic.make_batch(seed + 1000 * rank + 7 * i, B, N, self.cat.name, dist_points) for i in range(n_batches)]

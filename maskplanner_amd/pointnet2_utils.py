@@ -239,7 +239,8 @@ class PointNetSetAbstraction(nn.Module):
               and sa_mlp.factored_supported(points, self.nsample, self.mlp_convs, self.mlp_bns, self.mlp_dtype, self.sync_bn)):
             # the first layer factorised: a linear map per source point, then a gather-add (sa_mlp.shared_mlp_max_factored)
             new_xyz, idx = sample_indices(self.npoint, self.radius, self.nsample, xyz)
-            new_points = sa_mlp.shared_mlp_max_factored(xyz, points, new_xyz, idx, self.mlp_convs, self.mlp_bns, "xyz_first", dtype=self.mlp_dtype)
+            new_points = sa_mlp.shared_mlp_max_factored(xyz, points, new_xyz, idx, self.mlp_convs, self.mlp_bns, "xyz_first", dtype=self.mlp_dtype,
+                                                        sync_bn=self.sync_bn)
             return new_xyz.permute(0, 2, 1), new_points.permute(0, 2, 1)
         elif (points is not None and full_points is None and os.environ.get("MP_GATHER_FUSED", "0") != "0"
               and sa_mlp.gathered_supported(points, self.nsample, self.mlp_convs, self.mlp_bns, self.mlp_dtype, self.sync_bn)):
@@ -291,7 +292,7 @@ class PointNetSetAbstractionMsg(nn.Module):
             if (points is not None and sa_mlp.FACTORED_FIRST in ("1", "msg", True)
                     and sa_mlp.factored_supported(points, K, convs, bns, self.mlp_dtype, self.sync_bn)):
                 # first layer factorised (features: a linear map per source point; then a gather-add): no grouped tensor
-                outs.append(sa_mlp.shared_mlp_max_factored(xyz, points, new_xyz, idx, convs, bns, "xyz_last", dtype=self.mlp_dtype))
+                outs.append(sa_mlp.shared_mlp_max_factored(xyz, points, new_xyz, idx, convs, bns, "xyz_last", dtype=self.mlp_dtype, sync_bn=self.sync_bn))
                 continue
             grouped = ops.group(xyz, points, new_xyz, idx, xyz_last=True, pad_to=4)
             outs.append(sa_mlp.shared_mlp_max(grouped, convs, bns, dtype=self.mlp_dtype, sync_bn=self.sync_bn))

@@ -222,7 +222,7 @@ class _SharedMLPMaxFactored(torch.autograd.Function):
     Backward: the library writes dZ_0 [P, Co + 4]; its reduction over the gathering rows (ops.group's backward kernel) is dA."""
 
     @staticmethod
-    def forward(ctx, A, xyz, new_xyz, idx, training, momentum, eps, n_layers, bf16, *params):
+    def forward(ctx, A, xyz, new_xyz, idx, training, momentum, eps, n_layers, bf16, sync_group, *params):
         dev = A.device
         B, N, C0 = A.shape
         _, S, K = idx.shape
@@ -232,7 +232,8 @@ class _SharedMLPMaxFactored(torch.autograd.Function):
         chans = [4] + [params[6 * l].shape[0] for l in range(n_layers)]
         lib = _lib.load()
         ch_ = (ctypes.c_int64 * len(chans))(*chans)
-        lean_last = (not bf16) and LEAN_LAST and bool(lib.mp_sa_mlp_lean_last(n_layers, ch_, K, P))      # (see _SharedMLPMax)
+        sync = sync_group is not False and training      # global-batch BatchNorm statistics (sync_bn.py), as in _SharedMLPMax
+        lean_last = (not bf16) and (not sync) and LEAN_LAST and bool(lib.mp_sa_mlp_lean_last(n_layers, ch_, K, P))      # (see _SharedMLPMax)
         for l in range(n_layers):
             w, b, gam, bet, rm, rv = params[6 * l:6 * l + 6]
             co, ci = w.shape
@@ -249,8 +250,18 @@ class _SharedMLPMaxFactored(torch.autograd.Function):
         ch = (ctypes.c_int64 * len(chans))(*chans)
         ws = torch.empty((lib.mp_sa_mlp_workspace_bytes(P, K, n_layers, ch, 0),), dtype=torch.uint8, device=dev)
         g = _lib.Gather(_ptr(A), _ptr(xyz), _ptr(new_xyz), _ptr(idx), N, S, C0)
-        ops._run("sa_mlp_fwd", A, lib.mp_sa_mlp_fwd_gather_bf16 if bf16 else lib.mp_sa_mlp_fwd_gather_f32, ctypes.byref(g), P, K, n_layers, layers, int(training), float(momentum),
-                 float(eps), _ptr(out), _ptr(argk), _ptr(zmax), _ptr(ws), ws.numel())
+        if sync:
+            from . import sync_bn
+            ex = sync_bn.Exchange(sync_group, max(chans), dev)
+            ops._run("sa_mlp_fwd", A, lib.mp_sa_mlp_fwd_gather_ex, ctypes.byref(g), P, K, n_layers, layers, int(training), float(momentum),
+                     float(eps), _ptr(out), _ptr(argk), _ptr(zmax), _ptr(ws), ws.numel(), int(bool(bf16)), ctypes.byref(ex.struct))
+            if ex.error is not None:
+                raise ex.error
+        else:
+            sync_group = False
+            ops._run("sa_mlp_fwd", A, lib.mp_sa_mlp_fwd_gather_bf16 if bf16 else lib.mp_sa_mlp_fwd_gather_f32, ctypes.byref(g), P, K, n_layers, layers, int(training), float(momentum),
+                     float(eps), _ptr(out), _ptr(argk), _ptr(zmax), _ptr(ws), ws.numel())
+        ctx.sync_group = sync_group
         ctx.meta = (P, K, bool(training), n_layers, chans, (B, N, S, C0), bool(bf16))
         ctx.keep = keep
         ctx.save_for_backward(A, xyz, new_xyz, idx, out, argk, zmax)
@@ -261,8 +272,19 @@ class _SharedMLPMaxFactored(torch.autograd.Function):
     def backward(ctx, grad_out):
         A, xyz, new_xyz, idx, out, argk, zmax = ctx.saved_tensors
         P, K, training, n_layers, chans, (B, N, S, C0), bf16 = ctx.meta
-        bwd_fn = lambda lib: lib.mp_sa_mlp_bwd_gather_bf16 if bf16 else lib.mp_sa_mlp_bwd_gather_f32
         dev = A.device
+        ex = None
+        if ctx.sync_group is not False:
+            from . import sync_bn
+            ex = sync_bn.Exchange(ctx.sync_group, max(chans), dev)
+
+        def run_bwd(lib, *a):
+            if ex is not None:
+                ops._run("sa_mlp_bwd", A, lib.mp_sa_mlp_bwd_gather_ex, *a, int(bool(bf16)), ctypes.byref(ex.struct))
+                if ex.error is not None:
+                    raise ex.error
+            else:
+                ops._run("sa_mlp_bwd", A, lib.mp_sa_mlp_bwd_gather_bf16 if bf16 else lib.mp_sa_mlp_bwd_gather_f32, *a)
         grad_out = grad_out.contiguous().float()
         layers = (_lib.MlpLayer * n_layers)()
         grads = (_lib.MlpGrads * n_layers)()
@@ -289,19 +311,19 @@ class _SharedMLPMaxFactored(torch.autograd.Function):
         fused = FACTORED_REDUCE and not ops.DETERMINISTIC and N <= 15000 and S * K < (1 << 24)
         if fused:
             gA = torch.empty((B, N, C0), dtype=torch.float32, device=dev)
-            ops._run("sa_mlp_bwd", A, bwd_fn(lib), ctypes.byref(g), P, K, n_layers, layers, int(training), _ptr(grad_out),
-                     _ptr(out), _ptr(argk), _ptr(zmax), grads, _ptr(gA), 0, _ptr(ws), ws.numel())
+            run_bwd(lib, ctypes.byref(g), P, K, n_layers, layers, int(training), _ptr(grad_out),
+                    _ptr(out), _ptr(argk), _ptr(zmax), grads, _ptr(gA), 0, _ptr(ws), ws.numel())
             ctx.keep = None
-            return (gA, None, None, None, None, None, None, None, None, *ret)
+            return (gA, None, None, None, None, None, None, None, None, None, *ret)
         gz = torch.empty((P, stride), dtype=torch.float32, device=dev)       # dZ_0 rows (the pad quad is never read)
-        ops._run("sa_mlp_bwd", A, bwd_fn(lib), ctypes.byref(g), P, K, n_layers, layers, int(training), _ptr(grad_out),
-                 _ptr(out), _ptr(argk), _ptr(zmax), grads, _ptr(gz), C0, _ptr(ws), ws.numel())
+        run_bwd(lib, ctypes.byref(g), P, K, n_layers, layers, int(training), _ptr(grad_out),
+                _ptr(out), _ptr(argk), _ptr(zmax), grads, _ptr(gz), C0, _ptr(ws), ws.numel())
         ctx.keep = None
         gA = None
         if ctx.needs_input_grad[0]:
             gA = torch.empty((B, N, C0), dtype=torch.float32, device=dev)
             ops._run("group_bwd", gz, lib.mp_group_bwd_f32, _ptr(gz), _ptr(idx), B, N, S, K, C0, 1, stride, _ptr(gA), int(ops.DETERMINISTIC))
-        return (gA, None, None, None, None, None, None, None, None, *ret)
+        return (gA, None, None, None, None, None, None, None, None, None, *ret)
 
 
 PER_POINT_DW_SLICES = int(os.environ.get("MP_PER_POINT_DW_SLICES", "8"))
@@ -356,14 +378,14 @@ FACTORED_REDUCE = os.environ.get("MASKPLANNER_FACTORED_REDUCE", "1") != "0"   # 
 def factored_supported(feats, K, convs, bns, dtype="f32", sync_bn=None):
     """True when shared_mlp_max_factored can take this level (otherwise group + shared_mlp_max)."""
     from .sync_bn import resolve
-    if dtype not in ("f32", "bf16") or resolve(sync_bn) is not False or feats is None or not feats.is_cuda or feats.dtype != torch.float32:
-        return False
+    if dtype not in ("f32", "bf16") or feats is None or not feats.is_cuda or feats.dtype != torch.float32:
+        return False        # ([r3] SyncBN levels qualify too: mp_sa_mlp_{fwd,bwd}_gather_ex)
     if len(convs) < 2 or convs[0].in_channels != feats.shape[2] + 3 or convs[0].out_channels not in (64, 128, 256):
         return False
     return all(c.out_channels % 4 == 0 for c in convs)
 
 
-def shared_mlp_max_factored(xyz, feats, new_xyz, idx, convs, bns, weight_order="xyz_first", dtype="f32"):
+def shared_mlp_max_factored(xyz, feats, new_xyz, idx, convs, bns, weight_order="xyz_first", dtype="f32", sync_bn=None):
     """The level's output [B,S,Cout] from xyz [B,N,3], feats [B,N,CF], new_xyz [B,S,3], idx [B,S,K] without a grouped tensor and
     without a first-layer GEMM over the grouped rows.  weight_order: where the coordinate columns sit in the first conv's weight --
     "xyz_first" (PointNetSetAbstraction, models/pointnet2_utils.py:138) or "xyz_last" (the multi-scale class, :262).
@@ -394,9 +416,11 @@ def shared_mlp_max_factored(xyz, feats, new_xyz, idx, convs, bns, weight_order="
                 torch._foreach_add_(counters, 1)
     bn0 = bns[0]
     momentum = bn0.momentum if bn0.momentum is not None else 1.0 / max(float(bn0.num_batches_tracked), 1.0)
-    writeback = _widen_interior(params, [c.out_channels for c in convs]) if WIDEN_INTERIOR else []
+    from .sync_bn import resolve
+    sync_group = resolve(sync_bn)
+    writeback = _widen_interior(params, [c.out_channels for c in convs]) if (sync_group is False and WIDEN_INTERIOR) else []
     out = _SharedMLPMaxFactored.apply(A.contiguous(), xyz.contiguous().float(), new_xyz.contiguous().float(), idx.contiguous(), training,
-                                      momentum, bn0.eps, len(convs), dtype == "bf16", *params)
+                                      momentum, bn0.eps, len(convs), dtype == "bf16", sync_group, *params)
     if training:
         for dst, src in writeback:
             dst.copy_(src[:dst.numel()])

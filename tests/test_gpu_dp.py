@@ -30,10 +30,8 @@ def _run(mode, world):
         port = str(s.getsockname()[1])
     tmp = tempfile.mkdtemp(prefix="mp_dp_")
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    if mode == "syncbn":
-        # SyncBN levels take the grouped first layer (the factorised one has no exchange hook): the single-process reference does the
-        # same here, so that the comparison isolates the statistics exchange from the two routes' different fp32 summation orders
-        env["MASKPLANNER_FACTORED_FIRST"] = "0"
+    # ([r3] SyncBN levels keep the factorised first layer -- mp_sa_mlp_{fwd,bwd}_gather_ex carry the exchange hook --, so both sides of
+    # the comparison run the default route)
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dp_worker.py"), mode, str(r), str(world), port,
                                os.path.join(tmp, f"r{r}.pt")], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
              for r in range(world)]

@@ -7,8 +7,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from maskplanner_amd.harness import DropInLoop
 
-for on in (False,):
-    loop = DropInLoop("cuboids", B=32, N=5120)
+for kw in ({}, {"fused": True}):          # second line: torch.optim.Adam(..., fused=True) -- a one-word change of train_maskplanner.py:159
+    loop = DropInLoop("cuboids", B=32, N=5120, adam_kwargs=kw)
+    print("torch.optim.Adam kwargs:", kw)
     for _ in range(8):
         loop.step()
     torch.cuda.synchronize()
