@@ -45,25 +45,45 @@ def _split_template(name):
     return base.strip(), args
 
 
-def measured_traffic(kernel):
+def _variant_ok(tag_base, name_base, name_args):
+    """The library's launch tags name the operand variant in the kernel name (`pos_gemm_bf16_kernel`, `dw_gemm_split_kernel`,
+    `bwd_fused_bf16_kernel`), rocprofv3 prints it as a template argument: PREC (last) of the tiled GEMMs -- 0 fp32 MFMA, 1 bf16,
+    3 split planes --, ONE (last) of the position-stream kernels."""
+    bf16, split = "_bf16_" in tag_base, "_split_" in tag_base
+    if name_base in ("pos_gemm_kernel", "dw_gemm_kernel"):
+        return name_args[-1:] == [("1" if bf16 else "3" if split else "0")]
+    if name_base in ("fwd_chunk_kernel", "bwd_fused_kernel") and name_args and name_args[-1] in ("true", "false"):
+        return (name_args[-1] == "true") == bf16 if len(name_args) >= (8 if name_base == "fwd_chunk_kernel" else 6) else not bf16
+    return True
+
+
+def measured_traffic(kernel, config_key=None):
     """HBM bytes per launch of `kernel` from the most recent committed PMC passes (profiles/rNN_traffic.json, made by
-    tools/make_profile_summary.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this bench).  The library
-    tags a launch with the template arguments it chose; rocprofv3 prints every argument including defaulted ones, so a
-    tag matches the profile name whose argument list it is a prefix of."""
+    tools/make_profile_summary.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this bench; `config_key`: the table of
+    one of the other BASELINE configs -- tools/profile_configs.sh -- before the default one).  The library tags a launch with the template
+    arguments it chose; rocprofv3 prints every argument including defaulted ones, so a tag matches the profile name whose argument
+    list it is a prefix of."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
     if not files:
         return None
-    table = json.load(open(files[-1]))["kernels"]
-    if kernel in table:
-        return table[kernel]["hbm_bytes"]
-    base, args = _split_template(kernel)
-    hits = []
-    for name, v in table.items():
-        b, a = _split_template(name)
-        if b == base and a[:len(args)] == args:
-            hits.append(v["hbm_bytes"])
-    return hits[0] if len(hits) == 1 else None
+    doc = json.load(open(files[-1]))
+    tables = ([doc.get("configs", {}).get(config_key)] if config_key else []) + [doc["kernels"]]
+    tbase, args = _split_template(kernel)
+    base = tbase.replace("_bf16_kernel", "_kernel").replace("_split_kernel", "_kernel")
+    for table in tables:
+        if not table:
+            continue
+        if kernel in table:
+            return table[kernel]["hbm_bytes"]
+        hits = []
+        for name, v in table.items():
+            b, a = _split_template(name)
+            if b == base and a[:len(args)] == args and _variant_ok(tbase, b, a):
+                hits.append(v["hbm_bytes"])
+        if hits:
+            return max(hits)      # (several instantiations behind one tag, e.g. fps_kernel<256, 20, false|true>: the larger figure)
+    return None
 
 
 def collect_kernel_profile(lib):
@@ -341,6 +361,9 @@ def main():
             on_path = [k for k in kernels if not off_path(k)] or list(kernels)
             dom = max(on_path, key=lambda k: kernels[k]["ms"])
             split = args.dtype == "f32" and os.environ.get("MP_SA_SPLIT", "1") != "0"
+            # which table of profiles/rNN_traffic.json this run's kernels are looked up in (tools/profile_configs.sh)
+            cfg_key = (f"containers_msg_{args.dtype}" if (args.encoder == "msg" and args.category == "containers")
+                       else args.category if (args.category != "cuboids" and args.encoder == "ssg" and args.dtype == "f32") else None)
 
             def roof(k):
                 """One kernel against its roofs.  `achieved` / `peak` / `frac` price the ALGORITHMIC work per launch
@@ -358,7 +381,7 @@ def main():
                 else:
                     bound, ach, peak, unit = "hbm", nbytes / avg_s / 1e9, HBM_PEAK_GBS, "GB/s"
                 r = {"kernel": k, "bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak,
-                     "traffic": measured_traffic(k), "avg_us": avg_s * 1e6, "launches_per_step": d["calls"] / max(profiled_steps, 1),
+                     "traffic": measured_traffic(k, cfg_key), "avg_us": avg_s * 1e6, "launches_per_step": d["calls"] / max(profiled_steps, 1),
                      "flops_per_launch": flops, "bytes_per_launch": nbytes}
                 planes = 6.0 if (split and "bf16" not in k and any(t in k for t in ("fused", "chunk", "bwd_first", "gemm", "lean"))) else 1.0
                 ex_peak = BF16_PEAK_TFLOPS if (planes > 1 or "bf16" in k) else FP32_PEAK_TFLOPS

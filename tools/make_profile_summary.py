@@ -46,11 +46,29 @@ with open(f"{out}/{tag}_bench_kernel_stats.md", "w") as f:
 traffic = {}
 for k, fz in fetch.items():
     wz = write.get(k)
-    if wz is not None and any(t in k for t in ("gemm", "knn", "fps", "ball", "pool", "group", "fused", "chunk", "adam", "dw_ci4")):
+    if wz is not None and any(t in k for t in ("gemm", "knn", "fps", "ball", "pool", "group", "fused", "chunk", "adam", "dw_ci4", "first", "linear", "lean", "mask_match")):
         traffic[k.split("(")[0]] = dict(fetch_kib=fz, write_kib=wz, hbm_bytes=(2 * fz + wz) * 1024)
-json.dump(dict(source=f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes ({tag}), bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch",
-               kernels=traffic), open(f"{out}/{tag}_traffic.json", "w"), indent=1)
-print("wrote", len(traffic), "traffic entries")
+# the other BASELINE configs (tools/profile_configs.sh): one table per config key, looked up by bench.py before the default one
+configs = {}
+for d in sorted(glob.glob(f"{go}/{tag}_cfg_*_fetch")):
+    key = os.path.basename(d)[len(tag) + 5:-6]
+    def one(kind):
+        fs = glob.glob(f"{go}/{tag}_cfg_{key}_{kind}/*/*_counter_collection.csv")
+        agg = collections.defaultdict(list)
+        for r in csv.DictReader(open(max(fs, key=os.path.getmtime))) if fs else []:
+            agg[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+        return {k: sum(v) / len(v) for k, v in agg.items()}
+    cf, cw = one("fetch"), one("write")
+    tab = {}
+    for k, fz in cf.items():
+        wz = cw.get(k)
+        if wz is not None and any(t in k for t in ("gemm", "knn", "fps", "ball", "pool", "group", "fused", "chunk", "adam", "dw_ci4", "first", "linear", "lean", "mask_match", "lsap")):
+            tab[k.split("(")[0]] = dict(fetch_kib=fz, write_kib=wz, hbm_bytes=(2 * fz + wz) * 1024)
+    configs[key] = tab
+json.dump(dict(source=f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes ({tag}), bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch; "
+                      "`kernels`: the default bench (cuboids, SSG, fp32); `configs`: the same two passes over the other BASELINE configs",
+               kernels=traffic, configs=configs), open(f"{out}/{tag}_traffic.json", "w"), indent=1)
+print("wrote", len(traffic), "traffic entries,", {k: len(v) for k, v in configs.items()})
 
 # ---- MFMA utilisation of the hot grouped-MLP kernels (its own --pmc pass) ------------------------------------------------------
 import glob as _g
