@@ -1,11 +1,13 @@
 """After tools/refresh_profiles.sh <tag> has run on the GPU box and gpurun merged gpurun_out/ back: write everything under profiles/<tag>_*
 (kernel stats, traffic, MFMA utilisation, overlap, SQ counters, the bench lines) and print the headline numbers."""
 import json, os, subprocess, sys
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+lines_only = "--lines-only" in sys.argv
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.chdir(root)
-subprocess.run([sys.executable, "tools/make_profile_summary.py", tag], check=True, stdout=subprocess.DEVNULL)
-subprocess.run([sys.executable, "tools/make_overlap_summary.py", tag, f"gpurun_out/{tag}_overlap"], check=True, stdout=subprocess.DEVNULL)
+if not lines_only:
+    subprocess.run([sys.executable, "tools/make_profile_summary.py", tag], check=True, stdout=subprocess.DEVNULL)
+    subprocess.run([sys.executable, "tools/make_overlap_summary.py", tag, f"gpurun_out/{tag}_overlap"], check=True, stdout=subprocess.DEVNULL)
 
 
 def line(f):
@@ -27,6 +29,8 @@ for name, f in (("bench_line", "bench_full"), ("config3_windows", "windows"), ("
             print("   ", k, round(d[k]["value"], 1), round(d[k]["ms_per_step"], 3))
         print("    executed", {a: (round(b, 3) if isinstance(b, float) else b) for a, b in (r.get("executed") or {}).items() if a != "what"})
         print("    traffic", r.get("traffic"), "cpu", round(d["cpu_baseline"]["value"], 2), d["cpu_baseline"]["cores"])
+if lines_only:
+    sys.exit(0)
 hdr = open(f"profiles/{tag}_sq_counters.md").read().split("```")[0]
 body = open(f"gpurun_out/{tag}_pmc_hot.txt").read()
 body = body[body.index("kernel "):]
