@@ -1677,6 +1677,325 @@ __global__ __launch_bounds__(bwd_fused_threads(CO, CI, SPLIT, ONE), (CO >= 128 &
         }
 }
 
+// =================================================================================================================
+// [r3] Kernel 4b: the fused backward of the 128-input layers with the two products on DIFFERENT waves (MP_BF_ROLES; default for 256 outputs).
+// bwd_fused_kernel gives each of its eight waves a slice of both products; the 96 (256 outputs) weight-fragment registers of the dX
+// slice and the 64 accumulators of the dW slice leave no room to fetch operand fragments more than one step ahead, and the two waves
+// of a SIMD walk identical phases in lock step (tools/bwd_ablate.sh: each product costs ~1.8x its matrix-pipe time).  Here waves 0..3
+// own the dX product (32 columns each: the A fragments of the dZ chunk are read 4x per chunk instead of 8x, 12 MFMAs per fragment
+// triple instead of 6) and waves 4..7 the dW product (8 or 4 tiles each, every fragment plane fetched once): one wave of each kind
+// per SIMD.  Staging: all eight waves (128 outputs) or, where the dX waves have no registers left (256 outputs: 192 of them hold
+// weight planes), the four dW waves.  Same chunk images (row-swizzled K-packed planes), same arithmetic per product.
+// =================================================================================================================
+#ifndef MP_ROLES_SPLITSTAGE
+#define MP_ROLES_SPLITSTAGE 0       // (1: the dX waves stage the input operand -- 13 spilled registers, 203 -> 225 us)
+#endif
+#ifndef MP_ROLES_PD2
+#define MP_ROLES_PD2 0              // 256 outputs: two chunks of loads in flight in the staging (dW) waves (13 spilled registers: 205 -> 270 us)
+#endif
+#ifndef MP_ROLES_PRIO
+#define MP_ROLES_PRIO 1             // s_setprio for one kind of wave: 1 the dW (staging) waves (they are the longer chain: 204.8 -> 200.3 us), 2 the dX waves (no change)
+#endif
+template <int MODE_DZ, int CO>
+__global__ __launch_bounds__(512, 1) void bwd_roles_kernel(PosOperand DZ, PosOperand IN, int P, int p_per_block,
+                                                           const float* __restrict__ W, float* __restrict__ dW,
+                                                           float* __restrict__ G, float* __restrict__ partials)
+{
+    constexpr int CI = 128, DBK = 16, GS = DBK * 8, MODE_IN = SRC_ACT;
+    constexpr bool ALLSTAGE = CO == 128;
+    // 256 outputs: the dX waves hold 192 registers of weight planes -- they stage the (smaller) input operand only when MP_ROLES_SPLITSTAGE,
+    // the dW waves the dZ operand (or both)
+    constexpr bool SPLITSTAGE = !ALLSTAGE && MP_ROLES_SPLITSTAGE;
+    constexpr int NTS = ALLSTAGE ? 512 : 256, NWS = NTS / 64;          // staging threads / waves (per operand)
+    constexpr int NBA = CO / 64, NBB = CI / 64;
+    constexpr int PA = DBK * CO / 4 / NTS, PB = DBK * CI / 4 / NTS;
+    constexpr int KA_STEP = 4 * (NWS / NBA), KB_STEP = 4 * (NWS / NBB);
+    static_assert(PA * KA_STEP == DBK && PB * KB_STEP == DBK && (CO == 128 || CO == 256), "staging covers the chunk");
+    constexpr int NST = CO / 32;                                        // k-steps of the dX product
+    constexpr int TMW = CO / 64, TNW = 2;                               // 32 x 32 dW tiles per dW wave (waves 2 x 2 over [CO x 128])
+    __shared__ __attribute__((aligned(16))) __bf16 hA[2][3][(CO / 8) * GS];
+    __shared__ __attribute__((aligned(16))) __bf16 hB[2][3][(CI / 8) * GS];
+    __shared__ __attribute__((aligned(16))) float sZ[2][DBK * CI];
+    __shared__ float red[2][CI];
+    __shared__ float4 sKA[5][CO / 4];
+    __shared__ float4 sKB[2][CI / 4];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool role_dx = wave < 4;
+    const bool stage_a = ALLSTAGE || !role_dx;                          // this wave stages dZ rows
+    const bool stage_b = ALLSTAGE || (SPLITSTAGE ? role_dx : !role_dx); // ... input rows
+    const int p0 = blockIdx.x * p_per_block;
+    const int p1 = min(P, p0 + p_per_block);
+    const int nchunks = (p1 - p0 + DBK - 1) / DBK;
+    if (nchunks <= 0) return;
+
+    // ---- staging (16 lanes x 16 bytes per row: 256-byte global segments) --------------------------------------------------------
+    const int sw = ALLSTAGE ? wave : (wave & 3);
+    const int ca = (sw % NBA) * 64 + 4 * (lane & 15), ka0 = (sw / NBA) * 4 + (lane >> 4);
+    const int cb = (sw % NBB) * 64 + 4 * (lane & 15), kb0 = (sw / NBB) * 4 + (lane >> 4);
+    if (stage_a) {      // per-channel constants of the staging arithmetic wait in LDS between chunks
+        ChanConst ka;
+        load_consts<MODE_DZ>(DZ, ca, ka);
+        sKA[0][ca >> 2] = ka.s; sKA[1][ca >> 2] = ka.t; sKA[2][ca >> 2] = ka.a; sKA[3][ca >> 2] = ka.e; sKA[4][ca >> 2] = ka.f;
+    }
+    if (stage_b) {
+        ChanConst kb;
+        load_consts<MODE_IN>(IN, cb, kb);
+        sKB[0][cb >> 2] = kb.s; sKB[1][cb >> 2] = kb.t;
+    }
+    // dZ rows of a chunk.  Pooled layer (the host guarantees K = 2^kshift >= 16, so a chunk lies inside ONE group): the pooled gradient
+    // and the arg-max of the thread's four channels are the same for all its rows -- loaded once per chunk, not once per row
+    constexpr bool POOLED = MODE_DZ == SRC_DZ_POOLED;
+    struct RSetA {
+        Raw4<MODE_DZ> a[POOLED ? 1 : PA];       // pooled: a[0] carries (g, ak) and the chunk's first member index
+        float4 z[POOLED ? PA : 1];
+    };
+    struct RSetB { Raw4<MODE_IN> b[PB]; };
+    auto gload_a = [&](int pk, RSetA& rs) {
+        if constexpr (POOLED) {
+            const unsigned off = ((unsigned)pk >> DZ.kshift) * (unsigned)CO + (unsigned)ca;
+            rs.a[0].g = ld4(DZ.g + off);
+            rs.a[0].ak = *reinterpret_cast<const int4*>(DZ.argk + off);
+            rs.a[0].kk = pk & (DZ.K - 1);
+#pragma unroll
+            for (int ps = 0; ps < PA; ++ps) {
+                const int p = pk + ka0 + ps * KA_STEP;
+                rs.z[ps] = ld4(DZ.x + (size_t)((unsigned)(p < p1 ? p : p0) * (unsigned)CO + (unsigned)ca));
+            }
+        } else {
+#pragma unroll
+            for (int ps = 0; ps < PA; ++ps) raw_load<MODE_DZ>(DZ, p1, pk + ka0 + ps * KA_STEP, ca, rs.a[ps]);
+        }
+    };
+    auto gload_b = [&](int pk, RSetB& rs) {
+#pragma unroll
+        for (int ps = 0; ps < PB; ++ps) raw_load<MODE_IN>(IN, p1, pk + kb0 + ps * KB_STEP, cb, rs.b[ps]);
+    };
+    auto sstore_a = [&](int buf, int pk, RSetA& rs) {
+        ChanConst ka;
+        ka.s = sKA[0][ca >> 2]; ka.t = sKA[1][ca >> 2]; ka.a = sKA[2][ca >> 2]; ka.e = sKA[3][ca >> 2]; ka.f = sKA[4][ca >> 2];
+#pragma unroll
+        for (int ps = 0; ps < PA; ++ps) {
+            float4 dz;
+            if constexpr (POOLED) {
+                const int kk = rs.a[0].kk + ka0 + ps * KA_STEP;
+                const float4 z = rs.z[ps], g = rs.a[0].g;
+                const int4 ak = rs.a[0].ak;
+                dz.x = xf1<MODE_DZ>(z.x, ak.x == kk ? g.x : 0.0f, ka.s.x, ka.t.x, ka.a.x, ka.e.x, ka.f.x);
+                dz.y = xf1<MODE_DZ>(z.y, ak.y == kk ? g.y : 0.0f, ka.s.y, ka.t.y, ka.a.y, ka.e.y, ka.f.y);
+                dz.z = xf1<MODE_DZ>(z.z, ak.z == kk ? g.z : 0.0f, ka.s.z, ka.t.z, ka.a.z, ka.e.z, ka.f.z);
+                dz.w = xf1<MODE_DZ>(z.w, ak.w == kk ? g.w : 0.0f, ka.s.w, ka.t.w, ka.a.w, ka.e.w, ka.f.w);
+                if (pk + ka0 + ps * KA_STEP >= p1) dz = make_float4(0.f, 0.f, 0.f, 0.f);
+            } else {
+                dz = finish<MODE_DZ>(rs.a[ps], ka);
+            }
+            const Split4 sp = split3(dz);
+            const int o = (ca >> 3) * GS + ((ka0 + ps * KA_STEP) ^ kswz(ca >> 3)) * 8 + (ca & 7);
+            *reinterpret_cast<bf16x4*>(&hA[buf][0][o]) = sp.h;
+            *reinterpret_cast<bf16x4*>(&hA[buf][1][o]) = sp.m;
+            *reinterpret_cast<bf16x4*>(&hA[buf][2][o]) = sp.l;
+        }
+    };
+    auto sstore_b = [&](int buf, RSetB& rs) {
+        ChanConst kb;
+        kb.s = sKB[0][cb >> 2]; kb.t = sKB[1][cb >> 2];
+#pragma unroll
+        for (int ps = 0; ps < PB; ++ps) {
+            const Split4 sp = split3(finish<MODE_IN>(rs.b[ps], kb));
+            const int oh = (cb >> 3) * GS + ((kb0 + ps * KB_STEP) ^ kswz(cb >> 3)) * 8 + (cb & 7);
+            *reinterpret_cast<bf16x4*>(&hB[buf][0][oh]) = sp.h;
+            *reinterpret_cast<bf16x4*>(&hB[buf][1][oh]) = sp.m;
+            *reinterpret_cast<bf16x4*>(&hB[buf][2][oh]) = sp.l;
+            *reinterpret_cast<float4*>(&sZ[buf][(kb0 + ps * KB_STEP) * CI + cb]) = rs.b[ps].ok ? rs.b[ps].z : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    __syncthreads();                                   // the constants are in LDS
+
+    if (role_dx) {
+        // ================= waves 0..3: G_{l-1} chunk [16 x 128] = dZ [16 x CO] * W_l [CO x 128], 32 columns (two 16 x 16 tiles) per wave
+        if constexpr (MP_ROLES_PRIO == 2) __builtin_amdgcn_s_setprio(2);
+        const int l15 = lane & 15, kq = lane >> 4;
+        const int xcol0 = wave * 32;
+        bf16x8 wsp[2][NST][3];                         // lane (col, kq) holds W[32 st + 8 kq .. + 7][col] as (h, m, l) planes
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int st = 0; st < NST; ++st) {
+                const float* wp = W + (size_t)(32 * st + 8 * kq) * CI + xcol0 + 16 * h + l15;
+                const Split4 lo = split3(make_float4(wp[0], wp[CI], wp[2 * CI], wp[3 * CI]));
+                const Split4 hi = split3(make_float4(wp[4 * CI], wp[5 * CI], wp[6 * CI], wp[7 * CI]));
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    wsp[h][st][0][i] = lo.h[i]; wsp[h][st][0][4 + i] = hi.h[i];
+                    wsp[h][st][1][i] = lo.m[i]; wsp[h][st][1][4 + i] = hi.m[i];
+                    wsp[h][st][2][i] = lo.l[i]; wsp[h][st][2][4 + i] = hi.l[i];
+                }
+            }
+        float spx[2], tpx[2];
+        f2 sx1[2], sx2[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int col = xcol0 + 16 * h + l15;
+            spx[h] = IN.s[col];
+            tpx[h] = IN.t[col];
+            sx1[h] = f2{0.0f, 0.0f};
+            sx2[h] = f2{0.0f, 0.0f};
+        }
+        const __amdgpu_buffer_rsrc_t grsrc = __builtin_amdgcn_make_buffer_rsrc(G + (size_t)p0 * CI, 0, (p1 - p0) * CI * 4, 0x00020000);
+        int goff = ((4 * kq) * CI + xcol0 + l15) * 4;
+        RSetA ra_;
+        RSetB rb_;
+        if (ALLSTAGE) { gload_a(p0, ra_); sstore_a(0, p0, ra_); }
+        if (ALLSTAGE || SPLITSTAGE) { gload_b(p0, rb_); sstore_b(0, rb_); }
+        __syncthreads();
+        for (int kc = 0; kc < nchunks; ++kc) {
+            const int cur = kc & 1;
+            if (ALLSTAGE && kc + 1 < nchunks) gload_a(p0 + (kc + 1) * DBK, ra_);
+            if ((ALLSTAGE || SPLITSTAGE) && kc + 1 < nchunks) gload_b(p0 + (kc + 1) * DBK, rb_);
+            f32x4 ax[2], cx[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) { ax[h] = f32x4{0.f, 0.f, 0.f, 0.f}; cx[h] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+            const int ao = kq * GS + (l15 ^ kswz(kq)) * 8;
+            bf16x8 af[2][3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) af[0][pl] = *reinterpret_cast<const bf16x8*>(&hA[cur][pl][ao]);
+#pragma unroll
+            for (int st = 0; st < NST; ++st) {
+                if (st + 1 < NST) {
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) af[(st + 1) & 1][pl] = *reinterpret_cast<const bf16x8*>(&hA[cur][pl][ao + 4 * (st + 1) * GS]);
+                }
+                const bf16x8 ah = af[st & 1][0], am = af[st & 1][1], al = af[st & 1][2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    cx[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, wsp[h][st][0], cx[h], 0, 0, 0);
+                    ax[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wsp[h][st][0], ax[h], 0, 0, 0);
+                    cx[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wsp[h][st][2], cx[h], 0, 0, 0);
+                    cx[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, wsp[h][st][1], cx[h], 0, 0, 0);
+                    cx[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, wsp[h][st][0], cx[h], 0, 0, 0);
+                    cx[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wsp[h][st][1], cx[h], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                ax[h] += cx[h];
+                const float* zr = sZ[cur] + (4 * kq) * CI + xcol0 + 16 * h + l15;
+#pragma unroll
+                for (int i = 0; i < 4; i += 2) {
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ax[h][i]), grsrc, goff + 16 * h * 4, i * CI * 4, MP_STORE_AUX);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ax[h][i + 1]), grsrc, goff + 16 * h * 4, (i + 1) * CI * 4, MP_STORE_AUX);
+                    const f2 zp = {zr[i * CI], zr[(i + 1) * CI]};
+                    const f2 y = zp * f2{spx[h], spx[h]} + f2{tpx[h], tpx[h]};
+                    const f2 dy = {y.x > 0.0f ? ax[h][i] : 0.0f, y.y > 0.0f ? ax[h][i + 1] : 0.0f};
+                    sx1[h] += dy;
+                    sx2[h] += dy * zp;
+                }
+            }
+            goff += DBK * CI * 4;
+            if (ALLSTAGE && kc + 1 < nchunks) sstore_a(cur ^ 1, p0 + (kc + 1) * DBK, ra_);
+            if ((ALLSTAGE || SPLITSTAGE) && kc + 1 < nchunks) sstore_b(cur ^ 1, rb_);
+            __syncthreads();
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {       // BatchNorm-backward partial sums of layer l-1: the four 16-lane row groups of the wave
+            float s1x = sx1[h].x + sx1[h].y, s2x = sx2[h].x + sx2[h].y;
+            s1x += __shfl_xor(s1x, 16, 64); s1x += __shfl_xor(s1x, 32, 64);
+            s2x += __shfl_xor(s2x, 16, 64); s2x += __shfl_xor(s2x, 32, 64);
+            if (lane < 16) {
+                red[0][xcol0 + 16 * h + lane] = s1x;
+                red[1][xcol0 + 16 * h + lane] = s2x;
+            }
+        }
+    } else {
+        // ================= waves 4..7: dW [CO x 128] += dZ^T * act(Z_{l-1}), one k-step of 16 positions per chunk, TMW x 2 tiles per wave
+        if constexpr (MP_ROLES_PRIO == 1) __builtin_amdgcn_s_setprio(2);
+        const int w = wave - 4, l31 = lane & 31;
+        const int wrow0 = (w >> 1) * (CO / 2), wcol0 = (w & 1) * 64;
+        f32x16 accW[TMW][TNW];
+#pragma unroll
+        for (int mi = 0; mi < TMW; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < TNW; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) accW[mi][ni][r] = 0.0f;
+        constexpr bool PD2R = MP_ROLES_PD2 && !ALLSTAGE && !SPLITSTAGE;     // two register sets, the loop unrolled by two (as bwd_fused_kernel's PD2)
+        RSetA ra0, ra1;
+        RSetB rb0, rb1;
+        auto gload = [&](int pk, RSetA& ra_, RSetB& rb_) { gload_a(pk, ra_); if (!SPLITSTAGE) gload_b(pk, rb_); };
+        auto sstore = [&](int buf, int pk, RSetA& ra_, RSetB& rb_) { sstore_a(buf, pk, ra_); if (!SPLITSTAGE) sstore_b(buf, rb_); };
+        gload(p0, ra0, rb0);
+        sstore(0, p0, ra0, rb0);
+        if constexpr (PD2R) {
+            if (nchunks > 1) gload(p0 + DBK, ra0, rb0);
+            if (nchunks > 2) gload(p0 + 2 * DBK, ra1, rb1);
+        }
+        __syncthreads();
+        auto body = [&](const int kc, RSetA& ra_, RSetB& rb_) {        // (ra_, rb_) hold chunk kc + 1
+            const int cur = kc & 1;
+            if (!PD2R && kc + 1 < nchunks) gload(p0 + (kc + 1) * DBK, ra_, rb_);
+            // fragments in the order they are consumed (one dZ plane live at a time): l*h, h*l, h*m, h*h, m*m, m*h
+            bf16x8 fb[3][TNW], fa[TMW];
+#pragma unroll
+            for (int ni = 0; ni < TNW; ++ni) fb[0][ni] = tr_frag_packed<GS, true>(hB[cur][0], 0, wcol0 + ni * 32);
+#pragma unroll
+            for (int mi = 0; mi < TMW; ++mi) fa[mi] = tr_frag_packed<GS, true>(hA[cur][2], 0, wrow0 + mi * 32);
+#pragma unroll
+            for (int mi = 0; mi < TMW; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < TNW; ++ni) accW[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mi], fb[0][ni], accW[mi][ni], 0, 0, 0);
+#pragma unroll
+            for (int mi = 0; mi < TMW; ++mi) fa[mi] = tr_frag_packed<GS, true>(hA[cur][0], 0, wrow0 + mi * 32);
+#pragma unroll
+            for (int pl = 2; pl >= 1; --pl)
+#pragma unroll
+                for (int ni = 0; ni < TNW; ++ni) fb[pl][ni] = tr_frag_packed<GS, true>(hB[cur][pl], 0, wcol0 + ni * 32);
+#pragma unroll
+            for (int pl = 2; pl >= 0; --pl)
+#pragma unroll
+                for (int mi = 0; mi < TMW; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < TNW; ++ni) accW[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mi], fb[pl][ni], accW[mi][ni], 0, 0, 0);
+#pragma unroll
+            for (int mi = 0; mi < TMW; ++mi) fa[mi] = tr_frag_packed<GS, true>(hA[cur][1], 0, wrow0 + mi * 32);
+#pragma unroll
+            for (int pl = 1; pl >= 0; --pl)
+#pragma unroll
+                for (int mi = 0; mi < TMW; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < TNW; ++ni) accW[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mi], fb[pl][ni], accW[mi][ni], 0, 0, 0);
+            if (kc + 1 < nchunks) sstore(cur ^ 1, p0 + (kc + 1) * DBK, ra_, rb_);
+            if (PD2R && kc + 3 < nchunks) gload(p0 + (kc + 3) * DBK, ra_, rb_);
+            __syncthreads();
+        };
+        if constexpr (PD2R) {
+            for (int kc = 0; kc < nchunks; kc += 2) {
+                body(kc, ra0, rb0);
+                if (kc + 1 < nchunks) body(kc + 1, ra1, rb1);
+            }
+        } else {
+            for (int kc = 0; kc < nchunks; ++kc) body(kc, ra0, rb0);
+        }
+#pragma unroll
+        for (int mi = 0; mi < TMW; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < TNW; ++ni) {
+                const int col = wcol0 + ni * 32 + l31;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = wrow0 + mi * 32 + acc_row_in_tile(r);
+                    atomicAdd(dW + (size_t)(row * CI + col), accW[mi][ni][r]);
+                }
+            }
+    }
+    __syncthreads();
+    for (int e = tid; e < 2 * CI; e += 512) {
+        const int st = e / CI, c = e - st * CI;
+        partials[((size_t)blockIdx.x * 2 + st) * CI + c] = red[st][c];
+    }
+}
+
 // BatchNorm statistics of a RECOMPUTED first layer (SRC_*_RC): per workgroup the sums of z and z^2 of its positions, in the
 // partials layout of the GEMM epilogues ([block][2][C]) -- the layer's forward pass is this kernel and nothing else.
 // A wave loads 64 input rows with one coalesced access (lane i: position base + i) and every lane (= channel) walks them
@@ -2363,6 +2682,16 @@ inline bool chunk_fwd_enabled()
 {
     static const bool on = !(getenv("MP_CHUNK_FWD") && atoi(getenv("MP_CHUNK_FWD")) == 0);
     return on;
+}
+
+// MP_BF_ROLES (bit mask; bit 0: the 256-output layer, bit 1: 128 -> 128): the fused backward with dX and dW on different waves (bwd_roles_kernel)
+#ifndef MP_BF_ROLES_DEFAULT
+#define MP_BF_ROLES_DEFAULT 1       // the 256-output layer: 248 -> 212 us (slow box) / 235 -> 200; 128 -> 128: 127 -> 132, stays on bwd_fused_kernel
+#endif
+inline int roles_mask()
+{
+    static const int m = getenv("MP_BF_ROLES") ? atoi(getenv("MP_BF_ROLES")) : MP_BF_ROLES_DEFAULT;
+    return m;
 }
 
 // MP_FUSED_BWD=0 keeps the separate dX / dW kernels for the single-tile layers (A/B timing)
@@ -3173,6 +3502,13 @@ static int sa_mlp_bwd(const float* x0, int64_t P, int64_t K, int n_layers, const
                 else
                     MP_LAUNCH(tg, fl, by - 4.0 * (double)P * (Ci - 4), (bwd_fused_kernel<SRC_DZ, 128, 64, SRC_ACT_RC>), dim3(gx), dim3(256), 0, stream, DZ, IN,
                               (int)P, ppb, Ly.weight, grads[l].d_weight, Gn, partials);
+            } else if (!bf16 && split_enabled() && Ci == 128 && (Co == 256 || Co == 128) && ((roles_mask() >> (Co == 256 ? 0 : 1)) & 1) &&
+                       (!pooled || (DZ.kshift >= 4 && ppb % 16 == 0))) {
+                // [r3] the two products on different waves (bwd_roles_kernel; MP_BF_ROLES bit 0: 256 outputs, bit 1: 128)
+                if (Co == 256 && pooled) MP_LAUNCH(tg, fl, by, (bwd_roles_kernel<SRC_DZ_POOLED, 256>), dim3(gx), dim3(512), 0, stream, DZ, IN, (int)P, ppb, Ly.weight, grads[l].d_weight, Gn, partials);
+                else if (Co == 256) MP_LAUNCH(tg, fl, by, (bwd_roles_kernel<SRC_DZ, 256>), dim3(gx), dim3(512), 0, stream, DZ, IN, (int)P, ppb, Ly.weight, grads[l].d_weight, Gn, partials);
+                else if (pooled) MP_LAUNCH(tg, fl, by, (bwd_roles_kernel<SRC_DZ_POOLED, 128>), dim3(gx), dim3(512), 0, stream, DZ, IN, (int)P, ppb, Ly.weight, grads[l].d_weight, Gn, partials);
+                else MP_LAUNCH(tg, fl, by, (bwd_roles_kernel<SRC_DZ, 128>), dim3(gx), dim3(512), 0, stream, DZ, IN, (int)P, ppb, Ly.weight, grads[l].d_weight, Gn, partials);
             } else if (Co == 256) {
                 if (pooled) { MP_FUSED(SRC_DZ_POOLED, 256, 128); } else { MP_FUSED(SRC_DZ, 256, 128); }
             } else if (pooled) {
