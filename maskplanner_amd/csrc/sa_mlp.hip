@@ -1696,6 +1696,19 @@ __global__ __launch_bounds__(bwd_fused_threads(CO, CI, SPLIT, ONE), (CO >= 128 &
 #ifndef MP_ROLES_PRIO
 #define MP_ROLES_PRIO 1             // s_setprio for one kind of wave: 1 the dW (staging) waves (they are the longer chain: 204.8 -> 200.3 us), 2 the dX waves (no change)
 #endif
+// -DMP_ROLES_TIMING: per-phase s_memtime sums of bwd_roles_kernel (tools/roles_timing.sh): [kind: 0 dX wave, 1 dW wave][phase] in shader cycles,
+// summed over all waves of a launch; mp_debug_roles_times() copies and clears them.  phases dX: 0 fragment loop + MFMAs, 1 epilogue, 2 barrier wait,
+// 3 whole loop; dW: 0 fragment reads + MFMAs, 1 staging, 2 barrier wait, 3 whole loop, 4 the gload issue
+#ifdef MP_ROLES_TIMING
+__device__ unsigned long long g_roles_t[2][8];
+#define RT_DECL unsigned long long rt_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long rt0_ = __builtin_readcyclecounter(), rtl_ = rt0_
+#define RT_MARK(i) { const unsigned long long n_ = __builtin_readcyclecounter(); rt_[i] += n_ - rtl_; rtl_ = n_; }
+#define RT_FLUSH(kind) { rt_[3] = __builtin_readcyclecounter() - rt0_; if (lane == 0) { for (int i_ = 0; i_ < 8; ++i_) atomicAdd(&g_roles_t[kind][i_], rt_[i_]); } }
+#else
+#define RT_DECL
+#define RT_MARK(i)
+#define RT_FLUSH(kind)
+#endif
 template <int MODE_DZ, int CO>
 __global__ __launch_bounds__(512, 1) void bwd_roles_kernel(PosOperand DZ, PosOperand IN, int P, int p_per_block,
                                                            const float* __restrict__ W, float* __restrict__ dW,
@@ -1850,8 +1863,10 @@ __global__ __launch_bounds__(512, 1) void bwd_roles_kernel(PosOperand DZ, PosOpe
         if (ALLSTAGE) { gload_a(p0, ra_); sstore_a(0, p0, ra_); }
         if (ALLSTAGE || SPLITSTAGE) { gload_b(p0, rb_); sstore_b(0, rb_); }
         __syncthreads();
+        RT_DECL;
         for (int kc = 0; kc < nchunks; ++kc) {
             const int cur = kc & 1;
+            RT_MARK(5);
             if (ALLSTAGE && kc + 1 < nchunks) gload_a(p0 + (kc + 1) * DBK, ra_);
             if ((ALLSTAGE || SPLITSTAGE) && kc + 1 < nchunks) gload_b(p0 + (kc + 1) * DBK, rb_);
             f32x4 ax[2], cx[2];
@@ -1878,6 +1893,7 @@ __global__ __launch_bounds__(512, 1) void bwd_roles_kernel(PosOperand DZ, PosOpe
                     cx[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wsp[h][st][1], cx[h], 0, 0, 0);
                 }
             }
+            RT_MARK(0);
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 ax[h] += cx[h];
@@ -1894,10 +1910,14 @@ __global__ __launch_bounds__(512, 1) void bwd_roles_kernel(PosOperand DZ, PosOpe
                 }
             }
             goff += DBK * CI * 4;
+            RT_MARK(1);
             if (ALLSTAGE && kc + 1 < nchunks) sstore_a(cur ^ 1, p0 + (kc + 1) * DBK, ra_);
             if ((ALLSTAGE || SPLITSTAGE) && kc + 1 < nchunks) sstore_b(cur ^ 1, rb_);
+            RT_MARK(4);
             __syncthreads();
+            RT_MARK(2);
         }
+        RT_FLUSH(0);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {       // BatchNorm-backward partial sums of layer l-1: the four 16-lane row groups of the wave
             float s1x = sx1[h].x + sx1[h].y, s2x = sx2[h].x + sx2[h].y;
@@ -1932,9 +1952,12 @@ __global__ __launch_bounds__(512, 1) void bwd_roles_kernel(PosOperand DZ, PosOpe
             if (nchunks > 2) gload(p0 + 2 * DBK, ra1, rb1);
         }
         __syncthreads();
+        RT_DECL;
         auto body = [&](const int kc, RSetA& ra_, RSetB& rb_) {        // (ra_, rb_) hold chunk kc + 1
             const int cur = kc & 1;
+            RT_MARK(5);
             if (!PD2R && kc + 1 < nchunks) gload(p0 + (kc + 1) * DBK, ra_, rb_);
+            RT_MARK(4);
             // fragments in the order they are consumed (one dZ plane live at a time): l*h, h*l, h*m, h*h, m*m, m*h
             bf16x8 fb[3][TNW], fa[TMW];
 #pragma unroll
@@ -1965,9 +1988,12 @@ __global__ __launch_bounds__(512, 1) void bwd_roles_kernel(PosOperand DZ, PosOpe
                 for (int mi = 0; mi < TMW; ++mi)
 #pragma unroll
                     for (int ni = 0; ni < TNW; ++ni) accW[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mi], fb[pl][ni], accW[mi][ni], 0, 0, 0);
+            RT_MARK(0);
             if (kc + 1 < nchunks) sstore(cur ^ 1, p0 + (kc + 1) * DBK, ra_, rb_);
             if (PD2R && kc + 3 < nchunks) gload(p0 + (kc + 3) * DBK, ra_, rb_);
+            RT_MARK(1);
             __syncthreads();
+            RT_MARK(2);
         };
         if constexpr (PD2R) {
             for (int kc = 0; kc < nchunks; kc += 2) {
@@ -1976,6 +2002,293 @@ __global__ __launch_bounds__(512, 1) void bwd_roles_kernel(PosOperand DZ, PosOpe
             }
         } else {
             for (int kc = 0; kc < nchunks; ++kc) body(kc, ra0, rb0);
+        }
+        RT_FLUSH(1);
+#pragma unroll
+        for (int mi = 0; mi < TMW; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < TNW; ++ni) {
+                const int col = wcol0 + ni * 32 + l31;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = wrow0 + mi * 32 + acc_row_in_tile(r);
+                    atomicAdd(dW + (size_t)(row * CI + col), accW[mi][ni][r]);
+                }
+            }
+    }
+    __syncthreads();
+    for (int e = tid; e < 2 * CI; e += 512) {
+        const int st = e / CI, c = e - st * CI;
+        partials[((size_t)blockIdx.x * 2 + st) * CI + c] = red[st][c];
+    }
+}
+
+// [r3] Kernel 4c (experiment, MP_BF_ROLES_LDS = RS): bwd_roles_kernel<SRC_DZ_POOLED, 256> with the chunk's raw rows loaded STRAIGHT INTO LDS
+// (global_load_lds_dwordx4: 64 lanes x 16 bytes = one 1 KB row of Z_l, or two 512-byte rows of Z_{l-1}, per instruction) by the dX
+// waves, which have issue slots to spare but no registers: nothing of a chunk waits in registers any more, loads are in flight for
+// RS - 1 iterations (RS raw buffers of the dZ operand, RS + 1 of the input operand, which the dX epilogue reads one iteration after the
+// staging), and the staging (dW) waves only transform LDS -> LDS.  vmcnt is in order (loads and stores alike): before the chunk's
+// barrier a dX wave waits until everything up to the loads of chunk kc + 2 has landed, i.e. vmcnt(8 stores [+ 6 loads + 8 stores]).
+// 16 bytes per lane from global memory straight into LDS: lane i's data lands at lds_dst + 16 i (lds_dst wave-uniform: it travels in M0).
+// Inline assembly on purpose: the compiler does not see the instruction, so it neither counts it in the s_waitcnt it inserts (its own waits
+// stay sufficient: vmcnt is in order, an unknown operation in the queue only makes them wait longer) nor drains the queue before every LDS
+// read that might alias the destination (with __builtin_amdgcn_global_load_lds it put s_waitcnt vmcnt(0) in front of the epilogue's reads
+// of the buffer two stages away).  The caller orders it with explicit s_waitcnt vmcnt(N) + a barrier.
+__device__ __forceinline__ void load_lds16(const float* src, float* lds_dst)
+{
+    const unsigned l = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)lds_dst);
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(l) : "memory");
+}
+
+template <int RS>
+__global__ __launch_bounds__(512, 1) void bwd_roles_lds_kernel(PosOperand DZ, PosOperand IN, int P, int p_per_block,
+                                                               const float* __restrict__ W, float* __restrict__ dW,
+                                                               float* __restrict__ G, float* __restrict__ partials)
+{
+    constexpr int CO = 256, CI = 128, DBK = 16, GS = DBK * 8, NST = CO / 32, TMW = 4, TNW = 2;
+    constexpr int PA = 4, PB = 2, KA_STEP = 4, KB_STEP = 8;             // staging by the four dW waves
+    constexpr int MODE_DZ = SRC_DZ_POOLED, MODE_IN = SRC_ACT;
+    static_assert(RS == 2 || RS == 3, "raw stages");
+    __shared__ __attribute__((aligned(16))) __bf16 hA[2][3][(CO / 8) * GS];
+    __shared__ __attribute__((aligned(16))) __bf16 hB[2][3][(CI / 8) * GS];
+    __shared__ __attribute__((aligned(16))) float rawZ[RS][DBK * CO];
+    __shared__ __attribute__((aligned(16))) float rawI[RS + 1][DBK * CI];
+    __shared__ float red[2][CI];
+    __shared__ float4 sKA[5][CO / 4];
+    __shared__ float4 sKB[2][CI / 4];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool role_dx = wave < 4;
+    const int p0 = blockIdx.x * p_per_block;
+    const int p1 = min(P, p0 + p_per_block);
+    const int nchunks = (p1 - p0 + DBK - 1) / DBK;
+    if (nchunks <= 0) return;
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    constexpr int VM_STEADY = 8 + (RS - 2) * (6 + 8);                   // operations a dX wave issues behind the loads it waits for
+    constexpr int WAIT_STEADY = (VM_STEADY & 15) | (7 << 4) | (15 << 8) | ((VM_STEADY >> 4) << 14);   // s_waitcnt vmcnt(VM_STEADY) only
+    constexpr int WAIT_ALL = (0 & 15) | (7 << 4) | (15 << 8) | (0 << 14);                            // s_waitcnt vmcnt(0)
+
+    if (role_dx) {
+        // ================= waves 0..3: loads of the raw chunks into LDS; G_{l-1} chunk = dZ * W_l, 32 columns per wave ==============
+        const int l15 = lane & 15, kq = lane >> 4;
+        const int xcol0 = wave * 32;
+        auto issue = [&](int c) {      // chunk c -> rawZ[c % RS], rawI[c % (RS + 1)]; rows past the end re-read row p0 (staged as zeros)
+            const int pk = p0 + c * DBK;
+            float* dz = rawZ[c % RS];
+            float* di = rawI[c % (RS + 1)];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = wave + 4 * j, pr = pk + r;
+                const float* src = DZ.x + (size_t)((unsigned)(pr < p1 ? pr : p0) * (unsigned)CO) + lane * 4;
+                load_lds16(src, dz + r * CO);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int r2 = 2 * (wave + 4 * j), pr = pk + r2 + (lane >> 5);
+                const float* src = IN.x + (size_t)((unsigned)(pr < p1 ? pr : p0) * (unsigned)CI) + (lane & 31) * 4;
+                load_lds16(src, di + r2 * CI);
+            }
+        };
+#pragma unroll
+        for (int c = 0; c < RS; ++c)
+            if (c < nchunks) issue(c);
+        bf16x8 wsp[2][NST][3];                         // lane (col, kq) holds W[32 st + 8 kq .. + 7][col] as (h, m, l) planes
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int st = 0; st < NST; ++st) {
+                const float* wp = W + (size_t)(32 * st + 8 * kq) * CI + xcol0 + 16 * h + l15;
+                const Split4 lo = split3(make_float4(wp[0], wp[CI], wp[2 * CI], wp[3 * CI]));
+                const Split4 hi = split3(make_float4(wp[4 * CI], wp[5 * CI], wp[6 * CI], wp[7 * CI]));
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    wsp[h][st][0][i] = lo.h[i]; wsp[h][st][0][4 + i] = hi.h[i];
+                    wsp[h][st][1][i] = lo.m[i]; wsp[h][st][1][4 + i] = hi.m[i];
+                    wsp[h][st][2][i] = lo.l[i]; wsp[h][st][2][4 + i] = hi.l[i];
+                }
+            }
+        float spx[2], tpx[2];
+        f2 sx1[2], sx2[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int col = xcol0 + 16 * h + l15;
+            spx[h] = IN.s[col];
+            tpx[h] = IN.t[col];
+            sx1[h] = f2{0.0f, 0.0f};
+            sx2[h] = f2{0.0f, 0.0f};
+        }
+        const __amdgpu_buffer_rsrc_t grsrc = __builtin_amdgcn_make_buffer_rsrc(G + (size_t)p0 * CI, 0, (p1 - p0) * CI * 4, 0x00020000);
+        int goff = ((4 * kq) * CI + xcol0 + l15) * 4;
+        __builtin_amdgcn_s_waitcnt(WAIT_ALL);          // the first RS chunks have landed
+        __syncthreads();                               // B0: raw chunks 0 .. RS-1 + the staging constants
+        __syncthreads();                               // B1: chunk 0 staged
+        for (int kc = 0; kc < nchunks; ++kc) {
+            const int cur = kc & 1;
+            const bool more = kc + RS < nchunks;
+            if (more) issue(kc + RS);
+            f32x4 ax[2], cx[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) { ax[h] = f32x4{0.f, 0.f, 0.f, 0.f}; cx[h] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+            const int ao = kq * GS + (l15 ^ kswz(kq)) * 8;
+            bf16x8 af[2][3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) af[0][pl] = *reinterpret_cast<const bf16x8*>(&hA[cur][pl][ao]);
+#pragma unroll
+            for (int st = 0; st < NST; ++st) {
+                if (st + 1 < NST) {
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) af[(st + 1) & 1][pl] = *reinterpret_cast<const bf16x8*>(&hA[cur][pl][ao + 4 * (st + 1) * GS]);
+                }
+                const bf16x8 ah = af[st & 1][0], am = af[st & 1][1], al = af[st & 1][2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    cx[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, wsp[h][st][0], cx[h], 0, 0, 0);
+                    ax[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wsp[h][st][0], ax[h], 0, 0, 0);
+                    cx[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wsp[h][st][2], cx[h], 0, 0, 0);
+                    cx[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, wsp[h][st][1], cx[h], 0, 0, 0);
+                    cx[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, wsp[h][st][0], cx[h], 0, 0, 0);
+                    cx[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wsp[h][st][1], cx[h], 0, 0, 0);
+                }
+            }
+            const float* zi = rawI[kc % (RS + 1)];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                ax[h] += cx[h];
+                const float* zr = zi + (4 * kq) * CI + xcol0 + 16 * h + l15;
+#pragma unroll
+                for (int i = 0; i < 4; i += 2) {
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ax[h][i]), grsrc, goff + 16 * h * 4, i * CI * 4, MP_STORE_AUX);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ax[h][i + 1]), grsrc, goff + 16 * h * 4, (i + 1) * CI * 4, MP_STORE_AUX);
+                    const f2 zp = {zr[i * CI], zr[(i + 1) * CI]};
+                    const f2 y = zp * f2{spx[h], spx[h]} + f2{tpx[h], tpx[h]};
+                    const f2 dy = {y.x > 0.0f ? ax[h][i] : 0.0f, y.y > 0.0f ? ax[h][i + 1] : 0.0f};
+                    sx1[h] += dy;
+                    sx2[h] += dy * zp;
+                }
+            }
+            goff += DBK * CI * 4;
+            // chunk kc + 2 is staged during the next iteration: its rows must be in LDS behind this barrier
+            if (more) __builtin_amdgcn_s_waitcnt(WAIT_STEADY); else __builtin_amdgcn_s_waitcnt(WAIT_ALL);
+            __syncthreads();
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            float s1x = sx1[h].x + sx1[h].y, s2x = sx2[h].x + sx2[h].y;
+            s1x += __shfl_xor(s1x, 16, 64); s1x += __shfl_xor(s1x, 32, 64);
+            s2x += __shfl_xor(s2x, 16, 64); s2x += __shfl_xor(s2x, 32, 64);
+            if (lane < 16) {
+                red[0][xcol0 + 16 * h + lane] = s1x;
+                red[1][xcol0 + 16 * h + lane] = s2x;
+            }
+        }
+    } else {
+        // ================= waves 4..7: staging LDS -> LDS and dW [256 x 128] += dZ^T * act(Z_{l-1}) ================================
+        if constexpr (MP_ROLES_PRIO == 1) __builtin_amdgcn_s_setprio(2);
+        const int w = wave - 4, l31 = lane & 31;
+        const int wrow0 = (w >> 1) * (CO / 2), wcol0 = (w & 1) * 64;
+        const int ca = w * 64 + 4 * (lane & 15), ka0 = lane >> 4;
+        const int cb = (w & 1) * 64 + 4 * (lane & 15), kb0 = (w >> 1) * 4 + (lane >> 4);
+        {
+            ChanConst ka, kb;
+            load_consts<MODE_DZ>(DZ, ca, ka);
+            load_consts<MODE_IN>(IN, cb, kb);
+            sKA[0][ca >> 2] = ka.s; sKA[1][ca >> 2] = ka.t; sKA[2][ca >> 2] = ka.a; sKA[3][ca >> 2] = ka.e; sKA[4][ca >> 2] = ka.f;
+            sKB[0][cb >> 2] = kb.s; sKB[1][cb >> 2] = kb.t;
+        }
+        f32x16 accW[TMW][TNW];
+#pragma unroll
+        for (int mi = 0; mi < TMW; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < TNW; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) accW[mi][ni][r] = 0.0f;
+        float4 pg;          // pooled gradient / arg-max of this thread's four channels for the chunk that is staged next (one group per chunk)
+        int4 pak;
+        auto gload_g = [&](int c) {
+            const unsigned off = ((unsigned)(p0 + c * DBK) >> DZ.kshift) * (unsigned)CO + (unsigned)ca;
+            pg = ld4(DZ.g + off);
+            pak = *reinterpret_cast<const int4*>(DZ.argk + off);
+        };
+        auto stage = [&](int c) {      // raw chunk c (LDS) -> plane buffer c & 1
+            const int buf = c & 1, pk = p0 + c * DBK;
+            const float* rz = rawZ[c % RS];
+            const float* ri = rawI[c % (RS + 1)];
+            ChanConst ka, kb;
+            ka.s = sKA[0][ca >> 2]; ka.t = sKA[1][ca >> 2]; ka.a = sKA[2][ca >> 2]; ka.e = sKA[3][ca >> 2]; ka.f = sKA[4][ca >> 2];
+            kb.s = sKB[0][cb >> 2]; kb.t = sKB[1][cb >> 2];
+            const int kk0 = pk & (DZ.K - 1);
+#pragma unroll
+            for (int ps = 0; ps < PA; ++ps) {
+                const int row = ka0 + ps * KA_STEP, kk = kk0 + row;
+                const float4 z = *reinterpret_cast<const float4*>(rz + row * CO + ca);
+                float4 dz;
+                dz.x = xf1<MODE_DZ>(z.x, pak.x == kk ? pg.x : 0.0f, ka.s.x, ka.t.x, ka.a.x, ka.e.x, ka.f.x);
+                dz.y = xf1<MODE_DZ>(z.y, pak.y == kk ? pg.y : 0.0f, ka.s.y, ka.t.y, ka.a.y, ka.e.y, ka.f.y);
+                dz.z = xf1<MODE_DZ>(z.z, pak.z == kk ? pg.z : 0.0f, ka.s.z, ka.t.z, ka.a.z, ka.e.z, ka.f.z);
+                dz.w = xf1<MODE_DZ>(z.w, pak.w == kk ? pg.w : 0.0f, ka.s.w, ka.t.w, ka.a.w, ka.e.w, ka.f.w);
+                if (pk + row >= p1) dz = make_float4(0.f, 0.f, 0.f, 0.f);
+                const Split4 sp = split3(dz);
+                const int o = (ca >> 3) * GS + (row ^ kswz(ca >> 3)) * 8 + (ca & 7);
+                *reinterpret_cast<bf16x4*>(&hA[buf][0][o]) = sp.h;
+                *reinterpret_cast<bf16x4*>(&hA[buf][1][o]) = sp.m;
+                *reinterpret_cast<bf16x4*>(&hA[buf][2][o]) = sp.l;
+            }
+#pragma unroll
+            for (int ps = 0; ps < PB; ++ps) {
+                const int row = kb0 + ps * KB_STEP;
+                const float4 z = *reinterpret_cast<const float4*>(ri + row * CI + cb);
+                float4 a;
+                a.x = xf1<MODE_IN>(z.x, 0.f, kb.s.x, kb.t.x, 0.f, 0.f, 0.f);
+                a.y = xf1<MODE_IN>(z.y, 0.f, kb.s.y, kb.t.y, 0.f, 0.f, 0.f);
+                a.z = xf1<MODE_IN>(z.z, 0.f, kb.s.z, kb.t.z, 0.f, 0.f, 0.f);
+                a.w = xf1<MODE_IN>(z.w, 0.f, kb.s.w, kb.t.w, 0.f, 0.f, 0.f);
+                if (pk + row >= p1) a = make_float4(0.f, 0.f, 0.f, 0.f);
+                const Split4 sp = split3(a);
+                const int oh = (cb >> 3) * GS + (row ^ kswz(cb >> 3)) * 8 + (cb & 7);
+                *reinterpret_cast<bf16x4*>(&hB[buf][0][oh]) = sp.h;
+                *reinterpret_cast<bf16x4*>(&hB[buf][1][oh]) = sp.m;
+                *reinterpret_cast<bf16x4*>(&hB[buf][2][oh]) = sp.l;
+            }
+        };
+        gload_g(0);
+        __syncthreads();                               // B0
+        stage(0);
+        __syncthreads();                               // B1
+        for (int kc = 0; kc < nchunks; ++kc) {
+            const int cur = kc & 1;
+            if (kc + 1 < nchunks) gload_g(kc + 1);
+            bf16x8 fb[3][TNW], fa[TMW];
+#pragma unroll
+            for (int ni = 0; ni < TNW; ++ni) fb[0][ni] = tr_frag_packed<GS, true>(hB[cur][0], 0, wcol0 + ni * 32);
+#pragma unroll
+            for (int mi = 0; mi < TMW; ++mi) fa[mi] = tr_frag_packed<GS, true>(hA[cur][2], 0, wrow0 + mi * 32);
+#pragma unroll
+            for (int mi = 0; mi < TMW; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < TNW; ++ni) accW[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mi], fb[0][ni], accW[mi][ni], 0, 0, 0);
+#pragma unroll
+            for (int mi = 0; mi < TMW; ++mi) fa[mi] = tr_frag_packed<GS, true>(hA[cur][0], 0, wrow0 + mi * 32);
+#pragma unroll
+            for (int pl = 2; pl >= 1; --pl)
+#pragma unroll
+                for (int ni = 0; ni < TNW; ++ni) fb[pl][ni] = tr_frag_packed<GS, true>(hB[cur][pl], 0, wcol0 + ni * 32);
+#pragma unroll
+            for (int pl = 2; pl >= 0; --pl)
+#pragma unroll
+                for (int mi = 0; mi < TMW; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < TNW; ++ni) accW[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mi], fb[pl][ni], accW[mi][ni], 0, 0, 0);
+#pragma unroll
+            for (int mi = 0; mi < TMW; ++mi) fa[mi] = tr_frag_packed<GS, true>(hA[cur][1], 0, wrow0 + mi * 32);
+#pragma unroll
+            for (int pl = 1; pl >= 0; --pl)
+#pragma unroll
+                for (int mi = 0; mi < TMW; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < TNW; ++ni) accW[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mi], fb[pl][ni], accW[mi][ni], 0, 0, 0);
+            if (kc + 1 < nchunks) stage(kc + 1);
+            __syncthreads();
         }
 #pragma unroll
         for (int mi = 0; mi < TMW; ++mi)
@@ -2694,6 +3007,16 @@ inline int roles_mask()
     return m;
 }
 
+// MP_BF_ROLES_LDS = 2 | 3: the role-split kernel of the pooled 256-output layer with its raw chunks loaded straight into LDS (bwd_roles_lds_kernel<RS>)
+#ifndef MP_BF_ROLES_LDS_DEFAULT
+#define MP_BF_ROLES_LDS_DEFAULT 0
+#endif
+inline int roles_lds()
+{
+    static const int m = getenv("MP_BF_ROLES_LDS") ? atoi(getenv("MP_BF_ROLES_LDS")) : MP_BF_ROLES_LDS_DEFAULT;
+    return m;
+}
+
 // MP_FUSED_BWD=0 keeps the separate dX / dW kernels for the single-tile layers (A/B timing)
 inline bool fused_bwd_enabled()
 {
@@ -2706,6 +3029,15 @@ inline bool fused_bwd_enabled()
 // ---------------------------------------------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------------------------------------------
+#ifdef MP_ROLES_TIMING
+extern "C" int mp_debug_roles_times(unsigned long long* host_out)      // [2][8] cycle sums since the last call (timing builds only)
+{
+    unsigned long long z[16] = {0};
+    if (hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_roles_t), sizeof z) != hipSuccess) return MP_ELAUNCH;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_roles_t), z, sizeof z) == hipSuccess ? MP_OK : MP_ELAUNCH;
+}
+#endif
+
 extern "C" size_t mp_sa_mlp_workspace_bytes(int64_t P, int64_t K, int n_layers, const int64_t* channels, int backward)
 {
     if (P <= 0 || n_layers <= 0 || !channels) return 0;
@@ -3505,7 +3837,9 @@ static int sa_mlp_bwd(const float* x0, int64_t P, int64_t K, int n_layers, const
             } else if (!bf16 && split_enabled() && Ci == 128 && (Co == 256 || Co == 128) && ((roles_mask() >> (Co == 256 ? 0 : 1)) & 1) &&
                        (!pooled || (DZ.kshift >= 4 && ppb % 16 == 0))) {
                 // [r3] the two products on different waves (bwd_roles_kernel; MP_BF_ROLES bit 0: 256 outputs, bit 1: 128)
-                if (Co == 256 && pooled) MP_LAUNCH(tg, fl, by, (bwd_roles_kernel<SRC_DZ_POOLED, 256>), dim3(gx), dim3(512), 0, stream, DZ, IN, (int)P, ppb, Ly.weight, grads[l].d_weight, Gn, partials);
+                if (Co == 256 && pooled && roles_lds() == 2) MP_LAUNCH(tg, fl, by, (bwd_roles_lds_kernel<2>), dim3(gx), dim3(512), 0, stream, DZ, IN, (int)P, ppb, Ly.weight, grads[l].d_weight, Gn, partials);
+                else if (Co == 256 && pooled && roles_lds() == 3) MP_LAUNCH(tg, fl, by, (bwd_roles_lds_kernel<3>), dim3(gx), dim3(512), 0, stream, DZ, IN, (int)P, ppb, Ly.weight, grads[l].d_weight, Gn, partials);
+                else if (Co == 256 && pooled) MP_LAUNCH(tg, fl, by, (bwd_roles_kernel<SRC_DZ_POOLED, 256>), dim3(gx), dim3(512), 0, stream, DZ, IN, (int)P, ppb, Ly.weight, grads[l].d_weight, Gn, partials);
                 else if (Co == 256) MP_LAUNCH(tg, fl, by, (bwd_roles_kernel<SRC_DZ, 256>), dim3(gx), dim3(512), 0, stream, DZ, IN, (int)P, ppb, Ly.weight, grads[l].d_weight, Gn, partials);
                 else if (pooled) MP_LAUNCH(tg, fl, by, (bwd_roles_kernel<SRC_DZ_POOLED, 128>), dim3(gx), dim3(512), 0, stream, DZ, IN, (int)P, ppb, Ly.weight, grads[l].d_weight, Gn, partials);
                 else MP_LAUNCH(tg, fl, by, (bwd_roles_kernel<SRC_DZ, 128>), dim3(gx), dim3(512), 0, stream, DZ, IN, (int)P, ppb, Ly.weight, grads[l].d_weight, Gn, partials);
