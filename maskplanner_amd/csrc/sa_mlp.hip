@@ -75,6 +75,8 @@ struct PosOperand {
     const int64_t* gidx; // SRC_ID_G: ball-query result [B, gS, K] (flat: [P])
     int gN, gS, gCF;
     int gshift;          // log2(gS * K) when a power of two, else -1
+    const __bf16* pl;    // PREC == 4 ("planes"): this operand AFTER its transform, pre-split into (h, m, l) bf16 planes [3][P][C] (act_split_kernel)
+    size_t pls;          //   plane stride in elements
 };
 
 // Per-channel constants of 4 consecutive channels, loaded ONCE per thread and tile (not per element).
@@ -477,22 +479,26 @@ struct PoolOut {
     int K;
 };
 
-template <int MODE, bool W_KROW, int EPI, int WAVES_M, int WAVES_N, int TM, int TN, int PREC = 0>   // PREC: 0 fp32 MFMA, 1 bf16, 3 split (h, m, l) planes
+// PREC 4 [r3]: the split product with BOTH operands already in memory as (h, m, l) planes (A.pl: act_split_kernel; W: w_split_kernel, plane
+// stride wps) -- the main loop copies, it neither transforms nor splits: for the few-row levels (group_all: 4 096 positions) the tiled
+// kernel is bound by the split arithmetic of its staging, repeated for every tile that shares an operand
+template <int MODE, bool W_KROW, int EPI, int WAVES_M, int WAVES_N, int TM, int TN, int PREC = 0>   // PREC: 0 fp32 MFMA, 1 bf16, 3 split (h, m, l) planes, 4 planes in memory
 __global__ __launch_bounds__(THREADS) void pos_gemm_kernel(PosOperand A, int P, const float* __restrict__ W, int N,
                                                            int Kd, float* __restrict__ C, float* __restrict__ partials,
                                                            const float* __restrict__ zprev,
                                                            const float* __restrict__ sprev,
                                                            const float* __restrict__ tprev, PoolOut po, int ldw,
-                                                           int ldc)
+                                                           int ldc, size_t wps)
 {   // ldw: row stride of W in the NN form (>= N: only the first N columns are produced); ldc: row stride of C
     constexpr int BM = WAVES_M * TM * 32;
     constexpr int BN = WAVES_N * TN * 32;
     // (these shadow the file-level constants) split planes on the 64 x 64 tile: K chunks of 64 -- the six-product chunk of 32 is over
     // before the next chunk's loads have landed, and a barrier pair per 12 MFMAs is too many
-    constexpr int BK = (PREC == 3 && BM * BN <= 64 * 64) ? 64 : MP_BK;
+    constexpr bool SPL = PREC >= 3, PLN = PREC == 4;
+    constexpr int BK = (SPL && BM * BN <= 64 * 64) ? 64 : MP_BK;
     constexpr int TPR = BK / 4, RPP = 256 / TPR, LDK = BK + 1;
     constexpr bool BF16 = PREC != 0;
-    constexpr int NPL = PREC == 3 ? 3 : 1;                        // operand planes in LDS
+    constexpr int NPL = SPL ? 3 : 1;                              // operand planes in LDS
     using TL = std::conditional_t<BF16, __bf16, float>;           // element type of the LDS tiles
     constexpr int LDA = BF16 ? BK + 8 : LDK;                      // bf16: 80-byte rows (16-byte aligned, conflict-free b128 reads)
     constexpr int LDB = BF16 ? (W_KROW ? tr_ld(BN) : BK + 8) : (W_KROW ? BN : LDK);
@@ -505,7 +511,7 @@ __global__ __launch_bounds__(THREADS) void pos_gemm_kernel(PosOperand A, int P, 
     static_assert(WAVES_M * WAVES_N == 4, "4 waves");
     // split planes: ONE buffer (three planes of each operand are 3x the fp32 tile's bytes; two or three workgroups per CU cover
     // each other's staging instead of a second buffer)
-    constexpr int NBUF = PREC == 3 ? 1 : 2;
+    constexpr int NBUF = SPL ? 1 : 2;
     __shared__ __attribute__((aligned(16))) TL sA[NBUF][NPL * PSA];
     __shared__ __attribute__((aligned(16))) TL sB[NBUF][NPL * PSB];
     __shared__ float red[WAVES_M][2][BN];
@@ -525,11 +531,35 @@ __global__ __launch_bounds__(THREADS) void pos_gemm_kernel(PosOperand A, int P, 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
 
-    Raw4<MODE> ra[A_PASSES];
-    float4 rb[B_PASSES];
+    Raw4<MODE> ra[PLN ? 1 : A_PASSES];
+    float4 rb[PLN ? 1 : B_PASSES];
+    bf16x4 pa[PLN ? A_PASSES : 1][3], pb[PLN ? B_PASSES : 1][3];
     ChanConst kc;
     const int arow = tid / TPR, acol = (tid % TPR) * 4;
+    const __bf16* Wp = reinterpret_cast<const __bf16*>(W);
     auto gload = [&](int k0) {
+        if constexpr (PLN) {
+            const bf16x4 zero4 = {(__bf16)0.0f, (__bf16)0.0f, (__bf16)0.0f, (__bf16)0.0f};
+#pragma unroll
+            for (int ps = 0; ps < A_PASSES; ++ps) {
+                const int row = m0 + ps * RPP + arow, col = k0 + acol;
+                const bool ok = row < P && col < A.C;
+                const __bf16* q = A.pl + (size_t)((unsigned)(ok ? row : 0) * (unsigned)A.C + (unsigned)(ok ? col : 0));
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) pa[ps][pl] = ok ? *reinterpret_cast<const bf16x4*>(q + pl * A.pls) : zero4;
+            }
+#pragma unroll
+            for (int ps = 0; ps < B_PASSES; ++ps) {
+                int r_, c_, ld_;
+                bool ok;
+                if constexpr (W_KROW) { const int e = (ps * THREADS + tid) * 4; r_ = k0 + e / BN; c_ = n0 + e % BN; ld_ = ldw; ok = r_ < Kd && c_ < N; }
+                else { r_ = n0 + ps * RPP + arow; c_ = k0 + acol; ld_ = Kd; ok = r_ < N && c_ < Kd; }
+                const __bf16* q = Wp + (size_t)((unsigned)(ok ? r_ : 0) * (unsigned)ld_ + (unsigned)(ok ? c_ : 0));
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) pb[ps][pl] = ok ? *reinterpret_cast<const bf16x4*>(q + pl * wps) : zero4;
+            }
+            return;
+        }
         load_consts<MODE>(A, k0 + acol, kc);
 #ifdef MP_ABLATE_LOAD
         if (k0 > 0) return;   // only the first chunk is really loaded
@@ -547,6 +577,22 @@ __global__ __launch_bounds__(THREADS) void pos_gemm_kernel(PosOperand A, int P, 
         }
     };
     auto sstore = [&](int buf) {
+        if constexpr (PLN) {
+#pragma unroll
+            for (int ps = 0; ps < A_PASSES; ++ps) {
+                const int o = (ps * RPP + arow) * LDA + acol;
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<bf16x4*>(&sA[buf][pl * PSA + o]) = pa[ps][pl];
+            }
+#pragma unroll
+            for (int ps = 0; ps < B_PASSES; ++ps) {
+                const int e = (ps * THREADS + tid) * 4;
+                const int o = W_KROW ? (e / BN) * LDB + e % BN : (ps * RPP + arow) * LDB + acol;
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<bf16x4*>(&sB[buf][pl * PSB + o]) = pb[ps][pl];
+            }
+            return;
+        }
 #pragma unroll
         for (int ps = 0; ps < A_PASSES; ++ps) {
             const float4 v = finish<MODE>(ra[ps], kc);
@@ -596,7 +642,7 @@ __global__ __launch_bounds__(THREADS) void pos_gemm_kernel(PosOperand A, int P, 
         const int cur = NBUF == 1 ? 0 : (kc_ & 1);
         if (kc_ + 1 < nchunks) gload((kc_ + 1) * BK);
 #ifndef MP_ABLATE_MFMA
-        if constexpr (PREC == 3) mma_chunk_split<false, W_KROW, LDA, LDB, TM, TN, BK, PSA, PSB>(sA[cur], sB[cur], wrow0, wcol0, acc);
+        if constexpr (SPL) mma_chunk_split<false, W_KROW, LDA, LDB, TM, TN, BK, PSA, PSB>(sA[cur], sB[cur], wrow0, wcol0, acc);
         else if constexpr (BF16) mma_chunk_bf16<false, W_KROW, LDA, LDB, TM, TN, BK>(sA[cur], sB[cur], wrow0, wcol0, acc);
         else mma_chunk<false, W_KROW, LDA, LDB, TM, TN, BK>(sA[cur], sB[cur], wrow0, wcol0, acc);
 #endif
@@ -2913,10 +2959,74 @@ __global__ __launch_bounds__(256) void pool_bwd_prep_kernel(const float* __restr
     partials[((int64_t)blockIdx.x * 2 + 1) * C + c] = s2;
 }
 
+// [r3] an operand AFTER its transform (BatchNorm + ReLU, or the dZ algebra) as three bf16 planes [3][P][C]: one pass per operand instead of
+// one split per tile that shares it (pos_gemm_kernel / dw_gemm_kernel PREC 4)
+template <int MODE>
+__global__ __launch_bounds__(256) void act_split_kernel(PosOperand A, int P, __bf16* __restrict__ out, size_t pls)
+{
+    const int q = A.C >> 2;
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= (unsigned)P * (unsigned)q) return;
+    const int p = (int)(i / (unsigned)q), c = (int)(i - (unsigned)p * (unsigned)q) * 4;
+    ChanConst k;
+    load_consts<MODE>(A, c, k);
+    Raw4<MODE> r;
+    raw_load<MODE>(A, P, p, c, r);
+    const Split4 sp = split3(finish<MODE>(r, k));
+    __bf16* o = out + (size_t)i * 4;
+    *reinterpret_cast<bf16x4*>(o) = sp.h;
+    *reinterpret_cast<bf16x4*>(o + pls) = sp.m;
+    *reinterpret_cast<bf16x4*>(o + 2 * pls) = sp.l;
+}
+
+__global__ __launch_bounds__(256) void w_split_kernel(const float* __restrict__ W, unsigned n4, __bf16* __restrict__ out, size_t pls)
+{
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n4) return;
+    const Split4 sp = split3(ld4(W + (size_t)i * 4));
+    __bf16* o = out + (size_t)i * 4;
+    *reinterpret_cast<bf16x4*>(o) = sp.h;
+    *reinterpret_cast<bf16x4*>(o + pls) = sp.m;
+    *reinterpret_cast<bf16x4*>(o + 2 * pls) = sp.l;
+}
+
+// scratch for the planes of one call (carved from the caller's workspace by sa_mlp_fwd / sa_mlp_bwd; null: the planes route is off)
+struct PlanesWs { __bf16* a; __bf16* b; __bf16* w; };
+// MP_PLANES=1 (experiment, forward only, off): measured on the group_all level -- the products themselves 45 -> 41, 19 -> 17, 17.5 -> 15.5 us
+// with NOTHING but copies in their main loops, against 6 extra launches (3 x act_split ~8 us, 3 x w_split ~7.5 us): +34 us per step.  The
+// tiled kernels of the few-row levels are not bound by their split arithmetic: a 128 x 64 tile's K loop is 16 iterations of one global
+// round trip each (one chunk prefetched in registers, one LDS buffer, 24 MFMAs per wave and chunk).
+inline bool planes_enabled()
+{
+    static const bool on = getenv("MP_PLANES") && atoi(getenv("MP_PLANES")) != 0;
+    return on;
+}
+constexpr int64_t PLANES_MAX_P = 16384;       // the route pays where tiles re-split shared operands and the extra passes are small: few-row levels
+
+template <int MODE>
+int launch_act_split(PosOperand& A, int64_t P, __bf16* out, hipStream_t stream)
+{
+    const size_t pls = (size_t)P * (size_t)A.C;
+    const unsigned n = (unsigned)(pls / 4);
+    char tag[48];
+    snprintf(tag, sizeof tag, "act_split_kernel<%d>", MODE);
+    MP_LAUNCH(tag, 0.0, (4.0 * (MODE == SRC_DZ ? 2.0 : 1.0) + 6.0) * (double)pls, (act_split_kernel<MODE>), dim3((n + 255) / 256), dim3(256), 0, stream, A, (int)P, out, pls);
+    MP_CHECK_LAUNCH();
+    A.pl = out;
+    A.pls = pls;
+    return MP_OK;
+}
+inline int launch_w_split(const float* W, size_t n, __bf16* out, hipStream_t stream)
+{
+    MP_LAUNCH("w_split_kernel", 0.0, 10.0 * (double)n, w_split_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, stream, W, (unsigned)(n / 4), out, n);
+    MP_CHECK_LAUNCH();
+    return MP_OK;
+}
+
 template <int MODE, bool W_KROW, int EPI, int PREC = 0>
 int launch_pos_gemm(const PosOperand& A, int64_t P, const float* W, int N, int Kd, float* C, float* partials,
                     const float* zprev, const float* sprev, const float* tprev, hipStream_t stream, int* nblk_out,
-                    PoolOut po = PoolOut{}, int ldw = 0, int ldc = 0)
+                    PoolOut po = PoolOut{}, int ldw = 0, int ldc = 0, size_t wps = 0)
 {
     if (ldw == 0) ldw = N;
     if (ldc == 0) ldc = N;
@@ -2935,29 +3045,29 @@ int launch_pos_gemm(const PosOperand& A, int64_t P, const float* W, int N, int K
     // (split planes, [r2]: 64 x 64 tiles on all CUs run at 66-80 TFLOP/s on the group_all level; 128 x 128 tiles on half of them were
     // tried -- MP_POS_BIG_MIN=128 -- and are slower: 55 -> 93 us, one workgroup's K loop alone does not cover its load latency)
     static const int big_min = getenv("MP_POS_BIG_MIN") ? atoi(getenv("MP_POS_BIG_MIN")) : (1 << 30);
-    if (PREC == 3 && shape == 2 && t128 >= big_min) shape = 0;
+    if (PREC >= 3 && shape == 2 && t128 >= big_min) shape = 0;
     char tag[96];
-    const char* kn = PREC == 1 ? "pos_gemm_bf16_kernel" : (PREC == 3 ? "pos_gemm_split_kernel" : "pos_gemm_kernel");
+    const char* kn = PREC == 1 ? "pos_gemm_bf16_kernel" : (PREC == 3 ? "pos_gemm_split_kernel" : (PREC == 4 ? "pos_gemm_planes_kernel" : "pos_gemm_kernel"));
     if (shape == 1) {
         const unsigned gm = (unsigned)((P + 127) / 128);
         if (nblk_out) *nblk_out = (int)gm;
         snprintf(tag, sizeof tag, "%s<%d, %s, %d, 4, 1, 1, 2>", kn, MODE, W_KROW ? "true" : "false", EPI);
         MP_LAUNCH(tag, flops, bytes, (pos_gemm_kernel<MODE, W_KROW, EPI, 4, 1, 1, 2, PREC>), dim3(gm, (N + 63) / 64),
-                  dim3(THREADS), 0, stream, A, (int)P, W, N, Kd, C, partials, zprev, sprev, tprev, po, ldw, ldc);
+                  dim3(THREADS), 0, stream, A, (int)P, W, N, Kd, C, partials, zprev, sprev, tprev, po, ldw, ldc, wps);
     } else if (shape == 2) {
         if constexpr (EPI != EPI_SQ_POOL) {
             const unsigned gm = (unsigned)((P + 63) / 64);
             if (nblk_out) *nblk_out = (int)gm;
             snprintf(tag, sizeof tag, "%s<%d, %s, %d, 2, 2, 1, 1>", kn, MODE, W_KROW ? "true" : "false", EPI);
             MP_LAUNCH(tag, flops, bytes, (pos_gemm_kernel<MODE, W_KROW, EPI, 2, 2, 1, 1, PREC>), dim3(gm, (N + 63) / 64),
-                      dim3(THREADS), 0, stream, A, (int)P, W, N, Kd, C, partials, zprev, sprev, tprev, po, ldw, ldc);
+                      dim3(THREADS), 0, stream, A, (int)P, W, N, Kd, C, partials, zprev, sprev, tprev, po, ldw, ldc, wps);
         }
     } else {
         const unsigned gm = (unsigned)((P + 127) / 128);
         if (nblk_out) *nblk_out = (int)gm;
         snprintf(tag, sizeof tag, "%s<%d, %s, %d, 2, 2, 2, 2>", kn, MODE, W_KROW ? "true" : "false", EPI);
         MP_LAUNCH(tag, flops, bytes, (pos_gemm_kernel<MODE, W_KROW, EPI, 2, 2, 2, 2, PREC>), dim3(gm, (N + 127) / 128),
-                  dim3(THREADS), 0, stream, A, (int)P, W, N, Kd, C, partials, zprev, sprev, tprev, po, ldw, ldc);
+                  dim3(THREADS), 0, stream, A, (int)P, W, N, Kd, C, partials, zprev, sprev, tprev, po, ldw, ldc, wps);
     }
     MP_CHECK_LAUNCH();
     return MP_OK;
@@ -3038,9 +3148,40 @@ extern "C" int mp_debug_roles_times(unsigned long long* host_out)      // [2][8]
 }
 #endif
 
+// the planes route's scratch (PREC 4: few-row levels): operand planes [3][P][cmax] bf16 (two of them in backward: dZ and the layer input)
+// and the weight planes [3][max Co * Ci]; carved behind everything else
+static size_t planes_bytes(int64_t P, int n_layers, const int64_t* channels, int backward, size_t* op_bytes = nullptr)
+{
+    if (P > PLANES_MAX_P || !planes_enabled()) return 0;
+    int64_t cmax = 0, wmax = 0;
+    for (int l = 0; l <= n_layers; ++l) cmax = channels[l] > cmax ? channels[l] : cmax;
+    for (int l = 0; l < n_layers; ++l) wmax = channels[l] * channels[l + 1] > wmax ? channels[l] * channels[l + 1] : wmax;
+    const size_t op = align_up((size_t)3 * (size_t)P * (size_t)cmax * sizeof(__bf16), 256);
+    if (op_bytes) *op_bytes = op;
+    return (backward ? 2 : 1) * op + align_up((size_t)3 * (size_t)wmax * sizeof(__bf16), 256);
+}
+static size_t ws_core_bytes(int64_t P, int64_t K, int n_layers, const int64_t* channels, int backward);
+static PlanesWs planes_ws(void* workspace, int64_t P, int64_t K, int n_layers, const int64_t* channels, int backward)
+{
+    PlanesWs ws{nullptr, nullptr, nullptr};
+    size_t op = 0;
+    if (!planes_bytes(P, n_layers, channels, backward, &op)) return ws;
+    unsigned char* w = reinterpret_cast<unsigned char*>(workspace) + ws_core_bytes(P, K, n_layers, channels, backward);
+    ws.a = reinterpret_cast<__bf16*>(w);
+    w += op;
+    if (backward) { ws.b = reinterpret_cast<__bf16*>(w); w += op; }
+    ws.w = reinterpret_cast<__bf16*>(w);
+    return ws;
+}
+
 extern "C" size_t mp_sa_mlp_workspace_bytes(int64_t P, int64_t K, int n_layers, const int64_t* channels, int backward)
 {
     if (P <= 0 || n_layers <= 0 || !channels) return 0;
+    return ws_core_bytes(P, K, n_layers, channels, backward) + planes_bytes(P, n_layers, channels, backward);
+}
+
+static size_t ws_core_bytes(int64_t P, int64_t K, int n_layers, const int64_t* channels, int backward)
+{
     int64_t cmax = 0;
     for (int l = 0; l <= n_layers; ++l) cmax = channels[l] > cmax ? channels[l] : cmax;
     const size_t nblk = (size_t)((P + 63) / 64);                           // row tiles are 128 or (small grids) 64 high
@@ -3387,6 +3528,18 @@ static void set_gather(PosOperand& o, const mp_gather_t* g, int64_t K)
 // same position-stream kernels as the fp32 path with ONE operand plane instead of three (fwd_chunk / bwd_fused <..., ONE>), the
 // recomputed and the factorised first layers included (their VALU products on rounded operands: rb16); widths outside those
 // kernels take the generic tiled kernels.  Everything else as in fp32.
+// one forward layer of a few-row level on the planes route: the layer input (after BatchNorm + ReLU) and the weight pre-split, then the
+// tiled product with nothing but copies in its main loop
+template <int MODE, int EPI>
+static int fwd_planes(PosOperand A, int64_t P, const mp_mlp_layer_t& L, float* partials, hipStream_t stream, int* nblk, PoolOut po, const PlanesWs& ws)
+{
+    const size_t wn = (size_t)L.c_out * (size_t)L.c_in;
+    if (int rc = launch_act_split<MODE>(A, P, ws.a, stream)) return rc;
+    if (int rc = launch_w_split(L.weight, wn, ws.w, stream)) return rc;
+    return launch_pos_gemm<MODE, false, EPI, 4>(A, P, reinterpret_cast<const float*>(ws.w), (int)L.c_out, (int)L.c_in, L.z, partials, nullptr, nullptr,
+                                                nullptr, stream, nblk, po, 0, 0, wn);
+}
+
 static int sa_mlp_fwd(const float* x0, int64_t P, int64_t K, int n_layers, const mp_mlp_layer_t* layers,
                       int training, double momentum, double eps, float* out, int32_t* argk, float* zmax,
                       void* workspace, size_t workspace_bytes, mp_stream_t stream_, bool bf16, const mp_syncbn_t* sync,
@@ -3435,6 +3588,9 @@ static int sa_mlp_fwd(const float* x0, int64_t P, int64_t K, int n_layers, const
         po.imin = reinterpret_cast<int*>(w + 3 * pb);
         po.K = (int)K;
     }
+
+    const PlanesWs pws = planes_ws(workspace, P, K, n_layers, ch, 0);
+    const bool use_planes = pws.a && !bf16 && !gather && split_enabled() && planes_enabled();
 
     PosOperand A{};
     A.x = x0;
@@ -3541,6 +3697,11 @@ static int sa_mlp_fwd(const float* x0, int64_t P, int64_t K, int n_layers, const
 #undef MP_FWD
             MP_CHECK_LAUNCH();
             nblk = (int)gx;
+        } else if (use_planes) {       // [r3] few-row level (group_all): operands pre-split once, PREC 4
+            if (fuse_pool) rc = (l == 0) ? fwd_planes<SRC_ID, EPI_SQ_POOL>(A, P, L, partials, stream, &nblk, po, pws)
+                                         : fwd_planes<SRC_ACT, EPI_SQ_POOL>(A, P, L, partials, stream, &nblk, po, pws);
+            else rc = (l == 0) ? fwd_planes<SRC_ID, EPI_SQ>(A, P, L, partials, stream, &nblk, PoolOut{}, pws)
+                               : fwd_planes<SRC_ACT, EPI_SQ>(A, P, L, partials, stream, &nblk, PoolOut{}, pws);
         } else if (fuse_pool) {
             if (l == 0)
                 rc = MP_POS_GEMM(SRC_ID, false, EPI_SQ_POOL, A, P, L.weight, (int)L.c_out, (int)L.c_in, L.z, partials,
