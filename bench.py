@@ -383,7 +383,7 @@ def main():
                 r = {"kernel": k, "bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak,
                      "traffic": measured_traffic(k, cfg_key), "avg_us": avg_s * 1e6, "launches_per_step": d["calls"] / max(profiled_steps, 1),
                      "flops_per_launch": flops, "bytes_per_launch": nbytes}
-                planes = 6.0 if (split and "bf16" not in k and any(t in k for t in ("fused", "chunk", "bwd_first", "gemm", "lean"))) else 1.0
+                planes = 6.0 if (split and "bf16" not in k and any(t in k for t in ("fused", "roles", "chunk", "bwd_first", "gemm", "lean"))) else 1.0
                 ex_peak = BF16_PEAK_TFLOPS if (planes > 1 or "bf16" in k) else FP32_PEAK_TFLOPS
                 ex = {"mfma_TFLOPs": planes * flops / avg_s / 1e12, "mfma_peak": ex_peak, "mfma_frac": planes * flops / avg_s / 1e12 / ex_peak,
                       "hbm_GBps": nbytes / avg_s / 1e9, "hbm_peak": HBM_PEAK_GBS, "hbm_frac": nbytes / avg_s / 1e9 / HBM_PEAK_GBS}

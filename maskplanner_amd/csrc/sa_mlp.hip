@@ -3998,6 +3998,8 @@ static int sa_mlp_bwd(const float* x0, int64_t P, int64_t K, int n_layers, const
             } else if (!bf16 && split_enabled() && Ci == 128 && (Co == 256 || Co == 128) && ((roles_mask() >> (Co == 256 ? 0 : 1)) & 1) &&
                        (!pooled || (DZ.kshift >= 4 && ppb % 16 == 0))) {
                 // [r3] the two products on different waves (bwd_roles_kernel; MP_BF_ROLES bit 0: 256 outputs, bit 1: 128)
+                snprintf(tg, sizeof tg, (Co == 256 && pooled && roles_lds()) ? "bwd_roles_lds_kernel<%d>" : "bwd_roles_kernel<%d, %d>",
+                         (Co == 256 && pooled && roles_lds()) ? roles_lds() : (pooled ? 3 : 2), Co);
                 if (Co == 256 && pooled && roles_lds() == 2) MP_LAUNCH(tg, fl, by, (bwd_roles_lds_kernel<2>), dim3(gx), dim3(512), 0, stream, DZ, IN, (int)P, ppb, Ly.weight, grads[l].d_weight, Gn, partials);
                 else if (Co == 256 && pooled && roles_lds() == 3) MP_LAUNCH(tg, fl, by, (bwd_roles_lds_kernel<3>), dim3(gx), dim3(512), 0, stream, DZ, IN, (int)P, ppb, Ly.weight, grads[l].d_weight, Gn, partials);
                 else if (Co == 256 && pooled) MP_LAUNCH(tg, fl, by, (bwd_roles_kernel<SRC_DZ_POOLED, 256>), dim3(gx), dim3(512), 0, stream, DZ, IN, (int)P, ppb, Ly.weight, grads[l].d_weight, Gn, partials);

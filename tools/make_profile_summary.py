@@ -46,7 +46,7 @@ with open(f"{out}/{tag}_bench_kernel_stats.md", "w") as f:
 traffic = {}
 for k, fz in fetch.items():
     wz = write.get(k)
-    if wz is not None and any(t in k for t in ("gemm", "knn", "fps", "ball", "pool", "group", "fused", "chunk", "adam", "dw_ci4", "first", "linear", "lean", "mask_match")):
+    if wz is not None and any(t in k for t in ("gemm", "knn", "fps", "ball", "pool", "group", "fused", "roles", "chunk", "adam", "dw_ci4", "first", "linear", "lean", "mask_match")):
         traffic[k.split("(")[0]] = dict(fetch_kib=fz, write_kib=wz, hbm_bytes=(2 * fz + wz) * 1024)
 # the other BASELINE configs (tools/profile_configs.sh): one table per config key, looked up by bench.py before the default one
 configs = {}
@@ -62,7 +62,7 @@ for d in sorted(glob.glob(f"{go}/{tag}_cfg_*_fetch")):
     tab = {}
     for k, fz in cf.items():
         wz = cw.get(k)
-        if wz is not None and any(t in k for t in ("gemm", "knn", "fps", "ball", "pool", "group", "fused", "chunk", "adam", "dw_ci4", "first", "linear", "lean", "mask_match", "lsap")):
+        if wz is not None and any(t in k for t in ("gemm", "knn", "fps", "ball", "pool", "group", "fused", "roles", "chunk", "adam", "dw_ci4", "first", "linear", "lean", "mask_match", "lsap")):
             tab[k.split("(")[0]] = dict(fetch_kib=fz, write_kib=wz, hbm_bytes=(2 * fz + wz) * 1024)
     configs[key] = tab
 json.dump(dict(source=f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes ({tag}), bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch; "
@@ -96,7 +96,7 @@ if mf:
                 "| kernel | launches | avg us | GUI_ACTIVE/8 (cycles) | held clock GHz | MFMA_BUSY (SIMD-cycles) | MFMA util | util x clk/2.4 |\n|---|---|---|---|---|---|---|---|\n")
         names = sorted(agg, key=lambda n: -dur.get(n, 0.0) * len(agg[n].get("GRBM_GUI_ACTIVE", [])))
         for n in names:
-            if not any(t in n for t in ("fused", "chunk", "gemm", "bwd_first", "dw_ci4", "rc_stats", "bf16")):
+            if not any(t in n for t in ("fused", "roles", "chunk", "gemm", "bwd_first", "dw_ci4", "rc_stats", "bf16")):
                 continue
             c = agg[n]
             gui = sum(c["GRBM_GUI_ACTIVE"]) / max(len(c["GRBM_GUI_ACTIVE"]), 1) / 8.0
