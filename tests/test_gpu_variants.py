@@ -37,6 +37,12 @@ def test_fused_backward_variants_of_the_second_level(env):
     _same(_run("sa2", **env), _run("sa2"), env)
 
 
+def test_interior_256_output_layer_on_both_fused_backward_kernels():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    _same(_run("mid256", MP_BF_ROLES=0), _run("mid256"), "interior 256")
+
+
 def test_planes_route_of_the_group_all_level():
     if not torch.cuda.is_available():
         pytest.skip("needs an MI355X")

@@ -6,7 +6,8 @@ import torch
 from maskplanner_amd import sa_mlp
 
 shape, out = sys.argv[1], sys.argv[2]
-B, S, K, C0, mlp = {"sa2": (8, 128, 64, 131, [128, 128, 256]), "sa3": (16, 1, 128, 259, [256, 512, 1024])}[shape]
+B, S, K, C0, mlp = {"sa2": (8, 128, 64, 131, [128, 128, 256]), "sa3": (16, 1, 128, 259, [256, 512, 1024]),
+                     "mid256": (8, 64, 32, 131, [128, 256, 128])}[shape]      # mid256: an INTERIOR 128 -> 256 layer (the non-pooled form of the 256-output kernels)
 torch.manual_seed(5)
 convs, bns = torch.nn.ModuleList(), torch.nn.ModuleList()
 last = C0
