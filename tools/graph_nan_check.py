@@ -2,6 +2,8 @@
 synchronise after every step and stop at the first non-finite loss / parameter / optimizer moment."""
 import sys
 import torch
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from maskplanner_amd.harness import TrainStep
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
