@@ -251,14 +251,6 @@ int mp_bn_relu_rows_bwd_f32(const float* grad_y, const float* y, const float* x,
 /* The same block with the nn.Dropout(p) behind it (models/pointnet2_cls_ssg.py:309-327: self.dropout(F.relu(self.bn1(.)))) in the same
  * launch.  rng: device int64 [2] = (seed, step), advanced by the caller once per training step; the keep mask is a counter-based hash of
  * (seed, step, layer, element) -- Bernoulli(1 - p) like torch's, not the same draws.  Backward: the mask is `y > 0`. */
-/* a whole head block -- dropout(relu(bn(linear(x)))), models/pointnet2_cls_ssg.py:309-327 -- in one launch: x [B <= 32, K], weight [N, K]
- * (K % 128 == 0), lin_out [B, N] = the Linear's output (BatchNorm's input, kept for the backward), y [B, N]; statistics, running-stat update
- * and dropout as in mp_bn_relu_drop_rows_f32 (rng NULL: no dropout).  The product runs on the bf16 matrix cores with three-plane split
- * operands (fp32-accurate).  Backward: mp_bn_relu_drop_rows_bwd_f32 on (grad_y, y, lin_out), then the Linear's own backward. */
-int mp_linear_block_f32(const float* x, const float* weight, const float* bias, int64_t B, int64_t N, int64_t K, int training,
-                        double momentum, double eps, const float* gamma, const float* beta, float* running_mean, float* running_var,
-                        float* lin_out, float* y, float* save_mean, float* save_rstd, double drop_p, const int64_t* rng, int layer,
-                        mp_stream_t stream);
 int mp_bn_relu_drop_rows_f32(const float* x, int64_t B, int64_t C, int training, double momentum, double eps,
                              const float* gamma, const float* beta, float* running_mean, float* running_var, float* y,
                              float* save_mean, float* save_rstd, double drop_p, const int64_t* rng, int layer, mp_stream_t stream);
@@ -312,19 +304,9 @@ size_t mp_sa_mlp_workspace_bytes(int64_t P, int64_t K, int n_layers, const int64
  * element.  channels[n_layers + 1] as for the workspace query.  (Reference: the first Conv2d of sa1, pointnet2_utils.py:208-213;
  * the reference stores every activation for autograd.) */
 int mp_sa_mlp_recompute_first(int n_layers, const int64_t* channels, int64_t K);
-/* 1 if the POOLED (last) layer of the chain can run without its stored activation: pass layers[n_layers - 1].z = NULL to
- * mp_sa_mlp_fwd_f32 / _gather_f32 and to the matching backward call, and Z_L [P, c_out] is neither written nor read.  The backward
- * pass then never forms the dense dZ_L = a * gm + e * z + f either: with A = act(Z_{L-1}) and a shift m~ near its column means,
- * G_{L-1} = (A - m~) M + v~ + sparse rows (M = W^T diag(e) W) and dW_L = a .* S + e .* (W Gp) + f~ (x) colsum(A) -- contractions of
- * width c_in instead of c_out (csrc/sa_lean.hip).  Same results as the stored form up to fp32 rounding; dW_L is bit-reproducible.
- * (Reference: the last Conv2d + BatchNorm2d + ReLU + max of a level, pointnet2_utils.py:208-214; autograd stores Z_L.) */
-int mp_sa_mlp_lean_last(int n_layers, const int64_t* channels, int64_t K, int64_t P);
-/* The grouped input of a level that is NOT materialised: row p = (b, s, k) of x0 is [feats[b, idx[p], 0:CF] | xyz[b, idx[p]] - new_xyz[b, s] | 0]
- * (models/pointnet2_utils.py:133-143 fused into the consumers).  mp_sa_mlp_gather_supported tells whether a chain qualifies (BASELINE's second
- * level: CF = 128, first layer 132 -> 128); the gather forms take this descriptor instead of x0, everything else as in the plain calls
- * (grad_x0 [P, 132] with grad_x0_cols = 128 is still written: the caller scatters it with mp_group_bwd_f32).
- * FACTORISED first layer (second form of the same two calls, recognised by layers[0].c_in == 4 and CF == layers[0].c_out in {64, 128,
- * 256}): the first Conv2d is linear in [f ; x - c] (pointnet2_utils.py:138 / :262 + :208-213), so the caller computes A = F W_f^T once per
+/* FACTORISED first layer of a level with input features: the gather forms (mp_sa_mlp_{fwd,bwd}_gather_*) take this descriptor instead
+ * of x0 -- the grouped input [feats[b, idx[p]] | xyz[b, idx[p]] - new_xyz[b, s]] (models/pointnet2_utils.py:133-143) is never materialised.
+ * Shapes: layers[0].c_in == 4 and CF == layers[0].c_out in {64, 128, 256}.  The first Conv2d is linear in [f ; x - c] (pointnet2_utils.py:138 / :262 + :208-213), so the caller computes A = F W_f^T once per
  * SOURCE point and passes it as `feats` [B, N, Co]; layers[0].weight is the coordinate part (W_x | 0) [Co, 4].  The library forms
  * Z_0[p] = A[b, idx[p]] + W_x (xyz[b, idx[p]] - new_xyz[b, s]) and its BatchNorm statistics, then the ordinary chain; backward it writes
  * dZ_0 into grad_x0 [P, Co + 4] (grad_x0_cols = Co; mp_group_bwd_f32 over the gathering rows turns it into dA [B, N, Co], from which dW_f
@@ -345,7 +327,6 @@ int mp_sa_mlp_bwd_f32(const float* x0, int64_t P, int64_t K, int n_layers, const
                       const float* grad_out, const float* out, const int32_t* argk, const float* zmax,
                       const mp_mlp_grads_t* grads, float* grad_x0, int64_t grad_x0_cols, void* workspace,
                       size_t workspace_bytes, mp_stream_t stream);
-int mp_sa_mlp_gather_supported(int n_layers, const int64_t* channels, int64_t K, int64_t CF);
 int mp_sa_mlp_fwd_gather_f32(const mp_gather_t* gather, int64_t P, int64_t K, int n_layers, const mp_mlp_layer_t* layers,
                              int training, double momentum, double eps, float* out, int32_t* argk, float* zmax,
                              void* workspace, size_t workspace_bytes, mp_stream_t stream);

@@ -80,7 +80,6 @@ SIGNATURES = {
     "mp_mask_loss_bwd_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _dbl, _dbl, _dbl, _vp, _vp, _vp]),
     "mp_bn_relu_rows_f32": (_int, [_vp, _i64, _i64, _int, _dbl, _dbl, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mp_bn_relu_rows_bwd_f32": (_int, [_vp, _vp, _vp, _i64, _i64, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "mp_linear_block_f32": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _int, _dbl, _dbl, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _dbl, _vp, _int, _vp]),
     "mp_bn_relu_drop_rows_f32": (_int, [_vp, _i64, _i64, _int, _dbl, _dbl, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _dbl, _vp, _int, _vp]),
     "mp_bn_relu_drop_rows_bwd_f32": (_int, [_vp, _vp, _vp, _i64, _i64, _int, _vp, _vp, _vp, _vp, _vp, _vp, _dbl, _vp]),
     "mp_knn_workspace_bytes": (_sz, [_i64, _i64, _i64]),
@@ -100,13 +99,11 @@ SIGNATURES = {
     "mp_profiler_collect": (_int, [ctypes.c_char_p, _sz]),
     "mp_sa_mlp_workspace_bytes": (_sz, [_i64, _i64, _int, ctypes.POINTER(_i64), _int]),
     "mp_sa_mlp_recompute_first": (_int, [_int, ctypes.POINTER(_i64), _i64]),
-    "mp_sa_mlp_lean_last": (_int, [_int, ctypes.POINTER(_i64), _i64, _i64]),
     "mp_adam_multi_f32": (_int, [_i64, _vp, _vp, _vp, _vp, ctypes.POINTER(_i64), ctypes.c_double, ctypes.c_double, ctypes.c_double,
                                  ctypes.c_double, ctypes.c_double, _i64, _vp, _vp]),
     "mp_colsum_multi_f32": (_int, [_i64, _vp, _vp, ctypes.POINTER(_i64), _i64, _vp]),
     "mp_pad_ragged_f32": (_int, [_vp, _vp, _i64, _i64, _i64, ctypes.c_float, _vp, _vp]),
     "mp_lambda_segments_f32": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp]),
-    "mp_sa_mlp_gather_supported": (_int, [_int, _vp, _i64, _i64]),
     "mp_sa_mlp_fwd_gather_f32": (_int, [ctypes.POINTER(Gather), _i64, _i64, _int, ctypes.POINTER(MlpLayer), _int, _dbl, _dbl, _vp, _vp, _vp, _vp,
                                         _sz, _vp]),
     "mp_sa_mlp_fwd_gather_bf16": (_int, [ctypes.POINTER(Gather), _i64, _i64, _int, ctypes.POINTER(MlpLayer), _int, _dbl, _dbl, _vp, _vp, _vp, _vp,

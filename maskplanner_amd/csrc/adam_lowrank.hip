@@ -263,8 +263,7 @@ extern "C" int mp_adam_lowrank_f32(float* param, float* exp_avg, float* exp_avg_
     const double c1 = 1.0 - pow(beta1, sh), c2 = 1.0 - pow(beta2, sh);
     const dim3 grid((unsigned)((I + AL_TI - 1) / AL_TI), (unsigned)((O + AL_TO - 1) / AL_TO));
     // more factor rows than one GPU's batch (all-gathered factors of a data-parallel run): rebuild on the matrix cores
-    static const int force = getenv("MP_ADAM_LOWRANK_MFMA") ? atoi(getenv("MP_ADAM_LOWRANK_MFMA")) : -1;   // A/B knob
-    const bool mfma = force >= 0 ? force != 0 : Bg > 32;
+    const bool mfma = Bg > 32;
     if (mfma)
         MP_LAUNCH("adam_lowrank_kernel<mfma>", 2.0 * (double)Bg * O * I, 24.0 * (double)O * I + 4.0 * Bg * (double)(O + I),
                   adam_lowrank_kernel<true>, grid, dim3(256), 0, mp_stream(stream_), param, exp_avg, exp_avg_sq, x, g, (int)Bg, (int)O,

@@ -164,11 +164,6 @@ extern "C" int mp_fps_f32(const float* xyz, int64_t B, int64_t N, int64_t S, con
     const int b = (int)B, n = (int)N, s = (int)S;
 #define MP_FPS_CASE(T, P) \
     if (n <= (T) * (P)) return launch_fps<T, P>(xyz, b, n, s, start_idx, out_idx, out_xyz, stream)
-    // experiment knob (tools/bench_fps.py): force a block size
-    static const int forced = getenv("MP_FPS_THREADS") ? atoi(getenv("MP_FPS_THREADS")) : 0;
-    if (forced == 256) { MP_FPS_CASE(256, 8); MP_FPS_CASE(256, 12); MP_FPS_CASE(256, 16); MP_FPS_CASE(256, 20); MP_FPS_CASE(256, 24); MP_FPS_CASE(256, 32); }
-    if (forced == 512) { MP_FPS_CASE(512, 4); MP_FPS_CASE(512, 6); MP_FPS_CASE(512, 8); MP_FPS_CASE(512, 10); MP_FPS_CASE(512, 12); MP_FPS_CASE(512, 16); }
-    if (forced == 128) { MP_FPS_CASE(128, 4); MP_FPS_CASE(128, 8); MP_FPS_CASE(128, 16); MP_FPS_CASE(128, 40); }
     // one wave: no barrier at all
     MP_FPS_CASE(64, 1);
     MP_FPS_CASE(64, 2);

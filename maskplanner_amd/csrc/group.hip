@@ -495,9 +495,7 @@ extern "C" int mp_group_bwd_f32(const float* grad_out, const int64_t* idx, int64
                (reinterpret_cast<uintptr_t>(grad_feats) & 15) == 0) {
         // rpw = 64 / (D/4) in {4, 2, 1}: the shuffle combine of the gather kernel covers exactly these
         // one slab for the widths a wave covers by itself, else slabs of 128 columns (+ a 64-wide remainder): every slab width is in {64, 128, 256}
-        static const int slab_env = getenv("MP_GROUP_SLAB") ? atoi(getenv("MP_GROUP_SLAB")) : 0;     // experiments: 64 / 128 / 256
-        int slab = (D == 64 || D == 128 || D == 256) ? (int)D : 128;
-        if (slab_env == 64 || ((slab_env == 128 || slab_env == 256) && D % slab_env % 64 == 0)) slab = slab_env < D ? slab_env : (int)D;
+        const int slab = (D == 64 || D == 128 || D == 256) ? (int)D : 128;
         MP_LAUNCH("group_bwd_gather_kernel", 0.0, 4.0 * (double)(B * S * K) * (D + 2) + 4.0 * (double)(B * N * D), group_bwd_gather_kernel,
                   dim3((unsigned)((N + GP - 1) / GP), (unsigned)B, (unsigned)((D + slab - 1) / slab)), dim3(256), 0, stream, grad_out, idx, (int)N,
                   (int)(S * K), (int)D, slab, grad_feats);

@@ -354,161 +354,6 @@ __global__ __launch_bounds__(256) void bn_relu_rows_bwd_kernel(const float* __re
 
 }  // namespace
 
-// ---- Linear + BatchNorm1d + ReLU (+ Dropout) of a head block in ONE launch (models/pointnet2_cls_ssg.py:309-327) -------------
-// x [B <= 32, K] . W[N, K]^T + bias, train-mode statistics over the B rows, ReLU, optional dropout.  rocBLAS needs ~12 us for a
-// [32 x 1024] x [1024 x 1024] product (a latency-bound launch of 64 workgroups) and the BatchNorm launch follows it; here a
-// workgroup owns 32 output columns -- all B rows of a column, so the statistics are local -- its eight waves take an eighth of K
-// each on the bf16 matrix cores (three-plane split of both operands on the fly: fp32-accurate, see sa_mlp.hip), the partial tiles are
-// summed through LDS and the epilogue is bn_relu_rows_kernel's (same arithmetic order for the statistics, same dropout hash).
-namespace {
-typedef __attribute__((ext_vector_type(8))) __bf16 lbf16x8;
-typedef __attribute__((ext_vector_type(16))) float lf32x16;
-__device__ __forceinline__ void lsplit8(const float4& a, const float4& b, lbf16x8& h, lbf16x8& m, lbf16x8& l)
-{
-    const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const __bf16 hh = (__bf16)x[i];
-        const float r1 = x[i] - (float)hh;
-        const __bf16 mm = (__bf16)r1;
-        h[i] = hh; m[i] = mm; l[i] = (__bf16)(r1 - (float)mm);
-    }
-}
-
-__global__ __launch_bounds__(512) void linear_block_kernel(const float* __restrict__ x, const float* __restrict__ W, const float* __restrict__ bias,
-                                                           int B, int N, int K, int training, float momentum, float eps,
-                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                           float* __restrict__ running_mean, float* __restrict__ running_var,
-                                                           float* __restrict__ lin, float* __restrict__ y, float* __restrict__ save_mean,
-                                                           float* __restrict__ save_rstd, float drop_p, const long long* __restrict__ rng, int layer)
-{
-    __shared__ float part[8][32][33];        // the eight K-slice partial tiles [row][col]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r31 = lane & 31, kh = lane >> 5;
-    const int o0 = blockIdx.x * 32;
-    const int kq = K / 8, k0 = wave * kq;    // K % 128 == 0 (checked on the host)
-    lf32x16 acc, cor;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { acc[r] = 0.0f; cor[r] = 0.0f; }
-    const bool rok = r31 < B, ook = o0 + r31 < N;
-    const float* xp = x + (size_t)(rok ? r31 : 0) * K + k0 + 8 * kh;                // A: row b = lane & 31
-    const float* wp = W + (size_t)(ook ? o0 + r31 : 0) * K + k0 + 8 * kh;           // B: column o = lane & 31
-    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    // a wave's whole K slice is requested up front, eight k-steps at a time (one memory latency per workgroup, not one per k-step)
-    constexpr int DEPTH = 8;
-    const int nst = kq / 16;
-    for (int s0 = 0; s0 < nst; s0 += DEPTH) {
-        float4 xa[DEPTH][2], wa[DEPTH][2];
-#pragma unroll
-        for (int u = 0; u < DEPTH; ++u) {
-            const bool in = s0 + u < nst;
-            xa[u][0] = (rok && in) ? *reinterpret_cast<const float4*>(xp + 16 * (s0 + u)) : z4;
-            xa[u][1] = (rok && in) ? *reinterpret_cast<const float4*>(xp + 16 * (s0 + u) + 4) : z4;
-            wa[u][0] = (ook && in) ? *reinterpret_cast<const float4*>(wp + 16 * (s0 + u)) : z4;
-            wa[u][1] = (ook && in) ? *reinterpret_cast<const float4*>(wp + 16 * (s0 + u) + 4) : z4;
-        }
-#pragma unroll
-        for (int u = 0; u < DEPTH; ++u) {
-            lbf16x8 ah, am, al, bh, bm, bl;
-            lsplit8(xa[u][0], xa[u][1], ah, am, al);
-            lsplit8(wa[u][0], wa[u][1], bh, bm, bl);
-            cor = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, cor, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
-            cor = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, cor, 0, 0, 0);
-            cor = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, cor, 0, 0, 0);
-            cor = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, cor, 0, 0, 0);
-            cor = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, cor, 0, 0, 0);
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) part[wave][(r & 3) + 8 * (r >> 2) + 4 * kh][r31] = acc[r] + cor[r];
-    __syncthreads();
-    // epilogue: thread (column c, row group g of 16) holds rows g and g + 16 of its column
-    const int c = tid & 31, g = tid >> 5;
-    const int o = o0 + c;
-    const bool live = o < N;
-    constexpr int RK = 2;
-    float xv[RK];
-    const float bo = (live && bias) ? bias[o] : 0.0f;
-#pragma unroll
-    for (int k = 0; k < RK; ++k) {
-        const int r = g + 16 * k;
-        float t = 0.0f;
-#pragma unroll
-        for (int w = 0; w < 8; ++w) t += part[w][r][c];
-        xv[k] = r < B ? t + bo : 0.0f;
-        if (live && r < B) lin[(size_t)r * N + o] = xv[k];
-    }
-    float mean = 0.0f, rstd = 0.0f;
-    __shared__ float red16[16][32];
-    if (training) {
-        red16[g][c] = xv[0] + xv[1];
-        __syncthreads();
-        float tot = 0.0f;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) tot += red16[j][c];
-        mean = tot / (float)B;
-        __syncthreads();
-        float v = 0.0f;
-#pragma unroll
-        for (int k = 0; k < RK; ++k) { const float d = xv[k] - mean; v += (g + 16 * k < B) ? d * d : 0.0f; }
-        red16[g][c] = v;
-        __syncthreads();
-        v = 0.0f;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) v += red16[j][c];
-        const float var = v / (float)B;
-        rstd = 1.0f / sqrtf(var + eps);
-        if (live && g == 0 && running_mean) {
-            running_mean[o] = (1.0f - momentum) * running_mean[o] + momentum * mean;
-            running_var[o] = (1.0f - momentum) * running_var[o] + momentum * (B > 1 ? v / (float)(B - 1) : var);
-        }
-    } else if (live) {
-        mean = running_mean[o];
-        rstd = 1.0f / sqrtf(running_var[o] + eps);
-    }
-    if (!live) return;
-    if (g == 0) { save_mean[o] = mean; save_rstd[o] = rstd; }
-    const float ga = gamma ? gamma[o] : 1.0f, be = beta ? beta[o] : 0.0f;
-    const bool drop = rng != nullptr && drop_p > 0.0f;
-    const unsigned long long key = drop ? (unsigned long long)rng[0] + 0xD1B54A32D192ED03ull * (unsigned long long)rng[1] +
-                                          ((unsigned long long)(unsigned)layer << 48) : 0ull;
-    const float keep_scale = drop ? 1.0f / (1.0f - drop_p) : 1.0f;
-#pragma unroll
-    for (int k = 0; k < RK; ++k) {
-        const int r = g + 16 * k;
-        if (r >= B) continue;
-        float v = (xv[k] - mean) * rstd * ga + be;
-        v = v > 0.0f ? v : 0.0f;
-        if (drop) {       // the hash of bn_relu_rows_kernel: element index r * N + o
-            unsigned long long z = key + 0x9E3779B97F4A7C15ull * ((unsigned long long)r * (unsigned long long)N + (unsigned long long)o + 1ull);
-            z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-            z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-            z ^= z >> 31;
-            const float u = (float)(z >> 40) * (1.0f / 16777216.0f);
-            v = u >= drop_p ? v * keep_scale : 0.0f;
-        }
-        y[(size_t)r * N + o] = v;
-    }
-}
-}  // namespace
-
-extern "C" int mp_linear_block_f32(const float* x, const float* weight, const float* bias, int64_t B, int64_t N, int64_t K, int training,
-                                   double momentum, double eps, const float* gamma, const float* beta, float* running_mean,
-                                   float* running_var, float* lin_out, float* y, float* save_mean, float* save_rstd, double drop_p,
-                                   const int64_t* rng, int layer, mp_stream_t stream_)
-{
-    if (B <= 0 || N < 0 || K <= 0 || drop_p < 0.0 || drop_p >= 1.0) return MP_EINVAL;
-    if (N == 0) return MP_OK;
-    if (!x || !weight || !lin_out || !y || !save_mean || !save_rstd || (!training && (!running_mean || !running_var))) return MP_EINVAL;
-    if (B > 32 || (K & 127) || N > (1 << 24)) return MP_EUNSUPPORTED;
-    hipLaunchKernelGGL(linear_block_kernel, dim3((unsigned)((N + 31) / 32)), dim3(512), 0, mp_stream(stream_), x, weight, bias, (int)B, (int)N,
-                       (int)K, training, (float)momentum, (float)eps, gamma, beta, running_mean, running_var, lin_out, y, save_mean, save_rstd,
-                       (float)drop_p, reinterpret_cast<const long long*>(rng), layer);
-    MP_CHECK_LAUNCH();
-    return MP_OK;
-}
-
 static int bn_relu_rows_fwd(const float* x, int64_t B, int64_t C, int training, double momentum, double eps,
                             const float* gamma, const float* beta, float* running_mean, float* running_var, float* y,
                             float* save_mean, float* save_rstd, double drop_p, const int64_t* rng, int layer, mp_stream_t stream_)

@@ -26,7 +26,6 @@
 #include <type_traits>
 
 #include "common.h"
-#include "sa_lean.h"
 
 namespace {
 
@@ -40,11 +39,8 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 #endif
 constexpr int THREADS = 256;
 
-enum SrcMode { SRC_ID = 0, SRC_ACT = 1, SRC_DZ = 2, SRC_DZ_POOLED = 3, SRC_ACT_RC = 4, SRC_DZ_RC = 5, SRC_ID_G = 6 };
-// SRC_ID_G ("gathered"): the level's grouped input rows [features | centred xyz | pad] are not in memory -- row p = (b, s, k) is read
-// where it lives: features of point idx[p] of the previous level ([B, N, CF], 512-byte rows of an L2-resident table), coordinates as
-// xyz[idx[p]] - new_xyz[b, s].  Saves the grouping kernel's write of [P, CF + 4] floats and both later reads of it.
-constexpr bool is_id(int m) { return m == SRC_ID || m == SRC_ID_G; }
+enum SrcMode { SRC_ID = 0, SRC_ACT = 1, SRC_DZ = 2, SRC_DZ_POOLED = 3, SRC_ACT_RC = 4, SRC_DZ_RC = 5 };
+constexpr bool is_id(int m) { return m == SRC_ID; }
 // *_RC ("recompute"): the raw Z of this operand is not in memory -- it is the first layer of a level with a 4-channel input
 // (xyz + pad), z[p][c] = X0[p][0:4] . W0[c][0:4], four FMAs per element: cheaper to recompute from the 16-byte input row than
 // to write [P, C] floats once and read them back three times (next layer forward, next layer backward, its own dW).
@@ -69,14 +65,6 @@ struct PosOperand {
     int kshift;          // log2(K) when K is a power of two (every sampled level), else -1: position -> (group, member) by shift / mask
     const float* rx;     // *_RC: the level's input rows X0 [P, 4]
     const float* rw;     // *_RC: the first layer's weight W0 [C, 4]
-    const float* gf;     // SRC_ID_G: features of the previous level [B, gN, gCF]
-    const float* gxyz;   // SRC_ID_G: its coordinates [B, gN, 3]
-    const float* gnew;   // SRC_ID_G: this level's centroids [B, gS, 3]
-    const int64_t* gidx; // SRC_ID_G: ball-query result [B, gS, K] (flat: [P])
-    int gN, gS, gCF;
-    int gshift;          // log2(gS * K) when a power of two, else -1
-    const __bf16* pl;    // PREC == 4 ("planes"): this operand AFTER its transform, pre-split into (h, m, l) bf16 planes [3][P][C] (act_split_kernel)
-    size_t pls;          //   plane stride in elements
 };
 
 // Per-channel constants of 4 consecutive channels, loaded ONCE per thread and tile (not per element).
@@ -119,33 +107,12 @@ struct Raw4 {
     bool ok;
 };
 
-// SRC_ID_G: the source row b * N + idx[p] of position p (one int64 load).  Kernels fetch it ONE CHUNK AHEAD of the row itself, so that
-// the dependent feature load does not wait for it.
-__device__ __forceinline__ unsigned gather_row(const PosOperand& o, int P, int p)
-{
-    const int pp = p < P ? p : 0;
-    const unsigned per = (unsigned)o.gS * (unsigned)o.K;
-    const unsigned b = o.gshift >= 0 ? (unsigned)pp >> o.gshift : (unsigned)pp / per;
-    return b * (unsigned)o.gN + (unsigned)o.gidx[pp];
-}
-
 template <int MODE>
-__device__ __forceinline__ void raw_load(const PosOperand& o, int P, int p, int c, Raw4<MODE>& r, unsigned gsrc = 0xffffffffu)
+__device__ __forceinline__ void raw_load(const PosOperand& o, int P, int p, int c, Raw4<MODE>& r)
 {
     r.ok = (p < P) && (c < o.C);
     const int pp = r.ok ? p : 0, cc = r.ok ? c : 0;
     if constexpr (is_rc(MODE)) r.z = ld4(o.rx + (size_t)pp * 4);   // the input row; raw_z() turns it into 4 channels of z
-    else if constexpr (MODE == SRC_ID_G) {
-        const size_t src = gsrc != 0xffffffffu ? (size_t)gsrc : (size_t)gather_row(o, P, p);
-        if (cc < o.gCF) {
-            r.z = ld4(o.gf + src * (unsigned)o.gCF + (unsigned)cc);
-        } else {                    // the coordinate quad: xyz[idx] - new_xyz[group], 0
-            const unsigned grp = o.kshift >= 0 ? (unsigned)pp >> o.kshift : (unsigned)pp / (unsigned)o.K;
-            const float* a = o.gxyz + src * 3;
-            const float* c = o.gnew + (size_t)grp * 3;
-            r.z = make_float4(a[0] - c[0], a[1] - c[1], a[2] - c[2], 0.0f);
-        }
-    }
     else r.z = ld4(o.x + (size_t)((unsigned)pp * (unsigned)o.C + (unsigned)cc));
     if constexpr (MODE == SRC_DZ || MODE == SRC_DZ_RC) {
         r.g = ld4(o.g + (size_t)((unsigned)pp * (unsigned)o.C + (unsigned)cc));
@@ -479,22 +446,19 @@ struct PoolOut {
     int K;
 };
 
-// PREC 4 [r3]: the split product with BOTH operands already in memory as (h, m, l) planes (A.pl: act_split_kernel; W: w_split_kernel, plane
-// stride wps) -- the main loop copies, it neither transforms nor splits: for the few-row levels (group_all: 4 096 positions) the tiled
-// kernel is bound by the split arithmetic of its staging, repeated for every tile that shares an operand
-template <int MODE, bool W_KROW, int EPI, int WAVES_M, int WAVES_N, int TM, int TN, int PREC = 0>   // PREC: 0 fp32 MFMA, 1 bf16, 3 split (h, m, l) planes, 4 planes in memory
+template <int MODE, bool W_KROW, int EPI, int WAVES_M, int WAVES_N, int TM, int TN, int PREC = 0>   // PREC: 0 fp32 MFMA, 1 bf16, 3 split (h, m, l) planes
 __global__ __launch_bounds__(THREADS) void pos_gemm_kernel(PosOperand A, int P, const float* __restrict__ W, int N,
                                                            int Kd, float* __restrict__ C, float* __restrict__ partials,
                                                            const float* __restrict__ zprev,
                                                            const float* __restrict__ sprev,
                                                            const float* __restrict__ tprev, PoolOut po, int ldw,
-                                                           int ldc, size_t wps)
+                                                           int ldc)
 {   // ldw: row stride of W in the NN form (>= N: only the first N columns are produced); ldc: row stride of C
     constexpr int BM = WAVES_M * TM * 32;
     constexpr int BN = WAVES_N * TN * 32;
     // (these shadow the file-level constants) split planes on the 64 x 64 tile: K chunks of 64 -- the six-product chunk of 32 is over
     // before the next chunk's loads have landed, and a barrier pair per 12 MFMAs is too many
-    constexpr bool SPL = PREC >= 3, PLN = PREC == 4;
+    constexpr bool SPL = PREC == 3;
     constexpr int BK = (SPL && BM * BN <= 64 * 64) ? 64 : MP_BK;
     constexpr int TPR = BK / 4, RPP = 256 / TPR, LDK = BK + 1;
     constexpr bool BF16 = PREC != 0;
@@ -531,35 +495,11 @@ __global__ __launch_bounds__(THREADS) void pos_gemm_kernel(PosOperand A, int P, 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
 
-    Raw4<MODE> ra[PLN ? 1 : A_PASSES];
-    float4 rb[PLN ? 1 : B_PASSES];
-    bf16x4 pa[PLN ? A_PASSES : 1][3], pb[PLN ? B_PASSES : 1][3];
+    Raw4<MODE> ra[A_PASSES];
+    float4 rb[B_PASSES];
     ChanConst kc;
     const int arow = tid / TPR, acol = (tid % TPR) * 4;
-    const __bf16* Wp = reinterpret_cast<const __bf16*>(W);
     auto gload = [&](int k0) {
-        if constexpr (PLN) {
-            const bf16x4 zero4 = {(__bf16)0.0f, (__bf16)0.0f, (__bf16)0.0f, (__bf16)0.0f};
-#pragma unroll
-            for (int ps = 0; ps < A_PASSES; ++ps) {
-                const int row = m0 + ps * RPP + arow, col = k0 + acol;
-                const bool ok = row < P && col < A.C;
-                const __bf16* q = A.pl + (size_t)((unsigned)(ok ? row : 0) * (unsigned)A.C + (unsigned)(ok ? col : 0));
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl) pa[ps][pl] = ok ? *reinterpret_cast<const bf16x4*>(q + pl * A.pls) : zero4;
-            }
-#pragma unroll
-            for (int ps = 0; ps < B_PASSES; ++ps) {
-                int r_, c_, ld_;
-                bool ok;
-                if constexpr (W_KROW) { const int e = (ps * THREADS + tid) * 4; r_ = k0 + e / BN; c_ = n0 + e % BN; ld_ = ldw; ok = r_ < Kd && c_ < N; }
-                else { r_ = n0 + ps * RPP + arow; c_ = k0 + acol; ld_ = Kd; ok = r_ < N && c_ < Kd; }
-                const __bf16* q = Wp + (size_t)((unsigned)(ok ? r_ : 0) * (unsigned)ld_ + (unsigned)(ok ? c_ : 0));
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl) pb[ps][pl] = ok ? *reinterpret_cast<const bf16x4*>(q + pl * wps) : zero4;
-            }
-            return;
-        }
         load_consts<MODE>(A, k0 + acol, kc);
 #ifdef MP_ABLATE_LOAD
         if (k0 > 0) return;   // only the first chunk is really loaded
@@ -577,22 +517,6 @@ __global__ __launch_bounds__(THREADS) void pos_gemm_kernel(PosOperand A, int P, 
         }
     };
     auto sstore = [&](int buf) {
-        if constexpr (PLN) {
-#pragma unroll
-            for (int ps = 0; ps < A_PASSES; ++ps) {
-                const int o = (ps * RPP + arow) * LDA + acol;
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<bf16x4*>(&sA[buf][pl * PSA + o]) = pa[ps][pl];
-            }
-#pragma unroll
-            for (int ps = 0; ps < B_PASSES; ++ps) {
-                const int e = (ps * THREADS + tid) * 4;
-                const int o = W_KROW ? (e / BN) * LDB + e % BN : (ps * RPP + arow) * LDB + acol;
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<bf16x4*>(&sB[buf][pl * PSB + o]) = pb[ps][pl];
-            }
-            return;
-        }
 #pragma unroll
         for (int ps = 0; ps < A_PASSES; ++ps) {
             const float4 v = finish<MODE>(ra[ps], kc);
@@ -1036,21 +960,10 @@ __global__ __launch_bounds__(CO > 128 ? 512 : 256) void fwd_chunk_kernel(PosOper
     load_consts<MODE_A>(A, ca, kc);
     struct RSet { Raw4<MODE_A> a[PA]; Raw4<MODE_A> t; };
     RSet rs0, rs1;                             // (rs1: FPD2 only)
-    unsigned gs[PA], gst = 0xffffffffu;        // SRC_ID_G: source rows of the chunk that is loaded NEXT (fetched a chunk earlier)
-#pragma unroll
-    for (int ps = 0; ps < PA; ++ps) gs[ps] = 0xffffffffu;
-    auto gidx = [&](int pk) {
-        if constexpr (MODE_A == SRC_ID_G) {
-#pragma unroll
-            for (int ps = 0; ps < PA; ++ps) gs[ps] = gather_row(A, p1, pk + ka0 + ps * KA_STEP);
-            if (TAIL != 0 && tid < DBK) gst = gather_row(A, p1, pk + tid);
-        }
-    };
     auto gload = [&](int pk, RSet& rs) {
 #pragma unroll
-        for (int ps = 0; ps < PA; ++ps) raw_load<MODE_A>(A, p1, pk + ka0 + ps * KA_STEP, ca, rs.a[ps], gs[ps]);
-        if constexpr (TAIL != 0) { if (tid < DBK) raw_load<MODE_A>(A, p1, pk + tid, CI, rs.t, gst); }
-        gidx(pk + DBK);
+        for (int ps = 0; ps < PA; ++ps) raw_load<MODE_A>(A, p1, pk + ka0 + ps * KA_STEP, ca, rs.a[ps]);
+        if constexpr (TAIL != 0) { if (tid < DBK) raw_load<MODE_A>(A, p1, pk + tid, CI, rs.t); }
     };
     auto sstore = [&](int buf, RSet& rs) {
         auto& ra = rs.a;
@@ -1098,8 +1011,7 @@ __global__ __launch_bounds__(CO > 128 ? 512 : 256) void fwd_chunk_kernel(PosOper
 
     // ([r3] tried: the staggered barrier of bwd_fused_kernel's DESYNC for the 512-thread form -- 110.7 vs 111.0 us, not kept)
     // FPD2: two chunks of loads in flight (two register sets, the loop unrolled by two), as bwd_fused_kernel's PD2
-    constexpr bool FPD2 = MP_FPD2 && SPLIT && MODE_A != SRC_ID_G;
-    gidx(p0);
+    constexpr bool FPD2 = MP_FPD2 && SPLIT;
     gload(p0, rs0);
     sstore(0, rs0);
     if constexpr (FPD2) {
@@ -2069,292 +1981,6 @@ __global__ __launch_bounds__(512, 1) void bwd_roles_kernel(PosOperand DZ, PosOpe
     }
 }
 
-// [r3] Kernel 4c (experiment, MP_BF_ROLES_LDS = RS): bwd_roles_kernel<SRC_DZ_POOLED, 256> with the chunk's raw rows loaded STRAIGHT INTO LDS
-// (global_load_lds_dwordx4: 64 lanes x 16 bytes = one 1 KB row of Z_l, or two 512-byte rows of Z_{l-1}, per instruction) by the dX
-// waves, which have issue slots to spare but no registers: nothing of a chunk waits in registers any more, loads are in flight for
-// RS - 1 iterations (RS raw buffers of the dZ operand, RS + 1 of the input operand, which the dX epilogue reads one iteration after the
-// staging), and the staging (dW) waves only transform LDS -> LDS.  vmcnt is in order (loads and stores alike): before the chunk's
-// barrier a dX wave waits until everything up to the loads of chunk kc + 2 has landed, i.e. vmcnt(8 stores [+ 6 loads + 8 stores]).
-// 16 bytes per lane from global memory straight into LDS: lane i's data lands at lds_dst + 16 i (lds_dst wave-uniform: it travels in M0).
-// Inline assembly on purpose: the compiler does not see the instruction, so it neither counts it in the s_waitcnt it inserts (its own waits
-// stay sufficient: vmcnt is in order, an unknown operation in the queue only makes them wait longer) nor drains the queue before every LDS
-// read that might alias the destination (with __builtin_amdgcn_global_load_lds it put s_waitcnt vmcnt(0) in front of the epilogue's reads
-// of the buffer two stages away).  The caller orders it with explicit s_waitcnt vmcnt(N) + a barrier.
-__device__ __forceinline__ void load_lds16(const float* src, float* lds_dst)
-{
-    const unsigned l = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)lds_dst);
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(l) : "memory");
-}
-
-template <int RS>
-__global__ __launch_bounds__(512, 1) void bwd_roles_lds_kernel(PosOperand DZ, PosOperand IN, int P, int p_per_block,
-                                                               const float* __restrict__ W, float* __restrict__ dW,
-                                                               float* __restrict__ G, float* __restrict__ partials)
-{
-    constexpr int CO = 256, CI = 128, DBK = 16, GS = DBK * 8, NST = CO / 32, TMW = 4, TNW = 2;
-    constexpr int PA = 4, PB = 2, KA_STEP = 4, KB_STEP = 8;             // staging by the four dW waves
-    constexpr int MODE_DZ = SRC_DZ_POOLED, MODE_IN = SRC_ACT;
-    static_assert(RS == 2 || RS == 3, "raw stages");
-    __shared__ __attribute__((aligned(16))) __bf16 hA[2][3][(CO / 8) * GS];
-    __shared__ __attribute__((aligned(16))) __bf16 hB[2][3][(CI / 8) * GS];
-    __shared__ __attribute__((aligned(16))) float rawZ[RS][DBK * CO];
-    __shared__ __attribute__((aligned(16))) float rawI[RS + 1][DBK * CI];
-    __shared__ float red[2][CI];
-    __shared__ float4 sKA[5][CO / 4];
-    __shared__ float4 sKB[2][CI / 4];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool role_dx = wave < 4;
-    const int p0 = blockIdx.x * p_per_block;
-    const int p1 = min(P, p0 + p_per_block);
-    const int nchunks = (p1 - p0 + DBK - 1) / DBK;
-    if (nchunks <= 0) return;
-    typedef float f32x4 __attribute__((ext_vector_type(4)));
-    typedef float f2 __attribute__((ext_vector_type(2)));
-    constexpr int VM_STEADY = 8 + (RS - 2) * (6 + 8);                   // operations a dX wave issues behind the loads it waits for
-    constexpr int WAIT_STEADY = (VM_STEADY & 15) | (7 << 4) | (15 << 8) | ((VM_STEADY >> 4) << 14);   // s_waitcnt vmcnt(VM_STEADY) only
-    constexpr int WAIT_ALL = (0 & 15) | (7 << 4) | (15 << 8) | (0 << 14);                            // s_waitcnt vmcnt(0)
-
-    if (role_dx) {
-        // ================= waves 0..3: loads of the raw chunks into LDS; G_{l-1} chunk = dZ * W_l, 32 columns per wave ==============
-        const int l15 = lane & 15, kq = lane >> 4;
-        const int xcol0 = wave * 32;
-        auto issue = [&](int c) {      // chunk c -> rawZ[c % RS], rawI[c % (RS + 1)]; rows past the end re-read row p0 (staged as zeros)
-            const int pk = p0 + c * DBK;
-            float* dz = rawZ[c % RS];
-            float* di = rawI[c % (RS + 1)];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int r = wave + 4 * j, pr = pk + r;
-                const float* src = DZ.x + (size_t)((unsigned)(pr < p1 ? pr : p0) * (unsigned)CO) + lane * 4;
-                load_lds16(src, dz + r * CO);
-            }
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int r2 = 2 * (wave + 4 * j), pr = pk + r2 + (lane >> 5);
-                const float* src = IN.x + (size_t)((unsigned)(pr < p1 ? pr : p0) * (unsigned)CI) + (lane & 31) * 4;
-                load_lds16(src, di + r2 * CI);
-            }
-        };
-#pragma unroll
-        for (int c = 0; c < RS; ++c)
-            if (c < nchunks) issue(c);
-        bf16x8 wsp[2][NST][3];                         // lane (col, kq) holds W[32 st + 8 kq .. + 7][col] as (h, m, l) planes
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int st = 0; st < NST; ++st) {
-                const float* wp = W + (size_t)(32 * st + 8 * kq) * CI + xcol0 + 16 * h + l15;
-                const Split4 lo = split3(make_float4(wp[0], wp[CI], wp[2 * CI], wp[3 * CI]));
-                const Split4 hi = split3(make_float4(wp[4 * CI], wp[5 * CI], wp[6 * CI], wp[7 * CI]));
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    wsp[h][st][0][i] = lo.h[i]; wsp[h][st][0][4 + i] = hi.h[i];
-                    wsp[h][st][1][i] = lo.m[i]; wsp[h][st][1][4 + i] = hi.m[i];
-                    wsp[h][st][2][i] = lo.l[i]; wsp[h][st][2][4 + i] = hi.l[i];
-                }
-            }
-        float spx[2], tpx[2];
-        f2 sx1[2], sx2[2];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int col = xcol0 + 16 * h + l15;
-            spx[h] = IN.s[col];
-            tpx[h] = IN.t[col];
-            sx1[h] = f2{0.0f, 0.0f};
-            sx2[h] = f2{0.0f, 0.0f};
-        }
-        const __amdgpu_buffer_rsrc_t grsrc = __builtin_amdgcn_make_buffer_rsrc(G + (size_t)p0 * CI, 0, (p1 - p0) * CI * 4, 0x00020000);
-        int goff = ((4 * kq) * CI + xcol0 + l15) * 4;
-        __builtin_amdgcn_s_waitcnt(WAIT_ALL);          // the first RS chunks have landed
-        __syncthreads();                               // B0: raw chunks 0 .. RS-1 + the staging constants
-        __syncthreads();                               // B1: chunk 0 staged
-        for (int kc = 0; kc < nchunks; ++kc) {
-            const int cur = kc & 1;
-            const bool more = kc + RS < nchunks;
-            if (more) issue(kc + RS);
-            f32x4 ax[2], cx[2];
-#pragma unroll
-            for (int h = 0; h < 2; ++h) { ax[h] = f32x4{0.f, 0.f, 0.f, 0.f}; cx[h] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-            const int ao = kq * GS + (l15 ^ kswz(kq)) * 8;
-            bf16x8 af[2][3];
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl) af[0][pl] = *reinterpret_cast<const bf16x8*>(&hA[cur][pl][ao]);
-#pragma unroll
-            for (int st = 0; st < NST; ++st) {
-                if (st + 1 < NST) {
-#pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) af[(st + 1) & 1][pl] = *reinterpret_cast<const bf16x8*>(&hA[cur][pl][ao + 4 * (st + 1) * GS]);
-                }
-                const bf16x8 ah = af[st & 1][0], am = af[st & 1][1], al = af[st & 1][2];
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    cx[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, wsp[h][st][0], cx[h], 0, 0, 0);
-                    ax[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wsp[h][st][0], ax[h], 0, 0, 0);
-                    cx[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wsp[h][st][2], cx[h], 0, 0, 0);
-                    cx[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, wsp[h][st][1], cx[h], 0, 0, 0);
-                    cx[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, wsp[h][st][0], cx[h], 0, 0, 0);
-                    cx[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wsp[h][st][1], cx[h], 0, 0, 0);
-                }
-            }
-            const float* zi = rawI[kc % (RS + 1)];
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                ax[h] += cx[h];
-                const float* zr = zi + (4 * kq) * CI + xcol0 + 16 * h + l15;
-#pragma unroll
-                for (int i = 0; i < 4; i += 2) {
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ax[h][i]), grsrc, goff + 16 * h * 4, i * CI * 4, MP_STORE_AUX);
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ax[h][i + 1]), grsrc, goff + 16 * h * 4, (i + 1) * CI * 4, MP_STORE_AUX);
-                    const f2 zp = {zr[i * CI], zr[(i + 1) * CI]};
-                    const f2 y = zp * f2{spx[h], spx[h]} + f2{tpx[h], tpx[h]};
-                    const f2 dy = {y.x > 0.0f ? ax[h][i] : 0.0f, y.y > 0.0f ? ax[h][i + 1] : 0.0f};
-                    sx1[h] += dy;
-                    sx2[h] += dy * zp;
-                }
-            }
-            goff += DBK * CI * 4;
-            // chunk kc + 2 is staged during the next iteration: its rows must be in LDS behind this barrier
-            if (more) __builtin_amdgcn_s_waitcnt(WAIT_STEADY); else __builtin_amdgcn_s_waitcnt(WAIT_ALL);
-            __syncthreads();
-        }
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            float s1x = sx1[h].x + sx1[h].y, s2x = sx2[h].x + sx2[h].y;
-            s1x += __shfl_xor(s1x, 16, 64); s1x += __shfl_xor(s1x, 32, 64);
-            s2x += __shfl_xor(s2x, 16, 64); s2x += __shfl_xor(s2x, 32, 64);
-            if (lane < 16) {
-                red[0][xcol0 + 16 * h + lane] = s1x;
-                red[1][xcol0 + 16 * h + lane] = s2x;
-            }
-        }
-    } else {
-        // ================= waves 4..7: staging LDS -> LDS and dW [256 x 128] += dZ^T * act(Z_{l-1}) ================================
-        if constexpr (MP_ROLES_PRIO == 1) __builtin_amdgcn_s_setprio(2);
-        const int w = wave - 4, l31 = lane & 31;
-        const int wrow0 = (w >> 1) * (CO / 2), wcol0 = (w & 1) * 64;
-        const int ca = w * 64 + 4 * (lane & 15), ka0 = lane >> 4;
-        const int cb = (w & 1) * 64 + 4 * (lane & 15), kb0 = (w >> 1) * 4 + (lane >> 4);
-        {
-            ChanConst ka, kb;
-            load_consts<MODE_DZ>(DZ, ca, ka);
-            load_consts<MODE_IN>(IN, cb, kb);
-            sKA[0][ca >> 2] = ka.s; sKA[1][ca >> 2] = ka.t; sKA[2][ca >> 2] = ka.a; sKA[3][ca >> 2] = ka.e; sKA[4][ca >> 2] = ka.f;
-            sKB[0][cb >> 2] = kb.s; sKB[1][cb >> 2] = kb.t;
-        }
-        f32x16 accW[TMW][TNW];
-#pragma unroll
-        for (int mi = 0; mi < TMW; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < TNW; ++ni)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) accW[mi][ni][r] = 0.0f;
-        float4 pg;          // pooled gradient / arg-max of this thread's four channels for the chunk that is staged next (one group per chunk)
-        int4 pak;
-        auto gload_g = [&](int c) {
-            const unsigned off = ((unsigned)(p0 + c * DBK) >> DZ.kshift) * (unsigned)CO + (unsigned)ca;
-            pg = ld4(DZ.g + off);
-            pak = *reinterpret_cast<const int4*>(DZ.argk + off);
-        };
-        auto stage = [&](int c) {      // raw chunk c (LDS) -> plane buffer c & 1
-            const int buf = c & 1, pk = p0 + c * DBK;
-            const float* rz = rawZ[c % RS];
-            const float* ri = rawI[c % (RS + 1)];
-            ChanConst ka, kb;
-            ka.s = sKA[0][ca >> 2]; ka.t = sKA[1][ca >> 2]; ka.a = sKA[2][ca >> 2]; ka.e = sKA[3][ca >> 2]; ka.f = sKA[4][ca >> 2];
-            kb.s = sKB[0][cb >> 2]; kb.t = sKB[1][cb >> 2];
-            const int kk0 = pk & (DZ.K - 1);
-#pragma unroll
-            for (int ps = 0; ps < PA; ++ps) {
-                const int row = ka0 + ps * KA_STEP, kk = kk0 + row;
-                const float4 z = *reinterpret_cast<const float4*>(rz + row * CO + ca);
-                float4 dz;
-                dz.x = xf1<MODE_DZ>(z.x, pak.x == kk ? pg.x : 0.0f, ka.s.x, ka.t.x, ka.a.x, ka.e.x, ka.f.x);
-                dz.y = xf1<MODE_DZ>(z.y, pak.y == kk ? pg.y : 0.0f, ka.s.y, ka.t.y, ka.a.y, ka.e.y, ka.f.y);
-                dz.z = xf1<MODE_DZ>(z.z, pak.z == kk ? pg.z : 0.0f, ka.s.z, ka.t.z, ka.a.z, ka.e.z, ka.f.z);
-                dz.w = xf1<MODE_DZ>(z.w, pak.w == kk ? pg.w : 0.0f, ka.s.w, ka.t.w, ka.a.w, ka.e.w, ka.f.w);
-                if (pk + row >= p1) dz = make_float4(0.f, 0.f, 0.f, 0.f);
-                const Split4 sp = split3(dz);
-                const int o = (ca >> 3) * GS + (row ^ kswz(ca >> 3)) * 8 + (ca & 7);
-                *reinterpret_cast<bf16x4*>(&hA[buf][0][o]) = sp.h;
-                *reinterpret_cast<bf16x4*>(&hA[buf][1][o]) = sp.m;
-                *reinterpret_cast<bf16x4*>(&hA[buf][2][o]) = sp.l;
-            }
-#pragma unroll
-            for (int ps = 0; ps < PB; ++ps) {
-                const int row = kb0 + ps * KB_STEP;
-                const float4 z = *reinterpret_cast<const float4*>(ri + row * CI + cb);
-                float4 a;
-                a.x = xf1<MODE_IN>(z.x, 0.f, kb.s.x, kb.t.x, 0.f, 0.f, 0.f);
-                a.y = xf1<MODE_IN>(z.y, 0.f, kb.s.y, kb.t.y, 0.f, 0.f, 0.f);
-                a.z = xf1<MODE_IN>(z.z, 0.f, kb.s.z, kb.t.z, 0.f, 0.f, 0.f);
-                a.w = xf1<MODE_IN>(z.w, 0.f, kb.s.w, kb.t.w, 0.f, 0.f, 0.f);
-                if (pk + row >= p1) a = make_float4(0.f, 0.f, 0.f, 0.f);
-                const Split4 sp = split3(a);
-                const int oh = (cb >> 3) * GS + (row ^ kswz(cb >> 3)) * 8 + (cb & 7);
-                *reinterpret_cast<bf16x4*>(&hB[buf][0][oh]) = sp.h;
-                *reinterpret_cast<bf16x4*>(&hB[buf][1][oh]) = sp.m;
-                *reinterpret_cast<bf16x4*>(&hB[buf][2][oh]) = sp.l;
-            }
-        };
-        gload_g(0);
-        __syncthreads();                               // B0
-        stage(0);
-        __syncthreads();                               // B1
-        for (int kc = 0; kc < nchunks; ++kc) {
-            const int cur = kc & 1;
-            if (kc + 1 < nchunks) gload_g(kc + 1);
-            bf16x8 fb[3][TNW], fa[TMW];
-#pragma unroll
-            for (int ni = 0; ni < TNW; ++ni) fb[0][ni] = tr_frag_packed<GS, true>(hB[cur][0], 0, wcol0 + ni * 32);
-#pragma unroll
-            for (int mi = 0; mi < TMW; ++mi) fa[mi] = tr_frag_packed<GS, true>(hA[cur][2], 0, wrow0 + mi * 32);
-#pragma unroll
-            for (int mi = 0; mi < TMW; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < TNW; ++ni) accW[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mi], fb[0][ni], accW[mi][ni], 0, 0, 0);
-#pragma unroll
-            for (int mi = 0; mi < TMW; ++mi) fa[mi] = tr_frag_packed<GS, true>(hA[cur][0], 0, wrow0 + mi * 32);
-#pragma unroll
-            for (int pl = 2; pl >= 1; --pl)
-#pragma unroll
-                for (int ni = 0; ni < TNW; ++ni) fb[pl][ni] = tr_frag_packed<GS, true>(hB[cur][pl], 0, wcol0 + ni * 32);
-#pragma unroll
-            for (int pl = 2; pl >= 0; --pl)
-#pragma unroll
-                for (int mi = 0; mi < TMW; ++mi)
-#pragma unroll
-                    for (int ni = 0; ni < TNW; ++ni) accW[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mi], fb[pl][ni], accW[mi][ni], 0, 0, 0);
-#pragma unroll
-            for (int mi = 0; mi < TMW; ++mi) fa[mi] = tr_frag_packed<GS, true>(hA[cur][1], 0, wrow0 + mi * 32);
-#pragma unroll
-            for (int pl = 1; pl >= 0; --pl)
-#pragma unroll
-                for (int mi = 0; mi < TMW; ++mi)
-#pragma unroll
-                    for (int ni = 0; ni < TNW; ++ni) accW[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mi], fb[pl][ni], accW[mi][ni], 0, 0, 0);
-            if (kc + 1 < nchunks) stage(kc + 1);
-            __syncthreads();
-        }
-#pragma unroll
-        for (int mi = 0; mi < TMW; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < TNW; ++ni) {
-                const int col = wcol0 + ni * 32 + l31;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = wrow0 + mi * 32 + acc_row_in_tile(r);
-                    atomicAdd(dW + (size_t)(row * CI + col), accW[mi][ni][r]);
-                }
-            }
-    }
-    __syncthreads();
-    for (int e = tid; e < 2 * CI; e += 512) {
-        const int st = e / CI, c = e - st * CI;
-        partials[((size_t)blockIdx.x * 2 + st) * CI + c] = red[st][c];
-    }
-}
-
 // BatchNorm statistics of a RECOMPUTED first layer (SRC_*_RC): per workgroup the sums of z and z^2 of its positions, in the
 // partials layout of the GEMM epilogues ([block][2][C]) -- the layer's forward pass is this kernel and nothing else.
 // A wave loads 64 input rows with one coalesced access (lane i: position base + i) and every lane (= channel) walks them
@@ -2479,23 +2105,12 @@ __global__ __launch_bounds__(512) void bwd_first_kernel(PosOperand DZ, PosOperan
         brow[0] = ka0; bcol[0] = ca;
         brow[1] = tid & 15; bcol[1] = CIX;
     }
-    unsigned gs[PB];                           // SRC_ID_G: source rows of the chunk that is loaded next (fetched a chunk earlier)
-#pragma unroll
-    for (int ps = 0; ps < PB; ++ps) gs[ps] = 0xffffffffu;
-    auto gidx = [&](int pk) {
-        if constexpr (MODE_IN == SRC_ID_G) {
-#pragma unroll
-            for (int ps = 0; ps < PB; ++ps)
-                if (SPLIT ? (ps == 0 || tid < DBK) : (ps * NT + tid < NB4)) gs[ps] = gather_row(IN, p1, pk + brow[ps]);
-        }
-    };
     auto gload = [&](int pk) {
 #pragma unroll
         for (int ps = 0; ps < PA; ++ps) raw_load<MODE_DZ>(DZ, p1, pk + ka0 + ps * KA_STEP, ca, ra[ps]);
 #pragma unroll
         for (int ps = 0; ps < PB; ++ps)
-            if (SPLIT ? (ps == 0 || tid < DBK) : (ps * NT + tid < NB4)) raw_load<MODE_IN>(IN, p1, pk + brow[ps], bcol[ps], rb[ps], gs[ps]);
-        gidx(pk + DBK);
+            if (SPLIT ? (ps == 0 || tid < DBK) : (ps * NT + tid < NB4)) raw_load<MODE_IN>(IN, p1, pk + brow[ps], bcol[ps], rb[ps]);
     };
     auto sstore = [&](int buf) {
 #pragma unroll
@@ -2526,7 +2141,6 @@ __global__ __launch_bounds__(512) void bwd_first_kernel(PosOperand DZ, PosOperan
         }
     };
 
-    gidx(p0);
     gload(p0);
     sstore(0);
     __syncthreads();
@@ -2959,74 +2573,10 @@ __global__ __launch_bounds__(256) void pool_bwd_prep_kernel(const float* __restr
     partials[((int64_t)blockIdx.x * 2 + 1) * C + c] = s2;
 }
 
-// [r3] an operand AFTER its transform (BatchNorm + ReLU, or the dZ algebra) as three bf16 planes [3][P][C]: one pass per operand instead of
-// one split per tile that shares it (pos_gemm_kernel / dw_gemm_kernel PREC 4)
-template <int MODE>
-__global__ __launch_bounds__(256) void act_split_kernel(PosOperand A, int P, __bf16* __restrict__ out, size_t pls)
-{
-    const int q = A.C >> 2;
-    const unsigned i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= (unsigned)P * (unsigned)q) return;
-    const int p = (int)(i / (unsigned)q), c = (int)(i - (unsigned)p * (unsigned)q) * 4;
-    ChanConst k;
-    load_consts<MODE>(A, c, k);
-    Raw4<MODE> r;
-    raw_load<MODE>(A, P, p, c, r);
-    const Split4 sp = split3(finish<MODE>(r, k));
-    __bf16* o = out + (size_t)i * 4;
-    *reinterpret_cast<bf16x4*>(o) = sp.h;
-    *reinterpret_cast<bf16x4*>(o + pls) = sp.m;
-    *reinterpret_cast<bf16x4*>(o + 2 * pls) = sp.l;
-}
-
-__global__ __launch_bounds__(256) void w_split_kernel(const float* __restrict__ W, unsigned n4, __bf16* __restrict__ out, size_t pls)
-{
-    const unsigned i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= n4) return;
-    const Split4 sp = split3(ld4(W + (size_t)i * 4));
-    __bf16* o = out + (size_t)i * 4;
-    *reinterpret_cast<bf16x4*>(o) = sp.h;
-    *reinterpret_cast<bf16x4*>(o + pls) = sp.m;
-    *reinterpret_cast<bf16x4*>(o + 2 * pls) = sp.l;
-}
-
-// scratch for the planes of one call (carved from the caller's workspace by sa_mlp_fwd / sa_mlp_bwd; null: the planes route is off)
-struct PlanesWs { __bf16* a; __bf16* b; __bf16* w; };
-// MP_PLANES=1 (experiment, forward only, off): measured on the group_all level -- the products themselves 45 -> 41, 19 -> 17, 17.5 -> 15.5 us
-// with NOTHING but copies in their main loops, against 6 extra launches (3 x act_split ~8 us, 3 x w_split ~7.5 us): +34 us per step.  The
-// tiled kernels of the few-row levels are not bound by their split arithmetic: a 128 x 64 tile's K loop is 16 iterations of one global
-// round trip each (one chunk prefetched in registers, one LDS buffer, 24 MFMAs per wave and chunk).
-inline bool planes_enabled()
-{
-    static const bool on = getenv("MP_PLANES") && atoi(getenv("MP_PLANES")) != 0;
-    return on;
-}
-constexpr int64_t PLANES_MAX_P = 16384;       // the route pays where tiles re-split shared operands and the extra passes are small: few-row levels
-
-template <int MODE>
-int launch_act_split(PosOperand& A, int64_t P, __bf16* out, hipStream_t stream)
-{
-    const size_t pls = (size_t)P * (size_t)A.C;
-    const unsigned n = (unsigned)(pls / 4);
-    char tag[48];
-    snprintf(tag, sizeof tag, "act_split_kernel<%d>", MODE);
-    MP_LAUNCH(tag, 0.0, (4.0 * (MODE == SRC_DZ ? 2.0 : 1.0) + 6.0) * (double)pls, (act_split_kernel<MODE>), dim3((n + 255) / 256), dim3(256), 0, stream, A, (int)P, out, pls);
-    MP_CHECK_LAUNCH();
-    A.pl = out;
-    A.pls = pls;
-    return MP_OK;
-}
-inline int launch_w_split(const float* W, size_t n, __bf16* out, hipStream_t stream)
-{
-    MP_LAUNCH("w_split_kernel", 0.0, 10.0 * (double)n, w_split_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, stream, W, (unsigned)(n / 4), out, n);
-    MP_CHECK_LAUNCH();
-    return MP_OK;
-}
-
 template <int MODE, bool W_KROW, int EPI, int PREC = 0>
 int launch_pos_gemm(const PosOperand& A, int64_t P, const float* W, int N, int Kd, float* C, float* partials,
                     const float* zprev, const float* sprev, const float* tprev, hipStream_t stream, int* nblk_out,
-                    PoolOut po = PoolOut{}, int ldw = 0, int ldc = 0, size_t wps = 0)
+                    PoolOut po = PoolOut{}, int ldw = 0, int ldc = 0)
 {
     if (ldw == 0) ldw = N;
     if (ldc == 0) ldc = N;
@@ -3043,31 +2593,29 @@ int launch_pos_gemm(const PosOperand& A, int64_t P, const float* W, int N, int K
     if (shape == 0 && t128 < 384) shape = (t128x64 >= 384 || EPI == EPI_SQ_POOL) ? 1 : 2;
     if (shape == 1 && N > 64 && EPI != EPI_SQ_POOL && t128x64 < 384) shape = 2;
     // (split planes, [r2]: 64 x 64 tiles on all CUs run at 66-80 TFLOP/s on the group_all level; 128 x 128 tiles on half of them were
-    // tried -- MP_POS_BIG_MIN=128 -- and are slower: 55 -> 93 us, one workgroup's K loop alone does not cover its load latency)
-    static const int big_min = getenv("MP_POS_BIG_MIN") ? atoi(getenv("MP_POS_BIG_MIN")) : (1 << 30);
-    if (PREC >= 3 && shape == 2 && t128 >= big_min) shape = 0;
+    // slower: 55 -> 93 us, one workgroup's K loop alone does not cover its load latency)
     char tag[96];
-    const char* kn = PREC == 1 ? "pos_gemm_bf16_kernel" : (PREC == 3 ? "pos_gemm_split_kernel" : (PREC == 4 ? "pos_gemm_planes_kernel" : "pos_gemm_kernel"));
+    const char* kn = PREC == 1 ? "pos_gemm_bf16_kernel" : (PREC == 3 ? "pos_gemm_split_kernel" : "pos_gemm_kernel");
     if (shape == 1) {
         const unsigned gm = (unsigned)((P + 127) / 128);
         if (nblk_out) *nblk_out = (int)gm;
         snprintf(tag, sizeof tag, "%s<%d, %s, %d, 4, 1, 1, 2>", kn, MODE, W_KROW ? "true" : "false", EPI);
         MP_LAUNCH(tag, flops, bytes, (pos_gemm_kernel<MODE, W_KROW, EPI, 4, 1, 1, 2, PREC>), dim3(gm, (N + 63) / 64),
-                  dim3(THREADS), 0, stream, A, (int)P, W, N, Kd, C, partials, zprev, sprev, tprev, po, ldw, ldc, wps);
+                  dim3(THREADS), 0, stream, A, (int)P, W, N, Kd, C, partials, zprev, sprev, tprev, po, ldw, ldc);
     } else if (shape == 2) {
         if constexpr (EPI != EPI_SQ_POOL) {
             const unsigned gm = (unsigned)((P + 63) / 64);
             if (nblk_out) *nblk_out = (int)gm;
             snprintf(tag, sizeof tag, "%s<%d, %s, %d, 2, 2, 1, 1>", kn, MODE, W_KROW ? "true" : "false", EPI);
             MP_LAUNCH(tag, flops, bytes, (pos_gemm_kernel<MODE, W_KROW, EPI, 2, 2, 1, 1, PREC>), dim3(gm, (N + 63) / 64),
-                      dim3(THREADS), 0, stream, A, (int)P, W, N, Kd, C, partials, zprev, sprev, tprev, po, ldw, ldc, wps);
+                      dim3(THREADS), 0, stream, A, (int)P, W, N, Kd, C, partials, zprev, sprev, tprev, po, ldw, ldc);
         }
     } else {
         const unsigned gm = (unsigned)((P + 127) / 128);
         if (nblk_out) *nblk_out = (int)gm;
         snprintf(tag, sizeof tag, "%s<%d, %s, %d, 2, 2, 2, 2>", kn, MODE, W_KROW ? "true" : "false", EPI);
         MP_LAUNCH(tag, flops, bytes, (pos_gemm_kernel<MODE, W_KROW, EPI, 2, 2, 2, 2, PREC>), dim3(gm, (N + 127) / 128),
-                  dim3(THREADS), 0, stream, A, (int)P, W, N, Kd, C, partials, zprev, sprev, tprev, po, ldw, ldc, wps);
+                  dim3(THREADS), 0, stream, A, (int)P, W, N, Kd, C, partials, zprev, sprev, tprev, po, ldw, ldc);
     }
     MP_CHECK_LAUNCH();
     return MP_OK;
@@ -3092,39 +2640,15 @@ inline bool split_enabled()
     return on;
 }
 
-// workgroups the position-stream forward aims for (MP_FWD_WGS, experiments): positions per workgroup halve from 1024 until there are that many
+// workgroups the position-stream forward aims for: positions per workgroup halve from 1024 until there are that many
 // [r2] same-box sweep: 512 for most shapes; the 256-output kernel (512 threads, one workgroup per CU) is best with one round of 256, the
 // HBM-bound 64 -> 64 layer with 2048 small workgroups
-inline int fwd_wgs_wanted(int dflt = 512)
-{
-    static const int n = getenv("MP_FWD_WGS") ? atoi(getenv("MP_FWD_WGS")) : 0;
-    return n > 0 ? n : dflt;
-}
+inline int fwd_wgs_wanted(int dflt = 512) { return dflt; }
 
 inline bool chunk_fwd_enabled()
 {
     static const bool on = !(getenv("MP_CHUNK_FWD") && atoi(getenv("MP_CHUNK_FWD")) == 0);
     return on;
-}
-
-// MP_BF_ROLES (bit mask; bit 0: the 256-output layer, bit 1: 128 -> 128): the fused backward with dX and dW on different waves (bwd_roles_kernel)
-#ifndef MP_BF_ROLES_DEFAULT
-#define MP_BF_ROLES_DEFAULT 1       // the 256-output layer: 248 -> 212 us (slow box) / 235 -> 200; 128 -> 128: 127 -> 132, stays on bwd_fused_kernel
-#endif
-inline int roles_mask()
-{
-    static const int m = getenv("MP_BF_ROLES") ? atoi(getenv("MP_BF_ROLES")) : MP_BF_ROLES_DEFAULT;
-    return m;
-}
-
-// MP_BF_ROLES_LDS = 2 | 3: the role-split kernel of the pooled 256-output layer with its raw chunks loaded straight into LDS (bwd_roles_lds_kernel<RS>)
-#ifndef MP_BF_ROLES_LDS_DEFAULT
-#define MP_BF_ROLES_LDS_DEFAULT 0
-#endif
-inline int roles_lds()
-{
-    static const int m = getenv("MP_BF_ROLES_LDS") ? atoi(getenv("MP_BF_ROLES_LDS")) : MP_BF_ROLES_LDS_DEFAULT;
-    return m;
 }
 
 // MP_FUSED_BWD=0 keeps the separate dX / dW kernels for the single-tile layers (A/B timing)
@@ -3148,36 +2672,11 @@ extern "C" int mp_debug_roles_times(unsigned long long* host_out)      // [2][8]
 }
 #endif
 
-// the planes route's scratch (PREC 4: few-row levels): operand planes [3][P][cmax] bf16 (two of them in backward: dZ and the layer input)
-// and the weight planes [3][max Co * Ci]; carved behind everything else
-static size_t planes_bytes(int64_t P, int n_layers, const int64_t* channels, int backward, size_t* op_bytes = nullptr)
-{
-    if (P > PLANES_MAX_P || !planes_enabled()) return 0;
-    int64_t cmax = 0, wmax = 0;
-    for (int l = 0; l <= n_layers; ++l) cmax = channels[l] > cmax ? channels[l] : cmax;
-    for (int l = 0; l < n_layers; ++l) wmax = channels[l] * channels[l + 1] > wmax ? channels[l] * channels[l + 1] : wmax;
-    const size_t op = align_up((size_t)3 * (size_t)P * (size_t)cmax * sizeof(__bf16), 256);
-    if (op_bytes) *op_bytes = op;
-    return (backward ? 2 : 1) * op + align_up((size_t)3 * (size_t)wmax * sizeof(__bf16), 256);
-}
 static size_t ws_core_bytes(int64_t P, int64_t K, int n_layers, const int64_t* channels, int backward);
-static PlanesWs planes_ws(void* workspace, int64_t P, int64_t K, int n_layers, const int64_t* channels, int backward)
-{
-    PlanesWs ws{nullptr, nullptr, nullptr};
-    size_t op = 0;
-    if (!planes_bytes(P, n_layers, channels, backward, &op)) return ws;
-    unsigned char* w = reinterpret_cast<unsigned char*>(workspace) + ws_core_bytes(P, K, n_layers, channels, backward);
-    ws.a = reinterpret_cast<__bf16*>(w);
-    w += op;
-    if (backward) { ws.b = reinterpret_cast<__bf16*>(w); w += op; }
-    ws.w = reinterpret_cast<__bf16*>(w);
-    return ws;
-}
-
 extern "C" size_t mp_sa_mlp_workspace_bytes(int64_t P, int64_t K, int n_layers, const int64_t* channels, int backward)
 {
     if (P <= 0 || n_layers <= 0 || !channels) return 0;
-    return ws_core_bytes(P, K, n_layers, channels, backward) + planes_bytes(P, n_layers, channels, backward);
+    return ws_core_bytes(P, K, n_layers, channels, backward);
 }
 
 static size_t ws_core_bytes(int64_t P, int64_t K, int n_layers, const int64_t* channels, int backward)
@@ -3191,23 +2690,8 @@ static size_t ws_core_bytes(int64_t P, int64_t K, int n_layers, const int64_t* c
     if (backward) {
         bytes += 2 * align_up((size_t)P * (size_t)cmax * sizeof(float), 256);            // G ping-pong
         bytes += align_up((size_t)(P / (K > 0 ? K : 1)) * (size_t)channels[n_layers] * sizeof(float), 256);  // gp
-        if (n_layers > 1 && K > 0 && mp::lean_supported(P, K, channels[n_layers], channels[n_layers - 1]))
-            bytes += mp::lean_workspace_bytes(P, K, channels[n_layers], channels[n_layers - 1]);                   // lean pooled layer
     }
     return bytes;
-}
-
-// Can the pooled (last) layer of this chain run without its stored activation (layers[n_layers - 1].z = NULL in forward AND
-// backward; sa_lean.hip)?  Needs the position-stream kernels with split planes, a fused pool (K in {32, 64, 128}) and one of the
-// shapes the lean backward kernel is built for.  MP_LEAN_LAST=0 switches it off.
-extern "C" int mp_sa_mlp_lean_last(int n_layers, const int64_t* channels, int64_t K, int64_t P)
-{
-    if (!channels || n_layers < 2 || K <= 0 || P <= 0) return 0;
-    if (!chunk_fwd_enabled() || !fused_bwd_enabled() || !split_enabled()) return 0;
-    if (!(K == 32 || K == 64 || K == 128) || (1024 % K) != 0) return 0;
-    const int64_t Co = channels[n_layers], Ci = channels[n_layers - 1];
-    if (n_layers == 2 && channels[0] == 4) return 0;      // (layer L-1 must have a stored activation: not the recomputed first layer)
-    return mp::lean_supported(P, K, Co, Ci) ? 1 : 0;
 }
 
 // Can the first layer of this chain be recomputed instead of stored (layers[0].z = NULL in forward AND backward)?  Yes for a
@@ -3503,20 +2987,6 @@ static bool factored_ok(const mp_gather_t* g, int64_t P, int64_t K, int n_layers
     return true;
 }
 
-static bool gather_ok(const mp_gather_t* g, int64_t P, int64_t K, int n_layers, const mp_mlp_layer_t* layers, bool bf16)
-{
-    if (!g || !g->feats || !g->xyz || !g->new_xyz || !g->idx || g->N <= 0 || g->S <= 0) return false;
-    if (bf16 || n_layers < 2 || g->CF != 128 || layers[0].c_in != 132 || layers[0].c_out != 128) return false;
-    if (P % (g->S * K) != 0 || !chunk_fwd_enabled() || !fused_bwd_enabled()) return false;
-    return true;
-}
-static void set_gather(PosOperand& o, const mp_gather_t* g, int64_t K)
-{
-    o.gf = g->feats; o.gxyz = g->xyz; o.gnew = g->new_xyz; o.gidx = g->idx;
-    o.gN = (int)g->N; o.gS = (int)g->S; o.gCF = (int)g->CF;
-    o.gshift = log2_or_neg(g->S * K);
-}
-
 #define MP_POS_GEMM(MODE, KROW, EPI, ...)                                                                          \
     (bf16 ? launch_pos_gemm<MODE, KROW, EPI, 1>(__VA_ARGS__)                                                      \
           : (split_enabled() ? launch_pos_gemm<MODE, KROW, EPI, 3>(__VA_ARGS__) : launch_pos_gemm<MODE, KROW, EPI, 0>(__VA_ARGS__)))
@@ -3528,18 +2998,6 @@ static void set_gather(PosOperand& o, const mp_gather_t* g, int64_t K)
 // same position-stream kernels as the fp32 path with ONE operand plane instead of three (fwd_chunk / bwd_fused <..., ONE>), the
 // recomputed and the factorised first layers included (their VALU products on rounded operands: rb16); widths outside those
 // kernels take the generic tiled kernels.  Everything else as in fp32.
-// one forward layer of a few-row level on the planes route: the layer input (after BatchNorm + ReLU) and the weight pre-split, then the
-// tiled product with nothing but copies in its main loop
-template <int MODE, int EPI>
-static int fwd_planes(PosOperand A, int64_t P, const mp_mlp_layer_t& L, float* partials, hipStream_t stream, int* nblk, PoolOut po, const PlanesWs& ws)
-{
-    const size_t wn = (size_t)L.c_out * (size_t)L.c_in;
-    if (int rc = launch_act_split<MODE>(A, P, ws.a, stream)) return rc;
-    if (int rc = launch_w_split(L.weight, wn, ws.w, stream)) return rc;
-    return launch_pos_gemm<MODE, false, EPI, 4>(A, P, reinterpret_cast<const float*>(ws.w), (int)L.c_out, (int)L.c_in, L.z, partials, nullptr, nullptr,
-                                                nullptr, stream, nblk, po, 0, 0, wn);
-}
-
 static int sa_mlp_fwd(const float* x0, int64_t P, int64_t K, int n_layers, const mp_mlp_layer_t* layers,
                       int training, double momentum, double eps, float* out, int32_t* argk, float* zmax,
                       void* workspace, size_t workspace_bytes, mp_stream_t stream_, bool bf16, const mp_syncbn_t* sync,
@@ -3551,7 +3009,7 @@ static int sa_mlp_fwd(const float* x0, int64_t P, int64_t K, int n_layers, const
     if (P == 0) return MP_OK;
     if ((!x0 && !gather) || !out || !argk || !zmax || !workspace || (P % K) != 0) return MP_EINVAL;
     const bool factored = gather && factored_ok(gather, P, K, n_layers, layers, bf16);
-    if (gather && !factored && !gather_ok(gather, P, K, n_layers, layers, bf16)) return MP_EUNSUPPORTED;
+    if (gather && !factored) return MP_EUNSUPPORTED;      // the gather descriptor carries the factorised first layer only
     if (n_layers > 8 || P > ((int64_t)1 << 31)) return MP_EUNSUPPORTED;
     int64_t ch[9];
     ch[0] = layers[0].c_in;
@@ -3568,8 +3026,7 @@ static int sa_mlp_fwd(const float* x0, int64_t P, int64_t K, int n_layers, const
     // layers[0].z == NULL: the caller asks for the first layer to be recomputed instead of stored (mp_sa_mlp_recompute_first)
     const bool rc_first = layers[0].z == nullptr;
     if (rc_first && !mp_sa_mlp_recompute_first(n_layers, ch, K)) return MP_EINVAL;      // (bf16: x0 and layers[0].weight come pre-rounded)
-    // layers[n_layers - 1].z == NULL: the pooled layer's activation is not stored either (mp_sa_mlp_lean_last; sa_lean.hip)
-    if (n_layers > 1 && layers[n_layers - 1].z == nullptr && (bf16 || !mp_sa_mlp_lean_last(n_layers, ch, K, P))) return MP_EINVAL;
+    if (n_layers > 1 && layers[n_layers - 1].z == nullptr) return MP_EINVAL;
     hipStream_t stream = mp_stream(stream_);
     float* partials = reinterpret_cast<float*>(workspace);
     // fused max-pool: group size a multiple of the 32-row MFMA tile that divides the 128-row block tile
@@ -3589,15 +3046,11 @@ static int sa_mlp_fwd(const float* x0, int64_t P, int64_t K, int n_layers, const
         po.K = (int)K;
     }
 
-    const PlanesWs pws = planes_ws(workspace, P, K, n_layers, ch, 0);
-    const bool use_planes = pws.a && !bf16 && !gather && split_enabled() && planes_enabled();
-
     PosOperand A{};
     A.x = x0;
     A.C = (int)ch[0];
     A.K = (int)K;
     A.kshift = log2_or_neg(K);
-    if (gather && !factored) set_gather(A, gather, K);
     for (int l = 0; l < n_layers; ++l) {
         const mp_mlp_layer_t& L = layers[l];
         int nblk = 0, rc = MP_OK;
@@ -3629,13 +3082,7 @@ static int sa_mlp_fwd(const float* x0, int64_t P, int64_t K, int n_layers, const
             while ((P + ppb - 1) / ppb < fwd_wgs_wanted() && ppb > 128) ppb >>= 1;
             const unsigned gx = (unsigned)((P + ppb - 1) / ppb);
             const double fl = 2.0 * (double)P * Co_ * Ci_, by = 4.0 * ((double)P * (Ci_ + Co_) + (double)Co_ * Ci_);
-            if (gather && split_enabled())
-                MP_LAUNCH("fwd_chunk_kernel<128, 128, false, gathered, 4, split>", fl, by - 4.0 * (double)P * Ci_, (fwd_chunk_kernel<128, 128, false, SRC_ID_G, 4, true>), dim3(gx),
-                          dim3(256), 0, stream, A, (int)P, ppb, L.weight, L.z, partials, po, L.gamma);
-            else if (gather)
-                MP_LAUNCH("fwd_chunk_kernel<128, 128, false, gathered, 4>", fl, by - 4.0 * (double)P * Ci_, (fwd_chunk_kernel<128, 128, false, SRC_ID_G, 4>), dim3(gx), dim3(256), 0,
-                          stream, A, (int)P, ppb, L.weight, L.z, partials, po, L.gamma);
-            else if (split_enabled())
+            if (split_enabled())
                 MP_LAUNCH("fwd_chunk_kernel<128, 128, false, 0, 4, split>", fl, by, (fwd_chunk_kernel<128, 128, false, SRC_ID, 4, true>), dim3(gx), dim3(256), 0, stream, A,
                           (int)P, ppb, L.weight, L.z, partials, po, L.gamma);
             else
@@ -3672,16 +3119,13 @@ static int sa_mlp_fwd(const float* x0, int64_t P, int64_t K, int n_layers, const
             const unsigned gx = (unsigned)((P + ppb - 1) / ppb);
             const double fl = 2.0 * (double)P * Co_ * Ci_, by = 4.0 * ((double)P * (Ci_ + Co_) + (double)Co_ * Ci_);
             char tg[64];
-            snprintf(tg, sizeof tg, bf16 ? "fwd_chunk_bf16_kernel<%d, %d, %s>" : ((fuse_pool && !L.z) ? "fwd_chunk_kernel<%d, %d, %s, lean>" : "fwd_chunk_kernel<%d, %d, %s>"), Ci_, Co_, fuse_pool ? "true" : "false");
+            snprintf(tg, sizeof tg, bf16 ? "fwd_chunk_bf16_kernel<%d, %d, %s>" : "fwd_chunk_kernel<%d, %d, %s>", Ci_, Co_, fuse_pool ? "true" : "false");
 #define MP_FWD(CI, CO, PL)                                                                                                     \
     MP_LAUNCH(tg, fl, by, (fwd_chunk_kernel<CI, CO, PL>), dim3(gx), dim3(CO > 128 ? 512 : 256), 0, stream, A, (int)P, ppb, L.weight, L.z, \
               partials, po, L.gamma)
 #define MP_FWD_SPLIT(CI, CO, PL)                                                                                               \
     if (bf16)                                                                                                                  \
         MP_LAUNCH(tg, fl, by, (fwd_chunk_kernel<CI, CO, PL, SRC_ACT, 0, true, true, true>), dim3(gx), dim3(CO > 128 ? 512 : 256), 0, stream, A, (int)P, ppb, \
-                  L.weight, L.z, partials, po, L.gamma);                                                                       \
-    else if (PL && !L.z)                                                                                                            \
-        MP_LAUNCH(tg, fl, by - 4.0 * (double)P * Co_, (fwd_chunk_kernel<CI, CO, PL, SRC_ACT, 0, true, !PL>), dim3(gx), dim3(CO > 128 ? 512 : 256), 0, stream, A, (int)P, ppb, \
                   L.weight, L.z, partials, po, L.gamma);                                                                       \
     else                                                                                                                       \
         MP_LAUNCH(tg, fl, by, (fwd_chunk_kernel<CI, CO, PL, SRC_ACT, 0, true>), dim3(gx), dim3(CO > 128 ? 512 : 256), 0, stream, A, (int)P, ppb, \
@@ -3697,11 +3141,6 @@ static int sa_mlp_fwd(const float* x0, int64_t P, int64_t K, int n_layers, const
 #undef MP_FWD
             MP_CHECK_LAUNCH();
             nblk = (int)gx;
-        } else if (use_planes) {       // [r3] few-row level (group_all): operands pre-split once, PREC 4
-            if (fuse_pool) rc = (l == 0) ? fwd_planes<SRC_ID, EPI_SQ_POOL>(A, P, L, partials, stream, &nblk, po, pws)
-                                         : fwd_planes<SRC_ACT, EPI_SQ_POOL>(A, P, L, partials, stream, &nblk, po, pws);
-            else rc = (l == 0) ? fwd_planes<SRC_ID, EPI_SQ>(A, P, L, partials, stream, &nblk, PoolOut{}, pws)
-                               : fwd_planes<SRC_ACT, EPI_SQ>(A, P, L, partials, stream, &nblk, PoolOut{}, pws);
         } else if (fuse_pool) {
             if (l == 0)
                 rc = MP_POS_GEMM(SRC_ID, false, EPI_SQ_POOL, A, P, L.weight, (int)L.c_out, (int)L.c_in, L.z, partials,
@@ -3770,12 +3209,6 @@ extern "C" int mp_sa_mlp_fwd_f32(const float* x0, int64_t P, int64_t K, int n_la
     return sa_mlp_fwd(x0, P, K, n_layers, layers, training, momentum, eps, out, argk, zmax, workspace, workspace_bytes, stream, false, nullptr);
 }
 
-extern "C" int mp_sa_mlp_gather_supported(int n_layers, const int64_t* channels, int64_t K, int64_t CF)
-{
-    if (n_layers < 2 || !channels || K <= 0) return 0;
-    return (CF == 128 && channels[0] == 132 && channels[1] == 128 && chunk_fwd_enabled() && fused_bwd_enabled()) ? 1 : 0;
-}
-
 extern "C" int mp_sa_mlp_fwd_gather_f32(const mp_gather_t* gather, int64_t P, int64_t K, int n_layers, const mp_mlp_layer_t* layers,
                                         int training, double momentum, double eps, float* out, int32_t* argk, float* zmax,
                                         void* workspace, size_t workspace_bytes, mp_stream_t stream)
@@ -3832,7 +3265,7 @@ static int sa_mlp_bwd(const float* x0, int64_t P, int64_t K, int n_layers, const
     // factored: grad_x0_cols == Co: dZ_0 rows [P, Co + 4] for the caller to reduce; grad_x0_cols == 0: grad_x0 IS dA [B, N, Co], reduced here
     if (factored && (!grad_x0 || (grad_x0_cols != layers[0].c_out && grad_x0_cols != 0))) return MP_EINVAL;
     if (factored && grad_x0_cols == 0 && (gather->N > 15000 || gather->S * K >= ((int64_t)1 << 24))) return MP_EUNSUPPORTED;
-    if (gather && !factored && (!gather_ok(gather, P, K, n_layers, layers, bf16) || !grad_x0 || grad_x0_cols != 128)) return MP_EUNSUPPORTED;
+    if (gather && !factored) return MP_EUNSUPPORTED;
     if (n_layers > 8) return MP_EUNSUPPORTED;
     int64_t ch[9];
     ch[0] = layers[0].c_in;
@@ -3847,9 +3280,7 @@ static int sa_mlp_bwd(const float* x0, int64_t P, int64_t K, int n_layers, const
     if (workspace_bytes < mp_sa_mlp_workspace_bytes(P, K, n_layers, ch, 1)) return MP_EWORKSPACE;
     const bool rc_first = layers[0].z == nullptr;   // the forward pass did not store Z_0 (mp_sa_mlp_recompute_first)
     if (rc_first && (grad_x0 || !mp_sa_mlp_recompute_first(n_layers, ch, K))) return MP_EINVAL;
-    const bool lean = n_layers > 1 && layers[n_layers - 1].z == nullptr;      // the pooled layer without its stored activation (sa_lean.hip)
-    if (lean && (bf16 || !mp_sa_mlp_lean_last(n_layers, ch, K, P))) return MP_EINVAL;
-    for (int l = 1; l < n_layers - (lean ? 1 : 0); ++l)
+    for (int l = 1; l < n_layers; ++l)
         if (!layers[l].z) return MP_EINVAL;
     hipStream_t stream = mp_stream(stream_);
     // carve the workspace (same order as mp_sa_mlp_workspace_bytes)
@@ -3869,7 +3300,6 @@ static int sa_mlp_bwd(const float* x0, int64_t P, int64_t K, int n_layers, const
     }
     float* gp = reinterpret_cast<float*>(w);
     w += align_up((size_t)(P / K) * (size_t)ch[n_layers] * sizeof(float), 256);
-    void* lean_ws = w;
 
     const int64_t G = P / K;
     const int L = n_layers;
@@ -3934,31 +3364,18 @@ static int sa_mlp_bwd(const float* x0, int64_t P, int64_t K, int n_layers, const
         IN.C = Ci;
         IN.K = (int)K;
         IN.kshift = log2_or_neg(K);
-        if (l == 0) { IN.x = x0; if (gather && !factored) set_gather(IN, gather, K); }
+        if (l == 0) { IN.x = x0; }
         else { IN.x = layers[l - 1].z; IN.s = layers[l - 1].scale; IN.t = layers[l - 1].shift; }
         if (rc_first && l == 1) { IN.rx = x0; IN.rw = layers[0].weight; }   // act(Z_0) and raw Z_0 from the input rows
         if (rc_first && l == 0) { DZ.rx = x0; DZ.rw = Ly.weight; }          // dZ_0 = f(Z_0, G_0) likewise
 
-        if (lean && pooled) {
-            // dZ_L is never formed: G_{L-1} = Ac M + v~ + sparse rows, dW_L from Gram / S / column sums (sa_lean.hip)
-            const mp_mlp_layer_t& Pv = layers[l - 1];
-            float* Gn = gbuf[l & 1];
-            int nb = 0;
-            if (int rc = mp::lean_bwd(Pv.z, Pv.scale, Pv.shift, Pv.gamma, Pv.beta, Ly.weight, cbuf[0], cbuf[1], cbuf[2], gp, argk, P, K, Co, Ci, Gn,
-                                      partials, &nb, grads[l].d_weight, lean_ws, stream))
-                return rc;
-            if (int rc = finalize_bwd(l - 1, nb, Ci)) return rc;
-            G_cur = Gn;
-            continue;
-        }
         // dW_l = dZ_l^T * act(Z_{l-1})
         if (!dw_joint && !mp::zero_async(grads[l].d_weight, (size_t)Co * Ci, stream)) return MP_ELAUNCH;
         if (l > 0 && (Ci == 64 || Ci == 128) && (Co == 64 || Co == 128 || (Co == 256 && Ci == 128)) && fused_bwd_enabled() && !(bf16 && Co == 64 && Ci == 128)) {
             // single-tile layer: dX, dW and the BatchNorm-backward sums of layer l-1 in one pass over dZ_l (bwd_fused_kernel)
             const mp_mlp_layer_t& Pv = layers[l - 1];
             float* Gn = gbuf[l & 1];
-            static const int ppb_env = getenv("MP_BWD_PPB") ? atoi(getenv("MP_BWD_PPB")) : 1024;     // positions per workgroup (experiments)
-            const int ppb = ppb_env;
+            const int ppb = 1024;      // positions per workgroup
             const unsigned gx = (unsigned)((P + ppb - 1) / ppb);
             if ((size_t)gx > nblk_max) return MP_EUNSUPPORTED;
             const double fl = 4.0 * (double)P * Co * Ci;
@@ -3995,17 +3412,11 @@ static int sa_mlp_bwd(const float* x0, int64_t P, int64_t K, int n_layers, const
                 else
                     MP_LAUNCH(tg, fl, by - 4.0 * (double)P * (Ci - 4), (bwd_fused_kernel<SRC_DZ, 128, 64, SRC_ACT_RC>), dim3(gx), dim3(256), 0, stream, DZ, IN,
                               (int)P, ppb, Ly.weight, grads[l].d_weight, Gn, partials);
-            } else if (!bf16 && split_enabled() && Ci == 128 && (Co == 256 || Co == 128) && ((roles_mask() >> (Co == 256 ? 0 : 1)) & 1) &&
-                       (!pooled || (DZ.kshift >= 4 && ppb % 16 == 0))) {
-                // [r3] the two products on different waves (bwd_roles_kernel; MP_BF_ROLES bit 0: 256 outputs, bit 1: 128)
-                snprintf(tg, sizeof tg, (Co == 256 && pooled && roles_lds()) ? "bwd_roles_lds_kernel<%d>" : "bwd_roles_kernel<%d, %d>",
-                         (Co == 256 && pooled && roles_lds()) ? roles_lds() : (pooled ? 3 : 2), Co);
-                if (Co == 256 && pooled && roles_lds() == 2) MP_LAUNCH(tg, fl, by, (bwd_roles_lds_kernel<2>), dim3(gx), dim3(512), 0, stream, DZ, IN, (int)P, ppb, Ly.weight, grads[l].d_weight, Gn, partials);
-                else if (Co == 256 && pooled && roles_lds() == 3) MP_LAUNCH(tg, fl, by, (bwd_roles_lds_kernel<3>), dim3(gx), dim3(512), 0, stream, DZ, IN, (int)P, ppb, Ly.weight, grads[l].d_weight, Gn, partials);
-                else if (Co == 256 && pooled) MP_LAUNCH(tg, fl, by, (bwd_roles_kernel<SRC_DZ_POOLED, 256>), dim3(gx), dim3(512), 0, stream, DZ, IN, (int)P, ppb, Ly.weight, grads[l].d_weight, Gn, partials);
-                else if (Co == 256) MP_LAUNCH(tg, fl, by, (bwd_roles_kernel<SRC_DZ, 256>), dim3(gx), dim3(512), 0, stream, DZ, IN, (int)P, ppb, Ly.weight, grads[l].d_weight, Gn, partials);
-                else if (pooled) MP_LAUNCH(tg, fl, by, (bwd_roles_kernel<SRC_DZ_POOLED, 128>), dim3(gx), dim3(512), 0, stream, DZ, IN, (int)P, ppb, Ly.weight, grads[l].d_weight, Gn, partials);
-                else MP_LAUNCH(tg, fl, by, (bwd_roles_kernel<SRC_DZ, 128>), dim3(gx), dim3(512), 0, stream, DZ, IN, (int)P, ppb, Ly.weight, grads[l].d_weight, Gn, partials);
+            } else if (!bf16 && split_enabled() && Ci == 128 && Co == 256 && (!pooled || (DZ.kshift >= 4 && ppb % 16 == 0))) {
+                // [r3] the 256-output layer: the two products on different waves (bwd_roles_kernel)
+                snprintf(tg, sizeof tg, "bwd_roles_kernel<%d, %d>", pooled ? 3 : 2, Co);
+                if (pooled) MP_LAUNCH(tg, fl, by, (bwd_roles_kernel<SRC_DZ_POOLED, 256>), dim3(gx), dim3(512), 0, stream, DZ, IN, (int)P, ppb, Ly.weight, grads[l].d_weight, Gn, partials);
+                else MP_LAUNCH(tg, fl, by, (bwd_roles_kernel<SRC_DZ, 256>), dim3(gx), dim3(512), 0, stream, DZ, IN, (int)P, ppb, Ly.weight, grads[l].d_weight, Gn, partials);
             } else if (Co == 256) {
                 if (pooled) { MP_FUSED(SRC_DZ_POOLED, 256, 128); } else { MP_FUSED(SRC_DZ, 256, 128); }
             } else if (pooled) {
@@ -4028,19 +3439,10 @@ static int sa_mlp_bwd(const float* x0, int64_t P, int64_t K, int n_layers, const
         }
         if (!bf16 && l == 0 && grad_x0 && Co == 128 && Ci == 132 && grad_x0_cols == 128 && fused_bwd_enabled()) {
             // first layer of a level with a [128 features | xyz | pad] input: dW and the feature columns of grad_x0 in one pass
-            static const int ppb_env = getenv("MP_BWD_PPB") ? atoi(getenv("MP_BWD_PPB")) : 1024;     // positions per workgroup (experiments)
-            const int ppb = ppb_env;
+            const int ppb = 1024;      // positions per workgroup
             const unsigned gx = (unsigned)((P + ppb - 1) / ppb);
             const double fl = 2.0 * (double)P * Co * (Ci + 128), by = 4.0 * ((pooled ? 1.0 : 2.0) * (double)P * Co + (double)P * (Ci + 128));
-            if (gather && split_enabled() && !pooled)
-                MP_LAUNCH("bwd_first_kernel<2, gathered>", fl, by - 4.0 * (double)P * Ci, (bwd_first_kernel<SRC_DZ, true, SRC_ID_G>), dim3(gx), dim3(512), 0, stream, DZ, IN,
-                          (int)P, ppb, Ly.weight, grads[l].d_weight, grad_x0);
-            else if (gather && !pooled)
-                MP_LAUNCH("bwd_first_kernel<2, gathered>", fl, by - 4.0 * (double)P * Ci, (bwd_first_kernel<SRC_DZ, false, SRC_ID_G>), dim3(gx), dim3(512), 0, stream, DZ, IN,
-                          (int)P, ppb, Ly.weight, grads[l].d_weight, grad_x0);
-            else if (gather)
-                return MP_EUNSUPPORTED;
-            else if (pooled && split_enabled())
+            if (pooled && split_enabled())
                 MP_LAUNCH("bwd_first_kernel<3>", fl, by, (bwd_first_kernel<SRC_DZ_POOLED, true>), dim3(gx), dim3(512), 0, stream, DZ, IN, (int)P, ppb,
                           Ly.weight, grads[l].d_weight, grad_x0);
             else if (pooled)
@@ -4070,8 +3472,7 @@ static int sa_mlp_bwd(const float* x0, int64_t P, int64_t K, int n_layers, const
                 hipLaunchKernelGGL(csr_rows_kernel, dim3((unsigned)Bc), dim3(1024), smem, stream, gather->idx, Np, M, order, pts);
                 MP_CHECK_LAUNCH();
                 if (!mp::zero_async(grad_x0, (size_t)Bc * Np * Co, stream)) return MP_ELAUNCH;
-                static const int chunk_env = getenv("MP_FACT_CHUNK") ? atoi(getenv("MP_FACT_CHUNK")) : 128;   // rows per wave (measured: 32: 236 us, 64: 160, 128: 122, 256: 126 at the bench shape)
-                const int chunk = chunk_env;
+                const int chunk = 128;   // rows per wave (measured: 32: 236 us, 64: 160, 128: 122, 256: 126 at the bench shape)
                 const unsigned gxr = (unsigned)((M + 4 * chunk - 1) / (4 * chunk));
 #define MP_FACT_R(Q_)                                                                                                            \
     MP_LAUNCH("first_factored_reduce_kernel", fl, by, (first_factored_reduce_kernel<Q_>), dim3(gxr, (unsigned)Bc), dim3(256), 0, stream, DZ, order, pts, \

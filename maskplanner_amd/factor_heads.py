@@ -18,8 +18,7 @@ import os
 
 from . import _lib, dp, ops
 
-WIDE_LINEAR = os.environ.get("MASKPLANNER_WIDE_LINEAR", "1") != "0"   # 0: plain nn.Linear (rocBLAS backward) for the wide heads of a model without a factor store
-DX_MFMA = os.environ.get("MASKPLANNER_DX_MFMA", "1") != "0"      # 0: the VALU form (ordered partial sums) for the wide heads' input gradient
+WIDE_LINEAR = True   # False (tests): plain nn.Linear (rocBLAS backward) for the wide heads of a model without a factor store
 
 
 class _FactorLinear(torch.autograd.Function):
@@ -42,7 +41,7 @@ class _FactorLinear(torch.autograd.Function):
             # the streaming kernel pays off on the wide heads (O ~ 6000-12000 rows of W); the 1024 x 1024 layers have too few
             # row slabs to fill the chip and stay on rocBLAS
             if (g.is_cuda and B <= 32 and O >= 4096 and I % 128 == 0 and g.dtype == torch.float32 and weight.is_contiguous()
-                    and not ops.DETERMINISTIC and DX_MFMA):
+                    and not ops.DETERMINISTIC):
                 # the stream of W through the matrix cores (csrc/linear_dx.hip; atomics between its K slices: not bit-reproducible)
                 gx = torch.empty((B, I), dtype=torch.float32, device=g.device)
                 ops._run("linear_dx_mfma", g, _lib.load().mp_linear_dx_mfma_f32, g.data_ptr(), weight.data_ptr(), B, O, I, gx.data_ptr())
@@ -62,71 +61,6 @@ class _FactorLinear(torch.autograd.Function):
             else:
                 gb = g.sum(0)
         return gx, None, gb, None, None
-
-
-class _LinearBlock(torch.autograd.Function):
-    """dropout(relu(bn(linear(x)))) of one head block as ONE forward launch (csrc/loss_tail.hip: mp_linear_block_f32) with the weight
-    gradient kept as factors like _FactorLinear.  Backward: the BatchNorm + ReLU + dropout backward kernel, then the Linear's."""
-
-    @staticmethod
-    def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, store, key, training, momentum, eps, drop_p, rng, layer):
-        B, K = x.shape
-        N = weight.shape[0]
-        lin = torch.empty((B, N), dtype=torch.float32, device=x.device)
-        y = torch.empty_like(lin)
-        stats = torch.empty((2, N), dtype=torch.float32, device=x.device)
-        p = lambda t: None if t is None else t.data_ptr()
-        ops._run("linear_block", x, _lib.load().mp_linear_block_f32, p(x), p(weight), p(bias), B, N, K, int(training), float(momentum), float(eps),
-                 p(gamma), p(beta), p(running_mean), p(running_var), p(lin), p(y), stats[0].data_ptr(), stats[1].data_ptr(), float(drop_p), p(rng),
-                 int(layer))
-        ctx.save_for_backward(x, weight, lin, y, gamma, stats)
-        ctx.store, ctx.key, ctx.bias = store, key, bias
-        ctx.training, ctx.drop_p = bool(training), (float(drop_p) if rng is not None else None)
-        return y
-
-    @staticmethod
-    def backward(ctx, grad_y):
-        x, weight, lin, y, gamma, stats = ctx.saved_tensors
-        B, N = lin.shape
-        grad_y = grad_y.contiguous().float()
-        g = torch.empty_like(lin)                       # gradient w.r.t. the Linear's output
-        gg = torch.empty((N,), dtype=torch.float32, device=x.device) if ctx.needs_input_grad[3] else None
-        gb = torch.empty((N,), dtype=torch.float32, device=x.device) if ctx.needs_input_grad[4] else None
-        p = lambda t: None if t is None else t.data_ptr()
-        lib = _lib.load()
-        if ctx.drop_p is not None:
-            ops._run("bn_relu_rows_bwd", x, lib.mp_bn_relu_drop_rows_bwd_f32, p(grad_y), p(y), p(lin), B, N, int(ctx.training), p(gamma),
-                     stats[0].data_ptr(), stats[1].data_ptr(), p(g), p(gg), p(gb), ctx.drop_p)
-        else:
-            ops._run("bn_relu_rows_bwd", x, lib.mp_bn_relu_rows_bwd_f32, p(grad_y), p(y), p(lin), B, N, int(ctx.training), p(gamma),
-                     stats[0].data_ptr(), stats[1].data_ptr(), p(g), p(gg), p(gb))
-        ctx.store[ctx.key] = (x.detach(), g)            # the factors of dW = g^T x
-        gx = g @ weight if ctx.needs_input_grad[0] else None
-        gbias = None
-        if ctx.bias is not None:
-            pending = ctx.store.get(BIAS_QUEUE)
-            if pending is not None:
-                pending.append((ctx.bias, g))
-            else:
-                gbias = g.sum(0)
-        return gx, None, gbias, gg, gb, None, None, None, None, None, None, None, None, None, None
-
-
-def linear_block(x, linear, bn, store, key, dropout):
-    """dropout(relu(bn(linear(x)))) in one launch; `store` as for factor_linear, dropout = (p, rng, layer) as for ops.bn_relu_rows
-    (rng None: no dropout).  The caller has advanced bn.num_batches_tracked."""
-    ops._need_hip(x)
-    training = bn.training or bn.running_mean is None
-    track = bn.track_running_stats and bn.running_mean is not None
-    momentum = bn.momentum if bn.momentum is not None else 1.0 / max(float(bn.num_batches_tracked), 1.0)
-    p, rng, layer = dropout
-    return _LinearBlock.apply(x.contiguous(), linear.weight, linear.bias, bn.weight, bn.bias, bn.running_mean if track else None,
-                              bn.running_var if track else None, store, key, training, momentum, bn.eps, p, rng, layer)
-
-
-def linear_block_supported(x, linear, bn, store):
-    return (store is not None and x.is_cuda and x.dtype == torch.float32 and x.ndim == 2 and x.shape[0] <= 32 and linear.in_features % 128 == 0
-            and linear.weight.is_contiguous() and getattr(bn, "sync_bn", None) in (None, False))
 
 
 BIAS_QUEUE = "__bias_grads__"     # store[BIAS_QUEUE] = []: FactorLinear queues (bias, dy) pairs instead of reducing each one
@@ -167,7 +101,7 @@ class _WideLinear(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         x, weight = ctx.saved_tensors
-        g = g.contiguous()
+        g = g.contiguous().float()      # (the kernels read fp32: an autocast / half gradient is widened here, never reinterpreted)
         B, O = g.shape
         I = weight.shape[1]
         lib = _lib.load()
@@ -181,7 +115,7 @@ class _WideLinear(torch.autograd.Function):
                 ops._run("linear_dx_mfma", g, lib.mp_linear_dx_mfma_f32, g.data_ptr(), weight.data_ptr(), B, O, I, gx.data_ptr())
         if ctx.needs_input_grad[1]:
             gw = torch.empty_like(weight)
-            xc = x.contiguous()
+            xc = x.contiguous().float()
             ops._run("linear_dw_outer", g, lib.mp_linear_dw_outer_f32, g.data_ptr(), xc.data_ptr(), B, O, I, gw.data_ptr())
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = g.sum(0)

@@ -53,7 +53,7 @@ class TrainStep:
         self._graph, self._graph_loss, self._eager_steps, self._side = None, None, 0, None
         # Pipelined first-level sampling (see _eager_step): FPS can occupy only one workgroup per cloud -- 32 of 256 CUs for
         # ~0.35 ms at B=32 -- and depends on nothing but the input cloud, so the step computes the NEXT batch's FPS + ball
-        # query on a second stream underneath its own work (_pipeline_sampling).
+        # query on a second stream underneath its own work (_launch_sampling / _hand_over).
         if overlap_sampling is None:
             overlap_sampling = os.environ.get("MASKPLANNER_OVERLAP_SAMPLING", "1") != "0"
         # (the pipelined plan holds one ball query per level: the multi-radius encoder samples in line)
@@ -65,12 +65,7 @@ class TrainStep:
         # touch the head weights; the next step's second graph waits for it.
         self._graph_b, self._graph_b2, self._factor_args, self._adam_stream, self._adam_ev = None, None, None, None, None
         self._split_adam_wanted = os.environ.get("MASKPLANNER_SPLIT_ADAM", "1") != "0"
-        self._plan_late = os.environ.get("MASKPLANNER_PLAN_AFTER_FORWARD", "0") != "0"
-        # MASKPLANNER_ADAM_AFTER_PLAN=1 (experiment): the deferred head optimizer starts only when the next batch's sampling kernels are
-        # done, instead of sharing the first ~0.4 ms of the encoder forward with them.  [r2] measured: +45 us per step (the heads then wait
-        # for the optimizer), so it stays off.
-        self._adam_after_plan = os.environ.get("MASKPLANNER_ADAM_AFTER_PLAN", "0") != "0"
-        self._adam_pending = False
+        self._plan_mid = os.environ.get("MASKPLANNER_PLAN_AT", "start") == "mid"
         self._unit = torch.ones((), dtype=torch.float32, device=self.device)
         # train-mode dropout of the head blocks inside their BatchNorm + ReLU launches (pointnet2_cls_ssg._block): a device (seed, step)
         # pair, the step advanced once per training step.  MASKPLANNER_FUSED_DROPOUT=0 keeps nn.Dropout (torch's Philox stream).
@@ -107,7 +102,7 @@ class TrainStep:
                       for k, v in b.items()}
         # Streamed inputs (stream_batches = K > 0): K different host batches of ragged dataset items rotate through the step; batch
         # k+1 is collated onto the device (maskplanner_amd.collate: one flat copy per key + the pad kernel) and its sampling plan
-        # computed on the second stream WHILE step k runs (_pipeline_sampling).  The step's own tensors keep fixed shapes (ground
+        # computed on the second stream WHILE step k runs (_launch_sampling).  The step's own tensors keep fixed shapes (ground
         # truth padded to the category's maximum, per-sample lengths come from the -100 sentinel anyway), so the recorded graphs
         # stay valid.  0: the same resident batch every step (the headline bench: inputs resident in HBM).
         self._stream = None
@@ -182,23 +177,21 @@ class TrainStep:
         return loss
 
     def _step(self):
-        # MASKPLANNER_PLAN_AFTER_FORWARD=1: the next batch's sampling starts BEHIND the encoder forward (graph A), underneath the
-        # heads / loss part of graph B, instead of at the start of the step.  [r2] measured: the same step time either way (FPS then
-        # stretches the loss's kNN kernels by what it no longer costs the forward), so the switch is off.
-        late = self.overlap and self._graph_b is not None and self._plan_late
-        if self.overlap:
-            self._pipeline_sampling(launch=not late)
-        if self._adam_pending:
-            self._adam_pending = False
-            self._launch_factor_adam(after=self._plan_ev)
+        mid = self._plan_mid and self.overlap
+        if self.overlap and not mid:
+            self._launch_sampling()          # the NEXT batch's plan, on the second stream underneath this step
         if self._graph is not None:
+            if mid:
+                self._wait_plan()            # A's first node is the hand-over copy
             self._graph.replay()
-            if late:
-                self._launch_sampling()
+            if mid:
+                self._launch_sampling()      # behind graph A (and its hand-over copy)
             if self._graph_b is not None:
                 if self._adam_ev is not None:
                     torch.cuda.current_stream().wait_event(self._adam_ev)   # the head weights of the previous step are final
                 self._replay_b()
+            elif self.overlap and not mid:
+                self._hand_over()            # (single-graph step: the hand-over is not part of the recording)
             loss = self._graph_loss
             if self._guard_left > 0 and self.dp_graph:
                 self._guard_left -= 1
@@ -230,10 +223,21 @@ class TrainStep:
         try:
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
+            mid = self._plan_mid and self.overlap
+            if mid:
+                if self._plan_cur is None:
+                    self._plan_init()
+                self._wait_plan()
             with torch.cuda.graph(g):
-                loss = self._eager_step()
+                if mid:
+                    self._hand_over_copies()
+                loss = self._eager_step(hand_over=False)
             self._graph, self._graph_loss = g, loss
             g.replay()
+            if mid:
+                self._launch_sampling()
+            elif self.overlap:
+                self._hand_over()
         except Exception as exc:   # stay correct: eager from here on
             import warnings
             warnings.warn(f"hipGraph capture of the training step failed ({type(exc).__name__}: {exc}); running eagerly")
@@ -252,7 +256,14 @@ class TrainStep:
                 self._reset_factor_store()
             from . import sa_mlp
             ticks_prev, sa_mlp.DEFERRED_TICKS = sa_mlp.DEFERRED_TICKS, []      # every BatchNorm counter of the step: one launch, in B
+            mid = self._plan_mid and self.overlap
+            if mid:
+                if self._plan_cur is None:
+                    self._plan_init()
+                self._wait_plan()
             with torch.cuda.graph(ga, stream=cap):
+                if mid:
+                    self._hand_over_copies()
                 self._supply_plan()
                 self.reducer.zero_grad()
                 feat = self._encode()
@@ -299,12 +310,16 @@ class TrainStep:
                             elif seen[d_.data_ptr()] != s_.data_ptr():
                                 raise RuntimeError(f"factor {k}: expected to share its input activation")
                     torch._foreach_copy_(dsts, srcs)
+                if self.overlap and not split_bwd and not mid:
+                    self._hand_over_copies()
             if split_bwd:
                 with torch.cuda.graph(gb2, pool=ga.pool(), stream=cap):
                     feat.backward(leaf.grad)
                     if not self.dp_graph:
                         self.reducer.finish()
                         self.opt.step()
+                    if self.overlap and not mid:
+                        self._hand_over_copies()
             if self.dp_graph:
                 self._static_grads = [(p, p.grad) for p in self.reducer.params if p.grad is not None]
             self._factor_args = persist
@@ -313,6 +328,8 @@ class TrainStep:
             self._adam_stream = torch.cuda.Stream()
             self._graph, self._graph_b, self._graph_b2, self._graph_loss = ga, gb, gb2, loss
             ga.replay()
+            if mid:
+                self._launch_sampling()
             self._replay_b()
         except Exception as exc:   # stay correct: eager from here on
             import warnings
@@ -358,7 +375,7 @@ class TrainStep:
         self._graph, self._graph_b, self._graph_b2, self._graph_loss = None, None, None, None
         self.use_graph, self.dp_graph, self._guard_left, self.dp_fell_back = False, False, 0, True
         self.reducer.deferred = False
-        self._static_grads, self._factor_args, self._adam_ev, self._adam_pending = None, None, None, False
+        self._static_grads, self._factor_args, self._adam_ev = None, None, None
         state = list(self.model.parameters()) + [b for b in self.model.buffers() if b.is_floating_point()]
         for opt in (self.opt, self.factor_opt):
             if opt is None:
@@ -399,6 +416,8 @@ class TrainStep:
 
     def _replay_b(self):
         """Graph B (or B1, head optimizer, B2) and what follows it eagerly."""
+        if self.overlap and not self._plan_mid:
+            self._wait_plan()                   # B's last node is the hand-over copy
         self._graph_b.replay()
         if self._graph_b2 is not None:
             self._launch_factor_adam()          # behind B1: underneath the encoder backward
@@ -408,16 +427,11 @@ class TrainStep:
             self.reducer.finish()
             self.opt.step()
         if self.factor_opt is not None and self._graph_b2 is None:
-            if self._adam_after_plan and self.overlap:
-                self._adam_pending = True       # launched by the next step(), behind that step's sampling kernels
-            else:
-                self._launch_factor_adam()
+            self._launch_factor_adam()
 
-    def _launch_factor_adam(self, after=None):
+    def _launch_factor_adam(self):
         side = self._adam_stream
         side.wait_stream(torch.cuda.current_stream())
-        if after is not None:
-            side.wait_event(after)
         with torch.cuda.stream(side):
             if self._adam_delay_cycles:      # test hook: hold the optimizer back so that it overlaps the next replay of graph A
                 torch.cuda._sleep(int(self._adam_delay_cycles))
@@ -429,8 +443,8 @@ class TrainStep:
     def eager_step(self):
         """One step launched kernel by kernel even when a recorded graph exists (bench.py's per-kernel timing hooks live in
         the launch path).  Shares parameters and optimizer state with the graph, so the two can be interleaved."""
-        if self.overlap:
-            self._pipeline_sampling()
+        if self.overlap and not self._plan_mid:
+            self._launch_sampling()
         if self._adam_ev is not None:
             torch.cuda.current_stream().wait_event(self._adam_ev)
         return self._eager_step()
@@ -468,33 +482,35 @@ class TrainStep:
             ops.ball_query(m.radius, m.nsample, xyz, new_xyz, out=idx)
             xyz = new_xyz
 
-    def _pipeline_sampling(self, launch=True):
-        """Launched eagerly in front of every step (never recorded: a second branch inside the hipGraph made the replay
-        insert ~7 us synchronisation gaps all along the main chain, 26 per step): the plan computed during the previous step
-        becomes this step's with one copy kernel, then the next batch's sampling (here: the same resident synthetic batch,
-        recomputed every step) starts on the second stream and runs underneath the step.  launch=False: only the hand-over;
-        the caller starts the next sampling itself (_launch_sampling) at the point of the step it should run under."""
-        main = torch.cuda.current_stream()
-        if self._plan_next is None:
-            self._plan_next = torch.zeros(self._plan_size(), dtype=torch.int64, device=self.device)
-            self._plan_cur = torch.zeros_like(self._plan_next)
-            if self._stream is not None:
-                xyz, starts = self._stream.collate_next()
-                self._sample_levels(self._plan_next, xyz, starts)
-            else:
-                self._sample_levels(self._plan_next)
-            self._plan_stream = torch.cuda.Stream()
-        if self._plan_ev is not None:
-            main.wait_event(self._plan_ev)                       # the previous step's sampling (and collation) is complete
-        torch.add(self._plan_next, 0, out=self._plan_cur)        # an elementwise kernel into the step's static buffer
+    # Pipelined sampling, the protocol (the same for eager and replayed steps):
+    #   start of a step : the NEXT batch's collation + sampling plan (FPS + ball query of every level) is launched on the second
+    #                     stream into `_plan_next`, ordered after everything the step's stream holds (= the previous hand-over);
+    #   end of a step   : the step's stream waits for that plan and copies it into `_plan_cur` (and, with streamed inputs, the staged
+    #                     batch into the step's static tensors): the hand-over.  In the two-graph step the copy is the LAST NODE OF
+    #                     GRAPH B and the wait sits in front of B's replay -- nothing is launched eagerly on the step's stream
+    #                     between B and the next A.  [r4] measured: an eager kernel between two replays costs ~20 us before it and
+    #                     ~80 us before the first kernel of the next graph (a 104 us bubble per step), a graph following a graph 13-19 us.
+    # The sampling kernels themselves are never recorded: a second branch inside the hipGraph made the replay insert ~7 us
+    # synchronisation gaps all along the main chain (26 per step).
+    def _plan_init(self):
+        """Both plan buffers; the FIRST batch's plan is computed in line on the step's stream."""
+        self._plan_next = torch.zeros(self._plan_size(), dtype=torch.int64, device=self.device)
+        self._plan_cur = torch.zeros_like(self._plan_next)
+        self._plan_stream = torch.cuda.Stream()
+        first = self._plan_next if self._plan_mid else self._plan_cur      # "mid": every step starts with the hand-over copy
         if self._stream is not None:
-            self._stream.publish()                               # the collated next batch becomes the step's batch
-        if launch:
-            self._launch_sampling()
+            xyz, starts = self._stream.collate_next()
+            self._sample_levels(first, xyz, starts)
+            if not self._plan_mid:
+                self._stream.publish()
+        else:
+            self._sample_levels(first)
 
     def _launch_sampling(self):
         """The next batch's collation + sampling plan on the second stream, ordered after everything the step's stream holds so
-        far (at least the hand-over copy: only then may the next plan / the staging tensors be overwritten)."""
+        far (at least the previous hand-over: only then may the next plan / the staging tensors be overwritten)."""
+        if self._plan_cur is None:
+            self._plan_init()
         side = self._plan_stream
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -506,19 +522,45 @@ class TrainStep:
             self._plan_ev = torch.cuda.Event()
             self._plan_ev.record(side)
 
+    def _wait_plan(self):
+        if self._plan_ev is not None:
+            torch.cuda.current_stream().wait_event(self._plan_ev)    # the next batch's sampling (and collation) is complete
+
+    def _hand_over_copies(self):
+        """The next plan becomes the step's (one elementwise kernel into the static buffer); with streamed inputs the collated next
+        batch becomes the step's batch.  Static sources and destinations: recordable."""
+        torch.add(self._plan_next, 0, out=self._plan_cur)
+        if self._stream is not None:
+            self._stream.publish()
+
+    def _hand_over(self):
+        self._wait_plan()
+        self._hand_over_copies()
+
     def _supply_plan(self):
         if self.overlap:
             pu.clear_prefetched()    # nothing of an earlier (possibly aborted) step may survive into this one
             if self._plan_cur is None:
-                self._pipeline_sampling()
+                self._plan_init()
+                if self._plan_mid:
+                    self._hand_over_copies()
             xyz = self.batch["point_cloud"]
             for m, plan in zip(self._plan_levels(), self._plan_views(self._plan_cur)):
                 pu.supply_sampling(xyz, m.npoint, m.radius, m.nsample, plan)
                 xyz = plan[1]    # the next level's cloud IS this level's centroid tensor (same storage: the lookup key)
 
-    def _eager_step(self):
+    def _eager_step(self, hand_over=True):
         try:
-            return self._eager_step_body()
+            mid = self._plan_mid and self.overlap
+            if mid and hand_over:
+                if self._plan_cur is None:
+                    self._plan_init()
+                self._hand_over()
+                self._launch_sampling()
+            loss = self._eager_step_body()
+            if hand_over and self.overlap and not mid and self._plan_ev is not None:
+                self._hand_over()
+            return loss
         except BaseException:
             pu.clear_prefetched()    # a plan queued for this step must not outlive it
             raise

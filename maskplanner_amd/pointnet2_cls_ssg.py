@@ -15,7 +15,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops, sa_mlp
-from .factor_heads import factor_linear, linear_block, linear_block_supported
+from .factor_heads import factor_linear
 
 SAMPLE_AHEAD = os.environ.get("MASKPLANNER_SAMPLE_AHEAD", "1") != "0"
 from .pointnet2_utils import PointNetSetAbstraction, PointNetSetAbstractionMsg
@@ -81,7 +81,12 @@ class _SSGEncoder(nn.Module):
             idx2 = ops.ball_query(sa2.radius, sa2.nsample, new1, new2)
             ev = torch.cuda.Event()
             ev.record(side)
-        for t in (fps2, new2, idx2, s2):
+        # lifetimes across the two streams: s2 and new1 were allocated on the step's stream and are READ on the side stream
+        # (the allocator must not hand their blocks out again before the side stream's FPS has run); the three outputs were
+        # allocated on the side stream and are read by the step's stream
+        for t in (s2, new1):
+            t.record_stream(side)
+        for t in (fps2, new2, idx2):
             t.record_stream(main)
         idx1 = ops.ball_query(sa1.radius, sa1.nsample, pm, new1)
         pu.supply_sampling(pm, sa1.npoint, sa1.radius, sa1.nsample, (fps1, new1, idx1))
@@ -101,14 +106,7 @@ def _block(model, lin_out, bn, layer):
 
 
 def _head_block(model, x, linear, bn, store, key, layer):
-    """One block of the heads: dropout(relu(bn(linear(x)))): Linear, then _block.  MASKPLANNER_FUSED_BLOCK=1 (with a training
-    harness's factor store and fused dropout, on the GPU): ONE launch (factor_heads.linear_block).  [r2] measured: +50 us per step -- the
-    32-workgroup kernel streams its 4 MB of weights in 64-byte pieces and is slower than rocBLAS's 12 us + the 5 us BatchNorm launch --
-    so the switch is off."""
-    rng = getattr(model, "fused_dropout", None)
-    if (rng is not None and model.training and bn.training and os.environ.get("MASKPLANNER_FUSED_BLOCK", "0") != "0"
-            and linear_block_supported(x, linear, bn, store)):
-        return linear_block(x, linear, bn, store, key, (model.dropout.p, rng, layer))
+    """One block of the heads: dropout(relu(bn(linear(x)))): Linear, then _block."""
     return _block(model, factor_linear(x, linear, store, key), bn, layer)
 
 

@@ -242,14 +242,6 @@ class PointNetSetAbstraction(nn.Module):
             new_points = sa_mlp.shared_mlp_max_factored(xyz, points, new_xyz, idx, self.mlp_convs, self.mlp_bns, "xyz_first", dtype=self.mlp_dtype,
                                                         sync_bn=self.sync_bn)
             return new_xyz.permute(0, 2, 1), new_points.permute(0, 2, 1)
-        elif (points is not None and full_points is None and os.environ.get("MP_GATHER_FUSED", "0") != "0"
-              and sa_mlp.gathered_supported(points, self.nsample, self.mlp_convs, self.mlp_bns, self.mlp_dtype, self.sync_bn)):
-            # MP_GATHER_FUSED=1: the grouped tensor is never written, the first layer's kernels gather the rows themselves
-            # (sa_mlp.shared_mlp_max_gathered).  [r2] measured: the grouping kernel's 65 us go, the two consumers take 30 + 44 us longer
-            # (dependent index -> row loads inside their chunk loops): no gain, so the switch is off.
-            new_xyz, idx = sample_indices(self.npoint, self.radius, self.nsample, xyz)
-            new_points = sa_mlp.shared_mlp_max_gathered(xyz, points, new_xyz, idx, self.mlp_convs, self.mlp_bns)
-            return new_xyz.permute(0, 2, 1), new_points.permute(0, 2, 1)
         else:
             new_xyz, grouped = sample_and_group(self.npoint, self.radius, self.nsample, xyz, points,
                                                 full_points=full_points, _pad_to=4, _xyz_last=True)

@@ -56,12 +56,10 @@ class _SharedMLPMax(torch.autograd.Function):
             # bf16 values (in fp32 storage); the gradient still goes to the unrounded parameter
             x = _r16(x)
             params = (_r16(params[0]),) + tuple(params[1:])
-        # the pooled layer without its stored activation (csrc/sa_lean.hip): Z_L [P, Co] is neither written here nor read in backward
-        lean_last = (not bf16) and LEAN_LAST and bool(lib.mp_sa_mlp_lean_last(n_layers, ch, K, P))
         for l in range(n_layers):
             w, b, gam, bet, rm, rv = params[6 * l:6 * l + 6]
             co, ci = w.shape
-            skip_z = (l == 0 and recompute_first) or (l == n_layers - 1 and lean_last)
+            skip_z = l == 0 and recompute_first
             z = None if skip_z else torch.empty((P, co), dtype=torch.float32, device=dev)
             stats = torch.empty((4, co), dtype=torch.float32, device=dev)  # mean, rstd, scale, shift
             keep.append((w, b, gam, bet, rm, rv, z, stats))
@@ -135,86 +133,6 @@ class _SharedMLPMax(torch.autograd.Function):
         return (gx, None, None, None, None, None, None, None, None, *ret)
 
 
-class _SharedMLPMaxGathered(torch.autograd.Function):
-    """_SharedMLPMax on a grouped input that is never materialised (mp_sa_mlp_{fwd,bwd}_gather_f32): row (b, s, k) of the level's input
-    is read where it lives -- feats[b, idx[b,s,k]] and xyz[b, idx] - new_xyz[b, s] -- by the first layer's forward and backward
-    kernels.  args: feats [B,N,CF], xyz [B,N,3], new_xyz [B,S,3], idx [B,S,K] i64, training, momentum, eps, L, then the layers'
-    parameters as for _SharedMLPMax (first weight already in the internal column order).  Gradient w.r.t. feats (the library writes
-    grad_x0 [P, CF + 4]; the scatter back to the points is ops.group's backward kernel)."""
-
-    @staticmethod
-    def forward(ctx, feats, xyz, new_xyz, idx, training, momentum, eps, n_layers, *params):
-        dev = feats.device
-        B, N, CF = feats.shape
-        _, S, K = idx.shape
-        P = B * S * K
-        layers = (_lib.MlpLayer * n_layers)()
-        keep = []
-        chans = [CF + 4] + [params[6 * l].shape[0] for l in range(n_layers)]
-        lib = _lib.load()
-        ch_ = (ctypes.c_int64 * len(chans))(*chans)
-        lean_last = LEAN_LAST and bool(lib.mp_sa_mlp_lean_last(n_layers, ch_, K, P))      # (see _SharedMLPMax)
-        for l in range(n_layers):
-            w, b, gam, bet, rm, rv = params[6 * l:6 * l + 6]
-            co, ci = w.shape
-            z = None if (l == n_layers - 1 and lean_last) else torch.empty((P, co), dtype=torch.float32, device=dev)
-            stats = torch.empty((4, co), dtype=torch.float32, device=dev)
-            keep.append((w, b, gam, bet, rm, rv, z, stats))
-            layers[l] = _lib.MlpLayer(_ptr(w), _ptr(b), _ptr(gam), _ptr(bet), _ptr(rm), _ptr(rv), ci, co, _ptr(z),
-                                      stats[0].data_ptr(), stats[1].data_ptr(), stats[2].data_ptr(), stats[3].data_ptr())
-        G = P // K
-        cl = chans[-1]
-        out = torch.empty((G, cl), dtype=torch.float32, device=dev)
-        argk = torch.empty((G, cl), dtype=torch.int32, device=dev)
-        zmax = torch.empty((G, cl), dtype=torch.float32, device=dev)
-        ch = (ctypes.c_int64 * len(chans))(*chans)
-        ws = torch.empty((lib.mp_sa_mlp_workspace_bytes(P, K, n_layers, ch, 0),), dtype=torch.uint8, device=dev)
-        g = _lib.Gather(_ptr(feats), _ptr(xyz), _ptr(new_xyz), _ptr(idx), N, S, CF)
-        ops._run("sa_mlp_fwd", feats, lib.mp_sa_mlp_fwd_gather_f32, ctypes.byref(g), P, K, n_layers, layers, int(training), float(momentum),
-                 float(eps), _ptr(out), _ptr(argk), _ptr(zmax), _ptr(ws), ws.numel())
-        ctx.meta = (P, K, bool(training), n_layers, chans, (B, N, S, CF))
-        ctx.keep = keep
-        ctx.save_for_backward(feats, xyz, new_xyz, idx, out, argk, zmax)
-        ctx.mark_non_differentiable(argk, zmax)
-        return out
-
-    @staticmethod
-    def backward(ctx, grad_out):
-        feats, xyz, new_xyz, idx, out, argk, zmax = ctx.saved_tensors
-        P, K, training, n_layers, chans, (B, N, S, CF) = ctx.meta
-        dev = feats.device
-        grad_out = grad_out.contiguous().float()
-        layers = (_lib.MlpLayer * n_layers)()
-        grads = (_lib.MlpGrads * n_layers)()
-        ret = []
-        dw_all = torch.empty((sum(k[0].numel() for k in ctx.keep),), dtype=torch.float32, device=dev)
-        dw_off = 0
-        for l, (w, b, gam, bet, rm, rv, z, stats) in enumerate(ctx.keep):
-            co, ci = w.shape
-            layers[l] = _lib.MlpLayer(_ptr(w), _ptr(b), _ptr(gam), _ptr(bet), _ptr(rm), _ptr(rv), ci, co, _ptr(z),
-                                      stats[0].data_ptr(), stats[1].data_ptr(), stats[2].data_ptr(), stats[3].data_ptr())
-            dw = dw_all[dw_off:dw_off + w.numel()].view_as(w)
-            dw_off += w.numel()
-            db = None if b is None else torch.empty_like(b)
-            dg, dbe = torch.empty_like(gam), torch.empty_like(bet)
-            grads[l] = _lib.MlpGrads(_ptr(dw), _ptr(db), _ptr(dg), _ptr(dbe))
-            ret += [dw, db, dg, dbe, None, None]
-        stride = CF + 4
-        gx = torch.empty((P, stride), dtype=torch.float32, device=dev)
-        ch = (ctypes.c_int64 * len(chans))(*chans)
-        lib = _lib.load()
-        ws = torch.empty((lib.mp_sa_mlp_workspace_bytes(P, K, n_layers, ch, 1),), dtype=torch.uint8, device=dev)
-        g = _lib.Gather(_ptr(feats), _ptr(xyz), _ptr(new_xyz), _ptr(idx), N, S, CF)
-        ops._run("sa_mlp_bwd", feats, lib.mp_sa_mlp_bwd_gather_f32, ctypes.byref(g), P, K, n_layers, layers, int(training), _ptr(grad_out),
-                 _ptr(out), _ptr(argk), _ptr(zmax), grads, _ptr(gx), CF, _ptr(ws), ws.numel())
-        ctx.keep = None
-        gf = None
-        if ctx.needs_input_grad[0]:
-            gf = torch.empty((B, N, CF), dtype=torch.float32, device=dev)
-            ops._run("group_bwd", gx, lib.mp_group_bwd_f32, _ptr(gx), _ptr(idx), B, N, S, K, CF, 1, stride, _ptr(gf), int(ops.DETERMINISTIC))
-        return (gf, None, None, None, None, None, None, None, *ret)
-
-
 class _SharedMLPMaxFactored(torch.autograd.Function):
     """The level with its first layer factorised (sa_mlp.hip, first_factored_fwd_kernel): Z_0[p] = A[b, idx[p]] + W_x (x[idx[p]] - c),
     A = F W_f^T computed per SOURCE point by the caller.  args: A [B,N,Co] (carries the gradient), xyz [B,N,3], new_xyz [B,S,3],
@@ -233,11 +151,10 @@ class _SharedMLPMaxFactored(torch.autograd.Function):
         lib = _lib.load()
         ch_ = (ctypes.c_int64 * len(chans))(*chans)
         sync = sync_group is not False and training      # global-batch BatchNorm statistics (sync_bn.py), as in _SharedMLPMax
-        lean_last = (not bf16) and (not sync) and LEAN_LAST and bool(lib.mp_sa_mlp_lean_last(n_layers, ch_, K, P))      # (see _SharedMLPMax)
         for l in range(n_layers):
             w, b, gam, bet, rm, rv = params[6 * l:6 * l + 6]
             co, ci = w.shape
-            z = None if (l == n_layers - 1 and lean_last) else torch.empty((P, co), dtype=torch.float32, device=dev)
+            z = torch.empty((P, co), dtype=torch.float32, device=dev)
             stats = torch.empty((4, co), dtype=torch.float32, device=dev)
             keep.append((w, b, gam, bet, rm, rv, z, stats))
             layers[l] = _lib.MlpLayer(_ptr(w), _ptr(b), _ptr(gam), _ptr(bet), _ptr(rm), _ptr(rv), ci, co, _ptr(z),
@@ -326,10 +243,7 @@ class _SharedMLPMaxFactored(torch.autograd.Function):
         return (gA, None, None, None, None, None, None, None, None, None, *ret)
 
 
-PER_POINT_DW_SLICES = int(os.environ.get("MP_PER_POINT_DW_SLICES", "8"))
-# MASKPLANNER_LEAN_LAST=0: every level stores the raw activation of its pooled layer and backpropagates through the dense dZ_L
-# (the library's own switch MP_LEAN_LAST=0 does the same for every caller)
-LEAN_LAST = os.environ.get("MASKPLANNER_LEAN_LAST", "1") != "0"
+PER_POINT_DW_SLICES = 8      # K slices per cloud of the batched weight-gradient GEMM below
 
 
 class _PerPointFirst(torch.autograd.Function):
@@ -372,7 +286,7 @@ class _PerPointFirst(torch.autograd.Function):
 # 2.64 ms per step) and the multi-scale levels, whose 323-input first layers are otherwise tiled GEMMs over 935 MB of grouped rows
 # (config 5: 11.5 -> 9.0 ms); "msg": the multi-scale levels only; "0": none (the grouped route).
 FACTORED_FIRST = os.environ.get("MASKPLANNER_FACTORED_FIRST", "1")
-FACTORED_REDUCE = os.environ.get("MASKPLANNER_FACTORED_REDUCE", "1") != "0"   # 0: dZ_0 written out and reduced by the grouping backward's kernel
+FACTORED_REDUCE = True   # False (tests): dZ_0 written out and reduced by the grouping backward's kernel, as ops.DETERMINISTIC does
 
 
 def factored_supported(feats, K, convs, bns, dtype="f32", sync_bn=None):
@@ -424,54 +338,6 @@ def shared_mlp_max_factored(xyz, feats, new_xyz, idx, convs, bns, weight_order="
     if training:
         for dst, src in writeback:
             dst.copy_(src[:dst.numel()])
-    return out.view(B, S, -1)
-
-
-def gathered_supported(feats, K, convs, bns, dtype="f32", sync_bn=None):
-    """True when shared_mlp_max_gathered can take this level (otherwise group + shared_mlp_max)."""
-    from .sync_bn import resolve
-    if dtype != "f32" or resolve(sync_bn) is not False or feats is None or not feats.is_cuda or feats.dtype != torch.float32:
-        return False
-    if len(convs) < 2 or convs[0].in_channels != feats.shape[2] + 3:
-        return False
-    chans = [feats.shape[2] + 4] + [c.out_channels for c in convs]
-    ch = (ctypes.c_int64 * len(chans))(*chans)
-    return bool(_lib.load().mp_sa_mlp_gather_supported(len(convs), ch, int(K), feats.shape[2]))
-
-
-def shared_mlp_max_gathered(xyz, feats, new_xyz, idx, convs, bns):
-    """shared_mlp_max(ops.group(xyz, feats, new_xyz, idx, xyz_last=True, pad_to=4), ..., layout="feats_first") without the grouped
-    tensor: xyz [B,N,3], feats [B,N,CF], new_xyz [B,S,3], idx [B,S,K] -> [B,S,Cout].  Check gathered_supported() first."""
-    ops._need_hip(xyz, feats, new_xyz, idx)
-    B, S, K = idx.shape
-    cin = convs[0].in_channels
-    cpad = (cin + 3) // 4 * 4
-    training = bns[0].training
-    params = []
-    for i, (conv, bn) in enumerate(zip(convs, bns)):
-        if bn.training != training:
-            raise ValueError("all BatchNorm layers of a set-abstraction level must share one mode")
-        w = conv.weight.view(conv.out_channels, conv.in_channels)
-        if i == 0:
-            pre = _PREPERMUTED.pop(id(conv), None)
-            if pre is not None and (pre[1] != conv.weight._version or pre[0].shape != (conv.out_channels, cpad)):
-                pre = None
-            w = pre[0] if pre is not None else _PermuteCols.apply(w, *_first_weight_perm(cin, cpad, True, w.device))
-        track = bn.track_running_stats and bn.running_mean is not None
-        if not training and not track:
-            raise NotImplementedError("eval-mode BatchNorm without running statistics")
-        params += [w, conv.bias, bn.weight, bn.bias, bn.running_mean if track else None, bn.running_var if track else None]
-    if training:
-        counters = [bn.num_batches_tracked for bn in bns if bn.track_running_stats and bn.num_batches_tracked is not None]
-        if counters:
-            if DEFERRED_TICKS is not None:
-                DEFERRED_TICKS.extend(counters)
-            else:
-                torch._foreach_add_(counters, 1)
-    bn0 = bns[0]
-    momentum = bn0.momentum if bn0.momentum is not None else 1.0 / max(float(bn0.num_batches_tracked), 1.0)
-    out = _SharedMLPMaxGathered.apply(feats.contiguous(), xyz.contiguous().float(), new_xyz.contiguous().float(), idx.contiguous(), training,
-                                      momentum, bn0.eps, len(convs), *params)
     return out.view(B, S, -1)
 
 
@@ -648,7 +514,7 @@ def shared_mlp_max(grouped, convs, bns, layout="xyz_first", dtype="f32", sync_bn
 # [64, 96, 128] at 2 M positions -- is cheaper carried as 128 with 32 dead channels: zero weight rows / bias, gamma 1, beta 0 give
 # z = 0, BatchNorm maps that to exactly 0, ReLU keeps it, the next layer's zero columns ignore it, and every gradient of the dead
 # channels is exactly 0 (dy = 0 there).  The padding is made of autograd ops, so the parameters keep their shapes and gradients.
-WIDEN_INTERIOR = os.environ.get("MASKPLANNER_WIDEN_INTERIOR", "1") != "0"
+WIDEN_INTERIOR = True
 
 
 def _widen_interior(params, widths):

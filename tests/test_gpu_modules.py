@@ -1243,13 +1243,13 @@ def test_streamed_batches_feed_the_step_what_the_collate_produces():
     for step in range(9):
         losses.append(ts.step())
         torch.cuda.synchronize()
-        items = ts._stream.batches[step % 3]           # the batch this step consumed
+        items = ts._stream.batches[(step + 1) % 3]     # the hand-over at the END of a step publishes the batch the next step consumes
         want_pc = torch.from_numpy(np.stack([it["point_cloud"] for it in items])).cuda()
         assert torch.equal(ts.batch["point_cloud"], want_pc), step
         for k, fill in (("traj", -100.0), ("traj_as_pc", -100.0), ("stroke_ids", -1.0)):
             want = pad_ragged([it[k] for it in items], fill, "cuda", total_needed=ts.batch[k].shape[1])
             assert torch.equal(ts.batch[k], want), (step, k)
-        # the plan the step used (plan_cur) is the FPS / ball query of THIS cloud from the drawn starts: first index = the start
+        # the plan handed over with it (plan_cur) is the FPS / ball query of THAT cloud from the drawn starts: first index = the start
         fps_idx, new_xyz, idx = ts._plan_views(ts._plan_cur)[0]
         redo = ops.fps(ts.batch["point_cloud"], 512, fps_idx[:, 0].contiguous())
         assert torch.equal(redo, fps_idx), step
@@ -1290,44 +1290,6 @@ def test_every_launch_mode_updates_the_same_parameters(monkeypatch):
         frozen = [n for n in want if (want[n] > 0) != (got[n] > 0)]
         assert not frozen, (mode, frozen)
         assert all(got[n] < 10 * 2 * 1e-3 + 1e-6 for n in got), mode     # two steps of at most ~lr each
-
-
-@pytest.mark.gpu
-def test_gathered_first_layer_equals_the_grouped_one(monkeypatch):
-    """MP_GATHER_FUSED=1: set abstraction 2 never writes its grouped input -- the first layer's forward and backward kernels read row
-    (b, s, k) from the previous level's feature table and the coordinates (mp_sa_mlp_{fwd,bwd}_gather_f32).  Same rows, same kernels
-    otherwise: outputs identical, parameter and input gradients equal up to the atomics' summation order."""
-    from maskplanner_amd import ops, sa_mlp
-    from maskplanner_amd.pointnet2_utils import PointNetSetAbstraction, fps_start_override
-    monkeypatch.setattr(sa_mlp, "FACTORED_FIRST", "0")      # the grouped route and its gathered variant are what is compared here
-    torch.manual_seed(5)
-    B, N, D = 4, 512, 128
-    sa = PointNetSetAbstraction(npoint=128, radius=0.4, nsample=64, in_channel=D + 3, mlp=[128, 128, 256], group_all=False).cuda().train()
-    xyz = torch.rand(B, 3, N, device="cuda")
-    starts = [torch.zeros(B, dtype=torch.long)]
-    res = {}
-    det, ops.DETERMINISTIC = ops.DETERMINISTIC, True
-    try:
-        for mode in ("0", "1"):
-            monkeypatch.setenv("MP_GATHER_FUSED", mode)
-            feats = torch.randn(B, D, N, device="cuda").relu().requires_grad_(True)
-            torch.manual_seed(9)
-            feats.data = torch.randn(B, D, N, device="cuda").relu()
-            for p in sa.parameters():
-                p.grad = None
-            for bn in sa.mlp_bns:
-                bn.reset_running_stats()
-            with fps_start_override(list(starts)):
-                new_xyz, out = sa(xyz, feats)
-            (out * torch.linspace(-1, 1, out.numel(), device="cuda").view_as(out)).sum().backward()
-            res[mode] = (out.detach().clone(), feats.grad.clone(), [p.grad.clone() for p in sa.parameters()])
-    finally:
-        ops.DETERMINISTIC = det
-    (o0, g0, p0), (o1, g1, p1) = res["0"], res["1"]
-    assert torch.equal(o0, o1)
-    assert torch.allclose(g0, g1, rtol=1e-5, atol=1e-6 * float(g0.abs().max()))
-    for a, b in zip(p0, p1):
-        assert torch.allclose(a, b, rtol=1e-4, atol=2e-5 * float(a.abs().max())), float((a - b).abs().max())
 
 
 @pytest.mark.parametrize("reduce_in_library", [True, False])

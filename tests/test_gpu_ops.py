@@ -736,47 +736,6 @@ def test_screened_nearest_neighbour_equals_the_direct_scan(D, P1, P2):
     assert torch.equal(dd[..., 0], d0) and torch.equal(ii[..., 0], i0)
 
 
-@pytest.mark.gpu
-def test_fused_head_block_equals_linear_then_bn_relu_dropout():
-    """factor_heads.linear_block: dropout(relu(bn(linear(x)))) in ONE launch (mp_linear_block_f32: three-plane split product on the
-    matrix cores, BatchNorm statistics local to the workgroup's columns, the dropout hash of bn_relu_rows).  Against the two-launch
-    path (rocBLAS Linear, then ops.bn_relu_rows with the same rng): outputs, the dropout mask, running statistics, input / parameter
-    gradients and the weight-gradient factors agree at fp32 rounding level."""
-    from maskplanner_amd import ops
-    from maskplanner_amd.factor_heads import BIAS_QUEUE, factor_linear, flush_bias_grads, linear_block
-    torch.manual_seed(1)
-    B, K, N, p = 32, 1024, 1024, 0.3
-    lin = torch.nn.Linear(K, N).cuda()
-    bn = torch.nn.BatchNorm1d(N).cuda().train()
-    bn.weight.data.uniform_(0.5, 1.5); bn.bias.data.uniform_(-0.2, 0.2)
-    rng = torch.tensor([99, 7], dtype=torch.int64, device="cuda")
-    x0 = torch.randn(B, K, device="cuda")
-    w = torch.randn(B, N, device="cuda")
-    res = []
-    for fused in (False, True):
-        for t in (lin.weight, lin.bias, bn.weight, bn.bias):
-            t.grad = None
-        bn.reset_running_stats()
-        x = x0.clone().requires_grad_(True)
-        store = {BIAS_QUEUE: []}
-        if fused:
-            y = linear_block(x, lin, bn, store, "w", (p, rng, 2))
-        else:
-            y = ops.bn_relu_rows(factor_linear(x, lin, store, "w"), bn, dropout=(p, rng, 2))
-        (y * w).sum().backward()
-        flush_bias_grads(store)
-        res.append((y.detach().clone(), x.grad.clone(), lin.bias.grad.clone(), bn.weight.grad.clone(), bn.bias.grad.clone(),
-                    store["w"][1].clone(), bn.running_mean.clone(), bn.running_var.clone()))
-    a, b = res
-    assert float(((a[0] != 0) != (b[0] != 0)).float().mean()) < 1e-5     # same keep mask (activations within rounding of 0 aside)
-    for i, (u, v) in enumerate(zip(a, b)):
-        if i == 2:      # the Linear's bias sits in front of a train-mode BatchNorm: its gradient is rounding noise around zero
-            assert float(u.abs().max()) < 1e-4 and float(v.abs().max()) < 1e-4
-            continue
-        tol = 2e-5 * float(u.abs().max()) + 1e-6
-        assert float((u - v).abs().max()) < tol, (i, float((u - v).abs().max()), tol)
-
-
 @pytest.mark.parametrize("B,O,I", [(32, 11988, 1024), (32, 5994, 1024), (7, 4100, 256), (32, 4097, 128), (1, 16, 128)])
 def test_head_input_gradient_kernels_vs_fp64(ops, B, O, I):
     """grad_x = g W of the wide head Linears (autograd of nn.Linear, models/pointnet2_cls_ssg.py:311, 327, 336): the matrix-core form

@@ -1,7 +1,8 @@
-"""The switchable kernel variants against the default route, each in its own process (the library reads its switches once):
-the role-split fused backward of the 256-output layer (default) against the eight-wave kernel, its loads-straight-into-LDS forms,
-and the planes route of the few-row levels.  Same mathematics, other summation orders: outputs to fp32 rounding, gradients inside
-the max-pool routing bound."""
+"""The two contraction families of the set-abstraction MLP against each other, each in its own process (the library reads its switches
+once): the default split-plane kernels (fp32 operands as three bf16 planes on the bf16 matrix cores) and the fp32-MFMA kernels
+(MP_SA_SPLIT=0), on the second level's shape, an INTERIOR 128 -> 256 layer (the non-pooled form of the role-split backward) and the
+group_all level (tiled GEMMs).  Same mathematics, other summation orders: outputs to fp32 rounding, gradients inside the max-pool
+routing bound."""
 import os
 import subprocess
 import sys
@@ -24,26 +25,17 @@ def _run(shape, **env):
 
 def _same(a, b, what):
     for k in a:
-        ref = b[k]
-        tol = 2e-5 if k in ("y",) or k.startswith("rm") else 2e-3        # gradients: dW atomics + max-pool routing of near-ties
-        err = float((a[k] - ref).abs().max())
-        assert err <= tol * max(float(ref.abs().max()), 1e-6), (what, k, err, float(ref.abs().max()))
+        ref = b[k].double()
+        if k == "y" or k.startswith("rm"):       # forward values: fp32 rounding of two summation orders
+            err = float((a[k].double() - ref).abs().max())
+            assert err <= 2e-5 * max(float(ref.abs().max()), 1e-6), (what, k, err, float(ref.abs().max()))
+        else:                                    # gradients: the max-pool routes near-ties differently (relative L2, as the full-size tests)
+            err = float((a[k].double() - ref).norm() / ref.norm().clamp_min(1e-12))
+            assert err <= 3e-2, (what, k, err)
 
 
-@pytest.mark.parametrize("env", [dict(MP_BF_ROLES=0), dict(MP_BF_ROLES=3), dict(MP_BF_ROLES_LDS=2), dict(MP_BF_ROLES_LDS=3), dict(MP_LEAN_LAST=1)])
-def test_fused_backward_variants_of_the_second_level(env):
+@pytest.mark.parametrize("shape", ["sa2", "mid256", "sa3"])
+def test_split_plane_kernels_against_the_fp32_mfma_kernels(shape):
     if not torch.cuda.is_available():
         pytest.skip("needs an MI355X")
-    _same(_run("sa2", **env), _run("sa2"), env)
-
-
-def test_interior_256_output_layer_on_both_fused_backward_kernels():
-    if not torch.cuda.is_available():
-        pytest.skip("needs an MI355X")
-    _same(_run("mid256", MP_BF_ROLES=0), _run("mid256"), "interior 256")
-
-
-def test_planes_route_of_the_group_all_level():
-    if not torch.cuda.is_available():
-        pytest.skip("needs an MI355X")
-    _same(_run("sa3", MP_PLANES=1), _run("sa3"), "planes")
+    _same(_run(shape, MP_SA_SPLIT=0), _run(shape), shape)

@@ -19,7 +19,7 @@ def wrap(obj, name, label):
         marks.setdefault(label, []).append(time.perf_counter() - t0)
         return r
     setattr(obj, name, g)
-wrap(ts, "_pipeline_sampling", "pipeline_sampling (plan hand-over + next plan on the side stream)")
+wrap(ts, "_launch_sampling", "launch_sampling (next plan on the side stream)")
 wrap(ts._graph, "replay", "graph A replay")
 wrap(ts._graph_b, "replay", "graph B replay")
 wrap(ts, "_launch_factor_adam", "factor Adam launches")
