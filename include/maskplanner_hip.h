@@ -289,7 +289,16 @@ typedef struct {
     float* rstd;
     float* scale;
     float* shift;
+    double* bn_state; /* optional (NULL: as before).  MP_BN_STATE_DOUBLES(c_out) doubles of PERSISTENT, zero-initialised device memory owned by
+                       * the caller and used by one call at a time (keep it with the BatchNorm module).  With every layer's bn_state given (and
+                       * n_layers >= 2), a train-mode call without the SyncBN hook runs (almost) no BatchNorm finalize launches: the producing kernel
+                       * adds its fp64 sums into slot rows of this buffer and the first kernel that consumes the constants derives them in its
+                       * prologue (it also updates the running statistics / writes d_gamma, d_beta).  Rows are zeroed again by the kernels that
+                       * follow their consumer; between calls only rows that were already consumed can be non-zero, and every call starts by
+                       * zeroing those.  After a FAILED call zero the buffers yourself.  Same statistics up to the order of fp64 additions. */
 } mp_mlp_layer_t;
+#define MP_BN_SLOTS 8
+#define MP_BN_STATE_DOUBLES(c_out) ((size_t)4 * MP_BN_SLOTS * (size_t)(c_out))
 
 typedef struct {
     float* d_weight;

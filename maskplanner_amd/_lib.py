@@ -30,7 +30,7 @@ class MlpLayer(ctypes.Structure):
     """mp_mlp_layer_t"""
     _fields_ = [("weight", _vp), ("bias", _vp), ("gamma", _vp), ("beta", _vp), ("running_mean", _vp),
                 ("running_var", _vp), ("c_in", _i64), ("c_out", _i64), ("z", _vp), ("mean", _vp), ("rstd", _vp),
-                ("scale", _vp), ("shift", _vp)]
+                ("scale", _vp), ("shift", _vp), ("bn_state", _vp)]
 
 
 class MlpGrads(ctypes.Structure):

@@ -47,6 +47,148 @@ constexpr bool is_id(int m) { return m == SRC_ID; }
 constexpr bool is_rc(int m) { return m == SRC_ACT_RC || m == SRC_DZ_RC; }
 constexpr bool is_dz(int m) { return m == SRC_DZ || m == SRC_DZ_POOLED || m == SRC_DZ_RC; }
 
+// ---- BatchNorm statistics without a finalize launch of their own (train mode, per-replica statistics) ---------------------------
+// A layer's per-channel sums -- (sum z, sum z^2) forward, (sum dy, sum dy z) backward -- used to leave their producer as one fp32
+// partial row per workgroup and be reduced by bn_{fwd,bwd}_finalize_kernel: 18 launches of ~5 us per training step, each of them a
+// dependency bubble between two large kernels.  Now ("sites"):
+//  * the PRODUCER adds its fp64 sums into one of BN_NS slot rows with atomics (slot = workgroup index mod BN_NS: 8 rows to reduce
+//    instead of 512, a few dozen atomics per address);
+//  * the FIRST kernel that consumes the constants derives them in its prologue: every workgroup reduces the BN_NS rows of the
+//    channels it needs (L2 hits, one round trip), converts them (fp64, the finalize kernels' algebra) and keeps the result in LDS,
+//    where load_consts() reads it; workgroup 0 also writes the global arrays later kernels read (scale / shift for the backward
+//    pass, a / e / f for the second kernel of a dW + dX pair), updates the running statistics and writes dgamma / dbeta / dbias;
+//  * nobody counts readers: workgroup 0 of a kernel zeroes the slot rows of the site the PREVIOUS kernel of the call consumed
+//    (that kernel has completed), and the first kernel of a call zeroes the two sites the previous calls left behind (the last
+//    forward site and the first-layer backward site).  At any time the only non-zero rows are ones that were already consumed.
+// The rows live in caller-owned, persistent, zero-initialised memory (mp_mlp_layer_t::bn_state).  Statistics equal the finalize
+// kernels' up to the order of fp64 additions.
+constexpr int BN_NS = 8;
+constexpr int BN_POOL_CMAX = 1024;   // widest pooled layer whose select kernel derives its own constants
+// mp_mlp_layer_t::bn_state of a layer with C outputs, in doubles: [forward slots BN_NS * 2 * C | backward slots BN_NS * 2 * C]
+// (MP_BN_STATE_DOUBLES in the header)
+inline double* bn_fwd_slots(double* st, int C) { (void)C; return st; }
+inline double* bn_bwd_slots(double* st, int C) { return st + (size_t)BN_NS * 2 * C; }
+struct BnSite {
+    double* slots;            // [BN_NS][2][C]; NULL: off (the constants come from a finalize launch as before)
+    int C;
+    int kind;                 // 1: forward statistics -> scale, shift (+ mean, rstd, running stats); 2: backward sums -> a, e, f (+ dgamma, dbeta, dbias)
+    double invP, unbias, momentum, eps;
+    const float* gamma;
+    const float* beta;
+    const float* bias;
+    float* running_mean;
+    float* running_var;
+    float* mean;              // kind 1: out; kind 2: in
+    float* rstd;
+    float* o0;                // kind 1: scale, shift; kind 2: a, e, f (global copies, written by workgroup 0)
+    float* o1;
+    float* o2;
+    float* dgamma;
+    float* dbeta;
+    float* dbias;
+    double* z0;               // slot rows of the site the previous kernel consumed: zeroed by workgroup 0
+    int n0;
+};
+// where a producer's per-workgroup sums go: one fp32 partial row per workgroup (legacy: finalize kernels) or a site's slot rows
+struct BnOut {
+    float* rows;
+    double* slots;
+    double* z0;               // first kernel of a call: the two sites earlier calls left behind (zeroed by workgroup 0)
+    int n0;
+    double* z1;
+    int n1;
+};
+__device__ __forceinline__ int bn_linear_tid() { return (threadIdx.z * blockDim.y + threadIdx.y) * blockDim.x + threadIdx.x; }
+__device__ __forceinline__ void bn_zero_rows(double* z, int n)
+{
+    const int nt = blockDim.x * blockDim.y * blockDim.z;
+    if (z) for (int i = bn_linear_tid(); i < n; i += nt) z[i] = 0.0;
+}
+// producers call this once (any place): the zeroing duty of the first kernel of a call
+__device__ __forceinline__ void bn_zero(const BnOut& o)
+{
+    if ((blockIdx.x | blockIdx.y | blockIdx.z) != 0) return;
+    bn_zero_rows(o.z0, o.n0);
+    bn_zero_rows(o.z1, o.n1);
+}
+__device__ __forceinline__ void bn_emit(const BnOut& o, int C, unsigned blk, int c, double s1, double s2)
+{
+    if (o.slots) {
+        double* q = o.slots + (size_t)(blk & (BN_NS - 1)) * 2 * (unsigned)C;
+        atomicAdd(q + c, s1);
+        atomicAdd(q + C + c, s2);
+    } else {
+        o.rows[((size_t)blk * 2 + 0) * C + c] = (float)s1;
+        o.rows[((size_t)blk * 2 + 1) * C + c] = (float)s2;
+    }
+}
+// Consumer prologue: every thread of every workgroup calls it before load_consts(); contains one barrier.  The constants of channels
+// [c0, c0 + cn) go to lds[k * ld + (c - c0)] (k = 0, 1: scale, shift; or 0, 1, 2: a, e, f).  `writer`: this workgroup also writes
+// the global arrays and does the once-only duties for its channels (one workgroup per channel range must be the writer).
+__device__ __forceinline__ void bn_prologue(const BnSite& b, float* lds, int ld, int c0, int cn, bool writer)
+{
+    if (b.slots == nullptr) return;
+    const int nt = blockDim.x * blockDim.y * blockDim.z;
+    const int tid = bn_linear_tid();
+    const int C = b.C;
+    if ((blockIdx.x | blockIdx.y | blockIdx.z) == 0) bn_zero_rows(b.z0, b.n0);
+    for (int i = tid; i < cn; i += nt) {
+        const int c = c0 + i;
+        if (c >= C) break;
+        double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int s = 0; s < BN_NS; ++s) {
+            s1 += b.slots[(size_t)(s * 2 + 0) * C + c];
+            s2 += b.slots[(size_t)(s * 2 + 1) * C + c];
+        }
+        if (b.kind == 1) {      // bn_fwd_finalize_kernel, training branch
+            const double mean = s1 * b.invP;
+            double var = s2 * b.invP - mean * mean;
+            if (var < 0.0) var = 0.0;
+            const double rstd = 1.0 / sqrt(var + b.eps);
+            const float sc = (float)((double)b.gamma[c] * rstd);
+            const float sh = (float)((double)b.beta[c] - mean * (double)sc);
+            lds[i] = sc;
+            lds[ld + i] = sh;
+            if (writer) {
+                b.o0[c] = sc;
+                b.o1[c] = sh;
+                b.mean[c] = (float)mean;
+                b.rstd[c] = (float)rstd;
+                if (b.running_mean) {
+                    const float bi = b.bias ? b.bias[c] : 0.0f;
+                    b.running_mean[c] = (float)((1.0 - b.momentum) * (double)b.running_mean[c] + b.momentum * (mean + (double)bi));
+                    b.running_var[c] = (float)((1.0 - b.momentum) * (double)b.running_var[c] + b.momentum * var * b.unbias);
+                }
+            }
+        } else {                // bn_bwd_finalize_kernel, training branch
+            const double mu = b.mean[c], rs = b.rstd[c], g = b.gamma[c];
+            const double dbe = s1, dga = rs * (s2 - mu * s1);
+            const double a = g * rs, c1 = dbe * b.invP, c2 = dga * b.invP;
+            const float fa = (float)a, fe = (float)(-a * c2 * rs), ff = (float)(-a * c1 + a * c2 * rs * mu);
+            lds[i] = fa;
+            lds[ld + i] = fe;
+            lds[2 * ld + i] = ff;
+            if (writer) {
+                b.o0[c] = fa;
+                b.o1[c] = fe;
+                b.o2[c] = ff;
+                b.dbeta[c] = (float)dbe;
+                b.dgamma[c] = (float)dga;
+                if (b.dbias) b.dbias[c] = 0.0f;
+            }
+        }
+    }
+    __syncthreads();
+}
+// a site whose first consumer has no prologue (tiled forward GEMMs, the unfused pool): the same algebra as a launch of its own
+__global__ __launch_bounds__(256) void bn_site_finalize_kernel(BnSite b)
+{
+    __shared__ float scratch[3 * 256];
+    const int c0 = blockIdx.x * 256;
+    bn_prologue(b, scratch, 256, c0, 256, true);
+}
+
 // A positions-major operand: rows = positions, columns = channels (contiguous).  Every channel count is a multiple
 // of 4 (checked on the host; the Python layer zero-pads 3 -> 4, 131 -> 132, 259 -> 260), so a float4 of channels is
 // either entirely inside or entirely outside and every global access is an aligned 16-byte one.  Element offsets
@@ -65,6 +207,7 @@ struct PosOperand {
     int kshift;          // log2(K) when K is a power of two (every sampled level), else -1: position -> (group, member) by shift / mask
     const float* rx;     // *_RC: the level's input rows X0 [P, 4]
     const float* rw;     // *_RC: the first layer's weight W0 [C, 4]
+    BnSite bn;           // the kernel is the FIRST consumer of this operand's constants (s, t or a, e, f): derive them in its prologue
 };
 
 // Per-channel constants of 4 consecutive channels, loaded ONCE per thread and tile (not per element).
@@ -76,18 +219,33 @@ struct ChanConst {
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ float comp(const float4& v, int j) { return j == 0 ? v.x : (j == 1 ? v.y : (j == 2 ? v.z : v.w)); }
 
+// lds != NULL and o.bn on: the constants this kernel derived itself (bn_prologue) -- (scale, shift) of an activation operand or
+// (a, e, f) of a dZ operand -- are read from lds[k * ld + (c - c0)]; everything else from the global arrays as before.
 template <int MODE>
-__device__ __forceinline__ void load_consts(const PosOperand& o, int c, ChanConst& k)
+__device__ __forceinline__ void load_consts(const PosOperand& o, int c, ChanConst& k, const float* lds = nullptr, int ld = 0, int c0 = 0)
 {
     const int cc = c < o.C ? c : 0;  // clamped: out-of-range channels are zeroed by the `ok` flag of their data
+    const bool own = lds != nullptr && o.bn.slots != nullptr;
+    const int cl = c < o.C ? c - c0 : 0;
     if constexpr (!is_id(MODE)) {
-        k.s = ld4(o.s + cc);
-        k.t = ld4(o.t + cc);
+        if (!is_dz(MODE) && own) {
+            k.s = *reinterpret_cast<const float4*>(lds + cl);
+            k.t = *reinterpret_cast<const float4*>(lds + ld + cl);
+        } else {
+            k.s = ld4(o.s + cc);
+            k.t = ld4(o.t + cc);
+        }
     }
     if constexpr (is_dz(MODE)) {
-        k.a = ld4(o.a + cc);
-        k.e = ld4(o.e + cc);
-        k.f = ld4(o.f + cc);
+        if (own) {
+            k.a = *reinterpret_cast<const float4*>(lds + cl);
+            k.e = *reinterpret_cast<const float4*>(lds + ld + cl);
+            k.f = *reinterpret_cast<const float4*>(lds + 2 * ld + cl);
+        } else {
+            k.a = ld4(o.a + cc);
+            k.e = ld4(o.e + cc);
+            k.f = ld4(o.f + cc);
+        }
     }
     if constexpr (is_rc(MODE)) {
 #pragma unroll
@@ -448,12 +606,13 @@ struct PoolOut {
 
 template <int MODE, bool W_KROW, int EPI, int WAVES_M, int WAVES_N, int TM, int TN, int PREC = 0>   // PREC: 0 fp32 MFMA, 1 bf16, 3 split (h, m, l) planes
 __global__ __launch_bounds__(THREADS) void pos_gemm_kernel(PosOperand A, int P, const float* __restrict__ W, int N,
-                                                           int Kd, float* __restrict__ C, float* __restrict__ partials,
+                                                           int Kd, float* __restrict__ C, BnOut partials,
                                                            const float* __restrict__ zprev,
                                                            const float* __restrict__ sprev,
                                                            const float* __restrict__ tprev, PoolOut po, int ldw,
                                                            int ldc)
 {   // ldw: row stride of W in the NN form (>= N: only the first N columns are produced); ldc: row stride of C
+    bn_zero(partials);
     constexpr int BM = WAVES_M * TM * 32;
     constexpr int BN = WAVES_N * TN * 32;
     // (these shadow the file-level constants) split planes on the 64 x 64 tile: K chunks of 64 -- the six-product chunk of 32 is over
@@ -661,7 +820,10 @@ __global__ __launch_bounds__(THREADS) void pos_gemm_kernel(PosOperand A, int P, 
             float v = 0.0f;
 #pragma unroll
             for (int w = 0; w < WAVES_M; ++w) v += red[w][st][c];
-            if (n0 + c < N) partials[((size_t)blockIdx.x * 2 + st) * N + n0 + c] = v;
+            if (n0 + c < N) {
+                if (partials.slots) atomicAdd(partials.slots + ((size_t)(blockIdx.x & (BN_NS - 1)) * 2 + st) * N + n0 + c, (double)v);
+                else partials.rows[((size_t)blockIdx.x * 2 + st) * N + n0 + c] = v;
+            }
         }
     }
     if constexpr (EPI == EPI_SQ_POOL) {
@@ -689,47 +851,56 @@ __global__ __launch_bounds__(THREADS) void pos_gemm_kernel(PosOperand A, int P, 
 }
 
 // out = relu(z* * scale + shift) with z* = group max (scale >= 0) or group min (scale < 0) of the raw activations
-__global__ __launch_bounds__(256) void pool_select_kernel(PoolOut po, const float* __restrict__ s,
-                                                          const float* __restrict__ t, int64_t G, int C,
+__global__ __launch_bounds__(256) void pool_select_kernel(PoolOut po, const float* s, const float* t, int64_t G, int C,      // (s, t: written by bn_prologue)
                                                           float* __restrict__ out, int* __restrict__ argk,
-                                                          float* __restrict__ zmax)
+                                                          float* __restrict__ zmax, BnSite bn)
 {   // four channels per thread (C % 4 == 0, every buffer 16-byte aligned: the host checks); the min side is only read where a
-    // scale is negative
-    const int64_t e = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
-    if (e >= G * C) return;
-    const int c = (int)(e % C);
-    const float4 sc = *reinterpret_cast<const float4*>(s + c), sh = *reinterpret_cast<const float4*>(t + c);
-    float4 z = *reinterpret_cast<const float4*>(po.vmax + e);
-    int4 k = *reinterpret_cast<const int4*>(po.imax + e);
-    if (sc.x < 0.0f || sc.y < 0.0f || sc.z < 0.0f || sc.w < 0.0f) {
-        const float4 zn = *reinterpret_cast<const float4*>(po.vmin + e);
-        const int4 kn = *reinterpret_cast<const int4*>(po.imin + e);
-        if (sc.x < 0.0f) { z.x = zn.x; k.x = kn.x; }
-        if (sc.y < 0.0f) { z.y = zn.y; k.y = kn.y; }
-        if (sc.z < 0.0f) { z.z = zn.z; k.z = kn.z; }
-        if (sc.w < 0.0f) { z.w = zn.w; k.w = kn.w; }
+    // scale is negative.  Grid-stride: with its own BatchNorm prologue (bn.slots) the host launches fewer, longer workgroups.
+    __shared__ __attribute__((aligned(16))) float bn_lds[2 * BN_POOL_CMAX];
+    const int64_t tot = G * C;
+    const int64_t e0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    // the first element's loads are issued BEFORE the prologue (its slot reads then share their latency)
+    float4 z0 = make_float4(0.f, 0.f, 0.f, 0.f);
+    int4 k0 = make_int4(0, 0, 0, 0);
+    if (e0 < tot) { z0 = *reinterpret_cast<const float4*>(po.vmax + e0); k0 = *reinterpret_cast<const int4*>(po.imax + e0); }
+    bn_prologue(bn, bn_lds, BN_POOL_CMAX, 0, C, blockIdx.x == 0);
+    const float* sp = bn.slots ? bn_lds : s;
+    const float* tp = bn.slots ? bn_lds + BN_POOL_CMAX : t;
+    for (int64_t e = e0; e < tot; e += (int64_t)gridDim.x * 1024) {
+        const int c = (int)(e % C);
+        const float4 sc = *reinterpret_cast<const float4*>(sp + c), sh = *reinterpret_cast<const float4*>(tp + c);
+        float4 z = e == e0 ? z0 : *reinterpret_cast<const float4*>(po.vmax + e);
+        int4 k = e == e0 ? k0 : *reinterpret_cast<const int4*>(po.imax + e);
+        if (sc.x < 0.0f || sc.y < 0.0f || sc.z < 0.0f || sc.w < 0.0f) {
+            const float4 zn = *reinterpret_cast<const float4*>(po.vmin + e);
+            const int4 kn = *reinterpret_cast<const int4*>(po.imin + e);
+            if (sc.x < 0.0f) { z.x = zn.x; k.x = kn.x; }
+            if (sc.y < 0.0f) { z.y = zn.y; k.y = kn.y; }
+            if (sc.z < 0.0f) { z.z = zn.z; k.z = kn.z; }
+            if (sc.w < 0.0f) { z.w = zn.w; k.w = kn.w; }
+        }
+        float4 y;
+        y.x = z.x * sc.x + sh.x; y.y = z.y * sc.y + sh.y; y.z = z.z * sc.z + sh.z; y.w = z.w * sc.w + sh.w;
+        y.x = y.x > 0.0f ? y.x : 0.0f; y.y = y.y > 0.0f ? y.y : 0.0f; y.z = y.z > 0.0f ? y.z : 0.0f; y.w = y.w > 0.0f ? y.w : 0.0f;
+        *reinterpret_cast<float4*>(out + e) = y;
+        *reinterpret_cast<int4*>(argk + e) = k;
+        *reinterpret_cast<float4*>(zmax + e) = z;
     }
-    float4 y;
-    y.x = z.x * sc.x + sh.x; y.y = z.y * sc.y + sh.y; y.z = z.z * sc.z + sh.z; y.w = z.w * sc.w + sh.w;
-    y.x = y.x > 0.0f ? y.x : 0.0f; y.y = y.y > 0.0f ? y.y : 0.0f; y.z = y.z > 0.0f ? y.z : 0.0f; y.w = y.w > 0.0f ? y.w : 0.0f;
-    *reinterpret_cast<float4*>(out + e) = y;
-    *reinterpret_cast<int4*>(argk + e) = k;
-    *reinterpret_cast<float4*>(zmax + e) = z;
 }
 
-// the same, one channel per thread: for a channel count or buffers that do not take 16-byte accesses
-__global__ __launch_bounds__(256) void pool_select_scalar_kernel(PoolOut po, const float* __restrict__ s,
-                                                                 const float* __restrict__ t, int64_t G, int C,
+__global__ __launch_bounds__(256) void pool_select_scalar_kernel(PoolOut po, const float* s, const float* t, int64_t G, int C,
                                                                  float* __restrict__ out, int* __restrict__ argk,
-                                                                 float* __restrict__ zmax)
+                                                                 float* __restrict__ zmax, BnSite bn)
 {
+    __shared__ float bn_lds[2 * BN_POOL_CMAX];
+    bn_prologue(bn, bn_lds, BN_POOL_CMAX, 0, C, blockIdx.x == 0);
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (e >= G * C) return;
     const int c = (int)(e % C);
-    const float sc = s[c];
+    const float sc = bn.slots ? bn_lds[c] : s[c];
     const bool up = sc >= 0.0f;
     const float z = up ? po.vmax[e] : po.vmin[e];
-    const float y = z * sc + t[c];
+    const float y = z * sc + (bn.slots ? bn_lds[BN_POOL_CMAX + c] : t[c]);
     out[e] = y > 0.0f ? y : 0.0f;
     argk[e] = up ? po.imax[e] : po.imin[e];
     zmax[e] = z;
@@ -765,6 +936,8 @@ __global__ __launch_bounds__(THREADS) void dw_gemm_kernel(PosOperand DZ, PosOper
     const int wave = tid >> 6, lane = tid & 63;
     const int wrow0 = (wave / WAVES_N) * TM * 32, wcol0 = (wave % WAVES_N) * TN * 32;
     const int co0 = blockIdx.y * BM, ci0 = ci_base + blockIdx.z * BN;
+    __shared__ __attribute__((aligned(16))) float bn_lds[3 * BM];          // (a, e, f) of this workgroup's BM output channels
+    bn_prologue(DZ.bn, bn_lds, BM, co0, BM, blockIdx.x == 0 && blockIdx.z == 0);
     const bool do_tail = tail_ci >= 0 && blockIdx.z == gridDim.z - 1;
     float tacc0 = 0.0f, tacc1 = 0.0f;
     ChanConst kt;
@@ -786,7 +959,7 @@ __global__ __launch_bounds__(THREADS) void dw_gemm_kernel(PosOperand DZ, PosOper
     const int ka0 = (tid * 4) / BM, kb0 = (tid * 4) / BN;       // first slab row of this thread
     constexpr int KA_STEP = THREADS * 4 / BM, KB_STEP = THREADS * 4 / BN;
     ChanConst ka, kb;
-    load_consts<MODE_DZ>(DZ, co0 + ca, ka);
+    load_consts<MODE_DZ>(DZ, co0 + ca, ka, bn_lds, BM, co0);
     load_consts<MODE_IN>(IN, ci0 + cb, kb);
 
     Raw4<MODE_DZ> ra[PA];
@@ -902,10 +1075,12 @@ __global__ __launch_bounds__(THREADS) void dw_gemm_kernel(PosOperand DZ, PosOper
 template <int CI, int CO, bool POOL, int MODE_A = SRC_ACT, int TAIL = 0, bool SPLIT = false, bool STORE = true, bool ONE = false>   // TAIL = 4: input rows are [CI | 4] wide (features | xyz + pad)
 __global__ __launch_bounds__(CO > 128 ? 512 : 256) void fwd_chunk_kernel(PosOperand A, int P, int p_per_block,
                                                                          const float* __restrict__ W, float* __restrict__ Z,
-                                                                         float* __restrict__ partials, PoolOut po,
+                                                                         BnOut partials, PoolOut po,
                                                                          const float* __restrict__ gamma)
 {   // gamma (POOL): this layer's BatchNorm weight -- its sign is the sign of the affine scale, i.e. whether the pool of a column
     // takes the group's largest or smallest raw value, so every lane tracks ONE extremum
+    bn_zero(partials);
+    __shared__ __attribute__((aligned(16))) float bn_lds[2 * CI];           // (scale, shift) of the input activation when this kernel derives them
     constexpr int NT = CO > 128 ? 512 : 256, NW = NT / 64;
     constexpr int CW = CO / NW;                       // columns per wave: 32 (one 32x32 MFMA tile) or 16 (two 16x16 tiles)
     constexpr bool BIG = CW == 32;                    // v_mfma_f32_32x32x2_f32: a lane's 32 consecutive columns = whole 128-B lines
@@ -957,7 +1132,6 @@ __global__ __launch_bounds__(CO > 128 ? 512 : 256) void fwd_chunk_kernel(PosOper
     const int ca = (tid % (CI / 4)) * 4, ka0 = tid / (CI / 4);
     constexpr int KA_STEP = NT / (CI / 4);
     ChanConst kc;
-    load_consts<MODE_A>(A, ca, kc);
     struct RSet { Raw4<MODE_A> a[PA]; Raw4<MODE_A> t; };
     RSet rs0, rs1;                             // (rs1: FPD2 only)
     auto gload = [&](int pk, RSet& rs) {
@@ -1013,6 +1187,8 @@ __global__ __launch_bounds__(CO > 128 ? 512 : 256) void fwd_chunk_kernel(PosOper
     // FPD2: two chunks of loads in flight (two register sets, the loop unrolled by two), as bwd_fused_kernel's PD2
     constexpr bool FPD2 = MP_FPD2 && SPLIT;
     gload(p0, rs0);
+    bn_prologue(A.bn, bn_lds, CI, 0, CI, blockIdx.x == 0);      // (behind the first chunk's loads: its slot reads share their latency)
+    load_consts<MODE_A>(A, ca, kc, bn_lds, CI);
     sstore(0, rs0);
     if constexpr (FPD2) {
         if (nchunks > 1) gload(p0 + DBK, rs0);
@@ -1162,8 +1338,7 @@ __global__ __launch_bounds__(CO > 128 ? 512 : 256) void fwd_chunk_kernel(PosOper
         s2 += __shfl_xor(s2, d, 64);
     }
     if (kq == 0) {
-        partials[((size_t)blockIdx.x * 2 + 0) * CO + col] = (float)s1;
-        partials[((size_t)blockIdx.x * 2 + 1) * CO + col] = (float)s2;
+        bn_emit(partials, CO, blockIdx.x, col, s1, s2);
     }
 }
 
@@ -1201,8 +1376,9 @@ constexpr int bwd_fused_threads(int CO, int CI, bool SPLIT, bool ONE)
 template <int MODE_DZ, int CO, int CI, int MODE_IN = SRC_ACT, bool SPLIT = false, bool ONE = false>      // ONE: see fwd_chunk_kernel
 __global__ __launch_bounds__(bwd_fused_threads(CO, CI, SPLIT, ONE), (CO >= 128 && CI == 128 ? 1 : ((SPLIT && CI == 64) ? MP_SPLIT_WGS : 2))) void bwd_fused_kernel(PosOperand DZ, PosOperand IN, int P, int p_per_block,
                                                             const float* __restrict__ W, float* __restrict__ dW,
-                                                            float* __restrict__ G, float* __restrict__ partials)
+                                                            float* __restrict__ G, BnOut partials)
 {
+    __shared__ __attribute__((aligned(16))) float bn_lds[3 * CO];           // (a, e, f) of dZ_l when this kernel derives them
     constexpr int NT = bwd_fused_threads(CO, CI, SPLIT, ONE), NW = NT / 64;
     constexpr int DBK = (CI == 128 || SPLIT) ? 16 : 32;   // positions per chunk (LDS and registers: at least two workgroups per CU)
     constexpr int XW = DBK == 32 ? CI / (NW / 2) : CI / NW; // dX columns per wave (the chunk's dX tile is [DBK x CI])
@@ -1263,17 +1439,12 @@ __global__ __launch_bounds__(bwd_fused_threads(CO, CI, SPLIT, ONE), (CO >= 128 &
     constexpr int KA_STEP = SPLIT ? 4 * (NW / NBA) : NT / (CO / 4), KB_STEP = SPLIT ? 4 * (NW / NBB) : NT / (CI / 4);
     static_assert(!SPLIT || (PA * KA_STEP == DBK && PB * KB_STEP == DBK), "split staging covers the chunk");
     ChanConst ka, kb;
-    load_consts<MODE_DZ>(DZ, ca, ka);
     load_consts<MODE_IN>(IN, cb, kb);
     // SPLIT, 256-output layer: the registers hold 96 weight-plane and 64 dW-accumulator values per lane; the per-channel constants of
     // the staging arithmetic wait in LDS between chunks instead (five ds_read_b128 per chunk, no spill code in the loop)
     constexpr bool LDS_CONSTS = SPLIT && (CO == 256 || (CI == 64 && MP_SPLIT_WGS == 3)) && !is_rc(MODE_IN) && !is_rc(MODE_DZ);
     __shared__ float4 sKA[LDS_CONSTS ? 5 : 1][LDS_CONSTS ? CO / 4 : 1];
     __shared__ float4 sKB[LDS_CONSTS ? 2 : 1][LDS_CONSTS ? CI / 4 : 1];
-    if constexpr (LDS_CONSTS) {
-        sKA[0][ca >> 2] = ka.s; sKA[1][ca >> 2] = ka.t; sKA[2][ca >> 2] = ka.a; sKA[3][ca >> 2] = ka.e; sKA[4][ca >> 2] = ka.f;
-        sKB[0][cb >> 2] = kb.s; sKB[1][cb >> 2] = kb.t;
-    }
     struct RSet { Raw4<MODE_DZ> a[PA]; Raw4<MODE_IN> b[PB]; };
     RSet rs0, rs1;            // (rs1: PD2 only)
     auto gload = [&](int pk, RSet& rs) {
@@ -1384,6 +1555,12 @@ __global__ __launch_bounds__(bwd_fused_threads(CO, CI, SPLIT, ONE), (CO >= 128 &
     constexpr bool DESYNC = MP_DESYNC && NT == 512 && CO == 256 && SPLIT && !KSPLIT && !PD2;   // (<.,128,128>: 128 -> 134 us with it, 124 -> 116 with PD2)
     const int half = DESYNC ? __builtin_amdgcn_readfirstlane(wave >> 2) : 0;
     gload(p0, rs0);
+    bn_prologue(DZ.bn, bn_lds, CO, 0, CO, blockIdx.x == 0);     // (behind the first chunk's loads: its slot reads share their latency)
+    load_consts<MODE_DZ>(DZ, ca, ka, bn_lds, CO);
+    if constexpr (LDS_CONSTS) {
+        sKA[0][ca >> 2] = ka.s; sKA[1][ca >> 2] = ka.t; sKA[2][ca >> 2] = ka.a; sKA[3][ca >> 2] = ka.e; sKA[4][ca >> 2] = ka.f;
+        sKB[0][cb >> 2] = kb.s; sKB[1][cb >> 2] = kb.t;
+    }
     sstore(0, rs0);
     if (DESYNC && half && nchunks > 1) { gload(p0 + DBK, rs0); sstore(1, rs0); }
     if constexpr (PD2) {     // chunks 1 and 2 on their way before the first product
@@ -1619,7 +1796,9 @@ __global__ __launch_bounds__(bwd_fused_threads(CO, CI, SPLIT, ONE), (CO >= 128 &
     __syncthreads();
     for (int e = tid; e < 2 * CI; e += NT) {
         const int st = e / CI, c = e - st * CI;
-        partials[((size_t)blockIdx.x * 2 + st) * CI + c] = red[0][st][c] + red[1][st][c];
+        const float v = red[0][st][c] + red[1][st][c];
+        if (partials.slots) atomicAdd(partials.slots + ((size_t)(blockIdx.x & (BN_NS - 1)) * 2 + st) * CI + c, (double)v);
+        else partials.rows[((size_t)blockIdx.x * 2 + st) * CI + c] = v;
     }
     // dW
 #pragma unroll
@@ -1670,7 +1849,7 @@ __device__ unsigned long long g_roles_t[2][8];
 template <int MODE_DZ, int CO>
 __global__ __launch_bounds__(512, 1) void bwd_roles_kernel(PosOperand DZ, PosOperand IN, int P, int p_per_block,
                                                            const float* __restrict__ W, float* __restrict__ dW,
-                                                           float* __restrict__ G, float* __restrict__ partials)
+                                                           float* __restrict__ G, BnOut partials)
 {
     constexpr int CI = 128, DBK = 16, GS = DBK * 8, MODE_IN = SRC_ACT;
     constexpr bool ALLSTAGE = CO == 128;
@@ -1690,6 +1869,8 @@ __global__ __launch_bounds__(512, 1) void bwd_roles_kernel(PosOperand DZ, PosOpe
     __shared__ float red[2][CI];
     __shared__ float4 sKA[5][CO / 4];
     __shared__ float4 sKB[2][CI / 4];
+    // (a, e, f) of dZ_l when this kernel is their first consumer: derived straight into the rows of sKA that hold them between chunks
+    bn_prologue(DZ.bn, reinterpret_cast<float*>(&sKA[2][0]), CO, 0, CO, blockIdx.x == 0);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool role_dx = wave < 4;
@@ -1705,9 +1886,9 @@ __global__ __launch_bounds__(512, 1) void bwd_roles_kernel(PosOperand DZ, PosOpe
     const int ca = (sw % NBA) * 64 + 4 * (lane & 15), ka0 = (sw / NBA) * 4 + (lane >> 4);
     const int cb = (sw % NBB) * 64 + 4 * (lane & 15), kb0 = (sw / NBB) * 4 + (lane >> 4);
     if (stage_a) {      // per-channel constants of the staging arithmetic wait in LDS between chunks
-        ChanConst ka;
-        load_consts<MODE_DZ>(DZ, ca, ka);
-        sKA[0][ca >> 2] = ka.s; sKA[1][ca >> 2] = ka.t; sKA[2][ca >> 2] = ka.a; sKA[3][ca >> 2] = ka.e; sKA[4][ca >> 2] = ka.f;
+        sKA[0][ca >> 2] = ld4(DZ.s + ca);
+        sKA[1][ca >> 2] = ld4(DZ.t + ca);
+        if (DZ.bn.slots == nullptr) { sKA[2][ca >> 2] = ld4(DZ.a + ca); sKA[3][ca >> 2] = ld4(DZ.e + ca); sKA[4][ca >> 2] = ld4(DZ.f + ca); }
     }
     if (stage_b) {
         ChanConst kb;
@@ -1977,7 +2158,8 @@ __global__ __launch_bounds__(512, 1) void bwd_roles_kernel(PosOperand DZ, PosOpe
     __syncthreads();
     for (int e = tid; e < 2 * CI; e += 512) {
         const int st = e / CI, c = e - st * CI;
-        partials[((size_t)blockIdx.x * 2 + st) * CI + c] = red[st][c];
+        if (partials.slots) atomicAdd(partials.slots + ((size_t)(blockIdx.x & (BN_NS - 1)) * 2 + st) * CI + c, (double)red[st][c]);
+        else partials.rows[((size_t)blockIdx.x * 2 + st) * CI + c] = red[st][c];
     }
 }
 
@@ -1986,8 +2168,9 @@ __global__ __launch_bounds__(512, 1) void bwd_roles_kernel(PosOperand DZ, PosOpe
 // A wave loads 64 input rows with one coalesced access (lane i: position base + i) and every lane (= channel) walks them
 // through v_readlane; sums run in fp32 over the 64 positions and in fp64 across them.
 __global__ __launch_bounds__(256) void rc_stats_kernel(const float* __restrict__ x0, const float* __restrict__ W0, int P, int p_per_block,
-                                                       float* __restrict__ partials)
+                                                       BnOut partials)
 {
+    bn_zero(partials);
     constexpr int C = 64;
     __shared__ double red[4][2][C];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -2017,7 +2200,9 @@ __global__ __launch_bounds__(256) void rc_stats_kernel(const float* __restrict__
     __syncthreads();
     if (tid < 2 * C) {
         const int st = tid / C, c = tid - st * C;
-        partials[((size_t)blockIdx.x * 2 + st) * C + c] = (float)(((red[0][st][c] + red[1][st][c]) + red[2][st][c]) + red[3][st][c]);
+        const double v = ((red[0][st][c] + red[1][st][c]) + red[2][st][c]) + red[3][st][c];
+        if (partials.slots) atomicAdd(partials.slots + ((size_t)(blockIdx.x & (BN_NS - 1)) * 2 + st) * C + c, v);
+        else partials.rows[((size_t)blockIdx.x * 2 + st) * C + c] = (float)v;
     }
 }
 
@@ -2033,6 +2218,8 @@ __global__ __launch_bounds__(512) void bwd_first_kernel(PosOperand DZ, PosOperan
                                                            const float* __restrict__ W, float* __restrict__ dW,
                                                            float* __restrict__ G)
 {
+    __shared__ __attribute__((aligned(16))) float bn_lds[3 * 128];
+    bn_prologue(DZ.bn, bn_lds, 128, 0, 128, blockIdx.x == 0);
     constexpr int CO = 128, CIW = 132, CIX = 128, DBK = 16, LDA = CO + 4, LDB = CIW, KPL = CO / 4;   // LDA, KPL: see bwd_fused_kernel
     constexpr int NT = 512;                             // eight waves: half the accumulators / weight fragments per wave
     constexpr int PA = DBK * CO / 4 / NT;               // 1
@@ -2091,7 +2278,7 @@ __global__ __launch_bounds__(512) void bwd_first_kernel(PosOperand DZ, PosOperan
     const int ka0 = SPLIT ? (wave >> 1) * 4 + (MP_MAPWIDE ? (lane >> 4) : ((lane >> 3) & 3)) : tid / (CO / 4);
     constexpr int KA_STEP = NT / (CO / 4);
     ChanConst ka, kb;
-    load_consts<MODE_DZ>(DZ, ca, ka);
+    load_consts<MODE_DZ>(DZ, ca, ka, bn_lds, 128);
     Raw4<MODE_DZ> ra[PA];
     Raw4<MODE_IN> rb[PB];
     int brow[PB], bcol[PB];                              // this thread's (row, column) of the input chunk, per pass
@@ -2253,6 +2440,8 @@ __global__ __launch_bounds__(512) void bwd_first_kernel(PosOperand DZ, PosOperan
 template <int MODE_DZ, int MODE_IN>
 __global__ __launch_bounds__(256) void dw_ci4_kernel(PosOperand DZ, PosOperand IN, int P, int p_per_block, float* __restrict__ dW, int r16)
 {   // r16: the bf16 variant -- dZ and the input rows rounded to bf16 before the products
+    __shared__ __attribute__((aligned(16))) float bn_lds[3 * 1024];          // (Co <= 1024: launch_dw's condition for this kernel)
+    bn_prologue(DZ.bn, bn_lds, 1024, 0, DZ.C, blockIdx.x == 0);
     __shared__ float red[256][16 + 1];
     const int tid = threadIdx.x;
     const int Co = DZ.C;
@@ -2261,7 +2450,7 @@ __global__ __launch_bounds__(256) void dw_ci4_kernel(PosOperand DZ, PosOperand I
     const int PL = 256 / nq;                      // position lanes per workgroup
     const int p0 = blockIdx.x * p_per_block, p1 = min(P, p0 + p_per_block);
     ChanConst ka, kb;
-    load_consts<MODE_DZ>(DZ, 4 * q, ka);
+    load_consts<MODE_DZ>(DZ, 4 * q, ka, bn_lds, 1024);
     load_consts<MODE_IN>(IN, 0, kb);
     float acc[4][4];
 #pragma unroll
@@ -2354,7 +2543,9 @@ int launch_dw(const PosOperand& DZ, const PosOperand& IN, int64_t P64, float* dW
     if (main_ci < Ci && tail_ci < 0) {
         work(Ci - main_ci, flops, bytes);
         snprintf(tag, sizeof tag, "%s<%d, %d, 4, 1, 1, 1>", kn, MODE_DZ, MODE_IN);
-        MP_LAUNCH(tag, flops, bytes, (dw_gemm_kernel<MODE_DZ, MODE_IN, 4, 1, 1, 1, PREC>), dim3(gx, gy, (Ci - main_ci + 31) / 32), dim3(THREADS), 0, stream, DZ, IN, P, ppb, dW, main_ci, -1);
+        PosOperand DZ2 = DZ;
+        DZ2.bn = BnSite{};       // (the launch above derived the constants: its prologue consumed the slot rows)
+        MP_LAUNCH(tag, flops, bytes, (dw_gemm_kernel<MODE_DZ, MODE_IN, 4, 1, 1, 1, PREC>), dim3(gx, gy, (Ci - main_ci + 31) / 32), dim3(THREADS), 0, stream, DZ2, IN, P, ppb, dW, main_ci, -1);
     }
     MP_CHECK_LAUNCH();
     return MP_OK;
@@ -2502,8 +2693,7 @@ __global__ __launch_bounds__(256) void zero_cols_kernel(float* __restrict__ x, i
 }
 
 // out[g,c] = max_k relu(z[g*K+k, c]*s+t); first maximum wins; keeps arg-max and the raw z there.
-__global__ __launch_bounds__(256) void pool_fwd_kernel(const float* __restrict__ z, const float* __restrict__ s,
-                                                       const float* __restrict__ t, int64_t G, int K, int C,
+__global__ __launch_bounds__(256) void pool_fwd_kernel(const float* __restrict__ z, const float* s, const float* t, int64_t G, int K, int C,
                                                        float* __restrict__ out, int* __restrict__ argk,
                                                        float* __restrict__ zmax)
 {
@@ -2533,11 +2723,12 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(const float* __restrict__
 constexpr int POOL_ROWS = 16;
 __global__ __launch_bounds__(256) void pool_bwd_prep_kernel(const float* __restrict__ gout, const float* __restrict__ out,
                                                             const float* __restrict__ zmax, int64_t G, int C, int rows,
-                                                            float* __restrict__ gp, float* __restrict__ partials,
+                                                            float* __restrict__ gp, BnOut partials,
                                                             float* __restrict__ clear, size_t clear_n)
 {
     // clear: the level's dW block (accumulated with atomics by the kernels that follow) is zeroed here, in the first launch of the
     // level's backward, instead of by a launch of its own (16-byte stores when the block is aligned)
+    bn_zero(partials);
     {
         const size_t nthreads = (size_t)gridDim.x * gridDim.y * 256;
         const size_t me = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x;
@@ -2569,12 +2760,11 @@ __global__ __launch_bounds__(256) void pool_bwd_prep_kernel(const float* __restr
             s2 += v * zv[r];
         }
     }
-    partials[((int64_t)blockIdx.x * 2 + 0) * C + c] = s1;
-    partials[((int64_t)blockIdx.x * 2 + 1) * C + c] = s2;
+    bn_emit(partials, C, blockIdx.x, c, (double)s1, (double)s2);
 }
 
 template <int MODE, bool W_KROW, int EPI, int PREC = 0>
-int launch_pos_gemm(const PosOperand& A, int64_t P, const float* W, int N, int Kd, float* C, float* partials,
+int launch_pos_gemm(const PosOperand& A, int64_t P, const float* W, int N, int Kd, float* C, BnOut partials,
                     const float* zprev, const float* sprev, const float* tprev, hipStream_t stream, int* nblk_out,
                     PoolOut po = PoolOut{}, int ldw = 0, int ldc = 0)
 {
@@ -2731,8 +2921,9 @@ template <int Q>   // Q = Co / 4: lanes per row
 __global__ __launch_bounds__(256) void first_factored_fwd_kernel(const float* __restrict__ A, const float* __restrict__ xyz,
                                                                  const float* __restrict__ new_xyz, const int64_t* __restrict__ idx,
                                                                  const float* __restrict__ Wx, int P, int K, int kshift, int N, int per,
-                                                                 int gshift, int ppb, float* __restrict__ Z0, float* __restrict__ partials, int r16)
+                                                                 int gshift, int ppb, float* __restrict__ Z0, BnOut partials, int r16)
 {   // r16: the bf16 variant -- W_x and the centred coordinates rounded to bf16 (A comes from rounded operands already)
+    bn_zero(partials);
     constexpr int CO = 4 * Q, RW = 64 / Q, RB = 4 * RW, U = MP_FACT_U;      // rows per wave / per workgroup pass, passes in flight
     __shared__ float red[2][RB][CO];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -2779,7 +2970,8 @@ __global__ __launch_bounds__(256) void first_factored_fwd_kernel(const float* __
         float v = 0.0f;
 #pragma unroll
         for (int r = 0; r < RB; ++r) v += red[st][r][c];
-        partials[((size_t)blockIdx.x * 2 + st) * CO + c] = v;
+        if (partials.slots) atomicAdd(partials.slots + ((size_t)(blockIdx.x & (BN_NS - 1)) * 2 + st) * CO + c, (double)v);
+        else partials.rows[((size_t)blockIdx.x * 2 + st) * CO + c] = v;
     }
 }
 
@@ -2793,11 +2985,13 @@ __global__ __launch_bounds__(256) void first_factored_bwd_kernel(PosOperand DZ, 
 {   // r16: the bf16 variant -- dZ_0 (as written out, too: its reduction over the gathering rows then sums rounded values) and the
     // centred coordinates rounded to bf16
     constexpr int CO = 4 * Q, RW = 64 / Q, RB = 4 * RW, U = MP_FACT_U;
+    __shared__ __attribute__((aligned(16))) float bn_lds[3 * CO];
+    bn_prologue(DZ.bn, bn_lds, CO, 0, CO, blockIdx.x == 0);
     __shared__ float red[3][RB][CO];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ql = lane % Q, slot = wave * RW + lane / Q;
     ChanConst k;
-    load_consts<SRC_DZ>(DZ, 4 * ql, k);
+    load_consts<SRC_DZ>(DZ, 4 * ql, k, bn_lds, CO);
     const int p0 = blockIdx.x * ppb, p1 = min(P, p0 + ppb);
     float4 ax = make_float4(0.f, 0.f, 0.f, 0.f), ay = ax, az = ax;
     for (int p = p0 + slot; p < p1; p += RB * U) {
@@ -2898,6 +3092,8 @@ __global__ __launch_bounds__(256) void first_factored_reduce_kernel(PosOperand D
 #define MP_FACT_RU 4
 #endif
     constexpr int CO = 4 * Q, RW = 64 / Q, U = MP_FACT_RU;
+    __shared__ __attribute__((aligned(16))) float bn_lds[3 * CO];
+    bn_prologue(DZ.bn, bn_lds, CO, 0, CO, blockIdx.x == 0 && blockIdx.y == 0);
     __shared__ float red[3][4 * RW][CO];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ql = lane % Q, sub = lane / Q;
@@ -2905,7 +3101,7 @@ __global__ __launch_bounds__(256) void first_factored_reduce_kernel(PosOperand D
     const int j0 = (blockIdx.x * 4 + wave) * chunk, j1 = min(M, j0 + chunk);
     const int S = M / K;
     ChanConst k;
-    load_consts<SRC_DZ>(DZ, 4 * ql, k);
+    load_consts<SRC_DZ>(DZ, 4 * ql, k, bn_lds, CO);
     const int* bo = order + (size_t)b * M;
     const int* bp = pts + (size_t)b * M;
     float* dst = dA + (size_t)b * N * CO + 4 * ql;
@@ -3028,7 +3224,43 @@ static int sa_mlp_fwd(const float* x0, int64_t P, int64_t K, int n_layers, const
     if (rc_first && !mp_sa_mlp_recompute_first(n_layers, ch, K)) return MP_EINVAL;      // (bf16: x0 and layers[0].weight come pre-rounded)
     if (n_layers > 1 && layers[n_layers - 1].z == nullptr) return MP_EINVAL;
     hipStream_t stream = mp_stream(stream_);
-    float* partials = reinterpret_cast<float*>(workspace);
+    // consumer-side BatchNorm finalize (bn_prologue): train mode, per-replica statistics, every layer with its persistent state
+    bool bn_fused = training && !sync && n_layers >= 2;
+    for (int l = 0; l < n_layers; ++l) bn_fused = bn_fused && layers[l].bn_state != nullptr;
+    BnOut partials{reinterpret_cast<float*>(workspace), nullptr, nullptr, 0, nullptr, 0};
+    if (bn_fused) {     // the first kernel of the call zeroes what earlier calls left behind: the last forward site, the first-layer backward site
+        const mp_mlp_layer_t &Lz = layers[n_layers - 1], &L0 = layers[0];
+        partials.z0 = bn_fwd_slots(Lz.bn_state, (int)Lz.c_out);
+        partials.n0 = BN_NS * 2 * (int)Lz.c_out;
+        partials.z1 = bn_bwd_slots(L0.bn_state, (int)L0.c_out);
+        partials.n1 = BN_NS * 2 * (int)L0.c_out;
+    }
+    // the forward site of layer l, to be consumed by the kernel launched after layer l's own (which also zeroes the rows of site l-1)
+    auto fwd_site = [&](int l) {
+        BnSite b{};
+        if (!bn_fused) return b;
+        const mp_mlp_layer_t& Lb = layers[l];
+        const int C = (int)Lb.c_out;
+        b.slots = bn_fwd_slots(Lb.bn_state, C);
+        if (l > 0) { b.z0 = bn_fwd_slots(layers[l - 1].bn_state, (int)layers[l - 1].c_out); b.n0 = BN_NS * 2 * (int)layers[l - 1].c_out; }
+        b.C = C;
+        b.kind = 1;
+        b.invP = 1.0 / (double)P;
+        b.unbias = P > 1 ? (double)P / ((double)P - 1.0) : 1.0;
+        b.momentum = momentum;
+        b.eps = eps;
+        b.gamma = Lb.gamma; b.beta = Lb.beta; b.bias = Lb.bias;
+        b.running_mean = Lb.running_mean; b.running_var = Lb.running_var;
+        b.mean = Lb.mean; b.rstd = Lb.rstd; b.o0 = Lb.scale; b.o1 = Lb.shift;
+        return b;
+    };
+    // a consumer without a prologue (tiled GEMMs, the unfused pool): the site's algebra as a launch of its own
+    auto settle = [&](BnSite& b) -> int {
+        if (!b.slots) return MP_OK;
+        hipLaunchKernelGGL(bn_site_finalize_kernel, dim3((unsigned)((b.C + 255) / 256)), dim3(256), 0, stream, b);
+        b = BnSite{};
+        return hipGetLastError() == hipSuccess ? MP_OK : MP_ELAUNCH;
+    };
     // fused max-pool: group size a multiple of the 32-row MFMA tile that divides the 128-row block tile
     const bool fused_pool = (K == 32 || K == 64 || K == 128);
     PoolOut po{};
@@ -3054,6 +3286,7 @@ static int sa_mlp_fwd(const float* x0, int64_t P, int64_t K, int n_layers, const
     for (int l = 0; l < n_layers; ++l) {
         const mp_mlp_layer_t& L = layers[l];
         int nblk = 0, rc = MP_OK;
+        partials.slots = bn_fused ? bn_fwd_slots(L.bn_state, (int)L.c_out) : nullptr;
         const bool fuse_pool = (l == n_layers - 1) && fused_pool;
         const int Ci_ = (int)L.c_in, Co_ = (int)L.c_out;
         const bool last_unfused = (l == n_layers - 1) && !fused_pool;
@@ -3142,6 +3375,7 @@ static int sa_mlp_fwd(const float* x0, int64_t P, int64_t K, int n_layers, const
             MP_CHECK_LAUNCH();
             nblk = (int)gx;
         } else if (fuse_pool) {
+            if (int r2 = settle(A.bn)) return r2;
             if (l == 0)
                 rc = MP_POS_GEMM(SRC_ID, false, EPI_SQ_POOL, A, P, L.weight, (int)L.c_out, (int)L.c_in, L.z, partials,
                                  nullptr, nullptr, nullptr, stream, &nblk, po);
@@ -3151,25 +3385,30 @@ static int sa_mlp_fwd(const float* x0, int64_t P, int64_t K, int n_layers, const
         } else if (l == 0)
             rc = MP_POS_GEMM(SRC_ID, false, EPI_SQ, A, P, L.weight, (int)L.c_out, (int)L.c_in, L.z, partials, nullptr,
                              nullptr, nullptr, stream, &nblk);
-        else
+        else {
+            if (int r2 = settle(A.bn)) return r2;
             rc = MP_POS_GEMM(SRC_ACT, false, EPI_SQ, A, P, L.weight, (int)L.c_out, (int)L.c_in, L.z, partials, nullptr,
                              nullptr, nullptr, stream, &nblk);
-        if (rc != MP_OK) return rc;
-        const int C = (int)L.c_out;
-        double Pg = (double)P;
-        const double* gsums = nullptr;
-        if (sync) {     // global-batch statistics: local fp64 sums -> all-reduce (the caller's collective) -> finalize
-            hipLaunchKernelGGL(bn_sums_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_SL), 0, stream, partials, nblk, C,
-                               sync->exchange, (double*)nullptr);
-            MP_CHECK_LAUNCH();
-            if (sync->allreduce(sync->user, sync->exchange, 2 * (int64_t)C, stream_) != 0) return MP_ELAUNCH;
-            Pg = (double)P * (double)sync->world;
-            gsums = sync->exchange;
         }
-        hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_SL), 0, stream, partials, nblk, C,
-                           1.0 / Pg, Pg > 1.0 ? Pg / (Pg - 1.0) : 1.0, training, momentum, eps, L.gamma,
-                           L.beta, L.bias, L.running_mean, L.running_var, L.mean, L.rstd, L.scale, L.shift, gsums);
-        MP_CHECK_LAUNCH();
+        if (rc != MP_OK) return rc;
+        partials.z0 = partials.z1 = nullptr;      // (only the first kernel of the call has the zeroing duty)
+        const int C = (int)L.c_out;
+        if (!bn_fused) {
+            double Pg = (double)P;
+            const double* gsums = nullptr;
+            if (sync) {     // global-batch statistics: local fp64 sums -> all-reduce (the caller's collective) -> finalize
+                hipLaunchKernelGGL(bn_sums_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_SL), 0, stream, partials.rows, nblk, C,
+                                   sync->exchange, (double*)nullptr);
+                MP_CHECK_LAUNCH();
+                if (sync->allreduce(sync->user, sync->exchange, 2 * (int64_t)C, stream_) != 0) return MP_ELAUNCH;
+                Pg = (double)P * (double)sync->world;
+                gsums = sync->exchange;
+            }
+            hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_SL), 0, stream, partials.rows, nblk, C,
+                               1.0 / Pg, Pg > 1.0 ? Pg / (Pg - 1.0) : 1.0, training, momentum, eps, L.gamma,
+                               L.beta, L.bias, L.running_mean, L.running_var, L.mean, L.rstd, L.scale, L.shift, gsums);
+            MP_CHECK_LAUNCH();
+        }
         A = PosOperand{};
         A.x = L.z;
         A.s = L.scale;
@@ -3177,21 +3416,27 @@ static int sa_mlp_fwd(const float* x0, int64_t P, int64_t K, int n_layers, const
         A.C = C;
         A.K = (int)K;
         A.kshift = log2_or_neg(K);
+        A.bn = fwd_site(l);            // the next kernel that reads act(Z_l) derives (scale, shift) of layer l in its prologue
         if (l == 0 && rc_first) { A.rx = x0; A.rw = L.weight; }
     }
     const mp_mlp_layer_t& LL = layers[n_layers - 1];
     const int64_t G = P / K;
     const int64_t tot = G * LL.c_out;
+    BnSite last_site = fwd_site(n_layers - 1);
+    if (!fused_pool || LL.c_out > BN_POOL_CMAX) { if (int r2 = settle(last_site)) return r2; }
     if (fused_pool) {
         const bool wide = !(LL.c_out & 3) && !((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(argk) | reinterpret_cast<uintptr_t>(zmax) |
                                                 reinterpret_cast<uintptr_t>(LL.scale) | reinterpret_cast<uintptr_t>(LL.shift) | reinterpret_cast<uintptr_t>(po.vmax) |
                                                 reinterpret_cast<uintptr_t>(po.vmin) | reinterpret_cast<uintptr_t>(po.imax) | reinterpret_cast<uintptr_t>(po.imin)) & 15);
-        if (wide)
-            MP_LAUNCH("pool_select_kernel", 0.0, 28.0 * (double)tot, pool_select_kernel, dim3((unsigned)((tot / 4 + 255) / 256)),
-                      dim3(256), 0, stream, po, LL.scale, LL.shift, G, (int)LL.c_out, out, argk, zmax);
+        if (wide) {
+            unsigned gx = (unsigned)((tot / 4 + 255) / 256);
+            if (last_site.slots && gx > 512) gx = 512;       // every workgroup pays the BatchNorm prologue: fewer, grid-striding ones
+            MP_LAUNCH("pool_select_kernel", 0.0, 28.0 * (double)tot, pool_select_kernel, dim3(gx),
+                      dim3(256), 0, stream, po, LL.scale, LL.shift, G, (int)LL.c_out, out, argk, zmax, last_site);
+        }
         else
             MP_LAUNCH("pool_select_kernel", 0.0, 28.0 * (double)tot, pool_select_scalar_kernel, dim3((unsigned)((tot + 255) / 256)),
-                      dim3(256), 0, stream, po, LL.scale, LL.shift, G, (int)LL.c_out, out, argk, zmax);
+                      dim3(256), 0, stream, po, LL.scale, LL.shift, G, (int)LL.c_out, out, argk, zmax, last_site);
         MP_CHECK_LAUNCH();
         return MP_OK;
     }
@@ -3286,7 +3531,16 @@ static int sa_mlp_bwd(const float* x0, int64_t P, int64_t K, int n_layers, const
     // carve the workspace (same order as mp_sa_mlp_workspace_bytes)
     unsigned char* w = reinterpret_cast<unsigned char*>(workspace);
     const size_t nblk_max = (size_t)((P + 63) / 64);
-    float* partials = reinterpret_cast<float*>(w);
+    bool bn_fused = training && !sync && n_layers >= 2;      // consumer-side BatchNorm finalize (bn_prologue), as in the forward pass
+    for (int l = 0; l < n_layers; ++l) bn_fused = bn_fused && layers[l].bn_state != nullptr;
+    BnOut partials{reinterpret_cast<float*>(w), nullptr, nullptr, 0, nullptr, 0};
+    if (bn_fused) {     // pool_bwd_prep_kernel, the first kernel of the call: the rows the forward pass and an earlier backward pass left behind
+        const mp_mlp_layer_t &Lz = layers[n_layers - 1], &L0 = layers[0];
+        partials.z0 = bn_fwd_slots(Lz.bn_state, (int)Lz.c_out);
+        partials.n0 = BN_NS * 2 * (int)Lz.c_out;
+        partials.z1 = bn_bwd_slots(L0.bn_state, (int)L0.c_out);
+        partials.n1 = BN_NS * 2 * (int)L0.c_out;
+    }
     w += align_up(nblk_max * 2 * (size_t)cmax * sizeof(float), 256);
     float* cbuf[3];
     for (int i = 0; i < 3; ++i) {
@@ -3304,13 +3558,32 @@ static int sa_mlp_bwd(const float* x0, int64_t P, int64_t K, int n_layers, const
     const int64_t G = P / K;
     const int L = n_layers;
     const mp_mlp_layer_t& last = layers[L - 1];
+    // the backward sums of layer `li`: where its producer adds them, and the site its first consumer derives (a, e, f) from
+    auto bwd_slots = [&](int li) -> double* { return bn_fused ? bn_bwd_slots(layers[li].bn_state, (int)layers[li].c_out) : nullptr; };
+    auto bwd_site = [&](int li) {
+        BnSite b{};
+        if (!bn_fused) return b;
+        const mp_mlp_layer_t& Lb = layers[li];
+        const int C = (int)Lb.c_out;
+        b.slots = bn_bwd_slots(Lb.bn_state, C);
+        if (li + 1 < n_layers) { b.z0 = bn_bwd_slots(layers[li + 1].bn_state, (int)layers[li + 1].c_out); b.n0 = BN_NS * 2 * (int)layers[li + 1].c_out; }
+        b.C = C;
+        b.kind = 2;
+        b.invP = 1.0 / (double)P;
+        b.gamma = Lb.gamma;
+        b.mean = Lb.mean; b.rstd = Lb.rstd;
+        b.o0 = cbuf[0]; b.o1 = cbuf[1]; b.o2 = cbuf[2];
+        b.dgamma = grads[li].d_gamma; b.dbeta = grads[li].d_beta; b.dbias = grads[li].d_bias;
+        return b;
+    };
     // BatchNorm-backward finalize of layer `li` from `nb` partial rows (SyncBN: local sums kept, global sums exchanged)
     auto finalize_bwd = [&](int li, int nb, int C) -> int {
+        if (bn_fused) return MP_OK;          // the first kernel that forms dZ_li does it in its prologue
         const mp_mlp_layer_t& Lf = layers[li];
         double Pg = (double)P;
         const double *gs = nullptr, *ls = nullptr;
         if (sync) {
-            hipLaunchKernelGGL(bn_sums_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_SL), 0, stream, partials, nb, C,
+            hipLaunchKernelGGL(bn_sums_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_SL), 0, stream, partials.rows, nb, C,
                                sync->exchange, sync->exchange + 2 * (size_t)C);
             if (hipGetLastError() != hipSuccess) return MP_ELAUNCH;
             if (sync->allreduce(sync->user, sync->exchange, 2 * (int64_t)C, stream_) != 0) return MP_ELAUNCH;
@@ -3318,7 +3591,7 @@ static int sa_mlp_bwd(const float* x0, int64_t P, int64_t K, int n_layers, const
             gs = sync->exchange;
             ls = sync->exchange + 2 * (size_t)C;
         }
-        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_SL), 0, stream, partials, nb, C,
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_SL), 0, stream, partials.rows, nb, C,
                            1.0 / Pg, training, Lf.gamma, Lf.mean, Lf.rstd, grads[li].d_gamma, grads[li].d_beta, grads[li].d_bias,
                            cbuf[0], cbuf[1], cbuf[2], gs, ls);
         return hipGetLastError() == hipSuccess ? MP_OK : MP_ELAUNCH;
@@ -3339,9 +3612,11 @@ static int sa_mlp_bwd(const float* x0, int64_t P, int64_t K, int n_layers, const
         while (rows > 1 && ((G + rows - 1) / rows) * ((C + 255) / 256) < 512 && (size_t)((G + rows / 2 - 1) / (rows / 2)) <= nblk_max) rows >>= 1;
         const int nb = (int)((G + rows - 1) / rows);
         if ((size_t)nb > nblk_max) return MP_EUNSUPPORTED;  // partials hold P/64 rows: needs K >= 4
+        partials.slots = bwd_slots(L - 1);
         hipLaunchKernelGGL(pool_bwd_prep_kernel, dim3(nb, (C + 255) / 256), dim3(256), 0, stream, grad_out, out, zmax, G, C, rows, gp,
                            partials, dw_joint ? grads[0].d_weight : nullptr, dw_joint ? dw_total : (size_t)0);
         MP_CHECK_LAUNCH();
+        partials.z0 = partials.z1 = nullptr;
         if (int rc = finalize_bwd(L - 1, nb, C)) return rc;
     }
     const float* G_cur = nullptr;  // dense gradient w.r.t. the activation output of layer l (l < L-1)
@@ -3360,6 +3635,8 @@ static int sa_mlp_bwd(const float* x0, int64_t P, int64_t K, int n_layers, const
         DZ.K = (int)K;
         DZ.kshift = log2_or_neg(K);
         if (pooled) { DZ.g = gp; DZ.argk = argk; } else { DZ.g = G_cur; }
+        DZ.bn = bwd_site(l);                            // the first kernel below that forms dZ_l derives its constants
+        partials.slots = l > 0 ? bwd_slots(l - 1) : nullptr;      // ... and the kernel that computes G_{l-1} adds the sums of layer l-1
         PosOperand IN{};
         IN.C = Ci;
         IN.K = (int)K;
@@ -3506,6 +3783,7 @@ static int sa_mlp_bwd(const float* x0, int64_t P, int64_t K, int n_layers, const
             else rc = (l == 0) ? MP_DW_GEMM(SRC_DZ, SRC_ID, DZ, IN, P, grads[l].d_weight, stream)
                                : MP_DW_GEMM(SRC_DZ, SRC_ACT, DZ, IN, P, grads[l].d_weight, stream);
             if (rc != MP_OK) return rc;
+            DZ.bn = BnSite{};        // (consumed by the weight-gradient kernel: the kernels below read the constants it wrote)
         }
         // G_{l-1} = dZ_l * W_l  (+ BN-backward sums of layer l-1)
         if (l > 0) {
@@ -3527,9 +3805,9 @@ static int sa_mlp_bwd(const float* x0, int64_t P, int64_t K, int n_layers, const
             int ncols = (grad_x0_cols > 0 && grad_x0_cols < Ci) ? (int)((grad_x0_cols + 3) / 4 * 4) : Ci;
             int rc;
             if (pooled)
-                rc = MP_POS_GEMM(SRC_DZ_POOLED, true, EPI_NONE, DZ, P, Ly.weight, ncols, Co, grad_x0, nullptr, nullptr, nullptr, nullptr, stream, nullptr, PoolOut{}, Ci, Ci);
+                rc = MP_POS_GEMM(SRC_DZ_POOLED, true, EPI_NONE, DZ, P, Ly.weight, ncols, Co, grad_x0, BnOut{nullptr, nullptr}, nullptr, nullptr, nullptr, stream, nullptr, PoolOut{}, Ci, Ci);
             else
-                rc = MP_POS_GEMM(SRC_DZ, true, EPI_NONE, DZ, P, Ly.weight, ncols, Co, grad_x0, nullptr, nullptr, nullptr, nullptr, stream, nullptr, PoolOut{}, Ci, Ci);
+                rc = MP_POS_GEMM(SRC_DZ, true, EPI_NONE, DZ, P, Ly.weight, ncols, Co, grad_x0, BnOut{nullptr, nullptr}, nullptr, nullptr, nullptr, stream, nullptr, PoolOut{}, Ci, Ci);
             if (rc != MP_OK) return rc;
             if (ncols < Ci) {   // the columns that carry no gradient: defined (zero), so that no consumer can read garbage
                 hipLaunchKernelGGL(zero_cols_kernel, dim3((unsigned)((P * (Ci - ncols) + 255) / 256)), dim3(256), 0, stream, grad_x0, P, Ci, ncols);

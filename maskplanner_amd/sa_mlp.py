@@ -24,6 +24,30 @@ def _r16(t):
     return t.detach().to(torch.bfloat16).to(torch.float32)
 
 
+BN_SLOTS = 8      # MP_BN_SLOTS
+BN_FUSED = os.environ.get("MASKPLANNER_BN_FUSED", "1") != "0"   # 0: BatchNorm finalize as launches of its own (A/B, debugging)
+
+
+def bn_state(bn, C):
+    """The persistent, zero-initialised scratch of a BatchNorm layer for the library's consumer-side finalize (mp_mlp_layer_t::bn_state:
+    MP_BN_STATE_DOUBLES(C) doubles): kept with the module, one per (width, device); the library leaves it zero after every call.
+    One call at a time per module (two streams running the SAME module concurrently would share it)."""
+    dev = bn.weight.device
+    cache = bn.__dict__.setdefault("_mp_bn_state", {})
+    t = cache.get((C, dev))
+    if t is None:
+        t = cache[(C, dev)] = torch.zeros(4 * BN_SLOTS * C, dtype=torch.float64, device=dev)
+    return t
+
+
+def reset_bn_state(module):
+    """Zero every cached BatchNorm scratch under `module` (after an aborted step: a kernel that failed between a producer and its
+    consumer leaves partial sums behind)."""
+    for m in module.modules():
+        for t in m.__dict__.get("_mp_bn_state", {}).values():
+            t.zero_()
+
+
 # None: every level advances its BatchNorm counters (num_batches_tracked) itself.  A list: the counters are collected here
 # instead and the owner (harness.TrainStep) advances all of them -- set-abstraction levels and heads -- in one launch per step.
 DEFERRED_TICKS = None
@@ -40,7 +64,7 @@ class _SharedMLPMax(torch.autograd.Function):
     weight[Co,Ci], bias|None, gamma, beta, running_mean|None, running_var|None."""
 
     @staticmethod
-    def forward(ctx, x, K, training, momentum, eps, n_layers, grad_cols, bf16, sync_group, *params):
+    def forward(ctx, x, K, training, momentum, eps, n_layers, grad_cols, bf16, sync_group, states, *params):
         dev = x.device
         P, C0 = x.shape
         layers = (_lib.MlpLayer * n_layers)()
@@ -62,9 +86,10 @@ class _SharedMLPMax(torch.autograd.Function):
             skip_z = l == 0 and recompute_first
             z = None if skip_z else torch.empty((P, co), dtype=torch.float32, device=dev)
             stats = torch.empty((4, co), dtype=torch.float32, device=dev)  # mean, rstd, scale, shift
-            keep.append((w, b, gam, bet, rm, rv, z, stats))
+            st = states[l] if states is not None else None
+            keep.append((w, b, gam, bet, rm, rv, z, stats, st))
             layers[l] = _lib.MlpLayer(_ptr(w), _ptr(b), _ptr(gam), _ptr(bet), _ptr(rm), _ptr(rv), ci, co, _ptr(z),
-                                      stats[0].data_ptr(), stats[1].data_ptr(), stats[2].data_ptr(), stats[3].data_ptr())
+                                      stats[0].data_ptr(), stats[1].data_ptr(), stats[2].data_ptr(), stats[3].data_ptr(), _ptr(st))
         G = P // K
         cl = chans[-1]
         out = torch.empty((G, cl), dtype=torch.float32, device=dev)
@@ -103,10 +128,10 @@ class _SharedMLPMax(torch.autograd.Function):
         # launch (they are accumulated with atomics) instead of one per layer
         dw_all = torch.empty((sum(k[0].numel() for k in ctx.keep),), dtype=torch.float32, device=dev)
         dw_off = 0
-        for l, (w, b, gam, bet, rm, rv, z, stats) in enumerate(ctx.keep):
+        for l, (w, b, gam, bet, rm, rv, z, stats, st) in enumerate(ctx.keep):
             co, ci = w.shape
             layers[l] = _lib.MlpLayer(_ptr(w), _ptr(b), _ptr(gam), _ptr(bet), _ptr(rm), _ptr(rv), ci, co, _ptr(z),
-                                      stats[0].data_ptr(), stats[1].data_ptr(), stats[2].data_ptr(), stats[3].data_ptr())
+                                      stats[0].data_ptr(), stats[1].data_ptr(), stats[2].data_ptr(), stats[3].data_ptr(), _ptr(st))
             dw = dw_all[dw_off:dw_off + w.numel()].view_as(w)
             dw_off += w.numel()
             db = None if b is None else torch.empty_like(b)
@@ -130,7 +155,7 @@ class _SharedMLPMax(torch.autograd.Function):
             ops._run("sa_mlp_bwd", x, lib.mp_sa_mlp_bwd_bf16 if bf16 else lib.mp_sa_mlp_bwd_f32, _ptr(x), P, K, n_layers, layers, int(training), _ptr(grad_out),
                      _ptr(out), _ptr(argk), _ptr(zmax), grads, _ptr(gx), grad_cols, _ptr(ws), ws.numel())
         ctx.keep = None
-        return (gx, None, None, None, None, None, None, None, None, *ret)
+        return (gx, None, None, None, None, None, None, None, None, None, *ret)
 
 
 class _SharedMLPMaxFactored(torch.autograd.Function):
@@ -140,7 +165,7 @@ class _SharedMLPMaxFactored(torch.autograd.Function):
     Backward: the library writes dZ_0 [P, Co + 4]; its reduction over the gathering rows (ops.group's backward kernel) is dA."""
 
     @staticmethod
-    def forward(ctx, A, xyz, new_xyz, idx, training, momentum, eps, n_layers, bf16, sync_group, *params):
+    def forward(ctx, A, xyz, new_xyz, idx, training, momentum, eps, n_layers, bf16, sync_group, states, *params):
         dev = A.device
         B, N, C0 = A.shape
         _, S, K = idx.shape
@@ -156,9 +181,10 @@ class _SharedMLPMaxFactored(torch.autograd.Function):
             co, ci = w.shape
             z = torch.empty((P, co), dtype=torch.float32, device=dev)
             stats = torch.empty((4, co), dtype=torch.float32, device=dev)
-            keep.append((w, b, gam, bet, rm, rv, z, stats))
+            st = states[l] if states is not None else None
+            keep.append((w, b, gam, bet, rm, rv, z, stats, st))
             layers[l] = _lib.MlpLayer(_ptr(w), _ptr(b), _ptr(gam), _ptr(bet), _ptr(rm), _ptr(rv), ci, co, _ptr(z),
-                                      stats[0].data_ptr(), stats[1].data_ptr(), stats[2].data_ptr(), stats[3].data_ptr())
+                                      stats[0].data_ptr(), stats[1].data_ptr(), stats[2].data_ptr(), stats[3].data_ptr(), _ptr(st))
         G = P // K
         cl = chans[-1]
         out = torch.empty((G, cl), dtype=torch.float32, device=dev)
@@ -208,10 +234,10 @@ class _SharedMLPMaxFactored(torch.autograd.Function):
         ret = []
         dw_all = torch.empty((sum(k[0].numel() for k in ctx.keep),), dtype=torch.float32, device=dev)
         dw_off = 0
-        for l, (w, b, gam, bet, rm, rv, z, stats) in enumerate(ctx.keep):
+        for l, (w, b, gam, bet, rm, rv, z, stats, st) in enumerate(ctx.keep):
             co, ci = w.shape
             layers[l] = _lib.MlpLayer(_ptr(w), _ptr(b), _ptr(gam), _ptr(bet), _ptr(rm), _ptr(rv), ci, co, _ptr(z),
-                                      stats[0].data_ptr(), stats[1].data_ptr(), stats[2].data_ptr(), stats[3].data_ptr())
+                                      stats[0].data_ptr(), stats[1].data_ptr(), stats[2].data_ptr(), stats[3].data_ptr(), _ptr(st))
             dw = dw_all[dw_off:dw_off + w.numel()].view_as(w)
             dw_off += w.numel()
             db = None if b is None else torch.empty_like(b)
@@ -231,7 +257,7 @@ class _SharedMLPMaxFactored(torch.autograd.Function):
             run_bwd(lib, ctypes.byref(g), P, K, n_layers, layers, int(training), _ptr(grad_out),
                     _ptr(out), _ptr(argk), _ptr(zmax), grads, _ptr(gA), 0, _ptr(ws), ws.numel())
             ctx.keep = None
-            return (gA, None, None, None, None, None, None, None, None, None, *ret)
+            return (gA, None, None, None, None, None, None, None, None, None, None, *ret)
         gz = torch.empty((P, stride), dtype=torch.float32, device=dev)       # dZ_0 rows (the pad quad is never read)
         run_bwd(lib, ctypes.byref(g), P, K, n_layers, layers, int(training), _ptr(grad_out),
                 _ptr(out), _ptr(argk), _ptr(zmax), grads, _ptr(gz), C0, _ptr(ws), ws.numel())
@@ -240,7 +266,7 @@ class _SharedMLPMaxFactored(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             gA = torch.empty((B, N, C0), dtype=torch.float32, device=dev)
             ops._run("group_bwd", gz, lib.mp_group_bwd_f32, _ptr(gz), _ptr(idx), B, N, S, K, C0, 1, stride, _ptr(gA), int(ops.DETERMINISTIC))
-        return (gA, None, None, None, None, None, None, None, None, None, *ret)
+        return (gA, None, None, None, None, None, None, None, None, None, None, *ret)
 
 
 PER_POINT_DW_SLICES = 8      # K slices per cloud of the batched weight-gradient GEMM below
@@ -333,8 +359,9 @@ def shared_mlp_max_factored(xyz, feats, new_xyz, idx, convs, bns, weight_order="
     from .sync_bn import resolve
     sync_group = resolve(sync_bn)
     writeback = _widen_interior(params, [c.out_channels for c in convs]) if (sync_group is False and WIDEN_INTERIOR) else []
+    states = [bn_state(bn, params[6 * i].shape[0]) for i, bn in enumerate(bns)] if (training and sync_group is False and BN_FUSED) else None
     out = _SharedMLPMaxFactored.apply(A.contiguous(), xyz.contiguous().float(), new_xyz.contiguous().float(), idx.contiguous(), training,
-                                      momentum, bn0.eps, len(convs), dtype == "bf16", sync_group, *params)
+                                      momentum, bn0.eps, len(convs), dtype == "bf16", sync_group, states, *params)
     if training:
         for dst, src in writeback:
             dst.copy_(src[:dst.numel()])
@@ -502,7 +529,8 @@ def shared_mlp_max(grouped, convs, bns, layout="xyz_first", dtype="f32", sync_bn
     momentum = bn0.momentum if bn0.momentum is not None else 1.0 / max(float(bn0.num_batches_tracked), 1.0)
     grad_cols = cin - 3 if (layout == "feats_first" and cin > 3) else 0
     writeback = _widen_interior(params, [c.out_channels for c in convs]) if (sync_group is False and WIDEN_INTERIOR) else []
-    out = _SharedMLPMax.apply(x, K, training, momentum, bn0.eps, len(convs), grad_cols, dtype == "bf16", sync_group, *params)
+    states = [bn_state(bn, params[6 * i].shape[0]) for i, bn in enumerate(bns)] if (training and sync_group is False and BN_FUSED) else None
+    out = _SharedMLPMax.apply(x, K, training, momentum, bn0.eps, len(convs), grad_cols, dtype == "bf16", sync_group, states, *params)
     if training:
         for dst, src in writeback:          # running statistics of the real channels back into the module's buffers
             dst.copy_(src[:dst.numel()])

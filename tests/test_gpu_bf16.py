@@ -83,7 +83,7 @@ def test_bf16_layers_are_exact_products_of_the_rounded_operands(B, S, K, cin, wi
     out = sa_mlp.shared_mlp_max(x, convs, bns, dtype="bf16")
     keep = out.grad_fn.next_functions[0][0].keep                      # per layer: (w, b, gamma, beta, rm, rv, z, stats[mean, rstd, scale, shift])
     a = torch.nn.functional.pad(x.reshape(-1, cin), (0, (-cin) % 4))
-    for l, (w, b, gam, bet, rm, rv, z, stats) in enumerate(keep):
+    for l, (w, b, gam, bet, rm, rv, z, stats, _state) in enumerate(keep):
         want = r16(a) @ r16(w.detach().reshape(w.shape[0], -1)).t()          # fp32 sums of exact products
         if z is None:       # [r3] the recomputed first layer (4 input channels): never stored -- its consumers rebuild exactly these products
             assert l == 0 and a.shape[1] == 4
