@@ -428,6 +428,16 @@ size_t mp_linear_dx_skinny_workspace_bytes(int64_t B, int64_t O, int64_t I);
 int mp_linear_dx_skinny_f32(const float* g, const float* weight, int64_t B, int64_t O, int64_t I, float* grad_x,
                             void* workspace, size_t workspace_bytes, mp_stream_t stream);
 
+/* ---- zero arena (launch count) -------------------------------------------------------------------------------------------
+ * Outputs the library accumulates with atomics start from zero; by default each call clears its own (one small launch each).
+ * mp_zero_arena_arm clears [base, base + bytes) with ONE launch on `stream` and remembers the range: until it is armed again or
+ * disarmed, a call on the same stream whose zero-initialised output lies inside the range skips its own clear.  The caller hands
+ * out every part of the range at most once per arming (process-wide state, like the profiler: one arena at a time).
+ * replaces: the implicit zero-initialisation of autograd's scatter / index_add / matmul outputs (models/pointnet2_utils.py:45-62,
+ * pytorch3d knn_points backward) -- launch bookkeeping only, no arithmetic. */
+int mp_zero_arena_arm(void* base, size_t bytes, mp_stream_t stream);
+int mp_zero_arena_disarm(void);
+
 /* ---- optional per-kernel device timing (bench / profiling aid; off by default) ------------------------------------
  * No counterpart in the reference (its only timing is wall-clock prints: train_maskplanner.py:236-239).
  * When enabled, launches inside the library are bracketed by HIP events on the launch stream.  collect() waits for

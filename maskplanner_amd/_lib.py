@@ -95,6 +95,8 @@ SIGNATURES = {
     "mp_linear_dx_skinny_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _sz, _vp]),
     "mp_linear_dx_mfma_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp]),
     "mp_linear_dw_outer_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp]),
+    "mp_zero_arena_arm": (_int, [_vp, _sz, _vp]),
+    "mp_zero_arena_disarm": (_int, []),
     "mp_profiler_enable": (_int, [_int]),
     "mp_profiler_collect": (_int, [ctypes.c_char_p, _sz]),
     "mp_sa_mlp_workspace_bytes": (_sz, [_i64, _i64, _int, ctypes.POINTER(_i64), _int]),

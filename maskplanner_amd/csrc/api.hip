@@ -94,3 +94,48 @@ extern "C" int mp_profiler_collect(char* buf, size_t cap)
     if (buf) memcpy(buf, out.c_str(), out.size() + 1);
     return (int)out.size();
 }
+
+// ---- zero arena ------------------------------------------------------------------------------------------------------------------
+// A training step has half a dozen small outputs that are accumulated with atomics and must start from zero (the scatter targets of
+// the nearest-neighbour backward, the input gradients of the wide heads, dA of the factorised first layer): a clear launch each,
+// ~5 us apiece on a dependent chain.  The caller may instead carve them out of ONE buffer, clear it with this call at the start of
+// the phase, and the library then skips its own clear of every output inside the armed range (same stream only).  Every part of the
+// range must be handed out at most once per arming; arming again (or mp_zero_arena_disarm) ends the previous one.
+namespace {
+std::mutex g_arena_mu;
+const char* g_arena_base = nullptr;
+size_t g_arena_bytes = 0;
+hipStream_t g_arena_stream = nullptr;
+}  // namespace
+
+namespace mp {
+bool zero_arena_covers(const void* p, size_t bytes, hipStream_t stream)
+{
+    std::lock_guard<std::mutex> lk(g_arena_mu);
+    const char* q = static_cast<const char*>(p);
+    return g_arena_base && stream == g_arena_stream && q >= g_arena_base && q + bytes <= g_arena_base + g_arena_bytes;
+}
+}  // namespace mp
+
+extern "C" int mp_zero_arena_disarm(void)
+{
+    std::lock_guard<std::mutex> lk(g_arena_mu);
+    g_arena_base = nullptr;
+    g_arena_bytes = 0;
+    g_arena_stream = nullptr;
+    return MP_OK;
+}
+
+extern "C" int mp_zero_arena_arm(void* base, size_t bytes, mp_stream_t stream_)
+{
+    if (!base || (bytes & 3) || (reinterpret_cast<uintptr_t>(base) & 15)) return MP_EINVAL;
+    hipStream_t stream = mp_stream(stream_);
+    mp_zero_arena_disarm();
+    if (bytes == 0) return MP_OK;
+    if (!mp::zero_async(static_cast<float*>(base), bytes / 4, stream)) return MP_ELAUNCH;
+    std::lock_guard<std::mutex> lk(g_arena_mu);
+    g_arena_base = static_cast<const char*>(base);
+    g_arena_bytes = bytes;
+    g_arena_stream = stream;
+    return MP_OK;
+}

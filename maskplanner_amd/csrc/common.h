@@ -150,9 +150,14 @@ static __global__ __launch_bounds__(256) void zero_fill_kernel(float* __restrict
     for (size_t i = n4 * 4 + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) p[i] = 0.0f;
 }
 
+// Zero arena (mp_zero_arena_arm): a caller-owned range that ONE launch has just cleared on `stream`; an output of the library that lies
+// inside it is handed out once per arming and needs no clear of its own.  Defined in api.hip.
+bool zero_arena_covers(const void* p, size_t bytes, hipStream_t stream);
+
 static inline bool zero_async(float* p, size_t n, hipStream_t stream)
 {
     if (n == 0) return true;
+    if (zero_arena_covers(p, n * sizeof(float), stream)) return true;
     const size_t n4 = (reinterpret_cast<uintptr_t>(p) & 15) ? 0 : n / 4;   // float4 stores need 16-byte alignment
     size_t blocks = ((n4 ? n4 : n) + 255) / 256;
     if (blocks > 2048) blocks = 2048;

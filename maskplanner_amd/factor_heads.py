@@ -43,7 +43,7 @@ class _FactorLinear(torch.autograd.Function):
             if (g.is_cuda and B <= 32 and O >= 4096 and I % 128 == 0 and g.dtype == torch.float32 and weight.is_contiguous()
                     and not ops.DETERMINISTIC):
                 # the stream of W through the matrix cores (csrc/linear_dx.hip; atomics between its K slices: not bit-reproducible)
-                gx = torch.empty((B, I), dtype=torch.float32, device=g.device)
+                gx = ops.zeroed_empty((B, I), torch.float32, g.device)
                 ops._run("linear_dx_mfma", g, _lib.load().mp_linear_dx_mfma_f32, g.data_ptr(), weight.data_ptr(), B, O, I, gx.data_ptr())
             elif g.is_cuda and B <= 32 and O >= 4096 and I % 4 == 0 and g.dtype == torch.float32 and weight.is_contiguous():
                 gx = torch.empty((B, I), dtype=torch.float32, device=g.device)   # one streaming pass over W

@@ -67,6 +67,8 @@ class TrainStep:
         self._split_adam_wanted = os.environ.get("MASKPLANNER_SPLIT_ADAM", "1") != "0"
         self._plan_mid = os.environ.get("MASKPLANNER_PLAN_AT", "start") == "mid"
         self._unit = torch.ones((), dtype=torch.float32, device=self.device)
+        from . import ops as _ops
+        self._zero_arena = _ops.ZeroArena(self.device) if self.device.type == "cuda" else None
         # train-mode dropout of the head blocks inside their BatchNorm + ReLU launches (pointnet2_cls_ssg._block): a device (seed, step)
         # pair, the step advanced once per training step.  MASKPLANNER_FUSED_DROPOUT=0 keeps nn.Dropout (torch's Philox stream).
         self._drop_rng = None
@@ -142,6 +144,9 @@ class TrainStep:
             return self.model.encode(self.point_cloud)
 
     def _heads_loss(self, feat):
+        # the small zero-initialised outputs of the loss / heads / encoder backward out of one buffer cleared by one launch (ops.ZeroArena)
+        if self._zero_arena is not None:
+            self._zero_arena.arm()
         out, sm_out, mask_conf, seg_conf = self.model.heads(feat)
         if self._drop_rng is not None:      # next step, next dropout masks: the step counter rides in the BatchNorm counters' launch
             from . import sa_mlp
@@ -152,6 +157,10 @@ class TrainStep:
         return self.loss_handler.compute(return_list=False, y_pred=out, y=self.batch["traj"], pred_stroke_masks=sm_out,
                                          mask_scores=mask_conf, seg_logits=seg_conf, stroke_ids=self.batch["stroke_ids"],
                                          traj_as_pc=self.batch["traj_as_pc"])
+
+    def _disarm(self):
+        if self._zero_arena is not None:
+            self._zero_arena.disarm()
 
     def check(self, loss=None):
         """What the asynchronous step cannot do without a host sync: raise if the last stroke-mask matching failed (the reference
@@ -291,6 +300,7 @@ class TrainStep:
                     loss = self._heads_loss(feat)
                     sa_mlp.flush_ticks()
                     loss.backward(self._unit)     # (a cached 1: no fill launch for the seed gradient)
+                    self._disarm()
                 sa_mlp.DEFERRED_TICKS = ticks_prev
                 if self.factor_opt is not None:
                     flush_bias_grads(self.model.factor_store)
@@ -315,6 +325,7 @@ class TrainStep:
             if split_bwd:
                 with torch.cuda.graph(gb2, pool=ga.pool(), stream=cap):
                     feat.backward(leaf.grad)
+                    self._disarm()
                     if not self.dp_graph:
                         self.reducer.finish()
                         self.opt.step()
@@ -336,6 +347,7 @@ class TrainStep:
             from . import sa_mlp
             sa_mlp.DEFERRED_TICKS = None
             warnings.warn(f"hipGraph capture of the training step failed ({type(exc).__name__}: {exc}); running eagerly")
+            self._disarm()
             self._graph, self._graph_b, self._graph_b2, self.use_graph = None, None, None, False
             if self.dp_graph:
                 self.dp_graph, self._guard_left, self.reducer.deferred = False, 0, False
@@ -570,7 +582,10 @@ class TrainStep:
         self.reducer.zero_grad()
         with self._Ticks():
             loss = self.forward_loss()
-        loss.backward(self._unit)     # (a cached 1: no fill launch for the seed gradient)
+        try:
+            loss.backward(self._unit)     # (a cached 1: no fill launch for the seed gradient)
+        finally:
+            self._disarm()
         if self.factor_opt is not None:
             flush_bias_grads(self.model.factor_store)
         self.reducer.finish()

@@ -253,7 +253,7 @@ class _SharedMLPMaxFactored(torch.autograd.Function):
         # deterministic run asks for the ordered scatter: then dZ_0 comes back and ops.group's backward kernel reduces it
         fused = FACTORED_REDUCE and not ops.DETERMINISTIC and N <= 15000 and S * K < (1 << 24)
         if fused:
-            gA = torch.empty((B, N, C0), dtype=torch.float32, device=dev)
+            gA = ops.zeroed_empty((B, N, C0), torch.float32, dev)
             run_bwd(lib, ctypes.byref(g), P, K, n_layers, layers, int(training), _ptr(grad_out),
                     _ptr(out), _ptr(argk), _ptr(zmax), grads, _ptr(gA), 0, _ptr(ws), ws.numel())
             ctx.keep = None
