@@ -551,6 +551,10 @@ class _ChamferTerm(torch.autograd.Function):
         return g1, g2, None, None, None, None, None, None, (grad_out if ctx.needs_input_grad[8] else None)
 
 
+RELU_TAP = None     # test hook (tests/test_gpu_routing.py): a list that receives the ReLU mask [B, C] of every bn_relu_rows call
+KNN_TAP = None      # test hook (tests/test_gpu_routing.py): a list that receives the nearest-neighbour indices of every chamfer_term call
+
+
 def chamfer_term(p1, p2, lengths1, lengths2, point_reduction="mean", batch_reduction="mean", scale=1.0, add=None):
     """(value, dists [B,P1], idx [B,P1]) of one reduced one-directional chamfer term, see _ChamferTerm; lengths1 is required
     (the point mean divides by it).  Same numbers as knn(K=1) followed by chamfer_reduce."""
@@ -562,8 +566,11 @@ def chamfer_term(p1, p2, lengths1, lengths2, point_reduction="mean", batch_reduc
         raise ValueError("add must be a float32 scalar and needs a batch reduction")
     if point_reduction not in ("mean", "sum"):
         raise ValueError("point_reduction must be 'mean' or 'sum'")
-    return _ChamferTerm.apply(_f32(p1), _f32(p2), _i64(lengths1), None if lengths2 is None else _i64(lengths2),
-                              point_reduction == "mean", batch_mode, float(p1.shape[0]), float(scale), add)
+    res = _ChamferTerm.apply(_f32(p1), _f32(p2), _i64(lengths1), None if lengths2 is None else _i64(lengths2),
+                             point_reduction == "mean", batch_mode, float(p1.shape[0]), float(scale), add)
+    if KNN_TAP is not None:
+        KNN_TAP.append(res[2])
+    return res
 
 
 class _ChamferReduce(torch.autograd.Function):
@@ -721,6 +728,9 @@ def bn_relu_rows(x, bn, dropout=None):
         _need_hip(rng)
         if rng.dtype != torch.int64 or rng.numel() != 2:
             raise ValueError("dropout rng must be an int64 tensor (seed, step)")
-    return _BnReluRows.apply(_f32(x), bn.weight, bn.bias, bn.running_mean if track else None, bn.running_var if track else None,
-                             training, momentum, bn.eps, p, rng, layer)
+    y = _BnReluRows.apply(_f32(x), bn.weight, bn.bias, bn.running_mean if track else None, bn.running_var if track else None,
+                          training, momentum, bn.eps, p, rng, layer)
+    if RELU_TAP is not None:
+        RELU_TAP.append(y.detach() > 0)
+    return y
 

@@ -48,6 +48,12 @@ def reset_bn_state(module):
             t.zero_()
 
 
+# Test hook (tests/test_gpu_routing.py): a list that receives, per level, (the max-pool arg-max [G, C] -- member index inside the group --,
+# [(raw Z_l [P, C] | None, scale [C], shift [C]) per layer]) as the forward pass computes them, so that an oracle can be evaluated with
+# the SAME discrete decisions (pool routing, ReLU masks = (Z * scale + shift > 0)).
+ROUTE_TAP = None
+
+
 # None: every level advances its BatchNorm counters (num_batches_tracked) itself.  A list: the counters are collected here
 # instead and the owner (harness.TrainStep) advances all of them -- set-abstraction levels and heads -- in one launch per step.
 DEFERRED_TICKS = None
@@ -111,6 +117,8 @@ class _SharedMLPMax(torch.autograd.Function):
         ctx.sync_group = sync_group
         ctx.meta = (P, K, bool(training), n_layers, chans, int(grad_cols), bool(bf16))
         ctx.keep = keep
+        if ROUTE_TAP is not None:
+            ROUTE_TAP.append((argk, [(k[6], k[7][2], k[7][3]) for k in keep]))
         ctx.save_for_backward(x, out, argk, zmax)
         ctx.mark_non_differentiable(argk, zmax)
         return out
@@ -207,6 +215,8 @@ class _SharedMLPMaxFactored(torch.autograd.Function):
         ctx.sync_group = sync_group
         ctx.meta = (P, K, bool(training), n_layers, chans, (B, N, S, C0), bool(bf16))
         ctx.keep = keep
+        if ROUTE_TAP is not None:
+            ROUTE_TAP.append((argk, [(k[6], k[7][2], k[7][3]) for k in keep]))
         ctx.save_for_backward(A, xyz, new_xyz, idx, out, argk, zmax)
         ctx.mark_non_differentiable(argk, zmax)
         return out
@@ -272,6 +282,16 @@ class _SharedMLPMaxFactored(torch.autograd.Function):
 PER_POINT_DW_SLICES = 8      # K slices per cloud of the batched weight-gradient GEMM below
 
 
+_ZERO_COLS = {}
+
+
+def _zero_col(n, device):
+    t = _ZERO_COLS.get((n, device))
+    if t is None:
+        t = _ZERO_COLS[(n, device)] = torch.zeros((n, 1), dtype=torch.float32, device=device)
+    return t
+
+
 class _PerPointFirst(torch.autograd.Function):
     """The feature half of a factorised first layer and the split of its weight, with a backward that costs four launches:
     (feats [B,N,CF], w [Co,Cin] in the module's column order, xyz_first) -> A = feats W_f^T [B,N,Co], (W_x | 0) [Co,4].
@@ -285,7 +305,7 @@ class _PerPointFirst(torch.autograd.Function):
             feats, w = _r16(feats), torch.cat([w[:, :3], _r16(w[:, 3:])], 1) if xyz_first else torch.cat([_r16(w[:, :CF]), w[:, CF:]], 1)
         wx, wf = (w[:, :3], w[:, 3:]) if xyz_first else (w[:, CF:], w[:, :CF])
         A = torch.matmul(feats, wf.t())
-        wx4 = torch.nn.functional.pad(wx, (0, 1))
+        wx4 = torch.cat([wx, _zero_col(wx.shape[0], wx.device)], 1)       # (one launch: F.pad is a fill + a copy)
         ctx.save_for_backward(feats, w)
         ctx.xyz_first = bool(xyz_first)
         return A, wx4

@@ -70,17 +70,28 @@ class _Bf16Matmul(torch.autograd.Function):
         return ga, gw
 
 
-def shared_mlp_max(x, layers, train, bf16=False):
+def shared_mlp_max(x, layers, train, bf16=False, route=None, argmax_out=None, relu_masks=None):
     """x [B,S,K,Cin] -> [B,S,Cout]: (1x1 conv, BN, ReLU) x len(layers), then max over K.
     layers: list of dict(weight[Co,Ci], bias[Co], gamma, beta, running_mean, running_var).
-    bf16: the contraction of every layer with bf16-rounded operands (_Bf16Matmul); everything else fp32."""
-    for L in layers:
+    bf16: the contraction of every layer with bf16-rounded operands (_Bf16Matmul); everything else fp32.
+    route [B,S,Cout] (int64, member index inside the group): ROUTING-CONDITIONED evaluation -- the pooled value of a (group, channel)
+    is read at the given member instead of at this evaluation's own arg-max, so that two implementations whose forward values
+    differ by rounding backpropagate through the SAME members (a max-pool's gradient is discontinuous at ties: with the routing taken
+    from the implementation under test, the gradients are comparable at rounding level).  argmax_out (list): receives this
+    evaluation's own arg-max [B,S,Cout], for counting the (group, channel) pairs the two implementations route differently.
+    relu_masks: per layer a bool tensor [B,S,K,Co] -- the ReLU of that layer as `z * mask` with the mask of the other implementation
+    (an activation within rounding of 0 is as much a discrete decision as an arg-max)."""
+    for li, L in enumerate(layers):
         z = (_Bf16Matmul.apply(x, L["weight"]) if bf16 else x @ L["weight"].t()) + L["bias"]
         if train:
             z = _bn_train(z, L["gamma"], L["beta"], (L["running_mean"], L["running_var"]))
         else:
             z = _bn_eval(z, L["gamma"], L["beta"], L["running_mean"], L["running_var"])
-        x = torch.relu(z)
+        x = torch.relu(z) if relu_masks is None else z * relu_masks[li].to(z.dtype)
+    if argmax_out is not None:
+        argmax_out.append(x.detach().max(dim=2)[1])
+    if route is not None:
+        return torch.gather(x, 2, route.to(torch.int64)[:, :, None, :]).squeeze(2)
     return x.max(dim=2)[0]
 
 
@@ -98,12 +109,14 @@ def layers_from_state(sd, prefix, convs="mlp_convs", bns="mlp_bns"):
     return out
 
 
-def set_abstraction(xyz, feats, layers, npoint, radius, nsample, fps_start, train, group_all=False, bf16=False):
-    """xyz [B,N,3], feats [B,N,D] or None (points-major).  Returns new_xyz [B,S,3], new_feats [B,S,C']."""
+def set_abstraction(xyz, feats, layers, npoint, radius, nsample, fps_start, train, group_all=False, bf16=False, route=None, argmax_out=None,
+                    relu_masks=None):
+    """xyz [B,N,3], feats [B,N,D] or None (points-major).  Returns new_xyz [B,S,3], new_feats [B,S,C'].
+    route / argmax_out: see shared_mlp_max."""
     B, N, _ = xyz.shape
     if group_all:  # sample_and_group_all :151-168 -- xyz NOT centred, new_xyz = 0
         x = xyz if feats is None else torch.cat([xyz, feats], -1)
-        return torch.zeros(B, 1, 3, dtype=xyz.dtype), shared_mlp_max(x[:, None], layers, train, bf16)
+        return torch.zeros(B, 1, 3, dtype=xyz.dtype), shared_mlp_max(x[:, None], layers, train, bf16, route, argmax_out, relu_masks)
     xyz_np = xyz.detach().float().numpy()
     fidx = O.fps(xyz_np, npoint, fps_start)
     new_xyz_np = O.index_points(xyz_np, fidx)
@@ -113,7 +126,7 @@ def set_abstraction(xyz, feats, layers, npoint, radius, nsample, fps_start, trai
     g = xyz[bidx, gidx] - new_xyz[:, :, None]
     if feats is not None:
         g = torch.cat([g, feats[bidx, gidx]], -1)  # xyz channels first (:138)
-    return new_xyz, shared_mlp_max(g, layers, train, bf16)
+    return new_xyz, shared_mlp_max(g, layers, train, bf16, route, argmax_out, relu_masks)
 
 
 def set_abstraction_msg(xyz, feats, blocks, npoint, radii, nsamples, fps_start, train, bf16=False):
@@ -158,34 +171,41 @@ def msg_blocks_from_state(sd, prefix):
 MSG_LEVELS = ((512, (0.1, 0.2, 0.4), (16, 32, 128)), (128, (0.2, 0.4, 0.8), (32, 64, 128)))
 
 
-def encoder_forward(sd, xyz, fps_starts, train, encoder="ssg", bf16=False):
+def encoder_forward(sd, xyz, fps_starts, train, encoder="ssg", bf16=False, routes=None, argmax_out=None, relu_masks=None):
     """xyz [B,N,3] -> global feature [B,1024]: sa1 -> sa2 -> sa3 of the SSG (models/pointnet2_cls_ssg.py:266-268, 299-307) or
-    the multi-scale encoder; bf16: the grouped-MLP contractions with bf16-rounded operands."""
+    the multi-scale encoder; bf16: the grouped-MLP contractions with bf16-rounded operands.
+    routes (SSG only): the three levels' max-pool routing [r1, r2, r3] (see shared_mlp_max); argmax_out: list receiving this
+    evaluation's own three arg-max tensors."""
     B = xyz.shape[0]
+    r = routes if routes is not None else (None, None, None)
+    m = relu_masks if relu_masks is not None else (None, None, None)       # per level: the three layers' ReLU masks
     if encoder == "msg":
         (n1, r1, k1), (n2, r2, k2) = MSG_LEVELS
         l1_xyz, l1 = set_abstraction_msg(xyz, None, msg_blocks_from_state(sd, "sa1."), n1, r1, k1, fps_starts[0], train, bf16)
         l2_xyz, l2 = set_abstraction_msg(l1_xyz, l1, msg_blocks_from_state(sd, "sa2."), n2, r2, k2, fps_starts[1], train, bf16)
     else:
-        l1_xyz, l1 = set_abstraction(xyz, None, layers_from_state(sd, "sa1."), 512, 0.2, 32, fps_starts[0], train, bf16=bf16)
-        l2_xyz, l2 = set_abstraction(l1_xyz, l1, layers_from_state(sd, "sa2."), 128, 0.4, 64, fps_starts[1], train, bf16=bf16)
-    _, l3 = set_abstraction(l2_xyz, l2, layers_from_state(sd, "sa3."), None, None, None, None, train, group_all=True, bf16=bf16)
+        l1_xyz, l1 = set_abstraction(xyz, None, layers_from_state(sd, "sa1."), 512, 0.2, 32, fps_starts[0], train, bf16=bf16, route=r[0], argmax_out=argmax_out, relu_masks=m[0])
+        l2_xyz, l2 = set_abstraction(l1_xyz, l1, layers_from_state(sd, "sa2."), 128, 0.4, 64, fps_starts[1], train, bf16=bf16, route=r[1], argmax_out=argmax_out, relu_masks=m[1])
+    _, l3 = set_abstraction(l2_xyz, l2, layers_from_state(sd, "sa3."), None, None, None, None, train, group_all=True, bf16=bf16,
+                            route=r[2] if encoder != "msg" else None, argmax_out=argmax_out if encoder != "msg" else None,
+                            relu_masks=m[2] if encoder != "msg" else None)
     return l3.reshape(B, -1)
 
 
 def strokemasks_forward(sd, xyz, fps_starts, train, out_vectors, n_masks, weight_orient=0.25, dropout_masks=None,
-                        encoder="ssg", bf16=False, return_feat=False):
+                        encoder="ssg", bf16=False, return_feat=False, routes=None, argmax_out=None, relu_masks=None, head_masks=None):
     """sd: reference-layout state_dict of tensors; xyz [B,N,3].  dropout_masks: optional list of 4
     pre-scaled keep masks (train mode) so dropout is reproducible; None = no dropout.
     encoder "msg": two multi-scale levels + group_all; bf16: the grouped-MLP contractions with bf16-rounded operands."""
     B = xyz.shape[0]
-    feat = encoder_forward(sd, xyz, fps_starts, train, encoder, bf16)
+    feat = encoder_forward(sd, xyz, fps_starts, train, encoder, bf16, routes, argmax_out, relu_masks)
+    act = (lambda z, i: torch.relu(z)) if head_masks is None else (lambda z, i: z * head_masks[i].to(z.dtype))     # head_masks: bn1, bn2, sm_bn1, sm_bn2
     dm = dropout_masks or [1.0, 1.0, 1.0, 1.0]
-    x = torch.relu(_bn1d(feat @ sd["fc1.weight"].t() + sd["fc1.bias"], sd, "bn1", train)) * dm[0]
-    final = torch.relu(_bn1d(x @ sd["fc2.weight"].t() + sd["fc2.bias"], sd, "bn2", train)) * dm[1]
+    x = act(_bn1d(feat @ sd["fc1.weight"].t() + sd["fc1.bias"], sd, "bn1", train), 0) * dm[0]
+    final = act(_bn1d(x @ sd["fc2.weight"].t() + sd["fc2.bias"], sd, "bn2", train), 1) * dm[1]
     pos = final @ sd["fc3.weight"].t() + sd["fc3.bias"]
-    s1 = torch.relu(_bn1d(feat @ sd["sm_fc1.weight"].t() + sd["sm_fc1.bias"], sd, "sm_bn1", train)) * dm[2]
-    s2 = torch.relu(_bn1d(s1 @ sd["sm_fc2.weight"].t() + sd["sm_fc2.bias"], sd, "sm_bn2", train)) * dm[3]
+    s1 = act(_bn1d(feat @ sd["sm_fc1.weight"].t() + sd["sm_fc1.bias"], sd, "sm_bn1", train), 2) * dm[2]
+    s2 = act(_bn1d(s1 @ sd["sm_fc2.weight"].t() + sd["sm_fc2.bias"], sd, "sm_bn2", train), 3) * dm[3]
     sm_out = (s2 @ sd["sm_fc3.weight"].t() + sd["sm_fc3.bias"]).view(B, n_masks, -1)
     mask_conf = s2 @ sd["mask_conf_out.weight"].t() + sd["mask_conf_out.bias"]
     nrm = torch.tanh(final @ sd["fc_normals.weight"].t() + sd["fc_normals.bias"]).view(B, -1, 3)
@@ -255,16 +275,28 @@ def _knn1_any_dtype(p1, p2, l1, l2):
     return torch.where(valid, d, torch.zeros((), dtype=d.dtype)), i
 
 
+def _knn1_given(p1, p2, l1, l2, i):
+    """The K = 1 'search' with the neighbour index GIVEN (routing-conditioned evaluation: the discrete decision of another
+    implementation); the squared distance to it is plain torch algebra in the inputs' own type."""
+    i = i.to(torch.int64)
+    nb = p2.gather(1, i[..., None].expand(-1, -1, p2.shape[2]))
+    d = (p1 - nb).square().sum(-1)
+    valid = (torch.arange(p1.shape[1])[None] < l1[:, None]) & (l2[:, None] > 0)
+    return torch.where(valid, d, torch.zeros((), dtype=d.dtype)), i
+
+
 def chamfer_distance(x, y, padded=False, asymmetric=False, reverse_asymmetric=False, return_matching=False,
-                     batch_reduction="mean", point_reduction="mean"):
+                     batch_reduction="mean", point_reduction="mean", nn_x=None, nn_y=None):
+    """nn_x / nn_y: nearest-neighbour indices [B,P1] / [B,P2] of the x -> y / y -> x direction taken from another implementation
+    (routing-conditioned evaluation); None: this evaluation's own search."""
     B, P1, D = x.shape
     P2 = y.shape[1]
     xl = torch.full((B,), P1, dtype=torch.int64)
     yl = torch.from_numpy(O.padded_lengths(y.detach().float().numpy())) if padded else torch.full((B,), P2, dtype=torch.int64)
     knn1 = _Knn1.apply if x.dtype == torch.float32 else _knn1_any_dtype
     y = y.to(x.dtype)
-    cx, ix = knn1(x, y, xl, yl)
-    cy, iy = knn1(y, x, yl, xl)
+    cx, ix = knn1(x, y, xl, yl) if nn_x is None else _knn1_given(x, y, xl, yl, nn_x)
+    cy, iy = knn1(y, x, yl, xl) if nn_y is None else _knn1_given(y, x, yl, xl, nn_y)
     # rows beyond the length already hold 0 (knn contract) == the reference's masking (:263-266)
     if point_reduction is not None:
         cx, cy = cx.sum(1), cy.sum(1)
@@ -305,14 +337,20 @@ def stroke_masks_loss(idx_x, pred_masks, scores, stroke_ids, w_masks=1.0, w_conf
     return (loss, pairs) if return_matching else loss
 
 
-def asymm_v6_loss(y_pred, traj, pred_masks, scores, stroke_ids, traj_as_pc, cfg):
-    """cfg: dict with the weights read at loss_handler.py:660-664,934."""
+def asymm_v6_loss(y_pred, traj, pred_masks, scores, stroke_ids, traj_as_pc, cfg, nn_routes=None, nn_out=None):
+    """cfg: dict with the weights read at loss_handler.py:660-664,934.
+    nn_routes: [pred segment -> GT segment, GT point -> predicted pose, GT segment -> pred segment] nearest-neighbour indices of the
+    three terms taken from another implementation (routing-conditioned evaluation); nn_out: list receiving this evaluation's own."""
     B = y_pred.shape[0]
+    r = nn_routes if nn_routes is not None else (None, None, None)
     d1, idx_x, _ = chamfer_distance(y_pred, traj, padded=True, asymmetric=True, return_matching=True,
-                                    point_reduction=None, batch_reduction=None)
+                                    point_reduction=None, batch_reduction=None, nn_x=r[0])
     t1 = 100 * d1.mean()
-    t2 = 100 * chamfer_distance(y_pred.reshape(B, -1, 6), traj_as_pc, padded=True, reverse_asymmetric=True)
-    t3 = 100 * chamfer_distance(y_pred, traj, padded=True, reverse_asymmetric=True)
+    t2, _, i2 = chamfer_distance(y_pred.reshape(B, -1, 6), traj_as_pc, padded=True, reverse_asymmetric=True, return_matching=True, nn_y=r[1])
+    t3, _, i3 = chamfer_distance(y_pred, traj, padded=True, reverse_asymmetric=True, return_matching=True, nn_y=r[2])
+    t2, t3 = 100 * t2, 100 * t3
+    if nn_out is not None:
+        nn_out.extend([idx_x, i2, i3])
     t4 = stroke_masks_loss(idx_x, pred_masks, scores, stroke_ids, cfg["explicit_weight_stroke_masks"],
                            cfg["explicit_weight_stroke_masks_confidence"], cfg["explicit_no_stroke_weight"])
     return (cfg["weight_asymm_segment_chamfer"] * t1 + cfg["weight_reverse_asymm_point_chamfer"] * t2
