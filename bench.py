@@ -334,7 +334,7 @@ def main():
         ms = dt / args.steps * 1e3
         enc = "SSG encoder" if args.encoder == "ssg" else "MSG encoder (two multi-radius set abstractions)"
         line = {
-            "metric": "point-clouds/sec fwd+bwd (N=5120, B=32)", "value": args.batch * world * args.steps / dt,
+            "metric": f"point-clouds/sec fwd+bwd (N={args.points}, B={args.batch})", "value": args.batch * world * args.steps / dt,
             "unit": "point-clouds/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"{cat.name}_v2 N={args.points} B={args.batch}/GPU {enc} + asymm_chamfer_v9 loss "
@@ -351,7 +351,7 @@ def main():
                 "launch": ("hipGraph replay of the recorded step" + (" (two graphs; head optimizer on its own stream under the next encoder forward)"
                                                                       if ts._graph_b is not None else ""))
                 if ts._graph is not None else "eager (kernel by kernel)",
-                "sampling": "next batch's first-level FPS + ball query on a second stream, under the step" if ts.overlap else "in line",
+                "sampling": "next batch's FPS + ball queries (every sampling level) on a second stream, under the step" if ts.overlap else "in line",
                 "batchnorm": "global-batch statistics (SyncBN)" if getattr(ts, "sync_bn", False) else "per-replica statistics",
                 "inputs": ("a fresh host batch per step, collated onto the device during the previous step" if getattr(ts, "_stream", None)
                            else "one batch resident in HBM")})

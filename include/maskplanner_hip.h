@@ -313,6 +313,14 @@ size_t mp_sa_mlp_workspace_bytes(int64_t P, int64_t K, int n_layers, const int64
  * element.  channels[n_layers + 1] as for the workspace query.  (Reference: the first Conv2d of sa1, pointnet2_utils.py:208-213;
  * the reference stores every activation for autograd.) */
 int mp_sa_mlp_recompute_first(int n_layers, const int64_t* channels, int64_t K);
+/* bf16 variant only (mp_sa_mlp_{fwd,bwd}_bf16, _gather_bf16, the _ex forms with bf16 = 1): 1 if this chain keeps its raw activations in
+ * memory as bf16 -- every layers[l].z the caller passes is then a bf16 [P, c_out] buffer (2 bytes per element) although the struct
+ * field is typed float*, and the gradient buffers inside the workspace are bf16 too.  first_layer: 1 = recomputed (layers[0].z NULL),
+ * 2 = factorised (gather forms), 0 = stored grouped input.  Chains that qualify run entirely on the position-stream kernels (first layer
+ * recomputed or factorised, later layers 64 / 128 -> 64 / 128 / 256, K in {32, 64, 128}); BatchNorm statistics are taken before the
+ * rounding, everything downstream sees the rounded value.  Other bf16 chains keep fp32 storage (and cannot recompute their first layer).
+ * (Reference: the activations autograd stores for models/pointnet2_utils.py:208-214; BASELINE configs[4] "bf16 MFMA grouped-MLP".) */
+int mp_sa_mlp_bf16_storage(int n_layers, const int64_t* channels, int64_t K, int first_layer);
 /* FACTORISED first layer of a level with input features: the gather forms (mp_sa_mlp_{fwd,bwd}_gather_*) take this descriptor instead
  * of x0 -- the grouped input [feats[b, idx[p]] | xyz[b, idx[p]] - new_xyz[b, s]] (models/pointnet2_utils.py:133-143) is never materialised.
  * Shapes: layers[0].c_in == 4 and CF == layers[0].c_out in {64, 128, 256}.  The first Conv2d is linear in [f ; x - c] (pointnet2_utils.py:138 / :262 + :208-213), so the caller computes A = F W_f^T once per

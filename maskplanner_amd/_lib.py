@@ -101,6 +101,7 @@ SIGNATURES = {
     "mp_profiler_collect": (_int, [ctypes.c_char_p, _sz]),
     "mp_sa_mlp_workspace_bytes": (_sz, [_i64, _i64, _int, ctypes.POINTER(_i64), _int]),
     "mp_sa_mlp_recompute_first": (_int, [_int, ctypes.POINTER(_i64), _i64]),
+    "mp_sa_mlp_bf16_storage": (_int, [_int, ctypes.POINTER(_i64), _i64, _int]),
     "mp_adam_multi_f32": (_int, [_i64, _vp, _vp, _vp, _vp, ctypes.POINTER(_i64), ctypes.c_double, ctypes.c_double, ctypes.c_double,
                                  ctypes.c_double, ctypes.c_double, _i64, _vp, _vp]),
     "mp_colsum_multi_f32": (_int, [_i64, _vp, _vp, ctypes.POINTER(_i64), _i64, _vp]),

@@ -217,6 +217,28 @@ struct ChanConst {
 };
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+// bf16 ACTIVATION STORAGE (the bf16 variant of BASELINE configs[4], chains that run entirely on the position-stream kernels): the raw
+// pre-BatchNorm activations Z_l and the activation gradients G_l live in memory as bf16 -- half the bytes of the kernels that are
+// HBM-bound on them.  A buffer keeps its `const float*` type in the operand structs; `h` says how to read it.  The BatchNorm sums are
+// taken from the fp32 accumulators BEFORE the rounding; everything downstream (the next layer, the backward pass) sees the rounded value.
+__device__ __forceinline__ float4 ld4h(const float* base, size_t elem)      // 4 consecutive bf16 elements (8 bytes) -> fp32
+{
+    const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(base) + elem);
+    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+}
+template <bool H>
+__device__ __forceinline__ float4 ldz4(const float* base, size_t elem) { if constexpr (H) return ld4h(base, elem); else return ld4(base + elem); }
+__device__ __forceinline__ float4 ldz4(const float* base, size_t elem, int h) { return h ? ld4h(base, elem) : ld4(base + elem); }
+__device__ __forceinline__ unsigned pack_bf16(float lo, float hi)            // two fp32 -> one dword of bf16 (nearest even), lo in the low half
+{
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    const bf16x2_t v = {(__bf16)lo, (__bf16)hi};
+    return *reinterpret_cast<const unsigned*>(&v);
+}
+__device__ __forceinline__ void st4h(float* base, size_t elem, const float4& v)   // 4 consecutive elements as bf16 (8 bytes)
+{
+    *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(base) + elem) = make_uint2(pack_bf16(v.x, v.y), pack_bf16(v.z, v.w));
+}
 __device__ __forceinline__ float comp(const float4& v, int j) { return j == 0 ? v.x : (j == 1 ? v.y : (j == 2 ? v.z : v.w)); }
 
 // lds != NULL and o.bn on: the constants this kernel derived itself (bn_prologue) -- (scale, shift) of an activation operand or
@@ -265,15 +287,15 @@ struct Raw4 {
     bool ok;
 };
 
-template <int MODE>
+template <int MODE, bool H = false>       // H: this operand's stored Z (and dense G) are bf16 in memory (ld4h)
 __device__ __forceinline__ void raw_load(const PosOperand& o, int P, int p, int c, Raw4<MODE>& r)
 {
     r.ok = (p < P) && (c < o.C);
     const int pp = r.ok ? p : 0, cc = r.ok ? c : 0;
     if constexpr (is_rc(MODE)) r.z = ld4(o.rx + (size_t)pp * 4);   // the input row; raw_z() turns it into 4 channels of z
-    else r.z = ld4(o.x + (size_t)((unsigned)pp * (unsigned)o.C + (unsigned)cc));
+    else r.z = ldz4<H>(o.x, (size_t)((unsigned)pp * (unsigned)o.C + (unsigned)cc));
     if constexpr (MODE == SRC_DZ || MODE == SRC_DZ_RC) {
-        r.g = ld4(o.g + (size_t)((unsigned)pp * (unsigned)o.C + (unsigned)cc));
+        r.g = ldz4<H>(o.g, (size_t)((unsigned)pp * (unsigned)o.C + (unsigned)cc));
     } else if constexpr (MODE == SRC_DZ_POOLED) {
         unsigned grp;
         if (o.kshift >= 0) { grp = (unsigned)pp >> o.kshift; r.kk = pp & (o.K - 1); }      // (a division by a run-time K is ~20 VALU instructions)
@@ -1136,8 +1158,8 @@ __global__ __launch_bounds__(CO > 128 ? 512 : 256) void fwd_chunk_kernel(PosOper
     RSet rs0, rs1;                             // (rs1: FPD2 only)
     auto gload = [&](int pk, RSet& rs) {
 #pragma unroll
-        for (int ps = 0; ps < PA; ++ps) raw_load<MODE_A>(A, p1, pk + ka0 + ps * KA_STEP, ca, rs.a[ps]);
-        if constexpr (TAIL != 0) { if (tid < DBK) raw_load<MODE_A>(A, p1, pk + tid, CI, rs.t); }
+        for (int ps = 0; ps < PA; ++ps) raw_load<MODE_A, ONE>(A, p1, pk + ka0 + ps * KA_STEP, ca, rs.a[ps]);
+        if constexpr (TAIL != 0) { if (tid < DBK) raw_load<MODE_A, ONE>(A, p1, pk + tid, CI, rs.t); }
     };
     auto sstore = [&](int buf, RSet& rs) {
         auto& ra = rs.a;
@@ -1177,8 +1199,12 @@ __global__ __launch_bounds__(CO > 128 ? 512 : 256) void fwd_chunk_kernel(PosOper
     //  * the BatchNorm sums run on register pairs (v_pk_add_f32 / v_pk_mul_f32); rows past P are exact zeros and need no mask;
     //  * the pool tracks one extremum per column (sign of gamma), as a maximum of the sign-flipped value.
     typedef float f2 __attribute__((ext_vector_type(2)));
-    const __amdgpu_buffer_rsrc_t zrsrc = __builtin_amdgcn_make_buffer_rsrc(Z + (size_t)p0 * CO, 0, (p1 - p0) * CO * 4, 0x00020000);
-    int zoff = ((BIG ? 4 * kq : 4 * kq) * CO + col) * 4;     // byte offset of this lane's first row inside the workgroup's slab
+    // ONE: Z is STORED as bf16 (2 bytes per element): adjacent lanes hold adjacent columns, so a lane pair exchanges one value per row
+    // pair and each lane stores one dword -- the even lane (col, col + 1) of the even row, the odd lane the same columns of the odd row
+    constexpr int ZB = ONE ? 2 : 4;
+    const __amdgpu_buffer_rsrc_t zrsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(Z) + (size_t)p0 * CO * ZB, 0, (p1 - p0) * CO * ZB, 0x00020000);
+    int zoff = ONE ? ((4 * kq) * CO + (col & ~1)) * 2 + ((lane & 1) ? CO * 2 : 0)
+                   : ((BIG ? 4 * kq : 4 * kq) * CO + col) * 4;     // byte offset of this lane's first row inside the workgroup's slab
     bool neg = false;
     if constexpr (POOL) neg = gamma[col] < 0.0f;
     const unsigned smask = neg ? 0x80000000u : 0u;
@@ -1283,7 +1309,11 @@ __global__ __launch_bounds__(CO > 128 ? 512 : 256) void fwd_chunk_kernel(PosOper
         int libest = 0;
 #pragma unroll
         for (int r = 0; r < NV; r += 2) {
-            if constexpr (STORE) {
+            if constexpr (STORE && ONE) {
+                const bool odd = lane & 1;
+                const float got = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(odd ? v[r] : v[r + 1]), 0xB1, 0xf, 0xf, true));   // lane ^ 1
+                __builtin_amdgcn_raw_buffer_store_b32(odd ? pack_bf16(got, v[r + 1]) : pack_bf16(v[r], got), zrsrc, zoff, rowc(r) * CO * 2, MP_STORE_AUX);
+            } else if constexpr (STORE) {
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[r]), zrsrc, zoff, rowc(r) * CO * 4, MP_STORE_AUX);
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[r + 1]), zrsrc, zoff, rowc(r + 1) * CO * 4, MP_STORE_AUX);
             }
@@ -1298,7 +1328,7 @@ __global__ __launch_bounds__(CO > 128 ? 512 : 256) void fwd_chunk_kernel(PosOper
                 }
             }
         }
-        zoff += DBK * CO * 4;
+        zoff += DBK * CO * ZB;
         s1 += (double)(c1.x + c1.y);
         s2 += (double)(c2.x + c2.y);
         if constexpr (POOL) {
@@ -1450,9 +1480,9 @@ __global__ __launch_bounds__(bwd_fused_threads(CO, CI, SPLIT, ONE), (CO >= 128 &
     auto gload = [&](int pk, RSet& rs) {
         if constexpr ((MP_BF_ABL >> 4) & 1) { if (pk != p0) return; }
 #pragma unroll
-        for (int ps = 0; ps < PA; ++ps) raw_load<MODE_DZ>(DZ, p1, pk + ka0 + ps * KA_STEP, ca, rs.a[ps]);
+        for (int ps = 0; ps < PA; ++ps) raw_load<MODE_DZ, ONE>(DZ, p1, pk + ka0 + ps * KA_STEP, ca, rs.a[ps]);
 #pragma unroll
-        for (int ps = 0; ps < PB; ++ps) raw_load<MODE_IN>(IN, p1, pk + kb0 + ps * KB_STEP, cb, rs.b[ps]);
+        for (int ps = 0; ps < PB; ++ps) raw_load<MODE_IN, ONE>(IN, p1, pk + kb0 + ps * KB_STEP, cb, rs.b[ps]);
     };
     auto sstore = [&](int buf, RSet& rs) {
         auto& ra = rs.a;
@@ -1545,8 +1575,11 @@ __global__ __launch_bounds__(bwd_fused_threads(CO, CI, SPLIT, ONE), (CO >= 128 &
         sx2[h] = f2_{0.0f, 0.0f};
     }
     // G_{l-1} rows of this workgroup through a buffer resource: lane part of the offset in one VGPR, row part as immediates
-    const __amdgpu_buffer_rsrc_t grsrc = __builtin_amdgcn_make_buffer_rsrc(G + (size_t)p0 * CI, 0, (p1 - p0) * CI * 4, 0x00020000);
-    int goff = ((xrow0 + 4 * (lane >> 4)) * CI + ecol0 + (lane & 15)) * 4;
+    // ONE: G_{l-1} is STORED as bf16 (see fwd_chunk_kernel: a lane pair exchanges one value per row pair, one dword store per lane)
+    constexpr int GB = ONE ? 2 : 4;
+    const __amdgpu_buffer_rsrc_t grsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(G) + (size_t)p0 * CI * GB, 0, (p1 - p0) * CI * GB, 0x00020000);
+    int goff = ONE ? ((xrow0 + 4 * (lane >> 4)) * CI + ecol0 + ((lane & 15) & ~1)) * 2 + ((lane & 1) ? CI * 2 : 0)
+                   : ((xrow0 + 4 * (lane >> 4)) * CI + ecol0 + (lane & 15)) * 4;
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     __shared__ f32x4 xbuf[KSPLIT ? NW : 1][64];      // KSPLIT: the partial of the tile the partner wave finalises
     f32x4 ax[HT];                                    // the finished dX tile(s) of this wave, between g_mfma and g_epi
@@ -1722,8 +1755,14 @@ __global__ __launch_bounds__(bwd_fused_threads(CO, CI, SPLIT, ONE), (CO >= 128 &
                 const float* zr = sZ[cur] + (xrow0 + 4 * kq) * CI + ecol0 + 16 * h + l15;
 #pragma unroll
                 for (int i = 0; i < 4; i += 2) {
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ax[h][i]), grsrc, goff + 16 * h * 4, i * CI * 4, MP_STORE_AUX);
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ax[h][i + 1]), grsrc, goff + 16 * h * 4, (i + 1) * CI * 4, MP_STORE_AUX);
+                    if constexpr (ONE) {
+                        const bool odd = lane & 1;
+                        const float got = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(odd ? ax[h][i] : ax[h][i + 1]), 0xB1, 0xf, 0xf, true));   // lane ^ 1
+                        __builtin_amdgcn_raw_buffer_store_b32(odd ? pack_bf16(got, ax[h][i + 1]) : pack_bf16(ax[h][i], got), grsrc, goff + 16 * h * 2, i * CI * 2, MP_STORE_AUX);
+                    } else {
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ax[h][i]), grsrc, goff + 16 * h * 4, i * CI * 4, MP_STORE_AUX);
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ax[h][i + 1]), grsrc, goff + 16 * h * 4, (i + 1) * CI * 4, MP_STORE_AUX);
+                    }
                     const f2 zp = {zr[i * CI], zr[(i + 1) * CI]};
                     const f2 y = zp * f2{spx[h], spx[h]} + f2{tpx[h], tpx[h]};
                     const f2 dy = {y.x > 0.0f ? ax[h][i] : 0.0f, y.y > 0.0f ? ax[h][i + 1] : 0.0f};
@@ -1731,7 +1770,7 @@ __global__ __launch_bounds__(bwd_fused_threads(CO, CI, SPLIT, ONE), (CO >= 128 &
                     sx2[h] += dy * zp;
                 }
             }
-            goff += DBK * CI * 4;
+            goff += DBK * CI * GB;
         }
         };
         // (tried: the two halves of the workgroup walking the two products in opposite order, so that only four waves at a time
@@ -2438,8 +2477,8 @@ __global__ __launch_bounds__(512) void bwd_first_kernel(PosOperand DZ, PosOperan
 }
 
 template <int MODE_DZ, int MODE_IN>
-__global__ __launch_bounds__(256) void dw_ci4_kernel(PosOperand DZ, PosOperand IN, int P, int p_per_block, float* __restrict__ dW, int r16)
-{   // r16: the bf16 variant -- dZ and the input rows rounded to bf16 before the products
+__global__ __launch_bounds__(256) void dw_ci4_kernel(PosOperand DZ, PosOperand IN, int P, int p_per_block, float* __restrict__ dW, int r16, int h16)
+{   // r16: the bf16 variant -- dZ and the input rows rounded to bf16 before the products; h16: the dZ operand's Z / G stored as bf16
     __shared__ __attribute__((aligned(16))) float bn_lds[3 * 1024];          // (Co <= 1024: launch_dw's condition for this kernel)
     bn_prologue(DZ.bn, bn_lds, 1024, 0, DZ.C, blockIdx.x == 0);
     __shared__ float red[256][16 + 1];
@@ -2463,7 +2502,7 @@ __global__ __launch_bounds__(256) void dw_ci4_kernel(PosOperand DZ, PosOperand I
             Raw4<MODE_IN> rx[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {          // four positions in flight
-                raw_load<MODE_DZ>(DZ, p1, p + u * PL, 4 * q, rz[u]);
+                if (h16) raw_load<MODE_DZ, true>(DZ, p1, p + u * PL, 4 * q, rz[u]); else raw_load<MODE_DZ, false>(DZ, p1, p + u * PL, 4 * q, rz[u]);
                 raw_load<MODE_IN>(IN, p1, p + u * PL, 0, rx[u]);
             }
 #pragma unroll
@@ -2515,7 +2554,7 @@ int launch_dw(const PosOperand& DZ, const PosOperand& IN, int64_t P64, float* dW
         double fl = 2.0 * (double)P * Co * Ci, by = 4.0 * ((MODE_DZ == SRC_DZ ? 2.0 : 1.0) * (double)P * Co + (double)P * Ci);
         char tg[64];
         snprintf(tg, sizeof tg, "dw_ci4_kernel<%d, %d>", MODE_DZ, MODE_IN);
-        MP_LAUNCH(tg, fl, by, (dw_ci4_kernel<MODE_DZ, MODE_IN>), dim3((unsigned)((P + 1023) / 1024)), dim3(256), 0, stream, DZ, IN, P, 1024, dW, PREC == 1 ? 1 : 0);
+        MP_LAUNCH(tg, fl, by, (dw_ci4_kernel<MODE_DZ, MODE_IN>), dim3((unsigned)((P + 1023) / 1024)), dim3(256), 0, stream, DZ, IN, P, 1024, dW, PREC == 1 ? 1 : 0, 0);
         MP_CHECK_LAUNCH();
         return MP_OK;
     }
@@ -2896,6 +2935,29 @@ extern "C" int mp_sa_mlp_recompute_first(int n_layers, const int64_t* channels, 
     return channels[0] == 4 && channels[1] == 64 && (channels[2] == 64 || channels[2] == 128) && K > 0;
 }
 
+// bf16 variant (mp_sa_mlp_*_bf16 / _gather_bf16): does this chain keep its activations IN MEMORY as bf16?  Yes when every layer runs on
+// the position-stream kernels -- first layer recomputed (first_layer = 1) or factorised (2), every later layer 64 / 128 inputs into
+// 64 / 128 / 256 outputs with a fused pool -- which then read and write Z_l / G_l as bf16 (half the bytes of kernels that are HBM-bound on
+// them).  The caller allocates layers[l].z as bf16 [P, c_out] exactly when this returns 1.  Any other bf16 chain runs on the tiled
+// kernels with fp32 storage (a recomputed first layer is then not available: pass layers[0].z).
+static bool chain_store16(int n_layers, const int64_t* ch, int64_t K, int first)
+{
+    if ((first != 1 && first != 2) || n_layers < 2) return false;
+    if (!chunk_fwd_enabled() || !fused_bwd_enabled() || !(K == 32 || K == 64 || K == 128)) return false;
+    if (first == 1 && !mp_sa_mlp_recompute_first(n_layers, ch, K)) return false;
+    if (first == 2 && !(ch[0] == 4 && (ch[1] == 64 || ch[1] == 128 || ch[1] == 256))) return false;
+    for (int l = 1; l < n_layers; ++l) {
+        const int64_t Ci = ch[l], Co = ch[l + 1];
+        if (!(Ci == 64 || Ci == 128) || !(Co == 64 || Co == 128 || Co == 256)) return false;
+        if ((Co == 64 && Ci == 128) || (Co == 256 && Ci != 128)) return false;
+    }
+    return true;
+}
+extern "C" int mp_sa_mlp_bf16_storage(int n_layers, const int64_t* channels, int64_t K, int first_layer)
+{
+    return (channels && K > 0 && chain_store16(n_layers, channels, K, first_layer)) ? 1 : 0;
+}
+
 // The gathered-input form (mp_sa_mlp_{fwd,bwd}_gather_f32) covers what BASELINE's second set-abstraction level is: a first layer of
 // [128 features | xyz | pad] -> 128 behind at least one more layer, fp32 results, fused kernels enabled.
 // =================================================================================================================
@@ -2921,8 +2983,8 @@ template <int Q>   // Q = Co / 4: lanes per row
 __global__ __launch_bounds__(256) void first_factored_fwd_kernel(const float* __restrict__ A, const float* __restrict__ xyz,
                                                                  const float* __restrict__ new_xyz, const int64_t* __restrict__ idx,
                                                                  const float* __restrict__ Wx, int P, int K, int kshift, int N, int per,
-                                                                 int gshift, int ppb, float* __restrict__ Z0, BnOut partials, int r16)
-{   // r16: the bf16 variant -- W_x and the centred coordinates rounded to bf16 (A comes from rounded operands already)
+                                                                 int gshift, int ppb, float* __restrict__ Z0, BnOut partials, int r16, int h16)
+{   // r16: the bf16 variant -- W_x and the centred coordinates rounded to bf16 (A comes from rounded operands already); h16: Z_0 stored as bf16
     bn_zero(partials);
     constexpr int CO = 4 * Q, RW = 64 / Q, RB = 4 * RW, U = MP_FACT_U;      // rows per wave / per workgroup pass, passes in flight
     __shared__ float red[2][RB][CO];
@@ -2956,7 +3018,8 @@ __global__ __launch_bounds__(256) void first_factored_fwd_kernel(const float* __
                 z.y = a[u].y + __builtin_fmaf(w[1].z, dz[u], __builtin_fmaf(w[1].y, dy[u], w[1].x * dx[u]));
                 z.z = a[u].z + __builtin_fmaf(w[2].z, dz[u], __builtin_fmaf(w[2].y, dy[u], w[2].x * dx[u]));
                 z.w = a[u].w + __builtin_fmaf(w[3].z, dz[u], __builtin_fmaf(w[3].y, dy[u], w[3].x * dx[u]));
-                *reinterpret_cast<float4*>(Z0 + (size_t)pp * CO + 4 * ql) = z;
+                if (h16) st4h(Z0, (size_t)pp * CO + 4 * ql, z);
+                else *reinterpret_cast<float4*>(Z0 + (size_t)pp * CO + 4 * ql) = z;
                 s1.x += z.x; s1.y += z.y; s1.z += z.z; s1.w += z.w;
                 s2.x += z.x * z.x; s2.y += z.y * z.y; s2.z += z.z * z.z; s2.w += z.w * z.w;
             }
@@ -2981,7 +3044,7 @@ __global__ __launch_bounds__(256) void first_factored_fwd_kernel(const float* __
 template <int Q>
 __global__ __launch_bounds__(256) void first_factored_bwd_kernel(PosOperand DZ, const float* __restrict__ xyz, const float* __restrict__ new_xyz,
                                                                  const int64_t* __restrict__ idx, int P, int K, int kshift, int N, int per,
-                                                                 int gshift, int ppb, float* __restrict__ dz_out, float* __restrict__ dW, int r16)
+                                                                 int gshift, int ppb, float* __restrict__ dz_out, float* __restrict__ dW, int r16, int h16)
 {   // r16: the bf16 variant -- dZ_0 (as written out, too: its reduction over the gathering rows then sums rounded values) and the
     // centred coordinates rounded to bf16
     constexpr int CO = 4 * Q, RW = 64 / Q, RB = 4 * RW, U = MP_FACT_U;
@@ -3003,8 +3066,8 @@ __global__ __launch_bounds__(256) void first_factored_bwd_kernel(PosOperand DZ, 
             const unsigned b = gshift >= 0 ? (unsigned)pp >> gshift : (unsigned)pp / (unsigned)per;
             const unsigned grp = kshift >= 0 ? (unsigned)pp >> kshift : (unsigned)pp / (unsigned)K;
             const size_t src = (size_t)b * (unsigned)N + (size_t)idx[pp];
-            z[u] = ld4(DZ.x + (size_t)pp * CO + 4 * ql);
-            g[u] = ld4(DZ.g + (size_t)pp * CO + 4 * ql);
+            z[u] = ldz4(DZ.x, (size_t)pp * CO + 4 * ql, h16);
+            g[u] = ldz4(DZ.g, (size_t)pp * CO + 4 * ql, h16);
             const float* x = xyz + src * 3;
             const float* c = new_xyz + (size_t)grp * 3;
             dx[u] = rb16(x[0] - c[0], r16); dy[u] = rb16(x[1] - c[1], r16); dzc[u] = rb16(x[2] - c[2], r16);
@@ -3086,7 +3149,7 @@ __global__ __launch_bounds__(1024) void csr_rows_kernel(const int64_t* __restric
 template <int Q>
 __global__ __launch_bounds__(256) void first_factored_reduce_kernel(PosOperand DZ, const int* __restrict__ order, const int* __restrict__ pts,
                                                                     const float* __restrict__ xyz, const float* __restrict__ new_xyz, int N, int M,
-                                                                    int K, int kshift, int chunk, float* __restrict__ dA, float* __restrict__ dW, int r16)
+                                                                    int K, int kshift, int chunk, float* __restrict__ dA, float* __restrict__ dW, int r16, int h16)
 {   // r16: see first_factored_bwd_kernel
 #ifndef MP_FACT_RU
 #define MP_FACT_RU 4
@@ -3133,8 +3196,8 @@ __global__ __launch_bounds__(256) void first_factored_reduce_kernel(PosOperand D
             nm[u] = bo[jn];
             npt[u] = bp[jn];
             const size_t row = (size_t)b * M + m;
-            z[u] = ld4(DZ.x + row * CO + 4 * ql);
-            g[u] = ld4(DZ.g + row * CO + 4 * ql);
+            z[u] = ldz4(DZ.x, row * CO + 4 * ql, h16);
+            g[u] = ldz4(DZ.g, row * CO + 4 * ql, h16);
             const unsigned grp = (unsigned)b * (unsigned)S + (kshift >= 0 ? (unsigned)m >> kshift : (unsigned)m / (unsigned)K);
             const float* x = xyz + ((size_t)b * N + pt[u]) * 3;
             const float* c = new_xyz + (size_t)grp * 3;
@@ -3222,6 +3285,11 @@ static int sa_mlp_fwd(const float* x0, int64_t P, int64_t K, int n_layers, const
     // layers[0].z == NULL: the caller asks for the first layer to be recomputed instead of stored (mp_sa_mlp_recompute_first)
     const bool rc_first = layers[0].z == nullptr;
     if (rc_first && !mp_sa_mlp_recompute_first(n_layers, ch, K)) return MP_EINVAL;      // (bf16: x0 and layers[0].weight come pre-rounded)
+    // bf16: activations stored as bf16 iff the whole chain runs on the position-stream kernels (mp_sa_mlp_bf16_storage); otherwise the
+    // bf16 contractions of every layer behind the first run on the tiled kernels with fp32 storage
+    const bool store16 = bf16 && chain_store16(n_layers, ch, K, rc_first ? 1 : (factored ? 2 : 0));
+    const bool stream_ok = !bf16 || store16;
+    if (bf16 && rc_first && !store16) return MP_EINVAL;
     if (n_layers > 1 && layers[n_layers - 1].z == nullptr) return MP_EINVAL;
     hipStream_t stream = mp_stream(stream_);
     // consumer-side BatchNorm finalize (bn_prologue): train mode, per-replica statistics, every layer with its persistent state
@@ -3298,7 +3366,7 @@ static int sa_mlp_fwd(const float* x0, int64_t P, int64_t K, int n_layers, const
 #define MP_FACT(Q_)                                                                                                              \
     MP_LAUNCH("first_factored_fwd_kernel", 8.0 * (double)P * Co_, by, (first_factored_fwd_kernel<Q_>), dim3((unsigned)nblk), dim3(256), 0,   \
               stream, gather->feats, gather->xyz, gather->new_xyz, gather->idx, L.weight, (int)P, (int)K, log2_or_neg(K), (int)gather->N, per, \
-              log2_or_neg(per), ppb, L.z, partials, (int)bf16)
+              log2_or_neg(per), ppb, L.z, partials, (int)bf16, (int)store16)
             if (Co_ == 64) MP_FACT(16); else if (Co_ == 128) MP_FACT(32); else MP_FACT(64);
 #undef MP_FACT
             MP_CHECK_LAUNCH();
@@ -3344,7 +3412,7 @@ static int sa_mlp_fwd(const float* x0, int64_t P, int64_t K, int n_layers, const
                 MP_LAUNCH(tg, fl, by, (fwd_chunk_kernel<64, 128, false, SRC_ACT_RC>), dim3(gx), dim3(256), 0, stream, A, (int)P, ppb, L.weight, L.z, partials, po, L.gamma);
             MP_CHECK_LAUNCH();
             nblk = (int)gx;
-        } else if (l > 0 && (Ci_ == 64 || Ci_ == 128) && (Co_ == 64 || Co_ == 128 || Co_ == 256) && (P % K) == 0 && (1024 % K == 0 || !fuse_pool) &&
+        } else if (l > 0 && stream_ok && (Ci_ == 64 || Ci_ == 128) && (Co_ == 64 || Co_ == 128 || Co_ == 256) && (P % K) == 0 && (1024 % K == 0 || !fuse_pool) &&
             chunk_fwd_enabled() && !(fuse_pool && (K % 32) != 0) && !(bf16 && Co_ == 64 && Ci_ == 128)) {
             (void)last_unfused;
             int ppb = 1024;
@@ -3525,6 +3593,9 @@ static int sa_mlp_bwd(const float* x0, int64_t P, int64_t K, int n_layers, const
     if (workspace_bytes < mp_sa_mlp_workspace_bytes(P, K, n_layers, ch, 1)) return MP_EWORKSPACE;
     const bool rc_first = layers[0].z == nullptr;   // the forward pass did not store Z_0 (mp_sa_mlp_recompute_first)
     if (rc_first && (grad_x0 || !mp_sa_mlp_recompute_first(n_layers, ch, K))) return MP_EINVAL;
+    const bool store16 = bf16 && chain_store16(n_layers, ch, K, rc_first ? 1 : (factored ? 2 : 0));     // (as in the forward pass)
+    const bool stream_ok = !bf16 || store16;
+    if (bf16 && rc_first && !store16) return MP_EINVAL;
     for (int l = 1; l < n_layers; ++l)
         if (!layers[l].z) return MP_EINVAL;
     hipStream_t stream = mp_stream(stream_);
@@ -3648,7 +3719,7 @@ static int sa_mlp_bwd(const float* x0, int64_t P, int64_t K, int n_layers, const
 
         // dW_l = dZ_l^T * act(Z_{l-1})
         if (!dw_joint && !mp::zero_async(grads[l].d_weight, (size_t)Co * Ci, stream)) return MP_ELAUNCH;
-        if (l > 0 && (Ci == 64 || Ci == 128) && (Co == 64 || Co == 128 || (Co == 256 && Ci == 128)) && fused_bwd_enabled() && !(bf16 && Co == 64 && Ci == 128)) {
+        if (l > 0 && stream_ok && (Ci == 64 || Ci == 128) && (Co == 64 || Co == 128 || (Co == 256 && Ci == 128)) && fused_bwd_enabled() && !(bf16 && Co == 64 && Ci == 128)) {
             // single-tile layer: dX, dW and the BatchNorm-backward sums of layer l-1 in one pass over dZ_l (bwd_fused_kernel)
             const mp_mlp_layer_t& Pv = layers[l - 1];
             float* Gn = gbuf[l & 1];
@@ -3753,7 +3824,7 @@ static int sa_mlp_bwd(const float* x0, int64_t P, int64_t K, int n_layers, const
                 const unsigned gxr = (unsigned)((M + 4 * chunk - 1) / (4 * chunk));
 #define MP_FACT_R(Q_)                                                                                                            \
     MP_LAUNCH("first_factored_reduce_kernel", fl, by, (first_factored_reduce_kernel<Q_>), dim3(gxr, (unsigned)Bc), dim3(256), 0, stream, DZ, order, pts, \
-              gather->xyz, gather->new_xyz, Np, M, (int)K, log2_or_neg(K), chunk, grad_x0, grads[l].d_weight, (int)bf16)
+              gather->xyz, gather->new_xyz, Np, M, (int)K, log2_or_neg(K), chunk, grad_x0, grads[l].d_weight, (int)bf16, (int)store16)
                 if (Co == 64) MP_FACT_R(16); else if (Co == 128) MP_FACT_R(32); else MP_FACT_R(64);
 #undef MP_FACT_R
                 MP_CHECK_LAUNCH();
@@ -3763,7 +3834,7 @@ static int sa_mlp_bwd(const float* x0, int64_t P, int64_t K, int n_layers, const
             const unsigned gxf = (unsigned)((P + ppb - 1) / ppb);
 #define MP_FACT_B(Q_)                                                                                                            \
     MP_LAUNCH("first_factored_bwd_kernel", fl, by + 4.0 * (double)P * Co, (first_factored_bwd_kernel<Q_>), dim3(gxf), dim3(256), 0, stream, DZ, gather->xyz, \
-              gather->new_xyz, gather->idx, (int)P, (int)K, log2_or_neg(K), (int)gather->N, per, log2_or_neg(per), ppb, grad_x0, grads[l].d_weight, (int)bf16)
+              gather->new_xyz, gather->idx, (int)P, (int)K, log2_or_neg(K), (int)gather->N, per, log2_or_neg(per), ppb, grad_x0, grads[l].d_weight, (int)bf16, (int)store16)
             if (Co == 64) MP_FACT_B(16); else if (Co == 128) MP_FACT_B(32); else MP_FACT_B(64);
 #undef MP_FACT_B
             MP_CHECK_LAUNCH();
@@ -3772,7 +3843,7 @@ static int sa_mlp_bwd(const float* x0, int64_t P, int64_t K, int n_layers, const
         if (rc_first && l == 0) {
             const double fl = 2.0 * (double)P * Co * Ci, by = 4.0 * ((double)P * Co + 2.0 * (double)P * Ci);
             MP_LAUNCH("dw_ci4_kernel<5, 0>", fl, by, (dw_ci4_kernel<SRC_DZ_RC, SRC_ID>), dim3((unsigned)((P + 1023) / 1024)), dim3(256), 0, stream, DZ, IN,
-                      (int)P, 1024, grads[l].d_weight, (int)bf16);
+                      (int)P, 1024, grads[l].d_weight, (int)bf16, (int)store16);
             MP_CHECK_LAUNCH();
             continue;
         }

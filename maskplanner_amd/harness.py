@@ -56,8 +56,8 @@ class TrainStep:
         # query on a second stream underneath its own work (_launch_sampling / _hand_over).
         if overlap_sampling is None:
             overlap_sampling = os.environ.get("MASKPLANNER_OVERLAP_SAMPLING", "1") != "0"
-        # (the pipelined plan holds one ball query per level: the multi-radius encoder samples in line)
-        self.overlap = bool(overlap_sampling) and fused and not prefetch_sampling and encoder == "ssg"
+        # ([r4] the plan of a multi-scale level holds one ball query per radius: both encoders sample on the side stream)
+        self.overlap = bool(overlap_sampling) and fused and not prefetch_sampling
         self._plan_next, self._plan_cur, self._plan_stream, self._plan_ev = None, None, None, None
         # Deferred head optimizer (see _record_split): the step is recorded as TWO graphs, encoder forward | everything else, and
         # the factor Adam of the seven head matrices (0.97 GB of HBM traffic, bandwidth-bound) is launched eagerly on its own
@@ -136,7 +136,9 @@ class TrainStep:
     def _encode(self):
         # sa1's start is consumed only when its sampling was not prefetched; sa2's always
         sa1 = self.model.sa1
-        ready = (self.prefetch or self.overlap) and pu.has_prefetched(self.batch["point_cloud"], sa1.npoint, sa1.radius, sa1.nsample)
+        _, r1, k1 = self._level_spec(sa1)
+        multi = hasattr(sa1, "radius_list")
+        ready = (self.prefetch or self.overlap) and pu.has_prefetched(self.batch["point_cloud"], sa1.npoint, r1 if multi else r1[0], k1 if multi else k1[0])
         starts = self.batch["fps_start"][1:] if ready else self.batch["fps_start"]
         if ready and self.overlap:
             starts = self.batch["fps_start"][len(self._plan_levels()):]   # every sampling level comes from the plan
@@ -465,33 +467,48 @@ class TrainStep:
         """The sampling levels of the encoder (set abstractions that are not group_all), in order."""
         return [m for m in (self.model.sa1, self.model.sa2, self.model.sa3) if not getattr(m, "group_all", False)]
 
+    @staticmethod
+    def _level_spec(m):
+        """(npoint, radii, group sizes) of a sampling level: one ball query for a single-scale level, one per radius for a multi-scale one."""
+        if hasattr(m, "radius_list"):
+            return m.npoint, list(m.radius_list), list(m.nsample_list)
+        return m.npoint, [m.radius], [m.nsample]
+
     def _plan_size(self):
         B, n = self.batch["point_cloud"].shape[0], 0
         for m in self._plan_levels():
-            n += B * m.npoint + (B * m.npoint * 3 + 1) // 2 + B * m.npoint * m.nsample
+            S, _, Ks = self._level_spec(m)
+            n += B * S + (B * S * 3 + 1) // 2 + sum(B * S * K for K in Ks)
         return n
 
     def _plan_views(self, buf):
-        """Per level (fps_idx i64 [B,S], new_xyz f32 [B,S,3], idx i64 [B,S,K]) as views of one flat int64 buffer."""
+        """Per level (fps_idx i64 [B,S], new_xyz f32 [B,S,3], [idx i64 [B,S,K] per radius]) as views of one flat int64 buffer."""
         B, o, out = self.batch["point_cloud"].shape[0], 0, []
         for m in self._plan_levels():
-            S, K = m.npoint, m.nsample
-            n0, n1, n2 = B * S, (B * S * 3 + 1) // 2, B * S * K
-            out.append((buf[o:o + n0].view(B, S), buf[o + n0:o + n0 + n1].view(torch.float32)[:B * S * 3].view(B, S, 3),
-                        buf[o + n0 + n1:o + n0 + n1 + n2].view(B, S, K)))
-            o += n0 + n1 + n2
+            S, _, Ks = self._level_spec(m)
+            n0, n1 = B * S, (B * S * 3 + 1) // 2
+            fps_idx = buf[o:o + n0].view(B, S)
+            new_xyz = buf[o + n0:o + n0 + n1].view(torch.float32)[:B * S * 3].view(B, S, 3)
+            o += n0 + n1
+            idxs = []
+            for K in Ks:
+                idxs.append(buf[o:o + B * S * K].view(B, S, K))
+                o += B * S * K
+            out.append((fps_idx, new_xyz, idxs))
         return out
 
     def _sample_levels(self, buf, xyz=None, starts=None):
-        """FPS + ball query of every level: each level samples the previous level's centroids, nothing else -- the whole
+        """FPS + ball queries of every level: each level samples the previous level's centroids, nothing else -- the whole
         plan depends on the input cloud only."""
         from . import ops
         xyz = self.batch["point_cloud"] if xyz is None else xyz
         starts = self.batch["fps_start"] if starts is None else starts
-        for m, start, (fps_idx, new_xyz, idx) in zip(self._plan_levels(), starts, self._plan_views(buf)):
+        for m, start, (fps_idx, new_xyz, idxs) in zip(self._plan_levels(), starts, self._plan_views(buf)):
+            _, radii, Ks = self._level_spec(m)
             start = torch.as_tensor(start, dtype=torch.long).to(xyz.device)
             ops.fps(xyz, m.npoint, start, out=(fps_idx, new_xyz))
-            ops.ball_query(m.radius, m.nsample, xyz, new_xyz, out=idx)
+            for r, K, idx in zip(radii, Ks, idxs):
+                ops.ball_query(r, K, xyz, new_xyz, out=idx)
             xyz = new_xyz
 
     # Pipelined sampling, the protocol (the same for eager and replayed steps):
@@ -557,9 +574,12 @@ class TrainStep:
                 if self._plan_mid:
                     self._hand_over_copies()
             xyz = self.batch["point_cloud"]
-            for m, plan in zip(self._plan_levels(), self._plan_views(self._plan_cur)):
-                pu.supply_sampling(xyz, m.npoint, m.radius, m.nsample, plan)
-                xyz = plan[1]    # the next level's cloud IS this level's centroid tensor (same storage: the lookup key)
+            for m, (fps_idx, new_xyz, idxs) in zip(self._plan_levels(), self._plan_views(self._plan_cur)):
+                if hasattr(m, "radius_list"):
+                    pu.supply_sampling(xyz, m.npoint, m.radius_list, m.nsample_list, (fps_idx, new_xyz, tuple(idxs)))
+                else:
+                    pu.supply_sampling(xyz, m.npoint, m.radius, m.nsample, (fps_idx, new_xyz, idxs[0]))
+                xyz = new_xyz    # the next level's cloud IS this level's centroid tensor (same storage: the lookup key)
 
     def _eager_step(self, hand_over=True):
         try:

@@ -86,10 +86,18 @@ def prefetch_sampling(xyz, npoint, radius, nsample, fps_start):
     _prefetched.setdefault((xyz.data_ptr(), npoint, float(radius), nsample), []).append((ev, fps_idx, new_xyz, idx))
 
 
+def _plan_key(xyz, npoint, radius, nsample):
+    """Plans are keyed by the cloud's storage and the sampling parameters; a multi-scale level has a tuple of radii / group sizes."""
+    r = tuple(float(x) for x in radius) if isinstance(radius, (list, tuple)) else float(radius)
+    k = tuple(int(x) for x in nsample) if isinstance(nsample, (list, tuple)) else nsample
+    return (xyz.data_ptr(), npoint, r, k)
+
+
 def supply_sampling(xyz, npoint, radius, nsample, plan):
     """Hand sample_and_group() a finished first-level sampling (fps_idx, new_xyz, idx) of `xyz`, already ordered on the
-    current stream (the pipelined step of harness.TrainStep: the plan was computed during the previous step)."""
-    _prefetched.setdefault((xyz.data_ptr(), npoint, float(radius), nsample), []).append((None,) + tuple(plan))
+    current stream (the pipelined step of harness.TrainStep: the plan was computed during the previous step).  A multi-scale
+    level (radius / nsample: the lists of PointNetSetAbstractionMsg) takes idx as a tuple, one ball query per radius."""
+    _prefetched.setdefault(_plan_key(xyz, npoint, radius, nsample), []).append((None,) + tuple(plan))
 
 
 def clear_prefetched():
@@ -99,11 +107,11 @@ def clear_prefetched():
 
 
 def has_prefetched(xyz, npoint, radius, nsample):
-    return bool(_prefetched.get((xyz.data_ptr(), npoint, float(radius), nsample)))
+    return bool(_prefetched.get(_plan_key(xyz, npoint, radius, nsample)))
 
 
 def _take_prefetched(xyz, npoint, radius, nsample):
-    key = (xyz.data_ptr(), npoint, float(radius), nsample)
+    key = _plan_key(xyz, npoint, radius, nsample)
     q = _prefetched.get(key)
     if not q:
         return None
@@ -277,10 +285,15 @@ class PointNetSetAbstractionMsg(nn.Module):
         xyz = _points_major(xyz)
         points = None if points is None else _points_major(points)
         B, N, _ = xyz.shape
-        _, new_xyz = ops.fps(xyz, self.npoint, _draw_fps_start(B, N, xyz.device), return_xyz=True)
+        plan = _take_prefetched(xyz, self.npoint, self.radius_list, self.nsample_list) if _prefetched else None
+        if plan is not None:        # (fps_idx, new_xyz, (idx per radius)): sampled ahead on a side stream (harness.TrainStep)
+            _, new_xyz, idxs = plan
+        else:
+            _, new_xyz = ops.fps(xyz, self.npoint, _draw_fps_start(B, N, xyz.device), return_xyz=True)
+            idxs = None
         outs = []
-        for radius, K, convs, bns in zip(self.radius_list, self.nsample_list, self.conv_blocks, self.bn_blocks):
-            idx = ops.ball_query(radius, K, xyz, new_xyz)
+        for si, (radius, K, convs, bns) in enumerate(zip(self.radius_list, self.nsample_list, self.conv_blocks, self.bn_blocks)):
+            idx = idxs[si] if idxs is not None else ops.ball_query(radius, K, xyz, new_xyz)
             if (points is not None and sa_mlp.FACTORED_FIRST in ("1", "msg", True)
                     and sa_mlp.factored_supported(points, K, convs, bns, self.mlp_dtype, self.sync_bn)):
                 # first layer factorised (features: a linear map per source point; then a gather-add): no grouped tensor

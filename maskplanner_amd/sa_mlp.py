@@ -81,6 +81,11 @@ class _SharedMLPMax(torch.autograd.Function):
         # first layer of a level fed by bare coordinates (4 input channels): Z_0 is recomputed by its consumers instead of being
         # written once and read three times (sa_mlp.hip, SRC_*_RC) -- no buffer for it at all
         recompute_first = (not x.requires_grad) and bool(lib.mp_sa_mlp_recompute_first(n_layers, ch, K))
+        # bf16 variant: chains that run entirely on the position-stream kernels keep Z_l in memory as bf16 (mp_sa_mlp_bf16_storage);
+        # the others keep fp32 storage and store their first layer
+        store16 = bool(bf16) and recompute_first and bool(lib.mp_sa_mlp_bf16_storage(n_layers, ch, K, 1))
+        if bf16 and not store16:
+            recompute_first = False
         if bf16 and recompute_first:
             # the recomputed first layer of the bf16 variant is an exact product of ROUNDED operands: the kernels get x and W_0 as
             # bf16 values (in fp32 storage); the gradient still goes to the unrounded parameter
@@ -90,7 +95,7 @@ class _SharedMLPMax(torch.autograd.Function):
             w, b, gam, bet, rm, rv = params[6 * l:6 * l + 6]
             co, ci = w.shape
             skip_z = l == 0 and recompute_first
-            z = None if skip_z else torch.empty((P, co), dtype=torch.float32, device=dev)
+            z = None if skip_z else torch.empty((P, co), dtype=torch.bfloat16 if store16 else torch.float32, device=dev)
             stats = torch.empty((4, co), dtype=torch.float32, device=dev)  # mean, rstd, scale, shift
             st = states[l] if states is not None else None
             keep.append((w, b, gam, bet, rm, rv, z, stats, st))
@@ -184,10 +189,11 @@ class _SharedMLPMaxFactored(torch.autograd.Function):
         lib = _lib.load()
         ch_ = (ctypes.c_int64 * len(chans))(*chans)
         sync = sync_group is not False and training      # global-batch BatchNorm statistics (sync_bn.py), as in _SharedMLPMax
+        store16 = bool(bf16) and bool(lib.mp_sa_mlp_bf16_storage(n_layers, ch_, K, 2))       # (see _SharedMLPMax)
         for l in range(n_layers):
             w, b, gam, bet, rm, rv = params[6 * l:6 * l + 6]
             co, ci = w.shape
-            z = torch.empty((P, co), dtype=torch.float32, device=dev)
+            z = torch.empty((P, co), dtype=torch.bfloat16 if store16 else torch.float32, device=dev)
             stats = torch.empty((4, co), dtype=torch.float32, device=dev)
             st = states[l] if states is not None else None
             keep.append((w, b, gam, bet, rm, rv, z, stats, st))

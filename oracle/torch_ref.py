@@ -27,9 +27,10 @@ BN_MOMENTUM = 0.1
 # ------------------------------------------------------------------------------------------------
 # set abstraction  (models/pointnet2_utils.py:112-216)
 # ------------------------------------------------------------------------------------------------
-def _bn_train(z, gamma, beta, running=None):
+def _bn_train(z, gamma, beta, running=None, stored=None):
     """BatchNorm (training mode) over all axes but the last; biased var for normalisation,
-    unbiased var for the running estimate (torch.nn.BatchNorm2d semantics)."""
+    unbiased var for the running estimate (torch.nn.BatchNorm2d semantics).
+    stored: the value that is normalised when it differs from the one the statistics are taken from (bf16 activation storage)."""
     red = tuple(range(z.ndim - 1))
     mean = z.mean(red)
     var = z.var(red, unbiased=False)
@@ -39,7 +40,7 @@ def _bn_train(z, gamma, beta, running=None):
         with torch.no_grad():
             rm.mul_(1 - BN_MOMENTUM).add_(BN_MOMENTUM * mean)
             rv.mul_(1 - BN_MOMENTUM).add_(BN_MOMENTUM * var * n / max(n - 1, 1))
-    return (z - mean) / torch.sqrt(var + BN_EPS) * gamma + beta
+    return ((z if stored is None else stored) - mean) / torch.sqrt(var + BN_EPS) * gamma + beta
 
 
 def _bn_eval(z, gamma, beta, rm, rv):
@@ -70,7 +71,48 @@ class _Bf16Matmul(torch.autograd.Function):
         return ga, gw
 
 
-def shared_mlp_max(x, layers, train, bf16=False, route=None, argmax_out=None, relu_masks=None):
+class _StoreRound(torch.autograd.Function):
+    """The bf16 variant's ACTIVATION STORAGE (csrc/sa_mlp.hip: chain_store16): an interior layer's raw activation lives in memory as
+    bf16 -- the next layer (and the backward pass) see the rounded value; the gradient passes straight through."""
+
+    @staticmethod
+    def forward(ctx, z):
+        return _r16(z)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+class _GradRound(torch.autograd.Function):
+    """... and the gradient with respect to a layer's input is stored as bf16 too."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _r16(g)
+
+
+def bf16_storage(first_kind, widths, K):
+    """oracle twin of mp_sa_mlp_bf16_storage: first_kind 1 = first layer fed by bare coordinates (recomputed by the kernels), 2 = fed by
+    coordinates + features (factorised); widths = the layers' output widths (an interior width in (64, 128) is carried as 128)."""
+    w = [128 if (64 < c < 128 and i < len(widths) - 1) else c for i, c in enumerate(widths)]
+    if len(w) < 2 or K not in (32, 64, 128):
+        return False
+    if first_kind == 1 and not (len(w) >= 3 and w[0] == 64 and w[1] in (64, 128)):
+        return False
+    if first_kind == 2 and w[0] not in (64, 128, 256):
+        return False
+    for ci, co in zip(w[:-1], w[1:]):
+        if ci not in (64, 128) or co not in (64, 128, 256) or (co == 64 and ci == 128) or (co == 256 and ci != 128):
+            return False
+    return first_kind in (1, 2)
+
+
+def shared_mlp_max(x, layers, train, bf16=False, route=None, argmax_out=None, relu_masks=None, store16=False):
     """x [B,S,K,Cin] -> [B,S,Cout]: (1x1 conv, BN, ReLU) x len(layers), then max over K.
     layers: list of dict(weight[Co,Ci], bias[Co], gamma, beta, running_mean, running_var).
     bf16: the contraction of every layer with bf16-rounded operands (_Bf16Matmul); everything else fp32.
@@ -80,13 +122,22 @@ def shared_mlp_max(x, layers, train, bf16=False, route=None, argmax_out=None, re
     from the implementation under test, the gradients are comparable at rounding level).  argmax_out (list): receives this
     evaluation's own arg-max [B,S,Cout], for counting the (group, channel) pairs the two implementations route differently.
     relu_masks: per layer a bool tensor [B,S,K,Co] -- the ReLU of that layer as `z * mask` with the mask of the other implementation
-    (an activation within rounding of 0 is as much a discrete decision as an arg-max)."""
+    (an activation within rounding of 0 is as much a discrete decision as an arg-max).
+    store16 (with bf16; 1: first layer recomputed, 2: first layer factorised -- bf16_storage()'s first_kind): the chain keeps its activations in memory as bf16 -- BatchNorm statistics from the unrounded z, the normalised
+    value (and everything downstream) from the rounded one; the pooled output of the LAST layer comes from the unrounded accumulators;
+    gradients with respect to the interior activations rounded likewise."""
     for li, L in enumerate(layers):
-        z = (_Bf16Matmul.apply(x, L["weight"]) if bf16 else x @ L["weight"].t()) + L["bias"]
+        if store16 and bf16 and li > 0:
+            x = _GradRound.apply(x)
+        z0 = _Bf16Matmul.apply(x, L["weight"]) if bf16 else x @ L["weight"].t()
+        z = z0 + L["bias"]
+        # what is stored is the BIAS-FREE product (the conv bias is folded into the BatchNorm shift);
+        # store16 == 1: the first layer is RECOMPUTED by its consumers from the input rows -- never stored, never rounded
+        zs = (_StoreRound.apply(z0) + L["bias"]) if (store16 and bf16 and li < len(layers) - 1 and not (li == 0 and store16 == 1)) else None
         if train:
-            z = _bn_train(z, L["gamma"], L["beta"], (L["running_mean"], L["running_var"]))
+            z = _bn_train(z, L["gamma"], L["beta"], (L["running_mean"], L["running_var"]), stored=zs)
         else:
-            z = _bn_eval(z, L["gamma"], L["beta"], L["running_mean"], L["running_var"])
+            z = _bn_eval(z if zs is None else zs, L["gamma"], L["beta"], L["running_mean"], L["running_var"])
         x = torch.relu(z) if relu_masks is None else z * relu_masks[li].to(z.dtype)
     if argmax_out is not None:
         argmax_out.append(x.detach().max(dim=2)[1])
@@ -126,7 +177,9 @@ def set_abstraction(xyz, feats, layers, npoint, radius, nsample, fps_start, trai
     g = xyz[bidx, gidx] - new_xyz[:, :, None]
     if feats is not None:
         g = torch.cat([g, feats[bidx, gidx]], -1)  # xyz channels first (:138)
-    return new_xyz, shared_mlp_max(g, layers, train, bf16, route, argmax_out, relu_masks)
+    kind = 1 if feats is None else 2
+    st16 = kind if (bf16 and bf16_storage(kind, [L["weight"].shape[0] for L in layers], nsample)) else 0
+    return new_xyz, shared_mlp_max(g, layers, train, bf16, route, argmax_out, relu_masks, store16=st16)
 
 
 def set_abstraction_msg(xyz, feats, blocks, npoint, radii, nsamples, fps_start, train, bf16=False):
@@ -143,7 +196,9 @@ def set_abstraction_msg(xyz, feats, blocks, npoint, radii, nsamples, fps_start, 
         g = xyz[bidx, gidx] - new_xyz[:, :, None]
         if feats is not None:
             g = torch.cat([feats[bidx, gidx], g], -1)
-        outs.append(shared_mlp_max(g, layers, train, bf16))
+        kind = 1 if feats is None else 2
+        st16 = kind if (bf16 and bf16_storage(kind, [L["weight"].shape[0] for L in layers], K)) else 0
+        outs.append(shared_mlp_max(g, layers, train, bf16, store16=st16))
     return new_xyz, torch.cat(outs, -1)
 
 

@@ -2,7 +2,9 @@
 configs[4] (containers, N = 10240, MSG, bf16).
 
 Contract of the variant: both operands of every contraction are rounded to bf16 (nearest even) as they are staged, products and
-sums are fp32, everything else (stored activations, BatchNorm, ReLU, pooling, dW accumulation) is fp32.  Checks:
+sums are fp32, BatchNorm / ReLU / pooling / dW accumulation are fp32.  [r4] Chains that run entirely on the position-stream kernels
+(mp_sa_mlp_bf16_storage) also STORE their raw activations and activation gradients as bf16: the statistics are taken from the fp32
+accumulators, the stored value is the rounded one (oracle: torch_ref._StoreRound / _GradRound).  Checks:
 
   * layer by layer, on the kernel's OWN stored activations: Z_l == bf16(act(Z_{l-1})) . bf16(W_l)^T recomputed in fp32 torch
     from the bit-identical rounded operands  =>  1e-5 holds element-wise (accumulation order is the only difference);
@@ -83,18 +85,30 @@ def test_bf16_layers_are_exact_products_of_the_rounded_operands(B, S, K, cin, wi
     out = sa_mlp.shared_mlp_max(x, convs, bns, dtype="bf16")
     keep = out.grad_fn.next_functions[0][0].keep                      # per layer: (w, b, gamma, beta, rm, rv, z, stats[mean, rstd, scale, shift])
     a = torch.nn.functional.pad(x.reshape(-1, cin), (0, (-cin) % 4))
+    store16 = False
     for l, (w, b, gam, bet, rm, rv, z, stats, _state) in enumerate(keep):
         want = r16(a) @ r16(w.detach().reshape(w.shape[0], -1)).t()          # fp32 sums of exact products
         if z is None:       # [r3] the recomputed first layer (4 input channels): never stored -- its consumers rebuild exactly these products
             assert l == 0 and a.shape[1] == 4
             z = want
-        err = float((z - want).abs().max())
-        assert err <= 1e-5 * max(1.0, float(want.abs().max())), (l, err)
+        if z.dtype == torch.bfloat16:
+            # [r4] bf16 activation storage: the stored value is the bf16 rounding of the fp32 sum -- identical to rounding torch's sum
+            # except where the two summation orders straddle a rounding boundary (one bf16 ulp, a few elements in 10^4)
+            store16 = True
+            z = z.float()
+            assert float((z - want).abs().max()) <= 2.0 ** -7 * max(1.0, float(want.abs().max())), l
+            assert float((z != r16(want)).float().mean()) < 2e-3, (l, float((z != r16(want)).float().mean()))
+        else:
+            err = float((z - want).abs().max())
+            assert err <= 1e-5 * max(1.0, float(want.abs().max())), (l, err)
         # BatchNorm folding of THIS layer, as the kernels apply it while staging: relu(z * scale + shift), mul and add rounded
         # separately -- bit-identical to what the next contraction rounded
         a = torch.relu(z * stats[2] + stats[3])
     pooled = a.view(B * S, K, -1).max(dim=1)[0].view(B, S, -1)
-    assert torch.equal(out, pooled)
+    if store16:      # the pooled output comes from the fp32 accumulators, `a` here from the stored (rounded) last activation
+        assert rel_l2(out, pooled) < 4e-3
+    else:
+        assert torch.equal(out, pooled)
 
 
 @pytest.mark.parametrize("B,S,K,cin,widths", CASES[:5])
@@ -111,14 +125,19 @@ def test_bf16_chain_forward_backward_vs_prerounded_oracle(B, S, K, cin, widths):
     out = sa_mlp.shared_mlp_max(xd, convs, bns, dtype="bf16")
     (out * gout.cuda()).sum().backward()
     xo = x.clone().requires_grad_(cin > 4)
-    ref = T.shared_mlp_max(xo, layers, True, bf16=True)
+    st16 = 1 if (cin <= 4 and T.bf16_storage(1, widths, K)) else 0
+    ref = T.shared_mlp_max(xo, layers, True, bf16=True, store16=st16)
     (ref * gout).sum().backward()
+    # reductions over all positions: 1e-3 with fp32 storage; with bf16 storage of Z_l / G_l every stored gradient element carries its own
+    # 2^-9 rounding and the backward pass uses the stored z where exact autograd of the oracle's expression uses the unrounded one: 3e-3
+    gtol = 3e-3 if st16 else 1e-3
     assert rel_l2(out, ref) < 2e-4 and outlier_share(out, ref, 1e-4) < 5e-3, (rel_l2(out, ref), outlier_share(out, ref, 1e-4))
     for i, (c, bn, L) in enumerate(zip(convs, bns, layers)):
         # reductions over all positions: single flipped roundings average out
         dw = c.weight.grad.reshape(c.out_channels, -1)
-        assert rel_l2(dw, L["weight"].grad) < 1e-3, (i, rel_l2(dw, L["weight"].grad))
-        assert rel_l2(bn.weight.grad, L["gamma"].grad) < 1e-3 and rel_l2(bn.bias.grad, L["beta"].grad) < 1e-3, i
+        assert rel_l2(dw, L["weight"].grad) < gtol, (i, rel_l2(dw, L["weight"].grad))
+        eg, eb = rel_l2(bn.weight.grad, L["gamma"].grad), rel_l2(bn.bias.grad, L["beta"].grad)
+        assert eg < (1e-2 if st16 else gtol) and eb < (1e-2 if st16 else gtol), (i, eg, eb)     # (sums of cancelling terms over bf16-stored gradients)
         np.testing.assert_allclose(bn.running_mean.cpu().numpy(), L["running_mean"].numpy(), rtol=1e-4, atol=1e-5)
         np.testing.assert_allclose(bn.running_var.cpu().numpy(), L["running_var"].numpy(), rtol=1e-4, atol=1e-5)
     if cin > 4:
@@ -221,3 +240,32 @@ def test_config5_training_step_runs_and_learns():
     ref = TrainStep("containers", B=8, N=10240, seed=5, encoder="msg", mlp_dtype="f32", graph=False)
     l0 = float(ref.step())
     assert abs(l0 - losses[0]) < 2e-2 * abs(l0), (l0, losses[0])
+
+
+def test_config5_at_bench_size_b32(oracle):
+    """BASELINE configs[4] at the size bench.py runs it (containers, N = 10240, B = 32, MSG encoder, bf16 grouped MLP with bf16 activation
+    storage): (a) the eval-mode encoder feature of the whole batch against the pre-rounded CPU oracle on a 4-cloud slice (eval-mode
+    BatchNorm: clouds are independent, so the slice is the same function), (b) 20 training steps through harness.TrainStep -- graph
+    replay, side-stream sampling plan of the multi-scale levels -- stay finite and reduce the loss."""
+    from maskplanner_amd import pointnet2_utils as pu
+    from maskplanner_amd.harness import TrainStep
+    from oracle import torch_ref as T
+    ts = TrainStep("containers", B=32, N=10240, seed=5, encoder="msg", mlp_dtype="bf16")
+    assert ts.overlap, "the multi-scale encoder samples on the side stream"
+    sd = {k: v.detach().cpu().clone() for k, v in ts.model.state_dict().items()}
+    batch = ts.batch
+    ts.model.eval()
+    with torch.no_grad(), pu.fps_start_override([s.clone() for s in batch["fps_start"]]):
+        feat = ts.model.encode(ts.point_cloud)
+    ts.model.train()
+    sl = slice(0, 4)
+    starts = [s[sl].cpu().numpy() for s in batch["fps_start"]]
+    with torch.no_grad():
+        o_feat = T.encoder_forward(sd, batch["point_cloud"][sl].cpu(), starts, False, "msg", True)
+    err = rel_l2(feat[sl], o_feat)
+    assert err < 2e-3, err            # bf16 operands AND bf16-stored activations on both sides; fp32 accumulation order differs
+    losses = [float(ts.step()) for _ in range(24)]
+    assert ts._graph is not None, "the step was not recorded"
+    assert np.isfinite(losses).all() and min(losses[-4:]) < losses[0], losses
+    for p in ts.model.parameters():
+        assert torch.isfinite(p).all()

@@ -744,9 +744,8 @@ def test_pipelined_first_level_sampling_changes_nothing_but_the_schedule():
     torch.cuda.synchronize()
     assert len(want) == 2
     for buf in (b._plan_cur, b._plan_next):
-        for got_l, want_l in zip(b._plan_views(buf), want):
-            for got, w in zip(got_l, want_l):
-                assert torch.equal(got, w)
+        for (g_fps, g_xyz, g_idxs), (w_fps, w_xyz, w_idx) in zip(b._plan_views(buf), want):
+            assert torch.equal(g_fps, w_fps) and torch.equal(g_xyz, w_xyz) and len(g_idxs) == 1 and torch.equal(g_idxs[0], w_idx)
     c = TrainStep("cuboids", B=4, N=1024, seed=7, graph=True, overlap_sampling=True)   # replay + eagerly launched pipeline
     lc = [float(c.step()) for _ in range(6)]
     assert c._graph is not None and lc[0] == la[0] and np.allclose(la[:3], lc[:3], rtol=1e-2) and np.allclose(la, lc, rtol=8e-2), (la, lc)
@@ -1250,7 +1249,7 @@ def test_streamed_batches_feed_the_step_what_the_collate_produces():
             want = pad_ragged([it[k] for it in items], fill, "cuda", total_needed=ts.batch[k].shape[1])
             assert torch.equal(ts.batch[k], want), (step, k)
         # the plan handed over with it (plan_cur) is the FPS / ball query of THAT cloud from the drawn starts: first index = the start
-        fps_idx, new_xyz, idx = ts._plan_views(ts._plan_cur)[0]
+        fps_idx, new_xyz, _ = ts._plan_views(ts._plan_cur)[0]
         redo = ops.fps(ts.batch["point_cloud"], 512, fps_idx[:, 0].contiguous())
         assert torch.equal(redo, fps_idx), step
     assert ts._graph is not None
