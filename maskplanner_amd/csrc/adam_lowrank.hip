@@ -39,15 +39,35 @@ __global__ __launch_bounds__(256) void adam_lowrank_kernel(float* __restrict__ p
         lr_c1 = (float)((double)lr / (1.0 - pow((double)beta1, st)));
         inv_sqrt_c2 = (float)(1.0 / sqrt(1.0 - pow((double)beta2, st)));
     }
-    __shared__ __attribute__((aligned(16))) float sg[AL_BC][AL_TO];
-    __shared__ __attribute__((aligned(16))) float sx[AL_BC][AL_TI];
+    // tile of the weight matrix per workgroup: 64 x 64 for the matrix-core rebuild (four 32 x 32 accumulators); [r4] 16 rows x 256 columns
+    // for the scalar rebuild -- a wave then streams 1 KB contiguous pieces of four rows of p, m and v instead of 256-byte pieces of
+    // sixteen (DRAM page locality: the kernel is a 24-byte-per-parameter stream and nothing else)
+    constexpr int TO = MFMA ? AL_TO : 16, TI = MFMA ? AL_TI : 256;
+    __shared__ __attribute__((aligned(16))) float sg[AL_BC][TO];
+    __shared__ __attribute__((aligned(16))) float sx[AL_BC][TI];
     const int tid = threadIdx.x;
-    const int to = tid >> 4, ti = tid & 15;
-    const int o0 = blockIdx.y * AL_TO, i0 = blockIdx.x * AL_TI;
+    const int to = MFMA ? (tid >> 4) : (tid >> 6), ti = MFMA ? (tid & 15) : (tid & 63);
+    const int o0 = blockIdx.y * TO, i0 = blockIdx.x * TI;
     const int lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
     const int wo = (wave >> 1) * 32, wi = (wave & 1) * 32;        // this wave's 32 x 32 sub-tile (MFMA form)
     float acc[4][4];
     f32x16 macc;
+    // [r4] the scalar-rebuild form streams 24 bytes per parameter and is bound by HBM latency x bytes in flight, not by the rebuild:
+    // the 12 float4 of (p, m, v) a thread updates are requested BEFORE the factor slabs are staged and multiplied (non-temporal: every
+    // byte is touched once per step), so that their latency runs under the rebuild instead of behind it
+    typedef float vf4 __attribute__((ext_vector_type(4)));          // (the non-temporal builtins take native vectors)
+    const bool fast = !MFMA && (I & 3) == 0 && i0 + ti * 4 + 3 < I;
+    vf4 p4[4], m4[4], v4[4];
+    if (fast) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int o = o0 + to * 4 + r;
+            const size_t off = (size_t)(o < O ? o : 0) * I + i0 + ti * 4;
+            p4[r] = __builtin_nontemporal_load(reinterpret_cast<const vf4*>(p + off));
+            m4[r] = __builtin_nontemporal_load(reinterpret_cast<const vf4*>(m + off));
+            v4[r] = __builtin_nontemporal_load(reinterpret_cast<const vf4*>(v + off));
+        }
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -57,22 +77,22 @@ __global__ __launch_bounds__(256) void adam_lowrank_kernel(float* __restrict__ p
 
     for (int b0 = 0; b0 < Bg; b0 += AL_BC) {
         __syncthreads();
-        // stage [AL_BC x 64] slabs of g and x (row-major in memory: coalesced along the 64 columns)
-        for (int e = tid; e < AL_BC * 16; e += 256) {
-            const int b = e >> 4, q = (e & 15) * 4;
-            float4 gv = make_float4(0.f, 0.f, 0.f, 0.f), xv = gv;
-            if (b0 + b < Bg) {
-                const float* gp = g + (size_t)(b0 + b) * O + o0 + q;
-                const float* xp = x + (size_t)(b0 + b) * I + i0 + q;
-                if (o0 + q + 3 < O && (O & 3) == 0) gv = *reinterpret_cast<const float4*>(gp);   // rows 16-B aligned
-                else if (o0 + q + 3 < O) { gv.x = gp[0]; gv.y = gp[1]; gv.z = gp[2]; gv.w = gp[3]; }
-                else { if (o0 + q < O) gv.x = gp[0]; if (o0 + q + 1 < O) gv.y = gp[1]; if (o0 + q + 2 < O) gv.z = gp[2]; }
-                if (i0 + q + 3 < I && (I & 3) == 0) xv = *reinterpret_cast<const float4*>(xp);
-                else if (i0 + q + 3 < I) { xv.x = xp[0]; xv.y = xp[1]; xv.z = xp[2]; xv.w = xp[3]; }
-                else { if (i0 + q < I) xv.x = xp[0]; if (i0 + q + 1 < I) xv.y = xp[1]; if (i0 + q + 2 < I) xv.z = xp[2]; }
-            }
-            *reinterpret_cast<float4*>(&sg[b][q]) = gv;
-            *reinterpret_cast<float4*>(&sx[b][q]) = xv;
+        // stage the [AL_BC x TO] slab of g and the [AL_BC x TI] slab of x (row-major in memory: coalesced along the columns)
+        auto ld_row4 = [](const float* base, int64_t row, int64_t ld, int col, int ncol) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            const float* q = base + (size_t)row * ld + col;
+            if (col + 3 < ncol && (ld & 3) == 0) v = *reinterpret_cast<const float4*>(q);   // rows 16-B aligned
+            else if (col + 3 < ncol) { v.x = q[0]; v.y = q[1]; v.z = q[2]; v.w = q[3]; }
+            else { if (col < ncol) v.x = q[0]; if (col + 1 < ncol) v.y = q[1]; if (col + 2 < ncol) v.z = q[2]; }
+            return v;
+        };
+        for (int e = tid; e < AL_BC * (TO / 4); e += 256) {
+            const int b = e / (TO / 4), q = (e % (TO / 4)) * 4;
+            *reinterpret_cast<float4*>(&sg[b][q]) = (b0 + b < Bg) ? ld_row4(g, b0 + b, O, o0 + q, O) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        for (int e = tid; e < AL_BC * (TI / 4); e += 256) {
+            const int b = e / (TI / 4), q = (e % (TI / 4)) * 4;
+            *reinterpret_cast<float4*>(&sx[b][q]) = (b0 + b < Bg) ? ld_row4(x, b0 + b, I, i0 + q, I) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
         __syncthreads();
         if constexpr (MFMA) {
@@ -121,16 +141,16 @@ __global__ __launch_bounds__(256) void adam_lowrank_kernel(float* __restrict__ p
         const int o = o0 + to * 4 + r;
         if (o >= O) continue;
         const size_t off = (size_t)o * I + i;
-        if (i + 3 < I && (I & 3) == 0) {   // whole float4 inside the row, rows 16-byte aligned
-            float4 p4 = *reinterpret_cast<float4*>(p + off), m4 = *reinterpret_cast<float4*>(m + off),
-                   v4 = *reinterpret_cast<float4*>(v + off);
-            upd(acc[r][0] * gscale, p4.x, m4.x, v4.x);
-            upd(acc[r][1] * gscale, p4.y, m4.y, v4.y);
-            upd(acc[r][2] * gscale, p4.z, m4.z, v4.z);
-            upd(acc[r][3] * gscale, p4.w, m4.w, v4.w);
-            *reinterpret_cast<float4*>(p + off) = p4;
-            *reinterpret_cast<float4*>(m + off) = m4;
-            *reinterpret_cast<float4*>(v + off) = v4;
+        if (fast) {   // whole float4 inside the row, rows 16-byte aligned: prefetched above
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float pp = p4[r][c], mm = m4[r][c], vv = v4[r][c];
+                upd(acc[r][c] * gscale, pp, mm, vv);
+                p4[r][c] = pp; m4[r][c] = mm; v4[r][c] = vv;
+            }
+            __builtin_nontemporal_store(p4[r], reinterpret_cast<vf4*>(p + off));
+            __builtin_nontemporal_store(m4[r], reinterpret_cast<vf4*>(m + off));
+            __builtin_nontemporal_store(v4[r], reinterpret_cast<vf4*>(v + off));
         } else {
 #pragma unroll
             for (int c = 0; c < 4; ++c)
@@ -261,9 +281,11 @@ extern "C" int mp_adam_lowrank_f32(float* param, float* exp_avg, float* exp_avg_
     if (!param || !exp_avg || !exp_avg_sq || (Bg > 0 && (!x || !g))) return MP_EINVAL;
     const double sh = step > 0 ? (double)step : 1.0;   // placeholders when the device-side count is used
     const double c1 = 1.0 - pow(beta1, sh), c2 = 1.0 - pow(beta2, sh);
-    const dim3 grid((unsigned)((I + AL_TI - 1) / AL_TI), (unsigned)((O + AL_TO - 1) / AL_TO));
+    const bool mfma_form = Bg > 32;
+    const int64_t TI = mfma_form ? AL_TI : 256, TO = mfma_form ? AL_TO : 16;       // (the kernel's tile: see adam_lowrank_kernel)
+    const dim3 grid((unsigned)((I + TI - 1) / TI), (unsigned)((O + TO - 1) / TO));
     // more factor rows than one GPU's batch (all-gathered factors of a data-parallel run): rebuild on the matrix cores
-    const bool mfma = Bg > 32;
+    const bool mfma = mfma_form;
     if (mfma)
         MP_LAUNCH("adam_lowrank_kernel<mfma>", 2.0 * (double)Bg * O * I, 24.0 * (double)O * I + 4.0 * Bg * (double)(O + I),
                   adam_lowrank_kernel<true>, grid, dim3(256), 0, mp_stream(stream_), param, exp_avg, exp_avg_sq, x, g, (int)Bg, (int)O,
