@@ -65,7 +65,6 @@ class TrainStep:
         # touch the head weights; the next step's second graph waits for it.
         self._graph_b, self._graph_b2, self._factor_args, self._adam_stream, self._adam_ev = None, None, None, None, None
         self._split_adam_wanted = os.environ.get("MASKPLANNER_SPLIT_ADAM", "1") != "0"
-        self._plan_mid = os.environ.get("MASKPLANNER_PLAN_AT", "start") == "mid"
         self._unit = torch.ones((), dtype=torch.float32, device=self.device)
         from . import ops as _ops
         self._zero_arena = _ops.ZeroArena(self.device) if self.device.type == "cuda" else None
@@ -188,20 +187,15 @@ class TrainStep:
         return loss
 
     def _step(self):
-        mid = self._plan_mid and self.overlap
-        if self.overlap and not mid:
+        if self.overlap:
             self._launch_sampling()          # the NEXT batch's plan, on the second stream underneath this step
         if self._graph is not None:
-            if mid:
-                self._wait_plan()            # A's first node is the hand-over copy
             self._graph.replay()
-            if mid:
-                self._launch_sampling()      # behind graph A (and its hand-over copy)
             if self._graph_b is not None:
                 if self._adam_ev is not None:
                     torch.cuda.current_stream().wait_event(self._adam_ev)   # the head weights of the previous step are final
                 self._replay_b()
-            elif self.overlap and not mid:
+            elif self.overlap:
                 self._hand_over()            # (single-graph step: the hand-over is not part of the recording)
             loss = self._graph_loss
             if self._guard_left > 0 and self.dp_graph:
@@ -234,20 +228,11 @@ class TrainStep:
         try:
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            mid = self._plan_mid and self.overlap
-            if mid:
-                if self._plan_cur is None:
-                    self._plan_init()
-                self._wait_plan()
             with torch.cuda.graph(g):
-                if mid:
-                    self._hand_over_copies()
                 loss = self._eager_step(hand_over=False)
             self._graph, self._graph_loss = g, loss
             g.replay()
-            if mid:
-                self._launch_sampling()
-            elif self.overlap:
+            if self.overlap:
                 self._hand_over()
         except Exception as exc:   # stay correct: eager from here on
             import warnings
@@ -267,14 +252,7 @@ class TrainStep:
                 self._reset_factor_store()
             from . import sa_mlp
             ticks_prev, sa_mlp.DEFERRED_TICKS = sa_mlp.DEFERRED_TICKS, []      # every BatchNorm counter of the step: one launch, in B
-            mid = self._plan_mid and self.overlap
-            if mid:
-                if self._plan_cur is None:
-                    self._plan_init()
-                self._wait_plan()
             with torch.cuda.graph(ga, stream=cap):
-                if mid:
-                    self._hand_over_copies()
                 self._supply_plan()
                 self.reducer.zero_grad()
                 feat = self._encode()
@@ -322,7 +300,7 @@ class TrainStep:
                             elif seen[d_.data_ptr()] != s_.data_ptr():
                                 raise RuntimeError(f"factor {k}: expected to share its input activation")
                     torch._foreach_copy_(dsts, srcs)
-                if self.overlap and not split_bwd and not mid:
+                if self.overlap and not split_bwd:
                     self._hand_over_copies()
             if split_bwd:
                 with torch.cuda.graph(gb2, pool=ga.pool(), stream=cap):
@@ -331,7 +309,7 @@ class TrainStep:
                     if not self.dp_graph:
                         self.reducer.finish()
                         self.opt.step()
-                    if self.overlap and not mid:
+                    if self.overlap:
                         self._hand_over_copies()
             if self.dp_graph:
                 self._static_grads = [(p, p.grad) for p in self.reducer.params if p.grad is not None]
@@ -341,8 +319,6 @@ class TrainStep:
             self._adam_stream = torch.cuda.Stream()
             self._graph, self._graph_b, self._graph_b2, self._graph_loss = ga, gb, gb2, loss
             ga.replay()
-            if mid:
-                self._launch_sampling()
             self._replay_b()
         except Exception as exc:   # stay correct: eager from here on
             import warnings
@@ -430,7 +406,7 @@ class TrainStep:
 
     def _replay_b(self):
         """Graph B (or B1, head optimizer, B2) and what follows it eagerly."""
-        if self.overlap and not self._plan_mid:
+        if self.overlap:
             self._wait_plan()                   # B's last node is the hand-over copy
         self._graph_b.replay()
         if self._graph_b2 is not None:
@@ -457,7 +433,7 @@ class TrainStep:
     def eager_step(self):
         """One step launched kernel by kernel even when a recorded graph exists (bench.py's per-kernel timing hooks live in
         the launch path).  Shares parameters and optimizer state with the graph, so the two can be interleaved."""
-        if self.overlap and not self._plan_mid:
+        if self.overlap:
             self._launch_sampling()
         if self._adam_ev is not None:
             torch.cuda.current_stream().wait_event(self._adam_ev)
@@ -526,14 +502,12 @@ class TrainStep:
         self._plan_next = torch.zeros(self._plan_size(), dtype=torch.int64, device=self.device)
         self._plan_cur = torch.zeros_like(self._plan_next)
         self._plan_stream = torch.cuda.Stream()
-        first = self._plan_next if self._plan_mid else self._plan_cur      # "mid": every step starts with the hand-over copy
         if self._stream is not None:
             xyz, starts = self._stream.collate_next()
-            self._sample_levels(first, xyz, starts)
-            if not self._plan_mid:
-                self._stream.publish()
+            self._sample_levels(self._plan_cur, xyz, starts)
+            self._stream.publish()
         else:
-            self._sample_levels(first)
+            self._sample_levels(self._plan_cur)
 
     def _launch_sampling(self):
         """The next batch's collation + sampling plan on the second stream, ordered after everything the step's stream holds so
@@ -571,8 +545,6 @@ class TrainStep:
             pu.clear_prefetched()    # nothing of an earlier (possibly aborted) step may survive into this one
             if self._plan_cur is None:
                 self._plan_init()
-                if self._plan_mid:
-                    self._hand_over_copies()
             xyz = self.batch["point_cloud"]
             for m, (fps_idx, new_xyz, idxs) in zip(self._plan_levels(), self._plan_views(self._plan_cur)):
                 if hasattr(m, "radius_list"):
@@ -583,14 +555,8 @@ class TrainStep:
 
     def _eager_step(self, hand_over=True):
         try:
-            mid = self._plan_mid and self.overlap
-            if mid and hand_over:
-                if self._plan_cur is None:
-                    self._plan_init()
-                self._hand_over()
-                self._launch_sampling()
             loss = self._eager_step_body()
-            if hand_over and self.overlap and not mid and self._plan_ev is not None:
+            if hand_over and self.overlap and self._plan_ev is not None:
                 self._hand_over()
             return loss
         except BaseException:
