@@ -317,16 +317,29 @@ class TrainStep:
             if self.factor_opt is not None:
                 self._reset_factor_store()
             self._adam_stream = torch.cuda.Stream()
-            self._graph, self._graph_b, self._graph_b2, self._graph_loss = ga, gb, gb2, loss
-            ga.replay()
-            self._replay_b()
+            captured = (ga, gb, gb2, loss)
         except Exception as exc:   # stay correct: eager from here on
             import warnings
             from . import sa_mlp
             sa_mlp.DEFERRED_TICKS = None
             warnings.warn(f"hipGraph capture of the training step failed ({type(exc).__name__}: {exc}); running eagerly")
+            captured = None
+        # data parallelism: the launch mode is a COLLECTIVE decision -- a rank whose capture failed would exchange gradients from hooks
+        # while the others replay graphs with the deferred exchange, and the mismatched collectives would hang the job
+        ok = captured is not None
+        if self.dp_graph:
+            import torch.distributed as dist
+            flag = torch.tensor([1.0 if ok else 0.0], device=self.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok = bool(flag.item() > 0.5)
+        if ok:
+            self._graph, self._graph_b, self._graph_b2, self._graph_loss = captured
+            self._graph.replay()
+            self._replay_b()
+        else:
             self._disarm()
             self._graph, self._graph_b, self._graph_b2, self.use_graph = None, None, None, False
+            self._factor_args = None
             if self.dp_graph:
                 self.dp_graph, self._guard_left, self.reducer.deferred = False, 0, False
             if self.factor_opt is not None:
@@ -348,6 +361,11 @@ class TrainStep:
         rows = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(rows, mine)                  # (the list form: every backend has it)
         table = torch.stack(rows).cpu()
+        if not bool(torch.isfinite(table).any(dim=1).any()) or not bool(torch.isfinite(table[:, 2]).any()):
+            # EVERY replica is non-finite: that is a diverged / poisoned run (e.g. a failed stroke-mask matching turns the loss into NaN
+            # by design), not a replica mismatch -- raise with the reason instead of quietly re-broadcasting rank 0's state
+            self.check(self._graph_loss)
+            raise FloatingPointError("data-parallel step: parameters or loss are non-finite on every rank")
         ok = bool(torch.isfinite(table).all()) and bool((table[:, :2] == table[0, :2]).all())
         if os.environ.get("MASKPLANNER_DP_GUARD_TRIP") == str(self._guard_left):      # test hook: behave as if the replicas differed
             ok = False

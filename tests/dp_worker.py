@@ -70,11 +70,16 @@ elif mode in ("dp_graph", "dp_eager", "dp_graph_trip"):
     os.environ["MASKPLANNER_DP_GRAPH"] = "0" if mode == "dp_eager" else "1"
     if mode == "dp_graph_trip":      # the replica guard's failure branch: the second guarded step pretends the replicas differ
         os.environ["MASKPLANNER_DP_GUARD_TRIP"] = "0"
+    from maskplanner_amd import ops
+    ops.DETERMINISTIC = True       # ordered scatter kernels: what is left to differ between two runs is the dW atomics of the MLP kernels
     ts = TrainStep("cuboids", B=4, N=1024, hidden_size=(128, 128), rank=rank, seed=9)
     ts.model.dropout.p = 0.0
-    losses = []
-    for _ in range(8):
+    losses, early = [], None
+    for i in range(8):
         losses.append(float(ts.step()))
+        if i == 1:
+            torch.cuda.synchronize()
+            early = torch.cat([p.detach().reshape(-1) for p in ts.model.parameters()]).cpu()
     torch.cuda.synchronize()
     flat = torch.cat([p.detach().reshape(-1) for p in ts.model.parameters()])
     ref = flat.clone()
@@ -87,7 +92,7 @@ elif mode in ("dp_graph", "dp_eager", "dp_graph_trip"):
         if d > 0:
             worst[n] = d
     result = dict(losses=losses, replica_diff=float((flat - ref).abs().max()), graph=ts._graph is not None and ts._graph_b is not None,
-                  params=flat.cpu(), diverged=worst, fell_back=ts.dp_fell_back)
+                  params=flat.cpu(), params_after_2=early, diverged=worst, fell_back=ts.dp_fell_back)
 else:
     raise SystemExit(f"unknown mode {mode}")
 

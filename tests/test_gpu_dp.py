@@ -92,9 +92,14 @@ def test_two_graph_step_replays_under_data_parallelism():
     assert max(r["replica_diff"] for r in g) == 0.0 and max(r["replica_diff"] for r in e) == 0.0, (g[1]["diverged"], e[1]["diverged"])
     lg, le = np.array(g[0]["losses"]), np.array(e[0]["losses"])
     assert np.isfinite(lg).all() and lg[-1] < lg[0]
-    # same first loss; then two optimisation walks that differ by the summation order of their atomics, on 4-cloud batches with
-    # train-mode BatchNorm: close for the first steps, the same trend afterwards (one run in ~10 leaves 5 % by step 8)
-    assert abs(lg[0] - le[0]) <= 1e-4 * abs(le[0]) and np.allclose(lg[:4], le[:4], rtol=5e-2) and np.allclose(lg, le, rtol=0.25), (lg, le)
+    # same first loss; then two optimisation walks that differ by the summation order of the dW atomics only (the scatter kernels run
+    # in their ordered form: ops.DETERMINISTIC), on 4-cloud batches with train-mode BatchNorm
+    assert abs(lg[0] - le[0]) <= 1e-4 * abs(le[0]) and np.allclose(lg[:4], le[:4], rtol=5e-2) and np.allclose(lg, le, rtol=0.1), (lg, le)
+    # the weights themselves after two steps: Adam moves every parameter by ~lr = 1e-3 per step; a missed bucket or a stale factor in the
+    # deferred exchange would move whole tensors differently, atomics noise flips the update of a few near-zero gradients
+    pg, pe = g[0]["params_after_2"], e[0]["params_after_2"]
+    off = float(((pg - pe).abs() > 2e-4).float().mean())
+    assert off < 0.02, off
 
 
 def test_four_ranks_replay_the_two_graph_step():
