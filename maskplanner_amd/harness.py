@@ -69,9 +69,9 @@ class TrainStep:
         from . import ops as _ops
         self._zero_arena = _ops.ZeroArena(self.device) if self.device.type == "cuda" else None
         # train-mode dropout of the head blocks inside their BatchNorm + ReLU launches (pointnet2_cls_ssg._block): a device (seed, step)
-        # pair, the step advanced once per training step.  MASKPLANNER_FUSED_DROPOUT=0 keeps nn.Dropout (torch's Philox stream).
+        # pair, the step advanced once per training step.
         self._drop_rng = None
-        if fused and os.environ.get("MASKPLANNER_FUSED_DROPOUT", "1") != "0" and hasattr(self.model, "heads"):
+        if fused and hasattr(self.model, "heads"):
             # (the rank is mixed in: the reference's single process draws an independent mask per row of the GLOBAL batch, so
             # replicas must not share theirs)
             self._drop_rng = torch.tensor([int(seed) * 0x9E3779B1 + 12345 + int(rank) * 0x632BE5AB, 0], dtype=torch.int64, device=self.device)
@@ -93,8 +93,8 @@ class TrainStep:
             self._reset_factor_store()
         self._static_grads = None
         # train_maskplanner.py:159.  On the GPU the dense parameters go through csrc/adam_multi.hip (same update, ~150 tensors in four
-        # launches); MASKPLANNER_TORCH_ADAM=1 keeps torch's fused Adam.
-        if fused and os.environ.get("MASKPLANNER_TORCH_ADAM", "0") == "0":
+        # launches).
+        if fused:
             self.opt = DenseAdam(dense, lr=lr, capturable=self.use_graph)
         else:
             self.opt = torch.optim.Adam(dense, lr=lr, fused=fused, capturable=self.use_graph)

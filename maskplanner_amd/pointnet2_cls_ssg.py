@@ -17,7 +17,7 @@ import torch.nn.functional as F
 from . import ops, sa_mlp
 from .factor_heads import factor_linear
 
-SAMPLE_AHEAD = os.environ.get("MASKPLANNER_SAMPLE_AHEAD", "1") != "0"
+SAMPLE_AHEAD = True      # False (tests): every level samples in line
 from .pointnet2_utils import PointNetSetAbstraction, PointNetSetAbstractionMsg
 
 
@@ -59,7 +59,7 @@ class _SSGEncoder(nn.Module):
         level's centroids, which exist as soon as the first level's FPS is done -- so both levels are sampled here, the second one on
         a side stream underneath the first level's grouping + MLP (its FPS is a one-wave-per-cloud latency chain: 60 + 40 us that
         otherwise sit on the critical path).  The FPS starts are drawn in the reference's order; the levels pick the plans up through
-        pointnet2_utils' plan queue.  MASKPLANNER_SAMPLE_AHEAD=0 switches it off."""
+        pointnet2_utils' plan queue."""
         from . import pointnet2_utils as pu
         sa1, sa2 = self.sa1, self.sa2
         if (not SAMPLE_AHEAD or not xyz.is_cuda or torch.cuda.is_current_stream_capturing() or getattr(sa1, "group_all", True)
