@@ -1,7 +1,7 @@
 #!/bin/bash
 # PMC traffic passes (FETCH_SIZE / WRITE_SIZE, each in its own run, counters + kernel trace only) for the other BASELINE configs, so that
 # `roofline.traffic` of every bench line is a measured number:  tools/profile_configs.sh r03  ->  gpurun_out/<tag>_cfg_<key>_{fetch,write}/
-TAG=${1:-r03}
+TAG=${1:-r04}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 run() {   # key, bench flags
   key=$1; shift

@@ -2,7 +2,7 @@
 # rocprofv3 passes over the default bench (run on the GPU box through gpurun): kernel trace + stats, then the PMC passes, each in
 # its own run (counters never together with trace domains other than --kernel-trace; FETCH_SIZE and WRITE_SIZE do not fit one pass).
 #   tools/profile_round.sh r02 [extra bench flags]   ->  gpurun_out/<tag>_{bench,fetch,write,mfma}/ ; then tools/make_profile_summary.py <tag>
-TAG=${1:-r03}; shift
+TAG=${1:-r04}; shift
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 COMMON="--no-cpu-baseline --no-side-legs $*"
 rm -rf gpurun_out/${TAG}_bench gpurun_out/${TAG}_fetch gpurun_out/${TAG}_write gpurun_out/${TAG}_mfma

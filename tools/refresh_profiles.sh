@@ -1,6 +1,6 @@
 # everything under profiles/<tag>_* from one GPU session: kernel stats + PMC passes of the default bench, the overlap trace, the SQ counter
 # table of the hot kernels, the full default bench line and the lines of the other BASELINE configs.   bash tools/refresh_profiles.sh r02
-TAG=${1:-r03}
+TAG=${1:-r04}
 cd "$GRAFT_REPO_ROOT"
 bash tools/profile_round.sh $TAG > gpurun_out/profile_round.log 2>&1
 cd /tmp; export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
