@@ -436,6 +436,25 @@ size_t mp_linear_dx_skinny_workspace_bytes(int64_t B, int64_t O, int64_t I);
 int mp_linear_dx_skinny_f32(const float* g, const float* weight, int64_t B, int64_t O, int64_t I, float* grad_x,
                             void* workspace, size_t workspace_bytes, mp_stream_t stream);
 
+/* ---- head blocks: Linear (+ BatchNorm1d + ReLU + Dropout) over a skinny batch, one launch each way [r4] ------------------------------
+ * replaces: models/pointnet2_cls_ssg.py:309-327 `self.dropout(F.relu(self.bn1(self.fc1(x))))` (bn != 0) and the plain nn.Linear of
+ *           :311, :327, :336 (bn == 0), with their autograd.  csrc/head_linear.hip.
+ *   x [B <= 32, I] f32, weight [O, I], bias [O] or NULL; I in {128, 256, 512, 1024, 2048} (mp_head_block_supported).
+ *   forward: y [B, O]; with bn: z [B, O] = the Linear's output (kept for the backward), save_mean / save_rstd [O], running statistics
+ *   updated like nn.BatchNorm1d (training) or used (eval), rng / drop_p / layer as mp_bn_relu_drop_rows_f32 (rng NULL: no dropout).
+ *   backward (bn blocks): dz [B, O] = gradient at the Linear's output (the factor of dW = dz^T x), grad_gamma / grad_beta [O] (or NULL),
+ *   grad_x [B, I] = dz W; with mp_head_block_bwd_slices(O) > 1 the row slices of W add their tiles with atomics (summation order not
+ *   fixed) into a grad_x the call clears first (unless it lies in the armed zero arena).  O <= 4096, I % 64 == 0. */
+int mp_head_block_supported(int64_t B, int64_t I, int64_t O);
+int mp_head_block_fwd_f32(const float* x, const float* weight, const float* bias, int64_t B, int64_t I, int64_t O, int bn, int training,
+                          double momentum, double eps, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                          float* z, float* y, float* save_mean, float* save_rstd, double drop_p, const int64_t* rng, int layer,
+                          mp_stream_t stream);
+int mp_head_block_bwd_slices(int64_t O);
+int mp_head_block_bwd_f32(const float* grad_y, const float* y, const float* z, const float* weight, int64_t B, int64_t I, int64_t O,
+                          int training, const float* gamma, const float* save_mean, const float* save_rstd, double drop_p, float* dz,
+                          float* grad_gamma, float* grad_beta, float* grad_x, mp_stream_t stream);
+
 /* ---- zero arena (launch count) -------------------------------------------------------------------------------------------
  * Outputs the library accumulates with atomics start from zero; by default each call clears its own (one small launch each).
  * mp_zero_arena_arm clears [base, base + bytes) with ONE launch on `stream` and remembers the range: until it is armed again or

@@ -21,13 +21,29 @@ from . import _lib, dp, ops
 WIDE_LINEAR = True   # False (tests): plain nn.Linear (rocBLAS backward) for the wide heads of a model without a factor store
 
 
+def _linear_fwd(x, weight, bias):
+    """F.linear for a skinny batch: one pass over W on the fp32 matrix cores (csrc/head_linear.hip, the block kernel without its
+    BatchNorm epilogue) where it applies -- the libraries' GEMMs for 32 rows stream the 49 MB heads at 2.2 TB/s."""
+    if (x.is_cuda and x.dtype == torch.float32 and x.ndim == 2 and x.is_contiguous() and weight.dtype == torch.float32
+            and weight.is_contiguous() and (bias is None or bias.dtype == torch.float32)
+            and _lib.load().mp_head_block_supported(x.shape[0], x.shape[1], weight.shape[0])):
+        B, I = x.shape
+        O = weight.shape[0]
+        y = torch.empty((B, O), dtype=torch.float32, device=x.device)
+        p = ops._p
+        ops._run("head_linear", x, _lib.load().mp_head_block_fwd_f32, p(x), p(weight), p(bias), B, I, O, 0, 0, 0.0, 0.0, None, None, None, None,
+                 None, p(y), None, None, 0.0, None, 0)
+        return y
+    return F.linear(x, weight, bias)
+
+
 class _FactorLinear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, store, key):
         ctx.save_for_backward(x, weight)
         ctx.store, ctx.key, ctx.has_bias = store, key, bias is not None
         ctx.bias = bias
-        return F.linear(x, weight, bias)
+        return _linear_fwd(x, weight, bias)
 
     @staticmethod
     def backward(ctx, g):
@@ -63,6 +79,92 @@ class _FactorLinear(torch.autograd.Function):
         return gx, None, gb, None, None
 
 
+class _HeadBlock(torch.autograd.Function):
+    """dropout(relu(bn(linear(x)))) of one head block (models/pointnet2_cls_ssg.py:309-327) as ONE launch forward and one backward
+    (csrc/head_linear.hip): the Linear on the fp32 matrix cores with the BatchNorm1d statistics, ReLU and the counter-based dropout
+    mask in its epilogue; backward = BatchNorm + ReLU + dropout backward, dgamma / dbeta and grad_x = dz W.  The weight gradient
+    stays as factors in `store[key]` (or, without a store, is materialised by the rank-B outer-product kernel)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, training, momentum, eps, drop_p, rng, layer, store, key):
+        B, I = x.shape
+        O = weight.shape[0]
+        z = torch.empty((B, O), dtype=torch.float32, device=x.device)
+        y = torch.empty((B, O), dtype=torch.float32, device=x.device)
+        stats = torch.empty((2, O), dtype=torch.float32, device=x.device)
+        p = ops._p
+        ops._run("head_block", x, _lib.load().mp_head_block_fwd_f32, p(x), p(weight), p(bias), B, I, O, 1, int(training), float(momentum),
+                 float(eps), p(gamma), p(beta), p(running_mean), p(running_var), p(z), p(y), stats[0].data_ptr(), stats[1].data_ptr(),
+                 float(drop_p) if rng is not None else 0.0, p(rng), int(layer))
+        ctx.save_for_backward(x, weight, z, y, gamma, stats)
+        ctx.bias = bias
+        ctx.meta = (bool(training), float(drop_p) if rng is not None else 0.0, store, key)
+        return y
+
+    @staticmethod
+    def backward(ctx, grad_y):
+        x, weight, z, y, gamma, stats = ctx.saved_tensors
+        training, drop_p, store, key = ctx.meta
+        B, I = x.shape
+        O = weight.shape[0]
+        lib = _lib.load()
+        p = ops._p
+        grad_y = grad_y.contiguous().float()
+        dz = torch.empty((B, O), dtype=torch.float32, device=x.device)
+        gg = torch.empty((O,), dtype=torch.float32, device=x.device) if (gamma is not None and ctx.needs_input_grad[3]) else None
+        gbeta = torch.empty((O,), dtype=torch.float32, device=x.device) if ctx.needs_input_grad[4] else None
+        if ops.DETERMINISTIC or O > 4096 or O % 4 or I % 64:
+            # the bit-reproducible form: the rows kernel, then the library GEMM
+            ops._run("bn_relu_rows_bwd", x, lib.mp_bn_relu_drop_rows_bwd_f32, p(grad_y), p(y), p(z), B, O, int(training), p(gamma),
+                     stats[0].data_ptr(), stats[1].data_ptr(), p(dz), p(gg), p(gbeta), drop_p)
+            gx = dz @ weight if ctx.needs_input_grad[0] else None
+        else:
+            gx = (ops.zeroed_empty((B, I), torch.float32, x.device) if lib.mp_head_block_bwd_slices(O) > 1
+                  else torch.empty((B, I), dtype=torch.float32, device=x.device))
+            ops._run("head_block_bwd", x, lib.mp_head_block_bwd_f32, p(grad_y), p(y), p(z), p(weight), B, I, O, int(training), p(gamma),
+                     stats[0].data_ptr(), stats[1].data_ptr(), drop_p, p(dz), p(gg), p(gbeta), p(gx))
+        gw = gb = None
+        if store is not None:
+            store[key] = (x.detach(), dz)                  # the factors of dW = dz^T x
+        elif ctx.needs_input_grad[1]:
+            if I % 4 == 0:
+                gw = torch.empty_like(weight)
+                ops._run("linear_dw_outer", dz, lib.mp_linear_dw_outer_f32, p(dz), p(x), B, O, I, p(gw))
+            else:
+                gw = dz.t() @ x
+        if ctx.bias is not None and ctx.needs_input_grad[2]:
+            pending = store.get(BIAS_QUEUE) if store is not None else None
+            if pending is not None:
+                pending.append((ctx.bias, dz))
+            else:
+                gb = dz.sum(0)
+        return (gx, gw, gb, gg, gbeta) + (None,) * 10
+
+
+def head_block_ok(x, linear, bn):
+    """The one-launch block applies: fp32 [B <= 32, I] on the GPU, contiguous fp32 parameters, a width csrc/head_linear.hip tiles, and
+    BatchNorm statistics local to this process."""
+    w = linear.weight
+    sync = getattr(bn, "sync_bn", None)
+    return (x.is_cuda and x.dtype == torch.float32 and x.ndim == 2 and x.is_contiguous() and w.dtype == torch.float32 and w.is_contiguous()
+            and (sync is None or sync is False) and (bn.training or bn.running_mean is not None)
+            and bool(_lib.load().mp_head_block_supported(x.shape[0], x.shape[1], w.shape[0])))
+
+
+def head_block(x, linear, bn, store, key, dropout=None):
+    """relu(bn(linear(x))) -- with dropout = (p, rng, layer) also the nn.Dropout(p) behind it, see ops.bn_relu_rows -- in one launch;
+    the caller has checked head_block_ok and advanced bn.num_batches_tracked."""
+    training = bn.training or bn.running_mean is None
+    track = bn.track_running_stats and bn.running_mean is not None
+    momentum = bn.momentum if bn.momentum is not None else 1.0 / max(float(bn.num_batches_tracked), 1.0)
+    p, rng, layer = dropout if dropout is not None else (0.0, None, 0)
+    y = _HeadBlock.apply(x, linear.weight, linear.bias, bn.weight, bn.bias, bn.running_mean if track else None,
+                         bn.running_var if track else None, training, momentum, bn.eps, p, rng, layer, store, key)
+    if ops.RELU_TAP is not None:
+        ops.RELU_TAP.append(y.detach() > 0)
+    return y
+
+
 BIAS_QUEUE = "__bias_grads__"     # store[BIAS_QUEUE] = []: FactorLinear queues (bias, dy) pairs instead of reducing each one
 
 
@@ -96,7 +198,7 @@ class _WideLinear(torch.autograd.Function):
     def forward(ctx, x, weight, bias):
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
-        return F.linear(x, weight, bias)
+        return _linear_fwd(x, weight, bias)
 
     @staticmethod
     def backward(ctx, g):

@@ -15,7 +15,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops, sa_mlp
-from .factor_heads import factor_linear
+from .factor_heads import factor_linear, head_block, head_block_ok
 
 SAMPLE_AHEAD = True      # False (tests): every level samples in line
 from .pointnet2_utils import PointNetSetAbstraction, PointNetSetAbstractionMsg
@@ -105,8 +105,17 @@ def _block(model, lin_out, bn, layer):
     return model.dropout(_bn_relu(lin_out, bn))
 
 
+HEAD_BLOCK = os.environ.get("MASKPLANNER_HEAD_BLOCK", "1") != "0"    # (A/B switch while the block kernels are new) False: Linear + ops.bn_relu_rows launches
+
+
 def _head_block(model, x, linear, bn, store, key, layer):
-    """One block of the heads: dropout(relu(bn(linear(x)))): Linear, then _block."""
+    """One block of the heads: dropout(relu(bn(linear(x)))) -- one launch each way where csrc/head_linear.hip applies
+    (factor_heads.head_block), else Linear, then _block."""
+    if HEAD_BLOCK and head_block_ok(x, linear, bn):
+        rng = getattr(model, "fused_dropout", None)
+        if rng is not None and model.training and bn.training:
+            return head_block(x, linear, bn, store, key, dropout=(model.dropout.p, rng, layer))
+        return model.dropout(head_block(x, linear, bn, store, key))
     return _block(model, factor_linear(x, linear, store, key), bn, layer)
 
 

@@ -1,0 +1,129 @@
+"""The one-launch head blocks (csrc/head_linear.hip; models/pointnet2_cls_ssg.py:309-327 `dropout(relu(bn1(fc1(x))))`) against torch's
+own nn.Linear + nn.BatchNorm1d + ReLU in float64 (outputs, every gradient, running statistics), and their dropout mask against the
+rows kernel's (same counter-based hash)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from maskplanner_amd import ops as O
+    return O
+
+
+def _modules(I, O, seed):
+    torch.manual_seed(seed)
+    lin = torch.nn.Linear(I, O).cuda()
+    bn = torch.nn.BatchNorm1d(O).cuda()
+    with torch.no_grad():
+        bn.weight.copy_(torch.linspace(0.5, 1.5, O))
+        bn.bias.copy_(torch.linspace(-0.3, 0.3, O))
+        bn.running_mean.copy_(torch.linspace(-0.2, 0.2, O))
+        bn.running_var.copy_(torch.linspace(0.5, 1.5, O))
+    return lin, bn
+
+
+def _rel(a, b):
+    b = b.double()
+    return float((a.double() - b).norm() / b.norm().clamp_min(1e-30))
+
+
+@pytest.mark.parametrize("train", [True, False])
+@pytest.mark.parametrize("store", [True, False])
+@pytest.mark.parametrize("B,I,O", [(32, 1024, 1024), (32, 1024, 512), (8, 128, 128), (5, 256, 200), (32, 512, 1000), (2, 2048, 48), (4, 128, 50)])
+def test_head_block_matches_linear_batchnorm_relu(ops, train, store, B, I, O):
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from maskplanner_amd import factor_heads as fh
+    lin, bn = _modules(I, O, B * I + O)
+    lin64, bn64 = torch.nn.Linear(I, O).cuda().double(), torch.nn.BatchNorm1d(O).cuda().double()
+    lin64.load_state_dict({k: v.double() for k, v in lin.state_dict().items()})
+    bn64.load_state_dict({k: (v.double() if v.is_floating_point() else v) for k, v in bn.state_dict().items()})
+    bn.train(train)
+    bn64.train(train)
+    x = torch.randn(B, I, device="cuda") * 0.7 + 0.1
+    xa, xb = x.clone().requires_grad_(True), x.double().requires_grad_(True)
+    assert fh.head_block_ok(xa, lin, bn)
+    st = {fh.BIAS_QUEUE: []} if store else None
+    ya = fh.head_block(xa, lin, bn, st, "w")
+    yb = F.relu(bn64(lin64(xb)))
+    assert _rel(ya, yb) <= (2e-6 if B >= 8 else 2e-5)      # (two to five rows: the normalisation divides by a difference of neighbours)
+    # the ReLU decisions of the two precisions agree except at pre-activations within rounding of zero
+    flips = ((ya.detach() > 0) != (yb.detach() > 0))
+    assert int(flips.sum()) <= max(2, ya.numel() // 20000)
+    g = torch.randn(B, O, device="cuda")
+    g[flips] = 0.0
+    ya.backward(g)
+    yb.backward(g.double())
+    tol = 2e-5 if train else 5e-6       # (training: the BatchNorm backward subtracts two nearly equal sums over <= 32 rows)
+    assert _rel(xa.grad, xb.grad) <= tol
+    assert _rel(bn.weight.grad, bn64.weight.grad) <= tol
+    assert _rel(bn.bias.grad, bn64.bias.grad) <= tol
+    if store:
+        fx, fg = st["w"]
+        assert _rel(fg.t() @ fx, lin64.weight.grad) <= tol
+        fh.flush_bias_grads(st)
+    else:
+        assert _rel(lin.weight.grad, lin64.weight.grad) <= tol
+    # (training: the column sums of dz vanish identically -- compare on the scale of dz, not of their rounding residue)
+    scale = float(lin64.weight.grad.abs().max()) if train else float(lin64.bias.grad.abs().max())
+    assert float((lin.bias.grad.double() - lin64.bias.grad).abs().max()) <= 1e-4 * max(scale, 1e-6)
+    np.testing.assert_allclose(bn.running_mean.cpu().numpy(), bn64.running_mean.float().cpu().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(bn.running_var.cpu().numpy(), bn64.running_var.float().cpu().numpy(), rtol=1e-5, atol=1e-6)
+
+
+def test_head_block_dropout_is_the_rows_kernels_mask(ops):
+    """dropout = (p, rng, layer) inside the block: the kept elements are the ones ops.bn_relu_rows keeps for the same (seed, step, layer),
+    scaled by 1 / (1 - p); the backward passes gradient through exactly those."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from maskplanner_amd import factor_heads as fh
+    B, I, O, p = 32, 1024, 1024, 0.3
+    lin, bn = _modules(I, O, 7)
+    rng = torch.tensor([1234567, 5], dtype=torch.int64, device="cuda")
+    x = torch.randn(B, I, device="cuda")
+    bn_rows = torch.nn.BatchNorm1d(O).cuda()
+    bn_rows.load_state_dict(bn.state_dict())
+    base = fh.head_block(x, lin, bn, None, "w").detach()
+    bn.load_state_dict(bn_rows.state_dict())
+    xa = x.clone().requires_grad_(True)
+    y = fh.head_block(xa, lin, bn, None, "w", dropout=(p, rng, 2))
+    rows = ops.bn_relu_rows(lin(x).detach(), bn_rows, dropout=(p, rng, 2))
+    kept = y != 0
+    sure = base > 1e-4                      # (away from the ReLU edge, where the two Linears may round differently)
+    assert torch.equal(kept[sure], (rows != 0)[sure])
+    np.testing.assert_allclose(y[kept].detach().cpu().numpy(), (base[kept] / (1 - p)).cpu().numpy(), rtol=1e-6)
+    assert 0.25 <= 1.0 - float(kept[sure].float().mean()) <= 0.35
+    y.backward(torch.ones_like(y))
+    # gradient reaches x only through kept, active units: with every unit dropped it would be zero -- compare against autograd of
+    # the same mask applied outside
+    xb = x.clone().requires_grad_(True)
+    bn.load_state_dict(bn_rows.state_dict())
+    lin.zero_grad()
+    yb = fh.head_block(xb, lin, bn, None, "w") * kept.float() / (1 - p)
+    yb.backward(torch.ones_like(yb))
+    assert _rel(xa.grad, xb.grad) <= 1e-5
+
+
+def test_plain_head_linear_forward(ops):
+    """bn == 0: the wide heads' nn.Linear through the same kernel."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from maskplanner_amd import _lib
+    lib = _lib.load()
+    for B, I, O in [(32, 1024, 11988), (32, 1024, 5994), (3, 256, 77)]:
+        torch.manual_seed(O)
+        lin = torch.nn.Linear(I, O).cuda()
+        x = torch.randn(B, I, device="cuda")
+        y = torch.empty(B, O, device="cuda")
+        rc = lib.mp_head_block_fwd_f32(x.data_ptr(), lin.weight.data_ptr(), lin.bias.data_ptr(), B, I, O, 0, 0, 0.0, 0.0, None, None, None, None,
+                                       None, y.data_ptr(), None, None, 0.0, None, 0, torch.cuda.current_stream().cuda_stream)
+        assert rc == 0
+        ref = F.linear(x.double(), lin.weight.double(), lin.bias.double())
+        assert _rel(y, ref) <= 1e-6
