@@ -429,6 +429,9 @@ int mp_adam_lowrank_f32(float* param, float* exp_avg, float* exp_avg_sq, const f
  * no workspace; the K slices meet in grad_x through fp32 atomics, so the summation order is not fixed (mp_linear_dx_skinny_f32 is the
  * bit-reproducible form).  ~4 TB/s of weight stream against ~1.5 TB/s. */
 int mp_linear_dx_mfma_f32(const float* g, const float* weight, int64_t B, int64_t O, int64_t I, float* grad_x, mp_stream_t stream);
+/* grad_x = g1 W1 + g2 W2 for two Linears fed by the same activation, one launch (the K slices of both add into grad_x): no fan-out add */
+int mp_linear_dx_mfma2_f32(const float* g1, const float* w1, int64_t O1, const float* g2, const float* w2, int64_t O2, int64_t B, int64_t I,
+                           float* grad_x, mp_stream_t stream);
 /* weight gradient of the same layers, materialised: dW [O, I] = g^T x (B <= 32 rows of factors, I % 4 == 0), b-ordered fma chains, one
  * streaming write of dW -- for loops that keep torch.optim.Adam on dense gradients (train_maskplanner.py:159) */
 int mp_linear_dw_outer_f32(const float* g, const float* x, int64_t B, int64_t O, int64_t I, float* dW, mp_stream_t stream);
@@ -450,6 +453,10 @@ int mp_head_block_fwd_f32(const float* x, const float* weight, const float* bias
                           double momentum, double eps, const float* gamma, const float* beta, float* running_mean, float* running_var,
                           float* z, float* y, float* save_mean, float* save_rstd, double drop_p, const int64_t* rng, int layer,
                           mp_stream_t stream);
+/* one or two plain Linears fed by the same x (w2 NULL: one) in one launch (models/pointnet2_cls_ssg.py:311 + :327: fc3 and fc_normals
+ * both read the last hidden activation); their input gradient in one launch: mp_linear_dx_mfma2_f32 below */
+int mp_head_linear2_fwd_f32(const float* x, int64_t B, int64_t I, const float* w1, const float* b1, int64_t O1, float* y1,
+                            const float* w2, const float* b2, int64_t O2, float* y2, mp_stream_t stream);
 int mp_head_block_bwd_slices(int64_t O);
 int mp_head_block_bwd_f32(const float* grad_y, const float* y, const float* z, const float* weight, int64_t B, int64_t I, int64_t O,
                           int training, const float* gamma, const float* save_mean, const float* save_rstd, double drop_p, float* dz,

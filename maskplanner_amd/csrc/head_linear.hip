@@ -48,11 +48,24 @@ __device__ __forceinline__ float drop_keep(unsigned long long key, int r, int C,
 // [16 rows][k range] tiles row-contiguous (16 lanes per 256 bytes of a row), all of them up front, and turns each through a private
 // 4 KB LDS tile into the fragment layout (row stride CH + 4: both directions conflict-free, no barrier: a wave's LDS operations are
 // ordered).
+// Second set (plain Linear only): two Linears fed by the same x in one launch -- column tiles >= tiles0 belong to (W2, bias2, y2, O2).
+struct HeadSet2 {
+    const float* W;
+    const float* bias;
+    float* y;
+    int O, tiles0;
+};
+
 template <int NJ>
-__global__ __launch_bounds__(HL_THREADS) void head_fwd_kernel(const float* __restrict__ x, const float* __restrict__ W,
-                                                              const float* __restrict__ bias, int B, int I, int O, HeadBn bn,
-                                                              float* __restrict__ z, float* __restrict__ y)
+__global__ __launch_bounds__(HL_THREADS) void head_fwd_kernel(const float* __restrict__ x, const float* __restrict__ W_,
+                                                              const float* __restrict__ bias_, int B, int I, int O_, HeadBn bn,
+                                                              float* __restrict__ z, float* __restrict__ y_, HeadSet2 s2)
 {
+    const bool second = s2.W != nullptr && (int)blockIdx.x >= s2.tiles0;
+    const float* __restrict__ W = second ? s2.W : W_;
+    const float* __restrict__ bias = second ? s2.bias : bias_;
+    float* __restrict__ y = second ? s2.y : y_;
+    const int O = second ? s2.O : O_;
     constexpr int KW = 16 * NJ;                 // k range of a wave
     constexpr int CH = KW < 64 ? KW : 64;       // k per pass through the LDS tile
     constexpr int NCH = KW / CH;
@@ -63,7 +76,7 @@ __global__ __launch_bounds__(HL_THREADS) void head_fwd_kernel(const float* __res
     __shared__ float zt[32][17];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int l16 = lane & 15, q = lane >> 4;
-    const int o0 = blockIdx.x * 16;
+    const int o0 = ((int)blockIdx.x - (second ? s2.tiles0 : 0)) * 16;
     const int lr = lane / LPR, lk = 4 * (lane % LPR);          // row / first k of this lane inside one load instruction
     const int k0 = wave * KW + lk;
     // the epilogue's per-column constants ride along with the operand requests (asked for after the products they would add a second
@@ -333,8 +346,35 @@ extern "C" int mp_head_block_fwd_f32(const float* x, const float* weight, const 
     const dim3 grid((unsigned)((O + 15) / 16));
     hipStream_t stream = mp_stream(stream_);
     const double flops = 2.0 * (double)B * (double)I * (double)O, bytes = 4.0 * ((double)I * (double)O + (double)B * (double)(I + 2 * O));
+    const HeadSet2 none{nullptr, nullptr, nullptr, 0, 0};
 #define HL_FWD(NJ) MP_LAUNCH("head_fwd_kernel", flops, bytes, head_fwd_kernel<NJ>, grid, dim3(HL_THREADS), 0, stream, x, weight, bias, \
-                             (int)B, (int)I, (int)O, h, z, y)
+                             (int)B, (int)I, (int)O, h, z, y, none)
+    switch (I) {
+        case 128: HL_FWD(1); break;
+        case 256: HL_FWD(2); break;
+        case 512: HL_FWD(4); break;
+        case 1024: HL_FWD(8); break;
+        default: HL_FWD(16); break;
+    }
+#undef HL_FWD
+    MP_CHECK_LAUNCH();
+    return MP_OK;
+}
+
+extern "C" int mp_head_linear2_fwd_f32(const float* x, int64_t B, int64_t I, const float* w1, const float* b1, int64_t O1, float* y1,
+                                       const float* w2, const float* b2, int64_t O2, float* y2, mp_stream_t stream_)
+{
+    if (!mp_head_block_supported(B, I, O1) || (w2 && !mp_head_block_supported(B, I, O2))) return MP_EUNSUPPORTED;
+    if (!x || !w1 || !y1 || (w2 && !y2)) return MP_EINVAL;
+    HeadBn h{};
+    const int tiles0 = (int)((O1 + 15) / 16);
+    const HeadSet2 s2{w2, b2, y2, (int)O2, tiles0};
+    const dim3 grid((unsigned)(tiles0 + (w2 ? (O2 + 15) / 16 : 0)));
+    hipStream_t stream = mp_stream(stream_);
+    const double Ot = (double)O1 + (w2 ? (double)O2 : 0.0);
+    const double flops = 2.0 * (double)B * (double)I * Ot, bytes = 4.0 * ((double)I * Ot + (double)B * ((double)I + Ot));
+#define HL_FWD(NJ) MP_LAUNCH("head_fwd_kernel", flops, bytes, head_fwd_kernel<NJ>, grid, dim3(HL_THREADS), 0, stream, x, w1, b1, (int)B, (int)I, \
+                             (int)O1, h, (float*)nullptr, y1, s2)
     switch (I) {
         case 128: HL_FWD(1); break;
         case 256: HL_FWD(2); break;

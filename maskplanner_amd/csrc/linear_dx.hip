@@ -36,13 +36,19 @@ __device__ __forceinline__ Planes8 split8(const float (&x)[8])
     return r;
 }
 
-__global__ __launch_bounds__(256, 2) void linear_dx_mfma_kernel(const float* __restrict__ g, const float* __restrict__ W, int B, int O, int I,
-                                                                int ns, float* __restrict__ gx)
+// (g2, W2, O2): a second Linear fed by the same activation (fc3 / fc_normals): K slices >= slices1 belong to it, both add into gx.
+__global__ __launch_bounds__(256, 2) void linear_dx_mfma_kernel(const float* __restrict__ g1, const float* __restrict__ W1, int B, int O1, int I,
+                                                                int ns, float* __restrict__ gx, const float* __restrict__ g2,
+                                                                const float* __restrict__ W2, int O2, int slices1)
 {
     __shared__ __attribute__((aligned(16))) __bf16 sG[3][LD_NS_MAX][64][8];     // A fragments: [plane][k-step][lane][8 k values]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int l31 = lane & 31, h = lane >> 5;
-    const int k_base = blockIdx.y * ns * 16;
+    const bool second = (int)blockIdx.y >= slices1;
+    const float* __restrict__ g = second ? g2 : g1;
+    const float* __restrict__ W = second ? W2 : W1;
+    const int O = second ? O2 : O1;
+    const int k_base = ((int)blockIdx.y - (second ? slices1 : 0)) * ns * 16;
     // ---- B operand: lane (column c, half h) of k-step s holds W[k_base + 16 s + 8 h + j][col], j = 0..7 (rows past O: clamped --
     // their g values are zeros).  Requested first: everything below runs under their latency.
     const int col = blockIdx.x * 128 + wave * 32 + l31;
@@ -155,23 +161,37 @@ extern "C" int mp_linear_dw_outer_f32(const float* g, const float* x, int64_t B,
     return MP_OK;
 }
 
-extern "C" int mp_linear_dx_mfma_f32(const float* g, const float* weight, int64_t B, int64_t O, int64_t I, float* grad_x, mp_stream_t stream_)
+static int linear_dx_mfma2(const float* g1, const float* w1, int64_t O1, const float* g2, const float* w2, int64_t O2, int64_t B, int64_t I,
+                           float* grad_x, mp_stream_t stream_)
 {
-    if (B < 0 || O < 0 || I < 0) return MP_EINVAL;
+    if (B < 0 || O1 < 0 || O2 < 0 || I < 0) return MP_EINVAL;
     if (B == 0 || I == 0) return MP_OK;
-    if (!grad_x || (O > 0 && (!g || !weight))) return MP_EINVAL;
-    if (B > 32 || (I % 128) != 0 || O >= ((int64_t)1 << 30)) return MP_EUNSUPPORTED;
+    if (!grad_x || (O1 > 0 && (!g1 || !w1)) || (O2 > 0 && (!g2 || !w2))) return MP_EINVAL;
+    if (B > 32 || (I % 128) != 0 || O1 >= ((int64_t)1 << 30) || O2 >= ((int64_t)1 << 30)) return MP_EUNSUPPORTED;
     hipStream_t stream = mp_stream(stream_);
     if (!mp::zero_async(grad_x, (size_t)(B * I), stream)) return MP_ELAUNCH;
-    if (O == 0) return MP_OK;
-    const int64_t ksteps = (O + 15) / 16, ncol = I / 128;
+    if (O1 == 0 && O2 == 0) return MP_OK;
+    if (O1 == 0) { O1 = O2; g1 = g2; w1 = w2; O2 = 0; }
+    const int64_t Omax = O1 > O2 ? O1 : O2, ksteps = (Omax + 15) / 16, ncol = I / 128;
     int64_t slices = (768 + ncol - 1) / ncol;                 // ~three workgroups per CU
     if (slices > ksteps) slices = ksteps;
     int64_t ns = (ksteps + slices - 1) / slices;
     if (ns > LD_NS_MAX) { ns = LD_NS_MAX; }
-    slices = (ksteps + ns - 1) / ns;
-    MP_LAUNCH("linear_dx_mfma_kernel", 2.0 * (double)B * O * I, 4.0 * ((double)O * I + (double)B * (O + I)), linear_dx_mfma_kernel,
-              dim3((unsigned)ncol, (unsigned)slices), dim3(256), 0, stream, g, weight, (int)B, (int)O, (int)I, (int)ns, grad_x);
+    const int64_t s1 = ((O1 + 15) / 16 + ns - 1) / ns, s2 = O2 > 0 ? ((O2 + 15) / 16 + ns - 1) / ns : 0;
+    const double Ot = (double)(O1 + O2);
+    MP_LAUNCH("linear_dx_mfma_kernel", 2.0 * (double)B * Ot * I, 4.0 * (Ot * I + (double)B * (Ot + I)), linear_dx_mfma_kernel,
+              dim3((unsigned)ncol, (unsigned)(s1 + s2)), dim3(256), 0, stream, g1, w1, (int)B, (int)O1, (int)I, (int)ns, grad_x, g2, w2, (int)O2, (int)s1);
     MP_CHECK_LAUNCH();
     return MP_OK;
+}
+
+extern "C" int mp_linear_dx_mfma_f32(const float* g, const float* weight, int64_t B, int64_t O, int64_t I, float* grad_x, mp_stream_t stream_)
+{
+    return linear_dx_mfma2(g, weight, O, nullptr, nullptr, 0, B, I, grad_x, stream_);
+}
+
+extern "C" int mp_linear_dx_mfma2_f32(const float* g1, const float* w1, int64_t O1, const float* g2, const float* w2, int64_t O2, int64_t B,
+                                      int64_t I, float* grad_x, mp_stream_t stream_)
+{
+    return linear_dx_mfma2(g1, w1, O1, g2, w2, O2, B, I, grad_x, stream_);
 }

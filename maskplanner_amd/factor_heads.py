@@ -165,6 +165,61 @@ def head_block(x, linear, bn, store, key, dropout=None):
     return y
 
 
+class _FactorLinear2(torch.autograd.Function):
+    """Two wide Linears fed by the same activation (fc3 / fc_normals, models/pointnet2_cls_ssg.py:311, :327): one launch forward, one
+    for grad_x = g1 W1 + g2 W2 (csrc/head_linear.hip, linear_dx.hip) -- no fan-out add; the weight gradients stay as factors in `store`."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, store, key1, key2):
+        B, I = x.shape
+        O1, O2 = w1.shape[0], w2.shape[0]
+        y1 = torch.empty((B, O1), dtype=torch.float32, device=x.device)
+        y2 = torch.empty((B, O2), dtype=torch.float32, device=x.device)
+        p = ops._p
+        ops._run("head_linear2", x, _lib.load().mp_head_linear2_fwd_f32, p(x), B, I, p(w1), p(b1), O1, p(y1), p(w2), p(b2), O2, p(y2))
+        ctx.save_for_backward(x, w1, w2)
+        ctx.biases = (b1, b2)
+        ctx.meta = (store, key1, key2)
+        ctx.set_materialize_grads(False)
+        return y1, y2
+
+    @staticmethod
+    def backward(ctx, g1, g2):
+        x, w1, w2 = ctx.saved_tensors
+        store, key1, key2 = ctx.meta
+        B, I = x.shape
+        g1 = torch.zeros((B, w1.shape[0]), dtype=torch.float32, device=x.device) if g1 is None else g1.contiguous().float()
+        g2 = torch.zeros((B, w2.shape[0]), dtype=torch.float32, device=x.device) if g2 is None else g2.contiguous().float()
+        store[key1] = (x.detach(), g1)
+        store[key2] = (x.detach(), g2)
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx = ops.zeroed_empty((B, I), torch.float32, x.device)
+            p = ops._p
+            ops._run("linear_dx_mfma", x, _lib.load().mp_linear_dx_mfma2_f32, p(g1), p(w1), w1.shape[0], p(g2), p(w2), w2.shape[0], B, I, p(gx))
+        gb = [None, None]
+        pending = store.get(BIAS_QUEUE)
+        for k, (b, g) in enumerate(zip(ctx.biases, (g1, g2))):
+            if b is not None:
+                if pending is not None:
+                    pending.append((b, g))
+                else:
+                    gb[k] = g.sum(0)
+        return gx, None, gb[0], None, gb[1], None, None, None
+
+
+def factor_linear2(x, lin1, lin2, store, key1, key2):
+    """(lin1(x), lin2(x)) for two Linears on the same input: one launch each way where the one-pass kernels apply and the gradients are
+    kept as factors, else two factor_linear calls."""
+    w1, w2 = lin1.weight, lin2.weight
+    if (store is not None and not ops.DETERMINISTIC and x.is_cuda and x.dtype == torch.float32 and x.ndim == 2 and x.is_contiguous()
+            and w1.dtype == torch.float32 and w2.dtype == torch.float32 and w1.is_contiguous() and w2.is_contiguous()
+            and x.shape[1] % 128 == 0 and _lib.load().mp_head_block_supported(x.shape[0], x.shape[1], w1.shape[0])
+            and _lib.load().mp_head_block_supported(x.shape[0], x.shape[1], w2.shape[0])):
+        return _FactorLinear2.apply(x, w1, lin1.bias, w2, lin2.bias, store, key1, key2)
+    return factor_linear(x, lin1, store, key1), factor_linear(x, lin2, store, key2)
+
+
 BIAS_QUEUE = "__bias_grads__"     # store[BIAS_QUEUE] = []: FactorLinear queues (bias, dy) pairs instead of reducing each one
 
 

@@ -15,7 +15,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops, sa_mlp
-from .factor_heads import factor_linear, head_block, head_block_ok
+from .factor_heads import factor_linear, factor_linear2, head_block, head_block_ok
 
 SAMPLE_AHEAD = True      # False (tests): every level samples in line
 from .pointnet2_utils import PointNetSetAbstraction, PointNetSetAbstractionMsg
@@ -248,7 +248,11 @@ class PointNet2Regressor_StrokeMasks(_SSGEncoder):
             _tick(*([self.bn1, self.bn2] + ([self.sm_bn1, self.sm_bn2] if self.pred_stroke_masks else [])))
         x = _head_block(self, feat, self.fc1, self.bn1, fs, "fc1.weight", 0)
         final = _head_block(self, x, self.fc2, self.bn2, fs, "fc2.weight", 1)
-        x = factor_linear(final, self.fc3, fs, "fc3.weight")
+        # (the order of the launches follows the reference's statements; fc3 and fc_normals read the same activation: one launch)
+        if self.outdim_orient > 0:
+            x, raw_normals = factor_linear2(final, self.fc3, self.fc_normals, fs, "fc3.weight", "fc_normals.weight")
+        else:
+            x = factor_linear(final, self.fc3, fs, "fc3.weight")
 
         seg_conf = None
         if self.segment_confidence_scores:
@@ -265,8 +269,7 @@ class PointNet2Regressor_StrokeMasks(_SSGEncoder):
                 mask_conf = getattr(self, self._CONF_LAYER)(s2)
 
         if self.outdim_orient > 0:
-            out = _pose_output(x, factor_linear(final, self.fc_normals, fs, "fc_normals.weight"), B, self.out_vectors,
-                               self.weight_orient)
+            out = _pose_output(x, raw_normals, B, self.out_vectors, self.weight_orient)
         else:
             out = x.view(B, self.out_vectors, self.outdim)
         return out, sm_out, mask_conf, seg_conf

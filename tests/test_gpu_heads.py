@@ -30,7 +30,8 @@ def _modules(I, O, seed):
 
 
 def _rel(a, b):
-    b = b.double()
+    b = b.detach().double()
+    a = a.detach()
     return float((a.double() - b).norm() / b.norm().clamp_min(1e-30))
 
 
@@ -127,3 +128,33 @@ def test_plain_head_linear_forward(ops):
         assert rc == 0
         ref = F.linear(x.double(), lin.weight.double(), lin.bias.double())
         assert _rel(y, ref) <= 1e-6
+
+
+def test_two_linears_on_one_input(ops):
+    """factor_linear2 (fc3 / fc_normals): outputs, grad_x = g1 W1 + g2 W2 and the stored factors against float64."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from maskplanner_amd import factor_heads as fh
+    for B, I, O1, O2 in [(32, 1024, 11988, 11988), (7, 256, 600, 50), (32, 128, 5994, 333), (32, 512, 40, 4000)]:
+        torch.manual_seed(O1 + O2)
+        l1, l2 = torch.nn.Linear(I, O1).cuda(), torch.nn.Linear(I, O2).cuda()
+        x = torch.randn(B, I, device="cuda")
+        xa, xb = x.clone().requires_grad_(True), x.double().requires_grad_(True)
+        st = {fh.BIAS_QUEUE: []}
+        y1, y2 = fh.factor_linear2(xa, l1, l2, st, "a", "b")
+        r1 = F.linear(xb, l1.weight.detach().double(), l1.bias.detach().double())
+        r2 = F.linear(xb, l2.weight.detach().double(), l2.bias.detach().double())
+        assert _rel(y1.detach(), r1.detach()) <= 1e-6 and _rel(y2.detach(), r2.detach()) <= 1e-6
+        g1, g2 = torch.randn(B, O1, device="cuda"), torch.randn(B, O2, device="cuda")
+        torch.autograd.backward([y1, y2], [g1, g2])
+        torch.autograd.backward([r1, r2], [g1.double(), g2.double()])
+        assert _rel(xa.grad, xb.grad) <= 2e-6
+        assert torch.equal(st["a"][1], g1) and torch.equal(st["b"][1], g2) and st["a"][0].data_ptr() == st["b"][0].data_ptr()
+        fh.flush_bias_grads(st)
+        assert _rel(l1.bias.grad, g1.double().sum(0)) <= 1e-6 and _rel(l2.bias.grad, g2.double().sum(0)) <= 1e-6
+        # one of the two outputs unused: its gradient arrives as None
+        xa2 = x.clone().requires_grad_(True)
+        st2 = {fh.BIAS_QUEUE: []}
+        y1, _ = fh.factor_linear2(xa2, l1, l2, st2, "a", "b")
+        y1.backward(g1)
+        assert _rel(xa2.grad, g1.double() @ l1.weight.detach().double()) <= 2e-6

@@ -609,8 +609,11 @@ def test_factor_adam_matches_torch_adam(B):
         opt_b.step()
         opt_w.step()
         assert "w" not in store
-        close(mine.weight, ref.weight, f"weight after step {step}", rtol=1e-6, atol=2e-7)
-        close(mine.bias, ref.bias, f"bias after step {step}", rtol=1e-6, atol=2e-7)
+        # The two forwards round differently (F.linear vs csrc/head_linear.hip for B <= 32), so g differs in its last bits -- and Adam's
+        # first steps divide by |g| + 1e-8: among six million elements some have |dW| ~ 1e-8, where that rounding moves the update by a
+        # percent of lr.  1e-5 = 1 % of one step; a wrong moment or bias correction shows up at the scale of lr itself.
+        close(mine.weight, ref.weight, f"weight after step {step}", rtol=1e-6, atol=1e-5)
+        close(mine.bias, ref.bias, f"bias after step {step}", rtol=1e-6, atol=1e-5)
 
 
 def test_train_step_with_and_without_factor_heads_agree():
@@ -1372,8 +1375,8 @@ def test_factorised_first_layer_of_the_multi_scale_level(monkeypatch):
 def test_wide_head_backward_kernels_and_sample_ahead_change_nothing(monkeypatch):
     """A model WITHOUT a factor store (the drop-in configuration): the wide heads' backward on the library's streaming kernels
     (factor_heads._WideLinear) and the second level's sampling on a side stream (pointnet2_cls_ssg._sample_ahead) against plain
-    nn.Linear autograd and in-line sampling: same outputs (bit for bit: the forward is untouched, the sampling plans are equal),
-    same gradients up to fp32 summation order."""
+    nn.Linear autograd, torch's BatchNorm-free block composition (HEAD_BLOCK off) and in-line sampling: same outputs and gradients up to
+    fp32 summation order (the sampling plans are equal)."""
     from maskplanner_amd import factor_heads, pointnet2_cls_ssg as pc, synthetic as syn
     cat = syn.CATEGORIES["cuboids"]
     B, N = 8, 2048
@@ -1383,6 +1386,7 @@ def test_wide_head_backward_kernels_and_sample_ahead_change_nothing(monkeypatch)
     for fast in (False, True):
         monkeypatch.setattr(factor_heads, "WIDE_LINEAR", fast)
         monkeypatch.setattr(pc, "SAMPLE_AHEAD", fast)
+        monkeypatch.setattr(pc, "HEAD_BLOCK", fast)
         torch.manual_seed(21)
         m = pc.maskplanner_model(cat).cuda().train()
         m.dropout.p = 0.0
@@ -1390,7 +1394,9 @@ def test_wide_head_backward_kernels_and_sample_ahead_change_nothing(monkeypatch)
         out, sm, conf, _ = m(x)
         ((out * w).sum() + sm.sum() + conf.sum()).backward()
         res[fast] = (out.detach(), sm.detach(), {n: p.grad.detach().clone() for n, p in m.named_parameters()})
-    assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
+    # ([r4] the heads' forward runs on the library's one-pass kernels too: equal to fp32 rounding, not bit for bit)
+    for k in (0, 1):
+        assert float((res[True][k] - res[False][k]).norm()) <= 1e-5 * float(res[False][k].norm())      # (two train-mode BatchNorms over 8 rows in between)
     for n, g0 in res[False][2].items():
         g1 = res[True][2][n]
         if n.endswith("bias") and ("mlp_convs" in n or n in ("fc1.bias", "fc2.bias", "sm_fc1.bias", "sm_fc2.bias", "sa3.mlp_bns.2.bias")):

@@ -36,3 +36,4 @@ for B, I, O in [(32, 1024, 1024), (32, 1024, 16384), (32, 128, 1024), (32, 128, 
         r = [timeit(fwd_bn), timeit(fwd_plain)]
         if O <= 4096: r.append(timeit(bwd))
     print(f"B{B} I{I} O{O}: F.linear {t_lin:.1f} bn_relu_rows {t_rows:.1f} mm(dz,W) {t_dx:.1f} | head_fwd bn {r[0]:.1f} plain {r[1]:.1f}" + (f" head_bwd {r[2]:.1f}" if len(r) > 2 else ""))
+
