@@ -166,8 +166,10 @@ def head_block(x, linear, bn, store, key, dropout=None):
 
 
 class _FactorLinear2(torch.autograd.Function):
-    """Two wide Linears fed by the same activation (fc3 / fc_normals, models/pointnet2_cls_ssg.py:311, :327): one launch forward, one
-    for grad_x = g1 W1 + g2 W2 (csrc/head_linear.hip, linear_dx.hip) -- no fan-out add; the weight gradients stay as factors in `store`."""
+    """Two Linears fed by the same activation (fc3 / fc_normals, models/pointnet2_cls_ssg.py:311, :327; sm_fc3 / the mask-confidence
+    layer, :336-338): one launch forward, one for grad_x = g1 W1 + g2 W2 (csrc/head_linear.hip, linear_dx.hip) -- no fan-out add.  A
+    weight with a key keeps its gradient as factors in `store`; one without (a small dense layer) gets dW from the rank-B outer-product
+    kernel."""
 
     @staticmethod
     def forward(ctx, x, w1, b1, w2, b2, store, key1, key2):
@@ -188,36 +190,40 @@ class _FactorLinear2(torch.autograd.Function):
         x, w1, w2 = ctx.saved_tensors
         store, key1, key2 = ctx.meta
         B, I = x.shape
-        g1 = torch.zeros((B, w1.shape[0]), dtype=torch.float32, device=x.device) if g1 is None else g1.contiguous().float()
-        g2 = torch.zeros((B, w2.shape[0]), dtype=torch.float32, device=x.device) if g2 is None else g2.contiguous().float()
-        store[key1] = (x.detach(), g1)
-        store[key2] = (x.detach(), g2)
+        lib = _lib.load()
+        p = ops._p
+        gs = [torch.zeros((B, w.shape[0]), dtype=torch.float32, device=x.device) if g is None else g.contiguous().float()
+              for g, w in ((g1, w1), (g2, w2))]
         gx = None
         if ctx.needs_input_grad[0]:
             gx = ops.zeroed_empty((B, I), torch.float32, x.device)
-            p = ops._p
-            ops._run("linear_dx_mfma", x, _lib.load().mp_linear_dx_mfma2_f32, p(g1), p(w1), w1.shape[0], p(g2), p(w2), w2.shape[0], B, I, p(gx))
-        gb = [None, None]
+            ops._run("linear_dx_mfma", x, lib.mp_linear_dx_mfma2_f32, p(gs[0]), p(w1), w1.shape[0], p(gs[1]), p(w2), w2.shape[0], B, I, p(gx))
+        gw, gb = [None, None], [None, None]
         pending = store.get(BIAS_QUEUE)
-        for k, (b, g) in enumerate(zip(ctx.biases, (g1, g2))):
+        for k, (w, b, g, key) in enumerate(zip((w1, w2), ctx.biases, gs, (key1, key2))):
+            if key is not None:
+                store[key] = (x.detach(), g)
+            elif ctx.needs_input_grad[1 + 2 * k]:
+                gw[k] = torch.empty_like(w)
+                ops._run("linear_dw_outer", g, lib.mp_linear_dw_outer_f32, p(g), p(x), B, w.shape[0], I, p(gw[k]))
             if b is not None:
                 if pending is not None:
                     pending.append((b, g))
                 else:
                     gb[k] = g.sum(0)
-        return gx, None, gb[0], None, gb[1], None, None, None
+        return gx, gw[0], gb[0], gw[1], gb[1], None, None, None
 
 
 def factor_linear2(x, lin1, lin2, store, key1, key2):
-    """(lin1(x), lin2(x)) for two Linears on the same input: one launch each way where the one-pass kernels apply and the gradients are
-    kept as factors, else two factor_linear calls."""
+    """(lin1(x), lin2(x)) for two Linears on the same input: one launch each way where the one-pass kernels apply (key None: that
+    layer's weight gradient is dense), else two factor_linear calls / plain calls."""
     w1, w2 = lin1.weight, lin2.weight
     if (store is not None and not ops.DETERMINISTIC and x.is_cuda and x.dtype == torch.float32 and x.ndim == 2 and x.is_contiguous()
             and w1.dtype == torch.float32 and w2.dtype == torch.float32 and w1.is_contiguous() and w2.is_contiguous()
             and x.shape[1] % 128 == 0 and _lib.load().mp_head_block_supported(x.shape[0], x.shape[1], w1.shape[0])
             and _lib.load().mp_head_block_supported(x.shape[0], x.shape[1], w2.shape[0])):
         return _FactorLinear2.apply(x, w1, lin1.bias, w2, lin2.bias, store, key1, key2)
-    return factor_linear(x, lin1, store, key1), factor_linear(x, lin2, store, key2)
+    return tuple(factor_linear(x, lin, store, key) if key is not None else lin(x) for lin, key in ((lin1, key1), (lin2, key2)))
 
 
 BIAS_QUEUE = "__bias_grads__"     # store[BIAS_QUEUE] = []: FactorLinear queues (bias, dy) pairs instead of reducing each one

@@ -264,9 +264,11 @@ class PointNet2Regressor_StrokeMasks(_SSGEncoder):
         if self.pred_stroke_masks:
             s1 = _head_block(self, feat, self.sm_fc1, self.sm_bn1, fs, "sm_fc1.weight", 2)
             s2 = _head_block(self, s1, self.sm_fc2, self.sm_bn2, fs, "sm_fc2.weight", 3)
-            sm_out = factor_linear(s2, self.sm_fc3, fs, "sm_fc3.weight").view(B, self.n_stroke_masks, -1)
-            if self.mask_confidence_scores:
-                mask_conf = getattr(self, self._CONF_LAYER)(s2)
+            if self.mask_confidence_scores:     # (sm_fc3 and the confidence layer read the same activation: one launch each way)
+                sm_out, mask_conf = factor_linear2(s2, self.sm_fc3, getattr(self, self._CONF_LAYER), fs, "sm_fc3.weight", None)
+            else:
+                sm_out = factor_linear(s2, self.sm_fc3, fs, "sm_fc3.weight")
+            sm_out = sm_out.view(B, self.n_stroke_masks, -1)
 
         if self.outdim_orient > 0:
             out = _pose_output(x, raw_normals, B, self.out_vectors, self.weight_orient)

@@ -158,3 +158,29 @@ def test_two_linears_on_one_input(ops):
         y1, _ = fh.factor_linear2(xa2, l1, l2, st2, "a", "b")
         y1.backward(g1)
         assert _rel(xa2.grad, g1.double() @ l1.weight.detach().double()) <= 2e-6
+
+
+def test_two_linears_second_one_dense(ops):
+    """factor_linear2 with key None for the second layer (sm_fc3 + the 6-wide mask-confidence layer): its weight gradient is dense."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from maskplanner_amd import factor_heads as fh
+    B, I, O1, O2 = 32, 1024, 5994, 6
+    torch.manual_seed(3)
+    l1, l2 = torch.nn.Linear(I, O1).cuda(), torch.nn.Linear(I, O2).cuda()
+    x = torch.randn(B, I, device="cuda")
+    xa, xb = x.clone().requires_grad_(True), x.double().requires_grad_(True)
+    st = {fh.BIAS_QUEUE: []}
+    y1, y2 = fh.factor_linear2(xa, l1, l2, st, "a", None)
+    r1 = F.linear(xb, l1.weight.detach().double(), l1.bias.detach().double())
+    w2 = l2.weight.detach().double().requires_grad_(True)
+    r2 = F.linear(xb, w2, l2.bias.detach().double())
+    assert _rel(y1, r1) <= 1e-6 and _rel(y2, r2) <= 1e-6
+    g1, g2 = torch.randn(B, O1, device="cuda"), torch.randn(B, O2, device="cuda")
+    torch.autograd.backward([y1, y2], [g1, g2])
+    torch.autograd.backward([r1, r2], [g1.double(), g2.double()])
+    assert _rel(xa.grad, xb.grad) <= 2e-6
+    assert "a" in st and l1.weight.grad is None
+    assert _rel(l2.weight.grad, w2.grad) <= 1e-6
+    fh.flush_bias_grads(st)
+    assert _rel(l2.bias.grad, g2.double().sum(0)) <= 1e-6
