@@ -439,6 +439,11 @@ size_t mp_linear_dx_skinny_workspace_bytes(int64_t B, int64_t O, int64_t I);
 int mp_linear_dx_skinny_f32(const float* g, const float* weight, int64_t B, int64_t O, int64_t I, float* grad_x,
                             void* workspace, size_t workspace_bytes, mp_stream_t stream);
 
+/* dW [Co, Ci] = dz^T x over P rows (dz [P, Co], x [P, Ci], row-major; Co, Ci multiples of 4, <= 1024): the weight gradient of the
+ * per-source-point half of a factorised first layer (models/pointnet2_utils.py:208-213 applied before the grouping);
+ * row slices add with atomics (summation order not fixed) into a dW the call clears first (unless it lies in the armed zero arena). */
+int mp_dw_gemm_f32(const float* dz, const float* x, int64_t P, int64_t Co, int64_t Ci, float* dW, mp_stream_t stream);
+
 /* ---- head blocks: Linear (+ BatchNorm1d + ReLU + Dropout) over a skinny batch, one launch each way [r4] ------------------------------
  * replaces: models/pointnet2_cls_ssg.py:309-327 `self.dropout(F.relu(self.bn1(self.fc1(x))))` (bn != 0) and the plain nn.Linear of
  *           :311, :327, :336 (bn == 0), with their autograd.  csrc/head_linear.hip.

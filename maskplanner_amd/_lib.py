@@ -93,6 +93,7 @@ SIGNATURES = {
     "mp_adam_lowrank_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _dbl, _dbl, _dbl, _dbl, _dbl, _i64, _vp, _vp]),
     "mp_linear_dx_skinny_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "mp_linear_dx_skinny_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _sz, _vp]),
+    "mp_dw_gemm_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp]),
     "mp_head_block_supported": (_int, [_i64, _i64, _i64]),
     "mp_head_block_fwd_f32": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _int, _int, _dbl, _dbl, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _dbl, _vp, _int, _vp]),
     "mp_head_linear2_fwd_f32": (_int, [_vp, _i64, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp]),

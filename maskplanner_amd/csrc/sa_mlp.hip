@@ -2953,6 +2953,24 @@ static bool chain_store16(int n_layers, const int64_t* ch, int64_t K, int first)
     }
     return true;
 }
+// dW [Co, Ci] = dz^T x over P rows, both operands as stored (the per-source-point half of a factorised first layer: dW_f = dA^T F over the
+// B*N source points, sa_mlp._PerPointFirst) -- the position-sliced weight-gradient GEMM of the levels' interior layers with identity
+// operands: slices of the rows add their tiles with atomics (summation order not fixed); dW is cleared first unless it lies in the armed
+// zero arena.
+extern "C" int mp_dw_gemm_f32(const float* dz, const float* x, int64_t P, int64_t Co, int64_t Ci, float* dW, mp_stream_t stream_)
+{
+    if (P < 0 || Co <= 0 || Ci <= 0) return MP_EINVAL;
+    if (!dW || (P > 0 && (!dz || !x))) return MP_EINVAL;
+    if (P >= ((int64_t)1 << 31) || (Co & 3) || (Ci & 3) || Co > 1024 || Ci > 1024) return MP_EUNSUPPORTED;
+    hipStream_t stream = mp_stream(stream_);
+    if (!mp::zero_async(dW, (size_t)(Co * Ci), stream)) return MP_ELAUNCH;
+    if (P == 0) return MP_OK;
+    PosOperand DZ{}, IN{};
+    DZ.x = dz; DZ.C = (int)Co; DZ.K = 1; DZ.kshift = 0;
+    IN.x = x; IN.C = (int)Ci; IN.K = 1; IN.kshift = 0;
+    return split_enabled() ? launch_dw<SRC_ID, SRC_ID, 3>(DZ, IN, P, dW, stream) : launch_dw<SRC_ID, SRC_ID, 0>(DZ, IN, P, dW, stream);
+}
+
 extern "C" int mp_sa_mlp_bf16_storage(int n_layers, const int64_t* channels, int64_t K, int first_layer)
 {
     return (channels && K > 0 && chain_store16(n_layers, channels, K, first_layer)) ? 1 : 0;

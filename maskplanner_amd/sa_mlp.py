@@ -326,8 +326,16 @@ class _PerPointFirst(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             # (more, shorter K slices than clouds: one 128 x 128 tile per cloud leaves the GEMM on 32 workgroups with a 512-long K loop)
             B, N, _ = feats.shape
-            sl = next(d for d in (PER_POINT_DW_SLICES, 4, 2, 1) if N % d == 0)
-            gwf = torch.bmm(gA.reshape(B * sl, N // sl, -1).transpose(1, 2), feats.reshape(B * sl, N // sl, CF)).sum(0)
+            Co = gA.shape[2]
+            if (gA.is_cuda and gA.dtype == torch.float32 and gA.is_contiguous() and feats.is_contiguous() and not ops.DETERMINISTIC
+                    and Co % 4 == 0 and CF % 4 == 0 and Co <= 1024 and CF <= 1024):
+                # [r4] the library's row-sliced weight-gradient GEMM (split planes, atomics between the slices): one launch instead of the
+                # batched GEMM + the 16 MB sum over its slices (29 us at the bench shape)
+                gwf = ops.zeroed_empty((Co, CF), torch.float32, gA.device)
+                ops._run("dw_gemm", gA, _lib.load().mp_dw_gemm_f32, _ptr(gA), _ptr(feats), B * N, Co, CF, _ptr(gwf))
+            else:
+                sl = next(d for d in (PER_POINT_DW_SLICES, 4, 2, 1) if N % d == 0)
+                gwf = torch.bmm(gA.reshape(B * sl, N // sl, -1).transpose(1, 2), feats.reshape(B * sl, N // sl, CF)).sum(0)
             gwx = gwx4[:, :3] if gwx4 is not None else torch.zeros_like(w[:, :3])
             gw = torch.cat([gwx, gwf], dim=1) if ctx.xyz_first else torch.cat([gwf, gwx], dim=1)
         return gfeats, gw, None, None
