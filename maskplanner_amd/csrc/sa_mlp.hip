@@ -3891,14 +3891,20 @@ static int sa_mlp_bwd(const float* x0, int64_t P, int64_t K, int n_layers, const
         } else if (grad_x0) {
             // only the first grad_x0_cols input channels need a gradient (the features; the centred coordinates that
             // follow them are not differentiated): skip the N tiles beyond them.  Rows of grad_x0 stay Ci apart.
-            int ncols = (grad_x0_cols > 0 && grad_x0_cols < Ci) ? (int)((grad_x0_cols + 3) / 4 * 4) : Ci;
+            // [r4] grad_x0_cols < 0: COMPACT -- grad_x0 is [P, -grad_x0_cols] (a multiple of 4), the gradient of the feature columns alone
+            // with nothing behind them (the caller differentiates the features, not the concatenated rows: no slice, no copy, no clear)
+            const bool compact = grad_x0_cols < 0;
+            const int64_t gcols = compact ? -grad_x0_cols : grad_x0_cols;
+            if (compact && ((gcols & 3) || gcols > Ci)) return MP_EINVAL;
+            int ncols = (gcols > 0 && gcols < Ci) ? (int)((gcols + 3) / 4 * 4) : Ci;
+            const int ldc = compact ? ncols : Ci;
             int rc;
             if (pooled)
-                rc = MP_POS_GEMM(SRC_DZ_POOLED, true, EPI_NONE, DZ, P, Ly.weight, ncols, Co, grad_x0, BnOut{nullptr, nullptr}, nullptr, nullptr, nullptr, stream, nullptr, PoolOut{}, Ci, Ci);
+                rc = MP_POS_GEMM(SRC_DZ_POOLED, true, EPI_NONE, DZ, P, Ly.weight, ncols, Co, grad_x0, BnOut{nullptr, nullptr}, nullptr, nullptr, nullptr, stream, nullptr, PoolOut{}, Ci, ldc);
             else
-                rc = MP_POS_GEMM(SRC_DZ, true, EPI_NONE, DZ, P, Ly.weight, ncols, Co, grad_x0, BnOut{nullptr, nullptr}, nullptr, nullptr, nullptr, stream, nullptr, PoolOut{}, Ci, Ci);
+                rc = MP_POS_GEMM(SRC_DZ, true, EPI_NONE, DZ, P, Ly.weight, ncols, Co, grad_x0, BnOut{nullptr, nullptr}, nullptr, nullptr, nullptr, stream, nullptr, PoolOut{}, Ci, ldc);
             if (rc != MP_OK) return rc;
-            if (ncols < Ci) {   // the columns that carry no gradient: defined (zero), so that no consumer can read garbage
+            if (!compact && ncols < Ci) {   // the columns that carry no gradient: defined (zero), so that no consumer can read garbage
                 hipLaunchKernelGGL(zero_cols_kernel, dim3((unsigned)((P * (Ci - ncols) + 255) / 256)), dim3(256), 0, stream, grad_x0, P, Ci, ncols);
                 MP_CHECK_LAUNCH();
             }

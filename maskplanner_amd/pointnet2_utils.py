@@ -234,6 +234,7 @@ class PointNetSetAbstraction(nn.Module):
         # internal channel order: features first, coordinates last, rows padded to a multiple of 4 floats (sa_mlp.py)
         # derived from the branch sample_and_group actually takes: `points` wins over `full_points` (:136-141)
         layout = "feats_first" if points is not None else "xyz_first"
+        grad_to = None
         if self.group_all:
             B, N, C = xyz.shape
             new_xyz = _zeros((B, 1, C), xyz.device)
@@ -241,7 +242,10 @@ class PointNetSetAbstraction(nn.Module):
                 grouped = xyz.view(B, 1, N, C)
             else:
                 pad = (-(C + points.shape[2])) % 4
-                parts = [points, xyz] + ([_zeros((B, N, pad), xyz.device)] if pad else [])
+                # (assembled outside autograd: the level's backward hands the gradient of `points` back compact -- no slice of the
+                # concatenated rows' gradient, no copy to make it contiguous, no clear of the coordinate columns)
+                grad_to = points if (points.requires_grad and torch.is_grad_enabled() and points.shape[2] % 4 == 0) else None
+                parts = [points.detach() if grad_to is not None else points, xyz] + ([_zeros((B, N, pad), xyz.device)] if pad else [])
                 grouped = torch.cat(parts, dim=-1).view(B, 1, N, -1)
         elif (points is not None and full_points is None and sa_mlp.FACTORED_FIRST in ("1", True)
               and sa_mlp.factored_supported(points, self.nsample, self.mlp_convs, self.mlp_bns, self.mlp_dtype, self.sync_bn)):
@@ -253,7 +257,8 @@ class PointNetSetAbstraction(nn.Module):
         else:
             new_xyz, grouped = sample_and_group(self.npoint, self.radius, self.nsample, xyz, points,
                                                 full_points=full_points, _pad_to=4, _xyz_last=True)
-        new_points = sa_mlp.shared_mlp_max(grouped, self.mlp_convs, self.mlp_bns, layout=layout, dtype=self.mlp_dtype, sync_bn=self.sync_bn)  # [B,S,C']
+        new_points = sa_mlp.shared_mlp_max(grouped, self.mlp_convs, self.mlp_bns, layout=layout, dtype=self.mlp_dtype, sync_bn=self.sync_bn,
+                                           grad_to=grad_to)  # [B,S,C']
         return new_xyz.permute(0, 2, 1), new_points.permute(0, 2, 1)
 
 

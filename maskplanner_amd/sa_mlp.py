@@ -70,7 +70,7 @@ class _SharedMLPMax(torch.autograd.Function):
     weight[Co,Ci], bias|None, gamma, beta, running_mean|None, running_var|None."""
 
     @staticmethod
-    def forward(ctx, x, K, training, momentum, eps, n_layers, grad_cols, bf16, sync_group, states, *params):
+    def forward(ctx, x, grad_to, K, training, momentum, eps, n_layers, grad_cols, bf16, sync_group, states, *params):
         dev = x.device
         P, C0 = x.shape
         layers = (_lib.MlpLayer * n_layers)()
@@ -121,6 +121,10 @@ class _SharedMLPMax(torch.autograd.Function):
                      float(eps), _ptr(out), _ptr(argk), _ptr(zmax), _ptr(ws), ws.numel())
         ctx.sync_group = sync_group
         ctx.meta = (P, K, bool(training), n_layers, chans, int(grad_cols), bool(bf16))
+        ctx.compact = grad_to is not None and grad_cols > 0 and grad_cols % 4 == 0 and grad_to.numel() == P * grad_cols
+        ctx.grad_to_shape = None if grad_to is None else tuple(grad_to.shape)
+        if grad_to is not None and not ctx.compact:
+            raise ValueError("grad_to needs a feats-first input whose feature width is a multiple of 4")
         ctx.keep = keep
         if ROUTE_TAP is not None:
             ROUTE_TAP.append((argk, [(k[6], k[7][2], k[7][3]) for k in keep]))
@@ -151,8 +155,15 @@ class _SharedMLPMax(torch.autograd.Function):
             dg, dbe = torch.empty_like(gam), torch.empty_like(bet)
             grads[l] = _lib.MlpGrads(_ptr(dw), _ptr(db), _ptr(dg), _ptr(dbe))
             ret += [dw, db, dg, dbe, None, None]
-        # with grad_cols only the leading (feature) columns carry a gradient; the library writes zeros into the others
-        gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        # with grad_cols only the leading (feature) columns carry a gradient; the library writes zeros into the others -- or, when the
+        # caller differentiates the FEATURES themselves (grad_to: x was assembled from them without autograd), nothing but those columns:
+        # a compact [P, grad_cols] gradient (grad_x0_cols < 0), no clear of the rest, no slice / copy downstream
+        compact = ctx.compact
+        if compact:
+            gx = torch.empty((P, grad_cols), dtype=torch.float32, device=dev) if ctx.needs_input_grad[1] else None
+            grad_cols = -grad_cols
+        else:
+            gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         ch = (ctypes.c_int64 * len(chans))(*chans)
         lib = _lib.load()
         ws = torch.empty((lib.mp_sa_mlp_workspace_bytes(P, K, n_layers, ch, 1),), dtype=torch.uint8, device=dev)
@@ -168,7 +179,9 @@ class _SharedMLPMax(torch.autograd.Function):
             ops._run("sa_mlp_bwd", x, lib.mp_sa_mlp_bwd_bf16 if bf16 else lib.mp_sa_mlp_bwd_f32, _ptr(x), P, K, n_layers, layers, int(training), _ptr(grad_out),
                      _ptr(out), _ptr(argk), _ptr(zmax), grads, _ptr(gx), grad_cols, _ptr(ws), ws.numel())
         ctx.keep = None
-        return (gx, None, None, None, None, None, None, None, None, None, *ret)
+        if compact:
+            return (None, None if gx is None else gx.view(ctx.grad_to_shape), None, None, None, None, None, None, None, None, None, *ret)
+        return (gx, None, None, None, None, None, None, None, None, None, None, *ret)
 
 
 class _SharedMLPMaxFactored(torch.autograd.Function):
@@ -502,7 +515,7 @@ def _first_weight_perm(cin, cpad, rotate, device):
     return _PERMS[key]
 
 
-def shared_mlp_max(grouped, convs, bns, layout="xyz_first", dtype="f32", sync_bn=None):
+def shared_mlp_max(grouped, convs, bns, layout="xyz_first", dtype="f32", sync_bn=None, grad_to=None):
     """grouped [B,S,K,C (+ zero padding up to a multiple of 4)] -> [B,S,Cout] = max_K relu(bn(conv(.))) chained over the
     layers (fused HIP path).
 
@@ -514,7 +527,9 @@ def shared_mlp_max(grouped, convs, bns, layout="xyz_first", dtype="f32", sync_bn
                       drops the near-empty second 128-column tile of a 131-channel input.
     The kernels work on float4 channel groups: an input with C % 4 != 0 is zero-padded here.
     dtype "bf16": the contractions run on the bf16 matrix cores (operands rounded to bf16 as they are staged, fp32 accumulation;
-    stored activations, BatchNorm, pooling and all outputs stay fp32) -- mp_sa_mlp_{fwd,bwd}_bf16."""
+    stored activations, BatchNorm, pooling and all outputs stay fp32) -- mp_sa_mlp_{fwd,bwd}_bf16.
+    grad_to ("feats_first" only): the feature tensor [B, S*K, Cin-3] that `grouped` was assembled from WITHOUT autograd (the caller
+    detached it): its gradient comes back compact and contiguous instead of as the leading columns of grouped's."""
     if dtype not in ("f32", "bf16"):
         raise ValueError("dtype must be 'f32' or 'bf16'")
     # sync_bn: None / False = per-replica statistics; True or a process group = train-mode statistics over that group's ranks
@@ -564,7 +579,7 @@ def shared_mlp_max(grouped, convs, bns, layout="xyz_first", dtype="f32", sync_bn
     grad_cols = cin - 3 if (layout == "feats_first" and cin > 3) else 0
     writeback = _widen_interior(params, [c.out_channels for c in convs]) if (sync_group is False and WIDEN_INTERIOR) else []
     states = [bn_state(bn, params[6 * i].shape[0]) for i, bn in enumerate(bns)] if (training and sync_group is False and BN_FUSED) else None
-    out = _SharedMLPMax.apply(x, K, training, momentum, bn0.eps, len(convs), grad_cols, dtype == "bf16", sync_group, states, *params)
+    out = _SharedMLPMax.apply(x, grad_to, K, training, momentum, bn0.eps, len(convs), grad_cols, dtype == "bf16", sync_group, states, *params)
     if training:
         for dst, src in writeback:          # running statistics of the real channels back into the module's buffers
             dst.copy_(src[:dst.numel()])
