@@ -453,6 +453,35 @@ int mp_dw_gemm_f32(const float* dz, const float* x, int64_t P, int64_t Co, int64
  *   backward (bn blocks): dz [B, O] = gradient at the Linear's output (the factor of dW = dz^T x), grad_gamma / grad_beta [O] (or NULL),
  *   grad_x [B, I] = dz W; with mp_head_block_bwd_slices(O) > 1 the row slices of W add their tiles with atomics (summation order not
  *   fixed) into a grad_x the call clears first (unless it lies in the armed zero arena).  O <= 4096, I % 64 == 0. */
+typedef struct {
+    /* forward */
+    const float* x;          /* [B, I] */
+    const float* weight;     /* [O, I] */
+    const float* bias;       /* [O] or NULL */
+    int64_t O;
+    int bn, training;        /* bn == 0: plain Linear (y only) */
+    double momentum, eps;
+    const float* gamma;
+    const float* beta;
+    float* running_mean;
+    float* running_var;
+    float* z;                /* [B, O] the Linear's output (bn blocks; kept for the backward) */
+    float* y;                /* [B, O] */
+    float* save_mean;        /* [O] */
+    float* save_rstd;        /* [O] */
+    double drop_p;
+    const int64_t* rng;      /* device (seed, step) or NULL */
+    int layer;
+    /* backward (bn blocks) */
+    const float* grad_y;     /* [B, O] */
+    float* dz;               /* [B, O] */
+    float* grad_gamma;       /* [O] or NULL */
+    float* grad_beta;        /* [O] or NULL */
+    float* grad_x;           /* [B, I]; two blocks of one call may name the SAME buffer: their contributions add (no fan-out add) */
+} mp_head_block_t;
+/* n = 1 or 2 blocks (same B and I) in ONE launch: the two branches of the heads advance side by side (fc1 / sm_fc1, fc2 / sm_fc2) */
+int mp_head_blocks_fwd_f32(int n, const mp_head_block_t* blocks, int64_t B, int64_t I, mp_stream_t stream);
+int mp_head_blocks_bwd_f32(int n, const mp_head_block_t* blocks, int64_t B, int64_t I, mp_stream_t stream);
 int mp_head_block_supported(int64_t B, int64_t I, int64_t O);
 int mp_head_block_fwd_f32(const float* x, const float* weight, const float* bias, int64_t B, int64_t I, int64_t O, int bn, int training,
                           double momentum, double eps, const float* gamma, const float* beta, float* running_mean, float* running_var,

@@ -33,6 +33,14 @@ class MlpLayer(ctypes.Structure):
                 ("scale", _vp), ("shift", _vp), ("bn_state", _vp)]
 
 
+class HeadBlock(ctypes.Structure):
+    """mp_head_block_t"""
+    _fields_ = [("x", _vp), ("weight", _vp), ("bias", _vp), ("O", _i64), ("bn", _int), ("training", _int), ("momentum", _dbl), ("eps", _dbl),
+                ("gamma", _vp), ("beta", _vp), ("running_mean", _vp), ("running_var", _vp), ("z", _vp), ("y", _vp), ("save_mean", _vp),
+                ("save_rstd", _vp), ("drop_p", _dbl), ("rng", _vp), ("layer", _int), ("grad_y", _vp), ("dz", _vp), ("grad_gamma", _vp),
+                ("grad_beta", _vp), ("grad_x", _vp)]
+
+
 class MlpGrads(ctypes.Structure):
     """mp_mlp_grads_t"""
     _fields_ = [("d_weight", _vp), ("d_bias", _vp), ("d_gamma", _vp), ("d_beta", _vp)]
@@ -94,6 +102,8 @@ SIGNATURES = {
     "mp_linear_dx_skinny_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "mp_linear_dx_skinny_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _sz, _vp]),
     "mp_dw_gemm_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp]),
+    "mp_head_blocks_fwd_f32": (_int, [_int, _vp, _i64, _i64, _vp]),
+    "mp_head_blocks_bwd_f32": (_int, [_int, _vp, _i64, _i64, _vp]),
     "mp_head_block_supported": (_int, [_i64, _i64, _i64]),
     "mp_head_block_fwd_f32": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _int, _int, _dbl, _dbl, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _dbl, _vp, _int, _vp]),
     "mp_head_linear2_fwd_f32": (_int, [_vp, _i64, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp]),

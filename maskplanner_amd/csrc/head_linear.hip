@@ -48,24 +48,30 @@ __device__ __forceinline__ float drop_keep(unsigned long long key, int r, int C,
 // [16 rows][k range] tiles row-contiguous (16 lanes per 256 bytes of a row), all of them up front, and turns each through a private
 // 4 KB LDS tile into the fragment layout (row stride CH + 4: both directions conflict-free, no barrier: a wave's LDS operations are
 // ordered).
-// Second set (plain Linear only): two Linears fed by the same x in one launch -- column tiles >= tiles0 belong to (W2, bias2, y2, O2).
-struct HeadSet2 {
+// One problem of a launch: y = [dropout(relu(bn(] x W^T + b [)))].  A launch carries up to two (same B and I): the column tiles of the
+// second follow the first's -- two blocks of the two head branches (fc1 / sm_fc1 on the global feature, fc2 / sm_fc2 on their outputs),
+// or two plain Linears fed by one activation (fc3 / fc_normals).
+struct HeadFwd {
+    const float* x;
     const float* W;
     const float* bias;
+    float* z;
     float* y;
-    int O, tiles0;
+    int O;
+    HeadBn bn;
 };
 
 template <int NJ>
-__global__ __launch_bounds__(HL_THREADS) void head_fwd_kernel(const float* __restrict__ x, const float* __restrict__ W_,
-                                                              const float* __restrict__ bias_, int B, int I, int O_, HeadBn bn,
-                                                              float* __restrict__ z, float* __restrict__ y_, HeadSet2 s2)
+__global__ __launch_bounds__(HL_THREADS) void head_fwd_kernel(HeadFwd pa, HeadFwd pb, int B, int I, int tiles_a)
 {
-    const bool second = s2.W != nullptr && (int)blockIdx.x >= s2.tiles0;
-    const float* __restrict__ W = second ? s2.W : W_;
-    const float* __restrict__ bias = second ? s2.bias : bias_;
-    float* __restrict__ y = second ? s2.y : y_;
-    const int O = second ? s2.O : O_;
+    const bool second = (int)blockIdx.x >= tiles_a;
+    const float* __restrict__ x = second ? pb.x : pa.x;
+    const float* __restrict__ W = second ? pb.W : pa.W;
+    const float* __restrict__ bias = second ? pb.bias : pa.bias;
+    float* __restrict__ z = second ? pb.z : pa.z;
+    float* __restrict__ y = second ? pb.y : pa.y;
+    const int O = second ? pb.O : pa.O;
+    const HeadBn bn = second ? pb.bn : pa.bn;
     constexpr int KW = 16 * NJ;                 // k range of a wave
     constexpr int CH = KW < 64 ? KW : 64;       // k per pass through the LDS tile
     constexpr int NCH = KW / CH;
@@ -76,7 +82,7 @@ __global__ __launch_bounds__(HL_THREADS) void head_fwd_kernel(const float* __res
     __shared__ float zt[32][17];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int l16 = lane & 15, q = lane >> 4;
-    const int o0 = ((int)blockIdx.x - (second ? s2.tiles0 : 0)) * 16;
+    const int o0 = ((int)blockIdx.x - (second ? tiles_a : 0)) * 16;
     const int lr = lane / LPR, lk = 4 * (lane % LPR);          // row / first k of this lane inside one load instruction
     const int k0 = wave * KW + lk;
     // the epilogue's per-column constants ride along with the operand requests (asked for after the products they would add a second
@@ -200,13 +206,40 @@ __global__ __launch_bounds__(HL_THREADS) void head_fwd_kernel(const float* __res
 constexpr int HB_OS = 256;
 constexpr int HB_LD = HB_OS + 4;      // row stride of the dz image: lane (row l16, k q) reads bank (4 l16 + q) -- conflict-free
 
-__global__ __launch_bounds__(HL_THREADS) void head_bwd_kernel(const float* __restrict__ grad_y, const float* __restrict__ y,
-                                                              const float* __restrict__ zin, const float* __restrict__ W, int B,
-                                                              int I, int O, int training, const float* __restrict__ gamma,
-                                                              const float* __restrict__ save_mean, const float* __restrict__ save_rstd,
-                                                              float keep_scale, float* __restrict__ dz, float* __restrict__ dgamma,
-                                                              float* __restrict__ dbeta, float* __restrict__ gx)
+struct HeadBwd {
+    const float* grad_y;
+    const float* y;
+    const float* z;
+    const float* W;
+    const float* gamma;
+    const float* save_mean;
+    const float* save_rstd;
+    float* dz;
+    float* dgamma;
+    float* dbeta;
+    float* gx;
+    int O, training;
+    float keep_scale;
+};
+
+// Up to two problems per launch (same B and I): the row slices of the second follow the first's in grid.y.  Their grad_x may be ONE buffer
+// (fc1 / sm_fc1 both read the global feature: no fan-out add) -- `atomic`: more than one slice adds into some grad_x.
+__global__ __launch_bounds__(HL_THREADS) void head_bwd_kernel(HeadBwd pa, HeadBwd pb, int B, int I, int slices_a, int atomic)
 {
+    const bool second = (int)blockIdx.y >= slices_a;
+    const float* __restrict__ grad_y = second ? pb.grad_y : pa.grad_y;
+    const float* __restrict__ y = second ? pb.y : pa.y;
+    const float* __restrict__ zin = second ? pb.z : pa.z;
+    const float* __restrict__ W = second ? pb.W : pa.W;
+    const float* __restrict__ gamma = second ? pb.gamma : pa.gamma;
+    const float* __restrict__ save_mean = second ? pb.save_mean : pa.save_mean;
+    const float* __restrict__ save_rstd = second ? pb.save_rstd : pa.save_rstd;
+    float* __restrict__ dz = second ? pb.dz : pa.dz;
+    float* __restrict__ dgamma = second ? pb.dgamma : pa.dgamma;
+    float* __restrict__ dbeta = second ? pb.dbeta : pa.dbeta;
+    float* __restrict__ gx = second ? pb.gx : pa.gx;
+    const int O = second ? pb.O : pa.O, training = second ? pb.training : pa.training;
+    const float keep_scale = second ? pb.keep_scale : pa.keep_scale;
     // LDS: the dz image + the column-sum exchange (49 KB) while dz is formed and multiplied, then -- behind a barrier -- the eight waves'
     // partial tiles (64 KB) over the same bytes.  (ds_add_f32 into one shared tile instead: ~200 cycles per instruction, 23 us.)
     __shared__ __attribute__((aligned(16))) float smem[16384];
@@ -215,7 +248,7 @@ __global__ __launch_bounds__(HL_THREADS) void head_bwd_kernel(const float* __res
     float (*part)[2][4][4][64] = reinterpret_cast<float (*)[2][4][4][64]>(smem);             // [HL_WAVES][2][4][4][64]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int l16 = lane & 15, q = lane >> 4;
-    const int i0 = blockIdx.x * 64, os = blockIdx.y * HB_OS;
+    const int i0 = blockIdx.x * 64, os = ((int)blockIdx.y - (second ? slices_a : 0)) * HB_OS;
     const int ow = os + wave * 32;
     // B operand: lane (n = l16, k = q) of step s: W[ow + 4 s + q][i0 + 4 l16 .. + 3]
     f32x4 wv[8];
@@ -316,7 +349,7 @@ __global__ __launch_bounds__(HL_THREADS) void head_bwd_kernel(const float* __res
             for (int w = 0; w < HL_WAVES; ++w)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] += part[w][t][e][r][ln];
-            if (gridDim.y == 1) *reinterpret_cast<f32x4*>(dst) = v;
+            if (!atomic) *reinterpret_cast<f32x4*>(dst) = v;
             else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) unsafeAtomicAdd(dst + e, v[e]);
@@ -333,22 +366,16 @@ extern "C" int mp_head_block_supported(int64_t B, int64_t I, int64_t O)
     return I == 128 || I == 256 || I == 512 || I == 1024 || I == 2048;
 }
 
-extern "C" int mp_head_block_fwd_f32(const float* x, const float* weight, const float* bias, int64_t B, int64_t I, int64_t O, int bn,
-                                     int training, double momentum, double eps, const float* gamma, const float* beta,
-                                     float* running_mean, float* running_var, float* z, float* y, float* save_mean, float* save_rstd,
-                                     double drop_p, const int64_t* rng, int layer, mp_stream_t stream_)
+static int head_fwd_launch(const HeadFwd& a, const HeadFwd* b, int64_t B, int64_t I, mp_stream_t stream_)
 {
-    if (!mp_head_block_supported(B, I, O)) return MP_EUNSUPPORTED;
-    if (!x || !weight || !y || drop_p < 0.0 || drop_p >= 1.0) return MP_EINVAL;
-    if (bn && (!save_mean || !save_rstd || (!training && (!running_mean || !running_var)))) return MP_EINVAL;
-    HeadBn h{bn, training, (float)momentum, (float)eps, (float)drop_p, gamma, beta, running_mean, running_var, save_mean, save_rstd,
-             reinterpret_cast<const long long*>(rng), layer};
-    const dim3 grid((unsigned)((O + 15) / 16));
+    const int tiles_a = (a.O + 15) / 16;
+    const dim3 grid((unsigned)(tiles_a + (b ? (b->O + 15) / 16 : 0)));
     hipStream_t stream = mp_stream(stream_);
-    const double flops = 2.0 * (double)B * (double)I * (double)O, bytes = 4.0 * ((double)I * (double)O + (double)B * (double)(I + 2 * O));
-    const HeadSet2 none{nullptr, nullptr, nullptr, 0, 0};
-#define HL_FWD(NJ) MP_LAUNCH("head_fwd_kernel", flops, bytes, head_fwd_kernel<NJ>, grid, dim3(HL_THREADS), 0, stream, x, weight, bias, \
-                             (int)B, (int)I, (int)O, h, z, y, none)
+    const double Ot = (double)a.O + (b ? (double)b->O : 0.0);
+    const double flops = 2.0 * (double)B * (double)I * Ot, bytes = 4.0 * ((double)I * Ot + (double)B * ((double)I + 2.0 * Ot));
+    const HeadFwd pb = b ? *b : a;
+#define HL_FWD(NJ) MP_LAUNCH("head_fwd_kernel", flops, bytes, head_fwd_kernel<NJ>, grid, dim3(HL_THREADS), 0, stream, a, pb, (int)B, (int)I, \
+                             b ? tiles_a : (1 << 30))
     switch (I) {
         case 128: HL_FWD(1); break;
         case 256: HL_FWD(2); break;
@@ -361,30 +388,45 @@ extern "C" int mp_head_block_fwd_f32(const float* x, const float* weight, const 
     return MP_OK;
 }
 
+static int head_fwd_set(const mp_head_block_t& h, int64_t B, int64_t I, HeadFwd& out)
+{
+    if (!mp_head_block_supported(B, I, h.O)) return MP_EUNSUPPORTED;
+    if (!h.x || !h.weight || !h.y || h.drop_p < 0.0 || h.drop_p >= 1.0) return MP_EINVAL;
+    if (h.bn && (!h.save_mean || !h.save_rstd || (!h.training && (!h.running_mean || !h.running_var)))) return MP_EINVAL;
+    out = HeadFwd{h.x, h.weight, h.bias, h.z, h.y, (int)h.O,
+                  HeadBn{h.bn, h.training, (float)h.momentum, (float)h.eps, (float)h.drop_p, h.gamma, h.beta, h.running_mean, h.running_var,
+                         h.save_mean, h.save_rstd, reinterpret_cast<const long long*>(h.rng), h.layer}};
+    return MP_OK;
+}
+
+extern "C" int mp_head_blocks_fwd_f32(int n, const mp_head_block_t* blocks, int64_t B, int64_t I, mp_stream_t stream_)
+{
+    if (n < 1 || n > 2 || !blocks) return MP_EINVAL;
+    HeadFwd s[2];
+    for (int k = 0; k < n; ++k)
+        if (int rc = head_fwd_set(blocks[k], B, I, s[k])) return rc;
+    return head_fwd_launch(s[0], n == 2 ? &s[1] : nullptr, B, I, stream_);
+}
+
+extern "C" int mp_head_block_fwd_f32(const float* x, const float* weight, const float* bias, int64_t B, int64_t I, int64_t O, int bn,
+                                     int training, double momentum, double eps, const float* gamma, const float* beta,
+                                     float* running_mean, float* running_var, float* z, float* y, float* save_mean, float* save_rstd,
+                                     double drop_p, const int64_t* rng, int layer, mp_stream_t stream_)
+{
+    mp_head_block_t h{};
+    h.x = x; h.weight = weight; h.bias = bias; h.O = O; h.bn = bn; h.training = training; h.momentum = momentum; h.eps = eps;
+    h.gamma = gamma; h.beta = beta; h.running_mean = running_mean; h.running_var = running_var; h.z = z; h.y = y;
+    h.save_mean = save_mean; h.save_rstd = save_rstd; h.drop_p = drop_p; h.rng = rng; h.layer = layer;
+    return mp_head_blocks_fwd_f32(1, &h, B, I, stream_);
+}
+
 extern "C" int mp_head_linear2_fwd_f32(const float* x, int64_t B, int64_t I, const float* w1, const float* b1, int64_t O1, float* y1,
                                        const float* w2, const float* b2, int64_t O2, float* y2, mp_stream_t stream_)
 {
-    if (!mp_head_block_supported(B, I, O1) || (w2 && !mp_head_block_supported(B, I, O2))) return MP_EUNSUPPORTED;
-    if (!x || !w1 || !y1 || (w2 && !y2)) return MP_EINVAL;
-    HeadBn h{};
-    const int tiles0 = (int)((O1 + 15) / 16);
-    const HeadSet2 s2{w2, b2, y2, (int)O2, tiles0};
-    const dim3 grid((unsigned)(tiles0 + (w2 ? (O2 + 15) / 16 : 0)));
-    hipStream_t stream = mp_stream(stream_);
-    const double Ot = (double)O1 + (w2 ? (double)O2 : 0.0);
-    const double flops = 2.0 * (double)B * (double)I * Ot, bytes = 4.0 * ((double)I * Ot + (double)B * ((double)I + Ot));
-#define HL_FWD(NJ) MP_LAUNCH("head_fwd_kernel", flops, bytes, head_fwd_kernel<NJ>, grid, dim3(HL_THREADS), 0, stream, x, w1, b1, (int)B, (int)I, \
-                             (int)O1, h, (float*)nullptr, y1, s2)
-    switch (I) {
-        case 128: HL_FWD(1); break;
-        case 256: HL_FWD(2); break;
-        case 512: HL_FWD(4); break;
-        case 1024: HL_FWD(8); break;
-        default: HL_FWD(16); break;
-    }
-#undef HL_FWD
-    MP_CHECK_LAUNCH();
-    return MP_OK;
+    mp_head_block_t h[2] = {};
+    h[0].x = x; h[0].weight = w1; h[0].bias = b1; h[0].O = O1; h[0].y = y1;
+    h[1].x = x; h[1].weight = w2; h[1].bias = b2; h[1].O = O2; h[1].y = y2;
+    return mp_head_blocks_fwd_f32(w2 ? 2 : 1, h, B, I, stream_);
 }
 
 // mp_head_block_bwd_slices(O) > 1: the row slices of W add their tiles into grad_x with atomics (summation order not fixed); the call
@@ -394,20 +436,45 @@ extern "C" int mp_head_block_bwd_slices(int64_t O)
     return (int)((O + HB_OS - 1) / HB_OS);
 }
 
+extern "C" int mp_head_blocks_bwd_f32(int n, const mp_head_block_t* blocks, int64_t B, int64_t I, mp_stream_t stream_)
+{
+    if (n < 1 || n > 2 || !blocks) return MP_EINVAL;
+    if (B < 1 || B > 32 || I < 64 || I % 64 != 0) return MP_EUNSUPPORTED;
+    HeadBwd s[2];
+    int slices[2] = {0, 0};
+    double Ot = 0.0;
+    for (int k = 0; k < n; ++k) {
+        const mp_head_block_t& h = blocks[k];
+        if (h.O < 4 || h.O % 4 != 0 || h.O > 4096) return MP_EUNSUPPORTED;
+        if (!h.grad_y || !h.y || !h.z || !h.weight || !h.save_mean || !h.save_rstd || !h.dz || !h.grad_x || h.drop_p < 0.0 || h.drop_p >= 1.0)
+            return MP_EINVAL;
+        s[k] = HeadBwd{h.grad_y, h.y, h.z, h.weight, h.gamma, h.save_mean, h.save_rstd, h.dz, h.grad_gamma, h.grad_beta, h.grad_x, (int)h.O,
+                       h.training, (float)(1.0 / (1.0 - h.drop_p))};
+        slices[k] = mp_head_block_bwd_slices(h.O);
+        Ot += (double)h.O;
+    }
+    const bool shared = n == 2 && blocks[0].grad_x == blocks[1].grad_x;
+    const int atomic = (slices[0] > 1 || slices[1] > 1 || shared) ? 1 : 0;
+    hipStream_t stream = mp_stream(stream_);
+    if (atomic) {
+        if (!mp::zero_async(blocks[0].grad_x, (size_t)(B * I), stream)) return MP_ELAUNCH;     // (nothing to do inside an armed zero arena)
+        if (n == 2 && !shared && !mp::zero_async(blocks[1].grad_x, (size_t)(B * I), stream)) return MP_ELAUNCH;
+    }
+    const dim3 grid((unsigned)(I / 64), (unsigned)(slices[0] + slices[1]));
+    const double flops = 2.0 * (double)B * (double)I * Ot, bytes = 4.0 * ((double)I * Ot + (double)B * ((double)I + 4.0 * Ot));
+    MP_LAUNCH("head_bwd_kernel", flops, bytes, head_bwd_kernel, grid, dim3(HL_THREADS), 0, stream, s[0], n == 2 ? s[1] : s[0], (int)B, (int)I,
+              n == 2 ? slices[0] : (1 << 30), atomic);
+    MP_CHECK_LAUNCH();
+    return MP_OK;
+}
+
 extern "C" int mp_head_block_bwd_f32(const float* grad_y, const float* y, const float* z, const float* weight, int64_t B, int64_t I,
                                      int64_t O, int training, const float* gamma, const float* save_mean, const float* save_rstd,
                                      double drop_p, float* dz, float* grad_gamma, float* grad_beta, float* grad_x, mp_stream_t stream_)
 {
-    if (B < 1 || B > 32 || I < 64 || I % 64 != 0 || O < 4 || O % 4 != 0 || O > 4096) return MP_EUNSUPPORTED;
-    if (!grad_y || !y || !z || !weight || !save_mean || !save_rstd || !dz || !grad_x || drop_p < 0.0 || drop_p >= 1.0) return MP_EINVAL;
-    const int slices = mp_head_block_bwd_slices(O);
-    const dim3 grid((unsigned)(I / 64), (unsigned)slices);
-    hipStream_t stream = mp_stream(stream_);
-    if (slices > 1 && !mp::zero_async(grad_x, (size_t)(B * I), stream)) return MP_ELAUNCH;     // (nothing to do inside an armed zero arena)
-    const float ks = (float)(1.0 / (1.0 - drop_p));
-    const double flops = 2.0 * (double)B * (double)I * (double)O, bytes = 4.0 * ((double)I * (double)O + (double)B * (double)(I + 4 * O));
-    MP_LAUNCH("head_bwd_kernel", flops, bytes, head_bwd_kernel, grid, dim3(HL_THREADS), 0, stream, grad_y, y, z, weight, (int)B, (int)I,
-              (int)O, training, gamma, save_mean, save_rstd, ks, dz, grad_gamma, grad_beta, grad_x);
-    MP_CHECK_LAUNCH();
-    return MP_OK;
+    mp_head_block_t h{};
+    h.grad_y = grad_y; h.y = const_cast<float*>(y); h.z = const_cast<float*>(z); h.weight = weight; h.O = O; h.training = training; h.gamma = gamma;
+    h.save_mean = const_cast<float*>(save_mean); h.save_rstd = const_cast<float*>(save_rstd); h.drop_p = drop_p; h.dz = dz;
+    h.grad_gamma = grad_gamma; h.grad_beta = grad_beta; h.grad_x = grad_x;
+    return mp_head_blocks_bwd_f32(1, &h, B, I, stream_);
 }

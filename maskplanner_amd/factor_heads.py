@@ -141,6 +141,114 @@ class _HeadBlock(torch.autograd.Function):
         return (gx, gw, gb, gg, gbeta) + (None,) * 10
 
 
+def _bn_args(bn):
+    training = bn.training or bn.running_mean is None
+    track = bn.track_running_stats and bn.running_mean is not None
+    momentum = bn.momentum if bn.momentum is not None else 1.0 / max(float(bn.num_batches_tracked), 1.0)
+    return training, momentum, (bn.running_mean if track else None), (bn.running_var if track else None)
+
+
+class _HeadBlocks2(torch.autograd.Function):
+    """Two head blocks in one launch each way (mp_head_blocks_{fwd,bwd}_f32): the blocks of the two head branches that stand side by side
+    in the network -- fc1 / sm_fc1 (both read the global feature: xb None, ONE grad_x, no fan-out add) and fc2 / sm_fc2 (each its own
+    input).  Otherwise as _HeadBlock."""
+
+    @staticmethod
+    def forward(ctx, xa, xb, wa, ba, ga, bea, rma, rva, wb, bb, gb, beb, rmb, rvb, meta):
+        shared = xb is None
+        B, I = xa.shape
+        dev = xa.device
+        blocks = (_lib.HeadBlock * 2)()
+        outs = []
+        p = ops._p
+        rng = meta["rng"]
+        for k, (x, w, b, g, be, rm, rv) in enumerate(((xa, wa, ba, ga, bea, rma, rva), (xa if shared else xb, wb, bb, gb, beb, rmb, rvb))):
+            O = w.shape[0]
+            z = torch.empty((B, O), dtype=torch.float32, device=dev)
+            y = torch.empty((B, O), dtype=torch.float32, device=dev)
+            stats = torch.empty((2, O), dtype=torch.float32, device=dev)
+            training, momentum, eps, layer = meta["bn"][k]
+            blocks[k] = _lib.HeadBlock(p(x), p(w), p(b), O, 1, int(training), float(momentum), float(eps), p(g), p(be), p(rm), p(rv), p(z), p(y),
+                                       stats[0].data_ptr(), stats[1].data_ptr(), float(meta["drop_p"]) if rng is not None else 0.0, p(rng), int(layer),
+                                       None, None, None, None, None)
+            outs.append((z, y, stats))
+        ops._run("head_blocks", xa, _lib.load().mp_head_blocks_fwd_f32, 2, blocks, B, I)
+        (za, ya, sa), (zb, yb, sb) = outs
+        ctx.save_for_backward(xa, xb, wa, wb, za, ya, sa, zb, yb, sb, ga, gb)
+        ctx.biases = (ba, bb)
+        ctx.meta = meta
+        return ya, yb
+
+    @staticmethod
+    def backward(ctx, gya, gyb):
+        xa, xb, wa, wb, za, ya, sa, zb, yb, sb, ga, gb = ctx.saved_tensors
+        meta = ctx.meta
+        shared = xb is None
+        B, I = xa.shape
+        dev = xa.device
+        lib = _lib.load()
+        p = ops._p
+        store = meta["store"]
+        drop_p = float(meta["drop_p"]) if meta["rng"] is not None else 0.0
+        blocks = (_lib.HeadBlock * 2)()
+        gx_a = ops.zeroed_empty((B, I), torch.float32, dev)
+        gx_b = gx_a if shared else ops.zeroed_empty((B, I), torch.float32, dev)
+        res = []
+        for k, (x, w, z, y, st, g, gy, gx) in enumerate(((xa, wa, za, ya, sa, ga, gya, gx_a), (xa if shared else xb, wb, zb, yb, sb, gb, gyb, gx_b))):
+            O = w.shape[0]
+            gy = gy.contiguous().float()
+            dz = torch.empty((B, O), dtype=torch.float32, device=dev)
+            gg = torch.empty((O,), dtype=torch.float32, device=dev) if g is not None else None
+            gbeta = torch.empty((O,), dtype=torch.float32, device=dev)
+            training = meta["bn"][k][0]
+            blocks[k] = _lib.HeadBlock(None, p(w), None, O, 1, int(training), 0.0, 0.0, p(g), None, None, None, p(z), p(y), st[0].data_ptr(),
+                                       st[1].data_ptr(), drop_p, None, 0, p(gy), p(dz), p(gg), p(gbeta), p(gx))
+            res.append((x, w, dz, gg, gbeta, gy))
+        ops._run("head_blocks_bwd", xa, lib.mp_head_blocks_bwd_f32, 2, blocks, B, I)
+        out = []
+        pending = store.get(BIAS_QUEUE) if store is not None else None
+        for k, (x, w, dz, gg, gbeta, _gy) in enumerate(res):
+            gw = gb_ = None
+            key = meta["keys"][k]
+            if store is not None and key is not None:
+                store[key] = (x.detach(), dz)
+            else:
+                gw = torch.empty_like(w)
+                ops._run("linear_dw_outer", dz, lib.mp_linear_dw_outer_f32, p(dz), p(x), B, w.shape[0], I, p(gw))
+            if ctx.biases[k] is not None:
+                if pending is not None:
+                    pending.append((ctx.biases[k], dz))
+                else:
+                    gb_ = dz.sum(0)
+            out.append((gw, gb_, gg, gbeta))
+        (gwa, gba, gga, gbea), (gwb, gbb, ggb, gbeb) = out
+        return (gx_a, None if shared else gx_b, gwa, gba, gga, gbea, None, None, gwb, gbb, ggb, gbeb, None, None, None)
+
+
+def head_blocks2_ok(xa, xb, lin_a, bn_a, lin_b, bn_b):
+    """The two blocks can share launches: each qualifies alone (head_block_ok), same input width, widths the backward kernel tiles."""
+    if ops.DETERMINISTIC or not head_block_ok(xa, lin_a, bn_a) or not head_block_ok(xa if xb is None else xb, lin_b, bn_b):
+        return False
+    wa, wb = lin_a.weight, lin_b.weight
+    return (wa.shape[1] == wb.shape[1] and wa.shape[1] % 64 == 0 and all(w.shape[0] % 4 == 0 and w.shape[0] <= 4096 for w in (wa, wb))
+            and (xb is None or xb.shape == xa.shape))
+
+
+def head_blocks2(xa, xb, lin_a, bn_a, lin_b, bn_b, store, key_a, key_b, drop=None, layers=(0, 0)):
+    """(relu(bn_a(lin_a(xa))), relu(bn_b(lin_b(xb)))) -- xb None: both read xa -- in one launch each way; drop = (p, rng): the nn.Dropout
+    behind both blocks in the same launch (mask layers `layers`).  Check head_blocks2_ok first."""
+    ta, ma, rma, rva = _bn_args(bn_a)
+    tb, mb, rmb, rvb = _bn_args(bn_b)
+    p, rng = drop if drop is not None else (0.0, None)
+    meta = dict(bn=((ta, ma, bn_a.eps, layers[0]), (tb, mb, bn_b.eps, layers[1])), drop_p=p, rng=rng, store=store, keys=(key_a, key_b))
+    ya, yb = _HeadBlocks2.apply(xa, xb, lin_a.weight, lin_a.bias, bn_a.weight, bn_a.bias, rma, rva,
+                                lin_b.weight, lin_b.bias, bn_b.weight, bn_b.bias, rmb, rvb, meta)
+    if ops.RELU_TAP is not None:
+        ops.RELU_TAP.append(ya.detach() > 0)
+        ops.RELU_TAP.append(yb.detach() > 0)
+    return ya, yb
+
+
 def head_block_ok(x, linear, bn):
     """The one-launch block applies: fp32 [B <= 32, I] on the GPU, contiguous fp32 parameters, a width csrc/head_linear.hip tiles, and
     BatchNorm statistics local to this process."""

@@ -15,7 +15,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops, sa_mlp
-from .factor_heads import factor_linear, factor_linear2, head_block, head_block_ok
+from .factor_heads import factor_linear, factor_linear2, head_block, head_block_ok, head_blocks2, head_blocks2_ok
 
 SAMPLE_AHEAD = True      # False (tests): every level samples in line
 from .pointnet2_utils import PointNetSetAbstraction, PointNetSetAbstractionMsg
@@ -246,8 +246,25 @@ class PointNet2Regressor_StrokeMasks(_SSGEncoder):
         fused = feat.is_cuda
         if fused:
             _tick(*([self.bn1, self.bn2] + ([self.sm_bn1, self.sm_bn2] if self.pred_stroke_masks else [])))
-        x = _head_block(self, feat, self.fc1, self.bn1, fs, "fc1.weight", 0)
-        final = _head_block(self, x, self.fc2, self.bn2, fs, "fc2.weight", 1)
+        # [r4] the pose branch and the stroke-mask branch advance side by side: fc1 / sm_fc1 (both on the global feature) and fc2 / sm_fc2
+        # are one launch each way per pair (factor_heads.head_blocks2); the statements below keep the reference's order otherwise
+        paired = (HEAD_BLOCK and self.pred_stroke_masks and head_blocks2_ok(feat, None, self.fc1, self.bn1, self.sm_fc1, self.sm_bn1)
+                  and self.fc2.weight.shape == self.sm_fc2.weight.shape and self.fc1.weight.shape[0] == self.sm_fc1.weight.shape[0])
+        s2 = None
+        if paired:
+            rng = getattr(self, "fused_dropout", None)
+            drop = (self.dropout.p, rng) if (rng is not None and self.training and self.bn1.training) else None
+            post = (lambda t: t) if drop is not None else self.dropout
+            x, s1 = head_blocks2(feat, None, self.fc1, self.bn1, self.sm_fc1, self.sm_bn1, fs, "fc1.weight", "sm_fc1.weight", drop, (0, 2))
+            x, s1 = post(x), post(s1)
+            if head_blocks2_ok(x, s1, self.fc2, self.bn2, self.sm_fc2, self.sm_bn2):
+                final, s2 = head_blocks2(x, s1, self.fc2, self.bn2, self.sm_fc2, self.sm_bn2, fs, "fc2.weight", "sm_fc2.weight", drop, (1, 3))
+                final, s2 = post(final), post(s2)
+            else:
+                final = _head_block(self, x, self.fc2, self.bn2, fs, "fc2.weight", 1)
+        else:
+            x = _head_block(self, feat, self.fc1, self.bn1, fs, "fc1.weight", 0)
+            final = _head_block(self, x, self.fc2, self.bn2, fs, "fc2.weight", 1)
         # (the order of the launches follows the reference's statements; fc3 and fc_normals read the same activation: one launch)
         if self.outdim_orient > 0:
             x, raw_normals = factor_linear2(final, self.fc3, self.fc_normals, fs, "fc3.weight", "fc_normals.weight")
@@ -262,8 +279,10 @@ class PointNet2Regressor_StrokeMasks(_SSGEncoder):
 
         sm_out, mask_conf = None, None
         if self.pred_stroke_masks:
-            s1 = _head_block(self, feat, self.sm_fc1, self.sm_bn1, fs, "sm_fc1.weight", 2)
-            s2 = _head_block(self, s1, self.sm_fc2, self.sm_bn2, fs, "sm_fc2.weight", 3)
+            if not paired:
+                s1 = _head_block(self, feat, self.sm_fc1, self.sm_bn1, fs, "sm_fc1.weight", 2)
+            if s2 is None:
+                s2 = _head_block(self, s1, self.sm_fc2, self.sm_bn2, fs, "sm_fc2.weight", 3)
             if self.mask_confidence_scores:     # (sm_fc3 and the confidence layer read the same activation: one launch each way)
                 sm_out, mask_conf = factor_linear2(s2, self.sm_fc3, getattr(self, self._CONF_LAYER), fs, "sm_fc3.weight", None)
             else:

@@ -447,6 +447,9 @@ class _PermuteColsMulti(torch.autograd.Function):
         _permute_multi(srcs, perms, [s_.shape[1] for s_ in srcs], dsts)
         ctx.save_for_backward(*perms, *invs)
         ctx.n = n
+        # an output no level picked up (the factorised first layer reads its weight in the module's own column order) must come back as
+        # None, not as a materialised zero: that was a fill, a wasted row of the gradient launch and an add onto the real gradient
+        ctx.set_materialize_grads(False)
         return tuple(dsts)
 
     @staticmethod

@@ -184,3 +184,39 @@ def test_two_linears_second_one_dense(ops):
     assert _rel(l2.weight.grad, w2.grad) <= 1e-6
     fh.flush_bias_grads(st)
     assert _rel(l2.bias.grad, g2.double().sum(0)) <= 1e-6
+
+
+@pytest.mark.parametrize("shared", [True, False])
+@pytest.mark.parametrize("B,I,O", [(32, 1024, 1024), (6, 128, 512)])
+def test_two_blocks_in_one_launch(ops, shared, B, I, O):
+    """factor_heads.head_blocks2 (fc1 / sm_fc1 on one input, fc2 / sm_fc2 on two) against the two single-block calls: identical outputs
+    and statistics (the same kernel code per column tile), gradients to fp32 summation order, ONE grad_x for a shared input."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from maskplanner_amd import factor_heads as fh
+    la, bna = _modules(I, O, 11)
+    lb, bnb = _modules(I, O, 12)
+    la2, bna2 = _modules(I, O, 11)
+    lb2, bnb2 = _modules(I, O, 12)
+    rng = torch.tensor([99, 3], dtype=torch.int64, device="cuda")
+    xa = torch.randn(B, I, device="cuda")
+    xb = None if shared else torch.randn(B, I, device="cuda")
+    xa1, xa2 = xa.clone().requires_grad_(True), xa.clone().requires_grad_(True)
+    xb1 = None if shared else xb.clone().requires_grad_(True)
+    xb2 = None if shared else xb.clone().requires_grad_(True)
+    assert fh.head_blocks2_ok(xa1, xb1, la, bna, lb, bnb)
+    st1, st2 = {fh.BIAS_QUEUE: []}, {fh.BIAS_QUEUE: []}
+    ya, yb = fh.head_blocks2(xa1, xb1, la, bna, lb, bnb, st1, "a", "b", (0.3, rng), (0, 2))
+    ra = fh.head_block(xa2, la2, bna2, st2, "a", dropout=(0.3, rng, 0))
+    rb = fh.head_block(xa2 if shared else xb2, lb2, bnb2, st2, "b", dropout=(0.3, rng, 2))
+    assert torch.equal(ya, ra) and torch.equal(yb, rb)
+    assert torch.equal(bna.running_var, bna2.running_var) and torch.equal(bnb.running_mean, bnb2.running_mean)
+    ga, gb = torch.randn(B, O, device="cuda"), torch.randn(B, O, device="cuda")
+    torch.autograd.backward([ya, yb], [ga, gb])
+    torch.autograd.backward([ra, rb], [ga, gb])
+    assert _rel(xa1.grad, xa2.grad) <= 2e-6
+    if not shared:
+        assert _rel(xb1.grad, xb2.grad) <= 2e-6
+    for k in ("a", "b"):
+        assert torch.equal(st1[k][1], st2[k][1])            # dz: the same arithmetic per column
+    assert torch.equal(bna.weight.grad, bna2.weight.grad) and torch.equal(bnb.bias.grad, bnb2.bias.grad)
