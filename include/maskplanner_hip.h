@@ -142,6 +142,13 @@ int mp_knn_bwd_f32(const float* p1, const float* p2, const int64_t* len1, const 
 size_t mp_knn1_workspace_bytes(int64_t B, int64_t P2, int64_t D);   /* 16-byte aligned device bytes for the screened search; 0 = not available */
 int mp_knn1_f32(const float* p1, const float* p2, const int64_t* len1, const int64_t* len2, int64_t B, int64_t P1, int64_t P2,
                 int64_t D, float* dists, int64_t* idx, int screened, void* workspace, size_t workspace_bytes, mp_stream_t stream);
+/* [r4] the screened search in two calls, for references that many searches share (a batch's ground-truth segments: prepared once per
+ * batch, off the step's stream): mp_knn1_prepare_f32 fills the workspace (planes + norms of p2 under len2), mp_knn1_prepared_f32 searches
+ * against it -- p2 / len2 unchanged in between.  Outputs identical to mp_knn_f32. */
+int mp_knn1_prepare_f32(const float* p2, const int64_t* len2, int64_t B, int64_t P2, int64_t D, void* workspace, size_t workspace_bytes,
+                        mp_stream_t stream);
+int mp_knn1_prepared_f32(const float* p1, const float* p2, const int64_t* len1, const int64_t* len2, int64_t B, int64_t P1, int64_t P2,
+                         int64_t D, float* dists, int64_t* idx, const void* workspace, size_t workspace_bytes, mp_stream_t stream);
 /* The backward of K = 1 distances that went straight into mp_chamfer_reduce_f32 (one loss term = nearest neighbours + reduction,
  * pytorch3d_chamfer.py:257-334): grad_out is the gradient of the REDUCED value ([1], or [B] when batch_mode == 0) and the per-row
  * factor scale / div / len1[b] is applied inside the scatter -- no [B,P1] gradient tensor, no mp_chamfer_reduce_bwd_f32 launch. */

@@ -95,6 +95,8 @@ SIGNATURES = {
     "mp_knn1_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "mp_knn1_f32": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _int, _vp, _sz, _vp]),
     "mp_knn_bwd_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _int, _vp]),
+    "mp_knn1_prepare_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _sz, _vp]),
+    "mp_knn1_prepared_f32": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _sz, _vp]),
     "mp_knn_bwd_reduced_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _dbl, _dbl, _i64, _i64, _i64, _i64, _vp, _vp, _int, _vp]),
     "mp_padded_lengths_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _vp]),
     "mp_mask_match_f32": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),

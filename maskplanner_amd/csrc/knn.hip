@@ -661,15 +661,18 @@ inline size_t knn1_screen_ws(int64_t B, int64_t P2, int64_t D)
 
 template <int D>
 int launch_knn1_screen(const float* p1, const float* p2, const int64_t* len1, const int64_t* len2, int B, int P1, int P2,
-                       float* dists, int64_t* idx, void* ws, size_t ws_bytes, hipStream_t stream)
-{
+                       float* dists, int64_t* idx, void* ws, size_t ws_bytes, hipStream_t stream, int phases = 3)
+{   // phases: 1 = the references' planes + norms into ws only, 2 = the search against a ws prepared by an earlier phase-1 call, 3 = both
     constexpr int DPAD = (D + 7) & ~7;
     if (!ws || ws_bytes < knn1_screen_ws(B, P2, D) || (reinterpret_cast<uintptr_t>(ws) & 15)) return MP_EINVAL;
     const int P2pad = (P2 + KS_RT - 1) / KS_RT * KS_RT;
     __bf16* planes = reinterpret_cast<__bf16*>(ws);
     float* norms = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + (size_t)B * P2pad * 3 * DPAD * 2);
-    hipLaunchKernelGGL((knn_planes_kernel<D>), dim3((P2pad + 255) / 256, B), dim3(256), 0, stream, p2, len2, P2, P2pad, planes, norms);
-    MP_CHECK_LAUNCH();
+    if (phases & 1) {
+        hipLaunchKernelGGL((knn_planes_kernel<D>), dim3((P2pad + 255) / 256, B), dim3(256), 0, stream, p2, len2, P2, P2pad, planes, norms);
+        MP_CHECK_LAUNCH();
+    }
+    if (!(phases & 2)) return MP_OK;
     char tag[48];
     snprintf(tag, sizeof tag, "knn1_screen_kernel<%d>", D);
     const double flops = 3.0 * D * (double)B * P1 * P2, bytes = (double)B * ((P1 + P2) * 4.0 * D + P1 * 12.0);
@@ -873,6 +876,39 @@ extern "C" int mp_knn_f32(const float* p1, const float* p2, const int64_t* len1,
     if (k == 2) return dispatch_d<2>(p1, p2, len1, len2, b, n1, n2, d, k, dists, idx, stream);
     if (k <= 4) return dispatch_d<4>(p1, p2, len1, len2, b, n1, n2, d, k, dists, idx, stream);
     return dispatch_d<8>(p1, p2, len1, len2, b, n1, n2, d, k, dists, idx, stream);
+}
+
+// The screened K = 1 search in two calls, for references that stay the same over many searches (the ground-truth segments of a batch:
+// their planes are prepared once per batch, off the training step's own stream): phase 1 = mp_knn1_prepare_f32 fills `workspace` from
+// (p2, len2); phase 2 = mp_knn1_prepared_f32 searches against it.  Same outputs as mp_knn_f32 / mp_knn1_f32(screened).
+static int knn1_phase(const float* p1, const float* p2, const int64_t* len1, const int64_t* len2, int64_t B, int64_t P1, int64_t P2, int64_t D,
+                      float* dists, int64_t* idx, void* ws, size_t ws_bytes, int phases, mp_stream_t stream_)
+{
+    if (B < 0 || P1 < 0 || P2 <= 0 || D <= 0) return MP_EINVAL;
+    if (B == 0 || ((phases & 2) && P1 == 0)) return MP_OK;
+    if (!p2 || !ws || ((phases & 2) && (!p1 || !dists || !idx))) return MP_EINVAL;
+    if (B > 65535 || P1 > (1 << 30) || P2 > (1 << 30) || mp_knn1_workspace_bytes(B, P2, D) == 0) return MP_EUNSUPPORTED;
+    hipStream_t stream = mp_stream(stream_);
+    const int b = (int)B, n1 = (int)P1, n2 = (int)P2;
+    switch ((int)D) {
+        case 3: return launch_knn1_screen<3>(p1, p2, len1, len2, b, n1, n2, dists, idx, ws, ws_bytes, stream, phases);
+        case 6: return launch_knn1_screen<6>(p1, p2, len1, len2, b, n1, n2, dists, idx, ws, ws_bytes, stream, phases);
+        case 12: return launch_knn1_screen<12>(p1, p2, len1, len2, b, n1, n2, dists, idx, ws, ws_bytes, stream, phases);
+        case 24: return launch_knn1_screen<24>(p1, p2, len1, len2, b, n1, n2, dists, idx, ws, ws_bytes, stream, phases);
+        default: return MP_EUNSUPPORTED;
+    }
+}
+
+extern "C" int mp_knn1_prepare_f32(const float* p2, const int64_t* len2, int64_t B, int64_t P2, int64_t D, void* ws, size_t ws_bytes,
+                                   mp_stream_t stream_)
+{
+    return knn1_phase(nullptr, p2, nullptr, len2, B, 0, P2, D, nullptr, nullptr, ws, ws_bytes, 1, stream_);
+}
+
+extern "C" int mp_knn1_prepared_f32(const float* p1, const float* p2, const int64_t* len1, const int64_t* len2, int64_t B, int64_t P1,
+                                    int64_t P2, int64_t D, float* dists, int64_t* idx, const void* ws, size_t ws_bytes, mp_stream_t stream_)
+{
+    return knn1_phase(p1, p2, len1, len2, B, P1, P2, D, dists, idx, const_cast<void*>(ws), ws_bytes, 2, stream_);
 }
 
 // The two K = 1 implementations behind mp_knn_f32, callable by name (tests compare them; tools time them): `screened` != 0 is the

@@ -115,6 +115,14 @@ class TrainStep:
         # permute back to points-major is free
         self.point_cloud = self.batch["point_cloud"].permute(0, 2, 1)
         self.prefetch = bool(prefetch_sampling) and self.device.type == "cuda"
+        # [r4] what the loss derives from the TARGETS alone -- the padded lengths of the ground-truth segments and points, the screening
+        # planes of the nearest-neighbour search against the ground-truth segments -- once for the resident batch instead of three launches
+        # per step (ops.register_static_target).  Streamed batches rewrite the tensors every step and keep the in-step launches.
+        if fused and self.device.type == "cuda" and self._stream is None:
+            for k, planes in (("traj", True), ("traj_as_pc", False)):
+                t = self.batch[k]
+                if torch.is_tensor(t) and t.dtype == torch.float32 and t.is_contiguous() and t.ndim == 3:
+                    _ops.register_static_target(t, planes=planes)
 
     def forward_loss(self):
         return self._heads_loss(self._encode())

@@ -757,3 +757,34 @@ def test_head_input_gradient_kernels_vs_fp64(ops, B, O, I):
     err_s = float((gy.double() - want).abs().max()) / scale
     assert err_m < 2e-6 and err_s < 2e-6, (err_m, err_s)
     assert err_m < 3.0 * err_s + 2e-7, (err_m, err_s)
+
+
+def test_static_target_lengths_and_prepared_planes(ops):
+    """ops.register_static_target: padded_lengths() returns the registered lengths without a launch, and a chamfer term whose reference
+    set is the registered tensor searches against the prepared planes (mp_knn1_prepare_f32 / mp_knn1_prepared_f32) -- bit-identical to
+    the unregistered path; refresh_static_target follows a rewrite of the buffer."""
+    torch.manual_seed(5)
+    B, P1, P2, D = 4, 300, 700, 24
+    y = torch.randn(B, P2, D, device="cuda")
+    y[1, 500:] = -100.0
+    y[3, 256:] = -100.0
+    x = torch.randn(B, P1, D, device="cuda", requires_grad=True)
+    len1 = torch.full((B,), P1, dtype=torch.int64, device="cuda")
+    ref_len = ops.padded_lengths(y)
+    ref = ops.chamfer_term(x, y, len1, ref_len, "mean", "mean", 3.0)
+    try:
+        e = ops.register_static_target(y, planes=True)
+        assert ops.padded_lengths(y) is e["lengths"] and torch.equal(e["lengths"], ref_len)
+        got = ops.chamfer_term(x, y, len1, ops.padded_lengths(y), "mean", "mean", 3.0)
+        assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]) and torch.equal(got[2], ref[2])
+        y[1, 400:] = -100.0
+        y[0] += 0.25
+        ops.refresh_static_target(y)
+        want = ops.chamfer_term(x, y.clone(), len1, ops.padded_lengths(y.clone()), "mean", "mean", 3.0)
+        got = ops.chamfer_term(x, y, len1, ops.padded_lengths(y), "mean", "mean", 3.0)
+        assert torch.equal(got[0], want[0]) and torch.equal(got[2], want[2])
+        g, = torch.autograd.grad(got[0], x)
+        gw, = torch.autograd.grad(want[0], x)
+        assert torch.equal(g, gw)
+    finally:
+        ops.forget_static_targets()

@@ -1,11 +1,14 @@
 """Which torch operators still launch kernels inside one training step: an eager step under torch.profiler, top-level aten ops with
-input shapes and the Python line that issued them.  usage: aten_ops.py"""
+input shapes and the Python line that issued them.  usage: aten_ops.py [c5]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from torch.profiler import profile, ProfilerActivity
 from maskplanner_amd.harness import TrainStep
-ts = TrainStep("cuboids", B=32, N=5120)
+if len(sys.argv) > 1 and sys.argv[1] == "c5":
+    ts = TrainStep("containers", B=32, N=10240, encoder="msg", mlp_dtype="bf16")
+else:
+    ts = TrainStep("cuboids", B=32, N=5120)
 for _ in range(6):
     ts.step()
 torch.cuda.synchronize()
