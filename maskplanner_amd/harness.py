@@ -115,14 +115,6 @@ class TrainStep:
         # permute back to points-major is free
         self.point_cloud = self.batch["point_cloud"].permute(0, 2, 1)
         self.prefetch = bool(prefetch_sampling) and self.device.type == "cuda"
-        # [r4] what the loss derives from the TARGETS alone -- the padded lengths of the ground-truth segments and points, the screening
-        # planes of the nearest-neighbour search against the ground-truth segments -- once for the resident batch instead of three launches
-        # per step (ops.register_static_target).  Streamed batches rewrite the tensors every step and keep the in-step launches.
-        if fused and self.device.type == "cuda" and self._stream is None:
-            for k, planes in (("traj", True), ("traj_as_pc", False)):
-                t = self.batch[k]
-                if torch.is_tensor(t) and t.dtype == torch.float32 and t.is_contiguous() and t.ndim == 3:
-                    _ops.register_static_target(t, planes=planes)
 
     def forward_loss(self):
         return self._heads_loss(self._encode())
@@ -476,12 +468,51 @@ class TrainStep:
             return m.npoint, list(m.radius_list), list(m.nsample_list)
         return m.npoint, [m.radius], [m.nsample]
 
+    # [r4] What the loss derives from the TARGETS alone travels with the sampling plan: the padded lengths of the ground-truth segments
+    # and points (pytorch3d_chamfer.py:138-149) and the screening planes of the nearest-neighbour search against the ground-truth
+    # segments are computed for the NEXT batch on the second stream, next to its FPS, and handed over with the plan -- three launches
+    # off the step's chain, still paid once per step (ops.register_static_target: the loss finds them by the target's address).
+    TARGETS = (("traj", True), ("traj_as_pc", False))
+
+    def _plan_targets(self):
+        from . import ops
+        out = []
+        if self.device.type != "cuda":
+            return out
+        for k, planes in self.TARGETS:
+            t = self.batch.get(k)
+            if torch.is_tensor(t) and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.ndim == 3:
+                B, P2, D = t.shape
+                out.append((k, B, (ops.target_aux_bytes(B, P2, D) + 7) // 8 if planes else 0))
+        return out
+
     def _plan_size(self):
         B, n = self.batch["point_cloud"].shape[0], 0
         for m in self._plan_levels():
             S, _, Ks = self._level_spec(m)
             n += B * S + (B * S * 3 + 1) // 2 + sum(B * S * K for K in Ks)
+        self._plan_aux_at = n
+        for _, b, w in self._plan_targets():
+            n += b + w
         return n
+
+    def _target_views(self, buf):
+        """Per target (key, lengths i64 [B], workspace u8 or None) as views of the plan buffer's tail."""
+        o, out = self._plan_aux_at, []
+        for k, b, w in self._plan_targets():
+            out.append((k, buf[o:o + b], buf[o + b:o + b + w].view(torch.uint8) if w else None))
+            o += b + w
+        return out
+
+    def _target_aux(self, buf, sources=None):
+        from . import ops
+        for k, lengths, ws in self._target_views(buf):
+            ops.compute_target_aux(self.batch[k] if sources is None else sources[k], lengths, ws)
+
+    def _register_targets(self):
+        from . import ops
+        for k, lengths, ws in self._target_views(self._plan_cur):
+            ops.register_static_target(self.batch[k], planes=ws is not None, storage=(lengths, ws))
 
     def _plan_views(self, buf):
         """Per level (fps_idx i64 [B,S], new_xyz f32 [B,S,3], [idx i64 [B,S,K] per radius]) as views of one flat int64 buffer."""
@@ -531,9 +562,12 @@ class TrainStep:
         if self._stream is not None:
             xyz, starts = self._stream.collate_next()
             self._sample_levels(self._plan_cur, xyz, starts)
+            self._target_aux(self._plan_cur, self._stream.stage)
             self._stream.publish()
         else:
             self._sample_levels(self._plan_cur)
+            self._target_aux(self._plan_cur)
+        self._register_targets()
 
     def _launch_sampling(self):
         """The next batch's collation + sampling plan on the second stream, ordered after everything the step's stream holds so
@@ -546,8 +580,10 @@ class TrainStep:
             if self._stream is not None:
                 xyz, starts = self._stream.collate_next()        # host items -> device staging tensors, on the side stream
                 self._sample_levels(self._plan_next, xyz, starts)
+                self._target_aux(self._plan_next, self._stream.stage)
             else:
                 self._sample_levels(self._plan_next)
+                self._target_aux(self._plan_next)
             self._plan_ev = torch.cuda.Event()
             self._plan_ev.record(side)
 

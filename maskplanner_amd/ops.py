@@ -207,32 +207,50 @@ _STATIC_TARGETS = {}
 
 
 @torch.no_grad()
-def register_static_target(y, planes=False):
-    """y [B, P2, D] float32 contiguous, a buffer whose CONTENT only changes through refresh_static_target(); planes: also the K = 1
-    search's reference planes (y as the reference set).  Returns the entry {"lengths", "ws", "nws"}."""
+def register_static_target(y, planes=False, storage=None):
+    """y [B, P2, D] float32 contiguous, a buffer whose CONTENT only changes together with its entry (compute_target_aux into the
+    entry's tensors, or into a second set that is copied over them when y is rewritten); planes: also the K = 1 search's reference
+    planes (y as the reference set).  storage: (lengths i64 [B], workspace u8 [target_aux_bytes(...)] or None) owned by the caller (a
+    harness keeps them inside its double-buffered plan); without it the entry allocates its own and is filled here.
+    Returns the entry {"lengths", "ws", "nws"}."""
     _need_hip(y)
     if y.dtype != torch.float32 or not y.is_contiguous() or y.ndim != 3:
         raise ValueError("static targets are contiguous float32 [B, P, D] tensors")
     B, P2, D = y.shape
-    e = {"shape": tuple(y.shape), "lengths": torch.empty((B,), dtype=torch.int64, device=y.device), "ws": None, "nws": 0, "ref": y}
-    if planes:
-        e["ws"], e["nws"] = _knn_workspace(y, B, P2, D, 1)
+    nws = target_aux_bytes(B, P2, D) if planes else 0
+    if storage is None:
+        lengths = torch.empty((B,), dtype=torch.int64, device=y.device)
+        ws = torch.empty((nws,), dtype=torch.uint8, device=y.device) if nws else None
+    else:
+        lengths, ws = storage
+    e = {"shape": tuple(y.shape), "lengths": lengths, "ws": ws if nws else None, "nws": nws, "ref": y}
     _STATIC_TARGETS[y.data_ptr()] = e
-    refresh_static_target(y)
+    if storage is None:
+        compute_target_aux(y, lengths, e["ws"])
     return e
 
 
+def target_aux_bytes(B, P2, D):
+    """Workspace bytes of a target's reference planes (0: the screened search does not take this shape)."""
+    return int(_lib.load().mp_knn1_workspace_bytes(B, P2, D))
+
+
 @torch.no_grad()
-def refresh_static_target(y, source=None):
-    """Recompute the registered entry of `y` on the current stream -- from `source` (same shape) when the new content is still in a
-    staging tensor that will be copied into y later."""
-    e = _STATIC_TARGETS[y.data_ptr()]
-    src = y if source is None else source
-    B, P2, D = e["shape"]
+def compute_target_aux(src, lengths, ws):
+    """Padded lengths of src [B, P2, D] into `lengths`, and (ws not None) the reference planes of src under those lengths into `ws`, on the
+    current stream."""
+    B, P2, D = src.shape
     lib = _lib.load()
-    _run("padded_lengths", src, lib.mp_padded_lengths_f32, _p(src), B, P2, D, _p(e["lengths"]))
-    if e["ws"] is not None:
-        _run("knn1_prepare", src, lib.mp_knn1_prepare_f32, _p(src), _p(e["lengths"]), B, P2, D, _p(e["ws"]), e["nws"])
+    _run("padded_lengths", src, lib.mp_padded_lengths_f32, _p(src), B, P2, D, _p(lengths))
+    if ws is not None:
+        _run("knn1_prepare", src, lib.mp_knn1_prepare_f32, _p(src), _p(lengths), B, P2, D, _p(ws), ws.numel())
+
+
+@torch.no_grad()
+def refresh_static_target(y):
+    """Recompute the registered entry of `y` in place on the current stream (after y was rewritten; nothing may be reading the entry)."""
+    e = _STATIC_TARGETS[y.data_ptr()]
+    compute_target_aux(y, e["lengths"], e["ws"])
 
 
 def forget_static_targets():
