@@ -512,6 +512,11 @@ int mp_head_block_bwd_f32(const float* grad_y, const float* y, const float* z, c
  * pytorch3d knn_points backward) -- launch bookkeeping only, no arithmetic. */
 int mp_zero_arena_arm(void* base, size_t bytes, mp_stream_t stream);
 int mp_zero_arena_disarm(void);
+/* [r4] mp_zero_arena_arm that also adds 1 to up to 40 int64 and 8 float32 device counters in the same launch (the num_batches_tracked of
+ * the step's train-mode BatchNorm layers, models/pointnet2_utils.py:208-213 / pointnet2_cls_ssg.py:309-327; a dropout step; an
+ * optimizer's device-side update count): bytes a non-zero multiple of 16. */
+int mp_zero_arena_arm_ticks(void* base, size_t bytes, int n_i64, int64_t* const* counters_i64, int n_f32, float* const* counters_f32,
+                            mp_stream_t stream);
 
 /* ---- optional per-kernel device timing (bench / profiling aid; off by default) ------------------------------------
  * No counterpart in the reference (its only timing is wall-clock prints: train_maskplanner.py:236-239).

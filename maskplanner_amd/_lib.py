@@ -115,6 +115,7 @@ SIGNATURES = {
     "mp_linear_dx_mfma_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp]),
     "mp_linear_dw_outer_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp]),
     "mp_zero_arena_arm": (_int, [_vp, _sz, _vp]),
+    "mp_zero_arena_arm_ticks": (_int, [_vp, _sz, _int, _vp, _int, _vp, _vp]),
     "mp_zero_arena_disarm": (_int, []),
     "mp_profiler_enable": (_int, [_int]),
     "mp_profiler_collect": (_int, [ctypes.c_char_p, _sz]),

@@ -126,6 +126,53 @@ extern "C" int mp_zero_arena_disarm(void)
     return MP_OK;
 }
 
+// [r4] The same launch may advance the step's device-side counters: the num_batches_tracked of every train-mode BatchNorm (int64), the
+// dropout step, the dense optimizer's update count (float32) -- each was an elementwise launch of its own on the dependent chain.
+namespace {
+constexpr int TICK_I64 = 40, TICK_F32 = 8;
+struct TickTable {
+    long long* i64[TICK_I64];
+    float* f32[TICK_F32];
+    int n64, n32;
+};
+__global__ __launch_bounds__(256) void arena_arm_kernel(float* __restrict__ p, size_t n4, TickTable t)
+{
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride)
+        reinterpret_cast<float4*>(p)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (blockIdx.x == 0) {
+        const int k = threadIdx.x;
+        if (k < t.n64) *t.i64[k] += 1;
+        else if (k - t.n64 < t.n32) *t.f32[k - t.n64] += 1.0f;
+    }
+}
+}  // namespace
+
+extern "C" int mp_zero_arena_arm_ticks(void* base, size_t bytes, int n_i64, int64_t* const* counters_i64, int n_f32,
+                                       float* const* counters_f32, mp_stream_t stream_)
+{
+    if (!base || (bytes & 15) || (reinterpret_cast<uintptr_t>(base) & 15) || bytes == 0) return MP_EINVAL;
+    if (n_i64 < 0 || n_f32 < 0 || (n_i64 > 0 && !counters_i64) || (n_f32 > 0 && !counters_f32)) return MP_EINVAL;
+    if (n_i64 > TICK_I64 || n_f32 > TICK_F32) return MP_EUNSUPPORTED;
+    hipStream_t stream = mp_stream(stream_);
+    mp_zero_arena_disarm();
+    TickTable t{};
+    t.n64 = n_i64;
+    t.n32 = n_f32;
+    for (int k = 0; k < n_i64; ++k) { if (!counters_i64[k]) return MP_EINVAL; t.i64[k] = reinterpret_cast<long long*>(counters_i64[k]); }
+    for (int k = 0; k < n_f32; ++k) { if (!counters_f32[k]) return MP_EINVAL; t.f32[k] = counters_f32[k]; }
+    const size_t n4 = bytes / 16;
+    size_t blocks = (n4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(arena_arm_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, static_cast<float*>(base), n4, t);
+    if (hipGetLastError() != hipSuccess) return MP_ELAUNCH;
+    std::lock_guard<std::mutex> lk(g_arena_mu);
+    g_arena_base = static_cast<const char*>(base);
+    g_arena_bytes = bytes;
+    g_arena_stream = stream;
+    return MP_OK;
+}
+
 extern "C" int mp_zero_arena_arm(void* base, size_t bytes, mp_stream_t stream_)
 {
     if (!base || (bytes & 3) || (reinterpret_cast<uintptr_t>(base) & 15)) return MP_EINVAL;

@@ -493,7 +493,8 @@ class DenseAdam:
         self._numel = [p.numel() for p in self.params]
 
     @torch.no_grad()
-    def step(self):
+    def step(self, ticked=False):
+        """ticked: the device-side update count was already advanced for this step (the harness does it in its arena launch)."""
         if not self.params:
             return
         live = 0
@@ -511,7 +512,7 @@ class DenseAdam:
         if not live:
             return
         self.steps += 1
-        if self.step_dev is not None:
+        if self.step_dev is not None and not ticked:
             self.step_dev.add_(1.0)
         ops._run("adam_multi", self.params[0], _lib.load().mp_adam_multi_f32, len(self.params), self._p, self._g, self._m, self._v, self._n,
                  1.0, self.lr, self.betas[0], self.betas[1], self.eps, 0 if self.step_dev is not None else self.steps,

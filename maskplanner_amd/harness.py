@@ -68,6 +68,7 @@ class TrainStep:
         self._unit = torch.ones((), dtype=torch.float32, device=self.device)
         from . import ops as _ops
         self._zero_arena = _ops.ZeroArena(self.device) if self.device.type == "cuda" else None
+        self._dense_ticked = False
         # train-mode dropout of the head blocks inside their BatchNorm + ReLU launches (pointnet2_cls_ssg._block): a device (seed, step)
         # pair, the step advanced once per training step.
         self._drop_rng = None
@@ -123,13 +124,19 @@ class TrainStep:
         """Collect the num_batches_tracked counters of every train-mode BatchNorm the enclosed forward passes touch and advance
         them with one launch on exit (instead of one per set-abstraction level and one for the heads)."""
 
+        def __init__(self, ts=None):
+            self.ts = ts
+
         def __enter__(self):
             from . import sa_mlp
             self.prev, sa_mlp.DEFERRED_TICKS = sa_mlp.DEFERRED_TICKS, []
 
         def __exit__(self, *exc):
             from . import sa_mlp
-            sa_mlp.flush_ticks()
+            if self.ts is not None and exc[0] is None:
+                self.ts._arm_and_tick()       # (the arena's launch advances the counters)
+            else:
+                sa_mlp.flush_ticks()
             sa_mlp.DEFERRED_TICKS = self.prev
 
     def _encode(self):
@@ -145,9 +152,6 @@ class TrainStep:
             return self.model.encode(self.point_cloud)
 
     def _heads_loss(self, feat):
-        # the small zero-initialised outputs of the loss / heads / encoder backward out of one buffer cleared by one launch (ops.ZeroArena)
-        if self._zero_arena is not None:
-            self._zero_arena.arm()
         out, sm_out, mask_conf, seg_conf = self.model.heads(feat)
         if self._drop_rng is not None:      # next step, next dropout masks: the step counter rides in the BatchNorm counters' launch
             from . import sa_mlp
@@ -158,6 +162,28 @@ class TrainStep:
         return self.loss_handler.compute(return_list=False, y_pred=out, y=self.batch["traj"], pred_stroke_masks=sm_out,
                                          mask_scores=mask_conf, seg_logits=seg_conf, stroke_ids=self.batch["stroke_ids"],
                                          traj_as_pc=self.batch["traj_as_pc"])
+
+    def _arm_and_tick(self):
+        """Between the loss and its backward: the small zero-initialised outputs of the heads' / loss's / encoder's backward come out of
+        one buffer cleared by ONE launch (ops.ZeroArena), and the same launch advances the step's counters -- every BatchNorm's
+        num_batches_tracked, the dropout step, the dense optimizer's update count (three elementwise launches before)."""
+        from . import sa_mlp
+        ticks = list(sa_mlp.DEFERRED_TICKS or [])
+        dense = getattr(self.opt, "step_dev", None)
+        self._dense_ticked = False
+        if self._zero_arena is not None and self._zero_arena.arm(ticks, [dense] if (dense is not None and not self.dp_graph) else None):
+            if sa_mlp.DEFERRED_TICKS:
+                del sa_mlp.DEFERRED_TICKS[:]
+            self._dense_ticked = dense is not None and not self.dp_graph
+        else:
+            sa_mlp.flush_ticks()
+
+    def _opt_step(self):
+        if isinstance(self.opt, DenseAdam):
+            self.opt.step(ticked=self._dense_ticked)
+        else:
+            self.opt.step()
+        self._dense_ticked = False
 
     def _disarm(self):
         if self._zero_arena is not None:
@@ -274,11 +300,11 @@ class TrainStep:
                 if split_bwd:
                     leaf = feat.detach().requires_grad_(True)
                     loss = self._heads_loss(leaf)
-                    sa_mlp.flush_ticks()
+                    self._arm_and_tick()
                     loss.backward(self._unit)     # (a cached 1: no fill launch for the seed gradient)
                 else:
                     loss = self._heads_loss(feat)
-                    sa_mlp.flush_ticks()
+                    self._arm_and_tick()
                     loss.backward(self._unit)     # (a cached 1: no fill launch for the seed gradient)
                     self._disarm()
                 sa_mlp.DEFERRED_TICKS = ticks_prev
@@ -286,7 +312,7 @@ class TrainStep:
                     flush_bias_grads(self.model.factor_store)
                 if not self.dp_graph and not split_bwd:
                     self.reducer.finish()
-                    self.opt.step()
+                    self._opt_step()
                 loss = loss.detach()
                 if persist:
                     srcs, dsts, seen = [], [], {}
@@ -308,7 +334,7 @@ class TrainStep:
                     self._disarm()
                     if not self.dp_graph:
                         self.reducer.finish()
-                        self.opt.step()
+                        self._opt_step()
                     if self.overlap:
                         self._hand_over_copies()
             if self.dp_graph:
@@ -628,7 +654,7 @@ class TrainStep:
     def _eager_step_body(self):
         self._supply_plan()
         self.reducer.zero_grad()
-        with self._Ticks():
+        with self._Ticks(self):
             loss = self.forward_loss()
         try:
             loss.backward(self._unit)     # (a cached 1: no fill launch for the seed gradient)
@@ -642,7 +668,7 @@ class TrainStep:
             # the side stream while the optimizer's bandwidth-bound streaming kernels occupy the main stream
             sa1 = self.model.sa1
             pu.prefetch_sampling(self.batch["point_cloud"], sa1.npoint, sa1.radius, sa1.nsample, self.batch["fps_start"][0])
-        self.opt.step()
+        self._opt_step()
         if self.factor_opt is not None:
             self.factor_opt.step()
         return loss.detach()   # callers never keep the autograd graph (and its accumulator nodes) alive across steps

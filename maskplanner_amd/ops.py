@@ -5,6 +5,8 @@ live on the same device; nothing here synchronises with the host.  PyTorch suppl
 bookkeeping only -- all arithmetic on the hot path happens inside libmaskplanner_hip.so.  There is no CPU path:
 a non-HIP tensor raises.
 """
+import ctypes
+
 import torch
 
 from . import _lib
@@ -71,16 +73,28 @@ class ZeroArena:
     def __init__(self, device):
         self.device, self.buf, self.cap, self.cur, self.want = device, None, 0, 0, 0
 
-    def arm(self):
-        """Clear the arena on the current stream and make it the source of empty() until disarm()."""
+    def arm(self, ticks=None, fticks=None):
+        """Clear the arena on the current stream and make it the source of empty() until disarm().  ticks / fticks: int64 / float32
+        device scalars advanced by 1 in the same launch (mp_zero_arena_arm_ticks); returns False when they were NOT advanced (no arena
+        yet, too many, other dtypes) and the caller has to."""
         need = max(self.want, self.cur)
         if need > self.cap and not torch.cuda.is_current_stream_capturing():
             self.cap = (need + 4095) // 4096 * 4096
             self.buf = torch.empty((self.cap,), dtype=torch.uint8, device=self.device)
         self.cur, self.want = 0, 0
         ZeroArena.active = self
-        if self.cap:
-            _run("zero_arena", self.buf, _lib.load().mp_zero_arena_arm, self.buf.data_ptr(), self.cap)
+        ticks, fticks = list(ticks or []), list(fticks or [])
+        if not self.cap:
+            return not (ticks or fticks)
+        if ((ticks or fticks) and len(ticks) <= 40 and len(fticks) <= 8
+                and all(t.dtype == torch.int64 and t.numel() == 1 and t.device == self.buf.device for t in ticks)
+                and all(t.dtype == torch.float32 and t.numel() == 1 and t.device == self.buf.device for t in fticks)):
+            a64 = (ctypes.c_void_p * max(len(ticks), 1))(*[t.data_ptr() for t in ticks])
+            a32 = (ctypes.c_void_p * max(len(fticks), 1))(*[t.data_ptr() for t in fticks])
+            _run("zero_arena", self.buf, _lib.load().mp_zero_arena_arm_ticks, self.buf.data_ptr(), self.cap, len(ticks), a64, len(fticks), a32)
+            return True
+        _run("zero_arena", self.buf, _lib.load().mp_zero_arena_arm, self.buf.data_ptr(), self.cap)
+        return not (ticks or fticks)
 
     def disarm(self):
         if ZeroArena.active is self:

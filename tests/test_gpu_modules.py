@@ -1403,3 +1403,20 @@ def test_wide_head_backward_kernels_and_sample_ahead_change_nothing(monkeypatch)
             continue                                   # exact gradient 0 (removed by the following train-mode BatchNorm): rounding noise on both sides
         tol = 2e-5 if n.startswith(("fc", "sm_", "mask_conf", "bn", "sm_bn")) else 5e-3     # encoder: dW atomics + max-pool routing noise
         assert float((g1 - g0).norm()) <= tol * float(g0.norm()) + 1e-7, (n, float((g1 - g0).norm() / g0.norm().clamp_min(1e-12)))
+
+
+def test_step_counters_advance_once_per_step():
+    """[r4] The BatchNorm counters, the dropout step and the dense optimizer's update count ride in the zero arena's launch
+    (harness._arm_and_tick): after n steps -- eager warm-up, the recording step, replays -- every one of them reads n."""
+    from maskplanner_amd.harness import TrainStep
+    ts = TrainStep("cuboids", B=4, N=1024, hidden_size=(128, 128))
+    n = 7
+    for _ in range(n):
+        ts.step()
+    torch.cuda.synchronize()
+    assert ts._graph is not None, "the step was not recorded"
+    bns = [m for m in ts.model.modules() if isinstance(m, torch.nn.modules.batchnorm._BatchNorm)]
+    assert len(bns) >= 13
+    assert all(int(bn.num_batches_tracked) == n for bn in bns), [int(bn.num_batches_tracked) for bn in bns]
+    assert int(ts._drop_rng[1]) == n
+    assert float(ts.opt.step_dev) == n and float(ts.factor_opt.step_dev) == n
