@@ -151,7 +151,9 @@ int mp_knn1_prepared_f32(const float* p1, const float* p2, const int64_t* len1, 
                          int64_t D, float* dists, int64_t* idx, const void* workspace, size_t workspace_bytes, mp_stream_t stream);
 /* The backward of K = 1 distances that went straight into mp_chamfer_reduce_f32 (one loss term = nearest neighbours + reduction,
  * pytorch3d_chamfer.py:257-334): grad_out is the gradient of the REDUCED value ([1], or [B] when batch_mode == 0) and the per-row
- * factor scale / div / len1[b] is applied inside the scatter -- no [B,P1] gradient tensor, no mp_chamfer_reduce_bwd_f32 launch. */
+ * factor scale / div / len1[b] is applied inside the scatter -- no [B,P1] gradient tensor, no mp_chamfer_reduce_bwd_f32 launch.
+ * `deterministic` is a flag word: bit 0 = ordered (bit-reproducible) grad_p2; bit 1 [r4] = grad_p1 is ADDED to (the terms of a composite
+ * loss on the same prediction accumulate into one buffer: loss_handler.py:660-664 without autograd's fan-out adds). */
 int mp_knn_bwd_reduced_f32(const float* p1, const float* p2, const int64_t* len1, const int64_t* len2,
                            const int64_t* idx, const float* grad_out, int point_mean, int batch_mode, double div,
                            double scale, int64_t B, int64_t P1, int64_t P2, int64_t D, float* grad_p1,

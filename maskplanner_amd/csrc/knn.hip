@@ -726,6 +726,7 @@ struct RowGrad {
     const float* grad_out;   // [1], or [B] when batch_mode == 0
     int point_mean, batch_mode;
     float div, scale;
+    int accumulate_p1;       // grad_p1 += (a running total shared by several loss terms on the same points) instead of =
     __device__ __forceinline__ float at(int64_t b, int64_t len) const
     {
         float g = (batch_mode == 0 ? grad_out[b] : grad_out[0]) * scale;
@@ -761,7 +762,7 @@ __global__ __launch_bounds__(256) void knn_bwd_kernel(const float* __restrict__ 
                 if (grad_p2_atomic) atomicAdd(grad_p2_atomic + (b * P2 + j) * D + t, -v);
             }
         }
-        if (grad_p1) grad_p1[e] = acc;
+        if (grad_p1) grad_p1[e] = rg.accumulate_p1 ? grad_p1[e] + acc : acc;
     }
 }
 
@@ -982,8 +983,10 @@ extern "C" int mp_knn_bwd_reduced_f32(const float* p1, const float* p2, const in
 {
     if (batch_mode < 0 || batch_mode > 2 || (point_mean && !len1)) return MP_EINVAL;
     if (B > 0 && P1 > 0 && P2 > 0 && !grad_out) return MP_EINVAL;
-    RowGrad rg{grad_out, point_mean, batch_mode, (float)div, (float)scale};
-    return knn_bwd(p1, p2, len1, len2, idx, nullptr, rg, B, P1, P2, D, 1, grad_p1, grad_p2, deterministic, stream_);
+    // `deterministic` carries flags: bit 0 = the ordered (bit-reproducible) grad_p2, bit 1 = grad_p1 ACCUMULATES ([r4] several loss terms
+    // on the same prediction share one gradient buffer: no fan-out adds)
+    RowGrad rg{grad_out, point_mean, batch_mode, (float)div, (float)scale, (deterministic & 2) ? 1 : 0};
+    return knn_bwd(p1, p2, len1, len2, idx, nullptr, rg, B, P1, P2, D, 1, grad_p1, grad_p2, deterministic & 1, stream_);
 }
 
 extern "C" int mp_padded_lengths_f32(const float* y, int64_t B, int64_t P2, int64_t D, int64_t* lengths,

@@ -277,12 +277,13 @@ class LossHandler:
         return 100 * chamfer_distance(y_pred, y, padded=True, asymmetric=True)[0]
 
     # `_w` (internal): a constant the composite losses fold into the reduction kernel together with the 100 (no scalar launches)
-    def get_reverse_asymm_point_chamfer(self, y_pred, y, traj_as_pc, _w=1.0, _add=None, **args):
+    def get_reverse_asymm_point_chamfer(self, y_pred, y, traj_as_pc, _w=1.0, _add=None, _acc=None, **args):
         return chamfer_distance(self._pose_cloud(y_pred), self._on_device(traj_as_pc, y_pred), padded=True,
-                                reverse_asymmetric=True, _scale=100.0 * float(_w), _add=_add)[0]
+                                reverse_asymmetric=True, _scale=100.0 * float(_w), _add=_add, _grad_accum=_acc)[0]
 
-    def get_reverse_asymm_segment_chamfer(self, y_pred, y, _w=1.0, _add=None, _y_found=None, **args):
-        return chamfer_distance(y_pred, y, padded=True, reverse_asymmetric=True, _scale=100.0 * float(_w), _add=_add, _y_found=_y_found)[0]
+    def get_reverse_asymm_segment_chamfer(self, y_pred, y, _w=1.0, _add=None, _y_found=None, _acc=None, **args):
+        return chamfer_distance(y_pred, y, padded=True, reverse_asymmetric=True, _scale=100.0 * float(_w), _add=_add, _y_found=_y_found,
+                                _grad_accum=_acc)[0]
 
     def get_attraction_chamfer(self, y_pred, **args):
         return 100 * chamfer_distance(y_pred[:, :, :3], y_pred[:, :, -3:], padded=False)[0]
@@ -323,7 +324,7 @@ class LossHandler:
         targets = self._transform_segment_distance_to_confidence(nn_distance)
         return self._cfg()["explicit_weight_segments_confidence"] * (logits - targets).square().sum(-1).mean()
 
-    def _segment_term(self, y_pred, y, seg_logits, _w=1.0):
+    def _segment_term(self, y_pred, y, seg_logits, _w=1.0, _acc=None):
         """Term 1 of the asymmetric losses: pred->GT segment chamfer, unreduced, with the matching (:604-621);
         returns _w * 100 * d.mean() (one reduction launch: every predicted cloud has the same length)."""
         cfg = self._cfg()
@@ -335,7 +336,7 @@ class LossHandler:
             y_dev = self._on_device(y, y_pred)
             self._y_found = ops.padded_lengths(y_dev)
             seg, d, match = ops.chamfer_term(y_pred, y_dev, _full_lengths(y_pred.shape[0], y_pred.shape[1], y_pred.device),
-                                             self._y_found, "mean", "mean", 100.0 * float(_w))
+                                             self._y_found, "mean", "mean", 100.0 * float(_w), grad_accum=_acc)
             return seg, 0, match, d
         d, _, match, _ = chamfer_distance(y_pred, y, padded=True, asymmetric=True, return_matching=True,
                                           point_reduction=None, batch_reduction=None, _matching_y=False)
@@ -354,13 +355,15 @@ class LossHandler:
         cfg = self._cfg()
         # the term weights of :660-664 travel into the reduction kernels (_w), and on the GPU the terms are chained through the
         # kernels' `add` input (each reduction adds the running total): the sum of :660-664 costs no launch of its own
-        seg, conf, match, d = self._segment_term(y_pred, y, seg_logits, _w=cfg["weight_asymm_segment_chamfer"])
         chain = y_pred.is_cuda
+        # the three chamfer terms differentiate the same prediction: one gradient buffer, filled by their backward launches in turn
+        acc = ops.GradAccum(y_pred) if (chain and y_pred.is_contiguous() and y_pred.dtype == torch.float32 and y_pred.requires_grad) else None
+        seg, conf, match, d = self._segment_term(y_pred, y, seg_logits, _w=cfg["weight_asymm_segment_chamfer"], _acc=acc)
         run = seg + conf if (chain and not isinstance(conf, int)) else seg
         pts = self.get_reverse_asymm_point_chamfer(y_pred, y, traj_as_pc, _w=cfg["weight_reverse_asymm_point_chamfer"],
-                                                   _add=run if chain else None)                                            # :623-637
+                                                   _add=run if chain else None, _acc=acc)                                  # :623-637
         rev = self.get_reverse_asymm_segment_chamfer(y_pred, y, _w=cfg["weight_reverse_asymm_segment_chamfer"],
-                                                     _add=pts if chain else None, _y_found=getattr(self, "_y_found", None))  # :641-645
+                                                     _add=pts if chain else None, _y_found=getattr(self, "_y_found", None), _acc=acc)  # :641-645
         masks = self.get_stroke_masks_loss(match, pred_stroke_masks, mask_scores, stroke_ids, nn_distance=d,
                                            smooth_targets=cfg.get("smooth_target_stroke_masks", False),
                                            _add=rev if chain else None, **kwargs)

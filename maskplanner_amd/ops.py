@@ -584,6 +584,35 @@ def _reduce_counter(device):
     return t
 
 
+class GradAccum:
+    """One gradient buffer for several chamfer terms on the same prediction (the asymmetric composite losses take three nearest-
+    neighbour terms of `y_pred`, loss_handler.py:604-664): each term's backward adds its part into the buffer and only the LAST one to
+    run hands it to autograd -- no fan-out add launches.  Needs the armed ZeroArena (the buffer starts zero and the library must not
+    clear it between the terms); otherwise, and under ops.DETERMINISTIC, the terms fall back to their own gradients."""
+
+    def __init__(self, base):
+        self.ptr, self.numel, self.shape = base.data_ptr(), base.numel(), tuple(base.shape)
+        self.pending, self.buf, self.off = 0, None, False
+
+    def operand(self, p1, p2):
+        """Which operand of a term is the shared prediction (1, 2) or 0."""
+        if p1.data_ptr() == self.ptr and p1.numel() == self.numel:
+            return 1
+        if p2.data_ptr() == self.ptr and p2.numel() == self.numel:
+            return 2
+        return 0
+
+    def buffer(self, device):
+        if self.off:
+            return None
+        if self.buf is None:
+            a = ZeroArena.active
+            self.buf = a.take(self.shape, torch.float32, device) if (a is not None and not DETERMINISTIC) else None
+            if self.buf is None:
+                self.off = True
+        return self.buf
+
+
 class _ChamferTerm(torch.autograd.Function):
     """One reduced, one-directional chamfer term (pytorch3d_chamfer.py:257-334 with asymmetric / reverse_asymmetric): nearest
     neighbour of every row of p1 in p2 (K = 1), sum or mean over the rows, sum or mean over the batch, times `scale`, plus the
@@ -592,7 +621,13 @@ class _ChamferTerm(torch.autograd.Function):
     gradient."""
 
     @staticmethod
-    def forward(ctx, p1, p2, len1, len2, point_mean, batch_mode, div, scale, add):
+    def forward(ctx, p1, p2, len1, len2, point_mean, batch_mode, div, scale, add, accum=None):
+        ctx.accum, ctx.which = None, 0
+        if accum is not None:
+            ctx.which = accum.operand(p1, p2)
+            if ctx.which:
+                ctx.accum = accum
+                accum.pending += 1
         B, P1, D = p1.shape
         P2 = p2.shape[1]
         lib = _lib.load()
@@ -622,26 +657,41 @@ class _ChamferTerm(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out, _gd, _gi):
         if grad_out is None:
-            return (None,) * 9
+            return (None,) * 10
         p1, p2, len1, len2, idx = ctx.saved_tensors
         point_mean, batch_mode, div, scale = ctx.meta
         B, P1, D = p1.shape
         P2 = p2.shape[1]
         need1, need2 = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
-        g1 = torch.empty_like(p1) if need1 else None
-        g2 = (torch.empty_like(p2) if DETERMINISTIC else zeroed_empty(p2.shape, torch.float32, p2.device)) if need2 else None
+        flags = int(DETERMINISTIC)
+        shared = ctx.accum.buffer(p1.device) if (ctx.accum is not None and ctx.needs_input_grad[ctx.which - 1]) else None
+        if shared is not None and ctx.which == 1:
+            g1, flags = shared.view(p1.shape), flags | 2          # += into the shared buffer
+        else:
+            g1 = torch.empty_like(p1) if need1 else None
+        if shared is not None and ctx.which == 2:
+            g2 = shared.view(p2.shape)                            # the scatter's atomics add; inside the arena the library does not clear
+        else:
+            g2 = (torch.empty_like(p2) if DETERMINISTIC else zeroed_empty(p2.shape, torch.float32, p2.device)) if need2 else None
         if need1 or need2:
             grad_out = _f32(grad_out)
             _run("knn_bwd", p1, _lib.load().mp_knn_bwd_reduced_f32, _p(p1), _p(p2), _p(len1), _p(len2), _p(idx), _p(grad_out), point_mean,
-                 batch_mode, div, scale, B, P1, P2, D, _p(g1), _p(g2), int(DETERMINISTIC))
-        return g1, g2, None, None, None, None, None, None, (grad_out if ctx.needs_input_grad[8] else None)
+                 batch_mode, div, scale, B, P1, P2, D, _p(g1), _p(g2), flags)
+        if shared is not None:        # only the last term to run hands the total to autograd
+            ctx.accum.pending -= 1
+            if ctx.accum.pending > 0:
+                if ctx.which == 1:
+                    g1 = None
+                else:
+                    g2 = None
+        return g1, g2, None, None, None, None, None, None, (grad_out if ctx.needs_input_grad[8] else None), None
 
 
 RELU_TAP = None     # test hook (tests/test_gpu_routing.py): a list that receives the ReLU mask [B, C] of every bn_relu_rows call
 KNN_TAP = None      # test hook (tests/test_gpu_routing.py): a list that receives the nearest-neighbour indices of every chamfer_term call
 
 
-def chamfer_term(p1, p2, lengths1, lengths2, point_reduction="mean", batch_reduction="mean", scale=1.0, add=None):
+def chamfer_term(p1, p2, lengths1, lengths2, point_reduction="mean", batch_reduction="mean", scale=1.0, add=None, grad_accum=None):
     """(value, dists [B,P1], idx [B,P1]) of one reduced one-directional chamfer term, see _ChamferTerm; lengths1 is required
     (the point mean divides by it).  Same numbers as knn(K=1) followed by chamfer_reduce."""
     _need_hip(p1, p2, lengths1, lengths2, add)
@@ -653,7 +703,7 @@ def chamfer_term(p1, p2, lengths1, lengths2, point_reduction="mean", batch_reduc
     if point_reduction not in ("mean", "sum"):
         raise ValueError("point_reduction must be 'mean' or 'sum'")
     res = _ChamferTerm.apply(_f32(p1), _f32(p2), _i64(lengths1), None if lengths2 is None else _i64(lengths2),
-                             point_reduction == "mean", batch_mode, float(p1.shape[0]), float(scale), add)
+                             point_reduction == "mean", batch_mode, float(p1.shape[0]), float(scale), add, grad_accum)
     if KNN_TAP is not None:
         KNN_TAP.append(res[2])
     return res

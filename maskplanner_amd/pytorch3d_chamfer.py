@@ -65,7 +65,7 @@ def chamfer_distance(x, y, x_lengths=None, y_lengths=None, x_normals=None, y_nor
                      batch_reduction: Union[str, None] = "mean", point_reduction: Union[str, None] = "mean",
                      velocities=False, min_centroids=False, padded=False, avoid_in_sequence_collapsing=False,
                      soft_attraction=False, asymmetric=False, reverse_asymmetric=False, return_matching=False,
-                     _matching_y=True, _scale=None, _add=None, _y_found=None):
+                     _matching_y=True, _scale=None, _add=None, _y_found=None, _grad_accum=None):
     """Chamfer distance between point sets x [N,P1,D] and y [N,P2,D]; see the reference docstring (:95-129) and the
     custom flags (:84-93).  Returns (dist, normals_dist_or_None) and, with return_matching, also the nearest
     neighbour indices (idx_x [N,P1], idx_y [N,P2]).  `_matching_y=False` (not a reference argument; used by this
@@ -73,7 +73,8 @@ def chamfer_distance(x, y, x_lengths=None, y_lengths=None, x_normals=None, y_nor
     does not need it; `_scale` (likewise internal) multiplies a REDUCED distance by a constant inside the reduction
     kernel (the loss folds its `100 * weight` factors in there instead of launching scalar multiplies); `_add` (internal, one
     direction + batch reduction only) is a device scalar -- the running total of a composite loss -- added in the same launch;
-    `_y_found` (internal) is ops.padded_lengths(y) when the caller already has it (one GT tensor feeds several terms)."""
+    `_y_found` (internal) is ops.padded_lengths(y) when the caller already has it (one GT tensor feeds several terms);
+    `_grad_accum` (internal): an ops.GradAccum shared by the terms of a composite loss on one prediction."""
     if not soft_attraction:
         _validate_chamfer_reduction_inputs(batch_reduction, point_reduction)
     if _scale is not None and (point_reduction is None or weights is not None or x_normals is not None or avoid_in_sequence_collapsing
@@ -152,9 +153,9 @@ def chamfer_distance(x, y, x_lengths=None, y_lengths=None, x_normals=None, y_nor
             # the training-step case: one direction, reduced -- knn + reduction forward, ONE launch backward (ops.chamfer_term)
             sc = 1.0 if _scale is None else float(_scale)
             if asymmetric:
-                val, _, ix = ops.chamfer_term(x, y, x_lengths, y_lengths, point_reduction, batch_reduction, sc, add=_add)
+                val, _, ix = ops.chamfer_term(x, y, x_lengths, y_lengths, point_reduction, batch_reduction, sc, add=_add, grad_accum=_grad_accum)
                 return (val, None, ix, None) if return_matching else (val, None)
-            val, _, _ = ops.chamfer_term(y, x, y_lengths, x_lengths, point_reduction, batch_reduction, sc, add=_add)
+            val, _, _ = ops.chamfer_term(y, x, y_lengths, x_lengths, point_reduction, batch_reduction, sc, add=_add, grad_accum=_grad_accum)
             return val, None
         if need_x:
             dx, idx_x = ops.knn(x, y, x_lengths, y_lengths, 1)
