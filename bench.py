@@ -298,10 +298,11 @@ def main():
             if prof:
                 lib.mp_profiler_enable(0)
             return loss
-        # per-kernel HIP events (two records per library launch) on every 50th timed step, rank 0 only: a profiled step is launched
-        # kernel by kernel from Python (the hooks live in the launch path, which a graph replay skips) and costs ~2 ms more than a
-        # replayed one, so sampling keeps the headline number honest (2 of the default 100 steps; they ARE part of the timed region)
-        prof = (lambda i: i % profile_every == 0) if (rank == 0 and profile_every) else None
+        # per-kernel HIP events (two records per library launch) on ONE timed step per `profile_every` x 4 steps (the middle one of the
+        # default 100), rank 0 only: a profiled step is launched kernel by kernel from Python (the hooks live in the launch path, which
+        # a graph replay skips) and costs ~2 ms more than a replayed one; it IS part of the timed region
+        every = 4 * profile_every if profile_every else 0
+        prof = (lambda i: i % every == min(every, steps) // 2) if (rank == 0 and every) else None
         dt, per_step, loss = time_steps(step, steps, warmup, barrier, prof)
         n_prof = len([i for i in range(steps) if prof is not None and prof(i)])
         return dt, per_step, float(loss.detach()), n_prof
