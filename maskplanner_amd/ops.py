@@ -6,6 +6,7 @@ bookkeeping only -- all arithmetic on the hot path happens inside libmaskplanner
 a non-HIP tensor raises.
 """
 import ctypes
+import weakref
 
 import torch
 
@@ -237,7 +238,10 @@ def register_static_target(y, planes=False, storage=None):
         ws = torch.empty((nws,), dtype=torch.uint8, device=y.device) if nws else None
     else:
         lengths, ws = storage
-    e = {"shape": tuple(y.shape), "lengths": lengths, "ws": ws if nws else None, "nws": nws, "ref": y}
+    # (a weak reference: the entry dies with the tensor -- a later tensor at the same address must not inherit it)
+    e = {"shape": tuple(y.shape), "lengths": lengths, "ws": ws if nws else None, "nws": nws, "ref": weakref.ref(y)}
+    for k in [k for k, v in _STATIC_TARGETS.items() if v["ref"]() is None]:
+        del _STATIC_TARGETS[k]
     _STATIC_TARGETS[y.data_ptr()] = e
     if storage is None:
         compute_target_aux(y, lengths, e["ws"])
@@ -273,7 +277,12 @@ def forget_static_targets():
 
 def _static_target(y):
     e = _STATIC_TARGETS.get(y.data_ptr())
-    return e if (e is not None and e["shape"] == tuple(y.shape) and y.dtype == torch.float32) else None
+    if e is None or e["shape"] != tuple(y.shape) or y.dtype != torch.float32:
+        return None
+    if e["ref"]() is None:
+        del _STATIC_TARGETS[y.data_ptr()]
+        return None
+    return e
 
 
 @torch.no_grad()
