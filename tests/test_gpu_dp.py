@@ -121,3 +121,25 @@ def test_replica_guard_falls_back_to_eager_launches():
     assert max(r["replica_diff"] for r in g) == 0.0, g[1]["diverged"]
     lg = np.array(g[0]["losses"])
     assert np.isfinite(lg).all() and lg[-1] < lg[0]
+
+
+def test_syncbn_step_replays_from_graphs_on_rccl():
+    """[r4] SyncBN no longer forces eager launches when the backend is RCCL: the per-layer all-reduces of the library's exchange hook are
+    recorded into the step's graphs (tools/syncbn_graph_probe.py: one forced RCCL rank -- the box has one GPU).  The replayed trainer
+    records, stays finite and tracks the kernel-by-kernel one (same seeds; fp32 atomics make two runs differ in the last bits, which
+    Adam amplifies over the steps)."""
+    import json
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = str(s.getsockname()[1])
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "syncbn_graph_probe.py"), port, "8", "2048"], capture_output=True, text=True,
+                         timeout=600, env=env)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
+    res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    e, g = res["eager"], res["graph"]
+    assert e["sync_bn"] and g["sync_bn"] and not e["recorded"] and g["recorded"], res
+    assert e["finite"] and g["finite"]
+    le, lg = np.array(e["losses"]), np.array(g["losses"])
+    assert np.allclose(lg[:3], le[:3], rtol=2e-3) and np.allclose(lg, le, rtol=8e-2), res       # (the first three steps are eager in both)
+    assert lg[-1] < 0.9 * lg[0]
