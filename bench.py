@@ -292,17 +292,21 @@ def main():
 
     def run_harness(ts, steps, warmup, profile_every=50):
         def step(prof):
-            if prof:
+            if prof and rank == 0:
                 lib.mp_profiler_enable(1)
             loss = ts.eager_step() if prof else ts.step()   # the timing hooks sit in the launch path, which a graph replay skips
-            if prof:
+            if prof and rank == 0:
                 lib.mp_profiler_enable(0)
             return loss
         # per-kernel HIP events (two records per library launch) on ONE timed step per `profile_every` x 4 steps (the middle one of the
         # default 100), rank 0 only: a profiled step is launched kernel by kernel from Python (the hooks live in the launch path, which
         # a graph replay skips) and costs ~2 ms more than a replayed one; it IS part of the timed region
+        # EVERY rank launches that step eagerly (rank 0 alone records events): a replayed data-parallel step issues its collectives in
+        # another order than an eager one (the factor all-gather sits behind the heads' backward, in front of the bucket all-reduces),
+        # so a rank that left the replay alone would pair its all-reduce with the others' all-gather -- a deadlock ([r4] found with two
+        # gloo ranks on one GPU; the profiled step used to be rank 0's alone)
         every = 4 * profile_every if profile_every else 0
-        prof = (lambda i: i % every == min(every, steps) // 2) if (rank == 0 and every) else None
+        prof = (lambda i: i % every == min(every, steps) // 2) if every else None
         dt, per_step, loss = time_steps(step, steps, warmup, barrier, prof)
         n_prof = len([i for i in range(steps) if prof is not None and prof(i)])
         return dt, per_step, float(loss.detach()), n_prof

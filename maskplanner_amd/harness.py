@@ -482,7 +482,9 @@ class TrainStep:
 
     def eager_step(self):
         """One step launched kernel by kernel even when a recorded graph exists (bench.py's per-kernel timing hooks live in
-        the launch path).  Shares parameters and optimizer state with the graph, so the two can be interleaved."""
+        the launch path).  Shares parameters and optimizer state with the graph, so the two can be interleaved.  Under data parallelism
+        EVERY rank must take the same kind of step at the same time: a replayed step issues its collectives in another order (factor
+        all-gather before the bucket all-reduces) than an eager one."""
         if self.overlap:
             self._launch_sampling()
         if self._adam_ev is not None:

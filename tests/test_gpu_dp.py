@@ -143,3 +143,23 @@ def test_syncbn_step_replays_from_graphs_on_rccl():
     le, lg = np.array(e["losses"]), np.array(g["losses"])
     assert np.allclose(lg[:3], le[:3], rtol=2e-3) and np.allclose(lg, le, rtol=8e-2), res       # (the first three steps are eager in both)
     assert lg[-1] < 0.9 * lg[0]
+
+
+def test_bench_runs_with_two_ranks():
+    """bench.py under torch.distributed.run with two ranks (gloo between them, both on the box's one GPU): the contract's JSON line comes
+    back with n_gpus = 2.  [r4] Regression: the step bench.py profiles is launched eagerly on EVERY rank -- when rank 0 alone left the
+    replay, its bucket all-reduce met the other ranks' factor all-gather (a replayed data-parallel step orders them the other way) and
+    the job hung."""
+    import json
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = str(s.getsockname()[1])
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASKPLANNER_DIST_BACKEND="gloo", MASKPLANNER_FAULT_DUMP="240")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", port,
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--batch", "8", "--points", "2048", "--no-cpu-baseline",
+           "--no-side-legs"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=400, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-2500:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["steps"] == 6 and line["value"] > 0 and np.isfinite(line["final_loss"])
+    assert line["config"]["global_batch"] == 16
