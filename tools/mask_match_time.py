@@ -10,7 +10,7 @@ from maskplanner_amd import ops  # noqa: E402
 def main():
     rng = np.random.default_rng(0)
     for name, B, M, S, n_ids in (("cuboids", 32, 6, 1280, 6), ("windows", 32, 6, 1280, 6), ("shelves", 32, 41, 1266, 41),
-                                 ("containers", 16, 64, 4096, 50)):
+                                 ("containers", 32, 33, 1333, 33)):
         pred = torch.from_numpy((rng.normal(size=(B, M, S)) * 2).astype(np.float32)).cuda()
         ids = torch.from_numpy(rng.integers(0, n_ids, size=(B, S)).astype(np.float32)).cuda()
         for _ in range(5):
