@@ -318,8 +318,8 @@ def main():
         def step(_prof):
             last[0] = loop.step()
             return torch.tensor(last[0])
-        for _ in range(3):
-            step(False)     # optimizer state, allocator
+        for _ in range(8):
+            step(False)     # optimizer state, allocator, the libraries' lazy kernel selection (a stall of tens of ms in the first steps)
         dt, per_step, _ = time_steps(step, steps, warmup, barrier)
         return dt, per_step, last[0]
 
