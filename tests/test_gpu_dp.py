@@ -130,11 +130,14 @@ def test_syncbn_step_replays_from_graphs_on_rccl():
     Adam amplifies over the steps)."""
     import json
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = str(s.getsockname()[1])
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "syncbn_graph_probe.py"), port, "8", "2048"], capture_output=True, text=True,
-                         timeout=600, env=env)
+    for _attempt in range(2):       # (RCCL's start-up in a child of a process that holds the GPU fails now and then on the shared boxes: one retry)
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = str(s.getsockname()[1])
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "syncbn_graph_probe.py"), port, "8", "2048"], capture_output=True,
+                             text=True, timeout=600, env=env)
+        if out.returncode == 0:
+            break
     assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
     res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     e, g = res["eager"], res["graph"]
