@@ -345,7 +345,11 @@ typedef struct {
     const float* new_xyz;  /* [B, S, 3] */
     const int64_t* idx;    /* [B, S, K] */
     int64_t N, S, CF;
+    const int32_t* rows;   /* [r4] NULL, or the sorted row lists of mp_csr_rows_i64(idx): the backward then sorts nothing itself */
 } mp_gather_t;
+/* rows [2][B][S*K] int32: per cloud its rows sorted by the source point they gathered, and that point -- a function of idx alone (a
+ * training harness prepares it with the sampling plan, off the step's stream); N <= 15000, S*K < 2^24 */
+int mp_csr_rows_i64(const int64_t* idx, int64_t B, int64_t N, int64_t M, int32_t* rows, mp_stream_t stream);
 int mp_sa_mlp_fwd_f32(const float* x0, int64_t P, int64_t K, int n_layers, const mp_mlp_layer_t* layers, int training,
                       double momentum, double eps, float* out, int32_t* argk, float* zmax, void* workspace,
                       size_t workspace_bytes, mp_stream_t stream);

@@ -52,7 +52,7 @@ ALLREDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, 
 
 class Gather(ctypes.Structure):
     """mp_gather_t"""
-    _fields_ = [("feats", _vp), ("xyz", _vp), ("new_xyz", _vp), ("idx", _vp), ("N", _i64), ("S", _i64), ("CF", _i64)]
+    _fields_ = [("feats", _vp), ("xyz", _vp), ("new_xyz", _vp), ("idx", _vp), ("N", _i64), ("S", _i64), ("CF", _i64), ("rows", _vp)]
 
 
 class SyncBN(ctypes.Structure):
@@ -103,6 +103,7 @@ SIGNATURES = {
     "mp_adam_lowrank_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _dbl, _dbl, _dbl, _dbl, _dbl, _i64, _vp, _vp]),
     "mp_linear_dx_skinny_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "mp_linear_dx_skinny_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _sz, _vp]),
+    "mp_csr_rows_i64": (_int, [_vp, _i64, _i64, _i64, _vp, _vp]),
     "mp_dw_gemm_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp]),
     "mp_head_blocks_fwd_f32": (_int, [_int, _vp, _i64, _i64, _vp]),
     "mp_head_blocks_bwd_f32": (_int, [_int, _vp, _i64, _i64, _vp]),

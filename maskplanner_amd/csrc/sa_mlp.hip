@@ -3164,6 +3164,16 @@ __global__ __launch_bounds__(1024) void csr_rows_kernel(const int64_t* __restric
     }
 }
 
+static int launch_csr_rows(const int64_t* idx, int64_t Bc, int Np, int M, int* order, int* pts, hipStream_t stream)
+{
+    static mp::DynLds lds;
+    const size_t smem = sizeof(int) * ((size_t)Np + 1024);
+    if (!lds.ensure(reinterpret_cast<const void*>(csr_rows_kernel), smem)) return MP_ELAUNCH;
+    hipLaunchKernelGGL(csr_rows_kernel, dim3((unsigned)Bc), dim3(1024), smem, stream, idx, Np, M, order, pts);
+    MP_CHECK_LAUNCH();
+    return MP_OK;
+}
+
 template <int Q>
 __global__ __launch_bounds__(256) void first_factored_reduce_kernel(PosOperand DZ, const int* __restrict__ order, const int* __restrict__ pts,
                                                                     const float* __restrict__ xyz, const float* __restrict__ new_xyz, int N, int M,
@@ -3830,13 +3840,16 @@ static int sa_mlp_bwd(const float* x0, int64_t P, int64_t K, int n_layers, const
                 // sorted-row reduce: no dZ_0 round trip.  Scratch: the G buffer that is free at this layer (2 ints per position).
                 const int M = (int)(gather->S * K), Np = (int)gather->N;
                 const int64_t Bc = P / M;
-                int* order = reinterpret_cast<int*>(gbuf[0]);
-                int* pts = order + P;
-                static mp::DynLds lds;
-                const size_t smem = sizeof(int) * ((size_t)Np + 1024);
-                if (!lds.ensure(reinterpret_cast<const void*>(csr_rows_kernel), smem)) return MP_ELAUNCH;
-                hipLaunchKernelGGL(csr_rows_kernel, dim3((unsigned)Bc), dim3(1024), smem, stream, gather->idx, Np, M, order, pts);
-                MP_CHECK_LAUNCH();
+                // [r4] gather->rows: the sorted row lists prepared by the caller (mp_csr_rows_i64: they depend on idx alone -- a training
+                // harness sorts them with the sampling plan, off the step's stream); NULL: sorted here
+                const int* order = gather->rows;
+                const int* pts = order ? order + P : nullptr;
+                if (!order) {
+                    int* o_ = reinterpret_cast<int*>(gbuf[0]);
+                    if (int rc = launch_csr_rows(gather->idx, Bc, Np, M, o_, o_ + P, stream)) return rc;
+                    order = o_;
+                    pts = o_ + P;
+                }
                 if (!mp::zero_async(grad_x0, (size_t)Bc * Np * Co, stream)) return MP_ELAUNCH;
                 const int chunk = 128;   // rows per wave (measured: 32: 236 us, 64: 160, 128: 122, 256: 126 at the bench shape)
                 const unsigned gxr = (unsigned)((M + 4 * chunk - 1) / (4 * chunk));
@@ -3968,4 +3981,15 @@ extern "C" int mp_sa_mlp_bwd_ex(const float* x0, int64_t P, int64_t K, int n_lay
 {
     return sa_mlp_bwd(x0, P, K, n_layers, layers, training, grad_out, out, argk, zmax, grads, grad_x0, grad_x0_cols, workspace,
                       workspace_bytes, stream, bf16 != 0, sync);
+}
+
+// rows [2][B][M] int32 (M = S * K): per cloud the rows 0 .. M-1 sorted by the source point idx[b, row] (rows[0]) and that point (rows[1]) --
+// what mp_sa_mlp_bwd_gather_* sorts for itself when mp_gather_t::rows is NULL.  Depends on idx alone.
+extern "C" int mp_csr_rows_i64(const int64_t* idx, int64_t B, int64_t N, int64_t M, int32_t* rows, mp_stream_t stream_)
+{
+    if (B < 0 || N <= 0 || M < 0) return MP_EINVAL;
+    if (B == 0 || M == 0) return MP_OK;
+    if (!idx || !rows) return MP_EINVAL;
+    if (N > 15000 || M >= ((int64_t)1 << 24) || B * M >= ((int64_t)1 << 31)) return MP_EUNSUPPORTED;
+    return launch_csr_rows(idx, B, (int)N, (int)M, rows, rows + B * M, mp_stream(stream_));
 }

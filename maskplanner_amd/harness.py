@@ -520,6 +520,26 @@ class TrainStep:
                 out.append((k, B, (ops.target_aux_bytes(B, P2, D) + 7) // 8 if planes else 0))
         return out
 
+    def _plan_extras(self):
+        """Per-batch preprocessing of the encoder that depends on the cloud and its sampling alone, carried by the plan as well [r4]:
+        ("gxyz", level, int64 units): the first level's grouped, centred coordinate rows [B,S,K,4] (a level without input features);
+        ("rows", level, units): the sorted row lists of a level whose first layer is factorised (sa_mlp.csr_rows)."""
+        from . import sa_mlp
+        out = []
+        if self.device.type != "cuda":
+            return out
+        B = self.batch["point_cloud"].shape[0]
+        levels = self._plan_levels()
+        for li, m in enumerate(levels):
+            if hasattr(m, "radius_list"):
+                continue
+            S, _, (K,) = self._level_spec(m)
+            if li == 0 and not getattr(self.model, "normal_channel", False):
+                out.append(("gxyz", li, B * S * K * 4 // 2))
+            if li > 0 and sa_mlp.FACTORED_FIRST in ("1", True) and not self.sync_bn:
+                out.append(("rows", li, 2 * B * S * K // 2))
+        return out
+
     def _plan_size(self):
         B, n = self.batch["point_cloud"].shape[0], 0
         for m in self._plan_levels():
@@ -528,7 +548,43 @@ class TrainStep:
         self._plan_aux_at = n
         for _, b, w in self._plan_targets():
             n += b + w
+        self._plan_extra_at = n
+        for _, _, units in self._plan_extras():
+            n += units
         return n
+
+    def _extra_views(self, buf):
+        B, o, out = self.batch["point_cloud"].shape[0], self._plan_extra_at, []
+        levels = self._plan_levels()
+        for kind, li, units in self._plan_extras():
+            S, _, (K,) = self._level_spec(levels[li])
+            v = buf[o:o + units]
+            out.append((kind, li, v.view(torch.float32).view(B, S, K, 4) if kind == "gxyz" else v.view(torch.int32).view(2, B, S * K)))
+            o += units
+        return out
+
+    def _extras(self, buf, xyz=None):
+        """Fill the extras of `buf` from ITS OWN sampling plan (same buffer: the views are consistent)."""
+        from . import ops, sa_mlp
+        xyz = self.batch["point_cloud"] if xyz is None else xyz
+        plans = self._plan_views(buf)
+        clouds = [xyz] + [p[1] for p in plans[:-1]]
+        for kind, li, v in self._extra_views(buf):
+            _, new_xyz, idxs = plans[li]
+            if kind == "gxyz":
+                ops.group_xyz_into(clouds[li], new_xyz, idxs[0], v)
+            else:
+                sa_mlp.csr_rows(idxs[0], clouds[li].shape[1], out=v)
+
+    def _register_extras(self):
+        from . import sa_mlp
+        plans = self._plan_views(self._plan_cur)
+        for kind, li, v in self._extra_views(self._plan_cur):
+            key = plans[li][2][0].data_ptr()
+            if kind == "gxyz":
+                pu._grouped_xyz[key] = v
+            else:
+                sa_mlp.CSR_ROWS[key] = v
 
     def _target_views(self, buf):
         """Per target (key, lengths i64 [B], workspace u8 or None) as views of the plan buffer's tail."""
@@ -597,11 +653,14 @@ class TrainStep:
             xyz, starts = self._stream.collate_next()
             self._sample_levels(self._plan_cur, xyz, starts)
             self._target_aux(self._plan_cur, self._stream.stage)
+            self._extras(self._plan_cur, xyz)
             self._stream.publish()
         else:
             self._sample_levels(self._plan_cur)
             self._target_aux(self._plan_cur)
+            self._extras(self._plan_cur)
         self._register_targets()
+        self._register_extras()
 
     def _launch_sampling(self):
         """The next batch's collation + sampling plan on the second stream, ordered after everything the step's stream holds so
@@ -615,9 +674,11 @@ class TrainStep:
                 xyz, starts = self._stream.collate_next()        # host items -> device staging tensors, on the side stream
                 self._sample_levels(self._plan_next, xyz, starts)
                 self._target_aux(self._plan_next, self._stream.stage)
+                self._extras(self._plan_next, xyz)
             else:
                 self._sample_levels(self._plan_next)
                 self._target_aux(self._plan_next)
+                self._extras(self._plan_next)
             self._plan_ev = torch.cuda.Event()
             self._plan_ev.record(side)
 

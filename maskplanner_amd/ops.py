@@ -507,6 +507,16 @@ class _Group(torch.autograd.Function):
         return None, grad, None, None, None, None
 
 
+@torch.no_grad()
+def group_xyz_into(xyz, new_xyz, idx, out):
+    """ops.group(xyz, None, new_xyz, idx, pad_to=out.shape[-1]) into a caller's buffer [B, S, K, stride] (no autograd: coordinates)."""
+    _need_hip(xyz, new_xyz, idx, out)
+    B, N, _ = xyz.shape
+    _, S, K = idx.shape
+    _run("group", xyz, _lib.load().mp_group_f32, _p(xyz), None, _p(new_xyz), _p(idx), B, N, S, K, 0, 0, out.shape[-1], _p(out))
+    return out
+
+
 def group(xyz, feats, new_xyz, idx, xyz_last=False, pad_to=1):
     """sample_and_group tail (models/pointnet2_utils.py:133-143; MSG order :258-262 when xyz_last):
     [B,S,K,3+D] = cat(xyz[idx] - new_xyz, feats[idx]).  Differentiable w.r.t. feats (the coordinates are network

@@ -93,6 +93,11 @@ def _plan_key(xyz, npoint, radius, nsample):
     return (xyz.data_ptr(), npoint, r, k)
 
 
+# idx.data_ptr() -> the grouped, centred coordinate rows [B, S, K, 4] of a level WITHOUT input features (ops.group(xyz, None, new_xyz,
+# idx, pad_to=4)): they depend on the cloud and its sampling plan alone, so a harness computes them with the plan, off the step's stream
+_grouped_xyz = {}
+
+
 def supply_sampling(xyz, npoint, radius, nsample, plan):
     """Hand sample_and_group() a finished first-level sampling (fps_idx, new_xyz, idx) of `xyz`, already ordered on the
     current stream (the pipelined step of harness.TrainStep: the plan was computed during the previous step).  A multi-scale
@@ -183,7 +188,11 @@ def sample_and_group(npoint, radius, nsample, xyz, points, returnfps=False, full
     elif full_points is not None:
         new_points = ops.index_points(full_points, idx)  # un-centred full features (:139-141)
     else:
-        new_points = ops.group(xyz, None, new_xyz, idx, pad_to=_pad_to)
+        g = _grouped_xyz.get(idx.data_ptr()) if _grouped_xyz else None      # prepared with the sampling plan (harness)
+        if g is not None and tuple(g.shape) == (B, npoint, nsample, (3 + _pad_to - 1) // _pad_to * _pad_to):
+            new_points = g
+        else:
+            new_points = ops.group(xyz, None, new_xyz, idx, pad_to=_pad_to)
     if returnfps:
         return new_xyz, new_points, ops.index_points(xyz, idx), fps_idx
     return new_xyz, new_points

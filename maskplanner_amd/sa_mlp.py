@@ -219,7 +219,7 @@ class _SharedMLPMaxFactored(torch.autograd.Function):
         zmax = torch.empty((G, cl), dtype=torch.float32, device=dev)
         ch = (ctypes.c_int64 * len(chans))(*chans)
         ws = torch.empty((lib.mp_sa_mlp_workspace_bytes(P, K, n_layers, ch, 0),), dtype=torch.uint8, device=dev)
-        g = _lib.Gather(_ptr(A), _ptr(xyz), _ptr(new_xyz), _ptr(idx), N, S, C0)
+        g = _lib.Gather(_ptr(A), _ptr(xyz), _ptr(new_xyz), _ptr(idx), N, S, C0, None)
         if sync:
             from . import sync_bn
             ex = sync_bn.Exchange(sync_group, max(chans), dev)
@@ -277,7 +277,10 @@ class _SharedMLPMaxFactored(torch.autograd.Function):
         ch = (ctypes.c_int64 * len(chans))(*chans)
         lib = _lib.load()
         ws = torch.empty((lib.mp_sa_mlp_workspace_bytes(P, K, n_layers, ch, 1),), dtype=torch.uint8, device=dev)
-        g = _lib.Gather(_ptr(A), _ptr(xyz), _ptr(new_xyz), _ptr(idx), N, S, C0)
+        rows = CSR_ROWS.get(idx.data_ptr())           # sorted row lists prepared with the sampling plan (harness), else the library sorts
+        if rows is not None and (rows.numel() != 2 * B * S * K or rows.dtype != torch.int32):
+            rows = None
+        g = _lib.Gather(_ptr(A), _ptr(xyz), _ptr(new_xyz), _ptr(idx), N, S, C0, _ptr(rows))
         # dA reduced inside the library from rows sorted by source point (no dZ_0 round trip; summation order not fixed), unless a
         # deterministic run asks for the ordered scatter: then dZ_0 comes back and ops.group's backward kernel reduces it
         fused = FACTORED_REDUCE and not ops.DETERMINISTIC and N <= 15000 and S * K < (1 << 24)
@@ -296,6 +299,20 @@ class _SharedMLPMaxFactored(torch.autograd.Function):
             gA = torch.empty((B, N, C0), dtype=torch.float32, device=dev)
             ops._run("group_bwd", gz, lib.mp_group_bwd_f32, _ptr(gz), _ptr(idx), B, N, S, K, C0, 1, stride, _ptr(gA), int(ops.DETERMINISTIC))
         return (gA, None, None, None, None, None, None, None, None, None, None, *ret)
+
+
+# idx.data_ptr() -> int32 [2, B, S*K]: the sorted row lists (mp_csr_rows_i64) of a level's ball-query result, registered by a harness that
+# computes them with the sampling plan (they depend on idx alone); the factorised backward then launches no sort of its own
+CSR_ROWS = {}
+
+
+def csr_rows(idx, N, out=None):
+    """idx i64 [B, S, K] (source points < N) -> int32 [2, B, S*K]: rows sorted by source point, and that point (mp_csr_rows_i64)."""
+    B, S, K = idx.shape
+    if out is None:
+        out = torch.empty((2, B, S * K), dtype=torch.int32, device=idx.device)
+    ops._run("csr_rows", idx, _lib.load().mp_csr_rows_i64, _ptr(idx), B, N, S * K, _ptr(out))
+    return out
 
 
 PER_POINT_DW_SLICES = 8      # K slices per cloud of the batched weight-gradient GEMM below
