@@ -3410,7 +3410,8 @@ static int sa_mlp_fwd(const float* x0, int64_t P, int64_t K, int n_layers, const
             int ppb = 1024;
             while ((P + ppb - 1) / ppb < fwd_wgs_wanted() && ppb > 128) ppb >>= 1;
             const unsigned gx = (unsigned)((P + ppb - 1) / ppb);
-            const double fl = 2.0 * (double)P * Co_ * Ci_, by = 4.0 * ((double)P * (Ci_ + Co_) + (double)Co_ * Ci_);
+            const double eb = store16 ? 2.0 : 4.0;      // bytes per stored activation (bf16 storage of the bf16 variant's stream chains)
+            const double fl = 2.0 * (double)P * Co_ * Ci_, by = eb * (double)P * (Ci_ + Co_) + 4.0 * (double)Co_ * Ci_;
             if (split_enabled())
                 MP_LAUNCH("fwd_chunk_kernel<128, 128, false, 0, 4, split>", fl, by, (fwd_chunk_kernel<128, 128, false, SRC_ID, 4, true>), dim3(gx), dim3(256), 0, stream, A,
                           (int)P, ppb, L.weight, L.z, partials, po, L.gamma);
@@ -3423,7 +3424,7 @@ static int sa_mlp_fwd(const float* x0, int64_t P, int64_t K, int n_layers, const
             int ppb = 1024;
             while ((P + ppb - 1) / ppb < fwd_wgs_wanted(Co_ == 64 ? 2048 : 512) && ppb > 128) ppb >>= 1;
             const unsigned gx = (unsigned)((P + ppb - 1) / ppb);
-            const double fl = 2.0 * (double)P * Co_ * Ci_, by = 4.0 * ((double)P * (4 + Co_) + (double)Co_ * Ci_);
+            const double fl = 2.0 * (double)P * Co_ * Ci_, by = 4.0 * ((double)P * 4 + (double)Co_ * Ci_) + (store16 ? 2.0 : 4.0) * (double)P * Co_;
             char tg[64];
             snprintf(tg, sizeof tg, "fwd_chunk_kernel<%d, %d, false, 4>", Ci_, Co_);
             if (bf16 && Co_ == 64)
@@ -3446,7 +3447,8 @@ static int sa_mlp_fwd(const float* x0, int64_t P, int64_t K, int n_layers, const
             int ppb = 1024;
             while ((P + ppb - 1) / ppb < fwd_wgs_wanted(Co_ == 256 ? 256 : 512) && ppb > 128 && (!fuse_pool || (ppb / 2) % K == 0)) ppb >>= 1;   // >= 512 workgroups when P allows
             const unsigned gx = (unsigned)((P + ppb - 1) / ppb);
-            const double fl = 2.0 * (double)P * Co_ * Ci_, by = 4.0 * ((double)P * (Ci_ + Co_) + (double)Co_ * Ci_);
+            const double eb = store16 ? 2.0 : 4.0;      // bytes per stored activation (bf16 storage of the bf16 variant's stream chains)
+            const double fl = 2.0 * (double)P * Co_ * Ci_, by = eb * (double)P * (Ci_ + Co_) + 4.0 * (double)Co_ * Ci_;
             char tg[64];
             snprintf(tg, sizeof tg, bf16 ? "fwd_chunk_bf16_kernel<%d, %d, %s>" : "fwd_chunk_kernel<%d, %d, %s>", Ci_, Co_, fuse_pool ? "true" : "false");
 #define MP_FWD(CI, CO, PL)                                                                                                     \
@@ -3755,7 +3757,8 @@ static int sa_mlp_bwd(const float* x0, int64_t P, int64_t K, int n_layers, const
             const unsigned gx = (unsigned)((P + ppb - 1) / ppb);
             if ((size_t)gx > nblk_max) return MP_EUNSUPPORTED;
             const double fl = 4.0 * (double)P * Co * Ci;
-            const double by = 4.0 * ((pooled ? 1.0 : 2.0) * (double)P * Co + 2.0 * (double)P * Ci);
+            const double eb = store16 ? 2.0 : 4.0;      // bytes per stored Z / G element
+            const double by = eb * ((pooled ? 1.0 : 2.0) * (double)P * Co + 2.0 * (double)P * Ci);
             char tg[64];
             snprintf(tg, sizeof tg, bf16 ? "bwd_fused_bf16_kernel<%d, %d, %d>" : "bwd_fused_kernel<%d, %d, %d>", pooled ? 3 : 2, Co, Ci);
 #define MP_FUSED(MODE, CO_, CI_)                                                                                              \
@@ -3771,22 +3774,22 @@ static int sa_mlp_bwd(const float* x0, int64_t P, int64_t K, int n_layers, const
             if (rc_first && l == 1) {   // (never the pooled layer: n_layers >= 3)
                 snprintf(tg, sizeof tg, bf16 ? "bwd_fused_bf16_kernel<2, %d, 64, 4>" : "bwd_fused_kernel<2, %d, 64, 4>", Co);
                 if (bf16 && Co == 64)
-                    MP_LAUNCH(tg, fl, by - 4.0 * (double)P * (Ci - 4), (bwd_fused_kernel<SRC_DZ, 64, 64, SRC_ACT_RC, true, true>), dim3(gx), dim3(256), 0, stream, DZ, IN,
+                    MP_LAUNCH(tg, fl, by - eb * (double)P * Ci + 16.0 * (double)P, (bwd_fused_kernel<SRC_DZ, 64, 64, SRC_ACT_RC, true, true>), dim3(gx), dim3(256), 0, stream, DZ, IN,
                               (int)P, ppb, Ly.weight, grads[l].d_weight, Gn, partials);
                 else if (bf16)
-                    MP_LAUNCH(tg, fl, by - 4.0 * (double)P * (Ci - 4), (bwd_fused_kernel<SRC_DZ, 128, 64, SRC_ACT_RC, true, true>), dim3(gx), dim3(256), 0, stream, DZ, IN,
+                    MP_LAUNCH(tg, fl, by - eb * (double)P * Ci + 16.0 * (double)P, (bwd_fused_kernel<SRC_DZ, 128, 64, SRC_ACT_RC, true, true>), dim3(gx), dim3(256), 0, stream, DZ, IN,
                               (int)P, ppb, Ly.weight, grads[l].d_weight, Gn, partials);
                 else if (Co == 64 && split_enabled())
-                    MP_LAUNCH(tg, fl, by - 4.0 * (double)P * (Ci - 4), (bwd_fused_kernel<SRC_DZ, 64, 64, SRC_ACT_RC, true>), dim3(gx), dim3(256), 0, stream, DZ, IN,
+                    MP_LAUNCH(tg, fl, by - eb * (double)P * Ci + 16.0 * (double)P, (bwd_fused_kernel<SRC_DZ, 64, 64, SRC_ACT_RC, true>), dim3(gx), dim3(256), 0, stream, DZ, IN,
                               (int)P, ppb, Ly.weight, grads[l].d_weight, Gn, partials);
                 else if (Co == 64)
-                    MP_LAUNCH(tg, fl, by - 4.0 * (double)P * (Ci - 4), (bwd_fused_kernel<SRC_DZ, 64, 64, SRC_ACT_RC>), dim3(gx), dim3(256), 0, stream, DZ, IN,
+                    MP_LAUNCH(tg, fl, by - eb * (double)P * Ci + 16.0 * (double)P, (bwd_fused_kernel<SRC_DZ, 64, 64, SRC_ACT_RC>), dim3(gx), dim3(256), 0, stream, DZ, IN,
                               (int)P, ppb, Ly.weight, grads[l].d_weight, Gn, partials);
                 else if (split_enabled())
-                    MP_LAUNCH(tg, fl, by - 4.0 * (double)P * (Ci - 4), (bwd_fused_kernel<SRC_DZ, 128, 64, SRC_ACT_RC, true>), dim3(gx), dim3(256), 0, stream, DZ, IN,
+                    MP_LAUNCH(tg, fl, by - eb * (double)P * Ci + 16.0 * (double)P, (bwd_fused_kernel<SRC_DZ, 128, 64, SRC_ACT_RC, true>), dim3(gx), dim3(256), 0, stream, DZ, IN,
                               (int)P, ppb, Ly.weight, grads[l].d_weight, Gn, partials);
                 else
-                    MP_LAUNCH(tg, fl, by - 4.0 * (double)P * (Ci - 4), (bwd_fused_kernel<SRC_DZ, 128, 64, SRC_ACT_RC>), dim3(gx), dim3(256), 0, stream, DZ, IN,
+                    MP_LAUNCH(tg, fl, by - eb * (double)P * Ci + 16.0 * (double)P, (bwd_fused_kernel<SRC_DZ, 128, 64, SRC_ACT_RC>), dim3(gx), dim3(256), 0, stream, DZ, IN,
                               (int)P, ppb, Ly.weight, grads[l].d_weight, Gn, partials);
             } else if (!bf16 && split_enabled() && Ci == 128 && Co == 256 && (!pooled || (DZ.kshift >= 4 && ppb % 16 == 0))) {
                 // [r3] the 256-output layer: the two products on different waves (bwd_roles_kernel)
