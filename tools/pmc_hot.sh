@@ -4,7 +4,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 i=0
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_LDS" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_MFMA SQ_WAIT_INST_LDS"; do
   i=$((i+1)); rm -rf gpurun_out/pmch$i
-  rocprofv3 --pmc $set --kernel-trace --output-format csv -d gpurun_out/pmch$i -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-side-legs > gpurun_out/pmch$i.log 2>&1
+  rocprofv3 --pmc $set --kernel-trace --output-format csv -d gpurun_out/pmch$i -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-side-legs $PMC_ARGS > gpurun_out/pmch$i.log 2>&1
 done
 python3 - <<'PY'
 import csv, glob, collections
