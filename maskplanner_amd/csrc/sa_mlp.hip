@@ -3180,7 +3180,7 @@ __global__ __launch_bounds__(256) void first_factored_reduce_kernel(PosOperand D
                                                                     int K, int kshift, int chunk, float* __restrict__ dA, float* __restrict__ dW, int r16, int h16)
 {   // r16: see first_factored_bwd_kernel
 #ifndef MP_FACT_RU
-#define MP_FACT_RU 4
+#define MP_FACT_RU 8          // rows in flight per slot ([r4] 4 -> 8: 87 -> 79 us)
 #endif
     constexpr int CO = 4 * Q, RW = 64 / Q, U = MP_FACT_RU;
     __shared__ __attribute__((aligned(16))) float bn_lds[3 * CO];
@@ -3189,7 +3189,12 @@ __global__ __launch_bounds__(256) void first_factored_reduce_kernel(PosOperand D
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ql = lane % Q, sub = lane / Q;
     const int b = blockIdx.y;
-    const int j0 = (blockIdx.x * 4 + wave) * chunk, j1 = min(M, j0 + chunk);
+    // [r4] every row-slot of a wave (`sub`: the Q lanes that hold one row) walks its OWN contiguous piece of the wave's chunk: a point's run of
+    // sorted rows then stays in one slot (interleaved, a run of R rows was flushed min(R, RW) times), and a run that neither opens nor closes
+    // the piece belongs to this slot alone -- it is written with one 16-byte store per lane instead of four atomics (dA is zero on entry and
+    // a point's rows are contiguous in the sorted order, so nobody else adds to that row)
+    const int len = chunk / RW;
+    const int j0 = (blockIdx.x * 4 + wave) * chunk + sub * len, j1 = min(M, j0 + len);
     const int S = M / K;
     ChanConst k;
     load_consts<SRC_DZ>(DZ, 4 * ql, k, bn_lds, CO);
@@ -3197,22 +3202,24 @@ __global__ __launch_bounds__(256) void first_factored_reduce_kernel(PosOperand D
     const int* bp = pts + (size_t)b * M;
     float* dst = dA + (size_t)b * N * CO + 4 * ql;
     int cur = -1;
+    bool opening = true;       // the run in `acc` is the first of this piece (it may have begun in the piece before)
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), ax = acc, ay = acc, az = acc;
-    auto flush = [&]() {
+    auto flush = [&](bool shared) {
         if (cur >= 0) {
             float* d = dst + (size_t)cur * CO;
-            atomicAdd(d + 0, acc.x); atomicAdd(d + 1, acc.y); atomicAdd(d + 2, acc.z); atomicAdd(d + 3, acc.w);
+            if (shared) { atomicAdd(d + 0, acc.x); atomicAdd(d + 1, acc.y); atomicAdd(d + 2, acc.z); atomicAdd(d + 3, acc.w); }
+            else *reinterpret_cast<float4*>(d) = acc;
         }
     };
     // the sorted (row, point) pairs are fetched one batch AHEAD of the rows they name: the row loads depend on them
     int nm[U], npt[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-        const int jj = min(j0 + sub + u * RW, max(j1 - 1, j0));
-        nm[u] = bo[jj];
-        npt[u] = bp[jj];
+        const int jj = min(j0 + u, max(j1 - 1, j0));
+        nm[u] = bo[min(jj, M - 1)];
+        npt[u] = bp[min(jj, M - 1)];
     }
-    for (int j = j0 + sub; j < j1; j += RW * U) {
+    for (int j = j0; j < j1; j += U) {
         float4 z[U], g[U];
         float dx[U], dy[U], dzc[U];
         int pt[U];
@@ -3220,7 +3227,7 @@ __global__ __launch_bounds__(256) void first_factored_reduce_kernel(PosOperand D
         for (int u = 0; u < U; ++u) {
             const int m = nm[u];
             pt[u] = npt[u];
-            const int jn = min(j + (U + u) * RW, j1 - 1);
+            const int jn = min(j + U + u, j1 - 1);
             nm[u] = bo[jn];
             npt[u] = bp[jn];
             const size_t row = (size_t)b * M + m;
@@ -3233,14 +3240,14 @@ __global__ __launch_bounds__(256) void first_factored_reduce_kernel(PosOperand D
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            if (j + u * RW < j1) {
+            if (j + u < j1) {
                 float4 d;
                 d.x = xf1<SRC_DZ>(z[u].x, g[u].x, k.s.x, k.t.x, k.a.x, k.e.x, k.f.x);
                 d.y = xf1<SRC_DZ>(z[u].y, g[u].y, k.s.y, k.t.y, k.a.y, k.e.y, k.f.y);
                 d.z = xf1<SRC_DZ>(z[u].z, g[u].z, k.s.z, k.t.z, k.a.z, k.e.z, k.f.z);
                 d.w = xf1<SRC_DZ>(z[u].w, g[u].w, k.s.w, k.t.w, k.a.w, k.e.w, k.f.w);
                 d = rb16(d, r16);
-                if (pt[u] != cur) { flush(); cur = pt[u]; acc = make_float4(0.f, 0.f, 0.f, 0.f); }
+                if (pt[u] != cur) { flush(opening); opening = cur < 0; cur = pt[u]; acc = make_float4(0.f, 0.f, 0.f, 0.f); }
                 acc.x += d.x; acc.y += d.y; acc.z += d.z; acc.w += d.w;
                 ax.x = __builtin_fmaf(d.x, dx[u], ax.x); ax.y = __builtin_fmaf(d.y, dx[u], ax.y); ax.z = __builtin_fmaf(d.z, dx[u], ax.z); ax.w = __builtin_fmaf(d.w, dx[u], ax.w);
                 ay.x = __builtin_fmaf(d.x, dy[u], ay.x); ay.y = __builtin_fmaf(d.y, dy[u], ay.y); ay.z = __builtin_fmaf(d.z, dy[u], ay.z); ay.w = __builtin_fmaf(d.w, dy[u], ay.w);
@@ -3248,7 +3255,7 @@ __global__ __launch_bounds__(256) void first_factored_reduce_kernel(PosOperand D
             }
         }
     }
-    flush();
+    flush(true);               // the closing run may go on in the next piece
     const int slot = wave * RW + sub;
     *reinterpret_cast<float4*>(&red[0][slot][4 * ql]) = ax;
     *reinterpret_cast<float4*>(&red[1][slot][4 * ql]) = ay;
@@ -3854,7 +3861,15 @@ static int sa_mlp_bwd(const float* x0, int64_t P, int64_t K, int n_layers, const
                     pts = o_ + P;
                 }
                 if (!mp::zero_async(grad_x0, (size_t)Bc * Np * Co, stream)) return MP_ELAUNCH;
-                const int chunk = 128;   // rows per wave (measured: 32: 236 us, 64: 160, 128: 122, 256: 126 at the bench shape)
+#ifndef MP_FACT_RCHUNK
+#define MP_FACT_RCHUNK 256
+#endif
+                // rows per wave: long pieces (fewer shared runs, more rows in flight per slot) as long as the grid still covers the chip.
+                // Measured at the bench shape (8 192 rows x 32 clouds, 512-byte rows): 64: 122 us, 128: 90, 256 (one workgroup per CU): 80,
+                // 512: 122; the multi-scale level's 256-byte rows (4 096 x 32) prefer two workgroups per CU
+                int chunk = MP_FACT_RCHUNK;
+                const int64_t min_wg = Co >= 128 ? 256 : 512;
+                while (chunk > 64 && (int64_t)((M + 4 * chunk - 1) / (4 * chunk)) * Bc < min_wg) chunk >>= 1;
                 const unsigned gxr = (unsigned)((M + 4 * chunk - 1) / (4 * chunk));
 #define MP_FACT_R(Q_)                                                                                                            \
     MP_LAUNCH("first_factored_reduce_kernel", fl, by, (first_factored_reduce_kernel<Q_>), dim3(gxr, (unsigned)Bc), dim3(256), 0, stream, DZ, order, pts, \
