@@ -3174,7 +3174,28 @@ static int launch_csr_rows(const int64_t* idx, int64_t Bc, int Np, int M, int* o
     return MP_OK;
 }
 
-template <int Q>
+// One gathered row's share of a lane: NV = 1: four channels (fp32 storage: 16 bytes; bf16 storage: 8 bytes), NV = 2: eight channels of a
+// bf16-stored row (16 bytes, kept packed until they are used).
+template <int NV> struct FactRow;
+template <> struct FactRow<1> {
+    float4 v;
+    __device__ __forceinline__ void load(const float* base, size_t elem, int h16) { v = ldz4(base, elem, h16); }
+    __device__ __forceinline__ float4 get(int) const { return v; }
+};
+template <> struct FactRow<2> {
+    uint4 r;
+    __device__ __forceinline__ void load(const float* base, size_t elem, int) { r = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(base) + elem); }
+    __device__ __forceinline__ float4 get(int i) const
+    {
+        const unsigned a = i ? r.z : r.x, c = i ? r.w : r.y;
+        return make_float4(__uint_as_float(a << 16), __uint_as_float(a & 0xffff0000u), __uint_as_float(c << 16), __uint_as_float(c & 0xffff0000u));
+    }
+};
+
+// NV = 2 ([r4], bf16 activation storage only): a lane takes EIGHT channels of a row, i.e. one 16-byte load per tensor instead of an
+// 8-byte one -- with four channels per lane the bf16 variant moved half the bytes with the same number of load instructions and rows
+// in flight, and ran at 1 TB/s (134 us for the 8 192 x 32-row level that takes 80 us in fp32)
+template <int Q, int NV>
 __global__ __launch_bounds__(256) void first_factored_reduce_kernel(PosOperand DZ, const int* __restrict__ order, const int* __restrict__ pts,
                                                                     const float* __restrict__ xyz, const float* __restrict__ new_xyz, int N, int M,
                                                                     int K, int kshift, int chunk, float* __restrict__ dA, float* __restrict__ dW, int r16, int h16)
@@ -3182,45 +3203,51 @@ __global__ __launch_bounds__(256) void first_factored_reduce_kernel(PosOperand D
 #ifndef MP_FACT_RU
 #define MP_FACT_RU 8          // rows in flight per slot ([r4] 4 -> 8: 87 -> 79 us)
 #endif
-    constexpr int CO = 4 * Q, RW = 64 / Q, U = MP_FACT_RU;
+    constexpr int CO = 4 * Q, CPL = 4 * NV, QL = CO / CPL, RW = 64 / QL, U = MP_FACT_RU;
     __shared__ __attribute__((aligned(16))) float bn_lds[3 * CO];
     bn_prologue(DZ.bn, bn_lds, CO, 0, CO, blockIdx.x == 0 && blockIdx.y == 0);
     __shared__ float red[3][4 * RW][CO];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int ql = lane % Q, sub = lane / Q;
+    const int ql = lane % QL, sub = lane / QL;
     const int b = blockIdx.y;
-    // [r4] every row-slot of a wave (`sub`: the Q lanes that hold one row) walks its OWN contiguous piece of the wave's chunk: a point's run of
+    // [r4] every row-slot of a wave (`sub`: the QL lanes that hold one row) walks its OWN contiguous piece of the wave's chunk: a point's run of
     // sorted rows then stays in one slot (interleaved, a run of R rows was flushed min(R, RW) times), and a run that neither opens nor closes
-    // the piece belongs to this slot alone -- it is written with one 16-byte store per lane instead of four atomics (dA is zero on entry and
-    // a point's rows are contiguous in the sorted order, so nobody else adds to that row)
+    // the piece belongs to this slot alone -- it is written with 16-byte stores instead of atomics (dA is zero on entry and a point's rows
+    // are contiguous in the sorted order, so nobody else adds to that row)
     const int len = chunk / RW;
     const int j0 = (blockIdx.x * 4 + wave) * chunk + sub * len, j1 = min(M, j0 + len);
     const int S = M / K;
-    ChanConst k;
-    load_consts<SRC_DZ>(DZ, 4 * ql, k, bn_lds, CO);
+    ChanConst k[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) load_consts<SRC_DZ>(DZ, CPL * ql + 4 * v, k[v], bn_lds, CO);
     const int* bo = order + (size_t)b * M;
     const int* bp = pts + (size_t)b * M;
-    float* dst = dA + (size_t)b * N * CO + 4 * ql;
+    float* dst = dA + (size_t)b * N * CO + CPL * ql;
     int cur = -1;
     bool opening = true;       // the run in `acc` is the first of this piece (it may have begun in the piece before)
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), ax = acc, ay = acc, az = acc;
+    float4 acc[NV], ax[NV], ay[NV], az[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) acc[v] = ax[v] = ay[v] = az[v] = make_float4(0.f, 0.f, 0.f, 0.f);
     auto flush = [&](bool shared) {
         if (cur >= 0) {
-            float* d = dst + (size_t)cur * CO;
-            if (shared) { atomicAdd(d + 0, acc.x); atomicAdd(d + 1, acc.y); atomicAdd(d + 2, acc.z); atomicAdd(d + 3, acc.w); }
-            else *reinterpret_cast<float4*>(d) = acc;
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                float* d = dst + (size_t)cur * CO + 4 * v;
+                if (shared) { atomicAdd(d + 0, acc[v].x); atomicAdd(d + 1, acc[v].y); atomicAdd(d + 2, acc[v].z); atomicAdd(d + 3, acc[v].w); }
+                else *reinterpret_cast<float4*>(d) = acc[v];
+            }
         }
     };
     // the sorted (row, point) pairs are fetched one batch AHEAD of the rows they name: the row loads depend on them
     int nm[U], npt[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-        const int jj = min(j0 + u, max(j1 - 1, j0));
-        nm[u] = bo[min(jj, M - 1)];
-        npt[u] = bp[min(jj, M - 1)];
+        const int jj = min(min(j0 + u, max(j1 - 1, j0)), M - 1);
+        nm[u] = bo[jj];
+        npt[u] = bp[jj];
     }
     for (int j = j0; j < j1; j += U) {
-        float4 z[U], g[U];
+        FactRow<NV> z[U], g[U];
         float dx[U], dy[U], dzc[U];
         int pt[U];
 #pragma unroll
@@ -3231,8 +3258,8 @@ __global__ __launch_bounds__(256) void first_factored_reduce_kernel(PosOperand D
             nm[u] = bo[jn];
             npt[u] = bp[jn];
             const size_t row = (size_t)b * M + m;
-            z[u] = ldz4(DZ.x, row * CO + 4 * ql, h16);
-            g[u] = ldz4(DZ.g, row * CO + 4 * ql, h16);
+            z[u].load(DZ.x, row * CO + CPL * ql, h16);
+            g[u].load(DZ.g, row * CO + CPL * ql, h16);
             const unsigned grp = (unsigned)b * (unsigned)S + (kshift >= 0 ? (unsigned)m >> kshift : (unsigned)m / (unsigned)K);
             const float* x = xyz + ((size_t)b * N + pt[u]) * 3;
             const float* c = new_xyz + (size_t)grp * 3;
@@ -3241,25 +3268,35 @@ __global__ __launch_bounds__(256) void first_factored_reduce_kernel(PosOperand D
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (j + u < j1) {
-                float4 d;
-                d.x = xf1<SRC_DZ>(z[u].x, g[u].x, k.s.x, k.t.x, k.a.x, k.e.x, k.f.x);
-                d.y = xf1<SRC_DZ>(z[u].y, g[u].y, k.s.y, k.t.y, k.a.y, k.e.y, k.f.y);
-                d.z = xf1<SRC_DZ>(z[u].z, g[u].z, k.s.z, k.t.z, k.a.z, k.e.z, k.f.z);
-                d.w = xf1<SRC_DZ>(z[u].w, g[u].w, k.s.w, k.t.w, k.a.w, k.e.w, k.f.w);
-                d = rb16(d, r16);
-                if (pt[u] != cur) { flush(opening); opening = cur < 0; cur = pt[u]; acc = make_float4(0.f, 0.f, 0.f, 0.f); }
-                acc.x += d.x; acc.y += d.y; acc.z += d.z; acc.w += d.w;
-                ax.x = __builtin_fmaf(d.x, dx[u], ax.x); ax.y = __builtin_fmaf(d.y, dx[u], ax.y); ax.z = __builtin_fmaf(d.z, dx[u], ax.z); ax.w = __builtin_fmaf(d.w, dx[u], ax.w);
-                ay.x = __builtin_fmaf(d.x, dy[u], ay.x); ay.y = __builtin_fmaf(d.y, dy[u], ay.y); ay.z = __builtin_fmaf(d.z, dy[u], ay.z); ay.w = __builtin_fmaf(d.w, dy[u], ay.w);
-                az.x = __builtin_fmaf(d.x, dzc[u], az.x); az.y = __builtin_fmaf(d.y, dzc[u], az.y); az.z = __builtin_fmaf(d.z, dzc[u], az.z); az.w = __builtin_fmaf(d.w, dzc[u], az.w);
+                if (pt[u] != cur) { flush(opening); opening = cur < 0; cur = pt[u];
+#pragma unroll
+                    for (int v = 0; v < NV; ++v) acc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    const float4 zz = z[u].get(v), gg = g[u].get(v);
+                    float4 d;
+                    d.x = xf1<SRC_DZ>(zz.x, gg.x, k[v].s.x, k[v].t.x, k[v].a.x, k[v].e.x, k[v].f.x);
+                    d.y = xf1<SRC_DZ>(zz.y, gg.y, k[v].s.y, k[v].t.y, k[v].a.y, k[v].e.y, k[v].f.y);
+                    d.z = xf1<SRC_DZ>(zz.z, gg.z, k[v].s.z, k[v].t.z, k[v].a.z, k[v].e.z, k[v].f.z);
+                    d.w = xf1<SRC_DZ>(zz.w, gg.w, k[v].s.w, k[v].t.w, k[v].a.w, k[v].e.w, k[v].f.w);
+                    d = rb16(d, r16);
+                    acc[v].x += d.x; acc[v].y += d.y; acc[v].z += d.z; acc[v].w += d.w;
+                    ax[v].x = __builtin_fmaf(d.x, dx[u], ax[v].x); ax[v].y = __builtin_fmaf(d.y, dx[u], ax[v].y); ax[v].z = __builtin_fmaf(d.z, dx[u], ax[v].z); ax[v].w = __builtin_fmaf(d.w, dx[u], ax[v].w);
+                    ay[v].x = __builtin_fmaf(d.x, dy[u], ay[v].x); ay[v].y = __builtin_fmaf(d.y, dy[u], ay[v].y); ay[v].z = __builtin_fmaf(d.z, dy[u], ay[v].z); ay[v].w = __builtin_fmaf(d.w, dy[u], ay[v].w);
+                    az[v].x = __builtin_fmaf(d.x, dzc[u], az[v].x); az[v].y = __builtin_fmaf(d.y, dzc[u], az[v].y); az[v].z = __builtin_fmaf(d.z, dzc[u], az[v].z); az[v].w = __builtin_fmaf(d.w, dzc[u], az[v].w);
+                }
             }
         }
     }
     flush(true);               // the closing run may go on in the next piece
     const int slot = wave * RW + sub;
-    *reinterpret_cast<float4*>(&red[0][slot][4 * ql]) = ax;
-    *reinterpret_cast<float4*>(&red[1][slot][4 * ql]) = ay;
-    *reinterpret_cast<float4*>(&red[2][slot][4 * ql]) = az;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        *reinterpret_cast<float4*>(&red[0][slot][CPL * ql + 4 * v]) = ax[v];
+        *reinterpret_cast<float4*>(&red[1][slot][CPL * ql + 4 * v]) = ay[v];
+        *reinterpret_cast<float4*>(&red[2][slot][CPL * ql + 4 * v]) = az[v];
+    }
     __syncthreads();
     for (int e = tid; e < 3 * CO; e += 256) {
         const int jc = e / CO, c = e - jc * CO;
@@ -3869,12 +3906,15 @@ static int sa_mlp_bwd(const float* x0, int64_t P, int64_t K, int n_layers, const
                 // 512: 122; the multi-scale level's 256-byte rows (4 096 x 32) prefer two workgroups per CU
                 int chunk = MP_FACT_RCHUNK;
                 const int64_t min_wg = Co >= 128 ? 256 : 512;
-                while (chunk > 64 && (int64_t)((M + 4 * chunk - 1) / (4 * chunk)) * Bc < min_wg) chunk >>= 1;
+                const bool wide = store16 && Co >= 64;          // bf16 storage: eight channels (16 bytes) per lane
+                const int slots = 64 / (int)(Co / (wide ? 8 : 4));       // rows per wave instruction
+                while (chunk > 16 * slots && (int64_t)((M + 4 * chunk - 1) / (4 * chunk)) * Bc < min_wg) chunk >>= 1;
                 const unsigned gxr = (unsigned)((M + 4 * chunk - 1) / (4 * chunk));
-#define MP_FACT_R(Q_)                                                                                                            \
-    MP_LAUNCH("first_factored_reduce_kernel", fl, by, (first_factored_reduce_kernel<Q_>), dim3(gxr, (unsigned)Bc), dim3(256), 0, stream, DZ, order, pts, \
+#define MP_FACT_R(Q_, NV_)                                                                                                       \
+    MP_LAUNCH("first_factored_reduce_kernel", fl, by, (first_factored_reduce_kernel<Q_, NV_>), dim3(gxr, (unsigned)Bc), dim3(256), 0, stream, DZ, order, pts, \
               gather->xyz, gather->new_xyz, Np, M, (int)K, log2_or_neg(K), chunk, grad_x0, grads[l].d_weight, (int)bf16, (int)store16)
-                if (Co == 64) MP_FACT_R(16); else if (Co == 128) MP_FACT_R(32); else MP_FACT_R(64);
+                if (wide) { if (Co == 64) MP_FACT_R(16, 2); else if (Co == 128) MP_FACT_R(32, 2); else MP_FACT_R(64, 2); }
+                else { if (Co == 64) MP_FACT_R(16, 1); else if (Co == 128) MP_FACT_R(32, 1); else MP_FACT_R(64, 1); }
 #undef MP_FACT_R
                 MP_CHECK_LAUNCH();
                 continue;
