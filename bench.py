@@ -168,6 +168,9 @@ def kernel_tables(kernels, profiled_steps, floors):
             e["frac_latency_floor"] = round(floors[k] / (t * 1e6), 4)
         named[k] = e
     per_step = {k: round(v["ms"] * 1e3 / profiled_steps, 1) for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]["ms"])}
+    if os.environ.get("MASKPLANNER_BENCH_RATES"):     # diagnostic: [us per step, launches per step, algorithmic GB/s, TFLOP/s] of every tagged kernel
+        per_step = {k: [per_step[k], round(v["calls"] / profiled_steps, 1), round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 0),
+                        round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 1)] for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]["ms"])}
     return named, per_step
 
 

@@ -1087,6 +1087,15 @@ __global__ __launch_bounds__(THREADS) void dw_gemm_kernel(PosOperand DZ, PosOper
 #ifndef MP_PD2
 #define MP_PD2 3            // [r3] fused backward: two chunks of loads in flight (two register sets, loop unrolled by two); bit mask, see PD2
 #endif
+#ifndef MP_PD2_ONE
+#define MP_PD2_ONE 0        // [r4] the one-plane (bf16 variant) kernels: one chunk of loads in flight (config 5: 6.27 -> 6.20 ms with the mask at 0; and see PHASE_SYNC)
+#endif
+#ifndef MP_ONE_PHASE_SYNC
+#define MP_ONE_PHASE_SYNC 2  // 1: the phase barrier of the 32-position one-plane kernels only with two chunks in flight, 2: always
+#endif
+#ifndef MP_ONE_DBK32
+#define MP_ONE_DBK32 1      // [r4] one-plane fused backward: 32 positions per chunk
+#endif
 #ifndef MP_FPD2
 #define MP_FPD2 0           // [r3] position-stream forward: two chunks of loads in flight
 #endif
@@ -1115,7 +1124,8 @@ __global__ __launch_bounds__(CO > 128 ? 512 : 256) void fwd_chunk_kernel(PosOper
     // SPLIT: the chunk as three bf16 planes [plane][row][k] (rows 16-byte aligned, stride = 4 dwords mod 64 banks)
     constexpr int LDH = CI + 8;
     __shared__ __attribute__((aligned(16))) float sA[2][SPLIT ? 4 : DBK * LDA];
-    __shared__ __attribute__((aligned(16))) __bf16 sH[2][3][SPLIT ? DBK * LDH : 8];
+    constexpr int NPLN = ONE ? 1 : 3;        // ([r4] ONE: the single plane only -- see bwd_fused_kernel)
+    __shared__ __attribute__((aligned(16))) __bf16 sH[2][NPLN][SPLIT ? DBK * LDH : 8];
     __shared__ float4 sT[2][TAIL ? DBK : 1];           // TAIL: the 4 extra input columns of the chunk's rows
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
@@ -1235,8 +1245,8 @@ __global__ __launch_bounds__(CO > 128 ? 512 : 256) void fwd_chunk_kernel(PosOper
                 for (int rt = 0; rt < 2; ++rt) {
                     const int o = ao + rt * 16 * LDH + 32 * st;
                     const bf16x8 ah = *reinterpret_cast<const bf16x8*>(&sH[cur][0][o]);
-                    const bf16x8 am = *reinterpret_cast<const bf16x8*>(&sH[cur][1][o]);
-                    const bf16x8 al = *reinterpret_cast<const bf16x8*>(&sH[cur][2][o]);
+                    const bf16x8 am = *reinterpret_cast<const bf16x8*>(&sH[cur][ONE ? 0 : 1][o]);
+                    const bf16x8 al = *reinterpret_cast<const bf16x8*>(&sH[cur][ONE ? 0 : 2][o]);
                     f32x4& a = rt ? a1 : a0;
                     f32x4& c = rt ? c1 : c0;
                     if constexpr (!ONE) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, wsp[0][st], c, 0, 0, 0);
@@ -1261,8 +1271,8 @@ __global__ __launch_bounds__(CO > 128 ? 512 : 256) void fwd_chunk_kernel(PosOper
 #pragma unroll
             for (int st = 0; st < CI / 16; ++st) {
                 const bf16x8 ah = *reinterpret_cast<const bf16x8*>(&sH[cur][0][ao + 16 * st]);
-                const bf16x8 am = *reinterpret_cast<const bf16x8*>(&sH[cur][1][ao + 16 * st]);
-                const bf16x8 al = *reinterpret_cast<const bf16x8*>(&sH[cur][2][ao + 16 * st]);
+                const bf16x8 am = *reinterpret_cast<const bf16x8*>(&sH[cur][ONE ? 0 : 1][ao + 16 * st]);
+                const bf16x8 al = *reinterpret_cast<const bf16x8*>(&sH[cur][ONE ? 0 : 2][ao + 16 * st]);
                 if constexpr (!ONE) cor = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, wsp[0][st], cor, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wsp[0][st], acc, 0, 0, 0);
                 if constexpr (!ONE) {
@@ -1410,7 +1420,10 @@ __global__ __launch_bounds__(bwd_fused_threads(CO, CI, SPLIT, ONE), (CO >= 128 &
 {
     __shared__ __attribute__((aligned(16))) float bn_lds[3 * CO];           // (a, e, f) of dZ_l when this kernel derives them
     constexpr int NT = bwd_fused_threads(CO, CI, SPLIT, ONE), NW = NT / 64;
-    constexpr int DBK = (CI == 128 || SPLIT) ? 16 : 32;   // positions per chunk (LDS and registers: at least two workgroups per CU)
+    // [r4] ONE (the bf16 variant's single plane): 32 positions per chunk -- a chunk's products are a sixth of the three-plane kernel's, so
+    // at 16 positions the two barriers and the LDS round trips of a chunk were most of its 3 300 cycles (MFMA 8 %, VALU 29 %, 65 % waiting)
+    constexpr int DBK = (SPLIT && ONE && MP_ONE_DBK32 && CO == 128 && CI == 128) ? 32 : ((CI == 128 || SPLIT) ? 16 : 32);   // (the other shapes spill with the doubled row sets)
+      // positions per chunk (LDS and registers: at least two workgroups per CU)
     constexpr int XW = DBK == 32 ? CI / (NW / 2) : CI / NW; // dX columns per wave (the chunk's dX tile is [DBK x CI])
     constexpr int HT = XW / 16;                             // 16x16 dX tiles per wave and chunk
     constexpr int LDA = CO + 4;                 // 16-byte aligned rows: one ds_write_b128 per staged float4, ds_read_b128 dX fragments
@@ -1419,7 +1432,7 @@ __global__ __launch_bounds__(bwd_fused_threads(CO, CI, SPLIT, ONE), (CO >= 128 &
 
     constexpr int PA = DBK * CO / 4 / NT, PB = DBK * CI / 4 / NT;
     static_assert((CO == 64 || CO == 128 || CO == 256) && (CI == 64 || CI == 128) && PA >= 1 && PB >= 1 && HT >= 1, "tile");
-    static_assert(!SPLIT || DBK == 16, "split: one 32x32x16 k-step of positions per chunk");
+    static_assert(!SPLIT || DBK == 16 || ONE, "split: one 32x32x16 k-step of positions per chunk (the one-plane form loops over two)");
     // KSPLIT (256 outputs): in the dX product every wave reads the WHOLE dZ chunk from LDS for its 16 columns -- 192 of the 332 KB of LDS
     // traffic per chunk.  Here a wave takes 32 columns (two tiles) and HALF of K, its partner (wave ^ 4) the other half; each
     // finalises one of the two tiles after adding the partner's partial (8 KB through LDS, one extra barrier per chunk).
@@ -1431,8 +1444,12 @@ __global__ __launch_bounds__(bwd_fused_threads(CO, CI, SPLIT, ONE), (CO >= 128 &
     constexpr int GS = DBK * 8 + (KSWZ ? 0 : ((SPLIT && CI == 64 && MP_SPLIT_WGS == 3) ? 16 : 32));
     __shared__ __attribute__((aligned(16))) float sA[2][SPLIT ? 4 : DBK * LDA];
     __shared__ __attribute__((aligned(16))) float sB[2][SPLIT ? 4 : DBK * CI];
-    __shared__ __attribute__((aligned(16))) __bf16 hA[2][3][SPLIT ? (CO / 8) * GS : 8];   // dZ chunk as (h, m, l) planes
-    __shared__ __attribute__((aligned(16))) __bf16 hB[2][3][SPLIT ? (CI / 8) * GS : 8];   // activated input chunk
+    // ([r4] ONE: a single plane -- the two unused ones were a third of the kernel's LDS.  It is the REGISTERS that keep the bf16 variant's
+    // 128 x 128 kernels at one eight-wave workgroup per CU (162 VGPRs; forcing 128 spills 34 dwords: 706 -> 1 100 us; four-wave workgroups
+    // take 281): two chunks of loads in flight per CU = the 2.3 TB/s they run at, with every unit idle)
+    constexpr int NPLN = ONE ? 1 : 3;
+    __shared__ __attribute__((aligned(16))) __bf16 hA[2][NPLN][SPLIT ? (CO / 8) * GS : 8];   // dZ chunk as (h, m, l) planes
+    __shared__ __attribute__((aligned(16))) __bf16 hB[2][NPLN][SPLIT ? (CI / 8) * GS : 8];   // activated input chunk
     __shared__ __attribute__((aligned(16))) float sZ[2][DBK * CI];
     __shared__ float red[2][2][CI];
     const int tid = threadIdx.x;
@@ -1584,7 +1601,9 @@ __global__ __launch_bounds__(bwd_fused_threads(CO, CI, SPLIT, ONE), (CO >= 128 &
     __shared__ f32x4 xbuf[KSPLIT ? NW : 1][64];      // KSPLIT: the partial of the tile the partner wave finalises
     f32x4 ax[HT];                                    // the finished dX tile(s) of this wave, between g_mfma and g_epi
 
-    constexpr bool PD2 = MP_PD2 && SPLIT && !KSPLIT && ((MP_PD2 >> (NT == 512 ? (CO == 256 ? 2 : 1) : 0)) & 1);   // bit 0: 256-thread kernels, 1: <.,128,128>, 2: <.,256,128>
+    constexpr int PD2M = ONE ? MP_PD2_ONE : MP_PD2;
+    constexpr bool PD2 = PD2M && SPLIT && !KSPLIT && ((PD2M >> (NT == 512 ? (CO == 256 ? 2 : 1) : 0)) & 1);
+    constexpr bool PHASE_SYNC = SPLIT && ONE && DBK == 32 && (PD2 || MP_ONE_PHASE_SYNC == 2) && MP_ONE_PHASE_SYNC;   // bit 0: 256-thread kernels, 1: <.,128,128>, 2: <.,256,128>
     constexpr bool DESYNC = MP_DESYNC && NT == 512 && CO == 256 && SPLIT && !KSPLIT && !PD2;   // (<.,128,128>: 128 -> 134 us with it, 124 -> 116 with PD2)
     const int half = DESYNC ? __builtin_amdgcn_readfirstlane(wave >> 2) : 0;
     gload(p0, rs0);
@@ -1606,16 +1625,19 @@ __global__ __launch_bounds__(bwd_fused_threads(CO, CI, SPLIT, ONE), (CO >= 128 &
         const int cur = kc & 1;
         if (!PD2 && kc + 1 + half < nchunks) gload(p0 + (kc + 1 + half) * DBK, rs);
         auto do_dw = [&]() {
-        if constexpr (SPLIT && ONE) {   // one plane: dW += bf16(dZ)^T * bf16(act(Z_{l-1}))
-            bf16x8 fb[TNW], fa[TMW];
+        if constexpr (SPLIT && ONE) {   // one plane: dW += bf16(dZ)^T * bf16(act(Z_{l-1})), one k-step per 16 positions of the chunk
 #pragma unroll
-            for (int ni = 0; ni < TNW; ++ni) fb[ni] = tr_frag_packed<GS, KSWZ>(hB[cur][0], 0, wcol0 + ni * 32);
+            for (int k0 = 0; k0 < DBK; k0 += 16) {
+                bf16x8 fb[TNW], fa[TMW];
 #pragma unroll
-            for (int mi = 0; mi < TMW; ++mi) fa[mi] = tr_frag_packed<GS, KSWZ>(hA[cur][0], 0, wrow0 + mi * 32);
+                for (int ni = 0; ni < TNW; ++ni) fb[ni] = tr_frag_packed<GS, KSWZ>(hB[cur][0], k0, wcol0 + ni * 32);
 #pragma unroll
-            for (int mi = 0; mi < TMW; ++mi)
+                for (int mi = 0; mi < TMW; ++mi) fa[mi] = tr_frag_packed<GS, KSWZ>(hA[cur][0], k0, wrow0 + mi * 32);
 #pragma unroll
-                for (int ni = 0; ni < TNW; ++ni) accW[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mi], fb[ni], accW[mi][ni], 0, 0, 0);
+                for (int mi = 0; mi < TMW; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < TNW; ++ni) accW[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mi], fb[ni], accW[mi][ni], 0, 0, 0);
+            }
         } else         if constexpr (SPLIT) {   // dW += dZ^T * act(Z_{l-1}): one k-step of 16 positions, six plane products per tile
             // fragments in the order they are consumed (one dZ plane live at a time): l*h, h*l, h*m, h*h, m*m, m*h
             bf16x8 fb[3][TNW], fa[TMW];
@@ -1664,14 +1686,14 @@ __global__ __launch_bounds__(bwd_fused_threads(CO, CI, SPLIT, ONE), (CO >= 128 &
                 const int ao = (4 * gst0 + kq) * GS + ((xrow0 + l15) ^ (KSWZ ? kswz(kq) : 0)) * 8;
                 bf16x8 af[2][3];
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) af[0][pl] = *reinterpret_cast<const bf16x8*>(&hA[cur][pl][ao]);
+                for (int pl = 0; pl < NPLN; ++pl) af[0][pl] = *reinterpret_cast<const bf16x8*>(&hA[cur][pl][ao]);
 #pragma unroll
                 for (int st = 0; st < NSTW; ++st) {
                     if (st + 1 < NSTW) {
 #pragma unroll
-                        for (int pl = 0; pl < 3; ++pl) af[(st + 1) & 1][pl] = *reinterpret_cast<const bf16x8*>(&hA[cur][pl][ao + 4 * (st + 1) * GS]);
+                        for (int pl = 0; pl < NPLN; ++pl) af[(st + 1) & 1][pl] = *reinterpret_cast<const bf16x8*>(&hA[cur][pl][ao + 4 * (st + 1) * GS]);
                     }
-                    const bf16x8 ah = af[st & 1][0], am = af[st & 1][1], al = af[st & 1][2];
+                    const bf16x8 ah = af[st & 1][0], am = af[st & 1][ONE ? 0 : 1], al = af[st & 1][ONE ? 0 : 2];
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
                         c2[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, wsp[h][st][0], c2[h], 0, 0, 0);
@@ -1692,14 +1714,14 @@ __global__ __launch_bounds__(bwd_fused_threads(CO, CI, SPLIT, ONE), (CO >= 128 &
                 const int ao = kq * GS + ((xrow0 + l15) ^ (KSWZ ? kswz(kq) : 0)) * 8;
                 bf16x8 af[2][3];       // the fragments of k-step st + 1 are requested before the MFMAs of step st are issued
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) af[0][pl] = *reinterpret_cast<const bf16x8*>(&hA[cur][pl][ao]);
+                for (int pl = 0; pl < NPLN; ++pl) af[0][pl] = *reinterpret_cast<const bf16x8*>(&hA[cur][pl][ao]);
 #pragma unroll
                 for (int st = 0; st < CO / 32; ++st) {
                     if (st + 1 < CO / 32) {
 #pragma unroll
-                        for (int pl = 0; pl < 3; ++pl) af[(st + 1) & 1][pl] = *reinterpret_cast<const bf16x8*>(&hA[cur][pl][ao + 4 * (st + 1) * GS]);
+                        for (int pl = 0; pl < NPLN; ++pl) af[(st + 1) & 1][pl] = *reinterpret_cast<const bf16x8*>(&hA[cur][pl][ao + 4 * (st + 1) * GS]);
                     }
-                    const bf16x8 ah = af[st & 1][0], am = af[st & 1][1], al = af[st & 1][2];
+                    const bf16x8 ah = af[st & 1][0], am = af[st & 1][ONE ? 0 : 1], al = af[st & 1][ONE ? 0 : 2];
 #pragma unroll
                     for (int h = 0; h < HT; ++h) {
                         if constexpr (!ONE) cx[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, wsp[h][st][0], cx[h], 0, 0, 0);
@@ -1802,6 +1824,14 @@ __global__ __launch_bounds__(bwd_fused_threads(CO, CI, SPLIT, ONE), (CO >= 128 &
                 for (int h = 0; h < HT; ++h) ax[h] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
             if constexpr (!((MP_BF_ABL >> 2) & 1)) g_epi();
+            // [r4] 32-position chunks of the one-plane kernels: a barrier between the products and the staging of the next chunk.  With two
+            // chunks of loads in flight and ONE barrier per chunk that form returned run-to-run varying weight gradients (tools/err_probe.py:
+            // 3e-3 ... 9e-2 against a steady 6.5e-4); a full vmcnt(0) wait at this point does not remove the spread, an s_barrier does, so
+            // the conflict is between one wave's staging writes and another wave's product reads -- the pair itself was not identified
+            // (NOTEBOOK.md).  With one chunk in flight (the default: MP_PD2_ONE = 0) 24 repetitions were bit-steady without this barrier as
+            // well; it is kept (MP_ONE_PHASE_SYNC = 2, +30 us at config 5) because the cause is not understood.  Two barriers per 32 positions
+            // is what the 16-position form pays.
+            if constexpr (PHASE_SYNC) __builtin_amdgcn_s_barrier();
             if (kc + 1 < nchunks) sstore(cur ^ 1, rs);
             // PD2: the set just emptied is refilled at once with the chunk it stages two iterations from now -- two chunks of
             // loads in flight per workgroup instead of one (an iteration of these kernels lasts about one loaded-HBM round trip)
