@@ -18,14 +18,34 @@ namespace {
 
 constexpr int LSAP_MAX = 2048;          // columns per sample: up to 32 per lane
 
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v)
+{
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    const unsigned lo = mp::dpp_u32<CTRL>((unsigned)u), hi = mp::dpp_u32<CTRL>((unsigned)(u >> 32));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+// wave-wide minimum, uniform in every lane: four DPP steps inside the 16-lane rows, then the four row results by readlane -- no LDS
+// round trips ([r4]: the xor-shuffle form was twelve dependent ds_bpermute on the serial path of every Dijkstra step)
 __device__ __forceinline__ double wave_min_f64(double v)
 {
+    double t;
+    t = dpp_f64<mp::DPP_QUAD_XOR1>(v); v = t < v ? t : v;
+    t = dpp_f64<mp::DPP_QUAD_XOR2>(v); v = t < v ? t : v;
+    t = dpp_f64<mp::DPP_ROW_HALF_MIRROR>(v); v = t < v ? t : v;
+    t = dpp_f64<mp::DPP_ROW_MIRROR>(v); v = t < v ? t : v;
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    double r[4];
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const double t = __shfl_xor(v, o, 64);
-        v = t < v ? t : v;
+    for (int i = 0; i < 4; ++i) {
+        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, 16 * i);
+        const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), 16 * i);
+        r[i] = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
     }
-    return v;
+    r[0] = r[1] < r[0] ? r[1] : r[0];
+    r[2] = r[3] < r[2] ? r[3] : r[2];
+    return r[2] < r[0] ? r[2] : r[0];
 }
 
 __device__ __forceinline__ void wave_sync()

@@ -3027,24 +3027,28 @@ extern "C" int mp_sa_mlp_bf16_storage(int n_layers, const int64_t* channels, int
 #ifndef MP_FACT_PPB
 #define MP_FACT_PPB 256    // positions per workgroup of the forward kernel = per BatchNorm partial row (the backward kernel takes twice as many)
 #endif
-template <int Q>   // Q = Co / 4: lanes per row
+// NV = 2 ([r4], bf16 storage of Z_0): eight channels per lane -- one 16-byte store of the rounded row piece instead of an 8-byte one
+// (the bf16 variant's launches wrote half the bytes with the same number of store instructions: 1.8 TB/s)
+template <int Q, int NV>   // Q = Co / 4; Q / NV lanes per row
 __global__ __launch_bounds__(256) void first_factored_fwd_kernel(const float* __restrict__ A, const float* __restrict__ xyz,
                                                                  const float* __restrict__ new_xyz, const int64_t* __restrict__ idx,
                                                                  const float* __restrict__ Wx, int P, int K, int kshift, int N, int per,
                                                                  int gshift, int ppb, float* __restrict__ Z0, BnOut partials, int r16, int h16)
 {   // r16: the bf16 variant -- W_x and the centred coordinates rounded to bf16 (A comes from rounded operands already); h16: Z_0 stored as bf16
     bn_zero(partials);
-    constexpr int CO = 4 * Q, RW = 64 / Q, RB = 4 * RW, U = MP_FACT_U;      // rows per wave / per workgroup pass, passes in flight
+    constexpr int CO = 4 * Q, CPL = 4 * NV, QL = CO / CPL, RW = 64 / QL, RB = 4 * RW, U = MP_FACT_U;      // rows per wave / per workgroup pass, passes in flight
     __shared__ float red[2][RB][CO];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int ql = lane % Q, slot = wave * RW + lane / Q;
-    float4 w[4];
+    const int ql = lane % QL, slot = wave * RW + lane / QL;
+    float4 w[CPL];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) w[j] = rb16(ld4(Wx + (size_t)(4 * ql + j) * 4), r16);
+    for (int j = 0; j < CPL; ++j) w[j] = rb16(ld4(Wx + (size_t)(CPL * ql + j) * 4), r16);
     const int p0 = blockIdx.x * ppb, p1 = min(P, p0 + ppb);
-    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+    float4 s1[NV], s2[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) s1[v] = s2[v] = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int p = p0 + slot; p < p1; p += RB * U) {
-        float4 a[U];
+        float4 a[U][NV];
         float dx[U], dy[U], dz[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -3052,7 +3056,8 @@ __global__ __launch_bounds__(256) void first_factored_fwd_kernel(const float* __
             const unsigned b = gshift >= 0 ? (unsigned)pp >> gshift : (unsigned)pp / (unsigned)per;
             const unsigned grp = kshift >= 0 ? (unsigned)pp >> kshift : (unsigned)pp / (unsigned)K;
             const size_t src = (size_t)b * (unsigned)N + (size_t)idx[pp];
-            a[u] = ld4(A + src * CO + 4 * ql);
+#pragma unroll
+            for (int v = 0; v < NV; ++v) a[u][v] = ld4(A + src * CO + CPL * ql + 4 * v);
             const float* x = xyz + src * 3;
             const float* c = new_xyz + (size_t)grp * 3;
             dx[u] = rb16(x[0] - c[0], r16); dy[u] = rb16(x[1] - c[1], r16); dz[u] = rb16(x[2] - c[2], r16);
@@ -3061,20 +3066,31 @@ __global__ __launch_bounds__(256) void first_factored_fwd_kernel(const float* __
         for (int u = 0; u < U; ++u) {
             const int pp = p + u * RB;
             if (pp < p1) {
-                float4 z;
-                z.x = a[u].x + __builtin_fmaf(w[0].z, dz[u], __builtin_fmaf(w[0].y, dy[u], w[0].x * dx[u]));
-                z.y = a[u].y + __builtin_fmaf(w[1].z, dz[u], __builtin_fmaf(w[1].y, dy[u], w[1].x * dx[u]));
-                z.z = a[u].z + __builtin_fmaf(w[2].z, dz[u], __builtin_fmaf(w[2].y, dy[u], w[2].x * dx[u]));
-                z.w = a[u].w + __builtin_fmaf(w[3].z, dz[u], __builtin_fmaf(w[3].y, dy[u], w[3].x * dx[u]));
-                if (h16) st4h(Z0, (size_t)pp * CO + 4 * ql, z);
-                else *reinterpret_cast<float4*>(Z0 + (size_t)pp * CO + 4 * ql) = z;
-                s1.x += z.x; s1.y += z.y; s1.z += z.z; s1.w += z.w;
-                s2.x += z.x * z.x; s2.y += z.y * z.y; s2.z += z.z * z.z; s2.w += z.w * z.w;
+                float4 z[NV];
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    z[v].x = a[u][v].x + __builtin_fmaf(w[4 * v + 0].z, dz[u], __builtin_fmaf(w[4 * v + 0].y, dy[u], w[4 * v + 0].x * dx[u]));
+                    z[v].y = a[u][v].y + __builtin_fmaf(w[4 * v + 1].z, dz[u], __builtin_fmaf(w[4 * v + 1].y, dy[u], w[4 * v + 1].x * dx[u]));
+                    z[v].z = a[u][v].z + __builtin_fmaf(w[4 * v + 2].z, dz[u], __builtin_fmaf(w[4 * v + 2].y, dy[u], w[4 * v + 2].x * dx[u]));
+                    z[v].w = a[u][v].w + __builtin_fmaf(w[4 * v + 3].z, dz[u], __builtin_fmaf(w[4 * v + 3].y, dy[u], w[4 * v + 3].x * dx[u]));
+                    s1[v].x += z[v].x; s1[v].y += z[v].y; s1[v].z += z[v].z; s1[v].w += z[v].w;
+                    s2[v].x += z[v].x * z[v].x; s2[v].y += z[v].y * z[v].y; s2[v].z += z[v].z * z[v].z; s2[v].w += z[v].w * z[v].w;
+                }
+                if constexpr (NV == 2) {     // (bf16 storage only)
+                    *reinterpret_cast<uint4*>(reinterpret_cast<unsigned short*>(Z0) + (size_t)pp * CO + CPL * ql) =
+                        make_uint4(pack_bf16(z[0].x, z[0].y), pack_bf16(z[0].z, z[0].w), pack_bf16(z[NV - 1].x, z[NV - 1].y), pack_bf16(z[NV - 1].z, z[NV - 1].w));
+                } else {
+                    if (h16) st4h(Z0, (size_t)pp * CO + 4 * ql, z[0]);
+                    else *reinterpret_cast<float4*>(Z0 + (size_t)pp * CO + 4 * ql) = z[0];
+                }
             }
         }
     }
-    *reinterpret_cast<float4*>(&red[0][slot][4 * ql]) = s1;
-    *reinterpret_cast<float4*>(&red[1][slot][4 * ql]) = s2;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        *reinterpret_cast<float4*>(&red[0][slot][CPL * ql + 4 * v]) = s1[v];
+        *reinterpret_cast<float4*>(&red[1][slot][CPL * ql + 4 * v]) = s2[v];
+    }
     __syncthreads();
     for (int e = tid; e < 2 * CO; e += 256) {
         const int st = e / CO, c = e - st * CO;
@@ -3463,13 +3479,14 @@ static int sa_mlp_fwd(const float* x0, int64_t P, int64_t K, int n_layers, const
         if (l == 0 && factored) {
             const int ppb = MP_FACT_PPB;
             nblk = (int)((P + ppb - 1) / ppb);
-            const double by = 4.0 * (2.0 * (double)P * Co_ + 5.0 * (double)P);
+            const double by = (store16 ? 2.0 : 4.0) * (double)P * Co_ + 4.0 * ((double)P * Co_ + 5.0 * (double)P);    // Z_0 written, A rows gathered (L2), indices + coordinates
             const int per = (int)(gather->S * K);
-#define MP_FACT(Q_)                                                                                                              \
-    MP_LAUNCH("first_factored_fwd_kernel", 8.0 * (double)P * Co_, by, (first_factored_fwd_kernel<Q_>), dim3((unsigned)nblk), dim3(256), 0,   \
+#define MP_FACT(Q_, NV_)                                                                                                         \
+    MP_LAUNCH("first_factored_fwd_kernel", 8.0 * (double)P * Co_, by, (first_factored_fwd_kernel<Q_, NV_>), dim3((unsigned)nblk), dim3(256), 0,   \
               stream, gather->feats, gather->xyz, gather->new_xyz, gather->idx, L.weight, (int)P, (int)K, log2_or_neg(K), (int)gather->N, per, \
               log2_or_neg(per), ppb, L.z, partials, (int)bf16, (int)store16)
-            if (Co_ == 64) MP_FACT(16); else if (Co_ == 128) MP_FACT(32); else MP_FACT(64);
+            if (store16) { if (Co_ == 64) MP_FACT(16, 2); else if (Co_ == 128) MP_FACT(32, 2); else MP_FACT(64, 2); }
+            else { if (Co_ == 64) MP_FACT(16, 1); else if (Co_ == 128) MP_FACT(32, 1); else MP_FACT(64, 1); }
 #undef MP_FACT
             MP_CHECK_LAUNCH();
         } else if (l == 0 && rc_first) {
@@ -3912,7 +3929,7 @@ static int sa_mlp_bwd(const float* x0, int64_t P, int64_t K, int n_layers, const
         }
         if (factored && l == 0) {
             // dW_x from the gathered coordinates, dZ_0 itself (= the gradient of the gathered A rows) out to the caller
-            const double fl = 2.0 * (double)P * Co * 4, by = 4.0 * (2.0 * (double)P * Co + 5.0 * (double)P);
+            const double fl = 2.0 * (double)P * Co * 4, by = (store16 ? 2.0 : 4.0) * 2.0 * (double)P * Co + 20.0 * (double)P;   // Z_0 and G_0 rows in their storage type
             if (grad_x0_cols == 0) {
                 // sorted-row reduce: no dZ_0 round trip.  Scratch: the G buffer that is free at this layer (2 ints per position).
                 const int M = (int)(gather->S * K), Np = (int)gather->N;
