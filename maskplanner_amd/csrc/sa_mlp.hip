@@ -1094,7 +1094,8 @@ __global__ __launch_bounds__(THREADS) void dw_gemm_kernel(PosOperand DZ, PosOper
 #define MP_ONE_PHASE_SYNC 2  // 1: the phase barrier of the 32-position one-plane kernels only with two chunks in flight, 2: always
 #endif
 #ifndef MP_ONE_DBK32
-#define MP_ONE_DBK32 1      // [r4] one-plane fused backward: 32 positions per chunk
+#define MP_ONE_DBK32 5      // [r4] one-plane fused backward, 32 positions per chunk: bit 0: 128 x 128 (700 -> 660 us, 312 -> 272), bit 1: 256 x 128 (spills: off),
+                            // bit 2: the 64-input shapes (195 -> 165, 85 -> 70, 74 -> 60 us; two workgroups per CU instead of three)
 #endif
 #ifndef MP_FPD2
 #define MP_FPD2 0           // [r3] position-stream forward: two chunks of loads in flight
@@ -1422,7 +1423,9 @@ __global__ __launch_bounds__(bwd_fused_threads(CO, CI, SPLIT, ONE), (CO >= 128 &
     constexpr int NT = bwd_fused_threads(CO, CI, SPLIT, ONE), NW = NT / 64;
     // [r4] ONE (the bf16 variant's single plane): 32 positions per chunk -- a chunk's products are a sixth of the three-plane kernel's, so
     // at 16 positions the two barriers and the LDS round trips of a chunk were most of its 3 300 cycles (MFMA 8 %, VALU 29 %, 65 % waiting)
-    constexpr int DBK = (SPLIT && ONE && MP_ONE_DBK32 && CO == 128 && CI == 128) ? 32 : ((CI == 128 || SPLIT) ? 16 : 32);   // (the other shapes spill with the doubled row sets)
+    // MP_ONE_DBK32: bit 0: 128 x 128, bit 1: 256 x 128, bit 2: the 64-input shapes
+    constexpr bool ONE32 = SPLIT && ONE && (((MP_ONE_DBK32 & 1) && CO == 128 && CI == 128) || ((MP_ONE_DBK32 & 2) && CO == 256 && CI == 128) || ((MP_ONE_DBK32 & 4) && CI == 64));
+    constexpr int DBK = ONE32 ? 32 : ((CI == 128 || SPLIT) ? 16 : 32);
       // positions per chunk (LDS and registers: at least two workgroups per CU)
     constexpr int XW = DBK == 32 ? CI / (NW / 2) : CI / NW; // dX columns per wave (the chunk's dX tile is [DBK x CI])
     constexpr int HT = XW / 16;                             // 16x16 dX tiles per wave and chunk
@@ -1604,7 +1607,7 @@ __global__ __launch_bounds__(bwd_fused_threads(CO, CI, SPLIT, ONE), (CO >= 128 &
     constexpr int PD2M = ONE ? MP_PD2_ONE : MP_PD2;
     constexpr bool PD2 = PD2M && SPLIT && !KSPLIT && ((PD2M >> (NT == 512 ? (CO == 256 ? 2 : 1) : 0)) & 1);
     constexpr bool PHASE_SYNC = SPLIT && ONE && DBK == 32 && (PD2 || MP_ONE_PHASE_SYNC == 2) && MP_ONE_PHASE_SYNC;   // bit 0: 256-thread kernels, 1: <.,128,128>, 2: <.,256,128>
-    constexpr bool DESYNC = MP_DESYNC && NT == 512 && CO == 256 && SPLIT && !KSPLIT && !PD2;   // (<.,128,128>: 128 -> 134 us with it, 124 -> 116 with PD2)
+    constexpr bool DESYNC = MP_DESYNC && NT == 512 && CO == 256 && SPLIT && !KSPLIT && !PD2 && DBK == 16;   // (<.,128,128>: 128 -> 134 us with it, 124 -> 116 with PD2)
     const int half = DESYNC ? __builtin_amdgcn_readfirstlane(wave >> 2) : 0;
     gload(p0, rs0);
     bn_prologue(DZ.bn, bn_lds, CO, 0, CO, blockIdx.x == 0);     // (behind the first chunk's loads: its slot reads share their latency)

@@ -145,7 +145,7 @@ def test_bf16_chain_forward_backward_vs_prerounded_oracle(B, S, K, cin, widths):
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "f32"])
-@pytest.mark.parametrize("B,S,K,cin,widths", [CASES[3], CASES[0], (4, 32, 64, 3, [64, 128, 128])])
+@pytest.mark.parametrize("B,S,K,cin,widths", [CASES[3], CASES[0], (4, 32, 64, 3, [64, 128, 128]), (2, 32, 64, 3, [128, 128, 256])])
 def test_position_stream_backward_is_steady_from_run_to_run(B, S, K, cin, widths, dtype):
     """The same chain, the same inputs, four times: every weight gradient must come out the same up to the order of the fp32 atomics
     between workgroups (<= 2e-6 relative).  A hazard inside the fused backward kernels -- one wave staging the next chunk into LDS while
