@@ -420,6 +420,10 @@ class PointNet2Regressor_StrokeMasks_MSG(PointNet2Regressor_StrokeMasks):
 
     def encode(self, xyz):
         B = xyz.shape[0]
+        if xyz.is_cuda:
+            # the first-layer weights that need the kernels' column order (three 3 -> 4 pads of the first level, the 643-column
+            # group_all level) with one launch, and one for their gradients, instead of eight
+            sa_mlp.prepermute([(convs[0], "xyz_first") for convs in self.sa1.conv_blocks] + [(self.sa3.mlp_convs[0], "feats_first")])
         l1_xyz, l1_points = self.sa1(xyz, None)
         l2_xyz, l2_points = self.sa2(l1_xyz, l1_points)
         _, l3_points = self.sa3(l2_xyz, l2_points)

@@ -24,6 +24,20 @@ def _r16(t):
     return t.detach().to(torch.bfloat16).to(torch.float32)
 
 
+_R16_LAST = [None, None]     # (tensor, its rounded copy) of the last feature table rounded by _r16_shared
+
+
+def _r16_shared(t):
+    """_r16 of a feature table that several scales of one multi-scale level round in turn: computed once (two launches) and handed out
+    again while the SAME tensor object comes back unmodified (the reference held here keeps its storage from being reused)."""
+    last = _R16_LAST[0]
+    if last is not None and last[0] is t and last[1] == t._version:
+        return _R16_LAST[1]
+    r = _r16(t)
+    _R16_LAST[0], _R16_LAST[1] = (t, t._version), r
+    return r
+
+
 BN_SLOTS = 8      # MP_BN_SLOTS
 BN_FUSED = os.environ.get("MASKPLANNER_BN_FUSED", "1") != "0"   # 0: BatchNorm finalize as launches of its own (A/B, debugging)
 
@@ -338,7 +352,7 @@ class _PerPointFirst(torch.autograd.Function):
     def forward(ctx, feats, w, xyz_first, bf16=False):
         CF = feats.shape[2]
         if bf16:       # the bf16 variant: both operands of the per-point map rounded (exact products, fp32 sums); W_x is rounded by the kernels
-            feats, w = _r16(feats), torch.cat([w[:, :3], _r16(w[:, 3:])], 1) if xyz_first else torch.cat([_r16(w[:, :CF]), w[:, CF:]], 1)
+            feats, w = _r16_shared(feats), torch.cat([w[:, :3], _r16(w[:, 3:])], 1) if xyz_first else torch.cat([_r16(w[:, :CF]), w[:, CF:]], 1)
         wx, wf = (w[:, :3], w[:, 3:]) if xyz_first else (w[:, CF:], w[:, :CF])
         A = torch.matmul(feats, wf.t())
         wx4 = torch.cat([wx, _zero_col(wx.shape[0], wx.device)], 1)       # (one launch: F.pad is a fill + a copy)
