@@ -23,6 +23,7 @@ class TrainStep:
         torch.manual_seed(seed)  # identical initial weights on every rank
         # encoder "msg" + mlp_dtype "bf16": BASELINE configs[4] (containers, N = 10240, multi-radius grouping, bf16 matrix cores)
         self.encoder, self.mlp_dtype = encoder, mlp_dtype
+        self.SAMPLING_BEHIND_A = os.environ.get("MASKPLANNER_SAMPLING_BEHIND_A", "1" if encoder == "msg" else "0") == "1"
         self.model = maskplanner_model(self.cat, hidden_size=hidden_size, encoder=encoder, mlp_dtype=mlp_dtype).to(self.device).train()
         # SyncBN (opt-in): train-mode BatchNorm statistics over the global batch, so that a data-parallel run reproduces the
         # single-device run on the concatenated batch; its per-layer collectives rule out graph replay
@@ -206,6 +207,7 @@ class TrainStep:
     DP_GUARD_EVERY = 500   # replayed data-parallel steps: the replica guard (checksum all-gather + one host read) also every so many steps; 0: first steps only
     _steps_done = 0
     _adam_delay_cycles = 0
+    SAMPLING_BEHIND_A = None   # set in __init__: MASKPLANNER_SAMPLING_BEHIND_A, default: multi-scale encoders
     GRAPH_AFTER = 3   # eager steps before recording (allocator warm, lazy kernel attributes set, optimizer state created)
 
     def step(self):
@@ -218,10 +220,21 @@ class TrainStep:
         return loss
 
     def _step(self):
-        if self.overlap:
+        # [r4] host order at the step boundary.  The NEXT batch's plan is launched kernel by kernel on the second stream (a multi-scale
+        # encoder with its plan extras: ~25 launches, 0.4 ms of host time); issued BEFORE the replay of graph A that host time is a bubble
+        # on the step's stream at every boundary (config 5: 0.8 ms under the tracer), so there the ordering point is recorded first, A is
+        # replayed, and the second stream's launches follow behind it on the host -- on the device they still wait for the previous
+        # step's end only.  The single-scale encoder's ~10 launches keep the old order (same step time either way: NOTEBOOK.md).
+        late = self.overlap and self._graph is not None and self._plan_cur is not None and self.SAMPLING_BEHIND_A
+        if self.overlap and not late:
             self._launch_sampling()          # the NEXT batch's plan, on the second stream underneath this step
         if self._graph is not None:
+            if late:
+                ev = torch.cuda.Event()
+                ev.record()
             self._graph.replay()
+            if late:
+                self._launch_sampling(ev)
             if self._graph_b is not None:
                 if self._adam_ev is not None:
                     torch.cuda.current_stream().wait_event(self._adam_ev)   # the head weights of the previous step are final
@@ -522,8 +535,9 @@ class TrainStep:
 
     def _plan_extras(self):
         """Per-batch preprocessing of the encoder that depends on the cloud and its sampling alone, carried by the plan as well [r4]:
-        ("gxyz", level, int64 units): the first level's grouped, centred coordinate rows [B,S,K,4] (a level without input features);
-        ("rows", level, units): the sorted row lists of a level whose first layer is factorised (sa_mlp.csr_rows)."""
+        ("gxyz", level, scale, int64 units): the first level's grouped, centred coordinate rows [B,S,K,4] (a level without input features;
+        one entry per radius of a multi-scale level), rounded to bf16 values when the level's first layer would round them itself;
+        ("rows", level, scale, units): the sorted row lists of a level whose first layer is factorised (sa_mlp.csr_rows)."""
         from . import sa_mlp
         out = []
         if self.device.type != "cuda":
@@ -531,13 +545,14 @@ class TrainStep:
         B = self.batch["point_cloud"].shape[0]
         levels = self._plan_levels()
         for li, m in enumerate(levels):
-            if hasattr(m, "radius_list"):
-                continue
-            S, _, (K,) = self._level_spec(m)
-            if li == 0 and not getattr(self.model, "normal_channel", False):
-                out.append(("gxyz", li, B * S * K * 4 // 2))
-            if li > 0 and sa_mlp.FACTORED_FIRST in ("1", True) and not self.sync_bn:
-                out.append(("rows", li, 2 * B * S * K // 2))
+            S, _, Ks = self._level_spec(m)
+            multi = hasattr(m, "radius_list")
+            factored = sa_mlp.FACTORED_FIRST in (("1", "msg", True) if multi else ("1", True))
+            for si, K in enumerate(Ks):
+                if li == 0 and not getattr(self.model, "normal_channel", False):
+                    out.append(("gxyz", li, si, B * S * K * 4 // 2))
+                if li > 0 and factored and not self.sync_bn:
+                    out.append(("rows", li, si, 2 * B * S * K // 2))
         return out
 
     def _plan_size(self):
@@ -549,19 +564,27 @@ class TrainStep:
         for _, b, w in self._plan_targets():
             n += b + w
         self._plan_extra_at = n
-        for _, _, units in self._plan_extras():
+        for _, _, _, units in self._plan_extras():
             n += units
         return n
 
     def _extra_views(self, buf):
         B, o, out = self.batch["point_cloud"].shape[0], self._plan_extra_at, []
         levels = self._plan_levels()
-        for kind, li, units in self._plan_extras():
-            S, _, (K,) = self._level_spec(levels[li])
+        for kind, li, si, units in self._plan_extras():
+            S, _, Ks = self._level_spec(levels[li])
+            K = Ks[si]
             v = buf[o:o + units]
-            out.append((kind, li, v.view(torch.float32).view(B, S, K, 4) if kind == "gxyz" else v.view(torch.int32).view(2, B, S * K)))
+            out.append((kind, li, si, v.view(torch.float32).view(B, S, K, 4) if kind == "gxyz" else v.view(torch.int32).view(2, B, S * K)))
             o += units
         return out
+
+    def _rounds_gxyz(self, li, si):
+        """The consumer of this level's grouped coordinates rounds them to bf16 values (sa_mlp.rounds_first_input): done here instead."""
+        from . import sa_mlp
+        m = self._plan_levels()[li]
+        convs = m.conv_blocks[si] if hasattr(m, "radius_list") else m.mlp_convs
+        return sa_mlp.rounds_first_input(convs, self._level_spec(m)[2][si], getattr(m, "mlp_dtype", "f32"))
 
     def _extras(self, buf, xyz=None):
         """Fill the extras of `buf` from ITS OWN sampling plan (same buffer: the views are consistent)."""
@@ -569,20 +592,24 @@ class TrainStep:
         xyz = self.batch["point_cloud"] if xyz is None else xyz
         plans = self._plan_views(buf)
         clouds = [xyz] + [p[1] for p in plans[:-1]]
-        for kind, li, v in self._extra_views(buf):
+        for kind, li, si, v in self._extra_views(buf):
             _, new_xyz, idxs = plans[li]
             if kind == "gxyz":
-                ops.group_xyz_into(clouds[li], new_xyz, idxs[0], v)
+                ops.group_xyz_into(clouds[li], new_xyz, idxs[si], v)
+                if self._rounds_gxyz(li, si):
+                    v.copy_(v.to(torch.bfloat16))
             else:
-                sa_mlp.csr_rows(idxs[0], clouds[li].shape[1], out=v)
+                sa_mlp.csr_rows(idxs[si], clouds[li].shape[1], out=v)
 
     def _register_extras(self):
         from . import sa_mlp
         plans = self._plan_views(self._plan_cur)
-        for kind, li, v in self._extra_views(self._plan_cur):
-            key = plans[li][2][0].data_ptr()
+        for kind, li, si, v in self._extra_views(self._plan_cur):
+            key = plans[li][2][si].data_ptr()
             if kind == "gxyz":
                 pu._grouped_xyz[key] = v
+                if self._rounds_gxyz(li, si):
+                    sa_mlp.ROUNDED_INPUTS[v.data_ptr()] = True
             else:
                 sa_mlp.CSR_ROWS[key] = v
 
@@ -662,13 +689,16 @@ class TrainStep:
         self._register_targets()
         self._register_extras()
 
-    def _launch_sampling(self):
+    def _launch_sampling(self, after=None):
         """The next batch's collation + sampling plan on the second stream, ordered after everything the step's stream holds so
         far (at least the previous hand-over: only then may the next plan / the staging tensors be overwritten)."""
         if self._plan_cur is None:
             self._plan_init()
         side = self._plan_stream
-        side.wait_stream(torch.cuda.current_stream())
+        if after is None:
+            side.wait_stream(torch.cuda.current_stream())
+        else:
+            side.wait_event(after)
         with torch.cuda.stream(side):
             if self._stream is not None:
                 xyz, starts = self._stream.collate_next()        # host items -> device staging tensors, on the side stream

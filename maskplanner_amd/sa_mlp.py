@@ -24,6 +24,25 @@ def _r16(t):
     return t.detach().to(torch.bfloat16).to(torch.float32)
 
 
+ROUNDED_INPUTS = {}     # data_ptr of grouped coordinate rows whose values are bf16 values already (rounded with the sampling plan: harness)
+
+
+def rounds_first_input(convs, K, dtype):
+    """True when _SharedMLPMax.forward rounds its input rows to bf16 itself (the bf16 variant's recomputed first layer on a chain
+    with bf16 activation storage): what a producer may do ahead of time instead (ROUNDED_INPUTS)."""
+    if dtype != "bf16":
+        return False
+    cin = convs[0].in_channels
+    widths = [c.out_channels for c in convs]
+    if WIDEN_INTERIOR:        # (as _widen_interior: interior widths between 64 and 128 run as 128)
+        widths = [128 if (i < len(widths) - 1 and 64 < c < 128) else c for i, c in enumerate(widths)]
+    chans = [(cin + 3) // 4 * 4] + widths
+    lib = _lib.load()
+    ch = (ctypes.c_int64 * len(chans))(*chans)
+    n = len(convs)
+    return bool(lib.mp_sa_mlp_recompute_first(n, ch, K)) and bool(lib.mp_sa_mlp_bf16_storage(n, ch, K, 1))
+
+
 _R16_LAST = [None, None]     # (tensor, its rounded copy) of the last feature table rounded by _r16_shared
 
 
@@ -103,7 +122,8 @@ class _SharedMLPMax(torch.autograd.Function):
         if bf16 and recompute_first:
             # the recomputed first layer of the bf16 variant is an exact product of ROUNDED operands: the kernels get x and W_0 as
             # bf16 values (in fp32 storage); the gradient still goes to the unrounded parameter
-            x = _r16(x)
+            if x.data_ptr() not in ROUNDED_INPUTS:
+                x = _r16(x)
             params = (_r16(params[0]),) + tuple(params[1:])
         for l in range(n_layers):
             w, b, gam, bet, rm, rv = params[6 * l:6 * l + 6]

@@ -1427,20 +1427,20 @@ def test_step_counters_advance_once_per_step():
     assert float(ts.opt.step_dev) == n and float(ts.factor_opt.step_dev) == n
 
 
-@pytest.mark.parametrize("streamed", [False, True])
-def test_plan_carried_preprocessing_equals_the_inline_kernels(streamed):
+@pytest.mark.parametrize("streamed,encoder,dtype", [(False, "ssg", "f32"), (True, "ssg", "f32"), (False, "msg", "bf16"), (False, "msg", "f32")])
+def test_plan_carried_preprocessing_equals_the_inline_kernels(streamed, encoder, dtype):
     """[r4] What travels with the double-buffered sampling plan besides the sampling itself -- padded lengths of the ground-truth
     segments / points, the screening planes of the ground-truth segments, the first level's grouped coordinate rows, the factorised
     level's sorted row lists -- equals what the in-line kernels compute from the step's CURRENT batch, bit for bit, after replayed steps
     (resident batch) and with a fresh host batch every step (streamed)."""
     from maskplanner_amd import ops, sa_mlp, pointnet2_utils as pu
     from maskplanner_amd.harness import TrainStep
-    ts = TrainStep("cuboids", B=4, N=1024, seed=5, stream_batches=3 if streamed else 0)
+    ts = TrainStep("cuboids", B=4, N=1024, seed=5, stream_batches=3 if streamed else 0, encoder=encoder, mlp_dtype=dtype)
     for _ in range(7):
         ts.step()
     torch.cuda.synchronize()
     assert ts._graph is not None and ts._plan_cur is not None
-    kinds = [k for k, _, _ in ts._plan_extras()]
+    kinds = [k for k, _, _, _ in ts._plan_extras()]
     assert "gxyz" in kinds and "rows" in kinds
     # targets
     for key, lengths, ws in ts._target_views(ts._plan_cur):
@@ -1457,23 +1457,34 @@ def test_plan_carried_preprocessing_equals_the_inline_kernels(streamed):
     # encoder-side extras against the plan of the same buffer
     plans = ts._plan_views(ts._plan_cur)
     clouds = [ts.batch["point_cloud"]] + [p[1] for p in plans[:-1]]
-    for kind, li, v in ts._extra_views(ts._plan_cur):
+    seen = set()
+    for kind, li, si, v in ts._extra_views(ts._plan_cur):
         _, new_xyz, idxs = plans[li]
+        seen.add((kind, li, si))
         if kind == "gxyz":
-            want = ops.group(clouds[li], None, new_xyz, idxs[0], pad_to=4)
-            assert torch.equal(v, want) and pu._grouped_xyz[idxs[0].data_ptr()].data_ptr() == v.data_ptr()
+            # (a multi-scale level: one entry per radius; bf16 variant: rounded to bf16 values where the level's first layer would round)
+            want = ops.group(clouds[li], None, new_xyz, idxs[si], pad_to=4)
+            rounded = ts._rounds_gxyz(li, si)
+            assert rounded == (v.data_ptr() in sa_mlp.ROUNDED_INPUTS) and (dtype == "bf16" or not rounded)
+            if rounded:
+                want = want.to(torch.bfloat16).float()
+            assert torch.equal(v, want) and pu._grouped_xyz[idxs[si].data_ptr()].data_ptr() == v.data_ptr()
         elif kind == "rows":
             # the order inside a source point follows LDS atomics: compare as (point, row) sets per cloud
-            want = sa_mlp.csr_rows(idxs[0], clouds[li].shape[1])
+            want = sa_mlp.csr_rows(idxs[si], clouds[li].shape[1])
             torch.cuda.synchronize()
-            assert torch.equal(v[1], want[1])                                  # the sorted source points
+            assert torch.equal(v[1], want[1]) and sa_mlp.CSR_ROWS[idxs[si].data_ptr()].data_ptr() == v.data_ptr()      # the sorted source points
             B, M = v.shape[1], v.shape[2]
-            flat = idxs[0].reshape(B, M)
+            flat = idxs[si].reshape(B, M)
             assert torch.equal(torch.gather(flat, 1, v[0].long()), v[1].long())     # every listed row gathers the listed point
             assert torch.equal(torch.sort(v[0], dim=1).values, torch.arange(M, device=v.device, dtype=torch.int32).expand(B, M))
     # and the plan itself is the sampling of the current batch
     xyz = ts.batch["point_cloud"]
     for m, (fps_idx, new_xyz, idxs) in zip(ts._plan_levels(), plans):
         assert torch.equal(new_xyz, ops.index_points(xyz, fps_idx))
-        assert torch.equal(idxs[0], ops.ball_query(m.radius, m.nsample, xyz, new_xyz))
+        _, radii, Ks = ts._level_spec(m)
+        for si, (r, K) in enumerate(zip(radii, Ks)):
+            assert torch.equal(idxs[si], ops.ball_query(r, K, xyz, new_xyz))
         xyz = new_xyz
+    if encoder == "msg":
+        assert {("gxyz", 0, 0), ("gxyz", 0, 1), ("gxyz", 0, 2), ("rows", 1, 0), ("rows", 1, 1), ("rows", 1, 2)} <= seen
