@@ -221,20 +221,19 @@ class TrainStep:
 
     def _step(self):
         # [r4] host order at the step boundary.  The NEXT batch's plan is launched kernel by kernel on the second stream (a multi-scale
-        # encoder with its plan extras: ~25 launches, 0.4 ms of host time); issued BEFORE the replay of graph A that host time is a bubble
-        # on the step's stream at every boundary (config 5: 0.8 ms under the tracer), so there the ordering point is recorded first, A is
-        # replayed, and the second stream's launches follow behind it on the host -- on the device they still wait for the previous
-        # step's end only.  The single-scale encoder's ~10 launches keep the old order (same step time either way: NOTEBOOK.md).
-        late = self.overlap and self._graph is not None and self._plan_cur is not None and self.SAMPLING_BEHIND_A
-        if self.overlap and not late:
-            self._launch_sampling()          # the NEXT batch's plan, on the second stream underneath this step
+        # encoder with its plan extras: ~25 launches); issued BEFORE the replay of graph A that host time is a bubble on the step's
+        # stream at every boundary (config 5: 0.75 ms under the tracer), issued entirely BEHIND it the first FPS starts late and graph B
+        # waits for the plan instead (0.45 ms under the tracer).  So: the first level's FPS, then graph A, then the rest of the plan.
+        # The single-scale encoder's ~10 launches keep the old order (same step time either way: NOTEBOOK.md).
+        late = self.overlap and self._graph is not None and self._plan_cur is not None and self.SAMPLING_BEHIND_A and self._stream is None
+        if self.overlap:
+            # the NEXT batch's plan, on the second stream underneath this step (late: only its first kernel -- the first level's FPS, the
+            # long pole of the plan -- before graph A; the other launches behind it)
+            self._launch_sampling(phase="head" if late else None)
         if self._graph is not None:
-            if late:
-                ev = torch.cuda.Event()
-                ev.record()
             self._graph.replay()
             if late:
-                self._launch_sampling(ev)
+                self._launch_sampling(phase="tail")
             if self._graph_b is not None:
                 if self._adam_ev is not None:
                     torch.cuda.current_stream().wait_event(self._adam_ev)   # the head weights of the previous step are final
@@ -647,16 +646,19 @@ class TrainStep:
             out.append((fps_idx, new_xyz, idxs))
         return out
 
-    def _sample_levels(self, buf, xyz=None, starts=None):
+    def _sample_levels(self, buf, xyz=None, starts=None, phase=None):
         """FPS + ball queries of every level: each level samples the previous level's centroids, nothing else -- the whole
-        plan depends on the input cloud only."""
+        plan depends on the input cloud only.  phase "head": the first level's FPS alone; "tail": everything but that."""
         from . import ops
         xyz = self.batch["point_cloud"] if xyz is None else xyz
         starts = self.batch["fps_start"] if starts is None else starts
-        for m, start, (fps_idx, new_xyz, idxs) in zip(self._plan_levels(), starts, self._plan_views(buf)):
+        for li, (m, start, (fps_idx, new_xyz, idxs)) in enumerate(zip(self._plan_levels(), starts, self._plan_views(buf))):
             _, radii, Ks = self._level_spec(m)
-            start = torch.as_tensor(start, dtype=torch.long).to(xyz.device)
-            ops.fps(xyz, m.npoint, start, out=(fps_idx, new_xyz))
+            if not (phase == "tail" and li == 0):
+                start = torch.as_tensor(start, dtype=torch.long).to(xyz.device)
+                ops.fps(xyz, m.npoint, start, out=(fps_idx, new_xyz))
+            if phase == "head":
+                return
             for r, K, idx in zip(radii, Ks, idxs):
                 ops.ball_query(r, K, xyz, new_xyz, out=idx)
             xyz = new_xyz
@@ -689,16 +691,15 @@ class TrainStep:
         self._register_targets()
         self._register_extras()
 
-    def _launch_sampling(self, after=None):
+    def _launch_sampling(self, phase=None):
         """The next batch's collation + sampling plan on the second stream, ordered after everything the step's stream holds so
-        far (at least the previous hand-over: only then may the next plan / the staging tensors be overwritten)."""
+        far (at least the previous hand-over: only then may the next plan / the staging tensors be overwritten).
+        phase "head": the ordering point and the first level's FPS only; "tail": everything behind it (resident batches)."""
         if self._plan_cur is None:
             self._plan_init()
         side = self._plan_stream
-        if after is None:
+        if phase != "tail":
             side.wait_stream(torch.cuda.current_stream())
-        else:
-            side.wait_event(after)
         with torch.cuda.stream(side):
             if self._stream is not None:
                 xyz, starts = self._stream.collate_next()        # host items -> device staging tensors, on the side stream
@@ -706,7 +707,9 @@ class TrainStep:
                 self._target_aux(self._plan_next, self._stream.stage)
                 self._extras(self._plan_next, xyz)
             else:
-                self._sample_levels(self._plan_next)
+                self._sample_levels(self._plan_next, phase=phase)
+                if phase == "head":
+                    return
                 self._target_aux(self._plan_next)
                 self._extras(self._plan_next)
             self._plan_ev = torch.cuda.Event()
