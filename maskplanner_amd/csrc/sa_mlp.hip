@@ -1822,6 +1822,7 @@ __global__ __launch_bounds__(bwd_fused_threads(CO, CI, SPLIT, ONE), (CO >= 128 &
         } else {
             if constexpr (!(MP_BF_ABL & 1)) do_dw();
             if constexpr (!((MP_BF_ABL >> 1) & 1)) g_mfma();
+
             else {
 #pragma unroll
                 for (int h = 0; h < HT; ++h) ax[h] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1829,12 +1830,12 @@ __global__ __launch_bounds__(bwd_fused_threads(CO, CI, SPLIT, ONE), (CO >= 128 &
             if constexpr (!((MP_BF_ABL >> 2) & 1)) g_epi();
             // [r4] 32-position chunks of the one-plane kernels: a barrier between the products and the staging of the next chunk.  With two
             // chunks of loads in flight and ONE barrier per chunk that form returned run-to-run varying weight gradients (tools/err_probe.py:
-            // 3e-3 ... 9e-2 against a steady 6.5e-4); a full vmcnt(0) wait at this point does not remove the spread, an s_barrier does, so
-            // the conflict is between one wave's staging writes and another wave's product reads -- the pair itself was not identified
-            // (NOTEBOOK.md).  With one chunk in flight (the default: MP_PD2_ONE = 0) 24 repetitions were bit-steady without this barrier as
+            // 3e-3 ... 9e-2 against a steady 6.5e-4); a full vmcnt(0) wait at this point does not remove the spread, a barrier here -- or one
+            // between the two products -- does, so the conflict is between one wave's staging writes and another wave's product reads;
+            // the pair itself was not identified (NOTEBOOK.md).  With one chunk in flight (the default: MP_PD2_ONE = 0) 24 repetitions were bit-steady without this barrier as
             // well; it is kept (MP_ONE_PHASE_SYNC = 2, +30 us at config 5) because the cause is not understood.  Two barriers per 32 positions
             // is what the 16-position form pays.
-            if constexpr (PHASE_SYNC) __builtin_amdgcn_s_barrier();
+            if constexpr (PHASE_SYNC) __syncthreads();        // (fence + barrier: with it no LDS read of a chunk overlaps any staging write in time)
             if (kc + 1 < nchunks) sstore(cur ^ 1, rs);
             // PD2: the set just emptied is refilled at once with the chunk it stages two iterations from now -- two chunks of
             // loads in flight per workgroup instead of one (an iteration of these kernels lasts about one loaded-HBM round trip)
