@@ -1097,6 +1097,9 @@ __global__ __launch_bounds__(THREADS) void dw_gemm_kernel(PosOperand DZ, PosOper
 #define MP_ONE_DBK32 5      // [r4] one-plane fused backward, 32 positions per chunk: bit 0: 128 x 128 (700 -> 660 us, 312 -> 272), bit 1: 256 x 128 (spills: off),
                             // bit 2: the 64-input shapes (195 -> 165, 85 -> 70, 74 -> 60 us; two workgroups per CU instead of three)
 #endif
+#ifndef MP_FPD2_ONE
+#define MP_FPD2_ONE 1       // [r4] ... of the one-plane (bf16 variant) forward kernels: on (config 5: 6.06 -> 6.02 ms, the forward kernels 1 080 -> 1 063 us)
+#endif
 #ifndef MP_FPD2
 #define MP_FPD2 0           // [r3] position-stream forward: two chunks of loads in flight
 #endif
@@ -1222,7 +1225,7 @@ __global__ __launch_bounds__(CO > 128 ? 512 : 256) void fwd_chunk_kernel(PosOper
 
     // ([r3] tried: the staggered barrier of bwd_fused_kernel's DESYNC for the 512-thread form -- 110.7 vs 111.0 us, not kept)
     // FPD2: two chunks of loads in flight (two register sets, the loop unrolled by two), as bwd_fused_kernel's PD2
-    constexpr bool FPD2 = MP_FPD2 && SPLIT;
+    constexpr bool FPD2 = (ONE ? MP_FPD2_ONE : MP_FPD2) && SPLIT;
     gload(p0, rs0);
     bn_prologue(A.bn, bn_lds, CI, 0, CI, blockIdx.x == 0);      // (behind the first chunk's loads: its slot reads share their latency)
     load_consts<MODE_A>(A, ca, kc, bn_lds, CI);
