@@ -1,4 +1,5 @@
-// Rectangular linear sum assignment for segment matching (up to 2048 x 2048 per sample), batched on device.
+// Rectangular linear sum assignment for segment matching (up to 2048 x 2048 per sample), batched on device (one wave per sample up to
+// 128 columns: lsap_kernel below; four waves beyond: lsap4_kernel).
 //
 // Reference: models/hungarianMatcher.py:58-61 copies a [S, Sgt] Euclidean cost matrix per sample to the host and calls
 // scipy.optimize.linear_sum_assignment (999 x ~900: ~0.2 s per sample on one core, serial over the batch).  Here one
@@ -12,6 +13,8 @@
 // lexicographic arg-min: lowest shortest-path cost first; among equal costs scipy's scan keeps the LAST free column
 // it meets, else the FIRST assigned one, in the order of its `remaining` array -- reproduced through pos[] / rem[].
 // A single wave needs no barriers: LDS operations of one wave execute in program order.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -168,6 +171,163 @@ __global__ __launch_bounds__(64) void lsap_kernel(const float* __restrict__ cost
     if (lane == 0) status[b] = feasible ? 0 : MP_EUNSUPPORTED;
 }
 
+// ---- [r4] the same algorithm with FOUR waves per sample --------------------------------------------------------------------
+// One wave per sample spends most of a Dijkstra step in its own vector work: 16 columns per lane x ~20 instructions (fp64 adds,
+// LDS reads of the column state) on ONE of the CU's four SIMDs.  Here a sample has a 256-thread workgroup, a thread owns the columns
+// tid + 256 t with their dual, shortest-path cost, assignment and scan position in REGISTERS (path[], rem[], u[], the row / column
+// assignments stay in LDS: they are accessed by index), every wave reduces its own columns to one candidate (value, key, column,
+// assigned row) and the four candidates meet in LDS behind one barrier per step.  Dual updates run from the column side:
+// u[row4col[j]] += minVal - spc[j] for every scanned column j but the sink -- the same expression as scipy's row loop, since
+// col4row[row4col[j]] = j.  The augmentation along the path is wave 0's (serial chain), the other waves reload their assignments
+// after it.  Tie-breaking as above (key from the column's position in scipy's `remaining`).
+struct LsapSlot { double val; unsigned key; int j; int r4c; int pad; };
+
+template <int T>   // columns per thread: Cmax <= 256 * T
+__global__ __launch_bounds__(256) void lsap4_kernel(const float* __restrict__ cost, int64_t batch_stride, int ld,
+                                                    const int32_t* __restrict__ nr_, const int32_t* __restrict__ nc_,
+                                                    int Rmax, int Cmax, int64_t* __restrict__ col4row_out,
+                                                    int32_t* __restrict__ status)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    double* u = reinterpret_cast<double*>(smem_raw);                 // [Rmax] row duals
+    LsapSlot* slots = reinterpret_cast<LsapSlot*>(u + Rmax);          // [2][4]
+    int* path = reinterpret_cast<int*>(slots + 8);                    // [Cmax]
+    int* row4col = path + Cmax;                                       // [Cmax]
+    int* rem = row4col + Cmax;                                        // [Cmax] scipy's `remaining`
+    int* col4row = rem + Cmax;                                        // [Rmax]
+
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nr = nr_[b], nc = nc_[b];
+    int64_t* out = col4row_out + (size_t)b * Rmax;
+    if (nr < 0 || nc < 0 || nr > nc || nc > Cmax || nr > Rmax || nc > 256 * T) {
+        if (tid == 0) status[b] = MP_EINVAL;
+        for (int i = tid; i < Rmax; i += 256) out[i] = -1;
+        return;
+    }
+    const float* C = cost + (size_t)b * batch_stride;
+    const double INF = __builtin_inf();
+    double v[T], spc[T];
+    int r4c[T], pos[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        v[t] = 0.0; r4c[t] = -1; spc[t] = INF; pos[t] = 0;
+        const int j = tid + 256 * t;
+        if (j < nc) row4col[j] = -1;
+    }
+    for (int i = tid; i < nr; i += 256) { u[i] = 0.0; col4row[i] = -1; }
+    __syncthreads();
+
+    bool feasible = true;
+    for (int cur = 0; cur < nr && feasible; ++cur) {
+        unsigned scanned = 0u;
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const int j = tid + 256 * t;
+            spc[t] = INF;
+            pos[t] = nc - 1 - j;                 // remaining[it] = nc - it - 1
+            if (j < nc) rem[nc - 1 - j] = j;
+        }
+        __syncthreads();
+        int num_remaining = nc;
+        int i = cur;
+        double minVal = 0.0;
+        int sink = -1;
+        int parity = 0;
+        while (sink == -1) {
+            const double ui = u[i];
+            const float* row = C + (size_t)i * ld;
+            float c[T];
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                const int j = tid + 256 * t;
+                c[t] = (j < nc) ? row[j] : 0.0f;
+            }
+            double bv = INF;
+            unsigned bkey = 0u;
+            int bj = -1, br = -1;
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                const int j = tid + 256 * t;
+                if (j < nc && !((scanned >> t) & 1u)) {
+                    const double r = minVal + (double)c[t] - ui - v[t];
+                    if (r < spc[t]) { spc[t] = r; path[j] = i; }
+                    const double s_ = spc[t];
+                    const unsigned p = (unsigned)pos[t];
+                    const unsigned key = (r4c[t] == -1) ? 0x80000000u + p : 0x7fffffffu - p;
+                    if (s_ < bv || (s_ == bv && key > bkey)) { bv = s_; bkey = key; bj = j; br = r4c[t]; }
+                }
+            }
+            const double wlow = wave_min_f64(bv);
+            const unsigned wkey = mp::wave_max_u32(bv == wlow ? bkey : 0u);
+            LsapSlot* sl = slots + parity * 4 + wave;
+            if (wkey == 0u) { if (lane == 0) { sl->val = INF; sl->key = 0u; sl->j = -1; sl->r4c = -1; } }
+            else if (bv == wlow && bkey == wkey) { sl->val = bv; sl->key = bkey; sl->j = bj; sl->r4c = br; }     // keys are unique: one lane
+            __syncthreads();
+            double lowest = INF;
+            unsigned key = 0u;
+            int jstar = -1, rstar = -1;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const LsapSlot q = slots[parity * 4 + w];
+                if (q.key != 0u && (q.val < lowest || (q.val == lowest && q.key > key))) { lowest = q.val; key = q.key; jstar = q.j; rstar = q.r4c; }
+            }
+            if (!(lowest < INF) || key == 0u) { feasible = false; break; }       // infeasible: non-finite costs
+            const int chosen_pos = (key & 0x80000000u) ? (int)(key - 0x80000000u) : (int)(0x7fffffffu - key);
+            --num_remaining;
+            const int last = rem[num_remaining];                 // remaining[index] = remaining[--num_remaining]
+            if (tid == 0) rem[chosen_pos] = last;                // (chosen_pos == num_remaining: the same value)
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                const int j = tid + 256 * t;
+                if (j == last) pos[t] = chosen_pos;
+                if (j == jstar) scanned |= 1u << t;
+            }
+            minVal = lowest;
+            if (rstar == -1) sink = jstar; else i = rstar;
+            parity ^= 1;
+        }
+        if (!feasible) break;
+        // dual updates from the column side (rows in the tree other than cur <-> scanned columns other than the sink)
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            if ((scanned >> t) & 1u) {
+                const double d = minVal - spc[t];
+                v[t] -= d;
+                if (r4c[t] != -1) u[r4c[t]] += d;
+            }
+        }
+        if (tid == 0) u[cur] += minVal;
+        __syncthreads();
+        if (wave == 0) {     // augment along the path: a serial chain, one wave (its LDS traffic is ordered by wave_sync)
+            int j = sink;
+            for (;;) {
+                const int pi = path[j];
+                const int t_ = col4row[pi];
+                wave_sync();
+                if (lane == 0) { row4col[j] = pi; col4row[pi] = j; }
+                wave_sync();
+                j = t_;
+                if (pi == cur) break;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const int j = tid + 256 * t;
+            if (j < nc) r4c[t] = row4col[j];
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < Rmax; i += 256) out[i] = (feasible && i < nr) ? (int64_t)col4row[i] : -1;
+    if (tid == 0) status[b] = feasible ? 0 : MP_EUNSUPPORTED;
+}
+
+size_t lsap4_smem(int64_t Rmax, int64_t Cmax)
+{
+    return sizeof(double) * (size_t)Rmax + sizeof(LsapSlot) * 8 + sizeof(int) * (size_t)(3 * Cmax + Rmax);
+}
+
 size_t lsap_smem(int64_t Rmax, int64_t Cmax)
 {
     return sizeof(double) * (size_t)(2 * Cmax + Rmax) + sizeof(int) * (size_t)(5 * Cmax + 2 * Rmax);
@@ -192,6 +352,22 @@ extern "C" int mp_lsap_f32(const float* cost, int64_t B, int64_t Rmax, int64_t C
         MP_CHECK_LAUNCH();
         return MP_OK;
     };
+    // [r4] four waves per sample (lsap4_kernel) where a sample has enough columns to feed them; MP_LSAP_WAVES=1: the one-wave kernel
+    static const bool four = []() { const char* e = getenv("MP_LSAP_WAVES"); return !(e && e[0] == '1'); }();
+    if (four && Cmax > 128) {
+        const size_t smem4 = lsap4_smem(Rmax, Cmax);
+        auto launch4 = [&](auto kernel, mp::DynLds& lds) -> int {
+            if (!lds.ensure(reinterpret_cast<const void*>(kernel), smem4)) return MP_ELAUNCH;
+            MP_LAUNCH("lsap4_kernel", 0.0, 4.0 * (double)(B * Rmax * Cmax), kernel, dim3((unsigned)B), dim3(256), smem4, mp_stream(stream_), cost,
+                      batch_stride, (int)ld, n_rows, n_cols, (int)Rmax, (int)Cmax, col4row, status);
+            MP_CHECK_LAUNCH();
+            return MP_OK;
+        };
+        static mp::DynLds c2, c4, c8;
+        if (Cmax <= 512) return launch4(lsap4_kernel<2>, c2);
+        if (Cmax <= 1024) return launch4(lsap4_kernel<4>, c4);
+        return launch4(lsap4_kernel<8>, c8);
+    }
     static mp::DynLds conf8, conf16, conf32;
     if (Cmax <= 512) return launch(lsap_kernel<8>, conf8);
     if (Cmax <= 1024) return launch(lsap_kernel<16>, conf16);

@@ -470,6 +470,25 @@ def test_lsap_ties_follow_scipy(ops):
         assert np.array_equal(i.cpu().numpy(), r) and np.array_equal(j.cpu().numpy(), k), c.shape
 
 
+@pytest.mark.parametrize("shapes,hi", [([(400, 1000), (999, 999), (130, 129)], 3), ([(300, 2048), (1500, 700)], 2), ([(512, 512), (256, 600)], 6)])
+def test_lsap_ties_at_the_sizes_of_the_four_wave_kernel(ops, shapes, hi):
+    """[r4] More than 128 columns: four waves per sample, column state in registers, one candidate per wave merged behind a barrier
+    (lsap4_kernel).  Small integer costs at 512 / 1024 / 2048 columns: almost every Dijkstra step is decided by scipy's scan-order
+    rules, across the waves too; a share of +inf entries (forbidden pairs that leave the problem feasible) rides along."""
+    rng = np.random.default_rng(hi + len(shapes))
+    costs = [rng.integers(0, hi, size=s).astype(np.float32) for s in shapes]
+    holes = costs[0].copy()
+    holes[rng.uniform(size=holes.shape) < 0.3] = np.inf
+    costs.append(holes)
+    dup = rng.uniform(0, 1, size=(300, 1, 3)).astype(np.float32).repeat(3, 1).reshape(900, 3)      # every target three times: tied columns
+    costs.append(np.sqrt(((rng.uniform(0, 1, size=(700, 1, 3)).astype(np.float32) - dup[None]) ** 2).sum(-1)).astype(np.float32))
+    pairs, status = ops.lsap([dev(c) for c in costs])
+    assert (status.cpu().numpy() == 0).all()
+    for c, (i, j) in zip(costs, pairs):
+        r, k = _scipy_pairs(c)
+        assert np.array_equal(i.cpu().numpy(), r) and np.array_equal(j.cpu().numpy(), k), c.shape
+
+
 def test_lsap_infeasible_and_empty(ops):
     c = np.full((3, 3), np.inf, np.float32)
     pairs, status = ops.lsap([dev(c), dev(np.eye(3, dtype=np.float32))])
