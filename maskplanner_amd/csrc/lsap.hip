@@ -181,6 +181,9 @@ __global__ __launch_bounds__(64) void lsap_kernel(const float* __restrict__ cost
 // col4row[row4col[j]] = j.  The augmentation along the path is wave 0's (serial chain), the other waves reload their assignments
 // after it.  Tie-breaking as above (key from the column's position in scipy's `remaining`).
 struct LsapSlot { double val; unsigned key; int j; int r4c; int pad; };
+#ifndef LSAP_SPEC
+#define LSAP_SPEC 1
+#endif
 
 template <int T>   // columns per thread: Cmax <= 256 * T
 __global__ __launch_bounds__(256) void lsap4_kernel(const float* __restrict__ cost, int64_t batch_stride, int ld,
@@ -209,9 +212,11 @@ __global__ __launch_bounds__(256) void lsap4_kernel(const float* __restrict__ co
     const double INF = __builtin_inf();
     double v[T], spc[T];
     int r4c[T], pos[T];
+    float cs[T];              // a prefetched cost row (this thread's columns) and which row it is
+    int spec_row = -1;
 #pragma unroll
     for (int t = 0; t < T; ++t) {
-        v[t] = 0.0; r4c[t] = -1; spc[t] = INF; pos[t] = 0;
+        v[t] = 0.0; r4c[t] = -1; spc[t] = INF; pos[t] = 0; cs[t] = 0.0f;
         const int j = tid + 256 * t;
         if (j < nc) row4col[j] = -1;
     }
@@ -238,10 +243,15 @@ __global__ __launch_bounds__(256) void lsap4_kernel(const float* __restrict__ co
             const double ui = u[i];
             const float* row = C + (size_t)i * ld;
             float c[T];
+            if (LSAP_SPEC && i == spec_row) {      // the row was requested a step ago as the runner-up's (below)
 #pragma unroll
-            for (int t = 0; t < T; ++t) {
-                const int j = tid + 256 * t;
-                c[t] = (j < nc) ? row[j] : 0.0f;
+                for (int t = 0; t < T; ++t) c[t] = cs[t];
+            } else {
+#pragma unroll
+                for (int t = 0; t < T; ++t) {
+                    const int j = tid + 256 * t;
+                    c[t] = (j < nc) ? row[j] : 0.0f;
+                }
             }
             double bv = INF;
             unsigned bkey = 0u;
@@ -264,15 +274,32 @@ __global__ __launch_bounds__(256) void lsap4_kernel(const float* __restrict__ co
             if (wkey == 0u) { if (lane == 0) { sl->val = INF; sl->key = 0u; sl->j = -1; sl->r4c = -1; } }
             else if (bv == wlow && bkey == wkey) { sl->val = bv; sl->key = bkey; sl->j = bj; sl->r4c = br; }     // keys are unique: one lane
             __syncthreads();
-            double lowest = INF;
-            unsigned key = 0u;
-            int jstar = -1, rstar = -1;
+            double lowest = INF, second = INF;
+            unsigned key = 0u, key2 = 0u;
+            int jstar = -1, rstar = -1, r2 = -1;
 #pragma unroll
             for (int w = 0; w < 4; ++w) {
                 const LsapSlot q = slots[parity * 4 + w];
-                if (q.key != 0u && (q.val < lowest || (q.val == lowest && q.key > key))) { lowest = q.val; key = q.key; jstar = q.j; rstar = q.r4c; }
+                if (q.key != 0u && (q.val < lowest || (q.val == lowest && q.key > key))) {
+                    second = lowest; key2 = key; r2 = rstar;
+                    lowest = q.val; key = q.key; jstar = q.j; rstar = q.r4c;
+                } else if (q.key != 0u && (q.val < second || (q.val == second && q.key > key2))) {
+                    second = q.val; key2 = q.key; r2 = q.r4c;
+                }
             }
             if (!(lowest < INF) || key == 0u) { feasible = false; break; }       // infeasible: non-finite costs
+            // the best candidate of the OTHER waves is the likely next minimum (unless the row about to be scanned, or the winner's own
+            // wave, beats it): its assigned row is requested now, a step ahead of its use -- the cost matrix never changes, so a
+            // prefetched row stays valid for as long as it is kept
+            if (LSAP_SPEC && rstar != -1 && r2 != -1 && r2 != spec_row && key2 != 0u) {
+                const float* row2 = C + (size_t)r2 * ld;
+#pragma unroll
+                for (int t = 0; t < T; ++t) {
+                    const int j = tid + 256 * t;
+                    cs[t] = (j < nc) ? row2[j] : 0.0f;
+                }
+                spec_row = r2;
+            }
             const int chosen_pos = (key & 0x80000000u) ? (int)(key - 0x80000000u) : (int)(0x7fffffffu - key);
             --num_remaining;
             const int last = rem[num_remaining];                 // remaining[index] = remaining[--num_remaining]
