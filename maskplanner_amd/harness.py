@@ -603,14 +603,33 @@ class TrainStep:
     def _register_extras(self):
         from . import sa_mlp
         plans = self._plan_views(self._plan_cur)
+        self._unregister_extras()
         for kind, li, si, v in self._extra_views(self._plan_cur):
             key = plans[li][2][si].data_ptr()
             if kind == "gxyz":
                 pu._grouped_xyz[key] = v
+                self._registered.append((pu._grouped_xyz, key))
                 if self._rounds_gxyz(li, si):
                     sa_mlp.ROUNDED_INPUTS[v.data_ptr()] = True
+                    self._registered.append((sa_mlp.ROUNDED_INPUTS, v.data_ptr()))
             else:
                 sa_mlp.CSR_ROWS[key] = v
+                self._registered.append((sa_mlp.CSR_ROWS, key))
+
+    _registered = ()
+
+    def _unregister_extras(self):
+        """The registries are keyed by addresses inside this object's plan buffer (and hold views of it): entries go when the object goes,
+        before the allocator can hand those addresses to somebody else."""
+        for reg, key in self._registered:
+            reg.pop(key, None)
+        self._registered = []
+
+    def __del__(self):
+        try:
+            self._unregister_extras()
+        except Exception:
+            pass
 
     def _target_views(self, buf):
         """Per target (key, lengths i64 [B], workspace u8 or None) as views of the plan buffer's tail."""
