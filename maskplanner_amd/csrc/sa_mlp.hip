@@ -500,6 +500,21 @@ __device__ __forceinline__ bf16x8 tr_frag_packed(const __bf16* tile, int k0, int
     return r8;
 }
 
+// [r4] Every transposed fragment requested so far has ARRIVED behind this point.  Found with the 32-position one-plane kernel: the
+// compiler's partial `s_waitcnt lgkmcnt(N)` in front of the MFMAs that consume ds_read_b64_tr_b16 results -- correct if LDS operations
+// complete in issue order -- let stale fragment registers into the dW product whenever other waves' staging writes kept the LDS busy
+// (run-to-run varying weight gradients; a full lgkmcnt(0) here removes it, NOTEBOOK.md).  MP_TR_FENCE: bit 0 the one-plane dW product,
+// bit 1 the three-plane dW product of bwd_fused_kernel (a fence behind each fragment batch), bit 2 the dW waves of bwd_roles_kernel.
+#ifndef MP_TR_FENCE
+#define MP_TR_FENCE 7       // (no measurable cost: headline 2.157 vs 2.149 ms median over three alternations)
+#endif
+__device__ __forceinline__ void tr_fence()
+{
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_waitcnt(0xC07F);     // lgkmcnt(0)
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 // acc += A * B over one K chunk.  A_TR / B_TR: the operand's tile is [k][row or col] (transposed reads) instead of [row][k].
 template <bool A_TR, bool B_TR, int LDA, int LDB, int TM, int TN, int KC>
 __device__ __forceinline__ void mma_chunk_bf16(const __bf16* sA, const __bf16* sB, int wrow0, int wcol0, f32x16 (&acc)[TM][TN])
@@ -1088,10 +1103,8 @@ __global__ __launch_bounds__(THREADS) void dw_gemm_kernel(PosOperand DZ, PosOper
 #define MP_PD2 3            // [r3] fused backward: two chunks of loads in flight (two register sets, loop unrolled by two); bit mask, see PD2
 #endif
 #ifndef MP_PD2_ONE
-#define MP_PD2_ONE 0        // [r4] the one-plane (bf16 variant) kernels: one chunk of loads in flight (config 5: 6.27 -> 6.20 ms with the mask at 0; and see PHASE_SYNC)
-#endif
-#ifndef MP_ONE_PHASE_SYNC
-#define MP_ONE_PHASE_SYNC 2  // 1: the phase barrier of the 32-position one-plane kernels only with two chunks in flight, 2: always
+#define MP_PD2_ONE 2        // [r4] the one-plane (bf16 variant) kernels: two chunks of loads in flight for the 128 x 128 shapes only (the 256-thread
+                            // kernels are faster with one: config 5 6.27 -> 6.20 ms; 128 x 128 with two: 668 -> 615 us, 262 -> 257 us)
 #endif
 #ifndef MP_ONE_DBK32
 #define MP_ONE_DBK32 5      // [r4] one-plane fused backward, 32 positions per chunk: bit 0: 128 x 128 (700 -> 660 us, 312 -> 272), bit 1: 256 x 128 (spills: off),
@@ -1609,7 +1622,7 @@ __global__ __launch_bounds__(bwd_fused_threads(CO, CI, SPLIT, ONE), (CO >= 128 &
 
     constexpr int PD2M = ONE ? MP_PD2_ONE : MP_PD2;
     constexpr bool PD2 = PD2M && SPLIT && !KSPLIT && ((PD2M >> (NT == 512 ? (CO == 256 ? 2 : 1) : 0)) & 1);
-    constexpr bool PHASE_SYNC = SPLIT && ONE && DBK == 32 && (PD2 || MP_ONE_PHASE_SYNC == 2) && MP_ONE_PHASE_SYNC;   // bit 0: 256-thread kernels, 1: <.,128,128>, 2: <.,256,128>
+   // bit 0: 256-thread kernels, 1: <.,128,128>, 2: <.,256,128>
     constexpr bool DESYNC = MP_DESYNC && NT == 512 && CO == 256 && SPLIT && !KSPLIT && !PD2 && DBK == 16;   // (<.,128,128>: 128 -> 134 us with it, 124 -> 116 with PD2)
     const int half = DESYNC ? __builtin_amdgcn_readfirstlane(wave >> 2) : 0;
     gload(p0, rs0);
@@ -1639,6 +1652,7 @@ __global__ __launch_bounds__(bwd_fused_threads(CO, CI, SPLIT, ONE), (CO >= 128 &
                 for (int ni = 0; ni < TNW; ++ni) fb[ni] = tr_frag_packed<GS, KSWZ>(hB[cur][0], k0, wcol0 + ni * 32);
 #pragma unroll
                 for (int mi = 0; mi < TMW; ++mi) fa[mi] = tr_frag_packed<GS, KSWZ>(hA[cur][0], k0, wrow0 + mi * 32);
+                if constexpr (MP_TR_FENCE & 1) tr_fence();
 #pragma unroll
                 for (int mi = 0; mi < TMW; ++mi)
 #pragma unroll
@@ -1651,6 +1665,7 @@ __global__ __launch_bounds__(bwd_fused_threads(CO, CI, SPLIT, ONE), (CO >= 128 &
             for (int ni = 0; ni < TNW; ++ni) fb[0][ni] = tr_frag_packed<GS, KSWZ>(hB[cur][0], 0, wcol0 + ni * 32);
 #pragma unroll
             for (int mi = 0; mi < TMW; ++mi) fa[mi] = tr_frag_packed<GS, KSWZ>(hA[cur][2], 0, wrow0 + mi * 32);
+            if constexpr ((MP_TR_FENCE >> 1) & 1) tr_fence();
 #pragma unroll
             for (int mi = 0; mi < TMW; ++mi)
 #pragma unroll
@@ -1661,6 +1676,7 @@ __global__ __launch_bounds__(bwd_fused_threads(CO, CI, SPLIT, ONE), (CO >= 128 &
             for (int pl = 2; pl >= 1; --pl)
 #pragma unroll
                 for (int ni = 0; ni < TNW; ++ni) fb[pl][ni] = tr_frag_packed<GS, KSWZ>(hB[cur][pl], 0, wcol0 + ni * 32);
+            if constexpr ((MP_TR_FENCE >> 1) & 1) tr_fence();
 #pragma unroll
             for (int pl = 2; pl >= 0; --pl)
 #pragma unroll
@@ -1669,6 +1685,7 @@ __global__ __launch_bounds__(bwd_fused_threads(CO, CI, SPLIT, ONE), (CO >= 128 &
                     for (int ni = 0; ni < TNW; ++ni) accW[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mi], fb[pl][ni], accW[mi][ni], 0, 0, 0);
 #pragma unroll
             for (int mi = 0; mi < TMW; ++mi) fa[mi] = tr_frag_packed<GS, KSWZ>(hA[cur][1], 0, wrow0 + mi * 32);
+            if constexpr ((MP_TR_FENCE >> 1) & 1) tr_fence();
 #pragma unroll
             for (int pl = 1; pl >= 0; --pl)
 #pragma unroll
@@ -1831,14 +1848,6 @@ __global__ __launch_bounds__(bwd_fused_threads(CO, CI, SPLIT, ONE), (CO >= 128 &
                 for (int h = 0; h < HT; ++h) ax[h] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
             if constexpr (!((MP_BF_ABL >> 2) & 1)) g_epi();
-            // [r4] 32-position chunks of the one-plane kernels: a barrier between the products and the staging of the next chunk.  With two
-            // chunks of loads in flight and ONE barrier per chunk that form returned run-to-run varying weight gradients (tools/err_probe.py:
-            // 3e-3 ... 9e-2 against a steady 6.5e-4); a full vmcnt(0) wait at this point does not remove the spread, a barrier here -- or one
-            // between the two products -- does, so the conflict is between one wave's staging writes and another wave's product reads;
-            // the pair itself was not identified (NOTEBOOK.md).  With one chunk in flight (the default: MP_PD2_ONE = 0) 24 repetitions were bit-steady without this barrier as
-            // well; it is kept (MP_ONE_PHASE_SYNC = 2, +30 us at config 5) because the cause is not understood.  Two barriers per 32 positions
-            // is what the 16-position form pays.
-            if constexpr (PHASE_SYNC) __syncthreads();        // (fence + barrier: with it no LDS read of a chunk overlaps any staging write in time)
             if (kc + 1 < nchunks) sstore(cur ^ 1, rs);
             // PD2: the set just emptied is refilled at once with the chunk it stages two iterations from now -- two chunks of
             // loads in flight per workgroup instead of one (an iteration of these kernels lasts about one loaded-HBM round trip)
@@ -2179,6 +2188,7 @@ __global__ __launch_bounds__(512, 1) void bwd_roles_kernel(PosOperand DZ, PosOpe
             for (int ni = 0; ni < TNW; ++ni) fb[0][ni] = tr_frag_packed<GS, true>(hB[cur][0], 0, wcol0 + ni * 32);
 #pragma unroll
             for (int mi = 0; mi < TMW; ++mi) fa[mi] = tr_frag_packed<GS, true>(hA[cur][2], 0, wrow0 + mi * 32);
+            if constexpr ((MP_TR_FENCE >> 2) & 1) tr_fence();
 #pragma unroll
             for (int mi = 0; mi < TMW; ++mi)
 #pragma unroll
@@ -2189,6 +2199,7 @@ __global__ __launch_bounds__(512, 1) void bwd_roles_kernel(PosOperand DZ, PosOpe
             for (int pl = 2; pl >= 1; --pl)
 #pragma unroll
                 for (int ni = 0; ni < TNW; ++ni) fb[pl][ni] = tr_frag_packed<GS, true>(hB[cur][pl], 0, wcol0 + ni * 32);
+            if constexpr ((MP_TR_FENCE >> 2) & 1) tr_fence();
 #pragma unroll
             for (int pl = 2; pl >= 0; --pl)
 #pragma unroll
@@ -2197,6 +2208,7 @@ __global__ __launch_bounds__(512, 1) void bwd_roles_kernel(PosOperand DZ, PosOpe
                     for (int ni = 0; ni < TNW; ++ni) accW[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mi], fb[pl][ni], accW[mi][ni], 0, 0, 0);
 #pragma unroll
             for (int mi = 0; mi < TMW; ++mi) fa[mi] = tr_frag_packed<GS, true>(hA[cur][1], 0, wrow0 + mi * 32);
+            if constexpr ((MP_TR_FENCE >> 2) & 1) tr_fence();
 #pragma unroll
             for (int pl = 1; pl >= 0; --pl)
 #pragma unroll
@@ -2415,6 +2427,7 @@ __global__ __launch_bounds__(512) void bwd_first_kernel(PosOperand DZ, PosOperan
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni) fb[0][ni] = tr_frag_packed<GS>(hB[cur][0], 0, wcol0 + ni * 32);
             fa = tr_frag_packed<GS>(hA[cur][2], 0, wrow0);
+            if constexpr ((MP_TR_FENCE >> 1) & 1) tr_fence();
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni) accW[0][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb[0][ni], accW[0][ni], 0, 0, 0);
             fa = tr_frag_packed<GS>(hA[cur][0], 0, wrow0);
@@ -2422,11 +2435,13 @@ __global__ __launch_bounds__(512) void bwd_first_kernel(PosOperand DZ, PosOperan
             for (int pl = 2; pl >= 1; --pl)
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni) fb[pl][ni] = tr_frag_packed<GS>(hB[cur][pl], 0, wcol0 + ni * 32);
+            if constexpr ((MP_TR_FENCE >> 1) & 1) tr_fence();
 #pragma unroll
             for (int pl = 2; pl >= 0; --pl)
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni) accW[0][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb[pl][ni], accW[0][ni], 0, 0, 0);
             fa = tr_frag_packed<GS>(hA[cur][1], 0, wrow0);
+            if constexpr ((MP_TR_FENCE >> 1) & 1) tr_fence();
 #pragma unroll
             for (int pl = 1; pl >= 0; --pl)
 #pragma unroll
