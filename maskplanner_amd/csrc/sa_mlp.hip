@@ -504,9 +504,11 @@ __device__ __forceinline__ bf16x8 tr_frag_packed(const __bf16* tile, int k0, int
 // compiler's partial `s_waitcnt lgkmcnt(N)` in front of the MFMAs that consume ds_read_b64_tr_b16 results -- correct if LDS operations
 // complete in issue order -- let stale fragment registers into the dW product whenever other waves' staging writes kept the LDS busy
 // (run-to-run varying weight gradients; a full lgkmcnt(0) here removes it, NOTEBOOK.md).  MP_TR_FENCE: bit 0 the one-plane dW product,
-// bit 1 the three-plane dW product of bwd_fused_kernel (a fence behind each fragment batch), bit 2 the dW waves of bwd_roles_kernel.
+// bit 1 the three-plane dW product of bwd_fused_kernel (a fence behind each fragment batch), bit 2 the dW waves of bwd_roles_kernel, bit 3 the tiled GEMM kernels' chunk products (mma_chunk_bf16 / mma_chunk_split with a
+// transposed operand).
 #ifndef MP_TR_FENCE
-#define MP_TR_FENCE 7       // (no measurable cost: headline 2.157 vs 2.149 ms median over three alternations)
+#define MP_TR_FENCE 15      // every consumer of transposed fragments (no measurable cost: headline 2.157 vs 2.149 ms median over three alternations;
+                            // the tiled GEMMs of the group_all level 322 vs 317 us)
 #endif
 __device__ __forceinline__ void tr_fence()
 {
@@ -534,6 +536,7 @@ __device__ __forceinline__ void mma_chunk_bf16(const __bf16* sA, const __bf16* s
             if constexpr (B_TR) b[ni] = tr_frag(sB, LDB, ks, wcol0 + ni * 32);
             else b[ni] = *reinterpret_cast<const bf16x8*>(sB + (wcol0 + ni * 32 + l31) * LDB + ks + 8 * hi);
         }
+        if constexpr ((A_TR || B_TR) && ((MP_TR_FENCE >> 3) & 1)) tr_fence();
 #pragma unroll
         for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
@@ -569,6 +572,7 @@ __device__ __forceinline__ void mma_chunk_split(const __bf16* sA, const __bf16* 
         for (int s = 0; s < 3; ++s) {
 #pragma unroll
             for (int mi = 0; mi < TM; ++mi) a[mi] = afrag(APL[s], ks, mi);
+            if constexpr ((A_TR || B_TR) && ((MP_TR_FENCE >> 3) & 1)) tr_fence();
 #pragma unroll
             for (int pl = NB[s] - 1; pl >= 0; --pl)
 #pragma unroll
