@@ -12,7 +12,7 @@ bash tools/pmc_hot.sh > gpurun_out/${TAG}_pmc_hot.txt 2>&1
 python3 bench.py > gpurun_out/${TAG}_bench_full.log 2>&1
 python3 bench.py --category windows --no-cpu-baseline --no-side-legs > gpurun_out/${TAG}_windows.log 2>&1
 python3 bench.py --category shelves --no-cpu-baseline --no-side-legs > gpurun_out/${TAG}_shelves.log 2>&1
-python3 bench.py --category containers --points 10240 --encoder msg --dtype bf16 --steps 10 --no-cpu-baseline --no-side-legs > gpurun_out/${TAG}_c5_bf16.log 2>&1
-python3 bench.py --category containers --points 10240 --encoder msg --dtype f32 --steps 10 --no-cpu-baseline --no-side-legs > gpurun_out/${TAG}_c5_f32.log 2>&1
+python3 bench.py --category containers --points 10240 --encoder msg --dtype bf16 --steps 40 --no-cpu-baseline --no-side-legs > gpurun_out/${TAG}_c5_bf16.log 2>&1
+python3 bench.py --category containers --points 10240 --encoder msg --dtype f32 --steps 40 --no-cpu-baseline --no-side-legs > gpurun_out/${TAG}_c5_f32.log 2>&1
 MP_SA_SPLIT=0 MP_KNN_SCREEN=0 python3 bench.py --no-cpu-baseline --no-side-legs > gpurun_out/${TAG}_fp32mfma.log 2>&1
 tail -c 300 gpurun_out/${TAG}_bench_full.log
