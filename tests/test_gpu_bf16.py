@@ -145,10 +145,12 @@ def test_bf16_chain_forward_backward_vs_prerounded_oracle(B, S, K, cin, widths):
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "f32"])
-@pytest.mark.parametrize("B,S,K,cin,widths", [CASES[3], CASES[0], (4, 32, 64, 3, [64, 128, 128]), (2, 32, 64, 3, [128, 128, 256])])
+@pytest.mark.parametrize("B,S,K,cin,widths", [CASES[3], CASES[0], (4, 32, 64, 3, [64, 128, 128]), (2, 32, 64, 3, [128, 128, 256]), (2, 48, 64, 131, [128, 128, 256]),
+                                            (8, 1, 512, 259, [256, 512, 1024])])
 def test_position_stream_backward_is_steady_from_run_to_run(B, S, K, cin, widths, dtype):
     """The same chain, the same inputs, four times: every weight gradient must come out the same up to the order of the fp32 atomics
-    between workgroups (<= 2e-6 relative).  A hazard inside the fused backward kernels -- a fragment register consumed before its LDS
+    between workgroups (<= 2e-6 relative; the last two shapes run the first-layer kernel of a level with input features and the tiled
+    GEMM kernels of a group_all level).  A hazard inside the fused backward kernels -- a fragment register consumed before its LDS
     read has landed, a wave staging into a buffer another still reads -- shows up as a gradient that moves by 1e-3 ... 1e-1 from run to
     run while every single run may still pass an accuracy bound (found that way in round 4: the 32-position one-plane kernel with two
     chunks of loads in flight consumed transposed fragments behind a partial lgkmcnt wait; csrc/sa_mlp.hip: tr_fence)."""
