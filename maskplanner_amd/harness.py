@@ -14,6 +14,11 @@ from .loss_handler import LossHandler, maskplanner_loss_config
 from .pointnet2_cls_ssg import maskplanner_model
 
 
+def _even(n):
+    """int64 units rounded up to a 16-byte multiple."""
+    return (int(n) + 1) // 2 * 2
+
+
 class TrainStep:
     def __init__(self, category="cuboids", B=32, N=5120, device="cuda", seed=1235, hidden_size=(1024, 1024), lr=1e-3,
                  dist_points="cuboid", rank=0, loss_overrides=None, prefetch_sampling=False, factor_heads=True, graph=None,
@@ -529,7 +534,9 @@ class TrainStep:
             t = self.batch.get(k)
             if torch.is_tensor(t) and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.ndim == 3:
                 B, P2, D = t.shape
-                out.append((k, B, (ops.target_aux_bytes(B, P2, D) + 7) // 8 if planes else 0))
+                # (every region of the plan buffer starts on a 16-byte boundary -- the screening workspace is read with 16-byte
+                # loads, launch_knn1_screen refuses anything else --, so the B lengths in front of it occupy an even number of units)
+                out.append((k, B, _even(B), _even((ops.target_aux_bytes(B, P2, D) + 7) // 8) if planes else 0))
         return out
 
     def _plan_extras(self):
@@ -559,12 +566,13 @@ class TrainStep:
         for m in self._plan_levels():
             S, _, Ks = self._level_spec(m)
             n += B * S + (B * S * 3 + 1) // 2 + sum(B * S * K for K in Ks)
+        n = _even(n)
         self._plan_aux_at = n
-        for _, b, w in self._plan_targets():
+        for _, _, b, w in self._plan_targets():
             n += b + w
         self._plan_extra_at = n
         for _, _, _, units in self._plan_extras():
-            n += units
+            n += _even(units)
         return n
 
     def _extra_views(self, buf):
@@ -575,7 +583,7 @@ class TrainStep:
             K = Ks[si]
             v = buf[o:o + units]
             out.append((kind, li, si, v.view(torch.float32).view(B, S, K, 4) if kind == "gxyz" else v.view(torch.int32).view(2, B, S * K)))
-            o += units
+            o += _even(units)
         return out
 
     def _rounds_gxyz(self, li, si):
@@ -634,8 +642,8 @@ class TrainStep:
     def _target_views(self, buf):
         """Per target (key, lengths i64 [B], workspace u8 or None) as views of the plan buffer's tail."""
         o, out = self._plan_aux_at, []
-        for k, b, w in self._plan_targets():
-            out.append((k, buf[o:o + b], buf[o + b:o + b + w].view(torch.uint8) if w else None))
+        for k, B, b, w in self._plan_targets():
+            out.append((k, buf[o:o + B], buf[o + b:o + b + w].view(torch.uint8) if w else None))
             o += b + w
         return out
 

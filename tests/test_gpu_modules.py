@@ -1427,15 +1427,17 @@ def test_step_counters_advance_once_per_step():
     assert float(ts.opt.step_dev) == n and float(ts.factor_opt.step_dev) == n
 
 
-@pytest.mark.parametrize("streamed,encoder,dtype", [(False, "ssg", "f32"), (True, "ssg", "f32"), (False, "msg", "bf16"), (False, "msg", "f32")])
-def test_plan_carried_preprocessing_equals_the_inline_kernels(streamed, encoder, dtype):
+@pytest.mark.parametrize("streamed,encoder,dtype,B", [(False, "ssg", "f32", 4), (True, "ssg", "f32", 4), (False, "msg", "bf16", 4), (False, "msg", "f32", 4),
+                                                       (False, "ssg", "f32", 1), (False, "ssg", "f32", 3), (True, "ssg", "f32", 3)])
+def test_plan_carried_preprocessing_equals_the_inline_kernels(streamed, encoder, dtype, B):
     """[r4] What travels with the double-buffered sampling plan besides the sampling itself -- padded lengths of the ground-truth
     segments / points, the screening planes of the ground-truth segments, the first level's grouped coordinate rows, the factorised
     level's sorted row lists -- equals what the in-line kernels compute from the step's CURRENT batch, bit for bit, after replayed steps
     (resident batch) and with a fresh host batch every step (streamed)."""
     from maskplanner_amd import ops, sa_mlp, pointnet2_utils as pu
     from maskplanner_amd.harness import TrainStep
-    ts = TrainStep("cuboids", B=4, N=1024, seed=5, stream_batches=3 if streamed else 0, encoder=encoder, mlp_dtype=dtype)
+    # (odd batches: every region of the plan buffer must still start on a 16-byte boundary -- ADVICE r4)
+    ts = TrainStep("cuboids", B=B, N=1024, seed=5, stream_batches=3 if streamed else 0, encoder=encoder, mlp_dtype=dtype)
     for _ in range(7):
         ts.step()
     torch.cuda.synchronize()
