@@ -3,7 +3,7 @@
 //             or the plain Linear (fc3 / fc_normals / sm_fc3, :311, :327, :336)
 //   backward  dz = BatchNorm + ReLU + dropout backward of grad_y, dgamma, dbeta, and grad_x = dz W
 //
-// B <= 32 rows against 1024 x 1024 .. 11988 x 1024 weights: every layer is one pass over W, and the libraries' GEMMs for a 32-row
+// B <= 32 rows ([r5] B <= 64: four 16-row tiles, MT = 4) against 1024 x 1024 .. 11988 x 1024 weights: every layer is one pass over W, and the libraries' GEMMs for a 32-row
 // batch pick 16 x 32 tiles on 64 workgroups (11-12 us for 4 MB; 20 us for 49 MB).  Here the batch is the 32-row side of
 // v_mfma_f32_16x16x4_f32 tiles (fp32 operands straight from memory into the matrix cores: no staging arithmetic at all), a workgroup
 // owns 16 output columns and its eight waves an eighth of K each, every operand byte of a wave requested up front (one memory latency
@@ -61,7 +61,8 @@ struct HeadFwd {
     HeadBn bn;
 };
 
-template <int NJ>
+// [r5] MT: 16-row tiles of the batch -- 2 (B <= 32) or 4 (B <= 64: the reference's own batch size, configs/maskplanner/cuboids_v2.yaml:12).
+template <int NJ, int MT = 2>
 __global__ __launch_bounds__(HL_THREADS) void head_fwd_kernel(HeadFwd pa, HeadFwd pb, int B, int I, int tiles_a)
 {
     const bool second = (int)blockIdx.x >= tiles_a;
@@ -78,8 +79,9 @@ __global__ __launch_bounds__(HL_THREADS) void head_fwd_kernel(HeadFwd pa, HeadFw
     constexpr int LPR = CH / 4, RPI = 64 / LPR, NI = 16 / RPI;     // lanes per row, rows per load instruction, instructions per 16-row tile
     constexpr int NF = CH / 16;                 // fragments (float4 per lane) per tile and pass
     __shared__ __attribute__((aligned(16))) float tr[HL_WAVES][16][CH + 4];
-    __shared__ float part[HL_WAVES][2][4][64];
-    __shared__ float zt[32][17];
+    constexpr int RB = 16 * MT, EPT = MT / 2;        // rows of the batch tile; epilogue elements per thread (rows b, b + 32)
+    __shared__ float part[HL_WAVES][MT][4][64];
+    __shared__ float zt[RB][17];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int l16 = lane & 15, q = lane >> 4;
     const int o0 = ((int)blockIdx.x - (second ? tiles_a : 0)) * 16;
@@ -100,7 +102,7 @@ __global__ __launch_bounds__(HL_THREADS) void head_fwd_kernel(HeadFwd pa, HeadFw
         if (bn.running_mean) { rm = bn.running_mean[o]; rv = bn.running_var[o]; }
     }
     if (drop) drop_key = (unsigned long long)bn.rng[0] + 0xD1B54A32D192ED03ull * (unsigned long long)bn.rng[1] + ((unsigned long long)(unsigned)bn.layer << 48);
-    f32x4 rw[NCH][NI], rx0[NCH][NI], rx1[NCH][NI];
+    f32x4 rw[NCH][NI], rx[MT][NCH][NI];
 #pragma unroll
     for (int c = 0; c < NCH; ++c)
 #pragma unroll
@@ -113,71 +115,79 @@ __global__ __launch_bounds__(HL_THREADS) void head_fwd_kernel(HeadFwd pa, HeadFw
 #pragma unroll
         for (int n = 0; n < NI; ++n) {
             const int row = n * RPI + lr;
-            rx0[c][n] = *reinterpret_cast<const f32x4*>(x + (size_t)min(row, B - 1) * I + k0 + c * CH);
-            rx1[c][n] = *reinterpret_cast<const f32x4*>(x + (size_t)min(16 + row, B - 1) * I + k0 + c * CH);
+#pragma unroll
+            for (int t = 0; t < MT; ++t) rx[t][c][n] = *reinterpret_cast<const f32x4*>(x + (size_t)min(16 * t + row, B - 1) * I + k0 + c * CH);
         }
     __builtin_amdgcn_sched_barrier(0);       // every operand byte requested before the first product: one memory latency per workgroup
-    f32x4 a0 = {0.0f, 0.0f, 0.0f, 0.0f}, a1 = {0.0f, 0.0f, 0.0f, 0.0f};
-    float (*t)[CH + 4] = tr[wave];
+    f32x4 acc[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) acc[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    float (*tl)[CH + 4] = tr[wave];
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
-        f32x4 wv[NF], xv0[NF], xv1[NF];
+        f32x4 wv[NF], xv[MT][NF];
 #pragma unroll
-        for (int n = 0; n < NI; ++n) *reinterpret_cast<f32x4*>(&t[n * RPI + lr][lk]) = rw[c][n];
+        for (int n = 0; n < NI; ++n) *reinterpret_cast<f32x4*>(&tl[n * RPI + lr][lk]) = rw[c][n];
 #pragma unroll
-        for (int j = 0; j < NF; ++j) wv[j] = *reinterpret_cast<const f32x4*>(&t[l16][16 * j + 4 * q]);
+        for (int j = 0; j < NF; ++j) wv[j] = *reinterpret_cast<const f32x4*>(&tl[l16][16 * j + 4 * q]);
 #pragma unroll
-        for (int n = 0; n < NI; ++n) *reinterpret_cast<f32x4*>(&t[n * RPI + lr][lk]) = rx0[c][n];
+        for (int t = 0; t < MT; ++t) {
 #pragma unroll
-        for (int j = 0; j < NF; ++j) xv0[j] = *reinterpret_cast<const f32x4*>(&t[l16][16 * j + 4 * q]);
+            for (int n = 0; n < NI; ++n) *reinterpret_cast<f32x4*>(&tl[n * RPI + lr][lk]) = rx[t][c][n];
 #pragma unroll
-        for (int n = 0; n < NI; ++n) *reinterpret_cast<f32x4*>(&t[n * RPI + lr][lk]) = rx1[c][n];
-#pragma unroll
-        for (int j = 0; j < NF; ++j) xv1[j] = *reinterpret_cast<const f32x4*>(&t[l16][16 * j + 4 * q]);
+            for (int j = 0; j < NF; ++j) xv[t][j] = *reinterpret_cast<const f32x4*>(&tl[l16][16 * j + 4 * q]);
+        }
         // k-step (c, j, e) multiplies elements [row][wave KW + c CH + 16 j + 4 q + e] of both operands
 #pragma unroll
         for (int j = 0; j < NF; ++j) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xv0[j][e], wv[j][e], a0, 0, 0, 0);
-                a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xv1[j][e], wv[j][e], a1, 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < MT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[t][j][e], wv[j][e], acc[t], 0, 0, 0);
             }
         }
     }
     // accumulator register r of lane (l16, q): row 4 q + r of the 16-row tile, column l16
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        part[wave][0][r][lane] = a0[r];
-        part[wave][1][r][lane] = a1[r];
-    }
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part[wave][t][r][lane] = acc[t][r];
     __syncthreads();
-    const bool live = colok && b < B;
-    {
-        const int t = b >> 4, qq = (b & 15) >> 2, r = b & 3, ln = qq * 16 + oc;
+    float zv[EPT];
+    bool live[EPT];
+#pragma unroll
+    for (int u = 0; u < EPT; ++u) {
+        const int bb = b + 32 * u;
+        live[u] = colok && bb < B;
+        const int t = bb >> 4, qq = (bb & 15) >> 2, r = bb & 3, ln = qq * 16 + oc;
         float s = 0.0f;
 #pragma unroll
         for (int w = 0; w < HL_WAVES; ++w) s += part[w][t][r][ln];
-        zt[b][oc] = s + bias_v;
+        zv[u] = s + bias_v;
+        zt[bb][oc] = zv[u];
     }
-    const float zv = zt[b][oc];
     if (!bn.on) {
-        if (live) y[(size_t)b * O + o] = zv;
+#pragma unroll
+        for (int u = 0; u < EPT; ++u)
+            if (live[u]) y[(size_t)(b + 32 * u) * O + o] = zv[u];
         return;
     }
-    if (live && z != nullptr) z[(size_t)b * O + o] = zv;
+#pragma unroll
+    for (int u = 0; u < EPT; ++u)
+        if (live[u] && z != nullptr) z[(size_t)(b + 32 * u) * O + o] = zv[u];
     __syncthreads();
     float mean, rstd;
     if (bn.training) {
-        float col[32];
+        float col[RB];
 #pragma unroll
-        for (int r = 0; r < 32; ++r) col[r] = zt[r][oc];        // (fixed trip count: the 32 reads are issued together)
+        for (int r = 0; r < RB; ++r) col[r] = zt[r][oc];        // (fixed trip count: the reads are issued together)
         float s = 0.0f;
 #pragma unroll
-        for (int r = 0; r < 32; ++r) s += r < B ? col[r] : 0.0f;
+        for (int r = 0; r < RB; ++r) s += r < B ? col[r] : 0.0f;
         mean = s / (float)B;
         float v = 0.0f;
 #pragma unroll
-        for (int r = 0; r < 32; ++r) { const float d = col[r] - mean; v += r < B ? d * d : 0.0f; }
+        for (int r = 0; r < RB; ++r) { const float d = col[r] - mean; v += r < B ? d * d : 0.0f; }
         const float var = v / (float)B;
         rstd = 1.0f / sqrtf(var + bn.eps);
         if (b == 0 && colok && bn.running_mean != nullptr) {
@@ -189,11 +199,15 @@ __global__ __launch_bounds__(HL_THREADS) void head_fwd_kernel(HeadFwd pa, HeadFw
         rstd = 1.0f / sqrtf(rv + bn.eps);
     }
     if (b == 0 && colok) { bn.save_mean[o] = mean; bn.save_rstd[o] = rstd; }
-    if (!live) return;
-    float v = (zv - mean) * rstd * ga + be;
-    v = v > 0.0f ? v : 0.0f;
-    if (drop) v = drop_keep(drop_key, b, O, o, bn.drop_p, 1.0f / (1.0f - bn.drop_p), v);
-    y[(size_t)b * O + o] = v;
+#pragma unroll
+    for (int u = 0; u < EPT; ++u) {
+        if (!live[u]) continue;
+        const int bb = b + 32 * u;
+        float v = (zv[u] - mean) * rstd * ga + be;
+        v = v > 0.0f ? v : 0.0f;
+        if (drop) v = drop_keep(drop_key, bb, O, o, bn.drop_p, 1.0f / (1.0f - bn.drop_p), v);
+        y[(size_t)bb * O + o] = v;
+    }
 }
 
 // ---- backward of a block:  dz = bn_relu_drop_bwd(grad_y),  grad_x += dz W  -------------------------------------------------------
@@ -224,8 +238,10 @@ struct HeadBwd {
 
 // Up to two problems per launch (same B and I): the row slices of the second follow the first's in grid.y.  Their grad_x may be ONE buffer
 // (fc1 / sm_fc1 both read the global feature: no fan-out add) -- `atomic`: more than one slice adds into some grad_x.
+template <int MT>       // 16-row tiles of the batch: 2 (B <= 32) or 4 (B <= 64)
 __global__ __launch_bounds__(HL_THREADS) void head_bwd_kernel(HeadBwd pa, HeadBwd pb, int B, int I, int slices_a, int atomic)
 {
+    constexpr int RB = 16 * MT, NR = MT * 2;          // batch rows of the tile; rows per thread while dz is formed (bq + 8 i)
     const bool second = (int)blockIdx.y >= slices_a;
     const float* __restrict__ grad_y = second ? pb.grad_y : pa.grad_y;
     const float* __restrict__ y = second ? pb.y : pa.y;
@@ -242,9 +258,10 @@ __global__ __launch_bounds__(HL_THREADS) void head_bwd_kernel(HeadBwd pa, HeadBw
     const float keep_scale = second ? pb.keep_scale : pa.keep_scale;
     // LDS: the dz image + the column-sum exchange (49 KB) while dz is formed and multiplied, then -- behind a barrier -- the eight waves'
     // partial tiles (64 KB) over the same bytes.  (ds_add_f32 into one shared tile instead: ~200 cycles per instruction, 23 us.)
-    __shared__ __attribute__((aligned(16))) float smem[16384];
-    float (*dzs)[HB_LD] = reinterpret_cast<float (*)[HB_LD]>(smem);                          // [32][HB_LD]
-    float (*red)[HB_OS][2] = reinterpret_cast<float (*)[HB_OS][2]>(smem + 32 * HB_LD);       // [HL_WAVES][HB_OS][2]
+    // (MT = 4: the image is 65 KB, the partial tiles go through it in two rounds of 64 KB)
+    __shared__ __attribute__((aligned(16))) float smem[MT == 2 ? 16384 : RB * HB_LD + HL_WAVES * HB_OS * 2];
+    float (*dzs)[HB_LD] = reinterpret_cast<float (*)[HB_LD]>(smem);                          // [RB][HB_LD]
+    float (*red)[HB_OS][2] = reinterpret_cast<float (*)[HB_OS][2]>(smem + RB * HB_LD);       // [HL_WAVES][HB_OS][2]
     float (*part)[2][4][4][64] = reinterpret_cast<float (*)[2][4][4][64]>(smem);             // [HL_WAVES][2][4][4][64]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int l16 = lane & 15, q = lane >> 4;
@@ -263,7 +280,7 @@ __global__ __launch_bounds__(HL_THREADS) void head_bwd_kernel(HeadBwd pa, HeadBw
         const int c4 = lane, bq = wave;
         const int oc = os + 4 * c4;
         const bool colok = oc < O;             // (O % 4 == 0)
-        f32x4 dy[4], xh[4];
+        f32x4 dy[NR], xh[NR];
         f32x4 mean = {0.0f, 0.0f, 0.0f, 0.0f}, rstd = mean, ga = {1.0f, 1.0f, 1.0f, 1.0f};
         if (colok) {
             mean = *reinterpret_cast<const f32x4*>(save_mean + oc);
@@ -272,7 +289,7 @@ __global__ __launch_bounds__(HL_THREADS) void head_bwd_kernel(HeadBwd pa, HeadBw
         }
         f32x4 db = {0.0f, 0.0f, 0.0f, 0.0f}, dg = db;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NR; ++i) {
             const int b = bq + 8 * i;
             const bool ok = colok && b < B;
             const size_t e = ok ? (size_t)b * O + oc : 0;
@@ -300,7 +317,7 @@ __global__ __launch_bounds__(HL_THREADS) void head_bwd_kernel(HeadBwd pa, HeadBw
         }
         const float inv = 1.0f / (float)B;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NR; ++i) {
             const int b = bq + 8 * i;
             f32x4 d;
 #pragma unroll
@@ -316,33 +333,37 @@ __global__ __launch_bounds__(HL_THREADS) void head_bwd_kernel(HeadBwd pa, HeadBw
         }
     }
     __syncthreads();
-    f32x4 acc[2][4];
+    f32x4 acc[MT][4];
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < MT; ++t)
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[t][e] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
-        const float d0 = dzs[l16][wave * 32 + 4 * s + q], d1 = dzs[16 + l16][wave * 32 + 4 * s + q];
+        float d[MT];
+#pragma unroll
+        for (int t = 0; t < MT; ++t) d[t] = dzs[16 * t + l16][wave * 32 + 4 * s + q];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            acc[0][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(d0, wv[s][e], acc[0][e], 0, 0, 0);
-            acc[1][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(d1, wv[s][e], acc[1][e], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < MT; ++t) acc[t][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(d[t], wv[s][e], acc[t][e], 0, 0, 0);
         }
     }
-    __syncthreads();                  // every wave has read its dz fragments: the image's bytes become the partial tiles
+    // the partial tiles of 32 batch rows at a time through the image's bytes
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int hh = 0; hh < MT / 2; ++hh) {
+        __syncthreads();              // every wave has read its dz fragments (/ the previous round's partial tiles)
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
+        for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) part[wave][t][e][r][lane] = acc[t][e][r];
-    __syncthreads();
-    // 32 rows x 64 columns, four per thread: thread -> (row b, columns i0 + 4 n .. + 3), n = tid & 15
-    {
-        const int b = tid >> 4, n = tid & 15;
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) part[wave][t][e][r][lane] = acc[2 * hh + t][e][r];
+        __syncthreads();
+        // 32 rows x 64 columns, four per thread: thread -> (row b, columns i0 + 4 n .. + 3), n = tid & 15
+        const int bl = tid >> 4, n = tid & 15, b = 32 * hh + bl;
         if (b < B) {
-            const int t = b >> 4, qq = (b & 15) >> 2, r = b & 3, ln = qq * 16 + n;
+            const int t = bl >> 4, qq = (bl & 15) >> 2, r = bl & 3, ln = qq * 16 + n;
             float* dst = gx + (size_t)b * I + i0 + 4 * n;
             f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
@@ -362,7 +383,7 @@ __global__ __launch_bounds__(HL_THREADS) void head_bwd_kernel(HeadBwd pa, HeadBw
 
 extern "C" int mp_head_block_supported(int64_t B, int64_t I, int64_t O)
 {
-    if (B < 1 || B > 32 || O < 1 || O > (1 << 24)) return 0;
+    if (B < 1 || B > 64 || O < 1 || O > (1 << 24)) return 0;
     return I == 128 || I == 256 || I == 512 || I == 1024 || I == 2048;
 }
 
@@ -374,8 +395,11 @@ static int head_fwd_launch(const HeadFwd& a, const HeadFwd* b, int64_t B, int64_
     const double Ot = (double)a.O + (b ? (double)b->O : 0.0);
     const double flops = 2.0 * (double)B * (double)I * Ot, bytes = 4.0 * ((double)I * Ot + (double)B * ((double)I + 2.0 * Ot));
     const HeadFwd pb = b ? *b : a;
-#define HL_FWD(NJ) MP_LAUNCH("head_fwd_kernel", flops, bytes, head_fwd_kernel<NJ>, grid, dim3(HL_THREADS), 0, stream, a, pb, (int)B, (int)I, \
-                             b ? tiles_a : (1 << 30))
+#define HL_FWD(NJ)                                                                                                                          \
+    if (B <= 32) MP_LAUNCH("head_fwd_kernel", flops, bytes, (head_fwd_kernel<NJ, 2>), grid, dim3(HL_THREADS), 0, stream, a, pb, (int)B, (int)I, \
+                           b ? tiles_a : (1 << 30));                                                                                         \
+    else MP_LAUNCH("head_fwd_kernel", flops, bytes, (head_fwd_kernel<NJ, 4>), grid, dim3(HL_THREADS), 0, stream, a, pb, (int)B, (int)I,    \
+                   b ? tiles_a : (1 << 30))
     switch (I) {
         case 128: HL_FWD(1); break;
         case 256: HL_FWD(2); break;
@@ -439,7 +463,7 @@ extern "C" int mp_head_block_bwd_slices(int64_t O)
 extern "C" int mp_head_blocks_bwd_f32(int n, const mp_head_block_t* blocks, int64_t B, int64_t I, mp_stream_t stream_)
 {
     if (n < 1 || n > 2 || !blocks) return MP_EINVAL;
-    if (B < 1 || B > 32 || I < 64 || I % 64 != 0) return MP_EUNSUPPORTED;
+    if (B < 1 || B > 64 || I < 64 || I % 64 != 0) return MP_EUNSUPPORTED;
     HeadBwd s[2];
     int slices[2] = {0, 0};
     double Ot = 0.0;
@@ -462,8 +486,12 @@ extern "C" int mp_head_blocks_bwd_f32(int n, const mp_head_block_t* blocks, int6
     }
     const dim3 grid((unsigned)(I / 64), (unsigned)(slices[0] + slices[1]));
     const double flops = 2.0 * (double)B * (double)I * Ot, bytes = 4.0 * ((double)I * Ot + (double)B * ((double)I + 4.0 * Ot));
-    MP_LAUNCH("head_bwd_kernel", flops, bytes, head_bwd_kernel, grid, dim3(HL_THREADS), 0, stream, s[0], n == 2 ? s[1] : s[0], (int)B, (int)I,
-              n == 2 ? slices[0] : (1 << 30), atomic);
+    if (B <= 32)
+        MP_LAUNCH("head_bwd_kernel", flops, bytes, head_bwd_kernel<2>, grid, dim3(HL_THREADS), 0, stream, s[0], n == 2 ? s[1] : s[0], (int)B, (int)I,
+                  n == 2 ? slices[0] : (1 << 30), atomic);
+    else
+        MP_LAUNCH("head_bwd_kernel", flops, bytes, head_bwd_kernel<4>, grid, dim3(HL_THREADS), 0, stream, s[0], n == 2 ? s[1] : s[0], (int)B, (int)I,
+                  n == 2 ? slices[0] : (1 << 30), atomic);
     MP_CHECK_LAUNCH();
     return MP_OK;
 }

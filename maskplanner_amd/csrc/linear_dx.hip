@@ -1,4 +1,4 @@
-// Input gradient of the weight-heavy head Linears on the matrix cores:  grad_x [B <= 32, I] = g [B, O] * W [O, I].
+// Input gradient of the weight-heavy head Linears on the matrix cores:  grad_x [B <= 64, I] = g [B, O] * W [O, I].
 //
 // Reference: autograd of nn.Linear for fc3 / fc_normals / sm_fc3 (models/pointnet2_cls_ssg.py:311, 327, 336): a [32, O] x [O, 1024]
 // GEMM with O = 6 000 .. 12 000 -- 25 .. 49 MB of weights read for 0.4 .. 0.8 GF: an HBM stream.  rocBLAS picks a 0.6 TB/s kernel
@@ -37,11 +37,13 @@ __device__ __forceinline__ Planes8 split8(const float (&x)[8])
 }
 
 // (g2, W2, O2): a second Linear fed by the same activation (fc3 / fc_normals): K slices >= slices1 belong to it, both add into gx.
-__global__ __launch_bounds__(256, 2) void linear_dx_mfma_kernel(const float* __restrict__ g1, const float* __restrict__ W1, int B, int O1, int I,
+// [r5] RT: 32-row tiles of the batch -- 1 (B <= 32) or 2 (B <= 64: the weight fragments are split once and meet both tiles).
+template <int RT>
+__global__ __launch_bounds__(256, RT == 1 ? 2 : 1) void linear_dx_mfma_kernel(const float* __restrict__ g1, const float* __restrict__ W1, int B, int O1, int I,
                                                                 int ns, float* __restrict__ gx, const float* __restrict__ g2,
                                                                 const float* __restrict__ W2, int O2, int slices1)
 {
-    __shared__ __attribute__((aligned(16))) __bf16 sG[3][LD_NS_MAX][64][8];     // A fragments: [plane][k-step][lane][8 k values]
+    __shared__ __attribute__((aligned(16))) __bf16 sG[RT][3][LD_NS_MAX][64][8];     // A fragments: [row tile][plane][k-step][lane][8 k values]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int l31 = lane & 31, h = lane >> 5;
     const bool second = (int)blockIdx.y >= slices1;
@@ -64,43 +66,50 @@ __global__ __launch_bounds__(256, 2) void linear_dx_mfma_kernel(const float* __r
     }
     // ---- the slice's g rows as A fragments: lane (batch row r, half h) of k-step s holds g[r][k_base + 16 s + 8 h .. + 7]
     // (consecutive threads take consecutive 8-float pieces of one batch row: coalesced reads of an L2-resident table)
-    for (int e = tid; e < ns * 64; e += 256) {
-        const int r = e / (2 * ns), sh = e - r * 2 * ns;
-        const int s = sh >> 1, ln = r + 32 * (sh & 1);
+    for (int e = tid; e < RT * ns * 64; e += 256) {
+        const int r = e / (2 * ns), sh = e - r * 2 * ns;      // r: batch row 0 .. 32 RT - 1
+        const int s = sh >> 1, ln = (r & 31) + 32 * (sh & 1);
         const int k0 = k_base + 8 * sh;
         float x[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) x[j] = (r < B && k0 + j < O) ? g[(size_t)r * O + k0 + j] : 0.0f;
         const Planes8 p = split8(x);
-        *reinterpret_cast<bf16x8*>(&sG[0][s][ln][0]) = p.h;
-        *reinterpret_cast<bf16x8*>(&sG[1][s][ln][0]) = p.m;
-        *reinterpret_cast<bf16x8*>(&sG[2][s][ln][0]) = p.l;
+        *reinterpret_cast<bf16x8*>(&sG[r >> 5][0][s][ln][0]) = p.h;
+        *reinterpret_cast<bf16x8*>(&sG[r >> 5][1][s][ln][0]) = p.m;
+        *reinterpret_cast<bf16x8*>(&sG[r >> 5][2][s][ln][0]) = p.l;
     }
     __syncthreads();
-    f32x16 acc, cor;
+    f32x16 acc[RT], cor[RT];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { acc[r] = 0.0f; cor[r] = 0.0f; }
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[t][r] = 0.0f; cor[t][r] = 0.0f; }
 #pragma unroll
     for (int s = 0; s < LD_NS_MAX; ++s) {
         if (s < ns) {
             const Planes8 b = split8(wq[s]);
-            const bf16x8 ah = *reinterpret_cast<const bf16x8*>(&sG[0][s][lane][0]);
-            const bf16x8 am = *reinterpret_cast<const bf16x8*>(&sG[1][s][lane][0]);
-            const bf16x8 al = *reinterpret_cast<const bf16x8*>(&sG[2][s][lane][0]);
-            cor = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, b.h, cor, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b.h, acc, 0, 0, 0);
-            cor = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b.l, cor, 0, 0, 0);
-            cor = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, b.m, cor, 0, 0, 0);
-            cor = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, b.h, cor, 0, 0, 0);
-            cor = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b.m, cor, 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < RT; ++t) {
+                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(&sG[t][0][s][lane][0]);
+                const bf16x8 am = *reinterpret_cast<const bf16x8*>(&sG[t][1][s][lane][0]);
+                const bf16x8 al = *reinterpret_cast<const bf16x8*>(&sG[t][2][s][lane][0]);
+                cor[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, b.h, cor[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b.h, acc[t], 0, 0, 0);
+                cor[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b.l, cor[t], 0, 0, 0);
+                cor[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, b.m, cor[t], 0, 0, 0);
+                cor[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, b.h, cor[t], 0, 0, 0);
+                cor[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b.m, cor[t], 0, 0, 0);
+            }
         }
     }
     // ---- the slice's tile into grad_x: register r of lane (c, h) is batch row (r & 3) + 8 (r >> 2) + 4 h
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (row < B) atomicAdd(gx + (size_t)row * I + col, acc[r] + cor[r]);
-    }
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (row < B) atomicAdd(gx + (size_t)row * I + col, acc[t][r] + cor[t][r]);
+        }
 }
 
 // Dense weight gradient of the same layers for callers that need it materialised (an unchanged training loop with torch.optim.Adam
@@ -114,28 +123,31 @@ __global__ __launch_bounds__(256) void linear_dw_outer_kernel(const float* __res
     __shared__ __attribute__((aligned(16))) float sx[32][256];         // [b][i]
     const int tid = threadIdx.x;
     const int o0 = blockIdx.y * 64, i0 = blockIdx.x * 256;
-    for (int e = tid; e < 32 * 64; e += 256) {
-        const int b = e >> 6, o = e & 63;
-        sg[b][o] = (b < B && o0 + o < O) ? g[(size_t)b * O + o0 + o] : 0.0f;
-    }
-    for (int e = tid; e < 32 * 64; e += 256) {
-        const int b = e >> 6, q = e & 63;
-        const float4 v = (b < B && i0 + 4 * q < I) ? *reinterpret_cast<const float4*>(x + (size_t)b * I + i0 + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
-        *reinterpret_cast<float4*>(&sx[b][4 * q]) = v;
-    }
-    __syncthreads();
     const int cq = tid & 63, rg = tid >> 6;            // columns i0 + 4 cq .. + 3, rows o0 + 16 rg .. + 15
     float4 acc[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int b0 = 0; b0 < B; b0 += 32) {               // ([r5] batches beyond 32 rows: slabs of 32, b ascending throughout)
+        if (b0) __syncthreads();
+        for (int e = tid; e < 32 * 64; e += 256) {
+            const int b = b0 + (e >> 6), o = e & 63;
+            sg[e >> 6][o] = (b < B && o0 + o < O) ? g[(size_t)b * O + o0 + o] : 0.0f;
+        }
+        for (int e = tid; e < 32 * 64; e += 256) {
+            const int b = b0 + (e >> 6), q = e & 63;
+            const float4 v = (b < B && i0 + 4 * q < I) ? *reinterpret_cast<const float4*>(x + (size_t)b * I + i0 + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4*>(&sx[e >> 6][4 * q]) = v;
+        }
+        __syncthreads();
 #pragma unroll 4
-    for (int b = 0; b < 32; ++b) {
-        const float4 xv = *reinterpret_cast<const float4*>(&sx[b][4 * cq]);
+        for (int b = 0; b < 32; ++b) {
+            const float4 xv = *reinterpret_cast<const float4*>(&sx[b][4 * cq]);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float gv = sg[b][16 * rg + r];       // (broadcast: one address per wave)
-            acc[r].x = __builtin_fmaf(gv, xv.x, acc[r].x); acc[r].y = __builtin_fmaf(gv, xv.y, acc[r].y);
-            acc[r].z = __builtin_fmaf(gv, xv.z, acc[r].z); acc[r].w = __builtin_fmaf(gv, xv.w, acc[r].w);
+            for (int r = 0; r < 16; ++r) {
+                const float gv = sg[b][16 * rg + r];       // (broadcast: one address per wave)
+                acc[r].x = __builtin_fmaf(gv, xv.x, acc[r].x); acc[r].y = __builtin_fmaf(gv, xv.y, acc[r].y);
+                acc[r].z = __builtin_fmaf(gv, xv.z, acc[r].z); acc[r].w = __builtin_fmaf(gv, xv.w, acc[r].w);
+            }
         }
     }
     if (i0 + 4 * cq < I) {
@@ -154,7 +166,7 @@ extern "C" int mp_linear_dw_outer_f32(const float* g, const float* x, int64_t B,
     if (B < 0 || O < 0 || I < 0) return MP_EINVAL;
     if (O == 0 || I == 0) return MP_OK;
     if (!dW || (B > 0 && (!g || !x))) return MP_EINVAL;
-    if (B > 32 || (I & 3) || O >= ((int64_t)1 << 30)) return MP_EUNSUPPORTED;
+    if (B > 4096 || (I & 3) || O >= ((int64_t)1 << 30)) return MP_EUNSUPPORTED;
     MP_LAUNCH("linear_dw_outer_kernel", 2.0 * (double)B * O * I, 4.0 * ((double)O * I + (double)B * (O + I)), linear_dw_outer_kernel,
               dim3((unsigned)((I + 255) / 256), (unsigned)((O + 63) / 64)), dim3(256), 0, mp_stream(stream_), g, x, (int)B, (int)O, (int)I, dW);
     MP_CHECK_LAUNCH();
@@ -167,7 +179,7 @@ static int linear_dx_mfma2(const float* g1, const float* w1, int64_t O1, const f
     if (B < 0 || O1 < 0 || O2 < 0 || I < 0) return MP_EINVAL;
     if (B == 0 || I == 0) return MP_OK;
     if (!grad_x || (O1 > 0 && (!g1 || !w1)) || (O2 > 0 && (!g2 || !w2))) return MP_EINVAL;
-    if (B > 32 || (I % 128) != 0 || O1 >= ((int64_t)1 << 30) || O2 >= ((int64_t)1 << 30)) return MP_EUNSUPPORTED;
+    if (B > 64 || (I % 128) != 0 || O1 >= ((int64_t)1 << 30) || O2 >= ((int64_t)1 << 30)) return MP_EUNSUPPORTED;
     hipStream_t stream = mp_stream(stream_);
     if (!mp::zero_async(grad_x, (size_t)(B * I), stream)) return MP_ELAUNCH;
     if (O1 == 0 && O2 == 0) return MP_OK;
@@ -179,8 +191,12 @@ static int linear_dx_mfma2(const float* g1, const float* w1, int64_t O1, const f
     if (ns > LD_NS_MAX) { ns = LD_NS_MAX; }
     const int64_t s1 = ((O1 + 15) / 16 + ns - 1) / ns, s2 = O2 > 0 ? ((O2 + 15) / 16 + ns - 1) / ns : 0;
     const double Ot = (double)(O1 + O2);
-    MP_LAUNCH("linear_dx_mfma_kernel", 2.0 * (double)B * Ot * I, 4.0 * (Ot * I + (double)B * (Ot + I)), linear_dx_mfma_kernel,
-              dim3((unsigned)ncol, (unsigned)(s1 + s2)), dim3(256), 0, stream, g1, w1, (int)B, (int)O1, (int)I, (int)ns, grad_x, g2, w2, (int)O2, (int)s1);
+    if (B <= 32)
+        MP_LAUNCH("linear_dx_mfma_kernel", 2.0 * (double)B * Ot * I, 4.0 * (Ot * I + (double)B * (Ot + I)), linear_dx_mfma_kernel<1>,
+                  dim3((unsigned)ncol, (unsigned)(s1 + s2)), dim3(256), 0, stream, g1, w1, (int)B, (int)O1, (int)I, (int)ns, grad_x, g2, w2, (int)O2, (int)s1);
+    else
+        MP_LAUNCH("linear_dx_mfma_kernel", 2.0 * (double)B * Ot * I, 4.0 * (Ot * I + (double)B * (Ot + I)), linear_dx_mfma_kernel<2>,
+                  dim3((unsigned)ncol, (unsigned)(s1 + s2)), dim3(256), 0, stream, g1, w1, (int)B, (int)O1, (int)I, (int)ns, grad_x, g2, w2, (int)O2, (int)s1);
     MP_CHECK_LAUNCH();
     return MP_OK;
 }

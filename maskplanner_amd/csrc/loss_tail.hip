@@ -367,6 +367,9 @@ static int bn_relu_rows_fwd(const float* x, int64_t B, int64_t C, int training, 
     if (B <= 32)
         hipLaunchKernelGGL(bn_relu_rows_kernel<8>, grid, dim3(256), 0, mp_stream(stream_), x, (int)B, (int)C, training, (float)momentum,
                            (float)eps, gamma, beta, running_mean, running_var, y, save_mean, save_rstd, (float)drop_p, r, layer);
+    else if (B <= 64)
+        hipLaunchKernelGGL(bn_relu_rows_kernel<16>, grid, dim3(256), 0, mp_stream(stream_), x, (int)B, (int)C, training, (float)momentum,
+                           (float)eps, gamma, beta, running_mean, running_var, y, save_mean, save_rstd, (float)drop_p, r, layer);
     else
         hipLaunchKernelGGL(bn_relu_rows_kernel<0>, grid, dim3(256), 0, mp_stream(stream_), x, (int)B, (int)C, training, (float)momentum,
                            (float)eps, gamma, beta, running_mean, running_var, y, save_mean, save_rstd, (float)drop_p, r, layer);
@@ -385,6 +388,9 @@ static int bn_relu_rows_bwd(const float* grad_y, const float* y, const float* x,
     const dim3 grid((unsigned)((C + 63) / 64));
     if (B <= 32)
         hipLaunchKernelGGL(bn_relu_rows_bwd_kernel<8>, grid, dim3(256), 0, mp_stream(stream_), grad_y, y, x, (int)B, (int)C, training, gamma,
+                           save_mean, save_rstd, grad_x, grad_gamma, grad_beta, (float)keep_scale);
+    else if (B <= 64)
+        hipLaunchKernelGGL(bn_relu_rows_bwd_kernel<16>, grid, dim3(256), 0, mp_stream(stream_), grad_y, y, x, (int)B, (int)C, training, gamma,
                            save_mean, save_rstd, grad_x, grad_gamma, grad_beta, (float)keep_scale);
     else
         hipLaunchKernelGGL(bn_relu_rows_bwd_kernel<0>, grid, dim3(256), 0, mp_stream(stream_), grad_y, y, x, (int)B, (int)C, training, gamma,

@@ -463,6 +463,28 @@ __device__ __forceinline__ Split4 split3(const float4& v)
     return r;
 }
 
+// [r5] Two planes (h, m) for the BACKWARD contractions: x = h + m + O(2^-18 |x|) (h rounded to nearest: |x - h| <= 2^-9 |x|, m the bf16 of the
+// exact difference), x * w = h_x h_w + (h_x m_w + m_x h_w) + O(2^-17 |x w|): three plane products instead of six, two thirds of the staging's split
+// arithmetic and LDS writes, two thirds of the weight fragments.  The result carries ~1e-5 of relative error per product -- random in sign,
+// averaged over the 64 ... 262 144 terms of a sum -- where the three-plane form carries 6e-8: used for gradients only (the forward pass, whose
+// outputs north_star holds to 1e-5, keeps six products); gate: tests/test_gpu_routing.py (every parameter gradient within twice the fp32
+// oracle's distance from the fp64 evaluation).  MP_BWD_PLANES=3 restores the three-plane backward (read on every call).
+__device__ __forceinline__ Split4 split2(const float4& v)
+{
+    Split4 r;
+    const float x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const __bf16 h = (__bf16)x[i];
+        r.h[i] = h;
+        r.m[i] = (__bf16)(x[i] - (float)h);
+    }
+    r.l = r.m;
+    return r;
+}
+template <int NPL>
+__device__ __forceinline__ Split4 splitn(const float4& v) { if constexpr (NPL == 2) return split2(v); else return split3(v); }
+
 // K-packed bf16 tile for the split backward kernel: element (row, c) of a [rows][C] chunk sits at (c / 8) * GS + row * 8 + c % 8
 // (GS = rows * 8 + 32 halves: 16-byte groups of 8 channels, rows of one group contiguous, groups 16 dwords apart mod 64 banks:
 // the transposed read's 16 lanes -- 4 rows x 2 half-groups x 2 groups -- then cover 32 distinct banks, 32 lanes all 64).
@@ -1434,7 +1456,7 @@ constexpr int bwd_fused_threads(int CO, int CI, bool SPLIT, bool ONE)
     if (CO >= 128 && CI == 128) return (SPLIT && !ONE && ((MP_BF_NT256 >> (CO == 256 ? 0 : 1)) & 1)) ? 256 : 512;
     return 256;
 }
-template <int MODE_DZ, int CO, int CI, int MODE_IN = SRC_ACT, bool SPLIT = false, bool ONE = false>      // ONE: see fwd_chunk_kernel
+template <int MODE_DZ, int CO, int CI, int MODE_IN = SRC_ACT, bool SPLIT = false, bool ONE = false, int PL = 3>      // ONE: see fwd_chunk_kernel; PL: operand planes of the split form (split2 / split3)
 __global__ __launch_bounds__(bwd_fused_threads(CO, CI, SPLIT, ONE), (CO >= 128 && CI == 128 ? 1 : ((SPLIT && CI == 64) ? MP_SPLIT_WGS : 2))) void bwd_fused_kernel(PosOperand DZ, PosOperand IN, int P, int p_per_block,
                                                             const float* __restrict__ W, float* __restrict__ dW,
                                                             float* __restrict__ G, BnOut partials)
@@ -1459,7 +1481,7 @@ __global__ __launch_bounds__(bwd_fused_threads(CO, CI, SPLIT, ONE), (CO >= 128 &
     // KSPLIT (256 outputs): in the dX product every wave reads the WHOLE dZ chunk from LDS for its 16 columns -- 192 of the 332 KB of LDS
     // traffic per chunk.  Here a wave takes 32 columns (two tiles) and HALF of K, its partner (wave ^ 4) the other half; each
     // finalises one of the two tiles after adding the partner's partial (8 KB through LDS, one extra barrier per chunk).
-    constexpr bool KSPLIT = SPLIT && !ONE && CO == 256 && CI == 128 && MP_BWD_KSPLIT;
+    constexpr bool KSPLIT = SPLIT && !ONE && PL == 3 && CO == 256 && CI == 128 && MP_BWD_KSPLIT;
     constexpr int HTW = KSPLIT ? 2 : HT, NSTW = KSPLIT ? CO / 64 : CO / 32;     // weight-plane tiles / k-steps per wave
     // SPLIT: K-packed planes (tr_frag_packed), group stride in halves: 16 dwords mod 64 banks.  The 64-input layers are HBM-bound:
     // a smaller pad (8 dwords: some 2-way conflicts in the transposed reads) lets a third workgroup onto the CU -- more loads in flight
@@ -1470,7 +1492,8 @@ __global__ __launch_bounds__(bwd_fused_threads(CO, CI, SPLIT, ONE), (CO >= 128 &
     // ([r4] ONE: a single plane -- the two unused ones were a third of the kernel's LDS.  It is the REGISTERS that keep the bf16 variant's
     // 128 x 128 kernels at one eight-wave workgroup per CU (162 VGPRs; forcing 128 spills 34 dwords: 706 -> 1 100 us; four-wave workgroups
     // take 281): two chunks of loads in flight per CU = the 2.3 TB/s they run at, with every unit idle)
-    constexpr int NPLN = ONE ? 1 : 3;
+    constexpr int NPLN = ONE ? 1 : PL;
+    static_assert(PL == 3 || (PL == 2 && SPLIT && !ONE), "two planes: the split form only");
     __shared__ __attribute__((aligned(16))) __bf16 hA[2][NPLN][SPLIT ? (CO / 8) * GS : 8];   // dZ chunk as (h, m, l) planes
     __shared__ __attribute__((aligned(16))) __bf16 hB[2][NPLN][SPLIT ? (CI / 8) * GS : 8];   // activated input chunk
     __shared__ __attribute__((aligned(16))) float sZ[2][DBK * CI];
@@ -1537,13 +1560,11 @@ __global__ __launch_bounds__(bwd_fused_threads(CO, CI, SPLIT, ONE), (CO >= 128 &
             if constexpr (SPLIT) {
                 Split4 sp;
                 if constexpr ((MP_BF_ABL >> 3) & 1) { const bf16x4 c = to_bf16x4(ra[ps].z); sp.h = c; sp.m = c; sp.l = c; }
-                else sp = split3(finish<MODE_DZ>(ra[ps], ka));
+                else sp = splitn<PL>(finish<MODE_DZ>(ra[ps], ka));
                 const int o = (ca >> 3) * GS + ((ka0 + ps * KA_STEP) ^ (KSWZ ? kswz(ca >> 3) : 0)) * 8 + (ca & 7);
                 *reinterpret_cast<bf16x4*>(&hA[buf][0][o]) = sp.h;
-                if constexpr (!ONE) {
-                    *reinterpret_cast<bf16x4*>(&hA[buf][1][o]) = sp.m;
-                    *reinterpret_cast<bf16x4*>(&hA[buf][2][o]) = sp.l;
-                }
+                if constexpr (NPLN >= 2) *reinterpret_cast<bf16x4*>(&hA[buf][1][o]) = sp.m;
+                if constexpr (NPLN >= 3) *reinterpret_cast<bf16x4*>(&hA[buf][2][o]) = sp.l;
             } else {
                 *reinterpret_cast<float4*>(&sA[buf][(ka0 + ps * KA_STEP) * LDA + ca]) = finish<MODE_DZ>(ra[ps], ka);
             }
@@ -1554,13 +1575,11 @@ __global__ __launch_bounds__(bwd_fused_threads(CO, CI, SPLIT, ONE), (CO >= 128 &
             if constexpr (SPLIT) {
                 Split4 sp;
                 if constexpr ((MP_BF_ABL >> 3) & 1) { const bf16x4 c = to_bf16x4(rb[ps].z); sp.h = c; sp.m = c; sp.l = c; }
-                else sp = split3(finish<MODE_IN>(rb[ps], kb));
+                else sp = splitn<PL>(finish<MODE_IN>(rb[ps], kb));
                 const int oh = (cb >> 3) * GS + ((kb0 + ps * KB_STEP) ^ (KSWZ ? kswz(cb >> 3) : 0)) * 8 + (cb & 7);
                 *reinterpret_cast<bf16x4*>(&hB[buf][0][oh]) = sp.h;
-                if constexpr (!ONE) {
-                    *reinterpret_cast<bf16x4*>(&hB[buf][1][oh]) = sp.m;
-                    *reinterpret_cast<bf16x4*>(&hB[buf][2][oh]) = sp.l;
-                }
+                if constexpr (NPLN >= 2) *reinterpret_cast<bf16x4*>(&hB[buf][1][oh]) = sp.m;
+                if constexpr (NPLN >= 3) *reinterpret_cast<bf16x4*>(&hB[buf][2][oh]) = sp.l;
             } else {
                 *reinterpret_cast<float4*>(&sB[buf][o]) = finish<MODE_IN>(rb[ps], kb);
             }
@@ -1578,7 +1597,7 @@ __global__ __launch_bounds__(bwd_fused_threads(CO, CI, SPLIT, ONE), (CO >= 128 &
     const int xrow0 = DBK == 32 ? (wave / (NW / 2)) * 16 : 0;
     const int xcol0 = DBK == 32 ? (wave % (NW / 2)) * XW : wave * XW;
     float wfrag[SPLIT ? 1 : HT][SPLIT ? 1 : CO / 4];
-    bf16x8 wsp[SPLIT ? HTW : 1][SPLIT ? NSTW : 1][3];   // SPLIT (16x16x32): lane (col, kq) holds W[32*st + 8*kq .. + 7][col] as planes
+    bf16x8 wsp[SPLIT ? HTW : 1][SPLIT ? NSTW : 1][PL];  // SPLIT (16x16x32): lane (col, kq) holds W[32*st + 8*kq .. + 7][col] as planes
     const int gcol0 = KSPLIT ? (wave & 3) * 32 : xcol0;      // first dX column of this wave's tiles
     const int gst0 = KSPLIT ? (wave >> 2) * NSTW : 0;        // first k-step of its share of K
     if constexpr (SPLIT) {
@@ -1587,13 +1606,13 @@ __global__ __launch_bounds__(bwd_fused_threads(CO, CI, SPLIT, ONE), (CO >= 128 &
 #pragma unroll
             for (int st = 0; st < NSTW; ++st) {
                 const float* wp = W + (size_t)(32 * (gst0 + st) + 8 * (lane >> 4)) * CI + gcol0 + 16 * h + (lane & 15);
-                const Split4 lo = split3(make_float4(wp[0], wp[CI], wp[2 * CI], wp[3 * CI]));
-                const Split4 hi = split3(make_float4(wp[4 * CI], wp[5 * CI], wp[6 * CI], wp[7 * CI]));
+                const Split4 lo = splitn<PL>(make_float4(wp[0], wp[CI], wp[2 * CI], wp[3 * CI]));
+                const Split4 hi = splitn<PL>(make_float4(wp[4 * CI], wp[5 * CI], wp[6 * CI], wp[7 * CI]));
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     wsp[h][st][0][i] = lo.h[i]; wsp[h][st][0][4 + i] = hi.h[i];
                     wsp[h][st][1][i] = lo.m[i]; wsp[h][st][1][4 + i] = hi.m[i];
-                    wsp[h][st][2][i] = lo.l[i]; wsp[h][st][2][4 + i] = hi.l[i];
+                    if constexpr (PL == 3) { wsp[h][st][2][i] = lo.l[i]; wsp[h][st][2][4 + i] = hi.l[i]; }
                 }
             }
     } else {
@@ -1662,7 +1681,29 @@ __global__ __launch_bounds__(bwd_fused_threads(CO, CI, SPLIT, ONE), (CO >= 128 &
 #pragma unroll
                     for (int ni = 0; ni < TNW; ++ni) accW[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mi], fb[ni], accW[mi][ni], 0, 0, 0);
             }
-        } else         if constexpr (SPLIT) {   // dW += dZ^T * act(Z_{l-1}): one k-step of 16 positions, six plane products per tile
+        } else if constexpr (SPLIT && PL == 2) {   // [r5] two planes: h*m, h*h, m*h
+            bf16x8 fb[2][TNW], fa[TMW];
+#pragma unroll
+            for (int pl = 1; pl >= 0; --pl)
+#pragma unroll
+                for (int ni = 0; ni < TNW; ++ni) fb[pl][ni] = tr_frag_packed<GS, KSWZ>(hB[cur][pl], 0, wcol0 + ni * 32);
+#pragma unroll
+            for (int mi = 0; mi < TMW; ++mi) fa[mi] = tr_frag_packed<GS, KSWZ>(hA[cur][0], 0, wrow0 + mi * 32);
+            if constexpr ((MP_TR_FENCE >> 1) & 1) tr_fence();
+#pragma unroll
+            for (int pl = 1; pl >= 0; --pl)
+#pragma unroll
+                for (int mi = 0; mi < TMW; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < TNW; ++ni) accW[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mi], fb[pl][ni], accW[mi][ni], 0, 0, 0);
+#pragma unroll
+            for (int mi = 0; mi < TMW; ++mi) fa[mi] = tr_frag_packed<GS, KSWZ>(hA[cur][1], 0, wrow0 + mi * 32);
+            if constexpr ((MP_TR_FENCE >> 1) & 1) tr_fence();
+#pragma unroll
+            for (int mi = 0; mi < TMW; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < TNW; ++ni) accW[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mi], fb[0][ni], accW[mi][ni], 0, 0, 0);
+        } else if constexpr (SPLIT) {   // dW += dZ^T * act(Z_{l-1}): one k-step of 16 positions, six plane products per tile
             // fragments in the order they are consumed (one dZ plane live at a time): l*h, h*l, h*m, h*h, m*m, m*h
             bf16x8 fb[3][TNW], fa[TMW];
 #pragma unroll
@@ -1748,14 +1789,16 @@ __global__ __launch_bounds__(bwd_fused_threads(CO, CI, SPLIT, ONE), (CO >= 128 &
 #pragma unroll
                         for (int pl = 0; pl < NPLN; ++pl) af[(st + 1) & 1][pl] = *reinterpret_cast<const bf16x8*>(&hA[cur][pl][ao + 4 * (st + 1) * GS]);
                     }
-                    const bf16x8 ah = af[st & 1][0], am = af[st & 1][ONE ? 0 : 1], al = af[st & 1][ONE ? 0 : 2];
+                    const bf16x8 ah = af[st & 1][0], am = af[st & 1][NPLN >= 2 ? 1 : 0], al = af[st & 1][NPLN >= 3 ? 2 : 0];
 #pragma unroll
                     for (int h = 0; h < HT; ++h) {
-                        if constexpr (!ONE) cx[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, wsp[h][st][0], cx[h], 0, 0, 0);
+                        if constexpr (NPLN == 3) cx[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, wsp[h][st][0], cx[h], 0, 0, 0);
                         ax[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wsp[h][st][0], ax[h], 0, 0, 0);
-                        if constexpr (!ONE) {
+                        if constexpr (NPLN == 3) {
                             cx[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wsp[h][st][2], cx[h], 0, 0, 0);
                             cx[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, wsp[h][st][1], cx[h], 0, 0, 0);
+                        }
+                        if constexpr (NPLN >= 2) {
                             cx[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, wsp[h][st][0], cx[h], 0, 0, 0);
                             cx[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wsp[h][st][1], cx[h], 0, 0, 0);
                         }
@@ -1935,7 +1978,7 @@ __device__ unsigned long long g_roles_t[2][8];
 #define RT_MARK(i)
 #define RT_FLUSH(kind)
 #endif
-template <int MODE_DZ, int CO>
+template <int MODE_DZ, int CO, int PL = 3>      // PL: operand planes (3: h, m, l, six products; 2: h, m, three products -- split2)
 __global__ __launch_bounds__(512, 1) void bwd_roles_kernel(PosOperand DZ, PosOperand IN, int P, int p_per_block,
                                                            const float* __restrict__ W, float* __restrict__ dW,
                                                            float* __restrict__ G, BnOut partials)
@@ -1952,8 +1995,8 @@ __global__ __launch_bounds__(512, 1) void bwd_roles_kernel(PosOperand DZ, PosOpe
     static_assert(PA * KA_STEP == DBK && PB * KB_STEP == DBK && (CO == 128 || CO == 256), "staging covers the chunk");
     constexpr int NST = CO / 32;                                        // k-steps of the dX product
     constexpr int TMW = CO / 64, TNW = 2;                               // 32 x 32 dW tiles per dW wave (waves 2 x 2 over [CO x 128])
-    __shared__ __attribute__((aligned(16))) __bf16 hA[2][3][(CO / 8) * GS];
-    __shared__ __attribute__((aligned(16))) __bf16 hB[2][3][(CI / 8) * GS];
+    __shared__ __attribute__((aligned(16))) __bf16 hA[2][PL][(CO / 8) * GS];
+    __shared__ __attribute__((aligned(16))) __bf16 hB[2][PL][(CI / 8) * GS];
     __shared__ __attribute__((aligned(16))) float sZ[2][DBK * CI];
     __shared__ float red[2][CI];
     __shared__ float4 sKA[5][CO / 4];
@@ -2030,11 +2073,11 @@ __global__ __launch_bounds__(512, 1) void bwd_roles_kernel(PosOperand DZ, PosOpe
             } else {
                 dz = finish<MODE_DZ>(rs.a[ps], ka);
             }
-            const Split4 sp = split3(dz);
+            const Split4 sp = splitn<PL>(dz);
             const int o = (ca >> 3) * GS + ((ka0 + ps * KA_STEP) ^ kswz(ca >> 3)) * 8 + (ca & 7);
             *reinterpret_cast<bf16x4*>(&hA[buf][0][o]) = sp.h;
             *reinterpret_cast<bf16x4*>(&hA[buf][1][o]) = sp.m;
-            *reinterpret_cast<bf16x4*>(&hA[buf][2][o]) = sp.l;
+            if constexpr (PL == 3) *reinterpret_cast<bf16x4*>(&hA[buf][2][o]) = sp.l;
         }
     };
     auto sstore_b = [&](int buf, RSetB& rs) {
@@ -2042,11 +2085,11 @@ __global__ __launch_bounds__(512, 1) void bwd_roles_kernel(PosOperand DZ, PosOpe
         kb.s = sKB[0][cb >> 2]; kb.t = sKB[1][cb >> 2];
 #pragma unroll
         for (int ps = 0; ps < PB; ++ps) {
-            const Split4 sp = split3(finish<MODE_IN>(rs.b[ps], kb));
+            const Split4 sp = splitn<PL>(finish<MODE_IN>(rs.b[ps], kb));
             const int oh = (cb >> 3) * GS + ((kb0 + ps * KB_STEP) ^ kswz(cb >> 3)) * 8 + (cb & 7);
             *reinterpret_cast<bf16x4*>(&hB[buf][0][oh]) = sp.h;
             *reinterpret_cast<bf16x4*>(&hB[buf][1][oh]) = sp.m;
-            *reinterpret_cast<bf16x4*>(&hB[buf][2][oh]) = sp.l;
+            if constexpr (PL == 3) *reinterpret_cast<bf16x4*>(&hB[buf][2][oh]) = sp.l;
             *reinterpret_cast<float4*>(&sZ[buf][(kb0 + ps * KB_STEP) * CI + cb]) = rs.b[ps].ok ? rs.b[ps].z : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
@@ -2059,19 +2102,19 @@ __global__ __launch_bounds__(512, 1) void bwd_roles_kernel(PosOperand DZ, PosOpe
         if constexpr (MP_ROLES_PRIO == 2) __builtin_amdgcn_s_setprio(2);
         const int l15 = lane & 15, kq = lane >> 4;
         const int xcol0 = wave * 32;
-        bf16x8 wsp[2][NST][3];                         // lane (col, kq) holds W[32 st + 8 kq .. + 7][col] as (h, m, l) planes
+        bf16x8 wsp[2][NST][PL];                        // lane (col, kq) holds W[32 st + 8 kq .. + 7][col] as (h, m, l) planes
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
             for (int st = 0; st < NST; ++st) {
                 const float* wp = W + (size_t)(32 * st + 8 * kq) * CI + xcol0 + 16 * h + l15;
-                const Split4 lo = split3(make_float4(wp[0], wp[CI], wp[2 * CI], wp[3 * CI]));
-                const Split4 hi = split3(make_float4(wp[4 * CI], wp[5 * CI], wp[6 * CI], wp[7 * CI]));
+                const Split4 lo = splitn<PL>(make_float4(wp[0], wp[CI], wp[2 * CI], wp[3 * CI]));
+                const Split4 hi = splitn<PL>(make_float4(wp[4 * CI], wp[5 * CI], wp[6 * CI], wp[7 * CI]));
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     wsp[h][st][0][i] = lo.h[i]; wsp[h][st][0][4 + i] = hi.h[i];
                     wsp[h][st][1][i] = lo.m[i]; wsp[h][st][1][4 + i] = hi.m[i];
-                    wsp[h][st][2][i] = lo.l[i]; wsp[h][st][2][4 + i] = hi.l[i];
+                    if constexpr (PL == 3) { wsp[h][st][2][i] = lo.l[i]; wsp[h][st][2][4 + i] = hi.l[i]; }
                 }
             }
         float spx[2], tpx[2];
@@ -2101,22 +2144,24 @@ __global__ __launch_bounds__(512, 1) void bwd_roles_kernel(PosOperand DZ, PosOpe
 #pragma unroll
             for (int h = 0; h < 2; ++h) { ax[h] = f32x4{0.f, 0.f, 0.f, 0.f}; cx[h] = f32x4{0.f, 0.f, 0.f, 0.f}; }
             const int ao = kq * GS + (l15 ^ kswz(kq)) * 8;
-            bf16x8 af[2][3];
+            bf16x8 af[2][PL];
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) af[0][pl] = *reinterpret_cast<const bf16x8*>(&hA[cur][pl][ao]);
+            for (int pl = 0; pl < PL; ++pl) af[0][pl] = *reinterpret_cast<const bf16x8*>(&hA[cur][pl][ao]);
 #pragma unroll
             for (int st = 0; st < NST; ++st) {
                 if (st + 1 < NST) {
 #pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) af[(st + 1) & 1][pl] = *reinterpret_cast<const bf16x8*>(&hA[cur][pl][ao + 4 * (st + 1) * GS]);
+                    for (int pl = 0; pl < PL; ++pl) af[(st + 1) & 1][pl] = *reinterpret_cast<const bf16x8*>(&hA[cur][pl][ao + 4 * (st + 1) * GS]);
                 }
-                const bf16x8 ah = af[st & 1][0], am = af[st & 1][1], al = af[st & 1][2];
+                const bf16x8 ah = af[st & 1][0], am = af[st & 1][1], al = af[st & 1][PL - 1];
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
-                    cx[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, wsp[h][st][0], cx[h], 0, 0, 0);
+                    if constexpr (PL == 3) cx[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, wsp[h][st][0], cx[h], 0, 0, 0);
                     ax[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wsp[h][st][0], ax[h], 0, 0, 0);
-                    cx[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wsp[h][st][2], cx[h], 0, 0, 0);
-                    cx[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, wsp[h][st][1], cx[h], 0, 0, 0);
+                    if constexpr (PL == 3) {
+                        cx[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wsp[h][st][PL - 1], cx[h], 0, 0, 0);
+                        cx[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, wsp[h][st][1], cx[h], 0, 0, 0);
+                    }
                     cx[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, wsp[h][st][0], cx[h], 0, 0, 0);
                     cx[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wsp[h][st][1], cx[h], 0, 0, 0);
                 }
@@ -2186,12 +2231,35 @@ __global__ __launch_bounds__(512, 1) void bwd_roles_kernel(PosOperand DZ, PosOpe
             RT_MARK(5);
             if (!PD2R && kc + 1 < nchunks) gload(p0 + (kc + 1) * DBK, ra_, rb_);
             RT_MARK(4);
+            if constexpr (PL == 2) {      // [r5] two planes: h*m, h*h, m*h
+                bf16x8 fb[2][TNW], fa[TMW];
+#pragma unroll
+                for (int pl = 1; pl >= 0; --pl)
+#pragma unroll
+                    for (int ni = 0; ni < TNW; ++ni) fb[pl][ni] = tr_frag_packed<GS, true>(hB[cur][pl], 0, wcol0 + ni * 32);
+#pragma unroll
+                for (int mi = 0; mi < TMW; ++mi) fa[mi] = tr_frag_packed<GS, true>(hA[cur][0], 0, wrow0 + mi * 32);
+                if constexpr ((MP_TR_FENCE >> 2) & 1) tr_fence();
+#pragma unroll
+                for (int pl = 1; pl >= 0; --pl)
+#pragma unroll
+                    for (int mi = 0; mi < TMW; ++mi)
+#pragma unroll
+                        for (int ni = 0; ni < TNW; ++ni) accW[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mi], fb[pl][ni], accW[mi][ni], 0, 0, 0);
+#pragma unroll
+                for (int mi = 0; mi < TMW; ++mi) fa[mi] = tr_frag_packed<GS, true>(hA[cur][1], 0, wrow0 + mi * 32);
+                if constexpr ((MP_TR_FENCE >> 2) & 1) tr_fence();
+#pragma unroll
+                for (int mi = 0; mi < TMW; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < TNW; ++ni) accW[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mi], fb[0][ni], accW[mi][ni], 0, 0, 0);
+            } else {
             // fragments in the order they are consumed (one dZ plane live at a time): l*h, h*l, h*m, h*h, m*m, m*h
             bf16x8 fb[3][TNW], fa[TMW];
 #pragma unroll
             for (int ni = 0; ni < TNW; ++ni) fb[0][ni] = tr_frag_packed<GS, true>(hB[cur][0], 0, wcol0 + ni * 32);
 #pragma unroll
-            for (int mi = 0; mi < TMW; ++mi) fa[mi] = tr_frag_packed<GS, true>(hA[cur][2], 0, wrow0 + mi * 32);
+            for (int mi = 0; mi < TMW; ++mi) fa[mi] = tr_frag_packed<GS, true>(hA[cur][PL - 1], 0, wrow0 + mi * 32);
             if constexpr ((MP_TR_FENCE >> 2) & 1) tr_fence();
 #pragma unroll
             for (int mi = 0; mi < TMW; ++mi)
@@ -2219,6 +2287,7 @@ __global__ __launch_bounds__(512, 1) void bwd_roles_kernel(PosOperand DZ, PosOpe
                 for (int mi = 0; mi < TMW; ++mi)
 #pragma unroll
                     for (int ni = 0; ni < TNW; ++ni) accW[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mi], fb[pl][ni], accW[mi][ni], 0, 0, 0);
+            }
             RT_MARK(0);
             if (kc + 1 < nchunks) sstore(cur ^ 1, p0 + (kc + 1) * DBK, ra_, rb_);
             if (PD2R && kc + 3 < nchunks) gload(p0 + (kc + 3) * DBK, ra_, rb_);
@@ -2929,6 +2998,14 @@ inline bool split_enabled()
 // [r2] same-box sweep: 512 for most shapes; the 256-output kernel (512 threads, one workgroup per CU) is best with one round of 256, the
 // HBM-bound 64 -> 64 layer with 2048 small workgroups
 inline int fwd_wgs_wanted(int dflt = 512) { return dflt; }
+
+// [r5] operand planes of the fp32 BACKWARD contractions on the position-stream kernels: 2 (default: h, m -- three plane products, split2) or 3
+// (MP_BWD_PLANES=3: h, m, l -- six products, as the forward pass).  Read on every call.
+inline int bwd_planes()
+{
+    const char* e = getenv("MP_BWD_PLANES");
+    return (e && atoi(e) == 3) ? 3 : 2;
+}
 
 inline bool chunk_fwd_enabled()
 {
@@ -3745,6 +3822,7 @@ static int sa_mlp_bwd(const float* x0, int64_t P, int64_t K, int n_layers, const
     if (bf16 && rc_first && !store16) return MP_EINVAL;
     for (int l = 1; l < n_layers; ++l)
         if (!layers[l].z) return MP_EINVAL;
+    const int npl = bwd_planes();
     hipStream_t stream = mp_stream(stream_);
     // carve the workspace (same order as mp_sa_mlp_workspace_bytes)
     unsigned char* w = reinterpret_cast<unsigned char*>(workspace);
@@ -3882,6 +3960,9 @@ static int sa_mlp_bwd(const float* x0, int64_t P, int64_t K, int n_layers, const
     if (bf16)                                                                                                                 \
         MP_LAUNCH(tg, fl, by, (bwd_fused_kernel<MODE, CO_, CI_, SRC_ACT, true, true>), dim3(gx), dim3(bwd_fused_threads(CO_, CI_, true, true)), 0, stream, DZ, IN, (int)P, \
                   ppb, Ly.weight, grads[l].d_weight, Gn, partials);                                                           \
+    else if (split_enabled() && npl == 2)                                                                                     \
+        MP_LAUNCH(tg, fl, by, (bwd_fused_kernel<MODE, CO_, CI_, SRC_ACT, true, false, 2>), dim3(gx), dim3(bwd_fused_threads(CO_, CI_, true, false)), 0, stream, DZ, IN, (int)P, \
+                  ppb, Ly.weight, grads[l].d_weight, Gn, partials);                                                           \
     else if (split_enabled())                                                                                                      \
         MP_LAUNCH(tg, fl, by, (bwd_fused_kernel<MODE, CO_, CI_, SRC_ACT, true>), dim3(gx), dim3(bwd_fused_threads(CO_, CI_, true, false)), 0, stream, DZ, IN, (int)P, \
                   ppb, Ly.weight, grads[l].d_weight, Gn, partials);                                                           \
@@ -3896,11 +3977,17 @@ static int sa_mlp_bwd(const float* x0, int64_t P, int64_t K, int n_layers, const
                 else if (bf16)
                     MP_LAUNCH(tg, fl, by - eb * (double)P * Ci + 16.0 * (double)P, (bwd_fused_kernel<SRC_DZ, 128, 64, SRC_ACT_RC, true, true>), dim3(gx), dim3(256), 0, stream, DZ, IN,
                               (int)P, ppb, Ly.weight, grads[l].d_weight, Gn, partials);
+                else if (Co == 64 && split_enabled() && npl == 2)
+                    MP_LAUNCH(tg, fl, by - eb * (double)P * Ci + 16.0 * (double)P, (bwd_fused_kernel<SRC_DZ, 64, 64, SRC_ACT_RC, true, false, 2>), dim3(gx), dim3(256), 0, stream, DZ, IN,
+                              (int)P, ppb, Ly.weight, grads[l].d_weight, Gn, partials);
                 else if (Co == 64 && split_enabled())
                     MP_LAUNCH(tg, fl, by - eb * (double)P * Ci + 16.0 * (double)P, (bwd_fused_kernel<SRC_DZ, 64, 64, SRC_ACT_RC, true>), dim3(gx), dim3(256), 0, stream, DZ, IN,
                               (int)P, ppb, Ly.weight, grads[l].d_weight, Gn, partials);
                 else if (Co == 64)
                     MP_LAUNCH(tg, fl, by - eb * (double)P * Ci + 16.0 * (double)P, (bwd_fused_kernel<SRC_DZ, 64, 64, SRC_ACT_RC>), dim3(gx), dim3(256), 0, stream, DZ, IN,
+                              (int)P, ppb, Ly.weight, grads[l].d_weight, Gn, partials);
+                else if (split_enabled() && npl == 2)
+                    MP_LAUNCH(tg, fl, by - eb * (double)P * Ci + 16.0 * (double)P, (bwd_fused_kernel<SRC_DZ, 128, 64, SRC_ACT_RC, true, false, 2>), dim3(gx), dim3(256), 0, stream, DZ, IN,
                               (int)P, ppb, Ly.weight, grads[l].d_weight, Gn, partials);
                 else if (split_enabled())
                     MP_LAUNCH(tg, fl, by - eb * (double)P * Ci + 16.0 * (double)P, (bwd_fused_kernel<SRC_DZ, 128, 64, SRC_ACT_RC, true>), dim3(gx), dim3(256), 0, stream, DZ, IN,
@@ -3911,7 +3998,9 @@ static int sa_mlp_bwd(const float* x0, int64_t P, int64_t K, int n_layers, const
             } else if (!bf16 && split_enabled() && Ci == 128 && Co == 256 && (!pooled || (DZ.kshift >= 4 && ppb % 16 == 0))) {
                 // [r3] the 256-output layer: the two products on different waves (bwd_roles_kernel)
                 snprintf(tg, sizeof tg, "bwd_roles_kernel<%d, %d>", pooled ? 3 : 2, Co);
-                if (pooled) MP_LAUNCH(tg, fl, by, (bwd_roles_kernel<SRC_DZ_POOLED, 256>), dim3(gx), dim3(512), 0, stream, DZ, IN, (int)P, ppb, Ly.weight, grads[l].d_weight, Gn, partials);
+                if (pooled && npl == 2) MP_LAUNCH(tg, fl, by, (bwd_roles_kernel<SRC_DZ_POOLED, 256, 2>), dim3(gx), dim3(512), 0, stream, DZ, IN, (int)P, ppb, Ly.weight, grads[l].d_weight, Gn, partials);
+                else if (pooled) MP_LAUNCH(tg, fl, by, (bwd_roles_kernel<SRC_DZ_POOLED, 256>), dim3(gx), dim3(512), 0, stream, DZ, IN, (int)P, ppb, Ly.weight, grads[l].d_weight, Gn, partials);
+                else if (npl == 2) MP_LAUNCH(tg, fl, by, (bwd_roles_kernel<SRC_DZ, 256, 2>), dim3(gx), dim3(512), 0, stream, DZ, IN, (int)P, ppb, Ly.weight, grads[l].d_weight, Gn, partials);
                 else MP_LAUNCH(tg, fl, by, (bwd_roles_kernel<SRC_DZ, 256>), dim3(gx), dim3(512), 0, stream, DZ, IN, (int)P, ppb, Ly.weight, grads[l].d_weight, Gn, partials);
             } else if (Co == 256) {
                 if (pooled) { MP_FUSED(SRC_DZ_POOLED, 256, 128); } else { MP_FUSED(SRC_DZ, 256, 128); }

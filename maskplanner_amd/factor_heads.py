@@ -37,6 +37,22 @@ def _linear_fwd(x, weight, bias):
     return F.linear(x, weight, bias)
 
 
+def _dx_skinny(g, weight):
+    """grad_x = g W by the ordered streaming kernel (csrc/adam_lowrank.hip: linear_dx_skinny_kernel, bit-reproducible; 32 batch rows per
+    pass over W -- a larger batch takes one pass per slab of 32)."""
+    lib = _lib.load()
+    B, O = g.shape
+    I = weight.shape[1]
+    gx = torch.empty((B, I), dtype=torch.float32, device=g.device)
+    for b0 in range(0, B, 32):
+        gs = g[b0:b0 + 32]
+        n = gs.shape[0]
+        ws = torch.empty((lib.mp_linear_dx_skinny_workspace_bytes(n, O, I),), dtype=torch.uint8, device=g.device)
+        ops._run("linear_dx_skinny", g, lib.mp_linear_dx_skinny_f32, gs.data_ptr(), weight.data_ptr(), n, O, I, gx[b0:b0 + 32].data_ptr(),
+                 ws.data_ptr(), ws.numel())
+    return gx
+
+
 class _FactorLinear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, store, key):
@@ -56,17 +72,13 @@ class _FactorLinear(torch.autograd.Function):
             I = weight.shape[1]
             # the streaming kernel pays off on the wide heads (O ~ 6000-12000 rows of W); the 1024 x 1024 layers have too few
             # row slabs to fill the chip and stay on rocBLAS
-            if (g.is_cuda and B <= 32 and O >= 4096 and I % 128 == 0 and g.dtype == torch.float32 and weight.is_contiguous()
+            if (g.is_cuda and B <= 64 and O >= 4096 and I % 128 == 0 and g.dtype == torch.float32 and weight.is_contiguous()
                     and not ops.DETERMINISTIC):
                 # the stream of W through the matrix cores (csrc/linear_dx.hip; atomics between its K slices: not bit-reproducible)
                 gx = ops.zeroed_empty((B, I), torch.float32, g.device)
                 ops._run("linear_dx_mfma", g, _lib.load().mp_linear_dx_mfma_f32, g.data_ptr(), weight.data_ptr(), B, O, I, gx.data_ptr())
-            elif g.is_cuda and B <= 32 and O >= 4096 and I % 4 == 0 and g.dtype == torch.float32 and weight.is_contiguous():
-                gx = torch.empty((B, I), dtype=torch.float32, device=g.device)   # one streaming pass over W
-                lib = _lib.load()
-                ws = torch.empty((lib.mp_linear_dx_skinny_workspace_bytes(B, O, I),), dtype=torch.uint8, device=g.device)
-                ops._run("linear_dx_skinny", g, lib.mp_linear_dx_skinny_f32, g.data_ptr(), weight.data_ptr(), B, O, I,
-                         gx.data_ptr(), ws.data_ptr(), ws.numel())
+            elif g.is_cuda and B <= 64 and O >= 4096 and I % 4 == 0 and g.dtype == torch.float32 and weight.is_contiguous():
+                gx = _dx_skinny(g, weight)
             else:
                 gx = g @ weight
         gb = None
@@ -250,7 +262,7 @@ def head_blocks2(xa, xb, lin_a, bn_a, lin_b, bn_b, store, key_a, key_b, drop=Non
 
 
 def head_block_ok(x, linear, bn):
-    """The one-launch block applies: fp32 [B <= 32, I] on the GPU, contiguous fp32 parameters, a width csrc/head_linear.hip tiles, and
+    """The one-launch block applies: fp32 [B <= 64, I] on the GPU, contiguous fp32 parameters, a width csrc/head_linear.hip tiles, and
     BatchNorm statistics local to this process."""
     w = linear.weight
     sync = getattr(bn, "sync_bn", None)
@@ -378,11 +390,10 @@ class _WideLinear(torch.autograd.Function):
         lib = _lib.load()
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            gx = torch.empty((B, I), dtype=torch.float32, device=g.device)
             if ops.DETERMINISTIC:
-                ws = torch.empty((lib.mp_linear_dx_skinny_workspace_bytes(B, O, I),), dtype=torch.uint8, device=g.device)
-                ops._run("linear_dx_skinny", g, lib.mp_linear_dx_skinny_f32, g.data_ptr(), weight.data_ptr(), B, O, I, gx.data_ptr(), ws.data_ptr(), ws.numel())
+                gx = _dx_skinny(g, weight)
             else:
+                gx = torch.empty((B, I), dtype=torch.float32, device=g.device)
                 ops._run("linear_dx_mfma", g, lib.mp_linear_dx_mfma_f32, g.data_ptr(), weight.data_ptr(), B, O, I, gx.data_ptr())
         if ctx.needs_input_grad[1]:
             gw = torch.empty_like(weight)
@@ -395,7 +406,7 @@ class _WideLinear(torch.autograd.Function):
 
 def _wide_ok(x, linear):
     w = linear.weight
-    return (WIDE_LINEAR and x.is_cuda and x.dtype == torch.float32 and x.ndim == 2 and x.shape[0] <= 32 and w.shape[0] >= 4096
+    return (WIDE_LINEAR and x.is_cuda and x.dtype == torch.float32 and x.ndim == 2 and x.shape[0] <= 64 and w.shape[0] >= 4096
             and w.shape[1] % 128 == 0 and w.dtype == torch.float32 and w.is_contiguous() and torch.is_grad_enabled())
 
 

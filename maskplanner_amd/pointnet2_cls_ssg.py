@@ -248,7 +248,12 @@ class PointNet2Regressor_StrokeMasks(_SSGEncoder):
             _tick(*([self.bn1, self.bn2] + ([self.sm_bn1, self.sm_bn2] if self.pred_stroke_masks else [])))
         # [r4] the pose branch and the stroke-mask branch advance side by side: fc1 / sm_fc1 (both on the global feature) and fc2 / sm_fc2
         # are one launch each way per pair (factor_heads.head_blocks2); the statements below keep the reference's order otherwise
-        paired = (HEAD_BLOCK and self.pred_stroke_masks and head_blocks2_ok(feat, None, self.fc1, self.bn1, self.sm_fc1, self.sm_bn1)
+        # (with torch's own nn.Dropout active -- a training model without `fused_dropout`, i.e. the drop-in model inside the reference's loop --
+        # the pairs would draw their masks in the order fc1, sm_fc1, fc2, sm_fc2 where the reference draws fc1, fc2, [seg_conf x 2], sm_fc1,
+        # sm_fc2 (:309-324): that path keeps the reference's statement order, so that one torch seed gives the reference's masks)
+        torch_dropout = self.training and self.dropout.p > 0 and getattr(self, "fused_dropout", None) is None
+        paired = (HEAD_BLOCK and self.pred_stroke_masks and not torch_dropout
+                  and head_blocks2_ok(feat, None, self.fc1, self.bn1, self.sm_fc1, self.sm_bn1)
                   and self.fc2.weight.shape == self.sm_fc2.weight.shape and self.fc1.weight.shape[0] == self.sm_fc1.weight.shape[0])
         s2 = None
         if paired:

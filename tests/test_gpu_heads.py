@@ -37,7 +37,8 @@ def _rel(a, b):
 
 @pytest.mark.parametrize("train", [True, False])
 @pytest.mark.parametrize("store", [True, False])
-@pytest.mark.parametrize("B,I,O", [(32, 1024, 1024), (32, 1024, 512), (8, 128, 128), (5, 256, 200), (32, 512, 1000), (2, 2048, 48), (4, 128, 50)])
+@pytest.mark.parametrize("B,I,O", [(32, 1024, 1024), (32, 1024, 512), (8, 128, 128), (5, 256, 200), (32, 512, 1000), (2, 2048, 48), (4, 128, 50),
+                                   (64, 1024, 1024), (64, 1024, 512), (48, 256, 200), (33, 128, 50), (64, 2048, 48)])   # [r5] B > 32: four row tiles
 def test_head_block_matches_linear_batchnorm_relu(ops, train, store, B, I, O):
     if not torch.cuda.is_available():
         pytest.skip("needs an MI355X")
@@ -135,7 +136,7 @@ def test_two_linears_on_one_input(ops):
     if not torch.cuda.is_available():
         pytest.skip("needs an MI355X")
     from maskplanner_amd import factor_heads as fh
-    for B, I, O1, O2 in [(32, 1024, 11988, 11988), (7, 256, 600, 50), (32, 128, 5994, 333), (32, 512, 40, 4000)]:
+    for B, I, O1, O2 in [(32, 1024, 11988, 11988), (7, 256, 600, 50), (32, 128, 5994, 333), (32, 512, 40, 4000), (64, 1024, 11988, 11988), (37, 256, 600, 50)]:
         torch.manual_seed(O1 + O2)
         l1, l2 = torch.nn.Linear(I, O1).cuda(), torch.nn.Linear(I, O2).cuda()
         x = torch.randn(B, I, device="cuda")
@@ -165,7 +166,12 @@ def test_two_linears_second_one_dense(ops):
     if not torch.cuda.is_available():
         pytest.skip("needs an MI355X")
     from maskplanner_amd import factor_heads as fh
-    B, I, O1, O2 = 32, 1024, 5994, 6
+    for B in (32, 64):
+        _second_dense(fh, B)
+
+
+def _second_dense(fh, B):
+    I, O1, O2 = 1024, 5994, 6
     torch.manual_seed(3)
     l1, l2 = torch.nn.Linear(I, O1).cuda(), torch.nn.Linear(I, O2).cuda()
     x = torch.randn(B, I, device="cuda")
@@ -187,7 +193,7 @@ def test_two_linears_second_one_dense(ops):
 
 
 @pytest.mark.parametrize("shared", [True, False])
-@pytest.mark.parametrize("B,I,O", [(32, 1024, 1024), (6, 128, 512)])
+@pytest.mark.parametrize("B,I,O", [(32, 1024, 1024), (6, 128, 512), (64, 1024, 1024), (40, 128, 512)])
 def test_two_blocks_in_one_launch(ops, shared, B, I, O):
     """factor_heads.head_blocks2 (fc1 / sm_fc1 on one input, fc2 / sm_fc2 on two) against the two single-block calls: identical outputs
     and statistics (the same kernel code per column tile), gradients to fp32 summation order, ONE grad_x for a shared input."""
@@ -220,3 +226,40 @@ def test_two_blocks_in_one_launch(ops, shared, B, I, O):
     for k in ("a", "b"):
         assert torch.equal(st1[k][1], st2[k][1])            # dz: the same arithmetic per column
     assert torch.equal(bna.weight.grad, bna2.weight.grad) and torch.equal(bnb.bias.grad, bnb2.bias.grad)
+
+
+@pytest.mark.parametrize("seg_conf", [False, True])
+def test_dropin_heads_draw_dropout_masks_in_the_reference_order(ops, seg_conf):
+    """[r5, ADVICE r4] A training model WITHOUT `fused_dropout` (the drop-in model inside the reference's unchanged loop) applies torch's own
+    nn.Dropout: with the same torch seed its masks are the ones the reference's statements draw -- fc1, fc2, [seg_conf x 2], sm_fc1, sm_fc2
+    (models/pointnet2_cls_ssg.py:309-324) -- not the paired launches' order.  Checked against the same statements in plain torch."""
+    from maskplanner_amd.pointnet2_cls_ssg import PointNet2Regressor_StrokeMasks
+    torch.manual_seed(4)
+    m = PointNet2Regressor_StrokeMasks(outdim=12, outdim_orient=12, weight_orient=0.25, out_vectors=40, hidden_size=(256, 256), pred_stroke_masks=True,
+                                       n_stroke_masks=6, mask_confidence_scores=True, segment_confidence_scores=seg_conf).cuda().train()
+    B = 8
+    feat = torch.randn(B, 1024, device="cuda")
+    torch.manual_seed(77)
+    out, sm_out, mask_conf, sc = m.heads(feat)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    torch.manual_seed(77)
+    drop = lambda t: F.dropout(t, 0.3, True)
+    bn = lambda t, n: F.batch_norm(t, None, None, sd[n + ".weight"], sd[n + ".bias"], True, 0.1, 1e-5)
+    lin = lambda t, n: F.linear(t, sd[n + ".weight"], sd[n + ".bias"])
+    x = drop(F.relu(bn(lin(feat, "fc1"), "bn1")))
+    final = drop(F.relu(bn(lin(x, "fc2"), "bn2")))
+    x3 = lin(final, "fc3")
+    if seg_conf:
+        s = drop(F.relu(lin(feat, "seg_conf_fc1")))
+        s = drop(F.relu(lin(s, "seg_conf_fc2")))
+        want_sc = torch.sigmoid(lin(s, "seg_conf_out"))
+    s1 = drop(F.relu(bn(lin(feat, "sm_fc1"), "sm_bn1")))
+    s2 = drop(F.relu(bn(lin(s1, "sm_fc2"), "sm_bn2")))
+    want_sm = lin(s2, "sm_fc3").view(B, 6, -1)
+    want_conf = lin(s2, "mask_conf_out")
+    normals = F.normalize(torch.tanh(lin(final, "fc_normals")).view(B, -1, 3), dim=-1) * 0.25
+    want_out = torch.cat((x3.view(B, -1, 3), normals), dim=-1).view(B, 40, -1)
+    # the SAME masks: a different draw order would change a third of the activations outright
+    assert _rel(sm_out, want_sm) <= 2e-5 and _rel(mask_conf, want_conf) <= 2e-5 and _rel(out, want_out) <= 2e-5
+    if seg_conf:
+        assert _rel(sc, want_sc) <= 2e-5

@@ -1152,6 +1152,82 @@ def test_windows_shelves_at_bench_size(category, oracle):
     assert np.isfinite(losses).all() and min(losses[-10:]) < losses[0], losses[::10]
 
 
+def test_reference_batch_size_64(oracle):
+    """[r5] The reference's own batch size: `config=[maskplanner,cuboids_v2,longx_v2]` (README.md:115) merges to batch_size 64
+    (configs/maskplanner/cuboids_v2.yaml:12 over asymm_chamfer_v9.yaml:3; utils/args.py:77-94).  No fallback route: every head kernel
+    takes B = 64 (four 16-row tiles).  First 4 clouds' eval-mode forward + loss against the CPU oracle at 1e-5, then 20 replayed training steps:
+    finite, loss going down."""
+    from maskplanner_amd import _lib, loss_handler as LH
+    from maskplanner_amd.harness import TrainStep
+    from oracle import torch_ref as T
+    lib = _lib.load()
+    assert lib.mp_head_block_supported(64, 1024, 1024) == 1 and lib.mp_head_block_supported(64, 1024, 11988) == 1
+    ts = TrainStep("cuboids", B=64, N=5120, graph=True)
+    sd = {k: v.detach().cpu().clone() for k, v in ts.model.state_dict().items()}
+    b = {k: (v[:4].cpu() if torch.is_tensor(v) else [t[:4].cpu() for t in v]) for k, v in ts.batch.items()}
+    ts.model.eval()
+    full = ts.batch
+    ts.batch = {k: (v[:4].contiguous() if torch.is_tensor(v) else [t[:4].contiguous() for t in v]) for k, v in full.items()}
+    ts.point_cloud = ts.batch["point_cloud"].permute(0, 2, 1)
+    overlap, ts.overlap = ts.overlap, False
+    with torch.no_grad():
+        got = float(ts.forward_loss())
+    ts.batch, ts.overlap = full, overlap
+    ts.point_cloud = full["point_cloud"].permute(0, 2, 1)
+    o_out, o_sm, o_conf = T.strokemasks_forward(sd, b["point_cloud"], [s.numpy() for s in b["fps_start"]], train=False,
+                                                out_vectors=ts.cat.out_vectors, n_masks=ts.cat.max_n_strokes)
+    ref = float(T.asymm_v6_loss(o_out, b["traj"], o_sm, o_conf, b["stroke_ids"], b["traj_as_pc"], ts.cfg))
+    assert abs(got - ref) <= 1e-5 * max(1.0, abs(ref)), (got, ref)
+    ts.model.train()
+    params = list(ts.model.parameters())
+    losses = []
+    for s in range(20):
+        losses.append(ts.step())
+        if s % 5 == 0:
+            assert all(bool(torch.isfinite(p).all()) for p in params), s
+    assert ts._graph is not None
+    LH.check_mask_matching()
+    losses = [float(l) for l in losses]
+    assert np.isfinite(losses).all() and min(losses[-5:]) < losses[0], losses
+
+
+@pytest.mark.parametrize("graphed", [False, True])
+def test_batch_of_one_inference_vs_oracle(oracle, graphed):
+    """[r5] test_maskplanner.py:253-257, 299: the reference times `model(point_cloud)` on ONE cloud in eval mode.  B = 1, N = 5120: outputs
+    against the CPU oracle at 1e-5 (of the output scale), launched kernel by kernel and replayed from a recorded hipGraph."""
+    from maskplanner_amd import pointnet2_utils as pu
+    from maskplanner_amd import synthetic as syn
+    from maskplanner_amd.pointnet2_cls_ssg import maskplanner_model
+    from oracle import torch_ref as T
+    cat = syn.CATEGORIES["cuboids"]
+    batch = syn.make_batch(23, 1, 5120, "cuboids", "cuboid")
+    torch.manual_seed(9)
+    model = maskplanner_model(cat).cuda().eval()
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    pc = batch["point_cloud"].cuda().permute(0, 2, 1)
+    starts = [s.cuda() for s in batch["fps_start"]]
+
+    def fwd():
+        with torch.no_grad(), pu.fps_start_override(starts):
+            return model(pc)
+    if graphed:
+        for _ in range(3):
+            fwd()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            outs = fwd()
+        g.replay()
+    else:
+        outs = fwd()
+    out, sm, conf, _ = outs
+    o_out, o_sm, o_conf = T.strokemasks_forward(sd, batch["point_cloud"], [s.numpy() for s in batch["fps_start"]], train=False,
+                                                out_vectors=cat.out_vectors, n_masks=cat.max_n_strokes)
+    for got, want in ((out, o_out), (sm, o_sm), (conf, o_conf)):
+        want = want.detach()
+        assert float((got.cpu() - want).abs().max()) <= 1e-5 * max(1.0, float(want.abs().max()))
+
+
 def test_full_size_train_step_b32_vs_oracle(oracle):
     """BASELINE configs[1] exactly -- cuboids, N = 5120, B = 32, train-mode BatchNorm, dropout off -- forward, loss and
     backward against the CPU oracle.  The encoder's global feature meets the contract's 1e-5.  Behind it the heads normalise
