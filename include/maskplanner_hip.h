@@ -63,6 +63,12 @@ int mp_fps_floor_f32(const float* xyz, int64_t B, int64_t N, int64_t S, const in
  *   in every slot, as the reference's intermediate does).  K <= 1024.  N <= 13312. */
 int mp_ball_query_f32(const float* xyz, const float* new_xyz, int64_t B, int64_t N, int64_t S,
                       double radius, int64_t K, int64_t* out_idx, mp_stream_t stream);
+/* replaces: the loop over `radius_list` of PointNetSetAbstractionMsg (models/pointnet2_utils.py:255-258): n_radii (<= 3) ball queries of ONE
+ *   (cloud, query set) pair in one scan of the cloud -- one distance per pair, one membership test and one hit list per radius.
+ *   radii [n_radii], K [n_radii] on the HOST; out_idx: host array of n_radii device pointers, out_idx[r] is [B,S,K[r]] i64.  Each list equals
+ *   mp_ball_query_f32(radii[r], K[r]) bit for bit. */
+int mp_ball_query_multi_f32(const float* xyz, const float* new_xyz, int64_t B, int64_t N, int64_t S, int64_t n_radii,
+                            const double* radii, const int64_t* K, int64_t* const* out_idx, mp_stream_t stream);
 
 /* ---- square_distance -------------------------------------------------------------------------
  * replaces: models/pointnet2_utils.py:21-42 square_distance(src, dst) -> [B,S,N] f32 (expanded form) */

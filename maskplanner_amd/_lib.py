@@ -67,6 +67,7 @@ SIGNATURES = {
     "mp_fps_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp]),
     "mp_fps_floor_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp]),
     "mp_ball_query_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _dbl, _i64, _vp, _vp]),
+    "mp_ball_query_multi_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, ctypes.POINTER(_dbl), ctypes.POINTER(_i64), ctypes.POINTER(_vp), _vp]),
     "mp_square_distance_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp]),
     "mp_index_points_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),
     "mp_index_points_bwd_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _int, _vp]),

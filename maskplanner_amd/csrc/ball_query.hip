@@ -12,6 +12,8 @@
 // Arithmetic (bit-exact membership is the contract): d = ((-2*dot) + |q|^2) + |p|^2 with
 // dot = fma(qz,pz, fma(qy,py, qx*px)), norms (x*x + y*y) + z*z, test !(d > (float)(radius*radius)).
 // -2*dot is exact, so fma(-2, dot, |q|^2) rounds once exactly like the reference's separate add.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -93,6 +95,115 @@ __global__ __launch_bounds__(BQ_THREADS) void ball_query_kernel(const float* __r
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// [r5] Register-tiled scan: Q queries per wave and all radii of a multi-scale level in one pass.
+//
+// ball_query_kernel above reads every point from LDS once PER QUERY (three ds_read_b32 + the point's norm + the test: ~13 VALU and three LDS
+// reads per pair -- ~1 GB of LDS reads per call at one query per wave).  Here a lane loads its point and forms |p|^2 ONCE per step and tests
+// it against the wave's Q queries (six VALU per pair: the reference's expanded form, unchanged), and against every radius of a
+// multi-scale level (models/pointnet2_utils.py:255-258 loops `query_ball_point` over the radius list on the same query / cloud pair: one
+// distance, NR compares).  Hits go straight to their row of the output (rank = hits so far + popcount prefix: index order), the padding
+// (`first hit`, pointnet2_utils.py:106-108) behind the scan: no LDS hit buffers, no wave barriers.  A wave's scan ends when every one of
+// its Q x NR lists is full.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int BQM_MAXR = 3;
+struct BqRadii {
+    float r2[BQM_MAXR];
+    int K[BQM_MAXR];
+    int64_t* out[BQM_MAXR];
+};
+
+template <int Q, int NR, int WAVES>
+__global__ __launch_bounds__(WAVES * MP_WAVE) void ball_query_multi_kernel(const float* __restrict__ xyz, const float* __restrict__ new_xyz,
+                                                                           int N, int S, BqRadii rr, int qpb)
+{
+    constexpr int T = WAVES * MP_WAVE, U = 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int npad = (N + 127) & ~127;
+    float* sx = reinterpret_cast<float*>(smem_raw);
+    float* sy = sx + npad;
+    float* sz = sy + npad;
+    const int b = blockIdx.y;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const float* p = xyz + (size_t)b * N * 3;
+    for (int i = tid; i < 3 * N; i += T) {
+        const float v = p[i];
+        const int pt = i / 3;
+        const int c = i - 3 * pt;
+        (c == 0 ? sx : (c == 1 ? sy : sz))[pt] = v;
+    }
+    for (int i = N + tid; i < npad; i += T) { sx[i] = 3.0e18f; sy[i] = 3.0e18f; sz[i] = 3.0e18f; }   // (also masked by i < N)
+    __syncthreads();
+
+    const int q0 = blockIdx.x * qpb;
+    const int q1 = min(S, q0 + qpb);
+    for (int qb = q0 + wave * Q; qb < q1; qb += WAVES * Q) {
+        float qx[Q], qy[Q], qz[Q], qn[Q];
+        int cnt[Q][NR], first[Q][NR];
+#pragma unroll
+        for (int j = 0; j < Q; ++j) {
+            const int q = min(qb + j, q1 - 1);       // (a ragged last tile repeats its last query; nothing is written for the repeats)
+            const float* qp = new_xyz + ((size_t)b * S + q) * 3;
+            qx[j] = qp[0]; qy[j] = qp[1]; qz[j] = qp[2];
+            qn[j] = norm3(qx[j], qy[j], qz[j]);
+#pragma unroll
+            for (int r = 0; r < NR; ++r) { cnt[j][r] = (qb + j < q1) ? 0 : rr.K[r]; first[j][r] = N; }
+        }
+        for (int base = 0; base < N; base += 64 * U) {
+            unsigned long long m[U][Q][NR];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i = base + u * 64 + lane;       // < npad
+                const float x = sx[i], y = sy[i], z = sz[i];
+                const float pn = norm3(x, y, z);
+                const bool inb = i < N;
+#pragma unroll
+                for (int j = 0; j < Q; ++j) {
+                    const float dot = __builtin_fmaf(qz[j], z, __builtin_fmaf(qy[j], y, qx[j] * x));
+                    const float d = ((-2.0f * dot) + qn[j]) + pn;
+#pragma unroll
+                    for (int r = 0; r < NR; ++r) m[u][j][r] = __ballot(inb && !(d > rr.r2[r]));
+                }
+            }
+            bool open = false;
+#pragma unroll
+            for (int j = 0; j < Q; ++j)
+#pragma unroll
+                for (int r = 0; r < NR; ++r) {
+                    const int K = rr.K[r];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const unsigned long long mm = m[u][j][r];
+                        if (mm != 0ull && cnt[j][r] < K) {
+                            const int rank = cnt[j][r] + mp::prefix_popc(mm);
+                            const int i = base + u * 64 + lane;
+                            if (((mm >> lane) & 1ull) && rank < K) rr.out[r][((size_t)b * S + (qb + j)) * K + rank] = (int64_t)i;
+                            if (cnt[j][r] == 0) first[j][r] = base + u * 64 + (int)__builtin_ctzll(mm);
+                            cnt[j][r] += __popcll(mm);
+                        }
+                    }
+                    open = open || cnt[j][r] < K;
+                }
+            if (!open) break;
+        }
+        // padding: the slots behind the hits repeat the first hit (N when the ball is empty)
+#pragma unroll
+        for (int j = 0; j < Q; ++j) {
+            if (qb + j >= q1) continue;
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                const int K = rr.K[r];
+                const int c = min(cnt[j][r], K);
+                int64_t* o = rr.out[r] + ((size_t)b * S + (qb + j)) * K;
+                for (int k = c + lane; k < K; k += 64) o[k] = (int64_t)first[j][r];
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void square_distance_kernel(const float* __restrict__ src,
                                                               const float* __restrict__ dst, int S, int N,
                                                               float* __restrict__ out)
@@ -111,6 +222,56 @@ __global__ __launch_bounds__(256) void square_distance_kernel(const float* __res
 
 }  // namespace
 
+// [r5] n_radii ball queries of ONE (cloud, query) pair in one scan (PointNetSetAbstractionMsg, models/pointnet2_utils.py:255-258);
+// out_idx[r]: [B, S, K[r]].  n_radii = 1 is mp_ball_query_f32.
+template <int Q, int NR, int WAVES>
+static int launch_bq_multi(const float* xyz, const float* new_xyz, int64_t B, int64_t N, int64_t S, const BqRadii& rr, hipStream_t stream)
+{
+    const int npad = ((int)N + 127) & ~127;
+    const size_t smem = (size_t)3 * npad * sizeof(float);
+    if (smem > 160 * 1024) return MP_EUNSUPPORTED;
+    // queries per block: whole wave tiles, enough blocks to cover the chip a few times
+    int64_t qpb = (B * S + 767) / 768;
+    qpb = ((qpb + WAVES * Q - 1) / (WAVES * Q)) * (WAVES * Q);
+    const int chunks = (int)((S + qpb - 1) / qpb);
+    auto kern = ball_query_multi_kernel<Q, NR, WAVES>;
+    static mp::DynLds lds;
+    if (!lds.ensure(reinterpret_cast<const void*>(kern), smem)) return MP_ELAUNCH;
+    double wr = 0.0;
+    for (int r = 0; r < NR; ++r) wr += (double)rr.K[r];
+    MP_LAUNCH("ball_query_kernel", 8.0 * B * (double)S * N, (double)B * (N * 12.0 + S * 12.0 + S * wr * 8.0), kern, dim3(chunks, (unsigned)B),
+              dim3(WAVES * MP_WAVE), smem, stream, xyz, new_xyz, (int)N, (int)S, rr, (int)qpb);
+    MP_CHECK_LAUNCH();
+    return MP_OK;
+}
+
+extern "C" int mp_ball_query_multi_f32(const float* xyz, const float* new_xyz, int64_t B, int64_t N, int64_t S, int64_t n_radii,
+                                       const double* radii, const int64_t* K, int64_t* const* out_idx, mp_stream_t stream_)
+{
+    if (B < 0 || N <= 0 || S < 0 || n_radii < 1 || !radii || !K || !out_idx) return MP_EINVAL;
+    if (n_radii > BQM_MAXR) return MP_EUNSUPPORTED;
+    BqRadii rr{};
+    for (int r = 0; r < (int)n_radii; ++r) {
+        if (K[r] <= 0 || !(radii[r] >= 0.0)) return MP_EINVAL;
+        if (K[r] > 1024) return MP_EUNSUPPORTED;
+        if ((B > 0 && S > 0) && !out_idx[r]) return MP_EINVAL;
+        rr.r2[r] = (float)(radii[r] * radii[r]);      // squared in double, then cast: pointnet2_utils.py:104
+        rr.K[r] = (int)K[r];
+        rr.out[r] = out_idx[r];
+    }
+    if (B == 0 || S == 0) return MP_OK;
+    if (!xyz || !new_xyz) return MP_EINVAL;
+    if (N > 13312 || B > 65535) return MP_EUNSUPPORTED;
+    hipStream_t stream = mp_stream(stream_);
+    // small clouds (the second level: 512 points, 128 queries): fewer queries per wave, so that the grid still fills the chip
+    const bool small = B * S < 8192;
+    switch ((int)n_radii) {
+        case 1: return small ? launch_bq_multi<2, 1, 8>(xyz, new_xyz, B, N, S, rr, stream) : launch_bq_multi<4, 1, 8>(xyz, new_xyz, B, N, S, rr, stream);
+        case 2: return small ? launch_bq_multi<2, 2, 8>(xyz, new_xyz, B, N, S, rr, stream) : launch_bq_multi<4, 2, 8>(xyz, new_xyz, B, N, S, rr, stream);
+        default: return small ? launch_bq_multi<2, 3, 8>(xyz, new_xyz, B, N, S, rr, stream) : launch_bq_multi<4, 3, 8>(xyz, new_xyz, B, N, S, rr, stream);
+    }
+}
+
 extern "C" int mp_ball_query_f32(const float* xyz, const float* new_xyz, int64_t B, int64_t N, int64_t S,
                                  double radius, int64_t K, int64_t* out_idx, mp_stream_t stream_)
 {
@@ -118,6 +279,13 @@ extern "C" int mp_ball_query_f32(const float* xyz, const float* new_xyz, int64_t
     if (B == 0 || S == 0) return MP_OK;
     if (!xyz || !new_xyz || !out_idx) return MP_EINVAL;
     if (N > 13312 || K > 1024 || B > 65535) return MP_EUNSUPPORTED;
+    {   // [r5] the register-tiled scan (MP_BQ_LEGACY=1: the one-query-per-wave kernel below, for A/B timing)
+        const char* e = getenv("MP_BQ_LEGACY");
+        if (!(e && atoi(e) == 1)) {
+            int64_t* outs[1] = {out_idx};
+            return mp_ball_query_multi_f32(xyz, new_xyz, B, N, S, 1, &radius, &K, outs, stream_);
+        }
+    }
     const int npad = ((int)N + 255) & ~255;
     const size_t smem = (size_t)3 * npad * sizeof(float) + (size_t)BQ_WAVES * K * sizeof(int);
     if (smem > 160 * 1024) return MP_EUNSUPPORTED;

@@ -686,8 +686,10 @@ class TrainStep:
                 ops.fps(xyz, m.npoint, start, out=(fps_idx, new_xyz))
             if phase == "head":
                 return
-            for r, K, idx in zip(radii, Ks, idxs):
-                ops.ball_query(r, K, xyz, new_xyz, out=idx)
+            if len(radii) > 1:      # [r5] a multi-scale level: every radius in one scan of the cloud
+                ops.ball_query_multi(radii, Ks, xyz, new_xyz, out=idxs)
+            else:
+                ops.ball_query(radii[0], Ks[0], xyz, new_xyz, out=idxs[0])
             xyz = new_xyz
 
     # Pipelined sampling, the protocol (the same for eager and replayed steps):

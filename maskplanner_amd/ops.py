@@ -199,6 +199,33 @@ def ball_query(radius, nsample, xyz, new_xyz, out=None):
     return idx
 
 
+def ball_query_multi(radii, nsamples, xyz, new_xyz, out=None):
+    """The radius loop of PointNetSetAbstractionMsg (models/pointnet2_utils.py:255-258: `query_ball_point(radius, K, xyz, new_xyz)` per scale)
+    as ONE scan of the cloud (csrc/ball_query.hip: ball_query_multi_kernel): [i64 [B,S,K_r] per radius], each equal to ball_query(r, K_r)."""
+    _need_hip(xyz, new_xyz)
+    xyz, new_xyz = _f32(xyz), _f32(new_xyz)
+    B, N, _ = xyz.shape
+    S = new_xyz.shape[1]
+    n = len(radii)
+    if n != len(nsamples) or n < 1:
+        raise ValueError("ball_query_multi: one group size per radius")
+    if n > 3:       # (the kernel carries three lists per query)
+        return [ball_query(r, k, xyz, new_xyz, out=None if out is None else out[i]) for i, (r, k) in enumerate(zip(radii, nsamples))]
+    idxs = []
+    for i, k in enumerate(nsamples):
+        if out is not None:
+            _check_out(out[i], (B, S, k), torch.int64, xyz)
+            idxs.append(out[i])
+        else:
+            idxs.append(torch.empty((B, S, k), dtype=torch.int64, device=xyz.device))
+    import ctypes
+    rr = (ctypes.c_double * n)(*[float(r) for r in radii])
+    kk = (ctypes.c_int64 * n)(*[int(k) for k in nsamples])
+    oo = (ctypes.c_void_p * n)(*[t.data_ptr() for t in idxs])
+    _run("ball_query_multi", xyz, _lib.load().mp_ball_query_multi_f32, _p(xyz), _p(new_xyz), B, N, S, n, rr, kk, oo)
+    return idxs
+
+
 @torch.no_grad()
 def square_distance(src, dst):
     """square_distance (models/pointnet2_utils.py:21-42), expanded form.  src [B,S,3], dst [B,N,3] -> [B,S,N]."""

@@ -304,7 +304,8 @@ class PointNetSetAbstractionMsg(nn.Module):
             _, new_xyz, idxs = plan
         else:
             _, new_xyz = ops.fps(xyz, self.npoint, _draw_fps_start(B, N, xyz.device), return_xyz=True)
-            idxs = None
+            # (:255-258 loops query_ball_point over the radii on the same query / cloud pair: one scan, one distance per pair)
+            idxs = ops.ball_query_multi(self.radius_list, self.nsample_list, xyz, new_xyz)
         outs = []
         for si, (radius, K, convs, bns) in enumerate(zip(self.radius_list, self.nsample_list, self.conv_blocks, self.bn_blocks)):
             idx = idxs[si] if idxs is not None else ops.ball_query(radius, K, xyz, new_xyz)

@@ -91,6 +91,31 @@ def test_ball_query_vs_oracle(oracle, ops, B, N, S, r, K, dist):
     assert np.array_equal(got.cpu().numpy(), want)
 
 
+@pytest.mark.parametrize("B,N,S,radii,Ks,dist", [(4, 10240, 512, [0.1, 0.2, 0.4], [16, 32, 128], "cuboid"), (4, 10240, 512, [0.1, 0.2, 0.4], [16, 32, 128], "ucube"),
+                                                 (32, 512, 128, [0.2, 0.4, 0.8], [32, 64, 128], "cuboid"), (3, 777, 101, [0.35, 0.1], [48, 5], "ucube"),
+                                                 (2, 300, 7, [5.0, 1e-4, 0.3], [400, 8, 300], "ucube"), (5, 5120, 510, [0.2], [32], "cuboid")])
+def test_ball_query_all_radii_in_one_scan(oracle, ops, B, N, S, radii, Ks, dist):
+    """[r5] PointNetSetAbstractionMsg's radius loop (models/pointnet2_utils.py:255-258) as one scan of the cloud: every list equals the
+    single-radius call (the one-query-per-wave kernel, MP_BQ_LEGACY=1) and the oracle, bit for bit; ragged tiles (S % 4 != 0), full and
+    empty balls, K beyond the cloud included."""
+    import os
+    from maskplanner_amd import synthetic as syn
+    rng = np.random.default_rng(N + S + sum(Ks))
+    xyz = syn.point_cloud(rng, B, N, dist)
+    fidx = oracle.fps(xyz, S, rng.integers(0, N, size=B))
+    new_xyz = oracle.index_points(xyz, fidx)
+    got = ops.ball_query_multi(radii, Ks, dev(xyz), dev(new_xyz))
+    os.environ["MP_BQ_LEGACY"] = "1"
+    try:
+        legacy = [ops.ball_query(r, K, dev(xyz), dev(new_xyz)) for r, K in zip(radii, Ks)]
+    finally:
+        del os.environ["MP_BQ_LEGACY"]
+    for r, K, g, l in zip(radii, Ks, got, legacy):
+        assert torch.equal(g, l), (r, K)
+        if B * S * N <= 4 * 512 * 10240:
+            assert np.array_equal(g.cpu().numpy(), oracle.ball_query(r, K, xyz, new_xyz)), (r, K)
+
+
 def test_ball_query_no_hit_returns_N(oracle, ops):
     xyz = np.random.default_rng(0).uniform(-1, 1, size=(1, 200, 3)).astype(np.float32)
     q = np.full((1, 3, 3), 50.0, np.float32)
