@@ -185,6 +185,25 @@ def inference_b1(cat, N, dev, reps=50):
     return out
 
 
+def dp_overhead_leg():
+    """[r5] The N > 1 launch path against the N = 1 path on this one GPU (tools/dp_overhead.py, a child process with one forced RCCL rank):
+    what a future 1 -> 8 comparison must subtract before it reads the rest as communication."""
+    import socket
+    for _attempt in range(2):      # (RCCL's start-up next to a process that holds the GPU fails now and then on shared boxes: one retry)
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        try:
+            out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "dp_overhead.py"), str(port), "30"], capture_output=True, text=True,
+                                 timeout=300, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+        except subprocess.TimeoutExpired:
+            continue
+        lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+        if out.returncode == 0 and lines:
+            return json.loads(lines[-1])
+    return {"error": "tools/dp_overhead.py did not finish", "stderr": (out.stderr[-300:] if "out" in dir() else "")}
+
+
 def self_launch(args):
     """`python bench.py --gpus N` typed as is: start one worker per GPU with torch.distributed.run.  Nothing in this process
     has touched the GPU yet (device_count() does not initialise it); the workers inherit HSA_ENABLE_IPC_MODE_LEGACY=0, which
@@ -535,6 +554,7 @@ def main():
                 args.batch = 32
             torch.cuda.empty_cache()
             line["inference_b1"] = inference_b1(cat, args.points, dev)
+            line["dp_overhead"] = dp_overhead_leg()
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cat, args.points, 1235)
         print(json.dumps(line))

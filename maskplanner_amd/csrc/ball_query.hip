@@ -103,9 +103,10 @@ __global__ __launch_bounds__(BQ_THREADS) void ball_query_kernel(const float* __r
 // reads per pair -- ~1 GB of LDS reads per call at one query per wave).  Here a lane loads its point and forms |p|^2 ONCE per step and tests
 // it against the wave's Q queries (six VALU per pair: the reference's expanded form, unchanged), and against every radius of a
 // multi-scale level (models/pointnet2_utils.py:255-258 loops `query_ball_point` over the radius list on the same query / cloud pair: one
-// distance, NR compares).  Hits go straight to their row of the output (rank = hits so far + popcount prefix: index order), the padding
-// (`first hit`, pointnet2_utils.py:106-108) behind the scan: no LDS hit buffers, no wave barriers.  A wave's scan ends when every one of
-// its Q x NR lists is full.
+// distance, NR compares).  Hits are buffered per wave in LDS (rank = hits so far + popcount prefix: index order) and leave as coalesced
+// rows with their padding (`first hit`, pointnet2_utils.py:106-108).  (First version: hit lanes stored straight to the output rows -- a
+// partially active scattered 8-byte store costs the address unit a full pass per instruction: N = 10240, three radii: 297 us against 38 us
+// of arithmetic.)  A wave's scan ends when every one of its Q x NR lists is full.
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int BQM_MAXR = 3;
 struct BqRadii {
@@ -124,16 +125,45 @@ __global__ __launch_bounds__(WAVES * MP_WAVE) void ball_query_multi_kernel(const
     float* sx = reinterpret_cast<float*>(smem_raw);
     float* sy = sx + npad;
     float* sz = sy + npad;
+    int ksum = 0, koff[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) { koff[r] = ksum; ksum += rr.K[r]; }
     const int b = blockIdx.y;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int* hits = reinterpret_cast<int*>(sz + npad) + wave * Q * ksum;      // [WAVES][Q][sum K]
     const float* p = xyz + (size_t)b * N * 3;
-    for (int i = tid; i < 3 * N; i += T) {
-        const float v = p[i];
-        const int pt = i / 3;
-        const int c = i - 3 * pt;
-        (c == 0 ? sx : (c == 1 ? sy : sz))[pt] = v;
+    // staging: the [N, 3] rows as 16-byte pieces, eight requests per thread in flight (a 4-byte load per trip of a dependent loop cost one
+    // memory latency per trip: ~25 us of a 41 us launch at N = 5120), turned into the SoA image with one ds_write_b32 per float
+    if (((3 * N) & 3) == 0) {
+        const float4* p4 = reinterpret_cast<const float4*>(p);
+        const int n4 = (3 * N) >> 2;
+        for (int i0 = tid; i0 < n4; i0 += 8 * T) {
+            float4 v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = p4[min(i0 + k * T, n4 - 1)];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int i4 = i0 + k * T;
+                if (i4 < n4) {
+                    const float e[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+                    const int f0 = 4 * i4, pt0 = f0 / 3, c0 = f0 - 3 * pt0;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const int c = c0 + t, pt = pt0 + (c >= 3 ? 1 : 0) + (c >= 6 ? 1 : 0), cc = c - (c >= 3 ? 3 : 0) - (c >= 6 ? 3 : 0);
+                        (cc == 0 ? sx : (cc == 1 ? sy : sz))[pt] = e[t];
+                    }
+                }
+            }
+        }
+    } else {
+        for (int i = tid; i < 3 * N; i += T) {
+            const float v = p[i];
+            const int pt = i / 3;
+            const int c = i - 3 * pt;
+            (c == 0 ? sx : (c == 1 ? sy : sz))[pt] = v;
+        }
     }
     for (int i = N + tid; i < npad; i += T) { sx[i] = 3.0e18f; sy[i] = 3.0e18f; sz[i] = 3.0e18f; }   // (also masked by i < N)
     __syncthreads();
@@ -142,7 +172,7 @@ __global__ __launch_bounds__(WAVES * MP_WAVE) void ball_query_multi_kernel(const
     const int q1 = min(S, q0 + qpb);
     for (int qb = q0 + wave * Q; qb < q1; qb += WAVES * Q) {
         float qx[Q], qy[Q], qz[Q], qn[Q];
-        int cnt[Q][NR], first[Q][NR];
+        int cnt[Q][NR];
 #pragma unroll
         for (int j = 0; j < Q; ++j) {
             const int q = min(qb + j, q1 - 1);       // (a ragged last tile repeats its last query; nothing is written for the repeats)
@@ -150,10 +180,12 @@ __global__ __launch_bounds__(WAVES * MP_WAVE) void ball_query_multi_kernel(const
             qx[j] = qp[0]; qy[j] = qp[1]; qz[j] = qp[2];
             qn[j] = norm3(qx[j], qy[j], qz[j]);
 #pragma unroll
-            for (int r = 0; r < NR; ++r) { cnt[j][r] = (qb + j < q1) ? 0 : rr.K[r]; first[j][r] = N; }
+            for (int r = 0; r < NR; ++r) cnt[j][r] = (qb + j < q1) ? 0 : rr.K[r];
         }
+        // [second version] every mask is consumed where it is formed (24 live 64-bit masks + their counters spilled the scalar registers:
+        // ~1 000 scalar instructions per 128 points).  The radii are ASCENDING (host): a (point group, query) pair without a hit in the
+        // largest ball has none in the others -- one scalar test skips its NR lists.
         for (int base = 0; base < N; base += 64 * U) {
-            unsigned long long m[U][Q][NR];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int i = base + u * 64 + lane;       // < npad
@@ -164,32 +196,31 @@ __global__ __launch_bounds__(WAVES * MP_WAVE) void ball_query_multi_kernel(const
                 for (int j = 0; j < Q; ++j) {
                     const float dot = __builtin_fmaf(qz[j], z, __builtin_fmaf(qy[j], y, qx[j] * x));
                     const float d = ((-2.0f * dot) + qn[j]) + pn;
+                    const unsigned long long mbig = __ballot(inb && !(d > rr.r2[NR - 1]));
+                    if (mbig == 0ull) continue;
 #pragma unroll
-                    for (int r = 0; r < NR; ++r) m[u][j][r] = __ballot(inb && !(d > rr.r2[r]));
+                    for (int r = 0; r < NR; ++r) {
+                        const unsigned long long mm = (r == NR - 1) ? mbig : __ballot(inb && !(d > rr.r2[r]));
+                        const int K = rr.K[r];
+                        if (mm != 0ull && cnt[j][r] < K) {
+                            const int rank = cnt[j][r] + mp::prefix_popc(mm);
+                            if (((mm >> lane) & 1ull) && rank < K) hits[j * ksum + koff[r] + rank] = i;
+                            cnt[j][r] += __popcll(mm);
+                        }
+                    }
                 }
             }
             bool open = false;
 #pragma unroll
             for (int j = 0; j < Q; ++j)
 #pragma unroll
-                for (int r = 0; r < NR; ++r) {
-                    const int K = rr.K[r];
-#pragma unroll
-                    for (int u = 0; u < U; ++u) {
-                        const unsigned long long mm = m[u][j][r];
-                        if (mm != 0ull && cnt[j][r] < K) {
-                            const int rank = cnt[j][r] + mp::prefix_popc(mm);
-                            const int i = base + u * 64 + lane;
-                            if (((mm >> lane) & 1ull) && rank < K) rr.out[r][((size_t)b * S + (qb + j)) * K + rank] = (int64_t)i;
-                            if (cnt[j][r] == 0) first[j][r] = base + u * 64 + (int)__builtin_ctzll(mm);
-                            cnt[j][r] += __popcll(mm);
-                        }
-                    }
-                    open = open || cnt[j][r] < K;
-                }
+                for (int r = 0; r < NR; ++r) open = open || cnt[j][r] < rr.K[r];
             if (!open) break;
         }
-        // padding: the slots behind the hits repeat the first hit (N when the ball is empty)
+        // the lists leave as coalesced rows; the slots behind the hits repeat the first hit (N when the ball is empty)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
         for (int j = 0; j < Q; ++j) {
             if (qb + j >= q1) continue;
@@ -198,9 +229,12 @@ __global__ __launch_bounds__(WAVES * MP_WAVE) void ball_query_multi_kernel(const
                 const int K = rr.K[r];
                 const int c = min(cnt[j][r], K);
                 int64_t* o = rr.out[r] + ((size_t)b * S + (qb + j)) * K;
-                for (int k = c + lane; k < K; k += 64) o[k] = (int64_t)first[j][r];
+                const int first = c > 0 ? hits[j * ksum + koff[r]] : N;
+                for (int k = lane; k < K; k += 64) o[k] = (int64_t)(k < c ? hits[j * ksum + koff[r] + k] : first);
             }
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -228,7 +262,9 @@ template <int Q, int NR, int WAVES>
 static int launch_bq_multi(const float* xyz, const float* new_xyz, int64_t B, int64_t N, int64_t S, const BqRadii& rr, hipStream_t stream)
 {
     const int npad = ((int)N + 127) & ~127;
-    const size_t smem = (size_t)3 * npad * sizeof(float);
+    size_t ksum = 0;
+    for (int r = 0; r < NR; ++r) ksum += (size_t)rr.K[r];
+    const size_t smem = (size_t)3 * npad * sizeof(float) + (size_t)WAVES * Q * ksum * sizeof(int);
     if (smem > 160 * 1024) return MP_EUNSUPPORTED;
     // queries per block: whole wave tiles, enough blocks to cover the chip a few times
     int64_t qpb = (B * S + 767) / 768;
@@ -251,13 +287,22 @@ extern "C" int mp_ball_query_multi_f32(const float* xyz, const float* new_xyz, i
     if (B < 0 || N <= 0 || S < 0 || n_radii < 1 || !radii || !K || !out_idx) return MP_EINVAL;
     if (n_radii > BQM_MAXR) return MP_EUNSUPPORTED;
     BqRadii rr{};
+    int order[BQM_MAXR] = {0, 1, 2};
     for (int r = 0; r < (int)n_radii; ++r) {
         if (K[r] <= 0 || !(radii[r] >= 0.0)) return MP_EINVAL;
         if (K[r] > 1024) return MP_EUNSUPPORTED;
         if ((B > 0 && S > 0) && !out_idx[r]) return MP_EINVAL;
-        rr.r2[r] = (float)(radii[r] * radii[r]);      // squared in double, then cast: pointnet2_utils.py:104
-        rr.K[r] = (int)K[r];
-        rr.out[r] = out_idx[r];
+    }
+    // the kernel wants the radii ascending (the largest ball's mask decides whether a point group is looked at all); each list still goes
+    // to the caller's buffer for its radius
+    for (int a = 0; a < (int)n_radii; ++a)
+        for (int c = a + 1; c < (int)n_radii; ++c)
+            if (radii[order[c]] < radii[order[a]]) { const int t = order[a]; order[a] = order[c]; order[c] = t; }
+    for (int r = 0; r < (int)n_radii; ++r) {
+        const int o = order[r];
+        rr.r2[r] = (float)(radii[o] * radii[o]);      // squared in double, then cast: pointnet2_utils.py:104
+        rr.K[r] = (int)K[o];
+        rr.out[r] = out_idx[o];
     }
     if (B == 0 || S == 0) return MP_OK;
     if (!xyz || !new_xyz) return MP_EINVAL;

@@ -14,6 +14,23 @@ from .loss_handler import LossHandler, maskplanner_loss_config
 from .pointnet2_cls_ssg import maskplanner_model
 
 
+def _capture_kw():
+    """How the step is recorded while a process group is alive.  [r5] RCCL's watchdog thread polls the completion events of the
+    collectives issued so far (hipEventQuery, every 100 ms, until it has reaped them); under the default `global` capture mode such a call
+    from ANY thread while this thread records is an error -- it invalidates the capture AND raises inside the watchdog, which terminates the
+    process (seen with one forced RCCL rank, tools/dp_overhead.py: "operation not permitted when stream is capturing").  The eager steps in
+    front of the recording have issued collectives, so: record in `thread_local` mode (only this thread's calls are checked; it is the only
+    one that enqueues work) after the device has drained and the watchdog has had time to reap what completed."""
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        return {}
+    torch.cuda.synchronize()
+    if dist.get_backend() == "nccl":
+        import time
+        time.sleep(0.25)
+    return {"capture_error_mode": "thread_local"}
+
+
 def _even(n):
     """int64 units rounded up to a 16-byte multiple."""
     return (int(n) + 1) // 2 * 2
@@ -58,7 +75,10 @@ class TrainStep:
         # [r4] SyncBN no longer rules out replay: its per-layer all-reduces (launched through the library's hook, sync_bn.Exchange) are
         # recorded into the graphs like any other node when the backend is RCCL ("nccl": captures; measured with one forced rank:
         # 3.42 -> 2.35 ms per step).  A backend that cannot be captured (gloo: host-side collectives) keeps eager launches.
-        sync_graph = self.sync_bn and torch.distributed.is_initialized() and torch.distributed.get_backend() == "nccl"
+        # [r5, ADVICE r4] opt-in (MASKPLANNER_SYNCBN_GRAPH=1) until a run with >= 2 real RCCL ranks has confirmed loss parity with the eager SyncBN
+        # step: the only RCCL evidence so far is one forced rank, and a capture-time failure on ONE rank of many is not covered by the launch-mode vote
+        sync_graph = (self.sync_bn and torch.distributed.is_initialized() and torch.distributed.get_backend() == "nccl"
+                      and os.environ.get("MASKPLANNER_SYNCBN_GRAPH", "0") == "1")
         self.use_graph = bool(graph) and fused and (not dp.exchanging() or self.dp_graph) and not prefetch_sampling and (not self.sync_bn or sync_graph)
         self._graph, self._graph_loss, self._eager_steps, self._side = None, None, 0, None
         # Pipelined first-level sampling (see _eager_step): FPS can occupy only one workgroup per cloud -- 32 of 256 CUs for
@@ -277,7 +297,7 @@ class TrainStep:
         try:
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, **_capture_kw()):
                 loss = self._eager_step(hand_over=False)
             self._graph, self._graph_loss = g, loss
             g.replay()
@@ -301,7 +321,8 @@ class TrainStep:
                 self._reset_factor_store()
             from . import sa_mlp
             ticks_prev, sa_mlp.DEFERRED_TICKS = sa_mlp.DEFERRED_TICKS, []      # every BatchNorm counter of the step: one launch, in B
-            with torch.cuda.graph(ga, stream=cap):
+            kw = _capture_kw()
+            with torch.cuda.graph(ga, stream=cap, **kw):
                 self._supply_plan()
                 self.reducer.zero_grad()
                 feat = self._encode()
@@ -319,7 +340,7 @@ class TrainStep:
             # optimizer's ~1 GB costs the chain the same wherever it runs and the extra graph boundary costs ~60 us ([r2] 2.83 vs 2.76 ms).
             split_bwd = bool(persist) and os.environ.get("MASKPLANNER_SPLIT_BACKWARD", "1" if dp.exchanging() else "0") != "0"
             gb2 = torch.cuda.CUDAGraph() if split_bwd else None
-            with torch.cuda.graph(gb, pool=ga.pool(), stream=cap):
+            with torch.cuda.graph(gb, pool=ga.pool(), stream=cap, **kw):
                 if split_bwd:
                     leaf = feat.detach().requires_grad_(True)
                     loss = self._heads_loss(leaf)
@@ -352,7 +373,7 @@ class TrainStep:
                 if self.overlap and not split_bwd:
                     self._hand_over_copies()
             if split_bwd:
-                with torch.cuda.graph(gb2, pool=ga.pool(), stream=cap):
+                with torch.cuda.graph(gb2, pool=ga.pool(), stream=cap, **kw):
                     feat.backward(leaf.grad)
                     self._disarm()
                     if not self.dp_graph:

@@ -166,3 +166,23 @@ def test_bench_runs_with_two_ranks():
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["steps"] == 6 and line["value"] > 0 and np.isfinite(line["final_loss"])
     assert line["config"]["global_batch"] == 16
+
+
+def test_bench_control_flow_with_eight_ranks():
+    """[r5] `bench.py --gpus 8` exactly as the driver launches it (torch.distributed.run, eight ranks) at a reduced batch, the ranks sharing the
+    box's one GPU over gloo: rendezvous, rank-sharded batches, the recorded data-parallel step with its replica guard, the eagerly
+    profiled step on every rank, MAX-over-ranks timing, one JSON line from rank 0 with n_gpus = 8.  (No 8-GPU box is available to this
+    build: the first real run must not be the first time eight ranks execute this control flow.)"""
+    import json
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = str(s.getsockname()[1])
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASKPLANNER_DIST_BACKEND="gloo", MASKPLANNER_FAULT_DUMP="500")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1", "--master-port", port,
+           os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "6", "--warmup", "2", "--batch", "4", "--points", "1024", "--no-cpu-baseline",
+           "--no-side-legs"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-2500:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 8 and line["steps"] == 6 and line["value"] > 0 and np.isfinite(line["final_loss"])
+    assert line["config"]["global_batch"] == 32 and line["config"]["parallelism"] == "dp8"

@@ -4,6 +4,7 @@ launched kernel by kernel.  Prints one JSON line.  usage: syncbn_graph_probe.py 
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+os.environ["MASKPLANNER_SYNCBN_GRAPH"] = "1"     # (opt-in since r5: harness.TrainStep)
 os.environ.setdefault("MASTER_PORT", sys.argv[1] if len(sys.argv) > 1 else "29733")
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 N = int(sys.argv[3]) if len(sys.argv) > 3 else 5120
