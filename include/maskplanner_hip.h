@@ -519,11 +519,14 @@ int mp_head_block_bwd_f32(const float* grad_y, const float* y, const float* z, c
  * Outputs the library accumulates with atomics start from zero; by default each call clears its own (one small launch each).
  * mp_zero_arena_arm clears [base, base + bytes) with ONE launch on `stream` and remembers the range: until it is armed again or
  * disarmed, a call on the same stream whose zero-initialised output lies inside the range skips its own clear.  The caller hands
- * out every part of the range at most once per arming (process-wide state, like the profiler: one arena at a time).
+ * out every part of the range at most once per arming.  [r5] One armed range PER STREAM (a mutex-protected table keyed by the stream
+ * handle -- bookkeeping of caller-owned memory, the library holds no device memory): callers on different streams do not interact.
+ * mp_zero_arena_disarm_stream ends the arming of one stream, mp_zero_arena_disarm of every stream.
  * replaces: the implicit zero-initialisation of autograd's scatter / index_add / matmul outputs (models/pointnet2_utils.py:45-62,
  * pytorch3d knn_points backward) -- launch bookkeeping only, no arithmetic. */
 int mp_zero_arena_arm(void* base, size_t bytes, mp_stream_t stream);
 int mp_zero_arena_disarm(void);
+int mp_zero_arena_disarm_stream(mp_stream_t stream);
 /* [r4] mp_zero_arena_arm that also adds 1 to up to 40 int64 and 8 float32 device counters in the same launch (the num_batches_tracked of
  * the step's train-mode BatchNorm layers, models/pointnet2_utils.py:208-213 / pointnet2_cls_ssg.py:309-327; a dropout step; an
  * optimizer's device-side update count): bytes a non-zero multiple of 16. */

@@ -119,6 +119,7 @@ SIGNATURES = {
     "mp_zero_arena_arm": (_int, [_vp, _sz, _vp]),
     "mp_zero_arena_arm_ticks": (_int, [_vp, _sz, _int, _vp, _int, _vp, _vp]),
     "mp_zero_arena_disarm": (_int, []),
+    "mp_zero_arena_disarm_stream": (_int, [_vp]),
     "mp_profiler_enable": (_int, [_int]),
     "mp_profiler_collect": (_int, [ctypes.c_char_p, _sz]),
     "mp_sa_mlp_workspace_bytes": (_sz, [_i64, _i64, _int, ctypes.POINTER(_i64), _int]),

@@ -15,7 +15,7 @@ extern "C" const char* mp_error_string(int code)
     }
 }
 
-// ---- kernel profiler (debug/bench facility; the only process-wide state in the library) -----------------------
+// ---- kernel profiler (debug/bench facility; process-wide, off by default: with the zero arena's table below the only such state) ----
 #include <atomic>
 #include <map>
 #include <mutex>
@@ -100,12 +100,21 @@ extern "C" int mp_profiler_collect(char* buf, size_t cap)
 // the nearest-neighbour backward, the input gradients of the wide heads, dA of the factorised first layer): a clear launch each,
 // ~5 us apiece on a dependent chain.  The caller may instead carve them out of ONE buffer, clear it with this call at the start of
 // the phase, and the library then skips its own clear of every output inside the armed range (same stream only).  Every part of the
-// range must be handed out at most once per arming; arming again (or mp_zero_arena_disarm) ends the previous one.
+// range must be handed out at most once per arming; arming the same stream again (or mp_zero_arena_disarm[_stream]) ends the previous one.
+// [r5] One armed range PER STREAM (a table keyed by the stream handle, under a mutex): two training steps on two streams of one process
+// do not see each other's arena.  This table and the profiler above are the library's only process-wide state; both are bookkeeping of
+// caller-owned resources (no device memory is held).
 namespace {
+struct ArenaEntry { hipStream_t stream; const char* base; size_t bytes; };
 std::mutex g_arena_mu;
-const char* g_arena_base = nullptr;
-size_t g_arena_bytes = 0;
-hipStream_t g_arena_stream = nullptr;
+std::vector<ArenaEntry> g_arenas;
+void arena_set(hipStream_t stream, const char* base, size_t bytes)
+{
+    std::lock_guard<std::mutex> lk(g_arena_mu);
+    for (auto it = g_arenas.begin(); it != g_arenas.end(); ++it)
+        if (it->stream == stream) { g_arenas.erase(it); break; }
+    if (base && bytes) g_arenas.push_back(ArenaEntry{stream, base, bytes});
+}
 }  // namespace
 
 namespace mp {
@@ -113,16 +122,22 @@ bool zero_arena_covers(const void* p, size_t bytes, hipStream_t stream)
 {
     std::lock_guard<std::mutex> lk(g_arena_mu);
     const char* q = static_cast<const char*>(p);
-    return g_arena_base && stream == g_arena_stream && q >= g_arena_base && q + bytes <= g_arena_base + g_arena_bytes;
+    for (const ArenaEntry& e : g_arenas)
+        if (e.stream == stream) return q >= e.base && q + bytes <= e.base + e.bytes;
+    return false;
 }
 }  // namespace mp
 
-extern "C" int mp_zero_arena_disarm(void)
+extern "C" int mp_zero_arena_disarm_stream(mp_stream_t stream_)
+{
+    arena_set(mp_stream(stream_), nullptr, 0);
+    return MP_OK;
+}
+
+extern "C" int mp_zero_arena_disarm(void)       // every stream's
 {
     std::lock_guard<std::mutex> lk(g_arena_mu);
-    g_arena_base = nullptr;
-    g_arena_bytes = 0;
-    g_arena_stream = nullptr;
+    g_arenas.clear();
     return MP_OK;
 }
 
@@ -155,7 +170,7 @@ extern "C" int mp_zero_arena_arm_ticks(void* base, size_t bytes, int n_i64, int6
     if (n_i64 < 0 || n_f32 < 0 || (n_i64 > 0 && !counters_i64) || (n_f32 > 0 && !counters_f32)) return MP_EINVAL;
     if (n_i64 > TICK_I64 || n_f32 > TICK_F32) return MP_EUNSUPPORTED;
     hipStream_t stream = mp_stream(stream_);
-    mp_zero_arena_disarm();
+    arena_set(stream, nullptr, 0);
     TickTable t{};
     t.n64 = n_i64;
     t.n32 = n_f32;
@@ -166,10 +181,7 @@ extern "C" int mp_zero_arena_arm_ticks(void* base, size_t bytes, int n_i64, int6
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(arena_arm_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, static_cast<float*>(base), n4, t);
     if (hipGetLastError() != hipSuccess) return MP_ELAUNCH;
-    std::lock_guard<std::mutex> lk(g_arena_mu);
-    g_arena_base = static_cast<const char*>(base);
-    g_arena_bytes = bytes;
-    g_arena_stream = stream;
+    arena_set(stream, static_cast<const char*>(base), bytes);
     return MP_OK;
 }
 
@@ -177,12 +189,9 @@ extern "C" int mp_zero_arena_arm(void* base, size_t bytes, mp_stream_t stream_)
 {
     if (!base || (bytes & 3) || (reinterpret_cast<uintptr_t>(base) & 15)) return MP_EINVAL;
     hipStream_t stream = mp_stream(stream_);
-    mp_zero_arena_disarm();
+    arena_set(stream, nullptr, 0);
     if (bytes == 0) return MP_OK;
     if (!mp::zero_async(static_cast<float*>(base), bytes / 4, stream)) return MP_ELAUNCH;
-    std::lock_guard<std::mutex> lk(g_arena_mu);
-    g_arena_base = static_cast<const char*>(base);
-    g_arena_bytes = bytes;
-    g_arena_stream = stream;
+    arena_set(stream, static_cast<const char*>(base), bytes);
     return MP_OK;
 }

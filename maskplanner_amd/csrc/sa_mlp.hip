@@ -1959,6 +1959,9 @@ __global__ __launch_bounds__(bwd_fused_threads(CO, CI, SPLIT, ONE), (CO >= 128 &
 #ifndef MP_ROLES_SPLITSTAGE
 #define MP_ROLES_SPLITSTAGE 0       // (1: the dX waves stage the input operand -- 13 spilled registers, 203 -> 225 us)
 #endif
+#ifndef MP_ROLES_BALL
+#define MP_ROLES_BALL 1             // [r5] two planes: every wave stages a piece of the input operand (see BALL)
+#endif
 #ifndef MP_ROLES_PD2
 #define MP_ROLES_PD2 0              // 256 outputs: two chunks of loads in flight in the staging (dW) waves (13 spilled registers: 205 -> 270 us)
 #endif
@@ -1988,10 +1991,15 @@ __global__ __launch_bounds__(512, 1) void bwd_roles_kernel(PosOperand DZ, PosOpe
     // 256 outputs: the dX waves hold 192 registers of weight planes -- they stage the (smaller) input operand only when MP_ROLES_SPLITSTAGE,
     // the dW waves the dZ operand (or both)
     constexpr bool SPLITSTAGE = !ALLSTAGE && MP_ROLES_SPLITSTAGE;
+    // [r5] two planes: the input operand (a third of the staging) is staged by ALL EIGHT waves, one 16-byte piece per thread -- with three
+    // products per fp32 product the dX waves wait ~900 of a chunk's 3 800 cycles for the dW + staging waves (tools/roles_timing.sh), and
+    // they hold 128 registers of weight planes instead of 192
+    constexpr bool BALL = !ALLSTAGE && !SPLITSTAGE && PL == 2 && MP_ROLES_BALL;
     constexpr int NTS = ALLSTAGE ? 512 : 256, NWS = NTS / 64;          // staging threads / waves (per operand)
+    constexpr int NWSB = BALL ? 8 : NWS;
     constexpr int NBA = CO / 64, NBB = CI / 64;
-    constexpr int PA = DBK * CO / 4 / NTS, PB = DBK * CI / 4 / NTS;
-    constexpr int KA_STEP = 4 * (NWS / NBA), KB_STEP = 4 * (NWS / NBB);
+    constexpr int PA = DBK * CO / 4 / NTS, PB = DBK * CI / 4 / (NWSB * 64);
+    constexpr int KA_STEP = 4 * (NWS / NBA), KB_STEP = 4 * (NWSB / NBB);
     static_assert(PA * KA_STEP == DBK && PB * KB_STEP == DBK && (CO == 128 || CO == 256), "staging covers the chunk");
     constexpr int NST = CO / 32;                                        // k-steps of the dX product
     constexpr int TMW = CO / 64, TNW = 2;                               // 32 x 32 dW tiles per dW wave (waves 2 x 2 over [CO x 128])
@@ -2007,16 +2015,16 @@ __global__ __launch_bounds__(512, 1) void bwd_roles_kernel(PosOperand DZ, PosOpe
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool role_dx = wave < 4;
     const bool stage_a = ALLSTAGE || !role_dx;                          // this wave stages dZ rows
-    const bool stage_b = ALLSTAGE || (SPLITSTAGE ? role_dx : !role_dx); // ... input rows
+    const bool stage_b = ALLSTAGE || BALL || (SPLITSTAGE ? role_dx : !role_dx); // ... input rows
     const int p0 = blockIdx.x * p_per_block;
     const int p1 = min(P, p0 + p_per_block);
     const int nchunks = (p1 - p0 + DBK - 1) / DBK;
     if (nchunks <= 0) return;
 
     // ---- staging (16 lanes x 16 bytes per row: 256-byte global segments) --------------------------------------------------------
-    const int sw = ALLSTAGE ? wave : (wave & 3);
+    const int sw = ALLSTAGE ? wave : (wave & 3), swb = BALL ? wave : sw;
     const int ca = (sw % NBA) * 64 + 4 * (lane & 15), ka0 = (sw / NBA) * 4 + (lane >> 4);
-    const int cb = (sw % NBB) * 64 + 4 * (lane & 15), kb0 = (sw / NBB) * 4 + (lane >> 4);
+    const int cb = (swb % NBB) * 64 + 4 * (lane & 15), kb0 = (swb / NBB) * 4 + (lane >> 4);
     if (stage_a) {      // per-channel constants of the staging arithmetic wait in LDS between chunks
         sKA[0][ca >> 2] = ld4(DZ.s + ca);
         sKA[1][ca >> 2] = ld4(DZ.t + ca);
@@ -2132,14 +2140,14 @@ __global__ __launch_bounds__(512, 1) void bwd_roles_kernel(PosOperand DZ, PosOpe
         RSetA ra_;
         RSetB rb_;
         if (ALLSTAGE) { gload_a(p0, ra_); sstore_a(0, p0, ra_); }
-        if (ALLSTAGE || SPLITSTAGE) { gload_b(p0, rb_); sstore_b(0, rb_); }
+        if (ALLSTAGE || SPLITSTAGE || BALL) { gload_b(p0, rb_); sstore_b(0, rb_); }
         __syncthreads();
         RT_DECL;
         for (int kc = 0; kc < nchunks; ++kc) {
             const int cur = kc & 1;
             RT_MARK(5);
             if (ALLSTAGE && kc + 1 < nchunks) gload_a(p0 + (kc + 1) * DBK, ra_);
-            if ((ALLSTAGE || SPLITSTAGE) && kc + 1 < nchunks) gload_b(p0 + (kc + 1) * DBK, rb_);
+            if ((ALLSTAGE || SPLITSTAGE || BALL) && kc + 1 < nchunks) gload_b(p0 + (kc + 1) * DBK, rb_);
             f32x4 ax[2], cx[2];
 #pragma unroll
             for (int h = 0; h < 2; ++h) { ax[h] = f32x4{0.f, 0.f, 0.f, 0.f}; cx[h] = f32x4{0.f, 0.f, 0.f, 0.f}; }
@@ -2154,16 +2162,23 @@ __global__ __launch_bounds__(512, 1) void bwd_roles_kernel(PosOperand DZ, PosOpe
                     for (int pl = 0; pl < PL; ++pl) af[(st + 1) & 1][pl] = *reinterpret_cast<const bf16x8*>(&hA[cur][pl][ao + 4 * (st + 1) * GS]);
                 }
                 const bf16x8 ah = af[st & 1][0], am = af[st & 1][1], al = af[st & 1][PL - 1];
+                if constexpr (PL == 2) {       // (four accumulators: the two products into cx[h] stand three instructions apart)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) cx[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, wsp[h][st][0], cx[h], 0, 0, 0);
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) ax[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wsp[h][st][0], ax[h], 0, 0, 0);
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) cx[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wsp[h][st][1], cx[h], 0, 0, 0);
+                } else {
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
-                    if constexpr (PL == 3) cx[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, wsp[h][st][0], cx[h], 0, 0, 0);
+                    cx[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, wsp[h][st][0], cx[h], 0, 0, 0);
                     ax[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wsp[h][st][0], ax[h], 0, 0, 0);
-                    if constexpr (PL == 3) {
-                        cx[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wsp[h][st][PL - 1], cx[h], 0, 0, 0);
-                        cx[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, wsp[h][st][1], cx[h], 0, 0, 0);
-                    }
+                    cx[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wsp[h][st][PL - 1], cx[h], 0, 0, 0);
+                    cx[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, wsp[h][st][1], cx[h], 0, 0, 0);
                     cx[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, wsp[h][st][0], cx[h], 0, 0, 0);
                     cx[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wsp[h][st][1], cx[h], 0, 0, 0);
+                }
                 }
             }
             RT_MARK(0);
@@ -2185,7 +2200,7 @@ __global__ __launch_bounds__(512, 1) void bwd_roles_kernel(PosOperand DZ, PosOpe
             goff += DBK * CI * 4;
             RT_MARK(1);
             if (ALLSTAGE && kc + 1 < nchunks) sstore_a(cur ^ 1, p0 + (kc + 1) * DBK, ra_);
-            if ((ALLSTAGE || SPLITSTAGE) && kc + 1 < nchunks) sstore_b(cur ^ 1, rb_);
+            if ((ALLSTAGE || SPLITSTAGE || BALL) && kc + 1 < nchunks) sstore_b(cur ^ 1, rb_);
             RT_MARK(4);
             __syncthreads();
             RT_MARK(2);

@@ -69,21 +69,47 @@ class ZeroArena:
     wide heads' input gradients, dA of the factorised first layer): arm() clears it with ONE launch (mp_zero_arena_arm) and the library
     then skips its own clear of every output handed out by empty() -- five clear launches fewer per step.  Sizes are learnt: requests that
     do not fit fall back to an ordinary allocation (cleared by the library as before) and grow the arena for the next arm()."""
-    active = None
+    # [r5] armed arenas by (device index, raw stream): two training steps on two streams of one process each have their own (the library's
+    # table is keyed by the stream as well: csrc/api.hip)
+    _armed = {}
 
     def __init__(self, device):
         self.device, self.buf, self.cap, self.cur, self.want = device, None, 0, 0, 0
+        self._key, self._recorded, self._retired = None, False, []
+
+    @staticmethod
+    def current(device):
+        """The arena armed on `device`'s current stream, or None."""
+        if not ZeroArena._armed:
+            return None
+        idx = device.index if device.index is not None else _cur_device()
+        return ZeroArena._armed.get((idx, _raw_stream(idx)))
 
     def arm(self, ticks=None, fticks=None):
         """Clear the arena on the current stream and make it the source of empty() until disarm().  ticks / fticks: int64 / float32
         device scalars advanced by 1 in the same launch (mp_zero_arena_arm_ticks); returns False when they were NOT advanced (no arena
         yet, too many, other dtypes) and the caller has to."""
         need = max(self.want, self.cur)
-        if need > self.cap and not torch.cuda.is_current_stream_capturing():
+        capturing = torch.cuda.is_current_stream_capturing()
+        if need > self.cap and not capturing:
+            # (a buffer that was armed under capture has its address baked into recorded graphs -- the clear launch and every output carved
+            # out of it: it is kept alive, never handed back to the allocator [ADVICE r4])
+            if self.buf is not None and self._recorded:
+                self._retired.append(self.buf)
             self.cap = (need + 4095) // 4096 * 4096
             self.buf = torch.empty((self.cap,), dtype=torch.uint8, device=self.device)
+            self._recorded = False
+        self._recorded = self._recorded or capturing
         self.cur, self.want = 0, 0
-        ZeroArena.active = self
+        idx = self.device.index if self.device.index is not None else _cur_device()
+        key = (idx, _raw_stream(idx))
+        other = ZeroArena._armed.get(key)
+        if other is not None and other is not self:
+            raise RuntimeError("another ZeroArena is armed on this stream (one owner per stream: disarm() it first)")
+        if self._key is not None and self._key != key:
+            ZeroArena._armed.pop(self._key, None)
+        self._key = key
+        ZeroArena._armed[key] = self
         ticks, fticks = list(ticks or []), list(fticks or [])
         if not self.cap:
             return not (ticks or fticks)
@@ -98,9 +124,10 @@ class ZeroArena:
         return not (ticks or fticks)
 
     def disarm(self):
-        if ZeroArena.active is self:
-            ZeroArena.active = None
-            _lib.load().mp_zero_arena_disarm()
+        if self._key is not None and ZeroArena._armed.get(self._key) is self:
+            del ZeroArena._armed[self._key]
+            _lib.load().mp_zero_arena_disarm_stream(ctypes.c_void_p(self._key[1]))
+        self._key = None
 
     def take(self, shape, dtype, device):
         n = 1
@@ -118,7 +145,7 @@ class ZeroArena:
 def zeroed_empty(shape, dtype, device):
     """An output the LIBRARY zero-initialises before accumulating into it: from the armed ZeroArena when there is one (already clear),
     else an ordinary uninitialised allocation (the library clears it)."""
-    a = ZeroArena.active
+    a = ZeroArena.current(device)
     if a is not None:
         t = a.take(tuple(shape), dtype, device)
         if t is not None:
@@ -652,7 +679,7 @@ class GradAccum:
         if self.off:
             return None
         if self.buf is None:
-            a = ZeroArena.active
+            a = ZeroArena.current(device)
             self.buf = a.take(self.shape, torch.float32, device) if (a is not None and not DETERMINISTIC) else None
             if self.buf is None:
                 self.off = True
@@ -671,7 +698,9 @@ class _ChamferTerm(torch.autograd.Function):
         ctx.accum, ctx.which = None, 0
         if accum is not None:
             ctx.which = accum.operand(p1, p2)
-            if ctx.which:
+            # (a term counts only if its shared operand takes a gradient at all; every counted term MUST take part in the backward pass --
+            # the last one to run hands the total over -- which holds for the composite losses that sum all their terms)
+            if ctx.which and ctx.needs_input_grad[ctx.which - 1]:
                 ctx.accum = accum
                 accum.pending += 1
         B, P1, D = p1.shape
@@ -703,6 +732,11 @@ class _ChamferTerm(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out, _gd, _gi):
         if grad_out is None:
+            if ctx.accum is not None:       # [r5, ADVICE r4] a counted term leaves the count on EVERY exit
+                ctx.accum.pending -= 1
+                if ctx.accum.pending == 0 and ctx.accum.buf is not None:       # ... and the last one hands the total over even if it adds nothing
+                    g = ctx.accum.buf
+                    return ((g.view(ctx.saved_tensors[0].shape) if ctx.which == 1 else None), (g.view(ctx.saved_tensors[1].shape) if ctx.which == 2 else None)) + (None,) * 8
             return (None,) * 10
         p1, p2, len1, len2, idx = ctx.saved_tensors
         point_mean, batch_mode, div, scale = ctx.meta
@@ -710,7 +744,7 @@ class _ChamferTerm(torch.autograd.Function):
         P2 = p2.shape[1]
         need1, need2 = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         flags = int(DETERMINISTIC)
-        shared = ctx.accum.buffer(p1.device) if (ctx.accum is not None and ctx.needs_input_grad[ctx.which - 1]) else None
+        shared = ctx.accum.buffer(p1.device) if ctx.accum is not None else None
         if shared is not None and ctx.which == 1:
             g1, flags = shared.view(p1.shape), flags | 2          # += into the shared buffer
         else:
@@ -723,9 +757,9 @@ class _ChamferTerm(torch.autograd.Function):
             grad_out = _f32(grad_out)
             _run("knn_bwd", p1, _lib.load().mp_knn_bwd_reduced_f32, _p(p1), _p(p2), _p(len1), _p(len2), _p(idx), _p(grad_out), point_mean,
                  batch_mode, div, scale, B, P1, P2, D, _p(g1), _p(g2), flags)
-        if shared is not None:        # only the last term to run hands the total to autograd
+        if ctx.accum is not None:
             ctx.accum.pending -= 1
-            if ctx.accum.pending > 0:
+            if shared is not None and ctx.accum.pending > 0:        # only the last term to run hands the total to autograd
                 if ctx.which == 1:
                     g1 = None
                 else:

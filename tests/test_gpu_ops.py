@@ -832,3 +832,51 @@ def test_static_target_lengths_and_prepared_planes(ops):
         assert torch.equal(g, gw)
     finally:
         ops.forget_static_targets()
+
+
+def test_grad_accum_shared_buffer_equals_separate_gradients(ops):
+    """[r5, ADVICE r4] ops.GradAccum outside the full training step: three chamfer terms on one prediction (as x, as y, as x again) with an armed
+    ZeroArena -- the gradient handed to autograd by the LAST term to run equals the sum of the three separate gradients; a term whose shared
+    operand takes no gradient (a detached alias) is not counted; and two arenas on two streams do not interfere."""
+    torch.manual_seed(3)
+    B, P, Q, D = 3, 200, 150, 6
+    tgt = torch.randn(B, Q, D, device="cuda")
+    lp = torch.full((B,), P, dtype=torch.int64, device="cuda")
+    lq = torch.full((B,), Q, dtype=torch.int64, device="cuda")
+    base = torch.randn(B, P, D, device="cuda")
+
+    def loss(pred, acc):
+        a = ops.chamfer_term(pred, tgt, lp, lq, "mean", "mean", 1.0, grad_accum=acc)[0]
+        b = ops.chamfer_term(tgt, pred, lq, lp, "mean", "mean", 2.0, grad_accum=acc)[0]
+        c = ops.chamfer_term(pred, tgt, lp, lq, "sum", "mean", 0.5, grad_accum=acc)[0]
+        d = ops.chamfer_term(pred.detach(), tgt, lp, lq, "mean", "mean", 3.0, grad_accum=acc)[0]      # same storage, no gradient: not counted
+        return a + b + c + d
+
+    ref = base.clone().requires_grad_(True)
+    loss(ref, None).backward()
+    arena = ops.ZeroArena(torch.device("cuda", 0))
+    for _ in range(2):          # (the first pass teaches the arena its size)
+        got = base.clone().requires_grad_(True)
+        acc = ops.GradAccum(got)
+        val = loss(got, acc)
+        arena.arm()
+        try:
+            val.backward()
+        finally:
+            arena.disarm()
+    assert acc.pending == 0 and acc.buf is not None
+    assert float((got.grad - ref.grad).abs().max()) <= 1e-6 * float(ref.grad.abs().max())
+    # one owner per stream, independent streams
+    other = ops.ZeroArena(torch.device("cuda", 0))
+    arena.arm()
+    with pytest.raises(RuntimeError, match="another ZeroArena"):
+        other.arm()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        other.arm()
+        assert ops.ZeroArena.current(torch.device("cuda", 0)) is other
+        other.disarm()
+    assert ops.ZeroArena.current(torch.device("cuda", 0)) is arena
+    arena.disarm()
+    assert ops.ZeroArena.current(torch.device("cuda", 0)) is None
+    torch.cuda.synchronize()
