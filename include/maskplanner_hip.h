@@ -562,6 +562,7 @@ int mp_colsum_multi_f32(int64_t count, const void* const* g, void* const* out, c
 int mp_pad_ragged_f32(const float* flat, const int64_t* offsets, int64_t B, int64_t R, int64_t D, float fill, float* out,
                       mp_stream_t stream);
 
+
 /* ---- lambda-segments of a batch on the device ---------------------------------------------------------------------------
  * replaces: utils/pointcloud.py:294-413 get_sequences_of_lambda_points (+ add_padding :98-105) as the dataset calls it per
  *           sample (utils/dataset/paintnet_ODv1.py:294) followed by the collate function's padding (:738-748).

@@ -5,6 +5,8 @@
 // with one numpy concatenate + torch.as_tensor + torch.stack per sample and key, then the training loop copies the stacked
 // tensors to the GPU.  Here the samples of a key travel as ONE flat buffer (a single host-to-device copy) and this kernel lays
 // them out: out[b, r, :] = r < len_b ? flat[off_b + r, :] : fill.  Pure data movement, bound by the write of the padded tensor.
+#include <cstring>
+
 #include "common.h"
 
 namespace {

@@ -1962,6 +1962,12 @@ __global__ __launch_bounds__(bwd_fused_threads(CO, CI, SPLIT, ONE), (CO >= 128 &
 #ifndef MP_ROLES_BALL
 #define MP_ROLES_BALL 1             // [r5] two planes: every wave stages a piece of the input operand (see BALL)
 #endif
+#ifndef MP_ROLES_MFMA_ORDER
+#define MP_ROLES_MFMA_ORDER 0
+#endif
+#ifndef MP_ROLES_BEARLY
+#define MP_ROLES_BEARLY 1
+#endif
 #ifndef MP_ROLES_PD2
 #define MP_ROLES_PD2 0              // 256 outputs: two chunks of loads in flight in the staging (dW) waves (13 spilled registers: 205 -> 270 us)
 #endif
@@ -2162,7 +2168,7 @@ __global__ __launch_bounds__(512, 1) void bwd_roles_kernel(PosOperand DZ, PosOpe
                     for (int pl = 0; pl < PL; ++pl) af[(st + 1) & 1][pl] = *reinterpret_cast<const bf16x8*>(&hA[cur][pl][ao + 4 * (st + 1) * GS]);
                 }
                 const bf16x8 ah = af[st & 1][0], am = af[st & 1][1], al = af[st & 1][PL - 1];
-                if constexpr (PL == 2) {       // (four accumulators: the two products into cx[h] stand three instructions apart)
+                if constexpr (PL == 2 && MP_ROLES_MFMA_ORDER == 1) {       // (four accumulators: the two products into cx[h] stand three instructions apart)
 #pragma unroll
                     for (int h = 0; h < 2; ++h) cx[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, wsp[h][st][0], cx[h], 0, 0, 0);
 #pragma unroll
@@ -2172,16 +2178,22 @@ __global__ __launch_bounds__(512, 1) void bwd_roles_kernel(PosOperand DZ, PosOpe
                 } else {
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
-                    cx[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, wsp[h][st][0], cx[h], 0, 0, 0);
+                    if constexpr (PL == 3) cx[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, wsp[h][st][0], cx[h], 0, 0, 0);
                     ax[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wsp[h][st][0], ax[h], 0, 0, 0);
-                    cx[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wsp[h][st][PL - 1], cx[h], 0, 0, 0);
-                    cx[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, wsp[h][st][1], cx[h], 0, 0, 0);
+                    if constexpr (PL == 3) {
+                        cx[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wsp[h][st][PL - 1], cx[h], 0, 0, 0);
+                        cx[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, wsp[h][st][1], cx[h], 0, 0, 0);
+                    }
                     cx[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, wsp[h][st][0], cx[h], 0, 0, 0);
                     cx[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wsp[h][st][1], cx[h], 0, 0, 0);
                 }
                 }
             }
             RT_MARK(0);
+            // (BALL: this wave's piece of the next input chunk goes to LDS BEFORE the epilogue's stores are issued -- behind them the wait
+            // for its load also waited for their acknowledgements: 945 cycles for one 16-byte piece, tools/roles_timing.sh)
+            if constexpr (BALL && MP_ROLES_BEARLY) { if (kc + 1 < nchunks) sstore_b(cur ^ 1, rb_); }
+            RT_MARK(4);
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 ax[h] += cx[h];
@@ -2200,7 +2212,7 @@ __global__ __launch_bounds__(512, 1) void bwd_roles_kernel(PosOperand DZ, PosOpe
             goff += DBK * CI * 4;
             RT_MARK(1);
             if (ALLSTAGE && kc + 1 < nchunks) sstore_a(cur ^ 1, p0 + (kc + 1) * DBK, ra_);
-            if ((ALLSTAGE || SPLITSTAGE || BALL) && kc + 1 < nchunks) sstore_b(cur ^ 1, rb_);
+            if ((ALLSTAGE || SPLITSTAGE || (BALL && !MP_ROLES_BEARLY)) && kc + 1 < nchunks) sstore_b(cur ^ 1, rb_);
             RT_MARK(4);
             __syncthreads();
             RT_MARK(2);

@@ -251,13 +251,20 @@ class TrainStep:
         # waits for the plan instead (0.45 ms under the tracer).  So: the first level's FPS, then graph A, then the rest of the plan.
         # The single-scale encoder's ~10 launches keep the old order (same step time either way: NOTEBOOK.md).
         late = self.overlap and self._graph is not None and self._plan_cur is not None and self.SAMPLING_BEHIND_A and self._stream is None
-        if self.overlap:
+        # (streamed inputs, MASKPLANNER_STREAM_BEHIND_A=1: the ordering point is taken here, the collation + plan are ISSUED behind the replay of
+        # graph A -- their first kernels then do not start in the same instant as graph A's)
+        slate = self.overlap and self._graph is not None and self._plan_cur is not None and self._stream is not None and self.STREAM_BEHIND_A
+        if slate:
+            self._plan_stream.wait_stream(torch.cuda.current_stream())
+        elif self.overlap:
             # the NEXT batch's plan, on the second stream underneath this step (late: only its first kernel -- the first level's FPS, the
             # long pole of the plan -- before graph A; the other launches behind it)
             self._launch_sampling(phase="head" if late else None)
         if self._graph is not None:
             self._graph.replay()
             if late:
+                self._launch_sampling(phase="tail")
+            if slate:
                 self._launch_sampling(phase="tail")
             if self._graph_b is not None:
                 if self._adam_ev is not None:
@@ -730,6 +737,7 @@ class TrainStep:
         self._plan_stream = torch.cuda.Stream()
         if self._stream is not None:
             xyz, starts = self._stream.collate_next()
+            self._stream.collated()
             self._sample_levels(self._plan_cur, xyz, starts)
             self._target_aux(self._plan_cur, self._stream.stage)
             self._extras(self._plan_cur, xyz)
@@ -750,12 +758,27 @@ class TrainStep:
         side = self._plan_stream
         if phase != "tail":
             side.wait_stream(torch.cuda.current_stream())
+        if self._stream is not None:
+            # streamed inputs: ONE chain under the step (collation of the cloud -> FPS -> ball queries -> extras -> collation of the targets ->
+            # their lengths / planes), device to device: the host-to-device transfer ran a step earlier on the copy stream (_BatchStream).
+            # [r5] two chains on two streams (the targets beside the sampling) were measured: 2.38 vs 2.17 ms.
+            self._stream.prefetch()                              # host items of batch k + 2 -> pinned -> raw device set (copy stream)
+            with torch.cuda.stream(side):
+                xyz, starts = self._stream.collate_cloud()       # batch k + 1: raw device set -> staging tensors
+                if not self.STREAM_TARGETS_LAST:
+                    self._stream.collate_targets()
+                self._sample_levels(self._plan_next, xyz, starts)
+                self._extras(self._plan_next, xyz)
+                if self.STREAM_TARGETS_LAST:
+                    self._stream.collate_targets()
+                self._target_aux(self._plan_next, self._stream.stage)
+                self._plan_ev = torch.cuda.Event()
+                self._plan_ev.record(side)
+            self._stream.collated(self._plan_ev)
+            return
         with torch.cuda.stream(side):
             if self._stream is not None:
-                xyz, starts = self._stream.collate_next()        # host items -> device staging tensors, on the side stream
-                self._sample_levels(self._plan_next, xyz, starts)
-                self._target_aux(self._plan_next, self._stream.stage)
-                self._extras(self._plan_next, xyz)
+                pass
             else:
                 self._sample_levels(self._plan_next, phase=phase)
                 if phase == "head":
@@ -765,9 +788,15 @@ class TrainStep:
             self._plan_ev = torch.cuda.Event()
             self._plan_ev.record(side)
 
+    _plan_ev2 = None
+    STREAM_TARGETS_LAST = os.environ.get("MASKPLANNER_STREAM_TARGETS_LAST", "1") != "0"
+    STREAM_BEHIND_A = os.environ.get("MASKPLANNER_STREAM_BEHIND_A", "0") == "1"
+
     def _wait_plan(self):
         if self._plan_ev is not None:
             torch.cuda.current_stream().wait_event(self._plan_ev)    # the next batch's sampling (and collation) is complete
+        if self._plan_ev2 is not None:
+            torch.cuda.current_stream().wait_event(self._plan_ev2)   # ... and its targets' lengths / planes (streamed inputs)
 
     def _hand_over_copies(self):
         """The next plan becomes the step's (one elementwise kernel into the static buffer); with streamed inputs the collated next
@@ -827,13 +856,21 @@ class TrainStep:
 
 
 class _BatchStream:
-    """Host dataset items -> the step's device batch, one batch ahead (TrainStep(stream_batches=K)).  Staging tensors on the
-    device have the step's fixed shapes; collate_next() fills them on the CURRENT (side) stream from pinned host buffers (one
-    copy per key, then csrc/collate.hip's pad kernel); publish() copies them into the step's static tensors on the main stream."""
+    """Host dataset items -> the step's device batch (TrainStep(stream_batches=K)), as a two-stage pipeline [r5]:
+      upload(k+2)    host items -> a pinned set (numpy) -> a RAW device set (flat ragged rows, offsets, FPS start indices) by hipMemcpyAsync on
+                     a copy stream of its own, which waits for nothing but the event behind which that raw set was last read: the PCIe
+                     transfer (7.5 MB per cuboids batch, ~0.15 ms) sits on no chain of the step;
+      collate(k+1)   on the plan stream, under step k: raw set -> the staging tensors of the step's fixed shapes (csrc/collate.hip's pad
+                     kernel, device to device), then FPS / ball queries / target lengths + planes (harness._launch_sampling);
+      publish()      staging -> the step's static tensors, the last node of graph B.
+    With the transfer INSIDE the plan chain (r4, and the zero-copy / two-chain variants measured this round: tools/stream_gap.py) the plan of
+    batch k+1 was ready ~0.13 ms after graph A of step k had finished and graph B waited for it: 2.17 vs 2.03 ms per step."""
     KEYS = (("traj", -100.0), ("traj_as_pc", -100.0), ("stroke_ids", -1.0))
+    NSETS = 2
 
     def __init__(self, ts, batches):
-        self.ts, self.batches, self.i = ts, batches, 0
+        self.ts, self.batches = ts, batches
+        self.n_up, self.n_co = 0, 0
         dev = ts.device
         B, N = ts.batch["point_cloud"].shape[:2]
         self.width = {k: max(max(it[k].shape[0] for it in b) for b in batches) for k, _ in self.KEYS}
@@ -846,44 +883,92 @@ class _BatchStream:
         self.stage["point_cloud"] = torch.empty_like(ts.batch["point_cloud"])
         self.stage_starts = [torch.zeros(B, dtype=torch.long, device=dev) for _ in ts.batch["fps_start"]]
         cap = {k: B * self.width[k] * self.dim[k] for k, _ in self.KEYS}
-        self.pin = {k: torch.empty(cap[k], dtype=torch.float32).pin_memory() for k, _ in self.KEYS}
-        self.pin["point_cloud"] = torch.empty(B * N * 3, dtype=torch.float32).pin_memory()
-        self.pin_off = {k: torch.empty(B + 1, dtype=torch.int64).pin_memory() for k, _ in self.KEYS}
-        self.pin_starts = [torch.empty(B, dtype=torch.long).pin_memory() for _ in ts.batch["fps_start"]]
-        self.dev_flat = {k: torch.empty(cap[k], dtype=torch.float32, device=dev) for k, _ in self.KEYS}
-        self.dev_off = {k: torch.empty(B + 1, dtype=torch.int64, device=dev) for k, _ in self.KEYS}
-        self.host_ev = None        # the previous collation's copies out of the pinned buffers are complete
+        self.sets = []
+        for _ in range(self.NSETS):
+            pin = {k: torch.empty(cap[k], dtype=torch.float32).pin_memory() for k, _ in self.KEYS}
+            pin["point_cloud"] = torch.empty(B * N * 3, dtype=torch.float32).pin_memory()
+            raw = {k: torch.empty(cap[k], dtype=torch.float32, device=dev) for k, _ in self.KEYS}
+            raw["point_cloud"] = torch.empty_like(ts.batch["point_cloud"])
+            self.sets.append(dict(pin=pin, raw=raw, tot={},
+                                  pin_off={k: torch.empty(B + 1, dtype=torch.int64).pin_memory() for k, _ in self.KEYS},
+                                  raw_off={k: torch.empty(B + 1, dtype=torch.int64, device=dev) for k, _ in self.KEYS},
+                                  pin_starts=[torch.empty(B, dtype=torch.long).pin_memory() for _ in ts.batch["fps_start"]],
+                                  raw_starts=[torch.zeros(B, dtype=torch.long, device=dev) for _ in ts.batch["fps_start"]],
+                                  ev_h2d=None, ev_read=None))
+        self.copy_stream = torch.cuda.Stream()
         self.levels_n = [N] + [m.npoint for m in ts._plan_levels()][:-1]
+        self._cur = None
 
-    def collate_next(self):
+    def upload(self):
+        """The next host batch into a pinned set and on to its raw device set (copy stream); host-side numpy + seven asynchronous copies."""
         import numpy as np
-        from . import _lib, ops
-        items = self.batches[self.i % len(self.batches)]
-        self.i += 1
-        if self.host_ev is not None:
-            self.host_ev.synchronize()      # (long done: a whole step has passed) before the pinned buffers are rewritten
-        B = len(items)
-        np.stack([it["point_cloud"] for it in items], out=self.pin["point_cloud"].numpy().reshape(B, -1, 3))
-        self.stage["point_cloud"].copy_(self.pin["point_cloud"].view_as(self.stage["point_cloud"]), non_blocking=True)
-        lib = _lib.load()
-        for k, fill in self.KEYS:
+        items = self.batches[self.n_up % len(self.batches)]
+        hs = self.sets[self.n_up % self.NSETS]
+        self.n_up += 1
+        if hs["ev_h2d"] is not None:
+            hs["ev_h2d"].synchronize()      # (two uploads ago: long done) before this pinned set is rewritten
+        pin, B = hs["pin"], len(items)
+        np.stack([it["point_cloud"] for it in items], out=pin["point_cloud"].numpy().reshape(B, -1, 3))
+        for k, _fill in self.KEYS:
             arrs = [np.asarray(it[k], dtype=np.float32).reshape(it[k].shape[0], -1) for it in items]
             lens = [a.shape[0] for a in arrs]
             tot = sum(lens)
-            np.concatenate(arrs, axis=0, out=self.pin[k].numpy()[:tot * self.dim[k]].reshape(tot, self.dim[k]))
-            off = self.pin_off[k].numpy()
+            np.concatenate(arrs, axis=0, out=pin[k].numpy()[:tot * self.dim[k]].reshape(tot, self.dim[k]))
+            off = hs["pin_off"][k].numpy()
             off[0] = 0
             np.cumsum(lens, out=off[1:])
-            self.dev_flat[k][:tot * self.dim[k]].copy_(self.pin[k][:tot * self.dim[k]], non_blocking=True)
-            self.dev_off[k].copy_(self.pin_off[k], non_blocking=True)
-            ops._run("pad_ragged", self.stage[k], lib.mp_pad_ragged_f32, self.dev_flat[k].data_ptr(), self.dev_off[k].data_ptr(), B,
-                     self.width[k], self.dim[k], float(fill), self.stage[k].data_ptr())
-        for pin, dst, n in zip(self.pin_starts, self.stage_starts, self.levels_n):    # the reference's draw (pointnet2_utils.py:77)
-            pin.copy_(torch.randint(0, n, (B,), dtype=torch.long))
-            dst.copy_(pin, non_blocking=True)
-        self.host_ev = torch.cuda.Event()
-        self.host_ev.record()
+            hs["tot"][k] = tot
+        for p_, n in zip(hs["pin_starts"], self.levels_n):      # the reference's draw (pointnet2_utils.py:77)
+            p_.copy_(torch.randint(0, n, (B,), dtype=torch.long))
+        with torch.cuda.stream(self.copy_stream):
+            if hs["ev_read"] is not None:
+                self.copy_stream.wait_event(hs["ev_read"])      # the raw set's previous content has been collated
+            hs["raw"]["point_cloud"].copy_(pin["point_cloud"].view_as(hs["raw"]["point_cloud"]), non_blocking=True)
+            for k, _fill in self.KEYS:
+                n = hs["tot"][k] * self.dim[k]
+                hs["raw"][k][:n].copy_(pin[k][:n], non_blocking=True)
+                hs["raw_off"][k].copy_(hs["pin_off"][k], non_blocking=True)
+            for p_, d_ in zip(hs["pin_starts"], hs["raw_starts"]):
+                d_.copy_(p_, non_blocking=True)
+            hs["ev_h2d"] = torch.cuda.Event()
+            hs["ev_h2d"].record(self.copy_stream)
+
+    def prefetch(self):
+        """Keep the upload one batch ahead of the collation (call at the start of a step, before the plan chain is launched)."""
+        while self.n_up < self.n_co + 2:
+            self.upload()
+
+    def collate_next(self):
+        """Both halves on the current stream (the first batch, in line)."""
+        out = self.collate_cloud()
+        self.collate_targets()
+        return out
+
+    def collate_cloud(self):
+        """The next uploaded batch's cloud rows and FPS start indices into the staging tensors, on the current stream (device to device)."""
+        if self.n_up <= self.n_co:
+            self.upload()
+        hs = self._cur = self.sets[self.n_co % self.NSETS]
+        self.n_co += 1
+        torch.cuda.current_stream().wait_event(hs["ev_h2d"])
+        torch._foreach_copy_([self.stage["point_cloud"]] + list(self.stage_starts), [hs["raw"]["point_cloud"]] + list(hs["raw_starts"]))
         return self.stage["point_cloud"], self.stage_starts
+
+    def collate_targets(self):
+        from . import _lib, ops
+        lib = _lib.load()
+        hs = self._cur
+        B = self.stage["point_cloud"].shape[0]
+        for k, fill in self.KEYS:
+            ops._run("pad_ragged", self.stage[k], lib.mp_pad_ragged_f32, hs["raw"][k].data_ptr(), hs["raw_off"][k].data_ptr(), B,
+                     self.width[k], self.dim[k], float(fill), self.stage[k].data_ptr())
+
+    def collated(self, ev=None):
+        """ev: the event behind which the current raw set has been read (None: recorded here, on the current stream)."""
+        if ev is None:
+            ev = torch.cuda.Event()
+            ev.record()
+        self._cur["ev_read"] = ev
 
     def publish(self):
         b = self.ts.batch

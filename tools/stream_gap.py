@@ -47,17 +47,40 @@ ts = TrainStep("cuboids", B=32, N=5120, stream_batches=4)
 while ts._graph is None:
     ts.step()
 out["streamed"] = run(ts)
+# where the host's time inside _launch_sampling goes (streamed): per-call wall time of its pieces
+import collections
+acc = collections.defaultdict(list)
+def wrap(obj, name):
+    f = getattr(obj, name)
+    def g(*a, **k):
+        t0 = time.perf_counter(); r = f(*a, **k); acc[name].append(time.perf_counter() - t0); return r
+    setattr(obj, name, g)
+    return f
+saved = [(ts._stream, n, wrap(ts._stream, n)) for n in ("upload", "collate_cloud", "collate_targets", "collated")] + [(ts, n, wrap(ts, n)) for n in ("_sample_levels", "_extras", "_target_aux")]
+import numpy as _np
+_stack = _np.stack
+def tstack(*a, **k):
+    t0 = time.perf_counter(); r = _stack(*a, **k); acc["np.stack"].append(time.perf_counter() - t0); return r
+_np.stack = tstack
+run(ts, 40)
+_np.stack = _stack
+for o, n, f in saved:
+    setattr(o, n, f)
+out["host_pieces_ms"] = {k: round(sum(v) / len(v) * 1e3, 3) for k, v in acc.items()}
 st = ts._stream
-real = st.collate_next
-def no_host():
-    return st.stage["point_cloud"], st.stage_starts
-st.collate_next = no_host
+real = (st.collate_cloud, st.collate_targets, st.collated, st.prefetch)
+st.collate_cloud = lambda: (st.stage["point_cloud"], st.stage_starts)
+st.collate_targets = lambda: None
+st.collated = lambda *e: None
+st.prefetch = lambda: None
 out["streamed_without_collation"] = run(ts)
-st.collate_next = real
+st.collate_cloud, st.collate_targets, st.collated, st.prefetch = real
 # host pieces of one collation, alone
 t0 = time.perf_counter()
 for _ in range(20):
+    st.upload()
     st.collate_next()
+    st.collated()
 torch.cuda.synchronize()
-out["collate_next_alone_ms"] = (time.perf_counter() - t0) / 20 * 1e3
+out["upload_and_collate_alone_ms"] = (time.perf_counter() - t0) / 20 * 1e3
 print(json.dumps(out))
