@@ -627,9 +627,23 @@ __device__ __forceinline__ void mma_chunk_pipelined(const float* sA, const float
 // accumulator register r of this lane -> row inside a 32-row MFMA tile
 __device__ __forceinline__ int acc_row_in_tile(int r) { return (r & 3) + 8 * (r >> 2) + 4 * ((threadIdx.x & 63) >> 5); }
 
+// EPI_SQ_POOL (last forward layer, group size K in {32, 64, 128}): besides Z and the BatchNorm sums the epilogue
+// reduces every group of K rows to (max, argmax, min, argmin) of the RAW z per channel -- the max-pool commutes with
+// the monotone map z -> relu(z*scale + shift), max for scale >= 0, min for scale < 0 -- so the pooled output needs no
+// second pass over Z once the batch statistics are known (pool_select_kernel).
+struct PoolOut {
+    float* vmax;  // [P/K, N]
+    float* vmin;
+    int* imax;
+    int* imin;
+    int K;
+};
+
 }  // namespace
 
 // sa_stream16.hip ([r5] one-plane bf16 position-stream kernels): 1 = launched, 0 = no kernel for this shape, < 0 = error.  dz / in point at
 // PosOperand, partials at BnOut.
-int mp_s16_bwd_launch(int pooled, int Co, int Ci, const void* dz, const void* in, int64_t P, int ppb, const float* W, float* dW, float* G,
+int mp_s16_bwd_launch(int pooled, int rc_in, int Co, int Ci, const void* dz, const void* in, int64_t P, int ppb, const float* W, float* dW, float* G,
                       const void* partials, const char* tag, double flops, double bytes, hipStream_t stream);
+int mp_s16_fwd_launch(int pool, int rc_in, int Ci, int Co, const void* a, int64_t P, int ppb, const float* W, float* Z, const void* partials,
+                      const void* po, const float* gamma, const char* tag, double flops, double bytes, hipStream_t stream);

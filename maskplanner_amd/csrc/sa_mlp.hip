@@ -37,17 +37,6 @@ namespace {
 // =================================================================================================================
 enum Epi { EPI_NONE = 0, EPI_SQ = 1, EPI_DY = 2, EPI_SQ_POOL = 3 };
 
-// EPI_SQ_POOL (last forward layer, group size K in {32, 64, 128}): besides Z and the BatchNorm sums the epilogue
-// reduces every group of K rows to (max, argmax, min, argmin) of the RAW z per channel -- the max-pool commutes with
-// the monotone map z -> relu(z*scale + shift), max for scale >= 0, min for scale < 0 -- so the pooled output needs no
-// second pass over Z once the batch statistics are known (pool_select_kernel).
-struct PoolOut {
-    float* vmax;  // [P/K, N]
-    float* vmin;
-    int* imax;
-    int* imin;
-    int K;
-};
 
 template <int MODE, bool W_KROW, int EPI, int WAVES_M, int WAVES_N, int TM, int TN, int PREC = 0>   // PREC: 0 fp32 MFMA, 1 bf16, 3 split (h, m, l) planes
 __global__ __launch_bounds__(THREADS) void pos_gemm_kernel(PosOperand A, int P, const float* __restrict__ W, int N,
@@ -3030,7 +3019,15 @@ static int sa_mlp_fwd(const float* x0, int64_t P, int64_t K, int n_layers, const
             const double fl = 2.0 * (double)P * Co_ * Ci_, by = 4.0 * ((double)P * 4 + (double)Co_ * Ci_) + (store16 ? 2.0 : 4.0) * (double)P * Co_;
             char tg[64];
             snprintf(tg, sizeof tg, "fwd_chunk_kernel<%d, %d, false, 4>", Ci_, Co_);
-            if (bf16 && Co_ == 64)
+            int rc16 = 0;
+            if (bf16 && store16) {      // [r5] sa_stream16.hip
+                char tg16[64];
+                snprintf(tg16, sizeof tg16, "fwd_stream16_kernel<%d, %d, false, 4>", Ci_, Co_);
+                rc16 = mp_s16_fwd_launch(0, 1, Ci_, Co_, &A, P, ppb, L.weight, L.z, &partials, &po, L.gamma, tg16, fl, by, stream);
+                if (rc16 < 0) return rc16;
+            }
+            if (rc16 == 1) {
+            } else if (bf16 && Co_ == 64)
                 MP_LAUNCH("fwd_chunk_bf16_kernel<64, 64, false, 4>", fl, by, (fwd_chunk_kernel<64, 64, false, SRC_ACT_RC, 0, true, true, true>), dim3(gx), dim3(256), 0, stream, A, (int)P, ppb, L.weight, L.z, partials, po, L.gamma);
             else if (bf16)
                 MP_LAUNCH("fwd_chunk_bf16_kernel<64, 128, false, 4>", fl, by, (fwd_chunk_kernel<64, 128, false, SRC_ACT_RC, 0, true, true, true>), dim3(gx), dim3(256), 0, stream, A, (int)P, ppb, L.weight, L.z, partials, po, L.gamma);
@@ -3054,6 +3051,13 @@ static int sa_mlp_fwd(const float* x0, int64_t P, int64_t K, int n_layers, const
             const double fl = 2.0 * (double)P * Co_ * Ci_, by = eb * (double)P * (Ci_ + Co_) + 4.0 * (double)Co_ * Ci_;
             char tg[64];
             snprintf(tg, sizeof tg, bf16 ? "fwd_chunk_bf16_kernel<%d, %d, %s>" : "fwd_chunk_kernel<%d, %d, %s>", Ci_, Co_, fuse_pool ? "true" : "false");
+            int rc16 = 0;
+            if (bf16 && store16) {      // [r5] sa_stream16.hip
+                char tg16[64];
+                snprintf(tg16, sizeof tg16, "fwd_stream16_kernel<%d, %d, %s>", Ci_, Co_, fuse_pool ? "true" : "false");
+                rc16 = mp_s16_fwd_launch(fuse_pool ? 1 : 0, 0, Ci_, Co_, &A, P, ppb, L.weight, L.z, &partials, &po, L.gamma, tg16, fl, by, stream);
+                if (rc16 < 0) return rc16;
+            }
 #define MP_FWD(CI, CO, PL)                                                                                                     \
     MP_LAUNCH(tg, fl, by, (fwd_chunk_kernel<CI, CO, PL>), dim3(gx), dim3(CO > 128 ? 512 : 256), 0, stream, A, (int)P, ppb, L.weight, L.z, \
               partials, po, L.gamma)
@@ -3068,7 +3072,8 @@ static int sa_mlp_fwd(const float* x0, int64_t P, int64_t K, int n_layers, const
     if (Co_ == 64) { if (bf16) MP_FWD_SPLIT(CI, 64, PL); else MP_FWD(CI, 64, PL); }                     \
     else if (Co_ == 128) { if (split_enabled() || bf16) MP_FWD_SPLIT(CI, 128, PL); else MP_FWD(CI, 128, PL); }              \
     else { if (split_enabled() || bf16) MP_FWD_SPLIT(CI, 256, PL); else MP_FWD(CI, 256, PL); }
-            if (fuse_pool) { if (Ci_ == 64) { MP_FWD_CO(64, true); } else { MP_FWD_CO(128, true); } }
+            if (rc16 == 1) {
+            } else if (fuse_pool) { if (Ci_ == 64) { MP_FWD_CO(64, true); } else { MP_FWD_CO(128, true); } }
             else { if (Ci_ == 64) { MP_FWD_CO(64, false); } else { MP_FWD_CO(128, false); } }
 #undef MP_FWD_CO
 #undef MP_FWD_SPLIT
@@ -3378,11 +3383,13 @@ static int sa_mlp_bwd(const float* x0, int64_t P, int64_t K, int n_layers, const
     else                                                                                                                      \
         MP_LAUNCH(tg, fl, by, (bwd_fused_kernel<MODE, CO_, CI_>), dim3(gx), dim3(bwd_fused_threads(CO_, CI_, false, false)), 0, stream, DZ, IN, (int)P, ppb, Ly.weight, \
                   grads[l].d_weight, Gn, partials)
-            if (bf16 && store16 && !(rc_first && l == 1)) {
+            if (bf16 && store16) {
                 // [r5] the kernels written for one plane and bf16 storage (sa_stream16.hip: rows straight into an LDS ring)
                 char tg16[64];
-                snprintf(tg16, sizeof tg16, "bwd_stream16_kernel<%d, %d, %d>", pooled ? 3 : 2, Co, Ci);
-                const int rc16 = mp_s16_bwd_launch(pooled ? 1 : 0, Co, Ci, &DZ, &IN, P, ppb, Ly.weight, grads[l].d_weight, Gn, &partials, tg16, fl, by, stream);
+                const bool rc_in = rc_first && l == 1;
+                snprintf(tg16, sizeof tg16, rc_in ? "bwd_stream16_kernel<%d, %d, %d, 4>" : "bwd_stream16_kernel<%d, %d, %d>", pooled ? 3 : 2, Co, Ci);
+                const int rc16 = mp_s16_bwd_launch(pooled ? 1 : 0, rc_in ? 1 : 0, Co, Ci, &DZ, &IN, P, ppb, Ly.weight, grads[l].d_weight, Gn, &partials, tg16,
+                                                   fl, rc_in ? by - eb * (double)P * Ci + 16.0 * (double)P : by, stream);
                 if (rc16 < 0) return rc16;
                 if (rc16 == 1) {
                     if (int rc = finalize_bwd(l - 1, (int)gx, Ci)) return rc;

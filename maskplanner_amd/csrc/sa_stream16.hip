@@ -51,6 +51,9 @@ __device__ __forceinline__ float4 bf4_to_f4(const uint2 u)
     return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
 }
 
+#ifndef MP_S16_FRING
+#define MP_S16_FRING 3         // raw slots of the forward kernels' ring
+#endif
 #ifndef MP_S16_RING
 #define MP_S16_RING 3          // raw slots of the pooled layers' ring (the dense layers stage Z and G: two slots)
 #endif
@@ -60,23 +63,25 @@ constexpr int s16_threads(int CO) { return CO == 256 ? 512 : 256; }
 // dX + dW + the BatchNorm-backward sums of layer l - 1 in one pass over dZ_l (sa_mlp.hip: bwd_fused_kernel), bf16 storage, one plane.
 //   DZ.x: Z_l [P, CO] bf16;  pooled: DZ.g [P / K, CO] fp32 (relu-masked pooled gradient), DZ.argk [P / K, CO] int32;  dense: DZ.g = G_l [P, CO] bf16
 //   IN.x: Z_{l-1} [P, CI] bf16 (+ its scale / shift);  W [CO, CI] fp32;  G: G_{l-1} [P, CI] bf16 out;  dW [CO, CI] fp32 += (atomics)
-template <int MODE_DZ, int CO, int CI>
+//   MODE_IN = SRC_ACT_RC: the input layer is the level's RECOMPUTED first layer (sa_mlp.hip: *_RC): IN.rx = the level's input rows [P, 4] fp32,
+//   IN.rw = W_0 [CI, 4]; z_{l-1}[p][c] = dot4_rc(rx[p], rw[c]) is formed while staging (and again in the epilogue's sums), never read.
+template <int MODE_DZ, int CO, int CI, int MODE_IN = SRC_ACT>
 __global__ __launch_bounds__(s16_threads(CO), CO == 256 ? 1 : 2) void bwd_stream16_kernel(PosOperand DZ, PosOperand IN, int P, int p_per_block,
                                                                                           const float* __restrict__ W, float* __restrict__ dW,
                                                                                           float* __restrict__ G, BnOut partials)
 {
-    constexpr bool POOLED = MODE_DZ == SRC_DZ_POOLED;
-    static_assert(MODE_DZ == SRC_DZ || POOLED, "dZ operand");
+    constexpr bool POOLED = MODE_DZ == SRC_DZ_POOLED, RC = MODE_IN == SRC_ACT_RC;
+    static_assert((MODE_DZ == SRC_DZ || POOLED) && (MODE_IN == SRC_ACT || RC), "operands");
     constexpr int NT = s16_threads(CO), NW = NT / 64, DBK = 32, GS = DBK * 8;
     constexpr int R = POOLED ? MP_S16_RING : 2;
-    constexpr int RBA = CO * 2, RBB = CI * 2;                       // bytes of a raw row
+    constexpr int RBA = CO * 2, RBB = RC ? 32 : CI * 2;             // bytes of a raw row (RC: 16-byte input rows, the slot padded to one 1 KB load)
     constexpr int NBA = CO / 64, NBB = CI / 64;                     // 64-channel blocks of a row: one staging pass of a wave = 4 rows x one block
     constexpr int KA_STEP = 4 * (NW / NBA), KB_STEP = 4 * (NW / NBB);
     constexpr int PA = DBK / KA_STEP, PB = DBK / KB_STEP;           // staging passes per wave and chunk
     constexpr int TMW = CO / (32 * (NW / 2)), TNW = CI / 64;        // 32 x 32 dW tiles per wave (waves (NW / 2) x 2)
     constexpr int HT = CI / (16 * NW);                              // 16-column dX tiles per wave (both 16-row tiles of the chunk)
     constexpr int NST = CO / 32;                                    // k-steps of the dX product
-    constexpr int LZ = DBK * RBA / 1024 / NW, LI = DBK * RBB / 1024 / NW;   // 1 KB load instructions per wave and chunk
+    constexpr int LZ = DBK * RBA / 1024 / NW, LI = RC ? 1 : DBK * RBB / 1024 / NW;   // 1 KB load instructions per wave and chunk (RC: every wave, same bytes)
     constexpr int LPI = (CO / 2 + 63) / 64;                         // pooled: (gradient | arg-max) of the chunk's group, every wave (same bytes)
     constexpr int LD = LZ * (POOLED ? 1 : 2) + LI + (POOLED ? LPI : 0);
     constexpr int ST = 4 * HT;                                      // G stores per wave and chunk
@@ -115,12 +120,18 @@ __global__ __launch_bounds__(s16_threads(CO), CO == 256 ? 1 : 2) void bwd_stream
             glds16(zsrc + (size_t)pr * RBA + u * 16, rawZ[slot] + (wave * LZ + j) * 1024);
             if constexpr (!POOLED) glds16(gsrc + (size_t)pr * RBA + u * 16, rawG[slot] + (wave * LZ + j) * 1024);
         }
-#pragma unroll
-        for (int j = 0; j < LI; ++j) {
-            const int s = (wave * LI + j) * 64 + lane;
-            const int row = s / UB, u = (s % UB) ^ raw_swz<RBB>(row);
+        if constexpr (RC) {
+            const int row = lane & 31;                              // 32 rows x 16 bytes (lanes 32..63 repeat them into the slot's second half)
             const int pr = pk + row < p1 ? pk + row : p0;
-            glds16(isrc + (size_t)pr * RBB + u * 16, rawI[slot] + (wave * LI + j) * 1024);
+            glds16(reinterpret_cast<const unsigned char*>(IN.rx) + (size_t)pr * 16, rawI[slot]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < LI; ++j) {
+                const int s = (wave * LI + j) * 64 + lane;
+                const int row = s / UB, u = (s % UB) ^ raw_swz<RBB>(row);
+                const int pr = pk + row < p1 ? pk + row : p0;
+                glds16(isrc + (size_t)pr * RBB + u * 16, rawI[slot] + (wave * LI + j) * 1024);
+            }
         }
         if constexpr (POOLED) {
             const size_t grow = (size_t)((unsigned)pk >> DZ.kshift) * CO;      // the chunk lies inside one group (K = 2^kshift >= 32)
@@ -143,7 +154,7 @@ __global__ __launch_bounds__(s16_threads(CO), CO == 256 ? 1 : 2) void bwd_stream
     const int ca = (wave % NBA) * 64 + 4 * cq, ka0 = (wave / NBA) * 4 + prw;
     const int cb = (wave % NBB) * 64 + 4 * cq, kb0 = (wave / NBB) * 4 + prw;
     ChanConst ka, kb;
-    load_consts<SRC_ACT>(IN, cb, kb);
+    load_consts<MODE_IN>(IN, cb, kb);
     // dW tiles of this wave
     const int l31 = lane & 31;
     const int wrow0 = (wave >> 1) * TMW * 32, wcol0 = (wave & 1) * TNW * 32;
@@ -169,12 +180,14 @@ __global__ __launch_bounds__(s16_threads(CO), CO == 256 ? 1 : 2) void bwd_stream
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     typedef float f2 __attribute__((ext_vector_type(2)));
     float spx[HT], tpx[HT];
+    float4 w0c[RC ? HT : 1];                                       // RC: W_0 row of this lane's G column
     f2 sx1[HT], sx2[HT];
 #pragma unroll
     for (int h = 0; h < HT; ++h) {
         const int col = xcol0 + 16 * h + l15;
         spx[h] = IN.s[col];
         tpx[h] = IN.t[col];
+        if constexpr (RC) w0c[h] = ld4(IN.rw + (size_t)col * 4);
         sx1[h] = f2{0.0f, 0.0f};
         sx2[h] = f2{0.0f, 0.0f};
     }
@@ -228,8 +241,14 @@ __global__ __launch_bounds__(s16_threads(CO), CO == 256 ? 1 : 2) void bwd_stream
 #pragma unroll
             for (int ps = 0; ps < PB; ++ps) {
                 const int row = kb0 + ps * KB_STEP;
-                const int ro = row * RBB + (((cb >> 3) ^ raw_swz<RBB>(row)) * 16) + (cq & 1) * 8;
-                const float4 z = bf4_to_f4(*reinterpret_cast<const uint2*>(&rawI[slot][ro]));
+                float4 z;
+                if constexpr (RC) {
+                    const float4 xr = *reinterpret_cast<const float4*>(&rawI[slot][row * 16]);
+                    z = make_float4(dot4_rc(xr, kb.w[0]), dot4_rc(xr, kb.w[1]), dot4_rc(xr, kb.w[2]), dot4_rc(xr, kb.w[3]));
+                } else {
+                    const int ro = row * RBB + (((cb >> 3) ^ raw_swz<RBB>(row)) * 16) + (cq & 1) * 8;
+                    z = bf4_to_f4(*reinterpret_cast<const uint2*>(&rawI[slot][ro]));
+                }
                 float4 x;
                 x.x = xf1<SRC_ACT>(z.x, 0.f, kb.s.x, kb.t.x, 0.f, 0.f, 0.f);
                 x.y = xf1<SRC_ACT>(z.y, 0.f, kb.s.y, kb.t.y, 0.f, 0.f, 0.f);
@@ -278,9 +297,15 @@ __global__ __launch_bounds__(s16_threads(CO), CO == 256 ? 1 : 2) void bwd_stream
                     __builtin_amdgcn_raw_buffer_store_b32(odd ? pack_bf16(got, ax[h][i + 1]) : pack_bf16(ax[h][i], got), grsrc,
                                                           goff + (16 * rt * CI + 16 * h) * 2, i * CI * 2, MP_STORE_AUX);
                     const int r0 = 16 * rt + 4 * kq + i, r1 = r0 + 1;
-                    const unsigned short z0 = *reinterpret_cast<const unsigned short*>(&rawI[slot][r0 * RBB + (((col >> 3) ^ raw_swz<RBB>(r0)) * 16) + (col & 7) * 2]);
-                    const unsigned short z1 = *reinterpret_cast<const unsigned short*>(&rawI[slot][r1 * RBB + (((col >> 3) ^ raw_swz<RBB>(r1)) * 16) + (col & 7) * 2]);
-                    const f2 zp = {__uint_as_float((unsigned)z0 << 16), __uint_as_float((unsigned)z1 << 16)};
+                    f2 zp;
+                    if constexpr (RC) {
+                        zp = f2{dot4_rc(*reinterpret_cast<const float4*>(&rawI[slot][r0 * 16]), w0c[h]),
+                                dot4_rc(*reinterpret_cast<const float4*>(&rawI[slot][r1 * 16]), w0c[h])};
+                    } else {
+                        const unsigned short z0 = *reinterpret_cast<const unsigned short*>(&rawI[slot][r0 * RBB + (((col >> 3) ^ raw_swz<RBB>(r0)) * 16) + (col & 7) * 2]);
+                        const unsigned short z1 = *reinterpret_cast<const unsigned short*>(&rawI[slot][r1 * RBB + (((col >> 3) ^ raw_swz<RBB>(r1)) * 16) + (col & 7) * 2]);
+                        zp = f2{__uint_as_float((unsigned)z0 << 16), __uint_as_float((unsigned)z1 << 16)};
+                    }
                     const f2 y = zp * f2{spx[h], spx[h]} + f2{tpx[h], tpx[h]};
                     const f2 dy = {y.x > 0.0f ? ax[h][i] : 0.0f, y.y > 0.0f ? ax[h][i + 1] : 0.0f};
                     sx1[h] += dy;
@@ -321,11 +346,204 @@ __global__ __launch_bounds__(s16_threads(CO), CO == 256 ? 1 : 2) void bwd_stream
         }
 }
 
+
+// Forward layer Z_l = act(Z_{l-1}) W_l^T of the position stream (sa_mlp.hip: fwd_chunk_kernel), bf16 storage, one plane: the input rows through
+// the ring, BN + ReLU while staging into a row-major bf16 plane, W_l as one plane in registers; epilogue = bf16 store of Z_l, the layer's
+// BatchNorm sums (fp32 per chunk, fp64 across), and for the pooled layer the group's extremum per column (max-pool commutes with the
+// monotone BN + ReLU: one tracked extremum, chosen by the sign of gamma).
+//   A.x: Z_{l-1} [P, CI] bf16 (MODE_A = SRC_ACT) | A.rx: input rows [P, 4] fp32, A.rw: W_0 [CI, 4] (SRC_ACT_RC);  W [CO, CI] fp32;  Z [P, CO] bf16
+template <int CI, int CO, bool POOL, int MODE_A = SRC_ACT>
+__global__ __launch_bounds__(s16_threads(CO), CO == 256 ? 1 : 2) void fwd_stream16_kernel(PosOperand A, int P, int p_per_block, const float* __restrict__ W,
+                                                                                          float* __restrict__ Z, BnOut partials, PoolOut po,
+                                                                                          const float* __restrict__ gamma)
+{
+    bn_zero(partials);
+    constexpr bool RC = MODE_A == SRC_ACT_RC;
+    static_assert(MODE_A == SRC_ACT || RC, "input operand");
+    constexpr int NT = s16_threads(CO), NW = NT / 64, DBK = 32;
+    constexpr int CW = CO / NW;                       // columns per wave: 32 (one 32x32 tile) or 16 (two 16x16 row tiles)
+    constexpr bool BIG = CW == 32;
+    static_assert(CW == 32 || CW == 16, "shape");
+    constexpr int R = MP_S16_FRING;
+    constexpr int RB = RC ? 32 : CI * 2;              // bytes of a raw row (RC: the slot padded to one 1 KB load)
+    constexpr int LI = RC ? 1 : DBK * RB / 1024 / NW; // 1 KB load instructions per wave and chunk
+    constexpr int NV = BIG ? 16 : 8;                  // rows of the chunk held by one lane
+    constexpr int SV = NV / 2;                        // Z stores per wave and chunk (the pool's stores at a group's end come on top: the wait
+                                                      // counts assume the fewer -- waiting for one or two operations more is always safe)
+    constexpr int LDH = CI + 8;                       // plane row stride in halves: 16-byte aligned rows, conflict-free 16-byte fragment reads
+    constexpr int KST = BIG ? 16 : 32;
+    constexpr int PA = DBK * CI / 4 / NT;             // channel quads staged per thread and chunk
+    static_assert(LI >= 1 && PA >= 1 && (R == 2 || R == 3 || R == 4), "shape");
+    static_assert((R - 2) * LI + (R - 1) * SV < 64, "vmcnt");
+
+    __shared__ __attribute__((aligned(16))) unsigned char raw[R][RC ? 1024 : DBK * RB];
+    __shared__ __attribute__((aligned(16))) __bf16 sH[DBK * LDH];
+    __shared__ __attribute__((aligned(16))) float bn_lds[2 * CI];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lc = BIG ? (lane & 31) : (lane & 15);
+    const int kq = BIG ? (lane >> 5) : (lane >> 4);
+    const int col = wave * CW + lc;
+    const int p0 = blockIdx.x * p_per_block;
+    const int p1 = min(P, p0 + p_per_block);
+    const int nchunks = (p1 - p0 + DBK - 1) / DBK;
+    if (nchunks <= 0) return;
+    const unsigned char* xsrc = reinterpret_cast<const unsigned char*>(RC ? A.rx : A.x);
+
+    auto issue = [&](int c) {
+        const int slot = c % R;
+        const int pk = p0 + c * DBK;
+        if constexpr (RC) {
+            const int row = lane & 31;
+            const int pr = pk + row < p1 ? pk + row : p0;
+            glds16(xsrc + (size_t)pr * 16, raw[slot]);
+        } else {
+            constexpr int U = RB / 16;
+#pragma unroll
+            for (int j = 0; j < LI; ++j) {
+                const int s = (wave * LI + j) * 64 + lane;
+                const int row = s / U, u = s % U;
+                const int pr = pk + row < p1 ? pk + row : p0;
+                glds16(xsrc + (size_t)pr * RB + u * 16, raw[slot] + (wave * LI + j) * 1024);
+            }
+        }
+    };
+#pragma unroll
+    for (int c = 0; c < R - 1; ++c) issue(c < nchunks ? c : nchunks - 1);
+
+    // W_l^T fragments, one plane: lane (n = col, kq) holds W[col][KST st + 8 kq .. + 7]
+    bf16x8 wsp[CI / KST];
+#pragma unroll
+    for (int st = 0; st < CI / KST; ++st) {
+        const float* wp = W + (size_t)col * CI + KST * st + 8 * kq;
+        const float4 lo = ld4(wp), hi = ld4(wp + 4);
+        wsp[st][0] = (__bf16)lo.x; wsp[st][1] = (__bf16)lo.y; wsp[st][2] = (__bf16)lo.z; wsp[st][3] = (__bf16)lo.w;
+        wsp[st][4] = (__bf16)hi.x; wsp[st][5] = (__bf16)hi.y; wsp[st][6] = (__bf16)hi.z; wsp[st][7] = (__bf16)hi.w;
+    }
+    const int ca = (tid % (CI / 4)) * 4, ka0 = tid / (CI / 4);
+    constexpr int KA_STEP = NT / (CI / 4);
+    ChanConst kc;
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    double s1 = 0.0, s2 = 0.0;
+    float gbest = 0.0f;
+    int gibest = 0;
+    const int cpg = POOL ? po.K / DBK : 1;
+    const __amdgpu_buffer_rsrc_t zrsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(Z) + (size_t)p0 * CO * 2, 0, (p1 - p0) * CO * 2, 0x00020000);
+    int zoff = ((4 * kq) * CO + (col & ~1)) * 2 + ((lane & 1) ? CO * 2 : 0);
+    bool neg = false;
+    if constexpr (POOL) neg = gamma[col] < 0.0f;
+    const unsigned smask = neg ? 0x80000000u : 0u;
+
+    bn_prologue(A.bn, bn_lds, CI, 0, CI, blockIdx.x == 0);
+    load_consts<MODE_A>(A, ca, kc, bn_lds, CI);
+
+    for (int kcn = 0; kcn < nchunks; ++kcn) {
+        const int slot = kcn % R;
+        const int pk = p0 + kcn * DBK;
+        if (kcn >= R - 1) wait_vm<(R - 2) * LI + (R - 1) * SV>();
+        else if (R > 2 && kcn == 1) wait_vm<(R - 2) * LI + 1 * SV>();
+        else if (R > 3 && kcn == 2) wait_vm<(R - 2) * LI + 2 * SV>();
+        else wait_vm<(R - 2) * LI>();
+        lds_barrier();                                             // B1: the raw chunk is complete; the plane is free
+        issue(kcn + R - 1 < nchunks ? kcn + R - 1 : nchunks - 1);
+#pragma unroll
+        for (int ps = 0; ps < PA; ++ps) {
+            const int row = ka0 + ps * KA_STEP;
+            float4 z;
+            if constexpr (RC) {
+                const float4 xr = *reinterpret_cast<const float4*>(&raw[slot][row * 16]);
+                z = make_float4(dot4_rc(xr, kc.w[0]), dot4_rc(xr, kc.w[1]), dot4_rc(xr, kc.w[2]), dot4_rc(xr, kc.w[3]));
+            } else {
+                z = bf4_to_f4(*reinterpret_cast<const uint2*>(&raw[slot][row * RB + ca * 2]));
+            }
+            float4 x;
+            x.x = xf1<SRC_ACT>(z.x, 0.f, kc.s.x, kc.t.x, 0.f, 0.f, 0.f);
+            x.y = xf1<SRC_ACT>(z.y, 0.f, kc.s.y, kc.t.y, 0.f, 0.f, 0.f);
+            x.z = xf1<SRC_ACT>(z.z, 0.f, kc.s.z, kc.t.z, 0.f, 0.f, 0.f);
+            x.w = xf1<SRC_ACT>(z.w, 0.f, kc.s.w, kc.t.w, 0.f, 0.f, 0.f);
+            if (pk + row >= p1) x = make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<bf16x4*>(&sH[row * LDH + ca]) = to_bf16x4(x);
+        }
+        lds_barrier();                                             // B2: the plane is complete
+
+        float v[NV];
+        if constexpr (BIG) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+            const int ao = (lane & 31) * LDH + 8 * kq;                // A[row = lane & 31][k = 16 st + 8 kq .. + 7]
+#pragma unroll
+            for (int st = 0; st < CI / 16; ++st)
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&sH[ao + 16 * st]), wsp[st], acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = acc[r];               // rows (r & 3) + 8 (r >> 2) + 4 kq
+        } else {
+            f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+            const int ao = lc * LDH + 8 * kq;                         // A[row = 16 rt + lc][k = 32 st + 8 kq .. + 7]
+#pragma unroll
+            for (int st = 0; st < CI / 32; ++st) {
+                a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&sH[ao + 32 * st]), wsp[st], a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&sH[ao + 16 * LDH + 32 * st]), wsp[st], a1, 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { v[i] = a0[i]; v[4 + i] = a1[i]; }   // rows 4 kq + i and 16 + 4 kq + i
+        }
+        auto rowc = [](int r) { return BIG ? (r & 3) + 8 * (r >> 2) : (r < 4 ? r : 16 + (r - 4)); };
+        f2 c1 = {0.0f, 0.0f}, c2 = {0.0f, 0.0f};
+        float lbest = -__builtin_inff();
+        int libest = 0;
+#pragma unroll
+        for (int r = 0; r < NV; r += 2) {
+            const bool odd = lane & 1;
+            const float got = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(odd ? v[r] : v[r + 1]), 0xB1, 0xf, 0xf, true));   // lane ^ 1
+            __builtin_amdgcn_raw_buffer_store_b32(odd ? pack_bf16(got, v[r + 1]) : pack_bf16(v[r], got), zrsrc, zoff, rowc(r) * CO * 2, MP_STORE_AUX);
+            const f2 x = {v[r], v[r + 1]};
+            c1 += x;
+            c2 += x * x;
+            if constexpr (POOL) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const float t = __uint_as_float(__float_as_uint(v[r + u]) ^ smask);   // -x where the column pools its minimum
+                    if (t > lbest) { lbest = t; libest = rowc(r + u); }                    // strict: the first extremum stays
+                }
+            }
+        }
+        zoff += DBK * CO * 2;
+        s1 += (double)(c1.x + c1.y);
+        s2 += (double)(c2.x + c2.y);
+        if constexpr (POOL) {
+            libest += 4 * kq;
+#pragma unroll
+            for (int d = BIG ? 32 : 16; d <= 32; d <<= 1) {
+                const float ox = __shfl_xor(lbest, d, 64);
+                const int oix = __shfl_xor(libest, d, 64);
+                if (ox > lbest || (ox == lbest && oix < libest)) { lbest = ox; libest = oix; }
+            }
+            const int cig = kcn % cpg;                // chunk inside its group (p0 is a multiple of K)
+            if (cig == 0 || lbest > gbest) { gbest = lbest; gibest = cig * DBK + libest; }   // earlier chunk wins ties
+            if (cig == cpg - 1 && kq == 0) {
+                const size_t o = (size_t)((unsigned)(pk / po.K) * (unsigned)CO + (unsigned)col);
+                const float val = __uint_as_float(__float_as_uint(gbest) ^ smask);
+                if (neg) { po.vmin[o] = val; po.imin[o] = gibest; }
+                else { po.vmax[o] = val; po.imax[o] = gibest; }
+            }
+        }
+    }
+    wait_vm<0>();
+#pragma unroll
+    for (int d = BIG ? 32 : 16; d <= 32; d <<= 1) {
+        s1 += __shfl_xor(s1, d, 64);
+        s2 += __shfl_xor(s2, d, 64);
+    }
+    if (kq == 0) bn_emit(partials, CO, blockIdx.x, col, s1, s2);
+}
+
 }  // namespace
 
 // ---- launchers (called from sa_mlp.hip's level drivers; operands by pointer: the structs' layout is sa_common.h's) --------------------
 // Returns 1 when the shape has a kernel here (and it was launched), 0 when not, < 0 on a launch error.
-int mp_s16_bwd_launch(int pooled, int Co, int Ci, const void* dz_, const void* in_, int64_t P, int ppb, const float* W, float* dW, float* G,
+int mp_s16_bwd_launch(int pooled, int rc_in, int Co, int Ci, const void* dz_, const void* in_, int64_t P, int ppb, const float* W, float* dW, float* G,
                       const void* partials_, const char* tag, double flops, double bytes, hipStream_t stream)
 {
     const PosOperand& DZ = *static_cast<const PosOperand*>(dz_);
@@ -341,12 +559,18 @@ int mp_s16_bwd_launch(int pooled, int Co, int Ci, const void* dz_, const void* i
     if (partials.slots)
         while (ppb < 4096 && P / (2 * ppb) >= 1024) ppb *= 2;
     const unsigned gx = (unsigned)((P + ppb - 1) / ppb);
-#define MP_S16(MODE, CO_, CI_)                                                                                                     \
+#define MP_S16(MODE, CO_, CI_, ...)                                                                                                \
     do {                                                                                                                           \
-        MP_LAUNCH(tag, flops, bytes, (bwd_stream16_kernel<MODE, CO_, CI_>), dim3(gx), dim3(s16_threads(CO_)), 0, stream, DZ, IN, (int)P, \
+        MP_LAUNCH(tag, flops, bytes, (bwd_stream16_kernel<MODE, CO_, CI_, ##__VA_ARGS__>), dim3(gx), dim3(s16_threads(CO_)), 0, stream, DZ, IN, (int)P, \
                   ppb, W, dW, G, partials);                                                                                        \
         return hipGetLastError() == hipSuccess ? 1 : MP_ELAUNCH;                                                                   \
     } while (0)
+    if (rc_in) {        // the layer behind a recomputed first layer (never the pooled one)
+        if (pooled || !IN.rx || !IN.rw) return 0;
+        if (Co == 128 && Ci == 64) MP_S16(SRC_DZ, 128, 64, SRC_ACT_RC);
+        if (Co == 64 && Ci == 64) MP_S16(SRC_DZ, 64, 64, SRC_ACT_RC);
+        return 0;
+    }
     if (pooled) {
         if (Co == 128 && Ci == 128) MP_S16(SRC_DZ_POOLED, 128, 128);
         if (Co == 256 && Ci == 128) MP_S16(SRC_DZ_POOLED, 256, 128);
@@ -358,5 +582,44 @@ int mp_s16_bwd_launch(int pooled, int Co, int Ci, const void* dz_, const void* i
         if (Co == 64 && Ci == 64) MP_S16(SRC_DZ, 64, 64);
     }
 #undef MP_S16
+    return 0;
+}
+
+int mp_s16_fwd_launch(int pool, int rc_in, int Ci, int Co, const void* a_, int64_t P, int ppb, const float* W, float* Z, const void* partials_,
+                      const void* po_, const float* gamma, const char* tag, double flops, double bytes, hipStream_t stream)
+{
+    const PosOperand& A = *static_cast<const PosOperand*>(a_);
+    const BnOut& partials = *static_cast<const BnOut*>(partials_);
+    const PoolOut& po = *static_cast<const PoolOut*>(po_);
+    {
+        const char* e = getenv("MP_S16");
+        if (e && (atoi(e) == 0 || atoi(e) == 2)) return 0;         // MP_S16=2: the backward kernels only
+    }
+    if (pool && (po.K < 32 || (po.K & 31) || (ppb % po.K))) return 0;
+    if (rc_in && (!A.rx || !A.rw)) return 0;
+    const unsigned gx = (unsigned)((P + ppb - 1) / ppb);
+#define MP_S16F(CI_, CO_, POOL_, ...)                                                                                              \
+    do {                                                                                                                           \
+        MP_LAUNCH(tag, flops, bytes, (fwd_stream16_kernel<CI_, CO_, POOL_, ##__VA_ARGS__>), dim3(gx), dim3(s16_threads(CO_)), 0, stream, A, (int)P, ppb, \
+                  W, Z, partials, po, gamma);                                                                                      \
+        return hipGetLastError() == hipSuccess ? 1 : MP_ELAUNCH;                                                                   \
+    } while (0)
+    if (rc_in) {
+        if (pool) return 0;
+        if (Ci == 64 && Co == 128) MP_S16F(64, 128, false, SRC_ACT_RC);
+        if (Ci == 64 && Co == 64) MP_S16F(64, 64, false, SRC_ACT_RC);
+        return 0;
+    }
+    if (pool) {
+        if (Ci == 128 && Co == 128) MP_S16F(128, 128, true);
+        if (Ci == 128 && Co == 256) MP_S16F(128, 256, true);
+        if (Ci == 64 && Co == 128) MP_S16F(64, 128, true);
+        if (Ci == 64 && Co == 64) MP_S16F(64, 64, true);
+    } else {
+        if (Ci == 128 && Co == 128) MP_S16F(128, 128, false);
+        if (Ci == 64 && Co == 128) MP_S16F(64, 128, false);
+        if (Ci == 64 && Co == 64) MP_S16F(64, 64, false);
+    }
+#undef MP_S16F
     return 0;
 }
