@@ -465,10 +465,10 @@ def main():
                 flops, nbytes = d["flops"] / d["calls"], d["bytes"] / d["calls"]
                 # [r5] the BACKWARD position-stream kernels run two planes / three products per fp32 product (sa_mlp.hip: split2) unless MP_BWD_PLANES=3
                 bwd2 = os.environ.get("MP_BWD_PLANES", "2") != "3" and any(t in k for t in ("bwd_fused", "bwd_roles"))
-                planes = (3.0 if bwd2 else 6.0) if (split and "bf16" not in k and any(t in k for t in ("fused", "roles", "chunk", "bwd_first", "gemm", "lean"))) else 1.0
+                planes = (3.0 if bwd2 else 6.0) if (split and "bf16" not in k and "stream16" not in k and any(t in k for t in ("fused", "roles", "chunk", "bwd_first", "gemm", "lean"))) else 1.0
                 # the matrix-core roof is the one the kernel's INSTRUCTIONS run under: bf16 dense peak for the plane products of a split
                 # kernel (`planes` executed bf16 products per algorithmic fp32 product) and for --dtype bf16, the fp32-input MFMA peak otherwise
-                ex_peak = BF16_PEAK_TFLOPS if (planes > 1 or "bf16" in k) else FP32_PEAK_TFLOPS
+                ex_peak = BF16_PEAK_TFLOPS if (planes > 1 or "bf16" in k or "stream16" in k) else FP32_PEAK_TFLOPS      # (stream16: the one-plane bf16 kernels)
                 ex_flops = planes * flops
                 if ex_flops / (ex_peak * 1e12) >= nbytes / (HBM_PEAK_GBS * 1e9):
                     bound, ach, peak, unit = "mfma", ex_flops / avg_s / 1e12, ex_peak, "TFLOP/s"

@@ -251,20 +251,13 @@ class TrainStep:
         # waits for the plan instead (0.45 ms under the tracer).  So: the first level's FPS, then graph A, then the rest of the plan.
         # The single-scale encoder's ~10 launches keep the old order (same step time either way: NOTEBOOK.md).
         late = self.overlap and self._graph is not None and self._plan_cur is not None and self.SAMPLING_BEHIND_A and self._stream is None
-        # (streamed inputs, MASKPLANNER_STREAM_BEHIND_A=1: the ordering point is taken here, the collation + plan are ISSUED behind the replay of
-        # graph A -- their first kernels then do not start in the same instant as graph A's)
-        slate = self.overlap and self._graph is not None and self._plan_cur is not None and self._stream is not None and self.STREAM_BEHIND_A
-        if slate:
-            self._plan_stream.wait_stream(torch.cuda.current_stream())
-        elif self.overlap:
+        if self.overlap:
             # the NEXT batch's plan, on the second stream underneath this step (late: only its first kernel -- the first level's FPS, the
             # long pole of the plan -- before graph A; the other launches behind it)
             self._launch_sampling(phase="head" if late else None)
         if self._graph is not None:
             self._graph.replay()
             if late:
-                self._launch_sampling(phase="tail")
-            if slate:
                 self._launch_sampling(phase="tail")
             if self._graph_b is not None:
                 if self._adam_ev is not None:
@@ -756,21 +749,20 @@ class TrainStep:
         if self._plan_cur is None:
             self._plan_init()
         side = self._plan_stream
+        if self._stream is not None and phase != "tail":
+            with torch.cuda.stream(side):
+                self._stream.prefetch()                          # host items of batch k + 2 -> pinned -> raw device set, BEFORE the wait below
         if phase != "tail":
             side.wait_stream(torch.cuda.current_stream())
         if self._stream is not None:
             # streamed inputs: ONE chain under the step (collation of the cloud -> FPS -> ball queries -> extras -> collation of the targets ->
             # their lengths / planes), device to device: the host-to-device transfer ran a step earlier on the copy stream (_BatchStream).
             # [r5] two chains on two streams (the targets beside the sampling) were measured: 2.38 vs 2.17 ms.
-            self._stream.prefetch()                              # host items of batch k + 2 -> pinned -> raw device set (copy stream)
             with torch.cuda.stream(side):
                 xyz, starts = self._stream.collate_cloud()       # batch k + 1: raw device set -> staging tensors
-                if not self.STREAM_TARGETS_LAST:
-                    self._stream.collate_targets()
                 self._sample_levels(self._plan_next, xyz, starts)
                 self._extras(self._plan_next, xyz)
-                if self.STREAM_TARGETS_LAST:
-                    self._stream.collate_targets()
+                self._stream.collate_targets()
                 self._target_aux(self._plan_next, self._stream.stage)
                 self._plan_ev = torch.cuda.Event()
                 self._plan_ev.record(side)
@@ -788,15 +780,9 @@ class TrainStep:
             self._plan_ev = torch.cuda.Event()
             self._plan_ev.record(side)
 
-    _plan_ev2 = None
-    STREAM_TARGETS_LAST = os.environ.get("MASKPLANNER_STREAM_TARGETS_LAST", "1") != "0"
-    STREAM_BEHIND_A = os.environ.get("MASKPLANNER_STREAM_BEHIND_A", "0") == "1"
-
     def _wait_plan(self):
         if self._plan_ev is not None:
             torch.cuda.current_stream().wait_event(self._plan_ev)    # the next batch's sampling (and collation) is complete
-        if self._plan_ev2 is not None:
-            torch.cuda.current_stream().wait_event(self._plan_ev2)   # ... and its targets' lengths / planes (streamed inputs)
 
     def _hand_over_copies(self):
         """The next plan becomes the step's (one elementwise kernel into the static buffer); with streamed inputs the collated next
@@ -858,8 +844,8 @@ class TrainStep:
 class _BatchStream:
     """Host dataset items -> the step's device batch (TrainStep(stream_batches=K)), as a two-stage pipeline [r5]:
       upload(k+2)    host items -> a pinned set (numpy) -> a RAW device set (flat ragged rows, offsets, FPS start indices) by hipMemcpyAsync on
-                     a copy stream of its own, which waits for nothing but the event behind which that raw set was last read: the PCIe
-                     transfer (7.5 MB per cuboids batch, ~0.15 ms) sits on no chain of the step;
+                     the plan stream, IN FRONT of that stream's wait for step k: the PCIe transfer (7.5 MB per cuboids batch, ~0.15 ms) runs in
+                     the stream's idle tail of step k - 1, on no chain of any step;
       collate(k+1)   on the plan stream, under step k: raw set -> the staging tensors of the step's fixed shapes (csrc/collate.hip's pad
                      kernel, device to device), then FPS / ball queries / target lengths + planes (harness._launch_sampling);
       publish()      staging -> the step's static tensors, the last node of graph B.
@@ -895,12 +881,15 @@ class _BatchStream:
                                   pin_starts=[torch.empty(B, dtype=torch.long).pin_memory() for _ in ts.batch["fps_start"]],
                                   raw_starts=[torch.zeros(B, dtype=torch.long, device=dev) for _ in ts.batch["fps_start"]],
                                   ev_h2d=None, ev_read=None))
-        self.copy_stream = torch.cuda.Stream()
         self.levels_n = [N] + [m.npoint for m in ts._plan_levels()][:-1]
         self._cur = None
 
     def upload(self):
-        """The next host batch into a pinned set and on to its raw device set (copy stream); host-side numpy + seven asynchronous copies."""
+        """The next host batch into a pinned set and on to its raw device set, on the CURRENT stream (host-side numpy + seven asynchronous
+        copies).  The harness calls it on the plan stream BEFORE that stream's wait for the step: the copies then run right behind the
+        previous plan chain, in the stream's idle tail of the previous step, and need no stream or event of their own.  (A fourth busy stream
+        -- a copy stream of its own was the first version -- shares one of this runtime's four hardware queues with another stream of the
+        step: 2.32 ms per step instead of 2.06; GPU_MAX_HW_QUEUES=16 gave 2.10.)"""
         import numpy as np
         items = self.batches[self.n_up % len(self.batches)]
         hs = self.sets[self.n_up % self.NSETS]
@@ -920,18 +909,18 @@ class _BatchStream:
             hs["tot"][k] = tot
         for p_, n in zip(hs["pin_starts"], self.levels_n):      # the reference's draw (pointnet2_utils.py:77)
             p_.copy_(torch.randint(0, n, (B,), dtype=torch.long))
-        with torch.cuda.stream(self.copy_stream):
-            if hs["ev_read"] is not None:
-                self.copy_stream.wait_event(hs["ev_read"])      # the raw set's previous content has been collated
-            hs["raw"]["point_cloud"].copy_(pin["point_cloud"].view_as(hs["raw"]["point_cloud"]), non_blocking=True)
-            for k, _fill in self.KEYS:
-                n = hs["tot"][k] * self.dim[k]
-                hs["raw"][k][:n].copy_(pin[k][:n], non_blocking=True)
-                hs["raw_off"][k].copy_(hs["pin_off"][k], non_blocking=True)
-            for p_, d_ in zip(hs["pin_starts"], hs["raw_starts"]):
-                d_.copy_(p_, non_blocking=True)
-            hs["ev_h2d"] = torch.cuda.Event()
-            hs["ev_h2d"].record(self.copy_stream)
+        cur = torch.cuda.current_stream()
+        if hs["ev_read"] is not None:
+            cur.wait_event(hs["ev_read"])       # the raw set's previous content has been collated (same stream in steady state: no-op)
+        hs["raw"]["point_cloud"].copy_(pin["point_cloud"].view_as(hs["raw"]["point_cloud"]), non_blocking=True)
+        for k, _fill in self.KEYS:
+            n = hs["tot"][k] * self.dim[k]
+            hs["raw"][k][:n].copy_(pin[k][:n], non_blocking=True)
+            hs["raw_off"][k].copy_(hs["pin_off"][k], non_blocking=True)
+        for p_, d_ in zip(hs["pin_starts"], hs["raw_starts"]):
+            d_.copy_(p_, non_blocking=True)
+        hs["ev_h2d"] = torch.cuda.Event()
+        hs["ev_h2d"].record(cur)
 
     def prefetch(self):
         """Keep the upload one batch ahead of the collation (call at the start of a step, before the plan chain is launched)."""

@@ -1,11 +1,12 @@
-# generic same-box A/B of compile-time variants of sa_mlp.hip:  VARS="-DA=0;-DA=1" FILTER="pos_gemm|dw_gemm" [ENVV="MP_X=1"] [TESTS="tests/test_gpu_split.py"] bash tools/sa_variants.sh
+# generic same-box A/B of compile-time variants of sa_mlp.hip (SRC=sa_stream16.hip: of that file):  VARS="-DA=0;-DA=1" FILTER="pos_gemm|dw_gemm" [ENVV="MP_X=1"] [TESTS="tests/test_gpu_split.py"] bash tools/sa_variants.sh
 cd $GRAFT_REPO_ROOT/maskplanner_amd/csrc
-OBJS=$(for f in *.hip; do [ $f != sa_mlp.hip ] && echo $GRAFT_REPO_ROOT/maskplanner_amd/lib/obj/${f%.hip}.o; done)
+SRC=${SRC:-sa_mlp.hip}
+OBJS=$(for f in *.hip; do [ $f != $SRC ] && echo $GRAFT_REPO_ROOT/maskplanner_amd/lib/obj/${f%.hip}.o; done)
 IFS=';' read -ra VV <<< "${VARS}"
 n=0
 for v in "${VV[@]}"; do
   d=/tmp/sv$n; mkdir -p $d
-  hipcc $v -O3 -std=c++17 -fPIC -ffp-contract=off -munsafe-fp-atomics --offload-arch=gfx950 -Wno-unused-function -c sa_mlp.hip -o $d/sa_mlp.o 2>/dev/null &
+  hipcc $v -O3 -std=c++17 -fPIC -ffp-contract=off -munsafe-fp-atomics --offload-arch=gfx950 -Wno-unused-function -c $SRC -o $d/sa_mlp.o 2>/dev/null &
   n=$((n+1))
 done
 wait
