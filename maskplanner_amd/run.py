@@ -15,6 +15,9 @@ Options (before the script name):
                      wrapper and losses on top of the HIP kernels (dropin.MINIMAL)
     --hip-required   (default) fail at start-up if libmaskplanner_hip.so cannot be loaded; --no-hip-check skips the check (import-only dry
                      runs in a container without the library)
+    --fused-adam     opt-in: `torch.optim.Adam(...)` calls of the script default to `fused=True` (train_maskplanner.py:159 passes no such
+                     argument; same update rule, torch's single-kernel implementation: the unchanged loop is bound by host time, and the
+                     foreach Adam over 143 MB of dense gradients is 0.85 ms of it -- 4.4 -> 4.0 ms per step)
 """
 import os
 import runpy
@@ -23,7 +26,7 @@ import sys
 
 def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
-    minimal, check = False, True
+    minimal, check, fused_adam = False, True, False
     while argv and argv[0].startswith("--"):
         opt = argv.pop(0)
         if opt == "--minimal":
@@ -32,6 +35,8 @@ def main(argv=None):
             check = False
         elif opt == "--hip-required":
             check = True
+        elif opt == "--fused-adam":
+            fused_adam = True
         else:
             raise SystemExit(f"maskplanner_amd.run: unknown option {opt} (options go before the script name)")
     if not argv:
@@ -44,6 +49,17 @@ def main(argv=None):
         from . import _lib
         _lib.load()          # the product path has no CPU fallback: fail here, not at the first kernel call
     dropin.install(dropin.MINIMAL if minimal else None)
+    if fused_adam:
+        import torch
+        plain = torch.optim.Adam.__init__
+
+        def init(self, params, *a, **kw):
+            params = list(params)
+            first = params[0]["params"][0] if (params and isinstance(params[0], dict)) else (params[0] if params else None)
+            if "fused" not in kw and "foreach" not in kw and first is not None and getattr(first, "is_cuda", False):
+                kw["fused"] = True
+            plain(self, params, *a, **kw)
+        torch.optim.Adam.__init__ = init
     sys.argv = [script] + argv[1:]
     runpy.run_path(script, run_name="__main__")      # (puts the script's directory first on sys.path, like `python script.py`)
 
