@@ -516,7 +516,7 @@ def main():
             del ts
             torch.cuda.empty_cache()
             tsx = make_harness("cuboid", stream=4)
-            sdt, sper, sloss, _ = run_harness(tsx, k, 3, profile_every=None)
+            sdt, sper, sloss, _ = run_harness(tsx, k, max(args.warmup, 8), profile_every=None)
             line["streamed_inputs"] = {"value": args.batch * k / sdt, "unit": "point-clouds/s", "ms_per_step": sdt / k * 1e3, "steps": k,
                                        "step_ms_median": sper[len(sper) // 2] if sper else None, "final_loss": sloss,
                                        "what": "4 host batches of ragged dataset items in rotation; batch k+1 goes through the device collate "
@@ -526,7 +526,7 @@ def main():
             torch.cuda.empty_cache()
             tu = make_harness("ucube", stream=0)
             lib.mp_profiler_collect(None, 0)
-            udt, uper, uloss, uprof = run_harness(tu, k, 3, profile_every=20)
+            udt, uper, uloss, uprof = run_harness(tu, k, max(args.warmup, 8), profile_every=20)
             uk = collect_kernel_profile(lib)
             unamed, _ = kernel_tables(uk, max(uprof, 1), {})
             line["ucube"] = {"value": args.batch * k / udt, "unit": "point-clouds/s", "ms_per_step": udt / k * 1e3, "steps": k,
@@ -539,7 +539,7 @@ def main():
             args.batch = 64
             try:
                 tb = make_harness("cuboid", stream=0)
-                bdt, bper, bloss, _ = run_harness(tb, k, 3, profile_every=None)
+                bdt, bper, bloss, _ = run_harness(tb, k, max(args.warmup, 8), profile_every=None)
                 del tb
                 torch.cuda.empty_cache()
                 ddt, dper, dloss = run_dropin(k, 3)

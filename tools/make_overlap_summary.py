@@ -14,7 +14,7 @@ for s0, s1 in zip(starts[:-1], starts[1:]):
 steps = steps[-14:]
 med = statistics.median(t for t, _ in steps)
 replayed = [(t, ks) for t, ks in steps if t < 1.08 * med]              # drop the eagerly launched profiled steps
-side_names = ("fps_kernel", "ball_query_kernel", "adam_lowrank_kernel")
+side_names = ("fps_kernel", "ball_query", "adam_lowrank_kernel")
 out = [f"# {tag}: concurrency inside a replayed step (rocprofv3 --kernel-trace -- python3 bench.py --steps 20 --warmup 8 --no-cpu-baseline)\n",
        "Two recorded graphs (encoder forward | heads, loss, backward, dense Adam) on the step's stream; the NEXT batch's sampling plan (FPS + ball query of both levels) and the PREVIOUS step's factor Adam are launched eagerly on their own streams.\n",
        "| step | span us | kernel time, step's chain us | kernel time, other streams us | of which FPS / ball query / factor Adam | idle gaps > 2 us on the chain |", "|---|---|---|---|---|---|"]

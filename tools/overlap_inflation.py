@@ -4,11 +4,11 @@ import collections, csv, glob, os, sys
 f = max(glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True), key=os.path.getmtime)
 rows = list(csv.DictReader(open(f)))
 ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "").split("(")[0]) for r in rows)
-side = [e for e in ev if any(s in e[2] for s in ("fps_kernel", "ball_query_kernel", "adam_lowrank_kernel"))]
+side = [e for e in ev if any(s in e[2] for s in ("fps_kernel", "ball_query", "adam_lowrank_kernel"))]
 half = ev[len(ev) // 2][0]        # steady state only
 stat = collections.defaultdict(lambda: [0, 0.0, 0, 0.0, 0.0, 0.0])
 for s, e, n in ev:
-    if s < half or any(k in n for k in ("fps_kernel", "ball_query_kernel", "adam_lowrank_kernel")):
+    if s < half or any(k in n for k in ("fps_kernel", "ball_query", "adam_lowrank_kernel")):
         continue
     ov_f = sum(max(0, min(e, x[1]) - max(s, x[0])) for x in side if "fps" in x[2] or "ball" in x[2])
     ov_a = sum(max(0, min(e, x[1]) - max(s, x[0])) for x in side if "adam" in x[2])

@@ -10,7 +10,7 @@ ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), nm(r), r.get("S
 starts = [e[0] for e in ev if "rc_stats_kernel" in e[2]]
 s0, s1 = starts[-back - 1], starts[-back]
 ks = [e for e in ev if s0 <= e[0] < s1]
-side_names = ("fps_kernel", "ball_query_kernel", "adam_lowrank_kernel")
+side_names = ("fps_kernel", "ball_query", "adam_lowrank_kernel")
 busy = s0
 small = 0.0
 nsmall = 0
