@@ -546,10 +546,21 @@ __global__ __launch_bounds__(CO > 128 ? 512 : 256) void fwd_chunk_kernel(PosOper
     const int lc = BIG ? (lane & 31) : (lane & 15);   // column of this lane inside the wave's tile
     const int kq = BIG ? (lane >> 5) : (lane >> 4);   // k sub-index / row group of this lane
     const int col = wave * CW + lc;
-    const int p0 = blockIdx.x * p_per_block;
-    const int p1 = min(P, p0 + p_per_block);
-    const int nchunks = (p1 - p0 + DBK - 1) / DBK;
+    // [r5] negative p_per_block: interleaved workgroups (see bwd_fused_kernel) -- workgroup w takes units w, w + grid, ... where a unit is a
+    // chunk, or with the fused pool a whole group of K positions (its chunks stay in order inside one workgroup)
+    const bool il = p_per_block < 0;
+    if (il) p_per_block = -p_per_block;
+    const int cpu_ = POOL ? po.K / DBK : 1;           // chunks per unit
+    const int U = cpu_ * DBK;
+    const int p0 = il ? 0 : blockIdx.x * p_per_block;
+    const int p1 = il ? P : min(P, p0 + p_per_block);
+    const int nchunks = il ? (((P + U - 1) / U - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x) * cpu_ : (p1 - p0 + DBK - 1) / DBK;
     if (nchunks <= 0) return;
+    auto cpos = [&](int c) {                          // first position of this workgroup's chunk c
+        if (!il) return p0 + c * DBK;
+        const int u = POOL ? c / cpu_ : c, r = POOL ? c - u * cpu_ : 0;
+        return (u * (int)gridDim.x + (int)blockIdx.x) * U + r * DBK;
+    };
 
     // B[k][n] = W[n][k]: 32x32x2 lane (n, kq) holds W[col][2*st + kq]; 16x16x4 lane (n, kq) holds W[col][4*st + kq]
     float wfrag[SPLIT ? 1 : NFR];
@@ -627,7 +638,7 @@ __global__ __launch_bounds__(CO > 128 ? 512 : 256) void fwd_chunk_kernel(PosOper
     // pair and each lane stores one dword -- the even lane (col, col + 1) of the even row, the odd lane the same columns of the odd row
     constexpr int ZB = ONE ? 2 : 4;
     const __amdgpu_buffer_rsrc_t zrsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(Z) + (size_t)p0 * CO * ZB, 0, (p1 - p0) * CO * ZB, 0x00020000);
-    int zoff = ONE ? ((4 * kq) * CO + (col & ~1)) * 2 + ((lane & 1) ? CO * 2 : 0)
+    const int zoff0 = ONE ? ((4 * kq) * CO + (col & ~1)) * 2 + ((lane & 1) ? CO * 2 : 0)
                    : ((BIG ? 4 * kq : 4 * kq) * CO + col) * 4;     // byte offset of this lane's first row inside the workgroup's slab
     bool neg = false;
     if constexpr (POOL) neg = gamma[col] < 0.0f;
@@ -636,18 +647,20 @@ __global__ __launch_bounds__(CO > 128 ? 512 : 256) void fwd_chunk_kernel(PosOper
     // ([r3] tried: the staggered barrier of bwd_fused_kernel's DESYNC for the 512-thread form -- 110.7 vs 111.0 us, not kept)
     // FPD2: two chunks of loads in flight (two register sets, the loop unrolled by two), as bwd_fused_kernel's PD2
     constexpr bool FPD2 = (ONE ? MP_FPD2_ONE : MP_FPD2) && SPLIT;
-    gload(p0, rs0);
+    gload(cpos(0), rs0);
     bn_prologue(A.bn, bn_lds, CI, 0, CI, blockIdx.x == 0);      // (behind the first chunk's loads: its slot reads share their latency)
     load_consts<MODE_A>(A, ca, kc, bn_lds, CI);
     sstore(0, rs0);
     if constexpr (FPD2) {
-        if (nchunks > 1) gload(p0 + DBK, rs0);
-        if (nchunks > 2) gload(p0 + 2 * DBK, rs1);
+        if (nchunks > 1) gload(cpos(1), rs0);
+        if (nchunks > 2) gload(cpos(2), rs1);
     }
     __syncthreads();
     auto body = [&](const int kcn, RSet& rs) {
         const int cur = kcn & 1;
-        if (!FPD2 && kcn + 1 < nchunks) gload(p0 + (kcn + 1) * DBK, rs);
+        if (!FPD2 && kcn + 1 < nchunks) gload(cpos(kcn + 1), rs);
+        const int pkc = cpos(kcn);
+        const int zoff = zoff0 + (pkc - p0) * CO * ZB;
         float v[NV];
         if constexpr (SPLIT && !BIG) {
             // 16 columns per wave: two 16x16 row tiles, v_mfma_f32_16x16x32_bf16 (lane (row, kq) holds A[row][32*st + 8*kq .. + 7])
@@ -752,7 +765,6 @@ __global__ __launch_bounds__(CO > 128 ? 512 : 256) void fwd_chunk_kernel(PosOper
                 }
             }
         }
-        zoff += DBK * CO * ZB;
         s1 += (double)(c1.x + c1.y);
         s2 += (double)(c2.x + c2.y);
         if constexpr (POOL) {
@@ -767,7 +779,7 @@ __global__ __launch_bounds__(CO > 128 ? 512 : 256) void fwd_chunk_kernel(PosOper
             const int cig = kcn % cpg;                // chunk inside its group (p0 is a multiple of K)
             if (cig == 0 || lbest > gbest) { gbest = lbest; gibest = cig * DBK + libest; }   // earlier chunk wins ties
             if (cig == cpg - 1 && kq == 0) {
-                const int pk = p0 + kcn * DBK;
+                const int pk = pkc;
                 const size_t o = (size_t)((unsigned)(pk / po.K) * (unsigned)CO + (unsigned)col);
                 const float val = __uint_as_float(__float_as_uint(gbest) ^ smask);
                 if (neg) { po.vmin[o] = val; po.imin[o] = gibest; }
@@ -775,7 +787,7 @@ __global__ __launch_bounds__(CO > 128 ? 512 : 256) void fwd_chunk_kernel(PosOper
             }
         }
         if (kcn + 1 < nchunks) sstore(cur ^ 1, rs);
-        if (FPD2 && kcn + 3 < nchunks) gload(p0 + (kcn + 3) * DBK, rs);
+        if (FPD2 && kcn + 3 < nchunks) gload(cpos(kcn + 3), rs);
         __syncthreads();
     };
     if constexpr (FPD2) {
@@ -806,6 +818,9 @@ __global__ __launch_bounds__(CO > 128 ? 512 : 256) void fwd_chunk_kernel(PosOper
 // BatchNorm-backward sums of layer l-1 from the raw Z_{l-1} chunk kept beside the activated one: 4 tensor passes.
 // The dX tile of a chunk is computed as eight 16x16 MFMA tiles, two per wave.
 // =================================================================================================================
+#ifndef MP_BF_INTERLEAVE
+#define MP_BF_INTERLEAVE 1  // [r5] fused backward: chunk-interleaved workgroups (the host asks for it with a negative p_per_block; MP_BF_IL=0 at run time: contiguous ranges)
+#endif
 #ifndef MP_BWD_KSPLIT
 #define MP_BWD_KSPLIT 0     // [r2] measured on one box: 234 us without, 287 us with (the extra barrier and 8 spilled registers cost more than the halved LDS reads return)
 #endif
@@ -872,9 +887,17 @@ __global__ __launch_bounds__(bwd_fused_threads(CO, CI, SPLIT, ONE), (CO >= 128 &
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     const int wrow0 = (wave >> 1) * TMW * 32, wcol0 = (wave & 1) * TNW * 32;
-    const int p0 = blockIdx.x * p_per_block;
-    const int p1 = min(P, p0 + p_per_block);
-    const int nchunks = (p1 - p0 + DBK - 1) / DBK;
+    // [r5] MP_BF_INTERLEAVE: workgroup w walks chunks w, w + grid, w + 2 grid, ... instead of a contiguous range of p_per_block positions: at any
+    // moment the chip reads (and writes) one window of each operand, the order a copy kernel sweeps memory in (tools/probes/membw_probe.hip:
+    // copies at 256 workgroups 4.8 TB/s over contiguous ranges, 5.8 interleaved).  dW and the BatchNorm sums do not care which positions a
+    // workgroup sees; byte offsets into G stay 32-bit (host: mp_bf_interleave_ok).
+    const bool il = MP_BF_INTERLEAVE && p_per_block < 0;
+    if (p_per_block < 0) p_per_block = -p_per_block;
+    const int p0 = il ? 0 : blockIdx.x * p_per_block;
+    const int p1 = il ? P : min(P, p0 + p_per_block);
+    const int cstep = il ? (int)gridDim.x * DBK : DBK;             // positions from one chunk of this workgroup to its next
+    const int cp0 = il ? (int)blockIdx.x * DBK : p0;               // its first chunk
+    const int nchunks = il ? ((P + DBK - 1) / DBK - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : (p1 - p0 + DBK - 1) / DBK;
     if (nchunks <= 0) return;
 
     f32x16 accW[TMW][TNW];
@@ -1010,6 +1033,7 @@ __global__ __launch_bounds__(bwd_fused_threads(CO, CI, SPLIT, ONE), (CO >= 128 &
     const __amdgpu_buffer_rsrc_t grsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(G) + (size_t)p0 * CI * GB, 0, (p1 - p0) * CI * GB, 0x00020000);
     int goff = ONE ? ((xrow0 + 4 * (lane >> 4)) * CI + ecol0 + ((lane & 15) & ~1)) * 2 + ((lane & 1) ? CI * 2 : 0)
                    : ((xrow0 + 4 * (lane >> 4)) * CI + ecol0 + (lane & 15)) * 4;
+    goff += (cp0 - p0) * CI * GB;
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     __shared__ f32x4 xbuf[KSPLIT ? NW : 1][64];      // KSPLIT: the partial of the tile the partner wave finalises
     f32x4 ax[HT];                                    // the finished dX tile(s) of this wave, between g_mfma and g_epi
@@ -1019,7 +1043,7 @@ __global__ __launch_bounds__(bwd_fused_threads(CO, CI, SPLIT, ONE), (CO >= 128 &
    // bit 0: 256-thread kernels, 1: <.,128,128>, 2: <.,256,128>
     constexpr bool DESYNC = MP_DESYNC && NT == 512 && CO == 256 && SPLIT && !KSPLIT && !PD2 && DBK == 16;   // (<.,128,128>: 128 -> 134 us with it, 124 -> 116 with PD2)
     const int half = DESYNC ? __builtin_amdgcn_readfirstlane(wave >> 2) : 0;
-    gload(p0, rs0);
+    gload(cp0, rs0);
     bn_prologue(DZ.bn, bn_lds, CO, 0, CO, blockIdx.x == 0);     // (behind the first chunk's loads: its slot reads share their latency)
     load_consts<MODE_DZ>(DZ, ca, ka, bn_lds, CO);
     if constexpr (LDS_CONSTS) {
@@ -1027,16 +1051,16 @@ __global__ __launch_bounds__(bwd_fused_threads(CO, CI, SPLIT, ONE), (CO >= 128 &
         sKB[0][cb >> 2] = kb.s; sKB[1][cb >> 2] = kb.t;
     }
     sstore(0, rs0);
-    if (DESYNC && half && nchunks > 1) { gload(p0 + DBK, rs0); sstore(1, rs0); }
+    if (DESYNC && half && nchunks > 1) { gload(cp0 + cstep, rs0); sstore(1, rs0); }
     if constexpr (PD2) {     // chunks 1 and 2 on their way before the first product
-        if (nchunks > 1) gload(p0 + DBK, rs0);
-        if (nchunks > 2) gload(p0 + 2 * DBK, rs1);
+        if (nchunks > 1) gload(cp0 + cstep, rs0);
+        if (nchunks > 2) gload(cp0 + 2 * cstep, rs1);
     }
     __syncthreads();
     // one chunk: products of chunk kc (plane buffer kc & 1), then chunk kc + 1 (held by `rs`) is staged into the other buffer
     auto body = [&](const int kc, RSet& rs) {
         const int cur = kc & 1;
-        if (!PD2 && kc + 1 + half < nchunks) gload(p0 + (kc + 1 + half) * DBK, rs);
+        if (!PD2 && kc + 1 + half < nchunks) gload(cp0 + (kc + 1 + half) * cstep, rs);
         auto do_dw = [&]() {
         if constexpr (SPLIT && ONE) {   // one plane: dW += bf16(dZ)^T * bf16(act(Z_{l-1})), one k-step per 16 positions of the chunk
 #pragma unroll
@@ -1233,7 +1257,7 @@ __global__ __launch_bounds__(bwd_fused_threads(CO, CI, SPLIT, ONE), (CO >= 128 &
                     sx2[h] += dy * zp;
                 }
             }
-            goff += DBK * CI * GB;
+            goff += cstep * CI * GB;
         }
         };
         // (tried: the two halves of the workgroup walking the two products in opposite order, so that only four waves at a time
@@ -1269,7 +1293,7 @@ __global__ __launch_bounds__(bwd_fused_threads(CO, CI, SPLIT, ONE), (CO >= 128 &
             if (kc + 1 < nchunks) sstore(cur ^ 1, rs);
             // PD2: the set just emptied is refilled at once with the chunk it stages two iterations from now -- two chunks of
             // loads in flight per workgroup instead of one (an iteration of these kernels lasts about one loaded-HBM round trip)
-            if (PD2 && kc + 3 < nchunks) gload(p0 + (kc + 3) * DBK, rs);
+            if (PD2 && kc + 3 < nchunks) gload(cp0 + (kc + 3) * cstep, rs);
         }
         if constexpr (!DESYNC) __syncthreads();
     };
@@ -2395,6 +2419,14 @@ inline bool split_enabled()
 // workgroups the position-stream forward aims for: positions per workgroup halve from 1024 until there are that many
 // [r2] same-box sweep: 512 for most shapes; the 256-output kernel (512 threads, one workgroup per CU) is best with one round of 256, the
 // HBM-bound 64 -> 64 layer with 2048 small workgroups
+// [r5] fwd_chunk_kernel: chunk-interleaved workgroups (negative p_per_block) while byte offsets into Z fit 31 bits.  Same box, four alternations:
+// <64,128,pool> 95 -> 87 us, <128,256,pool> 105 -> 105, <128,128> 65 -> 66, <64,64> 54 -> 55: on for the first shape only (MP_FWD_IL=2: every
+// shape, 0: none)
+static int fwd_il(int ppb, int64_t P, int Co, bool gains)
+{
+    static const int mode = [] { const char* e = getenv("MP_FWD_IL"); return e ? atoi(e) : 1; }();
+    return ((mode == 2 || (mode == 1 && gains)) && (uint64_t)P * (uint64_t)Co * 4u < (1ull << 31)) ? -ppb : ppb;
+}
 inline int fwd_wgs_wanted(int dflt = 512) { return dflt; }
 
 // [r5] operand planes of the fp32 BACKWARD contractions on the position-stream kernels: 2 (default: h, m -- three plane products, split2) or 3
@@ -3006,10 +3038,10 @@ static int sa_mlp_fwd(const float* x0, int64_t P, int64_t K, int n_layers, const
             const double fl = 2.0 * (double)P * Co_ * Ci_, by = eb * (double)P * (Ci_ + Co_) + 4.0 * (double)Co_ * Ci_;
             if (split_enabled())
                 MP_LAUNCH("fwd_chunk_kernel<128, 128, false, 0, 4, split>", fl, by, (fwd_chunk_kernel<128, 128, false, SRC_ID, 4, true>), dim3(gx), dim3(256), 0, stream, A,
-                          (int)P, ppb, L.weight, L.z, partials, po, L.gamma);
+                          (int)P, fwd_il(ppb, P, Co_, false), L.weight, L.z, partials, po, L.gamma);
             else
                 MP_LAUNCH("fwd_chunk_kernel<128, 128, false, 0, 4>", fl, by, (fwd_chunk_kernel<128, 128, false, SRC_ID, 4>), dim3(gx), dim3(256), 0, stream, A,
-                          (int)P, ppb, L.weight, L.z, partials, po, L.gamma);
+                          (int)P, fwd_il(ppb, P, Co_, false), L.weight, L.z, partials, po, L.gamma);
             MP_CHECK_LAUNCH();
             nblk = (int)gx;
         } else if (l == 1 && rc_first) {
@@ -3028,17 +3060,17 @@ static int sa_mlp_fwd(const float* x0, int64_t P, int64_t K, int n_layers, const
             }
             if (rc16 == 1) {
             } else if (bf16 && Co_ == 64)
-                MP_LAUNCH("fwd_chunk_bf16_kernel<64, 64, false, 4>", fl, by, (fwd_chunk_kernel<64, 64, false, SRC_ACT_RC, 0, true, true, true>), dim3(gx), dim3(256), 0, stream, A, (int)P, ppb, L.weight, L.z, partials, po, L.gamma);
+                MP_LAUNCH("fwd_chunk_bf16_kernel<64, 64, false, 4>", fl, by, (fwd_chunk_kernel<64, 64, false, SRC_ACT_RC, 0, true, true, true>), dim3(gx), dim3(256), 0, stream, A, (int)P, fwd_il(ppb, P, Co_, false), L.weight, L.z, partials, po, L.gamma);
             else if (bf16)
-                MP_LAUNCH("fwd_chunk_bf16_kernel<64, 128, false, 4>", fl, by, (fwd_chunk_kernel<64, 128, false, SRC_ACT_RC, 0, true, true, true>), dim3(gx), dim3(256), 0, stream, A, (int)P, ppb, L.weight, L.z, partials, po, L.gamma);
+                MP_LAUNCH("fwd_chunk_bf16_kernel<64, 128, false, 4>", fl, by, (fwd_chunk_kernel<64, 128, false, SRC_ACT_RC, 0, true, true, true>), dim3(gx), dim3(256), 0, stream, A, (int)P, fwd_il(ppb, P, Co_, false), L.weight, L.z, partials, po, L.gamma);
             else if (Co_ == 64 && split_enabled())
-                MP_LAUNCH(tg, fl, by, (fwd_chunk_kernel<64, 64, false, SRC_ACT_RC, 0, true>), dim3(gx), dim3(256), 0, stream, A, (int)P, ppb, L.weight, L.z, partials, po, L.gamma);
+                MP_LAUNCH(tg, fl, by, (fwd_chunk_kernel<64, 64, false, SRC_ACT_RC, 0, true>), dim3(gx), dim3(256), 0, stream, A, (int)P, fwd_il(ppb, P, Co_, false), L.weight, L.z, partials, po, L.gamma);
             else if (Co_ == 64)
-                MP_LAUNCH(tg, fl, by, (fwd_chunk_kernel<64, 64, false, SRC_ACT_RC>), dim3(gx), dim3(256), 0, stream, A, (int)P, ppb, L.weight, L.z, partials, po, L.gamma);
+                MP_LAUNCH(tg, fl, by, (fwd_chunk_kernel<64, 64, false, SRC_ACT_RC>), dim3(gx), dim3(256), 0, stream, A, (int)P, fwd_il(ppb, P, Co_, false), L.weight, L.z, partials, po, L.gamma);
             else if (split_enabled())
-                MP_LAUNCH(tg, fl, by, (fwd_chunk_kernel<64, 128, false, SRC_ACT_RC, 0, true>), dim3(gx), dim3(256), 0, stream, A, (int)P, ppb, L.weight, L.z, partials, po, L.gamma);
+                MP_LAUNCH(tg, fl, by, (fwd_chunk_kernel<64, 128, false, SRC_ACT_RC, 0, true>), dim3(gx), dim3(256), 0, stream, A, (int)P, fwd_il(ppb, P, Co_, false), L.weight, L.z, partials, po, L.gamma);
             else
-                MP_LAUNCH(tg, fl, by, (fwd_chunk_kernel<64, 128, false, SRC_ACT_RC>), dim3(gx), dim3(256), 0, stream, A, (int)P, ppb, L.weight, L.z, partials, po, L.gamma);
+                MP_LAUNCH(tg, fl, by, (fwd_chunk_kernel<64, 128, false, SRC_ACT_RC>), dim3(gx), dim3(256), 0, stream, A, (int)P, fwd_il(ppb, P, Co_, false), L.weight, L.z, partials, po, L.gamma);
             MP_CHECK_LAUNCH();
             nblk = (int)gx;
         } else if (l > 0 && stream_ok && (Ci_ == 64 || Ci_ == 128) && (Co_ == 64 || Co_ == 128 || Co_ == 256) && (P % K) == 0 && (1024 % K == 0 || !fuse_pool) &&
@@ -3059,14 +3091,14 @@ static int sa_mlp_fwd(const float* x0, int64_t P, int64_t K, int n_layers, const
                 if (rc16 < 0) return rc16;
             }
 #define MP_FWD(CI, CO, PL)                                                                                                     \
-    MP_LAUNCH(tg, fl, by, (fwd_chunk_kernel<CI, CO, PL>), dim3(gx), dim3(CO > 128 ? 512 : 256), 0, stream, A, (int)P, ppb, L.weight, L.z, \
+    MP_LAUNCH(tg, fl, by, (fwd_chunk_kernel<CI, CO, PL>), dim3(gx), dim3(CO > 128 ? 512 : 256), 0, stream, A, (int)P, fwd_il(ppb, P, Co_, CI == 64 && PL), L.weight, L.z, \
               partials, po, L.gamma)
 #define MP_FWD_SPLIT(CI, CO, PL)                                                                                               \
     if (bf16)                                                                                                                  \
-        MP_LAUNCH(tg, fl, by, (fwd_chunk_kernel<CI, CO, PL, SRC_ACT, 0, true, true, true>), dim3(gx), dim3(CO > 128 ? 512 : 256), 0, stream, A, (int)P, ppb, \
+        MP_LAUNCH(tg, fl, by, (fwd_chunk_kernel<CI, CO, PL, SRC_ACT, 0, true, true, true>), dim3(gx), dim3(CO > 128 ? 512 : 256), 0, stream, A, (int)P, fwd_il(ppb, P, Co_, CI == 64 && PL), \
                   L.weight, L.z, partials, po, L.gamma);                                                                       \
     else                                                                                                                       \
-        MP_LAUNCH(tg, fl, by, (fwd_chunk_kernel<CI, CO, PL, SRC_ACT, 0, true>), dim3(gx), dim3(CO > 128 ? 512 : 256), 0, stream, A, (int)P, ppb, \
+        MP_LAUNCH(tg, fl, by, (fwd_chunk_kernel<CI, CO, PL, SRC_ACT, 0, true>), dim3(gx), dim3(CO > 128 ? 512 : 256), 0, stream, A, (int)P, fwd_il(ppb, P, Co_, CI == 64 && PL), \
                   L.weight, L.z, partials, po, L.gamma)
 #define MP_FWD_CO(CI, PL)                                  \
     if (Co_ == 64) { if (bf16) MP_FWD_SPLIT(CI, 64, PL); else MP_FWD(CI, 64, PL); }                     \
@@ -3363,6 +3395,9 @@ static int sa_mlp_bwd(const float* x0, int64_t P, int64_t K, int n_layers, const
             const mp_mlp_layer_t& Pv = layers[l - 1];
             float* Gn = gbuf[l & 1];
             const int ppb = 1024;      // positions per workgroup
+            // [r5] bwd_fused_kernel: chunk-interleaved workgroups (negative p_per_block) while byte offsets into the operands fit 31 bits
+            static const bool bf_il = [] { const char* e = getenv("MP_BF_IL"); return !e || atoi(e) != 0; }();
+            const int ppb_k = (bf_il && (uint64_t)P * (uint64_t)(Co > Ci ? Co : Ci) * 4u < (1ull << 31)) ? -ppb : ppb;
             const unsigned gx = (unsigned)((P + ppb - 1) / ppb);
             if ((size_t)gx > nblk_max) return MP_EUNSUPPORTED;
             const double fl = 4.0 * (double)P * Co * Ci;
@@ -3373,15 +3408,15 @@ static int sa_mlp_bwd(const float* x0, int64_t P, int64_t K, int n_layers, const
 #define MP_FUSED(MODE, CO_, CI_)                                                                                              \
     if (bf16)                                                                                                                 \
         MP_LAUNCH(tg, fl, by, (bwd_fused_kernel<MODE, CO_, CI_, SRC_ACT, true, true>), dim3(gx), dim3(bwd_fused_threads(CO_, CI_, true, true)), 0, stream, DZ, IN, (int)P, \
-                  ppb, Ly.weight, grads[l].d_weight, Gn, partials);                                                           \
+                  ppb_k, Ly.weight, grads[l].d_weight, Gn, partials);                                                           \
     else if (split_enabled() && npl == 2)                                                                                     \
         MP_LAUNCH(tg, fl, by, (bwd_fused_kernel<MODE, CO_, CI_, SRC_ACT, true, false, 2>), dim3(gx), dim3(bwd_fused_threads(CO_, CI_, true, false)), 0, stream, DZ, IN, (int)P, \
-                  ppb, Ly.weight, grads[l].d_weight, Gn, partials);                                                           \
+                  ppb_k, Ly.weight, grads[l].d_weight, Gn, partials);                                                           \
     else if (split_enabled())                                                                                                      \
         MP_LAUNCH(tg, fl, by, (bwd_fused_kernel<MODE, CO_, CI_, SRC_ACT, true>), dim3(gx), dim3(bwd_fused_threads(CO_, CI_, true, false)), 0, stream, DZ, IN, (int)P, \
-                  ppb, Ly.weight, grads[l].d_weight, Gn, partials);                                                           \
+                  ppb_k, Ly.weight, grads[l].d_weight, Gn, partials);                                                           \
     else                                                                                                                      \
-        MP_LAUNCH(tg, fl, by, (bwd_fused_kernel<MODE, CO_, CI_>), dim3(gx), dim3(bwd_fused_threads(CO_, CI_, false, false)), 0, stream, DZ, IN, (int)P, ppb, Ly.weight, \
+        MP_LAUNCH(tg, fl, by, (bwd_fused_kernel<MODE, CO_, CI_>), dim3(gx), dim3(bwd_fused_threads(CO_, CI_, false, false)), 0, stream, DZ, IN, (int)P, ppb_k, Ly.weight, \
                   grads[l].d_weight, Gn, partials)
             if (bf16 && store16) {
                 // [r5] the kernels written for one plane and bf16 storage (sa_stream16.hip: rows straight into an LDS ring)
@@ -3401,28 +3436,28 @@ static int sa_mlp_bwd(const float* x0, int64_t P, int64_t K, int n_layers, const
                 snprintf(tg, sizeof tg, bf16 ? "bwd_fused_bf16_kernel<2, %d, 64, 4>" : "bwd_fused_kernel<2, %d, 64, 4>", Co);
                 if (bf16 && Co == 64)
                     MP_LAUNCH(tg, fl, by - eb * (double)P * Ci + 16.0 * (double)P, (bwd_fused_kernel<SRC_DZ, 64, 64, SRC_ACT_RC, true, true>), dim3(gx), dim3(256), 0, stream, DZ, IN,
-                              (int)P, ppb, Ly.weight, grads[l].d_weight, Gn, partials);
+                              (int)P, ppb_k, Ly.weight, grads[l].d_weight, Gn, partials);
                 else if (bf16)
                     MP_LAUNCH(tg, fl, by - eb * (double)P * Ci + 16.0 * (double)P, (bwd_fused_kernel<SRC_DZ, 128, 64, SRC_ACT_RC, true, true>), dim3(gx), dim3(256), 0, stream, DZ, IN,
-                              (int)P, ppb, Ly.weight, grads[l].d_weight, Gn, partials);
+                              (int)P, ppb_k, Ly.weight, grads[l].d_weight, Gn, partials);
                 else if (Co == 64 && split_enabled() && npl == 2)
                     MP_LAUNCH(tg, fl, by - eb * (double)P * Ci + 16.0 * (double)P, (bwd_fused_kernel<SRC_DZ, 64, 64, SRC_ACT_RC, true, false, 2>), dim3(gx), dim3(256), 0, stream, DZ, IN,
-                              (int)P, ppb, Ly.weight, grads[l].d_weight, Gn, partials);
+                              (int)P, ppb_k, Ly.weight, grads[l].d_weight, Gn, partials);
                 else if (Co == 64 && split_enabled())
                     MP_LAUNCH(tg, fl, by - eb * (double)P * Ci + 16.0 * (double)P, (bwd_fused_kernel<SRC_DZ, 64, 64, SRC_ACT_RC, true>), dim3(gx), dim3(256), 0, stream, DZ, IN,
-                              (int)P, ppb, Ly.weight, grads[l].d_weight, Gn, partials);
+                              (int)P, ppb_k, Ly.weight, grads[l].d_weight, Gn, partials);
                 else if (Co == 64)
                     MP_LAUNCH(tg, fl, by - eb * (double)P * Ci + 16.0 * (double)P, (bwd_fused_kernel<SRC_DZ, 64, 64, SRC_ACT_RC>), dim3(gx), dim3(256), 0, stream, DZ, IN,
-                              (int)P, ppb, Ly.weight, grads[l].d_weight, Gn, partials);
+                              (int)P, ppb_k, Ly.weight, grads[l].d_weight, Gn, partials);
                 else if (split_enabled() && npl == 2)
                     MP_LAUNCH(tg, fl, by - eb * (double)P * Ci + 16.0 * (double)P, (bwd_fused_kernel<SRC_DZ, 128, 64, SRC_ACT_RC, true, false, 2>), dim3(gx), dim3(256), 0, stream, DZ, IN,
-                              (int)P, ppb, Ly.weight, grads[l].d_weight, Gn, partials);
+                              (int)P, ppb_k, Ly.weight, grads[l].d_weight, Gn, partials);
                 else if (split_enabled())
                     MP_LAUNCH(tg, fl, by - eb * (double)P * Ci + 16.0 * (double)P, (bwd_fused_kernel<SRC_DZ, 128, 64, SRC_ACT_RC, true>), dim3(gx), dim3(256), 0, stream, DZ, IN,
-                              (int)P, ppb, Ly.weight, grads[l].d_weight, Gn, partials);
+                              (int)P, ppb_k, Ly.weight, grads[l].d_weight, Gn, partials);
                 else
                     MP_LAUNCH(tg, fl, by - eb * (double)P * Ci + 16.0 * (double)P, (bwd_fused_kernel<SRC_DZ, 128, 64, SRC_ACT_RC>), dim3(gx), dim3(256), 0, stream, DZ, IN,
-                              (int)P, ppb, Ly.weight, grads[l].d_weight, Gn, partials);
+                              (int)P, ppb_k, Ly.weight, grads[l].d_weight, Gn, partials);
             } else if (!bf16 && split_enabled() && Ci == 128 && Co == 256 && (!pooled || (DZ.kshift >= 4 && ppb % 16 == 0))) {
                 // [r3] the 256-output layer: the two products on different waves (bwd_roles_kernel)
                 snprintf(tg, sizeof tg, "bwd_roles_kernel<%d, %d>", pooled ? 3 : 2, Co);

@@ -99,9 +99,14 @@ __global__ __launch_bounds__(s16_threads(CO), CO == 256 ? 1 : 2) void bwd_stream
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int p0 = blockIdx.x * p_per_block;
-    const int p1 = min(P, p0 + p_per_block);
-    const int nchunks = (p1 - p0 + DBK - 1) / DBK;
+    // negative p_per_block: chunk-interleaved workgroups (sa_mlp.hip: bwd_fused_kernel) -- workgroup w takes chunks w, w + grid, ...
+    const bool il = p_per_block < 0;
+    if (il) p_per_block = -p_per_block;
+    const int p0 = il ? 0 : blockIdx.x * p_per_block;
+    const int p1 = il ? P : min(P, p0 + p_per_block);
+    const int cstep = il ? (int)gridDim.x * DBK : DBK;
+    const int cp0 = il ? (int)blockIdx.x * DBK : p0;
+    const int nchunks = il ? ((P + DBK - 1) / DBK - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : (p1 - p0 + DBK - 1) / DBK;
     if (nchunks <= 0) return;
     const unsigned char* zsrc = reinterpret_cast<const unsigned char*>(DZ.x);
     const unsigned char* gsrc = reinterpret_cast<const unsigned char*>(DZ.g);
@@ -110,7 +115,7 @@ __global__ __launch_bounds__(s16_threads(CO), CO == 256 ? 1 : 2) void bwd_stream
     // ---- the ring: chunk c -> slot c % R --------------------------------------------------------------------------------------------
     auto issue = [&](int c) {
         const int slot = c % R;
-        const int pk = p0 + c * DBK;
+        const int pk = cp0 + c * cstep;
         constexpr int UA = RBA / 16, UB = RBB / 16;                 // 16-byte units per row
 #pragma unroll
         for (int j = 0; j < LZ; ++j) {
@@ -192,14 +197,14 @@ __global__ __launch_bounds__(s16_threads(CO), CO == 256 ? 1 : 2) void bwd_stream
         sx2[h] = f2{0.0f, 0.0f};
     }
     const __amdgpu_buffer_rsrc_t grsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(G) + (size_t)p0 * CI * 2, 0, (p1 - p0) * CI * 2, 0x00020000);
-    int goff = ((4 * kq) * CI + xcol0 + (l15 & ~1)) * 2 + ((lane & 1) ? CI * 2 : 0);
+    int goff = ((4 * kq) * CI + xcol0 + (l15 & ~1)) * 2 + ((lane & 1) ? CI * 2 : 0) + (cp0 - p0) * CI * 2;
 
     bn_prologue(DZ.bn, bn_lds, CO, 0, CO, blockIdx.x == 0);        // (a, e, f) of dZ_l when this kernel is their first consumer (contains a barrier)
     load_consts<MODE_DZ>(DZ, ca, ka, bn_lds, CO);
 
     for (int kc = 0; kc < nchunks; ++kc) {
         const int slot = kc % R;
-        const int pk = p0 + kc * DBK;
+        const int pk = cp0 + kc * cstep;
         // this wave's loads of chunk kc have landed: behind them it issued the loads of R - 2 more chunks and the stores of min(kc, R - 1) epilogues
         if (kc >= R - 1) wait_vm<(R - 2) * LD + (R - 1) * ST>();
         else if (R > 2 && kc == 1) wait_vm<(R - 2) * LD + 1 * ST>();
@@ -313,7 +318,7 @@ __global__ __launch_bounds__(s16_threads(CO), CO == 256 ? 1 : 2) void bwd_stream
                 }
             }
         }
-        goff += DBK * CI * 2;
+        goff += cstep * CI * 2;
     }
     wait_vm<0>();
     // ---- BatchNorm-backward sums of layer l - 1: the wave owns its columns; the four row groups of a lane column meet by shuffles -------
@@ -384,15 +389,25 @@ __global__ __launch_bounds__(s16_threads(CO), CO == 256 ? 1 : 2) void fwd_stream
     const int lc = BIG ? (lane & 31) : (lane & 15);
     const int kq = BIG ? (lane >> 5) : (lane >> 4);
     const int col = wave * CW + lc;
-    const int p0 = blockIdx.x * p_per_block;
-    const int p1 = min(P, p0 + p_per_block);
-    const int nchunks = (p1 - p0 + DBK - 1) / DBK;
+    // negative p_per_block: interleaved workgroups, a unit = one chunk, or with the fused pool one group of K positions (sa_mlp.hip: fwd_chunk_kernel)
+    const bool il = p_per_block < 0;
+    if (il) p_per_block = -p_per_block;
+    const int cpu_ = POOL ? po.K / DBK : 1;
+    const int U = cpu_ * DBK;
+    const int p0 = il ? 0 : blockIdx.x * p_per_block;
+    const int p1 = il ? P : min(P, p0 + p_per_block);
+    const int nchunks = il ? (((P + U - 1) / U - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x) * cpu_ : (p1 - p0 + DBK - 1) / DBK;
     if (nchunks <= 0) return;
+    auto cpos = [&](int c) {
+        if (!il) return p0 + c * DBK;
+        const int u = POOL ? c / cpu_ : c, r = POOL ? c - u * cpu_ : 0;
+        return (u * (int)gridDim.x + (int)blockIdx.x) * U + r * DBK;
+    };
     const unsigned char* xsrc = reinterpret_cast<const unsigned char*>(RC ? A.rx : A.x);
 
     auto issue = [&](int c) {
         const int slot = c % R;
-        const int pk = p0 + c * DBK;
+        const int pk = cpos(c);
         if constexpr (RC) {
             const int row = lane & 31;
             const int pr = pk + row < p1 ? pk + row : p0;
@@ -430,7 +445,7 @@ __global__ __launch_bounds__(s16_threads(CO), CO == 256 ? 1 : 2) void fwd_stream
     int gibest = 0;
     const int cpg = POOL ? po.K / DBK : 1;
     const __amdgpu_buffer_rsrc_t zrsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(Z) + (size_t)p0 * CO * 2, 0, (p1 - p0) * CO * 2, 0x00020000);
-    int zoff = ((4 * kq) * CO + (col & ~1)) * 2 + ((lane & 1) ? CO * 2 : 0);
+    const int zoff0 = ((4 * kq) * CO + (col & ~1)) * 2 + ((lane & 1) ? CO * 2 : 0);
     bool neg = false;
     if constexpr (POOL) neg = gamma[col] < 0.0f;
     const unsigned smask = neg ? 0x80000000u : 0u;
@@ -440,7 +455,8 @@ __global__ __launch_bounds__(s16_threads(CO), CO == 256 ? 1 : 2) void fwd_stream
 
     for (int kcn = 0; kcn < nchunks; ++kcn) {
         const int slot = kcn % R;
-        const int pk = p0 + kcn * DBK;
+        const int pk = cpos(kcn);
+        const int zoff = zoff0 + (pk - p0) * CO * 2;
         if (kcn >= R - 1) wait_vm<(R - 2) * LI + (R - 1) * SV>();
         else if (R > 2 && kcn == 1) wait_vm<(R - 2) * LI + 1 * SV>();
         else if (R > 3 && kcn == 2) wait_vm<(R - 2) * LI + 2 * SV>();
@@ -509,7 +525,6 @@ __global__ __launch_bounds__(s16_threads(CO), CO == 256 ? 1 : 2) void fwd_stream
                 }
             }
         }
-        zoff += DBK * CO * 2;
         s1 += (double)(c1.x + c1.y);
         s2 += (double)(c2.x + c2.y);
         if constexpr (POOL) {
@@ -543,6 +558,13 @@ __global__ __launch_bounds__(s16_threads(CO), CO == 256 ? 1 : 2) void fwd_stream
 
 // ---- launchers (called from sa_mlp.hip's level drivers; operands by pointer: the structs' layout is sa_common.h's) --------------------
 // Returns 1 when the shape has a kernel here (and it was launched), 0 when not, < 0 on a launch error.
+// MP_S16_IL=0: contiguous position ranges per workgroup (A/B timing); otherwise interleaved chunks while byte offsets fit 31 bits
+static bool s16_interleave(int64_t P, int C)
+{
+    static const bool on = [] { const char* e = getenv("MP_S16_IL"); return !e || atoi(e) != 0; }();
+    return on && (uint64_t)P * (uint64_t)C * 2u < (1ull << 31);
+}
+
 int mp_s16_bwd_launch(int pooled, int rc_in, int Co, int Ci, const void* dz_, const void* in_, int64_t P, int ppb, const float* W, float* dW, float* G,
                       const void* partials_, const char* tag, double flops, double bytes, hipStream_t stream)
 {
@@ -559,10 +581,11 @@ int mp_s16_bwd_launch(int pooled, int rc_in, int Co, int Ci, const void* dz_, co
     if (partials.slots)
         while (ppb < 4096 && P / (2 * ppb) >= 1024) ppb *= 2;
     const unsigned gx = (unsigned)((P + ppb - 1) / ppb);
+    const int ppb_k = s16_interleave(P, Co > Ci ? Co : Ci) ? -ppb : ppb;
 #define MP_S16(MODE, CO_, CI_, ...)                                                                                                \
     do {                                                                                                                           \
         MP_LAUNCH(tag, flops, bytes, (bwd_stream16_kernel<MODE, CO_, CI_, ##__VA_ARGS__>), dim3(gx), dim3(s16_threads(CO_)), 0, stream, DZ, IN, (int)P, \
-                  ppb, W, dW, G, partials);                                                                                        \
+                  ppb_k, W, dW, G, partials);                                                                                        \
         return hipGetLastError() == hipSuccess ? 1 : MP_ELAUNCH;                                                                   \
     } while (0)
     if (rc_in) {        // the layer behind a recomputed first layer (never the pooled one)
@@ -598,9 +621,11 @@ int mp_s16_fwd_launch(int pool, int rc_in, int Ci, int Co, const void* a_, int64
     if (pool && (po.K < 32 || (po.K & 31) || (ppb % po.K))) return 0;
     if (rc_in && (!A.rx || !A.rw)) return 0;
     const unsigned gx = (unsigned)((P + ppb - 1) / ppb);
+    static const bool fwd_il_on = [] { const char* e = getenv("MP_S16_FIL"); return !e || atoi(e) != 0; }();
+    const int ppb_k = (fwd_il_on && s16_interleave(P, Co > Ci ? Co : Ci)) ? -ppb : ppb;
 #define MP_S16F(CI_, CO_, POOL_, ...)                                                                                              \
     do {                                                                                                                           \
-        MP_LAUNCH(tag, flops, bytes, (fwd_stream16_kernel<CI_, CO_, POOL_, ##__VA_ARGS__>), dim3(gx), dim3(s16_threads(CO_)), 0, stream, A, (int)P, ppb, \
+        MP_LAUNCH(tag, flops, bytes, (fwd_stream16_kernel<CI_, CO_, POOL_, ##__VA_ARGS__>), dim3(gx), dim3(s16_threads(CO_)), 0, stream, A, (int)P, ppb_k, \
                   W, Z, partials, po, gamma);                                                                                      \
         return hipGetLastError() == hipSuccess ? 1 : MP_ELAUNCH;                                                                   \
     } while (0)
