@@ -1,0 +1,258 @@
+"""The drop-in model's `forward` (and its backward) replayed from two hipGraphs inside an UNCHANGED training loop.
+
+The reference's loop body (train_maskplanner.py:182-227) calls `model(point_cloud)`, `loss_handler.compute(...)`, `loss.backward()`,
+`opt.step()`: launched op by op from Python the step follows the host (4.8 ms for 2.1 ms of device work, tools/dropin_phases.py).  What the
+loop cannot see is HOW `model(...)` runs, so after a few eager calls with one input shape the model records
+
+  graph F   everything `forward` launches for a batch of that shape (sampling of both levels with the FPS start indices as static inputs,
+            the three set abstractions, the heads with their BatchNorm statistics and torch's own dropout: graph-safe Philox offsets), and
+  graph R   the backward of F's autograd graph from static output gradients into static parameter gradients,
+
+and from then on `forward` = copy the batch into F's input, draw the FPS starts the way the reference does (CPU generator, :77), replay F,
+hand out copies of the outputs behind ONE autograd node whose backward copies the output gradients in, replays R and publishes the
+parameter gradients as `param.grad` (assigned, or added when the loop accumulates).  The published tensors are the recording's own buffers:
+they hold their values until the model's next forward (the optimizer step, clipping, logging in between read them in place); a loop that
+keeps them past that point -- accumulation without zero_grad -- gets them copied out when that forward starts.  Same kernels, same order, same arithmetic as the eager
+module code -- the graphs are recorded FROM it.
+
+Forwards under `torch.no_grad()` (train_maskplanner.py:385-389, test_maskplanner.py:226-230) replay a graph F of their own mode (MASKPLANNER_DROPIN_GRAPH_EVAL=0:
+eager).  Left alone (eager, as before): forwards with autograd on in eval mode, inputs that require a gradient,
+a second forward before the first one's backward (both passes would share the static buffers), a model with a factor store (harness.TrainStep
+schedules `encode` / `heads` itself), a live process group (DDP's hooks hang off AccumulateGrad, which this path bypasses), shapes seen
+fewer than WARM times, and everything after a failed recording.  MASKPLANNER_DROPIN_GRAPH=0 switches the path off.
+"""
+import os
+import warnings
+import weakref
+
+import torch
+
+from . import pointnet2_utils as pu
+
+ENABLED = os.environ.get("MASKPLANNER_DROPIN_GRAPH", "1") != "0"
+EVAL = os.environ.get("MASKPLANNER_DROPIN_GRAPH_EVAL", "1") != "0"     # forwards under torch.no_grad() (the reference's eval / test loops): graph F alone
+FORK_IN_CAPTURE = os.environ.get("MASKPLANNER_DROPIN_GRAPH_FORK", "0") != "0"     # the second level's sampling as a parallel branch of graph F
+WARM = 3                 # eager calls with a shape before it is recorded (lazy initialisation, the allocator, kernel selection)
+MAX_SHAPES = 2           # recorded shapes per model and mode (the full batch and an epoch's last, smaller one)
+
+
+_DBG = os.environ.get("MASKPLANNER_DROPIN_GRAPH_DEBUG") == "1"
+
+
+def _dbg(*a):
+    if _DBG:
+        print("[graphed]", *a, flush=True)
+
+
+class _Replay(torch.autograd.Function):
+    """One autograd node for the whole model: forward = replay F, backward = replay R."""
+
+    @staticmethod
+    def forward(ctx, runner, anchor):
+        runner.graph_f.replay()
+        ctx.runner, ctx.ticket = runner, runner.ticket
+        return tuple(o.detach().clone() for o in runner.outs_t)
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        r = ctx.runner
+        if ctx.ticket != r.ticket or not r.pending:
+            raise RuntimeError("maskplanner_amd.graphed: backward through a forward whose recorded buffers were reused "
+                               "(a second backward, or a later forward of the same shape ran first)")
+        it = iter(gouts)
+        for o, s in zip(r.outs_t, r.gouts):
+            g = next(it)
+            if s is None:
+                continue
+            if g is None:
+                s.zero_()
+            else:
+                s.copy_(g)
+        # a loop that accumulates over several backward passes still holds the static buffers as .grad: move the old values out first
+        for p, g in r.grads:
+            if p.grad is g:
+                p.grad = g.clone()
+        r.graph_r.replay()
+        for p, g in r.grads:
+            if p.grad is None:
+                p.grad = g
+            else:
+                p.grad.add_(g)
+        r.pending = False
+        return None, None
+
+
+class _Runner:
+    def __init__(self, model, xyz, train):
+        self.model, self.train = model, train
+        self.failed, self.calls, self.pending, self.ticket, self.live = False, 0, False, 0, []
+        self.graph_f = self.graph_r = None
+        self.draws = []
+        self.shape, self.strides = tuple(xyz.shape), tuple(xyz.stride())
+
+    def _record(self, xyz):
+        from .harness import _capture_kw
+        model, dev = self.model, xyz.device
+        B, C, N = xyz.shape
+        # the loop hands over point_cloud.permute(0, 2, 1).to(device): points-major storage behind a channels-major view
+        self.x = torch.empty(B, N, C, device=dev, dtype=xyz.dtype).permute(0, 2, 1) if xyz.stride(1) == 1 else torch.empty_like(xyz)
+        self.x.copy_(xyz)
+        params = [p for p in model.parameters() if p.requires_grad]
+        self.anchor = params[0] if params else None
+        _dbg("rehearse")
+        self._rehearse(params)
+        _dbg("rehearsed")
+        kw = _capture_kw()
+        if os.environ.get("MASKPLANNER_DROPIN_GRAPH_MODE"):
+            kw = {"capture_error_mode": os.environ["MASKPLANNER_DROPIN_GRAPH_MODE"]}
+        torch.cuda.synchronize(dev)
+        gf = torch.cuda.CUDAGraph()
+        # static inputs live OUTSIDE the graphs' memory pool: a tensor allocated while recording may sit in a block an earlier temporary of
+        # the same recording left, and that temporary's kernel would overwrite it in every replay
+        self.starts = [(torch.empty(b, dtype=torch.long, device=dev), n) for b, n in self.draws]
+        pu._capture_starts = list(self.starts)
+        # The recorded forward runs on ALIASES of the parameters (same storage, fresh autograd leaves).  A parameter's AccumulateGrad node
+        # belongs to the stream its first forward ran on -- the loop's default stream -- and lives as long as any graph of an earlier
+        # forward does (the reference's loop keeps `loss` from one iteration into the next): autograd would hand every parameter gradient
+        # of the recorded backward over to that stream, i.e. pull the default stream into the recording, which ends it with a crash.  The
+        # aliases get their nodes while the recording stream is current and nobody else holds them.
+        names = [n for n, p in model.named_parameters() if p.requires_grad]
+        alias = {n: p.detach().requires_grad_(True) for n, p in zip(names, params)} if self.train else {}
+        try:
+            with torch.cuda.graph(gf, **kw):
+                outs = torch.func.functional_call(model, alias, (self.x,)) if alias else model._forward_eager(self.x)
+                _dbg("forward recorded")
+        finally:
+            pu._capture_starts = None
+            pu.clear_prefetched()
+        self.outs = outs
+        self.outs_t = [o for o in outs if o is not None]
+        self.mask = [o is not None for o in outs]
+        self.graph_f = gf
+        if self.train and self.anchor is not None:
+            req = [o for o in self.outs_t if o.requires_grad]
+            self.gouts = [torch.zeros_like(o) if o.requires_grad else None for o in self.outs_t]
+            # (torch.autograd.grad: the gradients are the recording's outputs, nothing is accumulated into .grad while recording)
+            gr = torch.cuda.CUDAGraph()
+            _dbg("recording backward")
+            with torch.cuda.graph(gr, pool=gf.pool(), **kw):
+                got = torch.autograd.grad(req, [alias[n] for n in names], [g for g in self.gouts if g is not None], allow_unused=True)
+            _dbg("backward recorded")
+            self.grads = [(p, g) for p, g in zip(params, got) if g is not None]
+            self.graph_r = gr
+        torch.cuda.synchronize(dev)
+
+    def _rehearse(self, params):
+        """One eager forward (+ backward from EVERY output) on the static input, its side effects undone: whatever a kernel does on its first
+        launch (code object load, the opt-in to large dynamic LDS) must not happen while a stream records -- and the loop's own eager steps
+        may never have run the backward of an output its loss does not use."""
+        model, dev = self.model, self.x.device
+        buffers = [(b, b.clone()) for b in model.buffers()]
+        rng_cpu, rng_dev = torch.get_rng_state(), torch.cuda.get_rng_state(dev)
+        try:
+            outs = [o for o in model._forward_eager(self.x) if o is not None]
+            if self.train:
+                req = [o for o in outs if o.requires_grad]
+                torch.autograd.grad(req, params, [torch.zeros_like(o) for o in req], allow_unused=True)
+            del outs
+        finally:
+            with torch.no_grad():
+                for b, c in buffers:
+                    b.copy_(c)
+            torch.set_rng_state(rng_cpu)
+            torch.cuda.set_rng_state(rng_dev, dev)
+            pu.clear_prefetched()
+
+    def __call__(self, xyz):
+        if self.graph_f is None:
+            self._record(xyz)
+        else:
+            self.x.copy_(xyz)
+        B, dev = xyz.shape[0], xyz.device
+        for t, n in self.starts:             # the reference's draws, in the reference's order (models/pointnet2_utils.py:77)
+            t.copy_(pu._draw_fps_start(B, n, dev), non_blocking=True)
+        if self.graph_r is not None:
+            # The static gradient buffers share the graphs' memory pool with the forward's temporaries: they hold the last backward's values
+            # until the NEXT forward replays.  A loop that still has them as .grad here is accumulating (no zero_grad): move the values out.
+            for p, g in self.grads:
+                if p.grad is g:
+                    p.grad = g.clone()
+            self.ticket += 1
+            self.pending = True
+            handed = _Replay.apply(self, self.anchor)
+            self.live = [weakref.ref(o) for o in handed]
+            outs = iter(handed)
+        else:
+            self.graph_f.replay()
+            outs = iter([o.detach().clone() for o in self.outs_t])
+        return tuple(next(outs) if keep else None for keep in self.mask)
+
+
+def _eligible(model, xyz):
+    if not ENABLED or not isinstance(xyz, torch.Tensor) or not xyz.is_cuda or xyz.dim() != 3 or xyz.requires_grad:
+        return None
+    if torch.cuda.is_current_stream_capturing() or getattr(model, "factor_store", None) is not None:
+        return None
+    train = model.training and torch.is_grad_enabled()
+    if not train and not (EVAL and not torch.is_grad_enabled()):
+        return None
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
+        return None
+    return train
+
+
+class _Runners(dict):
+    """The recorded graphs of one model.  Not state: a copy or a pickle of the model starts without them."""
+
+    def __deepcopy__(self, memo):
+        return _Runners()
+
+    def __reduce__(self):
+        return (_Runners, ())
+
+
+def call(model, xyz):
+    """`model.forward(xyz)` through the recorded graphs when the call qualifies, else None (the caller runs the eager code)."""
+    train = _eligible(model, xyz)
+    if train is None:
+        return None
+    runners = model.__dict__.setdefault("_graph_runners", _Runners())
+    key = (tuple(xyz.shape), tuple(xyz.stride()), xyz.dtype, train, model.training,
+           sum(1 for p in model.parameters() if p.requires_grad) if train else 0)      # (a layer frozen or thawed later: another recording)
+    r = runners.get(key)
+    if r is None:
+        if len(runners) >= 2 * MAX_SHAPES:
+            return None
+        r = runners[key] = _Runner(model, xyz, train)
+    if r.failed:
+        return None
+    if r.pending and all(w() is None for w in r.live):
+        r.pending = False      # that forward's outputs are gone: nobody can backpropagate through it any more
+    if r.pending:              # the previous forward of this shape may still be backpropagated: its buffers are in use, this call runs eagerly
+        return None
+    r.calls += 1
+    if r.graph_f is None and r.calls <= WARM:
+        pu._draw_log = log = []          # which FPS starts one forward of this shape draws: the recording's static inputs
+        try:
+            out = model._forward_eager(xyz)
+        finally:
+            pu._draw_log = None
+        r.draws = list(log)
+        return out
+    try:
+        return r(xyz)
+    except Exception as exc:
+        if r.graph_f is not None and r.graph_r is not None or (r.graph_f is not None and not train):
+            raise          # a recorded runner that fails at replay is a bug, not a reason to fall back silently
+        r.failed = True
+        r.graph_f = r.graph_r = None
+        pu.clear_prefetched()
+        torch.cuda.synchronize()
+        warnings.warn(f"maskplanner_amd.graphed: recording the model's forward/backward failed ({type(exc).__name__}: {exc}); "
+                      "this shape stays on the eager path")
+        return None
+
+
+def reset(model):
+    """Drop the recorded graphs of a model (after its parameters were replaced, e.g. `load_state_dict(assign=True)` or `.to()`)."""
+    model.__dict__.pop("_graph_runners", None)

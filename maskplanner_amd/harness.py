@@ -993,7 +993,8 @@ class DropInLoop:
         data = self.host_batches[self._i % len(self.host_batches)]
         self._i += 1
         model, device = self.model, self.device
-        model.train()
+        if self._i == 1:
+            model.train()            # (:181: once per epoch, in front of the batch loop)
         model.zero_grad()
         point_cloud, traj = data["point_cloud"], data["traj"]
         traj_as_pc, stroke_ids = data["traj_as_pc"], data["stroke_ids"]

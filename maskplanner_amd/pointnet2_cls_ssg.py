@@ -14,7 +14,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import ops, sa_mlp
+from . import graphed, ops, sa_mlp
 from .factor_heads import factor_linear, factor_linear2, head_block, head_block_ok, head_blocks2, head_blocks2_ok
 
 SAMPLE_AHEAD = True      # False (tests): every level samples in line
@@ -62,7 +62,9 @@ class _SSGEncoder(nn.Module):
         pointnet2_utils' plan queue."""
         from . import pointnet2_utils as pu
         sa1, sa2 = self.sa1, self.sa2
-        if (not SAMPLE_AHEAD or not xyz.is_cuda or torch.cuda.is_current_stream_capturing() or getattr(sa1, "group_all", True)
+        # (while a harness records its own graphs the plan is supplied from outside; graphed.py records THIS fork and join: FORK_IN_CAPTURE)
+        if (not SAMPLE_AHEAD or not xyz.is_cuda or (torch.cuda.is_current_stream_capturing() and not (graphed.FORK_IN_CAPTURE and pu._capture_starts is not None))
+                or getattr(sa1, "group_all", True)
                 or getattr(sa2, "group_all", True) or not isinstance(sa1, PointNetSetAbstraction) or not isinstance(sa2, PointNetSetAbstraction)):
             return
         pm = pu._points_major(xyz)                     # what sa1.forward computes (the same storage for a permuted [B,N,3] input)
@@ -236,7 +238,16 @@ class PointNet2Regressor_StrokeMasks(_SSGEncoder):
     fused_dropout = None
 
     def forward(self, xyz):
+        # [r5] inside an unchanged training loop: the whole call (and its backward) replayed from two recorded graphs (graphed.py)
+        out = graphed.call(self, xyz)
+        return out if out is not None else self._forward_eager(xyz)
+
+    def _forward_eager(self, xyz):
         return self.heads(self.encode(xyz))
+
+    def _apply(self, fn, *a, **kw):
+        graphed.reset(self)          # (.to() / .half() / ... replace the parameters the graphs were recorded with)
+        return super()._apply(fn, *a, **kw)
 
     def heads(self, feat):
         """Global feature [B,1024] -> (out, sm_out, mask_conf, seg_conf): everything behind the encoder (:309-341).  Split from

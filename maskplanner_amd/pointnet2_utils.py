@@ -140,7 +140,17 @@ def index_points(points, idx):
     return ops.index_points(points, idx)
 
 
+_capture_starts = None      # graphed.py, while it records a forward: [(static tensor, N)] handed out in call order instead of fresh draws --
+_draw_log = None            # allocated BEFORE the recording from the (B, N) of the draws an eager forward made (logged here)
+
+
 def _draw_fps_start(B, N, device):
+    if _capture_starts is not None:
+        if not _capture_starts or tuple(_capture_starts[0][0].shape) != (B,) or _capture_starts[0][1] != N:
+            raise RuntimeError("the recorded forward draws other FPS starts than the eager forward before it did")
+        return _capture_starts.pop(0)[0]
+    if _draw_log is not None:
+        _draw_log.append((B, N))
     if _fps_start_queue:
         s = _fps_start_queue.pop(0)
         return torch.as_tensor(s, dtype=torch.long).to(device)

@@ -1,0 +1,193 @@
+"""The drop-in model's forward / backward replayed from recorded graphs inside an unchanged loop (maskplanner_amd/graphed.py) against the same
+module code launched op by op: same outputs, same parameter gradients, same BatchNorm statistics from the same seeds; the cases that must
+stay eager do; gradient accumulation and a second forward before a backward keep autograd's meaning."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mods():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from maskplanner_amd import _lib, graphed, pointnet2_cls_ssg as pc, pointnet2_utils as pu, synthetic
+    _lib.load()
+    return graphed, pc, pu, synthetic
+
+
+def _model(pc, synthetic, seed=3, hidden=(256, 256)):
+    torch.manual_seed(seed)
+    return pc.maskplanner_model(synthetic.CATEGORIES["cuboids"], hidden_size=hidden).cuda().train()
+
+
+def _clouds(B, N, seed):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(B, N, 3, generator=g) * 2 - 1).permute(0, 2, 1).cuda()      # what the loop hands over: a permuted [B, N, 3]
+
+
+def _step(model, x, gouts, seed):
+    """One forward + backward with given output gradients; the CPU generator (FPS starts) and the device generator (dropout) seeded."""
+    torch.manual_seed(seed)
+    outs = model(x)
+    keep = [o for o in outs if o is not None]
+    torch.autograd.backward(keep, [g for g in gouts if g is not None])
+    return [o.detach().clone() for o in keep]
+
+
+def _rel(a, b):
+    return float((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-12))
+
+
+def _worst_grad(model, want):
+    """Largest gradient difference over the parameters, each relative to its own largest entry -- or, for the parameters whose true gradient is
+    zero (a bias in front of a BatchNorm: rounding noise only), to a thousandth of the largest gradient entry of the model."""
+    gmax = max(float(g.abs().max()) for g in want.values() if g is not None)
+    worst = 0.0
+    for n, p in model.named_parameters():
+        assert (p.grad is None) == (want[n] is None), n
+        if p.grad is not None:
+            d = float((p.grad.double() - want[n].double()).abs().max())
+            worst = max(worst, d / max(float(want[n].abs().max()), 1e-3 * gmax))
+    return worst
+
+
+def test_replayed_step_equals_the_eager_step(mods):
+    graphed, pc, pu, synthetic = mods
+    B, N = 4, 1024
+    eager, rec = _model(pc, synthetic), _model(pc, synthetic)
+    xs = [_clouds(B, N, 10 + i) for i in range(6)]
+    with torch.no_grad():
+        probe = [o for o in eager.eval()(xs[0]) if o is not None]
+    eager.train()
+    torch.manual_seed(0)
+    gouts = [torch.randn_like(o) for o in probe]
+    for i, x in enumerate(xs):
+        for m, on in ((eager, False), (rec, True)):
+            graphed.ENABLED = on
+            m.zero_grad()
+            try:
+                outs = _step(m, x, gouts, 100 + i)
+            finally:
+                graphed.ENABLED = True
+            if on:
+                got = outs
+            else:
+                want = outs
+        runner = next(iter(rec._graph_runners.values()))
+        assert (runner.graph_r is not None) == (i >= graphed.WARM)         # recorded on the fourth call, replayed from then on
+        for a, b in zip(got, want):
+            assert _rel(a, b) < 2e-5, (i, _rel(a, b))
+        worst = _worst_grad(rec, {n: q.grad for n, q in eager.named_parameters()})
+        assert worst < 2e-3, (i, worst)                                     # (atomics in the weight-gradient kernels: run-to-run rounding)
+        for (n, b), c in zip(rec.named_buffers(), eager.buffers()):
+            if b.dtype.is_floating_point:
+                assert _rel(b, c) < 1e-5, n
+            else:
+                assert torch.equal(b, c), n                                 # num_batches_tracked ticks inside the graph too
+
+
+def test_accumulation_and_second_forward_keep_autograd_meaning(mods):
+    graphed, pc, pu, synthetic = mods
+    B, N = 4, 1024
+    m = _model(pc, synthetic, seed=5)
+    x = _clouds(B, N, 40)
+    for i in range(graphed.WARM + 1):                                       # past the recording
+        m.zero_grad()
+        out = m(x)
+        out[0].sum().backward()
+    assert next(iter(m._graph_runners.values())).graph_r is not None
+    # two backward passes without zero_grad: the gradients add (the first pass's values live in the static buffers the second one rewrites)
+    m.zero_grad()
+    torch.manual_seed(1); m(x)[0].sum().backward()
+    g1 = {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+    torch.manual_seed(2); m(x)[0].sum().backward()
+    both = {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+    m.zero_grad()
+    torch.manual_seed(2); m(x)[0].sum().backward()
+    second = {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+    for n, p in m.named_parameters():
+        if p.grad is not None:
+            p.grad = both[n]
+    worst = _worst_grad(m, {n: (g1[n] + second[n] if n in g1 else None) for n, _ in m.named_parameters()})
+    assert worst < 2e-3, worst
+    # a second forward before the first one's backward runs eagerly and both can be backpropagated
+    m.zero_grad()
+    a = m(x)[0]
+    b = m(x)[0]
+    assert type(a.grad_fn).__name__.startswith("_Replay") and not type(b.grad_fn).__name__.startswith("_Replay")
+    (a.sum() + b.sum()).backward()
+    assert all(torch.isfinite(p.grad).all() for p in m.parameters() if p.grad is not None)
+    # a backward through a forward whose buffers were reused is an error, not stale numbers
+    m.zero_grad()
+    a = m(x)[0]
+    a.sum().backward()
+    with pytest.raises(RuntimeError):
+        a.sum().backward()
+
+
+def test_what_stays_eager_and_what_is_recorded_separately(mods):
+    graphed, pc, pu, synthetic = mods
+    m = _model(pc, synthetic, seed=6)
+    x = _clouds(4, 1024, 50)
+    # evaluation WITH autograd on (nobody backpropagates, but somebody could): eager
+    m.eval()
+    for _ in range(graphed.WARM + 2):
+        o = m(x)[0]
+        assert not type(o.grad_fn).__name__.startswith("_Replay")
+        del o
+    assert not m.__dict__.get("_graph_runners")
+    # evaluation under no_grad: a forward-only graph of its own; the outputs equal the eager evaluation for the same FPS starts
+    m.eval()
+    with torch.no_grad():
+        for i in range(graphed.WARM + 2):
+            torch.manual_seed(9)
+            got = m(x)
+        graphed.ENABLED = False
+        try:
+            torch.manual_seed(9)
+            want = m(x)
+        finally:
+            graphed.ENABLED = True
+    r = [r for k, r in m._graph_runners.items() if not k[3]]
+    assert len(r) == 1 and r[0].graph_f is not None and r[0].graph_r is None
+    for a, b in zip(got, want):
+        if a is not None:
+            assert _rel(a, b) < 1e-5
+    # another batch size: eager until it has been seen WARM times, then its own recording; a copy of the model starts without graphs
+    m.train()
+    x2 = _clouds(2, 1024, 51)
+    for i in range(graphed.WARM + 1):
+        m.zero_grad()
+        o = m(x2)[0]
+        assert type(o.grad_fn).__name__.startswith("_Replay") == (i >= graphed.WARM)
+        o.sum().backward()
+    assert not copy.deepcopy(m).__dict__.get("_graph_runners")
+    graphed.reset(m)
+    assert not m.__dict__.get("_graph_runners")
+
+
+def test_the_loop_body_on_graphs_trains_like_the_eager_loop(mods):
+    """harness.DropInLoop (the reference's loop body, statement for statement): 30 steps with and without the recorded graphs from one seed --
+    both fall, and stay within the spread two eager runs show (atomics make the trajectories diverge after a few steps)."""
+    graphed, pc, pu, synthetic = mods
+    from maskplanner_amd.harness import DropInLoop
+    runs = {}
+    for on in (False, True):
+        graphed.ENABLED = on
+        try:
+            torch.manual_seed(11)
+            loop = DropInLoop("cuboids", B=8, N=1024)
+            runs[on] = [loop.step() for _ in range(30)]
+            if on:
+                assert any(r.graph_r is not None for r in loop.model._graph_runners.values())
+        finally:
+            graphed.ENABLED = True
+    for on in (False, True):
+        v = runs[on]
+        assert np.isfinite(v).all() and np.mean(v[-5:]) < 0.9 * np.mean(v[:3]), v
+    assert abs(runs[True][0] - runs[False][0]) < 1e-3 * abs(runs[False][0])          # the first steps are the same eager code
+    assert abs(np.mean(runs[True][-5:]) - np.mean(runs[False][-5:])) < 0.25 * np.mean(runs[False][-5:])

@@ -7,9 +7,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from maskplanner_amd.harness import DropInLoop
 
-for kw in ({}, {"fused": True}):          # second line: torch.optim.Adam(..., fused=True) -- a one-word change of train_maskplanner.py:159
+from maskplanner_amd import graphed
+for kw, on in (({}, False), ({}, True), ({"fused": True}, False), ({"fused": True}, True)):   # fused=True: a one-word change of train_maskplanner.py:159
+    graphed.ENABLED = on          # [r5] the model's forward / backward replayed from recorded graphs (maskplanner_amd/graphed.py)
     loop = DropInLoop("cuboids", B=32, N=5120, adam_kwargs=kw)
-    print("torch.optim.Adam kwargs:", kw)
+    print("torch.optim.Adam kwargs:", kw, "| model graphs:", "on" if on else "off")
     for _ in range(8):
         loop.step()
     torch.cuda.synchronize()
@@ -23,7 +25,7 @@ for kw in ({}, {"fused": True}):          # second line: torch.optim.Adam(..., f
     m = loop.model
     ph = {}
     for _ in range(5):
-        m.train(); m.zero_grad()
+        m.zero_grad()
         torch.cuda.synchronize(); a = time.perf_counter()
         pc = data["point_cloud"].permute(0, 2, 1).to("cuda", dtype=torch.float); traj = data["traj"].to("cuda", dtype=torch.float)
         torch.cuda.synchronize(); b = time.perf_counter()
