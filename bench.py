@@ -20,8 +20,9 @@ Extra objects in the line (rank 0, N=1):
   named_kernels-- FPS / ball query / kNN / grouping against both roofs, `effective_scan_GBps`, and for FPS
                   the measured latency floor (the same kernel without distance arithmetic) and the fraction of it.
   dropin_path  -- the reference's own loop body (train_maskplanner.py:182-227) on the drop-in modules: torch.optim.Adam over
-                  all parameters, a fresh host batch per step, compute() -> numpy, loss.item().  `--path dropin` makes this
-                  the headline `value` instead.
+                  all parameters, a fresh host batch per step, compute() -> numpy, loss.item(); the model call and the loss call
+                  replay the graphs they record themselves (maskplanner_amd/graphed.py).  `--path dropin` makes this the headline
+                  `value` instead.
   streamed_inputs -- the harness step fed a fresh HOST batch every step (PCIe-inclusive): batch k+1 is collated onto the device
                   and sampled on the second stream during step k.  `--stream-batches K` makes this the headline run.
   ucube        -- the same step on U[-1,1]^3 clouds (sparse balls: full-scan ball query, heavy padding).
@@ -397,8 +398,9 @@ def main():
         def step(_prof):
             last[0] = loop.step()
             return torch.tensor(last[0])
-        for _ in range(8):
-            step(False)     # optimizer state, allocator, the libraries' lazy kernel selection (a stall of tens of ms in the first steps)
+        for _ in range(20):
+            step(False)     # optimizer state, allocator, the libraries' lazy kernel selection (a stall of tens of ms in the first steps), and
+                            # [r5] the recordings of maskplanner_amd/graphed.py: each of the four host batches' shapes is seen three times, then recorded
         dt, per_step, _ = time_steps(step, steps, warmup, barrier)
         return dt, per_step, last[0]
 
@@ -510,6 +512,8 @@ def main():
                                    "step_ms_median": dmed, "ms_per_step_mean": ddt / k * 1e3, "final_loss": dloss,
                                    "what": "train_maskplanner.py:182-227 loop body on the drop-in modules: torch.optim.Adam on all parameters, "
                                            "fresh host batch per step (H2D inside the step), FPS starts drawn per call, compute() -> numpy, loss.item(); "
+                                           "[r5] model(...) and loss_handler.compute(...) replay graphs they recorded from their own eager code after three "
+                                           "calls per shape (maskplanner_amd/graphed.py; MASKPLANNER_DROPIN_GRAPH=0: launched op by op); "
                                            "value / ms_per_step are the MEDIAN step (the loop follows the host, and on these shared hosts single "
                                            "steps stall for tens of ms: the mean is reported beside it)"}
             # PCIe-inclusive: a fresh host batch every step, collated + sampled on the second stream under the previous step

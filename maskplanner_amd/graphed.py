@@ -256,3 +256,138 @@ def call(model, xyz):
 def reset(model):
     """Drop the recorded graphs of a model (after its parameters were replaced, e.g. `load_state_dict(assign=True)` or `.to()`)."""
     model.__dict__.pop("_graph_runners", None)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# LossHandler.compute(...) of the same loop (train_maskplanner.py:212-218): graph L = every launch of the weighted terms for one set of
+# argument shapes and one config, graph LB = its backward from a static scalar into static gradients of the arguments that require one
+# (the model's outputs).  The reference's datasets pad every sample to the same number of segments (utils/dataset/paintnet_ODv1.py:293,
+# multipathdataset.py:400-402), so the shapes repeat from batch to batch; the config is part of the key because the reference changes loss
+# weights between epochs (PSACDScheduler, train_maskplanner.py:168).
+LOSS = os.environ.get("MASKPLANNER_DROPIN_GRAPH_LOSS", "1") != "0"
+MAX_LOSS_KEYS = 4
+
+
+class _LossReplay(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, runner, *req):
+        runner.graph_l.replay()
+        ctx.runner, ctx.ticket = runner, runner.ticket
+        return runner.total.detach().clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        r = ctx.runner
+        if ctx.ticket != r.ticket or not r.pending:
+            raise RuntimeError("maskplanner_amd.graphed: backward through a loss whose recorded buffers were reused "
+                               "(a second backward, or a later compute() with the same shapes ran first)")
+        r.gout.copy_(g)
+        r.graph_lb.replay()
+        r.pending = False
+        return (None,) + tuple(r.in_grads)
+
+
+class _LossRunner:
+    def __init__(self):
+        self.failed, self.calls, self.pending, self.ticket, self.live = False, 0, False, 0, None
+        self.graph_l = self.graph_lb = None
+
+    def _record(self, handler, args):
+        from .harness import _capture_kw
+        dev = args["y_pred"].device
+        self.names = [k for k, v in args.items() if isinstance(v, torch.Tensor)]
+        self.static, self.req = {}, []
+        for k in self.names:
+            v = args[k]
+            st = torch.empty(v.shape, dtype=v.dtype, device=dev)
+            with torch.no_grad():              # (a LEAF: copying a tensor with history into it under autograd would hang it onto that history)
+                st.copy_(v)
+            if v.requires_grad:
+                st.requires_grad_(True)
+                self.req.append(k)
+            self.static[k] = st
+        call = dict(args)
+        call.update(self.static)
+        # rehearsal (see _Runner._rehearse): every kernel of the terms and of their backward launched once outside a recording -- on leaves
+        # of its own, so that the static ones meet autograd for the first time on the recording stream
+        reh = dict(call)
+        reh.update({k: self.static[k].detach().clone().requires_grad_(True) for k in self.req})
+        total, _ = handler._terms(**reh)
+        torch.autograd.grad(total, [reh[k] for k in self.req], allow_unused=True)
+        del total, reh
+        kw = _capture_kw()
+        torch.cuda.synchronize(dev)
+        gl = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gl, **kw):
+            total, values = handler._terms(**call)
+            values = torch.stack(values)
+        self.total, self.values, self.status = total, values, getattr(handler, "last_match_status", None)
+        self.gout = torch.ones_like(total)
+        glb = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(glb, pool=gl.pool(), **kw):
+            got = torch.autograd.grad(total, [self.static[k] for k in self.req], self.gout, allow_unused=True)
+        self.in_grads = list(got)
+        self.graph_l, self.graph_lb = gl, glb
+        torch.cuda.synchronize(dev)
+
+    def __call__(self, handler, args):
+        if self.graph_l is None:
+            self._record(handler, args)
+        with torch.no_grad():
+            for k in self.names:
+                self.static[k].copy_(args[k], non_blocking=True)
+        handler.last_match_status = self.status
+        self.ticket += 1
+        self.pending = True
+        total = _LossReplay.apply(self, *[args[k] for k in self.req])
+        self.live = weakref.ref(total)
+        return total, self.values
+
+
+def _loss_key(handler, args):
+    sig = []
+    for k in sorted(args):
+        v = args[k]
+        if isinstance(v, torch.Tensor):
+            sig.append((k, tuple(v.shape), v.dtype, v.device.type, v.requires_grad))
+        elif v is None or isinstance(v, (int, float, bool, str)):
+            sig.append((k, v))
+        else:
+            return None                    # (lists of per-sample tensors and the like: not a fixed set of buffers)
+    cfg = handler._cfg()
+    return tuple(sig), tuple(handler.loss), repr([(k, cfg[k]) for k in sorted(cfg.keys())])
+
+
+def loss_call(handler, args):
+    """(total, stacked detached term values) through the recorded graphs when the call qualifies, else None."""
+    yp = args.get("y_pred")
+    if (not ENABLED or not LOSS or not isinstance(yp, torch.Tensor) or not yp.is_cuda or not yp.requires_grad or not torch.is_grad_enabled()
+            or torch.cuda.is_current_stream_capturing() or (torch.distributed.is_available() and torch.distributed.is_initialized())):
+        return None
+    key = _loss_key(handler, args)
+    if key is None:
+        return None
+    runners = handler.__dict__.setdefault("_graph_runners", _Runners())
+    r = runners.get(key)
+    if r is None:
+        while len(runners) >= MAX_LOSS_KEYS:
+            runners.pop(next(iter(runners)))       # oldest recording (an earlier epoch's weights)
+        r = runners[key] = _LossRunner()
+    if r.failed:
+        return None
+    if r.pending and (r.live is None or r.live() is None):
+        r.pending = False
+    if r.pending:
+        return None
+    r.calls += 1
+    if r.graph_l is None and r.calls <= WARM:
+        return None
+    try:
+        return r(handler, args)
+    except Exception as exc:
+        if r.graph_l is not None:
+            raise
+        r.failed = True
+        torch.cuda.synchronize()
+        warnings.warn(f"maskplanner_amd.graphed: recording the loss failed ({type(exc).__name__}: {exc}); these shapes stay on the eager path")
+        return None

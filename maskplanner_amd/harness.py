@@ -970,8 +970,10 @@ class DropInLoop:
     reference's factory builds (models/__init__.py:111-122), `torch.optim.Adam` over ALL parameters (:159), a fresh collated
     HOST batch every step (copied to the device inside the loop, :207-208; the GT tensors inside the loss, loss_handler.py:
     629, 838), FPS start indices drawn from the CPU generator per call (pointnet2_utils.py:77), `compute()` returning the
-    numpy list of terms and `loss.item()` (:212-224) -- two host synchronisations per step.  No graph replay, no factor heads,
-    no pipelined sampling: this is the drop-in figure, `TrainStep` is the path's ceiling."""
+    numpy list of terms and `loss.item()` (:212-224) -- two host synchronisations per step.  No factor heads, no pipelined sampling, no fused
+    optimizer: this is the drop-in figure, `TrainStep` is the path's ceiling.  ([r5] What the loop cannot see is how `model(...)` and
+    `loss_handler.compute(...)` launch their work: after three calls per shape they replay graphs recorded from their own eager code,
+    maskplanner_amd/graphed.py.)"""
 
     def __init__(self, category="cuboids", B=32, N=5120, device="cuda", seed=1235, lr=1e-3, dist_points="cuboid", n_batches=4,
                  rank=0, adam_kwargs=None):

@@ -215,7 +215,19 @@ class LossHandler:
     def compute(self, return_list=True, **loss_args):
         """Weighted sum of the configured terms (loss_handler.py:212-231).  The per-term values are returned as a
         numpy array like the reference does -- that conversion is the one host sync of the call; pass
-        return_list=False to stay asynchronous."""
+        return_list=False to stay asynchronous.  [r5] Inside an unchanged training loop the call (and its backward) is replayed from
+        recorded graphs once its argument shapes and the config have been seen a few times (graphed.loss_call)."""
+        from . import graphed
+        out = graphed.loss_call(self, loss_args)
+        total, values = out if out is not None else self._terms(**loss_args)
+        if return_list:
+            array = (values if isinstance(values, torch.Tensor) else torch.stack(values)).cpu().numpy()
+            check_mask_matching(self)
+            return total, array
+        return total
+
+    def _terms(self, **loss_args):
+        """(weighted sum, [detached term values]) -- everything compute() launches, nothing that waits for the device."""
         cfg = self._cfg()
         total = 0
         values = []
@@ -225,11 +237,7 @@ class LossHandler:
             term = value if (isinstance(w, (int, float)) and w == 1) else w * value      # (a launch saved for the usual weight 1)
             total = term if (isinstance(total, int) and total == 0) else total + term
             values.append(value.detach())
-        if return_list:
-            array = torch.stack(values).cpu().numpy()
-            check_mask_matching(self)
-            return total, array
-        return total
+        return total, values
 
     def check(self):
         """For callers of compute(return_list=False): raise with the decoded reason if the last stroke-mask matching of THIS

@@ -15,6 +15,8 @@ Options (before the script name):
                      wrapper and losses on top of the HIP kernels (dropin.MINIMAL)
     --hip-required   (default) fail at start-up if libmaskplanner_hip.so cannot be loaded; --no-hip-check skips the check (import-only dry
                      runs in a container without the library)
+    --no-graphs      `model(...)` and `loss_handler.compute(...)` launched op by op (default: after three calls per shape they replay graphs
+                     recorded from their own eager code, maskplanner_amd/graphed.py; the same as MASKPLANNER_DROPIN_GRAPH=0)
     --fused-adam     opt-in: `torch.optim.Adam(...)` calls of the script default to `fused=True` (train_maskplanner.py:159 passes no such
                      argument; same update rule, torch's single-kernel implementation: the unchanged loop is bound by host time, and the
                      foreach Adam over 143 MB of dense gradients is 0.85 ms of it -- 4.4 -> 4.0 ms per step)
@@ -37,6 +39,8 @@ def main(argv=None):
             check = True
         elif opt == "--fused-adam":
             fused_adam = True
+        elif opt == "--no-graphs":
+            os.environ["MASKPLANNER_DROPIN_GRAPH"] = "0"      # (read when maskplanner_amd.graphed is imported, below)
         else:
             raise SystemExit(f"maskplanner_amd.run: unknown option {opt} (options go before the script name)")
     if not argv:

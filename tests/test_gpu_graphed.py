@@ -191,3 +191,46 @@ def test_the_loop_body_on_graphs_trains_like_the_eager_loop(mods):
         assert np.isfinite(v).all() and np.mean(v[-5:]) < 0.9 * np.mean(v[:3]), v
     assert abs(runs[True][0] - runs[False][0]) < 1e-3 * abs(runs[False][0])          # the first steps are the same eager code
     assert abs(np.mean(runs[True][-5:]) - np.mean(runs[False][-5:])) < 0.25 * np.mean(runs[False][-5:])
+
+
+def test_replayed_loss_equals_the_eager_loss(mods):
+    """LossHandler.compute(...) of the loop: values, term list and the gradients of the model's outputs, recorded graphs against eager launches,
+    on changing batches; a config change (the reference reschedules loss weights between epochs) gets a recording of its own."""
+    graphed, pc, pu, synthetic = mods
+    from maskplanner_amd.loss_handler import LossHandler, maskplanner_loss_config
+    cat = synthetic.CATEGORIES["cuboids"]
+    B, N = 4, 1024
+    torch.manual_seed(21)
+    model = pc.maskplanner_model(cat, hidden_size=(256, 256)).cuda().eval()
+    handlers = {on: LossHandler(["asymm_v6_chamfer_with_stroke_masks"], maskplanner_loss_config()) for on in (False, True)}
+    W = graphed.WARM
+    data = synthetic.make_batch(300, B, N, cat.name, "cuboid")       # (the reference's datasets pad every sample to ONE length: the shapes repeat)
+    x = data["point_cloud"].permute(0, 2, 1).cuda().float()
+    with torch.no_grad():
+        base = model(x)
+    for i in range(2 * W + 4):
+        torch.manual_seed(500 + i)
+        outs = [None if o is None else o + 0.05 * torch.randn_like(o) for o in base]
+        if i == W + 2:
+            for h in handlers.values():
+                h.config["weight_asymm_v6_chamfer_with_stroke_masks"] = 0.5          # another epoch's weight
+        res = {}
+        for on in (False, True):
+            graphed.ENABLED = on
+            try:
+                leaves = [o.detach().clone().requires_grad_(True) if o is not None else None for o in outs]
+                loss, terms = handlers[on].compute(y_pred=leaves[0], y=data["traj"].cuda().float(), pred_stroke_masks=leaves[1], mask_scores=leaves[2],
+                                                   seg_logits=leaves[3], stroke_ids=data["stroke_ids"], traj_as_pc=data["traj_as_pc"])
+                (2.0 * loss).backward()
+            finally:
+                graphed.ENABLED = True
+            res[on] = (loss.detach(), terms, [l.grad for l in leaves if l is not None])
+            if on:
+                assert type(loss.grad_fn).__name__.startswith("_LossReplay") == (W <= i < W + 2 or i >= 2 * W + 2), i
+        assert _rel(res[True][0], res[False][0]) < 1e-5
+        assert np.allclose(res[True][1], res[False][1], rtol=1e-5)
+        for a, b in zip(res[True][2], res[False][2]):
+            assert (a is None) == (b is None)
+            if a is not None:
+                assert _rel(a, b) < 1e-4
+    assert len(handlers[True]._graph_runners) == 2          # the two weights

@@ -12,7 +12,7 @@ for kw, on in (({}, False), ({}, True), ({"fused": True}, False), ({"fused": Tru
     graphed.ENABLED = on          # [r5] the model's forward / backward replayed from recorded graphs (maskplanner_amd/graphed.py)
     loop = DropInLoop("cuboids", B=32, N=5120, adam_kwargs=kw)
     print("torch.optim.Adam kwargs:", kw, "| model graphs:", "on" if on else "off")
-    for _ in range(8):
+    for _ in range(24):      # (four host batches in rotation: every shape's recordings are behind us)
         loop.step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
