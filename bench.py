@@ -162,10 +162,18 @@ def inference_b1(cat, N, dev, reps=50):
             ts.append((time.perf_counter() - t0) * 1e3)
         ts.sort()
         return ts[len(ts) // 2], ts[0]
+    from maskplanner_amd import graphed
+    graphed.ENABLED = False
     e_med, e_min = timed(fwd)
-    out = {"eager_ms_median": e_med, "eager_ms_min": e_min, "unit": "ms per forward (B=1)", "reps": reps,
+    graphed.ENABLED = True
+    a_med, a_min = timed(fwd)         # [r5] what the unchanged test script gets: the forward replays the graph it recorded itself after three calls
+    graphed.ENABLED = False
+    out = {"eager_ms_median": e_med, "eager_ms_min": e_min, "unchanged_script_ms_median": a_med, "unchanged_script_ms_min": a_min,
+           "unit": "ms per forward (B=1)", "reps": reps,
            "what": f"eval-mode forward of one N={N} cloud (FPS 512 + 128, ball queries, three set abstractions, heads), host wall-clock "
-                   "including the synchronisation; FPS start indices drawn per call like the reference (pointnet2_utils.py:77)"}
+                   "including the synchronisation; FPS start indices drawn per call like the reference (pointnet2_utils.py:77).  eager: launched "
+                   "kernel by kernel (MASKPLANNER_DROPIN_GRAPH=0); unchanged_script: model(x) as test_maskplanner.py:253-257 calls it (the forward "
+                   "replays the graph it recorded itself, maskplanner_amd/graphed.py); graph: a bare replay with fixed FPS starts (lower bound)"}
     try:
         from maskplanner_amd import pointnet2_utils as pu
         starts = [torch.zeros(1, dtype=torch.long, device=dev), torch.zeros(1, dtype=torch.long, device=dev)]
@@ -183,7 +191,23 @@ def inference_b1(cat, N, dev, reps=50):
         out.update({"graph_ms_median": g_med, "graph_ms_min": g_min})
     except Exception as exc:       # the eager figure stands on its own
         out["graph_error"] = f"{type(exc).__name__}: {exc}"[:200]
+    graphed.ENABLED = True
     return out
+
+
+def streamed_leg(args, k):
+    """The harness step fed a fresh HOST batch every step, as a child process of its own (`bench.py --stream-batches 4`)."""
+    cmd = [sys.executable, os.path.abspath(__file__), "--stream-batches", "4", "--steps", str(k), "--warmup", str(max(args.warmup, 8)),
+           "--batch", str(args.batch), "--points", str(args.points), "--category", args.category, "--no-side-legs", "--no-cpu-baseline"]
+    try:
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    except Exception as exc:
+        return {"error": f"{type(exc).__name__}: {exc}"[:300]}
+    return {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"], "step_ms_median": d.get("step_ms_median"),
+            "final_loss": d.get("final_loss"),
+            "what": "4 host batches of ragged dataset items in rotation; batch k+1 goes through the device collate (pinned flat copy per key + "
+                    "pad kernel) and its FPS / ball query on the second stream during step k (a child process: bench.py --stream-batches 4)"}
 
 
 def dp_overhead_leg():
@@ -516,16 +540,13 @@ def main():
                                            "calls per shape (maskplanner_amd/graphed.py; MASKPLANNER_DROPIN_GRAPH=0: launched op by op); "
                                            "value / ms_per_step are the MEDIAN step (the loop follows the host, and on these shared hosts single "
                                            "steps stall for tens of ms: the mean is reported beside it)"}
-            # PCIe-inclusive: a fresh host batch every step, collated + sampled on the second stream under the previous step
+            # PCIe-inclusive: a fresh host batch every step, collated + sampled on the second stream under the previous step.  In a child
+            # process: this runtime spreads the streams a process creates over four hardware queues in creation order, and the streamed
+            # step keeps three of them busy -- after the legs above (graph recordings create streams of their own) its streams land
+            # wherever the count has got to, two of them on one queue (2.44 ms instead of 2.03; NOTEBOOK.md, "hardware-queue count")
             del ts
             torch.cuda.empty_cache()
-            tsx = make_harness("cuboid", stream=4)
-            sdt, sper, sloss, _ = run_harness(tsx, k, max(args.warmup, 8), profile_every=None)
-            line["streamed_inputs"] = {"value": args.batch * k / sdt, "unit": "point-clouds/s", "ms_per_step": sdt / k * 1e3, "steps": k,
-                                       "step_ms_median": sper[len(sper) // 2] if sper else None, "final_loss": sloss,
-                                       "what": "4 host batches of ragged dataset items in rotation; batch k+1 goes through the device collate "
-                                               "(pinned flat copy per key + pad kernel) and its FPS / ball query on the second stream during step k"}
-            del tsx
+            line["streamed_inputs"] = streamed_leg(args, k)
             # U-cube clouds: sparse balls => full-scan ball query and heavy padding
             torch.cuda.empty_cache()
             tu = make_harness("ucube", stream=0)
