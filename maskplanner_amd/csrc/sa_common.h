@@ -647,3 +647,9 @@ int mp_s16_bwd_launch(int pooled, int rc_in, int Co, int Ci, const void* dz, con
                       const void* partials, const char* tag, double flops, double bytes, hipStream_t stream);
 int mp_s16_fwd_launch(int pool, int rc_in, int Ci, int Co, const void* a, int64_t P, int ppb, const float* W, float* Z, const void* partials,
                       const void* po, const float* gamma, const char* tag, double flops, double bytes, hipStream_t stream);
+#ifndef MP_MAPWIDE
+#define MP_MAPWIDE 0        // 1: 16 lanes per row for every plane write of the fused backward kernels (A/B builds)
+#endif
+// sa_bwd_fused.hip
+int mp_bwd_fused_launch(int pooled, int rc_in, int bf16, int split, int npl, int Co, int Ci, const void* dz, const void* in, int64_t P, int ppb,
+                        const float* W, float* dW, float* G, const void* partials, double flops, double bytes, double bytes_rc, hipStream_t stream);
