@@ -87,7 +87,7 @@ class _Runner:
         self.model, self.train = model, train
         self.failed, self.calls, self.pending, self.ticket, self.live = False, 0, False, 0, []
         self.graph_f = self.graph_r = None
-        self.draws = []
+        self.draws, self.ptrs = [], ()
         self.shape, self.strides = tuple(xyz.shape), tuple(xyz.stride())
 
     def _record(self, xyz):
@@ -163,9 +163,14 @@ class _Runner:
             torch.cuda.set_rng_state(rng_dev, dev)
             pu.clear_prefetched()
 
+    def stale(self):
+        """The model's parameters are no longer the tensors the graphs were recorded with (`p.data = ...`, `load_state_dict(assign=True)`)."""
+        return self.graph_f is not None and self.ptrs != tuple(p.data_ptr() for p in self.model.parameters())
+
     def __call__(self, xyz):
         if self.graph_f is None:
             self._record(xyz)
+            self.ptrs = tuple(p.data_ptr() for p in self.model.parameters())
         else:
             self.x.copy_(xyz)
         B, dev = xyz.shape[0], xyz.device
@@ -225,6 +230,9 @@ def call(model, xyz):
             return None
         r = runners[key] = _Runner(model, xyz, train)
     if r.failed:
+        return None
+    if r.stale():
+        reset(model)
         return None
     if r.pending and all(w() is None for w in r.live):
         r.pending = False      # that forward's outputs are gone: nobody can backpropagate through it any more
@@ -358,10 +366,12 @@ def _loss_key(handler, args):
     return tuple(sig), tuple(handler.loss), repr([(k, cfg[k]) for k in sorted(cfg.keys())])
 
 
-def loss_call(handler, args):
-    """(total, stacked detached term values) through the recorded graphs when the call qualifies, else None."""
+def loss_call(handler, args, return_list=True):
+    """(total, stacked detached term values) through the recorded graphs when the call qualifies, else None.  Only the form the reference's loop
+    uses (`return_list=True`, train_maskplanner.py:212): a harness that schedules the step itself (harness.TrainStep: return_list=False) keeps
+    its launches -- its per-kernel profile and its own recordings are made of them."""
     yp = args.get("y_pred")
-    if (not ENABLED or not LOSS or not isinstance(yp, torch.Tensor) or not yp.is_cuda or not yp.requires_grad or not torch.is_grad_enabled()
+    if (not return_list or not ENABLED or not LOSS or not isinstance(yp, torch.Tensor) or not yp.is_cuda or not yp.requires_grad or not torch.is_grad_enabled()
             or torch.cuda.is_current_stream_capturing() or (torch.distributed.is_available() and torch.distributed.is_initialized())):
         return None
     key = _loss_key(handler, args)

@@ -218,7 +218,7 @@ class LossHandler:
         return_list=False to stay asynchronous.  [r5] Inside an unchanged training loop the call (and its backward) is replayed from
         recorded graphs once its argument shapes and the config have been seen a few times (graphed.loss_call)."""
         from . import graphed
-        out = graphed.loss_call(self, loss_args)
+        out = graphed.loss_call(self, loss_args, return_list)
         total, values = out if out is not None else self._terms(**loss_args)
         if return_list:
             array = (values if isinstance(values, torch.Tensor) else torch.stack(values)).cpu().numpy()

@@ -234,3 +234,19 @@ def test_replayed_loss_equals_the_eager_loss(mods):
             if a is not None:
                 assert _rel(a, b) < 1e-4
     assert len(handlers[True]._graph_runners) == 2          # the two weights
+
+
+def test_replaced_parameters_drop_the_recording(mods):
+    graphed, pc, pu, synthetic = mods
+    m = _model(pc, synthetic, seed=8)
+    x = _clouds(4, 1024, 60)
+    for _ in range(graphed.WARM + 1):
+        m.zero_grad()
+        m(x)[0].sum().backward()
+    assert any(r.graph_r is not None for r in m._graph_runners.values())
+    with torch.no_grad():
+        m.fc3.weight.data = m.fc3.weight.data.clone()          # the graphs still read the old storage
+    m.zero_grad()
+    o = m(x)[0]
+    assert not type(o.grad_fn).__name__.startswith("_Replay") and not m.__dict__.get("_graph_runners")
+    o.sum().backward()
