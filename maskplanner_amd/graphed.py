@@ -223,7 +223,8 @@ def call(model, xyz):
         return None
     runners = model.__dict__.setdefault("_graph_runners", _Runners())
     key = (tuple(xyz.shape), tuple(xyz.stride()), xyz.dtype, train, model.training,
-           sum(1 for p in model.parameters() if p.requires_grad) if train else 0)      # (a layer frozen or thawed later: another recording)
+           sum(1 for p in model.parameters() if p.requires_grad) if train else 0,      # (a layer frozen or thawed later: another recording)
+           sum(1 for m in model.modules() if m.training))                              # (a BatchNorm / dropout switched to eval on its own)
     r = runners.get(key)
     if r is None:
         if len(runners) >= 2 * MAX_SHAPES:
