@@ -12,8 +12,9 @@ reference's dataset is not public) and resident in HBM before the timed region. 
 
 `value` is the training step of `harness.TrainStep` (the path's ceiling: resident batch, hipGraph replay, factor heads).
 Extra objects in the line (rank 0, N=1):
-  roofline     -- the library kernel with the largest device time, timed with HIP events on its launch stream inside the
-                  timed region; algorithmic bytes / flops per launch from DESIGN.md; `traffic` from the committed PMC passes of the
+  roofline     -- the library kernel with the largest device time on the step's own stream; its duration is the mean over the K
+                  timed replays (wall-clock stamps recorded around it inside the graph: `timed_by`; the per-kernel table comes from one
+                  eagerly launched step at the end of the warm-up); algorithmic bytes / flops per launch from DESIGN.md; `traffic` from the committed PMC passes of the
                   run's own config.  For the split-plane kernels (fp32 products as six bf16 MFMA products) `achieved` / `peak` / `frac`
                   are the EXECUTED matrix-core figures against the bf16 dense peak; `algorithmic` keeps the fp32-equivalent rate,
                   `executed` both executed fractions and `binding` the larger of them.
@@ -101,6 +102,21 @@ def collect_kernel_profile(lib):
         for line in buf.value.decode().strip().split("\n"):
             name, calls, ms, flops, nbytes = line.split("\t")
             out[name] = dict(calls=int(calls), ms=float(ms), flops=float(flops), bytes=float(nbytes))
+    return out
+
+
+def read_kernel_marks(lib, last_n):
+    """[r5] The marked kernels' durations over their last `last_n` executions inside the replayed graphs (mp_profiler_mark: wall-clock stamps
+    around them, recorded with the graph).  -> {kernel name: dict(calls = samples, ms = their sum, flops, bytes)}"""
+    import ctypes
+    buf = ctypes.create_string_buffer(1 << 14)
+    n = lib.mp_profiler_read_marks(buf, len(buf), int(last_n))
+    out = {}
+    if n > 0:
+        for line in buf.value.decode().strip().split("\n"):
+            name, calls, ms, flops, nbytes = line.split("\t")
+            if float(ms) > 0:
+                out[name] = dict(calls=int(calls), ms=float(ms), flops=float(flops), bytes=float(nbytes))
     return out
 
 
@@ -391,7 +407,7 @@ def main():
         while ts.use_graph and ts._graph is None:
             ts.step()
         if ts._graph is not None:
-            ts.eager_step()   # the profiled steps of the timed region launch eagerly on this stream: warm its allocator blocks too
+            ts.eager_step()   # the profiled step launches eagerly on this stream: warm its allocator blocks too
         return ts
 
     def run_harness(ts, steps, warmup, profile_every=50):
@@ -409,10 +425,23 @@ def main():
         # another order than an eager one (the factor all-gather sits behind the heads' backward, in front of the bucket all-reduces),
         # so a rank that left the replay alone would pair its all-reduce with the others' all-gather -- a deadlock ([r4] found with two
         # gloo ranks on one GPU; the profiled step used to be rank 0's alone)
-        every = 4 * profile_every if profile_every else 0
-        prof = (lambda i: i % every == min(every, steps) // 2) if every else None
-        dt, per_step, loss = time_steps(step, steps, warmup, barrier, prof)
-        n_prof = len([i for i in range(steps) if prof is not None and prof(i)])
+        # [r5] That step now runs as the LAST step of the warm-up (the per-kernel table is a breakdown, not part of the rate): the K timed steps
+        # are K replays.  The roofline kernel's own duration still comes from the timed region -- the candidates for the largest kernel were
+        # marked while the graphs were recorded (mp_profiler_mark: a wall-clock stamp kernel in front of and behind each), so every replay
+        # timestamps them and read_kernel_marks() returns their mean over the K timed steps.  MASKPLANNER_BENCH_PROFILE_IN_TIMED=1: r4's way.
+        n_prof = 0
+        if profile_every and os.environ.get("MASKPLANNER_BENCH_PROFILE_IN_TIMED", "0") == "1":
+            every = 4 * profile_every
+            prof = lambda i: i % every == min(every, steps) // 2
+            dt, per_step, loss = time_steps(step, steps, warmup, barrier, prof)
+            n_prof = len([i for i in range(steps) if prof(i)])
+        else:
+            if profile_every:
+                for _ in range(max(warmup - 1, 0)):
+                    step(False)
+                step(True)
+                warmup, n_prof = 0, 1
+            dt, per_step, loss = time_steps(step, steps, warmup, barrier, None)
         return dt, per_step, float(loss.detach()), n_prof
 
     def run_dropin(steps, warmup, dist_points="cuboid"):
@@ -429,9 +458,16 @@ def main():
         return dt, per_step, last[0]
 
     line = None
+    marks = {}
     if args.path == "harness":
+        # (before the recording) the kernels that are the step's largest in one BASELINE config or another: at most one launch each per step
+        lib.mp_profiler_mark(os.environ.get("MASKPLANNER_BENCH_MARKS", "bwd_roles_kernel<3|bwd_stream16_kernel<3, 128, 128>|bwd_fused_kernel<3, 128, 128>"
+                                                                       "|bwd_fused_bf16_kernel<3, 128, 128>").encode())
         ts = make_harness(args.dist)
         dt, per_step, final_loss, profiled_steps = run_harness(ts, args.steps, args.warmup)
+        if rank == 0:
+            marks = read_kernel_marks(lib, args.steps)          # (their last K executions: the K timed replays)
+        lib.mp_profiler_mark(None)                  # (the side legs' recordings carry no marks)
         ts.check()      # (outside the timed region) a failed stroke-mask matching or a non-finite loss raises here
     else:
         dt, per_step, final_loss = run_dropin(args.steps, args.warmup, args.dist)
@@ -488,6 +524,11 @@ def main():
                 the kernel is really under."""
                 d = kernels[k]
                 avg_s = d["ms"] / d["calls"] * 1e-3
+                eager_avg_s, timed_by = avg_s, "HIP events around the launch in one eagerly launched step"
+                if k in marks:              # [r5] the kernel inside the replayed graphs, averaged over the K timed steps
+                    avg_s = marks[k]["ms"] / marks[k]["calls"] * 1e-3
+                    timed_by = (f"wall-clock stamps around the kernel inside the replayed graph, mean of the last {marks[k]['calls']} timed steps "
+                                "(the two stamp kernels' boundaries, ~3 us, are inside the interval)")
                 flops, nbytes = d["flops"] / d["calls"], d["bytes"] / d["calls"]
                 # [r5] the BACKWARD position-stream kernels run two planes / three products per fp32 product (sa_mlp.hip: split2) unless MP_BWD_PLANES=3
                 bwd2 = os.environ.get("MP_BWD_PLANES", "2") != "3" and any(t in k for t in ("bwd_fused", "bwd_roles"))
@@ -502,7 +543,7 @@ def main():
                     bound, ach, peak, unit = "hbm", nbytes / avg_s / 1e9, HBM_PEAK_GBS, "GB/s"
                 r = {"kernel": k, "bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak,
                      "traffic": measured_traffic(k, cfg_key), "avg_us": avg_s * 1e6, "launches_per_step": d["calls"] / max(profiled_steps, 1),
-                     "flops_per_launch": flops, "bytes_per_launch": nbytes}
+                     "flops_per_launch": flops, "bytes_per_launch": nbytes, "timed_by": timed_by, "eager_step_avg_us": eager_avg_s * 1e6}
                 ex = {"mfma_TFLOPs": ex_flops / avg_s / 1e12, "mfma_peak": ex_peak, "mfma_frac": ex_flops / avg_s / 1e12 / ex_peak,
                       "mfma_unit": "executed bf16 TFLOP/s (dense bf16 peak)" if ex_peak == BF16_PEAK_TFLOPS else "fp32 TFLOP/s (fp32-input MFMA peak)",
                       "hbm_GBps": nbytes / avg_s / 1e9, "hbm_peak": HBM_PEAK_GBS, "hbm_frac": nbytes / avg_s / 1e9 / HBM_PEAK_GBS}

@@ -540,6 +540,12 @@ int mp_zero_arena_arm_ticks(void* base, size_t bytes, int n_i64, int64_t* const*
  * returns the text length, 0 if nothing was recorded, MP_EWORKSPACE if `cap` is too small. */
 int mp_profiler_enable(int on);
 int mp_profiler_collect(char* buf, size_t cap);
+/* [r5] Marks: launches whose tag contains `tag_substr` (several substrings: separated by '|'; at most 8 launches per recording) are bracketed
+ * by two one-thread kernels that append the device's wall clock to a ring while a stream records a hipGraph, so that every replay timestamps
+ * them; mp_profiler_read_marks returns their durations summed over the last `last_n` executions (mp_profiler_collect's line format, calls =
+ * samples).  bench.py: the roofline kernel's average duration over the replayed, timed steps.  NULL / "": no marks. */
+int mp_profiler_mark(const char* tag_substr);
+int mp_profiler_read_marks(char* buf, size_t cap, int last_n);
 
 /* Adam (torch defaults, no weight decay / amsgrad) for `count` dense tensors in as few launches as their pointers fit into kernel
  * arguments (48 per launch).  params / grads / exp_avg / exp_avg_sq: HOST arrays of device pointers, numels their lengths; grad_scale

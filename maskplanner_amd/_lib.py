@@ -122,6 +122,8 @@ SIGNATURES = {
     "mp_zero_arena_disarm_stream": (_int, [_vp]),
     "mp_profiler_enable": (_int, [_int]),
     "mp_profiler_collect": (_int, [ctypes.c_char_p, _sz]),
+    "mp_profiler_mark": (_int, [ctypes.c_char_p]),
+    "mp_profiler_read_marks": (_int, [ctypes.c_char_p, _sz, _int]),
     "mp_sa_mlp_workspace_bytes": (_sz, [_i64, _i64, _int, ctypes.POINTER(_i64), _int]),
     "mp_sa_mlp_recompute_first": (_int, [_int, ctypes.POINTER(_i64), _i64]),
     "mp_sa_mlp_bf16_storage": (_int, [_int, ctypes.POINTER(_i64), _i64, _int]),

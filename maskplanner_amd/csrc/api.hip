@@ -33,13 +33,57 @@ struct ProfRec {
 std::atomic<int> g_prof_on{0};
 std::mutex g_prof_mu;
 std::vector<ProfRec> g_prof_recs;
+
+// [r5] Marks: while a stream RECORDS (hipGraph capture), launches whose tag contains a marked substring are bracketed by two one-thread
+// kernels that append the device's wall clock (100 MHz) to a ring, so every replay of the graph timestamps them; mp_profiler_read_marks()
+// turns the last `last_n` pairs into durations.  bench.py marks the kernels that can be the step's largest: the roofline figure then is the
+// kernel's AVERAGE over the K timed replays (no eagerly launched step inside the timed region; ~3 us per marked launch for the two stamps,
+// whose own boundaries are inside the measured interval: it overstates the kernel by about that much).  (Event records cannot do this here:
+// a plain record on a recording stream is a dependency marker that no replay signals, and hipEventRecordExternal nodes make the recording
+// fail over to eager launches on this runtime.)
+constexpr int MARK_MAX = 8, MARK_CAP = 256;           // marked launches per recording; samples kept per launch
+struct Mark { std::string tag; double flops, bytes; };
+std::atomic<int> g_mark_on{0};
+std::string g_mark;
+std::vector<Mark> g_marks;
+unsigned long long* g_mark_dev = nullptr;            // [MARK_MAX][2 + 2 * MARK_CAP]: begin count, end count, begin ring, end ring
+int g_mark_open = -1;
+__global__ void mp_stamp_kernel(unsigned long long* ctr, unsigned long long* ring)
+{
+    const unsigned long long i = atomicAdd(ctr, 1ull);
+    ring[i % MARK_CAP] = wall_clock64();
+}
+bool mark_matches(const char* tag)          // g_mark: substrings separated by '|'
+{
+    size_t a = 0;
+    while (a <= g_mark.size()) {
+        size_t b = g_mark.find('|', a);
+        if (b == std::string::npos) b = g_mark.size();
+        if (b > a && strstr(tag, g_mark.substr(a, b - a).c_str())) return true;
+        a = b + 1;
+    }
+    return false;
+}
 }  // namespace
 
 namespace mp {
-bool prof_on() { return g_prof_on.load(std::memory_order_relaxed) != 0; }
+bool prof_on() { return g_prof_on.load(std::memory_order_relaxed) != 0 || g_mark_on.load(std::memory_order_relaxed) != 0; }
 
 void prof_begin(const char* tag, double flops, double bytes, hipStream_t stream)
 {
+    if (g_prof_on.load(std::memory_order_relaxed) == 0) {        // marks only
+        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        g_mark_open = -1;
+        if (g_mark.empty() || !g_mark_dev || (int)g_marks.size() >= MARK_MAX || !mark_matches(tag) || hipStreamIsCapturing(stream, &st) != hipSuccess ||
+            st != hipStreamCaptureStatusActive)
+            return;
+        g_marks.push_back(Mark{tag, flops, bytes});
+        g_mark_open = (int)g_marks.size() - 1;
+        unsigned long long* m = g_mark_dev + (size_t)g_mark_open * (2 + 2 * MARK_CAP);
+        hipLaunchKernelGGL(mp_stamp_kernel, dim3(1), dim3(1), 0, stream, m, m + 2);
+        return;
+    }
     ProfRec r{tag, flops, bytes, nullptr, nullptr};
     if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
     (void)hipEventRecord(r.a, stream);
@@ -50,6 +94,14 @@ void prof_begin(const char* tag, double flops, double bytes, hipStream_t stream)
 void prof_end(hipStream_t stream)
 {
     std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (g_prof_on.load(std::memory_order_relaxed) == 0) {
+        if (g_mark_open >= 0) {
+            unsigned long long* m = g_mark_dev + (size_t)g_mark_open * (2 + 2 * MARK_CAP);
+            hipLaunchKernelGGL(mp_stamp_kernel, dim3(1), dim3(1), 0, stream, m + 1, m + 2 + MARK_CAP);
+        }
+        g_mark_open = -1;
+        return;
+    }
     if (!g_prof_recs.empty()) (void)hipEventRecord(g_prof_recs.back().b, stream);
 }
 }  // namespace mp
@@ -58,6 +110,69 @@ extern "C" int mp_profiler_enable(int on)
 {
     g_prof_on.store(on ? 1 : 0);
     return MP_OK;
+}
+
+// tag_substr: which launches to mark while a stream records, substrings separated by '|' (NULL or "": none).  Marks of an earlier call are
+// forgotten (graphs recorded with them keep stamping into the same buffer: read them before marking again).  Not while a stream records.
+extern "C" int mp_profiler_mark(const char* tag_substr)
+{
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_mark = tag_substr ? tag_substr : "";
+    g_marks.clear();
+    g_mark_open = -1;
+    const size_t bytes = (size_t)MARK_MAX * (2 + 2 * MARK_CAP) * sizeof(unsigned long long);
+    if (!g_mark.empty()) {
+        if (!g_mark_dev && hipMalloc(&g_mark_dev, bytes) != hipSuccess) { g_mark_dev = nullptr; g_mark.clear(); }
+        if (g_mark_dev && (hipDeviceSynchronize() != hipSuccess || hipMemset(g_mark_dev, 0, bytes) != hipSuccess)) g_mark.clear();
+    }
+    g_mark_on.store(g_mark.empty() ? 0 : 1);
+    return MP_OK;
+}
+
+// The marked launches' durations over their last `last_n` executions (waits for the device), aggregated per tag in mp_profiler_collect's
+// format: calls = samples used, total_ms their sum.
+extern "C" int mp_profiler_read_marks(char* buf, size_t cap, int last_n)
+{
+    std::vector<Mark> marks;
+    {
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        marks = g_marks;
+    }
+    std::string out;
+    if (!marks.empty() && g_mark_dev) {
+        const size_t per = 2 + 2 * MARK_CAP;
+        std::vector<unsigned long long> host(per * marks.size());
+        int dev = 0, khz = 0;
+        if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(host.data(), g_mark_dev, host.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess ||
+            hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || khz <= 0)
+            return MP_ELAUNCH;
+        struct Agg { long calls = 0; double ms = 0, flops = 0, bytes = 0; };
+        std::map<std::string, Agg> agg;
+        for (size_t m = 0; m < marks.size(); ++m) {
+            const unsigned long long* h = host.data() + m * per;
+            const unsigned long long n = h[0] < h[1] ? h[0] : h[1];          // completed pairs
+            unsigned long long use = n < (unsigned long long)MARK_CAP ? n : MARK_CAP;
+            if (last_n > 0 && use > (unsigned long long)last_n) use = last_n;
+            Agg& a = agg[marks[m].tag];
+            for (unsigned long long i = n - use; i < n; ++i) {
+                const unsigned long long t0 = h[2 + i % MARK_CAP], t1 = h[2 + MARK_CAP + i % MARK_CAP];
+                if (t1 <= t0) continue;
+                a.calls += 1;
+                a.ms += (double)(t1 - t0) / (double)khz;
+                a.flops += marks[m].flops;
+                a.bytes += marks[m].bytes;
+            }
+        }
+        char line[512];
+        for (auto& kv : agg) {
+            if (!kv.second.calls) continue;
+            snprintf(line, sizeof line, "%s\t%ld\t%.6f\t%.6e\t%.6e\n", kv.first.c_str(), kv.second.calls, kv.second.ms, kv.second.flops, kv.second.bytes);
+            out += line;
+        }
+    }
+    if (out.size() + 1 > cap) return MP_EWORKSPACE;
+    if (buf) memcpy(buf, out.c_str(), out.size() + 1);
+    return (int)out.size();
 }
 
 // Waits for the recorded events, aggregates per tag and writes lines "tag\tcalls\ttotal_ms\tflops\tbytes\n" into buf.
