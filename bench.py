@@ -437,9 +437,12 @@ def main():
             n_prof = len([i for i in range(steps) if prof(i)])
         else:
             if profile_every:
-                for _ in range(max(warmup - 1, 0)):
+                tail = min(2, max(warmup - 1, 0))        # two replays between that step and the timed region (the pipelined sampling plan
+                for _ in range(max(warmup - 1 - tail, 0)):   # and the optimizer stream find their rhythm again)
                     step(False)
                 step(True)
+                for _ in range(tail):
+                    step(False)
                 warmup, n_prof = 0, 1
             dt, per_step, loss = time_steps(step, steps, warmup, barrier, None)
         return dt, per_step, float(loss.detach()), n_prof
