@@ -880,3 +880,50 @@ def test_grad_accum_shared_buffer_equals_separate_gradients(ops):
     arena.disarm()
     assert ops.ZeroArena.current(torch.device("cuda", 0)) is None
     torch.cuda.synchronize()
+
+
+@pytest.mark.gpu
+def test_profiler_marks_time_a_kernel_inside_a_replayed_graph():
+    """mp_profiler_mark / mp_profiler_read_marks (bench.py's roofline timing): a marked launch recorded into a hipGraph is timestamped by every
+    replay; the mean over the last n replays is positive, close to the HIP-event figure of eager launches, and unmarked launches leave nothing."""
+    import ctypes
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from maskplanner_amd import _lib, ops
+    lib = _lib.load()
+    B, N, S = 8, 4096, 256
+    xyz = torch.rand(B, N, 3, device="cuda")
+    start = torch.zeros(B, dtype=torch.long, device="cuda")
+    ops.fps(xyz, S, start)                                  # first launch outside the recording (dynamic-LDS opt-in)
+    torch.cuda.synchronize()
+
+    def read(n):
+        buf = ctypes.create_string_buffer(1 << 12)
+        k = lib.mp_profiler_read_marks(buf, len(buf), n)
+        assert k >= 0
+        return {l.split("\t")[0]: (int(l.split("\t")[1]), float(l.split("\t")[2])) for l in buf.value.decode().strip().split("\n") if l}
+
+    try:
+        assert lib.mp_profiler_mark(b"no_such_kernel|fps_kernel") == 0
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            idx = ops.fps(xyz, S, start)
+            ops.ball_query(0.2, 16, xyz, xyz[:, :64].contiguous())     # not marked
+        for _ in range(6):
+            g.replay()
+        got = read(4)
+        assert list(got) and all(k.startswith("fps_kernel") for k in got), got
+        (calls, ms), = got.values()
+        assert calls == 4 and ms > 0
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(4):
+            ops.fps(xyz, S, start)
+        e1.record()
+        torch.cuda.synchronize()
+        eager = e0.elapsed_time(e1) / 4
+        assert 0.5 * eager < ms / calls < 1.5 * eager + 0.02, (ms / calls, eager)
+        assert torch.equal(idx, ops.fps(xyz, S, start))
+    finally:
+        lib.mp_profiler_mark(None)
+    assert read(4) == {}
