@@ -1,4 +1,4 @@
-# [r5] what do the dW atomic epilogues cost?  timing builds with them compiled out (results invalid)
+# [r5] what do the dW atomic epilogues cost?  timing builds with them compiled out (results invalid): apply experiments/r5_no_dw_atomics_probe.patch first
 cd $GRAFT_REPO_ROOT/maskplanner_amd/csrc
 for v in 0 1; do
   d=/tmp/ap$v; mkdir -p $d
