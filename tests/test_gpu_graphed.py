@@ -250,3 +250,62 @@ def test_replaced_parameters_drop_the_recording(mods):
     o = m(x)[0]
     assert not type(o.grad_fn).__name__.startswith("_Replay") and not m.__dict__.get("_graph_runners")
     o.sum().backward()
+
+
+def _g5_model(pc):
+    return pc.PointNet2Regressor_StrokeMasks(outdim=12, outdim_orient=12, weight_orient=0.25, out_vectors=99, hidden_size=(64, 64),
+                                             pred_stroke_masks=True, n_stroke_masks=6, mask_confidence_scores=True, segment_confidence_scores=False)
+
+
+def _load(module, g, prefix):
+    module.load_state_dict({k[len(prefix):]: torch.from_numpy(g[k].copy()) for k in g.files if k.startswith(prefix)}, strict=True)
+    return module.cuda()
+
+
+def _close(a, b, what, rtol=1e-5, atol=1e-5):
+    a, b = a.detach().cpu().numpy(), np.asarray(b)
+    assert a.shape == b.shape, what
+    err, scale = np.abs(a - b).max(), max(np.abs(b).max(), 1.0)
+    assert err <= atol + rtol * scale, f"{what}: max err {err:.3e} (scale {scale:.3e})"
+
+
+def test_replayed_forward_against_the_reference_fixtures(mods, golden):
+    """The recorded path pinned to the reference itself: g5 (the reference model's eval-mode outputs, 1e-5) through the forward-only graph, and
+    g15 (train mode, dropout 0: outputs, running statistics, gradients) through the forward + backward graphs -- the model called until it
+    replays, the FPS starts of the fixtures supplied per call as the loop's draws would be."""
+    graphed, pc, pu, synthetic = mods
+    g5, g15 = golden("g5_model"), golden("g15_train")
+    x5 = torch.from_numpy(np.ascontiguousarray(g5["xyz"])).cuda().permute(0, 2, 1)
+    model = _load(_g5_model(pc), g5, "sd_").eval()
+    with torch.no_grad():
+        for i in range(graphed.WARM + 2):
+            with pu.fps_start_override([g5["fps_start1"], g5["fps_start2"]]):
+                out, sm_out, mask_conf, seg_conf = model(x5)
+    assert any(r.graph_f is not None for r in model._graph_runners.values()) and seg_conf is None
+    _close(out, g5["out"], "out"); _close(sm_out, g5["sm_out"], "sm_out"); _close(mask_conf, g5["mask_conf"], "mask_conf")
+    # train mode: every call starts from the fixture's state (the running statistics and counters it left are compared after ONE pass)
+    x15 = torch.from_numpy(np.ascontiguousarray(g15["xyz"])).cuda().permute(0, 2, 1)
+    model = _load(_g5_model(pc), g5, "sd_").train()
+    model.dropout.p = 0.0
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+    w_out, w_sm = torch.from_numpy(g15["w_out"]).cuda(), torch.from_numpy(g15["w_sm"]).cuda()
+    for i in range(graphed.WARM + 2):
+        with torch.no_grad():
+            for k, v in model.state_dict().items():
+                v.copy_(state[k])
+        model.zero_grad()
+        with pu.fps_start_override([g15["fps_start1"], g15["fps_start2"]]):
+            out, sm_out, mask_conf, _ = model(x15)
+        ((out * w_out).sum() + (sm_out * w_sm).sum() + mask_conf.sum()).backward()
+    assert type(out.grad_fn).__name__.startswith("_Replay")
+    _close(out, g15["out"], "out", rtol=1e-4); _close(sm_out, g15["sm_out"], "sm_out", rtol=1e-4); _close(mask_conf, g15["mask_conf"], "mask_conf", rtol=1e-4)
+    for k, v in model.state_dict().items():
+        if "running" in k:
+            _close(v, g15["after_" + k], k, rtol=2e-5, atol=1e-6)
+        elif "num_batches" in k:
+            assert int(v) == int(g15["after_" + k]), k
+    params = dict(model.named_parameters())
+    for k in g15.files:
+        if k.startswith("grad_"):
+            got, want = params[k[5:]].grad.cpu(), torch.from_numpy(g15[k])
+            assert float((got - want).norm() / want.norm()) < 1e-2, k
