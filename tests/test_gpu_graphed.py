@@ -309,3 +309,25 @@ def test_replayed_forward_against_the_reference_fixtures(mods, golden):
         if k.startswith("grad_"):
             got, want = params[k[5:]].grad.cpu(), torch.from_numpy(g15[k])
             assert float((got - want).norm() / want.norm()) < 1e-2, k
+
+
+@pytest.mark.parametrize("tag", ["cub", "win"])
+def test_replayed_loss_against_the_reference_fixture(mods, golden, tag):
+    """g7 (the reference's asymm_v6 loss with stroke masks: value and the gradients of its three differentiable inputs) through the loss's
+    recorded graphs: compute() called until it replays, fresh leaves per call as the loop's model outputs are."""
+    graphed, pc, pu, synthetic = mods
+    from maskplanner_amd.loss_handler import LossHandler, maskplanner_loss_config
+    g = golden("g7_mask")
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    lh = LossHandler(["asymm_v6_chamfer_with_stroke_masks"], maskplanner_loss_config(explicit_no_stroke_weight=float(g[tag + "_no_stroke_weight"])))
+    for i in range(graphed.WARM + 2):
+        yp, mk, sc = (dev(g[tag + k]).requires_grad_(True) for k in ("_y_pred", "_masks", "_scores"))
+        loss, terms = lh.compute(y_pred=yp, y=dev(g[tag + "_traj"]), pred_stroke_masks=mk, mask_scores=sc, seg_logits=None,
+                                 stroke_ids=torch.from_numpy(g[tag + "_stroke_ids"]), traj_as_pc=torch.from_numpy(g[tag + "_traj_as_pc"]))
+        loss.backward()
+    assert type(loss.grad_fn).__name__.startswith("_LossReplay") and isinstance(terms, np.ndarray) and terms.shape == (1,)
+    _close(loss, g[tag + "_loss"], "loss", rtol=1e-5)
+    _close(torch.from_numpy(terms), g[tag + "_loss"].reshape(1), "terms", rtol=1e-5)
+    _close(yp.grad, g[tag + "_g_y_pred"], "g_y_pred", rtol=1e-4, atol=1e-6)
+    _close(mk.grad, g[tag + "_g_masks"], "g_masks", rtol=1e-5, atol=1e-6)
+    _close(sc.grad, g[tag + "_g_scores"], "g_scores", rtol=1e-5, atol=1e-6)
