@@ -179,6 +179,7 @@ def inference_b1(cat, N, dev, reps=50):
         ts.sort()
         return ts[len(ts) // 2], ts[0]
     from maskplanner_amd import graphed
+    was_enabled = graphed.ENABLED       # (a run started with MASKPLANNER_DROPIN_GRAPH=0 keeps its later legs eager: restored below)
     graphed.ENABLED = False
     e_med, e_min = timed(fwd)
     graphed.ENABLED = True
@@ -207,7 +208,8 @@ def inference_b1(cat, N, dev, reps=50):
         out.update({"graph_ms_median": g_med, "graph_ms_min": g_min})
     except Exception as exc:       # the eager figure stands on its own
         out["graph_error"] = f"{type(exc).__name__}: {exc}"[:200]
-    graphed.ENABLED = True
+    finally:
+        graphed.ENABLED = was_enabled
     return out
 
 
@@ -447,8 +449,11 @@ def main():
             dt, per_step, loss = time_steps(step, steps, warmup, barrier, None)
         return dt, per_step, float(loss.detach()), n_prof
 
-    def run_dropin(steps, warmup, dist_points="cuboid"):
-        loop = DropInLoop(cat, B=args.batch, N=args.points, device=dev, rank=rank, dist_points=dist_points)
+    def run_dropin(steps, warmup, dist_points="cuboid", adam_kwargs=None, info=None):
+        """[r6] The loop draws from 32 host batches, each padded to its own maximum like the reference's collate does (paintnet_ODv1.py:738-747):
+        ~30 distinct (n_segments, n_points) widths, visited in shuffled order.  `info` receives what the recorded calls did DURING THE TIMED
+        STEPS (replayed / eager / recorded; recordings' capacities) and the pool's widths."""
+        loop = DropInLoop(cat, B=args.batch, N=args.points, device=dev, rank=rank, dist_points=dist_points, adam_kwargs=adam_kwargs)
         last = [0.0]
 
         def step(_prof):
@@ -456,8 +461,20 @@ def main():
             return torch.tensor(last[0])
         for _ in range(20):
             step(False)     # optimizer state, allocator, the libraries' lazy kernel selection (a stall of tens of ms in the first steps), and
-                            # [r5] the recordings of maskplanner_amd/graphed.py: each of the four host batches' shapes is seen three times, then recorded
-        dt, per_step, _ = time_steps(step, steps, warmup, barrier)
+                            # the recordings of maskplanner_amd/graphed.py (three eager calls, then one recording per capacity bucket that turns up)
+        for _ in range(warmup):
+            step(False)
+        before = loop.graph_stats()
+        dt, per_step, _ = time_steps(step, steps, 0, barrier)
+        if info is not None:
+            after = loop.graph_stats()
+            timed = {who: {k: after[who][k] - before[who][k] for k in ("replayed", "eager", "recorded")} for who in ("model", "loss")}
+            for who in timed:
+                n = sum(timed[who].values())
+                timed[who]["hit_rate"] = timed[who]["replayed"] / n if n else 0.0
+            w = loop.widths()
+            info.update({"timed_steps": timed, "whole_run": after, "host_batches": len(loop.host_batches), "distinct_gt_widths": len(w),
+                         "gt_width_range": {"n_segments": [w[0][0], w[-1][0]], "n_points": [min(x[1] for x in w), max(x[1] for x in w)]}})
         return dt, per_step, last[0]
 
     line = None
@@ -473,7 +490,9 @@ def main():
         lib.mp_profiler_mark(None)                  # (the side legs' recordings carry no marks)
         ts.check()      # (outside the timed region) a failed stroke-mask matching or a non-finite loss raises here
     else:
-        dt, per_step, final_loss = run_dropin(args.steps, args.warmup, args.dist)
+        dropin_info = {}
+        dt, per_step, final_loss = run_dropin(args.steps, args.warmup, args.dist, info=dropin_info,
+                                              adam_kwargs={"fused": True} if os.environ.get("MASKPLANNER_BENCH_FUSED_ADAM") == "1" else None)
         ts, profiled_steps = None, 0
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -492,6 +511,8 @@ def main():
                        "parallelism": f"dp{world}", "global_batch": args.batch * world, "path": args.path},
             "final_loss": final_loss,
         }
+        if args.path == "dropin":
+            line["recorded_calls"] = dropin_info
         if per_step:
             line["step_ms_median"] = per_step[len(per_step) // 2]
             line["step_ms_min"] = per_step[0]
@@ -574,16 +595,26 @@ def main():
         if side:
             # the drop-in figure next to the harness figure
             k = max(10, min(args.steps, 40))
-            ddt, dper, dloss = run_dropin(k, 3)
+            dinfo = {}
+            ddt, dper, dloss = run_dropin(k, 3, info=dinfo)
             dmed = dper[len(dper) // 2]
             line["dropin_path"] = {"value": args.batch / dmed * 1e3, "unit": "point-clouds/s", "ms_per_step": dmed, "steps": k,
-                                   "step_ms_median": dmed, "ms_per_step_mean": ddt / k * 1e3, "final_loss": dloss,
+                                   "step_ms_median": dmed, "ms_per_step_mean": ddt / k * 1e3, "final_loss": dloss, "recorded_calls": dinfo,
                                    "what": "train_maskplanner.py:182-227 loop body on the drop-in modules: torch.optim.Adam on all parameters, "
                                            "fresh host batch per step (H2D inside the step), FPS starts drawn per call, compute() -> numpy, loss.item(); "
-                                           "[r5] model(...) and loss_handler.compute(...) replay graphs they recorded from their own eager code after three "
-                                           "calls per shape (maskplanner_amd/graphed.py; MASKPLANNER_DROPIN_GRAPH=0: launched op by op); "
-                                           "value / ms_per_step are the MEDIAN step (the loop follows the host, and on these shared hosts single "
-                                           "steps stall for tens of ms: the mean is reported beside it)"}
+                                           "[r6] the host batches are padded per batch like the reference's collate pads them (paintnet_ODv1.py:738-747: "
+                                           "32 batches, ~30 distinct ground-truth widths, shuffled); model(...) and loss_handler.compute(...) replay graphs "
+                                           "they recorded from their own eager code (maskplanner_amd/graphed.py: the loss's ground-truth buffers at "
+                                           "capacity buckets of 128 rows; MASKPLANNER_DROPIN_GRAPH=0: launched op by op); `recorded_calls.timed_steps` = "
+                                           "how many of the timed calls replayed; value / ms_per_step are the MEDIAN step (the loop follows the host, "
+                                           "and on these shared hosts single steps stall for tens of ms: the mean is reported beside it)"}
+            try:        # the same loop with the one-word change `torch.optim.Adam(..., fused=True)` of train_maskplanner.py:159
+                fdt, fper, floss = run_dropin(k, 3, adam_kwargs={"fused": True})
+                fmed = fper[len(fper) // 2]
+                line["dropin_path"]["fused_adam"] = {"value": args.batch / fmed * 1e3, "ms_per_step": fmed, "ms_per_step_mean": fdt / k * 1e3,
+                                                     "final_loss": floss, "what": "torch.optim.Adam(model.parameters(), lr=..., fused=True)"}
+            except Exception as exc:
+                line["dropin_path"]["fused_adam"] = {"error": f"{type(exc).__name__}: {exc}"[:200]}
             # PCIe-inclusive: a fresh host batch every step, collated + sampled on the second stream under the previous step.  In a child
             # process: this runtime spreads the streams a process creates over four hardware queues in creation order, and the streamed
             # step keeps three of them busy -- after the legs above (graph recordings create streams of their own) its streams land

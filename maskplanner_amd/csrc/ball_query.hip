@@ -310,11 +310,22 @@ extern "C" int mp_ball_query_multi_f32(const float* xyz, const float* new_xyz, i
     hipStream_t stream = mp_stream(stream_);
     // small clouds (the second level: 512 points, 128 queries): fewer queries per wave, so that the grid still fills the chip
     const bool small = B * S < 8192;
-    switch ((int)n_radii) {
-        case 1: return small ? launch_bq_multi<2, 1, 8>(xyz, new_xyz, B, N, S, rr, stream) : launch_bq_multi<4, 1, 8>(xyz, new_xyz, B, N, S, rr, stream);
-        case 2: return small ? launch_bq_multi<2, 2, 8>(xyz, new_xyz, B, N, S, rr, stream) : launch_bq_multi<4, 2, 8>(xyz, new_xyz, B, N, S, rr, stream);
-        default: return small ? launch_bq_multi<2, 3, 8>(xyz, new_xyz, B, N, S, rr, stream) : launch_bq_multi<4, 3, 8>(xyz, new_xyz, B, N, S, rr, stream);
+    // [r6] The hit lists take WAVES * Q * sum(K) * 4 bytes of LDS next to the cloud: where four queries per wave do not fit (N = 13312 with
+    // K = 64, N = 10240 with K = 512, N = 5120 with K = 1024) the launch steps down to two queries per wave, then to four waves of two --
+    // the LDS need of r4's one-query-per-wave kernel, so every shape that kernel took still runs.
+#define BQ_TRY(NR_)                                                                                           \
+    {                                                                                                         \
+        int rc = small ? MP_EUNSUPPORTED : launch_bq_multi<4, NR_, 8>(xyz, new_xyz, B, N, S, rr, stream);     \
+        if (rc == MP_EUNSUPPORTED) rc = launch_bq_multi<2, NR_, 8>(xyz, new_xyz, B, N, S, rr, stream);        \
+        if (rc == MP_EUNSUPPORTED) rc = launch_bq_multi<2, NR_, 4>(xyz, new_xyz, B, N, S, rr, stream);        \
+        return rc;                                                                                            \
     }
+    switch ((int)n_radii) {
+        case 1: BQ_TRY(1)
+        case 2: BQ_TRY(2)
+        default: BQ_TRY(3)
+    }
+#undef BQ_TRY
 }
 
 extern "C" int mp_ball_query_f32(const float* xyz, const float* new_xyz, int64_t B, int64_t N, int64_t S,

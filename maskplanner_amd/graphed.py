@@ -17,9 +17,12 @@ module code -- the graphs are recorded FROM it.
 
 Forwards under `torch.no_grad()` (train_maskplanner.py:385-389, test_maskplanner.py:226-230) replay a graph F of their own mode (MASKPLANNER_DROPIN_GRAPH_EVAL=0:
 eager).  Left alone (eager, as before): forwards with autograd on in eval mode, inputs that require a gradient,
-a second forward before the first one's backward (both passes would share the static buffers), a model with a factor store (harness.TrainStep
+a second forward before the first one's backward or while the first one's autograd graph is alive (both passes would share the static
+buffers), a model or parameter that carries hooks (they would stop firing: `_hooked`), a model with a factor store (harness.TrainStep
 schedules `encode` / `heads` itself), a live process group (DDP's hooks hang off AccumulateGrad, which this path bypasses), shapes seen
-fewer than WARM times, and everything after a failed recording.  MASKPLANNER_DROPIN_GRAPH=0 switches the path off.
+fewer than WARM times, and everything after a failed recording.  MASKPLANNER_DROPIN_GRAPH=0 switches the path off -- needed for
+`torch.autograd.grad(loss, model.parameters())`: the replaying node publishes the parameter gradients as `.grad` (it is not connected to the
+parameters' AccumulateGrad nodes: 150 copies per step), so a caller that asks autograd for them as return values gets "unused" inputs.
 """
 import os
 import warnings
@@ -48,9 +51,9 @@ class _Replay(torch.autograd.Function):
     """One autograd node for the whole model: forward = replay F, backward = replay R."""
 
     @staticmethod
-    def forward(ctx, runner, anchor):
+    def forward(ctx, runner, token, anchor):
         runner.graph_f.replay()
-        ctx.runner, ctx.ticket = runner, runner.ticket
+        ctx.runner, ctx.ticket, ctx.token = runner, runner.ticket, token        # (token: see _Token -- it dies with this node)
         return tuple(o.detach().clone() for o in runner.outs_t)
 
     @staticmethod
@@ -79,7 +82,13 @@ class _Replay(torch.autograd.Function):
             else:
                 p.grad.add_(g)
         r.pending = False
-        return None, None
+        return None, None, None
+
+
+class _Token:
+    """Lives as long as the autograd node it is stored on (`ctx.token`): the recorded buffers stay reserved for that node's backward until the
+    NODE is gone -- the tensors that were handed out may die long before it (`loss = f(batch)` keeps the graph, not the model's outputs)."""
+    __slots__ = ("__weakref__",)
 
 
 class _Runner:
@@ -184,13 +193,31 @@ class _Runner:
                     p.grad = g.clone()
             self.ticket += 1
             self.pending = True
-            handed = _Replay.apply(self, self.anchor)
-            self.live = [weakref.ref(o) for o in handed]
+            token = _Token()
+            handed = _Replay.apply(self, token, self.anchor)
+            self.live = [weakref.ref(token)]
+            del token
             outs = iter(handed)
         else:
             self.graph_f.replay()
             outs = iter([o.detach().clone() for o in self.outs_t])
         return tuple(next(outs) if keep else None for keep in self.mask)
+
+
+def _hooked(model):
+    """Anything that observes the module code or the parameters' gradients from outside: forward / pre / backward hooks on a submodule fire
+    only while the eager code runs (a replay launches kernels, not modules), tensor hooks and post-accumulate hooks on a parameter never fire
+    (the replaying node assigns `.grad` itself).  A model that carries one stays on the eager path."""
+    import torch.nn.modules.module as M
+    if M._global_forward_hooks or M._global_forward_pre_hooks or M._global_backward_hooks or M._global_backward_pre_hooks:
+        return True
+    for m in model.modules():
+        if m._forward_hooks or m._forward_pre_hooks or m._backward_hooks or m._backward_pre_hooks:
+            return True
+    for p in model.parameters():
+        if p._backward_hooks or getattr(p, "_post_accumulate_grad_hooks", None):
+            return True
+    return False
 
 
 def _eligible(model, xyz):
@@ -202,6 +229,8 @@ def _eligible(model, xyz):
     if not train and not (EVAL and not torch.is_grad_enabled()):
         return None
     if torch.distributed.is_available() and torch.distributed.is_initialized():
+        return None
+    if _hooked(model):
         return None
     return train
 
@@ -236,11 +265,14 @@ def call(model, xyz):
         reset(model)
         return None
     if r.pending and all(w() is None for w in r.live):
-        r.pending = False      # that forward's outputs are gone: nobody can backpropagate through it any more
+        r.pending = False      # that forward's autograd node is gone: nobody can backpropagate through it any more
+    stats = model.__dict__.setdefault("_graph_stats", {"replayed": 0, "eager": 0, "recorded": 0})
     if r.pending:              # the previous forward of this shape may still be backpropagated: its buffers are in use, this call runs eagerly
+        stats["eager"] += 1
         return None
     r.calls += 1
     if r.graph_f is None and r.calls <= WARM:
+        stats["eager"] += 1
         pu._draw_log = log = []          # which FPS starts one forward of this shape draws: the recording's static inputs
         try:
             out = model._forward_eager(xyz)
@@ -249,7 +281,10 @@ def call(model, xyz):
         r.draws = list(log)
         return out
     try:
-        return r(xyz)
+        recorded = r.graph_f is not None
+        out = r(xyz)
+        stats["replayed" if recorded else "recorded"] += 1
+        return out
     except Exception as exc:
         if r.graph_f is not None and r.graph_r is not None or (r.graph_f is not None and not train):
             raise          # a recorded runner that fails at replay is a bug, not a reason to fall back silently
@@ -262,6 +297,14 @@ def call(model, xyz):
         return None
 
 
+def stats(model):
+    """Counters of the model's qualifying forwards: replayed / eager (warm-up) / recorded, and the hit rate."""
+    st = dict(model.__dict__.get("_graph_stats") or {"replayed": 0, "eager": 0, "recorded": 0})
+    n = st["replayed"] + st["eager"] + st["recorded"]
+    st["hit_rate"] = st["replayed"] / n if n else 0.0
+    return st
+
+
 def reset(model):
     """Drop the recorded graphs of a model (after its parameters were replaced, e.g. `load_state_dict(assign=True)` or `.to()`)."""
     model.__dict__.pop("_graph_runners", None)
@@ -270,18 +313,36 @@ def reset(model):
 # ---------------------------------------------------------------------------------------------------------------------------------------
 # LossHandler.compute(...) of the same loop (train_maskplanner.py:212-218): graph L = every launch of the weighted terms for one set of
 # argument shapes and one config, graph LB = its backward from a static scalar into static gradients of the arguments that require one
-# (the model's outputs).  The reference's datasets pad every sample to the same number of segments (utils/dataset/paintnet_ODv1.py:293,
-# multipathdataset.py:400-402), so the shapes repeat from batch to batch; the config is part of the key because the reference changes loss
-# weights between epochs (PSACDScheduler, train_maskplanner.py:168).
+# (the model's outputs).
+#
+# [r6] The ground-truth arguments do NOT keep their shape from batch to batch: the maskplanner alias samples trajectories at equal spacing
+# (configs/maskplanner/traj_sampling_v2.yaml:1-9: "a varying number of traj points for different samples") and the collate pads every batch to
+# ITS OWN maximum (utils/dataset/paintnet_ODv1.py:738-747): `y` / `stroke_ids` are [B, max n_segments of the batch, ...], `traj_as_pc` is
+# [B, max n_points of the batch, 6], a new width with nearly every shuffled batch.  What makes one recording serve them all is the padding
+# contract itself: rows of -100 (ids: -1) behind a sample's last real row are what the collate writes, every kernel of the terms takes a
+# sample's length from the first sentinel row (pytorch3d_chamfer.py:138-149; ops.padded_lengths), and rows behind it reach no result.  So the
+# recording's static ground-truth buffers are allocated at a CAPACITY -- the batch's width rounded up to the next multiple of BUCKET rows --,
+# every call writes its batch into the leading columns and the sentinel behind them, and a recording serves every batch whose widths fit
+# its capacities.  Host tensors (the loop hands `stroke_ids` / `traj_as_pc` over as the collate made them, loss_handler.py:629, 838) are staged
+# through a persistent pinned image of the static buffer: one asynchronous copy per argument instead of a pageable one that waits.
+# The config is part of the key because the reference changes loss weights between epochs (PSACDScheduler, train_maskplanner.py:168) --
+# the entries the terms actually READ (LossHandler._cfg_reads), not the whole merged config of the run.
 LOSS = os.environ.get("MASKPLANNER_DROPIN_GRAPH_LOSS", "1") != "0"
-MAX_LOSS_KEYS = 4
+MAX_LOSS_KEYS = 4        # recordings kept per handler; the least recently USED one goes first
+BUCKET = int(os.environ.get("MASKPLANNER_DROPIN_GRAPH_BUCKET", "128"))       # rows; capacities are multiples of it
+# the collate's sentinels (paintnet_ODv1.py:743-747: add_fake_vectors_v2 -> -100 rows, add_fake_values_v2(fake_value=-1))
+PAD_SENTINEL = {"y": -100.0, "traj_as_pc": -100.0, "stroke_ids": -1.0, "stroke_ids_as_pc": -1.0}
+
+
+def _capacity(w):
+    return max(BUCKET, -(-int(w) // BUCKET) * BUCKET)
 
 
 class _LossReplay(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, runner, *req):
+    def forward(ctx, runner, token, *req):
         runner.graph_l.replay()
-        ctx.runner, ctx.ticket = runner, runner.ticket
+        ctx.runner, ctx.ticket, ctx.token = runner, runner.ticket, token
         return runner.total.detach().clone()
 
     @staticmethod
@@ -293,21 +354,62 @@ class _LossReplay(torch.autograd.Function):
         r.gout.copy_(g)
         r.graph_lb.replay()
         r.pending = False
-        return (None,) + tuple(r.in_grads)
+        return (None, None) + tuple(r.in_grads)
 
 
 class _LossRunner:
-    def __init__(self):
+    def __init__(self, caps):
         self.failed, self.calls, self.pending, self.ticket, self.live = False, 0, False, 0, None
         self.graph_l = self.graph_lb = None
+        self.caps = dict(caps)           # padded argument -> capacity (rows along dim 1)
+
+    def covers(self, widths):
+        return all(self.caps.get(k, -1) >= w for k, w in widths.items()) and len(widths) == len(self.caps)
+
+    # -- the ground-truth arguments: leading columns = the batch, sentinel behind them --------------------------------------------------
+    def _stage(self, k, v):
+        st, fill, w = self.static[k], PAD_SENTINEL[k], v.shape[1]
+        if v.is_cuda:
+            st[:, :w].copy_(v, non_blocking=True)
+            if w < self.width[k]:
+                st[:, w:self.width[k]].fill_(fill)
+        else:
+            pins = self.pins.get(k)
+            if pins is None:       # two pinned images of the static buffer in turn: the copy of call i may still be read when call i + 1 fills its own
+                pins = self.pins[k] = [dict(buf=torch.full(st.shape, fill, dtype=st.dtype).pin_memory(), ev=torch.cuda.Event(), busy=False, w=st.shape[1])
+                                       for _ in range(2)]
+            slot = pins[self.ticket % 2]
+            if slot["busy"]:
+                slot["ev"].synchronize()
+            # (numpy views: a torch CPU copy of this size fans out over the intra-op thread pool, whose workers then spin on every core of the
+            # host -- on a shared box the loop's own thread lost ~90 ms to them every few steps)
+            buf = slot.get("np")
+            if buf is None:
+                buf = slot["np"] = slot["buf"].numpy()
+            buf[:, :w] = v.detach().numpy()
+            if w < slot["w"]:
+                buf[:, w:slot["w"]] = fill
+            slot["w"] = w
+            buf = slot["buf"]
+            st.copy_(buf, non_blocking=True)
+            slot["ev"].record()
+            slot["busy"] = True
+        self.width[k] = w
 
     def _record(self, handler, args):
         from .harness import _capture_kw
         dev = args["y_pred"].device
         self.names = [k for k, v in args.items() if isinstance(v, torch.Tensor)]
-        self.static, self.req = {}, []
+        self.static, self.req, self.pins, self.width = {}, [], {}, {}
         for k in self.names:
             v = args[k]
+            if k in self.caps:
+                shape = (v.shape[0], self.caps[k]) + tuple(v.shape[2:])
+                self.static[k] = torch.full(shape, PAD_SENTINEL[k], dtype=v.dtype, device=dev)
+                self.width[k] = self.caps[k]
+                with torch.no_grad():
+                    self._stage(k, v)
+                continue
             st = torch.empty(v.shape, dtype=v.dtype, device=dev)
             with torch.no_grad():              # (a LEAF: copying a tensor with history into it under autograd would hang it onto that history)
                 st.copy_(v)
@@ -340,31 +442,63 @@ class _LossRunner:
         torch.cuda.synchronize(dev)
 
     def __call__(self, handler, args):
+        self.ticket += 1
         if self.graph_l is None:
             self._record(handler, args)
-        with torch.no_grad():
-            for k in self.names:
-                self.static[k].copy_(args[k], non_blocking=True)
+        else:
+            with torch.no_grad():
+                for k in self.names:
+                    if k in self.caps:
+                        self._stage(k, args[k])
+                    else:
+                        self.static[k].copy_(args[k], non_blocking=True)
         handler.last_match_status = self.status
-        self.ticket += 1
         self.pending = True
-        total = _LossReplay.apply(self, *[args[k] for k in self.req])
-        self.live = weakref.ref(total)
+        token = _Token()
+        total = _LossReplay.apply(self, token, *[args[k] for k in self.req])
+        self.live = weakref.ref(token)
+        del token
         return total, self.values
 
 
+def _cfg_signature(handler):
+    """The config entries the handler's terms have read so far, with their current values (None: nothing read yet -- the first call)."""
+    reads = getattr(handler, "_cfg_reads", None)
+    if not reads:
+        return None
+    cfg = handler._cfg(track=False)
+    return tuple((k, repr(cfg.get(k))) for k in sorted(reads))
+
+
 def _loss_key(handler, args):
-    sig = []
+    """(what must be equal for a recording to serve the call, {padded ground-truth argument: its width}) or None."""
+    sig, widths = [], {}
     for k in sorted(args):
         v = args[k]
         if isinstance(v, torch.Tensor):
-            sig.append((k, tuple(v.shape), v.dtype, v.device.type, v.requires_grad))
+            if k in PAD_SENTINEL and v.dim() >= 2 and not v.requires_grad and v.dtype.is_floating_point:
+                widths[k] = v.shape[1]
+                sig.append((k, v.shape[0], tuple(v.shape[2:]), v.dtype, "padded"))
+            else:
+                sig.append((k, tuple(v.shape), v.dtype, v.device.type, v.requires_grad))
         elif v is None or isinstance(v, (int, float, bool, str)):
             sig.append((k, v))
         else:
             return None                    # (lists of per-sample tensors and the like: not a fixed set of buffers)
-    cfg = handler._cfg()
-    return tuple(sig), tuple(handler.loss), repr([(k, cfg[k]) for k in sorted(cfg.keys())])
+    cfg = _cfg_signature(handler)
+    if cfg is None:
+        return None
+    return (tuple(sig), tuple(handler.loss), cfg), widths
+
+
+def loss_stats(handler):
+    """Counters of one handler's compute() calls that qualified for the recorded path: replayed / eager (warm-up, buffers in use) / recorded /
+    evicted, the recordings' capacities, and the hit rate = replayed / (replayed + eager + recorded)."""
+    st = dict(handler.__dict__.get("_graph_stats") or {"replayed": 0, "eager": 0, "recorded": 0, "evicted": 0})
+    n = st["replayed"] + st["eager"] + st["recorded"]
+    st["hit_rate"] = st["replayed"] / n if n else 0.0
+    st["capacities"] = [dict(r.caps) for r in handler.__dict__.get("_graph_runners", {}).values() if r.graph_l is not None]
+    return st
 
 
 def loss_call(handler, args, return_list=True):
@@ -378,23 +512,49 @@ def loss_call(handler, args, return_list=True):
     key = _loss_key(handler, args)
     if key is None:
         return None
+    fixed, widths = key
     runners = handler.__dict__.setdefault("_graph_runners", _Runners())
-    r = runners.get(key)
+    stats = handler.__dict__.setdefault("_graph_stats", {"replayed": 0, "eager": 0, "recorded": 0, "evicted": 0})
+    # the eager warm-up calls are counted per argument signature, not per capacity or config: what they are for (lazy initialisation, the
+    # allocator, kernel selection) depends on neither, so a batch that needs a larger capacity later, or an epoch with rescheduled weights,
+    # is recorded at its first sighting
+    seen = handler.__dict__.setdefault("_graph_seen", {})
+    warm = fixed[:2]
+    seen[warm] = seen.get(warm, 0) + 1
+    if len(seen) > 4 * MAX_LOSS_KEYS:
+        seen.pop(next(iter(seen)))
+    # a recording whose capacities hold this batch serves it (the smallest such); a shape one of them covers is never recorded again
+    full, r = None, None
+    for k, cand in runners.items():
+        if k[0] == fixed and cand.graph_l is not None and cand.covers(widths):
+            if r is None or sum(cand.caps.values()) < sum(r.caps.values()):
+                full, r = k, cand
     if r is None:
-        while len(runners) >= MAX_LOSS_KEYS:
-            runners.pop(next(iter(runners)))       # oldest recording (an earlier epoch's weights)
-        r = runners[key] = _LossRunner()
+        if seen[warm] <= WARM:
+            stats["eager"] += 1
+            return None
+        caps = tuple(sorted((k, _capacity(w)) for k, w in widths.items()))
+        full = (fixed, caps)
+        r = runners.get(full)
+        if r is None:
+            while len(runners) >= MAX_LOSS_KEYS:
+                runners.pop(next(iter(runners)))       # least recently used (an earlier epoch's weights, a capacity no batch asks for any more)
+                stats["evicted"] += 1
+            r = runners[full] = _LossRunner(caps)
+    runners[full] = runners.pop(full)                  # most recently used: last
     if r.failed:
         return None
     if r.pending and (r.live is None or r.live() is None):
-        r.pending = False
+        r.pending = False      # that call's autograd node is gone: nobody can backpropagate through it any more
     if r.pending:
+        stats["eager"] += 1
         return None
     r.calls += 1
-    if r.graph_l is None and r.calls <= WARM:
-        return None
     try:
-        return r(handler, args)
+        recorded = r.graph_l is not None
+        out = r(handler, args)
+        stats["replayed" if recorded else "recorded"] += 1
+        return out
     except Exception as exc:
         if r.graph_l is not None:
             raise

@@ -5,6 +5,8 @@ batches come from maskplanner_amd.synthetic with the collated-tensor contract of
 """
 import os
 
+import numpy as np
+
 import torch
 
 from . import dp, synthetic
@@ -973,9 +975,15 @@ class DropInLoop:
     numpy list of terms and `loss.item()` (:212-224) -- two host synchronisations per step.  No factor heads, no pipelined sampling, no fused
     optimizer: this is the drop-in figure, `TrainStep` is the path's ceiling.  ([r5] What the loop cannot see is how `model(...)` and
     `loss_handler.compute(...)` launch their work: after three calls per shape they replay graphs recorded from their own eager code,
-    maskplanner_amd/graphed.py.)"""
+    maskplanner_amd/graphed.py.)
 
-    def __init__(self, category="cuboids", B=32, N=5120, device="cuda", seed=1235, lr=1e-3, dist_points="cuboid", n_batches=4,
+    [r6] The host batches are what the reference's collate produces for the maskplanner alias (traj_with_equally_spaced_points:
+    configs/maskplanner/traj_sampling_v2.yaml:9): every batch padded to ITS OWN maximum (utils/dataset/paintnet_ODv1.py:738-747), so `traj`,
+    `stroke_ids` and `traj_as_pc` change width from batch to batch.  `n_batches` (default 32) of them, visited in a shuffled order per pass
+    like the loop's `DataLoader(shuffle=True)`; `widths()` says how many distinct shapes the pool holds, `graph_stats()` how often the two
+    calls replayed."""
+
+    def __init__(self, category="cuboids", B=32, N=5120, device="cuda", seed=1235, lr=1e-3, dist_points="cuboid", n_batches=32,
                  rank=0, adam_kwargs=None):
         self.cat = synthetic.CATEGORIES[category] if isinstance(category, str) else category
         self.device = torch.device(device)
@@ -987,12 +995,24 @@ class DropInLoop:
         self.loss_handler = LossHandler(["asymm_v6_chamfer_with_stroke_masks"], self.cfg)  # :163
         self.host_batches = [synthetic.make_batch(seed + 1000 * rank + 7 * i, B, N, self.cat.name, dist_points) for i in range(n_batches)]
         self._i = 0
+        self._order = list(range(n_batches))
+        self._rng = np.random.default_rng(seed + 17)
         self.tot_loss, self.tot_loss_list = 0.0, 0.0
+
+    def widths(self):
+        """The distinct (n_segments, n_points) paddings of the pool's batches."""
+        return sorted({(int(b["traj"].shape[1]), int(b["traj_as_pc"].shape[1])) for b in self.host_batches})
+
+    def graph_stats(self):
+        from . import graphed
+        return {"model": graphed.stats(self.model), "loss": graphed.loss_stats(self.loss_handler)}
 
     def step(self):
         """One iteration of the loop body; returns the host float `loss.item()`."""
-        import numpy as np
-        data = self.host_batches[self._i % len(self.host_batches)]
+        n = len(self.host_batches)
+        if self._i % n == 0 and n > 1:
+            self._rng.shuffle(self._order)        # a new pass over the pool: the DataLoader's shuffle (train_maskplanner.py:135-141)
+        data = self.host_batches[self._order[self._i % n]]
         self._i += 1
         model, device = self.model, self.device
         if self._i == 1:

@@ -37,21 +37,30 @@ def get_dim_traj_points(extra_data):
 
 
 class _Config:
-    """Mapping + attribute access over whatever config object the caller uses (the reference mixes both)."""
+    """Mapping + attribute access over whatever config object the caller uses (the reference mixes both).  `reads` (a set, optional)
+    collects the keys that are looked up: the recorded loss path keys its recordings on the entries the terms actually read
+    (graphed._cfg_signature), not on the whole merged config of a run."""
 
-    def __init__(self, cfg):
+    def __init__(self, cfg, reads=None):
         object.__setattr__(self, "_cfg", cfg)
+        object.__setattr__(self, "_reads", reads)
 
     def __getitem__(self, k):
+        if self._reads is not None:
+            self._reads.add(k)
         return self._cfg[k]
 
     def __getattr__(self, k):
+        if self._reads is not None:
+            self._reads.add(k)
         try:
             return self._cfg[k]
         except (KeyError, TypeError):
             return getattr(self._cfg, k)
 
     def get(self, k, default=None):
+        if self._reads is not None:
+            self._reads.add(k)
         try:
             return self._cfg[k]
         except (KeyError, AttributeError):
@@ -175,6 +184,7 @@ class LossHandler:
 
     def __init__(self, loss, config=None):
         loss = [loss] if isinstance(loss, str) else list(loss)
+        self._cfg_reads = set()      # config keys the terms look up (see _Config)
         self.loss_names = list(self.LOSS_NAMES)
         self.loss_methods = [getattr(self, "get_" + n, None) or self._out_of_scope(n) for n in self.loss_names]
         self.loss_index = {n: i for i, n in enumerate(self.loss_names)}
@@ -208,8 +218,8 @@ class LossHandler:
             raise NotImplementedError(f"loss term {name!r} is outside the MaskPlanner hot path of this build")
         return method
 
-    def _cfg(self):
-        return _Config(self.config)
+    def _cfg(self, track=True):
+        return _Config(self.config, self.__dict__.get("_cfg_reads") if track else None)
 
     # ---------------------------------------------------------------------------------------------------------
     def compute(self, return_list=True, **loss_args):

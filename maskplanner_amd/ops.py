@@ -249,7 +249,12 @@ def ball_query_multi(radii, nsamples, xyz, new_xyz, out=None):
     rr = (ctypes.c_double * n)(*[float(r) for r in radii])
     kk = (ctypes.c_int64 * n)(*[int(k) for k in nsamples])
     oo = (ctypes.c_void_p * n)(*[t.data_ptr() for t in idxs])
-    _run("ball_query_multi", xyz, _lib.load().mp_ball_query_multi_f32, _p(xyz), _p(new_xyz), B, N, S, n, rr, kk, oo)
+    with torch.cuda.device(xyz.device):
+        rc = _lib.load().mp_ball_query_multi_f32(_p(xyz), _p(new_xyz), B, N, S, n, rr, kk, oo, _stream(xyz))
+    if rc == _lib.MP_EUNSUPPORTED and n > 1 and N <= 13312 and max(nsamples) <= 1024:
+        # the lists of all radii do not fit beside the cloud in LDS (large N x large group sizes): one scan per radius, as the reference does
+        return [ball_query(r, k, xyz, new_xyz, out=idxs[i]) for i, (r, k) in enumerate(zip(radii, nsamples))]
+    _lib.check(rc, "ball_query_multi")
     return idxs
 
 

@@ -180,7 +180,7 @@ def test_the_loop_body_on_graphs_trains_like_the_eager_loop(mods):
         graphed.ENABLED = on
         try:
             torch.manual_seed(11)
-            loop = DropInLoop("cuboids", B=8, N=1024)
+            loop = DropInLoop("cuboids", B=8, N=1024, n_batches=4)       # (four batches in rotation: the loss of a pass is comparable to the last one's)
             runs[on] = [loop.step() for _ in range(30)]
             if on:
                 assert any(r.graph_r is not None for r in loop.model._graph_runners.values())
@@ -204,7 +204,7 @@ def test_replayed_loss_equals_the_eager_loss(mods):
     model = pc.maskplanner_model(cat, hidden_size=(256, 256)).cuda().eval()
     handlers = {on: LossHandler(["asymm_v6_chamfer_with_stroke_masks"], maskplanner_loss_config()) for on in (False, True)}
     W = graphed.WARM
-    data = synthetic.make_batch(300, B, N, cat.name, "cuboid")       # (the reference's datasets pad every sample to ONE length: the shapes repeat)
+    data = synthetic.make_batch(300, B, N, cat.name, "cuboid")       # (one batch: the widths repeat; the ragged case is the next test)
     x = data["point_cloud"].permute(0, 2, 1).cuda().float()
     with torch.no_grad():
         base = model(x)
@@ -226,7 +226,9 @@ def test_replayed_loss_equals_the_eager_loss(mods):
                 graphed.ENABLED = True
             res[on] = (loss.detach(), terms, [l.grad for l in leaves if l is not None])
             if on:
-                assert type(loss.grad_fn).__name__.startswith("_LossReplay") == (W <= i < W + 2 or i >= 2 * W + 2), i
+                # recorded on the fourth call; the rescheduled weight is recorded at its FIRST sighting (the eager warm-up is per argument
+                # signature, not per config)
+                assert type(loss.grad_fn).__name__.startswith("_LossReplay") == (i >= W), i
         assert _rel(res[True][0], res[False][0]) < 1e-5
         assert np.allclose(res[True][1], res[False][1], rtol=1e-5)
         for a, b in zip(res[True][2], res[False][2]):
@@ -234,6 +236,188 @@ def test_replayed_loss_equals_the_eager_loss(mods):
             if a is not None:
                 assert _rel(a, b) < 1e-4
     assert len(handlers[True]._graph_runners) == 2          # the two weights
+    st = graphed.loss_stats(handlers[True])
+    assert st["recorded"] == 2 and st["eager"] == W and st["replayed"] == W + 2 and st["evicted"] == 0, st
+
+
+def _narrow(synthetic, lo, hi):
+    """cuboids with the ground-truth pose count of a sample drawn from [lo, hi]: the batch maxima (= the collate's padding widths) fall where
+    the test wants them."""
+    import dataclasses
+    return dataclasses.replace(synthetic.CATEGORIES["cuboids"], points_lo=lo, points_hi=hi)
+
+
+def _loss_inputs(model, data, seed):
+    x = data["point_cloud"].permute(0, 2, 1).cuda().float()
+    with torch.no_grad():
+        base = model(x)
+    torch.manual_seed(seed)
+    return [None if o is None else o + 0.05 * torch.randn_like(o) for o in base]
+
+
+def _compute(handler, outs, data):
+    leaves = [o.detach().clone().requires_grad_(True) if o is not None else None for o in outs]
+    y = data["traj"].cuda().float()          # (the loop's own statement, train_maskplanner.py:208; stroke_ids / traj_as_pc stay host tensors)
+    loss, terms = handler.compute(y_pred=leaves[0], y=y, pred_stroke_masks=leaves[1], mask_scores=leaves[2], seg_logits=leaves[3],
+                                  stroke_ids=data["stroke_ids"], traj_as_pc=data["traj_as_pc"])
+    loss.backward()
+    return loss, terms, [l.grad for l in leaves if l is not None]
+
+
+def test_ragged_ground_truth_widths_share_recordings(mods):
+    """[r6] The reference's collate pads every batch to its own maximum (utils/dataset/paintnet_ODv1.py:738-747; traj_sampling_v2.yaml:9): 16
+    batches with 16 distinct (n_segments, n_points) widths, shuffled, twice over.  At most two recordings (one per capacity bucket the widths
+    fall into), everything after them replays, and every call's loss and gradients equal the eager call's."""
+    graphed, pc, pu, synthetic = mods
+    from maskplanner_amd.loss_handler import LossHandler, maskplanner_loss_config
+    B, N = 4, 1024
+    torch.manual_seed(31)
+    model = pc.maskplanner_model(synthetic.CATEGORIES["cuboids"], hidden_size=(256, 256)).cuda().eval()
+    pool, widths = [], set()
+    seed = 700
+    while len(pool) < 16:
+        # 13 batches whose pose maxima fall into (2816, 2944], three into (2944, 3072]; the segment maxima all into (896, 1024]
+        cat = _narrow(synthetic, 2830, 2940) if len(pool) < 13 else _narrow(synthetic, 2950, 3060)
+        d = synthetic.make_batch(seed, B, N, cat, "cuboid")
+        seed += 1
+        w = (d["traj"].shape[1], d["traj_as_pc"].shape[1])
+        if w not in widths:
+            widths.add(w)
+            pool.append(d)
+    assert len(widths) == 16 and len({w[0] for w in widths}) > 4 and len({w[1] for w in widths}) > 8
+    order = list(np.random.default_rng(5).permutation(16)) + list(np.random.default_rng(6).permutation(16))
+    handlers = {on: LossHandler(["asymm_v6_chamfer_with_stroke_masks"], maskplanner_loss_config()) for on in (False, True)}
+    replayed = 0
+    for step, j in enumerate(order):
+        data = pool[j]
+        outs = _loss_inputs(model, data, 900 + step)
+        res = {}
+        for on in (False, True):
+            graphed.ENABLED = on
+            try:
+                res[on] = _compute(handlers[on], outs, data)
+            finally:
+                graphed.ENABLED = True
+        replayed += type(res[True][0].grad_fn).__name__.startswith("_LossReplay")
+        assert _rel(res[True][0], res[False][0]) < 1e-6, (step, _rel(res[True][0], res[False][0]))
+        assert np.allclose(res[True][1], res[False][1], rtol=1e-6)
+        for a, b in zip(res[True][2], res[False][2]):
+            assert (a is None) == (b is None)
+            if a is not None:
+                assert _rel(a, b) < 1e-6, (step, _rel(a, b))
+    st = graphed.loss_stats(handlers[True])
+    assert st["recorded"] <= 2 and st["evicted"] == 0, st
+    assert st["replayed"] + st["recorded"] == replayed and st["replayed"] >= len(order) - graphed.WARM - 2, st
+    assert all(c["traj_as_pc"] in (2944, 3072) and c["y"] == 1024 and c["stroke_ids"] == 1024 for c in st["capacities"]), st
+
+
+def test_loss_recordings_are_evicted_least_recently_used(mods):
+    """More configs than MAX_LOSS_KEYS (the reference reschedules loss weights between epochs): the recording that was USED longest ago goes,
+    not the one that was recorded first; a call whose shapes were seen once is not recorded."""
+    graphed, pc, pu, synthetic = mods
+    from maskplanner_amd.loss_handler import LossHandler, maskplanner_loss_config
+    B, N = 4, 1024
+    torch.manual_seed(32)
+    model = pc.maskplanner_model(synthetic.CATEGORIES["cuboids"], hidden_size=(256, 256)).cuda().eval()
+    data = synthetic.make_batch(310, B, N, "cuboids", "cuboid")
+    outs = _loss_inputs(model, data, 1)
+    lh = LossHandler(["asymm_v6_chamfer_with_stroke_masks"], maskplanner_loss_config())
+    K = graphed.MAX_LOSS_KEYS
+
+    def call(weight):
+        lh.config["weight_asymm_v6_chamfer_with_stroke_masks"] = weight
+        loss, _, _ = _compute(lh, outs, data)
+        return loss
+
+    def recorded_weights():
+        return sorted(float(dict(k[0][2])["weight_asymm_v6_chamfer_with_stroke_masks"]) for k, r in lh._graph_runners.items() if r.graph_l is not None)
+    for _ in range(graphed.WARM):
+        call(1.0)
+    for w in range(1, K + 1):                       # K recordings: weights 1 .. K
+        assert type(call(float(w)).grad_fn).__name__.startswith("_LossReplay")
+    assert recorded_weights() == [float(w) for w in range(1, K + 1)]
+    call(1.0)                                       # weight 1 is the most recently used now
+    call(float(K + 1))                              # one more than fits: the least recently used (2) goes
+    assert recorded_weights() == sorted([1.0] + [float(w) for w in range(3, K + 2)])
+    st = graphed.loss_stats(lh)
+    assert st["evicted"] == 1 and st["recorded"] == K + 1, st
+    ref = LossHandler(["asymm_v6_chamfer_with_stroke_masks"], maskplanner_loss_config(weight_asymm_v6_chamfer_with_stroke_masks=1.0))
+    graphed.ENABLED = False
+    try:
+        want, _, _ = _compute(ref, outs, data)
+    finally:
+        graphed.ENABLED = True
+    assert _rel(call(1.0), want) < 1e-6             # the survivor still computes the loss
+    # another batch size, seen once: eager, nothing recorded for it
+    small = {k: (v[:2] if isinstance(v, torch.Tensor) and v.dim() and v.shape[0] == B else v) for k, v in data.items()}
+    n = len(lh._graph_runners)
+    loss, _, _ = _compute(lh, [None if o is None else o[:2] for o in outs], small)
+    assert not type(loss.grad_fn).__name__.startswith("_LossReplay") and len(lh._graph_runners) == n
+
+
+def test_hooks_keep_the_model_eager(mods):
+    """A forward hook on a submodule or a gradient hook on a parameter observes the eager code; a replay would silence it."""
+    graphed, pc, pu, synthetic = mods
+    x = _clouds(4, 1024, 70)
+    m = _model(pc, synthetic, seed=9)
+    fired = []
+    h = m.sa1.register_forward_hook(lambda mod, a, out: fired.append(1))
+    for _ in range(graphed.WARM + 2):
+        m.zero_grad()
+        o = m(x)[0]
+        assert not type(o.grad_fn).__name__.startswith("_Replay")
+        o.sum().backward()
+    assert len(fired) == graphed.WARM + 2 and not m.__dict__.get("_graph_runners")
+    h.remove()
+    seen = []
+    h = m.fc3.weight.register_hook(lambda g: seen.append(float(g.abs().max())))
+    for _ in range(graphed.WARM + 2):
+        m.zero_grad()
+        o = m(x)[0]
+        assert not type(o.grad_fn).__name__.startswith("_Replay")
+        o.sum().backward()
+    assert len(seen) == graphed.WARM + 2
+    h.remove()
+    for i in range(graphed.WARM + 1):               # hooks gone: recorded after the usual warm-up
+        m.zero_grad()
+        o = m(x)[0]
+        o.sum().backward()
+    assert type(o.grad_fn).__name__.startswith("_Replay")
+
+
+def test_buffers_stay_reserved_while_the_autograd_graph_lives(mods):
+    """`l1 = f(b1); l2 = f(b2); (l1 + l2).backward()` with f dropping the model's outputs: the first call's autograd graph outlives its output
+    tensors, so the second call must not reuse the recorded buffers (it did, and l1's backward raised)."""
+    graphed, pc, pu, synthetic = mods
+    from maskplanner_amd.loss_handler import LossHandler, maskplanner_loss_config
+    cat = synthetic.CATEGORIES["cuboids"]
+    B, N = 4, 1024
+    m = _model(pc, synthetic, seed=10)
+    lh = LossHandler(["asymm_v6_chamfer_with_stroke_masks"], maskplanner_loss_config())
+    batches = [synthetic.make_batch(320 + i, B, N, _narrow(synthetic, 2830, 2940), "cuboid") for i in range(2)]   # (two widths, one capacity bucket)
+    assert batches[0]["traj_as_pc"].shape != batches[1]["traj_as_pc"].shape
+
+    def f(b):
+        out = m(b["point_cloud"].permute(0, 2, 1).cuda().float())
+        return lh.compute(y_pred=out[0], y=b["traj"].cuda().float(), pred_stroke_masks=out[1], mask_scores=out[2], seg_logits=out[3],
+                          stroke_ids=b["stroke_ids"], traj_as_pc=b["traj_as_pc"])[0]
+    for i in range(graphed.WARM + 2):
+        m.zero_grad()
+        f(batches[i % 2]).backward()
+    assert any(r.graph_r is not None for r in m._graph_runners.values()) and any(r.graph_l is not None for r in lh._graph_runners.values())
+    m.zero_grad()
+    l1 = f(batches[0])
+    l2 = f(batches[1])                              # l1's graph is alive: this one runs eagerly, model and loss
+    assert type(l1.grad_fn).__name__.startswith("_LossReplay") and not type(l2.grad_fn).__name__.startswith("_LossReplay")
+    (l1 + l2).backward()
+    both = {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+    assert all(torch.isfinite(g).all() for g in both.values())
+    # and once that graph is gone the recorded path is taken again
+    del l1, l2
+    m.zero_grad()
+    l3 = f(batches[0])
+    assert type(l3.grad_fn).__name__.startswith("_LossReplay")
+    l3.backward()
 
 
 def test_replaced_parameters_drop_the_recording(mods):

@@ -116,6 +116,20 @@ def test_ball_query_all_radii_in_one_scan(oracle, ops, B, N, S, radii, Ks, dist)
             assert np.array_equal(g.cpu().numpy(), oracle.ball_query(r, K, xyz, new_xyz)), (r, K)
 
 
+@pytest.mark.parametrize("B,N,S,radii,Ks", [(1, 13312, 64, [0.3], [64]), (1, 10240, 64, [0.5], [512]), (1, 5120, 64, [0.9], [1024]), (1, 13312, 40, [0.3], [128]),
+                                            (1, 13312, 32, [0.1, 0.2, 0.3], [32, 64, 128])])
+def test_ball_query_at_the_lds_limits(oracle, ops, B, N, S, radii, Ks):
+    """[r6] Shapes inside the documented range (N <= 13312, K <= 1024) whose hit lists do not fit beside the cloud with four queries per wave:
+    the launch steps down to fewer lists per workgroup (and, for several radii, to one scan per radius) instead of refusing."""
+    from maskplanner_amd import synthetic as syn
+    rng = np.random.default_rng(N + sum(Ks))
+    xyz = syn.point_cloud(rng, B, N, "cuboid")
+    new_xyz = np.ascontiguousarray(xyz[:, :S])
+    got = ops.ball_query_multi(radii, Ks, dev(xyz), dev(new_xyz)) if len(radii) > 1 else [ops.ball_query(radii[0], Ks[0], dev(xyz), dev(new_xyz))]
+    for r, K, g in zip(radii, Ks, got):
+        assert np.array_equal(g.cpu().numpy(), oracle.ball_query(r, K, xyz, new_xyz)), (r, K)
+
+
 def test_ball_query_no_hit_returns_N(oracle, ops):
     xyz = np.random.default_rng(0).uniform(-1, 1, size=(1, 200, 3)).astype(np.float32)
     q = np.full((1, 3, 3), 50.0, np.float32)
