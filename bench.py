@@ -54,9 +54,9 @@ def _variant_ok(tag_base, name_base, name_args):
     """The library's launch tags name the operand variant in the kernel name (`pos_gemm_bf16_kernel`, `dw_gemm_split_kernel`,
     `bwd_fused_bf16_kernel`), rocprofv3 prints it as a template argument: PREC (last) of the tiled GEMMs -- 0 fp32 MFMA, 1 bf16,
     3 split planes --, ONE (last) of the position-stream kernels."""
-    bf16, split = "_bf16_" in tag_base, "_split_" in tag_base
+    bf16, split, split2 = "_bf16_" in tag_base, "_split_" in tag_base, "_split2_" in tag_base
     if name_base in ("pos_gemm_kernel", "dw_gemm_kernel"):
-        return name_args[-1:] == [("1" if bf16 else "3" if split else "0")]
+        return name_args[-1:] == [("1" if bf16 else "3" if split else "2" if split2 else "0")]
     if name_base in ("fwd_chunk_kernel", "bwd_fused_kernel") and name_args and name_args[-1] in ("true", "false"):
         return (name_args[-1] == "true") == bf16 if len(name_args) >= (8 if name_base == "fwd_chunk_kernel" else 6) else not bf16
     return True
@@ -75,7 +75,7 @@ def measured_traffic(kernel, config_key=None):
     doc = json.load(open(files[-1]))
     tables = ([doc.get("configs", {}).get(config_key)] if config_key else []) + [doc["kernels"]]
     tbase, args = _split_template(kernel)
-    base = tbase.replace("_bf16_kernel", "_kernel").replace("_split_kernel", "_kernel")
+    base = tbase.replace("_bf16_kernel", "_kernel").replace("_split_kernel", "_kernel").replace("_split2_kernel", "_kernel")
     for table in tables:
         if not table:
             continue
@@ -555,7 +555,7 @@ def main():
                                 "(the two stamp kernels' boundaries, ~3 us, are inside the interval)")
                 flops, nbytes = d["flops"] / d["calls"], d["bytes"] / d["calls"]
                 # [r5] the BACKWARD position-stream kernels run two planes / three products per fp32 product (sa_mlp.hip: split2) unless MP_BWD_PLANES=3
-                bwd2 = os.environ.get("MP_BWD_PLANES", "2") != "3" and any(t in k for t in ("bwd_fused", "bwd_roles"))
+                bwd2 = (os.environ.get("MP_BWD_PLANES", "2") != "3" and any(t in k for t in ("bwd_fused", "bwd_roles"))) or "_split2_" in k
                 planes = (3.0 if bwd2 else 6.0) if (split and "bf16" not in k and "stream16" not in k and any(t in k for t in ("fused", "roles", "chunk", "bwd_first", "gemm", "lean"))) else 1.0
                 # the matrix-core roof is the one the kernel's INSTRUCTIONS run under: bf16 dense peak for the plane products of a split
                 # kernel (`planes` executed bf16 products per algorithmic fp32 product) and for --dtype bf16, the fp32-input MFMA peak otherwise

@@ -551,7 +551,9 @@ __device__ __forceinline__ void mma_chunk_bf16(const __bf16* sA, const __bf16* s
 
 // The six plane products of the split scheme over one K chunk of the tiled kernels: sA / sB point at plane 0, planes are PSA / PSB
 // elements apart.  One A plane is live at a time (l, then h, then m), the three B planes stay.
-template <bool A_TR, bool B_TR, int LDA, int LDB, int TM, int TN, int KC, int PSA, int PSB>
+// [r6] NPL = 2: the two-plane form of the backward contractions (split2: h, m; three products m h, h m, h h -- smallest first), as the
+// position-stream backward kernels have used since r5; two thirds of the fragment reads, half the MFMAs.
+template <bool A_TR, bool B_TR, int LDA, int LDB, int TM, int TN, int KC, int PSA, int PSB, int NPL = 3>
 __device__ __forceinline__ void mma_chunk_split(const __bf16* sA, const __bf16* sB, int wrow0, int wcol0, f32x16 (&acc)[TM][TN])
 {
     const int lane = threadIdx.x & 63;
@@ -566,14 +568,15 @@ __device__ __forceinline__ void mma_chunk_split(const __bf16* sA, const __bf16* 
     };
 #pragma unroll
     for (int ks = 0; ks < KC; ks += 16) {
-        bf16x8 a[TM], b[3][TN];
+        bf16x8 a[TM], b[NPL][TN];
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
+        for (int pl = 0; pl < NPL; ++pl)
 #pragma unroll
             for (int ni = 0; ni < TN; ++ni) b[pl][ni] = bfrag(pl, ks, ni);
-        constexpr int APL[3] = {2, 0, 1}, NB[3] = {1, 3, 2};      // A plane l meets B plane h; h meets h, m, l; m meets h, m
+        // three planes: A plane l meets B plane h; h meets h, m, l; m meets h, m.  Two planes: m meets h; h meets h, m.
+        constexpr int APL[3] = {NPL == 3 ? 2 : 1, 0, 1}, NB[3] = {1, NPL, 2};
 #pragma unroll
-        for (int s = 0; s < 3; ++s) {
+        for (int s = 0; s < NPL; ++s) {
 #pragma unroll
             for (int mi = 0; mi < TM; ++mi) a[mi] = afrag(APL[s], ks, mi);
             if constexpr ((A_TR || B_TR) && ((MP_TR_FENCE >> 3) & 1)) tr_fence();

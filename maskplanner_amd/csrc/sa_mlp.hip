@@ -38,7 +38,7 @@ namespace {
 enum Epi { EPI_NONE = 0, EPI_SQ = 1, EPI_DY = 2, EPI_SQ_POOL = 3 };
 
 
-template <int MODE, bool W_KROW, int EPI, int WAVES_M, int WAVES_N, int TM, int TN, int PREC = 0>   // PREC: 0 fp32 MFMA, 1 bf16, 3 split (h, m, l) planes
+template <int MODE, bool W_KROW, int EPI, int WAVES_M, int WAVES_N, int TM, int TN, int PREC = 0>   // PREC: 0 fp32 MFMA, 1 bf16, 3 split (h, m, l) planes, 2 [r6] split (h, m) planes: gradients
 __global__ __launch_bounds__(THREADS) void pos_gemm_kernel(PosOperand A, int P, const float* __restrict__ W, int N,
                                                            int Kd, float* __restrict__ C, BnOut partials,
                                                            const float* __restrict__ zprev,
@@ -51,11 +51,11 @@ __global__ __launch_bounds__(THREADS) void pos_gemm_kernel(PosOperand A, int P, 
     constexpr int BN = WAVES_N * TN * 32;
     // (these shadow the file-level constants) split planes on the 64 x 64 tile: K chunks of 64 -- the six-product chunk of 32 is over
     // before the next chunk's loads have landed, and a barrier pair per 12 MFMAs is too many
-    constexpr bool SPL = PREC == 3;
+    constexpr bool SPL = PREC == 3 || PREC == 2;
     constexpr int BK = (SPL && BM * BN <= 64 * 64) ? 64 : MP_BK;
     constexpr int TPR = BK / 4, RPP = 256 / TPR, LDK = BK + 1;
     constexpr bool BF16 = PREC != 0;
-    constexpr int NPL = SPL ? 3 : 1;                              // operand planes in LDS
+    constexpr int NPL = SPL ? PREC : 1;                           // operand planes in LDS
     using TL = std::conditional_t<BF16, __bf16, float>;           // element type of the LDS tiles
     constexpr int LDA = BF16 ? BK + 8 : LDK;                      // bf16: 80-byte rows (16-byte aligned, conflict-free b128 reads)
     constexpr int LDB = BF16 ? (W_KROW ? tr_ld(BN) : BK + 8) : (W_KROW ? BN : LDK);
@@ -113,12 +113,12 @@ __global__ __launch_bounds__(THREADS) void pos_gemm_kernel(PosOperand A, int P, 
 #pragma unroll
         for (int ps = 0; ps < A_PASSES; ++ps) {
             const float4 v = finish<MODE>(ra[ps], kc);
-            if constexpr (PREC == 3) {
-                const Split4 sp = split3(v);
+            if constexpr (SPL) {
+                const Split4 sp = splitn<NPL>(v);
                 const int o = (ps * RPP + arow) * LDA + acol;
                 *reinterpret_cast<bf16x4*>(&sA[buf][o]) = sp.h;
                 *reinterpret_cast<bf16x4*>(&sA[buf][PSA + o]) = sp.m;
-                *reinterpret_cast<bf16x4*>(&sA[buf][2 * PSA + o]) = sp.l;
+                if constexpr (NPL == 3) *reinterpret_cast<bf16x4*>(&sA[buf][2 * PSA + o]) = sp.l;
             } else if constexpr (BF16) {
                 *reinterpret_cast<bf16x4*>(&sA[buf][(ps * RPP + arow) * LDA + acol]) = to_bf16x4(v);
             } else {
@@ -128,13 +128,13 @@ __global__ __launch_bounds__(THREADS) void pos_gemm_kernel(PosOperand A, int P, 
         }
 #pragma unroll
         for (int ps = 0; ps < B_PASSES; ++ps) {
-            if constexpr (PREC == 3) {
+            if constexpr (SPL) {
                 const int e = (ps * THREADS + tid) * 4;
                 const int o = W_KROW ? (e / BN) * LDB + e % BN : (ps * RPP + arow) * LDB + acol;
-                const Split4 sp = split3(rb[ps]);
+                const Split4 sp = splitn<NPL>(rb[ps]);
                 *reinterpret_cast<bf16x4*>(&sB[buf][o]) = sp.h;
                 *reinterpret_cast<bf16x4*>(&sB[buf][PSB + o]) = sp.m;
-                *reinterpret_cast<bf16x4*>(&sB[buf][2 * PSB + o]) = sp.l;
+                if constexpr (NPL == 3) *reinterpret_cast<bf16x4*>(&sB[buf][2 * PSB + o]) = sp.l;
             } else if constexpr (BF16) {
                 if constexpr (W_KROW) {   // slab element e = row k, column n of the [BK][BN] slab
                     const int e = (ps * THREADS + tid) * 4;
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(THREADS) void pos_gemm_kernel(PosOperand A, int P, 
         const int cur = NBUF == 1 ? 0 : (kc_ & 1);
         if (kc_ + 1 < nchunks) gload((kc_ + 1) * BK);
 #ifndef MP_ABLATE_MFMA
-        if constexpr (SPL) mma_chunk_split<false, W_KROW, LDA, LDB, TM, TN, BK, PSA, PSB>(sA[cur], sB[cur], wrow0, wcol0, acc);
+        if constexpr (SPL) mma_chunk_split<false, W_KROW, LDA, LDB, TM, TN, BK, PSA, PSB, NPL>(sA[cur], sB[cur], wrow0, wcol0, acc);
         else if constexpr (BF16) mma_chunk_bf16<false, W_KROW, LDA, LDB, TM, TN, BK>(sA[cur], sB[cur], wrow0, wcol0, acc);
         else mma_chunk<false, W_KROW, LDA, LDB, TM, TN, BK>(sA[cur], sB[cur], wrow0, wcol0, acc);
 #endif
@@ -358,11 +358,12 @@ __global__ __launch_bounds__(THREADS) void dw_gemm_kernel(PosOperand DZ, PosOper
     static_assert(WAVES_M * WAVES_N == 4 && PA >= 1 && PB >= 1, "tile");
     static_assert(BM == 128, "the tail-column path maps 256 threads onto 128 rows x 2 column pairs");
     constexpr bool BF16 = PREC != 0;
-    constexpr int NPL = PREC == 3 ? 3 : 1;
+    constexpr bool SPL = PREC == 3 || PREC == 2;       // [r6] 2: the two-plane form (h, m; three products), see mma_chunk_split
+    constexpr int NPL = SPL ? PREC : 1;
     using TL = std::conditional_t<BF16, __bf16, float>;
     constexpr int LDA = BF16 ? tr_ld(BM) : BM, LDB = BF16 ? tr_ld(BN) : BN;   // bf16: [k][row] tiles read through ds_read_b64_tr_b16
     constexpr int PSA = DBK * LDA, PSB = DBK * LDB;
-    constexpr int NBUF = PREC == 3 ? 1 : 2;       // split planes: one buffer, see pos_gemm_kernel
+    constexpr int NBUF = SPL ? 1 : 2;       // split planes: one buffer, see pos_gemm_kernel
     __shared__ __attribute__((aligned(16))) TL sA[NBUF][NPL * PSA];
     __shared__ __attribute__((aligned(16))) TL sB[NBUF][NPL * PSB];
     __shared__ __attribute__((aligned(16))) float sT[NBUF][DBK * 4];
@@ -408,24 +409,24 @@ __global__ __launch_bounds__(THREADS) void dw_gemm_kernel(PosOperand DZ, PosOper
     auto sstore = [&](int buf) {
 #pragma unroll
         for (int ps = 0; ps < PA; ++ps) {
-            if constexpr (PREC == 3) {
-                const Split4 sp = split3(finish<MODE_DZ>(ra[ps], ka));
+            if constexpr (SPL) {
+                const Split4 sp = splitn<NPL>(finish<MODE_DZ>(ra[ps], ka));
                 const int o = (ka0 + ps * KA_STEP) * LDA + ca;
                 *reinterpret_cast<bf16x4*>(&sA[buf][o]) = sp.h;
                 *reinterpret_cast<bf16x4*>(&sA[buf][PSA + o]) = sp.m;
-                *reinterpret_cast<bf16x4*>(&sA[buf][2 * PSA + o]) = sp.l;
+                if constexpr (NPL == 3) *reinterpret_cast<bf16x4*>(&sA[buf][2 * PSA + o]) = sp.l;
             }
             else if constexpr (BF16) *reinterpret_cast<bf16x4*>(&sA[buf][(ka0 + ps * KA_STEP) * LDA + ca]) = to_bf16x4(finish<MODE_DZ>(ra[ps], ka));
             else *reinterpret_cast<float4*>(&sA[buf][(ps * THREADS + tid) * 4]) = finish<MODE_DZ>(ra[ps], ka);
         }
 #pragma unroll
         for (int ps = 0; ps < PB; ++ps) {
-            if constexpr (PREC == 3) {
-                const Split4 sp = split3(finish<MODE_IN>(rb[ps], kb));
+            if constexpr (SPL) {
+                const Split4 sp = splitn<NPL>(finish<MODE_IN>(rb[ps], kb));
                 const int o = (kb0 + ps * KB_STEP) * LDB + cb;
                 *reinterpret_cast<bf16x4*>(&sB[buf][o]) = sp.h;
                 *reinterpret_cast<bf16x4*>(&sB[buf][PSB + o]) = sp.m;
-                *reinterpret_cast<bf16x4*>(&sB[buf][2 * PSB + o]) = sp.l;
+                if constexpr (NPL == 3) *reinterpret_cast<bf16x4*>(&sB[buf][2 * PSB + o]) = sp.l;
             }
             else if constexpr (BF16) *reinterpret_cast<bf16x4*>(&sB[buf][(kb0 + ps * KB_STEP) * LDB + cb]) = to_bf16x4(finish<MODE_IN>(rb[ps], kb));
             else *reinterpret_cast<float4*>(&sB[buf][(ps * THREADS + tid) * 4]) = finish<MODE_IN>(rb[ps], kb);
@@ -444,7 +445,7 @@ __global__ __launch_bounds__(THREADS) void dw_gemm_kernel(PosOperand DZ, PosOper
     for (int kc = 0; kc < nchunks; ++kc) {
         const int cur = NBUF == 1 ? 0 : (kc & 1);
         if (kc + 1 < nchunks) gload(p0 + (kc + 1) * DBK);
-        if constexpr (PREC == 3) mma_chunk_split<true, true, LDA, LDB, TM, TN, DBK, PSA, PSB>(sA[cur], sB[cur], wrow0, wcol0, acc);
+        if constexpr (SPL) mma_chunk_split<true, true, LDA, LDB, TM, TN, DBK, PSA, PSB, NPL>(sA[cur], sB[cur], wrow0, wcol0, acc);
         else if constexpr (BF16) mma_chunk_bf16<true, true, LDA, LDB, TM, TN, DBK>(sA[cur], sB[cur], wrow0, wcol0, acc);
         else mma_chunk<true, true, LDA, LDB, TM, TN, DBK>(sA[cur], sB[cur], wrow0, wcol0, acc);
         if (do_tail) {   // thread = (output channel tid & 127, column pair tid >> 7); bf16: the rounded dZ, fp32 coordinates
@@ -454,6 +455,7 @@ __global__ __launch_bounds__(THREADS) void dw_gemm_kernel(PosOperand DZ, PosOper
             for (int k = 0; k < DBK; ++k) {
                 float av = (float)a[k * LDA];
                 if constexpr (PREC == 3) av = (av + (float)a[PSA + k * LDA]) + (float)a[2 * PSA + k * LDA];   // h + m + l: the fp32 dZ again
+                if constexpr (PREC == 2) av = av + (float)a[PSA + k * LDA];                                    // h + m
                 tacc0 = __builtin_fmaf(av, t[k * 4], tacc0);
                 tacc1 = __builtin_fmaf(av, t[k * 4 + 1], tacc1);
             }
@@ -1162,7 +1164,7 @@ int launch_dw(const PosOperand& DZ, const PosOperand& IN, int64_t P64, float* dW
     };
     double flops, bytes;
     work(tail_ci >= 0 ? Ci : main_ci, flops, bytes);
-    const char* kn = PREC == 1 ? "dw_gemm_bf16_kernel" : (PREC == 3 ? "dw_gemm_split_kernel" : "dw_gemm_kernel");
+    const char* kn = PREC == 1 ? "dw_gemm_bf16_kernel" : (PREC == 3 ? "dw_gemm_split_kernel" : (PREC == 2 ? "dw_gemm_split2_kernel" : "dw_gemm_kernel"));
     if (main_ci <= 32) {
         snprintf(tag, sizeof tag, "%s<%d, %d, 4, 1, 1, 1>", kn, MODE_DZ, MODE_IN);
         MP_LAUNCH(tag, flops, bytes, (dw_gemm_kernel<MODE_DZ, MODE_IN, 4, 1, 1, 1, PREC>), dim3(gx, gy, (main_ci + 31) / 32), dim3(THREADS), 0, stream, DZ, IN, P, ppb, dW, 0, tail_ci);
@@ -1419,7 +1421,7 @@ int launch_pos_gemm(const PosOperand& A, int64_t P, const float* W, int N, int K
     // (split planes, [r2]: 64 x 64 tiles on all CUs run at 66-80 TFLOP/s on the group_all level; 128 x 128 tiles on half of them were
     // slower: 55 -> 93 us, one workgroup's K loop alone does not cover its load latency)
     char tag[96];
-    const char* kn = PREC == 1 ? "pos_gemm_bf16_kernel" : (PREC == 3 ? "pos_gemm_split_kernel" : "pos_gemm_kernel");
+    const char* kn = PREC == 1 ? "pos_gemm_bf16_kernel" : (PREC == 3 ? "pos_gemm_split_kernel" : (PREC == 2 ? "pos_gemm_split2_kernel" : "pos_gemm_kernel"));
     if (shape == 1) {
         const unsigned gm = (unsigned)((P + 127) / 128);
         if (nblk_out) *nblk_out = (int)gm;
@@ -1571,7 +1573,8 @@ extern "C" int mp_dw_gemm_f32(const float* dz, const float* x, int64_t P, int64_
     PosOperand DZ{}, IN{};
     DZ.x = dz; DZ.C = (int)Co; DZ.K = 1; DZ.kshift = 0;
     IN.x = x; IN.C = (int)Ci; IN.K = 1; IN.kshift = 0;
-    return split_enabled() ? launch_dw<SRC_ID, SRC_ID, 3>(DZ, IN, P, dW, stream) : launch_dw<SRC_ID, SRC_ID, 0>(DZ, IN, P, dW, stream);
+    if (!split_enabled()) return launch_dw<SRC_ID, SRC_ID, 0>(DZ, IN, P, dW, stream);
+    return bwd_planes() == 2 ? launch_dw<SRC_ID, SRC_ID, 2>(DZ, IN, P, dW, stream) : launch_dw<SRC_ID, SRC_ID, 3>(DZ, IN, P, dW, stream);     // (a gradient: two planes, [r6])
 }
 
 extern "C" int mp_sa_mlp_bf16_storage(int n_layers, const int64_t* channels, int64_t K, int first_layer)
@@ -1937,6 +1940,15 @@ static bool factored_ok(const mp_gather_t* g, int64_t P, int64_t K, int n_layers
     return true;
 }
 
+// [r6] the BACKWARD contractions of the tiled kernels on two planes / three products like the position-stream backward kernels (bwd_planes())
+#define MP_POS_GEMM_B(MODE, KROW, EPI, ...)                                                                        \
+    (bf16 ? launch_pos_gemm<MODE, KROW, EPI, 1>(__VA_ARGS__)                                                      \
+          : (split_enabled() ? (npl == 2 ? launch_pos_gemm<MODE, KROW, EPI, 2>(__VA_ARGS__) : launch_pos_gemm<MODE, KROW, EPI, 3>(__VA_ARGS__)) \
+                             : launch_pos_gemm<MODE, KROW, EPI, 0>(__VA_ARGS__)))
+#define MP_DW_GEMM_B(MODE_DZ, MODE_IN, ...)                                                                        \
+    (bf16 ? launch_dw<MODE_DZ, MODE_IN, 1>(__VA_ARGS__)                                                           \
+          : (split_enabled() ? (npl == 2 ? launch_dw<MODE_DZ, MODE_IN, 2>(__VA_ARGS__) : launch_dw<MODE_DZ, MODE_IN, 3>(__VA_ARGS__)) \
+                             : launch_dw<MODE_DZ, MODE_IN, 0>(__VA_ARGS__)))
 #define MP_POS_GEMM(MODE, KROW, EPI, ...)                                                                          \
     (bf16 ? launch_pos_gemm<MODE, KROW, EPI, 1>(__VA_ARGS__)                                                      \
           : (split_enabled() ? launch_pos_gemm<MODE, KROW, EPI, 3>(__VA_ARGS__) : launch_pos_gemm<MODE, KROW, EPI, 0>(__VA_ARGS__)))
@@ -2544,10 +2556,10 @@ static int sa_mlp_bwd(const float* x0, int64_t P, int64_t K, int n_layers, const
         }
         {
             int rc;
-            if (pooled) rc = (l == 0) ? MP_DW_GEMM(SRC_DZ_POOLED, SRC_ID, DZ, IN, P, grads[l].d_weight, stream)
-                                      : MP_DW_GEMM(SRC_DZ_POOLED, SRC_ACT, DZ, IN, P, grads[l].d_weight, stream);
-            else rc = (l == 0) ? MP_DW_GEMM(SRC_DZ, SRC_ID, DZ, IN, P, grads[l].d_weight, stream)
-                               : MP_DW_GEMM(SRC_DZ, SRC_ACT, DZ, IN, P, grads[l].d_weight, stream);
+            if (pooled) rc = (l == 0) ? MP_DW_GEMM_B(SRC_DZ_POOLED, SRC_ID, DZ, IN, P, grads[l].d_weight, stream)
+                                      : MP_DW_GEMM_B(SRC_DZ_POOLED, SRC_ACT, DZ, IN, P, grads[l].d_weight, stream);
+            else rc = (l == 0) ? MP_DW_GEMM_B(SRC_DZ, SRC_ID, DZ, IN, P, grads[l].d_weight, stream)
+                               : MP_DW_GEMM_B(SRC_DZ, SRC_ACT, DZ, IN, P, grads[l].d_weight, stream);
             if (rc != MP_OK) return rc;
             DZ.bn = BnSite{};        // (consumed by the weight-gradient kernel: the kernels below read the constants it wrote)
         }
@@ -2557,9 +2569,9 @@ static int sa_mlp_bwd(const float* x0, int64_t P, int64_t K, int n_layers, const
             float* Gn = gbuf[l & 1];
             int nblk = 0, rc;
             if (pooled)
-                rc = MP_POS_GEMM(SRC_DZ_POOLED, true, EPI_DY, DZ, P, Ly.weight, Ci, Co, Gn, partials, Pv.z, Pv.scale, Pv.shift, stream, &nblk);
+                rc = MP_POS_GEMM_B(SRC_DZ_POOLED, true, EPI_DY, DZ, P, Ly.weight, Ci, Co, Gn, partials, Pv.z, Pv.scale, Pv.shift, stream, &nblk);
             else
-                rc = MP_POS_GEMM(SRC_DZ, true, EPI_DY, DZ, P, Ly.weight, Ci, Co, Gn, partials, Pv.z, Pv.scale, Pv.shift, stream, &nblk);
+                rc = MP_POS_GEMM_B(SRC_DZ, true, EPI_DY, DZ, P, Ly.weight, Ci, Co, Gn, partials, Pv.z, Pv.scale, Pv.shift, stream, &nblk);
             if (rc != MP_OK) return rc;
             // the constants of layer l are still being read by the kernels above: they are stream-ordered, so
             // overwriting cbuf for layer l-1 here is safe.
@@ -2577,9 +2589,9 @@ static int sa_mlp_bwd(const float* x0, int64_t P, int64_t K, int n_layers, const
             const int ldc = compact ? ncols : Ci;
             int rc;
             if (pooled)
-                rc = MP_POS_GEMM(SRC_DZ_POOLED, true, EPI_NONE, DZ, P, Ly.weight, ncols, Co, grad_x0, BnOut{nullptr, nullptr}, nullptr, nullptr, nullptr, stream, nullptr, PoolOut{}, Ci, ldc);
+                rc = MP_POS_GEMM_B(SRC_DZ_POOLED, true, EPI_NONE, DZ, P, Ly.weight, ncols, Co, grad_x0, BnOut{nullptr, nullptr}, nullptr, nullptr, nullptr, stream, nullptr, PoolOut{}, Ci, ldc);
             else
-                rc = MP_POS_GEMM(SRC_DZ, true, EPI_NONE, DZ, P, Ly.weight, ncols, Co, grad_x0, BnOut{nullptr, nullptr}, nullptr, nullptr, nullptr, stream, nullptr, PoolOut{}, Ci, ldc);
+                rc = MP_POS_GEMM_B(SRC_DZ, true, EPI_NONE, DZ, P, Ly.weight, ncols, Co, grad_x0, BnOut{nullptr, nullptr}, nullptr, nullptr, nullptr, stream, nullptr, PoolOut{}, Ci, ldc);
             if (rc != MP_OK) return rc;
             if (!compact && ncols < Ci) {   // the columns that carry no gradient: defined (zero), so that no consumer can read garbage
                 hipLaunchKernelGGL(zero_cols_kernel, dim3((unsigned)((P * (Ci - ncols) + 255) / 256)), dim3(256), 0, stream, grad_x0, P, Ci, ncols);

@@ -7,6 +7,7 @@ parameters (Conv2d weight [Co,Ci,1,1], BatchNorm2d weight/bias/running stats) ar
 reference's state_dict stays valid.
 """
 import ctypes
+import weakref
 
 import os
 
@@ -552,7 +553,7 @@ def prepermute(levels):
         args += [w, *_first_weight_perm(cin, cpad, rotate, w.device)]
     outs = _PermuteColsMulti.apply(len(todo), *args)
     for (conv, *_), o in zip(todo, outs):
-        _PREPERMUTED[id(conv)] = (o, conv.weight._version)
+        _PREPERMUTED[id(conv)] = (o, conv.weight._version, weakref.ref(conv))     # (the module itself: an id() is reused once its owner is gone)
 
 
 def _first_weight_perm(cin, cpad, rotate, device):
@@ -613,8 +614,8 @@ def shared_mlp_max(grouped, convs, bns, layout="xyz_first", dtype="f32", sync_bn
             rotate = layout == "feats_first" and cin > 3
             if rotate or cpad != cin:   # one launch (and one in backward) instead of cat + pad and their autograd
                 pre = _PREPERMUTED.pop(id(conv), None)      # (all levels' first weights permuted together: prepermute())
-                if pre is not None and (pre[1] != conv.weight._version or pre[0].shape != (conv.out_channels, cpad)):
-                    pre = None                              # left over from a forward that never reached this level
+                if pre is not None and (pre[2]() is not conv or pre[1] != conv.weight._version or pre[0].shape != (conv.out_channels, cpad)):
+                    pre = None                              # left over from a forward that never reached this level (or from a module that is gone)
                 w = pre[0] if pre is not None else _PermuteCols.apply(w, *_first_weight_perm(cin, cpad, rotate, w.device))
         track = bn.track_running_stats and bn.running_mean is not None
         if not training and not track:
