@@ -316,7 +316,7 @@ def fps_floors(ts, lib):
             times.append((a, b))
         torch.cuda.synchronize()
         us = sorted(a.elapsed_time(b) * 1e3 for a, b in times[3:])
-        tag = {5120: "fps_kernel<256, 20>", 512: "fps_kernel<64, 8>", 10240: "fps_kernel<512, 20>"}.get(N)
+        tag = {5120: "fps_kernel<512, 10>", 512: "fps_kernel<64, 8>", 10240: "fps_kernel<512, 20>"}.get(N)
         if tag:
             out[tag] = us[len(us) // 2]
         xyz = new_xyz

@@ -24,6 +24,10 @@
 // rows are contiguous: a straight float4 copy).
 #include "sa_common.h"
 
+#ifndef MP_SPLIT2_NBUF
+#define MP_SPLIT2_NBUF 1        // LDS buffers of the two-plane tiled GEMMs ([r6] 2 measured: the pooled dX product 41 -> 64 us, dW 50 -> 60 -- the second buffer costs the co-resident workgroup)
+#endif
+
 namespace {
 
 
@@ -68,7 +72,7 @@ __global__ __launch_bounds__(THREADS) void pos_gemm_kernel(PosOperand A, int P, 
     static_assert(WAVES_M * WAVES_N == 4, "4 waves");
     // split planes: ONE buffer (three planes of each operand are 3x the fp32 tile's bytes; two or three workgroups per CU cover
     // each other's staging instead of a second buffer)
-    constexpr int NBUF = SPL ? 1 : 2;
+    constexpr int NBUF = (SPL && !(PREC == 2 && MP_SPLIT2_NBUF == 2)) ? 1 : 2;      // [r6] two planes, two buffers: measured slower, see MP_SPLIT2_NBUF
     __shared__ __attribute__((aligned(16))) TL sA[NBUF][NPL * PSA];
     __shared__ __attribute__((aligned(16))) TL sB[NBUF][NPL * PSB];
     __shared__ float red[WAVES_M][2][BN];
@@ -363,7 +367,7 @@ __global__ __launch_bounds__(THREADS) void dw_gemm_kernel(PosOperand DZ, PosOper
     using TL = std::conditional_t<BF16, __bf16, float>;
     constexpr int LDA = BF16 ? tr_ld(BM) : BM, LDB = BF16 ? tr_ld(BN) : BN;   // bf16: [k][row] tiles read through ds_read_b64_tr_b16
     constexpr int PSA = DBK * LDA, PSB = DBK * LDB;
-    constexpr int NBUF = SPL ? 1 : 2;       // split planes: one buffer, see pos_gemm_kernel
+    constexpr int NBUF = (SPL && !(PREC == 2 && MP_SPLIT2_NBUF == 2)) ? 1 : 2;       // split planes: one buffer, see pos_gemm_kernel
     __shared__ __attribute__((aligned(16))) TL sA[NBUF][NPL * PSA];
     __shared__ __attribute__((aligned(16))) TL sB[NBUF][NPL * PSB];
     __shared__ __attribute__((aligned(16))) float sT[NBUF][DBK * 4];
