@@ -14,6 +14,8 @@
 // -2*dot is exact, so fma(-2, dot, |q|^2) rounds once exactly like the reference's separate add.
 #include <cstdlib>
 
+#include <cstdio>
+
 #include "common.h"
 
 namespace {
@@ -275,7 +277,9 @@ static int launch_bq_multi(const float* xyz, const float* new_xyz, int64_t B, in
     if (!lds.ensure(reinterpret_cast<const void*>(kern), smem)) return MP_ELAUNCH;
     double wr = 0.0;
     for (int r = 0; r < NR; ++r) wr += (double)rr.K[r];
-    MP_LAUNCH("ball_query_kernel", 8.0 * B * (double)S * N, (double)B * (N * 12.0 + S * 12.0 + S * wr * 8.0), kern, dim3(chunks, (unsigned)B),
+    char tag[64];       // [r6] one profile row per launch SHAPE (the two levels of the encoder used to be averaged into one row)
+    snprintf(tag, sizeof tag, "ball_query_kernel[%dx%d]", (int)N, (int)S);
+    MP_LAUNCH(tag, 8.0 * B * (double)S * N, (double)B * (N * 12.0 + S * 12.0 + S * wr * 8.0), kern, dim3(chunks, (unsigned)B),
               dim3(WAVES * MP_WAVE), smem, stream, xyz, new_xyz, (int)N, (int)S, rr, (int)qpb);
     MP_CHECK_LAUNCH();
     return MP_OK;
@@ -353,7 +357,9 @@ extern "C" int mp_ball_query_f32(const float* xyz, const float* new_xyz, int64_t
     static mp::DynLds lds;   // see common.h
     if (!lds.ensure(reinterpret_cast<const void*>(ball_query_kernel), smem)) return MP_ELAUNCH;
     const float r2 = (float)(radius * radius);  // squared in double, then cast: pointnet2_utils.py:104
-    MP_LAUNCH("ball_query_kernel", 8.0 * B * (double)S * N, (double)B * (N * 12.0 + S * 12.0 + S * K * 8.0), ball_query_kernel,
+    char tag[64];
+    snprintf(tag, sizeof tag, "ball_query_kernel[%dx%d]", (int)N, (int)S);
+    MP_LAUNCH(tag, 8.0 * B * (double)S * N, (double)B * (N * 12.0 + S * 12.0 + S * K * 8.0), ball_query_kernel,
               dim3(chunks, (unsigned)B), dim3(BQ_THREADS), smem, mp_stream(stream_), xyz, new_xyz, (int)N, (int)S, r2, (int)K,
               (int)qpb, out_idx);
     MP_CHECK_LAUNCH();

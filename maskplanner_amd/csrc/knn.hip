@@ -674,7 +674,7 @@ int launch_knn1_screen(const float* p1, const float* p2, const int64_t* len1, co
     }
     if (!(phases & 2)) return MP_OK;
     char tag[48];
-    snprintf(tag, sizeof tag, "knn1_screen_kernel<%d>", D);
+    snprintf(tag, sizeof tag, "knn1_screen_kernel<%d>[%dx%d]", D, (int)P1, (int)P2);      // [r6] queries x references: one profile row per launch shape
     const double flops = 3.0 * D * (double)B * P1 * P2, bytes = (double)B * ((P1 + P2) * 4.0 * D + P1 * 12.0);
     MP_LAUNCH(tag, flops, bytes, (knn1_screen_kernel<D>), dim3((P1 + 127) / 128, B), dim3(512), 0, stream, p1, p2, len1, len2, P1, P2,
               P2pad, planes, norms, dists, idx);

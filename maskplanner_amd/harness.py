@@ -125,6 +125,7 @@ class TrainStep:
         if self.factor_opt is not None:
             self._reset_factor_store()
         self._static_grads = None
+        self._dp_recorded = False      # the data-parallel exchange is part of the recorded graphs (_record_split)
         # train_maskplanner.py:159.  On the GPU the dense parameters go through csrc/adam_multi.hip (same update, ~150 tensors in four
         # launches).
         if fused:
@@ -203,10 +204,11 @@ class TrainStep:
         ticks = list(sa_mlp.DEFERRED_TICKS or [])
         dense = getattr(self.opt, "step_dev", None)
         self._dense_ticked = False
-        if self._zero_arena is not None and self._zero_arena.arm(ticks, [dense] if (dense is not None and not self.dp_graph) else None):
+        eager_opt = self.dp_graph and not self._dp_recorded        # (the dense optimizer of r5's data-parallel structure steps outside the graphs)
+        if self._zero_arena is not None and self._zero_arena.arm(ticks, [dense] if (dense is not None and not eager_opt) else None):
             if sa_mlp.DEFERRED_TICKS:
                 del sa_mlp.DEFERRED_TICKS[:]
-            self._dense_ticked = dense is not None and not self.dp_graph
+            self._dense_ticked = dense is not None and not eager_opt
         else:
             sa_mlp.flush_ticks()
 
@@ -340,7 +342,15 @@ class TrainStep:
             # kernels instead of next to the HBM-bound first level of the following forward.
             # Default: only under data parallelism, where the factor all-gather then overlaps the backward as well.  On one GPU the
             # optimizer's ~1 GB costs the chain the same wherever it runs and the extra graph boundary costs ~60 us ([r2] 2.83 vs 2.76 ms).
-            split_bwd = bool(persist) and os.environ.get("MASKPLANNER_SPLIT_BACKWARD", "1" if dp.exchanging() else "0") != "0"
+            # [r6] Data parallel on RCCL: the bucket all-reduces and the dense Adam are RECORDED into the backward graph like the N = 1 step's
+            # (ProcessGroupNCCL's collectives record under thread-local capture, as the SyncBN opt-in's do), so the N > 1 launch path is the
+            # N = 1 path plus collective nodes: two graphs, then the head optimizer -- behind its factor all-gather -- on its own stream under
+            # the next encoder forward.  No third graph boundary (the backward was split so that the all-gather could hide under the encoder's
+            # backward; under the next forward it is hidden as well) and no eager exchange.  MASKPLANNER_DP_COLLECTIVES_GRAPH=0, or a
+            # backend that cannot record (gloo: host-side collectives): r5's structure (three graphs, eager exchange and dense Adam).
+            self._dp_recorded = bool(self.dp_graph and torch.distributed.get_backend() == "nccl"
+                                     and os.environ.get("MASKPLANNER_DP_COLLECTIVES_GRAPH", "1") != "0")
+            split_bwd = bool(persist) and os.environ.get("MASKPLANNER_SPLIT_BACKWARD", "1" if (dp.exchanging() and not self._dp_recorded) else "0") != "0"
             gb2 = torch.cuda.CUDAGraph() if split_bwd else None
             with torch.cuda.graph(gb, pool=ga.pool(), stream=cap, **kw):
                 if split_bwd:
@@ -356,7 +366,7 @@ class TrainStep:
                 sa_mlp.DEFERRED_TICKS = ticks_prev
                 if self.factor_opt is not None:
                     flush_bias_grads(self.model.factor_store)
-                if not self.dp_graph and not split_bwd:
+                if (not self.dp_graph or self._dp_recorded) and not split_bwd:
                     self.reducer.finish()
                     self._opt_step()
                 loss = loss.detach()
@@ -378,7 +388,7 @@ class TrainStep:
                 with torch.cuda.graph(gb2, pool=ga.pool(), stream=cap, **kw):
                     feat.backward(leaf.grad)
                     self._disarm()
-                    if not self.dp_graph:
+                    if not self.dp_graph or self._dp_recorded:
                         self.reducer.finish()
                         self._opt_step()
                     if self.overlap:
@@ -413,7 +423,7 @@ class TrainStep:
             self._graph, self._graph_b, self._graph_b2, self.use_graph = None, None, None, False
             self._factor_args = None
             if self.dp_graph:
-                self.dp_graph, self._guard_left, self.reducer.deferred = False, 0, False
+                self.dp_graph, self._guard_left, self.reducer.deferred, self._dp_recorded = False, 0, False, False
             if self.factor_opt is not None:
                 self._reset_factor_store()      # queued bias-gradient entries point into the dropped graph pool
             torch.cuda.synchronize()
@@ -453,7 +463,7 @@ class TrainStep:
         import torch.distributed as dist
         torch.cuda.synchronize()
         self._graph, self._graph_b, self._graph_b2, self._graph_loss = None, None, None, None
-        self.use_graph, self.dp_graph, self._guard_left, self.dp_fell_back = False, False, 0, True
+        self.use_graph, self.dp_graph, self._guard_left, self.dp_fell_back, self._dp_recorded = False, False, 0, True, False
         self.reducer.deferred = False
         self._static_grads, self._factor_args, self._adam_ev = None, None, None
         state = list(self.model.parameters()) + [b for b in self.model.buffers() if b.is_floating_point()]
@@ -502,7 +512,7 @@ class TrainStep:
         if self._graph_b2 is not None:
             self._launch_factor_adam()          # behind B1: underneath the encoder backward
             self._graph_b2.replay()
-        if self.dp_graph:      # the exchange and the dense optimizer of a data-parallel step, eagerly on the step's stream
+        if self.dp_graph and not self._dp_recorded:      # the exchange and the dense optimizer of a data-parallel step, eagerly on the step's stream
             self.reducer.rearm(self._static_grads)
             self.reducer.finish()
             self.opt.step()

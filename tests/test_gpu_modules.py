@@ -678,6 +678,10 @@ def test_rccl_single_rank_collectives_do_not_change_the_step():
     p8, g8 = np.array(res["plain8"]), np.array(res["forced_graph8"])
     assert np.isfinite(g8).all() and g8[0] == p8[0] and np.allclose(g8[:3], p8[:3], rtol=1e-2) and np.allclose(g8, p8, rtol=8e-2), res
     assert g8[-1] < 0.75 * g8[0]
+    # [r6] forced_graph8 has the bucket all-reduces and the dense Adam RECORDED into the backward graph (two graphs, the N = 1 structure plus
+    # collective nodes); r5's structure -- three graphs, the exchange launched eagerly between replays -- trains the same
+    e8 = np.array(res["forced_graph8_eager_exchange"])
+    assert np.isfinite(e8).all() and e8[0] == p8[0] and np.allclose(e8[:3], p8[:3], rtol=1e-2) and np.allclose(e8, g8, rtol=8e-2), res
 
 
 def test_graph_replay_of_the_training_step_tracks_the_eager_path():

@@ -1,5 +1,6 @@
-"""[r5] What the N > 1 LAUNCH PATH costs on one GPU, so that a 1 -> 8 comparison is like for like: the data-parallel step (graphs A, B1, B2
-recorded without collectives; bucket all-reduces, dense Adam, factor all-gather + factor Adam launched eagerly -- harness.TrainStep with
+"""[r5] What the N > 1 LAUNCH PATH costs on one GPU, so that a 1 -> 8 comparison is like for like: the data-parallel step ([r6] graphs A and B with
+the bucket all-reduces and the dense Adam recorded into B, then factor all-gather + factor Adam on the optimizer stream; r5 /
+MASKPLANNER_DP_COLLECTIVES_GRAPH=0: graphs A, B1, B2 recorded without collectives, everything else launched eagerly -- harness.TrainStep with
 dp.exchanging()) driven by ONE forced RCCL rank (every collective runs, each is an identity), next to the two-graph N = 1 step, alternating,
 same process.  Prints one JSON line.   python tools/dp_overhead.py [port] [steps] [B] [N]"""
 import json
@@ -46,7 +47,9 @@ def main():
         return per[len(per) // 2], wall
 
     plain, forced = build(False), build(True)
-    assert forced.dp_graph and forced._graph_b2 is not None and not plain.dp_graph, "launch paths"
+    assert forced.dp_graph and not plain.dp_graph, "launch paths"
+    recorded = bool(forced._dp_recorded)     # [r6] the exchange and the dense Adam are nodes of the backward graph (MASKPLANNER_DP_COLLECTIVES_GRAPH=0: r5's structure)
+    assert recorded == (forced._graph_b2 is None), "two graphs with the recorded exchange, three with the eager one"
     res = {"n1_path_ms": [], "dp_path_one_rank_ms": []}
     for _ in range(3):
         dp.FORCE_COLLECTIVES = False
@@ -57,8 +60,11 @@ def main():
     dist.destroy_process_group()
     a, b = sorted(res["n1_path_ms"])[1], sorted(res["dp_path_one_rank_ms"])[1]
     print(json.dumps({"n1_path_ms": a, "dp_path_one_rank_ms": b, "overhead_ms": b - a, "rounds": res, "steps": steps, "B": B, "N": N,
-                      "what": "median step, three alternations: two-graph N = 1 step vs the N > 1 launch path (three graphs + eager bucket all-reduce, "
-                              "dense Adam, factor all-gather, factor Adam) with one forced RCCL rank -- every collective issued, each an identity"}))
+                      "exchange_recorded": recorded,
+                      "what": "median step, three alternations: two-graph N = 1 step vs the N > 1 launch path with one forced RCCL rank -- every collective "
+                              "issued, each an identity.  [r6] exchange_recorded: the bucket all-reduces and the dense Adam are nodes of the backward "
+                              "graph (two graphs, then factor all-gather + factor Adam on the optimizer stream); false: r5's structure (three graphs + "
+                              "eager bucket all-reduce, dense Adam, factor all-gather, factor Adam)"}))
 
 
 if __name__ == "__main__":

@@ -61,19 +61,23 @@ def factor_run(force):
     return torch.cat([w1.detach().flatten(), w2.detach().flatten()]).cpu()
 
 
-def full_run(force, steps=3, dp_graph=False):
+def full_run(force, steps=3, dp_graph=False, record_exchange=True):
     import torch
     import maskplanner_amd.dp as dp
     from maskplanner_amd.harness import TrainStep
     dp.FORCE_COLLECTIVES = force
     os.environ["MASKPLANNER_DP_GRAPH"] = "1" if dp_graph else "0"
+    os.environ["MASKPLANNER_DP_COLLECTIVES_GRAPH"] = "1" if record_exchange else "0"
     ts = TrainStep("cuboids", B=4, N=1024, seed=4321)
     assert ts.reducer.active == force and ts.dp_graph == (force and dp_graph)
     losses = [float(ts.step()) for _ in range(steps)]
     torch.cuda.synchronize()
     if dp_graph:
         assert ts._graph is not None and ts._graph_b is not None and ts._static_grads, "the data-parallel step was not recorded"
+        # [r6] the exchange recorded into the backward graph: two graphs; launched eagerly between replays (r5): three
+        assert ts._dp_recorded == record_exchange and (ts._graph_b2 is None) == record_exchange, (ts._dp_recorded, ts._graph_b2 is None)
     os.environ["MASKPLANNER_DP_GRAPH"] = "0"
+    os.environ.pop("MASKPLANNER_DP_COLLECTIVES_GRAPH", None)
     return losses
 
 
@@ -87,12 +91,14 @@ def main():
     w1, nb = mlp_run(True)
     f0, f1 = factor_run(False), factor_run(True)
     plain, plain2, forced = full_run(False), full_run(False), full_run(True)
-    # opt-in: two recorded graphs without collectives, exchange + optimizers launched eagerly between replays (8 steps: 4 replays)
+    # the recorded data-parallel step (8 steps: 4 replays): [r6] exchange + dense Adam inside the backward graph; r5's form: launched eagerly between replays
     plain8, forced_graph8 = full_run(False, steps=8), full_run(True, steps=8, dp_graph=True)
+    forced_graph8_eager_exchange = full_run(True, steps=8, dp_graph=True, record_exchange=False)
     dist.barrier()
     dist.destroy_process_group()
     print(json.dumps({"mlp_identical": bool(torch.equal(w0, w1)), "mlp_buckets": nb, "factor_identical": bool(torch.equal(f0, f1)),
-                      "plain": plain, "plain2": plain2, "forced": forced, "plain8": plain8, "forced_graph8": forced_graph8}))
+                      "plain": plain, "plain2": plain2, "forced": forced, "plain8": plain8, "forced_graph8": forced_graph8,
+                      "forced_graph8_eager_exchange": forced_graph8_eager_exchange}))
 
 
 if __name__ == "__main__":
