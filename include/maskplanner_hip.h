@@ -10,8 +10,14 @@
  * Conventions (all entry points)
  *   - plain C: raw DEVICE pointers + int64 sizes; no torch / C++ types in any signature;
  *   - layouts are contiguous row-major; coordinates points-major [B,N,C]; indices int64 (reference dtype);
- *   - the caller owns every buffer (inputs, outputs, workspace).  The library never allocates, frees or
- *     retains device memory and keeps no mutable global state: re-entrant, thread-safe;
+ *   - the caller owns every buffer (inputs, outputs, workspace).  The COMPUTE entry points never allocate, free or retain
+ *     device memory and keep no mutable global state: re-entrant, thread-safe.  Three bookkeeping facilities do hold
+ *     process-wide state, each behind a mutex and each off unless the caller turns it on: the zero arena (a table of
+ *     caller-owned ranges keyed by stream: mp_zero_arena_*; no device memory), the kernel profiler (host-side event records:
+ *     mp_profiler_enable / _collect) and the profiler's marks (mp_profiler_mark: the ONE allocation the library ever makes --
+ *     a 33 KB device ring for in-graph time stamps, allocated at the first mark request and kept for the process; a process
+ *     that never calls mp_profiler_mark never triggers it).  The per-kernel dynamic-LDS opt-in (hipFuncSetAttribute, once per
+ *     kernel and device) is cached in atomics;
  *   - enqueue-only: work is queued on `stream` (a hipStream_t passed as void*; NULL = default stream);
  *     no hipDeviceSynchronize, no hidden device->host copies => safe under hipGraph capture;
  *   - return value: MP_OK (0) or a negative MP_E* code.  No exceptions, no abort().

@@ -684,6 +684,39 @@ def test_rccl_single_rank_collectives_do_not_change_the_step():
     assert np.isfinite(e8).all() and e8[0] == p8[0] and np.allclose(e8[:3], p8[:3], rtol=1e-2) and np.allclose(e8, g8, rtol=8e-2), res
 
 
+def test_two_training_steps_on_two_streams_of_one_process():
+    """[r6] Two harness.TrainStep objects (different seeds) driven alternately, each under its own stream, in ONE process: what the library
+    keeps per process (the zero arena's per-stream table, the dynamic-LDS cache, BatchNorm slot rows owned by each model) must not couple
+    them -- each trains like the same trainer alone (up to the dW atomics' run-to-run noise, amplified by Adam)."""
+    from maskplanner_amd.harness import TrainStep
+
+    def solo(seed, n):
+        ts = TrainStep("cuboids", B=4, N=1024, seed=seed, graph=True)
+        out = [float(ts.step()) for _ in range(n)]
+        ts.check()
+        return out
+    n = 10
+    want = {s: solo(s, n) for s in (11, 12)}
+    streams = {s: torch.cuda.Stream() for s in (11, 12)}
+    pair = {}
+    for s in (11, 12):
+        with torch.cuda.stream(streams[s]):
+            pair[s] = TrainStep("cuboids", B=4, N=1024, seed=s, graph=True)
+    got = {11: [], 12: []}
+    for _ in range(n):
+        for s in (11, 12):                       # interleaved: the other trainer's kernels are in flight on the other stream
+            with torch.cuda.stream(streams[s]):
+                got[s].append(pair[s].step())
+    torch.cuda.synchronize()
+    for s in (11, 12):
+        pair[s].check()
+        g, w = np.array([float(x) for x in got[s]]), np.array(want[s])
+        assert np.isfinite(g).all() and g[0] == w[0], (s, g, w)                      # the first step is deterministic up to its loss value
+        assert np.allclose(g[:4], w[:4], rtol=2e-2) and np.allclose(g, w, rtol=1e-1), (s, g, w)
+        assert g[-1] < g[0]
+    assert pair[11]._graph is not None and pair[12]._graph is not None
+
+
 def test_graph_replay_of_the_training_step_tracks_the_eager_path():
     """harness.TrainStep records the whole step (forward + loss + backward + both optimizers) into a hipGraph after three
     eager steps.  The recorded step must be statistically indistinguishable from launching kernel by kernel: two trainers
