@@ -706,7 +706,7 @@ def test_two_training_steps_on_two_streams_of_one_process():
     for _ in range(n):
         for s in (11, 12):                       # interleaved: the other trainer's kernels are in flight on the other stream
             with torch.cuda.stream(streams[s]):
-                got[s].append(pair[s].step())
+                got[s].append(pair[s].step().clone())      # (a replayed step returns its graph's static loss tensor: copy it on this stream)
     torch.cuda.synchronize()
     for s in (11, 12):
         pair[s].check()
