@@ -634,6 +634,7 @@ __device__ __forceinline__ int acc_row_in_tile(int r) { return (r & 3) + 8 * (r 
 // reduces every group of K rows to (max, argmax, min, argmin) of the RAW z per channel -- the max-pool commutes with
 // the monotone map z -> relu(z*scale + shift), max for scale >= 0, min for scale < 0 -- so the pooled output needs no
 // second pass over Z once the batch statistics are known (pool_select_kernel).
+enum Epi { EPI_NONE = 0, EPI_SQ = 1, EPI_DY = 2, EPI_SQ_POOL = 3 };      // epilogues of pos_gemm_kernel (sa_gemm.hip)
 struct PoolOut {
     float* vmax;  // [P/K, N]
     float* vmin;
@@ -653,6 +654,12 @@ int mp_s16_fwd_launch(int pool, int rc_in, int Ci, int Co, const void* a, int64_
 #ifndef MP_MAPWIDE
 #define MP_MAPWIDE 0        // 1: 16 lanes per row for every plane write of the fused backward kernels (A/B builds)
 #endif
+// sa_gemm.hip ([r6] the tiled GEMM kernels, split out of sa_mlp.hip): mode / epi / prec as the kernels' template arguments (SRC_*, Epi, PREC);
+// a / dz / in point at PosOperand, partials at BnOut, po at PoolOut (may be NULL)
+int mp_pos_gemm_launch(int mode, int w_krow, int epi, int prec, const void* a, int64_t P, const float* W, int N, int Kd, float* C, const void* partials,
+                       const float* zprev, const float* sprev, const float* tprev, hipStream_t stream, int* nblk_out, const void* po, int ldw, int ldc);
+int mp_dw_gemm_launch(int mode_dz, int mode_in, int prec, const void* dz, const void* in, int64_t P, float* dW, hipStream_t stream);
+int mp_dw_ci4_rc_launch(const void* dz, const void* in, int64_t P, float* dW, int r16, int h16, double flops, double bytes, hipStream_t stream);
 // sa_bwd_fused.hip
 int mp_bwd_fused_launch(int pooled, int rc_in, int bf16, int split, int npl, int Co, int Ci, const void* dz, const void* in, int64_t P, int ppb,
                         const float* W, float* dW, float* G, const void* partials, double flops, double bytes, double bytes_rc, hipStream_t stream);
