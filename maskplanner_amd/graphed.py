@@ -183,8 +183,23 @@ class _Runner:
         else:
             self.x.copy_(xyz)
         B, dev = xyz.shape[0], xyz.device
-        for t, n in self.starts:             # the reference's draws, in the reference's order (models/pointnet2_utils.py:77)
-            t.copy_(pu._draw_fps_start(B, n, dev), non_blocking=True)
+        self.turn = getattr(self, "turn", 0) + 1
+        for i, (t, n) in enumerate(self.starts):             # the reference's draws, in the reference's order (models/pointnet2_utils.py:77)
+            if pu._fps_start_queue or pu._capture_starts is not None or pu._draw_log is not None:
+                t.copy_(pu._draw_fps_start(B, n, dev), non_blocking=True)        # (an override / a recording in progress: the general path)
+                continue
+            # the same draw from the CPU generator, into one of two pinned buffers in turn and from there straight into the graph's static
+            # input: no device allocation and no pageable copy in front of the replay (the device is idle while the host gets here)
+            pins = self.__dict__.setdefault("start_pins", {})
+            slot = pins.get((i, self.turn & 1))
+            if slot is None:
+                slot = pins[(i, self.turn & 1)] = [torch.empty(B, dtype=torch.long).pin_memory(), torch.cuda.Event(), False]
+            if slot[2]:
+                slot[1].synchronize()
+            torch.randint(0, n, (B,), dtype=torch.long, out=slot[0])
+            t.copy_(slot[0], non_blocking=True)
+            slot[1].record()
+            slot[2] = True
         if self.graph_r is not None:
             # The static gradient buffers share the graphs' memory pool with the forward's temporaries: they hold the last backward's values
             # until the NEXT forward replays.  A loop that still has them as .grad here is accumulating (no zero_grad): move the values out.
@@ -453,7 +468,8 @@ class _LossRunner:
         gl = torch.cuda.CUDAGraph()
         with torch.cuda.graph(gl, **kw):
             total, values = handler._terms(**call)
-            values = torch.stack(values)
+            from .loss_handler import _pack_values
+            values = _pack_values(values, handler)          # (term values + the matching status's failure flag: ONE copy to the host per call)
         self.total, self.values, self.status = total, values, getattr(handler, "last_match_status", None)
         self.gout = torch.ones_like(total)
         glb = torch.cuda.CUDAGraph()

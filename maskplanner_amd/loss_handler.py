@@ -130,6 +130,18 @@ def stroke_masks_loss(pred_to_gt_match, pred_stroke_masks, scores, stroke_ids, w
     return (loss, match) if return_matching else loss
 
 
+def _pack_values(values, sink):
+    """[term values ..., 1.0 if any sample's stroke-mask matching failed else 0.0] as one device tensor (marked `_mp_packed`); without a
+    device-side status (no mask term, CPU tensors) the plain stacked values."""
+    vals = values if isinstance(values, torch.Tensor) else torch.stack(values)
+    st = getattr(sink, "last_match_status", None)
+    if st is None or not st.is_cuda or not vals.is_cuda or vals.dim() != 1:
+        return vals
+    packed = torch.cat([vals, (st != 0).any().to(vals.dtype).reshape(1)])
+    packed._mp_packed = True
+    return packed
+
+
 _last_status = []     # the most recent mask_match status tensor (device, i32 [B]) of a call without a `sink`
 
 
@@ -231,8 +243,16 @@ class LossHandler:
         out = graphed.loss_call(self, loss_args, return_list)
         total, values = out if out is not None else self._terms(**loss_args)
         if return_list:
-            array = (values if isinstance(values, torch.Tensor) else torch.stack(values)).cpu().numpy()
-            check_mask_matching(self)
+            # [r6] ONE device -> host copy: the term values with the matching status's "any sample failed" flag behind them (a recorded call
+            # packs them inside its graph, graphed._LossRunner).  The separate status read cost a launch and a second synchronisation between
+            # the loss and its backward, with the device idle.
+            packed = values if (isinstance(values, torch.Tensor) and getattr(values, "_mp_packed", False)) else _pack_values(values, self)
+            host = packed.cpu().numpy()
+            array = host[:-1] if getattr(packed, "_mp_packed", False) else host
+            if getattr(packed, "_mp_packed", False) and host[-1] != 0:
+                check_mask_matching(self)          # (reads the status itself and raises with the decoded reason)
+            elif not getattr(packed, "_mp_packed", False):
+                check_mask_matching(self)
             return total, array
         return total
 

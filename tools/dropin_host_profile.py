@@ -5,7 +5,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from maskplanner_amd.harness import DropInLoop
 loop = DropInLoop("cuboids", B=32, N=5120)
-for _ in range(8):
+for _ in range(24):
     loop.step()
 torch.cuda.synchronize()
 pr = cProfile.Profile()
