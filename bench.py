@@ -252,7 +252,8 @@ def inference_b1(cat, N, dev, reps=50):
             fwd_fixed()
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        from maskplanner_amd.harness import recording
+        with recording(g):
             fwd_fixed()
         g_med, g_min = timed(g.replay)
         out.update({"graph_ms_median": g_med, "graph_ms_min": g_min})

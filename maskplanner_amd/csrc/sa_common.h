@@ -659,6 +659,8 @@ int mp_s16_fwd_launch(int pool, int rc_in, int Ci, int Co, const void* a, int64_
 int mp_pos_gemm_launch(int mode, int w_krow, int epi, int prec, const void* a, int64_t P, const float* W, int N, int Kd, float* C, const void* partials,
                        const float* zprev, const float* sprev, const float* tprev, hipStream_t stream, int* nblk_out, const void* po, int ldw, int ldc);
 int mp_dw_gemm_launch(int mode_dz, int mode_in, int prec, const void* dz, const void* in, int64_t P, float* dW, hipStream_t stream);
+int mp_bwd_pair_launch(int mode_dz, int mode_in, int epi, const void* dz, const void* in, int64_t P, const float* W, int N, int Kd, float* G, const void* partials,
+                       const float* zprev, const float* sprev, const float* tprev, int ldw, int ldc, float* dW, hipStream_t stream, int* nblk_out, int probe);
 int mp_dw_ci4_rc_launch(const void* dz, const void* in, int64_t P, float* dW, int r16, int h16, double flops, double bytes, hipStream_t stream);
 // sa_bwd_fused.hip
 int mp_bwd_fused_launch(int pooled, int rc_in, int bf16, int split, int npl, int Co, int Ci, const void* dz, const void* in, int64_t P, int ppb,

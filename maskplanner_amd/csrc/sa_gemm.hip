@@ -30,12 +30,12 @@ namespace {
 
 
 template <int MODE, bool W_KROW, int EPI, int WAVES_M, int WAVES_N, int TM, int TN, int PREC = 0>   // PREC: 0 fp32 MFMA, 1 bf16, 3 split (h, m, l) planes, 2 [r6] split (h, m) planes: gradients
-__global__ __launch_bounds__(THREADS) void pos_gemm_kernel(PosOperand A, int P, const float* __restrict__ W, int N,
-                                                           int Kd, float* __restrict__ C, BnOut partials,
-                                                           const float* __restrict__ zprev,
-                                                           const float* __restrict__ sprev,
-                                                           const float* __restrict__ tprev, PoolOut po, int ldw,
-                                                           int ldc)
+__device__ __forceinline__ void pos_gemm_body(const uint3 bid, PosOperand A, int P, const float* __restrict__ W, int N,
+                                              int Kd, float* __restrict__ C, BnOut partials,
+                                              const float* __restrict__ zprev,
+                                              const float* __restrict__ sprev,
+                                              const float* __restrict__ tprev, PoolOut po, int ldw,
+                                              int ldc)
 {   // ldw: row stride of W in the NN form (>= N: only the first N columns are produced); ldc: row stride of C
     bn_zero(partials);
     constexpr int BM = WAVES_M * TM * 32;
@@ -68,8 +68,8 @@ __global__ __launch_bounds__(THREADS) void pos_gemm_kernel(PosOperand A, int P, 
     const int wave = tid >> 6, lane = tid & 63;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int wrow0 = wm * TM * 32, wcol0 = wn * TN * 32;
-    const int m0 = blockIdx.x * BM;
-    const int n0 = blockIdx.y * BN;
+    const int m0 = bid.x * BM;
+    const int n0 = bid.y * BN;
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -246,8 +246,8 @@ __global__ __launch_bounds__(THREADS) void pos_gemm_kernel(PosOperand A, int P, 
 #pragma unroll
             for (int w = 0; w < WAVES_M; ++w) v += red[w][st][c];
             if (n0 + c < N) {
-                if (partials.slots) atomicAdd(partials.slots + ((size_t)(blockIdx.x & (BN_NS - 1)) * 2 + st) * N + n0 + c, (double)v);
-                else partials.rows[((size_t)blockIdx.x * 2 + st) * N + n0 + c] = v;
+                if (partials.slots) atomicAdd(partials.slots + ((size_t)(bid.x & (BN_NS - 1)) * 2 + st) * N + n0 + c, (double)v);
+                else partials.rows[((size_t)bid.x * 2 + st) * N + n0 + c] = v;
             }
         }
     }
@@ -275,13 +275,23 @@ __global__ __launch_bounds__(THREADS) void pos_gemm_kernel(PosOperand A, int P, 
     }
 }
 
+// [r6] bid: the tile's (row block, column block) -- blockIdx of the kernel below, or the position inside bwd_pair_kernel's joint grid
+template <int MODE, bool W_KROW, int EPI, int WAVES_M, int WAVES_N, int TM, int TN, int PREC = 0>
+__global__ __launch_bounds__(THREADS) void pos_gemm_kernel(PosOperand A, int P, const float* __restrict__ W, int N, int Kd, float* __restrict__ C,
+                                                           BnOut partials, const float* __restrict__ zprev, const float* __restrict__ sprev,
+                                                           const float* __restrict__ tprev, PoolOut po, int ldw, int ldc)
+{
+    pos_gemm_body<MODE, W_KROW, EPI, WAVES_M, WAVES_N, TM, TN, PREC>(make_uint3(blockIdx.x, blockIdx.y, 0), A, P, W, N, Kd, C, partials, zprev, sprev, tprev, po, ldw,
+                                                                      ldc);
+}
+
 // =================================================================================================================
 // Kernel 3: dW[Co, Ci] += sum_p dZ[p, Co] * act(Zin)[p, Ci]   (split over P, fp32 atomics)
 //   both operands are positions-major slabs [BK positions][channels] -> LDS [k][row] layout, straight copies.
 // =================================================================================================================
 template <int MODE_DZ, int MODE_IN, int WAVES_M, int WAVES_N, int TM, int TN, int PREC = 0>
-__global__ __launch_bounds__(THREADS) void dw_gemm_kernel(PosOperand DZ, PosOperand IN, int P, int p_per_block,
-                                                          float* __restrict__ dW, int ci_base, int tail_ci)
+__device__ __forceinline__ void dw_gemm_body(const uint3 bid, const unsigned gdz, PosOperand DZ, PosOperand IN, int P, int p_per_block,
+                                             float* __restrict__ dW, int ci_base, int tail_ci)
 {   // tail_ci >= 0: the 4 input channels [tail_ci, tail_ci + 4) (132 = 128 + 4, 260 = 256 + 4: the centred xyz + pad of a
     // grouped input) are handled by the workgroups of the LAST column tile with plain FMAs on the staged dZ tile, instead of
     // a second launch that would stream dZ from HBM again for a 97 % empty MFMA tile
@@ -305,15 +315,15 @@ __global__ __launch_bounds__(THREADS) void dw_gemm_kernel(PosOperand DZ, PosOper
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     const int wrow0 = (wave / WAVES_N) * TM * 32, wcol0 = (wave % WAVES_N) * TN * 32;
-    const int co0 = blockIdx.y * BM, ci0 = ci_base + blockIdx.z * BN;
+    const int co0 = bid.y * BM, ci0 = ci_base + bid.z * BN;
     __shared__ __attribute__((aligned(16))) float bn_lds[3 * BM];          // (a, e, f) of this workgroup's BM output channels
-    bn_prologue(DZ.bn, bn_lds, BM, co0, BM, blockIdx.x == 0 && blockIdx.z == 0);
-    const bool do_tail = tail_ci >= 0 && blockIdx.z == gridDim.z - 1;
+    bn_prologue(DZ.bn, bn_lds, BM, co0, BM, bid.x == 0 && bid.z == 0);
+    const bool do_tail = tail_ci >= 0 && bid.z == gdz - 1;
     float tacc0 = 0.0f, tacc1 = 0.0f;
     ChanConst kt;
     Raw4<MODE_IN> rt;
     if (do_tail) load_consts<MODE_IN>(IN, tail_ci, kt);
-    const int p0 = blockIdx.x * p_per_block;
+    const int p0 = bid.x * p_per_block;
     const int p1 = min(P, p0 + p_per_block);
 
     f32x16 acc[TM][TN];
@@ -421,6 +431,39 @@ __global__ __launch_bounds__(THREADS) void dw_gemm_kernel(PosOperand DZ, PosOper
         }
 }
 
+template <int MODE_DZ, int MODE_IN, int WAVES_M, int WAVES_N, int TM, int TN, int PREC = 0>
+__global__ __launch_bounds__(THREADS) void dw_gemm_kernel(PosOperand DZ, PosOperand IN, int P, int p_per_block, float* __restrict__ dW, int ci_base, int tail_ci)
+{
+    dw_gemm_body<MODE_DZ, MODE_IN, WAVES_M, WAVES_N, TM, TN, PREC>(make_uint3(blockIdx.x, blockIdx.y, blockIdx.z), gridDim.z, DZ, IN, P, p_per_block, dW, ci_base,
+                                                                   tail_ci);
+}
+
+// [r6] G_{l-1} = dZ_l W_l and dW_l = dZ_l^T act(Z_{l-1}) of one group_all layer as ONE launch: the 64 x 64 tiles of the first and the
+// 128 x 128 tiles of the second alternate in a joint 1-D grid.  Neither product fills the chip at 4096 positions (0.3-1.5 waves per SIMD,
+// r5's counters) and both read the same dZ_l; the dW product feeds nothing but the optimizer.  As two launches on one stream they ran
+// one after the other; on two streams the fork / join of the recorded graph cost more than the overlap returned (experiments/r6_fork_dw.patch).
+// Two planes (PREC 2) only; the constants of dZ_l come from a finalize launch in front (both halves read the global arrays).
+template <int MODE_DZ, int MODE_IN, int EPI>
+__global__ __launch_bounds__(THREADS) void bwd_pair_kernel(PosOperand DZ, PosOperand IN, int P, const float* __restrict__ W, int N, int Kd,
+                                                           float* __restrict__ G, BnOut partials, const float* __restrict__ zprev,
+                                                           const float* __restrict__ sprev, const float* __restrict__ tprev, int ldw, int ldc, int gm, int gn,
+                                                           int ppb, float* __restrict__ dW, int tail_ci, int wx, int wy, int wz)
+{
+    const unsigned n_dx = (unsigned)(gm * gn), n_dw = (unsigned)(wx * wy * wz);
+    const unsigned lo = n_dx < n_dw ? n_dx : n_dw;          // the first 2 * lo blocks alternate, the longer list's rest follows
+    unsigned b = blockIdx.x;
+    bool dx;
+    if (b < 2 * lo) { dx = (b & 1) == 0; b >>= 1; }
+    else { dx = n_dx > n_dw; b -= lo; }
+    if (dx) {
+        pos_gemm_body<MODE_DZ, true, EPI, 2, 2, 1, 1, 2>(make_uint3(b % (unsigned)gm, b / (unsigned)gm, 0), DZ, P, W, N, Kd, G, partials, zprev, sprev, tprev, PoolOut{},
+                                                         ldw, ldc);
+    } else {
+        const unsigned x = b % (unsigned)wx, yz = b / (unsigned)wx;
+        dw_gemm_body<MODE_DZ, MODE_IN, 2, 2, 2, 2, 2>(make_uint3(x, yz % (unsigned)wy, yz / (unsigned)wy), (unsigned)wz, DZ, IN, P, ppb, dW, 0, tail_ci);
+    }
+}
+
 template <int MODE_DZ, int MODE_IN>
 __global__ __launch_bounds__(256) void dw_ci4_kernel(PosOperand DZ, PosOperand IN, int P, int p_per_block, float* __restrict__ dW, int r16, int h16)
 {   // r16: the bf16 variant -- dZ and the input rows rounded to bf16 before the products; h16: the dZ operand's Z / G stored as bf16
@@ -489,7 +532,8 @@ int launch_dw(const PosOperand& DZ, const PosOperand& IN, int64_t P64, float* dW
     int ppb = 1024;
     {
         const int64_t tiles = (int64_t)gy * ((Ci + 127) / 128);
-        const int64_t want = (512 + tiles - 1) / tiles;                     // slices wanted
+        static const int wgs = [] { const char* e = getenv("MP_DW_WGS"); return e ? atoi(e) : 512; }();      // (timing aid)
+        const int64_t want = (wgs + tiles - 1) / tiles;                     // slices wanted
         while ((P + ppb - 1) / ppb < want && ppb > 128) ppb >>= 1;
     }
     const unsigned gx = (unsigned)((P + ppb - 1) / ppb);
@@ -637,6 +681,69 @@ int mp_dw_gemm_launch(int mode_dz, int mode_in, int prec, const void* dz_, const
     MP_DG(SRC_ID, SRC_ID)
 #undef MP_DG
     return MP_EUNSUPPORTED;
+}
+
+// [r6] dX and dW of one layer as one launch (bwd_pair_kernel): returns 1 when it launched, 0 when the shapes are not the ones the joint kernel is
+// built for (the caller then launches the two products separately), < 0 on error.  Built for: two planes, the 64 x 64 tiling of the dX product
+// and the 128 x 128 tiling of the dW product without a remainder launch -- the group_all level.  DZ.bn must already be settled.
+int mp_bwd_pair_launch(int mode_dz, int mode_in, int epi, const void* dz_, const void* in_, int64_t P64, const float* W, int N, int Kd, float* G,
+                       const void* partials_, const float* zprev, const float* sprev, const float* tprev, int ldw, int ldc, float* dW, hipStream_t stream,
+                       int* nblk_out, int probe)
+{   // probe != 0: only answer whether the joint kernel applies (DZ.bn is ignored: the caller settles it before the real call)
+    static const bool off = getenv("MP_BWD_PAIR") && atoi(getenv("MP_BWD_PAIR")) == 0;
+    if (off) return 0;
+    const PosOperand& DZ = *static_cast<const PosOperand*>(dz_);
+    const PosOperand& IN = *static_cast<const PosOperand*>(in_);
+    const BnOut partials = partials_ ? *static_cast<const BnOut*>(partials_) : BnOut{nullptr, nullptr, nullptr, 0, nullptr, 0};
+    if ((!probe && DZ.bn.slots != nullptr) || P64 <= 0 || P64 >= ((int64_t)1 << 31)) return 0;
+    if (!(mode_dz == SRC_DZ && ((mode_in == SRC_ACT && epi == EPI_DY) || (mode_in == SRC_ID && epi == EPI_NONE)))) return 0;
+    const int P = (int)P64;
+    if (ldw == 0) ldw = N;
+    if (ldc == 0) ldc = N;
+    // the dX product's tiling (launch_pos_gemm): only its 64 x 64 shape
+    {
+        const int64_t t128 = ((P64 + 127) / 128) * ((N + 127) / 128), t128x64 = ((P64 + 127) / 128) * ((N + 63) / 64);
+        int shape = (N <= 64) ? 1 : 0;
+        if (shape == 0 && t128 < 384) shape = (t128x64 >= 384) ? 1 : 2;
+        if (shape == 1 && N > 64 && t128x64 < 384) shape = 2;
+        if (shape != 2) return 0;
+    }
+    const int gm = (int)((P64 + 63) / 64), gn = (N + 63) / 64;
+    // the dW product's tiling (launch_dw): only 128 x 128 tiles, the 4 leftover columns of a 4k + 4 input riding along
+    const int Co = DZ.C, Ci = IN.C;
+    if (Co != Kd || Ci == 4) return 0;
+    const int main_ci = (Ci > 128 && Ci % 128 != 0 && Ci % 128 <= 32) ? (Ci / 128) * 128 : Ci;
+    const int tail_ci = (main_ci < Ci && Ci - main_ci == 4) ? main_ci : -1;
+    if (main_ci <= 64 || (main_ci < Ci && tail_ci < 0)) return 0;
+    const int wy = (Co + 127) / 128, wz = (main_ci + 127) / 128;
+    int ppb = 1024;
+    {
+        const int64_t tiles = (int64_t)wy * ((Ci + 127) / 128);
+        const int64_t want = (512 + tiles - 1) / tiles;
+        while ((P + ppb - 1) / ppb < want && ppb > 128) ppb >>= 1;
+    }
+    const int wx = (P + ppb - 1) / ppb;
+    if (probe) return 1;
+    if (nblk_out) *nblk_out = gm;
+    const double dzr = (mode_dz == SRC_DZ ? 2.0 : 1.0) * (double)P * Co;
+    const double flops = 2.0 * (double)P * N * Kd + 2.0 * (double)P * Co * Ci;
+    const double bytes = 4.0 * (2.0 * dzr + (epi == EPI_DY ? (double)P * N : 0.0) + (G ? (double)P * N : 0.0) + (double)N * Kd + (double)P * Ci + (double)Co * Ci);
+    const dim3 grid((unsigned)(gm * gn + wx * wy * wz));
+    char tag[96];
+#define MP_PAIR(MDZ_, MIN_, EPI_)                                                                                                              \
+    if (mode_dz == MDZ_ && mode_in == MIN_ && epi == EPI_) {                                                                                    \
+        snprintf(tag, sizeof tag, "bwd_pair_kernel<%d, %d, %d>", MDZ_, MIN_, EPI_);                                                             \
+        MP_LAUNCH(tag, flops, bytes, (bwd_pair_kernel<MDZ_, MIN_, EPI_>), grid, dim3(THREADS), 0, stream, DZ, IN, P, W, N, Kd, G, partials, zprev, sprev, \
+                  tprev, ldw, ldc, gm, gn, ppb, dW, tail_ci, wx, wy, wz);                                                                       \
+        MP_CHECK_LAUNCH();                                                                                                                      \
+        return 1;                                                                                                                               \
+    }
+    // (the POOLED layer stays on two launches: its joint kernel took 130 us against 49 + 42 -- the pooled dZ operand's staging next to the 128 x 128
+    // accumulators; the dense layers: 44 against 28 + 23 us and 30 against 27 + 15 us)
+    MP_PAIR(SRC_DZ, SRC_ACT, EPI_DY)
+    MP_PAIR(SRC_DZ, SRC_ID, EPI_NONE)
+#undef MP_PAIR
+    return 0;
 }
 
 // the first layer of a level whose input is the 4-channel coordinate rows and is recomputed, not stored (dZ_0 from (Z_0 recomputed, G_0))

@@ -1987,6 +1987,53 @@ static int sa_mlp_bwd(const float* x0, int64_t P, int64_t K, int n_layers, const
             if (int rc = mp_dw_ci4_rc_launch(&DZ, &IN, P, grads[l].d_weight, (int)bf16, (int)store16, fl, by, stream)) return rc;
             continue;
         }
+        // [r6] both products of the layer as ONE launch where the joint kernel applies (sa_gemm.hip: bwd_pair_kernel -- two planes, the
+        // group_all level's shapes): the constants of dZ_l from a finalize launch in front, then dX and dW tiles side by side
+        if (!bf16 && split_enabled() && npl == 2 && bn_fused && (l > 0 || grad_x0)) {
+            const int mdz = pooled ? SRC_DZ_POOLED : SRC_DZ;
+            const float *zp = nullptr, *sp = nullptr, *tp = nullptr;
+            float* Gout = nullptr;
+            int ncols = Ci, ldw_ = 0, ldc_ = 0, epi = EPI_DY, min_ = SRC_ACT;
+            bool ok = true, zero_tail = false;
+            BnOut part = partials;
+            if (l > 0) {
+                Gout = gbuf[l & 1];
+                zp = layers[l - 1].z; sp = layers[l - 1].scale; tp = layers[l - 1].shift;
+            } else {
+                const bool compact = grad_x0_cols < 0;
+                const int64_t gcols = compact ? -grad_x0_cols : grad_x0_cols;
+                if (compact && ((gcols & 3) || gcols > Ci)) return MP_EINVAL;
+                ncols = (gcols > 0 && gcols < Ci) ? (int)((gcols + 3) / 4 * 4) : Ci;
+                ldw_ = Ci;
+                ldc_ = compact ? ncols : Ci;
+                zero_tail = !compact && ncols < Ci;
+                Gout = grad_x0;
+                epi = EPI_NONE;
+                min_ = SRC_ID;
+                part = BnOut{nullptr, nullptr};
+            }
+            ok = mp_bwd_pair_launch(mdz, min_, epi, &DZ, &IN, P, Ly.weight, ncols, Co, Gout, &part, zp, sp, tp, ldw_, ldc_, grads[l].d_weight, stream, nullptr, 1) == 1;
+            if (ok) {
+                if (DZ.bn.slots) {
+                    hipLaunchKernelGGL(bn_site_finalize_kernel, dim3((unsigned)((DZ.bn.C + 255) / 256)), dim3(256), 0, stream, DZ.bn);
+                    MP_CHECK_LAUNCH();
+                    DZ.bn = BnSite{};
+                }
+                int nblk = 0;
+                const int rc = mp_bwd_pair_launch(mdz, min_, epi, &DZ, &IN, P, Ly.weight, ncols, Co, Gout, &part, zp, sp, tp, ldw_, ldc_, grads[l].d_weight, stream, &nblk, 0);
+                if (rc < 0) return rc;
+                if (rc == 1) {
+                    if (l > 0) {
+                        if (int rc2 = finalize_bwd(l - 1, nblk, Ci)) return rc2;
+                        G_cur = Gout;
+                    } else if (zero_tail) {
+                        hipLaunchKernelGGL(zero_cols_kernel, dim3((unsigned)((P * (Ci - ncols) + 255) / 256)), dim3(256), 0, stream, grad_x0, P, Ci, ncols);
+                        MP_CHECK_LAUNCH();
+                    }
+                    continue;
+                }
+            }
+        }
         {
             int rc;
             if (pooled) rc = (l == 0) ? MP_DW_GEMM_B(SRC_DZ_POOLED, SRC_ID, DZ, IN, P, grads[l].d_weight, stream)

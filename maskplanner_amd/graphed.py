@@ -92,15 +92,18 @@ class _Token:
 
 
 class _Runner:
+    model = property(lambda self: self._model())
+
     def __init__(self, model, xyz, train):
-        self.model, self.train = model, train
+        self._model, self.train = weakref.ref(model), train        # (weak: the model owns this runner -- a strong reference would make the pair a cycle,
+                                                                   # freed whenever the collector runs, e.g. in the middle of somebody's recording)
         self.failed, self.calls, self.pending, self.ticket, self.live = False, 0, False, 0, []
         self.graph_f = self.graph_r = None
         self.draws, self.ptrs = [], ()
         self.shape, self.strides = tuple(xyz.shape), tuple(xyz.stride())
 
     def _record(self, xyz):
-        from .harness import _capture_kw
+        from .harness import _capture_kw, recording
         model, dev = self.model, xyz.device
         B, C, N = xyz.shape
         # the loop hands over point_cloud.permute(0, 2, 1).to(device): points-major storage behind a channels-major view
@@ -128,7 +131,7 @@ class _Runner:
         names = [n for n, p in model.named_parameters() if p.requires_grad]
         alias = {n: p.detach().requires_grad_(True) for n, p in zip(names, params)} if self.train else {}
         try:
-            with torch.cuda.graph(gf, **kw):
+            with recording(gf, **kw):
                 outs = torch.func.functional_call(model, alias, (self.x,)) if alias else model._forward_eager(self.x)
                 _dbg("forward recorded")
         finally:
@@ -144,7 +147,7 @@ class _Runner:
             # (torch.autograd.grad: the gradients are the recording's outputs, nothing is accumulated into .grad while recording)
             gr = torch.cuda.CUDAGraph()
             _dbg("recording backward")
-            with torch.cuda.graph(gr, pool=gf.pool(), **kw):
+            with recording(gr, pool=gf.pool(), **kw):
                 got = torch.autograd.grad(req, [alias[n] for n in names], [g for g in self.gouts if g is not None], allow_unused=True)
             _dbg("backward recorded")
             self.grads = [(p, g) for p, g in zip(params, got) if g is not None]
@@ -434,7 +437,7 @@ class _LossRunner:
         self.width[k] = w
 
     def _record(self, handler, args):
-        from .harness import _capture_kw
+        from .harness import _capture_kw, recording
         dev = args["y_pred"].device
         self.names = [k for k, v in args.items() if isinstance(v, torch.Tensor)]
         self.static, self.req, self.pins, self.width = {}, [], {}, {}
@@ -466,14 +469,14 @@ class _LossRunner:
         kw = _capture_kw()
         torch.cuda.synchronize(dev)
         gl = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(gl, **kw):
+        with recording(gl, **kw):
             total, values = handler._terms(**call)
             from .loss_handler import _pack_values
             values = _pack_values(values, handler)          # (term values + the matching status's failure flag: ONE copy to the host per call)
         self.total, self.values, self.status = total, values, getattr(handler, "last_match_status", None)
         self.gout = torch.ones_like(total)
         glb = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(glb, pool=gl.pool(), **kw):
+        with recording(glb, pool=gl.pool(), **kw):
             got = torch.autograd.grad(total, [self.static[k] for k in self.req], self.gout, allow_unused=True)
         self.in_grads = list(got)
         self.graph_l, self.graph_lb = gl, glb

@@ -33,6 +33,36 @@ def _capture_kw():
     return {"capture_error_mode": "thread_local"}
 
 
+class recording:
+    """`torch.cuda.graph(...)` with the garbage collector out of the way.  [r6] torch 2.10 no longer collects before a capture, and a dead
+    reference cycle that owns a pinned host buffer (or anything whose release queries an event) may then be collected WHILE a stream records:
+    the release's `hipEventQuery` is illegal under capture and aborts the process from a destructor (seen in a test session: `Fatal Python
+    error: Aborted`, `Garbage-collecting` inside `_record_split`).  So: collect before, no collection during."""
+
+    def __init__(self, g, **kw):
+        self.ctx = torch.cuda.graph(g, **kw)
+
+    def __enter__(self):
+        import gc
+        gc.collect()
+        self.was = gc.isenabled()
+        gc.disable()
+        try:
+            return self.ctx.__enter__()
+        except BaseException:
+            if self.was:
+                gc.enable()
+            raise
+
+    def __exit__(self, *exc):
+        import gc
+        try:
+            return self.ctx.__exit__(*exc)
+        finally:
+            if self.was:
+                gc.enable()
+
+
 def _even(n):
     """int64 units rounded up to a 16-byte multiple."""
     return (int(n) + 1) // 2 * 2
@@ -301,7 +331,7 @@ class TrainStep:
         try:
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, **_capture_kw()):
+            with recording(g, **_capture_kw()):
                 loss = self._eager_step(hand_over=False)
             self._graph, self._graph_loss = g, loss
             g.replay()
@@ -326,7 +356,7 @@ class TrainStep:
             from . import sa_mlp
             ticks_prev, sa_mlp.DEFERRED_TICKS = sa_mlp.DEFERRED_TICKS, []      # every BatchNorm counter of the step: one launch, in B
             kw = _capture_kw()
-            with torch.cuda.graph(ga, stream=cap, **kw):
+            with recording(ga, stream=cap, **kw):
                 self._supply_plan()
                 self.reducer.zero_grad()
                 feat = self._encode()
@@ -352,7 +382,7 @@ class TrainStep:
                                      and os.environ.get("MASKPLANNER_DP_COLLECTIVES_GRAPH", "1") != "0")
             split_bwd = bool(persist) and os.environ.get("MASKPLANNER_SPLIT_BACKWARD", "1" if (dp.exchanging() and not self._dp_recorded) else "0") != "0"
             gb2 = torch.cuda.CUDAGraph() if split_bwd else None
-            with torch.cuda.graph(gb, pool=ga.pool(), stream=cap, **kw):
+            with recording(gb, pool=ga.pool(), stream=cap, **kw):
                 if split_bwd:
                     leaf = feat.detach().requires_grad_(True)
                     loss = self._heads_loss(leaf)
@@ -385,7 +415,7 @@ class TrainStep:
                 if self.overlap and not split_bwd:
                     self._hand_over_copies()
             if split_bwd:
-                with torch.cuda.graph(gb2, pool=ga.pool(), stream=cap, **kw):
+                with recording(gb2, pool=ga.pool(), stream=cap, **kw):
                     feat.backward(leaf.grad)
                     self._disarm()
                     if not self.dp_graph or self._dp_recorded:

@@ -1252,7 +1252,8 @@ def test_batch_of_one_inference_vs_oracle(oracle, graphed):
             fwd()
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        from maskplanner_amd.harness import recording
+        with recording(g):          # (torch.cuda.graph with the garbage collector held off: harness.recording)
             outs = fwd()
         g.replay()
     else:

@@ -920,7 +920,8 @@ def test_profiler_marks_time_a_kernel_inside_a_replayed_graph():
     try:
         assert lib.mp_profiler_mark(b"no_such_kernel|fps_kernel") == 0
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        from maskplanner_amd.harness import recording
+        with recording(g):
             idx = ops.fps(xyz, S, start)
             ops.ball_query(0.2, 16, xyz, xyz[:, :64].contiguous())     # not marked
         for _ in range(6):
