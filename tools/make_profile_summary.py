@@ -62,7 +62,7 @@ for d in sorted(glob.glob(f"{go}/{tag}_cfg_*_fetch")):
     tab = {}
     for k, fz in cf.items():
         wz = cw.get(k)
-        if wz is not None and any(t in k for t in ("gemm", "knn", "fps", "ball", "pool", "group", "fused", "roles", "chunk", "adam", "dw_ci4", "first", "linear", "lean", "mask_match", "lsap")):
+        if wz is not None and any(t in k for t in ("gemm", "knn", "fps", "ball", "pool", "group", "fused", "roles", "chunk", "adam", "dw_ci4", "first", "linear", "lean", "mask_match", "lsap", "stream16", "pair", "head", "rc_stats")):
             tab[k.split("(")[0]] = dict(fetch_kib=fz, write_kib=wz, hbm_bytes=(2 * fz + wz) * 1024)
     configs[key] = tab
 json.dump(dict(source=f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes ({tag}), bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch; "
