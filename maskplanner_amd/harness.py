@@ -810,15 +810,12 @@ class TrainStep:
                 self._plan_ev.record(side)
             self._stream.collated(self._plan_ev)
             return
-        with torch.cuda.stream(side):
-            if self._stream is not None:
-                pass
-            else:
-                self._sample_levels(self._plan_next, phase=phase)
-                if phase == "head":
-                    return
-                self._target_aux(self._plan_next)
-                self._extras(self._plan_next)
+        with torch.cuda.stream(side):         # (resident inputs; the streamed case returned above)
+            self._sample_levels(self._plan_next, phase=phase)
+            if phase == "head":
+                return
+            self._target_aux(self._plan_next)
+            self._extras(self._plan_next)
             self._plan_ev = torch.cuda.Event()
             self._plan_ev.record(side)
 
