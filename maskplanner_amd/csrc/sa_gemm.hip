@@ -29,14 +29,52 @@ namespace {
 // =================================================================================================================
 
 
+// LDS layout of the two kernel bodies (one raw buffer per workgroup, carved here: bwd_pair_kernel gives both bodies the SAME buffer -- as
+// static arrays inside the bodies the joint kernel would reserve their sum for every workgroup and halve the workgroups per CU)
+constexpr size_t lds_al(size_t v) { return (v + 15) & ~(size_t)15; }
+template <bool W_KROW, int EPI, int WAVES_M, int WAVES_N, int TM, int TN, int PREC>
+struct PosLds {
+    static constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
+    static constexpr bool SPL = PREC == 3 || PREC == 2, BF16 = PREC != 0;
+    static constexpr int BK = (SPL && BM * BN <= 64 * 64) ? 64 : MP_BK;
+    static constexpr int NPL = SPL ? PREC : 1;
+    static constexpr int ES = BF16 ? 2 : 4;                         // bytes per LDS tile element
+    static constexpr int LDA = BF16 ? BK + 8 : BK + 1;
+    static constexpr int LDB = BF16 ? (W_KROW ? tr_ld(BN) : BK + 8) : (W_KROW ? BN : BK + 1);
+    static constexpr int PSA = BM * LDA, PSB = W_KROW ? BK * LDB : BN * LDB;
+    static constexpr int NBUF = (SPL && !(PREC == 2 && MP_SPLIT2_NBUF == 2)) ? 1 : 2;
+    static constexpr bool POOL = EPI == EPI_SQ_POOL;
+    static constexpr size_t OFF_A = 0;
+    static constexpr size_t OFF_B = OFF_A + lds_al((size_t)NBUF * NPL * PSA * ES);
+    static constexpr size_t OFF_RED = OFF_B + lds_al((size_t)NBUF * NPL * PSB * ES);
+    static constexpr size_t OFF_PV = OFF_RED + lds_al((size_t)WAVES_M * 2 * BN * 4);
+    static constexpr size_t OFF_PI = OFF_PV + lds_al(POOL ? (size_t)2 * (BM / 32) * BN * 4 : 16);
+    static constexpr size_t BYTES = OFF_PI + lds_al(POOL ? (size_t)2 * (BM / 32) * BN * 4 : 16);
+};
+template <int WAVES_M, int WAVES_N, int TM, int TN, int PREC>
+struct DwLds {
+    static constexpr int DBK = 32, BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
+    static constexpr bool SPL = PREC == 3 || PREC == 2, BF16 = PREC != 0;
+    static constexpr int NPL = SPL ? PREC : 1;
+    static constexpr int ES = BF16 ? 2 : 4;
+    static constexpr int LDA = BF16 ? tr_ld(BM) : BM, LDB = BF16 ? tr_ld(BN) : BN;
+    static constexpr int PSA = DBK * LDA, PSB = DBK * LDB;
+    static constexpr int NBUF = (SPL && !(PREC == 2 && MP_SPLIT2_NBUF == 2)) ? 1 : 2;
+    static constexpr size_t OFF_A = 0;
+    static constexpr size_t OFF_B = OFF_A + lds_al((size_t)NBUF * NPL * PSA * ES);
+    static constexpr size_t OFF_T = OFF_B + lds_al((size_t)NBUF * NPL * PSB * ES);
+    static constexpr size_t OFF_BN = OFF_T + lds_al((size_t)NBUF * DBK * 4 * 4);
+    static constexpr size_t BYTES = OFF_BN + lds_al((size_t)3 * BM * 4);
+};
+
 template <int MODE, bool W_KROW, int EPI, int WAVES_M, int WAVES_N, int TM, int TN, int PREC = 0>   // PREC: 0 fp32 MFMA, 1 bf16, 3 split (h, m, l) planes, 2 [r6] split (h, m) planes: gradients
 __device__ __forceinline__ void pos_gemm_body(const uint3 bid, PosOperand A, int P, const float* __restrict__ W, int N,
                                               int Kd, float* __restrict__ C, BnOut partials,
                                               const float* __restrict__ zprev,
                                               const float* __restrict__ sprev,
                                               const float* __restrict__ tprev, PoolOut po, int ldw,
-                                              int ldc)
-{   // ldw: row stride of W in the NN form (>= N: only the first N columns are produced); ldc: row stride of C
+                                              int ldc, unsigned char* lds)
+{   // lds: PosLds<...>::BYTES of the workgroup's LDS.  ldw: row stride of W in the NN form (>= N: only the first N columns are produced); ldc: row stride of C
     bn_zero(partials);
     constexpr int BM = WAVES_M * TM * 32;
     constexpr int BN = WAVES_N * TN * 32;
@@ -52,17 +90,20 @@ __device__ __forceinline__ void pos_gemm_body(const uint3 bid, PosOperand A, int
     constexpr int LDB = BF16 ? (W_KROW ? tr_ld(BN) : BK + 8) : (W_KROW ? BN : LDK);
     constexpr int PSA = BM * LDA, PSB = W_KROW ? BK * LDB : BN * LDB;   // plane strides
     constexpr bool SUMS = (EPI == EPI_SQ || EPI == EPI_DY || EPI == EPI_SQ_POOL);
-    __shared__ float pool_v[EPI == EPI_SQ_POOL ? 2 : 1][BM / 32][EPI == EPI_SQ_POOL ? BN : 1];
-    __shared__ int pool_i[EPI == EPI_SQ_POOL ? 2 : 1][BM / 32][EPI == EPI_SQ_POOL ? BN : 1];
+    using L = PosLds<W_KROW, EPI, WAVES_M, WAVES_N, TM, TN, PREC>;
+    static_assert(L::LDA == LDA && L::LDB == LDB && L::PSA == PSA && L::PSB == PSB && L::BK == BK && L::NPL == NPL && L::ES == (int)sizeof(TL), "PosLds mirrors these constants");
+    float (*pool_v)[BM / 32][EPI == EPI_SQ_POOL ? BN : 1] = reinterpret_cast<float (*)[BM / 32][EPI == EPI_SQ_POOL ? BN : 1]>(lds + L::OFF_PV);
+    int (*pool_i)[BM / 32][EPI == EPI_SQ_POOL ? BN : 1] = reinterpret_cast<int (*)[BM / 32][EPI == EPI_SQ_POOL ? BN : 1]>(lds + L::OFF_PI);
     constexpr int A_PASSES = BM / RPP;                // TPR threads x float4 per row, RPP rows per pass
     constexpr int B_PASSES = W_KROW ? (BK * BN / 4 / THREADS) : (BN / RPP);
     static_assert(WAVES_M * WAVES_N == 4, "4 waves");
     // split planes: ONE buffer (three planes of each operand are 3x the fp32 tile's bytes; two or three workgroups per CU cover
     // each other's staging instead of a second buffer)
     constexpr int NBUF = (SPL && !(PREC == 2 && MP_SPLIT2_NBUF == 2)) ? 1 : 2;      // [r6] two planes, two buffers: measured slower, see MP_SPLIT2_NBUF
-    __shared__ __attribute__((aligned(16))) TL sA[NBUF][NPL * PSA];
-    __shared__ __attribute__((aligned(16))) TL sB[NBUF][NPL * PSB];
-    __shared__ float red[WAVES_M][2][BN];
+    static_assert(L::NBUF == NBUF, "PosLds mirrors NBUF");
+    TL (*sA)[NPL * PSA] = reinterpret_cast<TL (*)[NPL * PSA]>(lds + L::OFF_A);
+    TL (*sB)[NPL * PSB] = reinterpret_cast<TL (*)[NPL * PSB]>(lds + L::OFF_B);
+    float (*red)[2][BN] = reinterpret_cast<float (*)[2][BN]>(lds + L::OFF_RED);
 
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
@@ -281,8 +322,9 @@ __global__ __launch_bounds__(THREADS) void pos_gemm_kernel(PosOperand A, int P, 
                                                            BnOut partials, const float* __restrict__ zprev, const float* __restrict__ sprev,
                                                            const float* __restrict__ tprev, PoolOut po, int ldw, int ldc)
 {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[PosLds<W_KROW, EPI, WAVES_M, WAVES_N, TM, TN, PREC>::BYTES];
     pos_gemm_body<MODE, W_KROW, EPI, WAVES_M, WAVES_N, TM, TN, PREC>(make_uint3(blockIdx.x, blockIdx.y, 0), A, P, W, N, Kd, C, partials, zprev, sprev, tprev, po, ldw,
-                                                                      ldc);
+                                                                      ldc, lds);
 }
 
 // =================================================================================================================
@@ -291,8 +333,8 @@ __global__ __launch_bounds__(THREADS) void pos_gemm_kernel(PosOperand A, int P, 
 // =================================================================================================================
 template <int MODE_DZ, int MODE_IN, int WAVES_M, int WAVES_N, int TM, int TN, int PREC = 0>
 __device__ __forceinline__ void dw_gemm_body(const uint3 bid, const unsigned gdz, PosOperand DZ, PosOperand IN, int P, int p_per_block,
-                                             float* __restrict__ dW, int ci_base, int tail_ci)
-{   // tail_ci >= 0: the 4 input channels [tail_ci, tail_ci + 4) (132 = 128 + 4, 260 = 256 + 4: the centred xyz + pad of a
+                                             float* __restrict__ dW, int ci_base, int tail_ci, unsigned char* lds)
+{   // lds: DwLds<...>::BYTES of the workgroup's LDS.  tail_ci >= 0: the 4 input channels [tail_ci, tail_ci + 4) (132 = 128 + 4, 260 = 256 + 4: the centred xyz + pad of a
     // grouped input) are handled by the workgroups of the LAST column tile with plain FMAs on the staged dZ tile, instead of
     // a second launch that would stream dZ from HBM again for a 97 % empty MFMA tile
     constexpr int DBK = 32;                 // positions per K chunk
@@ -309,14 +351,16 @@ __device__ __forceinline__ void dw_gemm_body(const uint3 bid, const unsigned gdz
     constexpr int LDA = BF16 ? tr_ld(BM) : BM, LDB = BF16 ? tr_ld(BN) : BN;   // bf16: [k][row] tiles read through ds_read_b64_tr_b16
     constexpr int PSA = DBK * LDA, PSB = DBK * LDB;
     constexpr int NBUF = (SPL && !(PREC == 2 && MP_SPLIT2_NBUF == 2)) ? 1 : 2;       // split planes: one buffer, see pos_gemm_kernel
-    __shared__ __attribute__((aligned(16))) TL sA[NBUF][NPL * PSA];
-    __shared__ __attribute__((aligned(16))) TL sB[NBUF][NPL * PSB];
-    __shared__ __attribute__((aligned(16))) float sT[NBUF][DBK * 4];
+    using L = DwLds<WAVES_M, WAVES_N, TM, TN, PREC>;
+    static_assert(L::LDA == LDA && L::LDB == LDB && L::PSA == PSA && L::PSB == PSB && L::NBUF == NBUF && L::NPL == NPL && L::ES == (int)sizeof(TL), "DwLds mirrors these constants");
+    TL (*sA)[NPL * PSA] = reinterpret_cast<TL (*)[NPL * PSA]>(lds + L::OFF_A);
+    TL (*sB)[NPL * PSB] = reinterpret_cast<TL (*)[NPL * PSB]>(lds + L::OFF_B);
+    float (*sT)[DBK * 4] = reinterpret_cast<float (*)[DBK * 4]>(lds + L::OFF_T);
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     const int wrow0 = (wave / WAVES_N) * TM * 32, wcol0 = (wave % WAVES_N) * TN * 32;
     const int co0 = bid.y * BM, ci0 = ci_base + bid.z * BN;
-    __shared__ __attribute__((aligned(16))) float bn_lds[3 * BM];          // (a, e, f) of this workgroup's BM output channels
+    float* bn_lds = reinterpret_cast<float*>(lds + L::OFF_BN);          // (a, e, f) of this workgroup's BM output channels
     bn_prologue(DZ.bn, bn_lds, BM, co0, BM, bid.x == 0 && bid.z == 0);
     const bool do_tail = tail_ci >= 0 && bid.z == gdz - 1;
     float tacc0 = 0.0f, tacc1 = 0.0f;
@@ -434,8 +478,9 @@ __device__ __forceinline__ void dw_gemm_body(const uint3 bid, const unsigned gdz
 template <int MODE_DZ, int MODE_IN, int WAVES_M, int WAVES_N, int TM, int TN, int PREC = 0>
 __global__ __launch_bounds__(THREADS) void dw_gemm_kernel(PosOperand DZ, PosOperand IN, int P, int p_per_block, float* __restrict__ dW, int ci_base, int tail_ci)
 {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[DwLds<WAVES_M, WAVES_N, TM, TN, PREC>::BYTES];
     dw_gemm_body<MODE_DZ, MODE_IN, WAVES_M, WAVES_N, TM, TN, PREC>(make_uint3(blockIdx.x, blockIdx.y, blockIdx.z), gridDim.z, DZ, IN, P, p_per_block, dW, ci_base,
-                                                                   tail_ci);
+                                                                   tail_ci, lds);
 }
 
 // [r6] G_{l-1} = dZ_l W_l and dW_l = dZ_l^T act(Z_{l-1}) of one group_all layer as ONE launch: the 64 x 64 tiles of the first and the
@@ -449,6 +494,8 @@ __global__ __launch_bounds__(THREADS) void bwd_pair_kernel(PosOperand DZ, PosOpe
                                                            const float* __restrict__ sprev, const float* __restrict__ tprev, int ldw, int ldc, int gm, int gn,
                                                            int ppb, float* __restrict__ dW, int tail_ci, int wx, int wy, int wz)
 {
+    constexpr size_t LB = PosLds<true, EPI, 2, 2, 1, 1, 2>::BYTES > DwLds<2, 2, 2, 2, 2>::BYTES ? PosLds<true, EPI, 2, 2, 1, 1, 2>::BYTES : DwLds<2, 2, 2, 2, 2>::BYTES;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[LB];          // ONE buffer for whichever body this workgroup runs
     const unsigned n_dx = (unsigned)(gm * gn), n_dw = (unsigned)(wx * wy * wz);
     const unsigned lo = n_dx < n_dw ? n_dx : n_dw;          // the first 2 * lo blocks alternate, the longer list's rest follows
     unsigned b = blockIdx.x;
@@ -457,10 +504,10 @@ __global__ __launch_bounds__(THREADS) void bwd_pair_kernel(PosOperand DZ, PosOpe
     else { dx = n_dx > n_dw; b -= lo; }
     if (dx) {
         pos_gemm_body<MODE_DZ, true, EPI, 2, 2, 1, 1, 2>(make_uint3(b % (unsigned)gm, b / (unsigned)gm, 0), DZ, P, W, N, Kd, G, partials, zprev, sprev, tprev, PoolOut{},
-                                                         ldw, ldc);
+                                                         ldw, ldc, lds);
     } else {
         const unsigned x = b % (unsigned)wx, yz = b / (unsigned)wx;
-        dw_gemm_body<MODE_DZ, MODE_IN, 2, 2, 2, 2, 2>(make_uint3(x, yz % (unsigned)wy, yz / (unsigned)wy), (unsigned)wz, DZ, IN, P, ppb, dW, 0, tail_ci);
+        dw_gemm_body<MODE_DZ, MODE_IN, 2, 2, 2, 2, 2>(make_uint3(x, yz % (unsigned)wy, yz / (unsigned)wy), (unsigned)wz, DZ, IN, P, ppb, dW, 0, tail_ci, lds);
     }
 }
 
@@ -690,13 +737,13 @@ int mp_bwd_pair_launch(int mode_dz, int mode_in, int epi, const void* dz_, const
                        const void* partials_, const float* zprev, const float* sprev, const float* tprev, int ldw, int ldc, float* dW, hipStream_t stream,
                        int* nblk_out, int probe)
 {   // probe != 0: only answer whether the joint kernel applies (DZ.bn is ignored: the caller settles it before the real call)
-    static const bool off = getenv("MP_BWD_PAIR") && atoi(getenv("MP_BWD_PAIR")) == 0;
-    if (off) return 0;
+    static const int level = [] { const char* e = getenv("MP_BWD_PAIR"); return e ? atoi(e) : 2; }();      // 0: never, 1: the dense layers only, 2 (default): the pooled layer too
+    if (level == 0) return 0;
     const PosOperand& DZ = *static_cast<const PosOperand*>(dz_);
     const PosOperand& IN = *static_cast<const PosOperand*>(in_);
     const BnOut partials = partials_ ? *static_cast<const BnOut*>(partials_) : BnOut{nullptr, nullptr, nullptr, 0, nullptr, 0};
     if ((!probe && DZ.bn.slots != nullptr) || P64 <= 0 || P64 >= ((int64_t)1 << 31)) return 0;
-    if (!(mode_dz == SRC_DZ && ((mode_in == SRC_ACT && epi == EPI_DY) || (mode_in == SRC_ID && epi == EPI_NONE)))) return 0;
+    if (!((mode_dz == SRC_DZ || (mode_dz == SRC_DZ_POOLED && level >= 2)) && ((mode_in == SRC_ACT && epi == EPI_DY) || (mode_in == SRC_ID && epi == EPI_NONE)))) return 0;
     const int P = (int)P64;
     if (ldw == 0) ldw = N;
     if (ldc == 0) ldc = N;
@@ -738,10 +785,12 @@ int mp_bwd_pair_launch(int mode_dz, int mode_in, int epi, const void* dz_, const
         MP_CHECK_LAUNCH();                                                                                                                      \
         return 1;                                                                                                                               \
     }
-    // (the POOLED layer stays on two launches: its joint kernel took 130 us against 49 + 42 -- the pooled dZ operand's staging next to the 128 x 128
-    // accumulators; the dense layers: 44 against 28 + 23 us and 30 against 27 + 15 us)
+    // (same box, alternating, the group_all level: dense layers 30-35 us against 28 + 23 and 27-29 against 27 + 15, the pooled layer 80-84 against
+    // 49 + 42 -- with ONE LDS buffer for whichever body a workgroup runs; as static arrays of both bodies the joint kernel reserved their sum,
+    // halved the workgroups per CU and took 130 us for the pooled layer)
     MP_PAIR(SRC_DZ, SRC_ACT, EPI_DY)
     MP_PAIR(SRC_DZ, SRC_ID, EPI_NONE)
+    MP_PAIR(SRC_DZ_POOLED, SRC_ACT, EPI_DY)
 #undef MP_PAIR
     return 0;
 }
