@@ -16,7 +16,7 @@ for i in (1, 2, 3, 4):
             agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 print(f"{'kernel':48s} {'act':>8s} {'mfma%':>6s} {'waves/simd':>10s} {'wait_any%':>9s} {'wait_inst%':>10s} {'valu%':>6s} {'lds%':>6s} {'vmem%':>6s} {'bankc%':>7s} {'waitlds%':>8s} {'n_valu':>9s} {'n_lds':>8s} {'n_mfma':>8s}")
 for k, c in sorted(agg.items(), key=lambda kv: -sum(kv[1].get("GRBM_GUI_ACTIVE", [0]))):
-    if not any(t in k for t in ("fused", "roles", "chunk", "bwd_first", "pos_gemm", "dw_gemm", "stream16")):
+    if not any(t in k for t in ("fused", "roles", "chunk", "bwd_first", "pos_gemm", "dw_gemm", "stream16", "bwd_pair")):
         continue
     m = {n: sum(v) / len(v) for n, v in c.items()}
     act = m.get("GRBM_GUI_ACTIVE", 0) / 8.0
