@@ -222,36 +222,115 @@ class _Runner:
         return tuple(next(outs) if keep else None for keep in self.mask)
 
 
-def _walk(model):
-    """ONE traversal of the module tree per call (model.parameters() / model.modules() walk it with a memo set each: four of them cost a
-    batch-of-one forward 0.06 ms of host time): (modules in training mode, parameters that require a gradient, anything hooked).
-    Hooks: forward / pre / backward hooks on a submodule fire only while the eager code runs (a replay launches kernels, not modules), tensor
-    hooks and post-accumulate hooks on a parameter never fire (the replaying node assigns `.grad` itself) -- a model that carries one stays on
-    the eager path."""
-    import torch.nn.modules.module as M
-    hooked = bool(M._global_forward_hooks or M._global_forward_pre_hooks or M._global_backward_hooks or M._global_backward_pre_hooks)
-    n_train = n_req = 0
-    ptrs = []
-    seen = set()
+# ---- the module tree, flattened once ------------------------------------------------------------------------------------------------
+# [r6] What the unchanged loop pays per step on the host -- with the device idle -- is mostly walks over the module tree: `model.zero_grad()`
+# twice per iteration (train_maskplanner.py:183, 226), this module's own look at hooks / training flags / parameter storages.  torch walks
+# with recursive generators and a memo set (~0.1 ms per walk for this model); here the tree is flattened ONCE into lists and every use
+# re-validates them cheaply: a global counter that torch's registration hooks bump whenever ANY module registers a parameter or a
+# submodule, and -- per entry, on use -- that the owner's dict still holds the very object (assignments that bypass registration).
+_STRUCT = [0]
+
+
+def _bump(*_a):
+    _STRUCT[0] += 1
+
+
+torch.nn.modules.module.register_module_parameter_registration_hook(_bump)
+torch.nn.modules.module.register_module_module_registration_hook(_bump)
+
+
+class _Flat:
+    """The flattened tree of one model.  Not state: a copy or a pickle of the model starts without it; the root itself is not in the lists
+    (the model owns this object: no cycle)."""
+    __slots__ = ("version", "mods", "pars")
+
+    def __init__(self, version=-1, mods=(), pars=()):
+        self.version, self.mods, self.pars = version, mods, pars
+
+    def __deepcopy__(self, memo):
+        return _Flat()
+
+    def __reduce__(self):
+        return (_Flat, ())
+
+
+def _flat(model):
+    """version + submodules [(owner's _modules dict, name, module)] + parameters [(owner's _parameters dict, name, parameter)], cached on the
+    model; shared parameters / modules once."""
+    c = model.__dict__.get("_mp_flat")
+    if c is not None and c.version == _STRUCT[0]:
+        return c
+    mods, pars, seen = [], [], {id(model)}
     stack = [model]
     while stack:
         m = stack.pop()
-        if id(m) in seen:
-            continue
-        seen.add(id(m))
+        for k, p in m._parameters.items():
+            if p is not None and id(p) not in seen:
+                seen.add(id(p))
+                pars.append((m._parameters, k, p))
+        for k, c_ in m._modules.items():
+            if c_ is not None and id(c_) not in seen:
+                seen.add(id(c_))
+                mods.append((m._modules, k, c_))
+                stack.append(c_)
+    c = _Flat(_STRUCT[0], mods, pars)
+    model.__dict__["_mp_flat"] = c
+    return c
+
+
+def _flat_valid(model):
+    """The flattened tree, re-built if an entry is no longer what its owner's dict holds."""
+    for _attempt in range(2):
+        c = _flat(model)
+        if all(d.get(k) is m for d, k, m in c.mods) and all(d.get(k) is p for d, k, p in c.pars):
+            return c
+        model.__dict__.pop("_mp_flat", None)
+    return _flat(model)
+
+
+def fast_zero_grad(model, set_to_none=True):
+    """`nn.Module.zero_grad()` for the drop-in models (the reference's loop calls it twice per iteration): the same effect through the flattened
+    parameter list, every entry checked against its owner's dict on the way."""
+    if not set_to_none or getattr(model, "_is_replica", False):
+        return torch.nn.Module.zero_grad(model, set_to_none)
+    for _attempt in range(2):
+        c = _flat(model)
+        stale = False
+        for d, k, p in c.pars:
+            if d.get(k) is not p:
+                stale = True
+                break
+            if p.grad is not None:
+                p.grad = None
+        if not stale and all(d.get(k) is m for d, k, m in c.mods):
+            return
+        model.__dict__.pop("_mp_flat", None)
+    torch.nn.Module.zero_grad(model, set_to_none)
+
+
+def _walk(model):
+    """ONE pass per call over the flattened module tree (model.parameters() / model.modules() walk it with a memo set each: four of them cost
+    a batch-of-one forward 0.06 ms of host time): (modules in training mode, parameters that require a gradient, anything hooked, the parameters'
+    storages).  Hooks: forward / pre / backward hooks on a submodule fire only while the eager code runs (a replay launches kernels, not
+    modules), tensor hooks and post-accumulate hooks on a parameter never fire (the replaying node assigns `.grad` itself) -- a model that
+    carries one stays on the eager path."""
+    import torch.nn.modules.module as M
+    hooked = bool(M._global_forward_hooks or M._global_forward_pre_hooks or M._global_backward_hooks or M._global_backward_pre_hooks)
+    c = _flat_valid(model)
+    n_train, n_req = int(model.training), 0
+    if model._forward_hooks or model._forward_pre_hooks or model._backward_hooks or model._backward_pre_hooks:
+        hooked = True
+    for _d, _k, m in c.mods:
         n_train += m.training
         if m._forward_hooks or m._forward_pre_hooks or m._backward_hooks or m._backward_pre_hooks:
             hooked = True
-        for p in m._parameters.values():
-            if p is None or id(p) in seen:
-                continue
-            seen.add(id(p))
-            ptrs.append(p.data_ptr())       # (a replaced parameter storage makes the recording stale: _Runner.stale)
-            if p.requires_grad:
-                n_req += 1
-                if p._backward_hooks or getattr(p, "_post_accumulate_grad_hooks", None):
-                    hooked = True
-        stack.extend(c for c in m._modules.values() if c is not None)
+    ptrs = []
+    for _d, _k, p in c.pars:
+        ptrs.append(p.data_ptr())       # (a replaced parameter storage makes the recording stale: _Runner.stale)
+        if p.requires_grad:
+            n_req += 1
+            if p._backward_hooks or getattr(p, "_post_accumulate_grad_hooks", None):
+                hooked = True
     return n_train, n_req, hooked, tuple(ptrs)
 
 

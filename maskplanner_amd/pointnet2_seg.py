@@ -18,6 +18,12 @@ from .pointnet2_utils import PointNetSetAbstraction
 
 
 class _SegBase(nn.Module):
+    def zero_grad(self, set_to_none=True):
+        """nn.Module.zero_grad through the flattened parameter list (graphed.fast_zero_grad): the reference's loop calls it twice per iteration
+        (train_maskplanner.py:183, 226), 0.1 ms of host time each with the device idle."""
+        from . import graphed
+        graphed.fast_zero_grad(self, set_to_none)
+
     def _build(self, in_channel):
         self.sa1 = PointNetSetAbstraction(npoint=512, radius=0.2, nsample=32, in_channel=in_channel, mlp=[64, 64, 128],
                                           group_all=False)

@@ -186,3 +186,47 @@ def test_widen_interior_pads_with_dead_channels_and_keeps_the_parameters():
     p2 = list(orig[:6]) + list(orig[12:18])
     same = list(p2)
     assert sa_mlp._widen_interior(p2, [64, 128]) == [] and all(a is b for a, b in zip(p2, same))
+
+
+def test_fast_zero_grad_and_the_flattened_module_tree():
+    """[r6] The drop-in models answer `zero_grad()` (twice per iteration of the reference's loop, train_maskplanner.py:183, 226) and this package's
+    per-call look at the module tree from ONE flattened list, re-validated on every use: same effect as nn.Module.zero_grad / parameters() /
+    modules() after parameters and submodules were replaced through registration, through the owner's dict, or added later; a copy of the model
+    starts without the cache; nothing of it reaches the state_dict."""
+    import copy
+    import torch
+    from maskplanner_amd import graphed, synthetic
+    from maskplanner_amd.pointnet2_cls_ssg import maskplanner_model
+    m = maskplanner_model(synthetic.CATEGORIES["cuboids"], hidden_size=(64, 64))
+
+    def dirty(model):
+        for p in model.parameters():
+            p.grad = torch.ones_like(p)
+
+    def clean(model):
+        return all(p.grad is None for p in model.parameters())
+    dirty(m); m.zero_grad(); assert clean(m)
+    n_train, n_req, hooked, ptrs = graphed._walk(m)
+    assert n_train == sum(1 for x in m.modules() if x.training) and n_req == sum(1 for p in m.parameters() if p.requires_grad)
+    assert not hooked and ptrs == tuple(p.data_ptr() for _, _, p in graphed._flat(m).pars) and len(ptrs) == sum(1 for _ in m.parameters())
+    m.fc3.weight = torch.nn.Parameter(torch.zeros_like(m.fc3.weight))                     # through registration (the global hook bumps the version)
+    m.fc2._parameters["weight"] = torch.nn.Parameter(torch.zeros_like(m.fc2.weight))      # behind registration's back (caught per entry)
+    m.extra = torch.nn.Linear(4, 4)                                                       # a new submodule
+    dirty(m); m.zero_grad(); assert clean(m)
+    assert graphed._walk(m)[1] == sum(1 for p in m.parameters() if p.requires_grad)
+    m.sa2.eval(); m.fc1.weight.requires_grad_(False)
+    n_train, n_req, _, _ = graphed._walk(m)
+    assert n_train == sum(1 for x in m.modules() if x.training) and n_req == sum(1 for p in m.parameters() if p.requires_grad)
+    h = m.sa1.register_forward_hook(lambda *a: None)
+    assert graphed._walk(m)[2]
+    h.remove()
+    h = m.fc3.weight.register_hook(lambda g: g)
+    assert graphed._walk(m)[2]
+    h.remove()
+    assert not graphed._walk(m)[2]
+    m2 = copy.deepcopy(m)
+    assert m2.__dict__["_mp_flat"].version == -1
+    dirty(m2); m2.zero_grad(); assert clean(m2)
+    dirty(m); m.zero_grad(set_to_none=False)
+    assert all(p.grad is not None and float(p.grad.abs().sum()) == 0.0 for p in m.parameters())
+    assert not any("_mp" in k for k in m.state_dict())
