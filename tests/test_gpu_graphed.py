@@ -518,3 +518,42 @@ def test_replayed_loss_against_the_reference_fixture(mods, golden, tag):
     _close(yp.grad, g[tag + "_g_y_pred"], "g_y_pred", rtol=1e-4, atol=1e-6)
     _close(mk.grad, g[tag + "_g_masks"], "g_masks", rtol=1e-5, atol=1e-6)
     _close(sc.grad, g[tag + "_g_scores"], "g_scores", rtol=1e-5, atol=1e-6)
+
+
+def test_recordings_keep_the_garbage_collector_out(mods):
+    """[r6] A dead reference cycle that owns a pinned host buffer must not be collected WHILE a stream records (its release queries events:
+    illegal under capture, raised inside a destructor -- the process aborted in a test session of this round).  harness.recording collects
+    before the capture and disables the collector inside it; here such garbage exists when a training step is recorded, and the collector's
+    state is restored afterwards."""
+    import gc
+    graphed, pc, pu, synthetic = mods
+    from maskplanner_amd.harness import TrainStep, recording
+
+    class Holder:
+        pass
+    was = gc.isenabled()
+    gc.disable()
+    try:
+        for _ in range(8):                       # cycles with pinned buffers that have been the source of asynchronous copies
+            a, b = Holder(), Holder()
+            a.other, b.other = b, a
+            a.buf = torch.empty(1 << 16, dtype=torch.float32).pin_memory()
+            a.dev = torch.empty(1 << 16, device="cuda")
+            a.dev.copy_(a.buf, non_blocking=True)
+            del a, b
+    finally:
+        if was:
+            gc.enable()
+    ts = TrainStep("cuboids", B=2, N=1024, seed=5, graph=True, hidden_size=(64, 64))
+    losses = [float(ts.step()) for _ in range(6)]
+    assert ts._graph is not None and np.isfinite(losses).all()
+    assert gc.isenabled() == was
+    g = torch.cuda.CUDAGraph()
+    x = torch.zeros(8, device="cuda")
+    with recording(g):
+        assert not gc.isenabled()
+        y = x + 1
+    assert gc.isenabled() == was
+    g.replay()
+    torch.cuda.synchronize()
+    assert float(y.sum()) == 8.0
